@@ -1,0 +1,315 @@
+#!/usr/bin/env python3
+"""
+Generate the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE
+(/root/reference, revrand v1.0.0) in the build container, and check the NumPy
+oracle (oracle/revrand_oracle.py) against every one of them while doing so.
+
+Run (build container only -- /root/reference does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python -B oracle/make_golden.py
+
+Only *data* (inputs + the reference's outputs) is written; no reference source
+travels.  Two process-local accommodations are needed to import the 2017-era
+reference under NumPy 2: the ``decorator`` stand-in in oracle/shim
+and ``np.asscalar`` (removed in NumPy 2.0, used at revrand/utils/base.py:285).
+Neither touches /root/reference.
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "shim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+
+if not hasattr(np, "asscalar"):
+    np.asscalar = lambda a: a.item()  # process-local, see docstring
+
+import revrand.basis_functions as rb  # noqa: E402
+from revrand.btypes import Parameter, Positive  # noqa: E402
+from revrand.mathfun.linalg import hadamard as ref_hadamard, solve_posdef as ref_solve  # noqa: E402
+from revrand.slm import StandardLinearModel  # noqa: E402
+
+import revrand_oracle as orc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+RFF = {
+    "RandomRBF": (rb.RandomRBF, lambda d, n, s: orc.weights_rbf(d, n, s)),
+    "RandomLaplace": (rb.RandomLaplace, lambda d, n, s: orc.weights_laplace(d, n, s)),
+    "RandomCauchy": (rb.RandomCauchy, lambda d, n, s: orc.weights_cauchy(d, n, s)),
+    "RandomMatern32": (rb.RandomMatern32, lambda d, n, s: orc.weights_matern(d, n, s, 1)),
+    "RandomMatern52": (rb.RandomMatern52, lambda d, n, s: orc.weights_matern(d, n, s, 2)),
+    "OrthogonalRBF": (rb.OrthogonalRBF, lambda d, n, s: orc.weights_orthogonal(d, n, s)),
+}
+
+
+def close(a, b, tol=1e-12):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    scale = max(1.0, np.abs(a).max() if a.size else 1.0)
+    err = np.abs(a - b).max() if a.size else 0.0
+    assert err <= tol * scale, err
+    return err
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %8.1f KB  %d arrays" % (name, os.path.getsize(path) / 1024., len(arrs)))
+
+
+def gen_weights():
+    out = {}
+    for cname, (cls, ofun) in RFF.items():
+        for (d, n, seed) in [(3, 4, 7), (8, 256, 1)]:
+            W = cls(nbases=n, Xdim=d, random_state=seed).W
+            assert np.array_equal(W.shape, (d, n))
+            close(W, ofun(d, n, seed), 1e-14)
+            out["%s_d%d_n%d_s%d" % (cname, d, n, seed)] = W
+    save("weights", **out)
+
+
+def gen_rff():
+    out = {}
+    N, n = 24, 12
+    for cname, (cls, ofun) in RFF.items():
+        dims = (1, 5, 8) if cname == "RandomRBF" else (5,)
+        for d in dims:
+            X = np.random.RandomState(0).randn(N, d)
+            out["X_d%d" % d] = X
+            seed = 11 + d
+            key = "%s_d%d" % (cname, d)
+            for tag, ls in [("iso0.7", 0.7), ("iso2.0", 2.0),
+                            ("ard", np.linspace(0.5, 2.0, d))]:
+                if tag == "ard":
+                    b = cls(nbases=n, Xdim=d, random_state=seed,
+                            lenscale=Parameter(np.ones(d), Positive()))
+                else:
+                    b = cls(nbases=n, Xdim=d, random_state=seed)
+                out[key + "_W"] = b.W
+                P = b.transform(X, ls)
+                dP = b.grad(X, ls)
+                assert P.dtype == np.float64
+                close(P, orc.rff_transform(X, b.W, ls))
+                close(dP, orc.rff_grad(X, b.W, ls))
+                out["%s_%s_Phi" % (key, tag)] = P
+                out["%s_%s_dPhi" % (key, tag)] = dP
+            out[key + "_seed"] = np.array(seed)
+    # float32 inputs: output stays float64 (np.dot promotes), SURVEY a-1
+    X32 = np.random.RandomState(0).randn(N, 5).astype(np.float32)
+    b = rb.RandomRBF(nbases=n, Xdim=5, random_state=16)
+    P = b.transform(X32, 1.3)
+    assert P.dtype == np.float64
+    out["RandomRBF_d5_f32in_iso1.3_Phi"] = P
+    close(P, orc.rff_transform(X32, b.W, 1.3))
+    save("rff", **out)
+
+
+def gen_hadamard():
+    Y = np.random.RandomState(5).randn(3, 16)
+    out = dict(Y=Y, nat=ref_hadamard(Y, ordering=False), seq=ref_hadamard(Y, ordering=True))
+    close(out["nat"], orc.hadamard(Y, False))
+    close(out["seq"], orc.hadamard(Y, True))
+    # the reference's own doctest vector (mathfun/linalg.py:202-206)
+    y = np.array([[1, 0, 1, 0, 0, 1, 1, 0]])
+    out["doctest_in"] = y
+    out["doctest_nat"] = ref_hadamard(y, ordering=False)
+    out["doctest_seq"] = ref_hadamard(y, ordering=True)
+    assert np.array_equal(out["doctest_nat"], [[.5, .25, 0, -.25, 0, .25, 0, .25]])
+    assert np.array_equal(out["doctest_seq"], [[.5, 0, 0, 0, -.25, .25, .25, .25]])
+    for L in (1, 2, 64, 128):
+        Z = np.random.RandomState(L).randn(2, L)
+        out["Y%d" % L] = Z
+        out["nat%d" % L] = ref_hadamard(Z, ordering=False)
+        close(out["nat%d" % L], orc.hadamard(Z, False))
+    save("hadamard", **out)
+
+
+def gen_fastfood():
+    out = {}
+    cases = [(1, 10, 3, 6, True), (2, 10, 3, 6, True), (5, 16, 3, 6, True),
+             (16, 64, 3, 4, True), (128, 256, 3, 4, False)]
+    for (d, nb, seed, N, ard) in cases:
+        key = "d%d_nb%d" % (d, nb)
+        X = np.random.RandomState(1).randn(N, d)
+        b = rb.FastFoodRBF(nbases=nb, Xdim=d, random_state=seed)
+        B, G, PI, S = orc.fastfood_matrices(nb, d, seed)
+        assert np.array_equal(B, b.B) and np.array_equal(PI, b.PI)
+        close(G, b.G, 1e-15)
+        close(S, b.S, 1e-13)
+        assert orc.fastfood_dims(nb, d) == (b.d2, b.k, b.n)
+        out.update({key + "_X": X, key + "_B": b.B, key + "_G": b.G,
+                    key + "_PI": b.PI, key + "_S": b.S})
+        VX = b._makeVX(X)
+        close(VX, orc.fastfood_VX(X, B, G, PI, S))
+        out[key + "_VX"] = VX
+        for tag, ls in [("iso0.7", 0.7), ("iso2.0", 2.0)]:
+            P, dP = b.transform(X, ls), b.grad(X, ls)
+            close(P, orc.fastfood_transform(X, B, G, PI, S, ls))
+            close(dP, orc.fastfood_grad(X, B, G, PI, S, ls))
+            out["%s_%s_Phi" % (key, tag)] = P
+            out["%s_%s_dPhi" % (key, tag)] = dP
+        if ard:
+            ls = np.linspace(0.5, 2.0, d)
+            ba = rb.FastFoodRBF(nbases=nb, Xdim=d, random_state=seed,
+                                lenscale=Parameter(np.ones(d), Positive()))
+            P, dP = ba.transform(X, ls), ba.grad(X, ls)
+            close(P, orc.fastfood_transform(X, B, G, PI, S, ls))
+            close(dP, orc.fastfood_grad(X, B, G, PI, S, ls))
+            out[key + "_ard_Phi"] = P
+            out[key + "_ard_dPhi"] = dP
+    save("fastfood", **out)
+
+
+def gen_concat():
+    out = {}
+    d, n, N = 6, 10, 20
+    X = np.random.RandomState(2).randn(N, d)
+    ls = np.linspace(0.5, 2.0, d)
+    base = rb.RandomMatern52(nbases=n, Xdim=d, random_state=4,
+                             lenscale=Parameter(np.ones(d), Positive())) \
+        + rb.LinearBasis(onescol=True)
+    P = base.transform(X, ls)
+    grads = list(base.grad(X, ls))
+    assert len(grads) == 1 and grads[0].shape == (N, 2 * n + d + 1, d)
+    diag, slices = base.regularizer_diagonal(X, 2.5, 0.5)
+    W = base.bases[0].W
+    Pref = np.hstack((orc.rff_transform(X, W, ls), orc.linear_transform(X)))
+    close(P, Pref)
+    gref = np.zeros((N, 2 * n + d + 1, d))
+    gref[:, :2 * n, :] = orc.rff_grad(X, W, ls)
+    close(grads[0], gref)
+    out.update(X=X, ls=ls, W=W, Phi=P, dPhi=grads[0], regdiag=diag,
+               slices=np.array([[s.start, s.stop] for s in slices]),
+               get_dim=np.array(base.get_dim(X)))
+    # apply_ind case modelled on tests/test_bases.py:223-238
+    X2 = np.random.RandomState(3).randn(N, 2)
+    base2 = rb.LinearBasis(onescol=False, apply_ind=[0]) \
+        + rb.RandomRBF(Xdim=1, nbases=1, apply_ind=[1], random_state=8) \
+        + rb.RandomRBF(Xdim=2, nbases=3, random_state=9,
+                       lenscale=Parameter(np.ones(2), Positive()), apply_ind=[1, 0])
+    P2 = base2.transform(X2, 1.5, np.array([0.8, 1.7]))
+    g2 = list(base2.grad(X2, 1.5, np.array([0.8, 1.7])))
+    assert P2.shape == (N, 9) and g2[0].shape == (N, 9) and g2[1].shape == (N, 9, 2)
+    out.update(ai_X=X2, ai_W1=base2.bases[1].W, ai_W2=base2.bases[2].W, ai_Phi=P2,
+               ai_dPhi0=g2[0], ai_dPhi1=g2[1])
+    save("concat", **out)
+
+
+def _elbo_case(basis, X, y, var, reg, hypers):
+    slm = StandardLinearModel(basis)
+    slm.obj_ = -np.inf
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, var, reg, hypers)
+    return dict(elbo=-nelbo, dvar=-np.asarray(ndvar),
+                dreg=-np.atleast_1d(np.asarray(ndreg, float)),
+                dhyp=[-np.atleast_1d(np.asarray(h, float)) for h in
+                      (ndhyp if isinstance(ndhyp, list) else [ndhyp])],
+                m=slm.weights_, C=slm.covariance_)
+
+
+def gen_elbo():
+    out = {}
+    N, d, n = 500, 4, 16
+    r = np.random.RandomState(6)
+    X = r.randn(N, d)
+    y = np.sin(X @ r.randn(d)) + 0.1 * r.randn(N)
+    out.update(X=X, y=y)
+    var = 0.37
+    ard = np.linspace(0.6, 1.8, d)
+
+    # single basis, iso (with the dimension-0-only gradient quirk) and ARD
+    for tag, ls, lsp in [("iso", 1.3, Parameter(1., Positive())),
+                         ("ard", ard, Parameter(np.ones(d), Positive()))]:
+        b = rb.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=lsp)
+        res = _elbo_case(b, X, y, var, 1.7, ls)
+        Phi = orc.rff_transform(X, b.W, ls)
+        dP = orc.rff_grad(X, b.W, ls)
+        dPl = [dP] if dP.ndim == 2 else [dP[:, :, i] for i in range(d)]
+        o = orc.slm_elbo(Phi, y, var, np.full(2 * n, 1.7), slice(None), dPl)
+        close(res["elbo"], o["elbo"], 1e-11)
+        close(res["m"], o["m"], 1e-9)
+        close(res["C"], o["C"], 1e-9)
+        close(res["dvar"], o["dvar"], 1e-9)
+        close(res["dreg"], o["dreg"], 1e-9)
+        close(np.concatenate(res["dhyp"]), np.array(o["dhyp"]), 1e-8)
+        out.update({tag + "_W": b.W, tag + "_ls": np.asarray(ls), tag + "_elbo": res["elbo"],
+                    tag + "_dvar": res["dvar"], tag + "_dreg": res["dreg"],
+                    tag + "_dhyp": np.concatenate(res["dhyp"]), tag + "_m": res["m"],
+                    tag + "_C": res["C"], tag + "_G": o["G"], tag + "_b": o["b"],
+                    tag + "_logdetC": o["logdetC"]})
+
+    # concatenation: Matern52 (ARD) + LinearBasis, two regularisers
+    b = rb.RandomMatern52(nbases=n, Xdim=d, random_state=22,
+                          lenscale=Parameter(np.ones(d), Positive())) + rb.LinearBasis(onescol=True)
+    res = _elbo_case(b, X, y, var, [1.7, 0.6], ard)
+    W = b.bases[0].W
+    Phi = np.hstack((orc.rff_transform(X, W, ard), orc.linear_transform(X)))
+    F = Phi.shape[1]
+    dP = np.zeros((N, F, d))
+    dP[:, :2 * n, :] = orc.rff_grad(X, W, ard)
+    rd = np.concatenate((np.full(2 * n, 1.7), np.full(d + 1, 0.6)))
+    o = orc.slm_elbo(Phi, y, var, rd, [slice(0, 2 * n), slice(2 * n, F)],
+                     [dP[:, :, i] for i in range(d)])
+    close(res["elbo"], o["elbo"], 1e-11)
+    close(res["dreg"], o["dreg"], 1e-9)
+    close(np.concatenate(res["dhyp"]), np.array(o["dhyp"]), 1e-8)
+    out.update(cat_W=W, cat_ls=ard, cat_reg=np.array([1.7, 0.6]), cat_elbo=res["elbo"],
+               cat_dvar=res["dvar"], cat_dreg=res["dreg"], cat_dhyp=np.concatenate(res["dhyp"]),
+               cat_m=res["m"], cat_C=res["C"])
+    out["var"] = np.array(var)
+    out["reg"] = np.array(1.7)
+    save("elbo", **out)
+
+
+def gen_solve_posdef():
+    r = np.random.RandomState(99)
+    Xc = r.randn(100, 5)
+    S = np.cov(Xc.T)
+    l, U = np.linalg.eigh(S)
+    l2 = l.copy()
+    l2[0] = -1e-13
+    Sn = (U * l2) @ U.T
+    out = {}
+    for tag, A in [("pd", S), ("npd", Sn)]:
+        Xr, ld = ref_solve(A, np.eye(5))
+        Xo, lo = orc.solve_posdef(A, np.eye(5))
+        close(Xr, Xo, 1e-9)
+        if np.isfinite(ld):
+            close(ld, lo, 1e-9)
+        out.update({tag + "_A": A, tag + "_X": Xr, tag + "_logdet": np.array(ld)})
+    save("solve_posdef", **out)
+
+
+def gen_fit():
+    """End-to-end C1-small: fit with fixed inits, nstarts=0, maxiter=20 (a-14)."""
+    N, d, n = 400, 3, 24
+    r = np.random.RandomState(7)
+    X = r.randn(N, d)
+    y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.05 * r.randn(N)
+    Xs = np.random.RandomState(8).randn(16, d)
+    b = rb.RandomRBF(nbases=n, Xdim=d, random_state=31, lenscale=Parameter(1.2, Positive()),
+                     regularizer=Parameter(1.5, Positive()))
+    slm = StandardLinearModel(b, var=Parameter(0.5, Positive()), nstarts=0, maxiter=20)
+    slm.fit(X, y)
+    Ey, Vy = slm.predict_moments(Xs)
+    save("fit", X=X, y=y, Xs=Xs, W=b.W, var_=np.array(slm.var_), reg_=np.array(slm.regularizer_),
+         hyp_=np.array(slm.hypers_), m=slm.weights_, C=slm.covariance_, obj=np.array(slm.obj_),
+         Ey=Ey, Vy=Vy)
+
+
+if __name__ == "__main__":
+    gen_weights()
+    gen_rff()
+    gen_hadamard()
+    gen_fastfood()
+    gen_concat()
+    gen_elbo()
+    gen_solve_posdef()
+    gen_fit()
+    print("oracle agrees with the reference on every fixture")

@@ -1,0 +1,369 @@
+"""
+CPU oracle for the revrand random-feature hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a NumPy restatement (written from the maths in SURVEY.md section 8a,
+not copied) of what NICTA/revrand computes on the path
+
+    basis.transform / basis.grad  ->  Phi^T Phi, Phi^T y  ->  posterior solve / ELBO
+
+It is the *checker*: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  Nothing under
+``revrand_amd/`` (the product) imports, links or executes anything in this
+directory; the product path runs on the HIP library and fails loudly without it.
+
+Pinning: every function here is checked against outputs of the reference itself
+(imported from /root/reference in the build container by ``oracle/make_golden.py``)
+which are committed as fixtures under ``tests/golden/``; ``hadamard`` is also
+pinned by the reference's own doctest vector (revrand/mathfun/linalg.py:202-206).
+See ``tests/test_oracle_golden.py``.
+
+All citations ``file:line`` are into the reference tree (revrand v1.0.0).
+"""
+
+import numpy as np
+from scipy import linalg as sla
+
+CHOLTHRESH = 1e-5  # revrand/mathfun/linalg.py:31
+
+
+# --------------------------------------------------------------------------
+# a-3  frequency matrices (host-side sampling, MT19937 legacy stream)
+# --------------------------------------------------------------------------
+
+def _rs(seed_or_state):
+    if isinstance(seed_or_state, np.random.RandomState):
+        return seed_or_state
+    return np.random.RandomState(seed_or_state)
+
+
+def weights_rbf(d, n, seed):
+    """RandomRBF._weightsamples  basis_functions.py:952-954 : randn(d, n)."""
+    return _rs(seed).randn(d, n)
+
+
+def weights_laplace(d, n, seed):
+    """RandomLaplace._weightsamples  basis_functions.py:993-995 : Cauchy draws."""
+    return _rs(seed).standard_cauchy(size=(d, n))
+
+
+def weights_cauchy(d, n, seed):
+    """RandomCauchy._weightsamples  basis_functions.py:1034-1045.
+
+    Gaussian draw scaled per column by sqrt(2 * Gamma(1)) (a Laplace-mixture).
+    """
+    r = _rs(seed)
+    g = r.randn(d, n)
+    z = r.standard_gamma(1., size=(1, n))
+    return g * np.sqrt(2. * z)
+
+
+def weights_matern(d, n, seed, p):
+    """_RandomMatern._maternweight  basis_functions.py:1051-1065.
+
+    Multivariate-t draw with df = 2p+1: normal / sqrt(chi2/df), chi2 per column.
+    p=1 -> Matern32 (:1107), p=2 -> Matern52 (:1150).
+    """
+    r = _rs(seed)
+    df = 2. * (p + 0.5)
+    g = r.randn(d, n)
+    u = r.chisquare(df, size=(n,))
+    return g * np.sqrt(df / u)
+
+
+def weights_orthogonal(d, n, seed):
+    """OrthogonalRBF._weightsamples  basis_functions.py:1198-1208.
+
+    ceil(n/d) QR blocks of a (d,d) Gaussian, columns truncated to n, rows scaled
+    by sqrt(chi2_d) draws (drawn AFTER all the Gaussian blocks).
+    """
+    r = _rs(seed)
+    reps = int(np.ceil(n / d))
+    blocks = []
+    for _ in range(reps):
+        q, _r = sla.qr(r.randn(d, d))
+        blocks.append(q)
+    Q = np.concatenate(blocks, axis=1)[:, :n]
+    s = np.sqrt(r.chisquare(df=d, size=d))
+    return s[:, None] * Q
+
+
+# --------------------------------------------------------------------------
+# a-1 / a-2  random Fourier features
+# --------------------------------------------------------------------------
+
+def _lenscale_col(lenscale, d):
+    ls = np.atleast_1d(np.asarray(lenscale, dtype=float))
+    if ls.shape not in ((1,), (d,)):
+        raise ValueError("Dimension of input parameter is inconsistent!")
+    return ls
+
+
+def rff_transform(X, W, lenscale):
+    """_RandomKernelBasis.transform  basis_functions.py:838-864.
+
+    Phi = [cos(X (W/l)), sin(X (W/l))] / sqrt(n), cos block first, always float64.
+    """
+    X = np.asarray(X)
+    d, n = W.shape
+    ls = _lenscale_col(lenscale, d)
+    Z = X @ (W / ls[:, None])
+    out = np.empty((X.shape[0], 2 * n))
+    np.cos(Z, out=out[:, :n])
+    np.sin(Z, out=out[:, n:])
+    out /= np.sqrt(n)
+    return out
+
+
+def rff_grad(X, W, lenscale):
+    """_RandomKernelBasis.grad  basis_functions.py:866-901.
+
+    For each entry i of the *given* lenscale vector (ONE entry when isotropic --
+    the reference then only differentiates through input dimension 0, a quirk
+    parity must keep):
+        dZ_i = -outer(X[:, i], W[i, :]) / l_i^2
+        dPhi_i = [ -sin(Z) * dZ_i , cos(Z) * dZ_i ] / sqrt(n)
+    Returns (N, 2n) for one lenscale, (N, 2n, d) for ARD.
+    """
+    X = np.asarray(X)
+    d, n = W.shape
+    ls = _lenscale_col(lenscale, d)
+    Z = X @ (W / ls[:, None])
+    ms, c = -np.sin(Z), np.cos(Z)
+    scale = 1. / np.sqrt(n)
+    slabs = []
+    for i, l in enumerate(ls):
+        dZ = -(X[:, i:i + 1] * W[i:i + 1, :]) / l ** 2
+        slabs.append(np.concatenate((dZ * ms, dZ * c), axis=1) * scale)
+    if len(slabs) == 1:
+        return slabs[0]
+    return np.stack(slabs, axis=2)
+
+
+# --------------------------------------------------------------------------
+# a-7  Walsh-Hadamard transform
+# --------------------------------------------------------------------------
+
+def hadamard(Y, ordering=False):
+    """mathfun.linalg.hadamard  linalg.py:182-220.
+
+    Natural(Hadamard)-order WHT normalised by 1/n  ( == Y @ H_n / n ).  Radix-2
+    butterflies, each stage halved.  ``ordering=True`` applies the sequency
+    permutation of linalg.py:223-236.
+    """
+    Y = np.array(Y, dtype=float)
+    rows, n = Y.shape
+    if n & (n - 1):
+        raise AssertionError("length must be a power of two")
+    h = 1
+    while h < n:
+        V = Y.reshape(rows, n // (2 * h), 2, h)
+        a = V[:, :, 0, :].copy()
+        b = V[:, :, 1, :].copy()
+        V[:, :, 0, :] = (a + b) * 0.5
+        V[:, :, 1, :] = (a - b) * 0.5
+        h *= 2
+    if ordering:
+        Y = Y[:, sequency(n)]
+    return Y
+
+
+def sequency(n):
+    """mathfun.linalg._sequency  linalg.py:223-236: bit-reversed Gray code."""
+    bits = int(np.log2(n))
+    idx = np.arange(n)
+    gray = idx ^ (idx >> 1)
+    out = np.zeros(n, dtype=int)
+    for b in range(bits):
+        out |= ((gray >> b) & 1) << (bits - 1 - b)
+    return out
+
+
+# --------------------------------------------------------------------------
+# a-5 / a-6  FastFood
+# --------------------------------------------------------------------------
+
+def fastfood_dims(nbases, d):
+    """FastFoodRBF._init_dims  basis_functions.py:1331-1340 -> (d2, k, n)."""
+    d2 = 1 << int(np.ceil(np.log2(d)))
+    k = int(np.ceil(nbases / d2))
+    return d2, k, d2 * k
+
+
+def fastfood_matrices(nbases, d, seed):
+    """FastFoodRBF._init_matrices/_weightsamples  basis_functions.py:1342-1354.
+
+    Draw order B -> G -> PI -> S.  S = d2 * sqrt(chi2_{d2}) / ||G_row||_2.
+    """
+    r = _rs(seed)
+    d2, k, _n = fastfood_dims(nbases, d)
+    B = r.randint(2, size=(k, d2)) * 2 - 1
+    G = r.randn(k, d2)
+    PI = np.array([r.permutation(d2) for _ in range(k)])
+    chi = np.sqrt(r.chisquare(d2, size=(k, d2)))
+    S = d2 * chi / np.sqrt((G ** 2).sum(axis=1))[:, None]
+    return B, G, PI, S
+
+
+def fastfood_VX(X, B, G, PI, S):
+    """FastFoodRBF._makeVX  basis_functions.py:1356-1371.
+
+    Per block: v = H(x~ * B); v = v[PI] * G; v = H(v) * S * sqrt(d2), H = WHT/d2.
+    """
+    N, d0 = X.shape
+    k, d2 = B.shape
+    Xp = np.zeros((N, d2))
+    Xp[:, :d0] = X
+    out = np.empty((N, k * d2))
+    root = np.sqrt(d2)
+    for j in range(k):
+        v = hadamard(Xp * B[j], ordering=False)
+        v = v[:, PI[j]] * G[j]
+        out[:, j * d2:(j + 1) * d2] = hadamard(v, ordering=False) * S[j] * root
+    return out
+
+
+def fastfood_transform(X, B, G, PI, S, lenscale):
+    """FastFoodRBF.transform  basis_functions.py:1263-1289."""
+    d = X.shape[1]
+    ls = _lenscale_col(lenscale, d)
+    V = fastfood_VX(X / ls, B, G, PI, S)
+    n = V.shape[1]
+    return np.concatenate((np.cos(V), np.sin(V)), axis=1) / np.sqrt(n)
+
+
+def fastfood_grad(X, B, G, PI, S, lenscale):
+    """FastFoodRBF.grad  basis_functions.py:1291-1329 (same iso quirk as RFF)."""
+    d = X.shape[1]
+    ls = _lenscale_col(lenscale, d)
+    V = fastfood_VX(X / ls, B, G, PI, S)
+    n = V.shape[1]
+    ms, c = -np.sin(V), np.cos(V)
+    slabs = []
+    for i, l in enumerate(ls):
+        e = np.zeros(d)
+        e[i] = 1. / l ** 2
+        dV = -fastfood_VX(X * e, B, G, PI, S)
+        slabs.append(np.concatenate((dV * ms, dV * c), axis=1) / np.sqrt(n))
+    if len(slabs) == 1:
+        return slabs[0]
+    return np.stack(slabs, axis=2)
+
+
+# --------------------------------------------------------------------------
+# a-8  LinearBasis / concatenation
+# --------------------------------------------------------------------------
+
+def linear_transform(X, onescol=True):
+    """LinearBasis.transform  basis_functions.py:468-485."""
+    X = np.asarray(X, dtype=float)
+    if not onescol:
+        return X
+    return np.concatenate((np.ones((X.shape[0], 1)), X), axis=1)
+
+
+# --------------------------------------------------------------------------
+# a-11  Gram statistics  (slm.py:145-146,157)
+# --------------------------------------------------------------------------
+
+def gram_stats(Phi, y):
+    """G = Phi^T Phi, b = Phi^T y, yty = y^T y   (slm.py:146,157,161-162)."""
+    return Phi.T @ Phi, Phi.T @ y, float(y @ y)
+
+
+def rff_gram_chunked(X, y, W, lenscale, chunk=10000, dtype=np.float64):
+    """Chunk-accumulated Phi + Phi^T Phi + Phi^T y: the metric's unit of work
+    exactly as revrand's NumPy path executes it (basis_functions.py:859-864,
+    slm.py:145-146,157), restated so that Phi for large N need not be held.
+    This is what bench.py times as ``cpu_baseline`` (kind "port")."""
+    d, n = W.shape
+    ls = _lenscale_col(lenscale, d)
+    Ws = (W / ls[:, None]).astype(dtype)
+    F = 2 * n
+    Gm = np.zeros((F, F))
+    b = np.zeros(F)
+    yty = 0.0
+    rn = 1. / np.sqrt(n)
+    for s in range(0, X.shape[0], chunk):
+        Xc = X[s:s + chunk]
+        yc = y[s:s + chunk]
+        Z = np.dot(Xc, Ws)
+        P = np.hstack((np.cos(Z), np.sin(Z))) * rn
+        Gm += P.T.dot(P)
+        b += P.T.dot(yc)
+        yty += float(yc.dot(yc))
+    return Gm, b, yty
+
+
+# --------------------------------------------------------------------------
+# a-13  solve_posdef
+# --------------------------------------------------------------------------
+
+def solve_posdef(A, B):
+    """mathfun.linalg.solve_posdef  linalg.py:84-125 (+ svd_solve :128-179).
+
+    Upper Cholesky; if it fails or any diagonal < CHOLTHRESH use the SVD with
+    singular values clamped at 1e-15.  Returns (A^-1 B, log|A|).
+    """
+    try:
+        U = sla.cholesky(A, lower=False)
+        if np.any(U.diagonal() < CHOLTHRESH):
+            raise sla.LinAlgError("unstable")
+        X = sla.cho_solve((U, False), B)
+        logdet = 2. * np.log(U.diagonal()).sum()
+    except sla.LinAlgError:
+        Us, s, Vt = sla.svd(A)
+        isq = 1. / np.sqrt(np.maximum(s, 1e-15))
+        X = (Us * isq) @ ((isq[:, None] * Vt) @ B)
+        logdet = np.log(s).sum()
+    return X, logdet
+
+
+# --------------------------------------------------------------------------
+# a-11 / a-12  ELBO of the standard linear model
+# --------------------------------------------------------------------------
+
+def slm_elbo(Phi, y, var, reg_diag, slices, dPhis):
+    """StandardLinearModel._elbo  slm.py:142-199, on a materialised Phi.
+
+    reg_diag : (F,) prior variance diagonal (basis.regularizer_diagonal)
+    slices   : slice or list of slices (one per concatenated basis)
+    dPhis    : list of 2-D (N,F) gradient slabs (already split along the ARD axis)
+
+    Returns dict(elbo, m, C, logdetC, dvar, dreg(list), dhyp(list)).  All
+    gradients are of +ELBO; the reference hands the optimiser the gradients of
+    -ELBO (``-dvar`` at slm.py:199, and ``dreg``/``dhyps`` are already defined
+    with the minus sign folded in, slm.py:187,194).
+    """
+    N, F = Phi.shape
+    G = Phi.T @ Phi
+    iL = 1. / reg_diag
+    iC = np.diag(iL) + G / var
+    C, logdet_iC = solve_posdef(iC, np.eye(F))
+    logdetC = -logdet_iC
+    m = C @ (Phi.T @ y) / var
+    trGC = (G * C).sum()
+    err = y - Phi @ m
+    sq = (err ** 2).sum()
+    elbo = -0.5 * (N * np.log(2 * np.pi * var) + sq / var + trGC / var
+                   + ((m ** 2 + C.diagonal()) * iL).sum()
+                   - logdetC + np.log(reg_diag).sum() - F)
+    dvar = 0.5 * (-N + (sq + trGC) / var) / var
+    sl = slices if isinstance(slices, (list, tuple)) else [slices]
+    dreg = [0.5 * (((m[s] ** 2 + C[s, s].diagonal()) * iL[s] ** 2).sum()
+                   - iL[s].sum()) for s in sl]
+    dhyp = [(m @ (err @ dP) - ((dP.T @ Phi) * C).sum()) / var for dP in dPhis]
+    return dict(elbo=elbo, m=m, C=C, logdetC=logdetC, dvar=dvar, dreg=dreg,
+                dhyp=dhyp, G=G, b=Phi.T @ y)
+
+
+def slm_posterior_from_stats(G, b, var, reg_diag):
+    """Posterior (m, C, logdetC) from sufficient statistics (slm.py:154-157)."""
+    F = G.shape[0]
+    iC = np.diag(1. / reg_diag) + G / var
+    C, logdet_iC = solve_posdef(iC, np.eye(F))
+    return C @ b / var, C, -logdet_iC
+
+
+def slm_predict_moments(Phi_s, m, C, var):
+    """StandardLinearModel.predict_moments  slm.py:219-244."""
+    return Phi_s @ m, ((Phi_s @ C) * Phi_s).sum(axis=1) + var

@@ -1,0 +1,124 @@
+"""
+The oracle (oracle/revrand_oracle.py) against the golden vectors that
+oracle/make_golden.py produced by importing the reference -- this is what pins
+the oracle (tier rule 3).  CPU only.
+"""
+import numpy as np
+import pytest
+
+import revrand_oracle as orc
+from conftest import normwise
+
+SAMPLERS = {
+    "RandomRBF": lambda d, n, s: orc.weights_rbf(d, n, s),
+    "RandomLaplace": lambda d, n, s: orc.weights_laplace(d, n, s),
+    "RandomCauchy": lambda d, n, s: orc.weights_cauchy(d, n, s),
+    "RandomMatern32": lambda d, n, s: orc.weights_matern(d, n, s, 1),
+    "RandomMatern52": lambda d, n, s: orc.weights_matern(d, n, s, 2),
+    "OrthogonalRBF": lambda d, n, s: orc.weights_orthogonal(d, n, s),
+}
+
+
+@pytest.mark.parametrize("cname", sorted(SAMPLERS))
+def test_weight_sampling_order(golden, cname):
+    g = golden("weights")
+    for (d, n, seed) in [(3, 4, 7), (8, 256, 1)]:
+        W = g["%s_d%d_n%d_s%d" % (cname, d, n, seed)]
+        assert normwise(SAMPLERS[cname](d, n, seed), W) < 1e-14
+
+
+@pytest.mark.parametrize("cname", sorted(SAMPLERS))
+def test_rff_transform_and_grad(golden, cname):
+    g = golden("rff")
+    for d in ((1, 5, 8) if cname == "RandomRBF" else (5,)):
+        X, W = g["X_d%d" % d], g["%s_d%d_W" % (cname, d)]
+        for tag, ls in [("iso0.7", 0.7), ("iso2.0", 2.0), ("ard", np.linspace(0.5, 2.0, d))]:
+            P = g["%s_d%d_%s_Phi" % (cname, d, tag)]
+            dP = g["%s_d%d_%s_dPhi" % (cname, d, tag)]
+            assert normwise(orc.rff_transform(X, W, ls), P) < 1e-13
+            assert normwise(orc.rff_grad(X, W, ls), dP) < 1e-13
+            # shape/index contract: cos block first, (N,2n[,d])
+            assert P.shape == (X.shape[0], 2 * W.shape[1])
+            assert dP.shape == (P.shape if (tag != "ard" or d == 1) else P.shape + (d,))
+
+
+def test_iso_grad_quirk_is_dimension_zero_only(golden):
+    """Scalar lenscale with d>1: the reference differentiates through X[:,0] only."""
+    g = golden("rff")
+    X, W = g["X_d5"], g["RandomRBF_d5_W"]
+    dP = g["RandomRBF_d5_iso0.7_dPhi"]
+    X0 = np.zeros_like(X)
+    X0[:, 0] = X[:, 0]
+    W0 = np.zeros_like(W)
+    W0[0] = W[0]
+    Z = X @ (W / 0.7)
+    n = W.shape[1]
+    dZ = -(X0 @ W0) / 0.7 ** 2
+    ref = np.hstack((-np.sin(Z) * dZ, np.cos(Z) * dZ)) / np.sqrt(n)
+    assert normwise(ref, dP) < 1e-13
+
+
+def test_hadamard(golden):
+    g = golden("hadamard")
+    assert np.array_equal(orc.hadamard(g["doctest_in"], False), g["doctest_nat"])
+    assert np.array_equal(orc.hadamard(g["doctest_in"], True), g["doctest_seq"])
+    assert normwise(orc.hadamard(g["Y"], False), g["nat"]) < 1e-14
+    assert normwise(orc.hadamard(g["Y"], True), g["seq"]) < 1e-14
+    for L in (1, 2, 64, 128):
+        assert normwise(orc.hadamard(g["Y%d" % L], False), g["nat%d" % L]) < 1e-14
+
+
+@pytest.mark.parametrize("case", [(1, 10), (2, 10), (5, 16), (16, 64), (128, 256)])
+def test_fastfood(golden, case):
+    d, nb = case
+    g = golden("fastfood")
+    k = "d%d_nb%d" % (d, nb)
+    B, G, PI, S = orc.fastfood_matrices(nb, d, 3)
+    assert np.array_equal(B, g[k + "_B"]) and np.array_equal(PI, g[k + "_PI"])
+    assert normwise(G, g[k + "_G"]) < 1e-15 and normwise(S, g[k + "_S"]) < 1e-13
+    X = g[k + "_X"]
+    assert normwise(orc.fastfood_VX(X, B, G, PI, S), g[k + "_VX"]) < 1e-13
+    for tag, ls in [("iso0.7", 0.7), ("iso2.0", 2.0)]:
+        assert normwise(orc.fastfood_transform(X, B, G, PI, S, ls), g["%s_%s_Phi" % (k, tag)]) < 1e-12
+        assert normwise(orc.fastfood_grad(X, B, G, PI, S, ls), g["%s_%s_dPhi" % (k, tag)]) < 1e-12
+    if k + "_ard_Phi" in g:
+        ls = np.linspace(0.5, 2.0, d)
+        assert normwise(orc.fastfood_transform(X, B, G, PI, S, ls), g[k + "_ard_Phi"]) < 1e-12
+        assert normwise(orc.fastfood_grad(X, B, G, PI, S, ls), g[k + "_ard_dPhi"]) < 1e-12
+
+
+def test_solve_posdef(golden):
+    g = golden("solve_posdef")
+    for tag in ("pd", "npd"):
+        X, ld = orc.solve_posdef(g[tag + "_A"], np.eye(5))
+        assert normwise(X, g[tag + "_X"]) < 1e-9
+        if np.isfinite(g[tag + "_logdet"]):
+            assert abs(ld - g[tag + "_logdet"]) < 1e-9 * max(1, abs(ld))
+
+
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+def test_elbo_single_basis(golden, tag):
+    g = golden("elbo")
+    X, y, W, ls = g["X"], g["y"], g[tag + "_W"], g[tag + "_ls"]
+    n = W.shape[1]
+    Phi = orc.rff_transform(X, W, ls)
+    dP = orc.rff_grad(X, W, ls)
+    dPl = [dP] if dP.ndim == 2 else [dP[:, :, i] for i in range(dP.shape[2])]
+    o = orc.slm_elbo(Phi, y, float(g["var"]), np.full(2 * n, float(g["reg"])), slice(None), dPl)
+    assert abs(o["elbo"] - g[tag + "_elbo"]) < 1e-10 * abs(g[tag + "_elbo"])
+    assert normwise(o["m"], g[tag + "_m"]) < 1e-9
+    assert normwise(o["C"], g[tag + "_C"]) < 1e-9
+    assert normwise(o["dvar"], g[tag + "_dvar"]) < 1e-9
+    assert normwise(o["dreg"], g[tag + "_dreg"]) < 1e-9
+    assert normwise(np.array(o["dhyp"]), g[tag + "_dhyp"]) < 1e-8
+    # the sufficient-statistics route gives the same posterior (SURVEY a-12)
+    m, C, ldC = orc.slm_posterior_from_stats(g[tag + "_G"], g[tag + "_b"], float(g["var"]),
+                                            np.full(2 * n, float(g["reg"])))
+    assert normwise(m, g[tag + "_m"]) < 1e-9 and abs(ldC - g[tag + "_logdetC"]) < 1e-8
+
+
+def test_fit_prediction_moments(golden):
+    g = golden("fit")
+    Phi = orc.rff_transform(g["Xs"], g["W"], float(g["hyp_"]))
+    Ey, Vy = orc.slm_predict_moments(Phi, g["m"], g["C"], float(g["var_"]))
+    assert normwise(Ey, g["Ey"]) < 1e-12 and normwise(Vy, g["Vy"]) < 1e-12
