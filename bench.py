@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""
+bench.py -- feature-rows/sec of the hot path (Phi + Phi^T Phi + Phi^T y) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`): RandomRBF, N = 10M rows, D = 32, F = 2*nbases = 4096,
+f32 arithmetic, synthetic Gaussian inputs resident in HBM before the timed region.  One
+"step" is one full pass of the fused kernel over this rank's rows: zero the (F,F)/(F,)
+accumulators, project + cos/sin + accumulate every row, (N>1: all-reduce the partial Gram
+over RCCL), mirror the triangle.  N>1 runs one process per GPU (torch.distributed.run sets
+RANK/LOCAL_RANK/WORLD_SIZE); rows are sharded across ranks (fixed global N -> "strong").
+
+Rank 0 prints ONE JSON line with the contract's keys plus
+  roofline     -- algorithmic flops of one launch / HIP-event time of the kernel, vs the
+                  f32 MFMA peak of gfx950 (157.3 TFLOP/s; MI355X_MICROARCH.md)
+  cpu_baseline -- the NumPy restatement of revrand's path (oracle/, kind "port") timed on
+                  this box's host cores over a bounded row sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+
+
+def flops_per_row(d, n):
+    F = 2 * n
+    return 2.0 * d * n + F * (F + 1.0) + 2.0 * F  # projection + upper-tri Gram + Phi^T y
+
+
+def gen_chunk(c, rows, d, wvec):
+    """Chunk c of the synthetic data set: X ~ N(0,1) f32, y = sin(X w) + 0.1 eps."""
+    rng = np.random.default_rng([20260928, c])
+    X = rng.standard_normal((rows, d), dtype=np.float32)
+    y = np.sin(X @ wvec) + 0.1 * rng.standard_normal(rows, dtype=np.float32)
+    return X, y.astype(np.float32)
+
+
+def cpu_baseline(d, n, W, wvec, sample_rows):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import revrand_oracle as orc  # checker/baseline only -- never on the product path
+    X, y = gen_chunk(10 ** 6, sample_rows, d, wvec)
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    orc.rff_gram_chunked(X64[:2000], y64[:2000], W, 1.0, chunk=1000)  # warm BLAS
+    t0 = time.perf_counter()
+    orc.rff_gram_chunked(X64, y64, W, 1.0, chunk=10000)
+    dt = time.perf_counter() - t0
+    threads = os.cpu_count()
+    try:
+        from threadpoolctl import threadpool_info
+        nt = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        threads = max(nt) if nt else threads
+    except Exception:
+        pass
+    return {"value": sample_rows / dt, "unit": "feature-rows/s", "cores": int(threads), "kind": "port",
+            "sample": "%d rows of the same workload, f64, 10000-row chunks, %.1f s" % (sample_rows, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="global N")
+    ap.add_argument("--dim", type=int, default=32)
+    ap.add_argument("--nbases", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch --gpus %d with: python -m torch.distributed.run --nnodes=1 "
+                             "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." %
+                             (args.gpus, args.gpus, args.gpus))
+        args.gpus = world
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from revrand_amd import _hip
+    dev = _hip.get_device(local_rank)
+    d, n = args.dim, args.nbases
+    F = 2 * n
+    W = np.random.RandomState(42).randn(d, n)
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    basis = _hip.RffHandle(W, compute="f32", device=local_rank)
+
+    # ---- this rank's shard, generated in 1M-row chunks and made resident in HBM ----
+    CH = 1_000_000
+    nchunks = (args.rows + CH - 1) // CH
+    mine = [c for c in range(nchunks) if c % world == rank]
+    rows_of = lambda c: min(CH, args.rows - c * CH)  # noqa: E731
+    my_rows = sum(rows_of(c) for c in mine)
+    dX = dev.empty_matrix(my_rows, d, np.float32, ld_dev=basis.padded_dim)
+    dy = dev.malloc(max(my_rows, 1) * 4)
+    dy.dtype = np.dtype(np.float32)
+    r0 = 0
+    for c in mine:
+        Xc, yc = gen_chunk(c, rows_of(c), d, wvec)
+        dev.upload_rows(dX, r0, Xc)
+        _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, _hip.ctypes.c_void_p(dy.ptr.value + r0 * 4),
+                                                   yc.ctypes.data_as(_hip.ctypes.c_void_p), yc.nbytes))
+        r0 += rows_of(c)
+
+    # ---- accumulators: [G (F*F) | b (F) | yty (1)] float64, one buffer so one all-reduce ----
+    nacc = F * F + F + 1
+    if world > 1:
+        acc_t = torch.zeros(nacc, dtype=torch.float64, device="cuda:%d" % local_rank)
+        acc_ptr = acc_t.data_ptr()
+        torch.cuda.synchronize()
+    else:
+        acc_buf = dev.zeros(nacc * 8)
+        acc_ptr = acc_buf.ptr.value
+    pG = _hip.ctypes.c_void_p(acc_ptr)
+    pb = _hip.ctypes.c_void_p(acc_ptr + F * F * 8)
+    pt = _hip.ctypes.c_void_p(acc_ptr + (F * F + F) * 8)
+    kernel_ms = []
+
+    def step(timed):
+        _hip._check(dev.lib, dev.lib.rr_memset(dev.ctx, pG, 0, nacc * 8))
+        if my_rows:
+            dev.timer_start()
+            basis.gram_dev(dX, dy, 1.0, pG, pb, pt)
+            ms = dev.timer_stop()
+            if timed:
+                kernel_ms.append(ms)
+        dev.sync()
+        if world > 1:
+            dist.all_reduce(acc_t)  # RCCL over xGMI: the one exchange step of the path
+            torch.cuda.synchronize()
+        _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
+        dev.sync()
+
+    def barrier():
+        dev.sync()
+        if world > 1:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the result of the last step: trace(G) == N (cos^2 + sin^2 = 1 per frequency)
+    if world > 1:
+        diag = acc_t[:F * F].view(F, F).diagonal().sum().item()
+    else:
+        G = dev.download(acc_buf, (F, F), np.float64)
+        diag = float(np.trace(G))
+        assert np.array_equal(G, G.T)
+    trace_err = abs(diag - args.rows) / args.rows
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+        value = args.rows / (elapsed / max(args.steps, 1))
+        kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+        achieved = flops_per_row(d, n) * my_rows / (kms * 1e-3) / 1e12 if kernel_ms else float("nan")
+        out = {
+            "metric": "feature-rows/sec (Phi + PhiT Phi + PhiT y) at N=%s D=%d F=%d" % (
+                "10M" if args.rows == 10_000_000 else args.rows, d, F),
+            "value": value, "unit": "feature-rows/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, fused Phi+Gram, rows sharded "
+                                   "over %d GPU(s)" % (n, F, d, args.rows, world),
+                       "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err},
+            "roofline": {"bound": "mfma", "kernel": basis.gram_kernel_name(), "achieved": achieved,
+                         "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel_ms": kms, "flops_per_row": flops_per_row(d, n), "rows_per_launch": my_rows},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    assert trace_err < 1e-4, trace_err
+
+
+if __name__ == "__main__":
+    main()

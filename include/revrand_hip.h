@@ -1,0 +1,163 @@
+/*
+ * revrand_hip.h -- C ABI of librevrand_hip.so: the MI355X (gfx950) hot path of
+ * NICTA/revrand's random-feature basis expansion + Gram assembly.
+ *
+ * The reference has no FFI layer (it is pure NumPy); the boundary its estimators
+ * program against is the duck-typed Basis protocol.  Each entry point below
+ * replaces the arithmetic of one reference method; the Python classes in
+ * revrand_amd/ keep the reference's names/arguments/errors and forward here via
+ * ctypes (INTEGRATION.md shows the binding).  Citations are file:line in the
+ * reference tree (revrand v1.0.0).
+ *
+ * Conventions
+ *  - C linkage, no exceptions cross the ABI.  Every call returns rr_status
+ *    (0 = OK, negative = error); rr_last_error() gives the message of the last
+ *    failing call made by the calling thread.
+ *  - Host buffers are caller-owned, row-major, with 64-bit row counts and explicit
+ *    leading dimensions (in ELEMENTS).  The library owns device memory behind the
+ *    opaque handles.  A handle is used by one host thread at a time.
+ *  - Calls taking host buffers are synchronous: buffers are valid on return.
+ *    *_dev calls take DEVICE pointers (from rr_malloc, or any hipMalloc'd memory
+ *    of the same device, e.g. a torch tensor's data_ptr) and are asynchronous on
+ *    the context's stream unless stated; rr_ctx_sync() waits for them.
+ *  - One rr_ctx per process per GPU (one process per GPU is the scaling model).
+ *  - There is no CPU fallback: without a usable gfx950 device rr_ctx_create fails
+ *    with RR_ERR_NO_DEVICE.
+ */
+#ifndef REVRAND_HIP_H
+#define REVRAND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_ABI_VERSION 1
+
+typedef struct rr_ctx rr_ctx;     /* device context: device id, stream, scratch  */
+typedef struct rr_basis rr_basis; /* device-resident constants of one basis      */
+
+typedef enum rr_status {
+    RR_OK = 0,
+    RR_ERR_INVALID = -1,     /* bad argument (shape, dtype, null pointer)          */
+    RR_ERR_NO_DEVICE = -2,   /* no HIP device / not gfx950                         */
+    RR_ERR_HIP = -3,         /* a HIP runtime call failed (message has the detail) */
+    RR_ERR_OOM = -4,         /* device allocation failed                           */
+    RR_ERR_UNSUPPORTED = -5  /* valid request this build cannot serve              */
+} rr_status;
+
+typedef enum rr_dtype { RR_F32 = 0, RR_F64 = 1 } rr_dtype;
+
+/* ---- library / context ------------------------------------------------- */
+
+int rr_abi_version(void);
+const char *rr_last_error(void);
+int rr_device_count(int *count);
+
+/* Bind a context to HIP device `device` (creates a stream, queries the arch). */
+int rr_ctx_create(int device, rr_ctx **out);
+void rr_ctx_destroy(rr_ctx *ctx);
+int rr_ctx_sync(rr_ctx *ctx);
+/* Device facts: name (<= 63 chars), number of CUs, total HBM bytes. */
+int rr_ctx_info(rr_ctx *ctx, char name[64], int *compute_units, uint64_t *hbm_bytes);
+/* The context's hipStream_t as an opaque pointer (for event timing by callers). */
+void *rr_ctx_stream(rr_ctx *ctx);
+
+/* ---- device memory (keeps X, y resident across optimiser iterations) ---- */
+
+int rr_malloc(rr_ctx *ctx, size_t bytes, void **dptr);
+int rr_free(rr_ctx *ctx, void *dptr);
+int rr_memset(rr_ctx *ctx, void *dptr, int value, size_t bytes);
+int rr_memcpy_h2d(rr_ctx *ctx, void *dst, const void *src, size_t bytes);
+int rr_memcpy_d2h(rr_ctx *ctx, void *dst, const void *src, size_t bytes);
+
+/* Timing helper: run between two events on the context's stream.
+ * rr_timer_start records an event; rr_timer_stop records a second one, waits for
+ * it and returns the elapsed milliseconds of everything enqueued in between. */
+int rr_timer_start(rr_ctx *ctx);
+int rr_timer_stop(rr_ctx *ctx, float *ms);
+
+/* ---- random Fourier feature bases --------------------------------------
+ * One object serves RandomRBF / RandomLaplace / RandomCauchy / RandomMatern32 /
+ * RandomMatern52 / OrthogonalRBF: they differ only in how the host samples W
+ * (basis_functions.py:952-954, 993-995, 1034-1045, 1051-1065, 1198-1208), which
+ * stays host-side NumPy.
+ *
+ * W: host, row-major (d, n) float64 -- the `self.W` of _RandomKernelBasis
+ * (basis_functions.py:830-834).  compute: RR_F32 or RR_F64 arithmetic. */
+int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_basis **out);
+void rr_basis_destroy(rr_basis *basis);
+
+/* Row length the kernels read from a DEVICE X: Xdim rounded up to 8/16/32/64/128.  Every
+ * *_dev entry point requires ldx >= this and elements [d, padded) of each row to be zero
+ * (they meet zero weights; NaN/Inf there would poison the row).  rr_upload_matrix with
+ * ld_dev = rr_rff_padded_dim() produces exactly this layout; the host-buffer entry points
+ * do it internally. */
+int rr_rff_padded_dim(rr_basis *basis);
+
+/* Allocate a device (N, ld_dev) matrix of `dtype`, zero the pad columns and copy the host
+ * (N, d) matrix with leading dimension ldx into it.  Free with rr_free. */
+int rr_upload_matrix(rr_ctx *ctx, const void *X, int dtype, int64_t N, int64_t d, int64_t ldx,
+                     int64_t ld_dev, void **dptr);
+
+/* Copy host rows (N, d; leading dimension ldx) into rows [row0, row0 + N) of an existing
+ * device matrix with leading dimension ld_dev (pad columns are left untouched: allocate
+ * with rr_malloc + rr_memset(0) first).  Lets callers stream a large X up in chunks. */
+int rr_upload_rows(rr_ctx *ctx, void *dptr, int64_t ld_dev, int64_t row0, const void *X, int dtype,
+                   int64_t N, int64_t d, int64_t ldx);
+
+/* lenscale: host float64, n_ls == 1 (isotropic) or n_ls == d (ARD), as validated
+ * by _LengthScaleBasis._check_dim (basis_functions.py:590-613). */
+
+/* Phi = [cos(X W/l), sin(X W/l)] / sqrt(n)            (N, 2n)
+ * replaces _RandomKernelBasis.transform  basis_functions.py:838-864.
+ * X host (N, d) of x_dtype, leading dimension ldx; Phi host (N, 2n) of out_dtype,
+ * leading dimension ldphi. */
+int rr_rff_transform(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
+                     const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi);
+
+/* dPhi/dl  replaces _RandomKernelBasis.grad  basis_functions.py:866-901.
+ * n_ls == 1: out is (N, 2n) and -- as in the reference -- holds ONLY input
+ * dimension 0's contribution (the loop at :896 runs once with i = 0).
+ * n_ls == d: out is (N, 2n, d), C-order (the np.dstack of :901). */
+int rr_rff_grad(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
+                const double *lenscale, int n_ls, void *dPhi, int out_dtype);
+
+/* Device-resident forms (X on the device, x_dtype, row-major, ldx). */
+int rr_rff_transform_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                         const double *lenscale, int n_ls, void *dPhi_out, int out_dtype,
+                         int64_t ldphi);
+
+/* The metric's unit of work: for every row, project, cos/sin, scale and
+ * accumulate   G += phi phi^T (F x F, F = 2n),  b += phi y,  yty += y^2
+ * without ever writing Phi to HBM.  Replaces, for a random Fourier basis,
+ *   Phi = basis.transform(X, l)      slm.py:145 (basis_functions.py:859-864)
+ *   PhiPhi = Phi.T.dot(Phi)          slm.py:146
+ *   Phi.T.dot(y)                     slm.py:157
+ * dX (N, d) x_dtype and dy (N,) x_dtype are DEVICE pointers.  dG (F*F), db (F),
+ * dyty (1) are DEVICE float64 buffers that are ACCUMULATED INTO (zero them with
+ * rr_memset for a fresh sum) so that row shards / chunks can be summed; only the
+ * upper triangle (row <= col) of G is written.  dy/db/dyty may be NULL together.
+ * Asynchronous on the context stream. */
+int rr_rff_gram_dev(rr_basis *basis, const void *dX, const void *dy, int x_dtype, int64_t N,
+                    int64_t ldx, const double *lenscale, int n_ls, double *dG, double *db,
+                    double *dyty);
+
+/* Mirror the upper triangle of a device (F, F) float64 matrix into the lower. */
+int rr_symmetrize_dev(rr_ctx *ctx, double *dG, int64_t F);
+
+/* Host-buffer convenience: uploads X, y in row chunks, runs rr_rff_gram_dev,
+ * symmetrises and downloads.  G host (F, F) float64 full symmetric; b (F,); yty (1). */
+int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int64_t N,
+                int64_t ldx, const double *lenscale, int n_ls, double *G, double *b,
+                double *yty);
+
+/* Name of the dominant kernel the last rr_rff_gram_dev launched (for profiles). */
+const char *rr_rff_gram_kernel_name(rr_basis *basis);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVRAND_HIP_H */

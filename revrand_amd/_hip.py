@@ -1,0 +1,378 @@
+"""
+ctypes binding of librevrand_hip.so (include/revrand_hip.h) -- the only door between the
+Python classes of this package and the GPU.  No torch, no numpy-side fallback: if the
+library or a gfx950 device is missing, the calls raise.
+
+A device context is created lazily, once per *process* (sklearn may fork workers, SURVEY
+8b), and is never pickled.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librevrand_hip.so")
+
+RR_F32, RR_F64 = 0, 1
+_NP2RR = {np.dtype(np.float32): RR_F32, np.dtype(np.float64): RR_F64}
+_RR2NP = {RR_F32: np.float32, RR_F64: np.float64}
+
+_c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+_c_double_p = ctypes.POINTER(ctypes.c_double)
+
+# name -> (restype, argtypes); every symbol include/revrand_hip.h declares
+SIGNATURES = {
+    "rr_abi_version": (ctypes.c_int, []),
+    "rr_last_error": (ctypes.c_char_p, []),
+    "rr_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
+    "rr_ctx_create": (ctypes.c_int, [ctypes.c_int, _c_void_pp]),
+    "rr_ctx_destroy": (None, [ctypes.c_void_p]),
+    "rr_ctx_sync": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_ctx_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int),
+                                   ctypes.POINTER(ctypes.c_uint64)]),
+    "rr_ctx_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "rr_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, _c_void_pp]),
+    "rr_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_memset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
+    "rr_memcpy_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "rr_memcpy_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "rr_timer_start": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_timer_stop": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "rr_rff_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_void_p, _c_void_pp]),
+    "rr_basis_destroy": (None, [ctypes.c_void_p]),
+    "rr_rff_padded_dim": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_upload_matrix": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, _c_void_pp]),
+    "rr_upload_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
+    "rr_rff_transform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                        ctypes.c_int, ctypes.c_int64]),
+    "rr_rff_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.c_int]),
+    "rr_rff_transform_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_int64]),
+    "rr_rff_gram_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_symmetrize_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
+    "rr_rff_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                   ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_rff_gram_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
+}
+
+
+class HipError(RuntimeError):
+    """A call into librevrand_hip.so failed; the message is rr_last_error()."""
+
+    def __init__(self, code, message):
+        super().__init__("librevrand_hip: %s (status %d)" % (message, code))
+        self.code = code
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load_library(path=None):
+    """Load the shared library and declare every prototype.  Raises if it is not built."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None and path is None:
+            return _lib
+        p = path or os.environ.get("REVRAND_HIP_LIB", LIB_PATH)
+        if not os.path.exists(p):
+            raise ImportError(
+                "librevrand_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C revrand_amd/csrc`; there is no CPU fallback for this path" % p)
+        lib = ctypes.CDLL(p)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is missing
+            fn.restype = res
+            fn.argtypes = args
+        if lib.rr_abi_version() != 1:
+            raise ImportError("librevrand_hip.so ABI version %d != 1" % lib.rr_abi_version())
+        if path is None:
+            _lib = lib
+        return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        msg = lib.rr_last_error()
+        raise HipError(rc, msg.decode("utf-8", "replace") if msg else "unknown error")
+
+
+def rr_dtype(np_dtype):
+    try:
+        return _NP2RR[np.dtype(np_dtype)]
+    except KeyError:
+        raise TypeError("only float32/float64 arrays can cross the HIP boundary, got %s" % np_dtype)
+
+
+def as_float_matrix(X):
+    """X as a float32/float64 2-d array whose rows are contiguous (other dtypes -> float64).
+
+    Row-sliced views with a larger row stride are passed through with their leading dimension.
+    """
+    X = np.asarray(X)
+    if X.dtype not in (np.float32, np.float64):
+        X = X.astype(np.float64)
+    if X.ndim != 2:
+        raise ValueError("expected a 2-d array")
+    N, d = X.shape
+    cols_ok = d == 0 or X.strides[1] == X.itemsize
+    rows_ok = N <= 1 or (X.strides[0] % X.itemsize == 0 and X.strides[0] >= d * X.itemsize)
+    if not (cols_ok and rows_ok):
+        X = np.ascontiguousarray(X)
+    return X
+
+
+def _ld(X):
+    return X.strides[0] // X.itemsize if X.shape[0] > 1 else max(X.shape[1], 1)
+
+
+class DeviceBuffer(object):
+    """A device allocation owned by Python (freed on garbage collection)."""
+
+    def __init__(self, dev, ptr, nbytes):
+        self.dev, self.ptr, self.nbytes = dev, ptr, nbytes
+
+    def free(self):
+        if self.ptr:
+            try:
+                self.dev.lib.rr_free(self.dev.ctx, self.ptr)
+            except Exception:
+                pass
+            self.ptr = None
+
+    def __del__(self):
+        self.free()
+
+
+class DeviceMatrix(DeviceBuffer):
+    """Row-major (N, d) matrix on the device with leading dimension `ld` (pad columns zero)."""
+
+    def __init__(self, dev, ptr, shape, ld, dtype):
+        super().__init__(dev, ptr, shape[0] * ld * np.dtype(dtype).itemsize)
+        self.shape, self.ld, self.dtype = tuple(shape), ld, np.dtype(dtype)
+
+
+class Device(object):
+    """One rr_ctx: a GPU, a stream, and helpers.  Use get_device()."""
+
+    def __init__(self, index):
+        self.lib = load_library()
+        self.index = index
+        self.pid = os.getpid()
+        ctx = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_ctx_create(index, ctypes.byref(ctx)))
+        self.ctx = ctx
+        name = ctypes.create_string_buffer(64)
+        cus = ctypes.c_int()
+        hbm = ctypes.c_uint64()
+        _check(self.lib, self.lib.rr_ctx_info(ctx, name, ctypes.byref(cus), ctypes.byref(hbm)))
+        self.name, self.compute_units, self.hbm_bytes = name.value.decode(), cus.value, hbm.value
+
+    # -- memory ---------------------------------------------------------------
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_malloc(self.ctx, nbytes, ctypes.byref(p)))
+        return DeviceBuffer(self, p, nbytes)
+
+    def zeros(self, nbytes):
+        buf = self.malloc(nbytes)
+        _check(self.lib, self.lib.rr_memset(self.ctx, buf.ptr, 0, nbytes))
+        return buf
+
+    def memset(self, buf, nbytes=None):
+        _check(self.lib, self.lib.rr_memset(self.ctx, buf.ptr, 0, buf.nbytes if nbytes is None else nbytes))
+
+    def upload_matrix(self, X, ld_dev=None):
+        X = as_float_matrix(X)
+        N, d = X.shape
+        ld_dev = max(d, 1) if ld_dev is None else ld_dev
+        p = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_upload_matrix(self.ctx, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype),
+                                                   N, max(d, 1), _ld(X), ld_dev, ctypes.byref(p)))
+        return DeviceMatrix(self, p, (N, d), ld_dev, X.dtype)
+
+    def empty_matrix(self, N, d, dtype, ld_dev=None):
+        """Zero-initialised device (N, d) matrix to be filled with upload_rows."""
+        ld_dev = max(d, 1) if ld_dev is None else ld_dev
+        nbytes = max(N * ld_dev, 1) * np.dtype(dtype).itemsize
+        p = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_malloc(self.ctx, nbytes, ctypes.byref(p)))
+        _check(self.lib, self.lib.rr_memset(self.ctx, p, 0, nbytes))
+        return DeviceMatrix(self, p, (N, d), ld_dev, dtype)
+
+    def upload_rows(self, dmat, row0, X):
+        X = as_float_matrix(X)
+        if X.dtype != dmat.dtype or X.shape[1] != dmat.shape[1] or row0 + X.shape[0] > dmat.shape[0]:
+            raise ValueError("upload_rows: dtype/shape mismatch")
+        _check(self.lib, self.lib.rr_upload_rows(self.ctx, dmat.ptr, dmat.ld, row0,
+                                                 X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype),
+                                                 X.shape[0], X.shape[1], _ld(X)))
+
+    def upload_vector(self, y, dtype=None):
+        y = np.ascontiguousarray(y, dtype=dtype)
+        buf = self.malloc(max(y.nbytes, 1))
+        if y.nbytes:
+            _check(self.lib, self.lib.rr_memcpy_h2d(self.ctx, buf.ptr, y.ctypes.data_as(ctypes.c_void_p), y.nbytes))
+        buf.shape, buf.dtype = y.shape, y.dtype
+        return buf
+
+    def download(self, buf, shape, dtype, offset_bytes=0):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            src = ctypes.c_void_p(buf.ptr.value + offset_bytes)
+            _check(self.lib, self.lib.rr_memcpy_d2h(self.ctx, out.ctypes.data_as(ctypes.c_void_p), src, out.nbytes))
+        return out
+
+    def sync(self):
+        _check(self.lib, self.lib.rr_ctx_sync(self.ctx))
+
+    def timer_start(self):
+        _check(self.lib, self.lib.rr_timer_start(self.ctx))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        _check(self.lib, self.lib.rr_timer_stop(self.ctx, ctypes.byref(ms)))
+        return ms.value
+
+
+_devices = {}
+
+
+def default_device_index():
+    for var in ("REVRAND_HIP_DEVICE", "LOCAL_RANK"):
+        if os.environ.get(var, "") != "":
+            return int(os.environ[var])
+    return 0
+
+
+def get_device(index=None):
+    """The process-local Device for GPU `index` (default: $REVRAND_HIP_DEVICE, $LOCAL_RANK, 0)."""
+    index = default_device_index() if index is None else int(index)
+    key = (os.getpid(), index)
+    dev = _devices.get(key)
+    if dev is None:
+        dev = Device(index)
+        _devices[key] = dev
+    return dev
+
+
+def device_available():
+    """True iff the library loads and sees at least one HIP device (never raises)."""
+    try:
+        lib = load_library()
+        n = ctypes.c_int()
+        return lib.rr_device_count(ctypes.byref(n)) == 0 and n.value > 0
+    except Exception:
+        return False
+
+
+def _ptr(x):
+    """DeviceBuffer / ctypes pointer / integer address / None -> c_void_p (or None)."""
+    if x is None:
+        return None
+    if isinstance(x, DeviceBuffer):
+        return x.ptr
+    if isinstance(x, ctypes.c_void_p):
+        return x
+    return ctypes.c_void_p(int(x))
+
+
+def _lenscale_arg(lenscale):
+    ls = np.ascontiguousarray(np.atleast_1d(np.asarray(lenscale, dtype=np.float64)))
+    return ls, ls.ctypes.data_as(ctypes.c_void_p), int(ls.size)
+
+
+class RffHandle(object):
+    """Device-resident random Fourier basis (rr_basis): W lives on the GPU."""
+
+    def __init__(self, W, compute="f32", device=None):
+        self.dev = get_device(device)
+        self.lib = self.dev.lib
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        self.d, self.n = W.shape
+        self.compute = {"f32": RR_F32, "f64": RR_F64}[compute]
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_rff_create(self.dev.ctx, self.compute, self.d, self.n,
+                                                W.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+        self.h = h
+        self.padded_dim = self.lib.rr_rff_padded_dim(h)
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.rr_basis_destroy(h)
+            except Exception:
+                pass
+
+    def transform(self, X, lenscale, out_dtype=np.float64):
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        out = np.empty((N, 2 * self.n), dtype=out_dtype)
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, self.lib.rr_rff_transform(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N,
+                                                   _ld(X), lsp, nls, out.ctypes.data_as(ctypes.c_void_p),
+                                                   rr_dtype(out.dtype), 2 * self.n))
+        return out
+
+    def grad(self, X, lenscale, out_dtype=np.float64):
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        shape = (N, 2 * self.n) if nls == 1 else (N, 2 * self.n, self.d)
+        out = np.empty(shape, dtype=out_dtype)
+        _check(self.lib, self.lib.rr_rff_grad(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N,
+                                              _ld(X), lsp, nls, out.ctypes.data_as(ctypes.c_void_p),
+                                              rr_dtype(out.dtype)))
+        return out
+
+    def gram(self, X, y, lenscale):
+        """(G (F,F) full symmetric, b (F,), yty) from host X (N,d), y (N,) or None."""
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        F = 2 * self.n
+        G = np.empty((F, F))
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        if y is None:
+            _check(self.lib, self.lib.rr_rff_gram(self.h, X.ctypes.data_as(ctypes.c_void_p), None, rr_dtype(X.dtype),
+                                                  N, _ld(X), lsp, nls, G.ctypes.data_as(ctypes.c_void_p), None, None))
+            return G, None, None
+        y = np.ascontiguousarray(y, dtype=X.dtype).ravel()
+        if y.shape[0] != N:
+            raise ValueError("X and y have inconsistent numbers of rows")
+        b = np.empty(F)
+        yty = np.empty(1)
+        _check(self.lib, self.lib.rr_rff_gram(self.h, X.ctypes.data_as(ctypes.c_void_p),
+                                              y.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N, _ld(X), lsp,
+                                              nls, G.ctypes.data_as(ctypes.c_void_p),
+                                              b.ctypes.data_as(ctypes.c_void_p), yty.ctypes.data_as(ctypes.c_void_p)))
+        return G, b, float(yty[0])
+
+    # -- device-resident API (fit loops, bench, shards) -------------------------
+    def upload(self, X):
+        """Upload X once in the padded layout the kernels read (rr_rff_padded_dim)."""
+        return self.dev.upload_matrix(X, ld_dev=self.padded_dim)
+
+    def gram_dev(self, dX, dy, lenscale, dG, db=None, dyty=None):
+        """Accumulate into device buffers (async).  dX: DeviceMatrix; dy: DeviceBuffer or None."""
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, self.lib.rr_rff_gram_dev(self.h, dX.ptr, _ptr(dy), rr_dtype(dX.dtype), dX.shape[0],
+                                                  dX.ld, lsp, nls, _ptr(dG), _ptr(db), _ptr(dyty)))
+
+    def symmetrize_dev(self, dG):
+        _check(self.lib, self.lib.rr_symmetrize_dev(self.dev.ctx, _ptr(dG), 2 * self.n))
+
+    def gram_kernel_name(self):
+        return self.lib.rr_rff_gram_kernel_name(self.h).decode()

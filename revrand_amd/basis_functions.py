@@ -1,0 +1,428 @@
+"""
+Basis objects with revrand's Basis protocol, backed by the HIP kernels of librevrand_hip.so.
+
+Same names, constructor arguments, argument meaning, error messages and array shapes as
+``revrand.basis_functions`` (reference file cited per item), so the reference's estimators
+and these are interchangeable on this path.  What differs is where the arithmetic runs:
+
+* ``transform`` / ``grad`` of the random Fourier bases (RandomRBF, RandomLaplace,
+  RandomCauchy, RandomMatern32/52, OrthogonalRBF) call ``rr_rff_transform`` / ``rr_rff_grad``;
+* those bases additionally expose ``gram(X, y, *params)`` -- the fused
+  Phi -> (Phi^T Phi, Phi^T y, y^T y) accumulation (``rr_rff_gram``) that
+  ``StandardLinearModel`` uses so that Phi never has to exist.
+
+Host-side by design (as in the reference): sampling of W from a seeded
+``RandomState`` (so seeds reproduce the reference's W bit-for-bit), parameter plumbing,
+concatenation bookkeeping.  There is NO NumPy fallback for the device parts: without the
+library or a GPU they raise.
+
+New keyword on the HIP-backed bases: ``dtype`` = "f32" (default; the arithmetic type of the
+kernels, BASELINE config 2) or "f64".  Returned arrays are always float64, like the
+reference's.
+"""
+import inspect
+from functools import reduce, wraps
+from itertools import repeat
+
+import numpy as np
+from scipy.linalg import qr
+from scipy.stats import gamma
+from sklearn.utils import check_random_state
+
+from . import _hip
+from .btypes import Parameter, Positive
+from .utils import atleast_list, atleast_tuple, issequence
+
+
+# --------------------------------------------------------------------------------------
+# helpers (reference: basis_functions.py:34-152)
+# --------------------------------------------------------------------------------------
+
+def count_args(func):
+    """Number of arguments of a (bound) method, excluding self (basis_functions.py:52-66)."""
+    return len(inspect.signature(func).parameters)
+
+
+def slice_init(func):
+    """Add the ``apply_ind`` keyword to a basis constructor (basis_functions.py:70-93)."""
+    @wraps(func)
+    def new_init(self, *args, **kwargs):
+        apply_ind = kwargs.pop("apply_ind", None)
+        if np.isscalar(apply_ind):
+            apply_ind = [apply_ind]
+        func(self, *args, **kwargs)
+        self.apply_ind = apply_ind
+    return new_init
+
+
+def slice_transform(func):
+    """Apply ``X[:, apply_ind]`` before transform/grad/gram (basis_functions.py:96-105).
+
+    ``functools.wraps`` records ``__wrapped__``, which ``inspect.signature`` follows, so
+    ``count_args`` still sees the wrapped method's own parameters -- BasisCat routes
+    positional hyper-parameters by that count.
+    """
+    @wraps(func)
+    def wrapper(self, X, *vargs, **kwargs):
+        if self.apply_ind is not None:
+            X = X[:, self.apply_ind]
+        return func(self, X, *vargs, **kwargs)
+    return wrapper
+
+
+def apply_grad(fun, grad):
+    """Map a functional of a 2-d gradient over structured gradients (basis_functions.py:109-152).
+
+    Sequences/generators recurse (a one-element result is unwrapped), ``[]`` stays ``[]``,
+    3-d arrays are mapped over their last axis.
+    """
+    if issequence(grad):
+        fgrad = [apply_grad(fun, g) for g in grad]
+        return fgrad if len(fgrad) != 1 else fgrad[0]
+    if len(grad) == 0:
+        return []
+    if grad.ndim in (1, 2):
+        return fun(grad)
+    if grad.ndim == 3:
+        return np.array([fun(grad[:, :, i]) for i in range(grad.shape[2])])
+    raise ValueError("Only up to 3d gradients allowed!")
+
+
+# --------------------------------------------------------------------------------------
+# Basis protocol (reference: basis_functions.py:159-384)
+# --------------------------------------------------------------------------------------
+
+class Basis(object):
+    """Base class: identity transform, no parameters, scalar regulariser."""
+
+    _params = Parameter()
+    _regularizer = Parameter(gamma(1.), Positive())
+
+    @slice_init
+    def __init__(self, regularizer=None):
+        if regularizer is not None:
+            if not regularizer.is_scalar:
+                raise ValueError("Regularizer parameters have to be scalar!")
+            if regularizer.bounds.lower <= 0:
+                raise ValueError("Regularizer has to be bounded below by 0!")
+            self._regularizer = regularizer
+
+    @slice_transform
+    def transform(self, X):
+        return X
+
+    @slice_transform
+    def grad(self, X):
+        return []
+
+    def get_dim(self, X):
+        """Output dimensionality, probed once with the first row (basis_functions.py:276-297)."""
+        if not hasattr(self, "_D"):
+            self._D = self.transform(X[[0]], *self.params_values()).shape[1]
+        return self._D
+
+    def params_values(self):
+        return [p.value for p in atleast_list(self.params) if p.has_value]
+
+    def regularizer_diagonal(self, X, regularizer=None):
+        """(diag of the prior weight variance (D,), slice it applies to)  (:307-340)."""
+        reg = self.regularizer.value if regularizer is None else regularizer
+        return np.full(self.get_dim(X), reg, dtype=float), slice(None)
+
+    def _transform_popargs(self, X, *args):
+        mine, rest = self.__split(args, self.transform)
+        return self.transform(X, *mine), rest
+
+    def _grad_popargs(self, X, *args):
+        mine, rest = self.__split(args, self.grad)
+        return self.grad(X, *mine), rest, mine
+
+    def __split(self, args, fn):
+        k = count_args(fn) - 1  # minus X
+        return args[:k], args[k:]
+
+    @property
+    def params(self):
+        return self._params
+
+    @property
+    def regularizer(self):
+        return self._regularizer
+
+    def __add__(self, other):
+        return BasisCat([self, other])
+
+    def __radd__(self, other):
+        return self if other == 0 else self.__add__(other)
+
+    def __repr__(self):
+        return "{}(regularizer={})".format(type(self).__name__, self.regularizer)
+
+
+class BiasBasis(Basis):
+    """A constant column (basis_functions.py:387-440)."""
+
+    @slice_init
+    def __init__(self, offset=1., regularizer=None):
+        self.offset = offset
+        super(BiasBasis, self).__init__(regularizer)
+
+    @slice_transform
+    def transform(self, X):
+        return np.ones((len(X), 1)) * self.offset
+
+    def __repr__(self):
+        return "{}(offset={}, regularizer={})".format(type(self).__name__, self.offset, self.regularizer)
+
+
+class LinearBasis(Basis):
+    """[1, X] or X (basis_functions.py:443-493); trivially host-side."""
+
+    @slice_init
+    def __init__(self, onescol=True, regularizer=None):
+        self.onescol = onescol
+        super(LinearBasis, self).__init__(regularizer)
+
+    @slice_transform
+    def transform(self, X):
+        N, D = X.shape
+        return np.hstack((np.ones((N, 1)), X)) if self.onescol else X
+
+    def __repr__(self):
+        return "{}(onescol={}, regularizer={})".format(type(self).__name__, self.onescol, self.regularizer)
+
+
+class _LengthScaleBasis(Basis):
+    """Length-scale validation shared by the kernel bases (basis_functions.py:579-613)."""
+
+    def _init_lenscale(self, lenscale):
+        if (lenscale.shape != (self.d,)) and (lenscale.shape != ()):
+            raise ValueError("Parameter dimension doesn't agree with X dimensions!")
+        self._params = lenscale
+
+    def _check_dim(self, Xdim, in_param, paramind=None):
+        if Xdim != self.d:
+            raise ValueError("Dimensions of data inconsistent!")
+        sparam = self.params if paramind is None else self.params[paramind]
+        if in_param is None:
+            in_param = sparam.value
+        sparam.bounds.check(in_param)  # result ignored, as in the reference (:603)
+        if np.isscalar(in_param):
+            in_param = np.array([in_param])
+        if (sparam.shape == () and len(in_param) == 1) or np.shape(in_param) == sparam.shape:
+            return in_param
+        raise ValueError("Dimension of input parameter is inconsistent!")
+
+
+# --------------------------------------------------------------------------------------
+# Random Fourier feature bases on the GPU (reference: basis_functions.py:818-1208)
+# --------------------------------------------------------------------------------------
+
+class _RandomKernelBasis(_LengthScaleBasis):
+    """Phi = [cos(X W/l), sin(X W/l)]/sqrt(nbases); subclasses only sample W."""
+
+    @slice_init
+    def __init__(self, nbases, Xdim, lenscale=Parameter(gamma(1.), Positive()), regularizer=None,
+                 random_state=None, dtype="f32"):
+        if dtype not in ("f32", "f64"):
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        self.d = Xdim
+        self.n = nbases
+        self.dtype = dtype
+        self.random_state = random_state  # for repr
+        self._random = check_random_state(random_state)
+        self.W = self._weightsamples()
+        self._init_lenscale(lenscale)
+        super(_LengthScaleBasis, self).__init__(regularizer)
+
+    # device handle: created on first use in this process, never pickled
+    def _handle(self):
+        h = self.__dict__.get("_hip_handle")
+        if h is None or h[0] != _hip.os.getpid():
+            h = (_hip.os.getpid(), _hip.RffHandle(self.W, compute=self.dtype))
+            self.__dict__["_hip_handle"] = h
+        return h[1]
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_hip_handle", None)
+        return state
+
+    def get_dim(self, X):
+        return 2 * self.n
+
+    @slice_transform
+    def transform(self, X, lenscale=None):
+        """(N, 2*nbases) float64, cos block then sin block (basis_functions.py:838-864)."""
+        N, D = X.shape
+        lenscale = self._check_dim(D, lenscale)
+        return self._handle().transform(X, lenscale)
+
+    @slice_transform
+    def grad(self, X, lenscale=None):
+        """dPhi/dl: (N, 2*nbases) for a scalar length scale -- dimension 0's contribution only,
+        exactly as the reference computes it -- or (N, 2*nbases, d) for ARD
+        (basis_functions.py:866-901)."""
+        N, D = X.shape
+        lenscale = self._check_dim(D, lenscale)
+        return self._handle().grad(X, lenscale)
+
+    @slice_transform
+    def gram(self, X, y=None, lenscale=None):
+        """Fused (Phi^T Phi, Phi^T y, y^T y) without materialising Phi (slm.py:145-146,157)."""
+        N, D = X.shape
+        lenscale = self._check_dim(D, lenscale)
+        return self._handle().gram(X, y, lenscale)
+
+    def __repr__(self):
+        return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(
+            type(self).__name__, self.n, self.d, self.params, self.regularizer, self.random_state)
+
+
+class RandomRBF(_RandomKernelBasis):
+    """RBF kernel features: W ~ N(0, 1) (basis_functions.py:916-954)."""
+
+    def _weightsamples(self):
+        return self._random.randn(self.d, self.n)
+
+
+class RandomLaplace(_RandomKernelBasis):
+    """Laplace kernel features: W ~ Cauchy (basis_functions.py:957-995)."""
+
+    def _weightsamples(self):
+        return self._random.standard_cauchy(size=(self.d, self.n))
+
+
+class RandomCauchy(_RandomKernelBasis):
+    """Cauchy kernel features: Gaussian scaled per frequency by sqrt(2 Gamma(1))
+    (basis_functions.py:998-1045)."""
+
+    def _weightsamples(self):
+        gauss = self._random.randn(self.d, self.n)
+        mix = self._random.standard_gamma(1., size=(1, self.n))
+        return gauss * np.sqrt(2 * mix)
+
+
+class _RandomMatern(_RandomKernelBasis):
+    """Multivariate-t frequencies with 2p+1 degrees of freedom (basis_functions.py:1048-1065)."""
+
+    def _maternweight(self, p):
+        df = 2 * (p + 0.5)
+        gauss = self._random.randn(self.d, self.n)
+        chi2 = self._random.chisquare(df, size=(self.n,))
+        return gauss * np.sqrt(df / chi2)
+
+
+class RandomMatern32(_RandomMatern):
+    """Matern 3/2 features (basis_functions.py:1068-1107)."""
+
+    def _weightsamples(self):
+        return self._maternweight(p=1)
+
+
+class RandomMatern52(_RandomMatern):
+    """Matern 5/2 features (basis_functions.py:1110-1150)."""
+
+    def _weightsamples(self):
+        return self._maternweight(p=2)
+
+
+class OrthogonalRBF(_RandomKernelBasis):
+    """Orthogonal random features (basis_functions.py:1153-1208): QR blocks, chi row scales."""
+
+    def _weightsamples(self):
+        reps = int(np.ceil(self.n / self.d))
+        Q = np.empty((self.d, self.d * reps))
+        for r in range(reps):
+            Q[:, r * self.d:(r + 1) * self.d] = qr(self._random.randn(self.d, self.d))[0]
+        S = np.sqrt(self._random.chisquare(df=self.d, size=self.d))
+        return S[:, np.newaxis] * Q[:, :self.n]
+
+
+# --------------------------------------------------------------------------------------
+# Concatenation (reference: basis_functions.py:1569-1790)
+# --------------------------------------------------------------------------------------
+
+class BasisCat(object):
+    """Column-wise concatenation of bases; parameters are routed positionally in
+    concatenation order, gradients are zero-padded to full width and yielded lazily."""
+
+    def __init__(self, basis_list):
+        def merge(blist, b):
+            rlist = atleast_list(blist)
+            if isinstance(b, BasisCat):
+                rlist.extend(b.bases)
+            else:
+                rlist.append(b)
+            return rlist
+        self.bases = reduce(merge, basis_list)
+        self.__dims = None
+        self.__baseinds = None
+        self.__slices = None
+
+    def transform(self, X, *params):
+        Phi, args = [], list(params)
+        for base in self.bases:
+            phi, args = base._transform_popargs(X, *args)
+            Phi.append(phi)
+        return np.hstack(Phi)
+
+    def grad(self, X, *params):
+        N = X.shape[0]
+        D = self.get_dim(X)
+        ends = self.__base_locations(X)
+        args = list(params)
+        for i, base in enumerate(self.bases):
+            g, args, _ = base._grad_popargs(X, *args)
+            for gg in atleast_tuple(g):
+                if len(gg) == 0:
+                    continue
+                full = np.zeros((N, D) if gg.ndim < 3 else (N, D, gg.shape[2]))
+                full[:, ends[i]:ends[i + 1]] = gg
+                yield full
+
+    def get_dim(self, X):
+        return np.sum(self.__all_dims(X))
+
+    def params_values(self):
+        return [v for b in self.bases for v in b.params_values()]
+
+    @property
+    def regularizer(self):
+        return [b.regularizer for b in self.bases]
+
+    def regularizer_diagonal(self, X, *regularizer):
+        regularizer = repeat(None) if regularizer == () else regularizer
+        regs, _ = zip(*(b.regularizer_diagonal(X, r) for b, r in zip(self.bases, regularizer)))
+        if self.__slices is None:
+            ends = self.__base_locations(X)
+            self.__slices = [slice(b, e) for b, e in zip(ends[:-1], ends[1:])]
+        return np.concatenate(regs), self.__slices
+
+    @property
+    def params(self):
+        plist = [b.params for b in self.bases if b.params.has_value]
+        if len(plist) == 0:
+            return Parameter()
+        return plist if len(plist) > 1 else plist[0]
+
+    def __all_dims(self, X):
+        if self.__dims is None:
+            self.__dims = [b.get_dim(X) for b in self.bases]
+        return self.__dims
+
+    def __base_locations(self, X):
+        if self.__baseinds is None:
+            self.__baseinds = np.cumsum([0] + self.__all_dims(X))
+        return self.__baseinds
+
+    def __add__(self, other):
+        if isinstance(other, BasisCat):
+            return BasisCat(self.bases + other.bases)
+        return BasisCat(self.bases + [other])
+
+    def __radd__(self, other):
+        return self if other == 0 else self.__add__(other)
+
+    def __repr__(self):
+        return "{}(basis_list={})".format(type(self).__name__, self.bases)

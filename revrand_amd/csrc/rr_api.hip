@@ -1,0 +1,262 @@
+// Host side of the C ABI: contexts, device memory, basis objects.
+// See include/revrand_hip.h for the contract of every entry point.
+#include "rr_internal.h"
+
+#include <cmath>
+
+static thread_local std::string g_last_error;
+
+void rr_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" {
+
+int rr_abi_version(void) { return RR_ABI_VERSION; }
+
+const char *rr_last_error(void) { return g_last_error.c_str(); }
+
+int rr_device_count(int *count) {
+    RR_REQUIRE(count != nullptr, "rr_device_count: null output");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        rr_set_error("hipGetDeviceCount failed: %s", hipGetErrorString(e));
+        return RR_ERR_NO_DEVICE;
+    }
+    *count = n;
+    return RR_OK;
+}
+
+int rr_ctx_create(int device, rr_ctx **out) {
+    RR_REQUIRE(out != nullptr, "rr_ctx_create: null output");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        rr_set_error("rr_ctx_create: no HIP device is visible (the hot path has no CPU fallback)");
+        return RR_ERR_NO_DEVICE;
+    }
+    RR_REQUIRE(device >= 0 && device < n, "rr_ctx_create: device %d out of range [0,%d)", device, n);
+    RR_CHECK_HIP(hipSetDevice(device));
+    rr_ctx *c = new rr_ctx();
+    c->device = device;
+    hipError_t e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) {
+        delete c;
+        rr_set_error("hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+        return RR_ERR_HIP;
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        rr_set_error("rr_ctx_create: device %d is %s; this library carries gfx950 code only",
+                     device, c->prop.gcnArchName);
+        delete c;
+        return RR_ERR_NO_DEVICE;
+    }
+    c->num_cu = c->prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        rr_set_error("rr_ctx_create: stream/event creation failed");
+        delete c;
+        return RR_ERR_HIP;
+    }
+    *out = c;
+    return RR_OK;
+}
+
+void rr_ctx_destroy(rr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+int rr_ctx_sync(rr_ctx *ctx) {
+    RR_REQUIRE(ctx != nullptr, "rr_ctx_sync: null context");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    RR_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return RR_OK;
+}
+
+int rr_ctx_info(rr_ctx *ctx, char name[64], int *compute_units, uint64_t *hbm_bytes) {
+    RR_REQUIRE(ctx != nullptr, "rr_ctx_info: null context");
+    if (name) {
+        snprintf(name, 64, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    if (compute_units) *compute_units = ctx->num_cu;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;
+    return RR_OK;
+}
+
+void *rr_ctx_stream(rr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int rr_malloc(rr_ctx *ctx, size_t bytes, void **dptr) {
+    RR_REQUIRE(ctx != nullptr && dptr != nullptr, "rr_malloc: null argument");
+    *dptr = nullptr;
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_malloc: hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        return RR_ERR_OOM;
+    }
+    return RR_OK;
+}
+
+int rr_free(rr_ctx *ctx, void *dptr) {
+    RR_REQUIRE(ctx != nullptr, "rr_free: null context");
+    if (!dptr) return RR_OK;
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    RR_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    RR_CHECK_HIP(hipFree(dptr));
+    return RR_OK;
+}
+
+int rr_memset(rr_ctx *ctx, void *dptr, int value, size_t bytes) {
+    RR_REQUIRE(ctx != nullptr && (dptr != nullptr || bytes == 0), "rr_memset: null argument");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    if (bytes) RR_CHECK_HIP(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return RR_OK;
+}
+
+int rr_memcpy_h2d(rr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    RR_REQUIRE(ctx != nullptr && (bytes == 0 || (dst && src)), "rr_memcpy_h2d: null argument");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    if (bytes) {
+        RR_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RR_OK;
+}
+
+int rr_memcpy_d2h(rr_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    RR_REQUIRE(ctx != nullptr && (bytes == 0 || (dst && src)), "rr_memcpy_d2h: null argument");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    if (bytes) {
+        RR_CHECK_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return RR_OK;
+}
+
+int rr_timer_start(rr_ctx *ctx) {
+    RR_REQUIRE(ctx != nullptr, "rr_timer_start: null context");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    RR_CHECK_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return RR_OK;
+}
+
+int rr_timer_stop(rr_ctx *ctx, float *ms) {
+    RR_REQUIRE(ctx != nullptr && ms != nullptr, "rr_timer_stop: null argument");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    RR_CHECK_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    RR_CHECK_HIP(hipEventSynchronize(ctx->ev1));
+    RR_CHECK_HIP(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RR_OK;
+}
+
+int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_basis **out) {
+    RR_REQUIRE(ctx != nullptr && out != nullptr && W != nullptr, "rr_rff_create: null argument");
+    *out = nullptr;
+    RR_REQUIRE(d >= 1 && n >= 1, "rr_rff_create: need d >= 1 and n >= 1 (got d=%d n=%d)", d, n);
+    RR_REQUIRE(compute == RR_F32 || compute == RR_F64, "rr_rff_create: bad compute dtype %d", compute);
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    rr_basis *b = new rr_basis();
+    b->ctx = ctx;
+    b->kind = RR_KIND_RFF;
+    b->compute = compute;
+    b->d = d;
+    b->n = n;
+    b->npad = ((n + 127) / 128) * 128;
+    b->dpad = rr_pick_dmax(d);
+    if (b->dpad == 0) {
+        delete b;
+        rr_set_error("rr_rff_create: Xdim=%d > 128 is not supported yet", d);
+        return RR_ERR_UNSUPPORTED;
+    }
+    b->W.assign(W, W + (size_t)d * n);
+    size_t elems = (size_t)b->dpad * b->npad;
+    hipError_t e1 = hipMalloc((void **)&b->dWs32, elems * sizeof(float));
+    hipError_t e2 = hipMalloc((void **)&b->dWs64, elems * sizeof(double));
+    hipError_t e3 = hipMalloc((void **)&b->dgfac32, (size_t)b->dpad * sizeof(float));
+    hipError_t e4 = hipMalloc((void **)&b->dgfac64, (size_t)b->dpad * sizeof(double));
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_rff_create: device allocation failed");
+        rr_basis_destroy(b);
+        return RR_ERR_OOM;
+    }
+    *out = b;
+    return RR_OK;
+}
+
+void rr_basis_destroy(rr_basis *b) {
+    if (!b) return;
+    if (b->ctx) {
+        (void)hipSetDevice(b->ctx->device);
+        (void)hipStreamSynchronize(b->ctx->stream);
+    }
+    if (b->dWs32) (void)hipFree(b->dWs32);
+    if (b->dWs64) (void)hipFree(b->dWs64);
+    if (b->dgfac32) (void)hipFree(b->dgfac32);
+    if (b->dgfac64) (void)hipFree(b->dgfac64);
+    delete b;
+}
+
+const char *rr_rff_gram_kernel_name(rr_basis *basis) { return basis ? basis->gram_kernel : ""; }
+
+}  // extern "C"
+
+// Scale W by 1/(l_i * 2pi) in f64 on the host (d*n elements: tiny) and upload.  The kernels
+// then obtain the phase directly in revolutions, which is what v_sin_f32/v_cos_f32 consume.
+int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
+    RR_REQUIRE(b != nullptr && lenscale != nullptr, "lenscale: null argument");
+    RR_REQUIRE(n_ls == 1 || n_ls == b->d,
+               "Dimension of input parameter is inconsistent! (n_ls=%d, d=%d)", n_ls, b->d);
+    for (int i = 0; i < n_ls; ++i)
+        RR_REQUIRE(std::isfinite(lenscale[i]) && lenscale[i] != 0.0, "lenscale[%d] is %g", i, lenscale[i]);
+    bool same = (int)b->ls_cache.size() == n_ls;
+    for (int i = 0; same && i < n_ls; ++i) same = (b->ls_cache[i] == lenscale[i]);
+    if (same) return RR_OK;
+
+    const double inv2pi = 0.15915494309189533576888;
+    const double twopi = 6.283185307179586476925;
+    const int d = b->d, n = b->n, npad = b->npad;
+    std::vector<double> w64((size_t)b->dpad * npad, 0.0);
+    std::vector<float> w32((size_t)b->dpad * npad, 0.0f);
+    std::vector<double> g64(b->dpad, 0.0);
+    std::vector<float> g32(b->dpad, 0.0f);
+    for (int i = 0; i < d; ++i) {
+        const double l = lenscale[n_ls == 1 ? 0 : i];
+        const double s = inv2pi / l;
+        for (int f = 0; f < n; ++f) {
+            const double v = b->W[(size_t)i * n + f] * s;
+            w64[(size_t)i * npad + f] = v;
+            w32[(size_t)i * npad + f] = (float)v;
+        }
+        g64[i] = twopi / l;
+        g32[i] = (float)g64[i];
+    }
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    // synchronous copies from short-lived host vectors
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(b->dWs32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->dWs64, w64.data(), w64.size() * sizeof(double), hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->dgfac32, g32.data(), g32.size() * sizeof(float), hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->dgfac64, g64.data(), g64.size() * sizeof(double), hipMemcpyHostToDevice));
+    b->ls_cache.assign(lenscale, lenscale + n_ls);
+    return RR_OK;
+}

@@ -1,0 +1,63 @@
+// Internal declarations shared by the translation units of librevrand_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/revrand_hip.h"
+
+struct rr_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipDeviceProp_t prop;
+    int num_cu = 0;
+};
+
+enum rr_kind { RR_KIND_RFF = 0, RR_KIND_FASTFOOD = 1 };
+
+struct rr_basis {
+    rr_ctx *ctx = nullptr;
+    int kind = RR_KIND_RFF;
+    int compute = RR_F32;
+    int d = 0, n = 0;
+    int dpad = 0;                 // d rounded up to 8/16/32/64/128: rows of Ws, row length kernels read
+    int npad = 0;                 // n rounded up to a multiple of 128 (device Ws row length)
+    std::vector<double> W;        // host copy (d, n) row-major, as given
+    std::vector<double> ls_cache; // lenscale the device copy was scaled with
+    float *dWs32 = nullptr;       // (dpad, npad), zero padded: W[i][f] / (l_i * 2pi)   -> phase in revolutions
+    double *dWs64 = nullptr;      // same in f64
+    float *dgfac32 = nullptr;     // (d,): 2pi / l_i  (grad kernels)
+    double *dgfac64 = nullptr;
+    const char *gram_kernel = "";
+};
+
+void rr_set_error(const char *fmt, ...);
+
+#define RR_CHECK_HIP(expr)                                                            \
+    do {                                                                              \
+        hipError_t _e = (expr);                                                       \
+        if (_e != hipSuccess) {                                                       \
+            rr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                         __FILE__, __LINE__);                                         \
+            return (_e == hipErrorOutOfMemory) ? RR_ERR_OOM : RR_ERR_HIP;             \
+        }                                                                             \
+    } while (0)
+
+#define RR_REQUIRE(cond, ...)                                                         \
+    do {                                                                              \
+        if (!(cond)) {                                                                \
+            rr_set_error(__VA_ARGS__);                                                \
+            return RR_ERR_INVALID;                                                    \
+        }                                                                             \
+    } while (0)
+
+// Upload W scaled by the given lenscale (cached); implemented in rr_api.hip.
+int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
+int rr_pick_dmax(int d);

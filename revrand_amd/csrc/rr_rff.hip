@@ -1,0 +1,754 @@
+// Random Fourier feature kernels for gfx950 (MI355X, CDNA4): Phi, dPhi/dl and the fused
+// Phi -> Phi^T Phi / Phi^T y accumulation.  HIP source, wave64, f32-input MFMA.
+//
+// Phase convention: the host uploads Ws[i][f] = W[i][f] / (l_i * 2 pi), so the projection
+// t = sum_i x_i Ws[i][f] is the phase in REVOLUTIONS; after the exact reduction
+// t - rint(t) in [-0.5, 0.5] the hardware v_sin_f32 / v_cos_f32 (which take revolutions)
+// give sin/cos directly.
+#include "rr_internal.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ void sincos_rev(float t, float &s, float &c) {
+    const float f = t - __builtin_rintf(t);
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
+}
+
+__device__ __forceinline__ void sincos_rev(double t, double &s, double &c) {
+    const double f = t - rint(t);
+    sincospi(2.0 * f, &s, &c);
+}
+
+// z = sum_i x[i] * w[i] with x wave-uniform (scalar loads) and w in registers.
+// GUARD == false: the row has at least DMAX readable, finite elements (the caller padded X with
+// zero columns up to DMAX, see rr_rff_padded_dim) and w[i] == 0 for i >= d, so the loop is
+// branch-free and the scalar loads merge.  GUARD == true: read exactly d elements.
+template <int DMAX, bool GUARD, typename TX, typename TC>
+__device__ __forceinline__ TC project_row(const TX *__restrict__ xr, int d, const TC (&w)[DMAX]) {
+    TC z = 0;
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+        if (!GUARD || i < d) z = fma((TC)xr[i], w[i], z);
+    }
+    return z;
+}
+
+// Ws has DMAX rows (rows >= d are zero) and npad columns (columns >= n are zero).
+template <int DMAX, typename TC>
+__device__ __forceinline__ void load_w(TC (&w)[DMAX], const TC *__restrict__ Ws, int npad, int f) {
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) w[i] = Ws[(size_t)i * npad + f];
+}
+
+// ---------------------------------------------------------------------------------------
+// Phi = [cos, sin] / sqrt(n)        (_RandomKernelBasis.transform, basis_functions.py:838-864)
+// grid.x = frequency blocks of 256, grid.y = row blocks; one frequency per thread, W column in
+// registers, X rows through the scalar cache, stores coalesced along the frequency axis.
+// ---------------------------------------------------------------------------------------
+template <int DMAX, typename TX, typename TC, typename TO>
+__global__ void __launch_bounds__(256)
+rr_rff_transform_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *__restrict__ Ws,
+                        int n, int npad, TO *__restrict__ Phi, int64_t ldphi, TC scale,
+                        int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    TC w[DMAX];
+    load_w<DMAX, TC>(w, Ws, npad, fvalid ? f : 0);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const TC t = project_row<DMAX, false, TX, TC>(X + r * ldx, DMAX, w);
+        TC s, c;
+        sincos_rev(t, s, c);
+        if (fvalid) {
+            TO *o = Phi + r * ldphi;
+            o[f] = (TO)(c * scale);
+            o[n + f] = (TO)(s * scale);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// dPhi/dl_i = [ -sin(z) dz_i , cos(z) dz_i ] / sqrt(n),  dz_i = -x_i W[i][f] / l_i^2
+//           (_RandomKernelBasis.grad, basis_functions.py:866-901)
+// nout == 1: (N, 2n), dimension 0 only (the reference's isotropic quirk);
+// nout == d: (N, 2n, d) C-order.
+// ---------------------------------------------------------------------------------------
+template <int DMAX, typename TX, typename TC, typename TO>
+__global__ void __launch_bounds__(256)
+rr_rff_grad_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *__restrict__ Ws,
+                   const TC *__restrict__ gfac, int n, int npad, int nout, TO *__restrict__ out,
+                   TC scale, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    TC w[DMAX];
+    load_w<DMAX, TC>(w, Ws, npad, fvalid ? f : 0);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const TX *xr = X + r * ldx;
+        const TC t = project_row<DMAX, false, TX, TC>(xr, DMAX, w);
+        TC s, c;
+        sincos_rev(t, s, c);
+        if (fvalid) {
+            TO *oc = out + ((size_t)r * 2 * n + f) * nout;
+            TO *os = out + ((size_t)r * 2 * n + n + f) * nout;
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) {
+                if (i < nout) {
+                    const TC dz = -(TC)xr[i] * w[i] * gfac[i] * scale;
+                    oc[i] = (TO)(-s * dz);
+                    os[i] = (TO)(c * dz);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused Phi -> Gram.  One workgroup (8 waves) owns the 256x256 block of G spanned by the
+// frequency blocks (fa, fb), fa <= fb, of 128 frequencies each -- local columns
+// [cos_a | sin_a] x [cos_b | sin_b] -- for one K-split (a contiguous range of rows).
+//
+// Per k-block of 32 rows:
+//   produce: thread (frequency fl = tid & 255, row parity h = tid >> 8) projects its 16 rows
+//            (X through the scalar cache, W column in registers), takes cos/sin and writes
+//            them to the LDS tile  [32 rows][512 cols]  (A side cols 0..255, B side 256..511);
+//   consume: wave (wr, wc) accumulates its 128x64 sub-block with v_mfma_f32_32x32x2_f32,
+//            operands straight from LDS with conflict-free ds_read_b32 (lane -> column,
+//            lane>>5 -> row of the 2-row k-step, which IS the 32x32x2 A/B operand layout).
+// The two waves that share a SIMD (w and w+4) run the two phases in opposite order
+// (waves 0-3: produce then consume; waves 4-7: consume then produce), so one wave's VALU /
+// transcendental work overlaps the other's MFMAs; the LDS tile is double-buffered and there
+// is ONE barrier per k-block.
+// Accumulation is f32 inside a K-split and f64 across K-splits (atomic add into G).
+// ---------------------------------------------------------------------------------------
+constexpr int GR_TF = 128;   // frequencies per tile side
+constexpr int GR_KB = 32;    // rows per k-block
+constexpr int GR_LD = 512;   // LDS tile row length (floats)
+constexpr int GR_THREADS = 512;
+
+template <typename TX>
+struct GramArgs {
+    const TX *X;
+    const TX *y;  // may be null
+    int64_t N, ldx;
+    const float *Ws;
+    int n, npad, nfb;  // nfb = npad / 128 frequency blocks
+    int ntiles;        // nfb (nfb + 1) / 2
+    int64_t rows_per_split;
+    double *G;
+    double *b;  // null iff y is null
+    float scale;
+};
+
+// Rows past row_end are clamped to the last valid row (so every load is in bounds) and their
+// features are zeroed through the per-row scale: no branches in the hot loop.
+template <int DMAX, bool HAS_Y, typename TX>
+__device__ __forceinline__ void gram_produce(const GramArgs<TX> &p, float *__restrict__ buf,
+                                             const float (&w)[DMAX], int64_t kb0, int64_t row_end,
+                                             int h, int colc, float fscale, float &by_c, float &by_s) {
+#pragma unroll 2
+    for (int t = 0; t < GR_KB / 2; ++t) {
+        const int lr = 2 * t + h;
+        const int64_t r = kb0 + lr;
+        const bool rvalid = r < row_end;  // wave-uniform
+        const int64_t rr = rvalid ? r : row_end - 1;
+        const float ph = project_row<DMAX, false, TX, float>(p.X + rr * p.ldx, DMAX, w);
+        float s, c;
+        sincos_rev(ph, s, c);
+        const float sc = rvalid ? fscale : 0.f;
+        c *= sc;
+        s *= sc;
+        if (HAS_Y) {
+            const float yv = (float)p.y[rr];
+            by_c = fmaf(c, yv, by_c);
+            by_s = fmaf(s, yv, by_s);
+        }
+        buf[lr * GR_LD + colc] = c;
+        buf[lr * GR_LD + colc + GR_TF] = s;
+    }
+}
+
+__device__ __forceinline__ void gram_consume(const float *__restrict__ buf, floatx16 (&acc)[4][2],
+                                             int aoff, int boff) {
+#pragma unroll 2
+    for (int t = 0; t < GR_KB / 2; ++t) {
+        const float *row = buf + (2 * t) * GR_LD;
+        float a[4], b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = row[aoff + i * 32];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = row[boff + j * 32];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <int DMAX, bool HAS_Y, typename TX>
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_rff_gram_f32_kernel(const GramArgs<TX> p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = wave >> 2;  // row parity this wave produces == ping-pong group
+
+    // tile (fa <= fb) and K-split of this workgroup
+    int tdx = blockIdx.x % p.ntiles;
+    const int ks = blockIdx.x / p.ntiles;
+    int fa = 0;
+    while (tdx >= p.nfb - fa) {
+        tdx -= p.nfb - fa;
+        ++fa;
+    }
+    const int fb = fa + tdx;
+    const bool diag = (fa == fb);
+
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.N) row_end = p.N;
+
+    // producer role: local frequency fl of side A (fl < 128) or B
+    const int fl = tid & 255;
+    const int gf = (fl < GR_TF) ? fa * GR_TF + fl : fb * GR_TF + (fl - GR_TF);  // < npad
+    const bool fvalid = gf < p.n;
+    const float fscale = fvalid ? p.scale : 0.f;
+    const int colc = fl + (fl & GR_TF);  // A: fl ; B: 256 + (fl - 128)
+    float w[DMAX];
+    load_w<DMAX, float>(w, p.Ws, p.npad, gf);
+    float by_c = 0.f, by_s = 0.f;
+
+    // consumer role: wave (wr, wc) -> rows [wr*128, +128) of side A, cols [wc*64, +64) of side B
+    const int wr = (wave & 3) >> 1, wc_ = (wave & 1) | ((wave >> 2) << 1);
+    const int aoff = (lane >> 5) * GR_LD + wr * 128 + (lane & 31);
+    const int boff = (lane >> 5) * GR_LD + 256 + wc_ * 64 + (lane & 31);
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int64_t nkb = (row_end - row_begin + GR_KB - 1) / GR_KB;
+    if (nkb > 0) {
+        gram_produce<DMAX, HAS_Y, TX>(p, lds, w, row_begin, row_end, h, colc, fscale, by_c, by_s);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            float *cur = lds + (kb & 1) * (GR_KB * GR_LD);
+            float *nxt = lds + ((kb + 1) & 1) * (GR_KB * GR_LD);
+            const bool more = (kb + 1 < nkb);
+            const int64_t kb1 = row_begin + (kb + 1) * GR_KB;
+            // one consume site (the accumulators never flow through a branch), produce before
+            // it for waves 0-3 and after it for waves 4-7
+            if (more && h == 0) gram_produce<DMAX, HAS_Y, TX>(p, nxt, w, kb1, row_end, 0, colc, fscale, by_c, by_s);
+            gram_consume(cur, acc, aoff, boff);
+            if (more && h != 0) gram_produce<DMAX, HAS_Y, TX>(p, nxt, w, kb1, row_end, 1, colc, fscale, by_c, by_s);
+            __syncthreads();
+        }
+    }
+
+    // ---- flush: f32 partial -> f64 G (upper triangle only) ----
+    const int64_t F = 2 * (int64_t)p.n;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int lb = wc_ * 64 + j * 32 + (lane & 31);  // local B column
+        const int fbq = fb * GR_TF + (lb & (GR_TF - 1));
+        const bool bvalid = fbq < p.n;
+        const int64_t gb = (lb < GR_TF) ? fbq : p.n + fbq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int la = wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const int faq = fa * GR_TF + (la & (GR_TF - 1));
+                const int64_t ga = (la < GR_TF) ? faq : p.n + faq;
+                const bool lower = ga > gb;
+                const bool keep = bvalid && (faq < p.n) && !(lower && diag);
+                const int64_t gr = lower ? gb : ga, gc = lower ? ga : gb;
+                if (keep) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+            }
+        }
+    }
+    if (HAS_Y && diag && fl < GR_TF && fvalid) {
+        unsafeAtomicAdd(&p.b[gf], (double)by_c);
+        unsafeAtomicAdd(&p.b[p.n + gf], (double)by_s);
+    }
+}
+
+// y^T y (slm.py:161-162 via sqErr = yty - 2 m.b + m G m)
+template <typename TX>
+__global__ void __launch_bounds__(256) rr_yty_kernel(const TX *__restrict__ y, int64_t N, double *out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// lower triangle <- upper triangle, 32x32 tiles through LDS so both sides stay coalesced
+__global__ void __launch_bounds__(256) rr_symmetrize_kernel(double *G, int64_t F) {
+    __shared__ double tile[32][33];
+    const int bi = blockIdx.y, bj = blockIdx.x;  // tile (bi, bj) of the UPPER part, bi <= bj
+    if (bi > bj) return;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = (int64_t)bi * 32 + k, c = (int64_t)bj * 32 + tx;
+        tile[k][tx] = (r < F && c < F) ? G[r * F + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int64_t r = (int64_t)bj * 32 + k, c = (int64_t)bi * 32 + tx;  // transposed position
+        if (r < F && c < F && r > c) G[r * F + c] = tile[tx][k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------
+
+int rr_pick_dmax(int d) { return d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 0; }
+
+template <typename TX, typename TC, typename TO>
+static int launch_transform(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *dPhi, int64_t ldphi) {
+    rr_ctx *c = b->ctx;
+    const TC *Ws = (sizeof(TC) == 4) ? (const TC *)b->dWs32 : (const TC *)b->dWs64;
+    const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    const int fblocks = (b->n + 255) / 256;
+    // enough row blocks to fill the chip a few times over, >= 16 rows each
+    int64_t rpb = (N * fblocks + (int64_t)c->num_cu * 16 - 1) / ((int64_t)c->num_cu * 16);
+    if (rpb < 16) rpb = 16;
+    if (rpb > 1024) rpb = 1024;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+#define RR_LT(DM)                                                                                  \
+    hipLaunchKernelGGL((rr_rff_transform_kernel<DM, TX, TC, TO>), grid, dim3(256), 0, c->stream,   \
+                       (const TX *)dX, N, ldx, Ws, b->n, b->npad, (TO *)dPhi, ldphi, scale, (int)rpb)
+    switch (b->dpad) {
+        case 8: RR_LT(8); break;
+        case 16: RR_LT(16); break;
+        case 32: RR_LT(32); break;
+        case 64: RR_LT(64); break;
+        case 128: RR_LT(128); break;
+        default: rr_set_error("transform: d=%d > 128 is not supported yet", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_LT
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+template <typename TX, typename TC, typename TO>
+static int launch_grad(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *dOut, int nout) {
+    rr_ctx *c = b->ctx;
+    const TC *Ws = (sizeof(TC) == 4) ? (const TC *)b->dWs32 : (const TC *)b->dWs64;
+    const TC *gf = (sizeof(TC) == 4) ? (const TC *)b->dgfac32 : (const TC *)b->dgfac64;
+    const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = 16;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+#define RR_LG(DM)                                                                                \
+    hipLaunchKernelGGL((rr_rff_grad_kernel<DM, TX, TC, TO>), grid, dim3(256), 0, c->stream,       \
+                       (const TX *)dX, N, ldx, Ws, gf, b->n, b->npad, nout, (TO *)dOut, scale,    \
+                       (int)rpb)
+    switch (b->dpad) {
+        case 8: RR_LG(8); break;
+        case 16: RR_LG(16); break;
+        case 32: RR_LG(32); break;
+        case 64: RR_LG(64); break;
+        case 128: RR_LG(128); break;
+        default: rr_set_error("grad: d=%d > 128 is not supported yet", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_LG
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// dispatch on (x dtype, compute dtype, out dtype)
+#define RR_DISPATCH3(FN, xdt, cdt, odt, ...)                                              \
+    do {                                                                                  \
+        const int key = (xdt) * 4 + (cdt) * 2 + (odt);                                    \
+        switch (key) {                                                                    \
+            case 0: return FN<float, float, float>(__VA_ARGS__);                          \
+            case 1: return FN<float, float, double>(__VA_ARGS__);                         \
+            case 2: return FN<float, double, float>(__VA_ARGS__);                         \
+            case 3: return FN<float, double, double>(__VA_ARGS__);                        \
+            case 4: return FN<double, float, float>(__VA_ARGS__);                         \
+            case 5: return FN<double, float, double>(__VA_ARGS__);                        \
+            case 6: return FN<double, double, float>(__VA_ARGS__);                        \
+            case 7: return FN<double, double, double>(__VA_ARGS__);                       \
+        }                                                                                 \
+        rr_set_error("bad dtype combination");                                            \
+        return RR_ERR_INVALID;                                                            \
+    } while (0)
+
+static bool dtype_ok(int t) { return t == RR_F32 || t == RR_F64; }
+static size_t dtype_size(int t) { return t == RR_F32 ? 4 : 8; }
+
+static int transform_dev_impl(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                              void *dPhi, int out_dtype, int64_t ldphi) {
+    RR_DISPATCH3(launch_transform, x_dtype, b->compute, out_dtype, b, dX, N, ldx, dPhi, ldphi);
+}
+
+static int grad_dev_impl(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, void *dOut,
+                         int out_dtype, int nout) {
+    RR_DISPATCH3(launch_grad, x_dtype, b->compute, out_dtype, b, dX, N, ldx, dOut, nout);
+}
+
+template <typename TX>
+static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t N, int64_t ldx, double *dG,
+                           double *db) {
+    rr_ctx *c = b->ctx;
+    const int nfb = b->npad / GR_TF;
+    const int ntiles = nfb * (nfb + 1) / 2;
+    // K-splits: f32 accumulation is limited to <= 32768 rows per split; use more (smaller)
+    // splits when that is needed to give every CU several workgroups.
+    int64_t rps = 32768;
+    const int64_t want_wgs = (int64_t)c->num_cu * 8;
+    while (rps > 1024 && ((N + rps - 1) / rps) * ntiles < want_wgs) rps /= 2;
+    const char *env = getenv("RR_GRAM_ROWS_PER_SPLIT");
+    if (env && atoll(env) >= GR_KB) rps = (atoll(env) / GR_KB) * GR_KB;
+    const int64_t nsplit = (N + rps - 1) / rps;
+    RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+    GramArgs<TX> a;
+    a.X = (const TX *)dX; a.y = (const TX *)dy; a.N = N; a.ldx = ldx; a.Ws = b->dWs32;
+    a.n = b->n; a.npad = b->npad; a.nfb = nfb; a.ntiles = ntiles;
+    a.rows_per_split = rps; a.G = dG; a.b = db;
+    a.scale = (float)(1.0 / sqrt((double)b->n));
+    const dim3 grid((unsigned)(nsplit * ntiles));
+#define RR_LGR(DM)                                                                                       \
+    do {                                                                                                 \
+        if (dy) hipLaunchKernelGGL((rr_rff_gram_f32_kernel<DM, true, TX>), grid, dim3(GR_THREADS), 0, c->stream, a);  \
+        else hipLaunchKernelGGL((rr_rff_gram_f32_kernel<DM, false, TX>), grid, dim3(GR_THREADS), 0, c->stream, a);    \
+    } while (0)
+    switch (b->dpad) {
+        case 8: RR_LGR(8); break;
+        case 16: RR_LGR(16); break;
+        case 32: RR_LGR(32); break;
+        case 64: RR_LGR(64); break;
+        default: rr_set_error("gram: d=%d > 64 is not supported yet", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_LGR
+    RR_CHECK_HIP(hipGetLastError());
+    b->gram_kernel = "rr_rff_gram_f32_kernel";
+    return RR_OK;
+}
+
+// Device staging buffer for host rows: (chunk, dpad) with the pad columns zeroed once.
+struct RowStage {
+    void *dX = nullptr;
+    int64_t chunk = 0;
+};
+
+static int stage_alloc(rr_basis *b, int x_dtype, int64_t N, size_t extra_row_bytes, RowStage *st) {
+    const size_t xs = dtype_size(x_dtype);
+    const size_t row_bytes = (size_t)b->dpad * xs + extra_row_bytes;
+    int64_t chunk = (int64_t)(((size_t)1 << 30) / row_bytes);  // ~1 GiB of device staging
+    if (chunk < 1) chunk = 1;
+    if (chunk > N) chunk = N;
+    RR_CHECK_HIP(hipMalloc(&st->dX, (size_t)chunk * b->dpad * xs));
+    RR_CHECK_HIP(hipMemsetAsync(st->dX, 0, (size_t)chunk * b->dpad * xs, b->ctx->stream));
+    st->chunk = chunk;
+    return RR_OK;
+}
+
+static hipError_t stage_rows(rr_basis *b, const RowStage &st, const void *X, int x_dtype, int64_t r0, int64_t m,
+                             int64_t ldx) {
+    const size_t xs = dtype_size(x_dtype);
+    return hipMemcpy2DAsync(st.dX, (size_t)b->dpad * xs, (const char *)X + (size_t)r0 * ldx * xs, (size_t)ldx * xs,
+                            (size_t)b->d * xs, (size_t)m, hipMemcpyHostToDevice, b->ctx->stream);
+}
+
+extern "C" {
+
+int rr_rff_padded_dim(rr_basis *b) { return b ? b->dpad : 0; }
+
+int rr_upload_matrix(rr_ctx *c, const void *X, int dtype, int64_t N, int64_t d, int64_t ldx, int64_t ld_dev,
+                     void **dptr) {
+    RR_REQUIRE(c != nullptr && dptr != nullptr, "rr_upload_matrix: null argument");
+    *dptr = nullptr;
+    RR_REQUIRE(dtype_ok(dtype), "rr_upload_matrix: bad dtype");
+    RR_REQUIRE(N >= 0 && d >= 1 && ldx >= d && ld_dev >= d, "rr_upload_matrix: bad shape");
+    RR_REQUIRE(N == 0 || X != nullptr, "rr_upload_matrix: null host buffer");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = dtype_size(dtype);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)(N > 0 ? N : 1) * ld_dev * es);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_upload_matrix: hipMalloc(%zu bytes) failed", (size_t)N * ld_dev * es);
+        return RR_ERR_OOM;
+    }
+    if (N > 0) {
+        if (ld_dev > d) e = hipMemsetAsync(p, 0, (size_t)N * ld_dev * es, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(p, (size_t)ld_dev * es, X, (size_t)ldx * es, (size_t)d * es, (size_t)N,
+                                 hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            (void)hipFree(p);
+            rr_set_error("rr_upload_matrix: copy failed: %s", hipGetErrorString(e));
+            return RR_ERR_HIP;
+        }
+    }
+    *dptr = p;
+    return RR_OK;
+}
+
+int rr_upload_rows(rr_ctx *c, void *dptr, int64_t ld_dev, int64_t row0, const void *X, int dtype, int64_t N,
+                   int64_t d, int64_t ldx) {
+    RR_REQUIRE(c != nullptr && dptr != nullptr, "rr_upload_rows: null argument");
+    RR_REQUIRE(dtype_ok(dtype), "rr_upload_rows: bad dtype");
+    RR_REQUIRE(N >= 0 && row0 >= 0 && d >= 1 && ldx >= d && ld_dev >= d, "rr_upload_rows: bad shape");
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(X != nullptr, "rr_upload_rows: null host buffer");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = dtype_size(dtype);
+    RR_CHECK_HIP(hipMemcpy2DAsync((char *)dptr + (size_t)row0 * ld_dev * es, (size_t)ld_dev * es, X,
+                                  (size_t)ldx * es, (size_t)d * es, (size_t)N, hipMemcpyHostToDevice, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return RR_OK;
+}
+
+int rr_rff_transform_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                         const double *lenscale, int n_ls, void *dPhi, int out_dtype, int64_t ldphi) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "rr_rff_transform_dev: not an RFF basis");
+    RR_REQUIRE(dtype_ok(x_dtype) && dtype_ok(out_dtype), "rr_rff_transform_dev: bad dtype");
+    RR_REQUIRE(N >= 0 && ldphi >= 2 * (int64_t)b->n, "rr_rff_transform_dev: bad shape");
+    RR_REQUIRE(ldx >= b->dpad, "rr_rff_transform_dev: device X needs ldx >= rr_rff_padded_dim() = %d "
+               "with zero pad columns (got ldx=%lld); use rr_upload_matrix", b->dpad, (long long)ldx);
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(dX != nullptr && dPhi != nullptr, "rr_rff_transform_dev: null buffer");
+    RR_CHECK_HIP(hipSetDevice(b->ctx->device));
+    return transform_dev_impl(b, dX, x_dtype, N, ldx, dPhi, out_dtype, ldphi);
+}
+
+// Host-buffer transform: stream X up / Phi down in row chunks sized to a fixed device budget.
+int rr_rff_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx,
+                     const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "rr_rff_transform: not an RFF basis");
+    RR_REQUIRE(dtype_ok(x_dtype) && dtype_ok(out_dtype), "rr_rff_transform: bad dtype");
+    RR_REQUIRE(N >= 0 && ldx >= b->d && ldphi >= 2 * (int64_t)b->n, "rr_rff_transform: bad shape");
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(X != nullptr && Phi != nullptr, "rr_rff_transform: null buffer");
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t os = dtype_size(out_dtype);
+    const int64_t F = 2 * (int64_t)b->n;
+    RowStage st;
+    rc = stage_alloc(b, x_dtype, N, (size_t)F * os, &st);
+    if (rc != RR_OK) return rc;
+    void *dP = nullptr;
+    hipError_t e = hipMalloc(&dP, (size_t)st.chunk * F * os);
+    if (e != hipSuccess) {
+        (void)hipFree(st.dX);
+        rr_set_error("rr_rff_transform: device allocation failed");
+        return RR_ERR_OOM;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += st.chunk) {
+        const int64_t m = (N - r0 < st.chunk) ? N - r0 : st.chunk;
+        e = stage_rows(b, st, X, x_dtype, r0, m, ldx);
+        if (e == hipSuccess) {
+            rc = transform_dev_impl(b, st.dX, x_dtype, m, b->dpad, dP, out_dtype, F);
+            if (rc != RR_OK) break;
+            e = hipMemcpy2DAsync((char *)Phi + (size_t)r0 * ldphi * os, (size_t)ldphi * os, dP,
+                                 (size_t)F * os, (size_t)F * os, (size_t)m, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_rff_transform: copy/launch failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(st.dX);
+    (void)hipFree(dP);
+    return rc;
+}
+
+int rr_rff_grad(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                int n_ls, void *dPhi, int out_dtype) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "rr_rff_grad: not an RFF basis");
+    RR_REQUIRE(dtype_ok(x_dtype) && dtype_ok(out_dtype), "rr_rff_grad: bad dtype");
+    RR_REQUIRE(N >= 0 && ldx >= b->d, "rr_rff_grad: bad shape");
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(X != nullptr && dPhi != nullptr, "rr_rff_grad: null buffer");
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int nout = (n_ls == 1) ? 1 : b->d;  // iso: dimension 0 only (reference quirk)
+    const size_t os = dtype_size(out_dtype);
+    const size_t out_row = (size_t)2 * b->n * nout;
+    RowStage st;
+    rc = stage_alloc(b, x_dtype, N, out_row * os, &st);
+    if (rc != RR_OK) return rc;
+    void *dO = nullptr;
+    hipError_t e = hipMalloc(&dO, (size_t)st.chunk * out_row * os);
+    if (e != hipSuccess) {
+        (void)hipFree(st.dX);
+        rr_set_error("rr_rff_grad: device allocation failed");
+        return RR_ERR_OOM;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += st.chunk) {
+        const int64_t m = (N - r0 < st.chunk) ? N - r0 : st.chunk;
+        e = stage_rows(b, st, X, x_dtype, r0, m, ldx);
+        if (e == hipSuccess) {
+            rc = grad_dev_impl(b, st.dX, x_dtype, m, b->dpad, dO, out_dtype, nout);
+            if (rc != RR_OK) break;
+            e = hipMemcpyAsync((char *)dPhi + (size_t)r0 * out_row * os, dO, (size_t)m * out_row * os,
+                               hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_rff_grad: copy/launch failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(st.dX);
+    (void)hipFree(dO);
+    return rc;
+}
+
+int rr_rff_gram_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, int64_t N, int64_t ldx,
+                    const double *lenscale, int n_ls, double *dG, double *db, double *dyty) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "rr_rff_gram_dev: not an RFF basis");
+    RR_REQUIRE(dtype_ok(x_dtype), "rr_rff_gram_dev: bad dtype");
+    RR_REQUIRE(N >= 0, "rr_rff_gram_dev: bad shape");
+    RR_REQUIRE(ldx >= b->dpad, "rr_rff_gram_dev: device X needs ldx >= rr_rff_padded_dim() = %d with zero "
+               "pad columns (got ldx=%lld); use rr_upload_matrix", b->dpad, (long long)ldx);
+    RR_REQUIRE(dG != nullptr, "rr_rff_gram_dev: null G");
+    RR_REQUIRE((dy == nullptr) == (db == nullptr) && (dy == nullptr) == (dyty == nullptr),
+               "rr_rff_gram_dev: y, b and yty must be given together");
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(dX != nullptr, "rr_rff_gram_dev: null X");
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    if (b->compute != RR_F32) {
+        rr_set_error("rr_rff_gram_dev: f64 Gram kernel not built yet");
+        return RR_ERR_UNSUPPORTED;
+    }
+    rc = (x_dtype == RR_F32) ? launch_gram_f32<float>(b, dX, dy, N, ldx, dG, db)
+                             : launch_gram_f32<double>(b, dX, dy, N, ldx, dG, db);
+    if (rc != RR_OK) return rc;
+    if (dy) {
+        int blocks = (int)((N + 255) / 256);
+        if (blocks > c->num_cu * 8) blocks = c->num_cu * 8;
+        if (x_dtype == RR_F32)
+            hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(blocks), dim3(256), 0, c->stream, (const float *)dy, N, dyty);
+        else
+            hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(blocks), dim3(256), 0, c->stream, (const double *)dy, N, dyty);
+        RR_CHECK_HIP(hipGetLastError());
+    }
+    return RR_OK;
+}
+
+int rr_symmetrize_dev(rr_ctx *c, double *dG, int64_t F) {
+    RR_REQUIRE(c != nullptr && dG != nullptr && F >= 0, "rr_symmetrize_dev: bad argument");
+    if (F == 0) return RR_OK;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const unsigned t = (unsigned)((F + 31) / 32);
+    hipLaunchKernelGGL(rr_symmetrize_kernel, dim3(t, t), dim3(256), 0, c->stream, dG, F);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_rff_gram(rr_basis *b, const void *X, const void *y, int x_dtype, int64_t N, int64_t ldx,
+                const double *lenscale, int n_ls, double *G, double *bvec, double *yty) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "rr_rff_gram: not an RFF basis");
+    RR_REQUIRE(dtype_ok(x_dtype), "rr_rff_gram: bad dtype");
+    RR_REQUIRE(N >= 0 && ldx >= b->d && G != nullptr, "rr_rff_gram: bad argument");
+    RR_REQUIRE((y == nullptr) == (bvec == nullptr) && (y == nullptr) == (yty == nullptr),
+               "rr_rff_gram: y, b and yty must be given together");
+    RR_REQUIRE(N == 0 || X != nullptr, "rr_rff_gram: null X");
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t xs = dtype_size(x_dtype);
+    const int64_t F = 2 * (int64_t)b->n;
+    double *dG = nullptr, *db = nullptr;
+    void *dy = nullptr;
+    RowStage st;
+    hipError_t e = hipMalloc((void **)&dG, (size_t)F * F * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)(F + 1) * sizeof(double));
+    if (e != hipSuccess) {
+        rr_set_error("rr_rff_gram: device allocation failed: %s", hipGetErrorString(e));
+        rc = RR_ERR_OOM;
+    }
+    if (rc == RR_OK) rc = stage_alloc(b, x_dtype, N > 0 ? N : 1, xs, &st);
+    if (rc == RR_OK && hipMalloc(&dy, (size_t)st.chunk * xs) != hipSuccess) {
+        rr_set_error("rr_rff_gram: device allocation failed");
+        rc = RR_ERR_OOM;
+    }
+    if (rc == RR_OK) {
+        e = hipMemsetAsync(dG, 0, (size_t)F * F * sizeof(double), c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)(F + 1) * sizeof(double), c->stream);
+        if (e != hipSuccess) rc = RR_ERR_HIP;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += st.chunk) {
+        const int64_t m = (N - r0 < st.chunk) ? N - r0 : st.chunk;
+        e = stage_rows(b, st, X, x_dtype, r0, m, ldx);
+        if (e == hipSuccess && y)
+            e = hipMemcpyAsync(dy, (const char *)y + (size_t)r0 * xs, (size_t)m * xs, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_rff_gram: upload failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+            break;
+        }
+        rc = rr_rff_gram_dev(b, st.dX, y ? dy : nullptr, x_dtype, m, b->dpad, lenscale, n_ls, dG,
+                             y ? db : nullptr, y ? db + F : nullptr);
+        if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            rr_set_error("rr_rff_gram: kernel failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    if (rc == RR_OK) rc = rr_symmetrize_dev(c, dG, F);
+    if (rc == RR_OK) {
+        e = hipMemcpyAsync(G, dG, (size_t)F * F * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && y) {
+            e = hipMemcpyAsync(bvec, db, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(yty, db + F, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_rff_gram: download failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (dG) (void)hipFree(dG);
+    if (db) (void)hipFree(db);
+    if (st.dX) (void)hipFree(st.dX);
+    if (dy) (void)hipFree(dy);
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+"""
+GPU parity of the random Fourier feature path (Phi, dPhi, fused Gram) through the C ABI,
+against (a) the golden vectors produced by the reference and (b) the NumPy oracle on seeded
+inputs.  Tolerances follow BASELINE.json: 1e-3 relative for f32 arithmetic, 1e-5 for f64;
+Phi crosses zero so "relative" is normwise: max|err| <= tol * max|ref|.
+"""
+import numpy as np
+import pytest
+
+import revrand_oracle as orc
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f32": 1e-3, "f64": 1e-5}
+CLASSES = ["RandomRBF", "RandomLaplace", "RandomCauchy", "RandomMatern32", "RandomMatern52", "OrthogonalRBF"]
+
+
+def _bs():
+    import revrand_amd.basis_functions as bs
+    return bs
+
+
+def _make(cname, d, n, seed, ard, dtype):
+    from revrand_amd.btypes import Parameter, Positive
+    cls = getattr(_bs(), cname)
+    if ard:
+        return cls(nbases=n, Xdim=d, random_state=seed, dtype=dtype,
+                   lenscale=Parameter(np.ones(d), Positive()))
+    return cls(nbases=n, Xdim=d, random_state=seed, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("cname", CLASSES)
+def test_golden_transform_grad(golden, cname, dtype):
+    """Same seeds as the reference -> same W (host sampling) -> Phi / dPhi within tolerance."""
+    g = golden("rff")
+    for d in ((1, 5, 8) if cname == "RandomRBF" else (5,)):
+        X = g["X_d%d" % d]
+        seed = int(g["%s_d%d_seed" % (cname, d)])
+        for tag, ls in [("iso0.7", 0.7), ("iso2.0", 2.0), ("ard", np.linspace(0.5, 2.0, d))]:
+            b = _make(cname, d, 12, seed, tag == "ard", dtype)
+            assert np.array_equal(b.W, g["%s_d%d_W" % (cname, d)])  # bit-exact host sampling
+            P = b.transform(X, ls)
+            dP = b.grad(X, ls)
+            Pref = g["%s_d%d_%s_Phi" % (cname, d, tag)]
+            dPref = g["%s_d%d_%s_dPhi" % (cname, d, tag)]
+            assert P.dtype == np.float64 and P.shape == Pref.shape  # always float64, cos|sin
+            assert dP.shape == dPref.shape
+            assert normwise(P, Pref) < TOL[dtype], (cname, d, tag)
+            assert normwise(dP, dPref) < TOL[dtype], (cname, d, tag)
+
+
+def test_float32_input_gives_float64_output(golden):
+    g = golden("rff")
+    X32 = np.random.RandomState(0).randn(24, 5).astype(np.float32)
+    b = _make("RandomRBF", 5, 12, 16, False, "f32")
+    P = b.transform(X32, 1.3)
+    assert P.dtype == np.float64
+    assert normwise(P, g["RandomRBF_d5_f32in_iso1.3_Phi"]) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("shape", [(1, 3, 4), (7, 8, 256), (513, 32, 130), (2000, 21, 300), (64, 64, 64),
+                                   (300, 100, 40)])
+def test_transform_shapes_vs_oracle(shape, dtype):
+    """Ragged N, n not a multiple of 128/256, d not a power of two, d up to 128."""
+    N, d, n = shape
+    rs = np.random.RandomState(N + d + n)
+    X = rs.randn(N, d)
+    b = _make("RandomRBF", d, n, 5, True, dtype)
+    ls = np.linspace(0.7, 1.9, d)
+    assert normwise(b.transform(X, ls), orc.rff_transform(X, b.W, ls)) < TOL[dtype]
+    # non-contiguous row view and float32 input take the same path
+    Xw = np.zeros((N, d + 3), dtype=np.float32)
+    Xw[:, :d] = X
+    assert normwise(b.transform(Xw[:, :d], ls), orc.rff_transform(Xw[:, :d], b.W, ls)) < TOL["f32"]
+
+
+def test_transform_empty_and_errors():
+    b = _make("RandomRBF", 4, 8, 0, False, "f32")
+    assert b.transform(np.zeros((0, 4))).shape == (0, 16)
+    with pytest.raises(ValueError, match="Dimensions of data inconsistent!"):
+        b.transform(np.zeros((3, 5)))
+    with pytest.raises(ValueError, match="Dimension of input parameter is inconsistent!"):
+        b.transform(np.zeros((3, 4)), np.ones(3))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_grad_ard_large(dtype):
+    N, d, n = 130, 9, 70
+    rs = np.random.RandomState(3)
+    X = rs.randn(N, d)
+    b = _make("RandomMatern52", d, n, 5, True, dtype)
+    ls = np.linspace(0.7, 1.9, d)
+    dP = b.grad(X, ls)
+    assert dP.shape == (N, 2 * n, d)
+    assert normwise(dP, orc.rff_grad(X, b.W, ls)) < TOL[dtype]
+    # iso quirk: dimension 0 only
+    bi = _make("RandomMatern52", d, n, 5, False, dtype)
+    assert normwise(bi.grad(X, 1.4), orc.rff_grad(X, bi.W, 1.4)) < TOL[dtype]
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4), (500, 4, 16), (4099, 8, 128), (3000, 32, 200), (1500, 21, 260),
+                                   (70000, 8, 128), (1000, 64, 128)])
+def test_gram_vs_oracle(shape):
+    """Fused Phi -> (Phi^T Phi, Phi^T y, yty): f32 MFMA, f64 across K-splits."""
+    N, d, n = shape
+    rs = np.random.RandomState(N + n)
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+    b = _make("RandomRBF", d, n, 2, True, "f32")
+    ls = np.linspace(0.8, 1.6, d)
+    G, bv, yty = b.gram(X, y, ls)
+    Gr, br, ytyr = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, ls)
+    assert G.shape == (2 * n, 2 * n)
+    assert np.array_equal(G, G.T)  # exactly symmetric, like the reference's syrk
+    assert normwise(G, Gr) < 1e-3
+    assert normwise(bv, br) < 1e-3
+    assert abs(yty - ytyr) < 1e-5 * ytyr
+    # tighter, informational bound actually achieved by f32 MFMA + f64 flush
+    assert normwise(G, Gr) < 2e-5, normwise(G, Gr)
+    # G only (no y)
+    G2, b2, t2 = b.gram(X, None, ls)
+    assert b2 is None and t2 is None and normwise(G2, Gr) < 1e-3
+
+
+def test_gram_posterior_weights():
+    """1e-3 on posterior weights (BASELINE north star) through the host Cholesky."""
+    N, d, n = 20000, 8, 128
+    rs = np.random.RandomState(11)
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+    b = _make("RandomRBF", d, n, 2, False, "f32")
+    G, bv, _ = b.gram(X, y, 1.1)
+    Gr, br, _ = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, 1.1)
+    m, C, _ = orc.slm_posterior_from_stats(G, bv, 0.5, np.full(2 * n, 1.0))
+    mr, Cr, _ = orc.slm_posterior_from_stats(Gr, br, 0.5, np.full(2 * n, 1.0))
+    assert normwise(m, mr) < 1e-3 and normwise(C, Cr) < 1e-3
+
+
+def test_gram_linearity_and_sharding():
+    """Size-independent properties: G(X1 ++ X2) = G(X1) + G(X2); device accumulation over shards."""
+    from revrand_amd import _hip
+    N, d, n = 6000, 16, 128
+    rs = np.random.RandomState(5)
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.randn(N).astype(np.float32)
+    b = _make("RandomRBF", d, n, 2, False, "f32")
+    G, bv, yty = b.gram(X, y, 1.0)
+    Ga, ba, ta = b.gram(X[:2500], y[:2500], 1.0)
+    Gb, bb, tb = b.gram(X[2500:], y[2500:], 1.0)
+    assert normwise(Ga + Gb, G) < 1e-6 and normwise(ba + bb, bv) < 1e-6
+    assert abs(ta + tb - yty) < 1e-9 * yty
+    # trace identity: sum_j cos^2 + sin^2 = 1  =>  trace(G) = N exactly (up to rounding)
+    assert abs(np.trace(G) - N) < 1e-4 * N
+    # device-resident accumulation across two shards equals the one-shot result
+    h = b._handle()
+    dev = h.dev
+    F = 2 * n
+    dG = dev.zeros(F * F * 8)
+    db = dev.zeros((F + 1) * 8)
+    for sl in (slice(0, 2500), slice(2500, N)):
+        dX = h.upload(X[sl])
+        dy = dev.upload_vector(y[sl])
+        h.gram_dev(dX, dy, 1.0, dG, db, _hip.ctypes.c_void_p(db.ptr.value + F * 8))
+        dev.sync()
+    h.symmetrize_dev(dG)
+    G2 = dev.download(dG, (F, F), np.float64)
+    b2 = dev.download(db, (F + 1,), np.float64)
+    assert normwise(G2, G) < 1e-6 and normwise(b2[:F], bv) < 1e-6 and abs(b2[F] - yty) < 1e-9 * yty

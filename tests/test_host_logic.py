@@ -1,0 +1,150 @@
+"""CPU tests of the host-side mirror: parameter types, W sampling against the golden vectors,
+concatenation bookkeeping, optimiser front-ends.  Modelled on the reference's
+tests/test_bases.py, test_btypes.py and test_optimize.py (no device needed)."""
+import pickle
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+from scipy.stats import gamma, norm
+
+import revrand_amd.basis_functions as bs
+from revrand_amd.btypes import Bound, Parameter, Positive
+from revrand_amd.linalg import solve_posdef
+from revrand_amd.optimize import logtrick_minimizer, structured_minimizer
+from revrand_amd.utils import flatten_values, unflatten
+
+CLASSES = ["RandomRBF", "RandomLaplace", "RandomCauchy", "RandomMatern32", "RandomMatern52", "OrthogonalRBF"]
+
+
+@pytest.mark.parametrize("cname", CLASSES)
+def test_weight_sampling_matches_reference(golden, cname):
+    g = golden("weights")
+    for (d, n, seed) in [(3, 4, 7), (8, 256, 1)]:
+        b = getattr(bs, cname)(nbases=n, Xdim=d, random_state=seed)
+        assert np.array_equal(b.W, g["%s_d%d_n%d_s%d" % (cname, d, n, seed)])
+
+
+def test_bounds_and_parameters():
+    assert Bound(1, 2).check(1.5) and not Bound(1, 2).check(3)
+    assert Bound(1, 2).clip(3) == 2
+    with pytest.raises(ValueError):
+        Bound(42, 10)
+    assert Positive().lower == 1e-14 and repr(Positive()) == "Positive(upper=None)"
+    p = Parameter()
+    assert p.value == [] and not p.has_value
+    p = Parameter(1.2, Bound(1, 2))
+    assert p.shape == () and p.rvs() == 1.2 and not p.is_random and p.is_scalar
+    p = Parameter(gamma(a=1, scale=1), Positive(), shape=(3,))
+    assert np.all(p.value == np.ones(3)) and p.rvs(0).shape == (3,) and p.is_random
+    with pytest.raises(ValueError):
+        Parameter(-1., Positive())
+    assert pickle.loads(pickle.dumps(Positive(3.))) == Positive(3.)
+
+
+def test_concat_params_and_regularizer():
+    d, D = 10, 20
+    base = bs.LinearBasis(onescol=True) + bs.RandomMatern52(nbases=D, Xdim=d, lenscale=Parameter(1., Positive()))
+    assert np.isscalar(base.params.value)
+    base = bs.LinearBasis(onescol=True) + bs.RandomMatern52(nbases=D, Xdim=d,
+                                                            lenscale=Parameter(np.ones(d), Positive()))
+    assert len(base.params.value) == d
+    base += bs.RandomMatern52(nbases=D, Xdim=d, lenscale=Parameter(1., Positive()))
+    assert len(base.params) == 2
+    X = np.random.RandomState(0).randn(7, d)
+    diag, slices = base.regularizer_diagonal(X, 2.0, 3.0, 4.0)
+    assert slices == [slice(0, d + 1), slice(d + 1, d + 1 + 2 * D), slice(d + 1 + 2 * D, d + 1 + 4 * D)]
+    assert np.all(diag[:d + 1] == 2.0) and np.all(diag[-2 * D:] == 4.0)
+    assert base.get_dim(X) == d + 1 + 4 * D
+    # single basis
+    b = bs.LinearBasis(regularizer=Parameter(2, Positive()))
+    dg, sl = b.regularizer_diagonal(X)
+    assert np.all(dg == 2.0) and sl == slice(None) and len(dg) == d + 1
+    with pytest.raises(ValueError, match="scalar"):
+        bs.LinearBasis(regularizer=Parameter(np.ones(2), Positive()))
+    with pytest.raises(ValueError, match="bounded below"):
+        bs.LinearBasis(regularizer=Parameter(1., Bound(-1., None)))
+
+
+def test_linear_concat_transform_and_empty_grads():
+    X = np.random.RandomState(1).randn(9, 3)
+    base = bs.LinearBasis(onescol=False) + bs.LinearBasis(onescol=False)
+    assert np.allclose(base.transform(X), np.hstack((X, X)))
+    assert list(base.grad(X)) == []
+    assert sum([bs.LinearBasis(), bs.BiasBasis()]).get_dim(X) == 5
+    sl = bs.LinearBasis(onescol=False, apply_ind=[0]) + bs.LinearBasis(onescol=True, apply_ind=slice(1, 3))
+    assert np.allclose(sl.transform(X), np.hstack((X[:, [0]], np.ones((9, 1)), X[:, 1:3])))
+
+
+def test_lenscale_validation_messages():
+    with pytest.raises(ValueError, match="Parameter dimension doesn't agree"):
+        bs.RandomRBF(nbases=4, Xdim=3, lenscale=Parameter(np.ones(2), Positive()))
+    b = bs.RandomRBF(nbases=4, Xdim=3, random_state=0)
+    with pytest.raises(ValueError, match="Dimensions of data inconsistent!"):
+        b._check_dim(4, None)
+    with pytest.raises(ValueError, match="Dimension of input parameter is inconsistent!"):
+        b._check_dim(3, np.ones(3))
+    assert b._check_dim(3, None)[0] == 1.0
+    assert bs.count_args(b.transform) == 2 and bs.count_args(b.grad) == 2
+    assert "RandomRBF(nbases=4, Xdim=3" in repr(b)
+
+
+def test_basis_pickles_without_device_handle():
+    b = bs.RandomRBF(nbases=4, Xdim=3, random_state=0)
+    b.__dict__["_hip_handle"] = (0, object())
+    b2 = pickle.loads(pickle.dumps(b))
+    assert "_hip_handle" not in b2.__dict__ and np.array_equal(b2.W, b.W)
+
+
+def test_apply_grad_structures():
+    f = lambda g: g.sum()  # noqa: E731
+    assert bs.apply_grad(f, []) == []
+    assert bs.apply_grad(f, np.ones((3, 4))) == 12
+    assert bs.apply_grad(f, np.ones((3, 4, 5))).shape == (5,)
+    out = bs.apply_grad(f, iter([np.ones((2, 2)), np.ones((2, 2, 3))]))
+    assert out[0] == 4 and out[1].shape == (3,)
+    assert bs.apply_grad(f, [np.ones((2, 2))]) == 4
+    with pytest.raises(ValueError):
+        bs.apply_grad(f, np.ones((1, 1, 1, 1)))
+
+
+def test_flatten_roundtrip():
+    nested = [1.5, [2.0, np.arange(3.)], [], np.ones((2, 2))]
+    shapes = [(), [(), (3,)], (0,), (2, 2)]
+    flat = flatten_values(nested)
+    assert flat.shape == (9,)
+    back = unflatten(flat, shapes)
+    assert back[0] == 1.5 and back[2] == [] and np.array_equal(back[1][1], np.arange(3.))
+    assert back[3].shape == (2, 2)
+
+
+def test_structured_logtrick_minimizer():
+    """Quadratic fit as in the reference's tests/test_optimize.py (tolerance 1e-3)."""
+    rs = np.random.RandomState(99)
+    x = np.linspace(-1, 1, 1000)
+    a, b, c = 3., 2., 1.
+    yv = a * x ** 2 + b * x + c + rs.randn(1000) * 1e-4
+    A = np.vstack((x ** 2, x, np.ones_like(x))).T
+
+    def obj(w, cc):
+        r = A[:, :2] @ w + cc - yv
+        return 0.5 * (r ** 2).sum(), [A[:, :2].T @ r, r.sum()]
+
+    nmin = structured_minimizer(logtrick_minimizer(minimize))
+    res = nmin(obj, [Parameter(np.array([1., 1.]), Positive()), Parameter(0.5, Bound(0.1, None))],
+               method="L-BFGS-B", jac=True)
+    w, cc = res.x
+    assert np.allclose(w, [a, b], atol=1e-3) and abs(cc - c) < 1e-3
+    # random starts pick the best candidate and keep the structure
+    res = nmin(obj, [Parameter(gamma(2.), Positive(), shape=(2,)), Parameter(norm(1., .1), Bound())],
+               method="L-BFGS-B", jac=True, nstarts=20, random_state=np.random.RandomState(1))
+    assert np.allclose(res.x[0], [a, b], atol=1e-3) and np.isscalar(res.x[1])
+
+
+def test_solve_posdef(golden):
+    g = golden("solve_posdef")
+    for tag in ("pd", "npd"):
+        X, ld = solve_posdef(g[tag + "_A"], np.eye(5))
+        assert np.abs(X - g[tag + "_X"]).max() < 1e-9 * np.abs(g[tag + "_X"]).max()
+        if np.isfinite(g[tag + "_logdet"]):
+            assert abs(ld - g[tag + "_logdet"]) < 1e-9 * abs(ld)
