@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000, help="global N")
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--nbases", type=int, default=2048)
-    ap.add_argument("--cpu-sample", type=int, default=40000)
+    ap.add_argument("--cpu-sample", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -199,7 +199,7 @@ def main():
                          "kernel_ms_per_step": gram_ms, "launches_per_step": launches,
                          "avg_launch_ms": gram_ms / max(launches, 1),
                          "flops_per_row": gram_flops_row, "rows_per_step": my_rows,
-                         "other_kernels_ms_per_step": {"rr_rff_phase_kernel": phase_ms},
+                         "other_kernels_ms_per_step": {"rr_rff_features_kernel": phase_ms},
                          "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
                          / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }

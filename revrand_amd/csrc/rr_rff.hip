@@ -115,190 +115,195 @@ rr_rff_grad_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *_
 // ---------------------------------------------------------------------------------------
 // Phi^T Phi / Phi^T y in two kernels per row chunk.
 //
-//  (A) rr_rff_phase_kernel:  Z[r][f] = frac(x_r . Ws[:, f])  in [-0.5, 0.5] revolutions, f32,
-//      (rows, npad) row-major in HBM scratch -- 4n bytes per row, written once.  It also takes
-//      cos/sin of its own phases to accumulate b = Phi^T y (one pass over every (row, f)).
-//  (B) rr_rff_gram_phase_kernel: one workgroup (8 waves) owns the 256x256 block of G spanned
-//      by frequency blocks (fa <= fb) of 128 frequencies -- local columns
-//      [cos_a | sin_a] x [cos_b | sin_b] -- for one K-split of rows.  Per k-block of 32 rows it
-//      loads its 2 x 128 phases per row (coalesced float4, prefetched one k-block ahead into
-//      registers), takes v_sin/v_cos, writes the [32][512] Phi tile to LDS (double-buffered, one
-//      barrier per k-block) and accumulates with v_mfma_f32_32x32x2_f32; operands come straight
-//      from LDS with conflict-free ds_read_b32 (lane -> column, lane>>5 -> row of the 2-row
-//      k-step, which IS the 32x32x2 A/B operand layout).  f32 accumulation inside a K-split,
-//      f64 atomics across K-splits into the upper triangle of G.
+//  (A) rr_rff_features_kernel:  P[r][f] = cos(2 pi z)/sqrt(n), P[r][n+f] = sin(2 pi z)/sqrt(n),
+//      z = x_r . Ws[:, f]; f32, (rows rounded up to 32, Fp = 2n rounded up to 256) row-major HBM
+//      scratch with zero pad rows/columns.  The same pass accumulates b = Phi^T y.
+//  (B) rr_syrk_f32_kernel: G(upper) += P^T P for any such zero-padded f32 feature matrix.  One
+//      workgroup (8 waves) owns a 256x256 block of G (column blocks ta <= tb) for one K-split of
+//      rows.  Per k-block of 32 rows the [32][256 | 256] tile arrives by LDS-DMA
+//      (global_load_lds_dwordx4, one 1 KiB row-segment per wave-instruction, no VGPRs, no
+//      VALU), double-buffered with one barrier per k-block; waves accumulate 128x64 sub-blocks
+//      with v_mfma_f32_32x32x2_f32, operands straight from LDS by conflict-free ds_read_b32
+//      (lane -> column, lane>>5 -> row of the 2-row k-step == the 32x32x2 A/B operand layout),
+//      prefetched one k-step ahead.  f32 accumulation inside a K-split, f64 atomics across
+//      K-splits into the upper triangle of G.
 //
-// Phi itself never exists in HBM; the projection is done once per row (not once per tile), so
-// the Gram kernel's MFMA pipe does Gram work only, independent of Xdim.
+// Why two kernels: on gfx950 the f32-input MFMA runs at the f32 VALU rate and (measured:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0, produce/consume times purely additive) does not overlap with
+// VALU work of either wave on the SIMD, so every VALU instruction in the Gram kernel is lost
+// MFMA time.  The projection and the transcendentals therefore run once per row in (A) instead
+// of once per (row, tile) inside (B), and (B)'s instruction stream is DMA + ds_read + MFMA only.
 // ---------------------------------------------------------------------------------------
-constexpr int GR_TF = 128;   // frequencies per tile side
+constexpr int GR_TC = 256;   // columns per tile side
 constexpr int GR_KB = 32;    // rows per k-block
-constexpr int GR_LD = 512;   // LDS tile row length (floats)
+constexpr int GR_LD = 512;   // LDS tile row length (floats): [A side 256 | B side 256]
 constexpr int GR_THREADS = 512;
-#ifndef RR_GRAM_NO_PRODUCE
-#define RR_GRAM_NO_PRODUCE 0  // build-time ablation: skip the in-loop cos/sin production
-#endif
-
-typedef float float4v __attribute__((ext_vector_type(4)));
 
 template <int DMAX, bool HAS_Y, typename TX>
 __global__ void __launch_bounds__(256)
-rr_rff_phase_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t ldx,
-                    const float *__restrict__ Ws, int n, int npad, float *__restrict__ Z,
-                    double *__restrict__ bvec, float scale, int rows_per_block) {
+rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad,
+                       int64_t ldx, const float *__restrict__ Ws, int n, int npad, float *__restrict__ P,
+                       int64_t ldp, double *__restrict__ bvec, float scale, int rows_per_block) {
     const int f = blockIdx.x * 256 + threadIdx.x;
-    const bool fpad = f < npad;
+    const bool fvalid = f < n;
     float w[DMAX];
-    load_w<DMAX, float>(w, Ws, npad, fpad ? f : 0);
+    load_w<DMAX, float>(w, Ws, npad, f < npad ? f : 0);
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
-    if (r1 > N) r1 = N;
+    if (r1 > Npad) r1 = Npad;
     float bc = 0.f, bs = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
-        const float t = project_row<DMAX, false, TX, float>(X + r * ldx, DMAX, w);
-        const float fr = t - __builtin_rintf(t);
-        if (fpad) Z[r * npad + f] = fr;
-        if (HAS_Y) {
-            const float yv = (float)y[r];
-            bc = fmaf(__builtin_amdgcn_cosf(fr), yv, bc);
-            bs = fmaf(__builtin_amdgcn_sinf(fr), yv, bs);
-        }
-    }
-    if (HAS_Y && f < n) {
-        unsafeAtomicAdd(&bvec[f], (double)(bc * scale));
-        unsafeAtomicAdd(&bvec[n + f], (double)(bs * scale));
-    }
-}
-
-struct GramArgs {
-    const float *Z;  // (rows, npad) phases in revolutions
-    int64_t N;       // rows in this chunk
-    int n, npad, nfb;  // nfb = npad / 128 frequency blocks
-    int ntiles;        // nfb (nfb + 1) / 2
-    int64_t rows_per_split;
-    double *G;
-    float scale;
-};
-
-// 32 rows x (128 + 128) phases = 2048 float4 per k-block, 4 per thread: wave w takes rows
-// w, w+8, w+16, w+24; lanes 0-31 the A-side frequencies (512 contiguous bytes), lanes 32-63 the B side.
-struct PhaseStage {
-    float4v v[4];
-    __device__ __forceinline__ void load(const GramArgs &p, int64_t kb0, int64_t row_end, int wave, int fcol) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            int64_t r = kb0 + wave + 8 * k;
-            if (r >= row_end) r = row_end - 1;  // clamp: loads stay in bounds, zeroed in sincos_store
-            v[k] = *(const float4v *)(p.Z + r * p.npad + fcol);
-        }
-    }
-    __device__ __forceinline__ void sincos_store(float *__restrict__ buf, int64_t kb0, int64_t row_end,
-                                                 int wave, int lcol, float scale) const {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lr = wave + 8 * k;
-            const float sc = (kb0 + lr < row_end) ? scale : 0.f;  // wave-uniform
-            float4v c, s;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                c[e] = __builtin_amdgcn_cosf(v[k][e]) * sc;
-                s[e] = __builtin_amdgcn_sinf(v[k][e]) * sc;
+        float c = 0.f, s = 0.f;
+        if (r < N) {  // uniform
+            const float t = project_row<DMAX, false, TX, float>(X + r * ldx, DMAX, w);
+            sincos_rev(t, s, c);
+            c *= scale;
+            s *= scale;
+            if (HAS_Y) {
+                const float yv = (float)y[r];
+                bc = fmaf(c, yv, bc);
+                bs = fmaf(s, yv, bs);
             }
-            *(float4v *)(buf + lr * GR_LD + lcol) = c;
-            *(float4v *)(buf + lr * GR_LD + lcol + GR_TF) = s;
+        }
+        if (fvalid) {
+            P[r * ldp + f] = c;
+            P[r * ldp + n + f] = s;
         }
     }
-};
-
-// One sixteenth of sincos_store (row group K, element E), meant to be dropped between the
-// MFMA groups of gram_consume so the transcendentals issue while the matrix pipe is busy.
-template <int K, int E>
-__device__ __forceinline__ void sincos_piece(const PhaseStage &st, float4v &c, float4v &s, float *__restrict__ buf,
-                                             int64_t kb0, int64_t row_end, int wave, int lcol, float scale) {
-    const int lr = wave + 8 * K;
-    const float sc = (kb0 + lr < row_end) ? scale : 0.f;  // wave-uniform
-    c[E] = __builtin_amdgcn_cosf(st.v[K][E]) * sc;
-    s[E] = __builtin_amdgcn_sinf(st.v[K][E]) * sc;
-    if (E == 3) {
-        *(float4v *)(buf + lr * GR_LD + lcol) = c;
-        *(float4v *)(buf + lr * GR_LD + lcol + GR_TF) = s;
+    if (HAS_Y && fvalid) {
+        unsafeAtomicAdd(&bvec[f], (double)bc);
+        unsafeAtomicAdd(&bvec[n + f], (double)bs);
     }
 }
 
-// MFMA operands of one 2-row k-step: a[i] = Phi[row][A col block i], b[j] = Phi[row][B col block j]
-struct KOps {
-    float a[4], b[2];
-    __device__ __forceinline__ void load(const float *__restrict__ buf, int t, int aoff, int boff) {
-        const float *row = buf + (2 * t) * GR_LD;
+// zero the pad columns [F, Fp) of a feature matrix (the feature kernels only write [0, F))
+__global__ void __launch_bounds__(256) rr_zero_padcols_kernel(float *P, int64_t rows, int64_t ldp, int F) {
+    const int w = (int)ldp - F;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > 0 && i < rows * w) P[(i / w) * ldp + F + (i % w)] = 0.f;
+}
+
+struct SyrkArgs {
+    const float *P;  // (rows, ldp) f32 features, zero padded; rows % 32 == 0, ldp % 256 == 0
+    int64_t rows, ldp;
+    int F;       // valid columns
+    int nb;      // ldp / 256 column blocks
+    int ntiles;  // nb (nb + 1) / 2
+    int64_t rows_per_split;  // multiple of 32
+    double *G;   // (F, F) f64, upper triangle accumulated
+};
+
+typedef __attribute__((address_space(1))) const void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// One k-block tile: 32 rows x (256 + 256) floats = 64 row-segments of 1 KiB; wave w moves rows
+// 4w..4w+3 (both sides) with 8 LDS-DMA instructions, lane l carrying bytes [16 l, 16 l + 16).
+__device__ __forceinline__ void syrk_dma_tile(const SyrkArgs &p, float *buf, int64_t kb0, int wave, int lane,
+                                              int ca, int cb) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = row[aoff + i * 32];
+    for (int k = 0; k < 4; ++k) {
+        const int lr = 4 * wave + k;
+        const float *src = p.P + (kb0 + lr) * p.ldp + 4 * lane;
+        float *dst = buf + lr * GR_LD;  // wave-uniform
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + ca), (lptr_t)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + cb), (lptr_t)(dst + GR_TC), 16, 0, 0);
+    }
+}
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+// ds_read2st64_b32: two dwords at byte addresses addr + O0*256 and addr + O1*256.  Written as
+// inline asm because hipcc prefers to pair neighbouring columns into ds_read2_b32, whose 8-bit
+// dword offsets cannot span rows, and then pays a v_add per row -- VALU time is MFMA time on
+// this chip.  The compiler does not count asm loads: lds_wait() + sched_barrier precede every use.
+template <int O0, int O1>
+__device__ __forceinline__ float2v lds_read2st64(unsigned addr) {
+    float2v r;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "i"(O0), "i"(O1));
+    return r;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// MFMA operands of k-steps 2P and 2P+1 (rows 4P + h and 4P + 2 + h, h = lane >> 5 folded into the
+// base addresses): a[i] = {A col block i of step 2P, of step 2P+1}, b[j] likewise.
+struct KOps2 {
+    float2v a[4], b[2];
+    template <int P>
+    __device__ __forceinline__ void load(const unsigned (&abase)[4], const unsigned (&bbase)[2]) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = row[boff + j * 32];
+        for (int i = 0; i < 4; ++i) a[i] = lds_read2st64<32 * P, 32 * P + 16>(abase[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = lds_read2st64<32 * P, 32 * P + 16>(bbase[j]);
     }
 };
 
-__device__ __forceinline__ void gram_mfma8(const KOps &o, floatx16 (&acc)[4][2]) {
+// MFMAs [FIRST, LAST) of the 16 of a k-step pair, in (s, i, j) order s*8 + i*2 + j
+template <int FIRST, int LAST>
+__device__ __forceinline__ void gram_mfma(const KOps2 &o, floatx16 (&acc)[4][2]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[i], o.b[j], acc[i][j], 0, 0, 0);
+    for (int q = FIRST; q < LAST; ++q)
+        acc[(q >> 1) & 3][q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(q >> 1) & 3][q >> 3], o.b[q & 1][q >> 3],
+                                                                        acc[(q >> 1) & 3][q & 1], 0, 0, 0);
 }
 
-// 16 k-steps (8 MFMAs each) over the current Phi tile.  The operands of k-step T+1 are read
-// from LDS BEFORE the MFMAs of k-step T are issued (an MFMA blocks the in-order stream until the
-// matrix pipe takes it, so a read placed after them would expose its latency); when PROD, one
-// sixteenth of the next tile's cos/sin is computed and stored per k-step in the MFMA shadow.
-template <bool PROD>
-__device__ __forceinline__ void gram_consume(const float *__restrict__ cur, floatx16 (&acc)[4][2],
-                                             int aoff, int boff, const PhaseStage &st, float *__restrict__ nxt,
-                                             int64_t kb1, int64_t row_end, int wave, int lcol, float scale) {
-    float4v c, s;
-    KOps o0, o1;
-    o0.load(cur, 0, aoff, boff);
-#define RR_STEP2(T)                                                                                 \
-    o1.load(cur, (T) + 1, aoff, boff);                                                              \
-    gram_mfma8(o0, acc);                                                                            \
-    if (PROD) sincos_piece<(T) / 4, (T) % 4>(st, c, s, nxt, kb1, row_end, wave, lcol, scale);       \
-    if ((T) + 2 < GR_KB / 2) o0.load(cur, (T) + 2, aoff, boff);                                     \
-    gram_mfma8(o1, acc);                                                                            \
-    if (PROD) sincos_piece<((T) + 1) / 4, ((T) + 1) % 4>(st, c, s, nxt, kb1, row_end, wave, lcol, scale);
-    RR_STEP2(0) RR_STEP2(2) RR_STEP2(4) RR_STEP2(6) RR_STEP2(8) RR_STEP2(10) RR_STEP2(12) RR_STEP2(14)
-#undef RR_STEP2
+// 16 k-steps (8 MFMAs each) over the current tile, operands double-buffered in registers, two
+// k-steps per buffer.  Pinned order per pair: [wait] [first MFMA of pair P] [LDS reads of pair
+// P+1] [other 15 MFMAs of P].  The wait for P's operands sits before P+1's reads are issued (so
+// it never waits for them), and the reads fly under 15 MFMAs (960 cycles).  If every read sat
+// just before its use, the two waves of a SIMD -- which interleave their MFMAs 1:1 and so stay
+// in lockstep -- would stall on LDS latency together.
+#define RR_PAIR(P, CUR, NXT)                                   \
+    lds_wait();                                                \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma<0, 1>(CUR, acc);                                 \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase); \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma<1, 16>(CUR, acc);                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+__device__ __forceinline__ void gram_consume(unsigned cur, floatx16 (&acc)[4][2], unsigned aoff, unsigned boff) {
+    unsigned abase[4], bbase[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) abase[i] = cur + aoff + i * 128;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bbase[j] = cur + boff + j * 128;
+    KOps2 o0, o1;
+    o0.load<0>(abase, bbase);
+    RR_PAIR(0, o0, o1) RR_PAIR(1, o1, o0) RR_PAIR(2, o0, o1) RR_PAIR(3, o1, o0)
+    RR_PAIR(4, o0, o1) RR_PAIR(5, o1, o0) RR_PAIR(6, o0, o1) RR_PAIR(7, o1, o0)
 }
+#undef RR_PAIR
 
 __global__ void __launch_bounds__(GR_THREADS, 2)
-rr_rff_gram_phase_kernel(const GramArgs p) {
-    __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB: two [32][512] Phi tiles
+rr_syrk_f32_kernel(const SyrkArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB: two [32][512] tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // tile (fa <= fb) and K-split of this workgroup
+    // tile (ta <= tb) and K-split of this workgroup
     int tdx = blockIdx.x % p.ntiles;
     const int ks = blockIdx.x / p.ntiles;
-    int fa = 0;
-    while (tdx >= p.nfb - fa) {
-        tdx -= p.nfb - fa;
-        ++fa;
+    int ta = 0;
+    while (tdx >= p.nb - ta) {
+        tdx -= p.nb - ta;
+        ++ta;
     }
-    const int fb = fa + tdx;
-    const bool diag = (fa == fb);
+    const int tb = ta + tdx;
+    const bool diag = (ta == tb);
+    const int ca = ta * GR_TC, cb = tb * GR_TC;
 
     const int64_t row_begin = (int64_t)ks * p.rows_per_split;
     int64_t row_end = row_begin + p.rows_per_split;
-    if (row_end > p.N) row_end = p.N;
-
-    // producer role: lanes 0-31 -> side A, 32-63 -> side B, 4 consecutive frequencies each
-    const int side = lane >> 5, f4 = lane & 31;
-    const int fcol = (side ? fb : fa) * GR_TF + 4 * f4;  // column of Z  (< npad)
-    const int lcol = side * 256 + 4 * f4;               // column of the LDS tile (cos; sin at +128)
+    if (row_end > p.rows) row_end = p.rows;
 
     // consumer role: wave (wr, wc) -> rows [wr*128, +128) of side A, cols [wc*64, +64) of side B
     const int wr = wave >> 2, wc_ = wave & 3;
-    const int aoff = (lane >> 5) * GR_LD + wr * 128 + (lane & 31);
-    const int boff = (lane >> 5) * GR_LD + 256 + wc_ * 64 + (lane & 31);
+    const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));          // bytes
+    const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));  // bytes
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     floatx16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -307,50 +312,37 @@ rr_rff_gram_phase_kernel(const GramArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int64_t nkb = (row_end - row_begin + GR_KB - 1) / GR_KB;
+    const int64_t nkb = (row_end - row_begin) / GR_KB;  // rows and splits are multiples of 32
     if (nkb > 0) {
-        PhaseStage st, pre;
-        st.load(p, row_begin, row_end, wave, fcol);
-        st.sincos_store(lds, row_begin, row_end, wave, lcol, p.scale);  // Phi(0) -> LDS
-        st.load(p, row_begin + GR_KB, row_end, wave, fcol);             // Z(1) (clamped if absent)
-        __syncthreads();
+        syrk_dma_tile(p, lds, row_begin, wave, lane, ca, cb);
+        __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
         for (int64_t kb = 0; kb < nkb; ++kb) {
-            const int cb = (int)(kb & 1);
-            const float *cur = lds + cb * (GR_KB * GR_LD);
-            float *nxt = lds + (cb ^ 1) * (GR_KB * GR_LD);
-            const int64_t kb1 = row_begin + (kb + 1) * GR_KB;
-            pre.load(p, kb1 + GR_KB, row_end, wave, fcol);  // Z(kb+2) -> regs, consumed next iteration
-            // Single consume site (the accumulators must not flow through divergent paths) that
-            // ALWAYS produces: in the last iteration it writes a tile nobody reads.
-            gram_consume<!RR_GRAM_NO_PRODUCE>(cur, acc, aoff, boff, st, nxt, kb1, row_end, wave, lcol, p.scale);
-            st = pre;
+            const int cbuf = (int)(kb & 1);
+            float *nxt = lds + (cbuf ^ 1) * (GR_KB * GR_LD);
+            // tile kb+1 flies while tile kb is consumed (its buffer was last read before the
+            // barrier that ended iteration kb-1)
+            if (kb + 1 < nkb) syrk_dma_tile(p, nxt, row_begin + (kb + 1) * GR_KB, wave, lane, ca, cb);
+            gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
             __syncthreads();
         }
     }
 
     // ---- flush: f32 partial -> f64 G (upper triangle only) ----
-    const int64_t F = 2 * (int64_t)p.n;
+    const int64_t F = p.F;
     const int hi = lane >> 5;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int lb = wc_ * 64 + j * 32 + (lane & 31);  // local B column
-        const int fbq = fb * GR_TF + (lb & (GR_TF - 1));
-        const bool bvalid = fbq < p.n;
-        const int64_t gb = (lb < GR_TF) ? fbq : p.n + fbq;
+        const int64_t gc = cb + wc_ * 64 + j * 32 + (lane & 31);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int la = wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                const int faq = fa * GR_TF + (la & (GR_TF - 1));
-                const int64_t ga = (la < GR_TF) ? faq : p.n + faq;
-                const bool lower = ga > gb;
-                const bool keep = bvalid && (faq < p.n) && !(lower && diag);
-                const int64_t gr = lower ? gb : ga, gc = lower ? ga : gb;
-                if (keep) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
             }
         }
     }
+    (void)diag;
 }
 
 // y^T y (slm.py:161-162 via sqErr = yty - 2 m.b + m G m)
@@ -479,7 +471,7 @@ static int grad_dev_impl(rr_basis *b, const void *dX, int x_dtype, int64_t N, in
     RR_DISPATCH3(launch_grad, x_dtype, b->compute, out_dtype, b, dX, N, ldx, dOut, nout);
 }
 
-// Z scratch: grow-only, owned by the basis (freed in rr_basis_destroy).
+// Feature scratch: grow-only, owned by the basis (freed in rr_basis_destroy).
 static int ensure_zbuf(rr_basis *b, size_t bytes) {
     if (b->zbuf_bytes >= bytes) return RR_OK;
     if (b->zbuf) {
@@ -491,10 +483,35 @@ static int ensure_zbuf(rr_basis *b, size_t bytes) {
     hipError_t e = hipMalloc((void **)&b->zbuf, bytes);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        rr_set_error("gram: could not allocate %zu bytes of phase scratch", bytes);
+        rr_set_error("gram: could not allocate %zu bytes of feature scratch", bytes);
         return RR_ERR_OOM;
     }
     b->zbuf_bytes = bytes;
+    return RR_OK;
+}
+
+// G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
+int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG) {
+    const int nb = (int)(ldp / GR_TC);
+    const int ntiles = nb * (nb + 1) / 2;
+    // Every workgroup costs the same, so make their number a multiple of the CU count (no
+    // partial last round): nsplit = k * CUs / gcd(CUs, ntiles), k minimal such that a split has
+    // <= 32768 rows (the bound on f32 accumulation length).
+    int64_t g = c->num_cu, t = ntiles;
+    while (t) { const int64_t u = g % t; g = t; t = u; }
+    const int64_t unit = c->num_cu / g;  // 32 for 256 CUs and 136 tiles
+    int64_t nsplit = ((rows + 32767) / 32768 + unit - 1) / unit * unit;
+    if (rows / nsplit < 1024) nsplit = (rows + 1023) / 1024;  // small inputs: just cover the rows
+    if (nsplit < 1) nsplit = 1;
+    int64_t rps = ((rows + nsplit - 1) / nsplit + GR_KB - 1) / GR_KB * GR_KB;
+    const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
+    if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
+    nsplit = (rows + rps - 1) / rps;
+    RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+    SyrkArgs a;
+    a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
+    hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
 
@@ -502,20 +519,27 @@ template <typename TX>
 static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t N, int64_t ldx, double *dG,
                            double *db) {
     rr_ctx *c = b->ctx;
-    const int nfb = b->npad / GR_TF;
-    const int ntiles = nfb * (nfb + 1) / 2;
+    const int F = 2 * b->n;
+    const int64_t ldp = ((int64_t)F + GR_TC - 1) / GR_TC * GR_TC;
     const float scale = (float)(1.0 / sqrt((double)b->n));
-    // row chunks: phase scratch of at most ~16 GiB (or RR_GRAM_CHUNK_ROWS)
-    int64_t chunk = (int64_t)(((size_t)16 << 30) / ((size_t)b->npad * sizeof(float)));
+    // row chunks: feature scratch of at most ~32 GiB (or RR_GRAM_CHUNK_ROWS), multiple of 32 rows
+    int64_t chunk = (int64_t)(((size_t)32 << 30) / ((size_t)ldp * sizeof(float)));
     const char *cenv = getenv("RR_GRAM_CHUNK_ROWS");
     if (cenv && atoll(cenv) >= GR_KB) chunk = atoll(cenv);
     if (chunk > N) chunk = N;
-    int rc = ensure_zbuf(b, (size_t)chunk * b->npad * sizeof(float));
+    chunk = (chunk + GR_KB - 1) / GR_KB * GR_KB;
+    int rc = ensure_zbuf(b, (size_t)chunk * ldp * sizeof(float));
     if (rc != RR_OK) return rc;
-    const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
+    if (ldp > F) {  // pad columns are never written by the feature kernel: zero them once per call
+        const int64_t cnt = chunk * (ldp - F);
+        hipLaunchKernelGGL(rr_zero_padcols_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
+                           b->zbuf, chunk, ldp, F);
+        RR_CHECK_HIP(hipGetLastError());
+    }
 
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
+        const int64_t mpad = (m + GR_KB - 1) / GR_KB * GR_KB;
         const TX *Xc = (const TX *)dX + r0 * ldx;
         const TX *yc = dy ? (const TX *)dy + r0 : nullptr;
         // three events per chunk bracket the two kernels (read back by rr_rff_gram_timings)
@@ -526,18 +550,18 @@ static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t 
             b->events.push_back(ev);
         }
         RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
-        // (A) phases (+ Phi^T y)
+        // (A) features (+ Phi^T y)
         {
-            const int fblocks = (b->npad + 255) / 256;
+            const int fblocks = (b->n + 255) / 256;
             int64_t rpb = 256;
-            if ((m + rpb - 1) / rpb > 65535) rpb = (m + 65534) / 65535;
-            const dim3 grid(fblocks, (unsigned)((m + rpb - 1) / rpb));
-#define RR_LPH(DM)                                                                                          \
-    do {                                                                                                    \
-        if (yc) hipLaunchKernelGGL((rr_rff_phase_kernel<DM, true, TX>), grid, dim3(256), 0, c->stream, Xc, yc, \
-                                   m, ldx, b->dWs32, b->n, b->npad, b->zbuf, db, scale, (int)rpb);         \
-        else hipLaunchKernelGGL((rr_rff_phase_kernel<DM, false, TX>), grid, dim3(256), 0, c->stream, Xc, yc, \
-                                m, ldx, b->dWs32, b->n, b->npad, b->zbuf, db, scale, (int)rpb);            \
+            if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
+            const dim3 grid(fblocks, (unsigned)((mpad + rpb - 1) / rpb));
+#define RR_LPH(DM)                                                                                             \
+    do {                                                                                                       \
+        if (yc) hipLaunchKernelGGL((rr_rff_features_kernel<DM, true, TX>), grid, dim3(256), 0, c->stream, Xc,  \
+                                   yc, m, mpad, ldx, b->dWs32, b->n, b->npad, b->zbuf, ldp, db, scale, (int)rpb); \
+        else hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, TX>), grid, dim3(256), 0, c->stream, Xc,    \
+                                yc, m, mpad, ldx, b->dWs32, b->n, b->npad, b->zbuf, ldp, db, scale, (int)rpb); \
     } while (0)
             switch (b->dpad) {
                 case 8: RR_LPH(8); break;
@@ -551,33 +575,13 @@ static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t 
             RR_CHECK_HIP(hipGetLastError());
         }
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
-        // (B) Gram from phases.  K-splits: f32 accumulation is limited to <= 32768 rows per
-        // split; use more (smaller) splits when needed to give every CU several workgroups.
-        {
-            // Every workgroup costs the same, so make their number a multiple of the CU count
-            // (no partial last round): nsplit = k * CUs / gcd(CUs, ntiles), k minimal such that
-            // a split has <= 32768 rows (the bound on f32 accumulation length).
-            int64_t g = c->num_cu, t = ntiles;
-            while (t) { const int64_t u = g % t; g = t; t = u; }
-            const int64_t unit = c->num_cu / g;  // 32 for 256 CUs and 136 tiles
-            int64_t nsplit = ((m + 32767) / 32768 + unit - 1) / unit * unit;
-            if (m / nsplit < 1024) nsplit = (m + 1023) / 1024;  // small inputs: just cover the rows
-            if (nsplit < 1) nsplit = 1;
-            int64_t rps = ((m + nsplit - 1) / nsplit + GR_KB - 1) / GR_KB * GR_KB;
-            if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
-            nsplit = (m + rps - 1) / rps;
-            RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
-            GramArgs a;
-            a.Z = b->zbuf; a.N = m; a.n = b->n; a.npad = b->npad; a.nfb = nfb; a.ntiles = ntiles;
-            a.rows_per_split = rps; a.G = dG; a.scale = scale;
-            hipLaunchKernelGGL(rr_rff_gram_phase_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0,
-                               c->stream, a);
-            RR_CHECK_HIP(hipGetLastError());
-        }
+        // (B) G += P^T P
+        rc = rr_launch_syrk_f32(c, b->zbuf, mpad, ldp, F, dG);
+        if (rc != RR_OK) return rc;
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
         b->events_used = e0 + 3;
     }
-    b->gram_kernel = "rr_rff_gram_phase_kernel";
+    b->gram_kernel = "rr_syrk_f32_kernel";
     return RR_OK;
 }
 
