@@ -159,6 +159,14 @@ int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int6
                 int64_t ldx, const double *lenscale, int n_ls, double *G, double *b,
                 double *yty);
 
+/* G = Phi^T Phi (full symmetric, F x F), b = Phi^T y, yty = y^T y for an ARBITRARY host feature
+ * matrix Phi (N, F) of `dtype` with leading dimension ldphi -- the Gram of concatenated or
+ * non-random bases (BasisCat.transform output, LinearBasis, ...), i.e. `Phi.T.dot(Phi)` and
+ * `Phi.T.dot(y)` of slm.py:146,157 for any basis.  Rows are repacked to f32 on the device and run
+ * through the same MFMA SYRK kernel as the fused path.  y/b/yty may be NULL together. */
+int rr_dense_gram(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi,
+                  const void *y, double *G, double *b, double *yty);
+
 /* Name of the dominant kernel the last rr_rff_gram_dev launched (for profiles). */
 const char *rr_rff_gram_kernel_name(rr_basis *basis);
 

@@ -66,6 +66,9 @@ SIGNATURES = {
     "rr_rff_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_dense_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_void_p]),
     "rr_rff_gram_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
 }
 
@@ -294,6 +297,27 @@ def _ptr(x):
 def _lenscale_arg(lenscale):
     ls = np.ascontiguousarray(np.atleast_1d(np.asarray(lenscale, dtype=np.float64)))
     return ls, ls.ctypes.data_as(ctypes.c_void_p), int(ls.size)
+
+
+def dense_gram(Phi, y=None, device=None):
+    """(Phi^T Phi, Phi^T y, y^T y) of an arbitrary host feature matrix on the GPU (rr_dense_gram)."""
+    dev = get_device(device)
+    Phi = as_float_matrix(Phi)
+    N, F = Phi.shape
+    G = np.empty((F, F))
+    if y is None:
+        _check(dev.lib, dev.lib.rr_dense_gram(dev.ctx, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype), N, F,
+                                              _ld(Phi), None, G.ctypes.data_as(ctypes.c_void_p), None, None))
+        return G, None, None
+    y = np.ascontiguousarray(y, dtype=Phi.dtype).ravel()
+    if y.shape[0] != N:
+        raise ValueError("Phi and y have inconsistent numbers of rows")
+    b, yty = np.empty(F), np.empty(1)
+    _check(dev.lib, dev.lib.rr_dense_gram(dev.ctx, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype), N, F,
+                                          _ld(Phi), y.ctypes.data_as(ctypes.c_void_p),
+                                          G.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                          yty.ctypes.data_as(ctypes.c_void_p)))
+    return G, b, float(yty[0])
 
 
 class RffHandle(object):

@@ -345,6 +345,34 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
     (void)diag;
 }
 
+// Host feature matrices of ANY basis (concatenations, LinearBasis, ...) reach the SYRK kernel
+// through this repack: (rows, F) f32|f64 with leading dimension lds -> zero-padded f32 (rows_pad, ldp).
+template <typename TS>
+__global__ void __launch_bounds__(256) rr_pack_f32_kernel(const TS *__restrict__ src, int64_t rows, int F,
+                                                          int64_t lds_, float *__restrict__ dst, int64_t ldp,
+                                                          int64_t rows_pad) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ldp) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    for (int64_t r = r0; r < r0 + 64 && r < rows_pad; ++r)
+        dst[r * ldp + c] = (r < rows && c < F) ? (float)src[r * lds_ + c] : 0.f;
+}
+
+// b += P^T y for a packed feature matrix (one column per thread, rows split over blockIdx.y)
+template <typename TY>
+__global__ void __launch_bounds__(256) rr_gemv_t_kernel(const float *__restrict__ P, const TY *__restrict__ y,
+                                                        int64_t rows, int F, int64_t ldp, double *__restrict__ bvec,
+                                                        int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (c >= F) return;
+    double acc = 0.0;
+    for (int64_t r = r0; r < r1; ++r) acc += (double)P[r * ldp + c] * (double)y[r];
+    unsafeAtomicAdd(&bvec[c], acc);
+}
+
 // y^T y (slm.py:161-162 via sqErr = yty - 2 m.b + m G m)
 template <typename TX>
 __global__ void __launch_bounds__(256) rr_yty_kernel(const TX *__restrict__ y, int64_t N, double *out) {
@@ -612,6 +640,8 @@ static hipError_t stage_rows(rr_basis *b, const RowStage &st, const void *X, int
 
 extern "C" {
 
+int rr_symmetrize_dev(rr_ctx *c, double *dG, int64_t F);
+
 int rr_rff_padded_dim(rr_basis *b) { return b ? b->dpad : 0; }
 
 int rr_upload_matrix(rr_ctx *c, const void *X, int dtype, int64_t N, int64_t d, int64_t ldx, int64_t ld_dev,
@@ -817,6 +847,104 @@ int rr_rff_gram_timings(rr_basis *b, float *phase_ms, float *gram_ms, int *launc
     if (gram_ms) *gram_ms = pg;
     if (launches) *launches = (int)(b->events_used / 3);
     return RR_OK;
+}
+
+int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi, const void *y,
+                  double *G, double *bvec, double *yty) {
+    RR_REQUIRE(c != nullptr && G != nullptr, "rr_dense_gram: null argument");
+    RR_REQUIRE(dtype_ok(dtype), "rr_dense_gram: bad dtype");
+    RR_REQUIRE(N >= 0 && F >= 1 && ldphi >= F && F < (1 << 30), "rr_dense_gram: bad shape");
+    RR_REQUIRE((y == nullptr) == (bvec == nullptr) && (y == nullptr) == (yty == nullptr),
+               "rr_dense_gram: y, b and yty must be given together");
+    RR_REQUIRE(N == 0 || Phi != nullptr, "rr_dense_gram: null Phi");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = dtype_size(dtype);
+    const int64_t ldp = (F + GR_TC - 1) / GR_TC * GR_TC;
+    int64_t chunk = (int64_t)(((size_t)1 << 30) / ((size_t)ldp * 4 + (size_t)F * es));
+    if (chunk > N) chunk = N;
+    chunk = (chunk + GR_KB - 1) / GR_KB * GR_KB;
+    if (chunk < GR_KB) chunk = GR_KB;
+    void *dRaw = nullptr, *dy = nullptr;
+    float *dP = nullptr;
+    double *dG = nullptr, *db = nullptr;
+    int rc = RR_OK;
+    hipError_t e = hipMalloc((void **)&dG, (size_t)F * F * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)(F + 1) * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&dRaw, (size_t)chunk * F * es);
+    if (e == hipSuccess) e = hipMalloc((void **)&dP, (size_t)chunk * ldp * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&dy, (size_t)chunk * es);
+    if (e == hipSuccess) e = hipMemsetAsync(dG, 0, (size_t)F * F * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)(F + 1) * sizeof(double), c->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_dense_gram: device allocation failed: %s", hipGetErrorString(e));
+        rc = RR_ERR_OOM;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
+        const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
+        const int64_t mpad = (m + GR_KB - 1) / GR_KB * GR_KB;
+        e = hipMemcpy2DAsync(dRaw, (size_t)F * es, (const char *)Phi + (size_t)r0 * ldphi * es, (size_t)ldphi * es,
+                             (size_t)F * es, (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && y)
+            e = hipMemcpyAsync(dy, (const char *)y + (size_t)r0 * es, (size_t)m * es, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_dense_gram: upload failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+            break;
+        }
+        const dim3 pg((unsigned)((ldp + 255) / 256), (unsigned)((mpad + 63) / 64));
+        const int rpb = 512;
+        const dim3 gg((unsigned)((F + 255) / 256), (unsigned)((m + rpb - 1) / rpb));
+        const int yb = (int)((m + 255) / 256) > c->num_cu * 8 ? c->num_cu * 8 : (int)((m + 255) / 256);
+        if (dtype == RR_F32) {
+            hipLaunchKernelGGL(rr_pack_f32_kernel<float>, pg, dim3(256), 0, c->stream, (const float *)dRaw, m, (int)F, F,
+                               dP, ldp, mpad);
+            if (y) {
+                hipLaunchKernelGGL(rr_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, dP, (const float *)dy, m,
+                                   (int)F, ldp, db, rpb);
+                hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, m, db + F);
+            }
+        } else {
+            hipLaunchKernelGGL(rr_pack_f32_kernel<double>, pg, dim3(256), 0, c->stream, (const double *)dRaw, m, (int)F,
+                               F, dP, ldp, mpad);
+            if (y) {
+                hipLaunchKernelGGL(rr_gemv_t_kernel<double>, gg, dim3(256), 0, c->stream, dP, (const double *)dy, m,
+                                   (int)F, ldp, db, rpb);
+                hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, m,
+                                   db + F);
+            }
+        }
+        if (hipGetLastError() != hipSuccess) {
+            rr_set_error("rr_dense_gram: launch failed");
+            rc = RR_ERR_HIP;
+            break;
+        }
+        rc = rr_launch_syrk_f32(c, dP, mpad, ldp, (int)F, dG);
+        if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            rr_set_error("rr_dense_gram: kernel failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    if (rc == RR_OK) rc = rr_symmetrize_dev(c, dG, F);
+    if (rc == RR_OK) {
+        e = hipMemcpyAsync(G, dG, (size_t)F * F * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess && y) {
+            e = hipMemcpyAsync(bvec, db, (size_t)F * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(yty, db + F, sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_dense_gram: download failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    if (dG) (void)hipFree(dG);
+    if (db) (void)hipFree(db);
+    if (dRaw) (void)hipFree(dRaw);
+    if (dP) (void)hipFree(dP);
+    if (dy) (void)hipFree(dy);
+    return rc;
 }
 
 int rr_symmetrize_dev(rr_ctx *c, double *dG, int64_t F) {

@@ -1,0 +1,147 @@
+"""
+The Bayesian standard linear model with revrand's interface (reference: revrand/slm.py), its
+O(N F^2) work on the MI355X.
+
+Same constructor, ``fit`` / ``predict`` / ``predict_moments`` and fitted attributes
+(``var_, regularizer_, hypers_, weights_, covariance_, obj_``) as
+``revrand.slm.StandardLinearModel``; sklearn-clonable.  Inside ``_elbo`` (slm.py:142-199):
+
+* ``Phi = basis.transform(X)``                 -> HIP (random bases)               slm.py:145
+* ``Phi.T.dot(Phi)``, ``Phi.T.dot(y)``         -> ``basis.gram`` (fused, Phi never built) for a
+  single random Fourier basis, else ``rr_dense_gram`` (same MFMA SYRK kernel)       slm.py:146,157
+* ``(dPhi.T.dot(Phi) * C).sum()``              -> the (Phi, dPhi) block of ``rr_dense_gram([Phi | dPhi])``
+                                                                                   slm.py:195
+* Cholesky / inverse ``solve_posdef``          -> host, by design                   slm.py:155
+
+Everything else is O(N F) or O(F^2) host arithmetic exactly as in the reference.
+"""
+import logging
+from functools import partial
+
+import numpy as np
+from scipy.optimize import minimize
+from scipy.stats import gamma
+from sklearn.base import BaseEstimator, RegressorMixin
+from sklearn.utils import check_random_state
+from sklearn.utils.validation import check_array, check_is_fitted, check_X_y
+
+from . import _hip
+from .basis_functions import LinearBasis, apply_grad
+from .btypes import Parameter, Positive
+from .linalg import solve_posdef
+from .optimize import logtrick_minimizer, structured_minimizer
+from .utils import atleast_list, issequence
+
+log = logging.getLogger(__name__)
+
+
+class StandardLinearModel(BaseEstimator, RegressorMixin):
+    """Bayesian linear regression on a basis; hyper-parameters by L-BFGS-B on the ELBO.
+
+    Parameters are those of the reference (slm.py:57-72): ``basis``, ``var``, ``tol``,
+    ``maxiter``, ``nstarts``, ``random_state``.
+    """
+
+    def __init__(self, basis=LinearBasis(), var=Parameter(gamma(1.), Positive()), tol=1e-8, maxiter=1000,
+                 nstarts=100, random_state=None):
+        self.basis = basis
+        self.var = var
+        self.tol = tol
+        self.maxiter = maxiter
+        self.nstarts = nstarts
+        self.random_state = random_state
+        self.random_ = check_random_state(random_state)
+
+    def fit(self, X, y):
+        """Learn (var, regularizer, basis hyper-parameters); returns self (slm.py:74-140)."""
+        X, y = check_X_y(X, y)
+        self.obj_ = -np.inf
+        params = [self.var, self.basis.regularizer, self.basis.params]
+        nmin = structured_minimizer(logtrick_minimizer(minimize))
+        elbo = partial(StandardLinearModel._elbo, self, X, y)
+        res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
+                   options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
+                   nstarts=self.nstarts)
+        self.var_, self.regularizer_, self.hypers_ = res.x
+        log.info("Done! ELBO = {}, var = {}, reg = {}, hypers = {}, message = {}."
+                 .format(-res["fun"], self.var_, self.regularizer_, self.hypers_, res.message))
+        return self
+
+    # -- device statistics -------------------------------------------------------------------
+    def _gram(self, X, y, Phi, hyp):
+        """(Phi^T Phi, Phi^T y) on the GPU: fused when the basis offers it, dense SYRK otherwise."""
+        if hasattr(self.basis, "gram"):
+            G, b, _ = self.basis.gram(X, y, *hyp)
+        else:
+            G, b, _ = _hip.dense_gram(Phi, y)
+        return G, b
+
+    @staticmethod
+    def _cross_gram(Phi, dPhi):
+        """Phi^T dPhi through the SYRK kernel: the off-diagonal block of [Phi | dPhi]^T [Phi | dPhi]."""
+        F = Phi.shape[1]
+        G2, _, _ = _hip.dense_gram(np.hstack((Phi, dPhi)))
+        return G2[:F, F:]
+
+    def _elbo(self, X, y, var, reg, hypers):
+        hyp = atleast_list(hypers)
+        Phi = self.basis.transform(X, *hyp)  # N x D
+        N, D = Phi.shape
+        PhiPhi, Phiy = self._gram(X, y, Phi, hyp)
+
+        L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
+        iL = 1. / L
+
+        # posterior (host Cholesky)
+        iC = np.diag(iL) + PhiPhi / var
+        C, logdetiC = solve_posdef(iC, np.eye(D))
+        logdetC = -logdetiC
+        m = C.dot(Phiy) / var
+
+        TrPhiPhiC = (PhiPhi * C).sum()
+        Err = y - Phi.dot(m)
+        sqErr = (Err ** 2).sum()
+
+        ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
+                       + ((m ** 2 + C.diagonal()) * iL).sum() - logdetC + np.log(L).sum() - D)
+
+        # keep the best posterior seen (slm.py:173-177)
+        if ELBO > self.obj_:
+            self.weights_ = m
+            self.covariance_ = C
+            self.obj_ = ELBO
+
+        log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
+
+        dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
+
+        def dreg(s):
+            return -0.5 * (((m[s] ** 2 + C[s, s].diagonal()) * iL[s] ** 2).sum() - iL[s].sum())
+
+        dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
+
+        def dhyps(dPhi):
+            # slm.py:193-195 with (dPhi^T Phi o C).sum() == (Phi^T dPhi o C).sum() (C symmetric)
+            return -(m.T.dot(Err.dot(dPhi)) - (self._cross_gram(Phi, dPhi) * C).sum()) / var
+
+        dhypers = apply_grad(dhyps, self.basis.grad(X, *hyp))
+
+        return -ELBO, [-dvar, dL, dhypers]
+
+    def predict(self, X):
+        """Predictive mean (slm.py:201-217)."""
+        Ey, _ = self.predict_moments(X)
+        return Ey
+
+    def predict_moments(self, X):
+        """Predictive mean and variance (slm.py:219-244)."""
+        check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
+        X = check_array(X)
+        Phi = self.basis.transform(X, *atleast_list(self.hypers_))
+        Ey = Phi.dot(self.weights_)
+        Vf = (Phi.dot(self.covariance_) * Phi).sum(axis=1)
+        return Ey, Vf + self.var_
+
+    def __repr__(self):
+        return "{}(basis={}, var={}, tol={}, maxiter={}, nstarts={}, random_state={})".format(
+            type(self).__name__, self.basis, self.var, self.tol, self.maxiter, self.nstarts, self.random_state)

@@ -1,0 +1,140 @@
+"""
+GPU parity of StandardLinearModel (reference: revrand/slm.py) -- single `_elbo` evaluations
+against the golden vectors the reference produced (ELBO, every gradient, posterior m and C),
+an end-to-end fit, and the sklearn-facing behaviour the reference's tests/test_models.py covers.
+"""
+import numpy as np
+import pytest
+from sklearn.base import clone
+from sklearn.decomposition import PCA
+from sklearn.model_selection import GridSearchCV
+from sklearn.pipeline import Pipeline
+
+import revrand_oracle as orc
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def smse(y_true, y_pred):
+    return ((y_true - y_pred) ** 2).sum() / (len(y_true) * y_true.var())
+
+
+def _imports():
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    return bs, Parameter, Positive, StandardLinearModel
+
+
+def test_dense_gram_vs_numpy():
+    from revrand_amd import _hip
+    rs = np.random.RandomState(0)
+    for (N, F) in [(1, 1), (33, 7), (700, 300), (5000, 513)]:
+        Phi = rs.randn(N, F)
+        y = rs.randn(N)
+        G, b, yty = _hip.dense_gram(Phi, y)
+        assert np.array_equal(G, G.T)
+        assert normwise(G, Phi.T @ Phi) < 1e-5
+        assert normwise(b, Phi.T @ y) < 1e-5
+        assert abs(yty - y @ y) < 1e-10 * max(1.0, y @ y)
+    G, b, yty = _hip.dense_gram(rs.randn(40, 5).astype(np.float32))
+    assert b is None and G.shape == (5, 5)
+
+
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+def test_elbo_single_basis_vs_reference(golden, tag):
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    lsp = Parameter(1., Positive()) if tag == "iso" else Parameter(np.ones(d), Positive())
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=lsp)
+    assert np.array_equal(basis.W, g[tag + "_W"])
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    ls = float(g[tag + "_ls"]) if tag == "iso" else g[tag + "_ls"]
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), float(g["reg"]), ls)
+    assert abs(-nelbo - g[tag + "_elbo"]) < 1e-4 * abs(g[tag + "_elbo"])
+    assert normwise(slm.weights_, g[tag + "_m"]) < 1e-3
+    assert normwise(slm.covariance_, g[tag + "_C"]) < 1e-3
+    assert normwise(-ndvar, g[tag + "_dvar"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndreg), g[tag + "_dreg"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 2e-3
+
+
+def test_elbo_concatenation_vs_reference(golden):
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    basis = bs.RandomMatern52(nbases=n, Xdim=d, random_state=22,
+                              lenscale=Parameter(np.ones(d), Positive())) + bs.LinearBasis(onescol=True)
+    assert np.array_equal(basis.bases[0].W, g["cat_W"])
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), list(g["cat_reg"]), g["cat_ls"])
+    assert abs(-nelbo - g["cat_elbo"]) < 1e-4 * abs(g["cat_elbo"])
+    assert normwise(slm.weights_, g["cat_m"]) < 1e-3
+    assert normwise(slm.covariance_, g["cat_C"]) < 1e-3
+    assert normwise(-np.asarray(ndreg), g["cat_dreg"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndhyp), g["cat_dhyp"]) < 2e-3
+
+
+def test_fit_end_to_end_vs_reference(golden):
+    """Same data, W, fixed initial values, nstarts=0, maxiter=20 as the reference run."""
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("fit")
+    X, y, Xs = g["X"], g["y"], g["Xs"]
+    basis = bs.RandomRBF(nbases=24, Xdim=3, random_state=31, lenscale=Parameter(1.2, Positive()),
+                         regularizer=Parameter(1.5, Positive()))
+    assert np.array_equal(basis.W, g["W"])
+    slm = SLM(basis, var=Parameter(0.5, Positive()), nstarts=0, maxiter=20).fit(X, y)
+    Ey, Vy = slm.predict_moments(Xs)
+    # L-BFGS trajectories are sensitive: compare at prediction level
+    assert smse(g["Ey"], Ey) < 1e-3
+    assert np.all(Vy > 0) and normwise(Vy, g["Vy"]) < 0.2
+    assert abs(slm.obj_ - float(g["obj"])) < 0.02 * abs(float(g["obj"]))
+    # predictions are consistent with the oracle given the fitted state
+    Phi = orc.rff_transform(Xs, basis.W, slm.hypers_)
+    Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
+    assert normwise(Ey, Eo) < 1e-3 and normwise(Vy, Vo) < 1e-3
+
+
+def _gaus_data():
+    rs = np.random.RandomState(99)
+    x = np.linspace(-5, 5, 600)
+    y = 3 + 2 * x + rs.randn(600) * 1e-4
+    X = np.hstack((np.ones((600, 1)), x[:, None]))
+    tr = rs.choice(600, 400, replace=False)
+    mask = np.zeros(600, dtype=bool)
+    mask[tr] = True
+    return X[mask], y[mask], X[~mask], y[~mask]
+
+
+def test_slm_like_reference_test_models():
+    """tests/test_models.py:16-36 of the reference: smse < 0.1 for linear and concatenated bases."""
+    bs, Parameter, Positive, SLM = _imports()
+    X, y, Xs, ys = _gaus_data()
+    slm = SLM(bs.LinearBasis(onescol=False), nstarts=10, random_state=1).fit(X, y)
+    assert smse(ys, slm.predict(Xs)) < 0.1
+    basis = bs.LinearBasis(onescol=False) + bs.RandomRBF(nbases=10, Xdim=2, random_state=2) \
+        + bs.RandomMatern52(nbases=10, Xdim=2, random_state=3)
+    slm = SLM(basis, nstarts=10, random_state=1, maxiter=50).fit(X, y)
+    assert smse(ys, slm.predict(Xs)) < 0.1
+
+
+def test_sklearn_protocol():
+    """Pipeline / GridSearchCV / clone (tests/test_models.py:39-80,197-238), single process."""
+    bs, Parameter, Positive, SLM = _imports()
+    X, y, Xs, ys = _gaus_data()
+    slm = SLM(bs.LinearBasis(onescol=True), nstarts=0)
+    pipe = Pipeline([("PCA", PCA()), ("SLM", slm)]).fit(X, y)
+    assert smse(ys, pipe.predict(Xs)) < 0.1
+    est = GridSearchCV(slm, {"var": [Parameter(v, Positive()) for v in [1.0, 2.0]]}, cv=2).fit(X, y)
+    assert len(est.predict(Xs)) == len(ys)
+    c = clone(slm)
+    assert repr(c.get_params()["basis"]) == repr(slm.basis) and not hasattr(c, "weights_")
+    from sklearn.exceptions import NotFittedError
+    with pytest.raises(NotFittedError):
+        c.predict(Xs)
