@@ -167,6 +167,29 @@ int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int6
 int rr_dense_gram(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi,
                   const void *y, double *G, double *b, double *yty);
 
+/* ---- FastFood -------------------------------------------------------------------------
+ * FastFoodRBF (basis_functions.py:1211-1383).  B (+-1, int64), G, PI (int64 permutations) and S are
+ * the host-sampled (k, d2) matrices of _init_matrices / _weightsamples (:1342-1354), row-major;
+ * d2 = 2^ceil(log2 d), n = d2 * k (:1331-1340).  The handle serves rr_fastfood_transform /
+ * rr_fastfood_vx; gradients and the Gram use the dense equivalent W = _makeVX(I_d) (obtained with
+ * rr_fastfood_vx on the identity) through the rr_rff_* entry points -- the chain is linear in x. */
+int rr_fastfood_create(rr_ctx *ctx, int compute, int d, int d2, int k, const int64_t *B, const double *G,
+                       const int64_t *PI, const double *S, rr_basis **out);
+
+/* Phi = [cos VX, sin VX] / sqrt(n), (N, 2n): FastFoodRBF.transform (basis_functions.py:1263-1289)
+ * by the Hadamard / permute / diagonal chain (in-wave butterflies, LDS permutation gather). */
+int rr_fastfood_transform(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
+                          const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi);
+
+/* VX = _makeVX(X / lenscale), (N, n) in radians (basis_functions.py:1356-1371). */
+int rr_fastfood_vx(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
+                   const double *lenscale, int n_ls, void *VX, int out_dtype, int64_t ldvx);
+
+/* mathfun.linalg.hadamard (mathfun/linalg.py:182-236): natural-order Walsh-Hadamard transform of each
+ * row of host Y (rows, n), n = 2^p <= 4096, normalised by 1/n; ordering != 0 applies the sequency
+ * permutation.  out has Y's dtype and shape. */
+int rr_hadamard(rr_ctx *ctx, const void *Y, int dtype, int64_t rows, int64_t n, int ordering, void *out);
+
 /* Name of the dominant kernel the last rr_rff_gram_dev launched (for profiles). */
 const char *rr_rff_gram_kernel_name(rr_basis *basis);
 

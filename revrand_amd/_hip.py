@@ -69,6 +69,17 @@ SIGNATURES = {
     "rr_dense_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+    "rr_fastfood_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                          _c_void_pp]),
+    "rr_fastfood_transform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_int64]),
+    "rr_fastfood_vx": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_int, ctypes.c_int64]),
+    "rr_hadamard": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                   ctypes.c_int, ctypes.c_void_p]),
     "rr_rff_gram_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
 }
 
@@ -318,6 +329,65 @@ def dense_gram(Phi, y=None, device=None):
                                           G.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                           yty.ctypes.data_as(ctypes.c_void_p)))
     return G, b, float(yty[0])
+
+
+def hadamard(Y, ordering=True, device=None):
+    """Row-wise Walsh-Hadamard transform on the GPU (rr_hadamard)."""
+    dev = get_device(device)
+    Y = np.ascontiguousarray(Y)
+    if Y.dtype not in (np.float32, np.float64):
+        Y = Y.astype(np.float64)
+    if Y.ndim != 2:
+        raise ValueError("expected a 2-d array")
+    out = np.empty_like(Y)
+    _check(dev.lib, dev.lib.rr_hadamard(dev.ctx, Y.ctypes.data_as(ctypes.c_void_p), rr_dtype(Y.dtype), Y.shape[0],
+                                        Y.shape[1], 1 if ordering else 0, out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+class FastFoodHandle(object):
+    """Device-resident FastFood block matrices (rr_basis of kind FASTFOOD)."""
+
+    def __init__(self, d, d2, k, B, G, PI, S, compute="f32", device=None):
+        self.dev = get_device(device)
+        self.lib = self.dev.lib
+        self.d, self.d2, self.k, self.n = d, d2, k, d2 * k
+        B = np.ascontiguousarray(B, dtype=np.int64)
+        PI = np.ascontiguousarray(PI, dtype=np.int64)
+        G = np.ascontiguousarray(G, dtype=np.float64)
+        S = np.ascontiguousarray(S, dtype=np.float64)
+        if not (B.shape == G.shape == PI.shape == S.shape == (k, d2)):
+            raise ValueError("FastFood matrices must all have shape (k, d2)")
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_fastfood_create(self.dev.ctx, {"f32": RR_F32, "f64": RR_F64}[compute], d, d2, k,
+                                                     B.ctypes.data_as(ctypes.c_void_p),
+                                                     G.ctypes.data_as(ctypes.c_void_p),
+                                                     PI.ctypes.data_as(ctypes.c_void_p),
+                                                     S.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.rr_basis_destroy(h)
+            except Exception:
+                pass
+
+    def _call(self, fn, X, lenscale, width, out_dtype):
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        out = np.empty((N, width), dtype=out_dtype)
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, fn(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N, _ld(X), lsp, nls,
+                            out.ctypes.data_as(ctypes.c_void_p), rr_dtype(out.dtype), width))
+        return out
+
+    def transform(self, X, lenscale, out_dtype=np.float64):
+        return self._call(self.lib.rr_fastfood_transform, X, lenscale, 2 * self.n, out_dtype)
+
+    def vx(self, X, lenscale=1.0, out_dtype=np.float64):
+        return self._call(self.lib.rr_fastfood_vx, X, lenscale, self.n, out_dtype)
 
 
 class RffHandle(object):

@@ -340,6 +340,94 @@ class OrthogonalRBF(_RandomKernelBasis):
 
 
 # --------------------------------------------------------------------------------------
+# FastFood (reference: basis_functions.py:1211-1383)
+# --------------------------------------------------------------------------------------
+
+class FastFoodRBF(_LengthScaleBasis):
+    """FastFood approximation of the RBF kernel: V = S H G PI H B in k blocks of d2 = 2^ceil(log2 d).
+
+    ``transform`` runs the Hadamard / permute / diagonal chain on the GPU (``rr_fastfood_transform``).
+    The chain is linear in x, so ``grad`` and ``gram`` go through the random-Fourier kernels with the
+    dense equivalent ``W = _makeVX(I_d)`` (itself produced by the chain on the device).
+    """
+
+    @slice_init
+    def __init__(self, nbases, Xdim, lenscale=Parameter(gamma(1.), Positive()), regularizer=None,
+                 random_state=None, dtype="f32"):
+        if dtype not in ("f32", "f64"):
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        self.dtype = dtype
+        self.random_state = random_state  # for repr
+        self._random = check_random_state(random_state)
+        self._init_dims(nbases, Xdim)
+        self._init_lenscale(lenscale)
+        self._init_matrices()
+        super(_LengthScaleBasis, self).__init__(regularizer)
+
+    def _init_dims(self, nbases, Xdim):
+        l = int(np.ceil(np.log2(Xdim)))
+        self.nbases = nbases
+        self.d = Xdim
+        self.d2 = pow(2, l)
+        self.k = int(np.ceil(nbases / self.d2))
+        self.n = self.d2 * self.k
+
+    def _init_matrices(self):
+        # draw order B -> G -> PI -> S (basis_functions.py:1346-1350)
+        shape = (self.k, self.d2)
+        self.B = self._random.randint(2, size=shape) * 2 - 1
+        self.G = self._random.randn(*shape)
+        self.PI = np.array([self._random.permutation(self.d2) for _ in range(self.k)])
+        self.S = self._weightsamples()
+
+    def _weightsamples(self):
+        s = np.sqrt(self._random.chisquare(self.d2, size=self.G.shape))
+        return self.d2 * s / np.sqrt((self.G ** 2).sum(axis=1))[:, np.newaxis]
+
+    def _handles(self):
+        h = self.__dict__.get("_hip_handle")
+        if h is None or h[0] != _hip.os.getpid():
+            ff = _hip.FastFoodHandle(self.d, self.d2, self.k, self.B, self.G, self.PI, self.S, compute=self.dtype)
+            V = ff.vx(np.eye(self.d), 1.0)  # (d, n): dense equivalent of the chain
+            h = (_hip.os.getpid(), ff, _hip.RffHandle(V, compute=self.dtype))
+            self.__dict__["_hip_handle"] = h
+        return h[1], h[2]
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_hip_handle", None)
+        return state
+
+    def get_dim(self, X):
+        return 2 * self.n
+
+    def _makeVX(self, X):
+        """(N, n) structured projection of X (basis_functions.py:1356-1371)."""
+        return self._handles()[0].vx(X, 1.0)
+
+    @slice_transform
+    def transform(self, X, lenscale=None):
+        """(N, 2*n) float64, n = d2*k >= nbases (basis_functions.py:1263-1289)."""
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        return self._handles()[0].transform(X, lenscale)
+
+    @slice_transform
+    def grad(self, X, lenscale=None):
+        """dPhi/dl, (N, 2n) or (N, 2n, d); same isotropic quirk as the reference (:1291-1329)."""
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        return self._handles()[1].grad(X, lenscale)
+
+    @slice_transform
+    def gram(self, X, y=None, lenscale=None):
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        return self._handles()[1].gram(X, y, lenscale)
+
+    def __repr__(self):
+        return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(
+            type(self).__name__, self.nbases, self.d, self.params, self.regularizer, self.random_state)
+
+
+# --------------------------------------------------------------------------------------
 # Concatenation (reference: basis_functions.py:1569-1790)
 # --------------------------------------------------------------------------------------
 

@@ -1,0 +1,388 @@
+// FastFood (Le, Sarlos, Smola) structured projection and the Walsh-Hadamard transform for gfx950.
+//
+//   VX = [ H( (H(x~ * B_j))[PI_j] * G_j ) * S_j * sqrt(d2) ]_{j<k},   H = natural-order WHT / d2
+//   Phi = [cos VX, sin VX] / sqrt(d2 k)
+//
+// reference: FastFoodRBF.transform / _makeVX  (revrand/basis_functions.py:1263-1289, 1356-1371),
+//            mathfun.linalg.hadamard          (revrand/mathfun/linalg.py:182-236).
+//
+// Kernel shape: ONE WAVE owns one block j (or 64/d2 blocks when d2 < 64) for a chunk of rows.  Its
+// diagonals B_j, G_j, S_j and permutation PI_j live in registers for the whole chunk; per row the wave
+// loads x~ (coalesced), runs the two length-d2 transforms with cross-lane butterflies
+// (__shfl_xor -> DPP / ds_bpermute, no barriers) plus register butterflies when d2 > 64, gathers the
+// permutation through a per-wave LDS line, takes cos/sin and streams 2 x d2 outputs.  The transform
+// is bound by the HBM write of Phi (4 (d + 2 d2 k) bytes per row in f32).
+#include "rr_internal.h"
+
+template <typename TC>
+__device__ __forceinline__ void ff_sincos_rev(TC t, TC &s, TC &c);
+template <>
+__device__ __forceinline__ void ff_sincos_rev<float>(float t, float &s, float &c) {
+    const float f = t - __builtin_rintf(t);
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
+}
+template <>
+__device__ __forceinline__ void ff_sincos_rev<double>(double t, double &s, double &c) {
+    const double f = t - rint(t);
+    sincospi(2.0 * f, &s, &c);
+}
+
+// In-wave unnormalised natural-order WHT of length L = min(d2, 64) * R: element index of register q in
+// lane l is q * 64 + (l % 64) when d2 >= 64, else l % d2 (several blocks side by side in one wave).
+template <int R, typename TC>
+__device__ __forceinline__ void wave_fwht(TC (&v)[R], int lane, int lane_len) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        if (m < lane_len) {  // wave-uniform
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const TC o = __shfl_xor(v[q], m, 64);
+                v[q] = (lane & m) ? (o - v[q]) : (v[q] + o);
+            }
+        }
+    }
+#pragma unroll
+    for (int s = 1; s < R; s <<= 1) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if (!(q & s)) {
+                const TC a = v[q], b = v[q | s];
+                v[q] = a + b;
+                v[q | s] = a - b;
+            }
+        }
+    }
+}
+
+// PHI = true : out (N, 2 n) = [cos | sin] * scale          (transform)
+// PHI = false: out (N, n)   = VX in radians                 (_makeVX; used to build the dense
+//                                                            equivalent matrix and by tests)
+template <int R, bool PHI, typename TX, typename TC, typename TO>
+__global__ void __launch_bounds__(256)
+rr_fastfood_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int d2, int k,
+                   const TC *__restrict__ Bm, const TC *__restrict__ Gm, const int *__restrict__ PIm,
+                   const TC *__restrict__ Sm, const TC *__restrict__ invls, TO *__restrict__ out, int64_t ldo,
+                   TC scale, int rows_per_block) {
+    __shared__ TC perm[4][64 * R];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int lane_len = d2 < 64 ? d2 : 64;       // lanes spanned by one block
+    const int bpw = 64 / lane_len;                // blocks per wave
+    const int sub = lane / lane_len, le = lane % lane_len;
+    const int j = (blockIdx.x * 4 + wave) * bpw + sub;  // FastFood block of this lane group
+    const bool active = j < k;
+    const int n = d2 * k;
+
+    TC Bv[R], Gv[R], Sv[R], Lv[R];
+    int Pv[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int e = q * 64 + le;
+        const size_t idx = (size_t)(active ? j : 0) * d2 + e;
+        Bv[q] = Bm[idx];
+        Gv[q] = Gm[idx];
+        Sv[q] = Sm[idx];  // S * d2^-1.5, and / (2 pi) when PHI (phase in revolutions)
+        Pv[q] = PIm[idx];
+        Lv[q] = (e < d) ? invls[e] : TC(0);
+    }
+    TC *line = perm[wave] + sub * d2;
+
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        TC v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            const int e = q * 64 + le;
+            const TC x = (e < d) ? (TC)X[r * ldx + e] : TC(0);
+            v[q] = x * Lv[q] * Bv[q];
+        }
+        wave_fwht<R, TC>(v, lane, lane_len);
+#pragma unroll
+        for (int q = 0; q < R; ++q) line[q * 64 + le] = v[q];
+        // same wave wrote and reads: LDS operations of a wave execute in order
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = line[Pv[q]] * Gv[q];
+        wave_fwht<R, TC>(v, lane, lane_len);
+        if (active) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int col = j * d2 + q * 64 + le;
+                const TC ph = v[q] * Sv[q];
+                if (PHI) {
+                    TC s, c;
+                    ff_sincos_rev<TC>(ph, s, c);
+                    out[r * ldo + col] = (TO)(c * scale);
+                    out[r * ldo + n + col] = (TO)(s * scale);
+                } else {
+                    out[r * ldo + col] = (TO)ph;
+                }
+            }
+        }
+    }
+}
+
+// mathfun.linalg.hadamard: rows x n (n = 2^p <= 4096), natural order, normalised by 1/n; optional
+// sequency reordering (linalg.py:223-236).  One workgroup per row, butterflies in LDS.
+template <typename TC>
+__global__ void __launch_bounds__(256)
+rr_hadamard_kernel(const TC *__restrict__ Y, int64_t rows, int n, int ordering, TC *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    TC *buf = reinterpret_cast<TC *>(smem_raw);
+    const int64_t r = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += 256) buf[i] = Y[r * n + i];
+    __syncthreads();
+    for (int h = 1; h < n; h <<= 1) {
+        for (int p = threadIdx.x; p < n / 2; p += 256) {
+            const int i = ((p / h) * 2 * h) + (p % h);
+            const TC a = buf[i], b = buf[i + h];
+            buf[i] = a + b;
+            buf[i + h] = a - b;
+        }
+        __syncthreads();
+    }
+    const TC inv = TC(1) / (TC)n;
+    int bits = 0;
+    while ((1 << bits) < n) ++bits;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        int src = i;
+        if (ordering) {  // out[i] = natural[bit-reversed Gray code of i]
+            const unsigned g = (unsigned)i ^ ((unsigned)i >> 1);
+            src = bits ? (int)(__brev(g) >> (32 - bits)) : 0;
+        }
+        out[r * n + i] = buf[src] * inv;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static size_t ff_dtype_size(int t) { return t == RR_F32 ? 4 : 8; }
+
+template <bool PHI, typename TX, typename TC, typename TO>
+static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *dOut, int64_t ldo) {
+    rr_ctx *c = b->ctx;
+    const int d2 = b->ff_d2, k = b->ff_k;
+    const int lane_len = d2 < 64 ? d2 : 64;
+    const int bpw = 64 / lane_len;
+    const int R = d2 <= 64 ? 1 : d2 / 64;
+    const unsigned gx = (unsigned)((k + 4 * bpw - 1) / (4 * bpw));
+    int64_t rpb = (N * gx + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+    if (rpb < 8) rpb = 8;
+    if (rpb > 512) rpb = 512;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    const dim3 grid(gx, (unsigned)((N + rpb - 1) / rpb));
+    const bool f32 = sizeof(TC) == 4;
+    const TC *Bm = (const TC *)(f32 ? (void *)b->ffB32 : (void *)b->ffB64);
+    const TC *Gm = (const TC *)(f32 ? (void *)b->ffG32 : (void *)b->ffG64);
+    const TC *Sm = (const TC *)(f32 ? (void *)(PHI ? b->ffSrev32 : b->ffSrad32) : (void *)(PHI ? b->ffSrev64 : b->ffSrad64));
+    const TC *Lm = (const TC *)(f32 ? (void *)b->ffL32 : (void *)b->ffL64);
+    const TC scale = (TC)(1.0 / sqrt((double)b->n));
+#define RR_FF(RR)                                                                                              \
+    hipLaunchKernelGGL((rr_fastfood_kernel<RR, PHI, TX, TC, TO>), grid, dim3(256), 0, c->stream, (const TX *)dX, N, \
+                       ldx, b->d, d2, k, Bm, Gm, b->ffPI, Sm, Lm, (TO *)dOut, ldo, scale, (int)rpb)
+    switch (R) {
+        case 1: RR_FF(1); break;
+        case 2: RR_FF(2); break;
+        case 4: RR_FF(4); break;
+        default: rr_set_error("fastfood: d2=%d is not supported", d2); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_FF
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+template <bool PHI>
+static int ff_dispatch(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, void *dOut, int out_dtype,
+                       int64_t ldo) {
+    const int key = x_dtype * 4 + b->compute * 2 + out_dtype;
+    switch (key) {
+        case 0: return ff_launch<PHI, float, float, float>(b, dX, N, ldx, dOut, ldo);
+        case 1: return ff_launch<PHI, float, float, double>(b, dX, N, ldx, dOut, ldo);
+        case 2: return ff_launch<PHI, float, double, float>(b, dX, N, ldx, dOut, ldo);
+        case 3: return ff_launch<PHI, float, double, double>(b, dX, N, ldx, dOut, ldo);
+        case 4: return ff_launch<PHI, double, float, float>(b, dX, N, ldx, dOut, ldo);
+        case 5: return ff_launch<PHI, double, float, double>(b, dX, N, ldx, dOut, ldo);
+        case 6: return ff_launch<PHI, double, double, float>(b, dX, N, ldx, dOut, ldo);
+        case 7: return ff_launch<PHI, double, double, double>(b, dX, N, ldx, dOut, ldo);
+    }
+    rr_set_error("fastfood: bad dtype combination");
+    return RR_ERR_INVALID;
+}
+
+// upload 1/l_i (per input dimension) for the FWHT kernels
+static int ff_prepare_lenscale(rr_basis *b, const double *lenscale, int n_ls) {
+    RR_REQUIRE(lenscale != nullptr, "lenscale: null argument");
+    RR_REQUIRE(n_ls == 1 || n_ls == b->d, "Dimension of input parameter is inconsistent! (n_ls=%d, d=%d)", n_ls, b->d);
+    std::vector<double> l64(b->ff_d2, 0.0);
+    std::vector<float> l32(b->ff_d2, 0.f);
+    for (int i = 0; i < b->d; ++i) {
+        const double l = lenscale[n_ls == 1 ? 0 : i];
+        RR_REQUIRE(l != 0.0 && l == l, "lenscale[%d] is %g", i, l);
+        l64[i] = 1.0 / l;
+        l32[i] = (float)l64[i];
+    }
+    RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    RR_CHECK_HIP(hipMemcpy(b->ffL64, l64.data(), l64.size() * 8, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->ffL32, l32.data(), l32.size() * 4, hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+// common host-buffer driver: stream rows up, run the kernel, stream the output down
+template <bool PHI>
+static int ff_host_call(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                        int n_ls, void *out, int out_dtype, int64_t ldo, const char *who) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_FASTFOOD, "%s: not a FastFood basis", who);
+    RR_REQUIRE((x_dtype == RR_F32 || x_dtype == RR_F64) && (out_dtype == RR_F32 || out_dtype == RR_F64), "%s: bad dtype", who);
+    const int64_t width = PHI ? 2 * (int64_t)b->n : (int64_t)b->n;
+    RR_REQUIRE(N >= 0 && ldx >= b->d && ldo >= width, "%s: bad shape", who);
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = ff_prepare_lenscale(b, lenscale, n_ls);
+    if (rc != RR_OK || N == 0) return rc;
+    RR_REQUIRE(X != nullptr && out != nullptr, "%s: null buffer", who);
+    const size_t xs = ff_dtype_size(x_dtype), os = ff_dtype_size(out_dtype);
+    int64_t chunk = (int64_t)(((size_t)1 << 30) / ((size_t)b->d * xs + (size_t)width * os));
+    if (chunk < 1) chunk = 1;
+    if (chunk > N) chunk = N;
+    void *dX = nullptr, *dO = nullptr;
+    if (hipMalloc(&dX, (size_t)chunk * b->d * xs) != hipSuccess || hipMalloc(&dO, (size_t)chunk * width * os) != hipSuccess) {
+        (void)hipGetLastError();
+        if (dX) (void)hipFree(dX);
+        rr_set_error("%s: device allocation failed", who);
+        return RR_ERR_OOM;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
+        const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
+        hipError_t e = hipMemcpy2DAsync(dX, (size_t)b->d * xs, (const char *)X + (size_t)r0 * ldx * xs, (size_t)ldx * xs,
+                                        (size_t)b->d * xs, (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) {
+            rc = ff_dispatch<PHI>(b, dX, x_dtype, m, b->d, dO, out_dtype, width);
+            if (rc != RR_OK) break;
+            e = hipMemcpy2DAsync((char *)out + (size_t)r0 * ldo * os, (size_t)ldo * os, dO, (size_t)width * os,
+                                 (size_t)width * os, (size_t)m, hipMemcpyDeviceToHost, c->stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("%s: copy/launch failed: %s", who, hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(dX);
+    (void)hipFree(dO);
+    return rc;
+}
+
+extern "C" {
+
+int rr_fastfood_create(rr_ctx *ctx, int compute, int d, int d2, int k, const int64_t *B, const double *G,
+                       const int64_t *PI, const double *S, rr_basis **out) {
+    RR_REQUIRE(ctx != nullptr && out != nullptr && B && G && PI && S, "rr_fastfood_create: null argument");
+    *out = nullptr;
+    RR_REQUIRE(d >= 1 && k >= 1 && d2 >= d && (d2 & (d2 - 1)) == 0, "rr_fastfood_create: need d2 = 2^p >= d, k >= 1");
+    RR_REQUIRE(d2 <= 256, "rr_fastfood_create: d2=%d > 256 is not supported yet", d2);
+    RR_REQUIRE(compute == RR_F32 || compute == RR_F64, "rr_fastfood_create: bad compute dtype %d", compute);
+    for (size_t i = 0; i < (size_t)k * d2; ++i)
+        RR_REQUIRE(PI[i] >= 0 && PI[i] < d2 && (B[i] == 1 || B[i] == -1), "rr_fastfood_create: bad B/PI entry at %zu", i);
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    const size_t cnt = (size_t)k * d2;
+    const double norm = pow((double)d2, -1.5);  // (1/d2)(1/d2) sqrt(d2): both WHT normalisations and :1368
+    const double inv2pi = 0.15915494309189533576888;
+    std::vector<double> b64(cnt), g64(G, G + cnt), srad64(cnt), srev64(cnt);
+    std::vector<float> b32(cnt), g32(cnt), srad32(cnt), srev32(cnt);
+    std::vector<int> pi(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+        b64[i] = (double)B[i];
+        srad64[i] = S[i] * norm;
+        srev64[i] = srad64[i] * inv2pi;
+        b32[i] = (float)b64[i];
+        g32[i] = (float)g64[i];
+        srad32[i] = (float)srad64[i];
+        srev32[i] = (float)srev64[i];
+        pi[i] = (int)PI[i];
+    }
+    rr_basis *b = new rr_basis();
+    b->ctx = ctx;
+    b->kind = RR_KIND_FASTFOOD;
+    b->compute = compute;
+    b->d = d;
+    b->n = d2 * k;
+    b->ff_d2 = d2;
+    b->ff_k = k;
+    hipError_t e = hipSuccess;
+#define RR_UP(dst, vec)                                                                       \
+    if (e == hipSuccess) e = hipMalloc((void **)&b->dst, (vec).size() * sizeof((vec)[0]));     \
+    if (e == hipSuccess) e = hipMemcpy(b->dst, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice);
+    RR_UP(ffB32, b32) RR_UP(ffB64, b64) RR_UP(ffG32, g32) RR_UP(ffG64, g64) RR_UP(ffSrad32, srad32)
+    RR_UP(ffSrad64, srad64) RR_UP(ffSrev32, srev32) RR_UP(ffSrev64, srev64) RR_UP(ffPI, pi)
+#undef RR_UP
+    if (e == hipSuccess) e = hipMalloc((void **)&b->ffL32, (size_t)d2 * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&b->ffL64, (size_t)d2 * 8);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_fastfood_create: device allocation failed: %s", hipGetErrorString(e));
+        rr_basis_destroy(b);
+        return RR_ERR_OOM;
+    }
+    *out = b;
+    return RR_OK;
+}
+
+int rr_fastfood_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                          int n_ls, void *Phi, int out_dtype, int64_t ldphi) {
+    return ff_host_call<true>(b, X, x_dtype, N, ldx, lenscale, n_ls, Phi, out_dtype, ldphi, "rr_fastfood_transform");
+}
+
+int rr_fastfood_vx(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale, int n_ls,
+                   void *VX, int out_dtype, int64_t ldvx) {
+    return ff_host_call<false>(b, X, x_dtype, N, ldx, lenscale, n_ls, VX, out_dtype, ldvx, "rr_fastfood_vx");
+}
+
+int rr_hadamard(rr_ctx *c, const void *Y, int dtype, int64_t rows, int64_t n, int ordering, void *out) {
+    RR_REQUIRE(c != nullptr, "rr_hadamard: null context");
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_hadamard: bad dtype");
+    RR_REQUIRE(rows >= 0 && n >= 1 && (n & (n - 1)) == 0, "rr_hadamard: length must be a power of two");
+    RR_REQUIRE(n <= 4096, "rr_hadamard: n=%lld > 4096 is not supported", (long long)n);
+    if (rows == 0) return RR_OK;
+    RR_REQUIRE(Y != nullptr && out != nullptr, "rr_hadamard: null buffer");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = ff_dtype_size(dtype);
+    const int64_t chunk = rows < 65535 ? rows : 65535;
+    void *dY = nullptr, *dO = nullptr;
+    if (hipMalloc(&dY, (size_t)chunk * n * es) != hipSuccess || hipMalloc(&dO, (size_t)chunk * n * es) != hipSuccess) {
+        (void)hipGetLastError();
+        if (dY) (void)hipFree(dY);
+        rr_set_error("rr_hadamard: device allocation failed");
+        return RR_ERR_OOM;
+    }
+    int rc = RR_OK;
+    for (int64_t r0 = 0; r0 < rows && rc == RR_OK; r0 += chunk) {
+        const int64_t m = rows - r0 < chunk ? rows - r0 : chunk;
+        hipError_t e = hipMemcpyAsync(dY, (const char *)Y + (size_t)r0 * n * es, (size_t)m * n * es, hipMemcpyHostToDevice,
+                                      c->stream);
+        if (e == hipSuccess) {
+            if (dtype == RR_F32)
+                hipLaunchKernelGGL(rr_hadamard_kernel<float>, dim3((unsigned)m), dim3(256), (size_t)n * 4, c->stream,
+                                   (const float *)dY, m, (int)n, ordering, (float *)dO);
+            else
+                hipLaunchKernelGGL(rr_hadamard_kernel<double>, dim3((unsigned)m), dim3(256), (size_t)n * 8, c->stream,
+                                   (const double *)dY, m, (int)n, ordering, (double *)dO);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((char *)out + (size_t)r0 * n * es, dO, (size_t)m * n * es, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_hadamard: copy/launch failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipFree(dY);
+    (void)hipFree(dO);
+    return rc;
+}
+
+}  // extern "C"

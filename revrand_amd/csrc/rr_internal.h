@@ -40,6 +40,11 @@ struct rr_basis {
     std::vector<hipEvent_t> events;  // 3 per row chunk of the last Gram call
     size_t events_used = 0;
     const char *gram_kernel = "";
+    // FastFood (kind == RR_KIND_FASTFOOD): (k, d2) diagonals / permutation, n = d2 * k
+    int ff_d2 = 0, ff_k = 0;
+    float *ffB32 = nullptr, *ffG32 = nullptr, *ffSrad32 = nullptr, *ffSrev32 = nullptr, *ffL32 = nullptr;
+    double *ffB64 = nullptr, *ffG64 = nullptr, *ffSrad64 = nullptr, *ffSrev64 = nullptr, *ffL64 = nullptr;
+    int *ffPI = nullptr;
 };
 
 void rr_set_error(const char *fmt, ...);

@@ -27,3 +27,14 @@ def solve_posdef(A, b):
         m = b.shape[1] if np.ndim(b) > 1 else 1
         X = left.dot(right.dot(b)) if m < n else left.dot(right).dot(b)
         return X, np.log(s).sum()
+
+
+def hadamard(Y, ordering=True):
+    """Fast Walsh-Hadamard transform of each row of Y (rows, 2^p), normalised by 1/n
+    (mathfun/linalg.py:182-220); ``ordering=True`` reorders from natural to sequency order.
+    Runs on the GPU (``rr_hadamard``)."""
+    from . import _hip
+    Y = np.asarray(Y)
+    n = Y.shape[1]
+    assert n & (n - 1) == 0  # required, as in the reference (:211)
+    return _hip.hadamard(Y, ordering=ordering)

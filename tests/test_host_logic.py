@@ -148,3 +148,16 @@ def test_solve_posdef(golden):
         assert np.abs(X - g[tag + "_X"]).max() < 1e-9 * np.abs(g[tag + "_X"]).max()
         if np.isfinite(g[tag + "_logdet"]):
             assert abs(ld - g[tag + "_logdet"]) < 1e-9 * abs(ld)
+
+
+@pytest.mark.parametrize("case", [(1, 10), (2, 10), (5, 16), (16, 64), (128, 256)])
+def test_fastfood_matrices_match_reference(golden, case):
+    d, nb = case
+    g = golden("fastfood")
+    k = "d%d_nb%d" % (d, nb)
+    b = bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=3)
+    assert np.array_equal(b.B, g[k + "_B"]) and np.array_equal(b.PI, g[k + "_PI"])
+    assert np.array_equal(b.G, g[k + "_G"])
+    assert np.abs(b.S - g[k + "_S"]).max() < 1e-13 * np.abs(b.S).max()
+    assert b.n == b.d2 * b.k and b.get_dim(None) == 2 * b.n
+    assert "FastFoodRBF(nbases=%d, Xdim=%d" % (nb, d) in repr(b)
