@@ -35,7 +35,7 @@ struct rr_basis {
     double *dWs64 = nullptr;      // same in f64
     float *dgfac32 = nullptr;     // (d,): 2pi / l_i  (grad kernels)
     double *dgfac64 = nullptr;
-    float *zbuf = nullptr;        // phase scratch of the Gram path (rows, npad) f32, grow-only
+    void *zbuf = nullptr;         // feature scratch of the Gram path (f32 or f64), grow-only
     size_t zbuf_bytes = 0;
     std::vector<hipEvent_t> events;  // 3 per row chunk of the last Gram call
     size_t events_used = 0;

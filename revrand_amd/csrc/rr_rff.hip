@@ -139,30 +139,30 @@ constexpr int GR_KB = 32;    // rows per k-block
 constexpr int GR_LD = 512;   // LDS tile row length (floats): [A side 256 | B side 256]
 constexpr int GR_THREADS = 512;
 
-template <int DMAX, bool HAS_Y, typename TX>
+template <int DMAX, bool HAS_Y, typename TX, typename TC>
 __global__ void __launch_bounds__(256)
 rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad,
-                       int64_t ldx, const float *__restrict__ Ws, int n, int npad, float *__restrict__ P,
-                       int64_t ldp, double *__restrict__ bvec, float scale, int rows_per_block) {
+                       int64_t ldx, const TC *__restrict__ Ws, int n, int npad, TC *__restrict__ P,
+                       int64_t ldp, double *__restrict__ bvec, TC scale, int rows_per_block) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     const bool fvalid = f < n;
-    float w[DMAX];
-    load_w<DMAX, float>(w, Ws, npad, f < npad ? f : 0);
+    TC w[DMAX];
+    load_w<DMAX, TC>(w, Ws, npad, f < npad ? f : 0);
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > Npad) r1 = Npad;
-    float bc = 0.f, bs = 0.f;
+    TC bc = 0, bs = 0;
     for (int64_t r = r0; r < r1; ++r) {
-        float c = 0.f, s = 0.f;
+        TC c = 0, s = 0;
         if (r < N) {  // uniform
-            const float t = project_row<DMAX, false, TX, float>(X + r * ldx, DMAX, w);
+            const TC t = project_row<DMAX, false, TX, TC>(X + r * ldx, DMAX, w);
             sincos_rev(t, s, c);
             c *= scale;
             s *= scale;
             if (HAS_Y) {
-                const float yv = (float)y[r];
-                bc = fmaf(c, yv, bc);
-                bs = fmaf(s, yv, bs);
+                const TC yv = (TC)y[r];
+                bc = fma(c, yv, bc);
+                bs = fma(s, yv, bs);
             }
         }
         if (fvalid) {
@@ -177,10 +177,11 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
 }
 
 // zero the pad columns [F, Fp) of a feature matrix (the feature kernels only write [0, F))
-__global__ void __launch_bounds__(256) rr_zero_padcols_kernel(float *P, int64_t rows, int64_t ldp, int F) {
+template <typename TC>
+__global__ void __launch_bounds__(256) rr_zero_padcols_kernel(TC *P, int64_t rows, int64_t ldp, int F) {
     const int w = (int)ldp - F;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w > 0 && i < rows * w) P[(i / w) * ldp + F + (i % w)] = 0.f;
+    if (w > 0 && i < rows * w) P[(i / w) * ldp + F + (i % w)] = TC(0);
 }
 
 struct SyrkArgs {
@@ -344,6 +345,148 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
     }
     (void)diag;
 }
+
+// ---------------------------------------------------------------------------------------
+// f64 Gram: G(upper) += P^T P with v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s peak).  Same structure
+// as the f32 kernel at half the tile: 128x128 block of G per workgroup of 4 waves (64x64 per
+// wave = 16 accumulators of 4 f64), k-blocks of 16 rows arriving by LDS-DMA as [16][128 | 128]
+// f64 with the row stride padded by 128 B so that the 4 rows of a k-step fall on different
+// bank halves (conflict-free ds_read_b64), two workgroups per CU (68 KiB of LDS each).
+// ---------------------------------------------------------------------------------------
+constexpr int G64_TC = 128;            // columns per tile side
+constexpr int G64_KB = 16;             // rows per k-block
+constexpr int G64_LDB = 2 * G64_TC * 8 + 128;  // LDS row stride in bytes (2048 + 128 pad)
+constexpr int G64_THREADS = 256;
+typedef double doublex4 __attribute__((ext_vector_type(4)));
+
+struct Syrk64Args {
+    const double *P;  // (rows, ldp) f64 features, zero padded; rows % 16 == 0, ldp % 128 == 0
+    int64_t rows, ldp;
+    int F, nb, ntiles;
+    int64_t rows_per_split;  // multiple of 16
+    double *G;
+};
+
+template <int OFF>
+__device__ __forceinline__ double lds_read_b64(unsigned addr) {
+    double r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+
+struct KOps64 {
+    double a[4], b[4];
+    // k-step T: rows 4T + (lane >> 4) (folded into the bases); block i at + i * 16 columns
+    template <int T>
+    __device__ __forceinline__ void load(unsigned abase, unsigned bbase) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = 0;
+        a[0] = lds_read_b64<4 * T * G64_LDB + 0 * 128>(abase);
+        a[1] = lds_read_b64<4 * T * G64_LDB + 1 * 128>(abase);
+        a[2] = lds_read_b64<4 * T * G64_LDB + 2 * 128>(abase);
+        a[3] = lds_read_b64<4 * T * G64_LDB + 3 * 128>(abase);
+        b[0] = lds_read_b64<4 * T * G64_LDB + 0 * 128>(bbase);
+        b[1] = lds_read_b64<4 * T * G64_LDB + 1 * 128>(bbase);
+        b[2] = lds_read_b64<4 * T * G64_LDB + 2 * 128>(bbase);
+        b[3] = lds_read_b64<4 * T * G64_LDB + 3 * 128>(bbase);
+    }
+};
+
+template <int FIRST, int LAST>
+__device__ __forceinline__ void gram64_mfma(const KOps64 &o, doublex4 (&acc)[4][4]) {
+#pragma unroll
+    for (int q = FIRST; q < LAST; ++q)
+        acc[q >> 2][q & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[q >> 2], o.b[q & 3], acc[q >> 2][q & 3], 0, 0, 0);
+}
+
+#define RR_STEP64(T, CUR, NXT)                                  \
+    lds_wait();                                                 \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    gram64_mfma<0, 1>(CUR, acc);                                \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    if ((T) + 1 < 4) NXT.template load<((T) + 1) & 3>(abase, bbase); \
+    __builtin_amdgcn_sched_barrier(0);                          \
+    gram64_mfma<1, 16>(CUR, acc);                               \
+    __builtin_amdgcn_sched_barrier(0);
+
+__global__ void __launch_bounds__(G64_THREADS, 2)
+rr_syrk_f64_kernel(const Syrk64Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G64_KB * G64_LDB];  // 68 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tdx = blockIdx.x % p.ntiles;
+    const int ks = blockIdx.x / p.ntiles;
+    int ta = 0;
+    while (tdx >= p.nb - ta) {
+        tdx -= p.nb - ta;
+        ++ta;
+    }
+    const int tb = ta + tdx;
+    const int ca = ta * G64_TC, cb = tb * G64_TC;
+
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+
+    // wave (wr, wc): rows [wr*64, +64) of side A x cols [wc*64, +64) of side B
+    const int wr = wave >> 1, wc_ = wave & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned aoff = (lane >> 4) * G64_LDB + 8u * (wr * 64 + (lane & 15));
+    const unsigned boff = (lane >> 4) * G64_LDB + 8u * (G64_TC + wc_ * 64 + (lane & 15));
+    doublex4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+
+    // DMA: 16 rows x 2 sides = 32 row segments of 1 KiB; wave w moves rows 4w..4w+3
+    auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const double *src = p.P + (kb0 + lr) * p.ldp + 2 * lane;  // 16 B per lane
+            unsigned char *dst = buf + lr * G64_LDB;
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + ca), (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + cb), (lptr_t)(dst + G64_TC * 8), 16, 0, 0);
+        }
+    };
+
+    const int64_t nkb = (row_end - row_begin) / G64_KB;
+    if (nkb > 0) {
+        dma_tile(lds, row_begin);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (G64_KB * G64_LDB), row_begin + (kb + 1) * G64_KB);
+            const unsigned abase = lds0 + cbuf * (G64_KB * G64_LDB) + aoff;
+            const unsigned bbase = lds0 + cbuf * (G64_KB * G64_LDB) + boff;
+            KOps64 o0, o1;
+            o0.load<0>(abase, bbase);
+            RR_STEP64(0, o0, o1) RR_STEP64(1, o1, o0) RR_STEP64(2, o0, o1) RR_STEP64(3, o1, o0)
+            __syncthreads();
+        }
+    }
+
+    // flush (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg)
+    const int64_t F = p.F;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t gc = cb + wc_ * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t gr = ca + wr * 64 + i * 16 + (lane >> 4) + 4 * e;
+                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], acc[i][j][e]);
+            }
+        }
+}
+#undef RR_STEP64
 
 // Host feature matrices of ANY basis (concatenations, LinearBasis, ...) reach the SYRK kernel
 // through this repack: (rows, F) f32|f64 with leading dimension lds -> zero-padded f32 (rows_pad, ldp).
@@ -543,31 +686,54 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     return RR_OK;
 }
 
-template <typename TX>
-static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t N, int64_t ldx, double *dG,
-                           double *db) {
+int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG) {
+    const int nb = (int)(ldp / G64_TC);
+    const int ntiles = nb * (nb + 1) / 2;
+    const int64_t slots = (int64_t)c->num_cu * 2;  // two workgroups per CU
+    int64_t nsplit = (slots * 4 + ntiles - 1) / ntiles;  // ~4 rounds of workgroups
+    if (rows / nsplit < 512) nsplit = (rows + 511) / 512;
+    if (nsplit < 1) nsplit = 1;
+    const int64_t rps = ((rows + nsplit - 1) / nsplit + G64_KB - 1) / G64_KB * G64_KB;
+    nsplit = (rows + rps - 1) / rps;
+    RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+    Syrk64Args a;
+    a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
+    hipLaunchKernelGGL(rr_syrk_f64_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(G64_THREADS), 0, c->stream, a);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// TC = float: f32 features + rr_syrk_f32_kernel;  TC = double: f64 features + rr_syrk_f64_kernel
+template <typename TX, typename TC>
+static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, int64_t ldx, double *dG,
+                       double *db) {
     rr_ctx *c = b->ctx;
+    constexpr bool F32 = sizeof(TC) == 4;
+    constexpr int TCOLS = F32 ? GR_TC : G64_TC;
+    constexpr int KB = F32 ? GR_KB : G64_KB;
     const int F = 2 * b->n;
-    const int64_t ldp = ((int64_t)F + GR_TC - 1) / GR_TC * GR_TC;
-    const float scale = (float)(1.0 / sqrt((double)b->n));
-    // row chunks: feature scratch of at most ~32 GiB (or RR_GRAM_CHUNK_ROWS), multiple of 32 rows
-    int64_t chunk = (int64_t)(((size_t)32 << 30) / ((size_t)ldp * sizeof(float)));
+    const int64_t ldp = ((int64_t)F + TCOLS - 1) / TCOLS * TCOLS;
+    const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    const TC *Ws = F32 ? (const TC *)b->dWs32 : (const TC *)b->dWs64;
+    // row chunks: feature scratch of at most ~32 GiB (or RR_GRAM_CHUNK_ROWS), multiple of KB rows
+    int64_t chunk = (int64_t)(((size_t)32 << 30) / ((size_t)ldp * sizeof(TC)));
     const char *cenv = getenv("RR_GRAM_CHUNK_ROWS");
-    if (cenv && atoll(cenv) >= GR_KB) chunk = atoll(cenv);
+    if (cenv && atoll(cenv) >= KB) chunk = atoll(cenv);
     if (chunk > N) chunk = N;
-    chunk = (chunk + GR_KB - 1) / GR_KB * GR_KB;
-    int rc = ensure_zbuf(b, (size_t)chunk * ldp * sizeof(float));
+    chunk = (chunk + KB - 1) / KB * KB;
+    int rc = ensure_zbuf(b, (size_t)chunk * ldp * sizeof(TC));
     if (rc != RR_OK) return rc;
+    TC *P = (TC *)b->zbuf;
     if (ldp > F) {  // pad columns are never written by the feature kernel: zero them once per call
         const int64_t cnt = chunk * (ldp - F);
-        hipLaunchKernelGGL(rr_zero_padcols_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
-                           b->zbuf, chunk, ldp, F);
+        hipLaunchKernelGGL(rr_zero_padcols_kernel<TC>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
+                           P, chunk, ldp, F);
         RR_CHECK_HIP(hipGetLastError());
     }
 
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
-        const int64_t mpad = (m + GR_KB - 1) / GR_KB * GR_KB;
+        const int64_t mpad = (m + KB - 1) / KB * KB;
         const TX *Xc = (const TX *)dX + r0 * ldx;
         const TX *yc = dy ? (const TX *)dy + r0 : nullptr;
         // three events per chunk bracket the two kernels (read back by rr_rff_gram_timings)
@@ -584,12 +750,12 @@ static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t 
             int64_t rpb = 256;
             if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
             const dim3 grid(fblocks, (unsigned)((mpad + rpb - 1) / rpb));
-#define RR_LPH(DM)                                                                                             \
-    do {                                                                                                       \
-        if (yc) hipLaunchKernelGGL((rr_rff_features_kernel<DM, true, TX>), grid, dim3(256), 0, c->stream, Xc,  \
-                                   yc, m, mpad, ldx, b->dWs32, b->n, b->npad, b->zbuf, ldp, db, scale, (int)rpb); \
-        else hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, TX>), grid, dim3(256), 0, c->stream, Xc,    \
-                                yc, m, mpad, ldx, b->dWs32, b->n, b->npad, b->zbuf, ldp, db, scale, (int)rpb); \
+#define RR_LPH(DM)                                                                                               \
+    do {                                                                                                         \
+        if (yc) hipLaunchKernelGGL((rr_rff_features_kernel<DM, true, TX, TC>), grid, dim3(256), 0, c->stream, Xc, \
+                                   yc, m, mpad, ldx, Ws, b->n, b->npad, P, ldp, db, scale, (int)rpb);            \
+        else hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, TX, TC>), grid, dim3(256), 0, c->stream, Xc,  \
+                                yc, m, mpad, ldx, Ws, b->n, b->npad, P, ldp, db, scale, (int)rpb);               \
     } while (0)
             switch (b->dpad) {
                 case 8: RR_LPH(8); break;
@@ -604,12 +770,13 @@ static int launch_gram_f32(rr_basis *b, const void *dX, const void *dy, int64_t 
         }
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
         // (B) G += P^T P
-        rc = rr_launch_syrk_f32(c, b->zbuf, mpad, ldp, F, dG);
+        if constexpr (F32) rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG);
+        else rc = rr_launch_syrk_f64(c, P, mpad, ldp, F, dG);
         if (rc != RR_OK) return rc;
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
         b->events_used = e0 + 3;
     }
-    b->gram_kernel = "rr_syrk_f32_kernel";
+    b->gram_kernel = F32 ? "rr_syrk_f32_kernel" : "rr_syrk_f64_kernel";
     return RR_OK;
 }
 
@@ -812,12 +979,12 @@ int rr_rff_gram_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, in
     RR_REQUIRE(dX != nullptr, "rr_rff_gram_dev: null X");
     rr_ctx *c = b->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
-    if (b->compute != RR_F32) {
-        rr_set_error("rr_rff_gram_dev: f64 Gram kernel not built yet");
-        return RR_ERR_UNSUPPORTED;
-    }
-    rc = (x_dtype == RR_F32) ? launch_gram_f32<float>(b, dX, dy, N, ldx, dG, db)
-                             : launch_gram_f32<double>(b, dX, dy, N, ldx, dG, db);
+    if (b->compute == RR_F32)
+        rc = (x_dtype == RR_F32) ? launch_gram<float, float>(b, dX, dy, N, ldx, dG, db)
+                                 : launch_gram<double, float>(b, dX, dy, N, ldx, dG, db);
+    else
+        rc = (x_dtype == RR_F32) ? launch_gram<float, double>(b, dX, dy, N, ldx, dG, db)
+                                 : launch_gram<double, double>(b, dX, dy, N, ldx, dG, db);
     if (rc != RR_OK) return rc;
     if (dy) {
         int blocks = (int)((N + 255) / 256);

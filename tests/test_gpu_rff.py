@@ -169,3 +169,26 @@ def test_gram_linearity_and_sharding():
     G2 = dev.download(dG, (F, F), np.float64)
     b2 = dev.download(db, (F + 1,), np.float64)
     assert normwise(G2, G) < 1e-6 and normwise(b2[:F], bv) < 1e-6 and abs(b2[F] - yty) < 1e-9 * yty
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4), (500, 4, 16), (4099, 8, 130), (3000, 32, 200), (1500, 21, 260),
+                                   (20000, 8, 128), (1000, 64, 64), (700, 100, 70)])
+def test_gram_f64_vs_oracle(shape):
+    """f64 mode (v_mfma_f64_16x16x4_f64): 1e-5 relative by BASELINE, ~1e-12 in practice."""
+    N, d, n = shape
+    rs = np.random.RandomState(N + n)
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    b = _make("RandomMatern32", d, n, 2, True, "f64")
+    ls = np.linspace(0.8, 1.6, d)
+    G, bv, yty = b.gram(X, y, ls)
+    Gr, br, ytyr = orc.rff_gram_chunked(X, y, b.W, ls)
+    assert np.array_equal(G, G.T)
+    assert normwise(G, Gr) < 1e-10 and normwise(bv, br) < 1e-10 and abs(yty - ytyr) < 1e-12 * ytyr
+    m, C, _ = orc.slm_posterior_from_stats(G, bv, 0.5, np.full(2 * n, 1.0))
+    mr, Cr, _ = orc.slm_posterior_from_stats(Gr, br, 0.5, np.full(2 * n, 1.0))
+    assert normwise(m, mr) < 1e-5 and normwise(C, Cr) < 1e-5
+    # float32 inputs with f64 arithmetic promote exactly like the reference's np.dot
+    X32 = X.astype(np.float32)
+    G32, _, _ = b.gram(X32, None, ls)
+    assert normwise(G32, orc.rff_gram_chunked(X32.astype(np.float64), y, b.W, ls)[0]) < 1e-10

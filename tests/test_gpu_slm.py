@@ -138,3 +138,25 @@ def test_sklearn_protocol():
     from sklearn.exceptions import NotFittedError
     with pytest.raises(NotFittedError):
         c.predict(Xs)
+
+
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+def test_elbo_f64_mode_vs_reference(golden, tag):
+    """dtype='f64': the whole `_elbo` within 1e-5 of the reference (BASELINE fp64 tolerance).
+    (The hyper-gradient's cross-Gram still runs through the f32 SYRK: 1e-3 there.)"""
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    lsp = Parameter(1., Positive()) if tag == "iso" else Parameter(np.ones(d), Positive())
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=lsp, dtype="f64")
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    ls = float(g[tag + "_ls"]) if tag == "iso" else g[tag + "_ls"]
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), float(g["reg"]), ls)
+    assert abs(-nelbo - g[tag + "_elbo"]) < 1e-9 * abs(g[tag + "_elbo"])
+    assert normwise(slm.weights_, g[tag + "_m"]) < 1e-5
+    assert normwise(slm.covariance_, g[tag + "_C"]) < 1e-5
+    assert normwise(-ndvar, g[tag + "_dvar"]) < 1e-5
+    assert normwise(-np.atleast_1d(ndreg), g[tag + "_dreg"]) < 1e-5
+    assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 2e-3
