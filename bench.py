@@ -94,7 +94,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from revrand_amd import _hip
+    from revrand_amd import _hip, parallel
     dev = _hip.get_device(local_rank)
     d, n = args.dim, args.nbases
     F = 2 * n
@@ -141,7 +141,7 @@ def main():
                 kernel_ms.append(basis.gram_timings())  # HIP events on the kernels' own stream
         dev.sync()
         if world > 1:
-            dist.all_reduce(acc_t)  # RCCL over xGMI: the one exchange step of the path
+            parallel.allreduce_packed(acc_t)  # RCCL over xGMI: the one exchange step of the path
             torch.cuda.synchronize()
         _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
         dev.sync()
