@@ -30,6 +30,15 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
 
+# HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools_prof.sh),
+# corrected as MI355X_MICROARCH.md prescribes; the committed summary is quoted, per launch.
+TRAFFIC = {}
+try:
+    with open(os.path.join(ROOT, "profiles", "traffic.json")) as _f:
+        TRAFFIC = json.load(_f)
+except Exception:
+    pass
+
 
 def flops_per_row(d, n):
     F = 2 * n
@@ -177,29 +186,39 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = args.rows / (elapsed / max(args.steps, 1))
-        # dominant kernel: the Gram-from-phases kernel.  Its algorithmic work is the upper-triangle
-        # Gram F(F+1) flops/row; the projection 2dn and Phi^T y 2F belong to the phase kernel.
-        phase_ms = float(np.mean([k[0] for k in kernel_ms])) if kernel_ms else float("nan")
-        gram_ms = float(np.mean([k[1] for k in kernel_ms])) if kernel_ms else float("nan")
-        launches = kernel_ms[0][2] if kernel_ms else 0
-        gram_flops_row = F * (F + 1.0)
-        achieved = gram_flops_row * my_rows / (gram_ms * 1e-3) / 1e12 if kernel_ms else float("nan")
+        # Kernels of one step: features (projection + cos/sin + Phi^T y), off-diagonal SYRK (dominant),
+        # diagonal SYRK.  Algorithmic work per row (upper triangle incl. diagonal, 2 flop per
+        # entry): off-diagonal tiles 2 sum_{i<j} w_i w_j, diagonal tiles sum_i w_i (w_i + 1), w_i = valid
+        # columns of 256-column block i; the projection 2dn and Phi^T y 2F belong to the features kernel.
+        feat_ms = float(np.mean([k[0] for k in kernel_ms])) if kernel_ms else float("nan")
+        syrk_ms = float(np.mean([k[1] for k in kernel_ms])) if kernel_ms else float("nan")
+        diag_ms = float(np.mean([k[2] for k in kernel_ms])) if kernel_ms else float("nan")
+        launches = kernel_ms[0][3] if kernel_ms else 0
+        widths = [min(256, F - 256 * i) for i in range((F + 255) // 256)]
+        off_flops = 2.0 * sum(widths[i] * widths[j] for i in range(len(widths)) for j in range(i + 1, len(widths)))
+        diag_flops = float(sum(w * (w + 1) for w in widths))
+        assert off_flops + diag_flops == F * (F + 1.0)
+        achieved = off_flops * my_rows / (syrk_ms * 1e-3) / 1e12 if kernel_ms else float("nan")
+        gram_tf = (off_flops + diag_flops) * my_rows / ((syrk_ms + diag_ms) * 1e-3) / 1e12 if kernel_ms else float("nan")
         out = {
             "metric": "feature-rows/sec (Phi + PhiT Phi + PhiT y) at N=%s D=%d F=%d" % (
                 "10M" if args.rows == 10_000_000 else args.rows, d, F),
             "value": value, "unit": "feature-rows/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, fused Phi+Gram, rows sharded "
+            "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, features + MFMA Gram, rows sharded "
                                    "over %d GPU(s)" % (n, F, d, args.rows, world),
                        "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err},
-            "roofline": {"bound": "mfma", "kernel": basis.gram_kernel_name(), "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "rr_syrk_f32_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel_ms_per_step": gram_ms, "launches_per_step": launches,
-                         "avg_launch_ms": gram_ms / max(launches, 1),
-                         "flops_per_row": gram_flops_row, "rows_per_step": my_rows,
-                         "other_kernels_ms_per_step": {"rr_rff_features_kernel": phase_ms},
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": TRAFFIC.get("hbm_bytes"),
+                         "traffic_note": TRAFFIC.get("note"),
+                         "kernel_ms_per_step": syrk_ms, "launches_per_step": launches,
+                         "avg_launch_ms": syrk_ms / max(launches, 1),
+                         "flops_per_row": off_flops, "rows_per_step": my_rows,
+                         "other_kernels_ms_per_step": {"rr_syrk_f32_diag_kernel": diag_ms,
+                                                       "rr_rff_features_kernel": feat_ms},
+                         "gram_both_kernels_frac": gram_tf / PEAK_F32_MFMA_TFLOPS,
                          "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
                          / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }

@@ -146,9 +146,11 @@ int rr_rff_gram_dev(rr_basis *basis, const void *dX, const void *dy, int x_dtype
                     double *dyty);
 
 /* HIP-event times of the kernels the LAST rr_rff_gram_dev call launched on this basis, summed
- * over its row chunks: the phase/projection kernel and the Gram kernel (the dominant one).
- * Waits for the stream.  launches = number of row chunks (= launches of each kernel). */
-int rr_rff_gram_timings(rr_basis *basis, float *phase_ms, float *gram_ms, int *launches);
+ * over its row chunks: the feature (projection + cos/sin) kernel, the off-diagonal-tile SYRK
+ * kernel (the dominant one) and the diagonal-tile SYRK kernel (0 in f64 mode, where one kernel
+ * does all tiles and is reported as syrk_ms).  Waits for the stream.  launches = number of row
+ * chunks (= launches of each kernel). */
+int rr_rff_gram_timings(rr_basis *basis, float *features_ms, float *syrk_ms, float *diag_ms, int *launches);
 
 /* Mirror the upper triangle of a device (F, F) float64 matrix into the lower. */
 int rr_symmetrize_dev(rr_ctx *ctx, double *dG, int64_t F);

@@ -61,7 +61,8 @@ SIGNATURES = {
                                        ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_rff_gram_timings": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float),
-                                           ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int)]),
+                                           ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float),
+                                           ctypes.POINTER(ctypes.c_int)]),
     "rr_symmetrize_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64]),
     "rr_rff_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                    ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
@@ -468,10 +469,11 @@ class RffHandle(object):
                                                   dX.ld, lsp, nls, _ptr(dG), _ptr(db), _ptr(dyty)))
 
     def gram_timings(self):
-        """(phase_kernel_ms, gram_kernel_ms, launches) of the last gram_dev call (waits for it)."""
-        a, g, k = ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
-        _check(self.lib, self.lib.rr_rff_gram_timings(self.h, ctypes.byref(a), ctypes.byref(g), ctypes.byref(k)))
-        return a.value, g.value, k.value
+        """(features_ms, syrk_ms, diag_ms, launches) of the last gram_dev call (waits for it)."""
+        a, g, d, k = ctypes.c_float(), ctypes.c_float(), ctypes.c_float(), ctypes.c_int()
+        _check(self.lib, self.lib.rr_rff_gram_timings(self.h, ctypes.byref(a), ctypes.byref(g), ctypes.byref(d),
+                                                      ctypes.byref(k)))
+        return a.value, g.value, d.value, k.value
 
     def symmetrize_dev(self, dG):
         _check(self.lib, self.lib.rr_symmetrize_dev(self.dev.ctx, _ptr(dG), 2 * self.n))

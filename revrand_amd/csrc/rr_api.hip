@@ -78,6 +78,7 @@ void rr_ctx_destroy(rr_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    if (ctx->tile_map) (void)hipFree(ctx->tile_map);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

@@ -18,6 +18,8 @@ struct rr_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipDeviceProp_t prop;
     int num_cu = 0;
+    int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
+    int tile_map_nb = 0;
 };
 
 enum rr_kind { RR_KIND_RFF = 0, RR_KIND_FASTFOOD = 1 };
@@ -37,7 +39,7 @@ struct rr_basis {
     double *dgfac64 = nullptr;
     void *zbuf = nullptr;         // feature scratch of the Gram path (f32 or f64), grow-only
     size_t zbuf_bytes = 0;
-    std::vector<hipEvent_t> events;  // 3 per row chunk of the last Gram call
+    std::vector<hipEvent_t> events;  // 4 per row chunk of the last Gram call
     size_t events_used = 0;
     const char *gram_kernel = "";
     // FastFood (kind == RR_KIND_FASTFOOD): (k, d2) diagonals / permutation, n = d2 * k

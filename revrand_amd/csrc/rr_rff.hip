@@ -192,6 +192,9 @@ struct SyrkArgs {
     int ntiles;  // nb (nb + 1) / 2
     int64_t rows_per_split;  // multiple of 32
     double *G;   // (F, F) f64, upper triangle accumulated
+    const int *tile_map;  // optional (ntiles): position in dispatch order -> tile id (XCD-aware), or null
+    int offdiag_only;     // 1: enumerate only tiles with ta < tb (the diagonal ones go to the diag kernel)
+    int ablate;  // debug (RR_GRAM_ABLATE): bit0 = no in-loop DMA, bit1 = no in-loop barrier
 };
 
 typedef __attribute__((address_space(1))) const void *gptr_t;
@@ -284,15 +287,19 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // tile (ta <= tb) and K-split of this workgroup
+    // tile (ta <= tb) and K-split of this workgroup.  Workgroups are dispatched round-robin over
+    // the 8 XCDs (block b -> XCD b % 8, observed); tile_map orders the tiles so that the ones an
+    // XCD receives share column blocks of P and its 4 MiB L2 fetches each of them once.
     int tdx = blockIdx.x % p.ntiles;
     const int ks = blockIdx.x / p.ntiles;
+    if (p.tile_map) tdx = p.tile_map[tdx];
     int ta = 0;
-    while (tdx >= p.nb - ta) {
-        tdx -= p.nb - ta;
+    const int od = p.offdiag_only;  // row ta then holds nb - ta - od tiles
+    while (tdx >= p.nb - ta - od) {
+        tdx -= p.nb - ta - od;
         ++ta;
     }
-    const int tb = ta + tdx;
+    const int tb = ta + tdx + od;
     const bool diag = (ta == tb);
     const int ca = ta * GR_TC, cb = tb * GR_TC;
 
@@ -322,9 +329,9 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
             float *nxt = lds + (cbuf ^ 1) * (GR_KB * GR_LD);
             // tile kb+1 flies while tile kb is consumed (its buffer was last read before the
             // barrier that ended iteration kb-1)
-            if (kb + 1 < nkb) syrk_dma_tile(p, nxt, row_begin + (kb + 1) * GR_KB, wave, lane, ca, cb);
+            if (kb + 1 < nkb && !(p.ablate & 1)) syrk_dma_tile(p, nxt, row_begin + (kb + 1) * GR_KB, wave, lane, ca, cb);
             gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
-            __syncthreads();
+            if (!(p.ablate & 2)) __syncthreads();
         }
     }
 
@@ -345,6 +352,257 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
     }
     (void)diag;
 }
+
+// ---------------------------------------------------------------------------------------
+// Diagonal tiles (ta == tb) of the f32 SYRK.  Of the 64 32x32 blocks of a diagonal 256x256 tile
+// only the 36 with block-row <= block-column are needed.  They are dealt to the 8 waves 5 + 4 per
+// SIMD pair (waves w and w+4 share a SIMD), the 4-block waves carrying one dummy block, so a
+// diagonal workgroup issues 5 instead of 8 MFMAs per k-step and needs only the A side of the tile
+// (32 KiB of DMA per k-block).  Launched as its own kernel after the off-diagonal one.
+// ---------------------------------------------------------------------------------------
+__constant__ unsigned char RR_DIAG_I[8][5] = {{0, 0, 0, 0, 0}, {1, 1, 1, 1, 1}, {2, 2, 2, 2, 2}, {3, 3, 3, 3, 3},
+                                              {0, 0, 0, 7, 0}, {1, 1, 6, 6, 1}, {2, 5, 5, 5, 2}, {4, 4, 4, 4, 4}};
+__constant__ unsigned char RR_DIAG_J[8][5] = {{0, 1, 2, 3, 4}, {1, 2, 3, 4, 5}, {2, 3, 4, 5, 6}, {3, 4, 5, 6, 7},
+                                              {5, 6, 7, 7, 5}, {6, 7, 6, 7, 6}, {7, 5, 6, 7, 7}, {4, 5, 6, 7, 4}};
+
+struct KOpsD {
+    float2v a[5], b[5];
+    template <int P>
+    __device__ __forceinline__ void load(const unsigned (&abase)[5], const unsigned (&bbase)[5]) {
+#pragma unroll
+        for (int e = 0; e < 5; ++e) a[e] = lds_read2st64<16 * P, 16 * P + 8>(abase[e]);
+#pragma unroll
+        for (int e = 0; e < 5; ++e) b[e] = lds_read2st64<16 * P, 16 * P + 8>(bbase[e]);
+    }
+};
+
+template <int FIRST, int LAST>
+__device__ __forceinline__ void gram_mfma_d(const KOpsD &o, floatx16 (&acc)[5]) {
+#pragma unroll
+    for (int q = FIRST; q < LAST; ++q)
+        acc[q % 5] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[q % 5][q / 5], o.b[q % 5][q / 5], acc[q % 5], 0, 0, 0);
+}
+
+#define RR_PAIRD(P, CUR, NXT)                                  \
+    lds_wait();                                                \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_d<0, 1>(CUR, acc);                               \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase); \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_d<1, 10>(CUR, acc);                              \
+    __builtin_amdgcn_sched_barrier(0);
+
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_f32_diag_kernel(const SyrkArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_TC];  // 64 KiB: two [32][256] tiles (A side only)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ta = blockIdx.x % p.nb;
+    const int ks = blockIdx.x / p.nb;
+    const int ca = ta * GR_TC;
+
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned lane_off = 4u * ((lane >> 5) * GR_TC + (lane & 31));  // row stride 1024 B = 4 units of 256 B
+    int bi[5], bj[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        bi[e] = RR_DIAG_I[wave][e];
+        bj[e] = RR_DIAG_J[wave][e];
+    }
+    floatx16 acc[5];
+#pragma unroll
+    for (int e = 0; e < 5; ++e)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[e][k] = 0.f;
+
+    // DMA: 32 row segments of 1 KiB per k-block; wave w moves rows 4w..4w+3
+    auto dma_tile = [&](float *buf, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * GR_TC), 16, 0, 0);
+        }
+    };
+
+    const int64_t nkb = (row_end - row_begin) / GR_KB;
+    if (nkb > 0) {
+        dma_tile(lds, row_begin);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_TC), row_begin + (kb + 1) * GR_KB);
+            unsigned abase[5], bbase[5];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                abase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bi[e];
+                bbase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bj[e];
+            }
+            KOpsD o0, o1;
+            o0.load<0>(abase, bbase);
+            RR_PAIRD(0, o0, o1) RR_PAIRD(1, o1, o0) RR_PAIRD(2, o0, o1) RR_PAIRD(3, o1, o0)
+            RR_PAIRD(4, o0, o1) RR_PAIRD(5, o1, o0) RR_PAIRD(6, o0, o1) RR_PAIRD(7, o1, o0)
+            __syncthreads();
+        }
+    }
+
+    const int64_t F = p.F;
+    const int hi = lane >> 5;
+    const int nblk = wave < 4 ? 5 : 4;  // the 5th block of waves 4-7 is the dummy
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+        if (e < nblk) {
+            const int64_t gc = ca + 32 * bj[e] + (lane & 31);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t gr = ca + 32 * bi[e] + (k & 3) + 8 * (k >> 2) + 4 * hi;
+                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[e][k]);
+            }
+        }
+    }
+}
+#undef RR_PAIRD
+
+// ---------------------------------------------------------------------------------------
+// Variant B of the f32 SYRK kernel: TWO independent workgroups of 4 waves per CU (one wave per
+// SIMD each) instead of one workgroup of 8.  A workgroup owns a 256 x 128 block of G (A column
+// block TA of 256, B column block tb of 128, tb >= 2 TA), k-blocks of 16 rows, 48 KiB of LDS.  The
+// two workgroups of a CU barrier independently, so while one sits in its per-k-block barrier /
+// first-operand latency the other keeps the SIMD's matrix pipe busy (the 8-wave kernel loses
+// ~5 % there: measured by removing its barrier and DMA).
+// ---------------------------------------------------------------------------------------
+constexpr int G2_KB = 16;
+constexpr int G2_THREADS = 256;
+constexpr int G2_ABYTES = G2_KB * 256 * 4;  // A tile [16][256] f32
+constexpr int G2_BBYTES = G2_KB * 128 * 4;  // B tile [16][128] f32
+constexpr int G2_BUF = G2_ABYTES + G2_BBYTES;
+
+struct KOps2B {
+    float2v a[4], b[2];
+    // k-steps 2P, 2P+1: rows 4P + h and 4P + 2 + h; A rows are 1024 B (4 units of 256 B) apart, B rows 512 B (2)
+    template <int P>
+    __device__ __forceinline__ void load(const unsigned (&abase)[4], const unsigned (&bbase)[2]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = lds_read2st64<16 * P, 16 * P + 8>(abase[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = lds_read2st64<8 * P, 8 * P + 4>(bbase[j]);
+    }
+};
+
+template <int FIRST, int LAST>
+__device__ __forceinline__ void gram_mfma_b(const KOps2B &o, floatx16 (&acc)[4][2]) {
+#pragma unroll
+    for (int q = FIRST; q < LAST; ++q)
+        acc[(q >> 1) & 3][q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(q >> 1) & 3][q >> 3], o.b[q & 1][q >> 3],
+                                                                        acc[(q >> 1) & 3][q & 1], 0, 0, 0);
+}
+
+#define RR_PAIRB(P, CUR, NXT)                                  \
+    lds_wait();                                                \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_b<0, 1>(CUR, acc);                               \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    if ((P) + 1 < 4) NXT.template load<((P) + 1) & 3>(abase, bbase); \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_b<1, 16>(CUR, acc);                              \
+    __builtin_amdgcn_sched_barrier(0);
+
+__global__ void __launch_bounds__(G2_THREADS, 2)
+rr_syrk_f32_kernel_b(const SyrkArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G2_BUF];  // 48 KiB
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // tile: A block TA (256 cols), B block tb (128 cols), tb >= 2 TA; nb128 = ldp / 128
+    const int nb128 = 2 * p.nb;
+    int tdx = blockIdx.x % p.ntiles;
+    const int ks = blockIdx.x / p.ntiles;
+    int TA = 0;
+    while (tdx >= nb128 - 2 * TA) {
+        tdx -= nb128 - 2 * TA;
+        ++TA;
+    }
+    const int tb = 2 * TA + tdx;
+    const int ca = TA * 256, cb = tb * 128;
+
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+
+    // wave (wr, wc): A cols [wr*128, +128) x B cols [wc*64, +64)
+    const int wr = wave >> 1, wc_ = wave & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned aoff = (lane >> 5) * 1024u + 4u * (wr * 128 + (lane & 31));
+    const unsigned boff = G2_ABYTES + (lane >> 5) * 512u + 4u * (wc_ * 64 + (lane & 31));
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // DMA per k-block: A = 16 row segments of 1 KiB (wave w: rows 4w..4w+3), B = 8 double-row segments of
+    // 1 KiB (wave w: row pairs 2w, 2w+1; lanes 0-31 first row of the pair, lanes 32-63 second)
+    auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int pr = 2 * wave + k;  // row pair
+            const float *src = p.P + (kb0 + 2 * pr + (lane >> 5)) * p.ldp + cb + 4 * (lane & 31);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + G2_ABYTES + pr * 1024), 16, 0, 0);
+        }
+    };
+
+    const int64_t nkb = (row_end - row_begin) / G2_KB;
+    if (nkb > 0) {
+        dma_tile(lds, row_begin);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * G2_BUF, row_begin + (kb + 1) * G2_KB);
+            unsigned abase[4], bbase[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) abase[i] = lds0 + cbuf * G2_BUF + aoff + i * 128;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bbase[j] = lds0 + cbuf * G2_BUF + boff + j * 128;
+            KOps2B o0, o1;
+            o0.load<0>(abase, bbase);
+            RR_PAIRB(0, o0, o1) RR_PAIRB(1, o1, o0) RR_PAIRB(2, o0, o1) RR_PAIRB(3, o1, o0)
+            __syncthreads();
+        }
+    }
+
+    const int64_t F = p.F;
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t gc = cb + wc_ * 64 + j * 32 + (lane & 31);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+            }
+        }
+    }
+}
+#undef RR_PAIRB
 
 // ---------------------------------------------------------------------------------------
 // f64 Gram: G(upper) += P^T P with v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s peak).  Same structure
@@ -661,16 +919,59 @@ static int ensure_zbuf(rr_basis *b, size_t bytes) {
     return RR_OK;
 }
 
+// Greedy XCD-aware tile order: dispatch position q goes to XCD q % 8, so XCD x receives positions
+// x, x+8, ...; fill each XCD's quota with tiles that add the fewest new column blocks to the set it
+// already reads.  Only used when ntiles is a multiple of 8 (equal quotas keep the load balanced).
+static void build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
+    const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
+    map.assign(ntiles, 0);
+    std::vector<int> ta(ntiles), tb(ntiles);
+    for (int a = 0, t = 0; a < nb; ++a)
+        for (int b2 = a + od; b2 < nb; ++b2, ++t) { ta[t] = a; tb[t] = b2; }
+    std::vector<char> used(ntiles, 0);
+    const int quota = ntiles / nxcd;
+    for (int x = 0; x < nxcd; ++x) {
+        std::vector<char> have(nb, 0);
+        for (int s = 0; s < quota; ++s) {
+            int best = -1, bestcost = 1 << 30;
+            for (int t = 0; t < ntiles; ++t) {
+                if (used[t]) continue;
+                const int cost = (have[ta[t]] ? 0 : 1) + ((have[tb[t]] || tb[t] == ta[t]) ? 0 : 1);
+                if (cost < bestcost) { bestcost = cost; best = t; }
+            }
+            used[best] = 1;
+            have[ta[best]] = have[tb[best]] = 1;
+            map[s * nxcd + x] = best;
+        }
+    }
+}
+
 // G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
-int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG) {
+int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
     const int nb = (int)(ldp / GR_TC);
-    const int ntiles = nb * (nb + 1) / 2;
-    // Every workgroup costs the same, so make their number a multiple of the CU count (no
-    // partial last round): nsplit = k * CUs / gcd(CUs, ntiles), k minimal such that a split has
-    // <= 32768 rows (the bound on f32 accumulation length).
-    int64_t g = c->num_cu, t = ntiles;
-    while (t) { const int64_t u = g % t; g = t; t = u; }
-    const int64_t unit = c->num_cu / g;  // 32 for 256 CUs and 136 tiles
+    const int od = (nb >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
+    const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
+    const int nxcd = 8;
+    const bool use_map = (ntiles % nxcd == 0) && !getenv("RR_GRAM_NO_TILE_MAP");
+    if (use_map && c->tile_map_nb != nb * 2 + od) {
+        std::vector<int> map;
+        build_tile_map(nb, od, nxcd, map);
+        if (c->tile_map) (void)hipFree(c->tile_map);
+        c->tile_map = nullptr;
+        RR_CHECK_HIP(hipMalloc((void **)&c->tile_map, map.size() * sizeof(int)));
+        RR_CHECK_HIP(hipMemcpy(c->tile_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->tile_map_nb = nb * 2 + od;
+    }
+    // K-splits: f32 accumulation over <= 32768 rows per split.  Workgroups of one kernel all cost
+    // the same, so make each kernel's workgroup count a multiple of the CU count (no partial last
+    // round): nsplit = k * lcm(CUs / gcd(CUs, ntiles), CUs / gcd(CUs, nb)), k minimal.
+    const int64_t total_tiles = (int64_t)nb * (nb + 1) / 2;
+    auto gcd64 = [](int64_t x, int64_t y) { while (y) { const int64_t u = x % y; x = y; y = u; } return x; };
+    int64_t unit = ntiles > 0 ? c->num_cu / gcd64(c->num_cu, ntiles) : 1;
+    if (od) {
+        const int64_t u2 = c->num_cu / gcd64(c->num_cu, nb);
+        unit = unit / gcd64(unit, u2) * u2;
+    }
     int64_t nsplit = ((rows + 32767) / 32768 + unit - 1) / unit * unit;
     if (rows / nsplit < 1024) nsplit = (rows + 1023) / 1024;  // small inputs: just cover the rows
     if (nsplit < 1) nsplit = 1;
@@ -678,10 +979,36 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
     if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
     nsplit = (rows + rps - 1) / rps;
-    RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+    RR_REQUIRE(nsplit * total_tiles < (int64_t)1 << 31, "gram: grid too large");
     SyrkArgs a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
-    hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    a.tile_map = use_map ? c->tile_map : nullptr;
+    a.offdiag_only = od;
+    a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
+    const char *venv = getenv("RR_SYRK_VARIANT");
+    if (venv && venv[0] == 'B') {
+        // variant B: 256x128 tiles, 16-row k-blocks, two 4-wave workgroups per CU
+        SyrkArgs b2 = a;
+        b2.ntiles = nb * (nb + 1);  // sum_{TA} (2 nb - 2 TA)
+        b2.tile_map = nullptr;
+        int64_t g2 = (int64_t)c->num_cu * 2, t2 = b2.ntiles;
+        while (t2) { const int64_t u = g2 % t2; g2 = t2; t2 = u; }
+        const int64_t unit2 = (int64_t)c->num_cu * 2 / g2;
+        int64_t ns2 = ((rows + 32767) / 32768 + unit2 - 1) / unit2 * unit2;
+        if (rows / ns2 < 1024) ns2 = (rows + 1023) / 1024;
+        if (ns2 < 1) ns2 = 1;
+        int64_t rps2 = ((rows + ns2 - 1) / ns2 + GR_KB - 1) / GR_KB * GR_KB;
+        if (renv && atoll(renv) >= GR_KB) rps2 = (atoll(renv) / GR_KB) * GR_KB;
+        ns2 = (rows + rps2 - 1) / rps2;
+        b2.rows_per_split = rps2;
+        hipLaunchKernelGGL(rr_syrk_f32_kernel_b, dim3((unsigned)(ns2 * b2.ntiles)), dim3(G2_THREADS), 0, c->stream, b2);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
+    if (ntiles > 0)
+        hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
+    if (od) hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit * nb)), dim3(GR_THREADS), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -736,9 +1063,9 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         const int64_t mpad = (m + KB - 1) / KB * KB;
         const TX *Xc = (const TX *)dX + r0 * ldx;
         const TX *yc = dy ? (const TX *)dy + r0 : nullptr;
-        // three events per chunk bracket the two kernels (read back by rr_rff_gram_timings)
-        const size_t e0 = (size_t)(r0 / chunk) * 3;
-        while (b->events.size() < e0 + 3) {
+        // four events per chunk bracket the kernels (read back by rr_rff_gram_timings)
+        const size_t e0 = (size_t)(r0 / chunk) * 4;
+        while (b->events.size() < e0 + 4) {
             hipEvent_t ev;
             RR_CHECK_HIP(hipEventCreate(&ev));
             b->events.push_back(ev);
@@ -770,11 +1097,15 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         }
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
         // (B) G += P^T P
-        if constexpr (F32) rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG);
-        else rc = rr_launch_syrk_f64(c, P, mpad, ldp, F, dG);
+        if constexpr (F32) {
+            rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG, b->events[e0 + 2]);
+        } else {
+            rc = rr_launch_syrk_f64(c, P, mpad, ldp, F, dG);
+            if (rc == RR_OK) RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
+        }
         if (rc != RR_OK) return rc;
-        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
-        b->events_used = e0 + 3;
+        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 3], c->stream));
+        b->events_used = e0 + 4;
     }
     b->gram_kernel = F32 ? "rr_syrk_f32_kernel" : "rr_syrk_f64_kernel";
     return RR_OK;
@@ -998,21 +1329,24 @@ int rr_rff_gram_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, in
     return RR_OK;
 }
 
-int rr_rff_gram_timings(rr_basis *b, float *phase_ms, float *gram_ms, int *launches) {
+int rr_rff_gram_timings(rr_basis *b, float *features_ms, float *syrk_ms, float *diag_ms, int *launches) {
     RR_REQUIRE(b != nullptr, "rr_rff_gram_timings: null basis");
     RR_CHECK_HIP(hipSetDevice(b->ctx->device));
     RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
-    float pa = 0.f, pg = 0.f;
-    for (size_t i = 0; i + 3 <= b->events_used; i += 3) {
+    float pa = 0.f, pg = 0.f, pd = 0.f;
+    for (size_t i = 0; i + 4 <= b->events_used; i += 4) {
         float t = 0.f;
         RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i], b->events[i + 1]));
         pa += t;
         RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i + 1], b->events[i + 2]));
         pg += t;
+        RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i + 2], b->events[i + 3]));
+        pd += t;
     }
-    if (phase_ms) *phase_ms = pa;
-    if (gram_ms) *gram_ms = pg;
-    if (launches) *launches = (int)(b->events_used / 3);
+    if (features_ms) *features_ms = pa;
+    if (syrk_ms) *syrk_ms = pg;
+    if (diag_ms) *diag_ms = pd;
+    if (launches) *launches = (int)(b->events_used / 4);
     return RR_OK;
 }
 
@@ -1086,7 +1420,7 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
             rc = RR_ERR_HIP;
             break;
         }
-        rc = rr_launch_syrk_f32(c, dP, mpad, ldp, (int)F, dG);
+        rc = rr_launch_syrk_f32(c, dP, mpad, ldp, (int)F, dG, nullptr);
         if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
             rr_set_error("rr_dense_gram: kernel failed: %s", hipGetErrorString(e));
             rc = RR_ERR_HIP;
