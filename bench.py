@@ -97,11 +97,16 @@ def main():
 
     dist = None
     torch = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("RR_BENCH_FORCE_DIST") == "1"  # the latter: plumbing check at N=1
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout (one JSON line)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from revrand_amd import _hip, parallel
     dev = _hip.get_device(local_rank)
@@ -130,7 +135,7 @@ def main():
 
     # ---- accumulators: [G (F*F) | b (F) | yty (1)] float64, one buffer so one all-reduce ----
     nacc = F * F + F + 1
-    if world > 1:
+    if use_dist:
         acc_t = torch.zeros(nacc, dtype=torch.float64, device="cuda:%d" % local_rank)
         acc_ptr = acc_t.data_ptr()
         torch.cuda.synchronize()
@@ -149,15 +154,18 @@ def main():
             if timed:
                 kernel_ms.append(basis.gram_timings())  # HIP events on the kernels' own stream
         dev.sync()
-        if world > 1:
-            parallel.allreduce_packed(acc_t)  # RCCL over xGMI: the one exchange step of the path
+        if use_dist:
+            if world > 1:
+                parallel.allreduce_packed(acc_t)  # RCCL over xGMI: the one exchange step of the path
+            else:
+                dist.all_reduce(acc_t)  # N=1 plumbing check only
             torch.cuda.synchronize()
         _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
         dev.sync()
 
     def barrier():
         dev.sync()
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
 
@@ -169,13 +177,13 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # sanity on the result of the last step: trace(G) == N (cos^2 + sin^2 = 1 per frequency)
-    if world > 1:
+    if use_dist:
         diag = acc_t[:F * F].view(F, F).diagonal().sum().item()
     else:
         G = dev.download(acc_buf, (F, F), np.float64)
@@ -211,7 +219,10 @@ def main():
                        "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err},
             "roofline": {"bound": "mfma", "kernel": "rr_syrk_f32_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": TRAFFIC.get("hbm_bytes"),
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                         # bytes per launch: the profiled launch's bytes/row x this run's rows per launch
+                         "traffic": (TRAFFIC["hbm_bytes"] / TRAFFIC["rows_per_launch"] * my_rows / max(launches, 1)
+                                     if TRAFFIC else None),
                          "traffic_note": TRAFFIC.get("note"),
                          "kernel_ms_per_step": syrk_ms, "launches_per_step": launches,
                          "avg_launch_ms": syrk_ms / max(launches, 1),
@@ -225,7 +236,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     assert trace_err < 1e-4 or os.environ.get("RR_GRAM_ABLATE"), trace_err
 
