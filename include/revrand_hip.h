@@ -169,6 +169,25 @@ int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int6
 int rr_dense_gram(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi,
                   const void *y, double *G, double *b, double *yty);
 
+/* ---- second data pass of the standard linear model (posterior known) -----------------------
+ * With m (F,) and C (F, F) from the host Cholesky (slm.py:154-157), for a random Fourier basis and
+ * DEVICE-resident X (padded layout, see rr_rff_padded_dim) and y:
+ *   *sqerr = sum_r (y_r - Phi_r . m)^2                                     (slm.py:161-162)
+ *   T (d, n) row-major = X^T A,  A = Err (Phi_c m_s - Phi_s m_c) - (Phi_c U_s - Phi_s U_c),  U = Phi C,
+ * from which the hyper-gradient of slm.py:193-197 follows WITHOUT the (N, 2n, d) dPhi tensor:
+ *   dhyps(dPhi_i) = -( m.(Err.dPhi_i) - sum(dPhi_i^T Phi o C) ) / var  =  sum_f T[i][f] W[i][f] / (var l_i^2)
+ * (isotropic length scale: the reference uses i = 0 only).  f32 arithmetic; U is an MFMA GEMM.
+ * m, C, sqerr, T are host buffers; the call is synchronous. */
+int rr_rff_elbo_pass2_dev(rr_basis *basis, const void *dX, const void *dy, int x_dtype, int64_t N,
+                          int64_t ldx, const double *lenscale, int n_ls, const double *m, const double *C,
+                          double *sqerr, double *T);
+
+/* predict_moments (slm.py:240-244) for DEVICE-resident query rows: Ey = Phi m, Vf = rowsum((Phi C) o Phi)
+ * (host outputs, length N; the caller adds var to Vf). */
+int rr_rff_predict_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                       const double *lenscale, int n_ls, const double *m, const double *C, double *Ey,
+                       double *Vf);
+
 /* ---- FastFood -------------------------------------------------------------------------
  * FastFoodRBF (basis_functions.py:1211-1383).  B (+-1, int64), G, PI (int64 permutations) and S are
  * the host-sampled (k, d2) matrices of _init_matrices / _weightsamples (:1342-1354), row-major;

@@ -70,6 +70,12 @@ SIGNATURES = {
     "rr_dense_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+    "rr_rff_elbo_pass2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_rff_predict_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_fastfood_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           _c_void_pp]),
@@ -467,6 +473,49 @@ class RffHandle(object):
         ls, lsp, nls = _lenscale_arg(lenscale)
         _check(self.lib, self.lib.rr_rff_gram_dev(self.h, dX.ptr, _ptr(dy), rr_dtype(dX.dtype), dX.shape[0],
                                                   dX.ld, lsp, nls, _ptr(dG), _ptr(db), _ptr(dyty)))
+
+    def gram_host(self, dX, dy, lenscale):
+        """(G, b, yty) as host arrays from device-resident X (DeviceMatrix) and y (DeviceBuffer)."""
+        F = 2 * self.n
+        acc = self.dev.zeros((F * F + F + 1) * 8)
+        base = acc.ptr.value
+        self.gram_dev(dX, dy, lenscale, ctypes.c_void_p(base), ctypes.c_void_p(base + F * F * 8),
+                      ctypes.c_void_p(base + (F * F + F) * 8))
+        self.symmetrize_dev(ctypes.c_void_p(base))
+        out = self.dev.download(acc, (F * F + F + 1,), np.float64)
+        acc.free()
+        return out[:F * F].reshape(F, F), out[F * F:F * F + F].copy(), float(out[-1])
+
+    def elbo_pass2(self, dX, dy, lenscale, m, C):
+        """(sqErr, T (d, n)) for the posterior (m, C): the second data pass of `_elbo`."""
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        sq = np.zeros(1)
+        T = np.zeros((self.d, self.n))
+        _check(self.lib, self.lib.rr_rff_elbo_pass2_dev(self.h, dX.ptr, dy.ptr, rr_dtype(dX.dtype), dX.shape[0], dX.ld,
+                                                        lsp, nls, m.ctypes.data_as(ctypes.c_void_p),
+                                                        C.ctypes.data_as(ctypes.c_void_p),
+                                                        sq.ctypes.data_as(ctypes.c_void_p),
+                                                        T.ctypes.data_as(ctypes.c_void_p)))
+        return float(sq[0]), T
+
+    def predict(self, X, lenscale, m, C):
+        """(Ey, Vf) = (Phi m, rowsum((Phi C) o Phi)) for host query rows X."""
+        dX = self.upload(X)
+        N = dX.shape[0]
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        Ey, Vf = np.empty(N), np.empty(N)
+        if N:
+            _check(self.lib, self.lib.rr_rff_predict_dev(self.h, dX.ptr, rr_dtype(dX.dtype), N, dX.ld, lsp, nls,
+                                                         m.ctypes.data_as(ctypes.c_void_p),
+                                                         C.ctypes.data_as(ctypes.c_void_p),
+                                                         Ey.ctypes.data_as(ctypes.c_void_p),
+                                                         Vf.ctypes.data_as(ctypes.c_void_p)))
+        dX.free()
+        return Ey, Vf
 
     def gram_timings(self):
         """(features_ms, syrk_ms, diag_ms, launches) of the last gram_dev call (waits for it)."""

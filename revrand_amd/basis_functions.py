@@ -218,6 +218,36 @@ class _LengthScaleBasis(Basis):
 # Random Fourier feature bases on the GPU (reference: basis_functions.py:818-1208)
 # --------------------------------------------------------------------------------------
 
+class DeviceFitState(object):
+    """X and y resident on the GPU for the whole of a ``fit`` (slm.py:118-126 calls ``_elbo``
+    ~50-200 times): per evaluation only the (F, F) statistics, the posterior and d+1 scalars cross PCIe.
+
+    ``gram(ls)``            -> (Phi^T Phi, Phi^T y, y^T y)                    slm.py:145-146,157
+    ``second_pass(ls, m, C)`` -> (sqErr, dhyp) with dhyp the value ``apply_grad(dhyps, basis.grad(X))``
+                               would have (slm.py:161-162,193-197), computed without dPhi.
+    """
+
+    def __init__(self, handle, W, X, y):
+        self.handle, self.W = handle, np.asarray(W, dtype=np.float64)
+        X32 = np.ascontiguousarray(X, dtype=np.float32)
+        self.dX = handle.upload(X32)
+        self.dy = handle.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+
+    def gram(self, lenscale):
+        return self.handle.gram_host(self.dX, self.dy, lenscale)
+
+    def second_pass(self, lenscale, m, C, var):
+        sq, T = self.handle.elbo_pass2(self.dX, self.dy, lenscale, m, C)
+        ls = np.atleast_1d(np.asarray(lenscale, dtype=float))
+        if ls.size == 1:  # the reference's isotropic gradient: input dimension 0 only
+            return sq, float((T[0] * self.W[0]).sum() / (var * ls[0] ** 2))
+        return sq, (T * self.W).sum(axis=1) / (var * ls ** 2)
+
+    def release(self):
+        self.dX.free()
+        self.dy.free()
+
+
 class _RandomKernelBasis(_LengthScaleBasis):
     """Phi = [cos(X W/l), sin(X W/l)]/sqrt(nbases); subclasses only sample W."""
 
@@ -273,6 +303,19 @@ class _RandomKernelBasis(_LengthScaleBasis):
         N, D = X.shape
         lenscale = self._check_dim(D, lenscale)
         return self._handle().gram(X, y, lenscale)
+
+    @slice_transform
+    def device_fit_state(self, X, y):
+        """Upload (X, y) once for a fit; None when this basis cannot serve the fused path (f64 mode)."""
+        if self.dtype != "f32" or X.shape[1] != self.d:
+            return None
+        return DeviceFitState(self._handle(), self.W, X, y)
+
+    @slice_transform
+    def predict_moments(self, X, lenscale, m, C):
+        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243); f32 mode only."""
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        return self._handle().predict(X, lenscale, m, C)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(
@@ -389,7 +432,7 @@ class FastFoodRBF(_LengthScaleBasis):
         if h is None or h[0] != _hip.os.getpid():
             ff = _hip.FastFoodHandle(self.d, self.d2, self.k, self.B, self.G, self.PI, self.S, compute=self.dtype)
             V = ff.vx(np.eye(self.d), 1.0)  # (d, n): dense equivalent of the chain
-            h = (_hip.os.getpid(), ff, _hip.RffHandle(V, compute=self.dtype))
+            h = (_hip.os.getpid(), ff, _hip.RffHandle(V, compute=self.dtype), V)
             self.__dict__["_hip_handle"] = h
         return h[1], h[2]
 
@@ -421,6 +464,18 @@ class FastFoodRBF(_LengthScaleBasis):
     def gram(self, X, y=None, lenscale=None):
         lenscale = self._check_dim(X.shape[1], lenscale)
         return self._handles()[1].gram(X, y, lenscale)
+
+    @slice_transform
+    def device_fit_state(self, X, y):
+        if self.dtype != "f32" or X.shape[1] != self.d:
+            return None
+        rff = self._handles()[1]
+        return DeviceFitState(rff, self.__dict__["_hip_handle"][3], X, y)
+
+    @slice_transform
+    def predict_moments(self, X, lenscale, m, C):
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        return self._handles()[1].predict(X, lenscale, m, C)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(

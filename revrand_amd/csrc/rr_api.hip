@@ -191,9 +191,10 @@ int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_ba
     size_t elems = (size_t)b->dpad * b->npad;
     hipError_t e1 = hipMalloc((void **)&b->dWs32, elems * sizeof(float));
     hipError_t e2 = hipMalloc((void **)&b->dWs64, elems * sizeof(double));
+    hipError_t e5 = hipMalloc((void **)&b->dWt32, elems * sizeof(float));
     hipError_t e3 = hipMalloc((void **)&b->dgfac32, (size_t)b->dpad * sizeof(float));
     hipError_t e4 = hipMalloc((void **)&b->dgfac64, (size_t)b->dpad * sizeof(double));
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess) {
         (void)hipGetLastError();
         rr_set_error("rr_rff_create: device allocation failed");
         rr_basis_destroy(b);
@@ -211,6 +212,7 @@ void rr_basis_destroy(rr_basis *b) {
     }
     if (b->dWs32) (void)hipFree(b->dWs32);
     if (b->dWs64) (void)hipFree(b->dWs64);
+    if (b->dWt32) (void)hipFree(b->dWt32);
     if (b->dgfac32) (void)hipFree(b->dgfac32);
     if (b->dgfac64) (void)hipFree(b->dgfac64);
     if (b->zbuf) (void)hipFree(b->zbuf);
@@ -243,6 +245,7 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     const int d = b->d, n = b->n, npad = b->npad;
     std::vector<double> w64((size_t)b->dpad * npad, 0.0);
     std::vector<float> w32((size_t)b->dpad * npad, 0.0f);
+    std::vector<float> wt32((size_t)npad * b->dpad, 0.0f);
     std::vector<double> g64(b->dpad, 0.0);
     std::vector<float> g32(b->dpad, 0.0f);
     for (int i = 0; i < d; ++i) {
@@ -252,6 +255,7 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
             const double v = b->W[(size_t)i * n + f] * s;
             w64[(size_t)i * npad + f] = v;
             w32[(size_t)i * npad + f] = (float)v;
+            wt32[(size_t)f * b->dpad + i] = (float)v;
         }
         g64[i] = twopi / l;
         g32[i] = (float)g64[i];
@@ -262,6 +266,7 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     RR_CHECK_HIP(hipMemcpy(b->dWs32, w32.data(), w32.size() * sizeof(float), hipMemcpyHostToDevice));
     RR_CHECK_HIP(hipMemcpy(b->dWs64, w64.data(), w64.size() * sizeof(double), hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->dWt32, wt32.data(), wt32.size() * sizeof(float), hipMemcpyHostToDevice));
     RR_CHECK_HIP(hipMemcpy(b->dgfac32, g32.data(), g32.size() * sizeof(float), hipMemcpyHostToDevice));
     RR_CHECK_HIP(hipMemcpy(b->dgfac64, g64.data(), g64.size() * sizeof(double), hipMemcpyHostToDevice));
     b->ls_cache.assign(lenscale, lenscale + n_ls);

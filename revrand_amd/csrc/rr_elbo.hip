@@ -1,0 +1,401 @@
+// Second data pass of StandardLinearModel._elbo and predict_moments on the device.
+//
+// With the posterior (m, C) from the host Cholesky, both need  U = Phi C  (rows x F x F):
+//   _elbo (slm.py:160-162,193-197):  Err = y - Phi m,  sqErr = sum Err^2,
+//        dhyp_i = -( m.(Err.dPhi_i) - sum(dPhi_i^T Phi o C) ) / var
+//      For a random Fourier basis dPhi_i[r, :] = dz_i[r, :] o [-Phi_s, Phi_c][r, :],  dz_i[r, f] = -x_ri W_if / l_i^2,
+//      so with  A[r, f] = Err_r (Phi_c m_s - Phi_s m_c)[r, f] - (Phi_c U_s - Phi_s U_c)[r, f]   (c/s = cos/sin halves)
+//      and  T = X^T A  (d x n):   dhyp_i = T[i, :] . W[i, :] / (var l_i^2).   The (N, 2n, d) tensor never exists.
+//   predict_moments (slm.py:240-244):  Ey = Phi m,  Vf = rowsum(U o Phi).
+//
+// Kernels: rr_rff_features_t_kernel (feature-major Phi^T + Phi m), rr_gemm_tn_f32_kernel (U = (Phi^T)^T C on the
+// SYRK kernel's LDS-DMA / MFMA structure, plain f32 stores), rr_rowdot_kernel, rr_grad_t_kernel.
+#include "rr_internal.h"
+#include "rr_mfma_tile.h"
+
+// ---------------------------------------------------------------------------------------------
+// Feature-major features:  Pt[f][r] = cos/sqrt(n), Pt[n+f][r] = sin/sqrt(n)  (GEMM operand, K-major),
+// and per row  dot[r] = Phi_r . m.  One row per thread (x in registers), frequencies looped with the
+// transposed weights Wt[f][DMAX] and m through the scalar cache, stores coalesced along r.
+// ---------------------------------------------------------------------------------------------
+template <int DMAX, typename TX>
+__global__ void __launch_bounds__(256)
+rr_rff_features_t_kernel(const TX *__restrict__ X, int64_t N, int64_t Npad, int64_t ldx,
+                         const float *__restrict__ Wt, const float *__restrict__ mvec, int n,
+                         float *__restrict__ Pt, int64_t ldt, float *__restrict__ dot, float scale) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool valid = r < N;
+    float x[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) x[i] = valid ? (float)X[r * ldx + i] : 0.f;
+    float acc = 0.f;
+    for (int f = 0; f < n; ++f) {
+        const float *w = Wt + (size_t)f * DMAX;  // wave-uniform
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) z = fmaf(x[i], w[i], z);
+        const float fr = z - __builtin_rintf(z);
+        const float c = valid ? __builtin_amdgcn_cosf(fr) * scale : 0.f;
+        const float s = valid ? __builtin_amdgcn_sinf(fr) * scale : 0.f;
+        if (r < Npad) {
+            Pt[(size_t)f * ldt + r] = c;
+            Pt[(size_t)(n + f) * ldt + r] = s;
+        }
+        if (mvec) acc = fmaf(c, mvec[f], fmaf(s, mvec[n + f], acc));
+    }
+    if (dot && valid) dot[r] = acc;
+}
+
+// zero rows [F, Fp) of the feature-major matrix (pad features)
+__global__ void __launch_bounds__(256) rr_zero_rows_kernel(float *P, int64_t row0, int64_t row1, int64_t ld) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < (row1 - row0) * ld) P[row0 * ld + i] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// D[M][N] = A^T B,  A: (K, lda) with M columns, B: (K, ldb) with N columns, all f32 row-major,
+// K % 32 == 0, M % 256 == 0, N % 256 == 0.  One workgroup per 256x256 block of D, whole K loop;
+// identical tile / operand / MFMA schedule to rr_syrk_f32_kernel, plain stores instead of atomics.
+// ---------------------------------------------------------------------------------------------
+struct GemmArgs {
+    const float *A, *B;
+    float *D;
+    int64_t lda, ldb, ldd;
+    int K, ntb;  // ntb = N / 256 column tiles (fastest-varying in blockIdx)
+};
+
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_gemm_tn_f32_kernel(const GemmArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ta = blockIdx.x / p.ntb;
+    const int tb = blockIdx.x % p.ntb;
+    const int64_t ca = ta * GR_TC;
+    const int cb = tb * GR_TC;
+
+    const int wr = wave >> 2, wc_ = wave & 3;
+    const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
+    const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto dma_tile = [&](float *buf, int kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
+            const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
+            float *dst = buf + lr * GR_LD;
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
+        }
+    };
+
+    const int nkb = p.K / GR_KB;
+    dma_tile(lds, 0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cbuf = kb & 1;
+        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB);
+        gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+        __syncthreads();
+    }
+
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gc = cb + wc_ * 64 + j * 32 + (lane & 31);
+                p.D[gr * p.ldd + gc] = acc[i][j][e];
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row reductions: one wave per row.
+//   MODE 0:  out[r] = sum_j U[r][j] P[r][j]                        (Vf of predict_moments)
+//   MODE 1:  err[r] = y[r] - dot[r];  *sq += sum_r err[r]^2         (Err, sqErr of _elbo)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+rr_rowdot_kernel(const float *__restrict__ U, const float *__restrict__ P, int64_t rows, int F, int64_t ld,
+                 double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float *u = U + r * ld, *q = P + r * ld;
+    float acc = 0.f;
+    for (int j = lane; j < F; j += 64) acc = fmaf(u[j], q[j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) out[r] = (double)acc;
+}
+
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_err_kernel(const TX *__restrict__ y, const float *__restrict__ dot, int64_t N, float *__restrict__ err,
+              double *__restrict__ sq) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    float e = 0.f;
+    if (r < N) {
+        e = (float)((double)y[r] - (double)dot[r]);
+        err[r] = e;
+    }
+    double acc = (double)e * (double)e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(sq, part[0] + part[1] + part[2] + part[3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// T[i][f] += sum_r x[r][i] * A[r][f],  A = err (P_c m_s - P_s m_c) - (P_c U_s - P_s U_c).
+// One frequency per thread; x rows, err and m through the scalar cache; P and U coalesced along f.
+// ---------------------------------------------------------------------------------------------
+template <int DMAX, typename TX>
+__global__ void __launch_bounds__(256)
+rr_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ P,
+                 const float *__restrict__ U, int64_t ldp, const float *__restrict__ err,
+                 const float *__restrict__ mvec, int n, int d, double *__restrict__ T, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    const int fc = fvalid ? f : 0;
+    const float mc = mvec[fc], ms = mvec[n + fc];
+    float t[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) t[i] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float pc = P[r * ldp + fc], ps = P[r * ldp + n + fc];
+        const float uc = U[r * ldp + fc], us = U[r * ldp + n + fc];
+        const float a = err[r] * (pc * ms - ps * mc) - (pc * us - ps * uc);
+        const TX *xr = X + r * ldx;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) t[i] = fmaf((float)xr[i], a, t[i]);
+    }
+    if (fvalid) {
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct Pass2Scratch {
+    float *P = nullptr, *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
+    double *acc = nullptr;  // [sqErr | T (d*n)] or Vf
+    void release() {
+        void *q[] = {P, Pt, U, C32, m32, dot, err, acc};
+        for (void *x : q)
+            if (x) (void)hipFree(x);
+    }
+};
+
+int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
+                             float *P, int64_t ldp);  // rr_rff.hip
+
+template <typename TX>
+static int launch_features_t(rr_basis *b, const TX *X, int64_t N, int64_t Npad, int64_t ldx, const float *m32,
+                             float *Pt, int64_t ldt, float *dot) {
+    rr_ctx *c = b->ctx;
+    const float scale = (float)(1.0 / sqrt((double)b->n));
+    const dim3 grid((unsigned)(Npad / 256));
+#define RR_FT(DM)                                                                                                  \
+    hipLaunchKernelGGL((rr_rff_features_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, X, N, Npad, ldx, b->dWt32, \
+                       m32, b->n, Pt, ldt, dot, scale)
+    switch (b->dpad) {
+        case 8: RR_FT(8); break;
+        case 16: RR_FT(16); break;
+        case 32: RR_FT(32); break;
+        case 64: RR_FT(64); break;
+        case 128: RR_FT(128); break;
+        default: rr_set_error("pass2: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_FT
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+template <typename TX>
+static int launch_grad_t(rr_basis *b, const TX *X, int64_t N, int64_t ldx, const float *P, const float *U, int64_t ldp,
+                         const float *err, const float *m32, double *T) {
+    rr_ctx *c = b->ctx;
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = (N * fblocks + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+    if (rpb < 64) rpb = 64;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+#define RR_GT(DM)                                                                                                 \
+    hipLaunchKernelGGL((rr_grad_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, X, N, ldx, P, U, ldp, err, m32,   \
+                       b->n, b->d, T, (int)rpb)
+    switch (b->dpad) {
+        case 8: RR_GT(8); break;
+        case 16: RR_GT(16); break;
+        case 32: RR_GT(32); break;
+        case 64: RR_GT(64); break;
+        case 128: RR_GT(128); break;
+        default: rr_set_error("pass2: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_GT
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// Common driver.  MODE_ELBO: out = [sqErr | T(d*n)] accumulated over row chunks (host doubles).
+//                 MODE_PRED: Ey, Vf per row (host doubles, length N).
+template <typename TX>
+static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t N, int64_t ldx, const double *mh,
+                     const double *Ch, double *out0, double *out1) {
+    rr_ctx *c = b->ctx;
+    const int F = 2 * b->n, n = b->n;
+    const int64_t Fp = ((int64_t)F + 255) / 256 * 256;
+    // rows per chunk: P, Pt, U  (3 x 4 Fp bytes per row) within ~24 GiB, multiple of 256
+    int64_t chunk = (int64_t)(((size_t)24 << 30) / ((size_t)12 * Fp));
+    const char *cenv = getenv("RR_PASS2_CHUNK_ROWS");
+    if (cenv && atoll(cenv) >= 256) chunk = atoll(cenv);
+    if (chunk > N) chunk = N;
+    chunk = (chunk + 255) / 256 * 256;
+    Pass2Scratch s;
+    const size_t nacc = pred ? (size_t)chunk : (size_t)1 + (size_t)b->d * n;
+    hipError_t e = hipMalloc((void **)&s.P, (size_t)chunk * Fp * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.Pt, (size_t)Fp * chunk * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.U, (size_t)chunk * Fp * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.C32, (size_t)Fp * Fp * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.m32, (size_t)F * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.dot, (size_t)chunk * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.err, (size_t)chunk * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&s.acc, nacc * 8);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        s.release();
+        rr_set_error("pass2: device allocation failed (%lld rows per chunk)", (long long)chunk);
+        return RR_ERR_OOM;
+    }
+    int rc = RR_OK;
+    {   // posterior to the device in f32: m (F), C padded to (Fp, Fp)
+        std::vector<float> m32(F), c32((size_t)Fp * Fp, 0.f);
+        for (int i = 0; i < F; ++i) m32[i] = (float)mh[i];
+        for (int i = 0; i < F; ++i)
+            for (int j = 0; j < F; ++j) c32[(size_t)i * Fp + j] = (float)Ch[(size_t)i * F + j];
+        e = hipMemcpy(s.m32, m32.data(), (size_t)F * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s.C32, c32.data(), c32.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !pred) e = hipMemsetAsync(s.acc, 0, nacc * 8, c->stream);
+        if (e == hipSuccess && Fp > F) {  // pad feature rows of Pt are never written by the kernel
+            const int64_t cnt = (Fp - F) * chunk;
+            hipLaunchKernelGGL(rr_zero_rows_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, s.Pt,
+                               (int64_t)F, Fp, chunk);
+        }
+        if (e != hipSuccess) {
+            rr_set_error("pass2: upload failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
+        const int64_t mrows = (N - r0 < chunk) ? N - r0 : chunk;
+        const int64_t mpad = (mrows + 255) / 256 * 256;
+        const TX *Xc = dX + r0 * ldx;
+        // row-major P (epilogues) and feature-major Pt + Phi m (GEMM operand)
+        rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp);
+        if (rc != RR_OK) break;
+        rc = launch_features_t<TX>(b, Xc, mrows, mpad, ldx, s.m32, s.Pt, chunk, s.dot);
+        if (rc != RR_OK) break;
+        // U = P C  as  (Pt)^T C : A = Pt (K = Fp, M = mpad columns), B = C32 (K = Fp, N = Fp)
+        GemmArgs g;
+        g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
+        hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+        if (hipGetLastError() != hipSuccess) {
+            rr_set_error("pass2: gemm launch failed");
+            rc = RR_ERR_HIP;
+            break;
+        }
+        if (pred) {
+            hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.U, s.P, mrows,
+                               F, Fp, s.acc);
+            std::vector<float> dot(mrows);
+            e = hipMemcpyAsync(out1 + r0, s.acc, (size_t)mrows * 8, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(dot.data(), s.dot, (size_t)mrows * 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) {
+                rr_set_error("pass2: download failed: %s", hipGetErrorString(e));
+                rc = RR_ERR_HIP;
+                break;
+            }
+            for (int64_t i = 0; i < mrows; ++i) out0[r0 + i] = (double)dot[i];
+        } else {
+            const TX *yc = dy + r0;
+            hipLaunchKernelGGL(rr_err_kernel<TX>, dim3((unsigned)(mpad / 256)), dim3(256), 0, c->stream, yc, s.dot, mrows,
+                               s.err, s.acc);
+            rc = launch_grad_t<TX>(b, Xc, mrows, ldx, s.P, s.U, Fp, s.err, s.m32, s.acc + 1);
+            if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+                rr_set_error("pass2: kernel failed: %s", hipGetErrorString(e));
+                rc = RR_ERR_HIP;
+            }
+        }
+    }
+    if (rc == RR_OK && !pred) {
+        std::vector<double> acc(nacc);
+        e = hipMemcpy(acc.data(), s.acc, nacc * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            rr_set_error("pass2: download failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        } else {
+            *out0 = acc[0];
+            memcpy(out1, acc.data() + 1, (nacc - 1) * 8);
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    s.release();
+    return rc;
+}
+
+static int pass2_checks(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                        int n_ls, const double *m, const double *C, const char *who) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "%s: not an RFF basis", who);
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "%s: bad dtype", who);
+    RR_REQUIRE(N >= 1 && dX != nullptr && m != nullptr && C != nullptr, "%s: null/empty argument", who);
+    RR_REQUIRE(ldx >= b->dpad, "%s: device X needs ldx >= rr_rff_padded_dim() = %d with zero pad columns", who, b->dpad);
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    RR_CHECK_HIP(hipSetDevice(b->ctx->device));
+    return RR_OK;
+}
+
+extern "C" {
+
+int rr_rff_elbo_pass2_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, int64_t N, int64_t ldx,
+                          const double *lenscale, int n_ls, const double *m, const double *C, double *sqerr,
+                          double *T) {
+    int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, C, "rr_rff_elbo_pass2_dev");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(dy != nullptr && sqerr != nullptr && T != nullptr, "rr_rff_elbo_pass2_dev: null argument");
+    return x_dtype == RR_F32 ? pass2_run<float>(b, false, (const float *)dX, (const float *)dy, N, ldx, m, C, sqerr, T)
+                             : pass2_run<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, C, sqerr, T);
+}
+
+int rr_rff_predict_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                       int n_ls, const double *m, const double *C, double *Ey, double *Vf) {
+    int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, C, "rr_rff_predict_dev");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(Ey != nullptr && Vf != nullptr, "rr_rff_predict_dev: null argument");
+    return x_dtype == RR_F32 ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, C, Ey, Vf)
+                             : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, C, Ey, Vf);
+}
+
+}  // extern "C"

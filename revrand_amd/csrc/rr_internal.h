@@ -35,6 +35,7 @@ struct rr_basis {
     std::vector<double> ls_cache; // lenscale the device copy was scaled with
     float *dWs32 = nullptr;       // (dpad, npad), zero padded: W[i][f] / (l_i * 2pi)   -> phase in revolutions
     double *dWs64 = nullptr;      // same in f64
+    float *dWt32 = nullptr;       // (npad, dpad): the same weights transposed (feature-major kernels)
     float *dgfac32 = nullptr;     // (d,): 2pi / l_i  (grad kernels)
     double *dgfac64 = nullptr;
     void *zbuf = nullptr;         // feature scratch of the Gram path (f32 or f64), grow-only

@@ -6,8 +6,8 @@
 // t - rint(t) in [-0.5, 0.5] the hardware v_sin_f32 / v_cos_f32 (which take revolutions)
 // give sin/cos directly.
 #include "rr_internal.h"
+#include "rr_mfma_tile.h"
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 // ---------------------------------------------------------------------------------------
 // device helpers
@@ -134,10 +134,6 @@ rr_rff_grad_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *_
 // MFMA time.  The projection and the transcendentals therefore run once per row in (A) instead
 // of once per (row, tile) inside (B), and (B)'s instruction stream is DMA + ds_read + MFMA only.
 // ---------------------------------------------------------------------------------------
-constexpr int GR_TC = 256;   // columns per tile side
-constexpr int GR_KB = 32;    // rows per k-block
-constexpr int GR_LD = 512;   // LDS tile row length (floats): [A side 256 | B side 256]
-constexpr int GR_THREADS = 512;
 
 template <int DMAX, bool HAS_Y, typename TX, typename TC>
 __global__ void __launch_bounds__(256)
@@ -197,8 +193,6 @@ struct SyrkArgs {
     int ablate;  // debug (RR_GRAM_ABLATE): bit0 = no in-loop DMA, bit1 = no in-loop barrier
 };
 
-typedef __attribute__((address_space(1))) const void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
 
 // One k-block tile: 32 rows x (256 + 256) floats = 64 row-segments of 1 KiB; wave w moves rows
 // 4w..4w+3 (both sides) with 8 LDS-DMA instructions, lane l carrying bytes [16 l, 16 l + 16).
@@ -213,71 +207,6 @@ __device__ __forceinline__ void syrk_dma_tile(const SyrkArgs &p, float *buf, int
         __builtin_amdgcn_global_load_lds((gptr_t)(src + cb), (lptr_t)(dst + GR_TC), 16, 0, 0);
     }
 }
-
-typedef float float2v __attribute__((ext_vector_type(2)));
-
-// ds_read2st64_b32: two dwords at byte addresses addr + O0*256 and addr + O1*256.  Written as
-// inline asm because hipcc prefers to pair neighbouring columns into ds_read2_b32, whose 8-bit
-// dword offsets cannot span rows, and then pays a v_add per row -- VALU time is MFMA time on
-// this chip.  The compiler does not count asm loads: lds_wait() + sched_barrier precede every use.
-template <int O0, int O1>
-__device__ __forceinline__ float2v lds_read2st64(unsigned addr) {
-    float2v r;
-    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "i"(O0), "i"(O1));
-    return r;
-}
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-// MFMA operands of k-steps 2P and 2P+1 (rows 4P + h and 4P + 2 + h, h = lane >> 5 folded into the
-// base addresses): a[i] = {A col block i of step 2P, of step 2P+1}, b[j] likewise.
-struct KOps2 {
-    float2v a[4], b[2];
-    template <int P>
-    __device__ __forceinline__ void load(const unsigned (&abase)[4], const unsigned (&bbase)[2]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = lds_read2st64<32 * P, 32 * P + 16>(abase[i]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = lds_read2st64<32 * P, 32 * P + 16>(bbase[j]);
-    }
-};
-
-// MFMAs [FIRST, LAST) of the 16 of a k-step pair, in (s, i, j) order s*8 + i*2 + j
-template <int FIRST, int LAST>
-__device__ __forceinline__ void gram_mfma(const KOps2 &o, floatx16 (&acc)[4][2]) {
-#pragma unroll
-    for (int q = FIRST; q < LAST; ++q)
-        acc[(q >> 1) & 3][q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(q >> 1) & 3][q >> 3], o.b[q & 1][q >> 3],
-                                                                        acc[(q >> 1) & 3][q & 1], 0, 0, 0);
-}
-
-// 16 k-steps (8 MFMAs each) over the current tile, operands double-buffered in registers, two
-// k-steps per buffer.  Pinned order per pair: [wait] [first MFMA of pair P] [LDS reads of pair
-// P+1] [other 15 MFMAs of P].  The wait for P's operands sits before P+1's reads are issued (so
-// it never waits for them), and the reads fly under 15 MFMAs (960 cycles).  If every read sat
-// just before its use, the two waves of a SIMD -- which interleave their MFMAs 1:1 and so stay
-// in lockstep -- would stall on LDS latency together.
-#define RR_PAIR(P, CUR, NXT)                                   \
-    lds_wait();                                                \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    gram_mfma<0, 1>(CUR, acc);                                 \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase); \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    gram_mfma<1, 16>(CUR, acc);                                \
-    __builtin_amdgcn_sched_barrier(0);
-
-__device__ __forceinline__ void gram_consume(unsigned cur, floatx16 (&acc)[4][2], unsigned aoff, unsigned boff) {
-    unsigned abase[4], bbase[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) abase[i] = cur + aoff + i * 128;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bbase[j] = cur + boff + j * 128;
-    KOps2 o0, o1;
-    o0.load<0>(abase, bbase);
-    RR_PAIR(0, o0, o1) RR_PAIR(1, o1, o0) RR_PAIR(2, o0, o1) RR_PAIR(3, o1, o0)
-    RR_PAIR(4, o0, o1) RR_PAIR(5, o1, o0) RR_PAIR(6, o0, o1) RR_PAIR(7, o1, o0)
-}
-#undef RR_PAIR
 
 __global__ void __launch_bounds__(GR_THREADS, 2)
 rr_syrk_f32_kernel(const SyrkArgs p) {
@@ -1108,6 +1037,45 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         b->events_used = e0 + 4;
     }
     b->gram_kernel = F32 ? "rr_syrk_f32_kernel" : "rr_syrk_f64_kernel";
+    return RR_OK;
+}
+
+// Row-major f32 features of a row block into a caller-provided scratch (used by the second _elbo pass).
+int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
+                             float *P, int64_t ldp) {
+    rr_ctx *c = b->ctx;
+    const int F = 2 * b->n;
+    const float scale = (float)(1.0 / sqrt((double)b->n));
+    if (ldp > F) {
+        const int64_t cnt = mpad * (ldp - F);
+        hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
+                           mpad, ldp, F);
+    }
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = 256;
+    if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((mpad + rpb - 1) / rpb));
+#define RR_LF(DM)                                                                                                   \
+    do {                                                                                                            \
+        if (x_dtype == RR_F32)                                                                                      \
+            hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, float, float>), grid, dim3(256), 0, c->stream,     \
+                               (const float *)dX, (const float *)nullptr, m, mpad, ldx, b->dWs32, b->n, b->npad, P,  \
+                               ldp, (double *)nullptr, scale, (int)rpb);                                             \
+        else                                                                                                        \
+            hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, double, float>), grid, dim3(256), 0, c->stream,    \
+                               (const double *)dX, (const double *)nullptr, m, mpad, ldx, b->dWs32, b->n, b->npad, P, \
+                               ldp, (double *)nullptr, scale, (int)rpb);                                             \
+    } while (0)
+    switch (b->dpad) {
+        case 8: RR_LF(8); break;
+        case 16: RR_LF(16); break;
+        case 32: RR_LF(32); break;
+        case 64: RR_LF(64); break;
+        case 128: RR_LF(128); break;
+        default: rr_set_error("features: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_LF
+    RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
 

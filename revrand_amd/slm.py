@@ -59,9 +59,16 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         params = [self.var, self.basis.regularizer, self.basis.params]
         nmin = structured_minimizer(logtrick_minimizer(minimize))
         elbo = partial(StandardLinearModel._elbo, self, X, y)
-        res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
-                   options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
-                   nstarts=self.nstarts)
+        # a single random-feature basis keeps (X, y) on the GPU for the whole optimisation
+        self._state = self.basis.device_fit_state(X, y) if hasattr(self.basis, "device_fit_state") else None
+        try:
+            res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
+                       options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
+                       nstarts=self.nstarts)
+        finally:
+            if self._state is not None:
+                self._state.release()
+            self._state = None
         self.var_, self.regularizer_, self.hypers_ = res.x
         log.info("Done! ELBO = {}, var = {}, reg = {}, hypers = {}, message = {}."
                  .format(-res["fun"], self.var_, self.regularizer_, self.hypers_, res.message))
@@ -83,7 +90,36 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         G2, _, _ = _hip.dense_gram(np.hstack((Phi, dPhi)))
         return G2[:F, F:]
 
+    def _elbo_resident(self, X, y, var, reg, hypers):
+        """`_elbo` for a single random-feature basis with (X, y) resident on the device: two data
+        passes on the GPU (statistics; Err / U = Phi C / gradient contraction), Cholesky on the host,
+        neither Phi nor dPhi ever materialised."""
+        st = self._state
+        N = X.shape[0]
+        PhiPhi, Phiy, _ = st.gram(hypers)
+        D = PhiPhi.shape[0]
+        L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
+        iL = 1. / L
+        iC = np.diag(iL) + PhiPhi / var
+        C, logdetiC = solve_posdef(iC, np.eye(D))
+        logdetC = -logdetiC
+        m = C.dot(Phiy) / var
+        TrPhiPhiC = (PhiPhi * C).sum()
+        sqErr, dhypers = st.second_pass(hypers, m, C, var)
+        ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
+                       + ((m ** 2 + C.diagonal()) * iL).sum() - logdetC + np.log(L).sum() - D)
+        if ELBO > self.obj_:
+            self.weights_ = m
+            self.covariance_ = C
+            self.obj_ = ELBO
+        log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
+        dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
+        dL = -0.5 * (((m ** 2 + C.diagonal()) * iL ** 2).sum() - iL.sum())
+        return -ELBO, [-dvar, dL, dhypers]
+
     def _elbo(self, X, y, var, reg, hypers):
+        if getattr(self, "_state", None) is not None:
+            return self._elbo_resident(X, y, var, reg, hypers)
         hyp = atleast_list(hypers)
         Phi = self.basis.transform(X, *hyp)  # N x D
         N, D = Phi.shape
@@ -137,6 +173,9 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         """Predictive mean and variance (slm.py:219-244)."""
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
         X = check_array(X)
+        if hasattr(self.basis, "predict_moments") and getattr(self.basis, "dtype", None) == "f32":
+            Ey, Vf = self.basis.predict_moments(X, self.hypers_, self.weights_, self.covariance_)  # on the GPU
+            return Ey, Vf + self.var_
         Phi = self.basis.transform(X, *atleast_list(self.hypers_))
         Ey = Phi.dot(self.weights_)
         Vf = (Phi.dot(self.covariance_) * Phi).sum(axis=1)

@@ -160,3 +160,54 @@ def test_elbo_f64_mode_vs_reference(golden, tag):
     assert normwise(-ndvar, g[tag + "_dvar"]) < 1e-5
     assert normwise(-np.atleast_1d(ndreg), g[tag + "_dreg"]) < 1e-5
     assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 2e-3
+
+
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+def test_resident_elbo_matches_reference(golden, tag):
+    """The device-resident `_elbo` (no Phi, no dPhi: statistics pass + U = Phi C GEMM pass) against the
+    reference's golden ELBO / gradients / posterior."""
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    lsp = Parameter(1., Positive()) if tag == "iso" else Parameter(np.ones(d), Positive())
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=lsp)
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    slm._state = basis.device_fit_state(X, y)
+    assert slm._state is not None
+    ls = float(g[tag + "_ls"]) if tag == "iso" else g[tag + "_ls"]
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), float(g["reg"]), ls)
+    slm._state.release()
+    assert abs(-nelbo - g[tag + "_elbo"]) < 1e-4 * abs(g[tag + "_elbo"])
+    assert normwise(slm.weights_, g[tag + "_m"]) < 1e-3
+    assert normwise(-ndvar, g[tag + "_dvar"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndreg), g[tag + "_dreg"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 2e-3
+    assert np.shape(ndhyp) == (() if tag == "iso" else (d,))
+
+
+@pytest.mark.parametrize("shape", [(700, 5, 40), (1500, 16, 96), (1025, 21, 130)])
+def test_second_pass_and_predict_vs_oracle(shape):
+    """sqErr, the gradient contraction and predict_moments on the device vs the oracle's dPhi-based formulas."""
+    bs, Parameter, Positive, SLM = _imports()
+    N, d, n = shape
+    rs = np.random.RandomState(N)
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    basis = bs.RandomMatern52(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+    ls = np.linspace(0.7, 1.5, d)
+    var, reg = 0.3, 1.4
+    Phi = orc.rff_transform(X, basis.W, ls)
+    dP = orc.rff_grad(X, basis.W, ls)
+    o = orc.slm_elbo(Phi, y, var, np.full(2 * n, reg), slice(None), [dP[:, :, i] for i in range(d)])
+    st = basis.device_fit_state(X, y)
+    sq, dh = st.second_pass(ls, o["m"], o["C"], var)
+    st.release()
+    err = y - Phi @ o["m"]
+    assert abs(sq - err @ err) < 1e-4 * (err @ err)
+    assert normwise(dh, -np.array(o["dhyp"])) < 2e-3        # reference passes -dELBO/dl to the optimiser
+    Xs = rs.randn(257, d)
+    Ey, Vf = basis.predict_moments(Xs, ls, o["m"], o["C"])
+    Eo, Vo = orc.slm_predict_moments(orc.rff_transform(Xs, basis.W, ls), o["m"], o["C"], 0.0)
+    assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
