@@ -169,6 +169,28 @@ int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int6
 int rr_dense_gram(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi,
                   const void *y, double *G, double *b, double *yty);
 
+/* ---- concatenated bases: one device feature matrix, one Gram ---------------------------------
+ * BasisCat.transform hstacks the children's Phi (basis_functions.py:1599-1627) before slm.py:146,157
+ * contract it.  Here the children write their column blocks into ONE zero-padded f32 device matrix
+ * (rows <= max_rows, F columns) and the MFMA SYRK kernel reduces it; nothing crosses PCIe.
+ *   rr_featmat_begin(rows)      start a row block (zeroes the matrix)
+ *   rr_featmat_put_rff          [cos | sin] / sqrt(n) of a random Fourier basis at columns [col0, col0 + 2n)
+ *   rr_featmat_put_linear       LinearBasis.transform ([1, X] or X, basis_functions.py:468-485) at col0
+ *   rr_featmat_put_host         any other basis: a host (rows, ncols) block at col0
+ *   rr_featmat_gram             G(upper) += P^T P, b += P^T y, yty += y^T y into DEVICE f64 buffers
+ * dX / dy are device pointers (dX in the padded layout for put_rff); all calls asynchronous on the
+ * context stream except put_host. */
+typedef struct rr_featmat rr_featmat;
+int rr_featmat_create(rr_ctx *ctx, int64_t max_rows, int64_t F, rr_featmat **out);
+void rr_featmat_destroy(rr_featmat *fm);
+int rr_featmat_begin(rr_featmat *fm, int64_t rows);
+int rr_featmat_put_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx,
+                       const double *lenscale, int n_ls, int64_t col0);
+int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol,
+                          int64_t col0);
+int rr_featmat_put_host(rr_featmat *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0);
+int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty);
+
 /* ---- second data pass of the standard linear model (posterior known) -----------------------
  * With m (F,) and C (F, F) from the host Cholesky (slm.py:154-157), for a random Fourier basis and
  * DEVICE-resident X (padded layout, see rr_rff_padded_dim) and y:

@@ -70,6 +70,17 @@ SIGNATURES = {
     "rr_dense_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+    "rr_featmat_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, _c_void_pp]),
+    "rr_featmat_destroy": (None, [ctypes.c_void_p]),
+    "rr_featmat_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "rr_featmat_put_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "rr_featmat_put_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "rr_featmat_put_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                           ctypes.c_int64, ctypes.c_int64]),
+    "rr_featmat_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p]),
     "rr_rff_elbo_pass2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -336,6 +347,46 @@ def dense_gram(Phi, y=None, device=None):
                                           G.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                           yty.ctypes.data_as(ctypes.c_void_p)))
     return G, b, float(yty[0])
+
+
+class FeatureMatrix(object):
+    """Device feature matrix of a concatenated basis (rr_featmat): children put column blocks, then one Gram."""
+
+    def __init__(self, max_rows, F, device=None):
+        self.dev = get_device(device)
+        self.lib = self.dev.lib
+        self.F, self.max_rows = int(F), int(max_rows)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_featmat_create(self.dev.ctx, self.max_rows, self.F, ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.rr_featmat_destroy(h)
+            except Exception:
+                pass
+
+    def begin(self, rows):
+        _check(self.lib, self.lib.rr_featmat_begin(self.h, rows))
+
+    def put_rff(self, handle, dX, lenscale, col0):
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, self.lib.rr_featmat_put_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, lsp, nls, col0))
+
+    def put_linear(self, dX, onescol, col0):
+        _check(self.lib, self.lib.rr_featmat_put_linear(self.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, dX.shape[1],
+                                                        1 if onescol else 0, col0))
+
+    def put_host(self, Phi, col0):
+        Phi = as_float_matrix(Phi)
+        _check(self.lib, self.lib.rr_featmat_put_host(self.h, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype),
+                                                      Phi.shape[1], _ld(Phi), col0))
+
+    def gram_into(self, dy, dG, db=None, dyty=None):
+        _check(self.lib, self.lib.rr_featmat_gram(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0,
+                                                  _ptr(dG), _ptr(db), _ptr(dyty)))
 
 
 def hadamard(Y, ordering=True, device=None):

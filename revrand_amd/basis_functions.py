@@ -133,6 +133,17 @@ class Basis(object):
         mine, rest = self.__split(args, self.transform)
         return self.transform(X, *mine), rest
 
+    def _put_features_popargs(self, X, fm, col0, *args):
+        """Write this basis' columns of a device feature matrix (concatenated Gram); returns the
+        parameters left for the following bases."""
+        mine, rest = self.__split(args, self.transform)
+        self._put_features(X, fm, col0, *mine)
+        return rest
+
+    def _put_features(self, X, fm, col0, *params):
+        # generic bases: host transform, one upload of their (usually narrow) column block
+        fm.put_host(self.transform(X, *params), col0)
+
     def _grad_popargs(self, X, *args):
         mine, rest = self.__split(args, self.grad)
         return self.grad(X, *mine), rest, mine
@@ -187,6 +198,13 @@ class LinearBasis(Basis):
     def transform(self, X):
         N, D = X.shape
         return np.hstack((np.ones((N, 1)), X)) if self.onescol else X
+
+    @slice_transform
+    def _put_features(self, X, fm, col0):
+        dX = fm.dev.upload_matrix(np.ascontiguousarray(X, dtype=np.float32))
+        fm.put_linear(dX, self.onescol, col0)
+        fm.dev.sync()
+        dX.free()
 
     def __repr__(self):
         return "{}(onescol={}, regularizer={})".format(type(self).__name__, self.onescol, self.regularizer)
@@ -303,6 +321,15 @@ class _RandomKernelBasis(_LengthScaleBasis):
         N, D = X.shape
         lenscale = self._check_dim(D, lenscale)
         return self._handle().gram(X, y, lenscale)
+
+    @slice_transform
+    def _put_features(self, X, fm, col0, lenscale=None):
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        h = self._handle()
+        dX = h.upload(np.ascontiguousarray(X, dtype=np.float32))
+        fm.put_rff(h, dX, lenscale, col0)
+        fm.dev.sync()
+        dX.free()
 
     @slice_transform
     def device_fit_state(self, X, y):
@@ -466,6 +493,15 @@ class FastFoodRBF(_LengthScaleBasis):
         return self._handles()[1].gram(X, y, lenscale)
 
     @slice_transform
+    def _put_features(self, X, fm, col0, lenscale=None):
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        h = self._handles()[1]
+        dX = h.upload(np.ascontiguousarray(X, dtype=np.float32))
+        fm.put_rff(h, dX, lenscale, col0)
+        fm.dev.sync()
+        dX.free()
+
+    @slice_transform
     def device_fit_state(self, X, y):
         if self.dtype != "f32" or X.shape[1] != self.d:
             return None
@@ -523,6 +559,38 @@ class BasisCat(object):
                 full = np.zeros((N, D) if gg.ndim < 3 else (N, D, gg.shape[2]))
                 full[:, ends[i]:ends[i + 1]] = gg
                 yield full
+
+    def gram(self, X, y=None, *params):
+        """(Phi^T Phi, Phi^T y, y^T y) of the concatenation with Phi assembled ON the device: every
+        child writes its column block of one feature matrix (random Fourier / FastFood / linear bases
+        by kernels, anything else by one upload of its host block), one MFMA SYRK reduces it
+        (slm.py:145-146,157 for a BasisCat).  f32 arithmetic."""
+        N = X.shape[0]
+        F = int(self.get_dim(X))
+        ends = self.__base_locations(X)
+        dev = _hip.get_device()
+        chunk = int(max(32, min(N, (8 << 30) // (4 * ((F + 255) // 256 * 256)))))
+        fm = _hip.FeatureMatrix(chunk, F)
+        acc = dev.zeros((F * F + F + 1) * 8)
+        base = acc.ptr.value
+        pG, pb, pt = (_hip.ctypes.c_void_p(base), _hip.ctypes.c_void_p(base + F * F * 8),
+                      _hip.ctypes.c_void_p(base + (F * F + F) * 8))
+        for r0 in range(0, N, chunk):
+            Xc = X[r0:r0 + chunk]
+            fm.begin(Xc.shape[0])
+            args = list(params)
+            for i, b in enumerate(self.bases):
+                args = b._put_features_popargs(Xc, fm, int(ends[i]), *args)
+            dy = None if y is None else dev.upload_vector(np.ascontiguousarray(y[r0:r0 + chunk], dtype=np.float32))
+            fm.gram_into(dy, pG, None if y is None else pb, None if y is None else pt)
+            dev.sync()
+        _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
+        out = dev.download(acc, (F * F + F + 1,), np.float64)
+        acc.free()
+        G = out[:F * F].reshape(F, F)
+        if y is None:
+            return G, None, None
+        return G, out[F * F:F * F + F].copy(), float(out[-1])
 
     def get_dim(self, X):
         return np.sum(self.__all_dims(X))

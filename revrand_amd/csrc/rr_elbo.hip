@@ -209,7 +209,7 @@ struct Pass2Scratch {
 };
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             float *P, int64_t ldp);  // rr_rff.hip
+                             float *P, int64_t ldp, bool zero_pad_cols);  // rr_rff.hip
 
 template <typename TX>
 static int launch_features_t(rr_basis *b, const TX *X, int64_t N, int64_t Npad, int64_t ldx, const float *m32,
@@ -312,7 +312,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         const int64_t mpad = (mrows + 255) / 256 * 256;
         const TX *Xc = dX + r0 * ldx;
         // row-major P (epilogues) and feature-major Pt + Phi m (GEMM operand)
-        rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp);
+        rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp, true);
         if (rc != RR_OK) break;
         rc = launch_features_t<TX>(b, Xc, mrows, mpad, ldx, s.m32, s.Pt, chunk, s.dot);
         if (rc != RR_OK) break;

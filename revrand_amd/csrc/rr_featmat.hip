@@ -1,0 +1,205 @@
+// Device feature matrix: the zero-padded f32 scratch P (rows % 32 == 0, ld % 256 == 0) that the MFMA
+// SYRK kernel consumes, filled column block by column block by the children of a concatenated basis
+// (BasisCat.transform's hstack, basis_functions.py:1599-1627, without leaving the GPU), then reduced
+// to Phi^T Phi / Phi^T y (slm.py:146,157).
+#include "rr_internal.h"
+
+int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
+                             float *P, int64_t ldp, bool zero_pad_cols);
+int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid);
+
+struct rr_featmat {
+    rr_ctx *ctx = nullptr;
+    float *P = nullptr;
+    int64_t max_rows = 0, ld = 0, rows = 0, rows_pad = 0;
+    int F = 0;
+};
+
+// [1, X] or X (LinearBasis.transform, basis_functions.py:468-485) into columns [col0, col0 + d + onescol)
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_linear_features_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int onescol, float *__restrict__ P,
+                          int64_t ldp) {
+    const int w = d + onescol;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * w) return;
+    const int64_t r = i / w;
+    const int c = (int)(i % w);
+    P[r * ldp + c] = (onescol && c == 0) ? 1.f : (float)X[r * ldx + (c - onescol)];
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(256)
+rr_copy_cols_kernel(const TS *__restrict__ src, int64_t N, int64_t lds_, int ncols, float *__restrict__ P, int64_t ldp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * ncols) return;
+    const int64_t r = i / ncols;
+    const int c = (int)(i % ncols);
+    P[r * ldp + c] = (float)src[r * lds_ + c];
+}
+
+template <typename TY>
+__global__ void __launch_bounds__(256) rr_fm_gemv_t_kernel(const float *__restrict__ P, const TY *__restrict__ y,
+                                                           int64_t rows, int F, int64_t ldp, double *__restrict__ bvec,
+                                                           int rows_per_block) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (c >= F) return;
+    float acc = 0.f;
+    for (int64_t r = r0; r < r1; ++r) acc = fmaf(P[r * ldp + c], (float)y[r], acc);
+    unsafeAtomicAdd(&bvec[c], (double)acc);
+}
+
+template <typename TY>
+__global__ void __launch_bounds__(256) rr_fm_yty_kernel(const TY *__restrict__ y, int64_t N, double *out) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[i];
+        acc += v * v;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+extern "C" {
+
+int rr_featmat_create(rr_ctx *ctx, int64_t max_rows, int64_t F, rr_featmat **out) {
+    RR_REQUIRE(ctx != nullptr && out != nullptr, "rr_featmat_create: null argument");
+    *out = nullptr;
+    RR_REQUIRE(max_rows >= 1 && F >= 1 && F < (1 << 30), "rr_featmat_create: bad shape");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    rr_featmat *fm = new rr_featmat();
+    fm->ctx = ctx;
+    fm->F = (int)F;
+    fm->ld = (F + 255) / 256 * 256;
+    fm->max_rows = (max_rows + 31) / 32 * 32;
+    hipError_t e = hipMalloc((void **)&fm->P, (size_t)fm->max_rows * fm->ld * sizeof(float));
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_featmat_create: hipMalloc(%zu bytes) failed", (size_t)fm->max_rows * fm->ld * 4);
+        delete fm;
+        return RR_ERR_OOM;
+    }
+    *out = fm;
+    return RR_OK;
+}
+
+void rr_featmat_destroy(rr_featmat *fm) {
+    if (!fm) return;
+    (void)hipSetDevice(fm->ctx->device);
+    (void)hipStreamSynchronize(fm->ctx->stream);
+    if (fm->P) (void)hipFree(fm->P);
+    delete fm;
+}
+
+int rr_featmat_begin(rr_featmat *fm, int64_t rows) {
+    RR_REQUIRE(fm != nullptr && rows >= 0 && rows <= fm->max_rows, "rr_featmat_begin: rows out of range");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    fm->rows = rows;
+    fm->rows_pad = (rows + 31) / 32 * 32;
+    // every column block is overwritten by a put_* call; zero everything once so pad rows/columns are zero
+    RR_CHECK_HIP(hipMemsetAsync(fm->P, 0, (size_t)fm->rows_pad * fm->ld * sizeof(float), fm->ctx->stream));
+    return RR_OK;
+}
+
+int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale,
+                       int n_ls, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && b != nullptr && b->kind == RR_KIND_RFF, "rr_featmat_put_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_put_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_put_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad, "rr_featmat_put_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK || fm->rows == 0) return rc;
+    RR_REQUIRE(dX != nullptr, "rr_featmat_put_rff: null X");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    // the feature kernel writes columns [0, 2n) relative to its base; pad handling is ours (begin())
+    return rr_features_rowmajor_f32(b, dX, x_dtype, fm->rows, fm->rows, ldx, fm->P + col0, fm->ld, false);
+}
+
+int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && d >= 1 && ldx >= d, "rr_featmat_put_linear: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_put_linear: bad dtype");
+    const int w = d + (onescol ? 1 : 0);
+    RR_REQUIRE(col0 >= 0 && col0 + w <= fm->F, "rr_featmat_put_linear: columns out of range");
+    if (fm->rows == 0) return RR_OK;
+    RR_REQUIRE(dX != nullptr, "rr_featmat_put_linear: null X");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    const int64_t cnt = fm->rows * w;
+    const dim3 grid((unsigned)((cnt + 255) / 256));
+    if (x_dtype == RR_F32)
+        hipLaunchKernelGGL(rr_linear_features_kernel<float>, grid, dim3(256), 0, fm->ctx->stream, (const float *)dX,
+                           fm->rows, ldx, d, onescol ? 1 : 0, fm->P + col0, fm->ld);
+    else
+        hipLaunchKernelGGL(rr_linear_features_kernel<double>, grid, dim3(256), 0, fm->ctx->stream, (const double *)dX,
+                           fm->rows, ldx, d, onescol ? 1 : 0, fm->P + col0, fm->ld);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_featmat_put_host(rr_featmat *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && ncols >= 1 && ldphi >= ncols, "rr_featmat_put_host: bad argument");
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_featmat_put_host: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + ncols <= fm->F, "rr_featmat_put_host: columns out of range");
+    if (fm->rows == 0) return RR_OK;
+    RR_REQUIRE(Phi != nullptr, "rr_featmat_put_host: null Phi");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = dtype == RR_F32 ? 4 : 8;
+    void *raw = nullptr;
+    RR_CHECK_HIP(hipMalloc(&raw, (size_t)fm->rows * ncols * es));
+    hipError_t e = hipMemcpy2DAsync(raw, (size_t)ncols * es, Phi, (size_t)ldphi * es, (size_t)ncols * es, (size_t)fm->rows,
+                                    hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int64_t cnt = fm->rows * ncols;
+        const dim3 grid((unsigned)((cnt + 255) / 256));
+        if (dtype == RR_F32)
+            hipLaunchKernelGGL(rr_copy_cols_kernel<float>, grid, dim3(256), 0, c->stream, (const float *)raw, fm->rows, ncols,
+                               (int)ncols, fm->P + col0, fm->ld);
+        else
+            hipLaunchKernelGGL(rr_copy_cols_kernel<double>, grid, dim3(256), 0, c->stream, (const double *)raw, fm->rows,
+                               ncols, (int)ncols, fm->P + col0, fm->ld);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(raw);
+    if (e != hipSuccess) {
+        rr_set_error("rr_featmat_put_host: copy failed: %s", hipGetErrorString(e));
+        return RR_ERR_HIP;
+    }
+    return RR_OK;
+}
+
+int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty) {
+    RR_REQUIRE(fm != nullptr && dG != nullptr, "rr_featmat_gram: null argument");
+    RR_REQUIRE((dy == nullptr) == (db == nullptr) && (dy == nullptr) == (dyty == nullptr),
+               "rr_featmat_gram: y, b and yty must be given together");
+    RR_REQUIRE(dy == nullptr || y_dtype == RR_F32 || y_dtype == RR_F64, "rr_featmat_gram: bad dtype");
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    if (dy) {
+        const int rpb = 512;
+        const dim3 gg((unsigned)((fm->F + 255) / 256), (unsigned)((fm->rows + rpb - 1) / rpb));
+        int yb = (int)((fm->rows + 255) / 256);
+        if (yb > c->num_cu * 8) yb = c->num_cu * 8;
+        if (y_dtype == RR_F32) {
+            hipLaunchKernelGGL(rr_fm_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, fm->P, (const float *)dy, fm->rows,
+                               fm->F, fm->ld, db, rpb);
+            hipLaunchKernelGGL(rr_fm_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, fm->rows, dyty);
+        } else {
+            hipLaunchKernelGGL(rr_fm_gemv_t_kernel<double>, gg, dim3(256), 0, c->stream, fm->P, (const double *)dy, fm->rows,
+                               fm->F, fm->ld, db, rpb);
+            hipLaunchKernelGGL(rr_fm_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, fm->rows, dyty);
+        }
+        RR_CHECK_HIP(hipGetLastError());
+    }
+    return rr_launch_syrk_f32(c, fm->P, fm->rows_pad, fm->ld, fm->F, dG, nullptr);
+}
+
+}  // extern "C"

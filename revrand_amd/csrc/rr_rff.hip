@@ -1042,11 +1042,11 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
 
 // Row-major f32 features of a row block into a caller-provided scratch (used by the second _elbo pass).
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             float *P, int64_t ldp) {
+                             float *P, int64_t ldp, bool zero_pad_cols) {
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n;
     const float scale = (float)(1.0 / sqrt((double)b->n));
-    if (ldp > F) {
+    if (zero_pad_cols && ldp > F) {
         const int64_t cnt = mpad * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);

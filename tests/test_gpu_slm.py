@@ -211,3 +211,30 @@ def test_second_pass_and_predict_vs_oracle(shape):
     Ey, Vf = basis.predict_moments(Xs, ls, o["m"], o["C"])
     Eo, Vo = orc.slm_predict_moments(orc.rff_transform(Xs, basis.W, ls), o["m"], o["C"], 0.0)
     assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
+
+
+def test_concat_gram_on_device_vs_oracle():
+    """BASELINE config 3 shape in miniature: RandomMatern52 + LinearBasis(onescol) (+ a generic basis),
+    Phi assembled on the device, one SYRK."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(8)
+    N, d, n = 3001, 12, 150
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    ls = np.linspace(0.7, 1.4, d)
+    base = bs.RandomMatern52(nbases=n, Xdim=d, random_state=4, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True) + bs.BiasBasis(offset=2.0) \
+        + bs.FastFoodRBF(nbases=20, Xdim=2, random_state=5, apply_ind=[3, 1])
+    G, b, yty = base.gram(X, y, ls, 0.9)
+    Phi = base.transform(X, ls, 0.9)       # per-child GPU transforms, host hstack
+    W = base.bases[0].W
+    B, Gm, PI, S = orc.fastfood_matrices(20, 2, 5)
+    ref = np.hstack((orc.rff_transform(X, W, ls), orc.linear_transform(X), np.full((N, 1), 2.0),
+                     orc.fastfood_transform(X[:, [3, 1]], B, Gm, PI, S, 0.9)))
+    assert normwise(Phi, ref) < 1e-3
+    F = ref.shape[1]
+    assert G.shape == (F, F) and np.array_equal(G, G.T)
+    assert normwise(G, ref.T @ ref) < 1e-4
+    assert normwise(b, ref.T @ y) < 1e-4 and abs(yty - y @ y) < 1e-5 * (y @ y)
+    G2, b2, t2 = base.gram(X, None, ls, 0.9)
+    assert b2 is None and normwise(G2, ref.T @ ref) < 1e-4
