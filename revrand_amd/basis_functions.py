@@ -269,9 +269,12 @@ class DeviceFitState(object):
 class _RandomKernelBasis(_LengthScaleBasis):
     """Phi = [cos(X W/l), sin(X W/l)]/sqrt(nbases); subclasses only sample W."""
 
+    _default_dtype = "f32"
+
     @slice_init
     def __init__(self, nbases, Xdim, lenscale=Parameter(gamma(1.), Positive()), regularizer=None,
-                 random_state=None, dtype="f32"):
+                 random_state=None, dtype=None):
+        dtype = self._default_dtype if dtype is None else dtype
         if dtype not in ("f32", "f64"):
             raise ValueError("dtype must be 'f32' or 'f64'")
         self.d = Xdim
@@ -357,7 +360,13 @@ class RandomRBF(_RandomKernelBasis):
 
 
 class RandomLaplace(_RandomKernelBasis):
-    """Laplace kernel features: W ~ Cauchy (basis_functions.py:957-995)."""
+    """Laplace kernel features: W ~ Cauchy (basis_functions.py:957-995).
+
+    Cauchy draws reach |W| ~ 1e5 at nbases = 2048, i.e. phases of ~1e5 revolutions, which an f32
+    accumulator resolves to only ~1e-2 rad: this class therefore defaults to ``dtype="f64"``
+    (measured: 6e-2 normwise error in f32 vs 1e-11 in f64 at d=32, nbases=2048).
+    """
+    _default_dtype = "f64"
 
     def _weightsamples(self):
         return self._random.standard_cauchy(size=(self.d, self.n))

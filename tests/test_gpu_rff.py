@@ -192,3 +192,18 @@ def test_gram_f64_vs_oracle(shape):
     X32 = X.astype(np.float32)
     G32, _, _ = b.gram(X32, None, ls)
     assert normwise(G32, orc.rff_gram_chunked(X32.astype(np.float64), y, b.W, ls)[0]) < 1e-10
+
+
+def test_heavy_tailed_weights_at_scale():
+    """Cauchy-distributed frequencies (RandomLaplace) at the headline width: phases of ~1e5 revolutions.
+    The class defaults to f64 arithmetic; f32 stays within tolerance for the lighter-tailed bases."""
+    bs = _bs()
+    rs = np.random.RandomState(0)
+    X = rs.randn(500, 32).astype(np.float32)
+    b = bs.RandomLaplace(nbases=2048, Xdim=32, random_state=1)
+    assert b.dtype == "f64" and np.abs(b.W).max() > 1e3
+    assert normwise(b.transform(X, 1.0), orc.rff_transform(X, b.W, 1.0)) < 1e-5
+    for cname in ("RandomRBF", "RandomCauchy", "RandomMatern32", "RandomMatern52", "OrthogonalRBF"):
+        b = getattr(bs, cname)(nbases=2048, Xdim=32, random_state=1)
+        assert b.dtype == "f32"
+        assert normwise(b.transform(X, 1.0), orc.rff_transform(X, b.W, 1.0)) < 1e-3, cname
