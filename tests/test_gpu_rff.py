@@ -207,3 +207,50 @@ def test_heavy_tailed_weights_at_scale():
         b = getattr(bs, cname)(nbases=2048, Xdim=32, random_state=1)
         assert b.dtype == "f32"
         assert normwise(b.transform(X, 1.0), orc.rff_transform(X, b.W, 1.0)) < 1e-3, cname
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 at full size (RandomRBF F=4096, D=32, N=1M, f32), checked through
+    size-independent properties instead of the (hours-long) CPU oracle:
+      * cos^2 + sin^2 = 1  =>  G[f,f] + G[n+f,n+f] = N/n for EVERY frequency, trace(G) = N;
+      * exact symmetry; linearity over row shards (two halves sum to the whole);
+      * a 4096-row slice agrees with the Gram of the GPU `transform` output of the same rows,
+        and that slice of Phi agrees with the oracle."""
+    from revrand_amd import _hip
+    N, d, n = 1_000_000, 32, 2048
+    F = 2 * n
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    y = np.sin(X @ rng.standard_normal(d, dtype=np.float32)).astype(np.float32)
+    b = _make("RandomRBF", d, n, 42, False, "f32")
+    h = b._handle()
+    dev = h.dev
+    dX = h.upload(X)
+    dy = dev.upload_vector(y)
+    G, bv, yty = h.gram_host(dX, dy, 1.0)
+    assert np.array_equal(G, G.T)
+    dg = np.diag(G)
+    assert np.abs(dg[:n] + dg[n:] - N / n).max() < 2e-5 * (N / n)
+    assert abs(np.trace(G) - N) < 1e-6 * N
+    assert abs(yty - float(y.astype(np.float64) @ y.astype(np.float64))) < 1e-9 * yty
+    # linearity over shards, through the device-resident accumulate-into API
+    acc = dev.zeros((F * F + F + 1) * 8)
+    base = acc.ptr.value
+    half = N // 2
+    for (r0, r1) in ((0, half), (half, N)):
+        dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value + r0 * dX.ld * 4), (r1 - r0, d), dX.ld, np.float32)
+        dys = _hip.DeviceBuffer(dev, _hip.ctypes.c_void_p(dy.ptr.value + r0 * 4), (r1 - r0) * 4)
+        h.gram_dev(dXs, dys, 1.0, _hip.ctypes.c_void_p(base), _hip.ctypes.c_void_p(base + F * F * 8),
+                   _hip.ctypes.c_void_p(base + (F * F + F) * 8))
+        dev.sync()
+        dXs.ptr = None  # views: not owned
+        dys.ptr = None
+    h.symmetrize_dev(_hip.ctypes.c_void_p(base))
+    out = dev.download(acc, (F * F + F + 1,), np.float64)
+    assert normwise(out[:F * F].reshape(F, F), G) < 1e-5 and normwise(out[F * F:F * F + F], bv) < 1e-5  # f32 K-splits differ
+    # a slice against transform + NumPy, and transform against the oracle
+    sl = slice(123_456, 123_456 + 4096)
+    P = b.transform(X[sl], 1.0)
+    Gs, bs_, _ = b.gram(X[sl], y[sl], 1.0)
+    assert normwise(Gs, P.T @ P) < 2e-5 and normwise(bs_, P.T @ y[sl].astype(np.float64)) < 2e-5
+    assert normwise(P[:256], orc.rff_transform(X[sl][:256], b.W, 1.0)) < 1e-3
