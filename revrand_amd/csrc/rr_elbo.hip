@@ -198,15 +198,30 @@ rr_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// Scratch of the second pass, kept by the basis between calls (a fit makes ~100 of them): grow-only.
 struct Pass2Scratch {
     float *P = nullptr, *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
     double *acc = nullptr;  // [sqErr | T (d*n)] or Vf
+    int64_t chunk = 0, Fp = 0;
+    size_t nacc = 0;
+    std::vector<float> hC, hm;  // host staging for the f64 -> f32 posterior
     void release() {
         void *q[] = {P, Pt, U, C32, m32, dot, err, acc};
         for (void *x : q)
             if (x) (void)hipFree(x);
+        P = Pt = U = C32 = m32 = dot = err = nullptr;
+        acc = nullptr;
+        chunk = Fp = 0;
+        nacc = 0;
     }
 };
+
+void rr_pass2_scratch_free(void *p) {
+    if (!p) return;
+    Pass2Scratch *s = (Pass2Scratch *)p;
+    s->release();
+    delete s;
+}
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              float *P, int64_t ldp, bool zero_pad_cols);  // rr_rff.hip
@@ -272,30 +287,44 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
     if (cenv && atoll(cenv) >= 256) chunk = atoll(cenv);
     if (chunk > N) chunk = N;
     chunk = (chunk + 255) / 256 * 256;
-    Pass2Scratch s;
+    if (!b->pass2) b->pass2 = new Pass2Scratch();
+    Pass2Scratch &s = *(Pass2Scratch *)b->pass2;
     const size_t nacc = pred ? (size_t)chunk : (size_t)1 + (size_t)b->d * n;
-    hipError_t e = hipMalloc((void **)&s.P, (size_t)chunk * Fp * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.Pt, (size_t)Fp * chunk * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.U, (size_t)chunk * Fp * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.C32, (size_t)Fp * Fp * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.m32, (size_t)F * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.dot, (size_t)chunk * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.err, (size_t)chunk * 4);
-    if (e == hipSuccess) e = hipMalloc((void **)&s.acc, nacc * 8);
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
+    if (s.chunk < chunk || s.Fp != Fp || s.nacc < nacc) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
         s.release();
-        rr_set_error("pass2: device allocation failed (%lld rows per chunk)", (long long)chunk);
-        return RR_ERR_OOM;
+        hipError_t ea = hipMalloc((void **)&s.P, (size_t)chunk * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Pt, (size_t)Fp * chunk * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.U, (size_t)chunk * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.C32, (size_t)Fp * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.m32, (size_t)F * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.dot, (size_t)chunk * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.err, (size_t)chunk * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.acc, nacc * 8);
+        if (ea != hipSuccess) {
+            (void)hipGetLastError();
+            s.release();
+            rr_set_error("pass2: device allocation failed (%lld rows per chunk)", (long long)chunk);
+            return RR_ERR_OOM;
+        }
+        s.chunk = chunk;
+        s.Fp = Fp;
+        s.nacc = nacc;
     }
+    chunk = s.chunk;  // the allocated leading dimension of Pt
+    hipError_t e = hipSuccess;
     int rc = RR_OK;
     {   // posterior to the device in f32: m (F), C padded to (Fp, Fp)
-        std::vector<float> m32(F), c32((size_t)Fp * Fp, 0.f);
-        for (int i = 0; i < F; ++i) m32[i] = (float)mh[i];
-        for (int i = 0; i < F; ++i)
-            for (int j = 0; j < F; ++j) c32[(size_t)i * Fp + j] = (float)Ch[(size_t)i * F + j];
-        e = hipMemcpy(s.m32, m32.data(), (size_t)F * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(s.C32, c32.data(), c32.size() * 4, hipMemcpyHostToDevice);
+        s.hm.resize(F);
+        s.hC.assign((size_t)Fp * Fp, 0.f);
+        for (int i = 0; i < F; ++i) s.hm[i] = (float)mh[i];
+        for (int i = 0; i < F; ++i) {
+            const double *src = Ch + (size_t)i * F;
+            float *dst = s.hC.data() + (size_t)i * Fp;
+            for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+        }
+        e = hipMemcpy(s.m32, s.hm.data(), (size_t)F * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice);
         if (e == hipSuccess && !pred) e = hipMemsetAsync(s.acc, 0, nacc * 8, c->stream);
         if (e == hipSuccess && Fp > F) {  // pad feature rows of Pt are never written by the kernel
             const int64_t cnt = (Fp - F) * chunk;
@@ -361,7 +390,6 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         }
     }
     (void)hipStreamSynchronize(c->stream);
-    s.release();
     return rc;
 }
 

@@ -43,6 +43,7 @@ struct rr_basis {
     std::vector<hipEvent_t> events;  // 4 per row chunk of the last Gram call
     size_t events_used = 0;
     const char *gram_kernel = "";
+    void *pass2 = nullptr;        // scratch of the second _elbo pass (rr_elbo.hip), grow-only
     // FastFood (kind == RR_KIND_FASTFOOD): (k, d2) diagonals / permutation, n = d2 * k
     int ff_d2 = 0, ff_k = 0;
     float *ffB32 = nullptr, *ffG32 = nullptr, *ffSrad32 = nullptr, *ffSrev32 = nullptr, *ffL32 = nullptr;
@@ -73,3 +74,4 @@ void rr_set_error(const char *fmt, ...);
 // Upload W scaled by the given lenscale (cached); implemented in rr_api.hip.
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
 int rr_pick_dmax(int d);
+void rr_pass2_scratch_free(void *p);
