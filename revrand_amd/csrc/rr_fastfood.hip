@@ -28,20 +28,53 @@ __device__ __forceinline__ void ff_sincos_rev<double>(double t, double &s, doubl
     sincospi(2.0 * f, &s, &c);
 }
 
+// Butterfly partner v[lane ^ M] without LDS traffic: DPP quad permutes (M = 1, 2), masked DPP row
+// shifts (M = 4, 8: lanes whose bit is clear read lane + M, the others lane - M, selected by bank
+// mask) and the gfx950 half-row / half-wave swaps (M = 16, 32).
+template <int M>
+__device__ __forceinline__ float xor_partner(float v) {
+    const int iv = __float_as_int(v);
+    int r;
+    if constexpr (M == 1) {
+        r = __builtin_amdgcn_update_dpp(iv, iv, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    } else if constexpr (M == 2) {
+        r = __builtin_amdgcn_update_dpp(iv, iv, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    } else if constexpr (M == 4) {
+        r = __builtin_amdgcn_update_dpp(iv, iv, 0x104, 0xF, 0x5, false);  // row_shl:4 -> banks 0,2
+        r = __builtin_amdgcn_update_dpp(r, iv, 0x114, 0xF, 0xA, false);   // row_shr:4 -> banks 1,3
+    } else if constexpr (M == 8) {
+        r = __builtin_amdgcn_update_dpp(iv, iv, 0x108, 0xF, 0x3, false);  // row_shl:8 -> banks 0,1
+        r = __builtin_amdgcn_update_dpp(r, iv, 0x118, 0xF, 0xC, false);   // row_shr:8 -> banks 2,3
+    } else if constexpr (M == 16) {
+        const auto p = __builtin_amdgcn_permlane16_swap(iv, iv, false, false);
+        r = ((threadIdx.x >> 4) & 1) ? p[0] : p[1];
+    } else {
+        const auto p = __builtin_amdgcn_permlane32_swap(iv, iv, false, false);
+        r = ((threadIdx.x >> 5) & 1) ? p[0] : p[1];
+    }
+    return __int_as_float(r);
+}
+template <int M>
+__device__ __forceinline__ double xor_partner(double v) { return __shfl_xor(v, M, 64); }
+
 // In-wave unnormalised natural-order WHT of length L = min(d2, 64) * R: element index of register q in
 // lane l is q * 64 + (l % 64) when d2 >= 64, else l % d2 (several blocks side by side in one wave).
+// Stage M: v <- partner + sgn_M * v with sgn_M = -1 on lanes whose bit M is set.
+template <int M, int R, typename TC>
+__device__ __forceinline__ void fwht_stage(TC (&v)[R], int lane) {
+    const TC sgn = (lane & M) ? TC(-1) : TC(1);
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = fma(sgn, v[q], xor_partner<M>(v[q]));
+}
+
 template <int R, typename TC>
 __device__ __forceinline__ void wave_fwht(TC (&v)[R], int lane, int lane_len) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        if (m < lane_len) {  // wave-uniform
-#pragma unroll
-            for (int q = 0; q < R; ++q) {
-                const TC o = __shfl_xor(v[q], m, 64);
-                v[q] = (lane & m) ? (o - v[q]) : (v[q] + o);
-            }
-        }
-    }
+    if (lane_len > 1) fwht_stage<1, R, TC>(v, lane);  // lane_len is wave-uniform
+    if (lane_len > 2) fwht_stage<2, R, TC>(v, lane);
+    if (lane_len > 4) fwht_stage<4, R, TC>(v, lane);
+    if (lane_len > 8) fwht_stage<8, R, TC>(v, lane);
+    if (lane_len > 16) fwht_stage<16, R, TC>(v, lane);
+    if (lane_len > 32) fwht_stage<32, R, TC>(v, lane);
 #pragma unroll
     for (int s = 1; s < R; s <<= 1) {
 #pragma unroll
@@ -91,13 +124,25 @@ rr_fastfood_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int 
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > N) r1 = N;
+    // x of the next row is fetched while this row is transformed (the only HBM read of the loop)
+    TX xn[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int e = q * 64 + le;
+        xn[q] = (e < d && r0 < r1) ? X[r0 * ldx + e] : TX(0);
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) Lv[q] *= Bv[q];  // fold the +-1 diagonal into 1/l
     for (int64_t r = r0; r < r1; ++r) {
         TC v[R];
 #pragma unroll
-        for (int q = 0; q < R; ++q) {
-            const int e = q * 64 + le;
-            const TC x = (e < d) ? (TC)X[r * ldx + e] : TC(0);
-            v[q] = x * Lv[q] * Bv[q];
+        for (int q = 0; q < R; ++q) v[q] = (TC)xn[q] * Lv[q];
+        if (r + 1 < r1) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                const int e = q * 64 + le;
+                xn[q] = (e < d) ? X[(r + 1) * ldx + e] : TX(0);
+            }
         }
         wave_fwht<R, TC>(v, lane, lane_len);
 #pragma unroll
