@@ -116,22 +116,26 @@ def main():
     wvec = np.random.RandomState(1).randn(d).astype(np.float32)
     basis = _hip.RffHandle(W, compute="f32", device=local_rank)
 
-    # ---- this rank's shard, generated in 1M-row chunks and made resident in HBM ----
-    CH = 1_000_000
-    nchunks = (args.rows + CH - 1) // CH
-    mine = [c for c in range(nchunks) if c % world == rank]
-    rows_of = lambda c: min(CH, args.rows - c * CH)  # noqa: E731
-    my_rows = sum(rows_of(c) for c in mine)
+    # ---- this rank's contiguous row shard (equal to within one row), generated in 250k-row chunks
+    # (chunk c of the data set always comes from RNG stream c, so the data do not depend on N_gpus)
+    # and made resident in HBM before anything is timed ----
+    CH = 250_000
+    row0, row1 = parallel.shard_bounds(args.rows, rank, world)
+    my_rows = row1 - row0
     dX = dev.empty_matrix(my_rows, d, np.float32, ld_dev=basis.padded_dim)
     dy = dev.malloc(max(my_rows, 1) * 4)
     dy.dtype = np.dtype(np.float32)
     r0 = 0
-    for c in mine:
-        Xc, yc = gen_chunk(c, rows_of(c), d, wvec)
+    for c in range(row0 // CH, (row1 + CH - 1) // CH if my_rows else 0):
+        c0 = c * CH
+        Xc, yc = gen_chunk(c, min(CH, args.rows - c0), d, wvec)
+        lo, hi = max(row0, c0) - c0, min(row1, c0 + CH) - c0
+        Xc, yc = np.ascontiguousarray(Xc[lo:hi]), np.ascontiguousarray(yc[lo:hi])
         dev.upload_rows(dX, r0, Xc)
         _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, _hip.ctypes.c_void_p(dy.ptr.value + r0 * 4),
                                                    yc.ctypes.data_as(_hip.ctypes.c_void_p), yc.nbytes))
-        r0 += rows_of(c)
+        r0 += hi - lo
+    assert r0 == my_rows
 
     # ---- accumulators: [G (F*F) | b (F) | yty (1)] float64, one buffer so one all-reduce ----
     nacc = F * F + F + 1

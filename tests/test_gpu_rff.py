@@ -254,3 +254,44 @@ def test_config2_full_size_properties():
     Gs, bs_, _ = b.gram(X[sl], y[sl], 1.0)
     assert normwise(Gs, P.T @ P) < 2e-5 and normwise(bs_, P.T @ y[sl].astype(np.float64)) < 2e-5
     assert normwise(P[:256], orc.rff_transform(X[sl][:256], b.W, 1.0)) < 1e-3
+
+
+def test_external_device_pointers_torch():
+    """The *_dev entry points take ANY device memory of the GPU: here torch CUDA tensors (what bench.py does
+    for the RCCL all-reduce).  Also: the padded-layout contract is enforced."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    from revrand_amd import _hip
+    N, d, n = 5000, 32, 256
+    F = 2 * n
+    rs = np.random.RandomState(0)
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.randn(N).astype(np.float32)
+    b = _make("RandomRBF", d, n, 3, False, "f32")
+    h = b._handle()
+    tX = torch.from_numpy(X).cuda()
+    ty = torch.from_numpy(y).cuda()
+    acc = torch.zeros(F * F + F + 1, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    dX = _hip.DeviceMatrix(h.dev, _hip.ctypes.c_void_p(tX.data_ptr()), (N, d), d, np.float32)
+    dy = _hip.DeviceBuffer(h.dev, _hip.ctypes.c_void_p(ty.data_ptr()), N * 4)
+    try:
+        p0 = acc.data_ptr()
+        h.gram_dev(dX, dy, 1.0, p0, p0 + F * F * 8, p0 + (F * F + F) * 8)
+        h.symmetrize_dev(p0)
+        h.dev.sync()
+        out = acc.cpu().numpy()
+        Gr, br, tr = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, 1.0)
+        assert normwise(out[:F * F].reshape(F, F), Gr) < 2e-5 and normwise(out[F * F:F * F + F], br) < 2e-5
+        assert abs(out[-1] - tr) < 1e-6 * tr
+        # a basis with d = 21 needs 32 padded columns: an unpadded device X is refused, not misread
+        b21 = _make("RandomRBF", 21, 64, 3, False, "f32")
+        t21 = torch.zeros(100, 21, dtype=torch.float32, device="cuda")
+        bad = _hip.DeviceMatrix(h.dev, _hip.ctypes.c_void_p(t21.data_ptr()), (100, 21), 21, np.float32)
+        with pytest.raises(_hip.HipError, match="padded"):
+            b21._handle().gram_dev(bad, None, 1.0, p0)
+        bad.ptr = None
+    finally:
+        dX.ptr = None  # torch owns the memory
+        dy.ptr = None
