@@ -48,6 +48,22 @@ def allreduce_packed(buf, group=None):
     return buf
 
 
+def allreduce_host(buf, group=None):
+    """Sum a host float64 vector over the ranks and return it: directly with gloo; with nccl (= RCCL)
+    through a CUDA tensor on this process's GPU, since that backend reduces device memory only."""
+    import torch
+    import torch.distributed as dist
+    buf = np.ascontiguousarray(buf, dtype=np.float64)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return buf
+    if dist.get_backend(group) == "nccl":
+        t = torch.from_numpy(buf).cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return t.cpu().numpy()
+    dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
+    return buf
+
+
 def sharded_gram(local_gram, X, y, rank, world, group=None):
     """Global (G, b, yty, N) from row shards.
 

@@ -39,17 +39,25 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
     """Bayesian linear regression on a basis; hyper-parameters by L-BFGS-B on the ELBO.
 
     Parameters are those of the reference (slm.py:57-72): ``basis``, ``var``, ``tol``,
-    ``maxiter``, ``nstarts``, ``random_state``.
+    ``maxiter``, ``nstarts``, ``random_state``, plus
+
+    distributed : bool
+        Row-sharded fit, one process per GPU under ``torch.distributed``: every rank calls ``fit`` with
+        ITS rows; each ``_elbo`` sums the per-rank statistics ``[G | b | y^T y | N]`` and
+        ``[sqErr | dhyp]`` with one all-reduce each (RCCL on the GPUs), so all ranks walk the same
+        L-BFGS path and end with identical parameters.  Needs a single random-feature basis (the
+        device-resident path) and a fixed ``random_state`` shared by all ranks when ``nstarts > 0``.
     """
 
     def __init__(self, basis=LinearBasis(), var=Parameter(gamma(1.), Positive()), tol=1e-8, maxiter=1000,
-                 nstarts=100, random_state=None):
+                 nstarts=100, random_state=None, distributed=False):
         self.basis = basis
         self.var = var
         self.tol = tol
         self.maxiter = maxiter
         self.nstarts = nstarts
         self.random_state = random_state
+        self.distributed = distributed
         self.random_ = check_random_state(random_state)
 
     def fit(self, X, y):
@@ -60,7 +68,9 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         nmin = structured_minimizer(logtrick_minimizer(minimize))
         elbo = partial(StandardLinearModel._elbo, self, X, y)
         # a single random-feature basis keeps (X, y) on the GPU for the whole optimisation
-        self._state = self.basis.device_fit_state(X, y) if hasattr(self.basis, "device_fit_state") else None
+        self._state = self._make_state(X, y)
+        if self.distributed and self._state is None:
+            raise ValueError("distributed=True needs a single random-feature basis in f32 mode")
         try:
             res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
                        options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
@@ -73,6 +83,17 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         log.info("Done! ELBO = {}, var = {}, reg = {}, hypers = {}, message = {}."
                  .format(-res["fun"], self.var_, self.regularizer_, self.hypers_, res.message))
         return self
+
+    def _make_state(self, X, y):
+        """(X, y) resident on the device for the whole optimisation, when the basis supports it."""
+        return self.basis.device_fit_state(X, y) if hasattr(self.basis, "device_fit_state") else None
+
+    def _allreduce(self, buf):
+        """Sum a float64 vector over the ranks (no-op unless distributed)."""
+        if not self.distributed:
+            return buf
+        from . import parallel
+        return parallel.allreduce_host(buf)
 
     # -- device statistics -------------------------------------------------------------------
     def _gram(self, X, y, Phi, hyp):
@@ -96,8 +117,11 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         neither Phi nor dPhi ever materialised."""
         st = self._state
         N = X.shape[0]
-        PhiPhi, Phiy, _ = st.gram(hypers)
+        PhiPhi, Phiy, yty = st.gram(hypers)
         D = PhiPhi.shape[0]
+        if self.distributed:  # one exchange: the packed sufficient statistics of all row shards
+            from . import parallel
+            PhiPhi, Phiy, yty, N = parallel.unpack_stats(self._allreduce(parallel.pack_stats(PhiPhi, Phiy, yty, N)), D)
         L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
         iL = 1. / L
         iC = np.diag(iL) + PhiPhi / var
@@ -106,6 +130,9 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         m = C.dot(Phiy) / var
         TrPhiPhiC = (PhiPhi * C).sum()
         sqErr, dhypers = st.second_pass(hypers, m, C, var)
+        if self.distributed:  # second exchange: 1 + d numbers
+            red = self._allreduce(np.concatenate(([sqErr], np.atleast_1d(dhypers))))
+            sqErr, dhypers = float(red[0]), (float(red[1]) if np.ndim(dhypers) == 0 else red[1:])
         ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
                        + ((m ** 2 + C.diagonal()) * iL).sum() - logdetC + np.log(L).sum() - D)
         if ELBO > self.obj_:

@@ -78,3 +78,88 @@ def test_two_rank_gloo_allreduce():
     assert all(r[1] == 1001 for r in res)
     assert all(r[2] < 1e-12 for r in res)
     assert res[0][3] == res[1][3]  # bitwise-identical reduced statistics -> identical weights
+
+
+class _OracleState(object):
+    """Test double for revrand_amd.basis_functions.DeviceFitState: the same interface, the per-rank
+    device computation replaced by the NumPy oracle (no GPU here).  Everything around it -- the
+    model's `_elbo_resident`, packing, the two all-reduces, L-BFGS -- is the product's code."""
+
+    def __init__(self, W, X, y):
+        self.W, self.X, self.y = W, X, y
+
+    def gram(self, ls):
+        return orc.rff_gram_chunked(self.X, self.y, self.W, ls)
+
+    def second_pass(self, ls, m, C, var):
+        Phi = orc.rff_transform(self.X, self.W, ls)
+        dP = orc.rff_grad(self.X, self.W, ls)
+        err = self.y - Phi @ m
+        slabs = [dP] if dP.ndim == 2 else [dP[:, :, i] for i in range(dP.shape[2])]
+        dh = [-(m @ (err @ g) - ((g.T @ Phi) * C).sum()) / var for g in slabs]
+        return float(err @ err), (dh[0] if dP.ndim == 2 else np.array(dh))
+
+    def release(self):
+        pass
+
+
+def _fit_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from revrand_amd.basis_functions import RandomRBF
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(3)
+        N, d, n = 600, 3, 12
+        X = rs.randn(N, d)
+        y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.3 * rs.randn(N)
+        a, b = parallel.shard_bounds(N, rank, world)
+        basis = RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
+                          regularizer=Parameter(1.0, Positive()))
+        slm = StandardLinearModel(basis, var=Parameter(0.1, Positive()), nstarts=0, maxiter=10,
+                                  distributed=world > 1, random_state=0)
+        slm._make_state = lambda Xs, ys: _OracleState(basis.W, Xs, ys)   # no GPU in this container
+        # one `_elbo` evaluation at fixed parameters: objective and every gradient
+        slm.obj_ = -np.inf
+        slm._state = slm._make_state(X[a:b], y[a:b])
+        ls = np.array([0.8, 1.1, 1.4])
+        f, (g_var, g_reg, g_hyp) = slm._elbo(X[a:b], y[a:b], 0.2, 1.3, ls)
+        ev = [float(f), float(g_var), float(g_reg)] + np.asarray(g_hyp).tolist() + slm.weights_.tolist()
+        slm._state = None
+        # and a short fit: every rank must walk the same path
+        slm.fit(X[a:b], y[a:b])
+        q.put((rank, ev, float(slm.var_), float(slm.regularizer_), np.asarray(slm.hypers_).tolist(), float(slm.obj_)))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_distributed_fit_equals_single_process():
+    """Row-sharded `_elbo` on 2 ranks == the same evaluation in one process (objective, all gradients,
+    posterior weights to 1e-9), and a distributed `fit` leaves every rank with identical parameters."""
+    import multiprocessing as pymp
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fit_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=400) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = pymp.Queue()
+    _fit_worker(0, 1, 0, q1)
+    single = q1.get(timeout=10)
+    assert res[0][1:] == res[1][1:]                       # ranks agree bit-for-bit, evaluation and fit
+    assert np.allclose(res[0][1], single[1], rtol=1e-9, atol=1e-9)
+    assert res[0][5] > -1e6 and np.isfinite(res[0][2])    # the fit moved to a finite optimum
