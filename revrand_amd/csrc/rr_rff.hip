@@ -400,140 +400,6 @@ rr_syrk_f32_diag_kernel(const SyrkArgs p) {
 #undef RR_PAIRD
 
 // ---------------------------------------------------------------------------------------
-// Variant B of the f32 SYRK kernel: TWO independent workgroups of 4 waves per CU (one wave per
-// SIMD each) instead of one workgroup of 8.  A workgroup owns a 256 x 128 block of G (A column
-// block TA of 256, B column block tb of 128, tb >= 2 TA), k-blocks of 16 rows, 48 KiB of LDS.  The
-// two workgroups of a CU barrier independently, so while one sits in its per-k-block barrier /
-// first-operand latency the other keeps the SIMD's matrix pipe busy (the 8-wave kernel loses
-// ~5 % there: measured by removing its barrier and DMA).
-// ---------------------------------------------------------------------------------------
-constexpr int G2_KB = 16;
-constexpr int G2_THREADS = 256;
-constexpr int G2_ABYTES = G2_KB * 256 * 4;  // A tile [16][256] f32
-constexpr int G2_BBYTES = G2_KB * 128 * 4;  // B tile [16][128] f32
-constexpr int G2_BUF = G2_ABYTES + G2_BBYTES;
-
-struct KOps2B {
-    float2v a[4], b[2];
-    // k-steps 2P, 2P+1: rows 4P + h and 4P + 2 + h; A rows are 1024 B (4 units of 256 B) apart, B rows 512 B (2)
-    template <int P>
-    __device__ __forceinline__ void load(const unsigned (&abase)[4], const unsigned (&bbase)[2]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = lds_read2st64<16 * P, 16 * P + 8>(abase[i]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) b[j] = lds_read2st64<8 * P, 8 * P + 4>(bbase[j]);
-    }
-};
-
-template <int FIRST, int LAST>
-__device__ __forceinline__ void gram_mfma_b(const KOps2B &o, floatx16 (&acc)[4][2]) {
-#pragma unroll
-    for (int q = FIRST; q < LAST; ++q)
-        acc[(q >> 1) & 3][q & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[(q >> 1) & 3][q >> 3], o.b[q & 1][q >> 3],
-                                                                        acc[(q >> 1) & 3][q & 1], 0, 0, 0);
-}
-
-#define RR_PAIRB(P, CUR, NXT)                                  \
-    lds_wait();                                                \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    gram_mfma_b<0, 1>(CUR, acc);                               \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    if ((P) + 1 < 4) NXT.template load<((P) + 1) & 3>(abase, bbase); \
-    __builtin_amdgcn_sched_barrier(0);                         \
-    gram_mfma_b<1, 16>(CUR, acc);                              \
-    __builtin_amdgcn_sched_barrier(0);
-
-__global__ void __launch_bounds__(G2_THREADS, 2)
-rr_syrk_f32_kernel_b(const SyrkArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G2_BUF];  // 48 KiB
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    // tile: A block TA (256 cols), B block tb (128 cols), tb >= 2 TA; nb128 = ldp / 128
-    const int nb128 = 2 * p.nb;
-    int tdx = blockIdx.x % p.ntiles;
-    const int ks = blockIdx.x / p.ntiles;
-    int TA = 0;
-    while (tdx >= nb128 - 2 * TA) {
-        tdx -= nb128 - 2 * TA;
-        ++TA;
-    }
-    const int tb = 2 * TA + tdx;
-    const int ca = TA * 256, cb = tb * 128;
-
-    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
-    int64_t row_end = row_begin + p.rows_per_split;
-    if (row_end > p.rows) row_end = p.rows;
-
-    // wave (wr, wc): A cols [wr*128, +128) x B cols [wc*64, +64)
-    const int wr = wave >> 1, wc_ = wave & 1;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
-    const unsigned aoff = (lane >> 5) * 1024u + 4u * (wr * 128 + (lane & 31));
-    const unsigned boff = G2_ABYTES + (lane >> 5) * 512u + 4u * (wc_ * 64 + (lane & 31));
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    // DMA per k-block: A = 16 row segments of 1 KiB (wave w: rows 4w..4w+3), B = 8 double-row segments of
-    // 1 KiB (wave w: row pairs 2w, 2w+1; lanes 0-31 first row of the pair, lanes 32-63 second)
-    auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lr = 4 * wave + k;
-            const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int pr = 2 * wave + k;  // row pair
-            const float *src = p.P + (kb0 + 2 * pr + (lane >> 5)) * p.ldp + cb + 4 * (lane & 31);
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + G2_ABYTES + pr * 1024), 16, 0, 0);
-        }
-    };
-
-    const int64_t nkb = (row_end - row_begin) / G2_KB;
-    if (nkb > 0) {
-        dma_tile(lds, row_begin);
-        __syncthreads();
-        for (int64_t kb = 0; kb < nkb; ++kb) {
-            const int cbuf = (int)(kb & 1);
-            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * G2_BUF, row_begin + (kb + 1) * G2_KB);
-            unsigned abase[4], bbase[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) abase[i] = lds0 + cbuf * G2_BUF + aoff + i * 128;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bbase[j] = lds0 + cbuf * G2_BUF + boff + j * 128;
-            KOps2B o0, o1;
-            o0.load<0>(abase, bbase);
-            RR_PAIRB(0, o0, o1) RR_PAIRB(1, o1, o0) RR_PAIRB(2, o0, o1) RR_PAIRB(3, o1, o0)
-            __syncthreads();
-        }
-    }
-
-    const int64_t F = p.F;
-    const int hi = lane >> 5;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t gc = cb + wc_ * 64 + j * 32 + (lane & 31);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
-            }
-        }
-    }
-}
-#undef RR_PAIRB
-
-// ---------------------------------------------------------------------------------------
 // f64 Gram: G(upper) += P^T P with v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s peak).  Same structure
 // as the f32 kernel at half the tile: 128x128 block of G per workgroup of 4 waves (64x64 per
 // wave = 16 accumulators of 4 f64), k-blocks of 16 rows arriving by LDS-DMA as [16][128 | 128]
@@ -914,26 +780,6 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
-    const char *venv = getenv("RR_SYRK_VARIANT");
-    if (venv && venv[0] == 'B') {
-        // variant B: 256x128 tiles, 16-row k-blocks, two 4-wave workgroups per CU
-        SyrkArgs b2 = a;
-        b2.ntiles = nb * (nb + 1);  // sum_{TA} (2 nb - 2 TA)
-        b2.tile_map = nullptr;
-        int64_t g2 = (int64_t)c->num_cu * 2, t2 = b2.ntiles;
-        while (t2) { const int64_t u = g2 % t2; g2 = t2; t2 = u; }
-        const int64_t unit2 = (int64_t)c->num_cu * 2 / g2;
-        int64_t ns2 = ((rows + 32767) / 32768 + unit2 - 1) / unit2 * unit2;
-        if (rows / ns2 < 1024) ns2 = (rows + 1023) / 1024;
-        if (ns2 < 1) ns2 = 1;
-        int64_t rps2 = ((rows + ns2 - 1) / ns2 + GR_KB - 1) / GR_KB * GR_KB;
-        if (renv && atoll(renv) >= GR_KB) rps2 = (atoll(renv) / GR_KB) * GR_KB;
-        ns2 = (rows + rps2 - 1) / rps2;
-        b2.rows_per_split = rps2;
-        hipLaunchKernelGGL(rr_syrk_f32_kernel_b, dim3((unsigned)(ns2 * b2.ntiles)), dim3(G2_THREADS), 0, c->stream, b2);
-        RR_CHECK_HIP(hipGetLastError());
-        return RR_OK;
-    }
     if (ntiles > 0)
         hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
