@@ -228,6 +228,16 @@ int rr_fastfood_transform(rr_basis *basis, const void *X, int x_dtype, int64_t N
 int rr_fastfood_vx(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
                    const double *lenscale, int n_ls, void *VX, int out_dtype, int64_t ldvx);
 
+/* FastFoodGM (basis_functions.py:1386-1562), a spectral-mixture component, on an rr_rff_create handle
+ * holding the dense equivalent W = _makeVX(I_d) of the FastFood chain:
+ *   Phi (N, 4n) = [cos(VX + mX), sin(VX + mX), cos(VX - mX), sin(VX - mX)] / sqrt(2n),  mX = X . mean   (:1443-1475)
+ *   rr_gm_grad: dPhi/dmean and dPhi/dlenscale, each (N, 4n, d) C-order ((N, 4n) when d == 1)          (:1477-1537)
+ * mean (d) and lenscale (n_ls == d) are host float64. */
+int rr_gm_transform(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                    const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi);
+int rr_gm_grad(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+               const double *lenscale, int n_ls, void *dmean, void *dlen, int out_dtype);
+
 /* mathfun.linalg.hadamard (mathfun/linalg.py:182-236): natural-order Walsh-Hadamard transform of each
  * row of host Y (rows, n), n = 2^p <= 4096, normalised by 1/n; ordering != 0 applies the sequency
  * permutation.  out has Y's dtype and shape. */

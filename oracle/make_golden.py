@@ -167,6 +167,29 @@ def gen_fastfood():
     save("fastfood", **out)
 
 
+def gen_fastfood_gm():
+    from revrand.btypes import Bound
+    out = {}
+    for (d, nb, seed, N) in [(1, 10, 3, 6), (3, 8, 4, 5), (5, 16, 3, 6), (16, 32, 3, 4)]:
+        key = "d%d_nb%d" % (d, nb)
+        X = np.random.RandomState(1).randn(N, d)
+        mean = np.linspace(-0.7, 0.9, d)
+        ls = np.linspace(0.6, 1.8, d)
+        b = rb.FastFoodGM(nbases=nb, Xdim=d, random_state=seed, mean=Parameter(np.zeros(d), Bound()),
+                          lenscale=Parameter(np.ones(d), Positive()))
+        B, G, PI, S = orc.fastfood_matrices(nb, d, seed)
+        assert np.array_equal(B, b.B) and np.array_equal(PI, b.PI)
+        P = b.transform(X, mean, ls)
+        dM, dL = b.grad(X, mean, ls)
+        close(P, orc.fastfood_gm_transform(X, B, G, PI, S, mean, ls))
+        oM, oL = orc.fastfood_gm_grad(X, B, G, PI, S, mean, ls)
+        close(dM, oM)
+        close(dL, oL)
+        out.update({key + "_X": X, key + "_mean": mean, key + "_ls": ls, key + "_Phi": P, key + "_dmean": dM,
+                    key + "_dlen": dL})
+    save("fastfood_gm", **out)
+
+
 def gen_concat():
     out = {}
     d, n, N = 6, 10, 20
@@ -308,6 +331,7 @@ if __name__ == "__main__":
     gen_rff()
     gen_hadamard()
     gen_fastfood()
+    gen_fastfood_gm()
     gen_concat()
     gen_elbo()
     gen_solve_posdef()

@@ -249,6 +249,41 @@ def fastfood_grad(X, B, G, PI, S, lenscale):
     return np.stack(slabs, axis=2)
 
 
+def fastfood_gm_transform(X, B, G, PI, S, mean, lenscale):
+    """FastFoodGM.transform  basis_functions.py:1443-1475: four trig blocks of VX +- X.mean, / sqrt(2n)."""
+    d = X.shape[1]
+    ls = _lenscale_col(lenscale, d)
+    mu = _lenscale_col(mean, d)
+    V = fastfood_VX(X / ls, B, G, PI, S)
+    mX = (X @ mu)[:, None]
+    n = V.shape[1]
+    return np.concatenate((np.cos(V + mX), np.sin(V + mX), np.cos(V - mX), np.sin(V - mX)), axis=1) / np.sqrt(2 * n)
+
+
+def fastfood_gm_grad(X, B, G, PI, S, mean, lenscale):
+    """FastFoodGM.grad  basis_functions.py:1477-1537 -> (dPhi/dmean, dPhi/dlenscale), each (N, 4n, d)
+    ((N, 4n) when d == 1)."""
+    d = X.shape[1]
+    ls = _lenscale_col(lenscale, d)
+    mu = _lenscale_col(mean, d)
+    V = fastfood_VX(X / ls, B, G, PI, S)
+    mX = (X @ mu)[:, None]
+    n = V.shape[1]
+    msp, msm, cp, cm = -np.sin(V + mX), -np.sin(V - mX), np.cos(V + mX), np.cos(V - mX)
+    rt = np.sqrt(2 * n)
+    gm, gl = [], []
+    for i, l in enumerate(ls):
+        xi = X[:, i:i + 1]
+        gm.append(np.concatenate((xi * msp, xi * cp, -xi * msm, -xi * cm), axis=1) / rt)
+        e = np.zeros(d)
+        e[i] = 1. / l ** 2
+        dV = -fastfood_VX(X * e, B, G, PI, S)
+        gl.append(np.concatenate((dV * msp, dV * cp, dV * msm, dV * cm), axis=1) / rt)
+    if d == 1:
+        return gm[0], gl[0]
+    return np.stack(gm, axis=2), np.stack(gl, axis=2)
+
+
 # --------------------------------------------------------------------------
 # a-8  LinearBasis / concatenation
 # --------------------------------------------------------------------------

@@ -96,6 +96,12 @@ SIGNATURES = {
     "rr_fastfood_vx": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int64]),
+    "rr_gm_transform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                       ctypes.c_int64]),
+    "rr_gm_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                  ctypes.c_int]),
     "rr_hadamard": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_int, ctypes.c_void_p]),
     "rr_rff_gram_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
@@ -513,6 +519,31 @@ class RffHandle(object):
                                               nls, G.ctypes.data_as(ctypes.c_void_p),
                                               b.ctypes.data_as(ctypes.c_void_p), yty.ctypes.data_as(ctypes.c_void_p)))
         return G, b, float(yty[0])
+
+    def gm_transform(self, X, mean, lenscale, out_dtype=np.float64):
+        """Spectral-mixture features (N, 4n) on this handle's W (rr_gm_transform)."""
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        out = np.empty((N, 4 * self.n), dtype=out_dtype)
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        mu = np.ascontiguousarray(mean, dtype=np.float64)
+        _check(self.lib, self.lib.rr_gm_transform(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N, _ld(X),
+                                                  mu.ctypes.data_as(ctypes.c_void_p), lsp, nls,
+                                                  out.ctypes.data_as(ctypes.c_void_p), rr_dtype(out.dtype), 4 * self.n))
+        return out
+
+    def gm_grad(self, X, mean, lenscale, out_dtype=np.float64):
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        mu = np.ascontiguousarray(mean, dtype=np.float64)
+        shape = (N, 4 * self.n) if self.d == 1 else (N, 4 * self.n, self.d)
+        dm, dl = np.empty(shape, dtype=out_dtype), np.empty(shape, dtype=out_dtype)
+        _check(self.lib, self.lib.rr_gm_grad(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N, _ld(X),
+                                             mu.ctypes.data_as(ctypes.c_void_p), lsp, nls,
+                                             dm.ctypes.data_as(ctypes.c_void_p), dl.ctypes.data_as(ctypes.c_void_p),
+                                             rr_dtype(dm.dtype)))
+        return dm, dl
 
     # -- device-resident API (fit loops, bench, shards) -------------------------
     def upload(self, X):

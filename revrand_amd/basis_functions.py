@@ -26,11 +26,11 @@ from itertools import repeat
 
 import numpy as np
 from scipy.linalg import qr
-from scipy.stats import gamma
+from scipy.stats import gamma, norm as norm_dist
 from sklearn.utils import check_random_state
 
 from . import _hip
-from .btypes import Parameter, Positive
+from .btypes import Bound, Parameter, Positive
 from .utils import atleast_list, atleast_tuple, issequence
 
 
@@ -525,6 +525,67 @@ class FastFoodRBF(_LengthScaleBasis):
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(
             type(self).__name__, self.nbases, self.d, self.params, self.regularizer, self.random_state)
+
+
+class FastFoodGM(FastFoodRBF):
+    """One Gaussian spectral-mixture component ("A la Carte"), basis_functions.py:1386-1562:
+    ``Phi = [cos(VX + mX), sin(VX + mX), cos(VX - mX), sin(VX - mX)] / sqrt(2n)`` with ``mX = X.mean``.
+    Parameters are always (d,)-shaped ``mean`` and ``lenscale`` (scalars are broadcast, :1539-1549);
+    ``grad`` returns the pair (dPhi/dmean, dPhi/dlenscale).  Runs on the dense equivalent of the
+    FastFood chain (``rr_gm_transform`` / ``rr_gm_grad``).
+    """
+
+    @slice_init
+    def __init__(self, nbases, Xdim, mean=Parameter(norm_dist(), Bound()), lenscale=Parameter(gamma(1.), Positive()),
+                 regularizer=None, random_state=None, dtype="f32"):
+        if dtype not in ("f32", "f64"):
+            raise ValueError("dtype must be 'f32' or 'f64'")
+        self.dtype = dtype
+        self.random_state = random_state  # for repr
+        self._random = check_random_state(random_state)
+        self._init_dims(nbases, Xdim)
+        self._params = [self._init_param(mean), self._init_param(lenscale)]
+        self._init_matrices()
+        super(_LengthScaleBasis, self).__init__(regularizer)
+
+    def _init_param(self, param):
+        if param.shape == (self.d,):
+            return param
+        if param.shape in ((), (1,)):
+            # broadcast to (d,).  The reference mutates `param` in place (:1543-1546), which corrupts the
+            # shared default argument for the next basis of a different Xdim; build a new Parameter instead.
+            if param.is_random:
+                return Parameter(param.dist, param.bounds, shape=(self.d,))
+            return Parameter(np.ones(self.d) * param.value, param.bounds)
+        raise ValueError("Parameter dimension doesn't agree with X dimensions!")
+
+    def get_dim(self, X):
+        return 4 * self.n
+
+    @slice_transform
+    def transform(self, X, mean=None, lenscale=None):
+        """(N, 4*n) float64 (basis_functions.py:1443-1475)."""
+        mean = self._check_dim(X.shape[1], mean, paramind=0)
+        lenscale = self._check_dim(X.shape[1], lenscale, paramind=1)
+        return self._handles()[1].gm_transform(X, mean, lenscale)
+
+    @slice_transform
+    def grad(self, X, mean=None, lenscale=None):
+        """(dPhi/dmean, dPhi/dlenscale), each (N, 4n, d) -- (N, 4n) when d == 1 (:1477-1537)."""
+        mean = self._check_dim(X.shape[1], mean, paramind=0)
+        lenscale = self._check_dim(X.shape[1], lenscale, paramind=1)
+        return self._handles()[1].gm_grad(X, mean, lenscale)
+
+    # the fused statistics / resident paths of FastFoodRBF do not apply to the 4-block features
+    gram = None
+    device_fit_state = None
+    predict_moments = None
+    _put_features = Basis._put_features
+
+    def __repr__(self):
+        return "{}(nbases={}, Xdim={}, mean={}, lenscale={}, regularizer={}, random_state={})".format(
+            type(self).__name__, self.nbases, self.d, self.params[0], self.params[1], self.regularizer,
+            self.random_state)
 
 
 # --------------------------------------------------------------------------------------

@@ -215,6 +215,8 @@ void rr_basis_destroy(rr_basis *b) {
     if (b->dWt32) (void)hipFree(b->dWt32);
     if (b->dgfac32) (void)hipFree(b->dgfac32);
     if (b->dgfac64) (void)hipFree(b->dgfac64);
+    if (b->dmu32) (void)hipFree(b->dmu32);
+    if (b->dmu64) (void)hipFree(b->dmu64);
     if (b->zbuf) (void)hipFree(b->zbuf);
     rr_pass2_scratch_free(b->pass2);
     for (hipEvent_t ev : b->events) (void)hipEventDestroy(ev);

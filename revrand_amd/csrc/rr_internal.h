@@ -37,6 +37,8 @@ struct rr_basis {
     double *dWs64 = nullptr;      // same in f64
     float *dWt32 = nullptr;       // (npad, dpad): the same weights transposed (feature-major kernels)
     float *dgfac32 = nullptr;     // (d,): 2pi / l_i  (grad kernels)
+    float *dmu32 = nullptr;       // (dpad,): mean / 2pi of a spectral-mixture component (rr_gm_*)
+    double *dmu64 = nullptr;
     double *dgfac64 = nullptr;
     void *zbuf = nullptr;         // feature scratch of the Gram path (f32 or f64), grow-only
     size_t zbuf_bytes = 0;

@@ -113,6 +113,91 @@ rr_rff_grad_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *_
 }
 
 // ---------------------------------------------------------------------------------------
+// Spectral-mixture component (FastFoodGM, basis_functions.py:1386-1562) on the dense equivalent of its
+// FastFood chain (W = _makeVX(I_d), see rr_fastfood.hip):
+//   Phi = [cos(z + mX), sin(z + mX), cos(z - mX), sin(z - mX)] / sqrt(2 n),  z = (x / l) . W[:, f],  mX = x . mean
+// mu[i] = mean_i / (2 pi) so that both phases are in revolutions.
+// ---------------------------------------------------------------------------------------
+template <int DMAX, typename TX, typename TC, typename TO>
+__global__ void __launch_bounds__(256)
+rr_gm_transform_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *__restrict__ Ws,
+                       const TC *__restrict__ mu, int n, int npad, TO *__restrict__ Phi, int64_t ldphi, TC scale,
+                       int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    TC w[DMAX];
+    load_w<DMAX, TC>(w, Ws, npad, fvalid ? f : 0);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const TX *xr = X + r * ldx;
+        const TC z = project_row<DMAX, false, TX, TC>(xr, DMAX, w);
+        TC mx = 0;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) mx = fma((TC)xr[i], mu[i], mx);
+        TC sp, cp, sm, cm;
+        sincos_rev(z + mx, sp, cp);
+        sincos_rev(z - mx, sm, cm);
+        if (fvalid) {
+            TO *o = Phi + r * ldphi;
+            o[f] = (TO)(cp * scale);
+            o[n + f] = (TO)(sp * scale);
+            o[2 * n + f] = (TO)(cm * scale);
+            o[3 * n + f] = (TO)(sm * scale);
+        }
+    }
+}
+
+// dPhi/dmean_i and dPhi/dl_i (basis_functions.py:1477-1537), each (N, 4n, d) C-order:
+//   dmean_i = x_i [-sin(z+m), cos(z+m),  sin(z-m), -cos(z-m)] / sqrt(2n)
+//   dlen_i  = dz_i [-sin(z+m), cos(z+m), -sin(z-m),  cos(z-m)] / sqrt(2n),  dz_i = -x_i W[i][f] / l_i^2
+template <int DMAX, typename TX, typename TC, typename TO>
+__global__ void __launch_bounds__(256)
+rr_gm_grad_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *__restrict__ Ws,
+                  const TC *__restrict__ mu, const TC *__restrict__ gfac, int n, int npad, int d,
+                  TO *__restrict__ dmean, TO *__restrict__ dlen, TC scale, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    TC w[DMAX];
+    load_w<DMAX, TC>(w, Ws, npad, fvalid ? f : 0);
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const TX *xr = X + r * ldx;
+        const TC z = project_row<DMAX, false, TX, TC>(xr, DMAX, w);
+        TC mx = 0;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) mx = fma((TC)xr[i], mu[i], mx);
+        TC sp, cp, sm, cm;
+        sincos_rev(z + mx, sp, cp);
+        sincos_rev(z - mx, sm, cm);
+        if (fvalid) {
+            const size_t row = (size_t)r * 4 * n;
+#pragma unroll
+            for (int i = 0; i < DMAX; ++i) {
+                if (i < d) {
+                    const TC xi = (TC)xr[i] * scale;
+                    const TC dz = -(TC)xr[i] * w[i] * gfac[i] * scale;
+                    TO *om = dmean + (row + f) * d + i;
+                    TO *ol = dlen + (row + f) * d + i;
+                    const size_t blk = (size_t)n * d;
+                    om[0] = (TO)(-sp * xi);
+                    om[blk] = (TO)(cp * xi);
+                    om[2 * blk] = (TO)(sm * xi);
+                    om[3 * blk] = (TO)(-cm * xi);
+                    ol[0] = (TO)(-sp * dz);
+                    ol[blk] = (TO)(cp * dz);
+                    ol[2 * blk] = (TO)(-sm * dz);
+                    ol[3 * blk] = (TO)(cm * dz);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Phi^T Phi / Phi^T y in two kernels per row chunk.
 //
 //  (A) rr_rff_features_kernel:  P[r][f] = cos(2 pi z)/sqrt(n), P[r][n+f] = sin(2 pi z)/sqrt(n),
@@ -1106,6 +1191,136 @@ int rr_rff_grad(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx,
     (void)hipFree(st.dX);
     (void)hipFree(dO);
     return rc;
+}
+
+}  // extern "C"
+
+// upload mean / (2 pi) for the spectral-mixture kernels
+static int gm_prepare_mean(rr_basis *b, const double *mean) {
+    RR_REQUIRE(mean != nullptr, "mean: null argument");
+    const double inv2pi = 0.15915494309189533576888;
+    std::vector<double> m64(b->dpad, 0.0);
+    std::vector<float> m32(b->dpad, 0.f);
+    for (int i = 0; i < b->d; ++i) {
+        m64[i] = mean[i] * inv2pi;
+        m32[i] = (float)m64[i];
+    }
+    if (!b->dmu32) {
+        RR_CHECK_HIP(hipMalloc((void **)&b->dmu32, (size_t)b->dpad * 4));
+        RR_CHECK_HIP(hipMalloc((void **)&b->dmu64, (size_t)b->dpad * 8));
+    }
+    RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    RR_CHECK_HIP(hipMemcpy(b->dmu32, m32.data(), m32.size() * 4, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->dmu64, m64.data(), m64.size() * 8, hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+template <typename TX, typename TC, typename TO>
+static int launch_gm(rr_basis *b, bool grad, const void *dX, int64_t N, int64_t ldx, void *o0, void *o1, int64_t ldo) {
+    rr_ctx *c = b->ctx;
+    const bool f32 = sizeof(TC) == 4;
+    const TC *Ws = f32 ? (const TC *)b->dWs32 : (const TC *)b->dWs64;
+    const TC *mu = f32 ? (const TC *)b->dmu32 : (const TC *)b->dmu64;
+    const TC *gf = f32 ? (const TC *)b->dgfac32 : (const TC *)b->dgfac64;
+    const TC scale = (TC)(1.0 / sqrt(2.0 * (double)b->n));
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = grad ? 16 : 64;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+#define RR_GM(DM)                                                                                                    \
+    do {                                                                                                             \
+        if (grad)                                                                                                    \
+            hipLaunchKernelGGL((rr_gm_grad_kernel<DM, TX, TC, TO>), grid, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
+                               Ws, mu, gf, b->n, b->npad, b->d, (TO *)o0, (TO *)o1, scale, (int)rpb);                 \
+        else                                                                                                         \
+            hipLaunchKernelGGL((rr_gm_transform_kernel<DM, TX, TC, TO>), grid, dim3(256), 0, c->stream, (const TX *)dX,  \
+                               N, ldx, Ws, mu, b->n, b->npad, (TO *)o0, ldo, scale, (int)rpb);                         \
+    } while (0)
+    switch (b->dpad) {
+        case 8: RR_GM(8); break;
+        case 16: RR_GM(16); break;
+        case 32: RR_GM(32); break;
+        case 64: RR_GM(64); break;
+        case 128: RR_GM(128); break;
+        default: rr_set_error("gm: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_GM
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+static int gm_dev_impl(rr_basis *b, bool grad, const void *dX, int x_dtype, int64_t N, int64_t ldx, void *o0, void *o1,
+                       int out_dtype, int64_t ldo) {
+    RR_DISPATCH3(launch_gm, x_dtype, b->compute, out_dtype, b, grad, dX, N, ldx, o0, o1, ldo);
+}
+
+// host-buffer driver shared by rr_gm_transform / rr_gm_grad
+static int gm_host_call(rr_basis *b, bool grad, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                        const double *lenscale, int n_ls, void *h0, void *h1, int out_dtype, int64_t ldo,
+                        const char *who) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "%s: not an RFF-type basis", who);
+    RR_REQUIRE(dtype_ok(x_dtype) && dtype_ok(out_dtype), "%s: bad dtype", who);
+    RR_REQUIRE(N >= 0 && ldx >= b->d, "%s: bad shape", who);
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc == RR_OK) rc = gm_prepare_mean(b, mean);
+    if (rc != RR_OK || N == 0) return rc;
+    RR_REQUIRE(X != nullptr && h0 != nullptr && (!grad || h1 != nullptr), "%s: null buffer", who);
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t os = dtype_size(out_dtype);
+    const size_t out_row = grad ? (size_t)4 * b->n * b->d : (size_t)4 * b->n;
+    RowStage st;
+    rc = stage_alloc(b, x_dtype, N, out_row * os * (grad ? 2 : 1), &st);
+    if (rc != RR_OK) return rc;
+    void *d0 = nullptr, *d1 = nullptr;
+    hipError_t e = hipMalloc(&d0, (size_t)st.chunk * out_row * os);
+    if (e == hipSuccess && grad) e = hipMalloc(&d1, (size_t)st.chunk * out_row * os);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(st.dX);
+        if (d0) (void)hipFree(d0);
+        rr_set_error("%s: device allocation failed", who);
+        return RR_ERR_OOM;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += st.chunk) {
+        const int64_t m = (N - r0 < st.chunk) ? N - r0 : st.chunk;
+        e = stage_rows(b, st, X, x_dtype, r0, m, ldx);
+        if (e == hipSuccess) {
+            rc = gm_dev_impl(b, grad, st.dX, x_dtype, m, b->dpad, d0, d1, out_dtype, (int64_t)out_row);
+            if (rc != RR_OK) break;
+            if (grad) {
+                e = hipMemcpyAsync((char *)h0 + (size_t)r0 * out_row * os, d0, (size_t)m * out_row * os, hipMemcpyDeviceToHost, c->stream);
+                if (e == hipSuccess)
+                    e = hipMemcpyAsync((char *)h1 + (size_t)r0 * out_row * os, d1, (size_t)m * out_row * os, hipMemcpyDeviceToHost, c->stream);
+            } else {
+                e = hipMemcpy2DAsync((char *)h0 + (size_t)r0 * ldo * os, (size_t)ldo * os, d0, out_row * os, out_row * os,
+                                     (size_t)m, hipMemcpyDeviceToHost, c->stream);
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("%s: copy/launch failed: %s", who, hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(st.dX);
+    (void)hipFree(d0);
+    if (d1) (void)hipFree(d1);
+    return rc;
+}
+
+extern "C" {
+
+int rr_gm_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                    const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi) {
+    RR_REQUIRE(b == nullptr || ldphi >= 4 * (int64_t)b->n, "rr_gm_transform: bad ldphi");
+    return gm_host_call(b, false, X, x_dtype, N, ldx, mean, lenscale, n_ls, Phi, nullptr, out_dtype, ldphi, "rr_gm_transform");
+}
+
+int rr_gm_grad(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+               const double *lenscale, int n_ls, void *dmean, void *dlen, int out_dtype) {
+    return gm_host_call(b, true, X, x_dtype, N, ldx, mean, lenscale, n_ls, dmean, dlen, out_dtype, 0, "rr_gm_grad");
 }
 
 int rr_rff_gram_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, int64_t N, int64_t ldx,

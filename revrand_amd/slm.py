@@ -86,7 +86,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
 
     def _make_state(self, X, y):
         """(X, y) resident on the device for the whole optimisation, when the basis supports it."""
-        return self.basis.device_fit_state(X, y) if hasattr(self.basis, "device_fit_state") else None
+        make = getattr(self.basis, "device_fit_state", None)
+        return make(X, y) if make is not None else None
 
     def _allreduce(self, buf):
         """Sum a float64 vector over the ranks (no-op unless distributed)."""
@@ -98,7 +99,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
     # -- device statistics -------------------------------------------------------------------
     def _gram(self, X, y, Phi, hyp):
         """(Phi^T Phi, Phi^T y) on the GPU: fused when the basis offers it, dense SYRK otherwise."""
-        if hasattr(self.basis, "gram"):
+        if getattr(self.basis, "gram", None) is not None:
             G, b, _ = self.basis.gram(X, y, *hyp)
         else:
             G, b, _ = _hip.dense_gram(Phi, y)
@@ -200,7 +201,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         """Predictive mean and variance (slm.py:219-244)."""
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
         X = check_array(X)
-        if hasattr(self.basis, "predict_moments") and getattr(self.basis, "dtype", None) == "f32":
+        if getattr(self.basis, "predict_moments", None) is not None and getattr(self.basis, "dtype", None) == "f32":
             Ey, Vf = self.basis.predict_moments(X, self.hypers_, self.weights_, self.covariance_)  # on the GPU
             return Ey, Vf + self.var_
         Phi = self.basis.transform(X, *atleast_list(self.hypers_))

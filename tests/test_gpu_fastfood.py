@@ -90,3 +90,55 @@ def test_fastfood_in_concat_and_slm():
     assert P.shape == (300, 2 * 20 + 4) and base.get_dim(X) == P.shape[1]
     slm = StandardLinearModel(base, nstarts=0, maxiter=100).fit(X, y)
     assert ((slm.predict(X) - y) ** 2).mean() < 0.25 * y.var()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("case", [(1, 10, 3), (3, 8, 4), (5, 16, 3), (16, 32, 3)])
+def test_fastfood_gm_golden(golden, case, dtype):
+    """FastFoodGM.transform / grad (mean and lenscale gradients) vs the reference's outputs."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Bound, Parameter, Positive
+    d, nb, seed = case
+    g = golden("fastfood_gm")
+    k = "d%d_nb%d" % (d, nb)
+    b = bs.FastFoodGM(nbases=nb, Xdim=d, random_state=seed, mean=Parameter(np.zeros(d), Bound()),
+                      lenscale=Parameter(np.ones(d), Positive()), dtype=dtype)
+    X, mean, ls = g[k + "_X"], g[k + "_mean"], g[k + "_ls"]
+    P = b.transform(X, mean, ls)
+    assert P.shape == g[k + "_Phi"].shape == (X.shape[0], 4 * b.n) and b.get_dim(X) == 4 * b.n
+    assert normwise(P, g[k + "_Phi"]) < TOL[dtype]
+    dM, dL = b.grad(X, mean, ls)
+    assert dM.shape == g[k + "_dmean"].shape and dL.shape == g[k + "_dlen"].shape
+    assert normwise(dM, g[k + "_dmean"]) < TOL[dtype] and normwise(dL, g[k + "_dlen"]) < TOL[dtype]
+    # defaults (None) use the initial parameter values, scalars are broadcast to (d,)
+    b2 = bs.FastFoodGM(nbases=nb, Xdim=d, random_state=seed, dtype=dtype)
+    assert b2.params[0].shape == (d,) and b2.params[1].shape == (d,) and len(b2.params_values()) == 2
+    assert b2.transform(X).shape == P.shape and bs.count_args(b2.transform) == 3
+
+
+def test_all_bases_concatenate_like_reference_test_bases():
+    """tests/test_bases.py:128-220 of the reference: every basis + one big concatenation, shapes only."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Bound, Parameter, Positive
+    from functools import reduce
+    from operator import add
+    rs = np.random.RandomState(0)
+    N, d = 50, 2
+    X = rs.randn(N, d)
+    ard = Parameter(np.ones(d), Positive())
+    bases = [bs.BiasBasis(), bs.LinearBasis(onescol=True), bs.RandomRBF(Xdim=d, nbases=10),
+             bs.RandomRBF(Xdim=d, nbases=10, lenscale=ard), bs.OrthogonalRBF(Xdim=d, nbases=10),
+             bs.OrthogonalRBF(Xdim=d, nbases=10, lenscale=ard), bs.FastFoodRBF(Xdim=d, nbases=10),
+             bs.FastFoodRBF(Xdim=d, nbases=10, lenscale=ard), bs.FastFoodGM(Xdim=d, nbases=10),
+             bs.FastFoodGM(Xdim=d, nbases=10, mean=Parameter(np.zeros(d), Bound()), lenscale=ard)]
+    hypers = [(), (), (1.,), (np.ones(d),), (1.,), (np.ones(d),), (1.,), (np.ones(d),),
+              (np.ones(d), np.ones(d)), (np.ones(d), np.ones(d))]
+    for b, h in zip(bases, hypers):
+        P = b.transform(X, *h)
+        assert P.shape[0] == N and P.ndim == 2
+    bcat = reduce(add, bases)
+    hyps = [v for h in hypers for v in h]
+    P = bcat.transform(X, *hyps)
+    assert bcat.get_dim(X) == P.shape[1]
+    grads = list(bcat.grad(X, *hyps))
+    assert len(grads) == 10 and all(g.shape[:2] == P.shape for g in grads)   # 6 lenscales + 2x(mean, lenscale)

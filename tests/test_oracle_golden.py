@@ -122,3 +122,15 @@ def test_fit_prediction_moments(golden):
     Phi = orc.rff_transform(g["Xs"], g["W"], float(g["hyp_"]))
     Ey, Vy = orc.slm_predict_moments(Phi, g["m"], g["C"], float(g["var_"]))
     assert normwise(Ey, g["Ey"]) < 1e-12 and normwise(Vy, g["Vy"]) < 1e-12
+
+
+@pytest.mark.parametrize("case", [(1, 10, 3), (3, 8, 4), (5, 16, 3), (16, 32, 3)])
+def test_fastfood_gm(golden, case):
+    d, nb, seed = case
+    g = golden("fastfood_gm")
+    k = "d%d_nb%d" % (d, nb)
+    B, G, PI, S = orc.fastfood_matrices(nb, d, seed)
+    X, mean, ls = g[k + "_X"], g[k + "_mean"], g[k + "_ls"]
+    assert normwise(orc.fastfood_gm_transform(X, B, G, PI, S, mean, ls), g[k + "_Phi"]) < 1e-12
+    dM, dL = orc.fastfood_gm_grad(X, B, G, PI, S, mean, ls)
+    assert normwise(dM, g[k + "_dmean"]) < 1e-12 and normwise(dL, g[k + "_dlen"]) < 1e-12
