@@ -204,6 +204,15 @@ int rr_rff_elbo_pass2_dev(rr_basis *basis, const void *dX, const void *dy, int x
                           int64_t ldx, const double *lenscale, int n_ls, const double *m, const double *C,
                           double *sqerr, double *T);
 
+/* Basis-gradient contraction for ANY consumer of basis.grad: given a host matrix E (N, 2n) -- the factor
+ * the caller would multiply element-wise with each dPhi_i and sum (slm.py:193-195: E = Err m^T - Phi C;
+ * glm.py:274-275: E = EdPhi) -- return T (d, n) row-major float64 with
+ *     sum_{r,j} E[r][j] dPhi_i[r][j]  ==  -(1 / l_i^2) * sum_f W[i][f] * T[i][f]
+ * (i = 0 only for an isotropic length scale, as in the reference).  The (N, 2n, d) tensor of
+ * basis_functions.py:866-901 is never formed.  f32 arithmetic; X, E are host buffers. */
+int rr_rff_grad_contract(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
+                         const double *lenscale, int n_ls, const void *E, int e_dtype, int64_t lde, double *T);
+
 /* predict_moments (slm.py:240-244) for DEVICE-resident query rows: Ey = Phi m, Vf = rowsum((Phi C) o Phi)
  * (host outputs, length N; the caller adds var to Vf). */
 int rr_rff_predict_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,

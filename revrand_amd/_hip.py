@@ -84,6 +84,9 @@ SIGNATURES = {
     "rr_rff_elbo_pass2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_rff_grad_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
     "rr_rff_predict_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -519,6 +522,19 @@ class RffHandle(object):
                                               nls, G.ctypes.data_as(ctypes.c_void_p),
                                               b.ctypes.data_as(ctypes.c_void_p), yty.ctypes.data_as(ctypes.c_void_p)))
         return G, b, float(yty[0])
+
+    def grad_contract(self, X, E, lenscale):
+        """T (d, n) with  sum(E o dPhi_i) = -(1/l_i^2) sum_f W[i,f] T[i,f]  (rr_rff_grad_contract)."""
+        X = as_float_matrix(X)
+        E = as_float_matrix(E)
+        if E.shape != (X.shape[0], 2 * self.n):
+            raise ValueError("E must have shape (N, 2*nbases)")
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        T = np.zeros((self.d, self.n))
+        _check(self.lib, self.lib.rr_rff_grad_contract(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype),
+                                                       X.shape[0], _ld(X), lsp, nls, E.ctypes.data_as(ctypes.c_void_p),
+                                                       rr_dtype(E.dtype), _ld(E), T.ctypes.data_as(ctypes.c_void_p)))
+        return T
 
     def gm_transform(self, X, mean, lenscale, out_dtype=np.float64):
         """Spectral-mixture features (N, 4n) on this handle's W (rr_gm_transform)."""

@@ -335,6 +335,18 @@ class _RandomKernelBasis(_LengthScaleBasis):
         dX.free()
 
     @slice_transform
+    def grad_contract(self, X, E, lenscale=None):
+        """``apply_grad(lambda dPhi: (E * dPhi).sum(), self.grad(X, lenscale))`` without the gradient
+        tensor (glm.py:274-275, slm.py:193-197): a scalar for an isotropic length scale (input dimension 0
+        only, as the reference computes it), else a (d,) array.  f32 arithmetic on the GPU."""
+        lenscale = self._check_dim(X.shape[1], lenscale)
+        T = self._handle().grad_contract(X, E, lenscale)
+        ls = np.asarray(lenscale, dtype=float)
+        if ls.size == 1:
+            return float(-(T[0] * self.W[0]).sum() / ls[0] ** 2)
+        return -(T * self.W).sum(axis=1) / ls ** 2
+
+    @slice_transform
     def device_fit_state(self, X, y):
         """Upload (X, y) once for a fit; None when this basis cannot serve the fused path (f64 mode)."""
         if self.dtype != "f32" or X.shape[1] != self.d:

@@ -196,6 +196,47 @@ rr_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *
 }
 
 // ---------------------------------------------------------------------------------------------
+// Generic basis-gradient contraction  sum_{r,j} E[r][j] dPhi_i[r][j]  for a random Fourier basis without
+// materialising dPhi:  T[i][f] += sum_r x[r][i] * scale * (E[r][n+f] cos - E[r][f] sin)(2 pi z_rf),
+// then (host)  d_i = -(1 / l_i^2) sum_f W[i][f] T[i][f].  This is the consumer of basis.grad in
+// slm.py:193-197 (E = Err m^T - Phi C) and glm.py:274-275 (E = EdPhi).  One frequency per thread.
+// ---------------------------------------------------------------------------------------------
+template <int DMAX, typename TX, typename TE>
+__global__ void __launch_bounds__(256)
+rr_grad_contract_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ Ws,
+                        const TE *__restrict__ E, int64_t lde, int n, int npad, int d, double *__restrict__ T,
+                        float scale, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    const int fc = fvalid ? f : 0;
+    float w[DMAX], t[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) {
+        w[i] = Ws[(size_t)i * npad + fc];
+        t[i] = 0.f;
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const TX *xr = X + r * ldx;
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) z = fmaf((float)xr[i], w[i], z);
+        const float fr = z - __builtin_rintf(z);
+        const float a = scale * ((float)E[r * lde + n + fc] * __builtin_amdgcn_cosf(fr) -
+                                 (float)E[r * lde + fc] * __builtin_amdgcn_sinf(fr));
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) t[i] = fmaf((float)xr[i], a, t[i]);
+    }
+    if (fvalid) {
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // Scratch of the second pass, kept by the basis between calls (a fit makes ~100 of them): grow-only.
@@ -405,7 +446,96 @@ static int pass2_checks(rr_basis *b, const void *dX, int x_dtype, int64_t N, int
     return RR_OK;
 }
 
+template <typename TX, typename TE>
+static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ldx, const TE *dE, int64_t lde, double *dT) {
+    rr_ctx *c = b->ctx;
+    const float scale = (float)(1.0 / sqrt((double)b->n));
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = (N * fblocks + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+    if (rpb < 32) rpb = 32;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+#define RR_GC(DM)                                                                                              \
+    hipLaunchKernelGGL((rr_grad_contract_kernel<DM, TX, TE>), grid, dim3(256), 0, c->stream, dX, N, ldx, b->dWs32, \
+                       dE, lde, b->n, b->npad, b->d, dT, scale, (int)rpb)
+    switch (b->dpad) {
+        case 8: RR_GC(8); break;
+        case 16: RR_GC(16); break;
+        case 32: RR_GC(32); break;
+        case 64: RR_GC(64); break;
+        case 128: RR_GC(128); break;
+        default: rr_set_error("grad_contract: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_GC
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 extern "C" {
+
+int rr_rff_grad_contract(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                         int n_ls, const void *E, int e_dtype, int64_t lde, double *T) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF, "rr_rff_grad_contract: not an RFF basis");
+    RR_REQUIRE((x_dtype == RR_F32 || x_dtype == RR_F64) && (e_dtype == RR_F32 || e_dtype == RR_F64),
+               "rr_rff_grad_contract: bad dtype");
+    RR_REQUIRE(N >= 0 && ldx >= b->d && lde >= 2 * (int64_t)b->n && T != nullptr, "rr_rff_grad_contract: bad argument");
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK) return rc;
+    const size_t tcount = (size_t)b->d * b->n;
+    memset(T, 0, tcount * sizeof(double));
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(X != nullptr && E != nullptr, "rr_rff_grad_contract: null buffer");
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t xs = x_dtype == RR_F32 ? 4 : 8, es = e_dtype == RR_F32 ? 4 : 8;
+    const int64_t F = 2 * (int64_t)b->n;
+    int64_t chunk = (int64_t)(((size_t)1 << 30) / ((size_t)b->dpad * xs + (size_t)F * es));
+    if (chunk < 1) chunk = 1;
+    if (chunk > N) chunk = N;
+    void *dX = nullptr, *dE = nullptr;
+    double *dT = nullptr;
+    hipError_t e = hipMalloc(&dX, (size_t)chunk * b->dpad * xs);
+    if (e == hipSuccess) e = hipMalloc(&dE, (size_t)chunk * F * es);
+    if (e == hipSuccess) e = hipMalloc((void **)&dT, tcount * 8);
+    if (e == hipSuccess) e = hipMemsetAsync(dX, 0, (size_t)chunk * b->dpad * xs, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(dT, 0, tcount * 8, c->stream);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_rff_grad_contract: device allocation failed");
+        rc = RR_ERR_OOM;
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
+        const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
+        e = hipMemcpy2DAsync(dX, (size_t)b->dpad * xs, (const char *)X + (size_t)r0 * ldx * xs, (size_t)ldx * xs,
+                             (size_t)b->d * xs, (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess)
+            e = hipMemcpy2DAsync(dE, (size_t)F * es, (const char *)E + (size_t)r0 * lde * es, (size_t)lde * es,
+                                 (size_t)F * es, (size_t)m, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) {
+            rr_set_error("rr_rff_grad_contract: upload failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+            break;
+        }
+        if (x_dtype == RR_F32)
+            rc = e_dtype == RR_F32 ? launch_grad_contract<float, float>(b, (const float *)dX, m, b->dpad, (const float *)dE, F, dT)
+                                   : launch_grad_contract<float, double>(b, (const float *)dX, m, b->dpad, (const double *)dE, F, dT);
+        else
+            rc = e_dtype == RR_F32 ? launch_grad_contract<double, float>(b, (const double *)dX, m, b->dpad, (const float *)dE, F, dT)
+                                   : launch_grad_contract<double, double>(b, (const double *)dX, m, b->dpad, (const double *)dE, F, dT);
+        if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            rr_set_error("rr_rff_grad_contract: kernel failed: %s", hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    if (rc == RR_OK && hipMemcpy(T, dT, tcount * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        rr_set_error("rr_rff_grad_contract: download failed");
+        rc = RR_ERR_HIP;
+    }
+    if (dX) (void)hipFree(dX);
+    if (dE) (void)hipFree(dE);
+    if (dT) (void)hipFree(dT);
+    return rc;
+}
 
 int rr_rff_elbo_pass2_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, int64_t N, int64_t ldx,
                           const double *lenscale, int n_ls, const double *m, const double *C, double *sqerr,

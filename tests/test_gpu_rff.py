@@ -295,3 +295,20 @@ def test_external_device_pointers_torch():
     finally:
         dX.ptr = None  # torch owns the memory
         dy.ptr = None
+
+
+@pytest.mark.parametrize("ard", [False, True])
+def test_grad_contract_vs_materialised_gradient(ard):
+    """sum(E o dPhi_i) through rr_rff_grad_contract == the same contraction of the oracle's dPhi tensor
+    (the GLM's basis-gradient consumer, glm.py:274-275), incl. the isotropic dimension-0 quirk."""
+    N, d, n = 3000, 7, 150
+    rs = np.random.RandomState(2)
+    X = rs.randn(N, d)
+    E = rs.randn(N, 2 * n)
+    b = _make("RandomCauchy", d, n, 4, ard, "f32")
+    ls = np.linspace(0.7, 1.6, d) if ard else 1.3
+    got = b.grad_contract(X, E, ls)
+    dP = orc.rff_grad(X, b.W, ls)
+    want = np.array([(E * dP[:, :, i]).sum() for i in range(d)]) if ard else (E * dP).sum()
+    assert np.shape(got) == np.shape(want)
+    assert normwise(np.atleast_1d(got), np.atleast_1d(want)) < 1e-3
