@@ -191,6 +191,21 @@ int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t l
 int rr_featmat_put_host(rr_featmat *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0);
 int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty);
 
+/* Second data pass of _elbo / predict_moments for a concatenated basis (slm.py:160-162,193-197,240-244),
+ * over the rows currently in the matrix (after rr_featmat_begin + put_*):
+ *   pass2_begin(m, C)      posterior (host float64, (F) and (F, F) row-major) to the device; sqErr = 0
+ *   pass2_rows(dy)         dot = P m, Err = y - dot, sqErr += |Err|^2, U = P C          (dy may be NULL)
+ *   pass2_rff(b, dX, col0, dT)   dT (d, n) float64 DEVICE buffer  +=  X^T A  for the random Fourier child
+ *                          at columns [col0, col0 + 2n), A as in rr_rff_elbo_pass2_dev
+ *   pass2_end(&sqErr)      wait, fetch the accumulated sqErr
+ *   predict_rows(Ey, Vf)   Ey = P m, Vf = rowsum((P C) o P) for the current rows (host float64) */
+int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C);
+int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype);
+int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
+                         double *dT);
+int rr_featmat_pass2_end(rr_featmat *fm, double *sqErr);
+int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf);
+
 /* ---- second data pass of the standard linear model (posterior known) -----------------------
  * With m (F,) and C (F, F) from the host Cholesky (slm.py:154-157), for a random Fourier basis and
  * DEVICE-resident X (padded layout, see rr_rff_padded_dim) and y:

@@ -84,6 +84,12 @@ SIGNATURES = {
     "rr_rff_elbo_pass2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_pass2_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_pass2_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rr_featmat_pass2_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat_pass2_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_predict_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_rff_grad_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
@@ -321,11 +327,26 @@ def device_available():
         return False
 
 
+class DeviceView(object):
+    """Non-owning window of device memory: rows [r0, r0 + rows) of a DeviceMatrix, or elements of a vector."""
+
+    def __init__(self, base, r0, rows):
+        self.base = base  # keeps the owner alive
+        if isinstance(base, DeviceMatrix):
+            self.ld, self.shape = base.ld, (rows, base.shape[1])
+            off = r0 * base.ld
+        else:
+            self.shape = (rows,)
+            off = r0
+        self.dtype = np.dtype(base.dtype)
+        self.ptr = ctypes.c_void_p(base.ptr.value + off * self.dtype.itemsize)
+
+
 def _ptr(x):
-    """DeviceBuffer / ctypes pointer / integer address / None -> c_void_p (or None)."""
+    """DeviceBuffer / DeviceView / ctypes pointer / integer address / None -> c_void_p (or None)."""
     if x is None:
         return None
-    if isinstance(x, DeviceBuffer):
+    if isinstance(x, (DeviceBuffer, DeviceView)):
         return x.ptr
     if isinstance(x, ctypes.c_void_p):
         return x
@@ -392,6 +413,31 @@ class FeatureMatrix(object):
         Phi = as_float_matrix(Phi)
         _check(self.lib, self.lib.rr_featmat_put_host(self.h, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype),
                                                       Phi.shape[1], _ld(Phi), col0))
+
+    def pass2_begin(self, m, C):
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        if m.shape != (self.F,) or C.shape != (self.F, self.F):
+            raise ValueError("posterior shape does not match the feature matrix")
+        _check(self.lib, self.lib.rr_featmat_pass2_begin(self.h, m.ctypes.data_as(ctypes.c_void_p),
+                                                         C.ctypes.data_as(ctypes.c_void_p)))
+
+    def pass2_rows(self, dy):
+        _check(self.lib, self.lib.rr_featmat_pass2_rows(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0))
+
+    def pass2_rff(self, handle, dX, col0, dT):
+        _check(self.lib, self.lib.rr_featmat_pass2_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))
+
+    def pass2_end(self):
+        sq = np.zeros(1)
+        _check(self.lib, self.lib.rr_featmat_pass2_end(self.h, sq.ctypes.data_as(ctypes.c_void_p)))
+        return float(sq[0])
+
+    def predict_rows(self, rows):
+        Ey, Vf = np.empty(rows), np.empty(rows)
+        _check(self.lib, self.lib.rr_featmat_predict_rows(self.h, Ey.ctypes.data_as(ctypes.c_void_p),
+                                                          Vf.ctypes.data_as(ctypes.c_void_p)))
+        return Ey, Vf
 
     def gram_into(self, dy, dG, db=None, dyty=None):
         _check(self.lib, self.lib.rr_featmat_gram(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0,

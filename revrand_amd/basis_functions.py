@@ -144,6 +144,10 @@ class Basis(object):
         # generic bases: host transform, one upload of their (usually narrow) column block
         fm.put_host(self.transform(X, *params), col0)
 
+    def _resident_child(self, X):
+        """This basis' share of a concatenated device-resident fit (CatFitState); None = not supported."""
+        return None
+
     def _grad_popargs(self, X, *args):
         mine, rest = self.__split(args, self.grad)
         return self.grad(X, *mine), rest, mine
@@ -182,6 +186,9 @@ class BiasBasis(Basis):
     def transform(self, X):
         return np.ones((len(X), 1)) * self.offset
 
+    def _resident_child(self, X):
+        return _ResidentHost(self)
+
     def __repr__(self):
         return "{}(offset={}, regularizer={})".format(type(self).__name__, self.offset, self.regularizer)
 
@@ -205,6 +212,10 @@ class LinearBasis(Basis):
         fm.put_linear(dX, self.onescol, col0)
         fm.dev.sync()
         dX.free()
+
+    @slice_transform
+    def _resident_child(self, X):
+        return _ResidentLinear(self, X)
 
     def __repr__(self):
         return "{}(onescol={}, regularizer={})".format(type(self).__name__, self.onescol, self.regularizer)
@@ -264,6 +275,141 @@ class DeviceFitState(object):
     def release(self):
         self.dX.free()
         self.dy.free()
+
+
+class _ResidentHost(object):
+    """Child of a resident concatenated fit whose (narrow, parameter-free) block is made on the host."""
+
+    nparams = 0
+
+    def __init__(self, basis):
+        self.basis = basis
+
+    def put(self, fm, X, r0, rows, col0, params):
+        fm.put_host(self.basis.transform(X[r0:r0 + rows]), col0)
+
+    def release(self):
+        pass
+
+
+class _ResidentLinear(object):
+    """LinearBasis child: its X columns stay on the device."""
+
+    nparams = 0
+
+    def __init__(self, basis, X):
+        self.onescol = basis.onescol
+        self.dX = _hip.get_device().upload_matrix(np.ascontiguousarray(X, dtype=np.float32))
+
+    def put(self, fm, X, r0, rows, col0, params):
+        fm.put_linear(_hip.DeviceView(self.dX, r0, rows), self.onescol, col0)
+
+    def release(self):
+        self.dX.free()
+
+
+class _ResidentRFF(object):
+    """Random Fourier (or FastFood, through its dense equivalent) child: X resident in the padded layout,
+    T = X^T A accumulated on the device by rr_featmat_pass2_rff."""
+
+    nparams = 1
+
+    def __init__(self, basis, X):
+        self.basis = basis
+        self.h, W = basis._dense_handle()
+        self.W = np.asarray(W, dtype=np.float64)
+        self.dX = self.h.upload(np.ascontiguousarray(X, dtype=np.float32))
+        self.dT = self.h.dev.zeros(self.W.size * 8)
+
+    def put(self, fm, X, r0, rows, col0, params):
+        self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
+        fm.put_rff(self.h, _hip.DeviceView(self.dX, r0, rows), self.ls, col0)
+
+    def reset(self):
+        self.h.dev.memset(self.dT)
+
+    def grad(self, fm, r0, rows, col0):
+        fm.pass2_rff(self.h, _hip.DeviceView(self.dX, r0, rows), col0, self.dT)
+
+    def dhyp(self, var):
+        T = self.h.dev.download(self.dT, self.W.shape, np.float64)
+        ls = np.atleast_1d(np.asarray(self.ls, dtype=float))
+        if ls.size == 1:  # the reference's isotropic gradient: input dimension 0 only
+            return float((T[0] * self.W[0]).sum() / (var * ls[0] ** 2))
+        return (T * self.W).sum(axis=1) / (var * ls ** 2)
+
+    def release(self):
+        self.dX.free()
+        self.dT.free()
+
+
+class CatFitState(object):
+    """DeviceFitState for a BasisCat: every child keeps its columns of X on the GPU, Phi is assembled in a
+    device feature matrix per row chunk; same ``gram`` / ``second_pass`` / ``release`` interface, ``dhyp``
+    structured like ``apply_grad(f, cat.grad(X, *hypers))``."""
+
+    def __init__(self, cat, children, X, y, chunk_rows=None):
+        self.X, self.N = X, X.shape[0]
+        self.children = children
+        self.F = int(cat.get_dim(X))
+        self.ends = [int(e) for e in np.cumsum([0] + [int(b.get_dim(X)) for b in cat.bases])]
+        self.dev = _hip.get_device()
+        self.dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+        Fp = (self.F + 255) // 256 * 256
+        if chunk_rows is None:  # P, its transpose and U = P C: 12 Fp bytes per row, within ~24 GiB
+            chunk_rows = (24 << 30) // (12 * Fp)
+        self.chunk = int(max(256, min(self.N, chunk_rows)))
+        self.fm = _hip.FeatureMatrix(self.chunk, self.F)
+        self._filled = None
+
+    def _fill(self, r0, rows, hypers):
+        key = (r0, rows, tuple(np.asarray(h, dtype=float).tobytes() for h in hypers))
+        if self._filled == key:  # single-chunk fits: the second pass reuses the Gram pass' features
+            return
+        self.fm.begin(rows)
+        args = list(hypers)
+        for child, col0 in zip(self.children, self.ends):
+            mine, args = args[:child.nparams], args[child.nparams:]
+            child.put(self.fm, self.X, r0, rows, col0, mine)
+        self._filled = key
+
+    def _chunks(self):
+        for r0 in range(0, self.N, self.chunk):
+            yield r0, min(self.chunk, self.N - r0)
+
+    def gram(self, hypers):
+        hypers, F, dev = atleast_list(hypers), self.F, self.dev
+        acc = dev.zeros((F * F + F + 1) * 8)
+        base = acc.ptr.value
+        pG, pb, pt = (_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
+        for r0, rows in self._chunks():
+            self._fill(r0, rows, hypers)
+            self.fm.gram_into(_hip.DeviceView(self.dy, r0, rows), pG, pb, pt)
+        _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
+        out = dev.download(acc, (F * F + F + 1,), np.float64)
+        acc.free()
+        return out[:F * F].reshape(F, F), out[F * F:F * F + F].copy(), float(out[-1])
+
+    def second_pass(self, hypers, m, C, var):
+        hypers = atleast_list(hypers)
+        self.fm.pass2_begin(m, C)
+        with_grad = [(c, col0) for c, col0 in zip(self.children, self.ends) if c.nparams]
+        for c, _ in with_grad:
+            c.reset()
+        for r0, rows in self._chunks():
+            self._fill(r0, rows, hypers)
+            self.fm.pass2_rows(_hip.DeviceView(self.dy, r0, rows))
+            for c, col0 in with_grad:
+                c.grad(self.fm, r0, rows, col0)
+        sq = self.fm.pass2_end()
+        grads = [c.dhyp(var) for c, _ in with_grad]
+        return sq, (grads if len(grads) != 1 else grads[0])
+
+    def release(self):
+        for c in self.children:
+            c.release()
+        self.dy.free()
+        self.fm = None
 
 
 class _RandomKernelBasis(_LengthScaleBasis):
@@ -353,11 +499,23 @@ class _RandomKernelBasis(_LengthScaleBasis):
             return None
         return DeviceFitState(self._handle(), self.W, X, y)
 
+    def _dense_handle(self):
+        """(RffHandle, W) whose kernels produce this basis' features."""
+        return self._handle(), self.W
+
+    @slice_transform
+    def _resident_child(self, X):
+        if self.dtype != "f32" or X.shape[1] != self.d:
+            return None
+        return _ResidentRFF(self, X)
+
     @slice_transform
     def predict_moments(self, X, lenscale, m, C):
-        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243); f32 mode only."""
+        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243); None in f64 mode (host path)."""
+        if self.dtype != "f32":
+            return None
         lenscale = self._check_dim(X.shape[1], lenscale)
-        return self._handle().predict(X, lenscale, m, C)
+        return self._dense_handle()[0].predict(X, lenscale, m, C)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(
@@ -522,17 +680,15 @@ class FastFoodRBF(_LengthScaleBasis):
         fm.dev.sync()
         dX.free()
 
+    def _dense_handle(self):
+        rff = self._handles()[1]
+        return rff, self.__dict__["_hip_handle"][3]
+
     @slice_transform
     def device_fit_state(self, X, y):
         if self.dtype != "f32" or X.shape[1] != self.d:
             return None
-        rff = self._handles()[1]
-        return DeviceFitState(rff, self.__dict__["_hip_handle"][3], X, y)
-
-    @slice_transform
-    def predict_moments(self, X, lenscale, m, C):
-        lenscale = self._check_dim(X.shape[1], lenscale)
-        return self._handles()[1].predict(X, lenscale, m, C)
+        return DeviceFitState(*self._dense_handle(), X=X, y=y)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(
@@ -593,6 +749,7 @@ class FastFoodGM(FastFoodRBF):
     device_fit_state = None
     predict_moments = None
     _put_features = Basis._put_features
+    _resident_child = Basis._resident_child
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, mean={}, lenscale={}, regularizer={}, random_state={})".format(
@@ -673,6 +830,44 @@ class BasisCat(object):
         if y is None:
             return G, None, None
         return G, out[F * F:F * F + F].copy(), float(out[-1])
+
+    def device_fit_state(self, X, y):
+        """(X, y) resident for a whole fit when every child can take part (f32 random Fourier / FastFood,
+        Linear, Bias); None otherwise (the estimator then uses transform / grad)."""
+        children = []
+        for b in self.bases:
+            c = b._resident_child(X)
+            if c is None:
+                for done in children:
+                    done.release()
+                return None
+            children.append(c)
+        if not any(c.nparams for c in children):  # nothing to learn on the device
+            for done in children:
+                done.release()
+            return None
+        return CatFitState(self, children, X, y)
+
+    def predict_moments(self, X, hypers, m, C):
+        """(Phi m, rowsum((Phi C) o Phi)) with Phi assembled on the device (slm.py:240-243); None when a child
+        asks for f64 arithmetic."""
+        if any(getattr(b, "dtype", "f32") != "f32" for b in self.bases):
+            return None
+        N, F = X.shape[0], int(self.get_dim(X))
+        ends = self.__base_locations(X)
+        Fp = (F + 255) // 256 * 256
+        chunk = int(max(256, min(N, (24 << 30) // (12 * Fp))))
+        fm = _hip.FeatureMatrix(chunk, F)
+        fm.pass2_begin(m, C)
+        Ey, Vf = np.empty(N), np.empty(N)
+        for r0 in range(0, N, chunk):
+            Xc = X[r0:r0 + chunk]
+            fm.begin(Xc.shape[0])
+            args = list(atleast_list(hypers))
+            for i, b in enumerate(self.bases):
+                args = b._put_features_popargs(Xc, fm, int(ends[i]), *args)
+            Ey[r0:r0 + chunk], Vf[r0:r0 + chunk] = fm.predict_rows(Xc.shape[0])
+        return Ey, Vf
 
     def get_dim(self, X):
         return np.sum(self.__all_dims(X))

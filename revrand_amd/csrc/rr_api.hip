@@ -251,17 +251,22 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     std::vector<float> wt32((size_t)npad * b->dpad, 0.0f);
     std::vector<double> g64(b->dpad, 0.0);
     std::vector<float> g32(b->dpad, 0.0f);
+    // f32 copies are clamped to a finite range: the optimiser's log-space bounds let a length scale reach
+    // 1e-100 (optimize/decorators.py:18), where the reference's float64 phases are finite noise; an f32
+    // phase that large has no fractional part left either way, but it must not become inf - inf = NaN.
+    const double wmax = 4611686018427387904.0;  // 2^62
+    auto clampf = [](double v, double lim) { return (float)(v > lim ? lim : (v < -lim ? -lim : v)); };
     for (int i = 0; i < d; ++i) {
         const double l = lenscale[n_ls == 1 ? 0 : i];
         const double s = inv2pi / l;
         for (int f = 0; f < n; ++f) {
             const double v = b->W[(size_t)i * n + f] * s;
             w64[(size_t)i * npad + f] = v;
-            w32[(size_t)i * npad + f] = (float)v;
-            wt32[(size_t)f * b->dpad + i] = (float)v;
+            w32[(size_t)i * npad + f] = clampf(v, wmax);
+            wt32[(size_t)f * b->dpad + i] = clampf(v, wmax);
         }
         g64[i] = twopi / l;
-        g32[i] = (float)g64[i];
+        g32[i] = clampf(g64[i], 3.0e38);
     }
     rr_ctx *c = b->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));

@@ -446,6 +446,73 @@ static int pass2_checks(rr_basis *b, const void *dX, int x_dtype, int64_t N, int
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Second pass over a device feature matrix (concatenated bases): the same Err / U = P C / gradient
+// contraction with P assembled by the children (rr_featmat_put_*).
+// ---------------------------------------------------------------------------------------------
+// Pt[c][r] = P[r][c] (r < rows; zero for rows <= r < rows256): the K-major GEMM operand.  64x64 tiles via LDS.
+__global__ void __launch_bounds__(256)
+rr_transpose_f32_kernel(const float *__restrict__ P, int64_t rows, int64_t ldp, float *__restrict__ Pt, int64_t ldt) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = r0 + ty + 4 * k;
+        tile[ty + 4 * k][tx] = r < rows ? P[r * ldp + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Pt[(c0 + ty + 4 * k) * ldt + r0 + tx] = tile[tx][ty + 4 * k];
+}
+
+// dot[r] = P[r][0:F] . m   (one wave per row)
+__global__ void __launch_bounds__(256)
+rr_rowvec_kernel(const float *__restrict__ P, const float *__restrict__ mvec, int64_t rows, int F, int64_t ld,
+                 float *__restrict__ dot) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float *q = P + r * ld;
+    float acc = 0.f;
+    for (int j = lane; j < F; j += 64) acc = fmaf(q[j], mvec[j], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) dot[r] = acc;
+}
+
+struct FmPass2 {
+    float *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
+    double *sq = nullptr, *vf = nullptr;
+    std::vector<float> hC, hm;
+    bool have_rows = false;
+};
+
+void rr_fm_pass2_free(void *p) {
+    if (!p) return;
+    FmPass2 *s = (FmPass2 *)p;
+    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf};
+    for (void *x : q)
+        if (x) (void)hipFree(x);
+    delete s;
+}
+
+// Err-independent part for the rows currently in the matrix: dot = P m, Pt = P^T, U = P C.
+static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
+    rr_ctx *c = fm->ctx;
+    const int64_t rows256 = (fm->rows + 255) / 256 * 256;
+    hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, s.m32,
+                       fm->rows, fm->F, fm->ld, s.dot);
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(fm->ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0,
+                       c->stream, fm->P, fm->rows, fm->ld, s.Pt, fm->max_rows);
+    GemmArgs g;
+    g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = fm->max_rows; g.ldb = fm->ld; g.ldd = fm->ld;
+    g.K = (int)fm->ld; g.ntb = (int)(fm->ld / 256);
+    hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 template <typename TX, typename TE>
 static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ldx, const TE *dE, int64_t lde, double *dT) {
     rr_ctx *c = b->ctx;
@@ -554,6 +621,113 @@ int rr_rff_predict_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int6
     RR_REQUIRE(Ey != nullptr && Vf != nullptr, "rr_rff_predict_dev: null argument");
     return x_dtype == RR_F32 ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, C, Ey, Vf)
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, C, Ey, Vf);
+}
+
+int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) {
+    RR_REQUIRE(fm != nullptr && m != nullptr && C != nullptr, "rr_featmat_pass2_begin: null argument");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int F = fm->F;
+    const int64_t Fp = fm->ld;
+    if (!fm->pass2) {
+        FmPass2 *s = new FmPass2();
+        fm->pass2 = s;
+        hipError_t ea = hipMalloc((void **)&s->Pt, (size_t)Fp * fm->max_rows * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->U, (size_t)fm->max_rows * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->C32, (size_t)Fp * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->m32, (size_t)Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->dot, (size_t)fm->max_rows * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->err, (size_t)fm->max_rows * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->sq, 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->vf, (size_t)fm->max_rows * 8);
+        if (ea != hipSuccess) {
+            (void)hipGetLastError();
+            rr_fm_pass2_free(s);
+            fm->pass2 = nullptr;
+            rr_set_error("rr_featmat_pass2_begin: device allocation failed");
+            return RR_ERR_OOM;
+        }
+    }
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.hm.assign((size_t)Fp, 0.f);
+    s.hC.assign((size_t)Fp * Fp, 0.f);
+    for (int i = 0; i < F; ++i) s.hm[i] = (float)m[i];
+    for (int i = 0; i < F; ++i) {
+        const double *src = C + (size_t)i * F;
+        float *dst = s.hC.data() + (size_t)i * Fp;
+        for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+    }
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(s.m32, s.hm.data(), (size_t)Fp * 4, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemsetAsync(s.sq, 0, 8, c->stream));
+    s.have_rows = false;
+    return RR_OK;
+}
+
+int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_rows: call rr_featmat_pass2_begin first");
+    RR_REQUIRE(dy == nullptr || y_dtype == RR_F32 || y_dtype == RR_F64, "rr_featmat_pass2_rows: bad dtype");
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.have_rows = true;
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = fm_pass2_products(fm, s);
+    if (rc != RR_OK || dy == nullptr) return rc;
+    const dim3 grid((unsigned)((fm->rows + 255) / 256));
+    if (y_dtype == RR_F32)
+        hipLaunchKernelGGL(rr_err_kernel<float>, grid, dim3(256), 0, c->stream, (const float *)dy, s.dot, fm->rows, s.err, s.sq);
+    else
+        hipLaunchKernelGGL(rr_err_kernel<double>, grid, dim3(256), 0, c->stream, (const double *)dy, s.dot, fm->rows, s.err, s.sq);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr && ((FmPass2 *)fm->pass2)->have_rows,
+               "rr_featmat_pass2_rff: call rr_featmat_pass2_rows first");
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr, "rr_featmat_pass2_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_pass2_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_pass2_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad, "rr_featmat_pass2_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
+    if (fm->rows == 0) return RR_OK;
+    RR_REQUIRE(dX != nullptr, "rr_featmat_pass2_rff: null X");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    if (x_dtype == RR_F32)
+        return launch_grad_t<float>(b, (const float *)dX, fm->rows, ldx, fm->P + col0, s.U + col0, fm->ld, s.err,
+                                    s.m32 + col0, dT);
+    return launch_grad_t<double>(b, (const double *)dX, fm->rows, ldx, fm->P + col0, s.U + col0, fm->ld, s.err,
+                                 s.m32 + col0, dT);
+}
+
+int rr_featmat_pass2_end(rr_featmat *fm, double *sqErr) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr && sqErr != nullptr, "rr_featmat_pass2_end: bad argument");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    RR_CHECK_HIP(hipStreamSynchronize(fm->ctx->stream));
+    RR_CHECK_HIP(hipMemcpy(sqErr, ((FmPass2 *)fm->pass2)->sq, 8, hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_predict_rows: call rr_featmat_pass2_begin first");
+    RR_REQUIRE(Ey != nullptr && Vf != nullptr, "rr_featmat_predict_rows: null output");
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    int rc = fm_pass2_products(fm, s);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, s.U, fm->P, fm->rows,
+                       fm->F, fm->ld, s.vf);
+    RR_CHECK_HIP(hipGetLastError());
+    std::vector<float> dot((size_t)fm->rows);
+    RR_CHECK_HIP(hipMemcpyAsync(Vf, s.vf, (size_t)fm->rows * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(dot.data(), s.dot, (size_t)fm->rows * 4, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (int64_t i = 0; i < fm->rows; ++i) Ey[i] = (double)dot[i];
+    return RR_OK;
 }
 
 }  // extern "C"

@@ -8,12 +8,6 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
                              float *P, int64_t ldp, bool zero_pad_cols);
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid);
 
-struct rr_featmat {
-    rr_ctx *ctx = nullptr;
-    float *P = nullptr;
-    int64_t max_rows = 0, ld = 0, rows = 0, rows_pad = 0;
-    int F = 0;
-};
 
 // [1, X] or X (LinearBasis.transform, basis_functions.py:468-485) into columns [col0, col0 + d + onescol)
 template <typename TX>
@@ -78,7 +72,7 @@ int rr_featmat_create(rr_ctx *ctx, int64_t max_rows, int64_t F, rr_featmat **out
     fm->ctx = ctx;
     fm->F = (int)F;
     fm->ld = (F + 255) / 256 * 256;
-    fm->max_rows = (max_rows + 31) / 32 * 32;
+    fm->max_rows = (max_rows + 255) / 256 * 256;  // the second pass' GEMM tiles rows by 256
     hipError_t e = hipMalloc((void **)&fm->P, (size_t)fm->max_rows * fm->ld * sizeof(float));
     if (e != hipSuccess) {
         (void)hipGetLastError();
@@ -95,6 +89,7 @@ void rr_featmat_destroy(rr_featmat *fm) {
     (void)hipSetDevice(fm->ctx->device);
     (void)hipStreamSynchronize(fm->ctx->stream);
     if (fm->P) (void)hipFree(fm->P);
+    rr_fm_pass2_free(fm->pass2);
     delete fm;
 }
 

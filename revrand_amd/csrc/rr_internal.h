@@ -77,3 +77,13 @@ void rr_set_error(const char *fmt, ...);
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
 int rr_pick_dmax(int d);
 void rr_pass2_scratch_free(void *p);
+
+// Device feature matrix of a concatenated basis (rr_featmat.hip; second pass in rr_elbo.hip).
+struct rr_featmat {
+    rr_ctx *ctx = nullptr;
+    float *P = nullptr;
+    int64_t max_rows = 0, ld = 0, rows = 0, rows_pad = 0;
+    int F = 0;
+    void *pass2 = nullptr;  // FmPass2 scratch, grow-never (sized by max_rows, ld)
+};
+void rr_fm_pass2_free(void *p);

@@ -70,7 +70,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         # a single random-feature basis keeps (X, y) on the GPU for the whole optimisation
         self._state = self._make_state(X, y)
         if self.distributed and self._state is None:
-            raise ValueError("distributed=True needs a single random-feature basis in f32 mode")
+            raise ValueError("distributed=True needs random-feature bases in f32 mode (alone or concatenated "
+                             "with Linear/Bias bases)")
         try:
             res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
                        options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
@@ -131,9 +132,14 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         m = C.dot(Phiy) / var
         TrPhiPhiC = (PhiPhi * C).sum()
         sqErr, dhypers = st.second_pass(hypers, m, C, var)
-        if self.distributed:  # second exchange: 1 + d numbers
-            red = self._allreduce(np.concatenate(([sqErr], np.atleast_1d(dhypers))))
-            sqErr, dhypers = float(red[0]), (float(red[1]) if np.ndim(dhypers) == 0 else red[1:])
+        if self.distributed:  # second exchange: 1 + (number of length scales) numbers
+            parts = dhypers if isinstance(dhypers, list) else [dhypers]
+            red = self._allreduce(np.concatenate([[sqErr]] + [np.atleast_1d(p) for p in parts]))
+            sqErr, out, k = float(red[0]), [], 1
+            for p in parts:
+                out.append(float(red[k]) if np.ndim(p) == 0 else red[k:k + np.size(p)])
+                k += np.size(p)
+            dhypers = out if isinstance(dhypers, list) else out[0]
         ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
                        + ((m ** 2 + C.diagonal()) * iL).sum() - logdetC + np.log(L).sum() - D)
         if ELBO > self.obj_:
@@ -142,7 +148,11 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             self.obj_ = ELBO
         log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
         dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
-        dL = -0.5 * (((m ** 2 + C.diagonal()) * iL ** 2).sum() - iL.sum())
+
+        def dreg(s):
+            return -0.5 * (((m[s] ** 2 + C[s, s].diagonal()) * iL[s] ** 2).sum() - iL[s].sum())
+
+        dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
         return -ELBO, [-dvar, dL, dhypers]
 
     def _elbo(self, X, y, var, reg, hypers):
@@ -201,9 +211,10 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         """Predictive mean and variance (slm.py:219-244)."""
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
         X = check_array(X)
-        if getattr(self.basis, "predict_moments", None) is not None and getattr(self.basis, "dtype", None) == "f32":
-            Ey, Vf = self.basis.predict_moments(X, self.hypers_, self.weights_, self.covariance_)  # on the GPU
-            return Ey, Vf + self.var_
+        if getattr(self.basis, "predict_moments", None) is not None:
+            res = self.basis.predict_moments(X, self.hypers_, self.weights_, self.covariance_)  # on the GPU
+            if res is not None:
+                return res[0], res[1] + self.var_
         Phi = self.basis.transform(X, *atleast_list(self.hypers_))
         Ey = Phi.dot(self.weights_)
         Vf = (Phi.dot(self.covariance_) * Phi).sum(axis=1)

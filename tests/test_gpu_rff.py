@@ -312,3 +312,17 @@ def test_grad_contract_vs_materialised_gradient(ard):
     want = np.array([(E * dP[:, :, i]).sum() for i in range(d)]) if ard else (E * dP).sum()
     assert np.shape(got) == np.shape(want)
     assert normwise(np.atleast_1d(got), np.atleast_1d(want)) < 1e-3
+
+
+def test_extreme_lenscale_stays_finite():
+    """The optimiser's log-space bounds reach lenscale = 1e-100 (optimize/decorators.py:18); the reference
+    returns finite (meaningless) features there and so must the f32 path -- no inf - inf."""
+    rs = np.random.RandomState(0)
+    X = rs.randn(500, 4)
+    y = rs.randn(500)
+    b = _make("RandomRBF", 4, 64, 1, True, "f32")
+    ls = np.array([1e-100, 3e68, 1e78, 3e58])
+    Phi = b.transform(X, ls)
+    assert np.isfinite(Phi).all() and np.abs(Phi).max() <= 1 / np.sqrt(64) + 1e-6
+    G, bb, _ = b.gram(X, y, ls)
+    assert np.isfinite(G).all() and np.isfinite(bb).all()

@@ -238,3 +238,104 @@ def test_concat_gram_on_device_vs_oracle():
     assert normwise(b, ref.T @ y) < 1e-4 and abs(yty - y @ y) < 1e-5 * (y @ y)
     G2, b2, t2 = base.gram(X, None, ls, 0.9)
     assert b2 is None and normwise(G2, ref.T @ ref) < 1e-4
+
+
+def test_resident_concat_elbo_matches_reference(golden):
+    """`_elbo` of a concatenation (config 3's RandomMatern52 + LinearBasis) with X, y resident on the device
+    and Phi / dPhi never built: against the reference's golden values."""
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    basis = bs.RandomMatern52(nbases=n, Xdim=d, random_state=22,
+                              lenscale=Parameter(np.ones(d), Positive())) + bs.LinearBasis(onescol=True)
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    slm._state = basis.device_fit_state(X, y)
+    assert slm._state is not None
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), list(g["cat_reg"]), g["cat_ls"])
+    slm._state.release()
+    assert abs(-nelbo - g["cat_elbo"]) < 1e-4 * abs(g["cat_elbo"])
+    assert normwise(slm.weights_, g["cat_m"]) < 1e-3
+    assert normwise(slm.covariance_, g["cat_C"]) < 1e-3
+    assert normwise(-np.asarray(ndreg), g["cat_dreg"]) < 1e-3
+    assert np.shape(ndhyp) == (d,) and normwise(-ndhyp, g["cat_dhyp"]) < 2e-3
+
+
+@pytest.mark.parametrize("chunk_rows", [None, 512])
+def test_concat_second_pass_and_predict_vs_oracle(chunk_rows):
+    """Two random-feature children (isotropic on a column subset, ARD) + Linear + Bias: statistics, sqErr, the
+    per-child gradient contraction (structured like apply_grad over BasisCat.grad) and predict_moments."""
+    bs, Parameter, Positive, SLM = _imports()
+    from revrand_amd.basis_functions import CatFitState
+    rs = np.random.RandomState(5)
+    N, d, n0, n1 = 1300, 6, 70, 90
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    cat = bs.RandomRBF(nbases=n0, Xdim=2, random_state=1, apply_ind=[4, 1]) \
+        + bs.RandomMatern32(nbases=n1, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=False) + bs.BiasBasis(offset=1.5)
+    ls0, ls1 = 0.8, np.linspace(0.7, 1.5, d)
+    var = 0.3
+    W0, W1 = cat.bases[0].W, cat.bases[1].W
+    Xa = X[:, [4, 1]]
+    Phi = np.hstack((orc.rff_transform(Xa, W0, ls0), orc.rff_transform(X, W1, ls1), X, np.full((N, 1), 1.5)))
+    F = Phi.shape[1]
+    ends = [0, 2 * n0, 2 * n0 + 2 * n1]
+    dPs = []
+    g0 = np.zeros((N, F))
+    g0[:, ends[0]:ends[1]] = orc.rff_grad(Xa, W0, ls0)
+    dPs.append(g0)
+    g1 = orc.rff_grad(X, W1, ls1)
+    for i in range(d):
+        gi = np.zeros((N, F))
+        gi[:, ends[1]:ends[2]] = g1[:, :, i]
+        dPs.append(gi)
+    L = np.concatenate((np.full(2 * n0, 1.1), np.full(2 * n1, 0.9), np.full(d, 2.0), [1.3]))
+    o = orc.slm_elbo(Phi, y, var, L, slice(None), dPs)
+
+    st = cat.device_fit_state(X, y)
+    assert isinstance(st, CatFitState)
+    if chunk_rows:
+        st.release()
+        st = CatFitState(cat, [b._resident_child(X) for b in cat.bases], X, y, chunk_rows=chunk_rows)
+    G, b, yty = st.gram([ls0, ls1])
+    assert normwise(G, Phi.T @ Phi) < 1e-4 and normwise(b, Phi.T @ y) < 1e-4 and abs(yty - y @ y) < 1e-5 * (y @ y)
+    sq, dh = st.second_pass([ls0, ls1], o["m"], o["C"], var)
+    st.release()
+    err = y - Phi @ o["m"]
+    assert abs(sq - err @ err) < 1e-4 * (err @ err)
+    assert isinstance(dh, list) and len(dh) == 2 and np.ndim(dh[0]) == 0 and np.shape(dh[1]) == (d,)
+    want = -np.array(o["dhyp"])
+    assert normwise(np.concatenate(([dh[0]], dh[1])), want) < 2e-3
+
+    Xs = rs.randn(300, d)
+    Ey, Vf = cat.predict_moments(Xs, [ls0, ls1], o["m"], o["C"])
+    Ps = np.hstack((orc.rff_transform(Xs[:, [4, 1]], W0, ls0), orc.rff_transform(Xs, W1, ls1), Xs, np.full((300, 1), 1.5)))
+    Eo, Vo = orc.slm_predict_moments(Ps, o["m"], o["C"], 0.0)
+    assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
+
+
+def test_concat_fit_runs_resident_and_predicts():
+    """fit() of RandomMatern52 (ARD) + LinearBasis stays on the device-resident path and generalises."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(0)
+    N, d = 4000, 4
+    X = rs.randn(N, d)
+    f = lambda Z: np.sin(2 * Z[:, 0]) + 0.5 * Z[:, 1] - 0.2 * Z[:, 2]
+    y = f(X) + 0.05 * rs.randn(N)
+    cat = bs.RandomMatern52(nbases=150, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
+    slm = SLM(cat, nstarts=0, maxiter=60, random_state=3)
+    made = []
+    orig = slm._make_state
+    slm._make_state = lambda X_, y_: made.append(orig(X_, y_)) or made[-1]
+    slm.fit(X, y)
+    assert made and type(made[0]).__name__ == "CatFitState"
+    Xs = rs.randn(500, d)
+    Ey, Vy = slm.predict_moments(Xs)
+    assert smse(f(Xs), Ey) < 0.15 and np.all(Vy > 0)
+    # device predict_moments of the concatenation == host formulas on the transformed features
+    Phi = cat.transform(Xs, *np.atleast_1d([slm.hypers_]) if np.ndim(slm.hypers_) == 0 else [slm.hypers_])
+    Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
+    assert normwise(Ey, Eo) < 1e-3 and normwise(Vy, Vo) < 1e-2
