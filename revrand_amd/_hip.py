@@ -8,6 +8,7 @@ A device context is created lazily, once per *process* (sklearn may fork workers
 """
 import ctypes
 import os
+import sys
 import threading
 
 import numpy as np
@@ -129,12 +130,33 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as
+    /opt/rocm's).  If torch is imported first the loader hands that copy to our library too; the other way
+    round torch would bring a SECOND runtime + HSA instance into the process and see no GPU.  So when torch is
+    installed but not yet imported, its copy is loaded first (no ``import torch``).  ``RR_HIP_RUNTIME=system``
+    keeps /opt/rocm's."""
+    if "torch" in sys.modules or os.environ.get("RR_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except (OSError, ImportError, ValueError):
+        pass  # fall back to the system runtime
+
+
 def load_library(path=None):
     """Load the shared library and declare every prototype.  Raises if it is not built."""
     global _lib
     with _lib_lock:
         if _lib is not None and path is None:
             return _lib
+        _share_hip_runtime_with_torch()
         p = path or os.environ.get("REVRAND_HIP_LIB", LIB_PATH)
         if not os.path.exists(p):
             raise ImportError(

@@ -48,3 +48,23 @@ def test_product_does_not_import_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "revrand_oracle" not in text and "oracle/" not in text, f
                 assert "/root/reference" not in text, f
+
+
+def test_single_hip_runtime_with_torch():
+    """Loading the library BEFORE torch must not leave two HIP/HSA runtimes in the process (torch would then
+    see no GPU): the loader shares torch's bundled runtime when torch is installed."""
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from revrand_amd import _hip\n"
+        "_hip.load_library()\n"
+        "import torch\n"
+        "maps = open('/proc/self/maps').read().splitlines()\n"
+        "for key in ('libamdhip64', 'libhsa-runtime64'):\n"
+        "    paths = sorted({l.split()[-1] for l in maps if key in l})\n"
+        "    assert len(paths) == 1, paths\n"
+        "print('ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
