@@ -206,6 +206,30 @@ int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_
 int rr_featmat_pass2_end(rr_featmat *fm, double *sqErr);
 int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf);
 
+/* One SVI minibatch step of the generalised linear model (glm.py:205-322) over the rows currently in the matrix.
+ * Likelihood ids (likelihoods.py): */
+#define RR_LIK_BERNOULLI 0        /* logistic link                      :18-150  */
+#define RR_LIK_BINOMIAL 1         /* per-row n in drowarg               :153-258 */
+#define RR_LIK_GAUSSIAN 2         /* lik_param = variance               :261-423 */
+#define RR_LIK_POISSON_EXP 3      /* exp link                           :426-545 */
+#define RR_LIK_POISSON_SOFTPLUS 4 /* softplus link                               */
+/* WS: host (K*L, F) float64 weight samples, component-major (rows [k*L, (k+1)*L) belong to component k).
+ * dy, drowarg: DEVICE vectors of fm rows (dtype RR_F32 / RR_F64), drowarg NULL unless binomial.
+ * Outputs (host float64): Edws (K*L, F) = dfs Phi (glm.py:308); per component k: llsum[k] = sum over its L samples
+ * and the rows of loglike WITHOUT its f-independent constant (-gammaln(y+1), log C(n,y), -log(2 pi var)/2), and
+ * aux[k] = sum (y - f)^2 (Gaussian; 0 otherwise).  EdPhi = dfs^T ws / (K L) (glm.py:311,229) stays on the device
+ * for rr_featmat_glm_rff / rr_featmat_glm_edphi. */
+int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                        const double *WS, int K, int L, double *Edws, double *llsum, double *aux);
+/* dT (d, n) float64 DEVICE buffer += X^T (E_s o P_c - E_c o P_s) for the random Fourier child at columns
+ * [col0, col0 + 2n):  sum(EdPhi o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]  (glm.py:274-275 without basis.grad). */
+int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
+                       double *dT);
+/* EdPhi[:, col0:col0+ncols] to the host (rows, ncols) float64, for bases whose gradient is formed on the host. */
+int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E);
+/* out (rows, S) = P W for a host (F, S) float64 matrix: the latent function samples of glm.py:572-620. */
+int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
+
 /* ---- second data pass of the standard linear model (posterior known) -----------------------
  * With m (F,) and C (F, F) from the host Cholesky (slm.py:154-157), for a random Fourier basis and
  * DEVICE-resident X (padded layout, see rr_rff_padded_dim) and y:

@@ -326,6 +326,89 @@ def gen_fit():
          Ey=Ey, Vy=Vy)
 
 
+
+def gen_glm():
+    """One minibatch `_elbo` of the reference's GeneralizedLinearModel (glm.py:205-322) per likelihood, with a
+    seeded ``random_``; the standard-normal draws are replayed from the same seed and stored so that the oracle
+    and the HIP path see the reference's exact samples.  Also a few steps of every SGD updater."""
+    from revrand.glm import GeneralizedLinearModel
+    import revrand.likelihoods as rl
+    import importlib
+    rsgd = importlib.import_module("revrand.optimize.sgd")
+    out = {}
+    rs = np.random.RandomState(11)
+    M, d, n, K, Ls = 256, 4, 32, 3, 8
+    X = rs.randn(M, d)
+    fl = np.sin(X @ rs.randn(d))
+    nbin = rs.randint(1, 9, size=M).astype(float)
+    ys = {
+        "poisson_exp": rs.poisson(np.exp(fl)).astype(float),
+        "poisson_softplus": rs.poisson(np.log1p(np.exp(fl))).astype(float),
+        "gaussian": fl + 0.1 * rs.randn(M),
+        "bernoulli": (rs.rand(M) < 1 / (1 + np.exp(-fl))).astype(float),
+        "binomial": rs.binomial(nbin.astype(int), 1 / (1 + np.exp(-fl))).astype(float),
+    }
+    liks = {
+        "poisson_exp": (lambda: rl.Poisson("exp"), [], ()),
+        "poisson_softplus": (lambda: rl.Poisson("softplus"), [], ()),
+        "gaussian": (lambda: rl.Gaussian(), [0.7], ()),
+        "bernoulli": (lambda: rl.Bernoulli(), [], ()),
+        "binomial": (lambda: rl.Binomial(), [], (nbin,)),
+    }
+    D = 2 * n
+    m = 0.3 * rs.randn(D, K)
+    C = rs.gamma(2., 0.5, size=(D, K))
+    out.update(X=X, nbin=nbin, m=m, C=C, K=K, L=Ls, B=10.0, reg=1.3, seed=5)
+    for ard in (False, True):
+        tag0 = "ard" if ard else "iso"
+        lsp = Parameter(np.ones(d), Positive()) if ard else Parameter(1., Positive())
+        ls = np.linspace(0.7, 1.4, d) if ard else 0.9
+        out[tag0 + "_ls"] = ls
+        for name, (mk, lpars, largs) in liks.items():
+            if ard and name not in ("poisson_exp", "gaussian"):
+                continue
+            basis = rb.RandomRBF(nbases=n, Xdim=d, random_state=7, lenscale=lsp)
+            glm = GeneralizedLinearModel(likelihood=mk(), basis=basis, K=K, nsamples=Ls, random_state=5)
+            glm.B_, glm.D_ = 10.0, D
+            glm._GeneralizedLinearModel__it = -1
+            y = ys[name]
+            lp = lpars[0] if lpars else []
+            nobj, (ndm, ndC, dL, dlp, dbp) = glm._elbo(m.copy(), C.copy(), 1.3, lp, ls, X, y, *largs)
+            e = np.stack([np.random.RandomState(5).randn(K * Ls, D)[k * Ls:(k + 1) * Ls] for k in range(K)])
+            Phi = basis.transform(X, ls)
+            dP = basis.grad(X, ls)
+            dPs = [dP[:, :, i] for i in range(d)] if ard else [dP]
+            o = orc.glm_elbo(m, C, np.full(D, 1.3), slice(None), name, lpars, largs, Phi, dPs, y, e, 10.0)
+            close(o[0], nobj, 1e-10)
+            close(o[1][0], ndm, 1e-10)
+            close(o[1][1], ndC, 1e-10)
+            close(o[1][2][0], dL, 1e-10)
+            if lpars:
+                close(o[1][3][0], np.atleast_1d(dlp)[0], 1e-10)
+            close(np.array(o[1][4]), np.atleast_1d(dbp), 1e-10)
+            t = tag0 + "_" + name
+            out.update({t + "_y": y, t + "_obj": nobj, t + "_ndm": ndm, t + "_ndC": ndC, t + "_dL": dL,
+                        t + "_dlp": np.atleast_1d(np.asarray(dlp, float)) if lpars else np.zeros(0),
+                        t + "_dbp": np.atleast_1d(dbp)})
+            out["W"] = basis.W
+    out["e"] = np.stack([np.random.RandomState(5).randn(K * Ls, D)[k * Ls:(k + 1) * Ls] for k in range(K)])
+    # SGD updaters: five steps on a fixed gradient sequence
+    gs = np.random.RandomState(3).randn(5, 6)
+    for name, upd in (("sgd", rsgd.SGDUpdater()), ("adadelta", rsgd.AdaDelta()), ("adagrad", rsgd.AdaGrad()),
+                      ("momentum", rsgd.Momentum()), ("adam", rsgd.Adam())):
+        x = np.linspace(-1, 1, 6)
+        xo, st = x.copy(), {}
+        traj = []
+        for g in gs:
+            x = upd(x, g)
+            xo = orc.sgd_update(name, st, xo, g)
+            traj.append(x.copy())
+        close(xo, x, 1e-12)
+        out["upd_" + name] = np.array(traj)
+    out["upd_grads"] = gs
+    save("glm", **out)
+
+
 if __name__ == "__main__":
     gen_weights()
     gen_rff()
@@ -336,4 +419,5 @@ if __name__ == "__main__":
     gen_elbo()
     gen_solve_posdef()
     gen_fit()
+    gen_glm()
     print("oracle agrees with the reference on every fixture")

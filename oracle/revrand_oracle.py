@@ -402,3 +402,151 @@ def slm_posterior_from_stats(G, b, var, reg_diag):
 def slm_predict_moments(Phi_s, m, C, var):
     """StandardLinearModel.predict_moments  slm.py:219-244."""
     return Phi_s @ m, ((Phi_s @ C) * Phi_s).sum(axis=1) + var
+
+
+# --------------------------------------------------------------------------
+# a-15  GeneralizedLinearModel._elbo (one SVI minibatch), likelihood derivatives, SGD updaters
+# --------------------------------------------------------------------------
+
+def softplus(f):
+    """mathfun/special.py:91-128: log(1 + exp(f)) through logsumexp([0, f])."""
+    f = np.asarray(f, dtype=float)
+    return np.maximum(f, 0.) + np.log1p(np.exp(-np.abs(f)))
+
+
+def _expit(f):
+    f = np.asarray(f, dtype=float)
+    return np.where(f >= 0, 1. / (1. + np.exp(-np.abs(f))), np.exp(-np.abs(f)) / (1. + np.exp(-np.abs(f))))
+
+
+def lik_loglike(name, y, f, *args):
+    """likelihoods.py: Bernoulli :46-67, Binomial :171-192, Gaussian :298-323, Poisson :456-481."""
+    from scipy.special import gammaln
+    y, f = np.broadcast_arrays(np.asarray(y, float), np.asarray(f, float))
+    if name == "bernoulli":
+        return y * f - softplus(f)
+    if name == "binomial":
+        n = np.broadcast_to(np.asarray(args[0], float), f.shape)
+        return gammaln(n + 1) - gammaln(y + 1) - gammaln(n - y + 1) + y * f - n * softplus(f)
+    if name == "gaussian":
+        var = args[0]
+        return -0.5 * (np.log(2 * np.pi * var) + (y - f) ** 2 / var)
+    if name == "poisson_exp":
+        return y * f - np.exp(f) - gammaln(y + 1)
+    if name == "poisson_softplus":
+        g = softplus(f)
+        return y * np.log(g) - g - gammaln(y + 1)
+    raise ValueError(name)
+
+
+def lik_df(name, y, f, *args):
+    """d loglike / d f: likelihoods.py :86-104, :213-233, :346-368, :500-521."""
+    y, f = np.broadcast_arrays(np.asarray(y, float), np.asarray(f, float))
+    if name == "bernoulli":
+        return y - _expit(f)
+    if name == "binomial":
+        return y - _expit(f) * np.broadcast_to(np.asarray(args[0], float), f.shape)
+    if name == "gaussian":
+        return (y - f) / args[0]
+    if name == "poisson_exp":
+        return y - np.exp(f)
+    if name == "poisson_softplus":
+        return _expit(f) * (y / np.maximum(softplus(f), 1e-100) - 1)
+    raise ValueError(name)
+
+
+def lik_dp(name, y, f, *args):
+    """d loglike / d likelihood-parameter: only the Gaussian has one (likelihoods.py:370-396)."""
+    if name != "gaussian":
+        return []
+    y, f = np.broadcast_arrays(np.asarray(y, float), np.asarray(f, float))
+    ivar = 1. / args[0]
+    return [0.5 * (((y - f) * ivar) ** 2 - ivar)]
+
+
+def glm_qmatrix(m, C):
+    """glm.py:697-712: logq[j, i] = log N(m_i | m_j, diag(C_i + C_j))."""
+    D, K = m.shape
+    q = np.empty((K, K))
+    for j in range(K):
+        for i in range(K):
+            dc = C[:, i] + C[:, j]
+            q[j, i] = -0.5 * (D * np.log(2 * np.pi) + np.log(dc).sum() + ((m[:, i] - m[:, j]) ** 2 / dc).sum())
+    return q
+
+
+def glm_elbo(m, C, reg_diag, slices, lik, lpars, largs, Phi, dPhis, y, e, B, calc_ll=True):
+    """GeneralizedLinearModel._elbo + _reparam_k  glm.py:205-322 for one minibatch, on a materialised Phi,
+    with the standard-normal draws e (K, L, D) given (the reference draws ``random_.randn(L, D)`` once per
+    mixture component, in order, glm.py:300).
+
+    Returns what the reference hands its optimiser: (-ELBO, [-dm, -dC, dL, dlpars, dbpars]) with dL a list
+    (one per slice), dlpars a list, dbpars a list (one per 2-D slab in dPhis).
+    """
+    D, K = m.shape
+    L = e.shape[1]
+    pars = list(lpars) + list(largs)
+    Ld = np.asarray(reg_diag, float)
+    iL = 1. / Ld[:, None]
+    logNkl = glm_qmatrix(m, C)
+    mx = logNkl.max(axis=0)
+    logzk = np.log(np.exp(logNkl - mx).sum(axis=0)) + mx
+    dm, dC, Ell = np.empty_like(m), np.empty_like(C), np.empty(K)
+    dlpars = [np.zeros_like(np.asarray(p, float)) for p in lpars]
+    EdPhi = np.zeros_like(Phi)
+    for k in range(K):
+        Sk = np.sqrt(C[:, k])
+        ws = m[:, k] + Sk * e[k]
+        fs = ws @ Phi.T
+        dfs = lik_df(lik, y, fs, *pars)
+        Edws = dfs @ Phi
+        Edm = Edws.sum(axis=0) / L
+        EdC = (Edws * e[k] / Sk).sum(axis=0) / L
+        EdPhi += (dfs.T @ ws / L) / K
+        for i, dp in enumerate(lik_dp(lik, y, fs, *pars)):
+            dlpars[i] = dlpars[i] - dp.sum() / L / K
+        Ell[k] = lik_loglike(lik, y, fs, *pars).sum() / L if calc_ll else np.inf
+        Nkl_zk = np.exp(logNkl[:, k] - logzk[k])
+        Nkl_zl = np.exp(logNkl[:, k] - logzk)
+        alpha = Nkl_zk + Nkl_zl
+        mkmj = m[:, k][:, None] - m
+        iCkCj = 1. / (C[:, k][:, None] + C)
+        dm[:, k] = (B * Edm - m[:, k] / Ld + (iCkCj * mkmj) @ alpha) / K
+        dC[:, k] = (B * EdC - 1. / Ld + (iCkCj - (mkmj * iCkCj) ** 2) @ alpha) / (2 * K)
+    sl = slices if isinstance(slices, (list, tuple)) else [slices]
+    dL = [-0.5 * (((m[s] ** 2 + C[s]) * iL[s] ** 2).sum() / K - iL[s].sum()) for s in sl]
+    dbpars = [-(EdPhi * dP).sum() for dP in dPhis]
+    elbo = -np.inf
+    if calc_ll:
+        elbo = (Ell.sum() * B - 0.5 * D * K * np.log(2 * np.pi) - 0.5 * K * np.log(Ld).sum()
+                - 0.5 * ((m ** 2 + C) * iL).sum() - logzk.sum() + np.log(K)) / K
+    return -elbo, [-dm, -dC, dL, dlpars, dbpars]
+
+
+def sgd_update(name, state, x, grad, **hp):
+    """One step of the updaters of optimize/sgd.py:14-223; `state` is a dict carried between calls."""
+    if name == "sgd":
+        return x - hp.get("eta", 0.1) * grad
+    if name == "adadelta":
+        rho, eps = hp.get("rho", 0.1), hp.get("epsilon", 1e-5)
+        state["Eg2"] = rho * state.get("Eg2", 0) + (1 - rho) * grad ** 2
+        dx = -grad * np.sqrt(state.get("Edx2", 0) + eps) / np.sqrt(state["Eg2"] + eps)
+        state["Edx2"] = rho * state.get("Edx2", 0) + (1 - rho) * dx ** 2
+        return x + dx
+    if name == "adagrad":
+        eta, eps = hp.get("eta", 1), hp.get("epsilon", 1e-6)
+        state["g2"] = state.get("g2", 0) + grad ** 2
+        return x - eta * grad / (eps + np.sqrt(state["g2"]))
+    if name == "momentum":
+        rho, eta = hp.get("rho", 0.5), hp.get("eta", 0.01)
+        state["dx"] = rho * state.get("dx", 0) - eta * grad
+        return x + state["dx"]
+    if name == "adam":
+        a, b1, b2, eps = hp.get("alpha", 0.01), hp.get("beta1", 0.9), hp.get("beta2", 0.99), hp.get("epsilon", 1e-8)
+        state["t"] = state.get("t", 0) + 1
+        state["m"] = b1 * state.get("m", 0) + (1 - b1) * grad
+        state["v"] = b2 * state.get("v", 0) + (1 - b2) * grad ** 2
+        mbar = state["m"] / (1 - b1 ** state["t"])
+        vbar = state["v"] / (1 - b2 ** state["t"])
+        return x - a * mbar / (np.sqrt(vbar) + eps)
+    raise ValueError(name)

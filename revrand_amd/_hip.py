@@ -91,6 +91,13 @@ SIGNATURES = {
                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_pass2_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_predict_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_glm_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_glm_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat_project": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "rr_rff_grad_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
@@ -460,6 +467,37 @@ class FeatureMatrix(object):
         _check(self.lib, self.lib.rr_featmat_predict_rows(self.h, Ey.ctypes.data_as(ctypes.c_void_p),
                                                           Vf.ctypes.data_as(ctypes.c_void_p)))
         return Ey, Vf
+
+    def glm_step(self, dy, drowarg, lik, lik_param, WS, K, L):
+        """(Edws (K*L, F), llsum (K,), aux (K,)) of one SVI minibatch step (rr_featmat_glm_step)."""
+        WS = np.ascontiguousarray(WS, dtype=np.float64)
+        if WS.shape != (K * L, self.F):
+            raise ValueError("weight samples must have shape (K*L, F)")
+        Edws, ll, aux = np.empty((K * L, self.F)), np.empty(K), np.empty(K)
+        _check(self.lib, self.lib.rr_featmat_glm_step(self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik),
+                                                      float(lik_param), WS.ctypes.data_as(ctypes.c_void_p), K, L,
+                                                      Edws.ctypes.data_as(ctypes.c_void_p),
+                                                      ll.ctypes.data_as(ctypes.c_void_p),
+                                                      aux.ctypes.data_as(ctypes.c_void_p)))
+        return Edws, ll, aux
+
+    def glm_rff(self, handle, dX, col0, dT):
+        _check(self.lib, self.lib.rr_featmat_glm_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))
+
+    def glm_edphi(self, rows, col0, ncols):
+        E = np.empty((rows, ncols))
+        _check(self.lib, self.lib.rr_featmat_glm_edphi(self.h, col0, ncols, E.ctypes.data_as(ctypes.c_void_p)))
+        return E
+
+    def project(self, rows, W):
+        """(rows, S) = P W for a host (F, S) matrix (rr_featmat_project)."""
+        W = np.ascontiguousarray(W, dtype=np.float64)
+        if W.ndim != 2 or W.shape[0] != self.F:
+            raise ValueError("W must have shape (F, S)")
+        out = np.empty((rows, W.shape[1]))
+        _check(self.lib, self.lib.rr_featmat_project(self.h, W.ctypes.data_as(ctypes.c_void_p), W.shape[1],
+                                                     out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     def gram_into(self, dy, dG, db=None, dyty=None):
         _check(self.lib, self.lib.rr_featmat_gram(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0,

@@ -343,6 +343,110 @@ class _ResidentRFF(object):
         self.dT.free()
 
 
+class _ResidentGeneric(object):
+    """Any other basis: its block is transformed by its own (GPU or host) ``transform`` and uploaded; its
+    gradient contraction is formed on the host from the downloaded EdPhi block."""
+
+    def __init__(self, basis):
+        self.basis = basis
+        self.nparams = count_args(basis.transform) - 1
+
+    def put(self, fm, X, r0, rows, col0, params):
+        self.mine = list(params)
+        fm.put_host(self.basis.transform(X[r0:r0 + rows], *params), col0)
+
+    def release(self):
+        pass
+
+
+class MinibatchFeatures(object):
+    """Phi of one minibatch (or of query rows) assembled in a device feature matrix for the generalised linear
+    model: ``glm_step`` (fs, likelihood derivatives, Edws, EdPhi on the device), ``glm_basis_grads``
+    (``apply_grad(lambda dPhi: -(EdPhi * dPhi).sum(), basis.grad(X, *hypers))`` without dPhi for the random
+    Fourier family) and ``project`` (latent function samples Phi w)."""
+
+    def __init__(self, basis):
+        self.basis = basis
+        self.is_cat = isinstance(basis, BasisCat)
+        self.bases = basis.bases if self.is_cat else [basis]
+        self.fm, self.children, self.dev = None, [], None
+
+    def _ensure(self, rows, F):
+        if self.fm is None or self.fm.max_rows < rows or self.fm.F != F:
+            self.fm = None  # free the old one first
+            self.fm = _hip.FeatureMatrix(rows, F)
+            self.dev = self.fm.dev
+
+    def _drop_children(self):
+        for c, _, _ in self.children:
+            c.release()
+        self.children = []
+
+    def assemble(self, X, hypers):
+        self._drop_children()
+        M = X.shape[0]
+        dims = [int(b.get_dim(X)) for b in self.bases]
+        self._ensure(M, int(sum(dims)))
+        self.fm.begin(M)
+        args, col0 = list(hypers), 0
+        for b, w in zip(self.bases, dims):
+            child = b._resident_child(X)
+            if child is None:
+                child = _ResidentGeneric(b)
+            mine, args = args[:child.nparams], args[child.nparams:]
+            child.put(self.fm, X, 0, M, col0, mine)
+            self.children.append((child, col0, w))
+            col0 += w
+        self.M = M
+
+    def glm_step(self, y, rowarg, lik, lik_param, WS, K, L):
+        dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+        dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
+        try:
+            return self.fm.glm_step(dy, dn, lik, lik_param, WS, K, L)
+        finally:
+            dy.free()
+            if dn is not None:
+                dn.free()
+
+    def glm_basis_grads(self, X):
+        grads = []
+        for child, col0, w in self.children:
+            if isinstance(child, _ResidentRFF):
+                child.reset()
+                self.fm.glm_rff(child.h, _hip.DeviceView(child.dX, 0, self.M), col0, child.dT)
+                g = [child.dhyp(1.0)]   # -(E o dPhi_i).sum() = +(1/l_i^2) W[i,:].T[i,:]
+            elif child.nparams:
+                E = self.fm.glm_edphi(self.M, col0, w)
+                g = apply_grad(lambda dPhi: -(E * dPhi).sum(), child.basis.grad(X, *child.mine))
+                if not self.is_cat:
+                    return g
+                g = atleast_list(g)
+            else:
+                g = []
+            grads.extend(g)
+        if not self.is_cat:
+            return grads[0] if grads else []
+        return grads if len(grads) != 1 else grads[0]
+
+    def project(self, X, hypers, W):
+        """Phi(X) W, (N, S), in row chunks."""
+        N = X.shape[0]
+        F = int(sum(int(b.get_dim(X)) for b in self.bases))
+        Fp = (F + 255) // 256 * 256
+        chunk = int(max(256, min(N, (8 << 30) // (8 * Fp))))
+        out = np.empty((N, W.shape[1]))
+        for r0 in range(0, N, chunk):
+            Xc = X[r0:r0 + chunk]
+            self.assemble(Xc, hypers)
+            out[r0:r0 + chunk] = self.fm.project(Xc.shape[0], W)
+        return out
+
+    def release(self):
+        self._drop_children()
+        self.fm = None
+
+
 class CatFitState(object):
     """DeviceFitState for a BasisCat: every child keeps its columns of X on the GPU, Phi is assembled in a
     device feature matrix per row chunk; same ``gram`` / ``second_pass`` / ``release`` interface, ``dhyp``

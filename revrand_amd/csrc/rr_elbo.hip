@@ -481,17 +481,115 @@ rr_rowvec_kernel(const float *__restrict__ P, const float *__restrict__ mvec, in
     if (lane == 0) dot[r] = acc;
 }
 
+// ---------------------------------------------------------------------------------------------
+// GLM SVI step (glm.py:296-322) on a device feature matrix.  FSt[r][kl] = Phi_r . ws_kl for all K*L weight
+// samples; this kernel turns it IN PLACE into dfs = d loglike / d f and reduces, per mixture component
+// k = kl / L,  sum(loglike) (without its f-independent constant) and the likelihood's auxiliary sum
+// (Gaussian: sum (y - f)^2).  One weight sample per thread (coalesced along kl), rows looped; rows >= M and
+// samples >= K*L are written as zero so the following GEMMs can run over the padded shapes.
+// likelihoods.py: Bernoulli :46-104, Binomial :171-233, Gaussian :298-396, Poisson :456-521.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float rr_softplus(float f) { return fmaxf(f, 0.f) + log1pf(__expf(-fabsf(f))); }
+__device__ __forceinline__ float rr_expit(float f) {
+    const float t = __expf(-fabsf(f));
+    return f >= 0.f ? 1.f / (1.f + t) : t / (1.f + t);
+}
+
+template <int LIK, typename TY>
+__global__ void __launch_bounds__(256)
+rr_glm_lik_kernel(float *__restrict__ FSt, int64_t M, int64_t rows256, int64_t ld, const TY *__restrict__ y,
+                  const TY *__restrict__ rowarg, float par, int KL, int L, double *__restrict__ llsum,
+                  double *__restrict__ aux, int rows_per_block) {
+    const int kl = blockIdx.x * 256 + threadIdx.x;
+    const bool kvalid = kl < KL;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows256) r1 = rows256;
+    float ll = 0.f, ax = 0.f;
+    const float ipar = LIK == RR_LIK_GAUSSIAN ? 1.f / par : 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+        float df = 0.f;
+        if (kvalid && r < M) {
+            const float f = FSt[r * ld + kl];
+            const float yr = (float)y[r];
+            if (LIK == RR_LIK_BERNOULLI) {
+                df = yr - rr_expit(f);
+                ll += yr * f - rr_softplus(f);
+            } else if (LIK == RR_LIK_BINOMIAL) {
+                const float n = (float)rowarg[r];
+                df = yr - n * rr_expit(f);
+                ll += yr * f - n * rr_softplus(f);
+            } else if (LIK == RR_LIK_GAUSSIAN) {
+                const float e = yr - f;
+                df = e * ipar;
+                ax = fmaf(e, e, ax);
+            } else if (LIK == RR_LIK_POISSON_EXP) {
+                const float g = __expf(f);
+                df = yr - g;
+                ll += yr * f - g;
+            } else {  // Poisson, softplus link
+                const float g = fmaxf(rr_softplus(f), 1e-37f);
+                df = rr_expit(f) * (yr / g - 1.f);
+                ll += yr * __logf(g) - g;
+            }
+        }
+        FSt[r * ld + kl] = df;
+    }
+    if (kvalid) {
+        if (LIK == RR_LIK_GAUSSIAN) {
+            unsafeAtomicAdd(&aux[kl / L], (double)ax);
+            unsafeAtomicAdd(&llsum[kl / L], -0.5 * (double)ax * (double)ipar);
+        } else {
+            unsafeAtomicAdd(&llsum[kl / L], (double)ll);
+        }
+    }
+}
+
+// T[i][f] += sum_r x[r][i] * (E[r][n+f] P[r][f] - E[r][f] P[r][n+f]):  sum(E o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]
+template <int DMAX, typename TX>
+__global__ void __launch_bounds__(256)
+rr_glm_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ P,
+                     const float *__restrict__ E, int64_t ldp, int n, int d, double *__restrict__ T,
+                     int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    const int fc = fvalid ? f : 0;
+    float t[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) t[i] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float a = E[r * ldp + n + fc] * P[r * ldp + fc] - E[r * ldp + fc] * P[r * ldp + n + fc];
+        const TX *xr = X + r * ldx;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) t[i] = fmaf((float)xr[i], a, t[i]);
+    }
+    if (fvalid) {
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+    }
+}
+
 struct FmPass2 {
     float *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
     double *sq = nullptr, *vf = nullptr;
     std::vector<float> hC, hm;
     bool have_rows = false;
+    // GLM step / projection: FSt (max_rows, klp), its transpose DFS (klp, max_rows), the sample matrices
+    float *FSt = nullptr, *DFS = nullptr, *WSt = nullptr, *WSs = nullptr, *Ed = nullptr;
+    double *kacc = nullptr;  // [llsum (K) | aux (K)]
+    int64_t klp = 0;
+    int kcap = 0;
+    bool have_edphi = false;
 };
 
 void rr_fm_pass2_free(void *p) {
     if (!p) return;
     FmPass2 *s = (FmPass2 *)p;
-    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf};
+    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->kacc};
     for (void *x : q)
         if (x) (void)hipFree(x);
     delete s;
@@ -509,6 +607,71 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
     g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = fm->max_rows; g.ldb = fm->ld; g.ldd = fm->ld;
     g.K = (int)fm->ld; g.ntb = (int)(fm->ld / 256);
     hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+static int fm_pass2_scratch(rr_featmat *fm) {
+    const int64_t Fp = fm->ld;
+    if (!fm->pass2) {
+        FmPass2 *s = new FmPass2();
+        fm->pass2 = s;
+        hipError_t ea = hipMalloc((void **)&s->Pt, (size_t)Fp * fm->max_rows * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->U, (size_t)fm->max_rows * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->C32, (size_t)Fp * Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->m32, (size_t)Fp * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->dot, (size_t)fm->max_rows * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->err, (size_t)fm->max_rows * 4);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->sq, 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s->vf, (size_t)fm->max_rows * 8);
+        if (ea != hipSuccess) {
+            (void)hipGetLastError();
+            rr_fm_pass2_free(s);
+            fm->pass2 = nullptr;
+            rr_set_error("featmat second pass: device allocation failed");
+            return RR_ERR_OOM;
+        }
+    }
+    return RR_OK;
+}
+
+// scratch of the GLM step / projection for klp (multiple of 256) sample columns and K components
+static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
+    int rc = fm_pass2_scratch(fm);
+    if (rc != RR_OK) return rc;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    if (s.klp >= klp && s.kcap >= K) return RR_OK;
+    RR_CHECK_HIP(hipStreamSynchronize(fm->ctx->stream));
+    if (klp < s.klp) klp = s.klp;  // grow-only in both dimensions
+    if (K < s.kcap) K = s.kcap;
+    void *q[] = {s.FSt, s.DFS, s.WSt, s.WSs, s.Ed, s.kacc};
+    for (void *x : q)
+        if (x) (void)hipFree(x);
+    s.FSt = s.DFS = s.WSt = s.WSs = s.Ed = nullptr;
+    s.kacc = nullptr;
+    s.klp = 0;
+    s.kcap = 0;
+    hipError_t ea = hipMalloc((void **)&s.FSt, (size_t)fm->max_rows * klp * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.DFS, (size_t)klp * fm->max_rows * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.WSt, (size_t)fm->ld * klp * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.WSs, (size_t)klp * fm->ld * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.Ed, (size_t)klp * fm->ld * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.kacc, (size_t)2 * (K > 1 ? K : 1) * 8);
+    if (ea != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("featmat GLM step: device allocation failed");
+        return RR_ERR_OOM;
+    }
+    s.klp = klp;
+    s.kcap = K;
+    return RR_OK;
+}
+
+static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd, int64_t Kd,
+                   int64_t Md, int64_t Nd) {
+    GemmArgs g;
+    g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)Kd; g.ntb = (int)(Nd / 256);
+    hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((Md / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -536,6 +699,26 @@ static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ld
 #undef RR_GC
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
+}
+
+template <typename TY>
+static void glm_launch_lik(rr_ctx *c, int lik, float *FSt, int64_t M, int64_t rows256, int64_t klp, const void *dy,
+                           const void *drow, float par, int KL, int L, double *llsum, double *aux) {
+    int64_t rpb = (rows256 * (klp / 256) + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+    if (rpb < 16) rpb = 16;
+    if ((rows256 + rpb - 1) / rpb > 65535) rpb = (rows256 + 65534) / 65535;
+    const dim3 grid((unsigned)(klp / 256), (unsigned)((rows256 + rpb - 1) / rpb));
+#define RR_LK(ID)                                                                                                   \
+    hipLaunchKernelGGL((rr_glm_lik_kernel<ID, TY>), grid, dim3(256), 0, c->stream, FSt, M, rows256, klp, (const TY *)dy, \
+                       (const TY *)drow, par, KL, L, llsum, aux, (int)rpb)
+    switch (lik) {
+        case RR_LIK_BERNOULLI: RR_LK(RR_LIK_BERNOULLI); break;
+        case RR_LIK_BINOMIAL: RR_LK(RR_LIK_BINOMIAL); break;
+        case RR_LIK_GAUSSIAN: RR_LK(RR_LIK_GAUSSIAN); break;
+        case RR_LIK_POISSON_EXP: RR_LK(RR_LIK_POISSON_EXP); break;
+        default: RR_LK(RR_LIK_POISSON_SOFTPLUS); break;
+    }
+#undef RR_LK
 }
 
 extern "C" {
@@ -629,24 +812,9 @@ int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) {
     RR_CHECK_HIP(hipSetDevice(c->device));
     const int F = fm->F;
     const int64_t Fp = fm->ld;
-    if (!fm->pass2) {
-        FmPass2 *s = new FmPass2();
-        fm->pass2 = s;
-        hipError_t ea = hipMalloc((void **)&s->Pt, (size_t)Fp * fm->max_rows * 4);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->U, (size_t)fm->max_rows * Fp * 4);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->C32, (size_t)Fp * Fp * 4);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->m32, (size_t)Fp * 4);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->dot, (size_t)fm->max_rows * 4);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->err, (size_t)fm->max_rows * 4);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->sq, 8);
-        if (ea == hipSuccess) ea = hipMalloc((void **)&s->vf, (size_t)fm->max_rows * 8);
-        if (ea != hipSuccess) {
-            (void)hipGetLastError();
-            rr_fm_pass2_free(s);
-            fm->pass2 = nullptr;
-            rr_set_error("rr_featmat_pass2_begin: device allocation failed");
-            return RR_ERR_OOM;
-        }
+    {
+        int rc0 = fm_pass2_scratch(fm);
+        if (rc0 != RR_OK) return rc0;
     }
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     s.hm.assign((size_t)Fp, 0.f);
@@ -727,6 +895,155 @@ int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
     RR_CHECK_HIP(hipMemcpyAsync(dot.data(), s.dot, (size_t)fm->rows * 4, hipMemcpyDeviceToHost, c->stream));
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     for (int64_t i = 0; i < fm->rows; ++i) Ey[i] = (double)dot[i];
+    return RR_OK;
+}
+
+int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                        const double *WS, int K, int L, double *Edws, double *llsum, double *aux) {
+    RR_REQUIRE(fm != nullptr && dy != nullptr && WS != nullptr && Edws != nullptr && llsum != nullptr && aux != nullptr,
+               "rr_featmat_glm_step: null argument");
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_featmat_glm_step: bad dtype");
+    RR_REQUIRE(lik >= RR_LIK_BERNOULLI && lik <= RR_LIK_POISSON_SOFTPLUS, "rr_featmat_glm_step: unknown likelihood %d", lik);
+    RR_REQUIRE(lik != RR_LIK_BINOMIAL || drowarg != nullptr, "rr_featmat_glm_step: the binomial needs its per-row n");
+    RR_REQUIRE(lik != RR_LIK_GAUSSIAN || lik_param > 0.0, "rr_featmat_glm_step: the Gaussian variance must be > 0");
+    RR_REQUIRE(K >= 1 && L >= 1 && (int64_t)K * L < (1 << 24), "rr_featmat_glm_step: bad K, L");
+    RR_REQUIRE(fm->rows >= 1, "rr_featmat_glm_step: the feature matrix is empty");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int KL = K * L, F = fm->F;
+    const int64_t klp = ((int64_t)KL + 255) / 256 * 256, Fp = fm->ld;
+    const int64_t rows256 = (fm->rows + 255) / 256 * 256;
+    int rc = fm_glm_scratch(fm, klp, K);
+    if (rc != RR_OK) return rc;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    const int64_t kl_ld = s.klp;
+    // weight samples: WSt (Fp, kl_ld) for fs, WSs (kl_ld, Fp) / (K L) for EdPhi
+    std::vector<float> wt((size_t)Fp * kl_ld, 0.f), wsn((size_t)kl_ld * Fp, 0.f);
+    const float inv = (float)(1.0 / ((double)K * (double)L));
+    for (int i = 0; i < KL; ++i) {
+        const double *src = WS + (size_t)i * F;
+        float *dn = wsn.data() + (size_t)i * Fp;
+        for (int j = 0; j < F; ++j) {
+            const float v = (float)src[j];
+            wt[(size_t)j * kl_ld + i] = v;
+            dn[j] = v * inv;
+        }
+    }
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(s.WSt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(s.WSs, wsn.data(), wsn.size() * 4, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
+    // Pt = P^T;  FSt (rows256, kl) = P WS^T
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                       fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+    rc = fm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+    if (rc != RR_OK) return rc;
+    // dfs in place + per-component reductions
+    if (dtype == RR_F32)
+        glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+    else
+        glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+    RR_CHECK_HIP(hipGetLastError());
+    // Edws (kl, Fp) = dfs Phi
+    rc = fm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
+    if (rc != RR_OK) return rc;
+    // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                       s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
+    rc = fm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
+    if (rc != RR_OK) return rc;
+    s.have_edphi = true;
+    std::vector<float> ed((size_t)KL * Fp);
+    std::vector<double> acc((size_t)2 * s.kcap);
+    RR_CHECK_HIP(hipMemcpyAsync(ed.data(), s.Ed, ed.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(acc.data(), s.kacc, acc.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < KL; ++i)
+        for (int j = 0; j < F; ++j) Edws[(size_t)i * F + j] = (double)ed[(size_t)i * Fp + j];
+    for (int k = 0; k < K; ++k) {
+        llsum[k] = acc[k];
+        aux[k] = acc[s.kcap + k];
+    }
+    return RR_OK;
+}
+
+int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr && ((FmPass2 *)fm->pass2)->have_edphi,
+               "rr_featmat_glm_rff: call rr_featmat_glm_step first");
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr && dX != nullptr, "rr_featmat_glm_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_glm_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_glm_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad, "rr_featmat_glm_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    const int64_t N = fm->rows;
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = (N * fblocks + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+    if (rpb < 64) rpb = 64;
+    if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+#define RR_GG(DM, TX)                                                                                                   \
+    hipLaunchKernelGGL((rr_glm_grad_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, fm->P + col0, \
+                       s.U + col0, fm->ld, b->n, b->d, dT, (int)rpb)
+#define RR_GGD(DM)                          \
+    if (x_dtype == RR_F32) RR_GG(DM, float); \
+    else RR_GG(DM, double)
+    switch (b->dpad) {
+        case 8: RR_GGD(8); break;
+        case 16: RR_GGD(16); break;
+        case 32: RR_GGD(32); break;
+        case 64: RR_GGD(64); break;
+        case 128: RR_GGD(128); break;
+        default: rr_set_error("rr_featmat_glm_rff: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_GGD
+#undef RR_GG
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr && ((FmPass2 *)fm->pass2)->have_edphi,
+               "rr_featmat_glm_edphi: call rr_featmat_glm_step first");
+    RR_REQUIRE(E != nullptr && col0 >= 0 && ncols >= 1 && col0 + ncols <= fm->F, "rr_featmat_glm_edphi: columns out of range");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    std::vector<float> h((size_t)fm->rows * ncols);
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy2D(h.data(), (size_t)ncols * 4, s.U + col0, (size_t)fm->ld * 4, (size_t)ncols * 4, (size_t)fm->rows,
+                             hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) E[i] = (double)h[i];
+    return RR_OK;
+}
+
+int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
+    RR_REQUIRE(fm != nullptr && W != nullptr && out != nullptr && S >= 1 && S < (1 << 24), "rr_featmat_project: bad argument");
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int F = fm->F;
+    const int64_t sp = ((int64_t)S + 255) / 256 * 256, Fp = fm->ld;
+    const int64_t rows256 = (fm->rows + 255) / 256 * 256;
+    int rc = fm_glm_scratch(fm, sp, 1);
+    if (rc != RR_OK) return rc;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    const int64_t ldw = s.klp;
+    std::vector<float> w((size_t)Fp * ldw, 0.f);
+    for (int j = 0; j < F; ++j)
+        for (int i = 0; i < S; ++i) w[(size_t)j * ldw + i] = (float)W[(size_t)j * S + i];
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(s.WSt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                       fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+    rc = fm_gemm(c, s.Pt, fm->max_rows, s.WSt, ldw, s.FSt, ldw, Fp, rows256, ldw);
+    if (rc != RR_OK) return rc;
+    s.have_edphi = false;
+    std::vector<float> h((size_t)fm->rows * S);
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy2D(h.data(), (size_t)S * 4, s.FSt, (size_t)ldw * 4, (size_t)S * 4, (size_t)fm->rows, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < h.size(); ++i) out[i] = (double)h[i];
     return RR_OK;
 }
 

@@ -99,7 +99,9 @@ int rr_featmat_begin(rr_featmat *fm, int64_t rows) {
     fm->rows = rows;
     fm->rows_pad = (rows + 31) / 32 * 32;
     // every column block is overwritten by a put_* call; zero everything once so pad rows/columns are zero
-    RR_CHECK_HIP(hipMemsetAsync(fm->P, 0, (size_t)fm->rows_pad * fm->ld * sizeof(float), fm->ctx->stream));
+    // (up to the next multiple of 256 rows: the second pass' and the GLM step's GEMMs read whole 256-row tiles)
+    const int64_t rows256 = (rows + 255) / 256 * 256;
+    RR_CHECK_HIP(hipMemsetAsync(fm->P, 0, (size_t)rows256 * fm->ld * sizeof(float), fm->ctx->stream));
     return RR_OK;
 }
 

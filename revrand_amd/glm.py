@@ -1,0 +1,288 @@
+"""
+The Bayesian generalised linear model with revrand's interface (reference: revrand/glm.py): a mixture of K
+diagonal Gaussians over the weights, auto-encoding variational Bayes with stochastic gradients.
+
+Same constructor, ``fit / predict / predict_moments / predict_logpdf / predict_cdf / predict_interval`` and
+fitted attributes (``weights_, covariance_, regularizer_, like_hypers_, basis_hypers_``) as
+``revrand.glm.GeneralizedLinearModel``.  Every O(M F L K) product of one SVI step (glm.py:205-322) runs on the
+MI355X with Phi of the minibatch assembled in HBM and never returned to the host:
+
+* ``Phi = basis.transform(X)``                           -> feature kernels into a device feature matrix  glm.py:215
+* ``fs = ws.dot(Phi.T)`` for all K*L weight samples at once -> MFMA GEMM                                  glm.py:304
+* ``likelihood.df / dp / loglike``                        -> one element-wise kernel with the reductions  glm.py:305,314,321
+* ``Edws = dfs.dot(Phi)``, ``EdPhi = dfs.T.dot(ws)``      -> MFMA GEMMs                                   glm.py:308,311
+* ``-(EdPhi * dPhi).sum()`` over ``basis.grad``           -> contraction kernel, no (M, F, d) tensor      glm.py:274-275
+
+The O(F K^2) mixture-entropy terms and the optimiser stay on the host, as in the reference.  The standard-normal
+draws come from the host ``random_`` in the reference's order (``randn(nsamples, D)`` per component), so a seeded
+run consumes the same random stream as the reference.
+"""
+import logging
+from itertools import chain
+from multiprocessing import Pool
+
+import numpy as np
+from scipy.optimize import brentq
+from scipy.stats.distributions import gamma, norm
+from sklearn.base import BaseEstimator, RegressorMixin
+from sklearn.utils import check_random_state
+from sklearn.utils.validation import check_array, check_is_fitted, check_X_y
+
+from .basis_functions import LinearBasis, MinibatchFeatures
+from .btypes import Bound, Parameter, Positive
+from .likelihoods import Gaussian
+from .optimize import logtrick_sgd, sgd, structured_sgd
+from .utils import atleast_list, issequence
+
+log = logging.getLogger(__name__)
+
+WGTRND = norm()                  # sampling distribution over mixture weights        glm.py:40
+COVRND = gamma(a=2, scale=0.5)   # sampling distribution over mixture covariances    glm.py:41
+LOGITER = 500                    # SGD iterations between ELBO log lines             glm.py:42
+
+
+class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
+    """Bayesian GLM; parameters as the reference (glm.py:45-139): ``likelihood, basis, K, maxiter, batch_size,
+    updater, nsamples, nstarts, random_state``."""
+
+    def __init__(self, likelihood=Gaussian(), basis=LinearBasis(), K=10, maxiter=3000, batch_size=10, updater=None,
+                 nsamples=50, nstarts=500, random_state=None):
+        self.likelihood = likelihood
+        self.basis = basis
+        self.K = K
+        self.maxiter = maxiter
+        self.batch_size = batch_size
+        self.updater = updater
+        self.nsamples = nsamples
+        self.nstarts = nstarts
+        self.random_state = random_state
+        self.random_ = check_random_state(self.random_state)
+
+    def fit(self, X, y, likelihood_args=()):
+        """Learn the posterior mixture and the hyper-parameters (glm.py:141-203)."""
+        X, y = check_X_y(X, y)
+        N, _ = X.shape
+        self.B_ = X.shape[0] / self.batch_size
+        self.D_ = self.basis.get_dim(X)
+        likelihood_args = _reshape_likelihood_args(likelihood_args, N)
+        data = (X, y) + likelihood_args
+        params = [Parameter(WGTRND, Bound(), shape=(self.D_, self.K)),
+                  Parameter(COVRND, Positive(), shape=(self.D_, self.K)),
+                  self.basis.regularizer,
+                  self.likelihood.params,
+                  self.basis.params]
+        log.info("Optimising parameters...")
+        self.__it = -self.nstarts
+        nsgd = structured_sgd(logtrick_sgd(sgd))
+        try:
+            res = nsgd(self._elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
+                       batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts)
+        finally:
+            self._release_features()
+        (self.weights_, self.covariance_, self.regularizer_, self.like_hypers_, self.basis_hypers_) = res.x
+        log.info("Finished! reg = {}, likelihood_hypers = {}, basis_hypers = {}, message: {}."
+                 .format(self.regularizer_, self.like_hypers_, self.basis_hypers_, res.message))
+        return self
+
+    # -- device features of one minibatch ------------------------------------------------------
+    def _features(self):
+        f = self.__dict__.get("_mbf")
+        if f is None:
+            f = self.__dict__["_mbf"] = MinibatchFeatures(self.basis)
+        return f
+
+    def _release_features(self):
+        f = self.__dict__.pop("_mbf", None)
+        if f is not None:
+            f.release()
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        state.pop("_mbf", None)
+        return state
+
+    def _elbo(self, m, C, reg, lpars, bpars, X, y, *largs):
+        """-ELBO and its gradients on one minibatch (glm.py:205-294)."""
+        D, K = m.shape
+        L_ = self.nsamples
+        lpars_l = atleast_list(lpars)
+
+        # reparameterised weight samples of ALL components: same draws, same order as glm.py:300
+        e = np.stack([self.random_.randn(L_, D) for _ in range(K)])          # K x L x D
+        Sk = np.sqrt(C).T[:, np.newaxis, :]                                   # K x 1 x D
+        ws = m.T[:, np.newaxis, :] + Sk * e                                   # K x L x D
+
+        feats = self._features()
+        feats.assemble(X, atleast_list(bpars))                                # Phi (M x D) in HBM
+        lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
+        Edws, llsum, aux = feats.glm_step(y, rowarg, lid, lpar, ws.reshape(K * L_, D), K, L_)
+        Edws = Edws.reshape(K, L_, D)
+
+        L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
+        iL = 1. / L[:, np.newaxis]
+        logNkl = _qmatrix(m, C)
+        mx = logNkl.max(axis=0)
+        logzk = np.log(np.exp(logNkl - mx).sum(axis=0)) + mx
+
+        dm, dC = np.empty_like(m), np.empty_like(C)
+        dlpars = [np.zeros_like(p) for p in lpars_l]
+        dolog = (self.__it % LOGITER == 0) or (self.__it == self.maxiter - 1)
+        calc_ll = dolog or (self.__it < 0)
+        Ell = llsum / L_ + llconst
+
+        for k in range(K):
+            Edmk = Edws[k].sum(axis=0) / L_
+            EdCk = (Edws[k] * e[k] / Sk[k]).sum(axis=0) / L_
+            Nkl_zk = np.exp(logNkl[:, k] - logzk[k])
+            Nkl_zl = np.exp(logNkl[:, k] - logzk)
+            alpha = Nkl_zk + Nkl_zl
+            mkmj = m[:, k][:, np.newaxis] - m
+            iCkCj = 1. / (C[:, k][:, np.newaxis] + C)
+            dm[:, k] = (self.B_ * Edmk - m[:, k] / L + (iCkCj * mkmj).dot(alpha)) / K
+            dC[:, k] = (self.B_ * EdCk - 1. / L + (iCkCj - (mkmj * iCkCj) ** 2).dot(alpha)) / (2 * K)
+        if len(dlpars) > 0:  # only the Gaussian has a likelihood parameter: dp = ((y-f)^2/var^2 - 1/var)/2
+            ivar = 1. / lpar
+            Edlp = 0.5 * (aux * ivar ** 2 - ivar * len(y) * L_) / L_
+            dlpars[0] = dlpars[0] - Edlp.sum() / K
+
+        def dreg(s):
+            return -0.5 * (((m[s] ** 2 + C[s]) * iL[s] ** 2).sum() / K - iL[s].sum())
+
+        dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
+        dbpars = feats.glm_basis_grads(X)                                     # -(EdPhi o dPhi).sum() per parameter
+
+        ELBO = -np.inf
+        if calc_ll:
+            ELBO = (Ell.sum() * self.B_ - 0.5 * D * K * np.log(2 * np.pi) - 0.5 * K * np.log(L).sum()
+                    - 0.5 * ((m ** 2 + C) * iL).sum() - logzk.sum() + np.log(K)) / K
+        if dolog:
+            log.info("{}Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
+                     .format("Random starts: " if self.__it < 0 else "", self.__it, ELBO, reg, lpars, bpars))
+        self.__it += 1
+        return -ELBO, [-dm, -dC, dL, dlpars, dbpars]
+
+    # -- prediction -----------------------------------------------------------------------------
+    def predict(self, X, nsamples=200, likelihood_args=()):
+        """Expected target values (glm.py:324-349)."""
+        Ey, _ = self.predict_moments(X, nsamples, likelihood_args)
+        return Ey
+
+    def predict_moments(self, X, nsamples=200, likelihood_args=()):
+        """Monte-Carlo predictive mean and variance (glm.py:351-393)."""
+        fs = self._sample_matrix(X, nsamples)                                 # N x nsamples
+        Eyargs = tuple(chain(atleast_list(self.like_hypers_), likelihood_args))
+        ys = np.empty(fs.shape)
+        for i in range(nsamples):
+            ys[:, i] = self.likelihood.Ey(fs[:, i], *Eyargs)
+        Ey = ys.mean(axis=1)
+        Vy = ((ys - Ey[:, np.newaxis]) ** 2).mean(axis=1)
+        return Ey, Vy
+
+    def predict_logpdf(self, X, y, nsamples=200, likelihood_args=()):
+        """Mean / min / max log predictive density over the latent samples (glm.py:395-444)."""
+        X, y = check_X_y(X, y)
+        fs = self._sample_matrix(X, nsamples)
+        llargs = tuple(chain(atleast_list(self.like_hypers_), likelihood_args))
+        ps = np.empty(fs.shape)
+        for i in range(nsamples):
+            ps[:, i] = self.likelihood.loglike(y, fs[:, i], *llargs)
+        return ps.mean(axis=1), ps.min(axis=1), ps.max(axis=1)
+
+    def predict_cdf(self, X, quantile, nsamples=200, likelihood_args=()):
+        """Predictive CDF at `quantile` (glm.py:446-495)."""
+        fs = self._sample_matrix(X, nsamples)
+        cdfarg = tuple(chain(atleast_list(self.like_hypers_), likelihood_args))
+        ps = np.empty(fs.shape)
+        for i in range(nsamples):
+            ps[:, i] = self.likelihood.cdf(quantile, fs[:, i], *cdfarg)
+        return ps.mean(axis=1), ps.min(axis=1), ps.max(axis=1)
+
+    def predict_interval(self, X, percentile, nsamples=200, likelihood_args=(), multiproc=True):
+        """Predictive percentile interval by root finding on the sampled CDF (glm.py:497-570)."""
+        N = X.shape[0]
+        fs = self._sample_matrix(X, nsamples)
+        if len(likelihood_args) > 0:
+            likelihood_args = _reshape_likelihood_args(likelihood_args, N)
+        like_hypers = atleast_list(self.like_hypers_)
+        work = ((f[0], self.likelihood, like_hypers, f[1:], percentile) for f in zip(fs, *likelihood_args))
+        if multiproc:
+            pool = Pool()
+            res = pool.map(_star_rootfinding, work)
+            pool.close()
+            pool.join()
+        else:
+            res = [_rootfinding(*w) for w in work]
+        ql, qu = zip(*res)
+        return np.array(ql), np.array(qu)
+
+    def _sample_matrix(self, X, nsamples):
+        """Latent function samples f = Phi w, (N, nsamples), the product on the device (glm.py:572-620)."""
+        check_is_fitted(self, ['weights_', 'covariance_', 'basis_hypers_', 'like_hypers_', 'regularizer_'])
+        X = check_array(X)
+        D, K = self.weights_.shape
+        k = self.random_.randint(0, K, size=(nsamples,))
+        w = self.weights_[:, k] + self.random_.randn(D, nsamples) * np.sqrt(self.covariance_[:, k])
+        feats = MinibatchFeatures(self.basis)
+        try:
+            return feats.project(X, atleast_list(self.basis_hypers_), w)
+        finally:
+            feats.release()
+
+    def _sample_func(self, X, nsamples, genaxis=1):
+        """Generator over latent function samples, column-wise (genaxis=1) or per observation (genaxis=0)."""
+        if genaxis not in (0, 1):
+            raise ValueError("Invalid axis to generate samples from")
+        fs = self._sample_matrix(X, nsamples)
+        return (f for f in (fs.T if genaxis == 1 else fs))
+
+    def __repr__(self):
+        return "{}(likelihood={}, basis={}, K={}, maxiter={}, batch_size={},updater={}, nsamples={}, nstarts={}, " \
+            "random_state={})".format(type(self).__name__, self.likelihood, self.basis, self.K, self.maxiter,
+                                      self.batch_size, self.updater, self.nsamples, self.nstarts, self.random_state)
+
+
+class GeneralisedLinearModel(GeneralizedLinearModel):
+    """GB/AU spelling (glm.py:640-642)."""
+
+
+def _reshape_likelihood_args(likelihood_args, N):
+    reshape_args = []
+    for l in likelihood_args:
+        if np.isscalar(l):
+            l = l * np.ones(N)
+        if (np.shape(l)[0] != N) and (len(l) != 0):
+            raise ValueError("Likelihood arguments not a compatible shape!")
+        reshape_args.append(l)
+    return tuple(reshape_args)
+
+
+def _star_rootfinding(args):
+    return _rootfinding(*args)
+
+
+def _rootfinding(fn, likelihood, likelihood_hypers, likelihood_args, percentile):
+    """Lower / upper quantile of the sampled predictive CDF at one observation (glm.py:665-695)."""
+    def predCDF(q, fs, percent):
+        return (likelihood.cdf(q, fs, *chain(likelihood_hypers, likelihood_args))).mean() - percent
+
+    lpercent = (1 - percentile) / 2
+    upercent = 1 - lpercent
+    Eyn = likelihood.Ey(fn, *chain(likelihood_hypers, likelihood_args)).mean()
+    lb, ub = -1000 * max(Eyn, 1), 1000 * max(Eyn, 1)
+    try:
+        qln = brentq(predCDF, a=lb, b=ub, args=(fn, lpercent))
+    except ValueError:
+        qln = np.nan
+    try:
+        qun = brentq(predCDF, a=lb, b=ub, args=(fn, upercent))
+    except ValueError:
+        qun = np.nan
+    return qln, qun
+
+
+def _qmatrix(m, C):
+    """logq[j, i] = log N(m_i | m_j, diag(C_i + C_j))  (glm.py:697-712), vectorised."""
+    D = m.shape[0]
+    dc = C[:, :, np.newaxis] + C[:, np.newaxis, :]                  # D x i x j
+    dm2 = (m[:, :, np.newaxis] - m[:, np.newaxis, :]) ** 2
+    return (-0.5 * (D * np.log(2 * np.pi) + np.log(dc).sum(axis=0) + (dm2 / dc).sum(axis=0))).T

@@ -132,3 +132,253 @@ def logtrick_minimizer(minimizer):
         result["x"] = from_log(result["x"])
         return result
     return new_minimizer
+
+
+# --------------------------------------------------------------------------------------
+# Stochastic gradients (reference: optimize/sgd.py, optimize/decorators.py:133-252,329-408)
+# --------------------------------------------------------------------------------------
+
+class SGDUpdater(object):
+    """x - eta * grad (sgd.py:14-68)."""
+
+    def __init__(self, eta=0.1):
+        self.eta = eta
+
+    def __call__(self, x, grad):
+        return x - self.eta * grad
+
+    def reset(self):
+        pass
+
+    def __repr__(self):
+        return "{}(eta={})".format(type(self).__name__, self.eta)
+
+
+class AdaDelta(SGDUpdater):
+    """sgd.py:71-133."""
+
+    def __init__(self, rho=0.1, epsilon=1e-5):
+        if rho < 0 or rho > 1:
+            raise ValueError("Decay rate 'rho' must be between 0 and 1!")
+        if epsilon <= 0:
+            raise ValueError("Constant 'epsilon' must be > 0!")
+        self.rho, self.epsilon = rho, epsilon
+        self.Eg2 = self.Edx2 = 0
+
+    def __call__(self, x, grad):
+        self.Eg2 = self.rho * self.Eg2 + (1 - self.rho) * grad ** 2
+        dx = -grad * np.sqrt(self.Edx2 + self.epsilon) / np.sqrt(self.Eg2 + self.epsilon)
+        self.Edx2 = self.rho * self.Edx2 + (1 - self.rho) * dx ** 2
+        return x + dx
+
+    def reset(self):
+        self.__init__(self.rho, self.epsilon)
+
+    def __repr__(self):
+        return "{}(rho={}, epsilon={})".format(type(self).__name__, self.rho, self.epsilon)
+
+
+class AdaGrad(SGDUpdater):
+    """sgd.py:136-196."""
+
+    def __init__(self, eta=1, epsilon=1e-6):
+        if eta <= 0:
+            raise ValueError("Learning rate 'eta' must be > 0!")
+        if epsilon <= 0:
+            raise ValueError("Constant 'epsilon' must be > 0!")
+        self.eta, self.epsilon = eta, epsilon
+        self.g2_hist = 0
+
+    def __call__(self, x, grad):
+        self.g2_hist = self.g2_hist + grad ** 2
+        return x - self.eta * grad / (self.epsilon + np.sqrt(self.g2_hist))
+
+    def reset(self):
+        self.__init__(self.eta, self.epsilon)
+
+    def __repr__(self):
+        return "{}(eta={}, epsilon={})".format(type(self).__name__, self.eta, self.epsilon)
+
+
+class Momentum(SGDUpdater):
+    """sgd.py:199-256."""
+
+    def __init__(self, rho=0.5, eta=0.01):
+        if eta <= 0:
+            raise ValueError("Learning rate 'eta' must be > 0!")
+        if rho < 0 or rho > 1:
+            raise ValueError("Decay rate 'rho' must be between 0 and 1!")
+        self.eta, self.rho = eta, rho
+        self.dx = 0
+
+    def __call__(self, x, grad):
+        self.dx = self.rho * self.dx - self.eta * grad
+        return x + self.dx
+
+    def reset(self):
+        self.__init__(self.rho, self.eta)
+
+    def __repr__(self):
+        return "{}(rho={}, eta={})".format(type(self).__name__, self.rho, self.eta)
+
+
+class Adam(SGDUpdater):
+    """sgd.py:259-330."""
+
+    def __init__(self, alpha=0.01, beta1=0.9, beta2=0.99, epsilon=1e-8):
+        self.alpha, self.beta1, self.beta2, self.epsilon = alpha, beta1, beta2, epsilon
+        self.t = 0
+        self.m = self.v = None
+
+    def __call__(self, x, grad):
+        self.t += 1
+        if self.m is None:
+            self.m = np.zeros_like(x)
+            self.v = np.zeros_like(x)
+        self.m = self.beta1 * self.m + (1 - self.beta1) * grad
+        self.v = self.beta2 * self.v + (1 - self.beta2) * grad ** 2
+        mbar = self.m / (1 - self.beta1 ** self.t)
+        vbar = self.v / (1 - self.beta2 ** self.t)
+        return x - self.alpha * mbar / (np.sqrt(vbar) + self.epsilon)
+
+    def reset(self):
+        self.__init__(self.alpha, self.beta1, self.beta2, self.epsilon)
+
+    def __repr__(self):
+        return "{}(alpha={}, beta1={}, beta2={}, epsilon={})".format(type(self).__name__, self.alpha, self.beta1,
+                                                                     self.beta2, self.epsilon)
+
+
+def _len_data(data):
+    if not issequence(data):
+        return data.shape[0]
+    N = len(data[0])
+    for d in data[1:]:
+        if d.shape[0] != N:
+            raise ValueError("Not all data is the same length!")
+    return N
+
+
+def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
+    """Minibatches by sweeping random permutations of the rows (sgd.py:428-470)."""
+    from .utils import endless_permutations
+    perms = endless_permutations(_len_data(data), random_state)
+    it = 0
+    while it < maxiter:
+        it += 1
+        ind = np.array([next(perms) for _ in range(batch_size)])
+        yield (data[ind],) if not issequence(data) else [d[ind] for d in data]
+
+
+def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, updater=None, eval_obj=False,
+        random_state=None):
+    """Stochastic gradient descent over minibatches of `data` (sgd.py:337-425): ``fun(x, *batch, *args)`` returns
+    the gradient (or ``(objective, gradient)`` with eval_obj); bounded coordinates have outward gradients
+    truncated and steps clipped."""
+    from scipy.optimize import OptimizeResult
+    if updater is None:
+        updater = Adam()
+    updater.reset()
+    N = _len_data(data)
+    x = np.array(x0, copy=True, dtype=float)
+    batch_size = min(batch_size, N)
+    if bounds is not None:
+        if len(bounds) != x.shape[0]:
+            raise ValueError("The dimension of the bounds does not match x0!")
+        lower = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=float)
+        upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
+    obj, objs, norms = None, [], []
+    for batch in gen_batch(data, batch_size, maxiter, random_state):
+        if not eval_obj:
+            grad = fun(x, *(list(batch) + list(args)))
+        else:
+            obj, grad = fun(x, *(list(batch) + list(args)))
+            objs.append(obj)
+        norms.append(np.linalg.norm(grad))
+        if bounds is not None:
+            xlower = x <= lower
+            grad[xlower] = np.minimum(grad[xlower], 0)
+            xupper = x >= upper
+            grad[xupper] = np.maximum(grad[xupper], 0)
+        x = updater(x, grad)
+        if bounds is not None:
+            x = np.clip(x, lower, upper)
+    return OptimizeResult(x=x, norms=norms, message='maxiter reached', fun=obj, objs=objs)
+
+
+def structured_sgd(sgd):
+    """Let `sgd` take nested Parameter lists (decorators.py:133-252).
+
+    new_sgd(fun, parameters, data, eval_obj=False, batch_size=10, args=(), random_state=None, nstarts=100, **kw):
+    ``fun(*values, *batch, *args)``.  With eval_obj and nstarts > 0 the best of `nstarts` random draws of the
+    Parameters (each scored on its own minibatch) is the starting point.  Unlike the reference -- which drops
+    ``batch_size`` here so its main loop always runs sgd's default of 10 rows (decorators.py:244-246) --
+    ``batch_size`` is forwarded to `sgd`; the two agree at the reference's default batch_size=10.
+    """
+    def new_sgd(fun, parameters, data, eval_obj=False, batch_size=10, args=(), random_state=None, nstarts=100,
+                **sgd_kwargs):
+        shapes = shapes_of(parameters, shape=lambda p: p.shape)
+        nparams = len(shapes)
+        x0 = flatten_values(_map(lambda p: p.value, parameters))
+        bounds = _flat_bounds(parameters)
+        if eval_obj and nstarts > 0:
+            data_gen = gen_batch(data, batch_size, random_state=random_state)
+            if any(flatten_values(_map(lambda p: float(p.is_random), parameters))):
+                log.info("Evaluating random starts...")
+                best_obj, best = np.inf, None
+                for _ in range(nstarts):
+                    batch = next(data_gen)
+                    cand = _map(lambda p: p.rvs(random_state), parameters)
+                    obj = fun(*(list(cand) + list(batch) + list(args)))[0]
+                    if best is None or obj < best_obj:
+                        best_obj, best = obj, cand
+                log.info("Best start found with objective = {}".format(best_obj))
+                x0 = flatten_values(best)
+            else:
+                log.info("No random parameters, not doing any random starts")
+
+        def flat_fun(x, *rest):
+            res = fun(*(unflatten(x, shapes)[:nparams] + list(rest)))
+            if eval_obj:
+                return res[0], flatten_values(res[1])
+            return flatten_values(res)
+
+        result = sgd(flat_fun, x0, data=data, bounds=bounds, args=args, eval_obj=eval_obj, batch_size=batch_size,
+                     random_state=random_state, **sgd_kwargs)
+        result["x"] = tuple(unflatten(result["x"], shapes))
+        return result
+    return new_sgd
+
+
+def logtrick_sgd(sgd):
+    """Optimise log(x) for every variable with a ``Positive`` bound (decorators.py:329-408)."""
+    def new_sgd(fun, x0, data, bounds=None, eval_obj=False, **sgd_kwargs):
+        if bounds is None:
+            return sgd(fun, x0, data, bounds=bounds, eval_obj=eval_obj, **sgd_kwargs)
+        pos = np.array([isinstance(b, Positive) for b in bounds], dtype=bool)
+
+        def from_log(z):
+            x = np.array(z, dtype=float)
+            x[pos] = np.exp(x[pos])
+            return x
+
+        def chain(g, z):
+            g = np.array(g, dtype=float)
+            g[pos] *= np.exp(z[pos])
+            return g
+
+        new_bounds = [Bound(LOGMINPOS, EXPMAX if b.upper is None else np.log(b.upper)) if p else b
+                      for b, p in zip(bounds, pos)]
+        if eval_obj:
+            def new_fun(z, *a, **k):
+                o, g = fun(from_log(z), *a, **k)
+                return o, chain(g, z)
+        else:
+            def new_fun(z, *a, **k):
+                return chain(fun(from_log(z), *a, **k), z)
+        z0 = np.array(x0, dtype=float)
+        z0[pos] = np.log(z0[pos])
+        result = sgd(new_fun, z0, data, bounds=new_bounds, eval_obj=eval_obj, **sgd_kwargs)
+        result["x"] = from_log(result["x"])
+        return result
+    return new_sgd

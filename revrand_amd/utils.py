@@ -61,3 +61,12 @@ def unflatten(x, shapes):
         pos[0] += k
         return v
     return [build(s) for s in shapes]
+
+
+def endless_permutations(N, random_state=None):
+    """Indices from successive permutations of range(N), forever (utils/rand.py:7-31)."""
+    from sklearn.utils import check_random_state
+    generator = check_random_state(random_state)
+    while True:
+        for b in generator.permutation(N):
+            yield b

@@ -1,0 +1,177 @@
+"""GLM SVI step on the MI355X against the reference's golden minibatch `_elbo`, the
+oracle on richer bases, and end-to-end fits in the style of the reference's tests/test_models.py."""
+import numpy as np
+import pytest
+
+import revrand_oracle as orc
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _imports():
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    return bs, lk, Parameter, Positive, GeneralizedLinearModel
+
+
+def smse(y_true, y_pred):
+    return ((y_true - y_pred) ** 2).mean() / y_true.var()
+
+
+def _lik(lk, name):
+    return {"poisson_exp": lambda: lk.Poisson("exp"), "poisson_softplus": lambda: lk.Poisson("softplus"),
+            "gaussian": lk.Gaussian, "bernoulli": lk.Bernoulli, "binomial": lk.Binomial}[name]()
+
+
+CASES = [("iso", n) for n in ("poisson_exp", "poisson_softplus", "gaussian", "bernoulli", "binomial")] \
+    + [("ard", "poisson_exp"), ("ard", "gaussian")]
+
+
+@pytest.mark.parametrize("tag,lik", CASES)
+def test_minibatch_elbo_vs_reference(golden, tag, lik):
+    """Same seed -> same standard-normal draws as the reference -> -ELBO and all five gradient blocks."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    g = golden("glm")
+    X, K, L = g["X"], int(g["K"]), int(g["L"])
+    d = X.shape[1]
+    ls = g[tag + "_ls"]
+    ls = float(ls) if np.ndim(ls) == 0 else ls
+    lsp = Parameter(np.ones(d), Positive()) if tag == "ard" else Parameter(1., Positive())
+    basis = bs.RandomRBF(nbases=32, Xdim=d, random_state=7, lenscale=lsp)
+    assert np.array_equal(basis.W, g["W"])
+    glm = GLM(likelihood=_lik(lk, lik), basis=basis, K=K, nsamples=L, random_state=int(g["seed"]))
+    glm.B_, glm.D_ = float(g["B"]), 64
+    glm._GeneralizedLinearModel__it = -1
+    t = tag + "_" + lik
+    lp = 0.7 if lik == "gaussian" else []
+    largs = (g["nbin"],) if lik == "binomial" else ()
+    nobj, (ndm, ndC, dL, dlp, dbp) = glm._elbo(g["m"].copy(), g["C"].copy(), float(g["reg"]), lp, ls, X, g[t + "_y"], *largs)
+    glm._release_features()
+    assert abs(nobj - g[t + "_obj"]) < 2e-4 * abs(g[t + "_obj"])
+    assert normwise(ndm, g[t + "_ndm"]) < 1e-3 and normwise(ndC, g[t + "_ndC"]) < 1e-3
+    assert abs(dL - g[t + "_dL"]) < 1e-6 * abs(g[t + "_dL"])
+    assert np.shape(dbp) == (() if tag == "iso" else (d,))
+    assert normwise(np.atleast_1d(dbp), g[t + "_dbp"]) < 2e-3
+    if lik == "gaussian":
+        assert normwise(np.atleast_1d(dlp[0]), g[t + "_dlp"]) < 1e-3
+    else:
+        assert dlp == []
+
+
+def test_minibatch_elbo_concat_and_generic_children_vs_oracle():
+    """RandomMatern32 (ARD) + LinearBasis + FastFoodGM (gradient formed on the host from the downloaded EdPhi
+    block) + a second random Fourier basis on a column subset; ragged sizes (M, K*L not multiples of anything)."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(3)
+    M, d, K, L = 333, 5, 4, 7
+    X = rs.randn(M, d)
+    y = rs.poisson(np.exp(0.5 * np.sin(X[:, 0]))).astype(float)
+    cat = bs.RandomMatern32(nbases=40, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True) \
+        + bs.FastFoodGM(nbases=8, Xdim=2, random_state=2, apply_ind=[1, 3]) \
+        + bs.RandomRBF(nbases=30, Xdim=2, random_state=4, apply_ind=[0, 2])
+    ls0, mu, lsg, ls3 = np.linspace(0.8, 1.3, d), np.array([0.3, -0.2]), np.array([1.1, 0.9]), 0.7
+    hyp = [ls0, mu, lsg, ls3]
+    Phi = cat.transform(X, *hyp)
+    dPs = []
+    for gfull in cat.grad(X, *hyp):
+        dPs.extend([gfull[:, :, i] for i in range(gfull.shape[2])] if gfull.ndim == 3 else [gfull])
+    D = Phi.shape[1]
+    m = 0.2 * rs.randn(D, K)
+    C = rs.gamma(2., 0.5, size=(D, K))
+    regs = [1.2, 0.8, 1.5, 0.6]
+    Ld, slices = cat.regularizer_diagonal(X, *regs)
+    e = np.stack([np.random.RandomState(9).randn(K * L, D)[k * L:(k + 1) * L] for k in range(K)])
+    want = orc.glm_elbo(m, C, Ld, slices, "poisson_exp", [], (), Phi, dPs, y, e, 6.0)
+
+    glm = GLM(likelihood=lk.Poisson(), basis=cat, K=K, nsamples=L, random_state=9)
+    glm.B_, glm.D_ = 6.0, D
+    glm._GeneralizedLinearModel__it = -1
+    nobj, (ndm, ndC, dL, dlp, dbp) = glm._elbo(m.copy(), C.copy(), regs, [], hyp, X, y)
+    glm._release_features()
+    assert abs(nobj - want[0]) < 2e-4 * abs(want[0])
+    assert normwise(ndm, want[1][0]) < 1e-3 and normwise(ndC, want[1][1]) < 1e-3
+    assert normwise(np.array(dL), np.array(want[1][2])) < 1e-6
+    assert isinstance(dbp, list) and len(dbp) == 4
+    assert [np.shape(v) for v in dbp] == [(d,), (2,), (2,), ()]
+    flat = np.concatenate([np.atleast_1d(v) for v in dbp])
+    assert normwise(flat, np.array(want[1][4])) < 2e-3
+
+
+def test_project_and_sample_func():
+    bs, lk, Parameter, Positive, GLM = _imports()
+    from revrand_amd.basis_functions import MinibatchFeatures
+    rs = np.random.RandomState(0)
+    X = rs.randn(700, 6)
+    basis = bs.RandomRBF(nbases=50, Xdim=6, random_state=1) + bs.LinearBasis(onescol=True)
+    W = rs.randn(107, 33)
+    f = MinibatchFeatures(basis)
+    out = f.project(X, [0.9], W)
+    f.release()
+    assert normwise(out, basis.transform(X, 0.9) @ W) < 1e-4
+
+
+def test_glm_gaussian_like_reference_test_models():
+    """tests/test_models.py:83-116 of the reference: linear data, LinearBasis then a concatenation; SMSE,
+    cdf, logpdf, interval."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(100)
+    x = np.linspace(-5, 5, 600)
+    yall = 3 + 2 * x + rs.randn(600) * 1e-4
+    Xall = np.column_stack((np.ones(600), x))
+    tr = rs.choice(600, 400, replace=False)
+    ts = np.setdiff1d(np.arange(600), tr)
+    X, y, Xs, ys = Xall[tr], yall[tr], Xall[ts], yall[ts]
+    glm = GLM(lk.Gaussian(), bs.LinearBasis(onescol=True), random_state=1)
+    glm.fit(X, y)
+    assert smse(ys, glm.predict(Xs)) < 0.1
+    basis = bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=20, Xdim=2) + bs.RandomMatern52(nbases=20, Xdim=2)
+    glm = GLM(lk.Gaussian(), basis, random_state=1)
+    glm.fit(X, y)
+    Ey = glm.predict(Xs)
+    assert smse(ys, Ey) < 0.1
+    py, _, _ = glm.predict_cdf(Xs, 1e5)
+    assert np.allclose(py, 1.)
+    lpy, _, _ = glm.predict_logpdf(Xs, Ey)
+    assert np.all(lpy > -100)
+    EyQn, EyQx = glm.predict_interval(Xs[:40], 0.9, multiproc=False)
+    assert all(Ey[:40] <= EyQx) and all(Ey[:40] >= EyQn)
+
+
+def test_glm_binomial_like_reference_test_models():
+    """tests/test_models.py:119-147 of the reference."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(100)
+    x = np.linspace(-50, 50, 600)
+    X = x[:, None]
+    p = 0.5 * (np.sin(x / 5.) + 1)
+    n = 1000
+    y = rs.binomial(n, p).astype(float)
+    basis = bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=20, Xdim=1) + bs.RandomMatern52(nbases=20, Xdim=1)
+    glm = GLM(lk.Binomial(), basis, random_state=1)
+    glm.fit(X, y, likelihood_args=(n,))
+    Ey = glm.predict(X, likelihood_args=(n,))
+    assert smse(p * n, Ey) < 1
+    py, _, _ = glm.predict_cdf(X, 1e5, likelihood_args=(n,))
+    assert np.allclose(py, 1.)
+
+
+def test_glm_poisson_large_minibatch():
+    """Config 5 in miniature: Poisson, RandomRBF ARD, a large minibatch per step; the fit must improve the
+    minibatch objective and recover the rate."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(0)
+    N, d = 20000, 4
+    X = rs.randn(N, d)
+    flat = 0.8 * np.sin(1.5 * X[:, 0]) + 0.4 * X[:, 1]
+    y = rs.poisson(np.exp(flat)).astype(float)
+    basis = bs.RandomRBF(nbases=100, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+    glm = GLM(lk.Poisson(), basis, K=3, nsamples=10, batch_size=4096, maxiter=300, nstarts=4, random_state=2)
+    glm.fit(X, y)
+    Xs = rs.randn(2000, d)
+    rate = np.exp(0.8 * np.sin(1.5 * Xs[:, 0]) + 0.4 * Xs[:, 1])
+    assert smse(rate, glm.predict(Xs)) < 0.2
+    assert glm.weights_.shape == (200, 3) and np.all(glm.covariance_ > 0) and np.shape(glm.basis_hypers_) == (d,)

@@ -161,3 +161,115 @@ def test_fastfood_matrices_match_reference(golden, case):
     assert np.abs(b.S - g[k + "_S"]).max() < 1e-13 * np.abs(b.S).max()
     assert b.n == b.d2 * b.k and b.get_dim(None) == 2 * b.n
     assert "FastFoodRBF(nbases=%d, Xdim=%d" % (nb, d) in repr(b)
+
+
+# -- GLM host side: updaters, SGD front-ends, likelihoods, mixture terms ---------------------------
+
+def test_sgd_updaters_match_reference(golden):
+    from revrand_amd import optimize as opt
+    g = golden("glm")
+    for name, upd in (("sgd", opt.SGDUpdater()), ("adadelta", opt.AdaDelta()), ("adagrad", opt.AdaGrad()),
+                      ("momentum", opt.Momentum()), ("adam", opt.Adam())):
+        for _ in range(2):   # reset() must restore the initial state
+            upd.reset()
+            x = np.linspace(-1, 1, 6)
+            for i, grad in enumerate(g["upd_grads"]):
+                x = upd(x, grad)
+                assert np.allclose(x, g["upd_" + name][i], rtol=1e-12, atol=1e-14), name
+    with pytest.raises(ValueError):
+        opt.AdaDelta(rho=2)
+    with pytest.raises(ValueError):
+        opt.AdaGrad(eta=0)
+    with pytest.raises(ValueError):
+        opt.Momentum(rho=-1)
+
+
+def test_sgd_and_structured_logtrick_sgd_fit_a_line():
+    """Least squares by minibatch SGD, plain and through the structured + log-trick front-ends
+    (mirrors the reference's tests/test_optimize.py use of sgd)."""
+    from revrand_amd import optimize as opt
+    rs = np.random.RandomState(0)
+    N = 400
+    x = np.linspace(-1, 1, N)
+    Xd = np.column_stack((np.ones(N), x))
+    y = Xd @ np.array([0.5, 2.0]) + 0.01 * rs.randn(N)
+
+    def grad(w, Xb, yb):
+        return -2 * Xb.T @ (yb - Xb @ w) / len(yb)
+
+    res = opt.sgd(grad, np.zeros(2), data=(Xd, y), maxiter=2000, batch_size=20, random_state=1,
+                  updater=opt.AdaGrad())
+    assert np.allclose(res.x, [0.5, 2.0], atol=0.05) and res.fun is None and len(res.norms) == 2000
+
+    def obj(w, s, Xb, yb):   # s > 0 scales nothing; its gradient is 0 -> stays put under the log trick
+        r = yb - Xb @ w
+        return (r ** 2).mean(), [-2 * Xb.T @ r / len(yb), 0.0]
+
+    nsgd = opt.structured_sgd(opt.logtrick_sgd(opt.sgd))
+    res = nsgd(obj, [Parameter(norm(), Bound(), shape=(2,)), Parameter(1.5, Positive())], (Xd, y), eval_obj=True,
+               maxiter=2000, batch_size=20, random_state=rs, nstarts=20, updater=opt.AdaGrad())
+    w, s = res.x
+    assert np.allclose(w, [0.5, 2.0], atol=0.05) and abs(s - 1.5) < 1e-12
+    assert len(res.objs) == 2000
+    # bounds are honoured
+    res = opt.sgd(grad, np.zeros(2), data=(Xd, y), maxiter=500, batch_size=20, random_state=1,
+                  bounds=[Bound(None, 0.2), Bound(0, None)], updater=opt.AdaGrad())
+    assert res.x[0] <= 0.2 + 1e-12
+    with pytest.raises(ValueError):
+        opt.sgd(grad, np.zeros(2), data=(Xd, y), bounds=[Bound()])
+
+
+def test_gen_batch_sweeps_permutations():
+    from revrand_amd.optimize import gen_batch
+    data = np.arange(10)
+    seen = np.concatenate([b[0] for b in gen_batch(data, 5, maxiter=2, random_state=0)])
+    assert sorted(seen) == list(range(10))
+    b = next(gen_batch((data, data * 2), 3, random_state=0))
+    assert np.array_equal(b[1], 2 * b[0])
+
+
+def test_likelihoods_match_oracle_formulas():
+    import revrand_oracle as orc
+    from revrand_amd import likelihoods as lk
+    rs = np.random.RandomState(0)
+    f = 2 * rs.randn(3, 50)
+    n = rs.randint(1, 9, 50).astype(float)
+    cases = [("bernoulli", lk.Bernoulli(), (rs.rand(50) < 0.5).astype(float), ()),
+             ("binomial", lk.Binomial(), np.minimum(rs.poisson(2, 50), n).astype(float), (n,)),
+             ("gaussian", lk.Gaussian(), rs.randn(50), (0.7,)),
+             ("poisson_exp", lk.Poisson("exp"), rs.poisson(2, 50).astype(float), ()),
+             ("poisson_softplus", lk.Poisson("softplus"), rs.poisson(2, 50).astype(float), ())]
+    for name, L, y, args in cases:
+        assert np.allclose(L.loglike(y, f, *args), orc.lik_loglike(name, y, f, *args), rtol=1e-10, atol=1e-12), name
+        assert np.allclose(L.df(y, f, *args), orc.lik_df(name, y, f, *args), rtol=1e-10, atol=1e-12), name
+        dp = L.dp(y, f, *args)
+        if name == "gaussian":
+            assert np.allclose(dp, orc.lik_dp(name, y, f, *args)[0])
+        else:
+            assert dp == []
+        lid, par, rowarg, const = L.device_spec(y, list(args) if name == "gaussian" else [], args)
+        assert (rowarg is not None) == (name == "binomial") and np.isfinite(const)
+        assert np.all(np.isfinite(L.Ey(f, *args))) and np.all((L.cdf(y, f, *args) >= 0) & (L.cdf(y, f, *args) <= 1))
+    with pytest.raises(ValueError):
+        lk.Poisson("log")
+    with pytest.raises(ValueError):
+        lk.Gaussian().loglike(0., 0., -1.0)
+
+
+def test_glm_qmatrix_and_clone():
+    import revrand_oracle as orc
+    from sklearn.base import clone
+    from revrand_amd import glm as G
+    from revrand_amd.likelihoods import Gaussian
+    rs = np.random.RandomState(1)
+    m, C = rs.randn(7, 4), rs.gamma(2., 0.5, (7, 4))
+    assert np.allclose(G._qmatrix(m, C), orc.glm_qmatrix(m, C), rtol=1e-12)
+    glm = G.GeneralizedLinearModel(likelihood=Gaussian(), basis=bs.LinearBasis(onescol=True), K=3, maxiter=10,
+                                   batch_size=5, nsamples=4, nstarts=2, random_state=0)
+    c = clone(glm)
+    for k in ("K", "maxiter", "batch_size", "nsamples", "nstarts", "random_state"):
+        assert glm.get_params()[k] == c.get_params()[k]
+    assert repr(c.basis) == repr(glm.basis) and isinstance(G.GeneralisedLinearModel(), G.GeneralizedLinearModel)
+    assert G._reshape_likelihood_args((2., np.arange(3.)), 3)[0].shape == (3,)
+    with pytest.raises(ValueError):
+        G._reshape_likelihood_args((np.arange(4.),), 3)

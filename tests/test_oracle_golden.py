@@ -134,3 +134,40 @@ def test_fastfood_gm(golden, case):
     assert normwise(orc.fastfood_gm_transform(X, B, G, PI, S, mean, ls), g[k + "_Phi"]) < 1e-12
     dM, dL = orc.fastfood_gm_grad(X, B, G, PI, S, mean, ls)
     assert normwise(dM, g[k + "_dmean"]) < 1e-12 and normwise(dL, g[k + "_dlen"]) < 1e-12
+
+
+GLM_CASES = [("iso", n) for n in ("poisson_exp", "poisson_softplus", "gaussian", "bernoulli", "binomial")] \
+    + [("ard", "poisson_exp"), ("ard", "gaussian")]
+
+
+@pytest.mark.parametrize("tag,lik", GLM_CASES)
+def test_glm_minibatch_elbo(golden, tag, lik):
+    """One SVI minibatch of the reference's GLM `_elbo` (glm.py:205-322), seeded: -ELBO and the five
+    gradient blocks, with the reference's own standard-normal draws."""
+    g = golden("glm")
+    X, W, ls = g["X"], g["W"], g[tag + "_ls"]
+    ls = float(ls) if np.ndim(ls) == 0 else ls
+    d, D = X.shape[1], 2 * W.shape[1]
+    t = tag + "_" + lik
+    Phi = orc.rff_transform(X, W, ls)
+    dP = orc.rff_grad(X, W, ls)
+    dPs = [dP[:, :, i] for i in range(d)] if tag == "ard" else [dP]
+    lpars = [0.7] if lik == "gaussian" else []
+    largs = (g["nbin"],) if lik == "binomial" else ()
+    nobj, (ndm, ndC, dL, dlp, dbp) = orc.glm_elbo(g["m"], g["C"], np.full(D, float(g["reg"])), slice(None), lik, lpars,
+                                                  largs, Phi, dPs, g[t + "_y"], g["e"], float(g["B"]))
+    assert abs(nobj - g[t + "_obj"]) < 1e-10 * abs(g[t + "_obj"])
+    assert normwise(ndm, g[t + "_ndm"]) < 1e-10 and normwise(ndC, g[t + "_ndC"]) < 1e-10
+    assert abs(dL[0] - g[t + "_dL"]) < 1e-10 * abs(g[t + "_dL"])
+    assert normwise(np.array(dbp), g[t + "_dbp"]) < 1e-10
+    if lpars:
+        assert normwise(np.atleast_1d(dlp[0]), g[t + "_dlp"]) < 1e-10
+
+
+@pytest.mark.parametrize("name", ["sgd", "adadelta", "adagrad", "momentum", "adam"])
+def test_sgd_updaters(golden, name):
+    g = golden("glm")
+    x, st = np.linspace(-1, 1, 6), {}
+    for i, grad in enumerate(g["upd_grads"]):
+        x = orc.sgd_update(name, st, x, grad)
+        assert normwise(x, g["upd_" + name][i]) < 1e-12
