@@ -62,6 +62,7 @@ struct GemmArgs {
     float *D;
     int64_t lda, ldb, ldd;
     int K, ntb;  // ntb = N / 256 column tiles (fastest-varying in blockIdx)
+    int kb_per_split = 0;  // > 0: blockIdx.y owns k-blocks [y * kb_per_split, ...) and ADDS into a zeroed D (f32 atomics)
 };
 
 __global__ void __launch_bounds__(GR_THREADS, 2)
@@ -99,17 +100,22 @@ rr_gemm_tn_f32_kernel(const GemmArgs p) {
         }
     };
 
-    const int nkb = p.K / GR_KB;
-    dma_tile(lds, 0);
+    int nkb = p.K / GR_KB, kb_first = 0;
+    if (p.kb_per_split > 0) {  // split-K: few output tiles, long K (Edws = dfs Phi)
+        kb_first = blockIdx.y * p.kb_per_split;
+        nkb = nkb - kb_first < p.kb_per_split ? nkb - kb_first : p.kb_per_split;
+    }
+    dma_tile(lds, kb_first * GR_KB);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const int cbuf = kb & 1;
-        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB);
+        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb_first + kb + 1) * GR_KB);
         gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
         __syncthreads();
     }
 
     const int hi = lane >> 5;
+    const bool atomic = p.kb_per_split > 0;  // wave-uniform
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -118,7 +124,10 @@ rr_gemm_tn_f32_kernel(const GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int gc = cb + wc_ * 64 + j * 32 + (lane & 31);
-                p.D[gr * p.ldd + gc] = acc[i][j][e];
+                if (atomic)
+                    unsafeAtomicAdd(&p.D[gr * p.ldd + gc], acc[i][j][e]);
+                else
+                    p.D[gr * p.ldd + gc] = acc[i][j][e];
             }
         }
 }
@@ -498,7 +507,7 @@ __device__ __forceinline__ float rr_expit(float f) {
 template <int LIK, typename TY>
 __global__ void __launch_bounds__(256)
 rr_glm_lik_kernel(float *__restrict__ FSt, int64_t M, int64_t rows256, int64_t ld, const TY *__restrict__ y,
-                  const TY *__restrict__ rowarg, float par, int KL, int L, double *__restrict__ llsum,
+                  const TY *__restrict__ rowarg, float par, float fscale, int KL, int L, double *__restrict__ llsum,
                   double *__restrict__ aux, int rows_per_block) {
     const int kl = blockIdx.x * 256 + threadIdx.x;
     const bool kvalid = kl < KL;
@@ -510,7 +519,7 @@ rr_glm_lik_kernel(float *__restrict__ FSt, int64_t M, int64_t rows256, int64_t l
     for (int64_t r = r0; r < r1; ++r) {
         float df = 0.f;
         if (kvalid && r < M) {
-            const float f = FSt[r * ld + kl];
+            const float f = FSt[r * ld + kl] * fscale;  // fs was formed with ws / (K L)
             const float yr = (float)y[r];
             if (LIK == RR_LIK_BERNOULLI) {
                 df = yr - rr_expit(f);
@@ -535,12 +544,22 @@ rr_glm_lik_kernel(float *__restrict__ FSt, int64_t M, int64_t rows256, int64_t l
         }
         FSt[r * ld + kl] = df;
     }
-    if (kvalid) {
+    // per-component sums: LDS first (a block spans at most 256 / L + 2 components), then one global atomic each
+    __shared__ float sacc[258];
+    const int k0 = (blockIdx.x * 256) / L;
+    for (int i = threadIdx.x; i < 258; i += 256) sacc[i] = 0.f;
+    __syncthreads();
+    if (kvalid) atomicAdd(&sacc[kl / L - k0], LIK == RR_LIK_GAUSSIAN ? ax : ll);
+    __syncthreads();
+    const int klast = blockIdx.x * 256 + 255 < KL ? blockIdx.x * 256 + 255 : KL - 1;
+    const int nk = klast >= blockIdx.x * 256 ? klast / L - k0 + 1 : 0;
+    for (int i = threadIdx.x; i < nk; i += 256) {
+        const double v = (double)sacc[i];
         if (LIK == RR_LIK_GAUSSIAN) {
-            unsafeAtomicAdd(&aux[kl / L], (double)ax);
-            unsafeAtomicAdd(&llsum[kl / L], -0.5 * (double)ax * (double)ipar);
+            unsafeAtomicAdd(&aux[k0 + i], v);
+            unsafeAtomicAdd(&llsum[k0 + i], -0.5 * v * (double)ipar);
         } else {
-            unsafeAtomicAdd(&llsum[kl / L], (double)ll);
+            unsafeAtomicAdd(&llsum[k0 + i], v);
         }
     }
 }
@@ -671,7 +690,16 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
                    int64_t Md, int64_t Nd) {
     GemmArgs g;
     g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)Kd; g.ntb = (int)(Nd / 256);
-    hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((Md / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+    const int64_t tiles = (Md / 256) * g.ntb, nkb = Kd / GR_KB;
+    unsigned splits = 1;
+    if (tiles < 2 * (int64_t)c->num_cu && nkb >= 16) {  // too few tiles to fill the chip: split K, >= 8 k-blocks each
+        int64_t want = (2 * (int64_t)c->num_cu + tiles - 1) / tiles;
+        if (want > nkb / 8) want = nkb / 8;
+        g.kb_per_split = (int)((nkb + want - 1) / want);
+        splits = (unsigned)((nkb + g.kb_per_split - 1) / g.kb_per_split);
+        RR_CHECK_HIP(hipMemsetAsync(D, 0, (size_t)Md * ldd * sizeof(float), c->stream));
+    }
+    hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)tiles, splits), dim3(GR_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -710,7 +738,7 @@ static void glm_launch_lik(rr_ctx *c, int lik, float *FSt, int64_t M, int64_t ro
     const dim3 grid((unsigned)(klp / 256), (unsigned)((rows256 + rpb - 1) / rpb));
 #define RR_LK(ID)                                                                                                   \
     hipLaunchKernelGGL((rr_glm_lik_kernel<ID, TY>), grid, dim3(256), 0, c->stream, FSt, M, rows256, klp, (const TY *)dy, \
-                       (const TY *)drow, par, KL, L, llsum, aux, (int)rpb)
+                       (const TY *)drow, par, (float)KL, KL, L, llsum, aux, (int)rpb)
     switch (lik) {
         case RR_LIK_BERNOULLI: RR_LK(RR_LIK_BERNOULLI); break;
         case RR_LIK_BINOMIAL: RR_LK(RR_LIK_BINOMIAL); break;
@@ -917,22 +945,20 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
     if (rc != RR_OK) return rc;
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     const int64_t kl_ld = s.klp;
-    // weight samples: WSt (Fp, kl_ld) for fs, WSs (kl_ld, Fp) / (K L) for EdPhi
-    std::vector<float> wt((size_t)Fp * kl_ld, 0.f), wsn((size_t)kl_ld * Fp, 0.f);
+    // weight samples: WSs (kl_ld, Fp) = ws / (K L) for EdPhi (uploaded), WSt (Fp, kl_ld) = K L WSs^T for fs
+    // (transposed on the device; the scale is undone in the likelihood kernel's read of fs)
+    std::vector<float> wsn((size_t)kl_ld * Fp, 0.f);
     const float inv = (float)(1.0 / ((double)K * (double)L));
     for (int i = 0; i < KL; ++i) {
         const double *src = WS + (size_t)i * F;
         float *dn = wsn.data() + (size_t)i * Fp;
-        for (int j = 0; j < F; ++j) {
-            const float v = (float)src[j];
-            wt[(size_t)j * kl_ld + i] = v;
-            dn[j] = v * inv;
-        }
+        for (int j = 0; j < F; ++j) dn[j] = (float)src[j] * inv;
     }
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
-    RR_CHECK_HIP(hipMemcpy(s.WSt, wt.data(), wt.size() * 4, hipMemcpyHostToDevice));
     RR_CHECK_HIP(hipMemcpy(s.WSs, wsn.data(), wsn.size() * 4, hipMemcpyHostToDevice));
     RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
+                       s.WSs, kl_ld, Fp, s.WSt, kl_ld);
     // Pt = P^T;  FSt (rows256, kl) = P WS^T
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
                        fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
