@@ -232,7 +232,7 @@ def main():
                          "avg_launch_ms": syrk_ms / max(launches, 1),
                          "flops_per_row": off_flops, "rows_per_step": my_rows,
                          "other_kernels_ms_per_step": {"rr_syrk_f32_diag_kernel": diag_ms,
-                                                       "rr_rff_features_kernel": feat_ms},
+                                                       "rr_rff_features_mfma_kernel": feat_ms},
                          "gram_both_kernels_frac": gram_tf / PEAK_F32_MFMA_TFLOPS,
                          "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
                          / world / 1e12 / PEAK_F32_MFMA_TFLOPS},

@@ -257,6 +257,140 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
     }
 }
 
+// (A') The same feature pass with the projection X Ws on the matrix cores (f32 X, f32 features).
+// A wave keeps the Ws operands of CB column blocks of 32 frequencies in registers (B of
+// v_mfma_f32_32x32x2_f32: lane (j, h) holds Ws[h KS + t][c0 + j] for k-step t, KS = DMAX / 2) and streams
+// 32-row tiles of X (A: lane (i, h) holds X[r0 + i][h KS + t], i.e. half a row per lane, read with
+// dwordx4 loads -- any pairing of the k index works as long as A and B agree).  Per tile and column
+// block: KS MFMAs give z for 32 x 32 (row, frequency) pairs, lane (j, h) owning frequency c0 + j and
+// rows r0 + (e & 3) + 8 (e >> 2) + 4 h; then rint / v_sin / v_cos / scale per value and two stores
+// whose half-waves each cover 128 contiguous bytes of one row of P.  Per (row, frequency) this costs
+// 1/64 of a 64-cycle MFMA instead of DMAX VALU FMAs.
+template <int DMAX, int CB, bool HAS_Y>
+__global__ void __launch_bounds__(256, 2)
+rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict__ y, int64_t N, int64_t Npad,
+                            int64_t ldx, const float *__restrict__ Ws, int n, int npad, float *__restrict__ P,
+                            int64_t ldp, double *__restrict__ bvec, float scale, int tiles_per_block) {
+    constexpr int KS = DMAX / 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row tiles, hence store bases, are wave-uniform
+    const int j = lane & 31, h = lane >> 5;
+    const int c0 = blockIdx.x * (32 * CB);
+    float bw[CB][KS];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) bw[cb][t] = Ws[(size_t)(h * KS + t) * npad + c0 + 32 * cb + j];
+    float bc[CB], bs[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bc[cb] = bs[cb] = 0.f;
+    const int64_t ntiles = (Npad + 31) / 32;
+    const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_block;
+    int64_t tile1 = tile0 + tiles_per_block;
+    if (tile1 > ntiles) tile1 = ntiles;
+    for (int64_t tl = tile0 + wave; tl < tile1; tl += 4) {
+        const int64_t r0 = tl * 32;
+        float a[KS];
+        {
+            const int64_t ra = r0 + j;
+            const float4 *src = reinterpret_cast<const float4 *>(X + (ra < N ? ra : 0) * ldx + h * KS);
+#pragma unroll
+            for (int q = 0; q < KS / 4; ++q) {
+                float4 v = src[q];
+                if (ra >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            }
+        }
+        // this lane's rows are r0 + 4 h + rr, rr = (e & 3) + 8 (e >> 2); data rows while rr < lim.  The scratch
+        // has whole 32-row tiles (caller contract), so pad rows are stored (as zeros) without a guard.
+        const int64_t d0 = N - r0 - 4 * h;
+        const int lim = (int)(d0 > 32 ? 32 : (d0 < 0 ? 0 : d0));
+        float yv[16];
+        if (HAS_Y) {  // one coalesced load of the tile's 32 targets, then the lane's 16 rows by cross-lane reads
+            const int64_t ry = r0 + j;
+            float yt = y[ry < N ? ry : N - 1];
+            yt = ry < N ? yt : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int rr = (e & 3) + 8 * (e >> 2);
+                yv[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * h + 4 * rr, __builtin_bit_cast(int, yt)));
+            }
+        }
+        // stores: wave-uniform tile bases (cos and sin halves) in SGPRs + one 32-bit byte offset per row of the
+        // lane (written as asm: left alone, the compiler keeps a 64-bit pointer induction variable per store)
+        const float *tile_c = P + r0 * ldp + c0;
+        const float *tile_s = tile_c + n;
+        const unsigned lane_off = 4u * ((unsigned)(4 * h) * (unsigned)ldp + (unsigned)j);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            floatx16 acc;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+            for (int t = 0; t < KS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bw[cb][t], acc, 0, 0, 0);
+            if (c0 + 32 * cb + j < n) {  // one divergent region per column block (ragged n only)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int rr = (e & 3) + 8 * (e >> 2);
+                    float sv, cv;
+                    sincos_rev(acc[e], sv, cv);
+                    cv = rr < lim ? cv * scale : 0.f;
+                    sv = rr < lim ? sv * scale : 0.f;
+                    const unsigned off = lane_off + 4u * (unsigned)rr * (unsigned)ldp;
+                    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
+                    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
+                    if (HAS_Y) {
+                        bc[cb] = fmaf(cv, yv[e], bc[cb]);
+                        bs[cb] = fmaf(sv, yv[e], bs[cb]);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // one column block at a time: 16 accumulators live, not 64
+        }
+    }
+    if (HAS_Y) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const int col = c0 + 32 * cb + j;
+            if (col < n) {
+                unsafeAtomicAdd(&bvec[col], (double)bc[cb]);
+                unsafeAtomicAdd(&bvec[n + col], (double)bs[cb]);
+            }
+        }
+    }
+}
+
+// launch (A') when its preconditions hold (f32 X with 16-byte aligned rows); false = use the VALU kernel
+static bool rr_features_mfma_launch(rr_basis *b, const float *X, const float *y, int64_t m, int64_t mpad, int64_t ldx,
+                                    float *P, int64_t ldp, double *db, float scale) {
+    static const bool disabled = getenv("RR_FEATURES_NO_MFMA") != nullptr;
+    if (disabled || (ldx & 3) != 0 || ((uintptr_t)X & 15) != 0 || b->dpad < 8) return false;
+    rr_ctx *c = b->ctx;
+    const int64_t ntiles = (mpad + 31) / 32;  // the scratch must hold ntiles * 32 rows
+#define RR_FM(DM, CBK)                                                                                              \
+    do {                                                                                                            \
+        const int cgroups = (b->n + 32 * CBK - 1) / (32 * CBK);                                                     \
+        int64_t tpb = 64;                                                                                           \
+        while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 4 * (int64_t)c->num_cu) tpb >>= 1;                 \
+        if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
+        const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
+        if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true>), grid, dim3(256), 0, c->stream, X, y, \
+                                  m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);              \
+        else hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false>), grid, dim3(256), 0, c->stream, X, y,  \
+                                m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);                \
+    } while (0)
+    switch (b->dpad) {
+        case 8: RR_FM(8, 4); break;
+        case 16: RR_FM(16, 4); break;
+        case 32: RR_FM(32, 4); break;
+        case 64: RR_FM(64, 2); break;
+        case 128: RR_FM(128, 1); break;
+        default: return false;
+    }
+#undef RR_FM
+    return true;
+}
+
 // zero the pad columns [F, Fp) of a feature matrix (the feature kernels only write [0, F))
 template <typename TC>
 __global__ void __launch_bounds__(256) rr_zero_padcols_kernel(TC *P, int64_t rows, int64_t ldp, int F) {
@@ -931,8 +1065,12 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
             b->events.push_back(ev);
         }
         RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
-        // (A) features (+ Phi^T y)
-        {
+        // (A) features (+ Phi^T y): MFMA projection for f32 X, else the VALU kernel
+        bool done_a = false;
+        if constexpr (F32 && sizeof(TX) == 4)
+            done_a = rr_features_mfma_launch(b, (const float *)Xc, (const float *)yc, m, mpad, ldx, (float *)P, ldp, db,
+                                             (float)scale);
+        if (!done_a) {
             const int fblocks = (b->n + 255) / 256;
             int64_t rpb = 256;
             if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
@@ -953,8 +1091,8 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
                 default: rr_set_error("gram: d=%d > 128 is not supported yet", b->d); return RR_ERR_UNSUPPORTED;
             }
 #undef RR_LPH
-            RR_CHECK_HIP(hipGetLastError());
         }
+        RR_CHECK_HIP(hipGetLastError());
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
         // (B) G += P^T P
         if constexpr (F32) {
@@ -981,6 +1119,11 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
         const int64_t cnt = mpad * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
+    }
+    if (x_dtype == RR_F32 &&
+        rr_features_mfma_launch(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)) {
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
     }
     const int fblocks = (b->n + 255) / 256;
     int64_t rpb = 256;
