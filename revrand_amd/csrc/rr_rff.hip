@@ -266,10 +266,10 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
 // rows r0 + (e & 3) + 8 (e >> 2) + 4 h; then rint / v_sin / v_cos / scale per value and two stores
 // whose half-waves each cover 128 contiguous bytes of one row of P.  Per (row, frequency) this costs
 // 1/64 of a 64-cycle MFMA instead of DMAX VALU FMAs.
-template <int DMAX, int CB, bool HAS_Y>
+template <int DMAX, int CB, bool HAS_Y, typename TX, typename TO>
 __global__ void __launch_bounds__(256, 2)
-rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict__ y, int64_t N, int64_t Npad,
-                            int64_t ldx, const float *__restrict__ Ws, int n, int npad, float *__restrict__ P,
+rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad,
+                            int64_t ldx, const float *__restrict__ Ws, int n, int npad, TO *__restrict__ P,
                             int64_t ldp, double *__restrict__ bvec, float scale, int tiles_per_block) {
     constexpr int KS = DMAX / 2;
     const int lane = threadIdx.x & 63;
@@ -293,12 +293,12 @@ rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict
         float a[KS];
         {
             const int64_t ra = r0 + j;
-            const float4 *src = reinterpret_cast<const float4 *>(X + (ra < N ? ra : 0) * ldx + h * KS);
+            const TX *src = X + (ra < N ? ra : 0) * ldx + h * KS;  // KS contiguous elements: dwordx4 loads
 #pragma unroll
-            for (int q = 0; q < KS / 4; ++q) {
-                float4 v = src[q];
-                if (ra >= N) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w;
+            for (int t = 0; t < KS; ++t) a[t] = (float)src[t];
+            if (ra >= N) {
+#pragma unroll
+                for (int t = 0; t < KS; ++t) a[t] = 0.f;
             }
         }
         // this lane's rows are r0 + 4 h + rr, rr = (e & 3) + 8 (e >> 2); data rows while rr < lim.  The scratch
@@ -308,7 +308,7 @@ rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict
         float yv[16];
         if (HAS_Y) {  // one coalesced load of the tile's 32 targets, then the lane's 16 rows by cross-lane reads
             const int64_t ry = r0 + j;
-            float yt = y[ry < N ? ry : N - 1];
+            float yt = (float)y[ry < N ? ry : N - 1];
             yt = ry < N ? yt : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -318,9 +318,10 @@ rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict
         }
         // stores: wave-uniform tile bases (cos and sin halves) in SGPRs + one 32-bit byte offset per row of the
         // lane (written as asm: left alone, the compiler keeps a 64-bit pointer induction variable per store)
-        const float *tile_c = P + r0 * ldp + c0;
-        const float *tile_s = tile_c + n;
-        const unsigned lane_off = 4u * ((unsigned)(4 * h) * (unsigned)ldp + (unsigned)j);
+        const TO *tile_c = P + r0 * ldp + c0;
+        const TO *tile_s = tile_c + n;
+        constexpr unsigned ES = sizeof(TO);
+        const unsigned lane_off = ES * ((unsigned)(4 * h) * (unsigned)ldp + (unsigned)j);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             floatx16 acc;
@@ -336,9 +337,15 @@ rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict
                     sincos_rev(acc[e], sv, cv);
                     cv = rr < lim ? cv * scale : 0.f;
                     sv = rr < lim ? sv * scale : 0.f;
-                    const unsigned off = lane_off + 4u * (unsigned)rr * (unsigned)ldp;
-                    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
-                    asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
+                    const unsigned off = lane_off + ES * (unsigned)rr * (unsigned)ldp;
+                    if constexpr (ES == 4) {
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
+                    } else {
+                        const double cd = (double)cv, sd = (double)sv;
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(off), "v"(cd), "s"(tile_c), "i"(256 * cb) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(off), "v"(sd), "s"(tile_s), "i"(256 * cb) : "memory");
+                    }
                     if (HAS_Y) {
                         bc[cb] = fmaf(cv, yv[e], bc[cb]);
                         bs[cb] = fmaf(sv, yv[e], bs[cb]);
@@ -360,13 +367,15 @@ rr_rff_features_mfma_kernel(const float *__restrict__ X, const float *__restrict
     }
 }
 
-// launch (A') when its preconditions hold (f32 X with 16-byte aligned rows); false = use the VALU kernel
-static bool rr_features_mfma_launch(rr_basis *b, const float *X, const float *y, int64_t m, int64_t mpad, int64_t ldx,
-                                    float *P, int64_t ldp, double *db, float scale) {
+// launch (A') when its preconditions hold (16-byte aligned X rows); false = use the VALU kernel.  The output
+// must have whole 32-row tiles: (mpad + 31) / 32 * 32 rows.
+template <typename TX, typename TO>
+static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64_t m, int64_t mpad, int64_t ldx,
+                                    TO *P, int64_t ldp, double *db, float scale) {
     static const bool disabled = getenv("RR_FEATURES_NO_MFMA") != nullptr;
-    if (disabled || (ldx & 3) != 0 || ((uintptr_t)X & 15) != 0 || b->dpad < 8) return false;
+    if (disabled || ((ldx * sizeof(TX)) & 15) != 0 || ((uintptr_t)X & 15) != 0 || b->dpad < 8 || m < 1) return false;
     rr_ctx *c = b->ctx;
-    const int64_t ntiles = (mpad + 31) / 32;  // the scratch must hold ntiles * 32 rows
+    const int64_t ntiles = (mpad + 31) / 32;
 #define RR_FM(DM, CBK)                                                                                              \
     do {                                                                                                            \
         const int cgroups = (b->n + 32 * CBK - 1) / (32 * CBK);                                                     \
@@ -374,10 +383,10 @@ static bool rr_features_mfma_launch(rr_basis *b, const float *X, const float *y,
         while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 4 * (int64_t)c->num_cu) tpb >>= 1;                 \
         if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
         const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
-        if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true>), grid, dim3(256), 0, c->stream, X, y, \
-                                  m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);              \
-        else hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false>), grid, dim3(256), 0, c->stream, X, y,  \
-                                m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);                \
+        if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true, TX, TO>), grid, dim3(256), 0, c->stream, \
+                                  X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);        \
+        else hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false, TX, TO>), grid, dim3(256), 0, c->stream, \
+                                X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);          \
     } while (0)
     switch (b->dpad) {
         case 8: RR_FM(8, 4); break;
@@ -833,6 +842,17 @@ static int launch_transform(rr_basis *b, const void *dX, int64_t N, int64_t ldx,
     rr_ctx *c = b->ctx;
     const TC *Ws = (sizeof(TC) == 4) ? (const TC *)b->dWs32 : (const TC *)b->dWs64;
     const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    if constexpr (sizeof(TC) == 4) {  // f32 arithmetic: whole 32-row tiles with the projection on MFMA, the rest below
+        const int64_t full = N / 32 * 32;
+        if (full > 0 && rr_features_mfma_launch<TX, TO>(b, (const TX *)dX, nullptr, full, full, ldx, (TO *)dPhi, ldphi,
+                                                        nullptr, (float)scale)) {
+            RR_CHECK_HIP(hipGetLastError());
+            if (full == N) return RR_OK;
+            dX = (const TX *)dX + full * ldx;
+            dPhi = (TO *)dPhi + full * ldphi;
+            N -= full;
+        }
+    }
     const int fblocks = (b->n + 255) / 256;
     // enough row blocks to fill the chip a few times over, >= 16 rows each
     int64_t rpb = (N * fblocks + (int64_t)c->num_cu * 16 - 1) / ((int64_t)c->num_cu * 16);
@@ -1067,9 +1087,7 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
         // (A) features (+ Phi^T y): MFMA projection for f32 X, else the VALU kernel
         bool done_a = false;
-        if constexpr (F32 && sizeof(TX) == 4)
-            done_a = rr_features_mfma_launch(b, (const float *)Xc, (const float *)yc, m, mpad, ldx, (float *)P, ldp, db,
-                                             (float)scale);
+        if constexpr (F32) done_a = rr_features_mfma_launch<TX, float>(b, Xc, yc, m, mpad, ldx, (float *)P, ldp, db, (float)scale);
         if (!done_a) {
             const int fblocks = (b->n + 255) / 256;
             int64_t rpb = 256;
@@ -1120,8 +1138,8 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
         hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
     }
-    if (x_dtype == RR_F32 &&
-        rr_features_mfma_launch(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)) {
+    if (x_dtype == RR_F32 ? rr_features_mfma_launch<float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)
+                          : rr_features_mfma_launch<double, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)) {
         RR_CHECK_HIP(hipGetLastError());
         return RR_OK;
     }
