@@ -45,7 +45,8 @@ typedef enum rr_status {
     RR_ERR_NO_DEVICE = -2,   /* no HIP device / not gfx950                         */
     RR_ERR_HIP = -3,         /* a HIP runtime call failed (message has the detail) */
     RR_ERR_OOM = -4,         /* device allocation failed                           */
-    RR_ERR_UNSUPPORTED = -5  /* valid request this build cannot serve              */
+    RR_ERR_UNSUPPORTED = -5, /* valid request this build cannot serve              */
+    RR_ERR_NOT_POSDEF = -6   /* rr_posterior_dev: take the host SVD route          */
 } rr_status;
 
 typedef enum rr_dtype { RR_F32 = 0, RR_F64 = 1 } rr_dtype;
@@ -200,6 +201,7 @@ int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, dou
  *   pass2_end(&sqErr)      wait, fetch the accumulated sqErr
  *   predict_rows(Ey, Vf)   Ey = P m, Vf = rowsum((P C) o P) for the current rows (host float64) */
 int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C);
+int rr_featmat_pass2_begin_devc(rr_featmat *fm, const double *m, const double *dC); /* C on the DEVICE */
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype);
 int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
                          double *dT);
@@ -230,6 +232,19 @@ int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E)
 /* out (rows, S) = P W for a host (F, S) float64 matrix: the latent function samples of glm.py:572-620. */
 int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
 
+/* ---- posterior of the standard linear model on the device -------------------
+ * iC = diag(iL) + G / var,  C = iC^-1 by Cholesky (solve_posdef(iC, I), mathfun/linalg.py:84-125, as called at
+ * slm.py:155),  m = C b / var (slm.py:157), and the O(F^2) reductions of slm.py:160,165-171.
+ *   dG (F, F) float64 DEVICE, symmetric (after rr_symmetrize_dev), unchanged;  db (F) float64 DEVICE;
+ *   iL (F) host float64 = 1 / regularizer_diagonal;  dC (F, F) float64 DEVICE output (full symmetric C).
+ *   Host outputs: m (F), diagC (F), scal[3] = { log|iC|, sum(G o C), smallest diagonal entry of the factor }.
+ * The factorisation / inverse are rocSOLVER's dpotrf / dpotri, loaded at run time (rr_posterior_available() tells
+ * whether they are there).  RR_ERR_NOT_POSDEF when the factorisation fails or its smallest diagonal entry is below
+ * 1e-5 (CHOLTHRESH, linalg.py:31,113): the caller then takes the reference's SVD route on the host. */
+int rr_posterior_available(void);
+int rr_posterior_dev(rr_ctx *ctx, int64_t F, const double *dG, const double *db, const double *iL, double var,
+                     double *dC, double *m, double *diagC, double *scal);
+
 /* ---- second data pass of the standard linear model (posterior known) -----------------------
  * With m (F,) and C (F, F) from the host Cholesky (slm.py:154-157), for a random Fourier basis and
  * DEVICE-resident X (padded layout, see rr_rff_padded_dim) and y:
@@ -242,6 +257,10 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
 int rr_rff_elbo_pass2_dev(rr_basis *basis, const void *dX, const void *dy, int x_dtype, int64_t N,
                           int64_t ldx, const double *lenscale, int n_ls, const double *m, const double *C,
                           double *sqerr, double *T);
+/* The same with C (F, F) float64 resident on the DEVICE (rr_posterior_dev's dC); m stays a host vector. */
+int rr_rff_elbo_pass2_devc(rr_basis *basis, const void *dX, const void *dy, int x_dtype, int64_t N,
+                           int64_t ldx, const double *lenscale, int n_ls, const double *m, const double *dC,
+                           double *sqerr, double *T);
 
 /* Basis-gradient contraction for ANY consumer of basis.grad: given a host matrix E (N, 2n) -- the factor
  * the caller would multiply element-wise with each dPhi_i and sum (slm.py:193-195: E = Err m^T - Phi C;

@@ -98,6 +98,14 @@ SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_project": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "rr_posterior_available": (ctypes.c_int, []),
+    "rr_posterior_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                        ctypes.c_void_p]),
+    "rr_rff_elbo_pass2_devc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_pass2_begin_devc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_rff_grad_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
@@ -145,16 +153,50 @@ def _share_hip_runtime_with_torch():
     keeps /opt/rocm's."""
     if "torch" in sys.modules or os.environ.get("RR_HIP_RUNTIME", "") == "system":
         return
+    cand = _torch_lib("libamdhip64.so")
+    if cand:
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass  # fall back to the system runtime
+
+
+def _torch_lib(name):
+    """Path of a library bundled with an installed torch wheel, or None."""
     try:
         import importlib.util
         spec = importlib.util.find_spec("torch")
         if spec is None or not spec.submodule_search_locations:
-            return
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
-        if os.path.exists(cand):
-            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-    except (OSError, ImportError, ValueError):
-        pass  # fall back to the system runtime
+            return None
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", name)
+        return cand if os.path.exists(cand) else None
+    except (ImportError, ValueError):
+        return None
+
+
+_solver_ready = None
+
+RR_ERR_NOT_POSDEF = -6
+
+
+def posterior_available():
+    """True when rr_posterior_dev can run (rocSOLVER loadable and RR_POSDEF != 'host').  As for the HIP runtime, an
+    installed torch's bundled rocBLAS / rocSOLVER are loaded first so that one copy serves the whole process."""
+    global _solver_ready
+    if os.environ.get("RR_POSDEF", "") == "host":
+        return False
+    if _solver_ready is None:
+        lib = load_library()
+        if os.environ.get("RR_HIP_RUNTIME", "") != "system":
+            for name in ("librocblas.so", "librocsolver.so"):
+                cand = _torch_lib(name)
+                if cand:
+                    try:
+                        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                    except OSError:
+                        pass
+        _solver_ready = bool(lib.rr_posterior_available())
+    return _solver_ready
 
 
 def load_library(path=None):
@@ -316,6 +358,19 @@ class Device(object):
     def sync(self):
         _check(self.lib, self.lib.rr_ctx_sync(self.ctx))
 
+    def posterior(self, F, dG, db, iL, var, dC):
+        """rr_posterior_dev: (m, diagC, log|iC|, sum(G o C)) with C left in the device buffer dC, or None when the
+        matrix is not safely positive definite (the caller then takes the host SVD route)."""
+        iL = np.ascontiguousarray(iL, dtype=np.float64)
+        m, dg, scal = np.empty(F), np.empty(F), np.zeros(3)
+        rc = self.lib.rr_posterior_dev(self.ctx, F, _ptr(dG), _ptr(db), iL.ctypes.data_as(ctypes.c_void_p), float(var),
+                                       _ptr(dC), m.ctypes.data_as(ctypes.c_void_p), dg.ctypes.data_as(ctypes.c_void_p),
+                                       scal.ctypes.data_as(ctypes.c_void_p))
+        if rc == RR_ERR_NOT_POSDEF:
+            return None
+        _check(self.lib, rc)
+        return m, dg, float(scal[0]), float(scal[1])
+
     def timer_start(self):
         _check(self.lib, self.lib.rr_timer_start(self.ctx))
 
@@ -444,12 +499,18 @@ class FeatureMatrix(object):
                                                       Phi.shape[1], _ld(Phi), col0))
 
     def pass2_begin(self, m, C):
+        """C: host (F, F) array or a device buffer / pointer (float64, rr_posterior_dev's output)."""
         m = np.ascontiguousarray(m, dtype=np.float64)
-        C = np.ascontiguousarray(C, dtype=np.float64)
-        if m.shape != (self.F,) or C.shape != (self.F, self.F):
+        if m.shape != (self.F,):
             raise ValueError("posterior shape does not match the feature matrix")
-        _check(self.lib, self.lib.rr_featmat_pass2_begin(self.h, m.ctypes.data_as(ctypes.c_void_p),
-                                                         C.ctypes.data_as(ctypes.c_void_p)))
+        if isinstance(C, np.ndarray):
+            C = np.ascontiguousarray(C, dtype=np.float64)
+            if C.shape != (self.F, self.F):
+                raise ValueError("posterior shape does not match the feature matrix")
+            _check(self.lib, self.lib.rr_featmat_pass2_begin(self.h, m.ctypes.data_as(ctypes.c_void_p),
+                                                             C.ctypes.data_as(ctypes.c_void_p)))
+        else:
+            _check(self.lib, self.lib.rr_featmat_pass2_begin_devc(self.h, m.ctypes.data_as(ctypes.c_void_p), _ptr(C)))
 
     def pass2_rows(self, dy):
         _check(self.lib, self.lib.rr_featmat_pass2_rows(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0))
@@ -691,17 +752,20 @@ class RffHandle(object):
         return out[:F * F].reshape(F, F), out[F * F:F * F + F].copy(), float(out[-1])
 
     def elbo_pass2(self, dX, dy, lenscale, m, C):
-        """(sqErr, T (d, n)) for the posterior (m, C): the second data pass of `_elbo`."""
+        """(sqErr, T (d, n)) for the posterior (m, C): the second data pass of `_elbo`.  C: host (F, F) array, or a
+        DeviceBuffer / pointer holding it in float64 on the device (rr_posterior_dev's output)."""
         ls, lsp, nls = _lenscale_arg(lenscale)
         m = np.ascontiguousarray(m, dtype=np.float64)
-        C = np.ascontiguousarray(C, dtype=np.float64)
         sq = np.zeros(1)
         T = np.zeros((self.d, self.n))
-        _check(self.lib, self.lib.rr_rff_elbo_pass2_dev(self.h, dX.ptr, dy.ptr, rr_dtype(dX.dtype), dX.shape[0], dX.ld,
-                                                        lsp, nls, m.ctypes.data_as(ctypes.c_void_p),
-                                                        C.ctypes.data_as(ctypes.c_void_p),
-                                                        sq.ctypes.data_as(ctypes.c_void_p),
-                                                        T.ctypes.data_as(ctypes.c_void_p)))
+        if isinstance(C, np.ndarray):
+            C = np.ascontiguousarray(C, dtype=np.float64)
+            fn, cp = self.lib.rr_rff_elbo_pass2_dev, C.ctypes.data_as(ctypes.c_void_p)
+        else:
+            fn, cp = self.lib.rr_rff_elbo_pass2_devc, _ptr(C)
+        _check(self.lib, fn(self.h, dX.ptr, dy.ptr, rr_dtype(dX.dtype), dX.shape[0], dX.ld, lsp, nls,
+                            m.ctypes.data_as(ctypes.c_void_p), cp, sq.ctypes.data_as(ctypes.c_void_p),
+                            T.ctypes.data_as(ctypes.c_void_p)))
         return float(sq[0]), T
 
     def predict(self, X, lenscale, m, C):

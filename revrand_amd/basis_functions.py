@@ -247,7 +247,54 @@ class _LengthScaleBasis(Basis):
 # Random Fourier feature bases on the GPU (reference: basis_functions.py:818-1208)
 # --------------------------------------------------------------------------------------
 
-class DeviceFitState(object):
+class _DevicePosterior(object):
+    """Mixin of the fit states: the sufficient statistics [G | b | y^T y] of the last Gram pass and the posterior
+    covariance stay in HBM (rr_posterior_dev), so an `_elbo` evaluation moves O(F) numbers over PCIe."""
+
+    def _stats_init(self, dev, F):
+        self.dev, self.F = dev, int(F)
+        self.acc = dev.malloc((self.F * self.F + self.F + 1) * 8)
+        self.dC = self.dCbest = None
+        self.best_on_device = False
+
+    def _stat_ptrs(self):
+        base, F = self.acc.ptr.value, self.F
+        return tuple(_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
+
+    def _finish_stats(self):
+        pG, _, _ = self._stat_ptrs()
+        _hip._check(self.dev.lib, self.dev.lib.rr_symmetrize_dev(self.dev.ctx, pG, self.F))
+        return float(self.dev.download(self.acc, (1,), np.float64, offset_bytes=(self.F * self.F + self.F) * 8)[0])
+
+    def stats_host(self):
+        F = self.F
+        out = self.dev.download(self.acc, (F * F + F + 1,), np.float64)
+        return out[:F * F].reshape(F, F), out[F * F:F * F + F].copy(), float(out[-1])
+
+    def posterior(self, iL, var):
+        """(m, diag C, log|iC|, sum(G o C)) from the statistics of the last ``gram_device``; C stays in ``self.dC``.
+        None when the Cholesky is not safe (the estimator then takes the host SVD route)."""
+        if self.dC is None:
+            self.dC = self.dev.malloc(self.F * self.F * 8)
+        pG, pb, _ = self._stat_ptrs()
+        return self.dev.posterior(self.F, pG, pb, iL, var, self.dC)
+
+    def keep_best(self):
+        """The covariance just computed is the best so far: keep it (buffer swap, no copy)."""
+        self.dC, self.dCbest = self.dCbest, self.dC
+        self.best_on_device = True
+
+    def best_covariance(self):
+        return self.dev.download(self.dCbest, (self.F, self.F), np.float64)
+
+    def _stats_release(self):
+        for b in (self.acc, self.dC, self.dCbest):
+            if b is not None:
+                b.free()
+        self.acc = self.dC = self.dCbest = None
+
+
+class DeviceFitState(_DevicePosterior):
     """X and y resident on the GPU for the whole of a ``fit`` (slm.py:118-126 calls ``_elbo``
     ~50-200 times): per evaluation only the (F, F) statistics, the posterior and d+1 scalars cross PCIe.
 
@@ -261,9 +308,17 @@ class DeviceFitState(object):
         X32 = np.ascontiguousarray(X, dtype=np.float32)
         self.dX = handle.upload(X32)
         self.dy = handle.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+        self._stats_init(handle.dev, 2 * handle.n)
 
     def gram(self, lenscale):
         return self.handle.gram_host(self.dX, self.dy, lenscale)
+
+    def gram_device(self, lenscale):
+        """Statistics of this length scale into the resident buffer; returns y^T y."""
+        self.dev.memset(self.acc)
+        pG, pb, pt = self._stat_ptrs()
+        self.handle.gram_dev(self.dX, self.dy, lenscale, pG, pb, pt)
+        return self._finish_stats()
 
     def second_pass(self, lenscale, m, C, var):
         sq, T = self.handle.elbo_pass2(self.dX, self.dy, lenscale, m, C)
@@ -275,6 +330,7 @@ class DeviceFitState(object):
     def release(self):
         self.dX.free()
         self.dy.free()
+        self._stats_release()
 
 
 class _ResidentHost(object):
@@ -447,7 +503,7 @@ class MinibatchFeatures(object):
         self.fm = None
 
 
-class CatFitState(object):
+class CatFitState(_DevicePosterior):
     """DeviceFitState for a BasisCat: every child keeps its columns of X on the GPU, Phi is assembled in a
     device feature matrix per row chunk; same ``gram`` / ``second_pass`` / ``release`` interface, ``dhyp``
     structured like ``apply_grad(f, cat.grad(X, *hypers))``."""
@@ -465,6 +521,7 @@ class CatFitState(object):
         self.chunk = int(max(256, min(self.N, chunk_rows)))
         self.fm = _hip.FeatureMatrix(self.chunk, self.F)
         self._filled = None
+        self._stats_init(self.dev, self.F)
 
     def _fill(self, r0, rows, hypers):
         key = (r0, rows, tuple(np.asarray(h, dtype=float).tobytes() for h in hypers))
@@ -481,18 +538,19 @@ class CatFitState(object):
         for r0 in range(0, self.N, self.chunk):
             yield r0, min(self.chunk, self.N - r0)
 
-    def gram(self, hypers):
-        hypers, F, dev = atleast_list(hypers), self.F, self.dev
-        acc = dev.zeros((F * F + F + 1) * 8)
-        base = acc.ptr.value
-        pG, pb, pt = (_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
+    def gram_device(self, hypers):
+        """Statistics of these hyper-parameters into the resident buffer; returns y^T y."""
+        hypers = atleast_list(hypers)
+        self.dev.memset(self.acc)
+        pG, pb, pt = self._stat_ptrs()
         for r0, rows in self._chunks():
             self._fill(r0, rows, hypers)
             self.fm.gram_into(_hip.DeviceView(self.dy, r0, rows), pG, pb, pt)
-        _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
-        out = dev.download(acc, (F * F + F + 1,), np.float64)
-        acc.free()
-        return out[:F * F].reshape(F, F), out[F * F:F * F + F].copy(), float(out[-1])
+        return self._finish_stats()
+
+    def gram(self, hypers):
+        self.gram_device(hypers)
+        return self.stats_host()
 
     def second_pass(self, hypers, m, C, var):
         hypers = atleast_list(hypers)
@@ -514,6 +572,7 @@ class CatFitState(object):
             c.release()
         self.dy.free()
         self.fm = None
+        self._stats_release()
 
 
 class _RandomKernelBasis(_LengthScaleBasis):

@@ -79,6 +79,7 @@ void rr_ctx_destroy(rr_ctx *ctx) {
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->tile_map) (void)hipFree(ctx->tile_map);
+    rr_posdef_scratch_free(ctx->posdef);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;

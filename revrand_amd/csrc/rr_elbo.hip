@@ -245,6 +245,15 @@ rr_grad_contract_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const 
     }
 }
 
+// C32 (Fp, Fp) f32, zero padded  <-  C (F, F) f64 on the device (the posterior of rr_posterior_dev)
+__global__ void __launch_bounds__(256)
+rr_c64_to_c32_kernel(const double *__restrict__ C, int64_t F, float *__restrict__ C32, int64_t Fp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Fp * Fp) return;
+    const int64_t r = i / Fp, c = i % Fp;
+    C32[i] = (r < F && c < F) ? (float)C[r * F + c] : 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -327,7 +336,7 @@ static int launch_grad_t(rr_basis *b, const TX *X, int64_t N, int64_t ldx, const
 //                 MODE_PRED: Ey, Vf per row (host doubles, length N).
 template <typename TX>
 static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t N, int64_t ldx, const double *mh,
-                     const double *Ch, double *out0, double *out1) {
+                     const double *Ch, double *out0, double *out1, bool c_on_device = false) {
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n, n = b->n;
     const int64_t Fp = ((int64_t)F + 255) / 256 * 256;
@@ -366,15 +375,20 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
     int rc = RR_OK;
     {   // posterior to the device in f32: m (F), C padded to (Fp, Fp)
         s.hm.resize(F);
-        s.hC.assign((size_t)Fp * Fp, 0.f);
         for (int i = 0; i < F; ++i) s.hm[i] = (float)mh[i];
-        for (int i = 0; i < F; ++i) {
-            const double *src = Ch + (size_t)i * F;
-            float *dst = s.hC.data() + (size_t)i * Fp;
-            for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
-        }
         e = hipMemcpy(s.m32, s.hm.data(), (size_t)F * 4, hipMemcpyHostToDevice);
-        if (e == hipSuccess) e = hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice);
+        if (c_on_device) {
+            hipLaunchKernelGGL(rr_c64_to_c32_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, Ch,
+                               (int64_t)F, s.C32, Fp);
+        } else {
+            s.hC.assign((size_t)Fp * Fp, 0.f);
+            for (int i = 0; i < F; ++i) {
+                const double *src = Ch + (size_t)i * F;
+                float *dst = s.hC.data() + (size_t)i * Fp;
+                for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+            }
+            if (e == hipSuccess) e = hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice);
+        }
         if (e == hipSuccess && !pred) e = hipMemsetAsync(s.acc, 0, nacc * 8, c->stream);
         if (e == hipSuccess && Fp > F) {  // pad feature rows of Pt are never written by the kernel
             const int64_t cnt = (Fp - F) * chunk;
@@ -825,6 +839,17 @@ int rr_rff_elbo_pass2_dev(rr_basis *b, const void *dX, const void *dy, int x_dty
                              : pass2_run<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, C, sqerr, T);
 }
 
+int rr_rff_elbo_pass2_devc(rr_basis *b, const void *dX, const void *dy, int x_dtype, int64_t N, int64_t ldx,
+                           const double *lenscale, int n_ls, const double *m, const double *dC, double *sqerr,
+                           double *T) {
+    int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, dC, "rr_rff_elbo_pass2_devc");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(dy != nullptr && sqerr != nullptr && T != nullptr, "rr_rff_elbo_pass2_devc: null argument");
+    return x_dtype == RR_F32
+               ? pass2_run<float>(b, false, (const float *)dX, (const float *)dy, N, ldx, m, dC, sqerr, T, true)
+               : pass2_run<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, dC, sqerr, T, true);
+}
+
 int rr_rff_predict_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
                        int n_ls, const double *m, const double *C, double *Ey, double *Vf) {
     int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, C, "rr_rff_predict_dev");
@@ -834,7 +859,7 @@ int rr_rff_predict_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int6
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, C, Ey, Vf);
 }
 
-int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) {
+static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool c_on_device) {
     RR_REQUIRE(fm != nullptr && m != nullptr && C != nullptr, "rr_featmat_pass2_begin: null argument");
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
@@ -846,20 +871,29 @@ int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) {
     }
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     s.hm.assign((size_t)Fp, 0.f);
-    s.hC.assign((size_t)Fp * Fp, 0.f);
     for (int i = 0; i < F; ++i) s.hm[i] = (float)m[i];
-    for (int i = 0; i < F; ++i) {
-        const double *src = C + (size_t)i * F;
-        float *dst = s.hC.data() + (size_t)i * Fp;
-        for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
-    }
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     RR_CHECK_HIP(hipMemcpy(s.m32, s.hm.data(), (size_t)Fp * 4, hipMemcpyHostToDevice));
-    RR_CHECK_HIP(hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice));
+    if (c_on_device) {
+        hipLaunchKernelGGL(rr_c64_to_c32_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, C,
+                           (int64_t)F, s.C32, Fp);
+        RR_CHECK_HIP(hipGetLastError());
+    } else {
+        s.hC.assign((size_t)Fp * Fp, 0.f);
+        for (int i = 0; i < F; ++i) {
+            const double *src = C + (size_t)i * F;
+            float *dst = s.hC.data() + (size_t)i * Fp;
+            for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+        }
+        RR_CHECK_HIP(hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice));
+    }
     RR_CHECK_HIP(hipMemsetAsync(s.sq, 0, 8, c->stream));
     s.have_rows = false;
     return RR_OK;
 }
+
+int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) { return fm_pass2_begin(fm, m, C, false); }
+int rr_featmat_pass2_begin_devc(rr_featmat *fm, const double *m, const double *dC) { return fm_pass2_begin(fm, m, dC, true); }
 
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_rows: call rr_featmat_pass2_begin first");

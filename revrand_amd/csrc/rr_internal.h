@@ -20,6 +20,7 @@ struct rr_ctx {
     int num_cu = 0;
     int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
     int tile_map_nb = 0;
+    void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): rocBLAS handle + small device vectors
 };
 
 enum rr_kind { RR_KIND_RFF = 0, RR_KIND_FASTFOOD = 1 };
@@ -77,6 +78,7 @@ void rr_set_error(const char *fmt, ...);
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
 int rr_pick_dmax(int d);
 void rr_pass2_scratch_free(void *p);
+void rr_posdef_scratch_free(void *p);
 
 // Device feature matrix of a concatenated basis (rr_featmat.hip; second pass in rr_elbo.hip).
 struct rr_featmat {

@@ -72,11 +72,15 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         if self.distributed and self._state is None:
             raise ValueError("distributed=True needs random-feature bases in f32 mode (alone or concatenated "
                              "with Linear/Bias bases)")
+        self._defer_cov = True
         try:
             res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
                        options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
                        nstarts=self.nstarts)
+            if self._state is not None and getattr(self._state, "best_on_device", False):
+                self.covariance_ = self._state.best_covariance()
         finally:
+            self._defer_cov = False
             if self._state is not None:
                 self._state.release()
             self._state = None
@@ -114,24 +118,42 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         return G2[:F, F:]
 
     def _elbo_resident(self, X, y, var, reg, hypers):
-        """`_elbo` for a single random-feature basis with (X, y) resident on the device: two data
-        passes on the GPU (statistics; Err / U = Phi C / gradient contraction), Cholesky on the host,
-        neither Phi nor dPhi ever materialised."""
+        """`_elbo` with (X, y) resident on the device: two data passes on the GPU (statistics; Err / U = Phi C /
+        gradient contraction) around the posterior -- Cholesky, inverse and the O(F^2) reductions also in HBM
+        (rr_posterior_dev) unless the statistics are summed over ranks or the matrix needs the SVD route; neither
+        Phi nor dPhi ever materialised, O(F) numbers over PCIe per evaluation."""
         st = self._state
         N = X.shape[0]
-        PhiPhi, Phiy, yty = st.gram(hypers)
-        D = PhiPhi.shape[0]
-        if self.distributed:  # one exchange: the packed sufficient statistics of all row shards
-            from . import parallel
-            PhiPhi, Phiy, yty, N = parallel.unpack_stats(self._allreduce(parallel.pack_stats(PhiPhi, Phiy, yty, N)), D)
+        # posterior on the device (Cholesky + inverse + reductions in HBM) unless the statistics must be summed
+        # over ranks on the host first, rocSOLVER is missing, or RR_POSDEF=host
+        on_dev = (not self.distributed) and hasattr(st, "posterior") and _hip.posterior_available()
+        if on_dev:
+            yty = st.gram_device(hypers)
+            D = st.F
+        else:
+            PhiPhi, Phiy, yty = st.gram(hypers)
+            D = PhiPhi.shape[0]
+            if self.distributed:  # one exchange: the packed sufficient statistics of all row shards
+                from . import parallel
+                PhiPhi, Phiy, yty, N = parallel.unpack_stats(
+                    self._allreduce(parallel.pack_stats(PhiPhi, Phiy, yty, N)), D)
         L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
         iL = 1. / L
-        iC = np.diag(iL) + PhiPhi / var
-        C, logdetiC = solve_posdef(iC, np.eye(D))
+        post = st.posterior(iL, var) if on_dev else None
+        if post is None:
+            if on_dev:  # not safely positive definite: the reference's SVD route, on the host
+                log.info("posterior not safely positive definite on the device: host solve_posdef for this step")
+                PhiPhi, Phiy, yty = st.stats_host()
+            iC = np.diag(iL) + PhiPhi / var
+            C, logdetiC = solve_posdef(iC, np.eye(D))
+            m = C.dot(Phiy) / var
+            TrPhiPhiC = (PhiPhi * C).sum()
+            Cdiag, Cpass = C.diagonal(), C
+        else:
+            m, Cdiag, logdetiC, TrPhiPhiC = post
+            Cpass = st.dC
         logdetC = -logdetiC
-        m = C.dot(Phiy) / var
-        TrPhiPhiC = (PhiPhi * C).sum()
-        sqErr, dhypers = st.second_pass(hypers, m, C, var)
+        sqErr, dhypers = st.second_pass(hypers, m, Cpass, var)
         if self.distributed:  # second exchange: 1 + (number of length scales) numbers
             parts = dhypers if isinstance(dhypers, list) else [dhypers]
             red = self._allreduce(np.concatenate([[sqErr]] + [np.atleast_1d(p) for p in parts]))
@@ -141,16 +163,22 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                 k += np.size(p)
             dhypers = out if isinstance(dhypers, list) else out[0]
         ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
-                       + ((m ** 2 + C.diagonal()) * iL).sum() - logdetC + np.log(L).sum() - D)
+                       + ((m ** 2 + Cdiag) * iL).sum() - logdetC + np.log(L).sum() - D)
         if ELBO > self.obj_:
             self.weights_ = m
-            self.covariance_ = C
             self.obj_ = ELBO
+            if post is None:
+                self.covariance_ = C
+                st.best_on_device = False
+            else:
+                st.keep_best()  # stays in HBM; fetched once at the end of fit
+                if not getattr(self, "_defer_cov", False):
+                    self.covariance_ = st.best_covariance()
         log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
         dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
 
         def dreg(s):
-            return -0.5 * (((m[s] ** 2 + C[s, s].diagonal()) * iL[s] ** 2).sum() - iL[s].sum())
+            return -0.5 * (((m[s] ** 2 + Cdiag[s]) * iL[s] ** 2).sum() - iL[s].sum())
 
         dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
         return -ELBO, [-dvar, dL, dhypers]

@@ -339,3 +339,84 @@ def test_concat_fit_runs_resident_and_predicts():
     Phi = cat.transform(Xs, *np.atleast_1d([slm.hypers_]) if np.ndim(slm.hypers_) == 0 else [slm.hypers_])
     Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
     assert normwise(Ey, Eo) < 1e-3 and normwise(Vy, Vo) < 1e-2
+
+
+@pytest.mark.parametrize("F", [37, 512, 1300])
+def test_posterior_on_device_vs_host_solve_posdef(F):
+    """rr_posterior_dev: C = (diag(iL) + G/var)^-1, m, log|iC|, sum(G o C), diag(C) against the host
+    solve_posdef (mathfun/linalg.py:84-125) -- float64 both sides."""
+    from revrand_amd import _hip
+    from revrand_amd.linalg import solve_posdef
+    assert _hip.posterior_available()
+    dev = _hip.get_device()
+    rs = np.random.RandomState(F)
+    A = rs.randn(F, 3 * F)
+    G = A @ A.T
+    b = rs.randn(F)
+    iL = 1. / rs.gamma(2., 1., F)
+    var = 0.37
+    acc = dev.upload_vector(np.concatenate((G.ravel(), b)))
+    dC = dev.malloc(F * F * 8)
+    pG, pb = _hip.ctypes.c_void_p(acc.ptr.value), _hip.ctypes.c_void_p(acc.ptr.value + F * F * 8)
+    m, dg, logdet, tr = dev.posterior(F, pG, pb, iL, var, dC)
+    C = dev.download(dC, (F, F), np.float64)
+    Ch, ldh = solve_posdef(np.diag(iL) + G / var, np.eye(F))
+    assert np.array_equal(C, C.T)
+    assert normwise(C, Ch) < 1e-9 and abs(logdet - ldh) < 1e-9 * abs(ldh)
+    assert normwise(m, Ch @ b / var) < 1e-9 and normwise(dg, Ch.diagonal()) < 1e-9
+    assert abs(tr - (G * Ch).sum()) < 1e-9 * abs((G * Ch).sum())
+    # a matrix whose Cholesky is not safe (diag below CHOLTHRESH = 1e-5): the call reports it, nothing raised
+    Gs = np.zeros((F, F))
+    acc2 = dev.upload_vector(np.concatenate((Gs.ravel(), b)))
+    p2 = _hip.ctypes.c_void_p(acc2.ptr.value)
+    assert dev.posterior(F, p2, _hip.ctypes.c_void_p(acc2.ptr.value + F * F * 8), np.full(F, 1e-12), 1.0, dC) is None
+    for buf in (acc, acc2, dC):
+        buf.free()
+
+
+def test_elbo_device_posterior_equals_host_posterior(monkeypatch):
+    """One resident `_elbo` evaluation with the posterior on the device and (RR_POSDEF=host) on the host: objective,
+    gradients, weights and covariance agree (float64 linear algebra on both sides); the fit then fetches the best
+    covariance from the device once."""
+    bs, Parameter, Positive, SLM = _imports()
+    from revrand_amd import _hip
+    X, y, Xs, ys = _gaus_data()
+    d = X.shape[1]
+    res = []
+    for mode in ("device", "host"):
+        monkeypatch.setenv("RR_POSDEF", mode)
+        assert _hip.posterior_available() == (mode == "device")
+        cat = bs.RandomRBF(nbases=40, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())) \
+            + bs.LinearBasis(onescol=True)
+        for basis, reg, hyp in ((cat.bases[0], 1.3, np.full(d, 0.8)), (cat, [1.3, 0.7], np.full(d, 0.8))):
+            slm = SLM(basis)
+            slm.obj_ = -np.inf
+            slm._state = basis.device_fit_state(X, y)
+            f, (gv, gr, gh) = slm._elbo(X, y, 0.4, reg, hyp)
+            slm._state.release()
+            res.append((f, gv, np.atleast_1d(gr), np.atleast_1d(gh), slm.weights_, slm.covariance_))
+    for dev_r, host_r in ((res[0], res[2]), (res[1], res[3])):
+        assert abs(dev_r[0] - host_r[0]) < 1e-7 * abs(host_r[0]) and abs(dev_r[1] - host_r[1]) < 1e-6 * abs(host_r[1])
+        assert normwise(dev_r[2], host_r[2]) < 1e-6 and normwise(dev_r[3], host_r[3]) < 1e-4
+        assert normwise(dev_r[4], host_r[4]) < 1e-6 and normwise(dev_r[5], host_r[5]) < 1e-6
+    monkeypatch.setenv("RR_POSDEF", "device")
+    basis = bs.RandomRBF(nbases=40, Xdim=d, random_state=3)
+    slm = SLM(basis, nstarts=0, maxiter=40)
+    best, orig = [], SLM._elbo_resident
+
+    def recording(self, X_, y_, var, reg, hypers):   # parameters of the evaluation that set the best posterior
+        before = self.obj_
+        out = orig(self, X_, y_, var, reg, hypers)
+        if self.obj_ > before:
+            best[:] = [var, reg, hypers]
+        return out
+
+    monkeypatch.setattr(SLM, "_elbo_resident", recording)
+    slm.fit(X, y)
+    assert slm.covariance_.shape == (80, 80) and normwise(slm.covariance_, slm.covariance_.T) < 1e-6
+    assert smse(ys, slm.predict(Xs)) < 0.1
+    # the covariance fetched at the end of fit belongs to the best evaluation, like weights_
+    var, reg, hyp = best
+    G, b, _ = basis.gram(X, y, hyp)
+    C = np.linalg.inv(np.eye(80) / reg + G / var)
+    assert normwise(slm.covariance_, C) < 1e-4 and normwise(slm.weights_, C @ b / var) < 1e-4
