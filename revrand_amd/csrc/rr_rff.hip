@@ -513,8 +513,8 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
 // ---------------------------------------------------------------------------------------
 // Diagonal tiles (ta == tb) of the f32 SYRK.  Of the 64 32x32 blocks of a diagonal 256x256 tile
 // only the 36 with block-row <= block-column are needed.  They are dealt to the 8 waves 5 + 4 per
-// SIMD pair (waves w and w+4 share a SIMD), the 4-block waves carrying one dummy block, so a
-// diagonal workgroup issues 5 instead of 8 MFMAs per k-step and needs only the A side of the tile
+// SIMD pair (waves w and w+4 share a SIMD: 9 MFMAs per k-step between them), so a diagonal
+// workgroup issues 4.5 instead of 8 MFMAs per wave and k-step and needs only the A side of the tile
 // (32 KiB of DMA per k-block).  Launched as its own kernel after the off-diagonal one.
 // ---------------------------------------------------------------------------------------
 __constant__ unsigned char RR_DIAG_I[8][5] = {{0, 0, 0, 0, 0}, {1, 1, 1, 1, 1}, {2, 2, 2, 2, 2}, {3, 3, 3, 3, 3},
@@ -522,41 +522,39 @@ __constant__ unsigned char RR_DIAG_I[8][5] = {{0, 0, 0, 0, 0}, {1, 1, 1, 1, 1}, 
 __constant__ unsigned char RR_DIAG_J[8][5] = {{0, 1, 2, 3, 4}, {1, 2, 3, 4, 5}, {2, 3, 4, 5, 6}, {3, 4, 5, 6, 7},
                                               {5, 6, 7, 7, 5}, {6, 7, 6, 7, 6}, {7, 5, 6, 7, 7}, {4, 5, 6, 7, 4}};
 
+template <int NB>
 struct KOpsD {
-    float2v a[5], b[5];
+    float2v a[NB], b[NB];
     template <int P>
-    __device__ __forceinline__ void load(const unsigned (&abase)[5], const unsigned (&bbase)[5]) {
+    __device__ __forceinline__ void load(const unsigned (&abase)[NB], const unsigned (&bbase)[NB]) {
 #pragma unroll
-        for (int e = 0; e < 5; ++e) a[e] = lds_read2st64<16 * P, 16 * P + 8>(abase[e]);
+        for (int e = 0; e < NB; ++e) a[e] = lds_read2st64<16 * P, 16 * P + 8>(abase[e]);
 #pragma unroll
-        for (int e = 0; e < 5; ++e) b[e] = lds_read2st64<16 * P, 16 * P + 8>(bbase[e]);
+        for (int e = 0; e < NB; ++e) b[e] = lds_read2st64<16 * P, 16 * P + 8>(bbase[e]);
     }
 };
 
-template <int FIRST, int LAST>
-__device__ __forceinline__ void gram_mfma_d(const KOpsD &o, floatx16 (&acc)[5]) {
+template <int NB, int FIRST, int LAST>
+__device__ __forceinline__ void gram_mfma_d(const KOpsD<NB> &o, floatx16 (&acc)[NB]) {
 #pragma unroll
     for (int q = FIRST; q < LAST; ++q)
-        acc[q % 5] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[q % 5][q / 5], o.b[q % 5][q / 5], acc[q % 5], 0, 0, 0);
+        acc[q % NB] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[q % NB][q / NB], o.b[q % NB][q / NB], acc[q % NB], 0, 0, 0);
 }
 
 #define RR_PAIRD(P, CUR, NXT)                                  \
     lds_wait();                                                \
     __builtin_amdgcn_sched_barrier(0);                         \
-    gram_mfma_d<0, 1>(CUR, acc);                               \
+    gram_mfma_d<NB, 0, 1>(CUR, acc);                           \
     __builtin_amdgcn_sched_barrier(0);                         \
     if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase); \
     __builtin_amdgcn_sched_barrier(0);                         \
-    gram_mfma_d<1, 10>(CUR, acc);                              \
+    gram_mfma_d<NB, 1, 2 * NB>(CUR, acc);                      \
     __builtin_amdgcn_sched_barrier(0);
 
-__global__ void __launch_bounds__(GR_THREADS, 2)
-rr_syrk_f32_diag_kernel(const SyrkArgs p) {
-    __shared__ float lds[2 * GR_KB * GR_TC];  // 64 KiB: two [32][256] tiles (A side only)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+// Everything a wave does in the diagonal kernel, for its NB blocks (5 for waves 0-3, 4 for waves 4-7: the two
+// waves of a SIMD issue 9 MFMAs per k-step between them, none wasted).
+template <int NB>
+__device__ __forceinline__ void syrk_diag_body(const SyrkArgs &p, float *lds, int wave, int lane) {
     const int ta = blockIdx.x % p.nb;
     const int ks = blockIdx.x / p.nb;
     const int ca = ta * GR_TC;
@@ -567,15 +565,15 @@ rr_syrk_f32_diag_kernel(const SyrkArgs p) {
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const unsigned lane_off = 4u * ((lane >> 5) * GR_TC + (lane & 31));  // row stride 1024 B = 4 units of 256 B
-    int bi[5], bj[5];
+    int bi[NB], bj[NB];
 #pragma unroll
-    for (int e = 0; e < 5; ++e) {
+    for (int e = 0; e < NB; ++e) {
         bi[e] = RR_DIAG_I[wave][e];
         bj[e] = RR_DIAG_J[wave][e];
     }
-    floatx16 acc[5];
+    floatx16 acc[NB];
 #pragma unroll
-    for (int e = 0; e < 5; ++e)
+    for (int e = 0; e < NB; ++e)
 #pragma unroll
         for (int k = 0; k < 16; ++k) acc[e][k] = 0.f;
 
@@ -596,14 +594,14 @@ rr_syrk_f32_diag_kernel(const SyrkArgs p) {
         for (int64_t kb = 0; kb < nkb; ++kb) {
             const int cbuf = (int)(kb & 1);
             if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_TC), row_begin + (kb + 1) * GR_KB);
-            unsigned abase[5], bbase[5];
+            unsigned abase[NB], bbase[NB];
 #pragma unroll
-            for (int e = 0; e < 5; ++e) {
+            for (int e = 0; e < NB; ++e) {
                 abase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bi[e];
                 bbase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bj[e];
             }
-            KOpsD o0, o1;
-            o0.load<0>(abase, bbase);
+            KOpsD<NB> o0, o1;
+            o0.template load<0>(abase, bbase);
             RR_PAIRD(0, o0, o1) RR_PAIRD(1, o1, o0) RR_PAIRD(2, o0, o1) RR_PAIRD(3, o1, o0)
             RR_PAIRD(4, o0, o1) RR_PAIRD(5, o1, o0) RR_PAIRD(6, o0, o1) RR_PAIRD(7, o1, o0)
             __syncthreads();
@@ -612,20 +610,28 @@ rr_syrk_f32_diag_kernel(const SyrkArgs p) {
 
     const int64_t F = p.F;
     const int hi = lane >> 5;
-    const int nblk = wave < 4 ? 5 : 4;  // the 5th block of waves 4-7 is the dummy
 #pragma unroll
-    for (int e = 0; e < 5; ++e) {
-        if (e < nblk) {
-            const int64_t gc = ca + 32 * bj[e] + (lane & 31);
+    for (int e = 0; e < NB; ++e) {
+        const int64_t gc = ca + 32 * bj[e] + (lane & 31);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int64_t gr = ca + 32 * bi[e] + (k & 3) + 8 * (k >> 2) + 4 * hi;
-                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[e][k]);
-            }
+        for (int k = 0; k < 16; ++k) {
+            const int64_t gr = ca + 32 * bi[e] + (k & 3) + 8 * (k >> 2) + 4 * hi;
+            if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[e][k]);
         }
     }
 }
 #undef RR_PAIRD
+
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_f32_diag_kernel(const SyrkArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_TC];  // 64 KiB: two [32][256] tiles (A side only)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave < 4)  // wave-uniform: both paths hit the same barriers
+        syrk_diag_body<5>(p, lds, wave, lane);
+    else
+        syrk_diag_body<4>(p, lds, wave, lane);
+}
 
 // ---------------------------------------------------------------------------------------
 // f64 Gram: G(upper) += P^T P with v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s peak).  Same structure
