@@ -261,7 +261,10 @@ class _DevicePosterior(object):
         base, F = self.acc.ptr.value, self.F
         return tuple(_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
 
-    def _finish_stats(self):
+    def _finish_stats(self, reduce=None):
+        if reduce is not None:  # row-sharded fit: sum the raw statistics of all ranks in place (RCCL)
+            self.dev.sync()
+            reduce(self.acc.ptr.value, self.F * self.F + self.F + 1)
         pG, _, _ = self._stat_ptrs()
         _hip._check(self.dev.lib, self.dev.lib.rr_symmetrize_dev(self.dev.ctx, pG, self.F))
         return float(self.dev.download(self.acc, (1,), np.float64, offset_bytes=(self.F * self.F + self.F) * 8)[0])
@@ -313,12 +316,13 @@ class DeviceFitState(_DevicePosterior):
     def gram(self, lenscale):
         return self.handle.gram_host(self.dX, self.dy, lenscale)
 
-    def gram_device(self, lenscale):
-        """Statistics of this length scale into the resident buffer; returns y^T y."""
+    def gram_device(self, lenscale, reduce=None):
+        """Statistics of this length scale into the resident buffer (summed over ranks by `reduce`); returns
+        y^T y."""
         self.dev.memset(self.acc)
         pG, pb, pt = self._stat_ptrs()
         self.handle.gram_dev(self.dX, self.dy, lenscale, pG, pb, pt)
-        return self._finish_stats()
+        return self._finish_stats(reduce)
 
     def second_pass(self, lenscale, m, C, var):
         sq, T = self.handle.elbo_pass2(self.dX, self.dy, lenscale, m, C)
@@ -538,15 +542,16 @@ class CatFitState(_DevicePosterior):
         for r0 in range(0, self.N, self.chunk):
             yield r0, min(self.chunk, self.N - r0)
 
-    def gram_device(self, hypers):
-        """Statistics of these hyper-parameters into the resident buffer; returns y^T y."""
+    def gram_device(self, hypers, reduce=None):
+        """Statistics of these hyper-parameters into the resident buffer (summed over ranks by `reduce`);
+        returns y^T y."""
         hypers = atleast_list(hypers)
         self.dev.memset(self.acc)
         pG, pb, pt = self._stat_ptrs()
         for r0, rows in self._chunks():
             self._fill(r0, rows, hypers)
             self.fm.gram_into(_hip.DeviceView(self.dy, r0, rows), pG, pb, pt)
-        return self._finish_stats()
+        return self._finish_stats(reduce)
 
     def gram(self, hypers):
         self.gram_device(hypers)

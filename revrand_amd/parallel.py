@@ -76,3 +76,34 @@ def sharded_gram(local_gram, X, y, rank, world, group=None):
     G, b, yty = local_gram(X[start:stop], y[start:stop])
     buf = allreduce_packed(pack_stats(G, b, yty, stop - start), group)
     return unpack_stats(buf, G.shape[0])
+
+
+class _DeviceSpan(object):
+    """A span of float64 device memory owned by librevrand_hip, exposed through ``__cuda_array_interface__`` so
+    that torch can wrap it WITHOUT a copy (torch and the library share one HIP runtime, see _hip.load_library)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_allreduce_available(group=None):
+    """True when a device buffer can be summed over the ranks in place: an initialised nccl (= RCCL) group."""
+    try:
+        import torch
+        import torch.distributed as dist
+    except ImportError:
+        return False
+    return bool(dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+                and torch.cuda.is_available())
+
+
+def allreduce_device(ptr, count, group=None):
+    """Sum `count` float64 values at device address `ptr` over the ranks, in place, with RCCL.  The caller has
+    synchronised its own stream; on return the collective has completed (torch's stream is synchronised)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.as_tensor(_DeviceSpan(ptr, count), device="cuda")
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    torch.cuda.synchronize()

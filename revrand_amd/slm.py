@@ -124,11 +124,20 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         Phi nor dPhi ever materialised, O(F) numbers over PCIe per evaluation."""
         st = self._state
         N = X.shape[0]
-        # posterior on the device (Cholesky + inverse + reductions in HBM) unless the statistics must be summed
-        # over ranks on the host first, rocSOLVER is missing, or RR_POSDEF=host
-        on_dev = (not self.distributed) and hasattr(st, "posterior") and _hip.posterior_available()
+        # posterior on the device (Cholesky + inverse + reductions in HBM) unless rocSOLVER is missing,
+        # RR_POSDEF=host, or the ranks' statistics cannot be summed in HBM (no RCCL group: gloo / CPU tests)
+        on_dev = hasattr(st, "posterior") and _hip.posterior_available()
+        if on_dev and self.distributed:
+            from . import parallel
+            on_dev = parallel.device_allreduce_available()
         if on_dev:
-            yty = st.gram_device(hypers)
+            reduce = None
+            if self.distributed:  # one exchange: [G | b | y^T y] of all row shards, summed in place over xGMI
+                reduce = parallel.allreduce_device
+                if getattr(st, "N_total", None) is None:
+                    st.N_total = int(round(float(parallel.allreduce_host(np.array([float(N)]))[0])))
+                N = st.N_total
+            yty = st.gram_device(hypers, reduce)
             D = st.F
         else:
             PhiPhi, Phiy, yty = st.gram(hypers)
