@@ -142,3 +142,25 @@ def test_all_bases_concatenate_like_reference_test_bases():
     assert bcat.get_dim(X) == P.shape[1]
     grads = list(bcat.grad(X, *hyps))
     assert len(grads) == 10 and all(g.shape[:2] == P.shape for g in grads)   # 6 lenscales + 2x(mean, lenscale)
+
+
+def test_config4_full_width_properties():
+    """BASELINE config 4's width (FastFoodRBF nbases=8192, D=128 -> F=16384), 20k rows, through size-independent
+    properties: unit row norms (cos^2 + sin^2), linearity of the structured projection, the FWHT chain against its
+    dense equivalent through the MFMA feature kernel, and a few rows against the oracle's NumPy chain."""
+    import revrand_amd.basis_functions as bs
+    N, d, nb = 20_000, 128, 8192
+    rs = np.random.RandomState(4)
+    X = rs.randn(N, d).astype(np.float32)
+    b = bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=6)
+    Phi = b.transform(X, 1.3)
+    assert Phi.shape == (N, 2 * nb) and Phi.dtype == np.float64
+    assert np.abs((Phi ** 2).sum(axis=1) - 1.0).max() < 1e-5
+    ff, rff = b._handles()
+    V1, V2 = ff.vx(X[:512], 1.0), ff.vx(X[512:1024], 1.0)
+    V12 = ff.vx(X[:512] + 2 * X[512:1024], 1.0)
+    assert normwise(V12, V1 + 2 * V2) < 1e-5
+    dense = rff.transform(X[:2048], 1.3)                     # W = _makeVX(I) through rr_rff_features_mfma_kernel
+    assert normwise(dense, Phi[:2048]) < 1e-4
+    B, G, PI, S = orc.fastfood_matrices(nb, d, 6)
+    assert normwise(Phi[:64], orc.fastfood_transform(X[:64].astype(np.float64), B, G, PI, S, 1.3)) < 1e-3

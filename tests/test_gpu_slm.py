@@ -470,3 +470,34 @@ print("RESULT" + json.dumps(out))
     assert r.returncode == 0 and line, (r.stdout[-1500:], r.stderr[-3000:])
     res = json.loads(line[0][len("RESULT"):])
     assert normwise(np.array(res["dist"]), np.array(res["single"])) < 1e-6
+
+
+def test_config3_width_concat_gram_properties():
+    """BASELINE config 3's shape at one GPU's share in miniature rows (RandomMatern52 n=4096 + LinearBasis(onescol),
+    D=64 -> F_tot = 8257, 30k rows): the device-assembled Gram through identities that need no CPU oracle --
+    symmetry, cos^2 + sin^2 per frequency, the exact [1, X] block, and shard linearity of the resident fit state."""
+    bs, Parameter, Positive, SLM = _imports()
+    N, d, n = 30_000, 64, 4096
+    rs = np.random.RandomState(2)
+    X = rs.randn(N, d).astype(np.float32).astype(np.float64)
+    y = np.sin(X[:, 0]) + 0.1 * rs.randn(N)
+    cat = bs.RandomMatern52(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
+    ls = np.linspace(0.8, 1.6, d)
+    st = cat.device_fit_state(X, y)
+    G, b, yty = st.gram([ls])
+    F = 2 * n + d + 1
+    assert G.shape == (F, F) and np.array_equal(G, G.T)
+    dg = np.diag(G)
+    assert np.abs(dg[:n] + dg[n:2 * n] - N / n).max() < 2e-5 * (N / n)
+    lin = np.hstack((np.ones((N, 1)), X))
+    assert normwise(G[2 * n:, 2 * n:], lin.T @ lin) < 1e-5 and normwise(b[2 * n:], lin.T @ y) < 1e-5
+    assert abs(yty - y @ y) < 1e-6 * (y @ y)
+    st.release()
+    # shard linearity: two halves through the same code path sum to the whole
+    parts = []
+    for sl in (slice(0, N // 2), slice(N // 2, N)):
+        sts = cat.device_fit_state(X[sl], y[sl])
+        parts.append(sts.gram([ls]))
+        sts.release()
+    assert normwise(parts[0][0] + parts[1][0], G) < 1e-5 and normwise(parts[0][1] + parts[1][1], b) < 1e-5
