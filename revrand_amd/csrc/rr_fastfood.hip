@@ -12,6 +12,8 @@
 // (__shfl_xor -> DPP / ds_bpermute, no barriers) plus register butterflies when d2 > 64, gathers the
 // permutation through a per-wave LDS line, takes cos/sin and streams 2 x d2 outputs.  The transform
 // is bound by the HBM write of Phi (4 (d + 2 d2 k) bytes per row in f32).
+#include <algorithm>
+
 #include "rr_internal.h"
 
 template <typename TC>
@@ -169,6 +171,192 @@ rr_fastfood_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// f32 fast path for d2 = 16 R, R in {1, 2, 4, 8, 16}: one block = 16 lanes (one DPP row) x R registers, element
+// e = lane16 * R + q (lane-major), four blocks side by side in a wave.  The WHT's low log2(R) bits are register
+// butterflies, the next four bits DPP butterflies inside the row (quad_perm for lane bits 0, 1, bank-masked
+// row_shl / row_shr for bits 2, 3) -- no permlane swaps, no LDS; pairs of registers go through the packed f32
+// ALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  x of a row is read once per wave (coalesced) and Phi is written
+// 64 x 4 contiguous floats per store instruction; both change layout through per-wave LDS lines (no barriers:
+// a wave's LDS operations execute in order).  ~2.7x fewer VALU cycles per (row, block) than the lane-minor
+// kernel above (which was issue-bound) -- this one is bound by the HBM write.
+// ---------------------------------------------------------------------------------------------
+typedef float ff2 __attribute__((ext_vector_type(2)));
+
+// d = v[lane ^ M] + t for lane bit M (1, 2, 4, 8) inside a row of 16 lanes, the partner read through the DPP
+// operand of the add itself (v_add_f32_dpp; the builtin route costs a v_mov_b32_dpp plus register copies).
+// M = 4, 8: two adds with complementary bank masks, each writing the lanes whose partner lies in its direction.
+// Hazard: a DPP read needs two wait states after the VALU write of that register; callers keep >= 2
+// instructions between them (NOP2 = true inserts s_nop 1 for the one-register case).
+template <int M, bool NOP2>
+__device__ __forceinline__ float row_add_partner(float v, float t) {
+    float d;
+    if constexpr (NOP2) asm volatile("s_nop 1");
+    if constexpr (M == 1) {
+        asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(v), "v"(t));
+    } else if constexpr (M == 2) {
+        asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=&v"(d) : "v"(v), "v"(t));
+    } else if constexpr (M == 4) {
+        asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:4 row_mask:0xf bank_mask:0x5" : "=&v"(d) : "v"(v), "v"(t));
+        asm volatile("v_add_f32_dpp %0, %1, %2 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(d) : "v"(v), "v"(t));
+    } else {
+        asm volatile("v_add_f32_dpp %0, %1, %2 row_shl:8 row_mask:0xf bank_mask:0x3" : "=&v"(d) : "v"(v), "v"(t));
+        asm volatile("v_add_f32_dpp %0, %1, %2 row_shr:8 row_mask:0xf bank_mask:0xc" : "+v"(d) : "v"(v), "v"(t));
+    }
+    return d;
+}
+
+// stage on lane bit M: v <- partner + sgn * v  (sgn = -1 on lanes whose bit is set)
+template <int M, int R>
+__device__ __forceinline__ void row_stage(float (&v)[R], float sgn) {
+    float t[R];
+    if constexpr (R >= 2) {
+        const ff2 s2 = {sgn, sgn};
+#pragma unroll
+        for (int q = 0; q < R; q += 2) {
+            const ff2 a = {v[q], v[q + 1]};
+            const ff2 o = s2 * a;  // v_pk_mul_f32
+            t[q] = o.x;
+            t[q + 1] = o.y;
+        }
+    } else {
+        t[0] = sgn * v[0];
+    }
+    float dnew[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) dnew[q] = row_add_partner<M, (R < 4)>(v[q], t[q]);
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = dnew[q];
+}
+
+// unnormalised natural-order WHT of the 16 R elements of a block (element = lane16 * R + q)
+template <int R>
+__device__ __forceinline__ void row_fwht(float (&v)[R], const float (&sg)[4]) {
+    // register butterflies: element bits below log2(R)
+    if constexpr (R >= 2) {
+#pragma unroll
+        for (int q = 0; q < R; q += 2) {  // bit 0: pairs inside a register pair
+            const float a = v[q], b = v[q + 1];
+            v[q] = a + b;
+            v[q + 1] = a - b;
+        }
+    }
+#pragma unroll
+    for (int st = 2; st < R; st <<= 1) {  // bits 1..: whole register pairs, packed
+#pragma unroll
+        for (int q = 0; q < R; q += 2) {
+            if (!(q & st)) {
+                const ff2 a = {v[q], v[q + 1]}, b = {v[q | st], v[(q | st) + 1]};
+                const ff2 su = a + b, di = a - b;
+                v[q] = su.x; v[q + 1] = su.y;
+                v[q | st] = di.x; v[(q | st) + 1] = di.y;
+            }
+        }
+    }
+    row_stage<1, R>(v, sg[0]);
+    row_stage<2, R>(v, sg[1]);
+    row_stage<4, R>(v, sg[2]);
+    row_stage<8, R>(v, sg[3]);
+}
+
+template <int R, bool PHI, typename TX, typename TO>
+__global__ void __launch_bounds__(256)
+rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int k, const float *__restrict__ Bm,
+                     const float *__restrict__ Gm, const int *__restrict__ PIm, const float *__restrict__ Sm,
+                     const float *__restrict__ invls, TO *__restrict__ out, int64_t ldo, float scale,
+                     int rows_per_block) {
+    constexpr int D2 = 16 * R;
+    constexpr int WC = 4 * D2;                 // output columns of a wave (its 4 blocks are adjacent)
+    constexpr int VW = R >= 4 ? 4 : R;         // floats per lane and store instruction
+    constexpr int NT = R / VW;                 // store instructions per lane and half (cos / sin)
+    typedef float fvec __attribute__((ext_vector_type(VW)));
+    __shared__ __attribute__((aligned(16))) float perm[4][WC];
+    __shared__ __attribute__((aligned(16))) float stage[4][PHI ? 2 : 1][WC];
+    __shared__ __attribute__((aligned(16))) float xline[4][D2 < 64 ? 64 : D2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, sub = lane >> 4;
+    const int jb = (blockIdx.x * 4 + wave) * 4;        // first FastFood block of this wave
+    const int j = jb + sub;                            // block of this DPP row
+    const bool active = j < k;
+    const int n = D2 * k;
+    const int e0 = l16 * R;                            // first element of this lane
+
+    float Lv[R], Gv[R], Sv[R];
+    int Pv[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const size_t idx = (size_t)(active ? j : 0) * D2 + e0 + q;
+        Lv[q] = (e0 + q < d ? invls[e0 + q] : 0.f) * Bm[idx];  // +-1 diagonal folded into 1/l
+        Gv[q] = Gm[idx];
+        Sv[q] = Sm[idx];  // S * d2^-1.5 (/ 2 pi when PHI: phase in revolutions)
+        Pv[q] = PIm[idx];
+    }
+    float sg[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sg[b] = (l16 >> b) & 1 ? -1.f : 1.f;
+    float *line = perm[wave] + sub * D2;
+
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    // x of a row is read once per wave, coalesced (lane i takes elements i, i + 64, ...: the 4 blocks of the wave
+    // share it), one row ahead, and handed to the lanes' R-element layout through an LDS line
+    constexpr int XL = (D2 + 63) / 64;
+    float xg[XL];
+#pragma unroll
+    for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d && r0 < r1) ? (float)X[r0 * ldx + u * 64 + lane] : 0.f;
+    float *xl = xline[wave];
+    for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int u = 0; u < XL; ++u)
+            if (u * 64 + lane < D2) xl[u * 64 + lane] = xg[u];
+        if (r + 1 < r1) {
+#pragma unroll
+            for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d) ? (float)X[(r + 1) * ldx + u * 64 + lane] : 0.f;
+        }
+        float v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = xl[e0 + q] * Lv[q];
+        row_fwht<R>(v, sg);
+#pragma unroll
+        for (int q = 0; q < R; ++q) line[e0 + q] = v[q];
+        // same wave wrote and reads: LDS operations of a wave execute in order
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = line[Pv[q]] * Gv[q];
+        row_fwht<R>(v, sg);
+        // the lane's R contiguous outputs go through an LDS line of the wave so that every global store
+        // instruction writes 64 x VW contiguous floats instead of 16 separate R-float pieces
+        float *st0 = stage[wave][0] + sub * D2 + e0;
+        if (PHI) {
+            float *st1 = stage[wave][1] + sub * D2 + e0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                float s1, c1;
+                ff_sincos_rev<float>(v[q] * Sv[q], s1, c1);
+                st0[q] = c1 * scale;
+                st1[q] = s1 * scale;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) st0[q] = v[q] * Sv[q];
+        }
+        TO *orow = out + r * ldo + (int64_t)jb * D2;
+#pragma unroll
+        for (int half = 0; half < (PHI ? 2 : 1); ++half) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = (t * 64 + lane) * VW;
+                const fvec val = *reinterpret_cast<const fvec *>(stage[wave][half] + c);
+                if (jb * D2 + c < n) {
+                    TO *o = orow + (half ? n : 0) + c;
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) o[u] = (TO)val[u];
+                }
+            }
+        }
+    }
+}
+
 // mathfun.linalg.hadamard: rows x n (n = 2^p <= 4096), natural order, normalised by 1/n; optional
 // sequency reordering (linalg.py:223-236).  One workgroup per row, butterflies in LDS.
 template <typename TC>
@@ -225,6 +413,34 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
     const TC *Sm = (const TC *)(f32 ? (void *)(PHI ? b->ffSrev32 : b->ffSrad32) : (void *)(PHI ? b->ffSrev64 : b->ffSrad64));
     const TC *Lm = (const TC *)(f32 ? (void *)b->ffL32 : (void *)b->ffL64);
     const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    if constexpr (sizeof(TC) == 4) {  // lane-major packed kernel: one block per DPP row of 16 lanes
+        static const bool old_kernel = getenv("RR_FASTFOOD_OLD") != nullptr;
+        if (!old_kernel && d2 >= 16 && d2 <= 256) {
+            const unsigned gx16 = (unsigned)((k + 15) / 16);
+            // whole rounds of workgroups: 6 fit a CU (~80 VGPRs, 26 KiB LDS at d2 = 128); rows per workgroup so that the grid is
+            // m x (CUs x 6) with at most 512 rows each
+            const int64_t per = std::max<int64_t>(1, (int64_t)c->num_cu * 6 / gx16);  // row blocks per round
+            const int64_t m = std::max<int64_t>(1, (N + per * 512 - 1) / (per * 512));
+            int64_t rp = (N + per * m - 1) / (per * m);
+            if (rp < 4) rp = 4;
+            if ((N + rp - 1) / rp > 65535) rp = (N + 65534) / 65535;
+            const dim3 g16(gx16, (unsigned)((N + rp - 1) / rp));
+#define RR_FF16(RR)                                                                                                  \
+    hipLaunchKernelGGL((rr_fastfood16_kernel<RR, PHI, TX, TO>), g16, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
+                       b->d, k, (const float *)Bm, (const float *)Gm, b->ffPI, (const float *)Sm, (const float *)Lm, \
+                       (TO *)dOut, ldo, (float)scale, (int)rp)
+            switch (d2 / 16) {
+                case 1: RR_FF16(1); break;
+                case 2: RR_FF16(2); break;
+                case 4: RR_FF16(4); break;
+                case 8: RR_FF16(8); break;
+                default: RR_FF16(16); break;
+            }
+#undef RR_FF16
+            RR_CHECK_HIP(hipGetLastError());
+            return RR_OK;
+        }
+    }
 #define RR_FF(RR)                                                                                              \
     hipLaunchKernelGGL((rr_fastfood_kernel<RR, PHI, TX, TC, TO>), grid, dim3(256), 0, c->stream, (const TX *)dX, N, \
                        ldx, b->d, d2, k, Bm, Gm, b->ffPI, Sm, Lm, (TO *)dOut, ldo, scale, (int)rpb)
