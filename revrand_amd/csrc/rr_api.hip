@@ -80,6 +80,10 @@ void rr_ctx_destroy(rr_ctx *ctx) {
     }
     if (ctx->tile_map) (void)hipFree(ctx->tile_map);
     rr_posdef_scratch_free(ctx->posdef);
+    for (int i = 0; i < 2; ++i) {
+        if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
+        if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
+    }
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -281,3 +285,102 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     b->ls_cache.assign(lenscale, lenscale + n_ls);
     return RR_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// rr_host_sink (rr_internal.h)
+// ---------------------------------------------------------------------------------------------
+#include <thread>
+
+static void sink_spread(char *dst, size_t dst_ld, const char *src, size_t rows, size_t row_bytes) {
+    const size_t total = rows * row_bytes;
+    unsigned T = std::thread::hardware_concurrency();
+    if (T > 8) T = 8;
+    if (T < 1 || total < ((size_t)8 << 20)) T = 1;
+    auto work = [=](unsigned t) {
+        if (dst_ld == row_bytes) {  // contiguous destination: split the bytes
+            const size_t a = total * t / T, b = total * (t + 1) / T;
+            memcpy(dst + a, src + a, b - a);
+        } else {
+            const size_t a = rows * t / T, b = rows * (t + 1) / T;
+            for (size_t r = a; r < b; ++r) memcpy(dst + r * dst_ld, src + r * row_bytes, row_bytes);
+        }
+    };
+    if (T == 1) {
+        work(0);
+        return;
+    }
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+}
+
+int rr_sink_open(rr_ctx *c, size_t chunk_bytes, rr_host_sink *s) {
+    *s = rr_host_sink();
+    s->c = c;
+    const char *env = getenv("RR_HOST_SINK");
+    if (env && atoi(env) == 0) {
+        s->direct = true;
+        return RR_OK;
+    }
+    if (c->pin_cap < chunk_bytes) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < 2; ++i) {
+            if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+            c->pin[i] = nullptr;
+        }
+        c->pin_cap = 0;
+        if (hipHostMalloc(&c->pin[0], chunk_bytes, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc(&c->pin[1], chunk_bytes, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            for (int i = 0; i < 2; ++i) {
+                if (c->pin[i]) (void)hipHostFree(c->pin[i]);
+                c->pin[i] = nullptr;
+            }
+            s->direct = true;  // no pinned memory to be had: the plain route still works
+            return RR_OK;
+        }
+        c->pin_cap = chunk_bytes;
+    }
+    for (int i = 0; i < 2; ++i)
+        if (!c->pin_ev[i]) RR_CHECK_HIP(hipEventCreateWithFlags(&c->pin_ev[i], hipEventDisableTiming));
+    return RR_OK;
+}
+
+static int sink_flush(rr_host_sink *s) {
+    if (!s->pending) return RR_OK;
+    const int buf = (s->k - 1) & 1;
+    RR_CHECK_HIP(hipEventSynchronize(s->c->pin_ev[buf]));
+    sink_spread(s->dst, s->dst_ld, (const char *)s->c->pin[buf], s->rows, s->row_bytes);
+    s->pending = false;
+    return RR_OK;
+}
+
+int rr_sink_push(rr_host_sink *s, const void *dsrc, void *dst, size_t rows, size_t row_bytes, size_t dst_ld_bytes) {
+    rr_ctx *c = s->c;
+    if (s->direct || rows * row_bytes > c->pin_cap) {
+        int rc = sink_flush(s);
+        if (rc != RR_OK) return rc;
+        RR_CHECK_HIP(hipMemcpy2DAsync(dst, dst_ld_bytes, dsrc, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        return RR_OK;
+    }
+    const int buf = s->k & 1;  // free: chunk k-2 left it during push(k-1)
+    RR_CHECK_HIP(hipMemcpyAsync(c->pin[buf], dsrc, rows * row_bytes, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipEventRecord(c->pin_ev[buf], c->stream));
+    ++s->k;
+    // while that transfer runs, spread the previous chunk
+    if (s->pending) {
+        const int pb = (s->k - 2) & 1;
+        RR_CHECK_HIP(hipEventSynchronize(c->pin_ev[pb]));
+        sink_spread(s->dst, s->dst_ld, (const char *)c->pin[pb], s->rows, s->row_bytes);
+    }
+    s->pending = true;
+    s->dst = (char *)dst;
+    s->rows = rows;
+    s->row_bytes = row_bytes;
+    s->dst_ld = dst_ld_bytes;
+    return RR_OK;
+}
+
+int rr_sink_close(rr_host_sink *s) { return sink_flush(s); }

@@ -505,7 +505,7 @@ static int ff_host_call(rr_basis *b, const void *X, int x_dtype, int64_t N, int6
     if (rc != RR_OK || N == 0) return rc;
     RR_REQUIRE(X != nullptr && out != nullptr, "%s: null buffer", who);
     const size_t xs = ff_dtype_size(x_dtype), os = ff_dtype_size(out_dtype);
-    int64_t chunk = (int64_t)(((size_t)1 << 30) / ((size_t)b->d * xs + (size_t)width * os));
+    int64_t chunk = (int64_t)(((size_t)256 << 20) / ((size_t)b->d * xs + (size_t)width * os));  // pipelined chunks
     if (chunk < 1) chunk = 1;
     if (chunk > N) chunk = N;
     void *dX = nullptr, *dO = nullptr;
@@ -515,22 +515,22 @@ static int ff_host_call(rr_basis *b, const void *X, int x_dtype, int64_t N, int6
         rr_set_error("%s: device allocation failed", who);
         return RR_ERR_OOM;
     }
+    rr_host_sink sink;
+    rc = rr_sink_open(c, (size_t)chunk * width * os, &sink);
     for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
         const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
         hipError_t e = hipMemcpy2DAsync(dX, (size_t)b->d * xs, (const char *)X + (size_t)r0 * ldx * xs, (size_t)ldx * xs,
                                         (size_t)b->d * xs, (size_t)m, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) {
-            rc = ff_dispatch<PHI>(b, dX, x_dtype, m, b->d, dO, out_dtype, width);
-            if (rc != RR_OK) break;
-            e = hipMemcpy2DAsync((char *)out + (size_t)r0 * ldo * os, (size_t)ldo * os, dO, (size_t)width * os,
-                                 (size_t)width * os, (size_t)m, hipMemcpyDeviceToHost, c->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
-            rr_set_error("%s: copy/launch failed: %s", who, hipGetErrorString(e));
+            rr_set_error("%s: upload failed: %s", who, hipGetErrorString(e));
             rc = RR_ERR_HIP;
+            break;
         }
+        rc = ff_dispatch<PHI>(b, dX, x_dtype, m, b->d, dO, out_dtype, width);
+        if (rc != RR_OK) break;
+        rc = rr_sink_push(&sink, dO, (char *)out + (size_t)r0 * ldo * os, (size_t)m, (size_t)width * os, (size_t)ldo * os);
     }
+    if (rc == RR_OK) rc = rr_sink_close(&sink);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(dX);
     (void)hipFree(dO);

@@ -21,6 +21,9 @@ struct rr_ctx {
     int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
     int tile_map_nb = 0;
     void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): rocBLAS handle + small device vectors
+    void *pin[2] = {nullptr, nullptr};  // pinned host double buffer of rr_host_sink (grow-only)
+    size_t pin_cap = 0;
+    hipEvent_t pin_ev[2] = {nullptr, nullptr};
 };
 
 enum rr_kind { RR_KIND_RFF = 0, RR_KIND_FASTFOOD = 1 };
@@ -89,3 +92,18 @@ struct rr_featmat {
     void *pass2 = nullptr;  // FmPass2 scratch, grow-never (sized by max_rows, ld)
 };
 void rr_fm_pass2_free(void *p);
+
+// Device -> caller's (pageable) host memory for the host-buffer entry points: chunk k is copied into one half of a
+// pinned double buffer (full PCIe rate, asynchronous) while chunk k-1 is spread into the caller's array by a few
+// host threads -- hipMemcpy to pageable memory does the same two steps serially on one thread (10-17 GB/s).
+struct rr_host_sink {
+    rr_ctx *c = nullptr;
+    bool direct = false;   // no pinned memory (or RR_HOST_SINK=0): plain hipMemcpy2DAsync
+    int k = 0;             // chunks pushed
+    bool pending = false;  // chunk k-1 is in pin[(k-1)&1], not yet in the caller's array
+    char *dst = nullptr;
+    size_t rows = 0, row_bytes = 0, dst_ld = 0;
+};
+int rr_sink_open(rr_ctx *c, size_t chunk_bytes, rr_host_sink *s);
+int rr_sink_push(rr_host_sink *s, const void *dsrc, void *dst, size_t rows, size_t row_bytes, size_t dst_ld_bytes);
+int rr_sink_close(rr_host_sink *s);

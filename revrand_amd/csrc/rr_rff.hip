@@ -1183,10 +1183,11 @@ struct RowStage {
     int64_t chunk = 0;
 };
 
-static int stage_alloc(rr_basis *b, int x_dtype, int64_t N, size_t extra_row_bytes, RowStage *st) {
+static int stage_alloc(rr_basis *b, int x_dtype, int64_t N, size_t extra_row_bytes, RowStage *st,
+                       size_t budget = (size_t)1 << 30) {
     const size_t xs = dtype_size(x_dtype);
     const size_t row_bytes = (size_t)b->dpad * xs + extra_row_bytes;
-    int64_t chunk = (int64_t)(((size_t)1 << 30) / row_bytes);  // ~1 GiB of device staging
+    int64_t chunk = (int64_t)(budget / row_bytes);  // device staging per chunk (1 GiB unless the caller pipelines)
     if (chunk < 1) chunk = 1;
     if (chunk > N) chunk = N;
     RR_CHECK_HIP(hipMalloc(&st->dX, (size_t)chunk * b->dpad * xs));
@@ -1285,7 +1286,7 @@ int rr_rff_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t
     const size_t os = dtype_size(out_dtype);
     const int64_t F = 2 * (int64_t)b->n;
     RowStage st;
-    rc = stage_alloc(b, x_dtype, N, (size_t)F * os, &st);
+    rc = stage_alloc(b, x_dtype, N, (size_t)F * os, &st, (size_t)256 << 20);  // 256 MiB chunks: pipelined to the host
     if (rc != RR_OK) return rc;
     void *dP = nullptr;
     hipError_t e = hipMalloc(&dP, (size_t)st.chunk * F * os);
@@ -1294,21 +1295,21 @@ int rr_rff_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t
         rr_set_error("rr_rff_transform: device allocation failed");
         return RR_ERR_OOM;
     }
+    rr_host_sink sink;
+    rc = rr_sink_open(c, (size_t)st.chunk * F * os, &sink);
     for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += st.chunk) {
         const int64_t m = (N - r0 < st.chunk) ? N - r0 : st.chunk;
         e = stage_rows(b, st, X, x_dtype, r0, m, ldx);
-        if (e == hipSuccess) {
-            rc = transform_dev_impl(b, st.dX, x_dtype, m, b->dpad, dP, out_dtype, F);
-            if (rc != RR_OK) break;
-            e = hipMemcpy2DAsync((char *)Phi + (size_t)r0 * ldphi * os, (size_t)ldphi * os, dP,
-                                 (size_t)F * os, (size_t)F * os, (size_t)m, hipMemcpyDeviceToHost, c->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
-            rr_set_error("rr_rff_transform: copy/launch failed: %s", hipGetErrorString(e));
+            rr_set_error("rr_rff_transform: upload failed: %s", hipGetErrorString(e));
             rc = RR_ERR_HIP;
+            break;
         }
+        rc = transform_dev_impl(b, st.dX, x_dtype, m, b->dpad, dP, out_dtype, F);
+        if (rc != RR_OK) break;
+        rc = rr_sink_push(&sink, dP, (char *)Phi + (size_t)r0 * ldphi * os, (size_t)m, (size_t)F * os, (size_t)ldphi * os);
     }
+    if (rc == RR_OK) rc = rr_sink_close(&sink);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(st.dX);
     (void)hipFree(dP);
@@ -1330,7 +1331,7 @@ int rr_rff_grad(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx,
     const size_t os = dtype_size(out_dtype);
     const size_t out_row = (size_t)2 * b->n * nout;
     RowStage st;
-    rc = stage_alloc(b, x_dtype, N, out_row * os, &st);
+    rc = stage_alloc(b, x_dtype, N, out_row * os, &st, (size_t)256 << 20);
     if (rc != RR_OK) return rc;
     void *dO = nullptr;
     hipError_t e = hipMalloc(&dO, (size_t)st.chunk * out_row * os);
@@ -1339,21 +1340,21 @@ int rr_rff_grad(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx,
         rr_set_error("rr_rff_grad: device allocation failed");
         return RR_ERR_OOM;
     }
+    rr_host_sink sink;
+    rc = rr_sink_open(c, (size_t)st.chunk * out_row * os, &sink);
     for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += st.chunk) {
         const int64_t m = (N - r0 < st.chunk) ? N - r0 : st.chunk;
         e = stage_rows(b, st, X, x_dtype, r0, m, ldx);
-        if (e == hipSuccess) {
-            rc = grad_dev_impl(b, st.dX, x_dtype, m, b->dpad, dO, out_dtype, nout);
-            if (rc != RR_OK) break;
-            e = hipMemcpyAsync((char *)dPhi + (size_t)r0 * out_row * os, dO, (size_t)m * out_row * os,
-                               hipMemcpyDeviceToHost, c->stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) {
-            rr_set_error("rr_rff_grad: copy/launch failed: %s", hipGetErrorString(e));
+            rr_set_error("rr_rff_grad: upload failed: %s", hipGetErrorString(e));
             rc = RR_ERR_HIP;
+            break;
         }
+        rc = grad_dev_impl(b, st.dX, x_dtype, m, b->dpad, dO, out_dtype, nout);
+        if (rc != RR_OK) break;
+        rc = rr_sink_push(&sink, dO, (char *)dPhi + (size_t)r0 * out_row * os, (size_t)m, out_row * os, out_row * os);
     }
+    if (rc == RR_OK) rc = rr_sink_close(&sink);
     (void)hipStreamSynchronize(c->stream);
     (void)hipFree(st.dX);
     (void)hipFree(dO);
