@@ -124,22 +124,21 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         mx = logNkl.max(axis=0)
         logzk = np.log(np.exp(logNkl - mx).sum(axis=0)) + mx
 
-        dm, dC = np.empty_like(m), np.empty_like(C)
         dlpars = [np.zeros_like(p) for p in lpars_l]
         dolog = (self.__it % LOGITER == 0) or (self.__it == self.maxiter - 1)
         calc_ll = dolog or (self.__it < 0)
         Ell = llsum / L_ + llconst
 
-        for k in range(K):
-            Edmk = Edws[k].sum(axis=0) / L_
-            EdCk = (Edws[k] * e[k] / Sk[k]).sum(axis=0) / L_
-            Nkl_zk = np.exp(logNkl[:, k] - logzk[k])
-            Nkl_zl = np.exp(logNkl[:, k] - logzk)
-            alpha = Nkl_zk + Nkl_zl
-            mkmj = m[:, k][:, np.newaxis] - m
-            iCkCj = 1. / (C[:, k][:, np.newaxis] + C)
-            dm[:, k] = (self.B_ * Edmk - m[:, k] / L + (iCkCj * mkmj).dot(alpha)) / K
-            dC[:, k] = (self.B_ * EdCk - 1. / L + (iCkCj - (mkmj * iCkCj) ** 2).dot(alpha)) / (2 * K)
+        # the reference's loop over the K mixture components (glm.py:238-262), all components at once:
+        Edm = Edws.sum(axis=1).T / L_                                        # D x K   glm.py:309
+        EdC = (Edws * e / Sk).sum(axis=1).T / L_                             # D x K   glm.py:310
+        # alpha[k, l] = N_kl / z_k + N_kl / z_l                                         glm.py:244-246
+        alpha = np.exp(logNkl.T - logzk[:, np.newaxis]) + np.exp(logNkl.T - logzk[np.newaxis, :])
+        mkmj = m[:, :, np.newaxis] - m[:, np.newaxis, :]                     # D x k x l
+        iCkCj = 1. / (C[:, :, np.newaxis] + C[:, np.newaxis, :])
+        dm = (self.B_ * Edm - m / L[:, np.newaxis] + np.einsum("dkl,kl->dk", iCkCj * mkmj, alpha)) / K
+        dC = (self.B_ * EdC - 1. / L[:, np.newaxis]
+              + np.einsum("dkl,kl->dk", iCkCj - (mkmj * iCkCj) ** 2, alpha)) / (2 * K)
         if len(dlpars) > 0:  # only the Gaussian has a likelihood parameter: dp = ((y-f)^2/var^2 - 1/var)/2
             ivar = 1. / lpar
             Edlp = 0.5 * (aux * ivar ** 2 - ivar * len(y) * L_) / L_

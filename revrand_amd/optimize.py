@@ -260,13 +260,28 @@ def _len_data(data):
 
 
 def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
-    """Minibatches by sweeping random permutations of the rows (sgd.py:428-470)."""
-    from .utils import endless_permutations
-    perms = endless_permutations(_len_data(data), random_state)
+    """Minibatches by sweeping random permutations of the rows (sgd.py:428-470).
+
+    The index stream is exactly ``endless_permutations`` (utils/rand.py:7-31) -- a new ``permutation(N)`` is drawn
+    from `random_state` only at the moment the previous one is used up, so the draws interleave with the caller's
+    other uses of the same RandomState as in the reference -- but a batch is cut from the permutation arrays
+    instead of 65 536 ``next()`` calls per step."""
+    from sklearn.utils import check_random_state
+    generator = check_random_state(random_state)
+    N = _len_data(data)
+    perm, pos = np.empty(0, dtype=int), 0
     it = 0
     while it < maxiter:
         it += 1
-        ind = np.array([next(perms) for _ in range(batch_size)])
+        parts, need = [], batch_size
+        while need > 0:
+            if pos == len(perm):
+                perm, pos = generator.permutation(N), 0
+            take = min(need, len(perm) - pos)
+            parts.append(perm[pos:pos + take])
+            pos += take
+            need -= take
+        ind = parts[0] if len(parts) == 1 else np.concatenate(parts)
         yield (data[ind],) if not issequence(data) else [d[ind] for d in data]
 
 
@@ -294,7 +309,7 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
         else:
             obj, grad = fun(x, *(list(batch) + list(args)))
             objs.append(obj)
-        norms.append(np.linalg.norm(grad))
+        norms.append(float(np.sqrt(np.square(grad).sum())))  # np.linalg.norm, without a threaded BLAS call per step
         if bounds is not None:
             xlower = x <= lower
             grad[xlower] = np.minimum(grad[xlower], 0)

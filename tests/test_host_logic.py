@@ -273,3 +273,19 @@ def test_glm_qmatrix_and_clone():
     assert G._reshape_likelihood_args((2., np.arange(3.)), 3)[0].shape == (3,)
     with pytest.raises(ValueError):
         G._reshape_likelihood_args((np.arange(4.),), 3)
+
+
+def test_gen_batch_is_the_endless_permutation_stream():
+    """The vectorised minibatch generator consumes the RandomState exactly like the reference's per-index
+    generator (utils/rand.py:7-31), including draws the caller makes in between (the GLM's randn)."""
+    from revrand_amd.optimize import gen_batch
+    from revrand_amd.utils import endless_permutations
+    N, B = 23, 7
+    rs1, rs2 = np.random.RandomState(3), np.random.RandomState(3)
+    g = gen_batch(np.arange(N), B, maxiter=12, random_state=rs1)
+    p = endless_permutations(N, rs2)
+    for _ in range(12):
+        a = next(g)[0]
+        b = np.array([next(p) for _ in range(B)])
+        assert np.array_equal(a, b)
+        assert rs1.randn() == rs2.randn()
