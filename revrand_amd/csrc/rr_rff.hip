@@ -1002,24 +1002,38 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         RR_CHECK_HIP(hipMemcpy(c->tile_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
         c->tile_map_nb = nb * 2 + od;
     }
-    // K-splits: f32 accumulation over <= 32768 rows per split.  Workgroups of one kernel all cost
-    // the same, so make each kernel's workgroup count a multiple of the CU count (no partial last
-    // round): nsplit = k * lcm(CUs / gcd(CUs, ntiles), CUs / gcd(CUs, nb)), k minimal.
+    // K-splits: f32 accumulation over <= 32768 rows per split.  Workgroups of one kernel all cost the same, so
+    // each kernel gets the split count that makes ITS workgroup count (close to) a multiple of the CU count:
+    // exactly for the off-diagonal kernel (nsplit = k * CUs / gcd(CUs, ntiles), k minimal), by search for the
+    // diagonal one (nb workgroups per split; an odd nb would otherwise force CUs splits on both).
     const int64_t total_tiles = (int64_t)nb * (nb + 1) / 2;
     auto gcd64 = [](int64_t x, int64_t y) { while (y) { const int64_t u = x % y; x = y; y = u; } return x; };
-    int64_t unit = ntiles > 0 ? c->num_cu / gcd64(c->num_cu, ntiles) : 1;
-    if (od) {
-        const int64_t u2 = c->num_cu / gcd64(c->num_cu, nb);
-        unit = unit / gcd64(unit, u2) * u2;
-    }
-    int64_t nsplit = ((rows + 32767) / 32768 + unit - 1) / unit * unit;
+    const int64_t min_splits = (rows + 32767) / 32768;
+    auto rows_per = [&](int64_t ns) { return ((rows + ns - 1) / ns + GR_KB - 1) / GR_KB * GR_KB; };
+    const int64_t unit = ntiles > 0 ? c->num_cu / gcd64(c->num_cu, ntiles) : 1;
+    int64_t nsplit = (min_splits + unit - 1) / unit * unit;
     if (rows / nsplit < 1024) nsplit = (rows + 1023) / 1024;  // small inputs: just cover the rows
     if (nsplit < 1) nsplit = 1;
-    int64_t rps = ((rows + nsplit - 1) / nsplit + GR_KB - 1) / GR_KB * GR_KB;
+    int64_t rps = rows_per(nsplit);
+    int64_t nsplit_d = nsplit, rps_d = rps;
+    if (od) {
+        double best = -1.0;
+        for (int64_t ns = min_splits; ns < min_splits + 96; ++ns) {
+            if (rows / ns < 1024 && ns > 1) break;
+            const int64_t wg = ns * nb, rounds = (wg + c->num_cu - 1) / c->num_cu;
+            const double eff = (double)wg / (double)(rounds * c->num_cu);
+            if (eff > best + 1e-9) {
+                best = eff;
+                nsplit_d = ns;
+            }
+        }
+        rps_d = rows_per(nsplit_d);
+    }
     const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
-    if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
+    if (renv && atoll(renv) >= GR_KB) rps = rps_d = (atoll(renv) / GR_KB) * GR_KB;
     nsplit = (rows + rps - 1) / rps;
-    RR_REQUIRE(nsplit * total_tiles < (int64_t)1 << 31, "gram: grid too large");
+    nsplit_d = (rows + rps_d - 1) / rps_d;
+    RR_REQUIRE(nsplit * total_tiles < (int64_t)1 << 31 && nsplit_d * nb < (int64_t)1 << 31, "gram: grid too large");
     SyrkArgs a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
     a.tile_map = use_map ? c->tile_map : nullptr;
@@ -1028,7 +1042,11 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     if (ntiles > 0)
         hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
-    if (od) hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit * nb)), dim3(GR_THREADS), 0, c->stream, a);
+    if (od) {
+        SyrkArgs ad = a;
+        ad.rows_per_split = rps_d;
+        hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb)), dim3(GR_THREADS), 0, c->stream, ad);
+    }
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
