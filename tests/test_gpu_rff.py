@@ -326,3 +326,36 @@ def test_extreme_lenscale_stays_finite():
     assert np.isfinite(Phi).all() and np.abs(Phi).max() <= 1 / np.sqrt(64) + 1e-6
     G, bb, _ = b.gram(X, y, ls)
     assert np.isfinite(G).all() and np.isfinite(bb).all()
+
+
+@pytest.mark.parametrize("N,d,n", [(1, 1, 1), (3, 2, 1), (31, 1, 5), (33, 9, 3), (257, 17, 129)])
+def test_tiny_and_ragged_shapes_end_to_end(N, d, n):
+    """One row, one frequency, one input dimension, sizes straddling every tile edge: transform, grad, Gram, the
+    second pass and predict_moments against the oracle."""
+    from revrand_amd.btypes import Parameter, Positive
+    rs = np.random.RandomState(N * 1000 + d * 10 + n)
+    X = rs.randn(N, d)
+    y = rs.randn(N)
+    b = _bs().RandomRBF(nbases=n, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive()))
+    ls = np.linspace(0.7, 1.3, d)
+    Phi = orc.rff_transform(X, b.W, ls)
+    dP = orc.rff_grad(X, b.W, ls)
+    assert normwise(b.transform(X, ls), Phi) < 1e-3
+    got = b.grad(X, ls)
+    assert got.shape == dP.shape and normwise(got, dP) < 1e-3
+    G, bv, yty = b.gram(X, y, ls)
+    assert normwise(G, Phi.T @ Phi) < 1e-4 and normwise(bv, Phi.T @ y) < 1e-4 and abs(yty - y @ y) < 1e-6 * max(y @ y, 1e-12)
+    F = 2 * n
+    C = np.linalg.inv(np.eye(F) / 1.3 + Phi.T @ Phi / 0.4)
+    m = C @ (Phi.T @ y) / 0.4
+    st = b.device_fit_state(X, y)
+    sq, dh = st.second_pass(ls, m, C, 0.4)
+    st.release()
+    err = y - Phi @ m
+    slabs = [dP[:, :, i] for i in range(d)] if dP.ndim == 3 else [dP]
+    want = np.array([-(m @ (err @ g) - ((g.T @ Phi) * C).sum()) / 0.4 for g in slabs])
+    scale = np.array([(abs(m @ (err @ g)) + abs(((g.T @ Phi) * C).sum())) / 0.4 for g in slabs])  # the two terms cancel
+    assert abs(sq - err @ err) < 1e-3 * max(err @ err, 1e-9)
+    assert np.all(np.abs(np.atleast_1d(dh) - want) < 5e-3 * scale + 1e-6)
+    Ey, Vf = b.predict_moments(X, ls, m, C)
+    assert normwise(Ey, Phi @ m) < 1e-3 and normwise(Vf, ((Phi @ C) * Phi).sum(axis=1)) < 1e-3
