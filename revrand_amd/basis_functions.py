@@ -306,11 +306,11 @@ class DeviceFitState(_DevicePosterior):
                                would have (slm.py:161-162,193-197), computed without dPhi.
     """
 
-    def __init__(self, handle, W, X, y):
+    def __init__(self, handle, W, X, y, dtype="f32"):
         self.handle, self.W = handle, np.asarray(W, dtype=np.float64)
-        X32 = np.ascontiguousarray(X, dtype=np.float32)
-        self.dX = handle.upload(X32)
-        self.dy = handle.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+        ft = np.float32 if dtype == "f32" else np.float64  # f64 bases keep X, y and every product in float64
+        self.dX = handle.upload(np.ascontiguousarray(X, dtype=ft))
+        self.dy = handle.dev.upload_vector(np.ascontiguousarray(y, dtype=ft))
         self._stats_init(handle.dev, 2 * handle.n)
 
     def gram(self, lenscale):
@@ -662,10 +662,10 @@ class _RandomKernelBasis(_LengthScaleBasis):
 
     @slice_transform
     def device_fit_state(self, X, y):
-        """Upload (X, y) once for a fit; None when this basis cannot serve the fused path (f64 mode)."""
-        if self.dtype != "f32" or X.shape[1] != self.d:
+        """Upload (X, y) once for a fit (float32, or float64 for dtype="f64" bases)."""
+        if X.shape[1] != self.d:
             return None
-        return DeviceFitState(self._handle(), self.W, X, y)
+        return DeviceFitState(self._handle(), self.W, X, y, dtype=self.dtype)
 
     def _dense_handle(self):
         """(RffHandle, W) whose kernels produce this basis' features."""
@@ -679,9 +679,7 @@ class _RandomKernelBasis(_LengthScaleBasis):
 
     @slice_transform
     def predict_moments(self, X, lenscale, m, C):
-        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243); None in f64 mode (host path)."""
-        if self.dtype != "f32":
-            return None
+        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243), in the basis' arithmetic."""
         lenscale = self._check_dim(X.shape[1], lenscale)
         return self._dense_handle()[0].predict(X, lenscale, m, C)
 
@@ -854,9 +852,9 @@ class FastFoodRBF(_LengthScaleBasis):
 
     @slice_transform
     def device_fit_state(self, X, y):
-        if self.dtype != "f32" or X.shape[1] != self.d:
+        if X.shape[1] != self.d:
             return None
-        return DeviceFitState(*self._dense_handle(), X=X, y=y)
+        return DeviceFitState(*self._dense_handle(), X=X, y=y, dtype=self.dtype)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(

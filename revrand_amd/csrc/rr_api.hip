@@ -224,6 +224,7 @@ void rr_basis_destroy(rr_basis *b) {
     if (b->dmu64) (void)hipFree(b->dmu64);
     if (b->zbuf) (void)hipFree(b->zbuf);
     rr_pass2_scratch_free(b->pass2);
+    rr_pass2d_scratch_free(b->pass2d);
     for (hipEvent_t ev : b->events) (void)hipEventDestroy(ev);
     void *ff[] = {b->ffB32, b->ffG32, b->ffSrad32, b->ffSrev32, b->ffL32, b->ffB64, b->ffG64,
                   b->ffSrad64, b->ffSrev64, b->ffL64, b->ffPI};

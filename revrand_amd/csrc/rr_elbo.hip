@@ -718,6 +718,238 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
     return RR_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// The second pass in f64 arithmetic (dtype = "f64" bases): same data flow, f64 features (sincospi), f64 MFMA GEMM
+// (rr_gemm_tn_f64_kernel, rr_rff.hip), f64 epilogues.  Small kernels are written for clarity, not tuned: the pass
+// is bound by the GEMM.
+// ---------------------------------------------------------------------------------------------
+int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
+                             double *P, int64_t ldp);  // rr_rff.hip
+int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
+                          int64_t K, int64_t M, int64_t N);
+
+__global__ void __launch_bounds__(256)
+rr_transpose_f64_kernel(const double *__restrict__ P, int64_t rows, int64_t ldp, double *__restrict__ Pt, int64_t ldt) {
+    __shared__ double tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = r0 + ty + 4 * k;
+        tile[ty + 4 * k][tx] = r < rows ? P[r * ldp + c0 + tx] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Pt[(c0 + ty + 4 * k) * ldt + r0 + tx] = tile[tx][ty + 4 * k];
+}
+
+// one wave per row: dot[r] = P[r] . m;  MODE 1 additionally out[r] = U[r] . P[r]
+template <int MODE>
+__global__ void __launch_bounds__(256)
+rr_rows64_kernel(const double *__restrict__ P, const double *__restrict__ U, const double *__restrict__ mvec, int64_t rows,
+                 int F, int64_t ld, double *__restrict__ dot, double *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const double *q = P + r * ld;
+    double a0 = 0.0, a1 = 0.0;
+    for (int j = lane; j < F; j += 64) {
+        a0 = fma(q[j], mvec[j], a0);
+        if (MODE == 1) a1 = fma(q[j], U[r * ld + j], a1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a0 += __shfl_down(a0, o, 64);
+        if (MODE == 1) a1 += __shfl_down(a1, o, 64);
+    }
+    if (lane == 0) {
+        dot[r] = a0;
+        if (MODE == 1) out[r] = a1;
+    }
+}
+
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_err64_kernel(const TX *__restrict__ y, const double *__restrict__ dot, int64_t N, double *__restrict__ err,
+                double *__restrict__ sq) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    double e = 0.0;
+    if (r < N) {
+        e = (double)y[r] - dot[r];
+        err[r] = e;
+    }
+    double acc = e * e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) unsafeAtomicAdd(sq, part[0] + part[1] + part[2] + part[3]);
+}
+
+template <int DMAX, typename TX>
+__global__ void __launch_bounds__(256)
+rr_grad_t64_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const double *__restrict__ P,
+                   const double *__restrict__ U, int64_t ldp, const double *__restrict__ err,
+                   const double *__restrict__ mvec, int n, int d, double *__restrict__ T, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    const int fc = fvalid ? f : 0;
+    const double mc = mvec[fc], ms = mvec[n + fc];
+    double t[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) t[i] = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const double pc = P[r * ldp + fc], ps = P[r * ldp + n + fc];
+        const double uc = U[r * ldp + fc], us = U[r * ldp + n + fc];
+        const double a = err[r] * (pc * ms - ps * mc) - (pc * us - ps * uc);
+        const TX *xr = X + r * ldx;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) t[i] = fma((double)xr[i], a, t[i]);
+    }
+    if (fvalid) {
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], t[i]);
+    }
+}
+
+// Cp (Fp, Fp) zero padded <- C (F, F), both f64 on the device
+__global__ void __launch_bounds__(256)
+rr_pad_c64_kernel(const double *__restrict__ C, int64_t F, double *__restrict__ Cp, int64_t Fp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Fp * Fp) return;
+    const int64_t r = i / Fp, c = i % Fp;
+    Cp[i] = (r < F && c < F) ? C[r * F + c] : 0.0;
+}
+
+struct Pass2Scratch64 {
+    double *P = nullptr, *Pt = nullptr, *U = nullptr, *Cp = nullptr, *Craw = nullptr, *m = nullptr, *dot = nullptr,
+           *err = nullptr, *acc = nullptr;
+    int64_t chunk = 0, Fp = 0;
+    size_t nacc = 0;
+    void release() {
+        void *q[] = {P, Pt, U, Cp, Craw, m, dot, err, acc};
+        for (void *x : q)
+            if (x) (void)hipFree(x);
+        P = Pt = U = Cp = Craw = m = dot = err = acc = nullptr;
+        chunk = Fp = 0;
+        nacc = 0;
+    }
+};
+
+void rr_pass2d_scratch_free(void *p) {
+    if (!p) return;
+    Pass2Scratch64 *s = (Pass2Scratch64 *)p;
+    s->release();
+    delete s;
+}
+
+template <typename TX>
+static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t N, int64_t ldx, const double *mh,
+                       const double *Ch, double *out0, double *out1, bool c_on_device) {
+    rr_ctx *c = b->ctx;
+    const int F = 2 * b->n, n = b->n;
+    const int64_t Fp = ((int64_t)F + 127) / 128 * 128;
+    int64_t chunk = (int64_t)(((size_t)24 << 30) / ((size_t)24 * Fp));  // P, Pt, U in f64
+    const char *cenv = getenv("RR_PASS2_CHUNK_ROWS");
+    if (cenv && atoll(cenv) >= 128) chunk = atoll(cenv);
+    if (chunk > N) chunk = N;
+    chunk = (chunk + 127) / 128 * 128;
+    if (!b->pass2d) b->pass2d = new Pass2Scratch64();
+    Pass2Scratch64 &s = *(Pass2Scratch64 *)b->pass2d;
+    const size_t nacc = pred ? (size_t)chunk : (size_t)1 + (size_t)b->d * n;
+    if (s.chunk < chunk || s.Fp != Fp || s.nacc < nacc) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        s.release();
+        hipError_t ea = hipMalloc((void **)&s.P, (size_t)chunk * Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Pt, (size_t)Fp * chunk * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.U, (size_t)chunk * Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Cp, (size_t)Fp * Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Craw, (size_t)F * F * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.m, (size_t)Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.dot, (size_t)chunk * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.err, (size_t)chunk * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.acc, nacc * 8);
+        if (ea != hipSuccess) {
+            (void)hipGetLastError();
+            s.release();
+            rr_set_error("pass2 (f64): device allocation failed (%lld rows per chunk)", (long long)chunk);
+            return RR_ERR_OOM;
+        }
+        s.chunk = chunk;
+        s.Fp = Fp;
+        s.nacc = nacc;
+    }
+    chunk = s.chunk;
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemset(s.m, 0, (size_t)Fp * 8));
+    RR_CHECK_HIP(hipMemcpy(s.m, mh, (size_t)F * 8, hipMemcpyHostToDevice));
+    const double *Csrc = Ch;
+    if (!c_on_device) {
+        RR_CHECK_HIP(hipMemcpy(s.Craw, Ch, (size_t)F * F * 8, hipMemcpyHostToDevice));
+        Csrc = s.Craw;
+    }
+    hipLaunchKernelGGL(rr_pad_c64_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, Csrc, (int64_t)F,
+                       s.Cp, Fp);
+    if (!pred) RR_CHECK_HIP(hipMemsetAsync(s.acc, 0, nacc * 8, c->stream));
+    RR_CHECK_HIP(hipGetLastError());
+    int rc = RR_OK;
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
+        const int64_t mrows = (N - r0 < chunk) ? N - r0 : chunk;
+        const int64_t mpad = (mrows + 127) / 128 * 128;
+        const TX *Xc = dX + r0 * ldx;
+        rc = rr_features_rowmajor_f64(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp);
+        if (rc != RR_OK) break;
+        hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
+                           s.P, mrows, Fp, s.Pt, chunk);
+        rc = rr_launch_gemm_tn_f64(c, s.Pt, chunk, s.Cp, Fp, s.U, Fp, Fp, mpad, Fp);
+        if (rc != RR_OK) break;
+        if (pred) {
+            hipLaunchKernelGGL(rr_rows64_kernel<1>, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.U, s.m,
+                               mrows, F, Fp, s.dot, s.acc);
+            RR_CHECK_HIP(hipMemcpyAsync(out0 + r0, s.dot, (size_t)mrows * 8, hipMemcpyDeviceToHost, c->stream));
+            RR_CHECK_HIP(hipMemcpyAsync(out1 + r0, s.acc, (size_t)mrows * 8, hipMemcpyDeviceToHost, c->stream));
+            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        } else {
+            hipLaunchKernelGGL(rr_rows64_kernel<0>, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.U, s.m,
+                               mrows, F, Fp, s.dot, s.acc);
+            hipLaunchKernelGGL(rr_err64_kernel<TX>, dim3((unsigned)((mrows + 255) / 256)), dim3(256), 0, c->stream, dy + r0,
+                               s.dot, mrows, s.err, s.acc);
+            const int fblocks = (n + 255) / 256;
+            int64_t rpb = (mrows * fblocks + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+            if (rpb < 64) rpb = 64;
+            if ((mrows + rpb - 1) / rpb > 65535) rpb = (mrows + 65534) / 65535;
+            const dim3 grid(fblocks, (unsigned)((mrows + rpb - 1) / rpb));
+#define RR_GT64(DM)                                                                                               \
+    hipLaunchKernelGGL((rr_grad_t64_kernel<DM, TX>), grid, dim3(256), 0, c->stream, Xc, mrows, ldx, s.P, s.U, Fp, s.err, \
+                       s.m, n, b->d, s.acc + 1, (int)rpb)
+            switch (b->dpad) {
+                case 8: RR_GT64(8); break;
+                case 16: RR_GT64(16); break;
+                case 32: RR_GT64(32); break;
+                case 64: RR_GT64(64); break;
+                case 128: RR_GT64(128); break;
+                default: rr_set_error("pass2: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+            }
+#undef RR_GT64
+            RR_CHECK_HIP(hipGetLastError());
+            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        }
+    }
+    if (rc == RR_OK && !pred) {
+        std::vector<double> acc(nacc);
+        RR_CHECK_HIP(hipMemcpy(acc.data(), s.acc, nacc * 8, hipMemcpyDeviceToHost));
+        *out0 = acc[0];
+        memcpy(out1, acc.data() + 1, (nacc - 1) * 8);
+    }
+    (void)hipStreamSynchronize(c->stream);
+    return rc;
+}
+
 template <typename TX, typename TE>
 static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ldx, const TE *dE, int64_t lde, double *dT) {
     rr_ctx *c = b->ctx;
@@ -835,6 +1067,10 @@ int rr_rff_elbo_pass2_dev(rr_basis *b, const void *dX, const void *dy, int x_dty
     int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, C, "rr_rff_elbo_pass2_dev");
     if (rc != RR_OK) return rc;
     RR_REQUIRE(dy != nullptr && sqerr != nullptr && T != nullptr, "rr_rff_elbo_pass2_dev: null argument");
+    if (b->compute == RR_F64)
+        return x_dtype == RR_F32
+                   ? pass2_run64<float>(b, false, (const float *)dX, (const float *)dy, N, ldx, m, C, sqerr, T, false)
+                   : pass2_run64<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, C, sqerr, T, false);
     return x_dtype == RR_F32 ? pass2_run<float>(b, false, (const float *)dX, (const float *)dy, N, ldx, m, C, sqerr, T)
                              : pass2_run<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, C, sqerr, T);
 }
@@ -845,6 +1081,10 @@ int rr_rff_elbo_pass2_devc(rr_basis *b, const void *dX, const void *dy, int x_dt
     int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, dC, "rr_rff_elbo_pass2_devc");
     if (rc != RR_OK) return rc;
     RR_REQUIRE(dy != nullptr && sqerr != nullptr && T != nullptr, "rr_rff_elbo_pass2_devc: null argument");
+    if (b->compute == RR_F64)
+        return x_dtype == RR_F32
+                   ? pass2_run64<float>(b, false, (const float *)dX, (const float *)dy, N, ldx, m, dC, sqerr, T, true)
+                   : pass2_run64<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, dC, sqerr, T, true);
     return x_dtype == RR_F32
                ? pass2_run<float>(b, false, (const float *)dX, (const float *)dy, N, ldx, m, dC, sqerr, T, true)
                : pass2_run<double>(b, false, (const double *)dX, (const double *)dy, N, ldx, m, dC, sqerr, T, true);
@@ -855,6 +1095,9 @@ int rr_rff_predict_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int6
     int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, C, "rr_rff_predict_dev");
     if (rc != RR_OK) return rc;
     RR_REQUIRE(Ey != nullptr && Vf != nullptr, "rr_rff_predict_dev: null argument");
+    if (b->compute == RR_F64)
+        return x_dtype == RR_F32 ? pass2_run64<float>(b, true, (const float *)dX, nullptr, N, ldx, m, C, Ey, Vf, false)
+                                 : pass2_run64<double>(b, true, (const double *)dX, nullptr, N, ldx, m, C, Ey, Vf, false);
     return x_dtype == RR_F32 ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, C, Ey, Vf)
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, C, Ey, Vf);
 }

@@ -50,6 +50,7 @@ struct rr_basis {
     size_t events_used = 0;
     const char *gram_kernel = "";
     void *pass2 = nullptr;        // scratch of the second _elbo pass (rr_elbo.hip), grow-only
+    void *pass2d = nullptr;       // the same for f64 arithmetic
     // FastFood (kind == RR_KIND_FASTFOOD): (k, d2) diagonals / permutation, n = d2 * k
     int ff_d2 = 0, ff_k = 0;
     float *ffB32 = nullptr, *ffG32 = nullptr, *ffSrad32 = nullptr, *ffSrev32 = nullptr, *ffL32 = nullptr;
@@ -81,6 +82,7 @@ void rr_set_error(const char *fmt, ...);
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
 int rr_pick_dmax(int d);
 void rr_pass2_scratch_free(void *p);
+void rr_pass2d_scratch_free(void *p);
 void rr_posdef_scratch_free(void *p);
 
 // Device feature matrix of a concatenated basis (rr_featmat.hip; second pass in rr_elbo.hip).

@@ -773,6 +773,72 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
             }
         }
 }
+
+// D[M][N] = A^T B in f64 (second pass of _elbo / predict_moments in f64 arithmetic): A (K, lda) with M columns,
+// B (K, ldb) with N columns, row-major, K % 16 == 0, M % 128 == 0, N % 128 == 0.  The f64 SYRK kernel's tile,
+// operand reads and MFMA schedule with two source matrices, the whole K loop in one workgroup, plain stores.
+struct Gemm64Args {
+    const double *A, *B;
+    double *D;
+    int64_t lda, ldb, ldd;
+    int K, ntb;  // ntb = N / 128
+};
+
+__global__ void __launch_bounds__(G64_THREADS, 2)
+rr_gemm_tn_f64_kernel(const Gemm64Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G64_KB * G64_LDB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ca = (int64_t)(blockIdx.x / p.ntb) * G64_TC;
+    const int cb = (int)(blockIdx.x % p.ntb) * G64_TC;
+    const int wr = wave >> 1, wc_ = wave & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned aoff = (lane >> 4) * G64_LDB + 8u * (wr * 64 + (lane & 15));
+    const unsigned boff = (lane >> 4) * G64_LDB + 8u * (G64_TC + wc_ * 64 + (lane & 15));
+    doublex4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+    auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const double *sa = p.A + (kb0 + lr) * p.lda + ca + 2 * lane;
+            const double *sb = p.B + (kb0 + lr) * p.ldb + cb + 2 * lane;
+            unsigned char *dst = buf + lr * G64_LDB;
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + G64_TC * 8), 16, 0, 0);
+        }
+    };
+    const int nkb = p.K / G64_KB;
+    dma_tile(lds, 0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cbuf = kb & 1;
+        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (G64_KB * G64_LDB), (int64_t)(kb + 1) * G64_KB);
+        const unsigned abase = lds0 + cbuf * (G64_KB * G64_LDB) + aoff;
+        const unsigned bbase = lds0 + cbuf * (G64_KB * G64_LDB) + boff;
+        KOps64 o0, o1;
+        o0.load<0>(abase, bbase);
+        RR_STEP64(0, o0, o1) RR_STEP64(1, o1, o0) RR_STEP64(2, o0, o1) RR_STEP64(3, o1, o0)
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gc = cb + wc_ * 64 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t gr = ca + wr * 64 + i * 16 + (lane >> 4) + 4 * e;
+                p.D[gr * p.ldd + gc] = acc[i][j][e];
+            }
+        }
+}
 #undef RR_STEP64
 
 // Host feature matrices of ANY basis (concatenations, LinearBasis, ...) reach the SYRK kernel
@@ -1068,6 +1134,15 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
     return RR_OK;
 }
 
+int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
+                          int64_t K, int64_t M, int64_t N) {
+    Gemm64Args g;
+    g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)K; g.ntb = (int)(N / G64_TC);
+    hipLaunchKernelGGL(rr_gemm_tn_f64_kernel, dim3((unsigned)((M / G64_TC) * g.ntb)), dim3(G64_THREADS), 0, c->stream, g);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 // TC = float: f32 features + rr_syrk_f32_kernel;  TC = double: f64 features + rr_syrk_f64_kernel
 template <typename TX, typename TC>
 static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, int64_t ldx, double *dG,
@@ -1191,6 +1266,45 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
         default: rr_set_error("features: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
     }
 #undef RR_LF
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// Row-major f64 features of a row block (second pass in f64 arithmetic): VALU feature kernel, sincospi.
+int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
+                             double *P, int64_t ldp) {
+    rr_ctx *c = b->ctx;
+    const int F = 2 * b->n;
+    const double scale = 1.0 / sqrt((double)b->n);
+    if (ldp > F) {
+        const int64_t cnt = mpad * (ldp - F);
+        hipLaunchKernelGGL(rr_zero_padcols_kernel<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
+                           mpad, ldp, F);
+    }
+    const int fblocks = (b->n + 255) / 256;
+    int64_t rpb = 256;
+    if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((mpad + rpb - 1) / rpb));
+#define RR_LF64(DM)                                                                                                 \
+    do {                                                                                                            \
+        if (x_dtype == RR_F32)                                                                                      \
+            hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, float, double>), grid, dim3(256), 0, c->stream,    \
+                               (const float *)dX, (const float *)nullptr, m, mpad, ldx, b->dWs64, b->n, b->npad, P,  \
+                               ldp, (double *)nullptr, scale, (int)rpb);                                             \
+        else                                                                                                        \
+            hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, double, double>), grid, dim3(256), 0, c->stream,   \
+                               (const double *)dX, (const double *)nullptr, m, mpad, ldx, b->dWs64, b->n, b->npad, P, \
+                               ldp, (double *)nullptr, scale, (int)rpb);                                             \
+    } while (0)
+    switch (b->dpad) {
+        case 8: RR_LF64(8); break;
+        case 16: RR_LF64(16); break;
+        case 32: RR_LF64(32); break;
+        case 64: RR_LF64(64); break;
+        case 128: RR_LF64(128); break;
+        default: rr_set_error("features: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+    }
+#undef RR_LF64
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -501,3 +501,54 @@ def test_config3_width_concat_gram_properties():
         parts.append(sts.gram([ls]))
         sts.release()
     assert normwise(parts[0][0] + parts[1][0], G) < 1e-5 and normwise(parts[0][1] + parts[1][1], b) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+def test_resident_elbo_f64_matches_reference(golden, tag):
+    """dtype='f64' with (X, y) resident: f64 features, f64 MFMA Gram, f64 posterior, f64 second pass (f64 MFMA
+    GEMM): every output of `_elbo`, the hyper-gradient included, within the BASELINE fp64 tolerance of the
+    reference's golden values; and predict_moments in f64."""
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    lsp = Parameter(1., Positive()) if tag == "iso" else Parameter(np.ones(d), Positive())
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=lsp, dtype="f64")
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    slm._state = basis.device_fit_state(X, y)
+    assert slm._state is not None
+    ls = float(g[tag + "_ls"]) if tag == "iso" else g[tag + "_ls"]
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), float(g["reg"]), ls)
+    slm._state.release()
+    assert abs(-nelbo - g[tag + "_elbo"]) < 1e-9 * abs(g[tag + "_elbo"])
+    assert normwise(slm.weights_, g[tag + "_m"]) < 1e-8 and normwise(slm.covariance_, g[tag + "_C"]) < 1e-8
+    assert normwise(-ndvar, g[tag + "_dvar"]) < 1e-8
+    assert normwise(-np.atleast_1d(ndreg), g[tag + "_dreg"]) < 1e-8
+    assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 1e-7
+    Xs = np.random.RandomState(3).randn(700, d)
+    Ey, Vf = basis.predict_moments(Xs, ls, slm.weights_, slm.covariance_)
+    Eo, Vo = orc.slm_predict_moments(orc.rff_transform(Xs, basis.W, ls), slm.weights_, slm.covariance_, 0.0)
+    assert normwise(Ey, Eo) < 1e-10 and normwise(Vf, Vo) < 1e-10
+
+
+def test_second_pass_f64_ragged_multi_chunk(monkeypatch):
+    """f64 second pass over several row chunks with ragged sizes against the oracle's dPhi-based formulas."""
+    bs, Parameter, Positive, SLM = _imports()
+    monkeypatch.setenv("RR_PASS2_CHUNK_ROWS", "512")
+    N, d, n = 1333, 7, 75
+    rs = np.random.RandomState(12)
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    basis = bs.RandomMatern32(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()), dtype="f64")
+    ls = np.linspace(0.7, 1.5, d)
+    Phi = orc.rff_transform(X, basis.W, ls)
+    dP = orc.rff_grad(X, basis.W, ls)
+    o = orc.slm_elbo(Phi, y, 0.3, np.full(2 * n, 1.4), slice(None), [dP[:, :, i] for i in range(d)])
+    st = basis.device_fit_state(X, y)
+    G, b, yty = st.gram(ls)
+    sq, dh = st.second_pass(ls, o["m"], o["C"], 0.3)
+    st.release()
+    err = y - Phi @ o["m"]
+    assert normwise(G, Phi.T @ Phi) < 1e-10 and abs(sq - err @ err) < 1e-10 * (err @ err)
+    assert normwise(dh, -np.array(o["dhyp"])) < 1e-8

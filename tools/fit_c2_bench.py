@@ -11,11 +11,12 @@ N, d, n = int(os.environ.get("ROWS", 1_000_000)), 32, int(os.environ.get("NBASES
 rng = np.random.default_rng(0)
 X = rng.standard_normal((N, d), dtype=np.float32)
 y = np.sin(X @ rng.standard_normal(d, dtype=np.float32)).astype(np.float32) + 0.1 * rng.standard_normal(N, dtype=np.float32)
-b = RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+DT = os.environ.get("DTYPE", "f32")
+b = RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()), dtype=DT)
 slm = StandardLinearModel(b)
 slm.obj_ = -np.inf
 slm._state = b.device_fit_state(X, y)
-print("posterior on device:", _hip.posterior_available(), flush=True)
+print("posterior on device:", _hip.posterior_available(), "arithmetic:", DT, flush=True)
 ls = np.ones(d)
 for rep in range(3):
     t0 = time.perf_counter()
