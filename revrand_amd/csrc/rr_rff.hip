@@ -1121,7 +1121,13 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
     const int nb = (int)(ldp / G64_TC);
     const int ntiles = nb * (nb + 1) / 2;
     const int64_t slots = (int64_t)c->num_cu * 2;  // two workgroups per CU
-    int64_t nsplit = (slots * 4 + ntiles - 1) / ntiles;  // ~4 rounds of workgroups
+    // equal-cost workgroups: make their count a multiple of the slots (no partial last round) while a split keeps
+    // >= 2048 rows; otherwise ~4 rounds
+    int64_t g = slots, t = ntiles;
+    while (t) { const int64_t u = g % t; g = t; t = u; }
+    const int64_t unit = slots / g;
+    int64_t nsplit = unit;
+    if (rows / nsplit < 2048) nsplit = (slots * 4 + ntiles - 1) / ntiles;
     if (rows / nsplit < 512) nsplit = (rows + 511) / 512;
     if (nsplit < 1) nsplit = 1;
     const int64_t rps = ((rows + nsplit - 1) / nsplit + G64_KB - 1) / G64_KB * G64_KB;
