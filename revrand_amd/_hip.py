@@ -179,11 +179,18 @@ _solver_ready = None
 RR_ERR_NOT_POSDEF = -6
 
 
-def posterior_available():
-    """True when rr_posterior_dev can run (rocSOLVER loadable and RR_POSDEF != 'host').  As for the HIP runtime, an
-    installed torch's bundled rocBLAS / rocSOLVER are loaded first so that one copy serves the whole process."""
+def posterior_available(F=None):
+    """Should the posterior of an F x F system be formed on the device (rr_posterior_dev)?
+
+    ``RR_POSDEF=host`` never, ``RR_POSDEF=device`` whenever rocSOLVER loads; by default from F >= 1024
+    (``RR_POSDEF_MIN_F``): below that the host LAPACK solve is a few milliseconds and the one-time cost of creating
+    a rocBLAS handle (~2 s) would not pay for itself within one fit.  As for the HIP runtime, an installed torch's
+    bundled rocBLAS / rocSOLVER are loaded first so that one copy serves the whole process."""
     global _solver_ready
-    if os.environ.get("RR_POSDEF", "") == "host":
+    mode = os.environ.get("RR_POSDEF", "")
+    if mode == "host":
+        return False
+    if mode != "device" and F is not None and F < int(os.environ.get("RR_POSDEF_MIN_F", "1024")):
         return False
     if _solver_ready is None:
         lib = load_library()

@@ -348,6 +348,7 @@ def test_posterior_on_device_vs_host_solve_posdef(F):
     from revrand_amd import _hip
     from revrand_amd.linalg import solve_posdef
     assert _hip.posterior_available()
+    assert not _hip.posterior_available(64) and _hip.posterior_available(4096)   # default: only from F >= 1024
     dev = _hip.get_device()
     rs = np.random.RandomState(F)
     A = rs.randn(F, 3 * F)
@@ -385,7 +386,7 @@ def test_elbo_device_posterior_equals_host_posterior(monkeypatch):
     res = []
     for mode in ("device", "host"):
         monkeypatch.setenv("RR_POSDEF", mode)
-        assert _hip.posterior_available() == (mode == "device")
+        assert _hip.posterior_available(80) == (mode == "device")
         cat = bs.RandomRBF(nbases=40, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())) \
             + bs.LinearBasis(onescol=True)
         for basis, reg, hyp in ((cat.bases[0], 1.3, np.full(d, 0.8)), (cat, [1.3, 0.7], np.full(d, 0.8))):
@@ -435,7 +436,8 @@ def test_distributed_elbo_with_rccl_group_keeps_posterior_on_device():
 import os, sys, json
 import numpy as np
 sys.path.insert(0, %r)
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                  RR_POSDEF="device")   # F = 120 here: below the default threshold for the device posterior
 import torch, torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
