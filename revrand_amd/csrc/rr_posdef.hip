@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <cmath>
+#include <mutex>
 
 #include "rr_internal.h"
 
@@ -33,9 +34,10 @@ Solver g_solver;
 
 const int RB_FILL_LOWER = 122;  // rocblas_fill_lower (rocblas-types.h)
 
-bool solver_load() {
+std::once_flag g_solver_once;
+
+void solver_load_once() {
     Solver &s = g_solver;
-    if (s.tried) return s.ok;
     s.tried = true;
     const char *blas_names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
     const char *solver_names[] = {"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"};
@@ -43,14 +45,18 @@ bool solver_load() {
         if ((s.lib_blas = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
     for (const char *nm : solver_names)
         if ((s.lib_solver = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!s.lib_blas || !s.lib_solver) return false;
+    if (!s.lib_blas || !s.lib_solver) return;
     s.create = (fn_create)dlsym(s.lib_blas, "rocblas_create_handle");
     s.destroy = (fn_destroy)dlsym(s.lib_blas, "rocblas_destroy_handle");
     s.set_stream = (fn_set_stream)dlsym(s.lib_blas, "rocblas_set_stream");
     s.potrf = (fn_potr)dlsym(s.lib_solver, "rocsolver_dpotrf");
     s.potri = (fn_potr)dlsym(s.lib_solver, "rocsolver_dpotri");
     s.ok = s.create && s.destroy && s.set_stream && s.potrf && s.potri;
-    return s.ok;
+}
+
+bool solver_load() {
+    std::call_once(g_solver_once, solver_load_once);
+    return g_solver.ok;
 }
 
 }  // namespace
