@@ -174,36 +174,20 @@ def _torch_lib(name):
         return None
 
 
-_solver_ready = None
-
 RR_ERR_NOT_POSDEF = -6
 
 
 def posterior_available(F=None):
     """Should the posterior of an F x F system be formed on the device (rr_posterior_dev)?
 
-    ``RR_POSDEF=host`` never, ``RR_POSDEF=device`` whenever rocSOLVER loads; by default from F >= 1024
-    (``RR_POSDEF_MIN_F``): below that the host LAPACK solve is a few milliseconds and the one-time cost of creating
-    a rocBLAS handle (~2 s) would not pay for itself within one fit.  As for the HIP runtime, an installed torch's
-    bundled rocBLAS / rocSOLVER are loaded first so that one copy serves the whole process."""
-    global _solver_ready
+    ``RR_POSDEF=host`` never, ``RR_POSDEF=device`` always; by default from F >= 256 (``RR_POSDEF_MIN_F``): below
+    that the host LAPACK solve takes well under a millisecond and the device pipeline is launch-bound."""
     mode = os.environ.get("RR_POSDEF", "")
     if mode == "host":
         return False
-    if mode != "device" and F is not None and F < int(os.environ.get("RR_POSDEF_MIN_F", "1024")):
+    if mode != "device" and F is not None and F < int(os.environ.get("RR_POSDEF_MIN_F", "256")):
         return False
-    if _solver_ready is None:
-        lib = load_library()
-        if os.environ.get("RR_HIP_RUNTIME", "") != "system":
-            for name in ("librocblas.so", "librocsolver.so"):
-                cand = _torch_lib(name)
-                if cand:
-                    try:
-                        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-                    except OSError:
-                        pass
-        _solver_ready = bool(lib.rr_posterior_available())
-    return _solver_ready
+    return bool(load_library().rr_posterior_available())
 
 
 def load_library(path=None):

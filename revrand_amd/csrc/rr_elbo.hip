@@ -726,7 +726,7 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
 int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              double *P, int64_t ldp);  // rr_rff.hip
 int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
-                          int64_t K, int64_t M, int64_t N);
+                          int64_t K, int64_t M, int64_t N, int subtract, int upper_only);
 
 __global__ void __launch_bounds__(256)
 rr_transpose_f64_kernel(const double *__restrict__ P, int64_t rows, int64_t ldp, double *__restrict__ Pt, int64_t ldt) {
@@ -906,7 +906,7 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
         if (rc != RR_OK) break;
         hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
                            s.P, mrows, Fp, s.Pt, chunk);
-        rc = rr_launch_gemm_tn_f64(c, s.Pt, chunk, s.Cp, Fp, s.U, Fp, Fp, mpad, Fp);
+        rc = rr_launch_gemm_tn_f64(c, s.Pt, chunk, s.Cp, Fp, s.U, Fp, Fp, mpad, Fp, 0, 0);
         if (rc != RR_OK) break;
         if (pred) {
             hipLaunchKernelGGL(rr_rows64_kernel<1>, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.U, s.m,

@@ -2,78 +2,163 @@
 // C = iC^-1 and the O(F^2) statistics of StandardLinearModel._elbo (slm.py:150-171), so that an L-BFGS
 // evaluation moves O(F) numbers over PCIe instead of two F x F matrices.
 //
-// The factorisation and the inverse are rocSOLVER's dpotrf / dpotri (plain LAPACK routines; bound at run
-// time with dlopen so the library itself links against nothing but the HIP runtime).  Everything around them
-// -- assembling iC, the CHOLTHRESH test of mathfun/linalg.py:31,113, log-determinant, m = C b / var,
-// sum(G o C), diag(C) -- are kernels here.  If the matrix is not safely positive definite the call reports
+// Blocked right-looking Cholesky iC = U^T U (upper, as mathfun/linalg.py:109) and the inverse, all in float64:
+//   per 128-column panel j:  rr_chol_diag_kernel   U_jj = chol(A_jj)          one workgroup, the block in LDS
+//                            rr_trsm_ut_kernel     U_j,> = U_jj^-T A_j,>      one column per thread, registers
+//                            rr_gemm_tn_f64_kernel A_>,> -= U_j,>^T U_j,>     f64 MFMA tiles, upper tiles only
+//   inverse:  Y = U^-T (block forward substitution on the identity: the same two kernels, Y lower triangular),
+//             C = Y^T Y  (rr_syrk_f64_kernel + mirror).
+// Everything is asynchronous on the context's stream; the host reads the factor's diagonal once for log|iC| and
+// the CHOLTHRESH test of linalg.py:31,113.  If the matrix is not safely positive definite the call reports
 // RR_ERR_NOT_POSDEF and the caller takes the reference's SVD route on the host (linalg.py:128-179).
-#include <dlfcn.h>
-
 #include <cmath>
-#include <mutex>
 
 #include "rr_internal.h"
 
-namespace {
+int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
+                          int64_t K, int64_t M, int64_t N, int subtract, int upper_only);             // rr_rff.hip
+int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG);  // rr_rff.hip
 
-typedef void *rb_handle;
-typedef int (*fn_create)(rb_handle *);
-typedef int (*fn_destroy)(rb_handle);
-typedef int (*fn_set_stream)(rb_handle, hipStream_t);
-typedef int (*fn_potr)(rb_handle, int /*rocblas_fill*/, int, double *, int, int *);
+constexpr int PB = 128;  // panel width = the f64 GEMM tile
 
-struct Solver {
-    void *lib_blas = nullptr, *lib_solver = nullptr;
-    fn_create create = nullptr;
-    fn_destroy destroy = nullptr;
-    fn_set_stream set_stream = nullptr;
-    fn_potr potrf = nullptr, potri = nullptr;
-    bool tried = false, ok = false;
-};
-Solver g_solver;
-
-const int RB_FILL_LOWER = 122;  // rocblas_fill_lower (rocblas-types.h)
-
-std::once_flag g_solver_once;
-
-void solver_load_once() {
-    Solver &s = g_solver;
-    s.tried = true;
-    const char *blas_names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"};
-    const char *solver_names[] = {"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"};
-    for (const char *nm : blas_names)
-        if ((s.lib_blas = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
-    for (const char *nm : solver_names)
-        if ((s.lib_solver = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
-    if (!s.lib_blas || !s.lib_solver) return;
-    s.create = (fn_create)dlsym(s.lib_blas, "rocblas_create_handle");
-    s.destroy = (fn_destroy)dlsym(s.lib_blas, "rocblas_destroy_handle");
-    s.set_stream = (fn_set_stream)dlsym(s.lib_blas, "rocblas_set_stream");
-    s.potrf = (fn_potr)dlsym(s.lib_solver, "rocsolver_dpotrf");
-    s.potri = (fn_potr)dlsym(s.lib_solver, "rocsolver_dpotri");
-    s.ok = s.create && s.destroy && s.set_stream && s.potrf && s.potri;
-}
-
-bool solver_load() {
-    std::call_once(g_solver_once, solver_load_once);
-    return g_solver.ok;
-}
-
-}  // namespace
-
-// A = G / var + diag(iL)
+// W (Fp, Fp) = G / var + diag(iL) in the top-left F x F, identity on the pad diagonal
 __global__ void __launch_bounds__(256)
-rr_assemble_ic_kernel(const double *__restrict__ G, const double *__restrict__ iL, double ivar, int64_t F,
-                      double *__restrict__ A) {
+rr_assemble_ic_kernel(const double *__restrict__ G, const double *__restrict__ iL, double ivar, int64_t F, int64_t Fp,
+                      double *__restrict__ W) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= F * F) return;
-    const int64_t r = i / F, c = i % F;
-    A[i] = G[i] * ivar + (r == c ? iL[r] : 0.0);
+    if (i >= Fp * Fp) return;
+    const int64_t r = i / Fp, c = i % Fp;
+    double v = 0.0;
+    if (r < F && c < F)
+        v = G[r * F + c] * ivar + (r == c ? iL[r] : 0.0);
+    else if (r == c)
+        v = 1.0;
+    W[i] = v;
 }
 
-__global__ void __launch_bounds__(256) rr_get_diag_kernel(const double *__restrict__ A, int64_t F, double *__restrict__ d) {
+__global__ void __launch_bounds__(256) rr_set_identity_kernel(double *Y, int64_t Fp) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < F) d[i] = A[i * F + i];
+    if (i < Fp * Fp) Y[i] = (i / Fp == i % Fp) ? 1.0 : 0.0;
+}
+
+__global__ void __launch_bounds__(256) rr_get_diag_kernel(const double *__restrict__ A, int64_t n, int64_t ld, double *__restrict__ d) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) d[i] = A[i * ld + i];
+}
+
+// C (F, F) <- top-left of Cp (Fp, Fp)
+__global__ void __launch_bounds__(256)
+rr_extract_kernel(const double *__restrict__ Cp, int64_t Fp, double *__restrict__ C, int64_t F) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < F * F) C[i] = Cp[(i / F) * Fp + (i % F)];
+}
+
+// In-place upper Cholesky of one 128 x 128 diagonal block (row-major, leading dimension ld): A = U^T U, the strict
+// lower part of the block is zeroed.  Right-looking and unblocked, but the block lives in REGISTERS: the 256
+// threads form a 16 x 16 grid, thread (ty, tx) owns the 8 x 8 elements (16 i + ty, 16 j + tx); per step k only
+// row k travels through LDS (written by its 16 owners, read by everybody), the rank-1 update is 64 predicated
+// FMAs on registers.  (The first version kept the block in LDS and updated it in place: 300 us per block, all of it
+// LDS read-modify-write latency; this one is bound by its 2 barriers per step.)  A non-positive pivot is replaced
+// by 1 and flagged through negative diagonal entries so that the host sees it in the diagonal it reads anyway.
+__global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ A, int64_t ld) {
+    __shared__ double rowbuf[2][PB];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    if (tid == 0) bad = 0;
+    double a[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[i][j] = A[(int64_t)(16 * i + ty) * ld + 16 * j + tx];
+#pragma unroll
+    for (int ki = 0; ki < 8; ++ki) {
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 16 * ki + kk;
+            double *rb = rowbuf[k & 1];  // double-buffered: one barrier per step is enough
+            if (ty == kk) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) rb[16 * j + tx] = a[ki][j];
+            }
+            __syncthreads();
+            double akk = rb[k];
+            if (!(akk > 0.0) || !isfinite(akk)) {  // uniform
+                if (tid == 0) bad = 1;
+                akk = 1.0;
+            }
+            const double dk = sqrt(akk), inv = 1.0 / dk;
+            double ur[8], uc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ur[i] = rb[16 * i + ty] * inv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) uc[j] = rb[16 * j + tx] * inv;
+            if (ty == kk) {  // row k becomes U[k][:]
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * j + tx;
+                    if (c == k) a[ki][j] = dk;
+                    else if (c > k) a[ki][j] = uc[j];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (i < ki) continue;  // rows 16 i + ty <= k
+                const int r = 16 * i + ty;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = 16 * j + tx;
+                    if (r > k && c >= r) a[i][j] = fma(-ur[i], uc[j], a[i][j]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * i + ty, c = 16 * j + tx;
+            double v = c >= r ? a[i][j] : 0.0;
+            if (bad && r == c) v = -1.0;
+            A[(int64_t)r * ld + c] = v;
+        }
+}
+
+// B <- U^-T B for an upper triangular 128 x 128 U (leading dimension ldu) and B (128, ncols) (leading dimension
+// ldb), in place: forward substitution on U^T, one column per thread, 32 rows at a time in registers; the entries
+// of U are wave-uniform (scalar loads).  The work is tiny and purely latency: the loop over solved rows is
+// unrolled so that its loads are in flight together, the reciprocals of the diagonal are taken off the chain.
+__global__ void __launch_bounds__(64)
+rr_trsm_ut_kernel(const double *__restrict__ U, int64_t ldu, double *__restrict__ B, int64_t ldb, int64_t ncols) {
+    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool valid = c < ncols;
+    const int64_t cc = valid ? c : 0;
+    for (int q = 0; q < PB / 32; ++q) {
+        double b[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) b[r] = B[(int64_t)(32 * q + r) * ldb + cc];
+#pragma unroll 8
+        for (int k = 0; k < 32 * q; ++k) {  // rows solved in earlier chunks
+            const double xk = B[(int64_t)k * ldb + cc];
+            const double *urow = U + (int64_t)k * ldu + 32 * q;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) b[r] = fma(-urow[r], xk, b[r]);
+        }
+        double rinv[32];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) rinv[r] = 1.0 / U[(int64_t)(32 * q + r) * (ldu + 1)];
+#pragma unroll
+        for (int r = 0; r < 32; ++r) {
+            const double *urow = U + (int64_t)(32 * q + r) * ldu + 32 * q;
+            b[r] = b[r] * rinv[r];
+#pragma unroll
+            for (int r2 = r + 1; r2 < 32; ++r2) b[r2] = fma(-urow[r2], b[r], b[r2]);
+        }
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < 32; ++r) B[(int64_t)(32 * q + r) * ldb + c] = b[r];
+        }
+    }
 }
 
 // one wave per row r:  m[r] = (C[r,:] . b) / var,  tr += C[r,:] . G[r,:],  dg[r] = C[r][r]
@@ -103,25 +188,28 @@ rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict_
 }
 
 struct PosdefScratch {
-    rb_handle handle = nullptr;
-    double *diL = nullptr, *dvec = nullptr;  // dvec: [chol diag (F) | m (F) | diagC (F) | tr (1)]
-    int *dinfo = nullptr;
-    int64_t F = 0;
+    double *W = nullptr, *Y = nullptr, *Cp = nullptr;  // (Fp, Fp) each
+    double *diL = nullptr, *dvec = nullptr;            // dvec: [chol diag (Fp) | m (F) | diagC (F) | tr (1)]
+    int64_t Fp = 0;
+    void release() {
+        void *q[] = {W, Y, Cp, diL, dvec};
+        for (void *x : q)
+            if (x) (void)hipFree(x);
+        W = Y = Cp = diL = dvec = nullptr;
+        Fp = 0;
+    }
 };
 
 void rr_posdef_scratch_free(void *p) {
     if (!p) return;
     PosdefScratch *s = (PosdefScratch *)p;
-    if (s->handle && g_solver.ok) g_solver.destroy(s->handle);
-    if (s->diL) (void)hipFree(s->diL);
-    if (s->dvec) (void)hipFree(s->dvec);
-    if (s->dinfo) (void)hipFree(s->dinfo);
+    s->release();
     delete s;
 }
 
 extern "C" {
 
-int rr_posterior_available(void) { return solver_load() ? 1 : 0; }
+int rr_posterior_available(void) { return 1; }
 
 int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, const double *iL, double var, double *dC,
                      double *m, double *diagC, double *scal) {
@@ -129,46 +217,63 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
                    diagC != nullptr && scal != nullptr,
                "rr_posterior_dev: null argument");
     RR_REQUIRE(F >= 1 && F < 46340 && var > 0.0 && std::isfinite(var), "rr_posterior_dev: bad F or var");
-    if (!solver_load()) {
-        rr_set_error("rr_posterior_dev: rocSOLVER (librocsolver.so / librocblas.so) could not be loaded: %s", dlerror());
-        return RR_ERR_UNSUPPORTED;
-    }
     RR_CHECK_HIP(hipSetDevice(c->device));
+    const int64_t Fp = (F + PB - 1) / PB * PB, nblk = Fp / PB;
     if (!c->posdef) c->posdef = new PosdefScratch();
     PosdefScratch &s = *(PosdefScratch *)c->posdef;
-    if (!s.handle) {
-        if (g_solver.create(&s.handle) != 0 || g_solver.set_stream(s.handle, c->stream) != 0) {
-            rr_set_error("rr_posterior_dev: rocblas_create_handle failed");
-            s.handle = nullptr;
-            return RR_ERR_HIP;
-        }
-    }
-    if (s.F < F) {
+    if (s.Fp != Fp) {  // sized exactly: the matrices are dense (Fp, Fp)
         RR_CHECK_HIP(hipStreamSynchronize(c->stream));
-        if (s.diL) (void)hipFree(s.diL);
-        if (s.dvec) (void)hipFree(s.dvec);
-        s.diL = s.dvec = nullptr;
-        s.F = 0;
-        RR_CHECK_HIP(hipMalloc((void **)&s.diL, (size_t)F * 8));
-        RR_CHECK_HIP(hipMalloc((void **)&s.dvec, (size_t)(3 * F + 1) * 8));
-        if (!s.dinfo) RR_CHECK_HIP(hipMalloc((void **)&s.dinfo, sizeof(int)));
-        s.F = F;
+        s.release();
+        hipError_t ea = hipMalloc((void **)&s.W, (size_t)Fp * Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Y, (size_t)Fp * Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Cp, (size_t)Fp * Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.diL, (size_t)Fp * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.dvec, (size_t)(3 * Fp + 1) * 8);
+        if (ea != hipSuccess) {
+            (void)hipGetLastError();
+            s.release();
+            rr_set_error("rr_posterior_dev: device allocation failed (F = %lld)", (long long)F);
+            return RR_ERR_OOM;
+        }
+        s.Fp = Fp;
     }
+    const int64_t ld = Fp;
     const double ivar = 1.0 / var;
     RR_CHECK_HIP(hipMemcpyAsync(s.diL, iL, (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
-    const unsigned eb = (unsigned)((F * F + 255) / 256), fb = (unsigned)((F + 255) / 256);
-    hipLaunchKernelGGL(rr_assemble_ic_kernel, dim3(eb), dim3(256), 0, c->stream, dG, s.diL, ivar, F, dC);
+    const unsigned eb = (unsigned)((Fp * Fp + 255) / 256);
+    hipLaunchKernelGGL(rr_assemble_ic_kernel, dim3(eb), dim3(256), 0, c->stream, dG, s.diL, ivar, F, Fp, s.W);
+    hipLaunchKernelGGL(rr_set_identity_kernel, dim3(eb), dim3(256), 0, c->stream, s.Y, Fp);
     RR_CHECK_HIP(hipGetLastError());
-    // column-major "lower" == the upper triangle of our row-major symmetric matrix: iC = U^T U as in linalg.py:109
-    if (g_solver.potrf(s.handle, RB_FILL_LOWER, (int)F, dC, (int)F, s.dinfo) != 0) {
-        rr_set_error("rr_posterior_dev: rocsolver_dpotrf failed");
-        return RR_ERR_HIP;
+    int rc = RR_OK;
+    // ---- factor: W = U^T U (upper triangle of W) ----
+    for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
+        double *Ujj = s.W + j * PB * (ld + 1);
+        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ujj, ld);
+        const int64_t rest = Fp - (j + 1) * PB;
+        if (rest > 0) {
+            double *panel = Ujj + PB;  // block row j, columns right of the diagonal block
+            hipLaunchKernelGGL(rr_trsm_ut_kernel, dim3((unsigned)((rest + 63) / 64)), dim3(64), 0, c->stream, Ujj, ld, panel,
+                               ld, rest);
+            rc = rr_launch_gemm_tn_f64(c, panel, ld, panel, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 1);
+        }
     }
-    hipLaunchKernelGGL(rr_get_diag_kernel, dim3(fb), dim3(256), 0, c->stream, dC, F, s.dvec);
-    int info = 0;
-    std::vector<double> h((size_t)3 * F + 1);
-    RR_CHECK_HIP(hipMemcpyAsync(&info, s.dinfo, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)F * 8, hipMemcpyDeviceToHost, c->stream));
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_get_diag_kernel, dim3((unsigned)((Fp + 255) / 256)), dim3(256), 0, c->stream, s.W, Fp, ld, s.dvec);
+    // ---- Y = U^-T by block forward substitution on the identity (Y lower triangular) ----
+    for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
+        const double *Ujj = s.W + j * PB * (ld + 1);
+        double *Yj = s.Y + j * PB * ld;
+        const int64_t width = (j + 1) * PB;  // non-zero columns of block row j
+        hipLaunchKernelGGL(rr_trsm_ut_kernel, dim3((unsigned)((width + 63) / 64)), dim3(64), 0, c->stream, Ujj, ld, Yj, ld,
+                           width);
+        const int64_t rest = Fp - (j + 1) * PB;
+        if (rest > 0) rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+    }
+    if (rc != RR_OK) return rc;
+    RR_CHECK_HIP(hipGetLastError());
+    // the diagonal decides before the rest is worth computing
+    std::vector<double> h((size_t)3 * Fp + 1);
+    RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)Fp * 8, hipMemcpyDeviceToHost, c->stream));
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     double logdet = 0.0, mind = INFINITY;
     for (int64_t i = 0; i < F; ++i) {
@@ -182,32 +287,27 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     }
     scal[0] = logdet;
     scal[2] = mind;
-    if (info != 0 || mind < 1e-5) {  // CHOLTHRESH, mathfun/linalg.py:31
-        rr_set_error("rr_posterior_dev: matrix is not safely positive definite (info %d, min diag %g)", info, mind);
+    if (mind < 1e-5) {  // CHOLTHRESH, mathfun/linalg.py:31
+        rr_set_error("rr_posterior_dev: matrix is not safely positive definite (min diag of the factor %g)", mind);
         return RR_ERR_NOT_POSDEF;
     }
-    if (g_solver.potri(s.handle, RB_FILL_LOWER, (int)F, dC, (int)F, s.dinfo) != 0) {
-        rr_set_error("rr_posterior_dev: rocsolver_dpotri failed");
-        return RR_ERR_HIP;
-    }
-    // column-major lower == row-major upper: mirror it into the lower triangle (rr_symmetrize_kernel)
-    int rc = rr_symmetrize_dev(c, dC, F);
+    // ---- C = Y^T Y ----
+    RR_CHECK_HIP(hipMemsetAsync(s.Cp, 0, (size_t)Fp * Fp * 8, c->stream));
+    rc = rr_launch_syrk_f64(c, s.Y, Fp, ld, (int)Fp, s.Cp);  // upper triangle of the (Fp, Fp) product
     if (rc != RR_OK) return rc;
-    double *dm = s.dvec + F, *ddg = s.dvec + 2 * F, *dtr = s.dvec + 3 * F;
+    rc = rr_symmetrize_dev(c, s.Cp, Fp);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_extract_kernel, dim3((unsigned)((F * F + 255) / 256)), dim3(256), 0, c->stream, s.Cp, Fp, dC, F);
+    double *dm = s.dvec + Fp, *ddg = s.dvec + 2 * Fp, *dtr = s.dvec + 3 * Fp;
     RR_CHECK_HIP(hipMemsetAsync(dtr, 0, 8, c->stream));
     hipLaunchKernelGGL(rr_posterior_rows_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream, dC, dG, db, ivar, F,
                        dm, ddg, dtr);
     RR_CHECK_HIP(hipGetLastError());
-    RR_CHECK_HIP(hipMemcpyAsync(h.data() + F, dm, (size_t)(2 * F + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    RR_CHECK_HIP(hipMemcpyAsync(&info, s.dinfo, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(h.data() + Fp, dm, (size_t)(2 * Fp + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
-    if (info != 0) {
-        rr_set_error("rr_posterior_dev: rocsolver_dpotri reported info %d", info);
-        return RR_ERR_NOT_POSDEF;
-    }
-    memcpy(m, h.data() + F, (size_t)F * 8);
-    memcpy(diagC, h.data() + 2 * F, (size_t)F * 8);
-    scal[1] = h[(size_t)3 * F];
+    memcpy(m, h.data() + Fp, (size_t)F * 8);
+    memcpy(diagC, h.data() + 2 * Fp, (size_t)F * 8);
+    scal[1] = h[(size_t)3 * Fp];
     return RR_OK;
 }
 

@@ -782,6 +782,8 @@ struct Gemm64Args {
     double *D;
     int64_t lda, ldb, ldd;
     int K, ntb;  // ntb = N / 128
+    int subtract;    // 1: D -= A^T B (blocked Cholesky updates) instead of D = A^T B
+    int upper_only;  // 1: only tiles with column tile >= row tile (symmetric trailing update, upper triangle kept)
 };
 
 __global__ void __launch_bounds__(G64_THREADS, 2)
@@ -792,6 +794,7 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t ca = (int64_t)(blockIdx.x / p.ntb) * G64_TC;
     const int cb = (int)(blockIdx.x % p.ntb) * G64_TC;
+    if (p.upper_only && cb < ca) return;  // workgroup-uniform
     const int wr = wave >> 1, wc_ = wave & 1;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned aoff = (lane >> 4) * G64_LDB + 8u * (wr * 64 + (lane & 15));
@@ -835,7 +838,10 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int64_t gr = ca + wr * 64 + i * 16 + (lane >> 4) + 4 * e;
-                p.D[gr * p.ldd + gc] = acc[i][j][e];
+                if (p.subtract)
+                    p.D[gr * p.ldd + gc] -= acc[i][j][e];
+                else
+                    p.D[gr * p.ldd + gc] = acc[i][j][e];
             }
         }
 }
@@ -1141,9 +1147,11 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
 }
 
 int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
-                          int64_t K, int64_t M, int64_t N) {
+                          int64_t K, int64_t M, int64_t N, int subtract, int upper_only) {
     Gemm64Args g;
     g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)K; g.ntb = (int)(N / G64_TC);
+    g.subtract = subtract;
+    g.upper_only = upper_only;
     hipLaunchKernelGGL(rr_gemm_tn_f64_kernel, dim3((unsigned)((M / G64_TC) * g.ntb)), dim3(G64_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;

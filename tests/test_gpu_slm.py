@@ -341,14 +341,14 @@ def test_concat_fit_runs_resident_and_predicts():
     assert normwise(Ey, Eo) < 1e-3 and normwise(Vy, Vo) < 1e-2
 
 
-@pytest.mark.parametrize("F", [37, 512, 1300])
+@pytest.mark.parametrize("F", [1, 37, 128, 129, 512, 1300])
 def test_posterior_on_device_vs_host_solve_posdef(F):
     """rr_posterior_dev: C = (diag(iL) + G/var)^-1, m, log|iC|, sum(G o C), diag(C) against the host
     solve_posdef (mathfun/linalg.py:84-125) -- float64 both sides."""
     from revrand_amd import _hip
     from revrand_amd.linalg import solve_posdef
     assert _hip.posterior_available()
-    assert not _hip.posterior_available(64) and _hip.posterior_available(4096)   # default: only from F >= 1024
+    assert not _hip.posterior_available(64) and _hip.posterior_available(4096)   # default: only from F >= 256
     dev = _hip.get_device()
     rs = np.random.RandomState(F)
     A = rs.randn(F, 3 * F)
@@ -397,9 +397,11 @@ def test_elbo_device_posterior_equals_host_posterior(monkeypatch):
             slm._state.release()
             res.append((f, gv, np.atleast_1d(gr), np.atleast_1d(gh), slm.weights_, slm.covariance_))
     for dev_r, host_r in ((res[0], res[2]), (res[1], res[3])):
-        assert abs(dev_r[0] - host_r[0]) < 1e-7 * abs(host_r[0]) and abs(dev_r[1] - host_r[1]) < 1e-6 * abs(host_r[1])
-        assert normwise(dev_r[2], host_r[2]) < 1e-6 and normwise(dev_r[3], host_r[3]) < 1e-4
-        assert normwise(dev_r[4], host_r[4]) < 1e-6 and normwise(dev_r[5], host_r[5]) < 1e-6
+        # (the two evaluations recompute the f32 statistics, whose atomically accumulated last bits differ run to run;
+        # the float64 algebra itself agrees to 1e-9: test_posterior_on_device_vs_host_solve_posdef)
+        assert abs(dev_r[0] - host_r[0]) < 1e-6 * abs(host_r[0]) and abs(dev_r[1] - host_r[1]) < 1e-5 * abs(host_r[1])
+        assert normwise(dev_r[2], host_r[2]) < 1e-5 and normwise(dev_r[3], host_r[3]) < 1e-3
+        assert normwise(dev_r[4], host_r[4]) < 1e-5 and normwise(dev_r[5], host_r[5]) < 1e-5
     monkeypatch.setenv("RR_POSDEF", "device")
     basis = bs.RandomRBF(nbases=40, Xdim=d, random_state=3)
     slm = SLM(basis, nstarts=0, maxiter=40)
