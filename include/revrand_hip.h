@@ -238,8 +238,8 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
  *   dG (F, F) float64 DEVICE, symmetric (after rr_symmetrize_dev), unchanged;  db (F) float64 DEVICE;
  *   iL (F) host float64 = 1 / regularizer_diagonal;  dC (F, F) float64 DEVICE output (full symmetric C).
  *   Host outputs: m (F), diagC (F), scal[3] = { log|iC|, sum(G o C), smallest diagonal entry of the factor }.
- * The factorisation / inverse are rocSOLVER's dpotrf / dpotri, loaded at run time (rr_posterior_available() tells
- * whether they are there).  RR_ERR_NOT_POSDEF when the factorisation fails or its smallest diagonal entry is below
+ * Blocked float64 Cholesky and inverse in hand-written kernels (rr_posdef.hip); rr_posterior_available() is 1.
+ * RR_ERR_NOT_POSDEF when the factorisation meets a non-positive pivot or its smallest diagonal entry is below
  * 1e-5 (CHOLTHRESH, linalg.py:31,113): the caller then takes the reference's SVD route on the host. */
 int rr_posterior_available(void);
 int rr_posterior_dev(rr_ctx *ctx, int64_t F, const double *dG, const double *db, const double *iL, double var,

@@ -3,10 +3,10 @@
 // evaluation moves O(F) numbers over PCIe instead of two F x F matrices.
 //
 // Blocked right-looking Cholesky iC = U^T U (upper, as mathfun/linalg.py:109) and the inverse, all in float64:
-//   per 128-column panel j:  rr_chol_diag_kernel   U_jj = chol(A_jj)          one workgroup, the block in LDS
-//                            rr_trsm_ut_kernel     U_j,> = U_jj^-T A_j,>      one column per thread, registers
-//                            rr_gemm_tn_f64_kernel A_>,> -= U_j,>^T U_j,>     f64 MFMA tiles, upper tiles only
-//   inverse:  Y = U^-T (block forward substitution on the identity: the same two kernels, Y lower triangular),
+//   per 128-column panel j:  rr_chol_diag_kernel   U_jj = chol(A_jj), U_jj^-1  one workgroup, the block in registers
+//                            rr_gemm_tn_f64_kernel U_j,> = U_jj^-T A_j,>       f64 MFMA tiles
+//                            rr_gemm_tn_f64_kernel A_>,> -= U_j,>^T U_j,>      upper tiles only
+//   inverse:  Y = U^-T (block forward substitution on the identity: the same two GEMMs, Y lower triangular),
 //             C = Y^T Y  (rr_syrk_f64_kernel + mirror).
 // Everything is asynchronous on the context's stream; the host reads the factor's diagonal once for log|iC| and
 // the CHOLTHRESH test of linalg.py:31,113.  If the matrix is not safely positive definite the call reports
@@ -53,14 +53,22 @@ rr_extract_kernel(const double *__restrict__ Cp, int64_t Fp, double *__restrict_
     if (i < F * F) C[i] = Cp[(i / F) * Fp + (i % F)];
 }
 
-// In-place upper Cholesky of one 128 x 128 diagonal block (row-major, leading dimension ld): A = U^T U, the strict
-// lower part of the block is zeroed.  Right-looking and unblocked, but the block lives in REGISTERS: the 256
-// threads form a 16 x 16 grid, thread (ty, tx) owns the 8 x 8 elements (16 i + ty, 16 j + tx); per step k only
-// row k travels through LDS (written by its 16 owners, read by everybody), the rank-1 update is 64 predicated
-// FMAs on registers.  (The first version kept the block in LDS and updated it in place: 300 us per block, all of it
-// LDS read-modify-write latency; this one is bound by its 2 barriers per step.)  A non-positive pivot is replaced
-// by 1 and flagged through negative diagonal entries so that the host sees it in the diagonal it reads anyway.
-__global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ A, int64_t ld) {
+// In-place upper Cholesky of one 128 x 128 diagonal block (row-major, leading dimension ld), A = U^T U, AND the
+// inverse of the factor, Uinv = U^-1 (128 x 128, dense leading dimension 128), which turns the two triangular
+// solves of a panel step into MFMA GEMMs.  The strict lower part of the block is zeroed.
+//
+// Right-looking and unblocked, with the block in REGISTERS: the 256 threads form a 16 x 16 grid, thread (ty, tx)
+// owns the 8 x 8 elements (16 i + ty, 16 j + tx); per step p only row p travels through LDS (written by its 16
+// owners, read by everybody) and the rank-1 update is 64 predicated FMAs on registers.  The upper-triangle slots
+// hold the Cholesky work matrix; the otherwise unused LOWER-triangle slots hold W of the forward substitution
+// U^T T = I done in the same right-looking form (T[p,:] = W[p,:] / U[p][p], then W[k,:] -= U[p][k] T[p,:] for
+// k > p): element (r, c), r > p, is updated by -U[p][r] * v[c] with v = U[p][c] in the upper triangle (c >= r) and
+// v = T[p][c] in the lower one (c <= p) -- one loop, one row buffer.  T = U^-T comes out in the lower triangle and
+// is written transposed.  (A first version kept the block in LDS and updated it in place: 300 us per block of LDS
+// read-modify-write latency; per-column triangular solves instead of the inverse: 145 us per call, each column a
+// serial chain of 8192 f64 FMAs.)  A non-positive pivot is replaced by 1 and flagged through negative diagonal
+// entries so that the host sees it in the diagonal it reads anyway.
+__global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ A, int64_t ld, double *__restrict__ Uinv) {
     __shared__ double rowbuf[2][PB];
     __shared__ int bad;
     const int tid = threadIdx.x;
@@ -70,44 +78,49 @@ __global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ 
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a[i][j] = A[(int64_t)(16 * i + ty) * ld + 16 * j + tx];
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * i + ty, c = 16 * j + tx;
+            a[i][j] = c >= r ? A[(int64_t)r * ld + c] : 0.0;  // lower slots: W = strictly lower part of I
+        }
 #pragma unroll
-    for (int ki = 0; ki < 8; ++ki) {
-        for (int kk = 0; kk < 16; ++kk) {
-            const int k = 16 * ki + kk;
-            double *rb = rowbuf[k & 1];  // double-buffered: one barrier per step is enough
-            if (ty == kk) {
+    for (int pi = 0; pi < 8; ++pi) {
+        for (int pk = 0; pk < 16; ++pk) {
+            const int p = 16 * pi + pk;
+            double *rb = rowbuf[p & 1];  // double-buffered: one barrier per step is enough
+            if (ty == pk) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) rb[16 * j + tx] = a[ki][j];
+                for (int j = 0; j < 8; ++j) rb[16 * j + tx] = a[pi][j];  // U part (c > p), pivot, W part (c < p)
             }
             __syncthreads();
-            double akk = rb[k];
-            if (!(akk > 0.0) || !isfinite(akk)) {  // uniform
+            double app = rb[p];
+            if (!(app > 0.0) || !isfinite(app)) {  // uniform
                 if (tid == 0) bad = 1;
-                akk = 1.0;
+                app = 1.0;
             }
-            const double dk = sqrt(akk), inv = 1.0 / dk;
-            double ur[8], uc[8];
+            const double dp = sqrt(app), inv = 1.0 / dp;
+            double ur[8], vc[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ur[i] = rb[16 * i + ty] * inv;
+            for (int i = 0; i < 8; ++i) ur[i] = rb[16 * i + ty] * inv;  // U[p][r] for this thread's rows r > p
 #pragma unroll
-            for (int j = 0; j < 8; ++j) uc[j] = rb[16 * j + tx] * inv;
-            if (ty == kk) {  // row k becomes U[k][:]
+            for (int j = 0; j < 8; ++j) {
+                const int c = 16 * j + tx;
+                vc[j] = c == p ? inv : rb[c] * inv;  // U[p][c] (c > p), T[p][p], T[p][c] (c < p)
+            }
+            if (ty == pk) {  // row p becomes final: U[p][c], and T[p][c] in the lower slots
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = 16 * j + tx;
-                    if (c == k) a[ki][j] = dk;
-                    else if (c > k) a[ki][j] = uc[j];
+                    a[pi][j] = c == p ? dp : vc[j];
                 }
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                if (i < ki) continue;  // rows 16 i + ty <= k
+                if (i < pi) continue;  // rows 16 i + ty <= p
                 const int r = 16 * i + ty;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = 16 * j + tx;
-                    if (r > k && c >= r) a[i][j] = fma(-ur[i], uc[j], a[i][j]);
+                    if (r > p && (c >= r || c <= p)) a[i][j] = fma(-ur[i], vc[j], a[i][j]);
                 }
             }
         }
@@ -118,47 +131,13 @@ __global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = 16 * i + ty, c = 16 * j + tx;
-            double v = c >= r ? a[i][j] : 0.0;
-            if (bad && r == c) v = -1.0;
-            A[(int64_t)r * ld + c] = v;
+            double u = c >= r ? a[i][j] : 0.0;
+            if (bad && r == c) u = -1.0;
+            A[(int64_t)r * ld + c] = u;
+            // Uinv = T^T: T[r][c] sits in the lower slots (c < r), T[r][r] = 1 / U[r][r]
+            if (c < r) Uinv[c * PB + r] = a[i][j];
+            else Uinv[c * PB + r] = (c == r) ? 1.0 / a[i][j] : 0.0;
         }
-}
-
-// B <- U^-T B for an upper triangular 128 x 128 U (leading dimension ldu) and B (128, ncols) (leading dimension
-// ldb), in place: forward substitution on U^T, one column per thread, 32 rows at a time in registers; the entries
-// of U are wave-uniform (scalar loads).  The work is tiny and purely latency: the loop over solved rows is
-// unrolled so that its loads are in flight together, the reciprocals of the diagonal are taken off the chain.
-__global__ void __launch_bounds__(64)
-rr_trsm_ut_kernel(const double *__restrict__ U, int64_t ldu, double *__restrict__ B, int64_t ldb, int64_t ncols) {
-    const int64_t c = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool valid = c < ncols;
-    const int64_t cc = valid ? c : 0;
-    for (int q = 0; q < PB / 32; ++q) {
-        double b[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) b[r] = B[(int64_t)(32 * q + r) * ldb + cc];
-#pragma unroll 8
-        for (int k = 0; k < 32 * q; ++k) {  // rows solved in earlier chunks
-            const double xk = B[(int64_t)k * ldb + cc];
-            const double *urow = U + (int64_t)k * ldu + 32 * q;
-#pragma unroll
-            for (int r = 0; r < 32; ++r) b[r] = fma(-urow[r], xk, b[r]);
-        }
-        double rinv[32];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) rinv[r] = 1.0 / U[(int64_t)(32 * q + r) * (ldu + 1)];
-#pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const double *urow = U + (int64_t)(32 * q + r) * ldu + 32 * q;
-            b[r] = b[r] * rinv[r];
-#pragma unroll
-            for (int r2 = r + 1; r2 < 32; ++r2) b[r2] = fma(-urow[r2], b[r], b[r2]);
-        }
-        if (valid) {
-#pragma unroll
-            for (int r = 0; r < 32; ++r) B[(int64_t)(32 * q + r) * ldb + c] = b[r];
-        }
-    }
 }
 
 // one wave per row r:  m[r] = (C[r,:] . b) / var,  tr += C[r,:] . G[r,:],  dg[r] = C[r][r]
@@ -190,12 +169,13 @@ rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict_
 struct PosdefScratch {
     double *W = nullptr, *Y = nullptr, *Cp = nullptr;  // (Fp, Fp) each
     double *diL = nullptr, *dvec = nullptr;            // dvec: [chol diag (Fp) | m (F) | diagC (F) | tr (1)]
+    double *Uinv = nullptr;                            // (Fp / 128) blocks of 128 x 128: U_jj^-1
     int64_t Fp = 0;
     void release() {
-        void *q[] = {W, Y, Cp, diL, dvec};
+        void *q[] = {W, Y, Cp, diL, dvec, Uinv};
         for (void *x : q)
             if (x) (void)hipFree(x);
-        W = Y = Cp = diL = dvec = nullptr;
+        W = Y = Cp = diL = dvec = Uinv = nullptr;
         Fp = 0;
     }
 };
@@ -229,6 +209,7 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         if (ea == hipSuccess) ea = hipMalloc((void **)&s.Cp, (size_t)Fp * Fp * 8);
         if (ea == hipSuccess) ea = hipMalloc((void **)&s.diL, (size_t)Fp * 8);
         if (ea == hipSuccess) ea = hipMalloc((void **)&s.dvec, (size_t)(3 * Fp + 1) * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.Uinv, (size_t)Fp * PB * 8);
         if (ea != hipSuccess) {
             (void)hipGetLastError();
             s.release();
@@ -245,16 +226,16 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     hipLaunchKernelGGL(rr_set_identity_kernel, dim3(eb), dim3(256), 0, c->stream, s.Y, Fp);
     RR_CHECK_HIP(hipGetLastError());
     int rc = RR_OK;
-    // ---- factor: W = U^T U (upper triangle of W) ----
+    // ---- factor: W = U^T U (upper triangle of W); Uinv_j = U_jj^-1 on the side ----
     for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
         double *Ujj = s.W + j * PB * (ld + 1);
-        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ujj, ld);
+        double *Uij = s.Uinv + j * PB * PB;
+        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ujj, ld, Uij);
         const int64_t rest = Fp - (j + 1) * PB;
         if (rest > 0) {
             double *panel = Ujj + PB;  // block row j, columns right of the diagonal block
-            hipLaunchKernelGGL(rr_trsm_ut_kernel, dim3((unsigned)((rest + 63) / 64)), dim3(64), 0, c->stream, Ujj, ld, panel,
-                               ld, rest);
-            rc = rr_launch_gemm_tn_f64(c, panel, ld, panel, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 1);
+            rc = rr_launch_gemm_tn_f64(c, Uij, PB, panel, ld, panel, ld, PB, PB, rest, 0, 0);  // panel <- U_jj^-T panel
+            if (rc == RR_OK) rc = rr_launch_gemm_tn_f64(c, panel, ld, panel, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 1);
         }
     }
     if (rc != RR_OK) return rc;
@@ -264,10 +245,10 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         const double *Ujj = s.W + j * PB * (ld + 1);
         double *Yj = s.Y + j * PB * ld;
         const int64_t width = (j + 1) * PB;  // non-zero columns of block row j
-        hipLaunchKernelGGL(rr_trsm_ut_kernel, dim3((unsigned)((width + 63) / 64)), dim3(64), 0, c->stream, Ujj, ld, Yj, ld,
-                           width);
+        rc = rr_launch_gemm_tn_f64(c, s.Uinv + j * PB * PB, PB, Yj, ld, Yj, ld, PB, PB, width, 0, 0);  // Y_j <- U_jj^-T Y_j
         const int64_t rest = Fp - (j + 1) * PB;
-        if (rest > 0) rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+        if (rc == RR_OK && rest > 0)
+            rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
     }
     if (rc != RR_OK) return rc;
     RR_CHECK_HIP(hipGetLastError());

@@ -124,8 +124,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         Phi nor dPhi ever materialised, O(F) numbers over PCIe per evaluation."""
         st = self._state
         N = X.shape[0]
-        # posterior on the device (Cholesky + inverse + reductions in HBM) for F >= 1024 unless rocSOLVER is missing,
-        # RR_POSDEF=host, or the ranks' statistics cannot be summed in HBM (no RCCL group: gloo / CPU tests)
+        # posterior on the device (Cholesky + inverse + reductions in HBM) for F >= 256 unless RR_POSDEF=host or the
+        # ranks' statistics cannot be summed in HBM (no RCCL group: gloo / CPU tests)
         on_dev = hasattr(st, "posterior") and _hip.posterior_available(getattr(st, "F", None))
         if on_dev and self.distributed:
             from . import parallel
