@@ -290,6 +290,10 @@ int rr_fastfood_create(rr_ctx *ctx, int compute, int d, int d2, int k, const int
  * by the Hadamard / permute / diagonal chain (in-wave butterflies, LDS permutation gather). */
 int rr_fastfood_transform(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,
                           const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi);
+/* The same for DEVICE-resident X (N, ldx >= d; no padding needed) and DEVICE output (N, ldphi >= 2n); asynchronous on
+ * the context's stream. */
+int rr_fastfood_transform_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                              const double *lenscale, int n_ls, void *dPhi, int out_dtype, int64_t ldphi);
 
 /* VX = _makeVX(X / lenscale), (N, n) in radians (basis_functions.py:1356-1371). */
 int rr_fastfood_vx(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx,

@@ -118,6 +118,9 @@ SIGNATURES = {
     "rr_fastfood_transform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                              ctypes.c_int, ctypes.c_int64]),
+    "rr_fastfood_transform_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                             ctypes.c_int, ctypes.c_int64]),
     "rr_fastfood_vx": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                       ctypes.c_int, ctypes.c_int64]),
@@ -610,6 +613,13 @@ class FastFoodHandle(object):
 
     def transform(self, X, lenscale, out_dtype=np.float64):
         return self._call(self.lib.rr_fastfood_transform, X, lenscale, 2 * self.n, out_dtype)
+
+    def transform_dev(self, dX, lenscale, dOut, out_dtype=np.float32, ldphi=None):
+        """Device-resident X (DeviceMatrix) -> Phi in the device buffer dOut (asynchronous)."""
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, self.lib.rr_fastfood_transform_dev(self.h, dX.ptr, rr_dtype(dX.dtype), dX.shape[0], dX.ld, lsp, nls,
+                                                            _ptr(dOut), rr_dtype(np.dtype(out_dtype)),
+                                                            2 * self.n if ldphi is None else ldphi))
 
     def vx(self, X, lenscale=1.0, out_dtype=np.float64):
         return self._call(self.lib.rr_fastfood_vx, X, lenscale, self.n, out_dtype)

@@ -597,6 +597,19 @@ int rr_fastfood_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, in
     return ff_host_call<true>(b, X, x_dtype, N, ldx, lenscale, n_ls, Phi, out_dtype, ldphi, "rr_fastfood_transform");
 }
 
+int rr_fastfood_transform_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                              int n_ls, void *dPhi, int out_dtype, int64_t ldphi) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_FASTFOOD, "rr_fastfood_transform_dev: not a FastFood basis");
+    RR_REQUIRE((x_dtype == RR_F32 || x_dtype == RR_F64) && (out_dtype == RR_F32 || out_dtype == RR_F64),
+               "rr_fastfood_transform_dev: bad dtype");
+    RR_REQUIRE(N >= 0 && ldx >= b->d && ldphi >= 2 * (int64_t)b->n, "rr_fastfood_transform_dev: bad shape");
+    RR_CHECK_HIP(hipSetDevice(b->ctx->device));
+    int rc = ff_prepare_lenscale(b, lenscale, n_ls);
+    if (rc != RR_OK || N == 0) return rc;
+    RR_REQUIRE(dX != nullptr && dPhi != nullptr, "rr_fastfood_transform_dev: null buffer");
+    return ff_dispatch<true>(b, dX, x_dtype, N, ldx, dPhi, out_dtype, ldphi);
+}
+
 int rr_fastfood_vx(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale, int n_ls,
                    void *VX, int out_dtype, int64_t ldvx) {
     return ff_host_call<false>(b, X, x_dtype, N, ldx, lenscale, n_ls, VX, out_dtype, ldvx, "rr_fastfood_vx");

@@ -171,3 +171,23 @@ def test_config4_full_width_properties():
     assert normwise(dense, Phi[:2048]) < 1e-4
     B, G, PI, S = orc.fastfood_matrices(nb, d, 6)
     assert normwise(Phi[:64], orc.fastfood_transform(X[:64].astype(np.float64), B, G, PI, S, 1.3)) < 1e-3
+
+
+def test_fastfood_transform_device_resident():
+    """rr_fastfood_transform_dev: X and Phi stay in HBM; same values as the host-buffer call, f32 and f64 output,
+    ragged row count and an output leading dimension wider than 2n."""
+    import revrand_amd.basis_functions as bs
+    rs = np.random.RandomState(1)
+    X = rs.randn(777, 21)
+    b = bs.FastFoodRBF(nbases=40, Xdim=21, random_state=2)
+    ff, _ = b._handles()
+    dev = ff.dev
+    F = 2 * ff.n
+    want = ff.transform(X, 0.8)
+    dX = dev.upload_matrix(X.astype(np.float32))
+    for dt, ld in ((np.float32, F), (np.float64, F + 5)):
+        out = dev.zeros(777 * ld * np.dtype(dt).itemsize)
+        ff.transform_dev(dX, 0.8, out, out_dtype=dt, ldphi=ld)
+        got = dev.download(out, (777, ld), dt)
+        assert normwise(got[:, :F], want) < 1e-5 and np.all(got[:, F:] == 0)
+        out.free()
