@@ -223,6 +223,14 @@ int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf);
  * for rr_featmat_glm_rff / rr_featmat_glm_edphi. */
 int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
                         const double *WS, int K, int L, double *Edws, double *llsum, double *aux);
+/* The same step with the reparameterisation draws made ON THE DEVICE (opt-in fast route; rr_featmat_glm_step with the
+ * caller's own draws is the parity route): e ~ N(0, 1) per (sample, feature) from a counter-based generator keyed by
+ * (seed, step), ws = m_k + sqrt(C_k) e.  m, C: host (F, K) float64 (the mixture means and diagonal covariances).
+ * Outputs (host float64, (K, F) row-major): Edm = sum_l Edws / L (glm.py:309), EdC = sum_l Edws e / (L sqrt C) (:310);
+ * llsum, aux as above.  EdPhi stays on the device as above. */
+int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik,
+                                double lik_param, const double *m, const double *C, int K, int L, uint64_t seed,
+                                uint64_t step, double *Edm, double *EdC, double *llsum, double *aux);
 /* dT (d, n) float64 DEVICE buffer += X^T (E_s o P_c - E_c o P_s) for the random Fourier child at columns
  * [col0, col0 + 2n):  sum(EdPhi o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]  (glm.py:274-275 without basis.grad). */
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,

@@ -94,6 +94,10 @@ SIGNATURES = {
     "rr_featmat_glm_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_double, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_glm_step_sampled": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                                   ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
+                                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_glm_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
@@ -535,6 +539,20 @@ class FeatureMatrix(object):
                                                       ll.ctypes.data_as(ctypes.c_void_p),
                                                       aux.ctypes.data_as(ctypes.c_void_p)))
         return Edws, ll, aux
+
+    def glm_step_sampled(self, dy, drowarg, lik, lik_param, m, C, K, L, seed, step):
+        """(Edm (F, K), EdC (F, K), llsum (K,), aux (K,)) with the reparameterisation draws made on the device."""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        if m.shape != (self.F, K) or C.shape != (self.F, K):
+            raise ValueError("m and C must have shape (F, K)")
+        Edm, EdC, ll, aux = np.empty((K, self.F)), np.empty((K, self.F)), np.empty(K), np.empty(K)
+        _check(self.lib, self.lib.rr_featmat_glm_step_sampled(
+            self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik), float(lik_param),
+            m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L, int(seed), int(step),
+            Edm.ctypes.data_as(ctypes.c_void_p), EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
+            aux.ctypes.data_as(ctypes.c_void_p)))
+        return Edm.T, EdC.T, ll, aux
 
     def glm_rff(self, handle, dX, col0, dT):
         _check(self.lib, self.lib.rr_featmat_glm_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))

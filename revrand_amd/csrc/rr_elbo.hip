@@ -606,13 +606,66 @@ rr_glm_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const flo
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Opt-in device-side reparameterisation draws for the GLM step ("device-side RNG", the host-generated
+// draws of rr_featmat_glm_step remain the parity route).  Counter-based: the normal for (step, sample kl, feature
+// f) is a pure function of (seed, step, kl F + f), two SplitMix64 rounds + Box-Muller.
+//   E[kl][f] = e;   WSs[kl][f] = (m[f][k] + sqrt(C[f][k]) e) / (K L),  k = kl / L
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t rr_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ void __launch_bounds__(256)
+rr_glm_draw_kernel(const double *__restrict__ mdev, const double *__restrict__ Cdev, int F, int K, int L, int64_t Fp,
+                   int64_t klp, uint64_t seed, uint64_t step, float *__restrict__ E, float *__restrict__ WSs) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= klp * Fp) return;
+    const int64_t kl = i / Fp;
+    const int f = (int)(i % Fp);
+    float e = 0.f, w = 0.f;
+    if (kl < (int64_t)K * L && f < F) {
+        const uint64_t ctr = (uint64_t)kl * (uint64_t)F + (uint64_t)f;
+        const uint64_t h = rr_splitmix64(rr_splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) ^ ctr);
+        const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+        const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+        e = sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);  // cos of u2 revolutions
+        const int k = (int)(kl / L);
+        w = (float)((mdev[(size_t)f * K + k] + sqrt(Cdev[(size_t)f * K + k]) * (double)e) / ((double)K * (double)L));
+    }
+    E[i] = e;
+    WSs[i] = w;
+}
+
+// Edm[k][f] = sum_l Ed[kL + l][f] / L;   EdC[k][f] = sum_l Ed[kL + l][f] e[kL + l][f] / (L sqrt(C[f][k]))   (glm.py:309-310)
+__global__ void __launch_bounds__(256)
+rr_glm_reduce_kernel(const float *__restrict__ Ed, const float *__restrict__ E, const double *__restrict__ Cdev, int F, int K,
+                     int L, int64_t Fp, double *__restrict__ Edm, double *__restrict__ EdC) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)K * F) return;
+    const int k = (int)(i / F), f = (int)(i % F);
+    double a = 0.0, b = 0.0;
+    for (int l = 0; l < L; ++l) {
+        const size_t o = (size_t)(k * L + l) * Fp + f;
+        const double ed = (double)Ed[o];
+        a += ed;
+        b += ed * (double)E[o];
+    }
+    Edm[i] = a / L;
+    EdC[i] = b / (L * sqrt(Cdev[(size_t)f * K + k]));
+}
+
 struct FmPass2 {
     float *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
     double *sq = nullptr, *vf = nullptr;
     std::vector<float> hC, hm;
     bool have_rows = false;
     // GLM step / projection: FSt (max_rows, klp), its transpose DFS (klp, max_rows), the sample matrices
-    float *FSt = nullptr, *DFS = nullptr, *WSt = nullptr, *WSs = nullptr, *Ed = nullptr;
+    float *FSt = nullptr, *DFS = nullptr, *WSt = nullptr, *WSs = nullptr, *Ed = nullptr, *Ee = nullptr;
+    double *mc = nullptr;  // [m (F K) | C (F K) | Edm (K F) | EdC (K F)] of the device-sampled step
     double *kacc = nullptr;  // [llsum (K) | aux (K)]
     int64_t klp = 0;
     int kcap = 0;
@@ -622,7 +675,7 @@ struct FmPass2 {
 void rr_fm_pass2_free(void *p) {
     if (!p) return;
     FmPass2 *s = (FmPass2 *)p;
-    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->kacc};
+    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->kacc, s->Ee, s->mc};
     for (void *x : q)
         if (x) (void)hipFree(x);
     delete s;
@@ -677,11 +730,12 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
     RR_CHECK_HIP(hipStreamSynchronize(fm->ctx->stream));
     if (klp < s.klp) klp = s.klp;  // grow-only in both dimensions
     if (K < s.kcap) K = s.kcap;
-    void *q[] = {s.FSt, s.DFS, s.WSt, s.WSs, s.Ed, s.kacc};
+    void *q[] = {s.FSt, s.DFS, s.WSt, s.WSs, s.Ed, s.kacc, s.Ee, s.mc};
     for (void *x : q)
         if (x) (void)hipFree(x);
-    s.FSt = s.DFS = s.WSt = s.WSs = s.Ed = nullptr;
+    s.FSt = s.DFS = s.WSt = s.WSs = s.Ed = s.Ee = nullptr;
     s.kacc = nullptr;
+    s.mc = nullptr;
     s.klp = 0;
     s.kcap = 0;
     hipError_t ea = hipMalloc((void **)&s.FSt, (size_t)fm->max_rows * klp * 4);
@@ -689,6 +743,8 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.WSt, (size_t)fm->ld * klp * 4);
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.WSs, (size_t)klp * fm->ld * 4);
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.Ed, (size_t)klp * fm->ld * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.Ee, (size_t)klp * fm->ld * 4);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.mc, (size_t)4 * (K > 1 ? K : 1) * fm->F * 8);
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.kacc, (size_t)2 * (K > 1 ? K : 1) * 8);
     if (ea != hipSuccess) {
         (void)hipGetLastError();
@@ -1203,27 +1259,66 @@ int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
     return RR_OK;
 }
 
+static int glm_step_checks(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param, int K,
+                           int L, const char *who) {
+    RR_REQUIRE(fm != nullptr && dy != nullptr, "%s: null argument", who);
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "%s: bad dtype", who);
+    RR_REQUIRE(lik >= RR_LIK_BERNOULLI && lik <= RR_LIK_POISSON_SOFTPLUS, "%s: unknown likelihood %d", who, lik);
+    RR_REQUIRE(lik != RR_LIK_BINOMIAL || drowarg != nullptr, "%s: the binomial needs its per-row n", who);
+    RR_REQUIRE(lik != RR_LIK_GAUSSIAN || lik_param > 0.0, "%s: the Gaussian variance must be > 0", who);
+    RR_REQUIRE(K >= 1 && L >= 1 && (int64_t)K * L < (1 << 24), "%s: bad K, L", who);
+    RR_REQUIRE(fm->rows >= 1, "%s: the feature matrix is empty", who);
+    return RR_OK;
+}
+
+// With WSs (kl_ld, Fp) = ws / (K L) on the device: fs, likelihood derivatives and sums, Ed = dfs Phi, EdPhi.
+static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *drowarg, int dtype, int lik,
+                        double lik_param, int K, int L) {
+    rr_ctx *c = fm->ctx;
+    const int KL = K * L;
+    const int64_t Fp = fm->ld, kl_ld = s.klp;
+    const int64_t rows256 = (fm->rows + 255) / 256 * 256;
+    RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
+    // WSt (Fp, kl_ld) = WSs^T (the 1 / (K L) scale is undone in the likelihood kernel's read of fs)
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
+                       s.WSs, kl_ld, Fp, s.WSt, kl_ld);
+    // Pt = P^T;  FSt (rows256, kl) = P WS^T
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                       fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+    int rc = fm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+    if (rc != RR_OK) return rc;
+    // dfs in place + per-component reductions
+    if (dtype == RR_F32)
+        glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+    else
+        glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+    RR_CHECK_HIP(hipGetLastError());
+    // Ed (kl, Fp) = dfs Phi
+    rc = fm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
+    if (rc != RR_OK) return rc;
+    // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
+    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                       s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
+    rc = fm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
+    if (rc != RR_OK) return rc;
+    s.have_edphi = true;
+    return RR_OK;
+}
+
 int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
                         const double *WS, int K, int L, double *Edws, double *llsum, double *aux) {
-    RR_REQUIRE(fm != nullptr && dy != nullptr && WS != nullptr && Edws != nullptr && llsum != nullptr && aux != nullptr,
-               "rr_featmat_glm_step: null argument");
-    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_featmat_glm_step: bad dtype");
-    RR_REQUIRE(lik >= RR_LIK_BERNOULLI && lik <= RR_LIK_POISSON_SOFTPLUS, "rr_featmat_glm_step: unknown likelihood %d", lik);
-    RR_REQUIRE(lik != RR_LIK_BINOMIAL || drowarg != nullptr, "rr_featmat_glm_step: the binomial needs its per-row n");
-    RR_REQUIRE(lik != RR_LIK_GAUSSIAN || lik_param > 0.0, "rr_featmat_glm_step: the Gaussian variance must be > 0");
-    RR_REQUIRE(K >= 1 && L >= 1 && (int64_t)K * L < (1 << 24), "rr_featmat_glm_step: bad K, L");
-    RR_REQUIRE(fm->rows >= 1, "rr_featmat_glm_step: the feature matrix is empty");
+    int rc = glm_step_checks(fm, dy, drowarg, dtype, lik, lik_param, K, L, "rr_featmat_glm_step");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(WS != nullptr && Edws != nullptr && llsum != nullptr && aux != nullptr, "rr_featmat_glm_step: null argument");
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
     const int KL = K * L, F = fm->F;
     const int64_t klp = ((int64_t)KL + 255) / 256 * 256, Fp = fm->ld;
-    const int64_t rows256 = (fm->rows + 255) / 256 * 256;
-    int rc = fm_glm_scratch(fm, klp, K);
+    rc = fm_glm_scratch(fm, klp, K);
     if (rc != RR_OK) return rc;
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     const int64_t kl_ld = s.klp;
-    // weight samples: WSs (kl_ld, Fp) = ws / (K L) for EdPhi (uploaded), WSt (Fp, kl_ld) = K L WSs^T for fs
-    // (transposed on the device; the scale is undone in the likelihood kernel's read of fs)
+    // weight samples: WSs (kl_ld, Fp) = ws / (K L)
     std::vector<float> wsn((size_t)kl_ld * Fp, 0.f);
     const float inv = (float)(1.0 / ((double)K * (double)L));
     for (int i = 0; i < KL; ++i) {
@@ -1233,29 +1328,8 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
     }
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     RR_CHECK_HIP(hipMemcpy(s.WSs, wsn.data(), wsn.size() * 4, hipMemcpyHostToDevice));
-    RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
-                       s.WSs, kl_ld, Fp, s.WSt, kl_ld);
-    // Pt = P^T;  FSt (rows256, kl) = P WS^T
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
-                       fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
-    rc = fm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, lik_param, K, L);
     if (rc != RR_OK) return rc;
-    // dfs in place + per-component reductions
-    if (dtype == RR_F32)
-        glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
-    else
-        glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
-    RR_CHECK_HIP(hipGetLastError());
-    // Edws (kl, Fp) = dfs Phi
-    rc = fm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
-    if (rc != RR_OK) return rc;
-    // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
-                       s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
-    rc = fm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
-    if (rc != RR_OK) return rc;
-    s.have_edphi = true;
     std::vector<float> ed((size_t)KL * Fp);
     std::vector<double> acc((size_t)2 * s.kcap);
     RR_CHECK_HIP(hipMemcpyAsync(ed.data(), s.Ed, ed.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1263,6 +1337,44 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < KL; ++i)
         for (int j = 0; j < F; ++j) Edws[(size_t)i * F + j] = (double)ed[(size_t)i * Fp + j];
+    for (int k = 0; k < K; ++k) {
+        llsum[k] = acc[k];
+        aux[k] = acc[s.kcap + k];
+    }
+    return RR_OK;
+}
+
+int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                                const double *m, const double *C, int K, int L, uint64_t seed, uint64_t step, double *Edm,
+                                double *EdC, double *llsum, double *aux) {
+    int rc = glm_step_checks(fm, dy, drowarg, dtype, lik, lik_param, K, L, "rr_featmat_glm_step_sampled");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(m != nullptr && C != nullptr && Edm != nullptr && EdC != nullptr && llsum != nullptr && aux != nullptr,
+               "rr_featmat_glm_step_sampled: null argument");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int KL = K * L, F = fm->F;
+    const int64_t klp = ((int64_t)KL + 255) / 256 * 256, Fp = fm->ld;
+    rc = fm_glm_scratch(fm, klp, K);
+    if (rc != RR_OK) return rc;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    const int64_t kl_ld = s.klp;
+    const size_t fk = (size_t)F * K;
+    RR_CHECK_HIP(hipMemcpyAsync(s.mc, m, fk * 8, hipMemcpyHostToDevice, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(s.mc + fk, C, fk * 8, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, c->stream, s.mc, s.mc + fk,
+                       F, K, L, Fp, kl_ld, seed, step, s.Ee, s.WSs);
+    RR_CHECK_HIP(hipGetLastError());
+    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, lik_param, K, L);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, c->stream, s.Ed, s.Ee, s.mc + fk,
+                       F, K, L, Fp, s.mc + 2 * fk, s.mc + 3 * fk);
+    RR_CHECK_HIP(hipGetLastError());
+    std::vector<double> acc((size_t)2 * s.kcap);
+    RR_CHECK_HIP(hipMemcpyAsync(Edm, s.mc + 2 * fk, fk * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(EdC, s.mc + 3 * fk, fk * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(acc.data(), s.kacc, acc.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     for (int k = 0; k < K; ++k) {
         llsum[k] = acc[k];
         aux[k] = acc[s.kcap + k];

@@ -43,10 +43,17 @@ LOGITER = 500                    # SGD iterations between ELBO log lines        
 
 class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     """Bayesian GLM; parameters as the reference (glm.py:45-139): ``likelihood, basis, K, maxiter, batch_size,
-    updater, nsamples, nstarts, random_state``."""
+    updater, nsamples, nstarts, random_state``, plus
+
+    sampler : "host" (default) | "device"
+        Where the standard-normal draws of the reparameterisation trick are made.  "host": from ``random_`` in the
+        reference's order, so a seeded run consumes the reference's random stream (1 M draws per step at config 5's
+        shape: 18 ms, more than everything else together).  "device": a counter-based generator on the GPU keyed by
+        one integer drawn from ``random_`` at the start of ``fit`` and the step number -- reproducible for a given
+        seed, statistically equivalent, not the reference's stream; only the (D, K) expectations come back."""
 
     def __init__(self, likelihood=Gaussian(), basis=LinearBasis(), K=10, maxiter=3000, batch_size=10, updater=None,
-                 nsamples=50, nstarts=500, random_state=None):
+                 nsamples=50, nstarts=500, random_state=None, sampler="host"):
         self.likelihood = likelihood
         self.basis = basis
         self.K = K
@@ -56,11 +63,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         self.nsamples = nsamples
         self.nstarts = nstarts
         self.random_state = random_state
+        self.sampler = sampler
         self.random_ = check_random_state(self.random_state)
 
     def fit(self, X, y, likelihood_args=()):
         """Learn the posterior mixture and the hyper-parameters (glm.py:141-203)."""
         X, y = check_X_y(X, y)
+        self._dev_seed = None  # the device sampler is re-keyed from random_ per fit
         N, _ = X.shape
         self.B_ = X.shape[0] / self.batch_size
         self.D_ = self.basis.get_dim(X)
@@ -107,16 +116,26 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         L_ = self.nsamples
         lpars_l = atleast_list(lpars)
 
-        # reparameterised weight samples of ALL components: same draws, same order as glm.py:300
-        e = np.stack([self.random_.randn(L_, D) for _ in range(K)])          # K x L x D
-        Sk = np.sqrt(C).T[:, np.newaxis, :]                                   # K x 1 x D
-        ws = m.T[:, np.newaxis, :] + Sk * e                                   # K x L x D
-
         feats = self._features()
         feats.assemble(X, atleast_list(bpars))                                # Phi (M x D) in HBM
         lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
-        Edws, llsum, aux = feats.glm_step(y, rowarg, lid, lpar, ws.reshape(K * L_, D), K, L_)
-        Edws = Edws.reshape(K, L_, D)
+        if self.sampler == "device":
+            if self.__dict__.get("_dev_seed") is None:
+                self._dev_seed, self._dev_step = int(self.random_.randint(0, 2 ** 31 - 1)), 0
+            Edm, EdC, llsum, aux = feats.glm_step_sampled(y, rowarg, lid, lpar, m, C, K, L_, self._dev_seed,
+                                                          self._dev_step)
+            self._dev_step += 1
+        else:
+            if self.sampler != "host":
+                raise ValueError("sampler must be 'host' or 'device'")
+            # reparameterised weight samples of ALL components: same draws, same order as glm.py:300
+            e = np.stack([self.random_.randn(L_, D) for _ in range(K)])      # K x L x D
+            Sk = np.sqrt(C).T[:, np.newaxis, :]                               # K x 1 x D
+            ws = m.T[:, np.newaxis, :] + Sk * e                               # K x L x D
+            Edws, llsum, aux = feats.glm_step(y, rowarg, lid, lpar, ws.reshape(K * L_, D), K, L_)
+            Edws = Edws.reshape(K, L_, D)
+            Edm = Edws.sum(axis=1).T / L_                                    # D x K   glm.py:309
+            EdC = (Edws * e / Sk).sum(axis=1).T / L_                         # D x K   glm.py:310
 
         L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
         iL = 1. / L[:, np.newaxis]
@@ -130,8 +149,6 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         Ell = llsum / L_ + llconst
 
         # the reference's loop over the K mixture components (glm.py:238-262), all components at once:
-        Edm = Edws.sum(axis=1).T / L_                                        # D x K   glm.py:309
-        EdC = (Edws * e / Sk).sum(axis=1).T / L_                             # D x K   glm.py:310
         # alpha[k, l] = N_kl / z_k + N_kl / z_l                                         glm.py:244-246
         alpha = np.exp(logNkl.T - logzk[:, np.newaxis]) + np.exp(logNkl.T - logzk[np.newaxis, :])
         mkmj = m[:, :, np.newaxis] - m[:, np.newaxis, :]                     # D x k x l

@@ -175,3 +175,57 @@ def test_glm_poisson_large_minibatch():
     rate = np.exp(0.8 * np.sin(1.5 * Xs[:, 0]) + 0.4 * Xs[:, 1])
     assert smse(rate, glm.predict(Xs)) < 0.2
     assert glm.weights_.shape == (200, 3) and np.all(glm.covariance_ > 0) and np.shape(glm.basis_hypers_) == (d,)
+
+
+def test_device_sampler_matches_host_sampler_in_expectation():
+    """sampler="device": the reparameterisation draws come from the counter-based generator on the GPU.  With many
+    samples the Monte-Carlo gradients agree with the host-sampled ones (same estimator, independent draws), the
+    result is reproducible for a seed and changes with the step."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(7)
+    M, d, n, K, L = 2048, 3, 24, 2, 3000
+    X = rs.randn(M, d)
+    y = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float)
+    D = 2 * n
+    m = 0.1 * rs.randn(D, K)
+    C = 0.05 * rs.gamma(2., 0.5, size=(D, K))
+    out = {}
+    for sampler in ("host", "device", "device2"):
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3)
+        glm = GLM(lk.Poisson(), basis, K=K, nsamples=L, random_state=11, sampler=sampler[:6])
+        glm.B_, glm.D_ = 4.0, D
+        glm._GeneralizedLinearModel__it = -1
+        glm._dev_seed = None
+        res = [glm._elbo(m.copy(), C.copy(), 1.0, [], 0.9, X, y) for _ in range(2)]
+        glm._release_features()
+        out[sampler] = res
+    h, dv, dv2 = out["host"][0], out["device"][0], out["device2"][0]
+    # same seed, same step: the same draws (the split-K GEMM's f32 atomics leave only last-bit differences)
+    assert normwise(dv[1][0], dv2[1][0]) < 1e-5 and abs(dv[0] - dv2[0]) < 1e-6 * abs(dv[0])
+    assert normwise(out["device"][0][1][0], out["device"][1][1][0]) > 1e-4           # next step: new draws
+    # Monte-Carlo agreement, calibrated by the spread between two independent HOST-sampled evaluations
+    h2 = out["host"][1]
+    assert abs(h[0] - dv[0]) < max(5 * abs(h[0] - h2[0]), 2e-3 * abs(h[0]))        # -ELBO
+    for blk in (0, 1):                                                               # -dm, -dC
+        noise = normwise(h2[1][blk], h[1][blk])
+        assert normwise(dv[1][blk], h[1][blk]) < max(3 * noise, 0.02), (blk, noise)
+    assert abs(dv[1][4] - h[1][4]) < max(5 * abs(h2[1][4] - h[1][4]), 0.05 * abs(h[1][4])) + 1e-3   # basis gradient
+    with pytest.raises(ValueError):
+        GLM(lk.Poisson(), bs.RandomRBF(nbases=4, Xdim=d), sampler="gpu")._elbo(m[:8], C[:8], 1.0, [], 0.9, X, y)
+
+
+def test_glm_poisson_fit_with_device_sampler():
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(0)
+    N, d = 20000, 4
+    X = rs.randn(N, d)
+    y = rs.poisson(np.exp(0.8 * np.sin(1.5 * X[:, 0]) + 0.4 * X[:, 1])).astype(float)
+    basis = bs.RandomRBF(nbases=100, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+    glm = GLM(lk.Poisson(), basis, K=3, nsamples=10, batch_size=4096, maxiter=300, nstarts=4, random_state=2,
+              sampler="device")
+    glm.fit(X, y)
+    Xs = rs.randn(2000, d)
+    rate = np.exp(0.8 * np.sin(1.5 * Xs[:, 0]) + 0.4 * Xs[:, 1])
+    assert smse(rate, glm.predict(Xs)) < 0.2
+    from sklearn.base import clone
+    assert clone(glm).get_params()["sampler"] == "device"
