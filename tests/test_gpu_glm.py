@@ -229,3 +229,40 @@ def test_glm_poisson_fit_with_device_sampler():
     assert smse(rate, glm.predict(Xs)) < 0.2
     from sklearn.base import clone
     assert clone(glm).get_params()["sampler"] == "device"
+
+
+def test_config5_full_minibatch_is_additive_over_rows():
+    """BASELINE config 5's step at full size (M = 65 536 rows, F = 2048, K = 10, L = 50, Poisson, ARD), through a
+    size-independent property instead of the CPU oracle (minutes at this size): for fixed weight samples every
+    output of the step is a sum over rows, so the full minibatch equals the sum of its two halves; and a 1024-row
+    slice agrees with the oracle."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    from revrand_amd.basis_functions import MinibatchFeatures
+    rs = np.random.RandomState(5)
+    M, d, n, K, L = 65536, 32, 1024, 10, 50
+    X = rs.randn(M, d).astype(np.float32).astype(np.float64)
+    y = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float)
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+    ls = np.linspace(0.8, 1.4, d)
+    WS = 0.05 * rs.randn(K * L, 2 * n)
+    f = MinibatchFeatures(basis)
+
+    def step(sl):
+        f.assemble(X[sl], [ls])
+        Edws, ll, aux = f.glm_step(y[sl], None, lk.RR_LIK_POISSON_EXP, 0.0, WS, K, L)
+        return Edws, ll, np.asarray(f.glm_basis_grads(X[sl]))
+
+    full, a, b = step(slice(0, M)), step(slice(0, M // 2)), step(slice(M // 2, M))
+    assert normwise(a[0] + b[0], full[0]) < 1e-4 and normwise(a[1] + b[1], full[1]) < 1e-5
+    assert normwise(a[2] + b[2], full[2]) < 1e-3
+    # a slice against the oracle's formulas (glm.py:296-322 with the same weight samples)
+    sl = slice(1000, 2024)
+    Edws, ll, g = step(sl)
+    f.release()
+    Phi = orc.rff_transform(X[sl], basis.W, ls)
+    fs = WS @ Phi.T
+    dfs = orc.lik_df("poisson_exp", y[sl], fs)
+    assert normwise(Edws, dfs @ Phi) < 1e-3
+    EdPhi = dfs.T @ WS / (K * L)
+    dP = orc.rff_grad(X[sl], basis.W, ls)
+    assert normwise(g, np.array([-(EdPhi * dP[:, :, i]).sum() for i in range(d)])) < 5e-3
