@@ -170,6 +170,10 @@ int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int6
 int rr_dense_gram(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi,
                   const void *y, double *G, double *b, double *yty);
 
+/* Minibatch gather from resident data: ddst[r][0:ld_words] = dsrc[didx[r]][0:ld_words] for rows of ld_words 4-byte
+ * words (float32 rows; float64 rows with ld_words = 2 * columns); didx is a DEVICE int32 vector.  Asynchronous. */
+int rr_gather_rows(rr_ctx *ctx, const void *dsrc, const int *didx, int64_t rows, int64_t ld_words, void *ddst);
+
 /* ---- concatenated bases: one device feature matrix, one Gram ---------------------------------
  * BasisCat.transform hstacks the children's Phi (basis_functions.py:1599-1627) before slm.py:146,157
  * contract it.  Here the children write their column blocks into ONE zero-padded f32 device matrix

@@ -98,6 +98,8 @@ SIGNATURES = {
                                                    ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                      ctypes.c_void_p]),
     "rr_featmat_glm_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
@@ -355,6 +357,12 @@ class Device(object):
 
     def sync(self):
         _check(self.lib, self.lib.rr_ctx_sync(self.ctx))
+
+    def gather_rows(self, src, didx, rows, dst):
+        """dst[r] = src[didx[r]] for two float32 DeviceMatrix objects of the same leading dimension (async)."""
+        if src.ld != dst.ld or src.dtype != np.float32 or dst.dtype != np.float32:
+            raise ValueError("gather_rows: float32 matrices with equal leading dimensions expected")
+        _check(self.lib, self.lib.rr_gather_rows(self.ctx, src.ptr, _ptr(didx), rows, src.ld, dst.ptr))
 
     def posterior(self, F, dG, db, iL, var, dC):
         """rr_posterior_dev: (m, diagC, log|iC|, sum(G o C)) with C left in the device buffer dC, or None when the

@@ -187,7 +187,7 @@ class BiasBasis(Basis):
         return np.ones((len(X), 1)) * self.offset
 
     def _resident_child(self, X):
-        return _ResidentHost(self)
+        return _ResidentHost(self, X.shape[1])
 
     def __repr__(self):
         return "{}(offset={}, regularizer={})".format(type(self).__name__, self.offset, self.regularizer)
@@ -342,11 +342,17 @@ class _ResidentHost(object):
 
     nparams = 0
 
-    def __init__(self, basis):
-        self.basis = basis
+    def __init__(self, basis, ncols=0):
+        self.basis, self.ncols = basis, ncols
 
     def put(self, fm, X, r0, rows, col0, params):
         fm.put_host(self.basis.transform(X[r0:r0 + rows]), col0)
+
+    def gather(self, didx, M):
+        pass
+
+    def put_batch(self, fm, M, col0, params):
+        fm.put_host(self.basis.transform(np.zeros((M, self.ncols))), col0)  # a constant column: only the row count matters
 
     def release(self):
         pass
@@ -364,8 +370,16 @@ class _ResidentLinear(object):
     def put(self, fm, X, r0, rows, col0, params):
         fm.put_linear(_hip.DeviceView(self.dX, r0, rows), self.onescol, col0)
 
+    def gather(self, didx, M):
+        self.dXb = _gather_batch(self.dX, getattr(self, "dXb", None), didx, M)
+
+    def put_batch(self, fm, M, col0, params):
+        fm.put_linear(_hip.DeviceView(self.dXb, 0, M), self.onescol, col0)
+
     def release(self):
         self.dX.free()
+        if getattr(self, "dXb", None) is not None:
+            self.dXb.free()
 
 
 class _ResidentRFF(object):
@@ -385,6 +399,17 @@ class _ResidentRFF(object):
         self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
         fm.put_rff(self.h, _hip.DeviceView(self.dX, r0, rows), self.ls, col0)
 
+    def gather(self, didx, M):
+        self.dXb = _gather_batch(self.dX, getattr(self, "dXb", None), didx, M)
+
+    def put_batch(self, fm, M, col0, params):
+        self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
+        fm.put_rff(self.h, _hip.DeviceView(self.dXb, 0, M), self.ls, col0)
+
+    def batch(self, M):
+        """The rows the feature matrix was last filled from: the gathered minibatch, or the first M resident rows."""
+        return _hip.DeviceView(self.dXb if getattr(self, "dXb", None) is not None else self.dX, 0, M)
+
     def reset(self):
         self.h.dev.memset(self.dT)
 
@@ -401,6 +426,19 @@ class _ResidentRFF(object):
     def release(self):
         self.dX.free()
         self.dT.free()
+        if getattr(self, "dXb", None) is not None:
+            self.dXb.free()
+
+
+def _gather_batch(dX, dXb, didx, M):
+    """Rows didx of the resident matrix dX into a (grow-only) batch matrix of the same layout."""
+    dev = dX.dev
+    if dXb is None or dXb.shape[0] < M:
+        if dXb is not None:
+            dXb.free()
+        dXb = dev.empty_matrix(M, dX.shape[1], np.float32, ld_dev=dX.ld)
+    dev.gather_rows(dX, didx, M, dXb)
+    return dXb
 
 
 class _ResidentGeneric(object):
@@ -438,9 +476,45 @@ class MinibatchFeatures(object):
             self.dev = self.fm.dev
 
     def _drop_children(self):
-        for c, _, _ in self.children:
-            c.release()
+        if not getattr(self, "resident", False):
+            for c, _, _ in self.children:
+                c.release()
         self.children = []
+
+    def make_resident(self, X):
+        """Keep every child's columns of X on the device for a whole fit (minibatches are then gathered there by
+        index); False -- and nothing kept -- if a child cannot."""
+        self._drop_children()
+        kids = []
+        for b in self.bases:
+            c = b._resident_child(X)
+            if c is None:
+                for k in kids:
+                    k.release()
+                return False
+            kids.append(c)
+        self._kids = kids
+        self._dims = [int(b.get_dim(X)) for b in self.bases]
+        self.resident = True
+        return True
+
+    def assemble_idx(self, idx, hypers):
+        """`assemble` for rows `idx` of the resident data."""
+        self.children = []
+        M = len(idx)
+        self._ensure(M, int(sum(self._dims)))
+        didx = self.dev.upload_vector(np.ascontiguousarray(idx, dtype=np.int32))
+        self.fm.begin(M)
+        args, col0 = list(hypers), 0
+        for child, w in zip(self._kids, self._dims):
+            mine, args = args[:child.nparams], args[child.nparams:]
+            child.gather(didx, M)
+            child.put_batch(self.fm, M, col0, mine)
+            self.children.append((child, col0, w))
+            col0 += w
+        self.dev.sync()
+        didx.free()
+        self.M = M
 
     def assemble(self, X, hypers):
         self._drop_children()
@@ -484,7 +558,7 @@ class MinibatchFeatures(object):
         for child, col0, w in self.children:
             if isinstance(child, _ResidentRFF):
                 child.reset()
-                self.fm.glm_rff(child.h, _hip.DeviceView(child.dX, 0, self.M), col0, child.dT)
+                self.fm.glm_rff(child.h, child.batch(self.M), col0, child.dT)
                 g = [child.dhyp(1.0)]   # -(E o dPhi_i).sum() = +(1/l_i^2) W[i,:].T[i,:]
             elif child.nparams:
                 E = self.fm.glm_edphi(self.M, col0, w)
@@ -513,6 +587,10 @@ class MinibatchFeatures(object):
         return out
 
     def release(self):
+        if getattr(self, "resident", False):
+            for k in self._kids:
+                k.release()
+            self.resident = False
         self._drop_children()
         self.fm = None
 

@@ -61,7 +61,28 @@ __global__ void __launch_bounds__(256) rr_fm_yty_kernel(const TY *__restrict__ y
     if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// dst[r][:] = src[idx[r]][:] for rows of ld 4-byte elements (minibatch gather from resident data)
+__global__ void __launch_bounds__(256)
+rr_gather_rows_kernel(const uint32_t *__restrict__ src, const int *__restrict__ idx, int64_t rows, int64_t ld,
+                      uint32_t *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * ld) return;
+    const int64_t r = i / ld, c = i % ld;
+    dst[i] = src[(int64_t)idx[r] * ld + c];
+}
+
 extern "C" {
+
+int rr_gather_rows(rr_ctx *c, const void *dsrc, const int *didx, int64_t rows, int64_t ld_words, void *ddst) {
+    RR_REQUIRE(c != nullptr && rows >= 0 && ld_words >= 1, "rr_gather_rows: bad argument");
+    if (rows == 0) return RR_OK;
+    RR_REQUIRE(dsrc != nullptr && didx != nullptr && ddst != nullptr, "rr_gather_rows: null buffer");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    hipLaunchKernelGGL(rr_gather_rows_kernel, dim3((unsigned)((rows * ld_words + 255) / 256)), dim3(256), 0, c->stream,
+                       (const uint32_t *)dsrc, didx, rows, ld_words, (uint32_t *)ddst);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
 
 int rr_featmat_create(rr_ctx *ctx, int64_t max_rows, int64_t F, rr_featmat **out) {
     RR_REQUIRE(ctx != nullptr && out != nullptr, "rr_featmat_create: null argument");

@@ -75,6 +75,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         self.D_ = self.basis.get_dim(X)
         likelihood_args = _reshape_likelihood_args(likelihood_args, N)
         data = (X, y) + likelihood_args
+        # when every basis can keep its columns of X in HBM, minibatches are gathered there: the optimiser then
+        # shuffles row INDICES (the same permutation stream) and a zero-width stand-in for X
+        self._resident_fit = self._features().make_resident(X)
+        if self._resident_fit:
+            data = (np.empty((N, 0)), y) + likelihood_args + (np.arange(N),)
         params = [Parameter(WGTRND, Bound(), shape=(self.D_, self.K)),
                   Parameter(COVRND, Positive(), shape=(self.D_, self.K)),
                   self.basis.regularizer,
@@ -87,6 +92,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             res = nsgd(self._elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts)
         finally:
+            self._resident_fit = False
             self._release_features()
         (self.weights_, self.covariance_, self.regularizer_, self.like_hypers_, self.basis_hypers_) = res.x
         log.info("Finished! reg = {}, likelihood_hypers = {}, basis_hypers = {}, message: {}."
@@ -117,7 +123,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         lpars_l = atleast_list(lpars)
 
         feats = self._features()
-        feats.assemble(X, atleast_list(bpars))                                # Phi (M x D) in HBM
+        if getattr(self, "_resident_fit", False):                            # rows by index from the resident data
+            idx, largs = largs[-1], largs[:-1]
+            feats.assemble_idx(idx, atleast_list(bpars))
+        else:
+            feats.assemble(X, atleast_list(bpars))                            # Phi (M x D) in HBM
         lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
         if self.sampler == "device":
             if self.__dict__.get("_dev_seed") is None:

@@ -266,3 +266,37 @@ def test_config5_full_minibatch_is_additive_over_rows():
     EdPhi = dfs.T @ WS / (K * L)
     dP = orc.rff_grad(X[sl], basis.W, ls)
     assert normwise(g, np.array([-(EdPhi * dP[:, :, i]).sum() for i in range(d)])) < 5e-3
+
+
+def test_resident_minibatch_gather_equals_host_gather():
+    """fit() keeps X on the device and gathers minibatches there by index: the step on rows `idx` of the resident data
+    equals the step on the host-gathered X[idx] (concatenation with Linear + Bias, column subsets)."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    from revrand_amd.basis_functions import MinibatchFeatures
+    rs = np.random.RandomState(2)
+    N, d, K, L = 5000, 6, 3, 5
+    X = rs.randn(N, d)
+    y = rs.poisson(np.exp(0.3 * X[:, 0])).astype(float)
+    cat = bs.RandomRBF(nbases=30, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True, apply_ind=[1, 4]) + bs.BiasBasis(offset=0.5) \
+        + bs.RandomMatern32(nbases=10, Xdim=2, random_state=2, apply_ind=[0, 5])
+    hyp = [np.linspace(0.8, 1.2, d), 0.9]
+    D = int(cat.get_dim(X))
+    WS = 0.1 * rs.randn(K * L, D)
+    idx = rs.permutation(N)[:777]
+    a = MinibatchFeatures(cat)
+    assert a.make_resident(X)
+    a.assemble_idx(idx, hyp)
+    Ea, la, _ = a.glm_step(y[idx], None, lk.RR_LIK_POISSON_EXP, 0.0, WS, K, L)
+    ga = a.glm_basis_grads(np.empty((777, 0)))
+    a.release()
+    b = MinibatchFeatures(cat)
+    b.assemble(X[idx], hyp)
+    Eb, lb, _ = b.glm_step(y[idx], None, lk.RR_LIK_POISSON_EXP, 0.0, WS, K, L)
+    gb = b.glm_basis_grads(X[idx])
+    b.release()
+    assert normwise(Ea, Eb) < 1e-5 and normwise(la, lb) < 1e-6
+    assert normwise(np.concatenate([np.atleast_1d(v) for v in ga]), np.concatenate([np.atleast_1d(v) for v in gb])) < 1e-4
+    # a basis that cannot stay resident (f64 arithmetic) declines, and nothing is kept
+    c = MinibatchFeatures(bs.RandomRBF(nbases=8, Xdim=d, dtype="f64") + bs.LinearBasis())
+    assert not c.make_resident(X)
