@@ -235,6 +235,12 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
 int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik,
                                 double lik_param, const double *m, const double *C, int K, int L, uint64_t seed,
                                 uint64_t step, double *Edm, double *EdC, double *llsum, double *aux);
+/* The parity route without the 2 x (K L, F) float64 traffic of rr_featmat_glm_step: the CALLER's standard-normal draws
+ * E (host float32 (K*L, F), component-major, e.g. the reference's random stream) go up once, ws = m_k + sqrt(C_k) e is
+ * formed on the device and only Edm, EdC (K, F) come back, as in rr_featmat_glm_step_sampled. */
+int rr_featmat_glm_step_draws(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik,
+                              double lik_param, const double *m, const double *C, int K, int L, const float *E,
+                              double *Edm, double *EdC, double *llsum, double *aux);
 /* dT (d, n) float64 DEVICE buffer += X^T (E_s o P_c - E_c o P_s) for the random Fourier child at columns
  * [col0, col0 + 2n):  sum(EdPhi o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]  (glm.py:274-275 without basis.grad). */
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,

@@ -98,6 +98,10 @@ SIGNATURES = {
                                                    ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                                    ctypes.c_int, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64,
                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_glm_step_draws": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_void_p]),
     "rr_featmat_glm_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -558,6 +562,21 @@ class FeatureMatrix(object):
         _check(self.lib, self.lib.rr_featmat_glm_step_sampled(
             self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik), float(lik_param),
             m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L, int(seed), int(step),
+            Edm.ctypes.data_as(ctypes.c_void_p), EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
+            aux.ctypes.data_as(ctypes.c_void_p)))
+        return Edm.T, EdC.T, ll, aux
+
+    def glm_step_draws(self, dy, drowarg, lik, lik_param, m, C, K, L, E):
+        """(Edm (F, K), EdC (F, K), llsum, aux) for the caller's standard-normal draws E (K*L, F)."""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        E = np.ascontiguousarray(E, dtype=np.float32)
+        if m.shape != (self.F, K) or C.shape != (self.F, K) or E.shape != (K * L, self.F):
+            raise ValueError("m, C must have shape (F, K) and E (K*L, F)")
+        Edm, EdC, ll, aux = np.empty((K, self.F)), np.empty((K, self.F)), np.empty(K), np.empty(K)
+        _check(self.lib, self.lib.rr_featmat_glm_step_draws(
+            self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik), float(lik_param),
+            m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L, E.ctypes.data_as(ctypes.c_void_p),
             Edm.ctypes.data_as(ctypes.c_void_p), EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
             aux.ctypes.data_as(ctypes.c_void_p)))
         return Edm.T, EdC.T, ll, aux

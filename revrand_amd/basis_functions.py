@@ -553,6 +553,16 @@ class MinibatchFeatures(object):
             if dn is not None:
                 dn.free()
 
+    def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E):
+        dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+        dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
+        try:
+            return self.fm.glm_step_draws(dy, dn, lik, lik_param, m, C, K, L, E)
+        finally:
+            dy.free()
+            if dn is not None:
+                dn.free()
+
     def glm_basis_grads(self, X):
         grads = []
         for child, col0, w in self.children:

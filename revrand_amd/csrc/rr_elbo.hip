@@ -621,18 +621,23 @@ __device__ __forceinline__ uint64_t rr_splitmix64(uint64_t x) {
 
 __global__ void __launch_bounds__(256)
 rr_glm_draw_kernel(const double *__restrict__ mdev, const double *__restrict__ Cdev, int F, int K, int L, int64_t Fp,
-                   int64_t klp, uint64_t seed, uint64_t step, float *__restrict__ E, float *__restrict__ WSs) {
+                   int64_t klp, uint64_t seed, uint64_t step, const float *__restrict__ Egiven, float *__restrict__ E,
+                   float *__restrict__ WSs) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= klp * Fp) return;
     const int64_t kl = i / Fp;
     const int f = (int)(i % Fp);
     float e = 0.f, w = 0.f;
     if (kl < (int64_t)K * L && f < F) {
-        const uint64_t ctr = (uint64_t)kl * (uint64_t)F + (uint64_t)f;
-        const uint64_t h = rr_splitmix64(rr_splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) ^ ctr);
-        const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-        const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
-        e = sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);  // cos of u2 revolutions
+        if (Egiven) {  // the caller's draws (K L, F): the parity route
+            e = Egiven[(size_t)kl * F + f];
+        } else {
+            const uint64_t ctr = (uint64_t)kl * (uint64_t)F + (uint64_t)f;
+            const uint64_t h = rr_splitmix64(rr_splitmix64(seed ^ (step * 0xD1B54A32D192ED03ull)) ^ ctr);
+            const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+            const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+            e = sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);  // cos of u2 revolutions
+        }
         const int k = (int)(kl / L);
         w = (float)((mdev[(size_t)f * K + k] + sqrt(Cdev[(size_t)f * K + k]) * (double)e) / ((double)K * (double)L));
     }
@@ -1344,9 +1349,9 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
     return RR_OK;
 }
 
-int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
-                                const double *m, const double *C, int K, int L, uint64_t seed, uint64_t step, double *Edm,
-                                double *EdC, double *llsum, double *aux) {
+static int glm_step_reduced(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                            const double *m, const double *C, int K, int L, uint64_t seed, uint64_t step,
+                            const float *Ehost, double *Edm, double *EdC, double *llsum, double *aux) {
     int rc = glm_step_checks(fm, dy, drowarg, dtype, lik, lik_param, K, L, "rr_featmat_glm_step_sampled");
     if (rc != RR_OK) return rc;
     RR_REQUIRE(m != nullptr && C != nullptr && Edm != nullptr && EdC != nullptr && llsum != nullptr && aux != nullptr,
@@ -1362,8 +1367,13 @@ int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drow
     const size_t fk = (size_t)F * K;
     RR_CHECK_HIP(hipMemcpyAsync(s.mc, m, fk * 8, hipMemcpyHostToDevice, c->stream));
     RR_CHECK_HIP(hipMemcpyAsync(s.mc + fk, C, fk * 8, hipMemcpyHostToDevice, c->stream));
+    const float *Egiven = nullptr;
+    if (Ehost) {  // the caller's draws go up as float32 (K L, F), staged in the (not yet used) Ed buffer
+        RR_CHECK_HIP(hipMemcpyAsync(s.Ed, Ehost, (size_t)KL * F * 4, hipMemcpyHostToDevice, c->stream));
+        Egiven = s.Ed;
+    }
     hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, c->stream, s.mc, s.mc + fk,
-                       F, K, L, Fp, kl_ld, seed, step, s.Ee, s.WSs);
+                       F, K, L, Fp, kl_ld, seed, step, Egiven, s.Ee, s.WSs);
     RR_CHECK_HIP(hipGetLastError());
     rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, lik_param, K, L);
     if (rc != RR_OK) return rc;
@@ -1380,6 +1390,19 @@ int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drow
         aux[k] = acc[s.kcap + k];
     }
     return RR_OK;
+}
+
+int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                                const double *m, const double *C, int K, int L, uint64_t seed, uint64_t step, double *Edm,
+                                double *EdC, double *llsum, double *aux) {
+    return glm_step_reduced(fm, dy, drowarg, dtype, lik, lik_param, m, C, K, L, seed, step, nullptr, Edm, EdC, llsum, aux);
+}
+
+int rr_featmat_glm_step_draws(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                              const double *m, const double *C, int K, int L, const float *E, double *Edm, double *EdC,
+                              double *llsum, double *aux) {
+    RR_REQUIRE(E != nullptr, "rr_featmat_glm_step_draws: null draws");
+    return glm_step_reduced(fm, dy, drowarg, dtype, lik, lik_param, m, C, K, L, 0, 0, E, Edm, EdC, llsum, aux);
 }
 
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {

@@ -138,14 +138,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         else:
             if self.sampler != "host":
                 raise ValueError("sampler must be 'host' or 'device'")
-            # reparameterised weight samples of ALL components: same draws, same order as glm.py:300
-            e = np.stack([self.random_.randn(L_, D) for _ in range(K)])      # K x L x D
-            Sk = np.sqrt(C).T[:, np.newaxis, :]                               # K x 1 x D
-            ws = m.T[:, np.newaxis, :] + Sk * e                               # K x L x D
-            Edws, llsum, aux = feats.glm_step(y, rowarg, lid, lpar, ws.reshape(K * L_, D), K, L_)
-            Edws = Edws.reshape(K, L_, D)
-            Edm = Edws.sum(axis=1).T / L_                                    # D x K   glm.py:309
-            EdC = (Edws * e / Sk).sum(axis=1).T / L_                         # D x K   glm.py:310
+            # the reference's draws, in its order (glm.py:300): randn(L, D) per component; ws = m_k + sqrt(C_k) e and
+            # the reductions over the samples (glm.py:309-310) happen on the device
+            e = np.empty((K * L_, D), dtype=np.float32)
+            for k in range(K):
+                e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
+            Edm, EdC, llsum, aux = feats.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L_, e)
 
         L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
         iL = 1. / L[:, np.newaxis]
