@@ -289,3 +289,32 @@ def test_gen_batch_is_the_endless_permutation_stream():
         b = np.array([next(p) for _ in range(B)])
         assert np.array_equal(a, b)
         assert rs1.randn() == rs2.randn()
+
+
+def test_likelihoods_like_reference_test_likelihoods():
+    """tests/test_likelihoods.py of the reference: shapes of every method, and the densities / CDFs against
+    scipy.stats (with f on the link scale)."""
+    from scipy.stats import bernoulli, binom, poisson
+    from scipy.special import logit
+    from revrand_amd import likelihoods as lk
+    N = 100
+    y, f = np.ones(N), np.ones(N) * 2
+    for like, args in zip([lk.Gaussian, lk.Poisson, lk.Bernoulli, lk.Binomial], [[1.], [], [], [5]]):
+        lobj = like()
+        for out in (lobj.loglike(y, f, *args), lobj.Ey(f, *args), lobj.df(y, f, *args), lobj.cdf(y, f, *args)):
+            assert np.shape(out) == (N,)
+        dp = lobj.dp(y, f, *args)
+        assert (np.shape(dp) == (N,)) if like is lk.Gaussian else (dp == [])
+    x = np.linspace(-10, 10, 100)
+    assert np.allclose(lk.Gaussian().loglike(x, 0., 2.), norm.logpdf(x, loc=0, scale=np.sqrt(2)))
+    assert np.allclose(lk.Gaussian().cdf(x, 0., 2.), norm.cdf(x, loc=0, scale=np.sqrt(2)))
+    xb = np.array([0, 1])
+    assert np.allclose(lk.Bernoulli().loglike(xb, logit(0.3)), bernoulli.logpmf(xb, 0.3))
+    assert np.allclose(lk.Bernoulli().cdf(xb, logit(0.3)), bernoulli.cdf(xb, 0.3))
+    xn = np.arange(6)
+    assert np.allclose(lk.Binomial().loglike(xn, logit(0.3), 5), binom.logpmf(xn, p=0.3, n=5))
+    assert np.allclose(lk.Binomial().cdf(xn, logit(0.3), 5), binom.cdf(xn, p=0.3, n=5))
+    assert np.allclose(lk.Poisson().loglike(xn, np.log(2.)), poisson.logpmf(xn, 2.))
+    assert np.allclose(lk.Poisson().cdf(xn, np.log(2.)), poisson.cdf(xn, 2.))
+    g = np.log(np.expm1(2.))   # softplus(g) = 2
+    assert np.allclose(lk.Poisson("softplus").loglike(xn, g), poisson.logpmf(xn, 2.))
