@@ -50,10 +50,15 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         reference's order, so a seeded run consumes the reference's random stream (1 M draws per step at config 5's
         shape: 18 ms, more than everything else together).  "device": a counter-based generator on the GPU keyed by
         one integer drawn from ``random_`` at the start of ``fit`` and the step number -- reproducible for a given
-        seed, statistically equivalent, not the reference's stream; only the (D, K) expectations come back."""
+        seed, statistically equivalent, not the reference's stream; only the (D, K) expectations come back.
+    distributed : bool
+        Row-sharded SVI, one process per GPU under ``torch.distributed``: every rank calls ``fit`` with ITS rows and
+        the same integer ``random_state``; per step each rank takes a minibatch of its shard, the Monte-Carlo sums
+        ``[Edm | EdC | sum loglike | likelihood sums | basis gradient | batch rows]`` are all-reduced (one message,
+        2 D K + O(d) numbers) and every rank applies the same update."""
 
     def __init__(self, likelihood=Gaussian(), basis=LinearBasis(), K=10, maxiter=3000, batch_size=10, updater=None,
-                 nsamples=50, nstarts=500, random_state=None, sampler="host"):
+                 nsamples=50, nstarts=500, random_state=None, sampler="host", distributed=False):
         self.likelihood = likelihood
         self.basis = basis
         self.K = K
@@ -64,6 +69,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         self.nstarts = nstarts
         self.random_state = random_state
         self.sampler = sampler
+        self.distributed = distributed
         self.random_ = check_random_state(self.random_state)
 
     def fit(self, X, y, likelihood_args=()):
@@ -72,6 +78,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         self._dev_seed = None  # the device sampler is re-keyed from random_ per fit
         N, _ = X.shape
         self.B_ = X.shape[0] / self.batch_size
+        if self.distributed:  # batch magnification of the whole job: N_total / (sum of the ranks' minibatch sizes)
+            from . import parallel
+            tot = parallel.allreduce_host(np.array([float(N), float(min(self.batch_size, N))]))
+            self.B_ = tot[0] / tot[1]
         self.D_ = self.basis.get_dim(X)
         likelihood_args = _reshape_likelihood_args(likelihood_args, N)
         data = (X, y) + likelihood_args
@@ -145,6 +155,23 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
             Edm, EdC, llsum, aux = feats.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L_, e)
 
+        dbpars = feats.glm_basis_grads(X)                                     # -(EdPhi o dPhi).sum() per parameter
+        nrows = float(len(y))
+        if self.distributed:  # one exchange per step: the per-rank Monte-Carlo sums
+            from . import parallel
+            from .utils import flatten_values
+            flat_db = flatten_values(dbpars)
+            buf = np.concatenate((Edm.ravel(), EdC.ravel(), llsum, aux, flat_db, [llconst, nrows]))
+            buf = parallel.allreduce_host(buf)
+            o = 0
+            Edm = buf[o:o + D * K].reshape(D, K); o += D * K
+            EdC = buf[o:o + D * K].reshape(D, K); o += D * K
+            llsum = buf[o:o + K]; o += K
+            aux = buf[o:o + K]; o += K
+            red_db = buf[o:o + flat_db.size]; o += flat_db.size
+            llconst, nrows = float(buf[o]), float(buf[o + 1])
+            dbpars = _like_structure(dbpars, red_db)
+
         L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
         iL = 1. / L[:, np.newaxis]
         logNkl = _qmatrix(m, C)
@@ -166,14 +193,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
               + np.einsum("dkl,kl->dk", iCkCj - (mkmj * iCkCj) ** 2, alpha)) / (2 * K)
         if len(dlpars) > 0:  # only the Gaussian has a likelihood parameter: dp = ((y-f)^2/var^2 - 1/var)/2
             ivar = 1. / lpar
-            Edlp = 0.5 * (aux * ivar ** 2 - ivar * len(y) * L_) / L_
+            Edlp = 0.5 * (aux * ivar ** 2 - ivar * nrows * L_) / L_
             dlpars[0] = dlpars[0] - Edlp.sum() / K
 
         def dreg(s):
             return -0.5 * (((m[s] ** 2 + C[s]) * iL[s] ** 2).sum() / K - iL[s].sum())
 
         dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
-        dbpars = feats.glm_basis_grads(X)                                     # -(EdPhi o dPhi).sum() per parameter
 
         ELBO = -np.inf
         if calc_ll:
@@ -267,6 +293,20 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
 class GeneralisedLinearModel(GeneralizedLinearModel):
     """GB/AU spelling (glm.py:640-642)."""
+
+
+def _like_structure(template, flat):
+    """`flat` cut back into the nesting of `template` (scalars, arrays, lists of them, [])."""
+    pos = [0]
+
+    def build(t):
+        if isinstance(t, list):
+            return [build(u) for u in t]
+        n = int(np.size(t))
+        v = flat[pos[0]:pos[0] + n]
+        pos[0] += n
+        return float(v[0]) if np.ndim(t) == 0 else np.array(v).reshape(np.shape(t))
+    return build(template)
 
 
 def _reshape_likelihood_args(likelihood_args, N):

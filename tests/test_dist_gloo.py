@@ -163,3 +163,112 @@ def test_two_rank_distributed_fit_equals_single_process():
     assert res[0][1:] == res[1][1:]                       # ranks agree bit-for-bit, evaluation and fit
     assert np.allclose(res[0][1], single[1], rtol=1e-9, atol=1e-9)
     assert res[0][5] > -1e6 and np.isfinite(res[0][2])    # the fit moved to a finite optimum
+
+
+# -- row-sharded SVI of the generalised linear model -------------------------------------------------
+
+class _OracleFeatures(object):
+    """Test double for revrand_amd.basis_functions.MinibatchFeatures: the same interface, the per-rank device step
+    replaced by the NumPy oracle (no GPU here).  The estimator's `_elbo`, the packing and the all-reduce are the
+    product's code."""
+
+    def __init__(self, basis):
+        self.basis = basis
+
+    def make_resident(self, X):
+        return False
+
+    def assemble(self, X, hypers):
+        self.X, self.ls = X, hypers[0]
+        self.Phi = orc.rff_transform(X, self.basis.W, self.ls)
+
+    def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E):
+        D = m.shape[0]
+        Edm, EdC, ll = np.empty((D, K)), np.empty((D, K)), np.empty(K)
+        self.EdPhi = np.zeros_like(self.Phi)
+        for k in range(K):
+            e = E[k * L:(k + 1) * L].astype(float)
+            Sk = np.sqrt(C[:, k])
+            ws = m[:, k] + Sk * e
+            fs = ws @ self.Phi.T
+            dfs = orc.lik_df("poisson_exp", y, fs)
+            Edws = dfs @ self.Phi
+            Edm[:, k] = Edws.sum(axis=0) / L
+            EdC[:, k] = (Edws * e / Sk).sum(axis=0) / L
+            ll[k] = (y * fs - np.exp(fs)).sum()
+            self.EdPhi += dfs.T @ ws / (L * K)
+        return Edm, EdC, ll, np.zeros(K)
+
+    def glm_basis_grads(self, X):
+        dP = orc.rff_grad(self.X, self.basis.W, self.ls)
+        return np.array([-(self.EdPhi * dP[:, :, i]).sum() for i in range(dP.shape[2])])
+
+    def release(self):
+        pass
+
+
+def _glm_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from revrand_amd.basis_functions import RandomRBF
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    from revrand_amd.likelihoods import Poisson
+    from revrand_amd.optimize import Adam
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(0)
+        N, d, n, K, L = 240, 3, 6, 2, 4
+        X = rs.randn(N, d)
+        y = rs.poisson(np.exp(0.3 * np.sin(X[:, 0]))).astype(float)
+        a, b = parallel.shard_bounds(N, rank, world)
+        basis = RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
+                          regularizer=Parameter(1.5, Positive()))
+        glm = GeneralizedLinearModel(Poisson(), basis, K=K, nsamples=L, batch_size=b - a, maxiter=6, nstarts=0,
+                                     random_state=3, updater=Adam(alpha=0.05), distributed=world > 1)
+        glm._mbf = _OracleFeatures(basis)                      # no GPU in this container
+        # one evaluation on the whole shard
+        glm.B_, glm.D_ = 1.0, 2 * n
+        glm._GeneralizedLinearModel__it = -1
+        m, C = 0.1 * rs.randn(2 * n, K), rs.gamma(2., 0.5, (2 * n, K))
+        f, (ndm, ndC, dL, dlp, dbp) = glm._elbo(m, C, 1.5, [], np.array([0.9, 1.1, 1.3]), X[a:b], y[a:b])
+        ev = [float(f), float(dL)] + ndm.ravel().tolist() + ndC.ravel().tolist() + np.asarray(dbp).tolist()
+        # and a short fit on the shard (the double is re-installed: fit() releases its features at the end)
+        glm.random_ = np.random.RandomState(3)
+        orig = glm._features
+        glm._features = lambda: glm.__dict__.setdefault("_mbf", _OracleFeatures(basis))
+        glm.fit(X[a:b], y[a:b])
+        q.put((rank, ev, glm.weights_.ravel().tolist(), np.asarray(glm.basis_hypers_).tolist(), float(glm.regularizer_)))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_distributed_glm_step_equals_single_process():
+    """Row-sharded SVI: with every rank's minibatch covering its shard, the all-reduced `_elbo` on 2 ranks equals the
+    single-process evaluation on all rows (same seed -> same draws), and after a short distributed `fit` the ranks
+    hold identical parameters."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_glm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs])
+    for p in procs:
+        p.join(60)
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_glm_worker, args=(0, 1, 0, q1))
+    p1.start()
+    single = q1.get(timeout=500)
+    p1.join(60)
+    assert np.allclose(res[0][1], res[1][1], rtol=0, atol=0)              # ranks agree exactly
+    assert np.allclose(res[0][1], single[1], rtol=1e-9, atol=1e-10)        # and equal the all-rows evaluation
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
