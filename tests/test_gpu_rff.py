@@ -359,3 +359,30 @@ def test_tiny_and_ragged_shapes_end_to_end(N, d, n):
     assert np.all(np.abs(np.atleast_1d(dh) - want) < 5e-3 * scale + 1e-6)
     Ey, Vf = b.predict_moments(X, ls, m, C)
     assert normwise(Ey, Phi @ m) < 1e-3 and normwise(Vf, ((Phi @ C) * Phi).sum(axis=1)) < 1e-3
+
+
+def test_random_shape_sweep_against_oracle():
+    """Thirty pseudo-random (N, d, nbases, class, iso/ARD, f32/f64) combinations -- every padded width of the
+    kernels (d in 1..128), frequencies not a multiple of any tile, ragged row counts: transform, Gram and Phi^T y
+    against the oracle."""
+    from revrand_amd.btypes import Parameter, Positive
+    rs = np.random.RandomState(2024)
+    classes = ["RandomRBF", "RandomCauchy", "RandomMatern32", "RandomMatern52", "OrthogonalRBF"]
+    for trial in range(30):
+        d = int(rs.choice([1, 2, 3, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 100, 128]))
+        n = int(rs.randint(1, 300))
+        N = int(rs.randint(1, 1500))
+        ard = bool(rs.randint(2))
+        dtype = "f64" if trial % 5 == 4 else "f32"
+        cname = classes[trial % len(classes)]
+        X = rs.randn(N, d)
+        y = rs.randn(N)
+        b = _make(cname, d, n, trial, ard, dtype)
+        ls = rs.uniform(0.6, 1.8, d) if ard else float(rs.uniform(0.6, 1.8))
+        Phi = orc.rff_transform(X, b.W, ls)
+        tol = 1e-3 if dtype == "f32" else 1e-9
+        assert normwise(b.transform(X, ls), Phi) < tol, (trial, cname, N, d, n)
+        G, bv, yty = b.gram(X, y, ls)
+        gt = 2e-5 if dtype == "f32" else 1e-10
+        assert normwise(G, Phi.T @ Phi) < gt * 10 and normwise(bv, Phi.T @ y) < gt * 10, (trial, cname, N, d, n, dtype)
+        assert np.array_equal(G, G.T) and abs(yty - y @ y) <= 1e-6 * (y @ y) + 1e-12
