@@ -897,12 +897,27 @@ class FastFoodRBF(_LengthScaleBasis):
         s = np.sqrt(self._random.chisquare(self.d2, size=self.G.shape))
         return self.d2 * s / np.sqrt((self.G ** 2).sum(axis=1))[:, np.newaxis]
 
+    class _LazyDense(object):
+        """The dense-equivalent random Fourier handle, built on first use (the chain kernel alone serves `transform`
+        and `_makeVX`, also for 128 < d <= 256 where the random Fourier kernels do not go)."""
+
+        def __init__(self, owner, ff):
+            self.owner, self.ff, self.rff, self.V = owner, ff, None, None
+
+        def get(self):
+            if self.rff is None:
+                self.V = self.ff.vx(np.eye(self.owner.d), 1.0)  # (d, n): dense equivalent of the chain
+                self.rff = _hip.RffHandle(self.V, compute=self.owner.dtype)
+            return self.rff
+
+        def __getattr__(self, name):  # h.grad(...), h.gram(...), h.upload(...), ... on the dense handle
+            return getattr(self.get(), name)
+
     def _handles(self):
         h = self.__dict__.get("_hip_handle")
         if h is None or h[0] != _hip.os.getpid():
             ff = _hip.FastFoodHandle(self.d, self.d2, self.k, self.B, self.G, self.PI, self.S, compute=self.dtype)
-            V = ff.vx(np.eye(self.d), 1.0)  # (d, n): dense equivalent of the chain
-            h = (_hip.os.getpid(), ff, _hip.RffHandle(V, compute=self.dtype), V)
+            h = (_hip.os.getpid(), ff, FastFoodRBF._LazyDense(self, ff))
             self.__dict__["_hip_handle"] = h
         return h[1], h[2]
 
@@ -945,8 +960,8 @@ class FastFoodRBF(_LengthScaleBasis):
         dX.free()
 
     def _dense_handle(self):
-        rff = self._handles()[1]
-        return rff, self.__dict__["_hip_handle"][3]
+        lazy = self._handles()[1]
+        return lazy.get(), lazy.V
 
     @slice_transform
     def device_fit_state(self, X, y):

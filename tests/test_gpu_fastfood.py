@@ -191,3 +191,17 @@ def test_fastfood_transform_device_resident():
         got = dev.download(out, (777, ld), dt)
         assert normwise(got[:, :F], want) < 1e-5 and np.all(got[:, F:] == 0)
         out.free()
+
+
+def test_fastfood_wide_input_transform_only():
+    """128 < d <= 256: the FWHT chain kernel serves `transform` / `_makeVX` (d2 = 256); the dense-equivalent random
+    Fourier route (grad, Gram) stops at d = 128 and says so instead of returning something wrong."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd._hip import HipError
+    rs = np.random.RandomState(0)
+    X = rs.randn(300, 200)
+    f = bs.FastFoodRBF(nbases=300, Xdim=200, random_state=1)
+    B, G, PI, S = orc.fastfood_matrices(300, 200, 1)
+    assert normwise(f.transform(X, 1.7), orc.fastfood_transform(X, B, G, PI, S, 1.7)) < 1e-3
+    with pytest.raises(HipError, match="not supported"):
+        f.gram(X, np.zeros(300), 1.7)
