@@ -556,3 +556,28 @@ def test_second_pass_f64_ragged_multi_chunk(monkeypatch):
     err = y - Phi @ o["m"]
     assert normwise(G, Phi.T @ Phi) < 1e-10 and abs(sq - err @ err) < 1e-10 * (err @ err)
     assert normwise(dh, -np.array(o["dhyp"])) < 1e-8
+
+
+def test_gridsearch_in_worker_processes_like_reference_test_models():
+    """tests/test_models.py:53-80,166-194 of the reference: GridSearchCV / RandomizedSearchCV over estimators, in
+    worker PROCESSES (n_jobs=2): estimators and bases are pickled to the workers (device handles are per process,
+    created lazily, never pickled) and each worker drives the GPU through its own context."""
+    from sklearn.model_selection import GridSearchCV, RandomizedSearchCV
+    bs, Parameter, Positive, SLM = _imports()
+    from revrand_amd.glm import GeneralizedLinearModel
+    from revrand_amd.likelihoods import Gaussian
+    X, y, Xs, ys = _gaus_data()
+    slm = SLM(bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=20, Xdim=X.shape[1], random_state=0), nstarts=0,
+              maxiter=30)
+    slm.basis.transform(X[:5], 1.0)   # the parent holds live handles when the estimator is pickled
+    est = GridSearchCV(slm, {"var": [Parameter(v, Positive()) for v in [1.0, 2.0]]}, n_jobs=2, cv=3)
+    est.fit(X, y)
+    assert len(est.predict(Xs)) == len(ys) and smse(ys, est.predict(Xs)) < 0.5
+    est = RandomizedSearchCV(SLM(bs.LinearBasis(onescol=True)), {"var": [Parameter(1.0 / v, Positive()) for v in range(1, 6)]},
+                             n_jobs=2, n_iter=2, cv=3, random_state=0)
+    est.fit(X, y)
+    assert len(est.predict(Xs)) == len(ys)
+    glm = GeneralizedLinearModel(Gaussian(), bs.LinearBasis(onescol=True), random_state=1, maxiter=100, nstarts=10)
+    est = GridSearchCV(glm, {"batch_size": [10, 20]}, n_jobs=2, cv=3)
+    est.fit(X, y)
+    assert len(est.predict(Xs)) == len(ys)
