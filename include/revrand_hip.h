@@ -91,7 +91,8 @@ int rr_timer_stop(rr_ctx *ctx, float *ms);
 int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_basis **out);
 void rr_basis_destroy(rr_basis *basis);
 
-/* Row length the kernels read from a DEVICE X: Xdim rounded up to 8/16/32/64/128.  Every
+/* Row length the kernels read from a DEVICE X: Xdim rounded up to 8/16/32/64/128, above
+ * that to a multiple of 128 (Xdim <= 4096).  Every
  * *_dev entry point requires ldx >= this and elements [d, padded) of each row to be zero
  * (they meet zero weights; NaN/Inf there would poison the row).  rr_upload_matrix with
  * ld_dev = rr_rff_padded_dim() produces exactly this layout; the host-buffer entry points

@@ -899,7 +899,7 @@ class FastFoodRBF(_LengthScaleBasis):
 
     class _LazyDense(object):
         """The dense-equivalent random Fourier handle, built on first use (the chain kernel alone serves `transform`
-        and `_makeVX`, also for 128 < d <= 256 where the random Fourier kernels do not go)."""
+        and `_makeVX`; `grad`, the Gram and resident fits use this handle)."""
 
         def __init__(self, owner, ff):
             self.owner, self.ff, self.rff, self.V = owner, ff, None, None

@@ -187,10 +187,15 @@ int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_ba
     b->n = n;
     b->npad = ((n + 127) / 128) * 128;
     b->dpad = rr_pick_dmax(d);
-    if (b->dpad == 0) {
-        delete b;
-        rr_set_error("rr_rff_create: Xdim=%d > 128 is not supported yet", d);
-        return RR_ERR_UNSUPPORTED;
+    if (b->dpad == 0) {  // d > 128: W columns no longer fit in registers, see "Xdim > 128" in rr_rff.hip
+        if (d > RR_MAX_XDIM) {
+            delete b;
+            rr_set_error("rr_rff_create: Xdim=%d > %d is not supported", d, RR_MAX_XDIM);
+            return RR_ERR_UNSUPPORTED;
+        }
+        b->large = true;
+        b->dpad = ((d + 127) / 128) * 128;
+        b->npad = ((n + 255) / 256) * 256;
     }
     b->W.assign(W, W + (size_t)d * n);
     size_t elems = (size_t)b->dpad * b->npad;
@@ -223,6 +228,8 @@ void rr_basis_destroy(rr_basis *b) {
     if (b->dmu32) (void)hipFree(b->dmu32);
     if (b->dmu64) (void)hipFree(b->dmu64);
     if (b->zbuf) (void)hipFree(b->zbuf);
+    if (b->lg_xt) (void)hipFree(b->lg_xt);
+    if (b->lg_z) (void)hipFree(b->lg_z);
     rr_pass2_scratch_free(b->pass2);
     rr_pass2d_scratch_free(b->pass2d);
     for (hipEvent_t ev : b->events) (void)hipEventDestroy(ev);

@@ -291,6 +291,10 @@ static int launch_features_t(rr_basis *b, const TX *X, int64_t N, int64_t Npad, 
     rr_ctx *c = b->ctx;
     const float scale = (float)(1.0 / sqrt((double)b->n));
     const dim3 grid((unsigned)(Npad / 256));
+    if (b->large) {  // Xdim > 128: no feature-major kernel; transpose the row-major features the caller just made
+        rr_set_error("pass2: internal: feature-major kernel called for Xdim > 128");
+        return RR_ERR_INVALID;
+    }
 #define RR_FT(DM)                                                                                                  \
     hipLaunchKernelGGL((rr_rff_features_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, X, N, Npad, ldx, b->dWt32, \
                        m32, b->n, Pt, ldt, dot, scale)
@@ -325,12 +329,20 @@ static int launch_grad_t(rr_basis *b, const TX *X, int64_t N, int64_t ldx, const
         case 32: RR_GT(32); break;
         case 64: RR_GT(64); break;
         case 128: RR_GT(128); break;
-        default: rr_set_error("pass2: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+        default:  // Xdim > 128: 128 input dimensions per launch (A is recomputed from P and U, 4 loads per (row, frequency))
+            for (int i0 = 0; i0 < b->d; i0 += 128)
+                hipLaunchKernelGGL((rr_grad_t_kernel<128, TX>), grid, dim3(256), 0, c->stream, X + i0, N, ldx, P, U, ldp, err,
+                                   m32, b->n, b->d - i0 < 128 ? b->d - i0 : 128, T + (size_t)i0 * b->n, (int)rpb);
     }
 #undef RR_GT
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
+
+__global__ void rr_transpose_f32_kernel(const float *__restrict__ P, int64_t rows, int64_t ldp, float *__restrict__ Pt,
+                                        int64_t ldt);
+__global__ void rr_rowvec_kernel(const float *__restrict__ P, const float *__restrict__ mvec, int64_t rows, int F, int64_t ld,
+                                 float *__restrict__ dot);
 
 // Common driver.  MODE_ELBO: out = [sqErr | T(d*n)] accumulated over row chunks (host doubles).
 //                 MODE_PRED: Ey, Vf per row (host doubles, length N).
@@ -407,7 +419,14 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         // row-major P (epilogues) and feature-major Pt + Phi m (GEMM operand)
         rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp, true);
         if (rc != RR_OK) break;
-        rc = launch_features_t<TX>(b, Xc, mrows, mpad, ldx, s.m32, s.Pt, chunk, s.dot);
+        if (b->large) {
+            hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
+                               s.P, mrows, Fp, s.Pt, chunk);
+            hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.m32, mrows,
+                               F, Fp, s.dot);
+        } else {
+            rc = launch_features_t<TX>(b, Xc, mrows, mpad, ldx, s.m32, s.Pt, chunk, s.dot);
+        }
         if (rc != RR_OK) break;
         // U = P C  as  (Pt)^T C : A = Pt (K = Fp, M = mpad columns), B = C32 (K = Fp, N = Fp)
         GemmArgs g;
@@ -779,6 +798,11 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
     return RR_OK;
 }
 
+int rr_launch_gemm_tn_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd,
+                          int64_t K, int64_t M, int64_t N) {  // D (M, N) = A^T B, A (K, M), B (K, N); M, N % 256 == 0, K % 32 == 0
+    return fm_gemm(c, A, lda, B, ldb, D, ldd, K, M, N);
+}
+
 // ---------------------------------------------------------------------------------------------
 // The second pass in f64 arithmetic (dtype = "f64" bases): same data flow, f64 features (sincospi), f64 MFMA GEMM
 // (rr_gemm_tn_f64_kernel, rr_rff.hip), f64 epilogues.  Small kernels are written for clarity, not tuned: the pass
@@ -994,7 +1018,11 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
                 case 32: RR_GT64(32); break;
                 case 64: RR_GT64(64); break;
                 case 128: RR_GT64(128); break;
-                default: rr_set_error("pass2: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+                default:
+                    for (int i0 = 0; i0 < b->d; i0 += 128)
+                        hipLaunchKernelGGL((rr_grad_t64_kernel<128, TX>), grid, dim3(256), 0, c->stream, Xc + i0, mrows, ldx, s.P,
+                                           s.U, Fp, s.err, s.m, n, b->d - i0 < 128 ? b->d - i0 : 128,
+                                           s.acc + 1 + (size_t)i0 * n, (int)rpb);
             }
 #undef RR_GT64
             RR_CHECK_HIP(hipGetLastError());
@@ -1009,6 +1037,44 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
     }
     (void)hipStreamSynchronize(c->stream);
     return rc;
+}
+
+// rr_grad_contract_kernel from finished features (Xdim > 128): a = E_s P_c - E_c P_s, T[i][f] += sum_r x[r][i] a
+template <int DMAX, typename TX, typename TE>
+__global__ void __launch_bounds__(256)
+rr_grad_contract_p_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ P, int64_t ldp,
+                          const TE *__restrict__ E, int64_t lde, int n, int d, double *__restrict__ T, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    const int fc = fvalid ? f : 0;
+    float t[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) t[i] = 0.f;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float a = (float)E[r * lde + n + fc] * P[r * ldp + fc] - (float)E[r * lde + fc] * P[r * ldp + n + fc];
+        const TX *xr = X + r * ldx;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) t[i] = fmaf((float)xr[i], a, t[i]);
+    }
+    if (fvalid) {
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i)
+            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+    }
+}
+
+static int large_scratch(rr_basis *b, size_t bytes) {  // the Gram feature scratch, reused (grow-only)
+    if (b->zbuf_bytes >= bytes) return RR_OK;
+    RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (b->zbuf) (void)hipFree(b->zbuf);
+    b->zbuf = nullptr;
+    b->zbuf_bytes = 0;
+    RR_CHECK_HIP(hipMalloc(&b->zbuf, bytes));
+    b->zbuf_bytes = bytes;
+    return RR_OK;
 }
 
 template <typename TX, typename TE>
@@ -1029,7 +1095,17 @@ static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ld
         case 32: RR_GC(32); break;
         case 64: RR_GC(64); break;
         case 128: RR_GC(128); break;
-        default: rr_set_error("grad_contract: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+        default: {  // Xdim > 128: features once (row-major f32 scratch), then 128 input dimensions per launch
+            const int64_t ldp = 2 * (int64_t)b->n;
+            int rc = large_scratch(b, (size_t)N * ldp * 4);
+            if (rc == RR_OK)
+                rc = rr_features_rowmajor_f32(b, dX, sizeof(TX) == 4 ? RR_F32 : RR_F64, N, N, ldx, (float *)b->zbuf, ldp, false);
+            if (rc != RR_OK) return rc;
+            for (int i0 = 0; i0 < b->d; i0 += 128)
+                hipLaunchKernelGGL((rr_grad_contract_p_kernel<128, TX, TE>), grid, dim3(256), 0, c->stream, dX + i0, N, ldx,
+                                   (const float *)b->zbuf, ldp, dE, lde, b->n, b->d - i0 < 128 ? b->d - i0 : 128,
+                                   dT + (size_t)i0 * b->n, (int)rpb);
+        }
     }
 #undef RR_GC
     RR_CHECK_HIP(hipGetLastError());
@@ -1433,7 +1509,16 @@ int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype,
         case 32: RR_GGD(32); break;
         case 64: RR_GGD(64); break;
         case 128: RR_GGD(128); break;
-        default: rr_set_error("rr_featmat_glm_rff: d=%d is not supported", b->d); return RR_ERR_UNSUPPORTED;
+        default:
+            for (int i0 = 0; i0 < b->d; i0 += 128) {
+                const int dd = b->d - i0 < 128 ? b->d - i0 : 128;
+                if (x_dtype == RR_F32)
+                    hipLaunchKernelGGL((rr_glm_grad_t_kernel<128, float>), grid, dim3(256), 0, c->stream, (const float *)dX + i0,
+                                       N, ldx, fm->P + col0, s.U + col0, fm->ld, b->n, dd, dT + (size_t)i0 * b->n, (int)rpb);
+                else
+                    hipLaunchKernelGGL((rr_glm_grad_t_kernel<128, double>), grid, dim3(256), 0, c->stream, (const double *)dX + i0,
+                                       N, ldx, fm->P + col0, s.U + col0, fm->ld, b->n, dd, dT + (size_t)i0 * b->n, (int)rpb);
+            }
     }
 #undef RR_GGD
 #undef RR_GG

@@ -27,14 +27,19 @@ struct rr_ctx {
 };
 
 enum rr_kind { RR_KIND_RFF = 0, RR_KIND_FASTFOOD = 1 };
+constexpr int RR_MAX_XDIM = 4096;  // random Fourier bases: largest input dimension
 
 struct rr_basis {
     rr_ctx *ctx = nullptr;
     int kind = RR_KIND_RFF;
     int compute = RR_F32;
     int d = 0, n = 0;
-    int dpad = 0;                 // d rounded up to 8/16/32/64/128: rows of Ws, row length kernels read
-    int npad = 0;                 // n rounded up to a multiple of 128 (device Ws row length)
+    int dpad = 0;                 // d rounded up to 8/16/32/64/128 (large: a multiple of 128): rows of Ws, row length kernels read
+    int npad = 0;                 // n rounded up to a multiple of 128 (large: 256) (device Ws row length)
+    bool large = false;           // d > 128: phases through a GEMM / phase kernel + trig kernel (rr_rff.hip)
+    float *lg_xt = nullptr;       // large: X^T scratch (dpad, rows), f32
+    void *lg_z = nullptr;         // large: phase scratch (rows, npad), compute dtype
+    size_t lg_xt_bytes = 0, lg_z_bytes = 0;
     std::vector<double> W;        // host copy (d, n) row-major, as given
     std::vector<double> ls_cache; // lenscale the device copy was scaled with
     float *dWs32 = nullptr;       // (dpad, npad), zero padded: W[i][f] / (l_i * 2pi)   -> phase in revolutions

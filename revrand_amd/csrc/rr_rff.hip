@@ -915,11 +915,196 @@ __global__ void __launch_bounds__(256) rr_symmetrize_kernel(double *G, int64_t F
 
 int rr_pick_dmax(int d) { return d <= 8 ? 8 : d <= 16 ? 16 : d <= 32 ? 32 : d <= 64 ? 64 : d <= 128 ? 128 : 0; }
 
+// ---------------------------------------------------------------------------------------
+// Xdim > 128 (b->large).  A frequency's W column no longer fits in a thread's registers, so the phases
+// Z = X Ws are produced as a matrix first -- f32 arithmetic: (X^T)^T Ws on the matrix cores
+// (rr_gemm_tn_f32_kernel, rr_elbo.hip; operands X^T (dpad, rows) and Ws (dpad, npad), both zero padded),
+// f64 arithmetic: a VALU kernel, 8 rows per thread -- and rr_trig_kernel applies cos / sin / scale (and
+// accumulates Phi^T y).  Row sub-chunks of RR_LG_ROWS bound the scratch (X^T: dpad x rows, Z: rows x npad).
+// Same arithmetic as the register kernels: f32 products of x and Ws summed in f32 (MFMA order), the phase
+// reduced to [-0.5, 0.5] revolutions before v_sin / v_cos.
+// ---------------------------------------------------------------------------------------
+constexpr int64_t RR_LG_ROWS = 131072;
+
+int rr_launch_gemm_tn_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd,
+                          int64_t K, int64_t M, int64_t N);  // rr_elbo.hip
+
+// Xt[c][r] = (float) X[r][c], c < dpad (grid.x = dpad / 64), r < rows256 (grid.y = rows256 / 64); rows >= `rows` -> 0
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_xt_kernel(const TX *__restrict__ X, int64_t rows, int64_t ldx, float *__restrict__ Xt, int64_t ldt) {
+    __shared__ float tile[64][65];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t r = r0 + ty + 4 * k;
+        tile[ty + 4 * k][tx] = r < rows ? (float)X[r * ldx + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) Xt[(c0 + ty + 4 * k) * ldt + r0 + tx] = tile[tx][ty + 4 * k];
+}
+
+// Z[r][f] = sum_i x[r][i] Ws[i][f] in f64: one frequency per thread, 8 rows per block (x through the scalar cache)
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_phase_f64_kernel(const TX *__restrict__ X, int64_t rows, int64_t ldx, const double *__restrict__ Ws, int dpad,
+                    int npad, double *__restrict__ Z, int64_t ldz) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 8;
+    const TX *xr[8];
+    double z[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t r = r0 + k < rows ? r0 + k : rows - 1;
+        xr[k] = X + r * ldx;
+        z[k] = 0.0;
+    }
+    for (int i = 0; i < dpad; ++i) {
+        const double w = Ws[(size_t)i * npad + f];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) z[k] = fma((double)xr[k][i], w, z[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (r0 + k < rows) Z[(r0 + k) * ldz + f] = z[k];
+}
+
+// P[r][f] = cos(2 pi Z[r][f]) scale, P[r][n + f] = sin(..) scale for r < N, zero rows for N <= r < Npad;
+// HAS_Y: bvec += P^T y.
+template <typename TC, typename TO, bool HAS_Y, typename TY>
+__global__ void __launch_bounds__(256)
+rr_trig_kernel(const TC *__restrict__ Z, int64_t ldz, const TY *__restrict__ y, int64_t N, int64_t Npad, int n,
+               TO *__restrict__ P, int64_t ldp, double *__restrict__ bvec, TC scale, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    const bool fvalid = f < n;
+    const int fc = fvalid ? f : 0;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > Npad) r1 = Npad;
+    TC bc = 0, bs = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+        TC c = 0, s = 0;
+        if (r < N) {  // uniform
+            sincos_rev(Z[r * ldz + fc], s, c);
+            c *= scale;
+            s *= scale;
+            if (HAS_Y) {
+                const TC yv = (TC)y[r];
+                bc = fma(c, yv, bc);
+                bs = fma(s, yv, bs);
+            }
+        }
+        if (fvalid) {
+            P[r * ldp + f] = (TO)c;
+            P[r * ldp + n + f] = (TO)s;
+        }
+    }
+    if (HAS_Y && fvalid) {
+        unsafeAtomicAdd(&bvec[f], (double)bc);
+        unsafeAtomicAdd(&bvec[n + f], (double)bs);
+    }
+}
+
+static int large_ensure(rr_basis *b, size_t xt_bytes, size_t z_bytes) {
+    if (b->lg_xt_bytes >= xt_bytes && b->lg_z_bytes >= z_bytes) return RR_OK;
+    RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (b->lg_xt_bytes < xt_bytes) {
+        if (b->lg_xt) (void)hipFree(b->lg_xt);
+        b->lg_xt = nullptr;
+        b->lg_xt_bytes = 0;
+        RR_CHECK_HIP(hipMalloc((void **)&b->lg_xt, xt_bytes));
+        b->lg_xt_bytes = xt_bytes;
+    }
+    if (b->lg_z_bytes < z_bytes) {
+        if (b->lg_z) (void)hipFree(b->lg_z);
+        b->lg_z = nullptr;
+        b->lg_z_bytes = 0;
+        RR_CHECK_HIP(hipMalloc(&b->lg_z, z_bytes));
+        b->lg_z_bytes = z_bytes;
+    }
+    return RR_OK;
+}
+
+// Features of m rows into P (row-major, leading dimension ldp, [cos | sin] at columns [0, n) and [n, 2n)); rows
+// [m, mpad) are written as zeros; db (optional, with y) accumulates Phi^T y.
+template <typename TX, typename TC, typename TO>
+static int large_features(rr_basis *b, const TX *X, const TX *y, int64_t m, int64_t mpad, int64_t ldx, TO *P, int64_t ldp,
+                          double *db) {
+    rr_ctx *c = b->ctx;
+    constexpr bool F32 = sizeof(TC) == 4;
+    const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    int64_t sub = (mpad + 255) / 256 * 256;
+    if (sub > RR_LG_ROWS) sub = RR_LG_ROWS;
+    int rc = large_ensure(b, F32 ? (size_t)b->dpad * sub * 4 : 16, (size_t)sub * b->npad * sizeof(TC));
+    if (rc != RR_OK) return rc;
+    TC *Z = (TC *)b->lg_z;
+    const int fblocks = (b->n + 255) / 256;
+    for (int64_t s0 = 0; s0 < mpad; s0 += sub) {
+        const int64_t rows_out = mpad - s0 < sub ? mpad - s0 : sub;                // rows of P this sub-chunk writes
+        const int64_t rows_in = m - s0 < 0 ? 0 : (m - s0 < sub ? m - s0 : sub);   // rows of X behind them
+        if (rows_in > 0) {
+            const TX *Xs = X + s0 * ldx;
+            const int64_t r256 = (rows_in + 255) / 256 * 256;
+            if constexpr (F32) {
+                hipLaunchKernelGGL(rr_xt_kernel<TX>, dim3((unsigned)(b->dpad / 64), (unsigned)(r256 / 64)), dim3(256), 0,
+                                   c->stream, Xs, rows_in, ldx, b->lg_xt, sub);
+                rc = rr_launch_gemm_tn_f32(c, b->lg_xt, sub, b->dWs32, b->npad, (float *)Z, b->npad, b->dpad, r256, b->npad);
+                if (rc != RR_OK) return rc;
+            } else {
+                hipLaunchKernelGGL(rr_phase_f64_kernel<TX>, dim3((unsigned)(b->npad / 256), (unsigned)((rows_in + 7) / 8)),
+                                   dim3(256), 0, c->stream, Xs, rows_in, ldx, b->dWs64, b->dpad, b->npad, (double *)Z,
+                                   (int64_t)b->npad);
+            }
+        }
+        int64_t rpb = (rows_out * fblocks + (int64_t)c->num_cu * 16 - 1) / ((int64_t)c->num_cu * 16);
+        if (rpb < 16) rpb = 16;
+        if (rpb > 1024) rpb = 1024;
+        const dim3 grid(fblocks, (unsigned)((rows_out + rpb - 1) / rpb));
+        TO *Ps = P + s0 * ldp;
+        if (y && db)
+            hipLaunchKernelGGL((rr_trig_kernel<TC, TO, true, TX>), grid, dim3(256), 0, c->stream, Z, (int64_t)b->npad, y + s0,
+                               rows_in, rows_out, b->n, Ps, ldp, db, scale, (int)rpb);
+        else
+            hipLaunchKernelGGL((rr_trig_kernel<TC, TO, false, TX>), grid, dim3(256), 0, c->stream, Z, (int64_t)b->npad,
+                               (const TX *)nullptr, rows_in, rows_out, b->n, Ps, ldp, (double *)nullptr, scale, (int)rpb);
+        RR_CHECK_HIP(hipGetLastError());
+    }
+    return RR_OK;
+}
+
+// d Phi / d l_i from finished features (large Xdim):  dz_i = -x_i Ws[i][f] gfac_i,  d cos = -(P_s) dz_i,  d sin = P_c dz_i
+// (P already carries the 1/sqrt(n) scale).  Same output layout as rr_rff_grad_kernel.
+template <typename TX, typename TC, typename TO>
+__global__ void __launch_bounds__(256)
+rr_rff_grad_p_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const TC *__restrict__ Ws,
+                     const TC *__restrict__ gfac, const TC *__restrict__ P, int64_t ldp, int n, int npad, int nout,
+                     TO *__restrict__ out, int rows_per_block) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    for (int64_t r = r0; r < r1; ++r) {
+        const TX *xr = X + r * ldx;
+        const TC c = P[r * ldp + f], s = P[r * ldp + n + f];
+        TO *oc = out + ((size_t)r * 2 * n + f) * nout;
+        TO *os = out + ((size_t)r * 2 * n + n + f) * nout;
+        for (int i = 0; i < nout; ++i) {
+            const TC dz = -(TC)xr[i] * Ws[(size_t)i * npad + f] * gfac[i];
+            oc[i] = (TO)(-s * dz);
+            os[i] = (TO)(c * dz);
+        }
+    }
+}
+
 template <typename TX, typename TC, typename TO>
 static int launch_transform(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *dPhi, int64_t ldphi) {
     rr_ctx *c = b->ctx;
     const TC *Ws = (sizeof(TC) == 4) ? (const TC *)b->dWs32 : (const TC *)b->dWs64;
     const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    if (b->large) return large_features<TX, TC, TO>(b, (const TX *)dX, nullptr, N, N, ldx, (TO *)dPhi, ldphi, nullptr);
     if constexpr (sizeof(TC) == 4) {  // f32 arithmetic: whole 32-row tiles with the projection on MFMA, the rest below
         const int64_t full = N / 32 * 32;
         if (full > 0 && rr_features_mfma_launch<TX, TO>(b, (const TX *)dX, nullptr, full, full, ldx, (TO *)dPhi, ldphi,
@@ -954,6 +1139,8 @@ static int launch_transform(rr_basis *b, const void *dX, int64_t N, int64_t ldx,
     return RR_OK;
 }
 
+static int ensure_zbuf(rr_basis *b, size_t bytes);
+
 template <typename TX, typename TC, typename TO>
 static int launch_grad(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *dOut, int nout) {
     rr_ctx *c = b->ctx;
@@ -964,6 +1151,16 @@ static int launch_grad(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void
     int64_t rpb = 16;
     if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
     dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+    if (b->large) {  // features first (compute dtype, in the Gram scratch), then the product rule per (row, frequency, i)
+        const int64_t ldp = 2 * (int64_t)b->n;
+        int rc = ensure_zbuf(b, (size_t)N * ldp * sizeof(TC));
+        if (rc == RR_OK) rc = large_features<TX, TC, TC>(b, (const TX *)dX, nullptr, N, N, ldx, (TC *)b->zbuf, ldp, nullptr);
+        if (rc != RR_OK) return rc;
+        hipLaunchKernelGGL((rr_rff_grad_p_kernel<TX, TC, TO>), grid, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, Ws, gf,
+                           (const TC *)b->zbuf, ldp, b->n, b->npad, nout, (TO *)dOut, (int)rpb);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
 #define RR_LG(DM)                                                                                \
     hipLaunchKernelGGL((rr_rff_grad_kernel<DM, TX, TC, TO>), grid, dim3(256), 0, c->stream,       \
                        (const TX *)dX, N, ldx, Ws, gf, b->n, b->npad, nout, (TO *)dOut, scale,    \
@@ -1200,7 +1397,11 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
         // (A) features (+ Phi^T y): MFMA projection for f32 X, else the VALU kernel
         bool done_a = false;
-        if constexpr (F32) done_a = rr_features_mfma_launch<TX, float>(b, Xc, yc, m, mpad, ldx, (float *)P, ldp, db, (float)scale);
+        if (b->large) {
+            rc = large_features<TX, TC, TC>(b, Xc, yc, m, mpad, ldx, P, ldp, db);
+            if (rc != RR_OK) return rc;
+            done_a = true;
+        } else if constexpr (F32) done_a = rr_features_mfma_launch<TX, float>(b, Xc, yc, m, mpad, ldx, (float *)P, ldp, db, (float)scale);
         if (!done_a) {
             const int fblocks = (b->n + 255) / 256;
             int64_t rpb = 256;
@@ -1251,6 +1452,9 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
         hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
     }
+    if (b->large)
+        return x_dtype == RR_F32 ? large_features<float, float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr)
+                                 : large_features<double, float, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr);
     if (x_dtype == RR_F32 ? rr_features_mfma_launch<float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)
                           : rr_features_mfma_launch<double, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)) {
         RR_CHECK_HIP(hipGetLastError());
@@ -1295,6 +1499,9 @@ int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m
         hipLaunchKernelGGL(rr_zero_padcols_kernel<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
     }
+    if (b->large)
+        return x_dtype == RR_F32 ? large_features<float, double, double>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr)
+                                 : large_features<double, double, double>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr);
     const int fblocks = (b->n + 255) / 256;
     int64_t rpb = 256;
     if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
