@@ -79,6 +79,7 @@ void rr_ctx_destroy(rr_ctx *ctx) {
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->tile_map) (void)hipFree(ctx->tile_map);
+    if (ctx->pb) (void)hipFree(ctx->pb);
     rr_posdef_scratch_free(ctx->posdef);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);

@@ -20,6 +20,8 @@ struct rr_ctx {
     int num_cu = 0;
     int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
     int tile_map_nb = 0;
+    void *pb = nullptr;       // split-bf16 copy of the feature chunk (rr_syrk_bf16x3_kernel), grow-only
+    size_t pb_bytes = 0;
     void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): rocBLAS handle + small device vectors
     void *pin[2] = {nullptr, nullptr};  // pinned host double buffer of rr_host_sink (grow-only)
     size_t pin_cap = 0;

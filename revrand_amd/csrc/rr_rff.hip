@@ -1256,7 +1256,13 @@ static void build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
 }
 
 // G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
+static int rr_launch_syrk_bf16x3(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid);
+
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
+    {
+        const char *eng = getenv("RR_SYRK_ENGINE");
+        if (eng && !strcmp(eng, "bf16x3")) return rr_launch_syrk_bf16x3(c, P, rows, ldp, F, dG, mid);
+    }
     const int nb = (int)(ldp / GR_TC);
     const int od = (nb >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
     const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
@@ -1316,6 +1322,216 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         ad.rows_per_split = rps_d;
         hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb)), dim3(GR_THREADS), 0, c->stream, ad);
     }
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Split-bf16 SYRK ("bf16x3"): every f32 feature value p is split into hi = bf16(p) and lo = bf16(p - hi)
+// (|p - hi - lo| <= 2^-17 |p|) and G accumulates hi.hi + hi.lo + lo.hi in f32 on the bf16 matrix pipe
+// (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate), dropping only lo.lo (<= 2^-18 |p_a p_b|).  Same workgroup
+// shape as rr_syrk_f32_kernel: 256x256 block of G, 8 waves of 128x64, k-blocks of 32 rows by LDS-DMA, double
+// buffered, f64 atomics across K-splits.
+//
+// Operands need 8 consecutive k (rows) of one column per lane, so the feature chunk is re-laid first
+// (rr_split_bf16_kernel): Pb[kb][c] = 128 B = [hi of rows 32 kb .. +32 | lo of the same rows], column c of ldp.
+// A 256-column side of a k-block is then 32 KiB contiguous.  In LDS the eight 16-B granules of a column are
+// XOR-swizzled with (c >> 1) & 7 -- the DMA (lane-linear in LDS) applies the permutation on its global
+// addresses -- which makes every ds_read_b128 operand fetch conflict-free.
+// ---------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+// grid (ldp / 256, rows / 32), 256 threads: thread = column, 32 rows of it in registers
+__global__ void __launch_bounds__(256)
+rr_split_bf16_kernel(const float *__restrict__ P, int64_t ldp, uintx4 *__restrict__ Pb) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, kb = blockIdx.y;
+    const float *src = P + kb * 32 * ldp + c;
+    unsigned hi[16], lo[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float x0 = src[(2 * k) * ldp], x1 = src[(2 * k + 1) * ldp];
+        const unsigned h0 = bf16_rne(x0), h1 = bf16_rne(x1);
+        const unsigned l0 = bf16_rne(x0 - __uint_as_float(h0 << 16)), l1 = bf16_rne(x1 - __uint_as_float(h1 << 16));
+        hi[k] = h0 | (h1 << 16);
+        lo[k] = l0 | (l1 << 16);
+    }
+    uintx4 *dst = Pb + (kb * ldp + c) * 8;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        dst[q] = uintx4{hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]};
+        dst[4 + q] = uintx4{lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]};
+    }
+}
+
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_bf16x3_kernel(const SyrkArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * 65536];  // two buffers of [A side 32 KiB | B side 32 KiB]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int tdx = blockIdx.x % p.ntiles;
+    const int ks = blockIdx.x / p.ntiles;
+    if (p.tile_map) tdx = p.tile_map[tdx];
+    int ta = 0;
+    const int od = p.offdiag_only;
+    while (tdx >= p.nb - ta - od) {
+        tdx -= p.nb - ta - od;
+        ++ta;
+    }
+    const int tb = ta + tdx + od;
+    const int ca = ta * GR_TC, cb = tb * GR_TC;
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+
+    // ---- DMA role: 64 instructions of 1 KiB (8 columns) per buffer; wave w issues t = 8 w + k: waves 0-3 the A
+    // side, 4-7 the B side.  Lane L fills granule t*64 + L = column 8 t' + (L >> 3), slot L & 7.
+    const char *Pb = (const char *)p.P;
+    const int cl = lane >> 3, x = lane & 7;
+    const unsigned lane_src0 = (unsigned)(cl * 128 + ((x ^ (cl >> 1)) * 16));
+    const unsigned lane_src1 = (unsigned)(cl * 128 + (((x ^ (cl >> 1)) ^ 4) * 16));
+    const int side = wave >> 2;
+    const int tt0 = (wave & 3) * 8;
+    const int64_t cside = side ? cb : ca;
+    auto dma_tile = [&](char *buf, int64_t kb) {
+        const char *src = Pb + (kb * p.ldp + cside) * 128 + (int64_t)tt0 * 1024;
+        char *dst = buf + side * 32768 + tt0 * 1024;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024 + ((k & 1) ? lane_src1 : lane_src0)),
+                                             (lptr_t)(dst + k * 1024), 16, 0, 0);
+    };
+
+    // ---- consumer role: wave (wr, wc) -> columns [wr*128, +128) of side A (4 blocks), [wc*64, +64) of side B (2)
+    const int wr = wave >> 2, wc_ = wave & 3;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int sw = (l31 >> 1) & 7;
+    unsigned offA[2][2], offB[2][2];  // [part][k-step]
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const unsigned xs = (unsigned)(((h ^ sw) ^ (4 * pp + 2 * s)) * 16);
+            offA[pp][s] = (unsigned)((wr * 128 + l31) * 128) + xs;
+            offB[pp][s] = 32768u + (unsigned)((wc_ * 64 + l31) * 128) + xs;
+        }
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int64_t kb0 = row_begin / GR_KB;
+    const int64_t nkb = (row_end - row_begin) / GR_KB;
+    if (nkb > 0) {
+        dma_tile(lds, kb0);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * 65536, kb0 + kb + 1);
+            const char *cur = lds + cbuf * 65536;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ah[i] = *(const bf16x8 *)(cur + offA[0][s] + i * 4096);
+                    al[i] = *(const bf16x8 *)(cur + offA[1][s] + i * 4096);
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[j] = *(const bf16x8 *)(cur + offB[0][s] + j * 4096);
+                    bl[j] = *(const bf16x8 *)(cur + offB[1][s] + j * 4096);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+        }
+    }
+
+    const int64_t F = p.F;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t gc = cb + wc_ * 64 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+            }
+        }
+    }
+}
+
+static int rr_launch_syrk_bf16x3(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
+    const int nb = (int)(ldp / GR_TC);
+    const int od = 0;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int nxcd = 8;
+    const bool use_map = (ntiles % nxcd == 0) && !getenv("RR_GRAM_NO_TILE_MAP");
+    if (use_map && c->tile_map_nb != nb * 2 + od) {
+        std::vector<int> map;
+        build_tile_map(nb, od, nxcd, map);
+        if (c->tile_map) (void)hipFree(c->tile_map);
+        c->tile_map = nullptr;
+        RR_CHECK_HIP(hipMalloc((void **)&c->tile_map, map.size() * sizeof(int)));
+        RR_CHECK_HIP(hipMemcpy(c->tile_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+        c->tile_map_nb = nb * 2 + od;
+    }
+    const size_t need = (size_t)rows * ldp * 4;
+    if (c->pb_bytes < need) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (c->pb) (void)hipFree(c->pb);
+        c->pb = nullptr;
+        c->pb_bytes = 0;
+        RR_CHECK_HIP(hipMalloc(&c->pb, need));
+        c->pb_bytes = need;
+    }
+    hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(ldp / 256), (unsigned)(rows / 32)), dim3(256), 0, c->stream, P, ldp,
+                       (uintx4 *)c->pb);
+    if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
+    auto gcd64 = [](int64_t x, int64_t y) { while (y) { const int64_t u = x % y; x = y; y = u; } return x; };
+    const int64_t min_splits = (rows + 32767) / 32768;
+    const int64_t unit = c->num_cu / gcd64(c->num_cu, ntiles);
+    int64_t nsplit = (min_splits + unit - 1) / unit * unit;
+    if (rows / nsplit < 1024) nsplit = (rows + 1023) / 1024;
+    if (nsplit < 1) nsplit = 1;
+    int64_t rps = ((rows + nsplit - 1) / nsplit + GR_KB - 1) / GR_KB * GR_KB;
+    const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
+    if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
+    nsplit = (rows + rps - 1) / rps;
+    RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+    SyrkArgs a;
+    a.P = (const float *)c->pb; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps;
+    a.G = dG;
+    a.tile_map = use_map ? c->tile_map : nullptr;
+    a.offdiag_only = od;
+    a.ablate = 0;
+    hipLaunchKernelGGL(rr_syrk_bf16x3_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
