@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 
 # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools_prof.sh),
 # corrected as MI355X_MICROARCH.md prescribes; the committed summary is quoted, per launch.
@@ -83,6 +84,9 @@ def main():
     ap.add_argument("--nbases", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", choices=["f32", "bf16x3", "bf16x4"], default=None,
+                    help="arithmetic of the Gram (default: f32 MFMA, or $RR_SYRK_ENGINE); see DESIGN.md 3.13")
+    ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational bf16x3 measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,6 +119,9 @@ def main():
     W = np.random.RandomState(42).randn(d, n)
     wvec = np.random.RandomState(1).randn(d).astype(np.float32)
     basis = _hip.RffHandle(W, compute="f32", device=local_rank)
+    if args.engine:
+        dev.set_gram_engine(args.engine)
+    engine = dev.gram_engine
 
     # ---- this rank's contiguous row shard (equal to within one row), generated in 250k-row chunks
     # (chunk c of the data set always comes from RNG stream c, so the data do not depend on N_gpus)
@@ -173,6 +180,34 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    # ---- parity of the measured path on a slice, off-diagonal entries included: Gram of the first rows against the
+    # oracle (checker only) before anything is timed ----
+    parity_err = None
+    if rank == 0 and my_rows >= 2048:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import revrand_oracle as orc
+        Xs, ys = gen_chunk(row0 // CH, min(CH, args.rows - (row0 // CH) * CH), d, wvec)
+        lo = row0 - (row0 // CH) * CH
+        Xs, ys = Xs[lo:lo + 2048], ys[lo:lo + 2048]
+        if len(Xs) == 2048:
+            dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value), (2048, d), dX.ld, np.float32)
+            dys = _hip.DeviceBuffer(dev, _hip.ctypes.c_void_p(dy.ptr.value), 2048 * 4)
+            dys.dtype = np.dtype(np.float32)
+            _hip._check(dev.lib, dev.lib.rr_memset(dev.ctx, pG, 0, nacc * 8))
+            basis.gram_dev(dXs, dys, 1.0, pG, pb, pt)
+            dev.sync()
+            _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
+            dev.sync()
+            dXs.ptr = None
+            dys.ptr = None
+            if use_dist:
+                Gs = acc_t[:F * F].view(F, F).cpu().numpy()
+            else:
+                Gs = dev.download(acc_buf, (F, F), np.float64)
+            Gr, _, _ = orc.rff_gram_chunked(Xs.astype(np.float64), ys.astype(np.float64), W, 1.0)
+            parity_err = float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
+            assert parity_err < 1e-4 or os.environ.get("RR_GRAM_ABLATE"), parity_err
+
     for _ in range(args.warmup):
         step(False)
     barrier()
@@ -194,6 +229,35 @@ def main():
         diag = float(np.trace(G))
         assert np.array_equal(G, G.T) or os.environ.get("RR_GRAM_ABLATE")
     trace_err = abs(diag - args.rows) / args.rows
+
+    # ---- informational: the same step on the split-bf16 engine (N=1 only; never `value`) ----
+    alt = None
+    if world == 1 and not use_dist and engine == "f32" and not args.no_alt_engine and not os.environ.get("RR_GRAM_ABLATE"):
+        dev.set_gram_engine("bf16x3")
+        step(False)
+        dev.sync()
+        ta = time.perf_counter()
+        nalt = min(max(args.steps, 1), 2)
+        alt_ms = []
+        for _ in range(nalt):
+            step(False)
+            alt_ms.append(basis.gram_timings())
+        dev.sync()
+        alt_elapsed = (time.perf_counter() - ta) / nalt
+        G3 = dev.download(acc_buf, (F, F), np.float64)
+        alt = {"engine": "bf16x3", "value": args.rows / alt_elapsed, "unit": "feature-rows/s",
+               "ms_per_step": 1e3 * alt_elapsed, "steps": nalt,
+               "max_abs_diff_vs_f32_engine_over_max_G": float(np.abs(G3 - G).max() / np.abs(G).max()),
+               "kernel": "rr_syrk_bf16_kernel<3>", "kernel_ms_per_step": float(np.mean([k[1] + k[2] for k in alt_ms])),
+               "features_ms_per_step": float(np.mean([k[0] for k in alt_ms])),
+               "note": "bf16 hi/lo split of the f32 features, 3 products on the bf16 matrix pipe, f32 accumulation; "
+                       "opt-in (Device.set_gram_engine / RR_SYRK_ENGINE), DESIGN.md 3.13"}
+        # 136 full 256x256 tiles x 3 products are issued for F (F + 1) algorithmic flops per row
+        alt["mfma_issued_tflops"] = 3.0 * 2.0 * 256 * 256 * (len(range(0, F, 256)) * (len(range(0, F, 256)) + 1) // 2) \
+            * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
+        alt["mfma_issued_frac_of_bf16_peak"] = alt["mfma_issued_tflops"] / PEAK_BF16_MFMA_TFLOPS
+        alt["algorithmic_tflops"] = F * (F + 1.0) * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
+        dev.set_gram_engine("f32")
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
@@ -220,7 +284,8 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, features + MFMA Gram, rows sharded "
                                    "over %d GPU(s)" % (n, F, d, args.rows, world),
-                       "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err},
+                       "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err,
+                       "gram_engine": engine, "parity_rel_err_2048_rows_vs_oracle": parity_err},
             "roofline": {"bound": "mfma", "kernel": "rr_syrk_f32_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
@@ -237,12 +302,31 @@ def main():
                          "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
                          / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
+        if engine != "f32":
+            # split-bf16 engine: one SYRK kernel over all 136 tiles; the roofline is the bf16 matrix pipe, `achieved`
+            # stays ALGORITHMIC flops (the kernel issues 3 or 4 bf16 products per f32 product: `issued_frac`)
+            nprod = 3 if engine == "bf16x3" else 4
+            k_ms = syrk_ms + diag_ms
+            nbk = len(widths)
+            alg = (off_flops + diag_flops) * my_rows / (k_ms * 1e-3) / 1e12
+            issued = nprod * 2.0 * 65536 * (nbk * (nbk + 1) // 2) * my_rows / (k_ms * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "rr_syrk_bf16_kernel<%d>" % nprod, "achieved": alg,
+                               "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_BF16_MFMA_TFLOPS,
+                               "issued": issued, "issued_frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
+                               "kernel_ms_per_step": k_ms, "launches_per_step": launches,
+                               "avg_launch_ms": k_ms / max(launches, 1), "flops_per_row": off_flops + diag_flops,
+                               "rows_per_step": my_rows,
+                               "other_kernels_ms_per_step": {"rr_rff_features_mfma_kernel": feat_ms},
+                               "f32_mfma_equivalent_frac": alg / PEAK_F32_MFMA_TFLOPS}
+            out["dtype"] = "f32 values as bf16 hi+lo, %d bf16 products per f32 product, f32 accumulate" % nprod
+        if alt:
+            out["split_bf16_engine"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
-    assert trace_err < 1e-4 or os.environ.get("RR_GRAM_ABLATE"), trace_err
+    assert trace_err < (1e-6 if engine == "f32" else 1e-5) or os.environ.get("RR_GRAM_ABLATE"), trace_err
 
 
 if __name__ == "__main__":

@@ -251,6 +251,18 @@ int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E)
 /* out (rows, S) = P W for a host (F, S) float64 matrix: the latent function samples of glm.py:572-620. */
 int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
 
+/* ---- arithmetic of the f32 Gram (Phi^T Phi of slm.py:145-150 for "f32" bases) -------------------
+ * RR_GRAM_F32 (default): f32 features, v_mfma_f32_32x32x2_f32, f32 accumulation per K-split -- bitwise an fmaf chain.
+ * RR_GRAM_BF16X3 / RR_GRAM_BF16X4: each f32 feature value is split into bf16 hi + lo and the Gram accumulates
+ * hi.hi + hi.lo + lo.hi (+ lo.lo) in f32 on the bf16 matrix pipe (16x the f32 MFMA rate).  Results agree with the
+ * f32 engine to ~4e-6 of max|G|, well inside the 1e-3 tolerance of the f32 path; the f64 Gram is
+ * unaffected.  The environment variable RR_SYRK_ENGINE = bf16x3 | bf16x4 sets the default of new contexts. */
+#define RR_GRAM_F32 0
+#define RR_GRAM_BF16X3 3
+#define RR_GRAM_BF16X4 4
+int rr_set_gram_engine(rr_ctx *ctx, int engine);
+int rr_get_gram_engine(rr_ctx *ctx);
+
 /* ---- posterior of the standard linear model on the device -------------------
  * iC = diag(iL) + G / var,  C = iC^-1 by Cholesky (solve_posdef(iC, I), mathfun/linalg.py:84-125, as called at
  * slm.py:155),  m = C b / var (slm.py:157), and the O(F^2) reductions of slm.py:160,165-171.

@@ -109,6 +109,8 @@ SIGNATURES = {
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_project": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "rr_posterior_available": (ctypes.c_int, []),
+    "rr_set_gram_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rr_get_gram_engine": (ctypes.c_int, [ctypes.c_void_p]),
     "rr_posterior_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p]),
@@ -303,6 +305,23 @@ class Device(object):
         hbm = ctypes.c_uint64()
         _check(self.lib, self.lib.rr_ctx_info(ctx, name, ctypes.byref(cus), ctypes.byref(hbm)))
         self.name, self.compute_units, self.hbm_bytes = name.value.decode(), cus.value, hbm.value
+
+    # -- arithmetic of the f32 Gram (include/revrand_hip.h: RR_GRAM_*) -------------
+    GRAM_ENGINES = {"f32": 0, "bf16x3": 3, "bf16x4": 4}
+
+    @property
+    def gram_engine(self):
+        code = self.lib.rr_get_gram_engine(self.ctx)
+        return {v: k for k, v in self.GRAM_ENGINES.items()}[code]
+
+    def set_gram_engine(self, name):
+        """'f32' (default; f32 MFMA), 'bf16x3' or 'bf16x4' (split-bf16 products on the bf16 matrix pipe, f32
+        accumulation; ~4e-6 / ~2e-6 of max|G| away from the f32 engine).  Returns the previous engine."""
+        if name not in self.GRAM_ENGINES:
+            raise ValueError("gram engine must be one of %s" % sorted(self.GRAM_ENGINES))
+        prev = self.gram_engine
+        _check(self.lib, self.lib.rr_set_gram_engine(self.ctx, self.GRAM_ENGINES[name]))
+        return prev
 
     # -- memory ---------------------------------------------------------------
     def malloc(self, nbytes):

@@ -1,6 +1,7 @@
 // Host side of the C ABI: contexts, device memory, basis objects.
 // See include/revrand_hip.h for the contract of every entry point.
 #include "rr_internal.h"
+#include <cstring>
 
 #include <cmath>
 
@@ -67,9 +68,20 @@ int rr_ctx_create(int device, rr_ctx **out) {
         delete c;
         return RR_ERR_HIP;
     }
+    if (const char *eng = getenv("RR_SYRK_ENGINE")) c->gram_engine = !strcmp(eng, "bf16x3") ? 3 : !strcmp(eng, "bf16x4") ? 4 : 0;
     *out = c;
     return RR_OK;
 }
+
+int rr_set_gram_engine(rr_ctx *ctx, int engine) {
+    RR_REQUIRE(ctx != nullptr, "rr_set_gram_engine: null context");
+    RR_REQUIRE(engine == RR_GRAM_F32 || engine == RR_GRAM_BF16X3 || engine == RR_GRAM_BF16X4,
+               "rr_set_gram_engine: unknown engine %d", engine);
+    ctx->gram_engine = engine;
+    return RR_OK;
+}
+
+int rr_get_gram_engine(rr_ctx *ctx) { return ctx ? ctx->gram_engine : -1; }
 
 void rr_ctx_destroy(rr_ctx *ctx) {
     if (!ctx) return;

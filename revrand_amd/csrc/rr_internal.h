@@ -20,6 +20,7 @@ struct rr_ctx {
     int num_cu = 0;
     int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
     int tile_map_nb = 0;
+    int gram_engine = 0;      // f32 Gram: 0 = f32 MFMA, 3 / 4 = split-bf16 with 3 / 4 products (rr_set_gram_engine)
     void *pb = nullptr;       // split-bf16 copy of the feature chunk (rr_syrk_bf16x3_kernel), grow-only
     size_t pb_bytes = 0;
     void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): rocBLAS handle + small device vectors

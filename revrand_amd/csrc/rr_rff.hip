@@ -7,6 +7,27 @@
 // give sin/cos directly.
 #include "rr_internal.h"
 #include "rr_mfma_tile.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+// Output tag of the feature kernel: the K-blocked split-bf16 layout of rr_syrk_bf16_kernel (see there):
+// Pb[kstep][column] = 64 B = granules [hi rows 0-7 | hi rows 8-15 | lo rows 0-7 | lo rows 8-15] of a 16-row k-step.
+struct rr_pb_t { uintx4 g[4]; };
+
+// 8 f32 values -> one granule of bf16 hi parts and one of lo parts (hi = bf16(v), lo = bf16(v - hi)); v_cvt_pk_bf16_f32
+__device__ __forceinline__ void split_bf16x8(const float *v, uintx4 &hi, uintx4 &lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float2v x = {v[2 * q], v[2 * q + 1]};
+        const bf16x2 hb = __builtin_convertvector(x, bf16x2);
+        const float2v hf = __builtin_convertvector(hb, float2v);
+        const bf16x2 lb = __builtin_convertvector(x - hf, bf16x2);
+        hi[q] = __builtin_bit_cast(unsigned, hb);
+        lo[q] = __builtin_bit_cast(unsigned, lb);
+    }
+}
 
 
 // ---------------------------------------------------------------------------------------
@@ -318,10 +339,13 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
         }
         // stores: wave-uniform tile bases (cos and sin halves) in SGPRs + one 32-bit byte offset per row of the
         // lane (written as asm: left alone, the compiler keeps a 64-bit pointer induction variable per store)
-        const TO *tile_c = P + r0 * ldp + c0;
-        const TO *tile_s = tile_c + n;
-        constexpr unsigned ES = sizeof(TO);
-        const unsigned lane_off = ES * ((unsigned)(4 * h) * (unsigned)ldp + (unsigned)j);
+        constexpr bool SPLIT = std::is_same<TO, rr_pb_t>::value;
+        // SPLIT: the tile is k-steps 2 tl and 2 tl + 1 of Pb; byte addresses, column stride 64
+        const char *tile_c = SPLIT ? (const char *)P + ((2 * tl) * ldp + c0) * 64 : (const char *)(P + r0 * ldp + c0);
+        const char *tile_s = tile_c + (int64_t)n * (SPLIT ? 64 : (int64_t)sizeof(TO));
+        const char *tile_c1 = tile_c + ldp * 64, *tile_s1 = tile_s + ldp * 64;  // SPLIT: second k-step
+        constexpr unsigned ES = SPLIT ? 4 : sizeof(TO);
+        const unsigned lane_off = SPLIT ? (unsigned)(j * 64 + h * 16) : ES * ((unsigned)(4 * h) * (unsigned)ldp + (unsigned)j);
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             floatx16 acc;
@@ -329,7 +353,40 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
             for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
             for (int t = 0; t < KS; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], bw[cb][t], acc, 0, 0, 0);
-            if (c0 + 32 * cb + j < n) {  // one divergent region per column block (ragged n only)
+            if (SPLIT) {
+                if (c0 + 32 * cb + j < n) {
+                    float cvv[16], svv[16];
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int rr = (e & 3) + 8 * (e >> 2);
+                        float sv, cv;
+                        sincos_rev(acc[e], sv, cv);
+                        cvv[e] = rr < lim ? cv * scale : 0.f;
+                        svv[e] = rr < lim ? sv * scale : 0.f;
+                        if (HAS_Y) {
+                            bc[cb] = fmaf(cvv[e], yv[e], bc[cb]);
+                            bs[cb] = fmaf(svv[e], yv[e], bs[cb]);
+                        }
+                    }
+                    // lane (j, h) holds rows {0-3, 8-11} + 4 h of each 16-row k-step: exactly granule h of each part.
+                    // s_nop after each store: a >8-byte store still reads its data registers for two more cycles and
+                    // the compiler's hazard recogniser does not look inside asm.
+                    const unsigned off = lane_off + 2048u * cb;
+                    uintx4 g_hi, g_lo;
+                    split_bf16x8(cvv, g_hi, g_lo);
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c) : "memory");
+                    split_bf16x8(cvv + 8, g_hi, g_lo);
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c1) : "memory");
+                    split_bf16x8(svv, g_hi, g_lo);
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s) : "memory");
+                    split_bf16x8(svv + 8, g_hi, g_lo);
+                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s1) : "memory");
+                }
+            } else if (c0 + 32 * cb + j < n) {  // one divergent region per column block (ragged n only)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2);
@@ -369,11 +426,16 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
 
 // launch (A') when its preconditions hold (16-byte aligned X rows); false = use the VALU kernel.  The output
 // must have whole 32-row tiles: (mpad + 31) / 32 * 32 rows.
+template <typename TX>
+static bool rr_features_mfma_ok(rr_basis *b, const TX *X, int64_t m, int64_t ldx) {
+    static const bool disabled = getenv("RR_FEATURES_NO_MFMA") != nullptr;
+    return !(disabled || b->large || ((ldx * sizeof(TX)) & 15) != 0 || ((uintptr_t)X & 15) != 0 || b->dpad < 8 || m < 1);
+}
+
 template <typename TX, typename TO>
 static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64_t m, int64_t mpad, int64_t ldx,
                                     TO *P, int64_t ldp, double *db, float scale) {
-    static const bool disabled = getenv("RR_FEATURES_NO_MFMA") != nullptr;
-    if (disabled || ((ldx * sizeof(TX)) & 15) != 0 || ((uintptr_t)X & 15) != 0 || b->dpad < 8 || m < 1) return false;
+    if (!rr_features_mfma_ok<TX>(b, X, m, ldx)) return false;
     rr_ctx *c = b->ctx;
     const int64_t ntiles = (mpad + 31) / 32;
 #define RR_FM(DM, CBK)                                                                                              \
@@ -406,6 +468,13 @@ __global__ void __launch_bounds__(256) rr_zero_padcols_kernel(TC *P, int64_t row
     const int w = (int)ldp - F;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w > 0 && i < rows * w) P[(i / w) * ldp + F + (i % w)] = TC(0);
+}
+
+// the same for the K-blocked split-bf16 layout: columns [F, ldp) of every k-step (64 B each)
+__global__ void __launch_bounds__(256) rr_zero_padcols_pb_kernel(uintx4 *Pb, int64_t ksteps, int64_t ldp, int F) {
+    const int64_t w = (ldp - F) * 4;  // granules per k-step
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w > 0 && i < ksteps * w) Pb[(i / w) * ldp * 4 + (int64_t)F * 4 + (i % w)] = uintx4{0u, 0u, 0u, 0u};
 }
 
 struct SyrkArgs {
@@ -1256,13 +1325,11 @@ static void build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
 }
 
 // G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
-static int rr_launch_syrk_bf16x3(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid);
+static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void *pb, int64_t rows, int64_t ldp, int F,
+                               double *dG, hipEvent_t mid);
 
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
-    {
-        const char *eng = getenv("RR_SYRK_ENGINE");
-        if (eng && !strcmp(eng, "bf16x3")) return rr_launch_syrk_bf16x3(c, P, rows, ldp, F, dG, mid);
-    }
+    if (c->gram_engine != 0) return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
     const int nb = (int)(ldp / GR_TC);
     const int od = (nb >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
     const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
@@ -1327,51 +1394,103 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
 }
 
 // ---------------------------------------------------------------------------------------
-// Split-bf16 SYRK ("bf16x3"): every f32 feature value p is split into hi = bf16(p) and lo = bf16(p - hi)
-// (|p - hi - lo| <= 2^-17 |p|) and G accumulates hi.hi + hi.lo + lo.hi in f32 on the bf16 matrix pipe
-// (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate), dropping only lo.lo (<= 2^-18 |p_a p_b|).  Same workgroup
-// shape as rr_syrk_f32_kernel: 256x256 block of G, 8 waves of 128x64, k-blocks of 32 rows by LDS-DMA, double
-// buffered, f64 atomics across K-splits.
+// Split-bf16 SYRK ("bf16x3" / "bf16x4"): every f32 feature value p is split into hi = bf16(p) and
+// lo = bf16(p - hi) (|p - hi - lo| <= 2^-18 |p|) and G accumulates hi.hi + hi.lo + lo.hi (+ lo.lo for x4) in f32 on
+// the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate).  x3 drops lo.lo (<= 2^-18 |p_a p_b|,
+// same sign on the diagonal: a ~1e-6 relative bias there); x4 keeps it.  Same workgroup shape as
+// rr_syrk_f32_kernel: 256x256 block of G, 8 waves of 128x64, f64 atomics across K-splits.
 //
-// Operands need 8 consecutive k (rows) of one column per lane, so the feature chunk is re-laid first
-// (rr_split_bf16_kernel): Pb[kb][c] = 128 B = [hi of rows 32 kb .. +32 | lo of the same rows], column c of ldp.
-// A 256-column side of a k-block is then 32 KiB contiguous.  In LDS the eight 16-B granules of a column are
-// XOR-swizzled with (c >> 1) & 7 -- the DMA (lane-linear in LDS) applies the permutation on its global
-// addresses -- which makes every ds_read_b128 operand fetch conflict-free.
+// Operands need 8 consecutive k (rows) of one column per lane, so the features are laid out K-blocked:
+// Pb[kb][c] = 64 B = four 16-B granules [hi rows 0-7 | hi rows 8-15 | lo rows 0-7 | lo rows 8-15] of the 16
+// rows of k-step kb, column c of ldp (rr_split_bf16_kernel converts a row-major f32 chunk).  A 256-column side
+// of one k-step is 16 KiB contiguous.  One k-step (16 rows, [A side | B side] = 32 KiB) is one stage of a
+// 4-stage LDS ring filled by LDS-DMA three k-steps ahead of its use; in LDS the four granules of a column are
+// XOR-swizzled with (c >> 2) & 3 -- the DMA is lane-linear in LDS and applies the permutation on its global
+// addresses -- which makes every ds_read_b128 operand fetch conflict-free.  Per k-step a wave issues its 4
+// DMA instructions, the 12 operand reads of the NEXT k-step (second register set) and 24 (32) MFMAs; one
+// barrier per k-step.
 // ---------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
+constexpr int B16_STAGE = 32768;  // bytes per ring stage: [A side 16 KiB | B side 16 KiB]
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {
     const unsigned u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-// grid (ldp / 256, rows / 32), 256 threads: thread = column, 32 rows of it in registers
+// grid (ldp / 256, rows64 / 16), 256 threads: thread = column, 16 rows of it in registers; rows >= `rows` -> 0
 __global__ void __launch_bounds__(256)
-rr_split_bf16_kernel(const float *__restrict__ P, int64_t ldp, uintx4 *__restrict__ Pb) {
+rr_split_bf16_kernel(const float *__restrict__ P, int64_t rows, int64_t ldp, uintx4 *__restrict__ Pb) {
     const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, kb = blockIdx.y;
-    const float *src = P + kb * 32 * ldp + c;
-    unsigned hi[16], lo[16];
+    const float *src = P + kb * 16 * ldp + c;
+    const bool live = kb * 16 < rows;  // rows is a multiple of 32
+    unsigned hi[8], lo[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const float x0 = src[(2 * k) * ldp], x1 = src[(2 * k + 1) * ldp];
+    for (int k = 0; k < 8; ++k) {
+        const float x0 = live ? src[(2 * k) * ldp] : 0.f, x1 = live ? src[(2 * k + 1) * ldp] : 0.f;
         const unsigned h0 = bf16_rne(x0), h1 = bf16_rne(x1);
         const unsigned l0 = bf16_rne(x0 - __uint_as_float(h0 << 16)), l1 = bf16_rne(x1 - __uint_as_float(h1 << 16));
         hi[k] = h0 | (h1 << 16);
         lo[k] = l0 | (l1 << 16);
     }
-    uintx4 *dst = Pb + (kb * ldp + c) * 8;
+    uintx4 *dst = Pb + (kb * ldp + c) * 4;
+    dst[0] = uintx4{hi[0], hi[1], hi[2], hi[3]};
+    dst[1] = uintx4{hi[4], hi[5], hi[6], hi[7]};
+    dst[2] = uintx4{lo[0], lo[1], lo[2], lo[3]};
+    dst[3] = uintx4{lo[4], lo[5], lo[6], lo[7]};
+}
+
+template <int OFF>
+__device__ __forceinline__ uintx4 lds_read_b128(unsigned addr) {
+    uintx4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+
+// operands of one k-step: hi / lo parts of 4 A blocks and 2 B blocks
+struct B16Ops {
+    uintx4 ah[4], al[4], bh[2], bl[2];
+    // BUF: ring stage 0..3; base addresses are for stages 0-1 (lo) / 2-3 (hi16 = + 65536): ds offsets are 16 bit
+    template <int BUF>
+    __device__ __forceinline__ void load_a(const unsigned (&a)[2][2]) {
+        constexpr int O = (BUF & 1) * B16_STAGE;
+        const unsigned a0 = a[BUF >> 1][0], a1 = a[BUF >> 1][1];
+        ah[0] = lds_read_b128<O>(a0);
+        al[0] = lds_read_b128<O>(a1);
+        ah[1] = lds_read_b128<O + 2048>(a0);
+        al[1] = lds_read_b128<O + 2048>(a1);
+        ah[2] = lds_read_b128<O + 4096>(a0);
+        al[2] = lds_read_b128<O + 4096>(a1);
+        ah[3] = lds_read_b128<O + 6144>(a0);
+        al[3] = lds_read_b128<O + 6144>(a1);
+    }
+    template <int BUF>
+    __device__ __forceinline__ void load_b(const unsigned (&b)[2][2]) {
+        constexpr int O = (BUF & 1) * B16_STAGE;
+        const unsigned b0 = b[BUF >> 1][0], b1 = b[BUF >> 1][1];
+        bh[0] = lds_read_b128<O>(b0);
+        bl[0] = lds_read_b128<O>(b1);
+        bh[1] = lds_read_b128<O + 2048>(b0);
+        bl[1] = lds_read_b128<O + 2048>(b1);
+    }
+};
+
+// MFMAs [FIRST, LAST) of a k-step in (product, i, j) order: product 0 hi.hi, 1 hi.lo, 2 lo.hi, 3 lo.lo
+template <int FIRST, int LAST>
+__device__ __forceinline__ void b16_mfma(const B16Ops &o, floatx16 (&acc)[4][2]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        dst[q] = uintx4{hi[4 * q], hi[4 * q + 1], hi[4 * q + 2], hi[4 * q + 3]};
-        dst[4 + q] = uintx4{lo[4 * q], lo[4 * q + 1], lo[4 * q + 2], lo[4 * q + 3]};
+    for (int q = FIRST; q < LAST; ++q) {
+        const int pr = q >> 3, i = (q >> 1) & 3, j = q & 1;
+        const uintx4 a = (pr & 2) ? o.al[i] : o.ah[i];
+        const uintx4 b = (pr & 1) ? o.bl[j] : o.bh[j];
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                            acc[i][j], 0, 0, 0);
     }
 }
 
+template <int NPROD>
 __global__ void __launch_bounds__(GR_THREADS, 2)
-rr_syrk_bf16x3_kernel(const SyrkArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * 65536];  // two buffers of [A side 32 KiB | B side 32 KiB]
+rr_syrk_bf16_kernel(const SyrkArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * B16_STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1387,40 +1506,39 @@ rr_syrk_bf16x3_kernel(const SyrkArgs p) {
     }
     const int tb = ta + tdx + od;
     const int ca = ta * GR_TC, cb = tb * GR_TC;
-    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;  // multiples of 64
     int64_t row_end = row_begin + p.rows_per_split;
     if (row_end > p.rows) row_end = p.rows;
+    const int S = (int)((row_end - row_begin) / 16);  // k-steps, a multiple of 4
 
-    // ---- DMA role: 64 instructions of 1 KiB (8 columns) per buffer; wave w issues t = 8 w + k: waves 0-3 the A
-    // side, 4-7 the B side.  Lane L fills granule t*64 + L = column 8 t' + (L >> 3), slot L & 7.
-    const char *Pb = (const char *)p.P;
-    const int cl = lane >> 3, x = lane & 7;
-    const unsigned lane_src0 = (unsigned)(cl * 128 + ((x ^ (cl >> 1)) * 16));
-    const unsigned lane_src1 = (unsigned)(cl * 128 + (((x ^ (cl >> 1)) ^ 4) * 16));
+    // ---- DMA role: 32 instructions of 1 KiB (16 columns) per stage; wave w issues t = 4 w + k: waves 0-3 the A side,
+    // 4-7 the B side.  Lane L fills granule t*64 + L = column 16 t' + (L >> 2), slot L & 3.
     const int side = wave >> 2;
-    const int tt0 = (wave & 3) * 8;
-    const int64_t cside = side ? cb : ca;
-    auto dma_tile = [&](char *buf, int64_t kb) {
-        const char *src = Pb + (kb * p.ldp + cside) * 128 + (int64_t)tt0 * 1024;
-        char *dst = buf + side * 32768 + tt0 * 1024;
+    const int tt0 = (wave & 3) * 4;
+    const unsigned lane_src = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    const char *src0 = (const char *)p.P + ((row_begin / 16) * p.ldp + (side ? cb : ca)) * 64 + tt0 * 1024 + lane_src;
+    const int64_t stage_stride = p.ldp * 64;
+    char *dst0 = lds + side * 16384 + tt0 * 1024;
+    auto dma = [&](int g, int buf) {
+        const char *src = src0 + (int64_t)((p.ablate & 8) ? (g & 7) : g) * stage_stride;
+        char *dst = dst0 + buf * B16_STAGE;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024 + ((k & 1) ? lane_src1 : lane_src0)),
-                                             (lptr_t)(dst + k * 1024), 16, 0, 0);
+        for (int k = 0; k < 4; ++k)
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024), (lptr_t)(dst + k * 1024), 16, 0, 0);
     };
 
     // ---- consumer role: wave (wr, wc) -> columns [wr*128, +128) of side A (4 blocks), [wc*64, +64) of side B (2)
     const int wr = wave >> 2, wc_ = wave & 3;
     const int l31 = lane & 31, h = lane >> 5;
-    const int sw = (l31 >> 1) & 7;
-    unsigned offA[2][2], offB[2][2];  // [part][k-step]
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    unsigned abase[2][2], bbase[2][2];  // [ring half][part]
 #pragma unroll
-    for (int pp = 0; pp < 2; ++pp)
+    for (int hf = 0; hf < 2; ++hf)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const unsigned xs = (unsigned)(((h ^ sw) ^ (4 * pp + 2 * s)) * 16);
-            offA[pp][s] = (unsigned)((wr * 128 + l31) * 128) + xs;
-            offB[pp][s] = 32768u + (unsigned)((wc_ * 64 + l31) * 128) + xs;
+        for (int pp = 0; pp < 2; ++pp) {
+            const unsigned xs = (unsigned)(((2 * pp + h) ^ ((l31 >> 2) & 3)) * 16);
+            abase[hf][pp] = lds0 + hf * 2 * B16_STAGE + (unsigned)((wr * 128 + l31) * 64) + xs;
+            bbase[hf][pp] = lds0 + hf * 2 * B16_STAGE + 16384u + (unsigned)((wc_ * 64 + l31) * 64) + xs;
         }
     floatx16 acc[4][2];
 #pragma unroll
@@ -1430,46 +1548,51 @@ rr_syrk_bf16x3_kernel(const SyrkArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int64_t kb0 = row_begin / GR_KB;
-    const int64_t nkb = (row_end - row_begin) / GR_KB;
-    if (nkb > 0) {
-        dma_tile(lds, kb0);
-        __syncthreads();
-        for (int64_t kb = 0; kb < nkb; ++kb) {
-            const int cbuf = (int)(kb & 1);
-            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * 65536, kb0 + kb + 1);
-            const char *cur = lds + cbuf * 65536;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                bf16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ah[i] = *(const bf16x8 *)(cur + offA[0][s] + i * 4096);
-                    al[i] = *(const bf16x8 *)(cur + offA[1][s] + i * 4096);
-                }
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bh[j] = *(const bf16x8 *)(cur + offB[0][s] + j * 4096);
-                    bl[j] = *(const bf16x8 *)(cur + offB[1][s] + j * 4096);
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            }
-            __syncthreads();
+    constexpr int NM = NPROD * 8;
+    if (S > 0) {
+        // prologue: stages 0..3 in flight, 0 and 1 landed, stage 0 in registers
+        dma(0, 0);
+        dma(1, 1);
+        dma(2, 2);
+        dma(3, 3);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        B16Ops r0, r1;
+        r0.load_b<0>(bbase);
+        r0.load_a<0>(abase);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // One k-step: [barrier: stage g+1 landed for everyone, stage g fully in registers everywhere -> its buffer is
+        // free] [first MFMAs] [DMA of stage g+4 into the freed buffer] [MFMAs] [reads of stage g+1] [MFMAs] [waits].
+#define RR_B16_STEP(Q, CUR, NXT)                                                        \
+    {                                                                                   \
+        const int g = g0 + (Q);                                                         \
+        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();                              \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        b16_mfma<0, 2>(CUR, acc);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (g + 4 < S && !(p.ablate & 1)) dma(g + 4, (Q));                              \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        b16_mfma<2, 4>(CUR, acc);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (g + 1 < S && !(p.ablate & 4)) NXT.template load_b<((Q) + 1) & 3>(bbase);    \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        b16_mfma<4, 6>(CUR, acc);                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (g + 1 < S && !(p.ablate & 4)) NXT.template load_a<((Q) + 1) & 3>(abase);    \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        b16_mfma<6, NM>(CUR, acc);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (g + 4 < S && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    }
+        for (int g0 = 0; g0 < S; g0 += 4) {
+            RR_B16_STEP(0, r0, r1)
+            RR_B16_STEP(1, r1, r0)
+            RR_B16_STEP(2, r0, r1)
+            RR_B16_STEP(3, r1, r0)
         }
+#undef RR_B16_STEP
     }
 
     const int64_t F = p.F;
@@ -1487,7 +1610,10 @@ rr_syrk_bf16x3_kernel(const SyrkArgs p) {
     }
 }
 
-static int rr_launch_syrk_bf16x3(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
+// nprod: 3 or 4 products.  Either P (row-major f32, rows % 32 == 0: converted here into the context's Pb scratch) or
+// pb (features already in the K-blocked layout, rows % 64 == 0, pad rows / columns zero).
+static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void *pb, int64_t rows, int64_t ldp, int F,
+                               double *dG, hipEvent_t mid) {
     const int nb = (int)(ldp / GR_TC);
     const int od = 0;
     const int ntiles = nb * (nb + 1) / 2;
@@ -1502,7 +1628,8 @@ static int rr_launch_syrk_bf16x3(rr_ctx *c, const float *P, int64_t rows, int64_
         RR_CHECK_HIP(hipMemcpy(c->tile_map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
         c->tile_map_nb = nb * 2 + od;
     }
-    const size_t need = (size_t)rows * ldp * 4;
+    const int64_t rows64 = (rows + 63) / 64 * 64;
+    const size_t need = pb ? 0 : (size_t)rows64 * ldp * 4;
     if (c->pb_bytes < need) {
         RR_CHECK_HIP(hipStreamSynchronize(c->stream));
         if (c->pb) (void)hipFree(c->pb);
@@ -1511,27 +1638,33 @@ static int rr_launch_syrk_bf16x3(rr_ctx *c, const float *P, int64_t rows, int64_
         RR_CHECK_HIP(hipMalloc(&c->pb, need));
         c->pb_bytes = need;
     }
-    hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(ldp / 256), (unsigned)(rows / 32)), dim3(256), 0, c->stream, P, ldp,
-                       (uintx4 *)c->pb);
+    if (!pb) {
+        hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(ldp / 256), (unsigned)(rows64 / 16)), dim3(256), 0, c->stream,
+                           P, rows, ldp, (uintx4 *)c->pb);
+        pb = c->pb;
+    }
     if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
     auto gcd64 = [](int64_t x, int64_t y) { while (y) { const int64_t u = x % y; x = y; y = u; } return x; };
-    const int64_t min_splits = (rows + 32767) / 32768;
+    const int64_t min_splits = (rows64 + 32767) / 32768;
     const int64_t unit = c->num_cu / gcd64(c->num_cu, ntiles);
     int64_t nsplit = (min_splits + unit - 1) / unit * unit;
-    if (rows / nsplit < 1024) nsplit = (rows + 1023) / 1024;
+    if (rows64 / nsplit < 1024) nsplit = (rows64 + 1023) / 1024;
     if (nsplit < 1) nsplit = 1;
-    int64_t rps = ((rows + nsplit - 1) / nsplit + GR_KB - 1) / GR_KB * GR_KB;
+    int64_t rps = ((rows64 + nsplit - 1) / nsplit + 63) / 64 * 64;
     const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
-    if (renv && atoll(renv) >= GR_KB) rps = (atoll(renv) / GR_KB) * GR_KB;
-    nsplit = (rows + rps - 1) / rps;
+    if (renv && atoll(renv) >= 64) rps = (atoll(renv) / 64) * 64;
+    nsplit = (rows64 + rps - 1) / rps;
     RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
     SyrkArgs a;
-    a.P = (const float *)c->pb; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps;
+    a.P = (const float *)pb; a.rows = rows64; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps;
     a.G = dG;
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
-    a.ablate = 0;
-    hipLaunchKernelGGL(rr_syrk_bf16x3_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
+    if (nprod == 4)
+        hipLaunchKernelGGL(rr_syrk_bf16_kernel<4>, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL(rr_syrk_bf16_kernel<3>, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1587,11 +1720,20 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
     const char *cenv = getenv("RR_GRAM_CHUNK_ROWS");
     if (cenv && atoll(cenv) >= KB) chunk = atoll(cenv);
     if (chunk > N) chunk = N;
-    chunk = (chunk + KB - 1) / KB * KB;
+    // split-bf16 engine with the MFMA feature kernel: the features are produced directly in the SYRK's K-blocked
+    // bf16 hi/lo layout (same 4 bytes per value), whole 64-row groups
+    const bool fused_pb = F32 && c->gram_engine != 0 && rr_features_mfma_ok<TX>(b, (const TX *)dX, N, ldx);
+    const int KBR = fused_pb ? 64 : KB;
+    chunk = (chunk + KBR - 1) / KBR * KBR;
     int rc = ensure_zbuf(b, (size_t)chunk * ldp * sizeof(TC));
     if (rc != RR_OK) return rc;
     TC *P = (TC *)b->zbuf;
-    if (ldp > F) {  // pad columns are never written by the feature kernel: zero them once per call
+    if (fused_pb && ldp > F) {
+        const int64_t cnt = (chunk / 16) * (ldp - F) * 4;
+        hipLaunchKernelGGL(rr_zero_padcols_pb_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
+                           (uintx4 *)P, chunk / 16, ldp, F);
+        RR_CHECK_HIP(hipGetLastError());
+    } else if (ldp > F) {  // pad columns are never written by the feature kernel: zero them once per call
         const int64_t cnt = chunk * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<TC>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
                            P, chunk, ldp, F);
@@ -1600,7 +1742,7 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
 
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
-        const int64_t mpad = (m + KB - 1) / KB * KB;
+        const int64_t mpad = (m + KBR - 1) / KBR * KBR;
         const TX *Xc = (const TX *)dX + r0 * ldx;
         const TX *yc = dy ? (const TX *)dy + r0 : nullptr;
         // four events per chunk bracket the kernels (read back by rr_rff_gram_timings)
@@ -1613,7 +1755,17 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
         // (A) features (+ Phi^T y): MFMA projection for f32 X, else the VALU kernel
         bool done_a = false;
-        if (b->large) {
+        if constexpr (F32) {
+            if (fused_pb) {
+                done_a = rr_features_mfma_launch<TX, rr_pb_t>(b, Xc, yc, m, mpad, ldx, (rr_pb_t *)P, ldp, db, (float)scale);
+                if (!done_a) {
+                    rr_set_error("gram: internal: split-bf16 feature launch refused");
+                    return RR_ERR_INVALID;
+                }
+            }
+        }
+        if (done_a) {
+        } else if (b->large) {
             rc = large_features<TX, TC, TC>(b, Xc, yc, m, mpad, ldx, P, ldp, db);
             if (rc != RR_OK) return rc;
             done_a = true;
@@ -1644,7 +1796,10 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
         // (B) G += P^T P
         if constexpr (F32) {
-            rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG, b->events[e0 + 2]);
+            if (fused_pb)
+                rc = rr_launch_syrk_bf16(c, c->gram_engine, nullptr, (const void *)P, mpad, ldp, F, dG, b->events[e0 + 2]);
+            else
+                rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG, b->events[e0 + 2]);
         } else {
             rc = rr_launch_syrk_f64(c, P, mpad, ldp, F, dG);
             if (rc == RR_OK) RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
@@ -1653,7 +1808,7 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 3], c->stream));
         b->events_used = e0 + 4;
     }
-    b->gram_kernel = F32 ? "rr_syrk_f32_kernel" : "rr_syrk_f64_kernel";
+    b->gram_kernel = !F32 ? "rr_syrk_f64_kernel" : c->gram_engine == 0 ? "rr_syrk_f32_kernel" : "rr_syrk_bf16_kernel";
     return RR_OK;
 }
 

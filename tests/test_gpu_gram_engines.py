@@ -1,0 +1,176 @@
+"""
+The split-bf16 engines of the f32 Gram (RR_GRAM_BF16X3 / RR_GRAM_BF16X4, include/revrand_hip.h): f32 feature values as
+bf16 hi + lo, 3 or 4 bf16 products per f32 product on the bf16 matrix pipe, f32 accumulation.  Parity against the
+NumPy oracle with the tolerance of the f32 path (1e-3 relative, BASELINE.json) and against the measured accuracy of the
+engines themselves (a few 1e-6 of max|G|), for every producer of the feature matrix: the MFMA feature kernel writing
+the K-blocked layout directly, and the conversion kernel behind concatenated bases and Xdim > 128.
+"""
+import numpy as np
+import pytest
+
+import revrand_oracle as orc
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _imports():
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd import _hip
+    return bs, Parameter, Positive, _hip
+
+
+@pytest.fixture(params=["bf16x3", "bf16x4"])
+def engine(request):
+    from revrand_amd import _hip
+    dev = _hip.get_device()
+    prev = dev.set_gram_engine(request.param)
+    assert dev.gram_engine == request.param
+    yield request.param
+    dev.set_gram_engine(prev)
+
+
+ENGINE_TOL = {"bf16x3": 1e-5, "bf16x4": 6e-6}   # measured: <= 5e-6 / 2.5e-6 of max|G|
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 4), (64, 4, 16), (500, 4, 16), (4099, 8, 128), (3000, 32, 200), (1500, 21, 260),
+                                   (70000, 8, 128), (1000, 64, 128), (777, 100, 40)])
+def test_gram_vs_oracle(engine, shape):
+    bs, Parameter, Positive, _ = _imports()
+    N, d, n = shape
+    rs = np.random.RandomState(N + n)
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+    b = bs.RandomRBF(nbases=n, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive()))
+    ls = np.linspace(0.8, 1.6, d)
+    G, bv, yty = b.gram(X, y, ls)
+    Gr, br, ytyr = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, ls)
+    assert G.shape == (2 * n, 2 * n) and np.array_equal(G, G.T)
+    assert normwise(G, Gr) < ENGINE_TOL[engine], normwise(G, Gr)
+    assert normwise(bv, br) < 1e-5            # Phi^T y is accumulated from the f32 values, before the split
+    assert abs(yty - ytyr) < 1e-5 * ytyr
+    G2, b2, _ = b.gram(X.astype(np.float64), None, ls)      # float64 X, no y
+    assert b2 is None and normwise(G2, Gr) < ENGINE_TOL[engine]
+
+
+def test_row_chunks_and_engines_agree(engine, monkeypatch):
+    """Several row chunks (pad rows at each seam are zero in the K-blocked layout) and the three engines on one input."""
+    bs, Parameter, Positive, _hip = _imports()
+    N, d, n = 5003, 16, 300
+    rs = np.random.RandomState(0)
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.randn(N).astype(np.float32)
+    b = bs.RandomMatern32(nbases=n, Xdim=d, random_state=1)
+    G1, b1, _ = b.gram(X, y, 1.2)
+    monkeypatch.setenv("RR_GRAM_CHUNK_ROWS", "1024")
+    Gc, bc, _ = b.gram(X, y, 1.2)
+    monkeypatch.delenv("RR_GRAM_CHUNK_ROWS")
+    assert normwise(Gc, G1) < 2e-6 and normwise(bc, b1) < 1e-6      # f32 partial sums over different row groups
+    dev = _hip.get_device()
+    dev.set_gram_engine("f32")
+    Gf, bf, _ = b.gram(X, y, 1.2)
+    dev.set_gram_engine(engine)
+    assert normwise(G1, Gf) < ENGINE_TOL[engine] and normwise(b1, bf) < 1e-6
+
+
+def test_linearity_over_row_shards(engine):
+    bs, Parameter, Positive, _ = _imports()
+    N, d, n = 40000, 32, 512
+    rs = np.random.RandomState(3)
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.randn(N).astype(np.float32)
+    b = bs.RandomRBF(nbases=n, Xdim=d, random_state=7)
+    G, bv, yty = b.gram(X, y, 1.0)
+    Ga, ba, ta = b.gram(X[:17001], y[:17001], 1.0)
+    Gb, bb, tb = b.gram(X[17001:], y[17001:], 1.0)
+    assert normwise(Ga + Gb, G) < 3e-6 and normwise(ba + bb, bv) < 1e-6 and abs(ta + tb - yty) < 1e-9 * yty
+    dg = np.diag(G)
+    assert np.abs(dg[:n] + dg[n:] - N / n).max() < 2e-5 * (N / n)      # cos^2 + sin^2 = 1 per frequency
+    assert abs(np.trace(G) - N) < 1e-5 * N
+
+
+def test_concatenated_bases_and_wide_inputs_use_the_conversion_kernel(engine):
+    """Feature matrices not written by the MFMA feature kernel (device-side concatenation; Xdim > 128) are converted
+    from row-major f32 to the K-blocked bf16 layout before the same SYRK."""
+    bs, Parameter, Positive, _ = _imports()
+    rs = np.random.RandomState(8)
+    N, d, n = 3001, 12, 150
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    ls = np.linspace(0.7, 1.4, d)
+    base = bs.RandomMatern52(nbases=n, Xdim=d, random_state=4, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True) + bs.BiasBasis(offset=2.0)
+    G, b, yty = base.gram(X, y, ls)
+    ref = np.hstack((orc.rff_transform(X, base.bases[0].W, ls), orc.linear_transform(X), np.full((N, 1), 2.0)))
+    assert np.array_equal(G, G.T)
+    assert normwise(G, ref.T @ ref) < 2e-5 and normwise(b, ref.T @ y) < 1e-4
+    Xw = rs.randn(1500, 200) / 5.0
+    yw = rs.randn(1500)
+    bw = bs.RandomRBF(nbases=130, Xdim=200, random_state=2)
+    Gw, bvw, _ = bw.gram(Xw.astype(np.float32), yw.astype(np.float32), 1.3)
+    Gr, br, _ = orc.rff_gram_chunked(Xw.astype(np.float32).astype(np.float64), yw.astype(np.float32).astype(np.float64), bw.W, 1.3)
+    assert normwise(Gw, Gr) < 2e-5 and normwise(bvw, br) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["iso", "ard"])
+def test_resident_elbo_matches_reference(golden, engine, tag):
+    """The whole `_elbo` (Gram on the split-bf16 engine, device posterior / host Cholesky, second pass) against the
+    reference's golden ELBO, gradients and posterior weights, at the tolerances of the f32 path."""
+    bs, Parameter, Positive, _ = _imports()
+    from revrand_amd import StandardLinearModel as SLM
+    g = golden("elbo")
+    X, y = g["X"], g["y"]
+    d, n = X.shape[1], 16
+    lsp = Parameter(1., Positive()) if tag == "iso" else Parameter(np.ones(d), Positive())
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=lsp)
+    slm = SLM(basis)
+    slm.obj_ = -np.inf
+    slm._state = basis.device_fit_state(X, y)
+    ls = float(g[tag + "_ls"]) if tag == "iso" else g[tag + "_ls"]
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, float(g["var"]), float(g["reg"]), ls)
+    slm._state.release()
+    assert abs(-nelbo - g[tag + "_elbo"]) < 1e-4 * abs(g[tag + "_elbo"])
+    assert normwise(slm.weights_, g[tag + "_m"]) < 1e-3
+    assert normwise(-ndvar, g[tag + "_dvar"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndreg), g[tag + "_dreg"]) < 1e-3
+    assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 2e-3
+
+
+def test_posterior_weights_within_tolerance(engine):
+    """North star: 1e-3 relative on the posterior weights of the f32 path."""
+    bs, Parameter, Positive, _ = _imports()
+    N, d, n = 20000, 8, 128
+    rs = np.random.RandomState(5)
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+    b = bs.RandomRBF(nbases=n, Xdim=d, random_state=3)
+    G, bv, _ = b.gram(X, y, 1.1)
+    Gr, br, _ = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, 1.1)
+    var, reg = 0.05, 1.0
+    m = np.linalg.solve(np.eye(2 * n) / reg + G / var, bv / var)
+    mr = np.linalg.solve(np.eye(2 * n) / reg + Gr / var, br / var)
+    assert normwise(m, mr) < 1e-3, normwise(m, mr)
+
+
+def test_engine_api():
+    _, _, _, _hip = _imports()
+    dev = _hip.get_device()
+    prev = dev.gram_engine
+    with pytest.raises(ValueError):
+        dev.set_gram_engine("fp8")
+    assert dev.set_gram_engine("bf16x3") == prev and dev.gram_engine == "bf16x3"
+    rc = dev.lib.rr_set_gram_engine(dev.ctx, 7)
+    assert rc != 0 and dev.gram_engine == "bf16x3"
+    dev.set_gram_engine(prev)
+    assert dev.gram_engine == prev
+
+
+def test_f64_gram_is_unaffected(engine):
+    bs, Parameter, Positive, _ = _imports()
+    rs = np.random.RandomState(1)
+    X, y = rs.randn(900, 5), rs.randn(900)
+    b = bs.RandomRBF(nbases=40, Xdim=5, random_state=2, dtype="f64")
+    G, bv, _ = b.gram(X, y, 0.9)
+    Gr, br, _ = orc.rff_gram_chunked(X, y, b.W, 0.9)
+    assert normwise(G, Gr) < 1e-12 and normwise(bv, br) < 1e-12
