@@ -18,6 +18,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof")
 tag = sys.argv[1]
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "rr_syrk_f32_kernel"  # dominant kernel (prefix match)
 dst = os.path.join(ROOT, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(SRC, "kt", "kt_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
@@ -29,22 +30,24 @@ for p in ("fetch", "write", "sq", "lds"):
         continue
     shutil.copy(f, os.path.join(dst, "pmc_%s.csv" % p))
     for r in csv.DictReader(open(f)):
-        agg[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[r["Kernel_Name"].split("(")[0].split("<")[0].replace("void ", "")][r["Counter_Name"]] += float(r["Counter_Value"])
 summary = {k: dict(v) for k, v in agg.items() if k.startswith("rr_")}
-k = summary.get("rr_syrk_f32_kernel", {})
+k = summary.get(KERNEL, {})
 rows = json.loads([l for l in open(os.path.join(SRC, "pmc_fetch.json")) if l.startswith("{")][-1])["roofline"]["rows_per_step"]
 traffic = None
 if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-    traffic = {"kernel": "rr_syrk_f32_kernel", "rows_per_launch": rows,
+    traffic = {"kernel": KERNEL, "rows_per_launch": rows,
                "fetch_bytes": k["FETCH_SIZE"] * 1024 * 2, "write_bytes": k["WRITE_SIZE"] * 1024,
                "hbm_bytes": k["FETCH_SIZE"] * 1024 * 2 + k["WRITE_SIZE"] * 1024,
                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of one %d-row launch; "
                        "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024; L2->fabric side, "
                        "includes Infinity-Cache hits; profiles/%s" % (rows, tag)}
-    json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    if KERNEL == "rr_syrk_f32_kernel":  # bench.py's default line quotes this file
+        json.dump(traffic, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 if "SQ_VALU_MFMA_BUSY_CYCLES" in k and "GRBM_GUI_ACTIVE" in k:
-    summary["rr_syrk_f32_kernel"]["mfma_busy_frac"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (k["GRBM_GUI_ACTIVE"] / 8 * 1024)
+    summary[KERNEL]["mfma_busy_frac"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (k["GRBM_GUI_ACTIVE"] / 8 * 1024)
 json.dump({"counters": summary, "traffic": traffic}, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
 print(open(os.path.join(dst, "kernel_stats.csv")).read())
 print(json.dumps(traffic, indent=1))
-print("mfma_busy_frac", summary.get("rr_syrk_f32_kernel", {}).get("mfma_busy_frac"))
+print("mfma_busy_frac", summary.get(KERNEL, {}).get("mfma_busy_frac"))
+print(json.dumps(summary.get(KERNEL, {}), indent=1))
