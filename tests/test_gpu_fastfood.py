@@ -193,15 +193,16 @@ def test_fastfood_transform_device_resident():
         out.free()
 
 
-def test_fastfood_wide_input_transform_only():
-    """128 < d <= 256: the FWHT chain kernel serves `transform` / `_makeVX` (d2 = 256); the dense-equivalent random
-    Fourier route (grad, Gram) stops at d = 128 and says so instead of returning something wrong."""
+def test_fastfood_wide_input():
+    """128 < d <= 256: the FWHT chain kernel serves `transform` / `_makeVX` (d2 = 256); grad and the Gram go through the
+    dense-equivalent random Fourier handle (GEMM route for Xdim > 128, tests/test_gpu_large_xdim.py)."""
     import revrand_amd.basis_functions as bs
-    from revrand_amd._hip import HipError
     rs = np.random.RandomState(0)
     X = rs.randn(300, 200)
+    y = rs.randn(300)
     f = bs.FastFoodRBF(nbases=300, Xdim=200, random_state=1)
     B, G, PI, S = orc.fastfood_matrices(300, 200, 1)
-    assert normwise(f.transform(X, 1.7), orc.fastfood_transform(X, B, G, PI, S, 1.7)) < 1e-3
-    with pytest.raises(HipError, match="not supported"):
-        f.gram(X, np.zeros(300), 1.7)
+    want = orc.fastfood_transform(X, B, G, PI, S, 1.7)
+    assert normwise(f.transform(X, 1.7), want) < 1e-3
+    Gm, bv, _ = f.gram(X, y, 1.7)
+    assert normwise(Gm, want.T @ want) < 1e-3 and normwise(bv, want.T @ y) < 1e-3
