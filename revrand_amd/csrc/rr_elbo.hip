@@ -260,15 +260,17 @@ rr_c64_to_c32_kernel(const double *__restrict__ C, int64_t F, float *__restrict_
 // Scratch of the second pass, kept by the basis between calls (a fit makes ~100 of them): grow-only.
 struct Pass2Scratch {
     float *P = nullptr, *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
+    void *Ab = nullptr, *Cb = nullptr;  // split-bf16 engine: K-blocked copies of Pt and C32 (rr_launch_gemm_tn_bf16)
     double *acc = nullptr;  // [sqErr | T (d*n)] or Vf
     int64_t chunk = 0, Fp = 0;
     size_t nacc = 0;
     std::vector<float> hC, hm;  // host staging for the f64 -> f32 posterior
     void release() {
-        void *q[] = {P, Pt, U, C32, m32, dot, err, acc};
+        void *q[] = {P, Pt, U, C32, m32, dot, err, acc, Ab, Cb};
         for (void *x : q)
             if (x) (void)hipFree(x);
         P = Pt = U = C32 = m32 = dot = err = nullptr;
+        Ab = Cb = nullptr;
         acc = nullptr;
         chunk = Fp = 0;
         nacc = 0;
@@ -284,6 +286,8 @@ void rr_pass2_scratch_free(void *p) {
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              float *P, int64_t ldp, bool zero_pad_cols);  // rr_rff.hip
+int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
+                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready);  // rr_rff.hip
 
 template <typename TX>
 static int launch_features_t(rr_basis *b, const TX *X, int64_t N, int64_t Npad, int64_t ldx, const float *m32,
@@ -382,6 +386,16 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         s.Fp = Fp;
         s.nacc = nacc;
     }
+    if (c->gram_engine != 0 && !s.Ab) {  // the U = Phi C GEMM on the split-bf16 engine
+        hipError_t eb = hipMalloc(&s.Ab, (size_t)Fp * s.chunk * 4);
+        if (eb == hipSuccess) eb = hipMalloc(&s.Cb, (size_t)Fp * Fp * 4);
+        if (eb != hipSuccess) {
+            (void)hipGetLastError();
+            s.release();
+            rr_set_error("pass2: device allocation failed (split-bf16 operands)");
+            return RR_ERR_OOM;
+        }
+    }
     chunk = s.chunk;  // the allocated leading dimension of Pt
     hipError_t e = hipSuccess;
     int rc = RR_OK;
@@ -429,9 +443,14 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         }
         if (rc != RR_OK) break;
         // U = P C  as  (Pt)^T C : A = Pt (K = Fp, M = mpad columns), B = C32 (K = Fp, N = Fp)
-        GemmArgs g;
-        g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
-        hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+        if (c->gram_engine != 0) {
+            rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, chunk, s.C32, Fp, s.U, Fp, Fp, mpad, Fp, s.Ab, s.Cb, r0 > 0);
+            if (rc != RR_OK) break;
+        } else {
+            GemmArgs g;
+            g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
+            hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+        }
         if (hipGetLastError() != hipSuccess) {
             rr_set_error("pass2: gemm launch failed");
             rc = RR_ERR_HIP;

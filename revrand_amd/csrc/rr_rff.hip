@@ -488,6 +488,11 @@ struct SyrkArgs {
     const int *tile_map;  // optional (ntiles): position in dispatch order -> tile id (XCD-aware), or null
     int offdiag_only;     // 1: enumerate only tiles with ta < tb (the diagonal ones go to the diag kernel)
     int ablate;  // debug (RR_GRAM_ABLATE): bit0 = no in-loop DMA, bit1 = no in-loop barrier
+    // GEMM mode of rr_syrk_bf16_kernel (D = A^T B over K-blocked operands): B side matrix, output
+    const float *P2 = nullptr;
+    int64_t ldp2 = 0;
+    float *D = nullptr;   // (M, ldd) f32, plain stores
+    int64_t ldd = 0;
 };
 
 
@@ -1487,7 +1492,10 @@ __device__ __forceinline__ void b16_mfma(const B16Ops &o, floatx16 (&acc)[4][2])
     }
 }
 
-template <int NPROD>
+// GEMM = true: D (M, N) = A^T B for two K-blocked operands (A = p.P with ldp = M columns, B = p.P2 with ldp2 = N columns,
+// K = p.rows, no K-split): block -> (M tile ta, N tile tb) = (blockIdx / nb, blockIdx % nb), f32 stores.  Used for
+// U = Phi C of the second _elbo pass (rr_elbo.hip).
+template <int NPROD, bool GEMM>
 __global__ void __launch_bounds__(GR_THREADS, 2)
 rr_syrk_bf16_kernel(const SyrkArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[4 * B16_STAGE];
@@ -1495,16 +1503,21 @@ rr_syrk_bf16_kernel(const SyrkArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    int tdx = blockIdx.x % p.ntiles;
-    const int ks = blockIdx.x / p.ntiles;
-    if (p.tile_map) tdx = p.tile_map[tdx];
-    int ta = 0;
-    const int od = p.offdiag_only;
-    while (tdx >= p.nb - ta - od) {
-        tdx -= p.nb - ta - od;
-        ++ta;
+    int tdx = GEMM ? (int)blockIdx.x : (int)(blockIdx.x % p.ntiles);
+    const int ks = GEMM ? 0 : (int)(blockIdx.x / p.ntiles);
+    int ta = 0, tb = 0;
+    if (GEMM) {
+        ta = tdx / p.nb;
+        tb = tdx % p.nb;
+    } else {
+        if (p.tile_map) tdx = p.tile_map[tdx];
+        const int od = p.offdiag_only;
+        while (tdx >= p.nb - ta - od) {
+            tdx -= p.nb - ta - od;
+            ++ta;
+        }
+        tb = ta + tdx + od;
     }
-    const int tb = ta + tdx + od;
     const int ca = ta * GR_TC, cb = tb * GR_TC;
     const int64_t row_begin = (int64_t)ks * p.rows_per_split;  // multiples of 64
     int64_t row_end = row_begin + p.rows_per_split;
@@ -1516,8 +1529,10 @@ rr_syrk_bf16_kernel(const SyrkArgs p) {
     const int side = wave >> 2;
     const int tt0 = (wave & 3) * 4;
     const unsigned lane_src = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
-    const char *src0 = (const char *)p.P + ((row_begin / 16) * p.ldp + (side ? cb : ca)) * 64 + tt0 * 1024 + lane_src;
-    const int64_t stage_stride = p.ldp * 64;
+    const int64_t ld_side = (GEMM && side) ? p.ldp2 : p.ldp;
+    const char *src0 = (const char *)((GEMM && side) ? p.P2 : p.P) + ((row_begin / 16) * ld_side + (side ? cb : ca)) * 64 +
+                       tt0 * 1024 + lane_src;
+    const int64_t stage_stride = ld_side * 64;
     char *dst0 = lds + side * 16384 + tt0 * 1024;
     auto dma = [&](int g, int buf) {
         const char *src = src0 + (int64_t)((p.ablate & 8) ? (g & 7) : g) * stage_stride;
@@ -1604,10 +1619,36 @@ rr_syrk_bf16_kernel(const SyrkArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+                if (GEMM)
+                    p.D[gr * p.ldd + gc] = acc[i][j][e];
+                else if (gr <= gc && gc < F)
+                    unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
             }
         }
     }
+}
+
+// D (M, N) f32 = A^T B with A (K, M), B (K, N) row-major f32 (K % 64 == 0, M, N % 256 == 0, all zero padded): both are
+// converted to the K-blocked split-bf16 layout into caller scratch (sa: K*lda*4 bytes, sb: K*ldb*4; sb_ready: B was
+// converted by an earlier call and is unchanged) and multiplied on the bf16 matrix pipe with nprod products.
+int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
+                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready) {
+    hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(M / 256), (unsigned)(K / 16)), dim3(256), 0, c->stream, A, K, lda,
+                       (uintx4 *)sa);
+    if (!sb_ready)
+        hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(N / 256), (unsigned)(K / 16)), dim3(256), 0, c->stream, B, K,
+                           ldb, (uintx4 *)sb);
+    SyrkArgs a;
+    a.P = (const float *)sa; a.ldp = lda; a.P2 = (const float *)sb; a.ldp2 = ldb; a.rows = K; a.rows_per_split = K;
+    a.F = (int)N; a.nb = (int)(N / 256); a.ntiles = (int)((M / 256) * (N / 256)); a.G = nullptr; a.tile_map = nullptr;
+    a.offdiag_only = 0; a.ablate = 0; a.D = D; a.ldd = ldd;
+    RR_REQUIRE((M / 256) * (N / 256) < (int64_t)1 << 31, "gemm: grid too large");
+    if (nprod == 4)
+        hipLaunchKernelGGL((rr_syrk_bf16_kernel<4, true>), dim3((unsigned)a.ntiles), dim3(GR_THREADS), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, true>), dim3((unsigned)a.ntiles), dim3(GR_THREADS), 0, c->stream, a);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // nprod: 3 or 4 products.  Either P (row-major f32, rows % 32 == 0: converted here into the context's Pb scratch) or
@@ -1662,9 +1703,9 @@ static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void 
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
     if (nprod == 4)
-        hipLaunchKernelGGL(rr_syrk_bf16_kernel<4>, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_bf16_kernel<4, false>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     else
-        hipLaunchKernelGGL(rr_syrk_bf16_kernel<3>, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, false>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -137,6 +137,32 @@ def test_resident_elbo_matches_reference(golden, engine, tag):
     assert normwise(-np.atleast_1d(ndhyp), g[tag + "_dhyp"]) < 2e-3
 
 
+@pytest.mark.parametrize("shape", [(700, 5, 40), (1500, 16, 96), (1025, 21, 130), (2000, 6, 300)])
+def test_second_pass_and_predict_vs_oracle(engine, shape):
+    """U = Phi C of the second pass / predict_moments runs on the same split-bf16 engine (GEMM mode of the kernel)."""
+    bs, Parameter, Positive, _ = _imports()
+    N, d, n = shape
+    rs = np.random.RandomState(N)
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    basis = bs.RandomMatern52(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+    ls = np.linspace(0.7, 1.5, d)
+    var, reg = 0.3, 1.4
+    Phi = orc.rff_transform(X, basis.W, ls)
+    dP = orc.rff_grad(X, basis.W, ls)
+    o = orc.slm_elbo(Phi, y, var, np.full(2 * n, reg), slice(None), [dP[:, :, i] for i in range(d)])
+    st = basis.device_fit_state(X, y)
+    sq, dh = st.second_pass(ls, o["m"], o["C"], var)
+    st.release()
+    err = y - Phi @ o["m"]
+    assert abs(sq - err @ err) < 1e-4 * (err @ err)
+    assert normwise(dh, -np.array(o["dhyp"])) < 2e-3
+    Xs = rs.randn(257, d)
+    Ey, Vf = basis.predict_moments(Xs, ls, o["m"], o["C"])
+    Eo, Vo = orc.slm_predict_moments(orc.rff_transform(Xs, basis.W, ls), o["m"], o["C"], 0.0)
+    assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
+
+
 def test_posterior_weights_within_tolerance(engine):
     """North star: 1e-3 relative on the posterior weights of the f32 path."""
     bs, Parameter, Positive, _ = _imports()
