@@ -706,6 +706,8 @@ struct FmPass2 {
     double *sq = nullptr, *vf = nullptr;
     std::vector<float> hC, hm;
     bool have_rows = false;
+    void *Ab = nullptr, *Cb = nullptr;  // split-bf16 engine: K-blocked copies of Pt and C32
+    bool cb_ready = false;              // Cb matches C32
     // GLM step / projection: FSt (max_rows, klp), its transpose DFS (klp, max_rows), the sample matrices
     float *FSt = nullptr, *DFS = nullptr, *WSt = nullptr, *WSs = nullptr, *Ed = nullptr, *Ee = nullptr;
     double *mc = nullptr;  // [m (F K) | C (F K) | Edm (K F) | EdC (K F)] of the device-sampled step
@@ -718,7 +720,8 @@ struct FmPass2 {
 void rr_fm_pass2_free(void *p) {
     if (!p) return;
     FmPass2 *s = (FmPass2 *)p;
-    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->kacc, s->Ee, s->mc};
+    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->kacc, s->Ee, s->mc,
+                 s->Ab, s->Cb};
     for (void *x : q)
         if (x) (void)hipFree(x);
     delete s;
@@ -732,6 +735,16 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
                        fm->rows, fm->F, fm->ld, s.dot);
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(fm->ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0,
                        c->stream, fm->P, fm->rows, fm->ld, s.Pt, fm->max_rows);
+    if (c->gram_engine != 0) {  // split-bf16 engine (rr_rff.hip)
+        if (!s.Ab) {
+            RR_CHECK_HIP(hipMalloc(&s.Ab, (size_t)fm->ld * fm->max_rows * 4));
+            RR_CHECK_HIP(hipMalloc(&s.Cb, (size_t)fm->ld * fm->ld * 4));
+        }
+        int rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, fm->max_rows, s.C32, fm->ld, s.U, fm->ld, fm->ld, rows256,
+                                        fm->ld, s.Ab, s.Cb, s.cb_ready);
+        s.cb_ready = true;
+        return rc;
+    }
     GemmArgs g;
     g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = fm->max_rows; g.ldb = fm->ld; g.ldd = fm->ld;
     g.K = (int)fm->ld; g.ntb = (int)(fm->ld / 256);
@@ -1288,6 +1301,7 @@ static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool
     }
     RR_CHECK_HIP(hipMemsetAsync(s.sq, 0, 8, c->stream));
     s.have_rows = false;
+    s.cb_ready = false;
     return RR_OK;
 }
 

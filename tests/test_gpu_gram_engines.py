@@ -200,3 +200,11 @@ def test_f64_gram_is_unaffected(engine):
     G, bv, _ = b.gram(X, y, 0.9)
     Gr, br, _ = orc.rff_gram_chunked(X, y, b.W, 0.9)
     assert normwise(G, Gr) < 1e-12 and normwise(bv, br) < 1e-12
+
+
+@pytest.mark.parametrize("chunk_rows", [None, 512])
+def test_concat_second_pass_and_predict_on_the_engine(engine, chunk_rows):
+    """The concatenated-basis case of test_gpu_slm.py (statistics, sqErr, per-child gradients, predict_moments) with the
+    Gram and U = Phi C on the split-bf16 engine."""
+    from test_gpu_slm import test_concat_second_pass_and_predict_vs_oracle as concat_case
+    concat_case(chunk_rows)
