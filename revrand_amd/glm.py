@@ -98,9 +98,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         log.info("Optimising parameters...")
         self.__it = -self.nstarts
         nsgd = structured_sgd(logtrick_sgd(sgd))
+        if self.sampler == "device":
+            # keyed here, so that `_elbo` never draws from random_ and the minibatches can be built one step ahead
+            self._dev_seed, self._dev_step = int(self.random_.randint(0, 2 ** 31 - 1)), 0
         try:
             res = nsgd(self._elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
-                       batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts)
+                       batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
+                       prefetch=self.sampler == "device")
         finally:
             self._resident_fit = False
             self._release_features()

@@ -285,11 +285,51 @@ def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
         yield (data[ind],) if not issequence(data) else [d[ind] for d in data]
 
 
+def _prefetched(batches):
+    """The same batches, each produced one step ahead on a worker thread: the device calls inside `fun` release the
+    GIL, so the permutation draw and the row gather of step t+1 overlap the kernels of step t.  The order of the
+    batches, hence the generator's use of its RandomState, is unchanged."""
+    import queue
+    import threading
+    q, stop, END = queue.Queue(maxsize=1), threading.Event(), object()
+
+    def put(item):
+        while not stop.is_set():
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                pass
+        return False
+
+    def work():
+        try:
+            for item in batches:
+                if not put(item):
+                    return
+            put(END)
+        except BaseException as e:  # surfaces in the consumer
+            put(e)
+
+    threading.Thread(target=work, daemon=True).start()
+    try:
+        while True:
+            item = q.get()
+            if item is END:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+    finally:
+        stop.set()
+
+
 def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, updater=None, eval_obj=False,
-        random_state=None):
+        random_state=None, prefetch=False):
     """Stochastic gradient descent over minibatches of `data` (sgd.py:337-425): ``fun(x, *batch, *args)`` returns
     the gradient (or ``(objective, gradient)`` with eval_obj); bounded coordinates have outward gradients
-    truncated and steps clipped."""
+    truncated and steps clipped.  `prefetch` (not in the reference): build each minibatch one step ahead on a worker
+    thread -- only valid when `fun` does not draw from `random_state` itself."""
     from scipy.optimize import OptimizeResult
     if updater is None:
         updater = Adam()
@@ -303,7 +343,8 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
         lower = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=float)
         upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
     obj, objs, norms = None, [], []
-    for batch in gen_batch(data, batch_size, maxiter, random_state):
+    batches = gen_batch(data, batch_size, maxiter, random_state)
+    for batch in (_prefetched(batches) if prefetch else batches):
         if not eval_obj:
             grad = fun(x, *(list(batch) + list(args)))
         else:

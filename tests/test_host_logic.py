@@ -318,3 +318,48 @@ def test_likelihoods_like_reference_test_likelihoods():
     assert np.allclose(lk.Poisson().cdf(xn, np.log(2.)), poisson.cdf(xn, 2.))
     g = np.log(np.expm1(2.))   # softplus(g) = 2
     assert np.allclose(lk.Poisson("softplus").loglike(xn, g), poisson.logpmf(xn, 2.))
+
+
+def test_sgd_prefetch_changes_nothing_but_the_thread():
+    """`prefetch=True` builds each minibatch one step ahead on a worker thread: same batches, same result, the
+    generator's exceptions still surface, and an abandoned run does not leave the worker blocked."""
+    import threading
+    from revrand_amd.optimize import sgd, Adam, _prefetched
+    rs = np.random.RandomState(0)
+    X = rs.randn(500, 3)
+    w = np.array([1.0, -2.0, 0.5])
+    y = X @ w
+
+    def grad(wv, Xb, yb):
+        return 2 * Xb.T @ (Xb @ wv - yb) / len(yb)
+
+    res = [sgd(grad, np.zeros(3), [X, y], batch_size=37, maxiter=200, updater=Adam(alpha=0.05),
+               random_state=np.random.RandomState(5), prefetch=pf) for pf in (False, True)]
+    assert np.array_equal(res[0].x, res[1].x) and res[0].norms == res[1].norms
+    assert np.allclose(res[1].x, w, atol=1e-2)
+
+    def boom():
+        yield 1
+        raise RuntimeError("from the generator")
+    it = _prefetched(boom())
+    assert next(it) == 1
+    with pytest.raises(RuntimeError, match="from the generator"):
+        next(it)
+    before = threading.active_count()
+    it = _prefetched(iter(range(1000)))
+    assert next(it) == 0
+    it.close()                      # consumer walks away: the worker must notice and end
+    import time
+    for _ in range(50):
+        if threading.active_count() <= before:
+            break
+        time.sleep(0.05)
+    assert threading.active_count() <= before
+
+
+def test_poisson_log_factorial_table():
+    from scipy.special import gammaln
+    from revrand_amd.likelihoods import _sum_gammaln1p
+    rs = np.random.RandomState(1)
+    for y in (rs.poisson(3.0, size=1000).astype(float), np.zeros(5), np.array([]), rs.rand(20) * 7, np.array([5000.0, 2.0])):
+        assert abs(_sum_gammaln1p(y) - float(gammaln(y + 1).sum())) <= 1e-12 * max(1.0, abs(float(gammaln(y + 1).sum())))
