@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense (same rate for fp16)
 
 # HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools_prof.sh),
 # corrected as MI355X_MICROARCH.md prescribes; the committed summary is quoted, per launch.
@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--nbases", type=int, default=2048)
     ap.add_argument("--cpu-sample", type=int, default=150000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--engine", choices=["f32", "bf16x3", "bf16x4"], default=None,
+    ap.add_argument("--engine", choices=["f32", "bf16x3", "bf16x4", "fp16x3"], default=None,
                     help="arithmetic of the Gram (default: f32 MFMA, or $RR_SYRK_ENGINE); see DESIGN.md 3.13")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational bf16x3 measurement")
     args = ap.parse_args()
@@ -230,10 +230,10 @@ def main():
         assert np.array_equal(G, G.T) or os.environ.get("RR_GRAM_ABLATE")
     trace_err = abs(diag - args.rows) / args.rows
 
-    # ---- informational: the same step on the split-bf16 engine (N=1 only; never `value`) ----
+    # ---- informational: the same step on the split-fp16 engine (N=1 only; never `value`) ----
     alt = None
     if world == 1 and not use_dist and engine == "f32" and not args.no_alt_engine and not os.environ.get("RR_GRAM_ABLATE"):
-        dev.set_gram_engine("bf16x3")
+        dev.set_gram_engine("fp16x3")
         step(False)
         dev.sync()
         ta = time.perf_counter()
@@ -245,17 +245,21 @@ def main():
         dev.sync()
         alt_elapsed = (time.perf_counter() - ta) / nalt
         G3 = dev.download(acc_buf, (F, F), np.float64)
-        alt = {"engine": "bf16x3", "value": args.rows / alt_elapsed, "unit": "feature-rows/s",
+        Gr_alt = None
+        alt = {"engine": "fp16x3", "value": args.rows / alt_elapsed, "unit": "feature-rows/s",
                "ms_per_step": 1e3 * alt_elapsed, "steps": nalt,
                "max_abs_diff_vs_f32_engine_over_max_G": float(np.abs(G3 - G).max() / np.abs(G).max()),
-               "kernel": "rr_syrk_bf16_kernel<3>", "kernel_ms_per_step": float(np.mean([k[1] + k[2] for k in alt_ms])),
+               "kernel": "rr_syrk_bf16_kernel<3, false, true>",
+               "kernel_ms_per_step": float(np.mean([k[1] + k[2] for k in alt_ms])),
                "features_ms_per_step": float(np.mean([k[0] for k in alt_ms])),
-               "note": "bf16 hi/lo split of the f32 features, 3 products on the bf16 matrix pipe, f32 accumulation; "
-                       "opt-in (Device.set_gram_engine / RR_SYRK_ENGINE), DESIGN.md 3.13"}
+               "trace_rel_err": abs(float(np.trace(G3)) - args.rows) / args.rows,
+               "note": "features scaled into [-1, 1] and split into fp16 hi + lo (22 mantissa bits), 3 products on the "
+                       "fp16 matrix pipe, f32 accumulation: same error against the float64 oracle as the f32 MFMA engine "
+                       "(tests/test_gpu_gram_engines.py); opt-in (Device.set_gram_engine / RR_SYRK_ENGINE), DESIGN.md 3.13"}
         # 136 full 256x256 tiles x 3 products are issued for F (F + 1) algorithmic flops per row
         alt["mfma_issued_tflops"] = 3.0 * 2.0 * 256 * 256 * (len(range(0, F, 256)) * (len(range(0, F, 256)) + 1) // 2) \
             * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
-        alt["mfma_issued_frac_of_bf16_peak"] = alt["mfma_issued_tflops"] / PEAK_BF16_MFMA_TFLOPS
+        alt["mfma_issued_frac_of_fp16_peak"] = alt["mfma_issued_tflops"] / PEAK_BF16_MFMA_TFLOPS
         alt["algorithmic_tflops"] = F * (F + 1.0) * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
         dev.set_gram_engine("f32")
 
@@ -305,7 +309,7 @@ def main():
         if engine != "f32":
             # split-bf16 engine: one SYRK kernel over all 136 tiles; the roofline is the bf16 matrix pipe, `achieved`
             # stays ALGORITHMIC flops (the kernel issues 3 or 4 bf16 products per f32 product: `issued_frac`)
-            nprod = 3 if engine == "bf16x3" else 4
+            nprod = 4 if engine == "bf16x4" else 3
             k_ms = syrk_ms + diag_ms
             nbk = len(widths)
             alg = (off_flops + diag_flops) * my_rows / (k_ms * 1e-3) / 1e12
@@ -318,9 +322,10 @@ def main():
                                "rows_per_step": my_rows,
                                "other_kernels_ms_per_step": {"rr_rff_features_mfma_kernel": feat_ms},
                                "f32_mfma_equivalent_frac": alg / PEAK_F32_MFMA_TFLOPS}
-            out["dtype"] = "f32 values as bf16 hi+lo, %d bf16 products per f32 product, f32 accumulate" % nprod
+            out["dtype"] = "f32 values as %s hi+lo, %d 16-bit products per f32 product, f32 accumulate" % (
+                "fp16" if engine == "fp16x3" else "bf16", nprod)
         if alt:
-            out["split_bf16_engine"] = alt
+            out["split_fp16_engine"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
         print(json.dumps(out))

@@ -256,10 +256,13 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
  * RR_GRAM_BF16X3 / RR_GRAM_BF16X4: each f32 feature value is split into bf16 hi + lo and the Gram accumulates
  * hi.hi + hi.lo + lo.hi (+ lo.lo) in f32 on the bf16 matrix pipe (16x the f32 MFMA rate).  Results agree with the
  * f32 engine to ~4e-6 of max|G|, well inside the 1e-3 tolerance of the f32 path; the f64 Gram is
- * unaffected.  The environment variable RR_SYRK_ENGINE = bf16x3 | bf16x4 sets the default of new contexts. */
+ * unaffected.  The environment variable RR_SYRK_ENGINE = bf16x3 | bf16x4 | fp16x3 sets the default of new contexts. */
 #define RR_GRAM_F32 0
 #define RR_GRAM_BF16X3 3
 #define RR_GRAM_BF16X4 4
+#define RR_GRAM_FP16X3 5 /* random Fourier features (bounded by 1/sqrt(n)) scaled into [-1, 1] and split into fp16 hi + lo:
+                          * 22 mantissa bits, 3 fp16 products; other feature matrices (concatenations, Xdim > 128) use
+                          * the bf16x3 split under this setting */
 int rr_set_gram_engine(rr_ctx *ctx, int engine);
 int rr_get_gram_engine(rr_ctx *ctx);
 

@@ -307,7 +307,7 @@ class Device(object):
         self.name, self.compute_units, self.hbm_bytes = name.value.decode(), cus.value, hbm.value
 
     # -- arithmetic of the f32 Gram (include/revrand_hip.h: RR_GRAM_*) -------------
-    GRAM_ENGINES = {"f32": 0, "bf16x3": 3, "bf16x4": 4}
+    GRAM_ENGINES = {"f32": 0, "bf16x3": 3, "bf16x4": 4, "fp16x3": 5}
 
     @property
     def gram_engine(self):

@@ -68,14 +68,14 @@ int rr_ctx_create(int device, rr_ctx **out) {
         delete c;
         return RR_ERR_HIP;
     }
-    if (const char *eng = getenv("RR_SYRK_ENGINE")) c->gram_engine = !strcmp(eng, "bf16x3") ? 3 : !strcmp(eng, "bf16x4") ? 4 : 0;
+    if (const char *eng = getenv("RR_SYRK_ENGINE")) c->gram_engine = !strcmp(eng, "bf16x3") ? 3 : !strcmp(eng, "bf16x4") ? 4 : !strcmp(eng, "fp16x3") ? 5 : 0;
     *out = c;
     return RR_OK;
 }
 
 int rr_set_gram_engine(rr_ctx *ctx, int engine) {
     RR_REQUIRE(ctx != nullptr, "rr_set_gram_engine: null context");
-    RR_REQUIRE(engine == RR_GRAM_F32 || engine == RR_GRAM_BF16X3 || engine == RR_GRAM_BF16X4,
+    RR_REQUIRE(engine == RR_GRAM_F32 || engine == RR_GRAM_BF16X3 || engine == RR_GRAM_BF16X4 || engine == RR_GRAM_FP16X3,
                "rr_set_gram_engine: unknown engine %d", engine);
     ctx->gram_engine = engine;
     return RR_OK;

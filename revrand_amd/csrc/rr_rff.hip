@@ -15,6 +15,30 @@ typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 // Output tag of the feature kernel: the K-blocked split-bf16 layout of rr_syrk_bf16_kernel (see there):
 // Pb[kstep][column] = 64 B = granules [hi rows 0-7 | hi rows 8-15 | lo rows 0-7 | lo rows 8-15] of a 16-row k-step.
 struct rr_pb_t { uintx4 g[4]; };
+// The same layout with fp16 parts of the value scaled by a power of two into [-1, 1] (random Fourier features are
+// bounded by 1/sqrt(n)): 11 + 11 mantissa bits, |p' - hi - lo| <= 2^-23 of full scale -- f32-grade products from
+// three fp16 MFMAs.  lo is below the fp16 normal range; the matrix pipe takes fp16 denormals at full precision.
+struct rr_pf_t { uintx4 g[4]; };
+typedef _Float16 halfx2 __attribute__((ext_vector_type(2)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split_f16x8(const float *v, float s16, uintx4 &hi, uintx4 &lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float x0 = v[2 * q] * s16, x1 = v[2 * q + 1] * s16;
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+        const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+        hi[q] = __builtin_bit_cast(unsigned, halfx2{h0, h1});
+        lo[q] = __builtin_bit_cast(unsigned, halfx2{l0, l1});
+    }
+}
+
+// power of two s with scale * s in [0.5, 1)
+__host__ __device__ __forceinline__ float f16_store_scale(float scale) {
+    int ex;
+    (void)frexpf(scale, &ex);
+    return ldexpf(1.f, -ex);
+}
 
 // 8 f32 values -> one granule of bf16 hi parts and one of lo parts (hi = bf16(v), lo = bf16(v - hi)); v_cvt_pk_bf16_f32
 __device__ __forceinline__ void split_bf16x8(const float *v, uintx4 &hi, uintx4 &lo) {
@@ -339,7 +363,9 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
         }
         // stores: wave-uniform tile bases (cos and sin halves) in SGPRs + one 32-bit byte offset per row of the
         // lane (written as asm: left alone, the compiler keeps a 64-bit pointer induction variable per store)
-        constexpr bool SPLIT = std::is_same<TO, rr_pb_t>::value;
+        constexpr bool F16 = std::is_same<TO, rr_pf_t>::value;
+        constexpr bool SPLIT = std::is_same<TO, rr_pb_t>::value || F16;
+        const float s16 = F16 ? f16_store_scale(scale) : 1.f;
         // SPLIT: the tile is k-steps 2 tl and 2 tl + 1 of Pb; byte addresses, column stride 64
         const char *tile_c = SPLIT ? (const char *)P + ((2 * tl) * ldp + c0) * 64 : (const char *)(P + r0 * ldp + c0);
         const char *tile_s = tile_c + (int64_t)n * (SPLIT ? 64 : (int64_t)sizeof(TO));
@@ -373,16 +399,20 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
                     // the compiler's hazard recogniser does not look inside asm.
                     const unsigned off = lane_off + 2048u * cb;
                     uintx4 g_hi, g_lo;
-                    split_bf16x8(cvv, g_hi, g_lo);
+                    auto split8 = [&](const float *v) {
+                        if (F16) split_f16x8(v, s16, g_hi, g_lo);
+                        else split_bf16x8(v, g_hi, g_lo);
+                    };
+                    split8(cvv);
                     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c) : "memory");
                     asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c) : "memory");
-                    split_bf16x8(cvv + 8, g_hi, g_lo);
+                    split8(cvv + 8);
                     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c1) : "memory");
                     asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c1) : "memory");
-                    split_bf16x8(svv, g_hi, g_lo);
+                    split8(svv);
                     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s) : "memory");
                     asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s) : "memory");
-                    split_bf16x8(svv + 8, g_hi, g_lo);
+                    split8(svv + 8);
                     asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s1) : "memory");
                     asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s1) : "memory");
                 }
@@ -493,6 +523,7 @@ struct SyrkArgs {
     int64_t ldp2 = 0;
     float *D = nullptr;   // (M, ldd) f32, plain stores
     int64_t ldd = 0;
+    float out_scale = 1.f;  // fp16 operands: 1 / s^2 of the producer's store scale
 };
 
 
@@ -1331,7 +1362,7 @@ static void build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
 
 // G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
 static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void *pb, int64_t rows, int64_t ldp, int F,
-                               double *dG, hipEvent_t mid);
+                               double *dG, hipEvent_t mid, float f16_scale = 0.f);
 
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
     if (c->gram_engine != 0) return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
@@ -1480,22 +1511,26 @@ struct B16Ops {
 };
 
 // MFMAs [FIRST, LAST) of a k-step in (product, i, j) order: product 0 hi.hi, 1 hi.lo, 2 lo.hi, 3 lo.lo
-template <int FIRST, int LAST>
+template <int FIRST, int LAST, bool F16 = false>
 __device__ __forceinline__ void b16_mfma(const B16Ops &o, floatx16 (&acc)[4][2]) {
 #pragma unroll
     for (int q = FIRST; q < LAST; ++q) {
         const int pr = q >> 3, i = (q >> 1) & 3, j = q & 1;
         const uintx4 a = (pr & 2) ? o.al[i] : o.ah[i];
         const uintx4 b = (pr & 1) ? o.bl[j] : o.bh[j];
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                            acc[i][j], 0, 0, 0);
+        if (F16)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b),
+                                                               acc[i][j], 0, 0, 0);
+        else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                                acc[i][j], 0, 0, 0);
     }
 }
 
 // GEMM = true: D (M, N) = A^T B for two K-blocked operands (A = p.P with ldp = M columns, B = p.P2 with ldp2 = N columns,
 // K = p.rows, no K-split): block -> (M tile ta, N tile tb) = (blockIdx / nb, blockIdx % nb), f32 stores.  Used for
 // U = Phi C of the second _elbo pass (rr_elbo.hip).
-template <int NPROD, bool GEMM>
+template <int NPROD, bool GEMM, bool F16 = false>
 __global__ void __launch_bounds__(GR_THREADS, 2)
 rr_syrk_bf16_kernel(const SyrkArgs p) {
     __shared__ __attribute__((aligned(16))) char lds[4 * B16_STAGE];
@@ -1583,19 +1618,19 @@ rr_syrk_bf16_kernel(const SyrkArgs p) {
         const int g = g0 + (Q);                                                         \
         if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();                              \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<0, 2>(CUR, acc);                                                       \
+        b16_mfma<0, 2, F16>(CUR, acc);                                                       \
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (g + 4 < S && !(p.ablate & 1)) dma(g + 4, (Q));                              \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<2, 4>(CUR, acc);                                                       \
+        b16_mfma<2, 4, F16>(CUR, acc);                                                       \
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (g + 1 < S && !(p.ablate & 4)) NXT.template load_b<((Q) + 1) & 3>(bbase);    \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<4, 6>(CUR, acc);                                                       \
+        b16_mfma<4, 6, F16>(CUR, acc);                                                       \
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (g + 1 < S && !(p.ablate & 4)) NXT.template load_a<((Q) + 1) & 3>(abase);    \
         __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<6, NM>(CUR, acc);                                                      \
+        b16_mfma<6, NM, F16>(CUR, acc);                                                      \
         __builtin_amdgcn_sched_barrier(0);                                              \
         if (g + 4 < S && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                \
@@ -1622,7 +1657,7 @@ rr_syrk_bf16_kernel(const SyrkArgs p) {
                 if (GEMM)
                     p.D[gr * p.ldd + gc] = acc[i][j][e];
                 else if (gr <= gc && gc < F)
-                    unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+                    unsafeAtomicAdd(&p.G[gr * F + gc], (double)(F16 ? acc[i][j][e] * p.out_scale : acc[i][j][e]));
             }
         }
     }
@@ -1653,8 +1688,10 @@ int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, co
 
 // nprod: 3 or 4 products.  Either P (row-major f32, rows % 32 == 0: converted here into the context's Pb scratch) or
 // pb (features already in the K-blocked layout, rows % 64 == 0, pad rows / columns zero).
+// f16_scale > 0: pb holds fp16 parts of value * f16_scale (rr_pf_t, RR_GRAM_FP16X3); engine code 5 without such a
+// producer (conversion path) falls back to the bf16 split with 3 products.
 static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void *pb, int64_t rows, int64_t ldp, int F,
-                               double *dG, hipEvent_t mid) {
+                               double *dG, hipEvent_t mid, float f16_scale) {
     const int nb = (int)(ldp / GR_TC);
     const int od = 0;
     const int ntiles = nb * (nb + 1) / 2;
@@ -1686,7 +1723,10 @@ static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void 
     }
     if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
     auto gcd64 = [](int64_t x, int64_t y) { while (y) { const int64_t u = x % y; x = y; y = u; } return x; };
-    const int64_t min_splits = (rows64 + 32767) / 32768;
+    // f32 accumulation per K-split: the fp16 engine is accurate enough (max error = the f32 engine's) for the pipe's
+    // accumulate bias to show in trace(G) -- 1.0e-6 of N at 32 768 rows per split, 6e-7 at 16 384 (+1.3 % time)
+    const int64_t max_rows_split = f16_scale > 0.f ? 16384 : 32768;
+    const int64_t min_splits = (rows64 + max_rows_split - 1) / max_rows_split;
     const int64_t unit = c->num_cu / gcd64(c->num_cu, ntiles);
     int64_t nsplit = (min_splits + unit - 1) / unit * unit;
     if (rows64 / nsplit < 1024) nsplit = (rows64 + 1023) / 1024;
@@ -1702,7 +1742,10 @@ static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void 
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
-    if (nprod == 4)
+    if (f16_scale > 0.f) {
+        a.out_scale = 1.f / (f16_scale * f16_scale);
+        hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, false, true>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    } else if (nprod == 4)
         hipLaunchKernelGGL((rr_syrk_bf16_kernel<4, false>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     else
         hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, false>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
@@ -1798,7 +1841,9 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         bool done_a = false;
         if constexpr (F32) {
             if (fused_pb) {
-                done_a = rr_features_mfma_launch<TX, rr_pb_t>(b, Xc, yc, m, mpad, ldx, (rr_pb_t *)P, ldp, db, (float)scale);
+                done_a = c->gram_engine == RR_GRAM_FP16X3
+                             ? rr_features_mfma_launch<TX, rr_pf_t>(b, Xc, yc, m, mpad, ldx, (rr_pf_t *)P, ldp, db, (float)scale)
+                             : rr_features_mfma_launch<TX, rr_pb_t>(b, Xc, yc, m, mpad, ldx, (rr_pb_t *)P, ldp, db, (float)scale);
                 if (!done_a) {
                     rr_set_error("gram: internal: split-bf16 feature launch refused");
                     return RR_ERR_INVALID;
@@ -1838,7 +1883,8 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         // (B) G += P^T P
         if constexpr (F32) {
             if (fused_pb)
-                rc = rr_launch_syrk_bf16(c, c->gram_engine, nullptr, (const void *)P, mpad, ldp, F, dG, b->events[e0 + 2]);
+                rc = rr_launch_syrk_bf16(c, c->gram_engine, nullptr, (const void *)P, mpad, ldp, F, dG, b->events[e0 + 2],
+                                         c->gram_engine == RR_GRAM_FP16X3 ? f16_store_scale((float)scale) : 0.f);
             else
                 rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG, b->events[e0 + 2]);
         } else {
