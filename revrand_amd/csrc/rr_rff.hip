@@ -1663,6 +1663,181 @@ rr_syrk_bf16_kernel(const SyrkArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same computation with ONE wave per SIMD (4 waves of 128x128, 256 accumulator registers each): a wave's
+// non-MFMA work -- 8 DMA instructions and 16 operand reads per k-step -- is placed one instruction at a time into the
+// shadows of its own 48 (64) MFMAs (a 32x32x16 MFMA occupies the pipe for 32 cycles = ~5 issue slots), so the matrix
+// pipe never waits for a partner wave that is at the same barrier anyway.  Per MFMA 1/3 fewer operand reads than the
+// 128x64 waves.  The k loop is branch-free: past the end of a K-split the DMA re-fetches the last k-step into a free
+// buffer and the reads fetch operands that are never used.
+// ---------------------------------------------------------------------------------------
+struct B16Ops4 {
+    uintx4 ah[4], al[4], bh[4], bl[4];
+    // read IDX (0..15) of ring stage BUF, in the order the MFMAs need them: (b0, a0, a1, a2, a3, b1, b2, b3) x (hi, lo)
+    template <int BUF, int IDX>
+    __device__ __forceinline__ void load_one(const unsigned (&a)[2][2], const unsigned (&b)[2][2]) {
+        constexpr int O = (BUF & 1) * B16_STAGE;
+        constexpr int PART = IDX >> 3, W = IDX & 7;
+        if constexpr (W == 0) (PART ? bl[0] : bh[0]) = lds_read_b128<O>(b[BUF >> 1][PART]);
+        else if constexpr (W <= 4) (PART ? al[W - 1] : ah[W - 1]) = lds_read_b128<O + (W - 1) * 2048>(a[BUF >> 1][PART]);
+        else (PART ? bl[W - 4] : bh[W - 4]) = lds_read_b128<O + (W - 4) * 2048>(b[BUF >> 1][PART]);
+    }
+};
+
+// MFMA Q of a k-step: products in the order hi.hi (needs only the "hi" reads), hi.lo, lo.hi, lo.lo; tiles (i, j)
+template <int Q, bool F16>
+__device__ __forceinline__ void b16w4_mfma(const B16Ops4 &o, floatx16 (&acc)[4][4]) {
+    constexpr int pr = Q >> 4, i = (Q >> 2) & 3, j = Q & 3;
+    const uintx4 a = (pr & 2) ? o.al[i] : o.ah[i];
+    const uintx4 b = (pr & 1) ? o.bl[j] : o.bh[j];
+    if (F16)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b),
+                                                           acc[i][j], 0, 0, 0);
+    else
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                            acc[i][j], 0, 0, 0);
+}
+
+template <int NPROD, bool GEMM, bool F16>
+__global__ void __launch_bounds__(256, 1)
+rr_syrk_b16w4_kernel(const SyrkArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * B16_STAGE];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    int tdx = GEMM ? (int)blockIdx.x : (int)(blockIdx.x % p.ntiles);
+    const int ks = GEMM ? 0 : (int)(blockIdx.x / p.ntiles);
+    int ta = 0, tb = 0;
+    if (GEMM) {
+        ta = tdx / p.nb;
+        tb = tdx % p.nb;
+    } else {
+        if (p.tile_map) tdx = p.tile_map[tdx];
+        const int od = p.offdiag_only;
+        while (tdx >= p.nb - ta - od) {
+            tdx -= p.nb - ta - od;
+            ++ta;
+        }
+        tb = ta + tdx + od;
+    }
+    const int ca = ta * GR_TC, cb = tb * GR_TC;
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+    const int S = (int)((row_end - row_begin) / 16);  // k-steps, a multiple of 4
+
+    // DMA role: 32 instructions of 1 KiB per stage; wave w issues t = 8 w + k: waves 0-1 the A side, 2-3 the B side
+    const int side = wave >> 1;
+    const int tt0 = (wave & 1) * 8;
+    const unsigned lane_src = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+    const int64_t ld_side = (GEMM && side) ? p.ldp2 : p.ldp;
+    const char *src0 = (const char *)((GEMM && side) ? p.P2 : p.P) + ((row_begin / 16) * ld_side + (side ? cb : ca)) * 64 +
+                       tt0 * 1024 + lane_src;
+    const int64_t stage_stride = ld_side * 64;
+    char *dst0 = lds + side * 16384 + tt0 * 1024;
+
+    // consumer role: wave (wr, wc) -> columns [wr*128, +128) of side A, [wc*128, +128) of side B
+    const int wr = wave >> 1, wc_ = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
+    unsigned abase[2][2], bbase[2][2];  // [ring half][part]
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const unsigned xs = (unsigned)(((2 * pp + h) ^ ((l31 >> 2) & 3)) * 16);
+            abase[hf][pp] = lds0 + hf * 2 * B16_STAGE + (unsigned)((wr * 128 + l31) * 64) + xs;
+            bbase[hf][pp] = lds0 + hf * 2 * B16_STAGE + 16384u + (unsigned)((wc_ * 128 + l31) * 64) + xs;
+        }
+    floatx16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    constexpr int NM = NPROD * 16;
+    if (S > 0) {
+        auto dma_one = [&](int g, int buf, int k) {  // g is clamped: past the end the last k-step is fetched again
+            const char *src = src0 + (int64_t)(g < S ? g : S - 1) * stage_stride + k * 1024;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst0 + buf * B16_STAGE + k * 1024), 16, 0, 0);
+        };
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) dma_one(st, st, k);
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        B16Ops4 r0, r1;
+#define RR_W4_LOADALL(R, BUF)                                                                                    \
+    R.template load_one<BUF, 0>(abase, bbase); R.template load_one<BUF, 1>(abase, bbase);                         \
+    R.template load_one<BUF, 2>(abase, bbase); R.template load_one<BUF, 3>(abase, bbase);                         \
+    R.template load_one<BUF, 4>(abase, bbase); R.template load_one<BUF, 5>(abase, bbase);                         \
+    R.template load_one<BUF, 6>(abase, bbase); R.template load_one<BUF, 7>(abase, bbase);                         \
+    R.template load_one<BUF, 8>(abase, bbase); R.template load_one<BUF, 9>(abase, bbase);                         \
+    R.template load_one<BUF, 10>(abase, bbase); R.template load_one<BUF, 11>(abase, bbase);                       \
+    R.template load_one<BUF, 12>(abase, bbase); R.template load_one<BUF, 13>(abase, bbase);                       \
+    R.template load_one<BUF, 14>(abase, bbase); R.template load_one<BUF, 15>(abase, bbase);
+        RR_W4_LOADALL(r0, 0)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // MFMA Q, then one filler: DMA instruction Q of stage g+4 (Q < 8), operand read Q-8 of stage g+1 (8 <= Q < 24)
+#define RR_W4_M(Q, CUR, NXT, BUFN)                                                           \
+    if constexpr ((Q) < NM) {                                                                \
+        b16w4_mfma<(Q), F16>(CUR, acc);                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        if constexpr ((Q) < 8) dma_one(g + 4, QB, (Q));                                      \
+        else if constexpr ((Q) < 24) NXT.template load_one<BUFN, ((Q) - 8) & 15>(abase, bbase); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    }
+#define RR_W4_M8(Q, CUR, NXT, BUFN)                                                                          \
+    RR_W4_M((Q), CUR, NXT, BUFN) RR_W4_M((Q) + 1, CUR, NXT, BUFN) RR_W4_M((Q) + 2, CUR, NXT, BUFN)           \
+    RR_W4_M((Q) + 3, CUR, NXT, BUFN) RR_W4_M((Q) + 4, CUR, NXT, BUFN) RR_W4_M((Q) + 5, CUR, NXT, BUFN)       \
+    RR_W4_M((Q) + 6, CUR, NXT, BUFN) RR_W4_M((Q) + 7, CUR, NXT, BUFN)
+#define RR_W4_STEP(QQ, CUR, NXT)                                                             \
+    {                                                                                        \
+        const int g = g0 + (QQ);                                                             \
+        constexpr int QB = (QQ);                                                             \
+        constexpr int BUFN = ((QQ) + 1) & 3;                                                 \
+        __builtin_amdgcn_s_barrier();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        RR_W4_M8(0, CUR, NXT, BUFN) RR_W4_M8(8, CUR, NXT, BUFN) RR_W4_M8(16, CUR, NXT, BUFN) \
+        RR_W4_M8(24, CUR, NXT, BUFN) RR_W4_M8(32, CUR, NXT, BUFN) RR_W4_M8(40, CUR, NXT, BUFN) \
+        RR_W4_M8(48, CUR, NXT, BUFN) RR_W4_M8(56, CUR, NXT, BUFN)                            \
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");                         \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    }
+        for (int g0 = 0; g0 < S; g0 += 4) {
+            RR_W4_STEP(0, r0, r1)
+            RR_W4_STEP(1, r1, r0)
+            RR_W4_STEP(2, r0, r1)
+            RR_W4_STEP(3, r1, r0)
+        }
+#undef RR_W4_STEP
+#undef RR_W4_M8
+#undef RR_W4_M
+#undef RR_W4_LOADALL
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail DMAs must land before the LDS is released
+    }
+
+    const int64_t F = p.F;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t gc = cb + wc_ * 128 + j * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (GEMM)
+                    p.D[gr * p.ldd + gc] = acc[i][j][e];
+                else if (gr <= gc && gc < F)
+                    unsafeAtomicAdd(&p.G[gr * F + gc], (double)(F16 ? acc[i][j][e] * p.out_scale : acc[i][j][e]));
+            }
+        }
+    }
+}
+
 // D (M, N) f32 = A^T B with A (K, M), B (K, N) row-major f32 (K % 64 == 0, M, N % 256 == 0, all zero padded): both are
 // converted to the K-blocked split-bf16 layout into caller scratch (sa: K*lda*4 bytes, sb: K*ldb*4; sb_ready: B was
 // converted by an earlier call and is unchanged) and multiplied on the bf16 matrix pipe with nprod products.
@@ -1678,7 +1853,12 @@ int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, co
     a.F = (int)N; a.nb = (int)(N / 256); a.ntiles = (int)((M / 256) * (N / 256)); a.G = nullptr; a.tile_map = nullptr;
     a.offdiag_only = 0; a.ablate = 0; a.D = D; a.ldd = ldd;
     RR_REQUIRE((M / 256) * (N / 256) < (int64_t)1 << 31, "gemm: grid too large");
-    if (nprod == 4)
+    static const bool w4 = !(getenv("RR_B16_KERNEL") && !strcmp(getenv("RR_B16_KERNEL"), "w8"));
+    if (w4 && nprod == 4)
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
+    else if (w4)
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
+    else if (nprod == 4)
         hipLaunchKernelGGL((rr_syrk_bf16_kernel<4, true>), dim3((unsigned)a.ntiles), dim3(GR_THREADS), 0, c->stream, a);
     else
         hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, true>), dim3((unsigned)a.ntiles), dim3(GR_THREADS), 0, c->stream, a);
@@ -1742,7 +1922,17 @@ static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void 
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
-    if (f16_scale > 0.f) {
+    static const bool w4 = !(getenv("RR_B16_KERNEL") && !strcmp(getenv("RR_B16_KERNEL"), "w8"));  // w8: the 8-wave kernel
+    if (w4) {
+        const dim3 grid((unsigned)(nsplit * ntiles));
+        if (f16_scale > 0.f) {
+            a.out_scale = 1.f / (f16_scale * f16_scale);
+            hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, false, true>), grid, dim3(256), 0, c->stream, a);
+        } else if (nprod == 4)
+            hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, false, false>), grid, dim3(256), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, false, false>), grid, dim3(256), 0, c->stream, a);
+    } else if (f16_scale > 0.f) {
         a.out_scale = 1.f / (f16_scale * f16_scale);
         hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, false, true>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     } else if (nprod == 4)
