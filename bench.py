@@ -249,7 +249,7 @@ def main():
         alt = {"engine": "fp16x3", "value": args.rows / alt_elapsed, "unit": "feature-rows/s",
                "ms_per_step": 1e3 * alt_elapsed, "steps": nalt,
                "max_abs_diff_vs_f32_engine_over_max_G": float(np.abs(G3 - G).max() / np.abs(G).max()),
-               "kernel": "rr_syrk_bf16_kernel<3, false, true>",
+               "kernel": "rr_syrk_b16w4_kernel<3, false, true>",
                "kernel_ms_per_step": float(np.mean([k[1] + k[2] for k in alt_ms])),
                "features_ms_per_step": float(np.mean([k[0] for k in alt_ms])),
                "trace_rel_err": abs(float(np.trace(G3)) - args.rows) / args.rows,
@@ -314,7 +314,7 @@ def main():
             nbk = len(widths)
             alg = (off_flops + diag_flops) * my_rows / (k_ms * 1e-3) / 1e12
             issued = nprod * 2.0 * 65536 * (nbk * (nbk + 1) // 2) * my_rows / (k_ms * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "rr_syrk_bf16_kernel<%d>" % nprod, "achieved": alg,
+            out["roofline"] = {"bound": "mfma", "kernel": "rr_syrk_b16w4_kernel<%d, ...>" % nprod, "achieved": alg,
                                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg / PEAK_BF16_MFMA_TFLOPS,
                                "issued": issued, "issued_frac": issued / PEAK_BF16_MFMA_TFLOPS, "traffic": None,
                                "kernel_ms_per_step": k_ms, "launches_per_step": launches,
