@@ -12,7 +12,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
-// Output tag of the feature kernel: the K-blocked split-bf16 layout of rr_syrk_bf16_kernel (see there):
+// Output tag of the feature kernel: the K-blocked split-bf16 layout of rr_syrk_b16w4_kernel (see there):
 // Pb[kstep][column] = 64 B = granules [hi rows 0-7 | hi rows 8-15 | lo rows 0-7 | lo rows 8-15] of a 16-row k-step.
 struct rr_pb_t { uintx4 g[4]; };
 // The same layout with fp16 parts of the value scaled by a power of two into [-1, 1] (random Fourier features are
@@ -518,7 +518,7 @@ struct SyrkArgs {
     const int *tile_map;  // optional (ntiles): position in dispatch order -> tile id (XCD-aware), or null
     int offdiag_only;     // 1: enumerate only tiles with ta < tb (the diagonal ones go to the diag kernel)
     int ablate;  // debug (RR_GRAM_ABLATE): bit0 = no in-loop DMA, bit1 = no in-loop barrier
-    // GEMM mode of rr_syrk_bf16_kernel (D = A^T B over K-blocked operands): B side matrix, output
+    // GEMM mode of rr_syrk_b16w4_kernel (D = A^T B over K-blocked operands): B side matrix, output
     const float *P2 = nullptr;
     int64_t ldp2 = 0;
     float *D = nullptr;   // (M, ldd) f32, plain stores
@@ -1433,8 +1433,8 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
 // Split-bf16 SYRK ("bf16x3" / "bf16x4"): every f32 feature value p is split into hi = bf16(p) and
 // lo = bf16(p - hi) (|p - hi - lo| <= 2^-18 |p|) and G accumulates hi.hi + hi.lo + lo.hi (+ lo.lo for x4) in f32 on
 // the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, 16x the f32 MFMA rate).  x3 drops lo.lo (<= 2^-18 |p_a p_b|,
-// same sign on the diagonal: a ~1e-6 relative bias there); x4 keeps it.  Same workgroup shape as
-// rr_syrk_f32_kernel: 256x256 block of G, 8 waves of 128x64, f64 atomics across K-splits.
+// same sign on the diagonal: a ~1e-6 relative bias there); x4 keeps it; fp16x3 (rr_pf_t) uses fp16 parts of values
+// scaled into [-1, 1].  One workgroup owns a 256x256 block of G for one K-split, f64 atomics across K-splits.
 //
 // Operands need 8 consecutive k (rows) of one column per lane, so the features are laid out K-blocked:
 // Pb[kb][c] = 64 B = four 16-B granules [hi rows 0-7 | hi rows 8-15 | lo rows 0-7 | lo rows 8-15] of the 16
@@ -1442,9 +1442,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
 // of one k-step is 16 KiB contiguous.  One k-step (16 rows, [A side | B side] = 32 KiB) is one stage of a
 // 4-stage LDS ring filled by LDS-DMA three k-steps ahead of its use; in LDS the four granules of a column are
 // XOR-swizzled with (c >> 2) & 3 -- the DMA is lane-linear in LDS and applies the permutation on its global
-// addresses -- which makes every ds_read_b128 operand fetch conflict-free.  Per k-step a wave issues its 4
-// DMA instructions, the 12 operand reads of the NEXT k-step (second register set) and 24 (32) MFMAs; one
-// barrier per k-step.
+// addresses -- which makes every ds_read_b128 operand fetch conflict-free.  One barrier per k-step.
 // ---------------------------------------------------------------------------------------
 constexpr int B16_STAGE = 32768;  // bytes per ring stage: [A side 16 KiB | B side 16 KiB]
 
@@ -1482,193 +1480,13 @@ __device__ __forceinline__ uintx4 lds_read_b128(unsigned addr) {
     return r;
 }
 
-// operands of one k-step: hi / lo parts of 4 A blocks and 2 B blocks
-struct B16Ops {
-    uintx4 ah[4], al[4], bh[2], bl[2];
-    // BUF: ring stage 0..3; base addresses are for stages 0-1 (lo) / 2-3 (hi16 = + 65536): ds offsets are 16 bit
-    template <int BUF>
-    __device__ __forceinline__ void load_a(const unsigned (&a)[2][2]) {
-        constexpr int O = (BUF & 1) * B16_STAGE;
-        const unsigned a0 = a[BUF >> 1][0], a1 = a[BUF >> 1][1];
-        ah[0] = lds_read_b128<O>(a0);
-        al[0] = lds_read_b128<O>(a1);
-        ah[1] = lds_read_b128<O + 2048>(a0);
-        al[1] = lds_read_b128<O + 2048>(a1);
-        ah[2] = lds_read_b128<O + 4096>(a0);
-        al[2] = lds_read_b128<O + 4096>(a1);
-        ah[3] = lds_read_b128<O + 6144>(a0);
-        al[3] = lds_read_b128<O + 6144>(a1);
-    }
-    template <int BUF>
-    __device__ __forceinline__ void load_b(const unsigned (&b)[2][2]) {
-        constexpr int O = (BUF & 1) * B16_STAGE;
-        const unsigned b0 = b[BUF >> 1][0], b1 = b[BUF >> 1][1];
-        bh[0] = lds_read_b128<O>(b0);
-        bl[0] = lds_read_b128<O>(b1);
-        bh[1] = lds_read_b128<O + 2048>(b0);
-        bl[1] = lds_read_b128<O + 2048>(b1);
-    }
-};
-
-// MFMAs [FIRST, LAST) of a k-step in (product, i, j) order: product 0 hi.hi, 1 hi.lo, 2 lo.hi, 3 lo.lo
-template <int FIRST, int LAST, bool F16 = false>
-__device__ __forceinline__ void b16_mfma(const B16Ops &o, floatx16 (&acc)[4][2]) {
-#pragma unroll
-    for (int q = FIRST; q < LAST; ++q) {
-        const int pr = q >> 3, i = (q >> 1) & 3, j = q & 1;
-        const uintx4 a = (pr & 2) ? o.al[i] : o.ah[i];
-        const uintx4 b = (pr & 1) ? o.bl[j] : o.bh[j];
-        if (F16)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(halfx8, a), __builtin_bit_cast(halfx8, b),
-                                                               acc[i][j], 0, 0, 0);
-        else
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                                acc[i][j], 0, 0, 0);
-    }
-}
-
-// GEMM = true: D (M, N) = A^T B for two K-blocked operands (A = p.P with ldp = M columns, B = p.P2 with ldp2 = N columns,
-// K = p.rows, no K-split): block -> (M tile ta, N tile tb) = (blockIdx / nb, blockIdx % nb), f32 stores.  Used for
-// U = Phi C of the second _elbo pass (rr_elbo.hip).
-template <int NPROD, bool GEMM, bool F16 = false>
-__global__ void __launch_bounds__(GR_THREADS, 2)
-rr_syrk_bf16_kernel(const SyrkArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * B16_STAGE];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    int tdx = GEMM ? (int)blockIdx.x : (int)(blockIdx.x % p.ntiles);
-    const int ks = GEMM ? 0 : (int)(blockIdx.x / p.ntiles);
-    int ta = 0, tb = 0;
-    if (GEMM) {
-        ta = tdx / p.nb;
-        tb = tdx % p.nb;
-    } else {
-        if (p.tile_map) tdx = p.tile_map[tdx];
-        const int od = p.offdiag_only;
-        while (tdx >= p.nb - ta - od) {
-            tdx -= p.nb - ta - od;
-            ++ta;
-        }
-        tb = ta + tdx + od;
-    }
-    const int ca = ta * GR_TC, cb = tb * GR_TC;
-    const int64_t row_begin = (int64_t)ks * p.rows_per_split;  // multiples of 64
-    int64_t row_end = row_begin + p.rows_per_split;
-    if (row_end > p.rows) row_end = p.rows;
-    const int S = (int)((row_end - row_begin) / 16);  // k-steps, a multiple of 4
-
-    // ---- DMA role: 32 instructions of 1 KiB (16 columns) per stage; wave w issues t = 4 w + k: waves 0-3 the A side,
-    // 4-7 the B side.  Lane L fills granule t*64 + L = column 16 t' + (L >> 2), slot L & 3.
-    const int side = wave >> 2;
-    const int tt0 = (wave & 3) * 4;
-    const unsigned lane_src = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
-    const int64_t ld_side = (GEMM && side) ? p.ldp2 : p.ldp;
-    const char *src0 = (const char *)((GEMM && side) ? p.P2 : p.P) + ((row_begin / 16) * ld_side + (side ? cb : ca)) * 64 +
-                       tt0 * 1024 + lane_src;
-    const int64_t stage_stride = ld_side * 64;
-    char *dst0 = lds + side * 16384 + tt0 * 1024;
-    auto dma = [&](int g, int buf) {
-        const char *src = src0 + (int64_t)((p.ablate & 8) ? (g & 7) : g) * stage_stride;
-        char *dst = dst0 + buf * B16_STAGE;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + k * 1024), (lptr_t)(dst + k * 1024), 16, 0, 0);
-    };
-
-    // ---- consumer role: wave (wr, wc) -> columns [wr*128, +128) of side A (4 blocks), [wc*64, +64) of side B (2)
-    const int wr = wave >> 2, wc_ = wave & 3;
-    const int l31 = lane & 31, h = lane >> 5;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char *)lds;
-    unsigned abase[2][2], bbase[2][2];  // [ring half][part]
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-        for (int pp = 0; pp < 2; ++pp) {
-            const unsigned xs = (unsigned)(((2 * pp + h) ^ ((l31 >> 2) & 3)) * 16);
-            abase[hf][pp] = lds0 + hf * 2 * B16_STAGE + (unsigned)((wr * 128 + l31) * 64) + xs;
-            bbase[hf][pp] = lds0 + hf * 2 * B16_STAGE + 16384u + (unsigned)((wc_ * 64 + l31) * 64) + xs;
-        }
-    floatx16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    constexpr int NM = NPROD * 8;
-    if (S > 0) {
-        // prologue: stages 0..3 in flight, 0 and 1 landed, stage 0 in registers
-        dma(0, 0);
-        dma(1, 1);
-        dma(2, 2);
-        dma(3, 3);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        B16Ops r0, r1;
-        r0.load_b<0>(bbase);
-        r0.load_a<0>(abase);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        // One k-step: [barrier: stage g+1 landed for everyone, stage g fully in registers everywhere -> its buffer is
-        // free] [first MFMAs] [DMA of stage g+4 into the freed buffer] [MFMAs] [reads of stage g+1] [MFMAs] [waits].
-#define RR_B16_STEP(Q, CUR, NXT)                                                        \
-    {                                                                                   \
-        const int g = g0 + (Q);                                                         \
-        if (!(p.ablate & 2)) __builtin_amdgcn_s_barrier();                              \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<0, 2, F16>(CUR, acc);                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        if (g + 4 < S && !(p.ablate & 1)) dma(g + 4, (Q));                              \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<2, 4, F16>(CUR, acc);                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        if (g + 1 < S && !(p.ablate & 4)) NXT.template load_b<((Q) + 1) & 3>(bbase);    \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<4, 6, F16>(CUR, acc);                                                       \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        if (g + 1 < S && !(p.ablate & 4)) NXT.template load_a<((Q) + 1) & 3>(abase);    \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        b16_mfma<6, NM, F16>(CUR, acc);                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-        if (g + 4 < S && !(p.ablate & 1)) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); \
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                \
-        __builtin_amdgcn_sched_barrier(0);                                              \
-    }
-        for (int g0 = 0; g0 < S; g0 += 4) {
-            RR_B16_STEP(0, r0, r1)
-            RR_B16_STEP(1, r1, r0)
-            RR_B16_STEP(2, r0, r1)
-            RR_B16_STEP(3, r1, r0)
-        }
-#undef RR_B16_STEP
-    }
-
-    const int64_t F = p.F;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int64_t gc = cb + wc_ * 64 + j * 32 + l31;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (GEMM)
-                    p.D[gr * p.ldd + gc] = acc[i][j][e];
-                else if (gr <= gc && gc < F)
-                    unsafeAtomicAdd(&p.G[gr * F + gc], (double)(F16 ? acc[i][j][e] * p.out_scale : acc[i][j][e]));
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------
-// The same computation with ONE wave per SIMD (4 waves of 128x128, 256 accumulator registers each): a wave's
-// non-MFMA work -- 8 DMA instructions and 16 operand reads per k-step -- is placed one instruction at a time into the
-// shadows of its own 48 (64) MFMAs (a 32x32x16 MFMA occupies the pipe for 32 cycles = ~5 issue slots), so the matrix
-// pipe never waits for a partner wave that is at the same barrier anyway.  Per MFMA 1/3 fewer operand reads than the
-// 128x64 waves.  The k loop is branch-free: past the end of a K-split the DMA re-fetches the last k-step into a free
+// ONE wave per SIMD (4 waves of 128x128, 256 accumulator registers each in AGPRs): a wave's non-MFMA work -- 8 DMA
+// instructions and the 16 operand reads of the NEXT k-step (second register set) -- is placed one instruction at a
+// time into the shadows of its own 48 (64) MFMAs (a 32x32x16 MFMA occupies the pipe for 32 cycles = ~5 issue slots).
+// An earlier version with 8 waves of 128x64 (two per SIMD, as in the f32 kernel) left the pipe 26 % idle: both waves
+// of a SIMD sit at the same barrier, so neither covers the other's DMA issue and reads; it also needed 1/3 more
+// operand reads per MFMA.  The k loop is branch-free: past the end of a K-split the DMA re-fetches the last k-step into a free
 // buffer and the reads fetch operands that are never used.
 // ---------------------------------------------------------------------------------------
 struct B16Ops4 {
@@ -1769,6 +1587,18 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
             for (int k = 0; k < 8; ++k) dma_one(st, st, k);
         asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (!GEMM && ta == tb && wr == 1 && wc_ == 0) {
+            // diagonal tile: this wave's 128x128 block lies below the diagonal.  It keeps its DMA duty and the
+            // barriers but issues no reads and no MFMAs (the kernel is power-limited: an idle SIMD is not wasted).
+            for (int g = 0; g < S; ++g) {
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) dma_one(g + 4, g & 3, k);
+                asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
         B16Ops4 r0, r1;
 #define RR_W4_LOADALL(R, BUF)                                                                                    \
     R.template load_one<BUF, 0>(abase, bbase); R.template load_one<BUF, 1>(abase, bbase);                         \
@@ -1853,15 +1683,10 @@ int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, co
     a.F = (int)N; a.nb = (int)(N / 256); a.ntiles = (int)((M / 256) * (N / 256)); a.G = nullptr; a.tile_map = nullptr;
     a.offdiag_only = 0; a.ablate = 0; a.D = D; a.ldd = ldd;
     RR_REQUIRE((M / 256) * (N / 256) < (int64_t)1 << 31, "gemm: grid too large");
-    static const bool w4 = !(getenv("RR_B16_KERNEL") && !strcmp(getenv("RR_B16_KERNEL"), "w8"));
-    if (w4 && nprod == 4)
+    if (nprod == 4)
         hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
-    else if (w4)
-        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
-    else if (nprod == 4)
-        hipLaunchKernelGGL((rr_syrk_bf16_kernel<4, true>), dim3((unsigned)a.ntiles), dim3(GR_THREADS), 0, c->stream, a);
     else
-        hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, true>), dim3((unsigned)a.ntiles), dim3(GR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1922,23 +1747,14 @@ static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void 
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
-    static const bool w4 = !(getenv("RR_B16_KERNEL") && !strcmp(getenv("RR_B16_KERNEL"), "w8"));  // w8: the 8-wave kernel
-    if (w4) {
-        const dim3 grid((unsigned)(nsplit * ntiles));
-        if (f16_scale > 0.f) {
-            a.out_scale = 1.f / (f16_scale * f16_scale);
-            hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, false, true>), grid, dim3(256), 0, c->stream, a);
-        } else if (nprod == 4)
-            hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, false, false>), grid, dim3(256), 0, c->stream, a);
-        else
-            hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, false, false>), grid, dim3(256), 0, c->stream, a);
-    } else if (f16_scale > 0.f) {
+    const dim3 grid((unsigned)(nsplit * ntiles));
+    if (f16_scale > 0.f) {
         a.out_scale = 1.f / (f16_scale * f16_scale);
-        hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, false, true>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, false, true>), grid, dim3(256), 0, c->stream, a);
     } else if (nprod == 4)
-        hipLaunchKernelGGL((rr_syrk_bf16_kernel<4, false>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, false, false>), grid, dim3(256), 0, c->stream, a);
     else
-        hipLaunchKernelGGL((rr_syrk_bf16_kernel<3, false>), dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, false, false>), grid, dim3(256), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -2085,7 +1901,7 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 3], c->stream));
         b->events_used = e0 + 4;
     }
-    b->gram_kernel = !F32 ? "rr_syrk_f64_kernel" : c->gram_engine == 0 ? "rr_syrk_f32_kernel" : "rr_syrk_bf16_kernel";
+    b->gram_kernel = !F32 ? "rr_syrk_f64_kernel" : c->gram_engine == 0 ? "rr_syrk_f32_kernel" : "rr_syrk_b16w4_kernel";
     return RR_OK;
 }
 
