@@ -89,6 +89,12 @@ def main():
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational bf16x3 measurement")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line (the JSON).  RCCL writes its version banner and warnings to file descriptor 1
+    # from its own threads, so fd 1 is pointed at stderr for the whole run and the JSON goes to a private duplicate.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -328,7 +334,8 @@ def main():
             out["split_fp16_engine"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
-        print(json.dumps(out))
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
     if use_dist:
         dist.destroy_process_group()
     assert trace_err < (1e-6 if engine == "f32" else 1e-5) or os.environ.get("RR_GRAM_ABLATE"), trace_err
