@@ -92,6 +92,8 @@ void rr_ctx_destroy(rr_ctx *ctx) {
     }
     if (ctx->tile_map) (void)hipFree(ctx->tile_map);
     if (ctx->pb) (void)hipFree(ctx->pb);
+    if (ctx->gsa) (void)hipFree(ctx->gsa);
+    if (ctx->gsb) (void)hipFree(ctx->gsb);
     rr_posdef_scratch_free(ctx->posdef);
     for (int i = 0; i < 2; ++i) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);

@@ -1385,6 +1385,31 @@ static int glm_step_checks(rr_featmat *fm, const void *dy, const void *drowarg, 
     return RR_OK;
 }
 
+// The GLM step's GEMMs: f32 MFMA, or -- with a split Gram engine selected -- bf16 hi + lo operands on the 16-bit matrix
+// pipe (rr_launch_gemm_tn_bf16; both operands are converted per call into context scratch).  The Monte-Carlo noise of
+// the step (L samples) is orders of magnitude above either arithmetic's error.
+static int glm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd, int64_t K,
+                    int64_t M, int64_t N) {
+    if (c->gram_engine == 0 || (K % 64) != 0) return fm_gemm(c, A, lda, B, ldb, D, ldd, K, M, N);
+    const size_t na = (size_t)K * lda * 4, nb = (size_t)K * ldb * 4;
+    if (c->gsa_bytes < na || c->gsb_bytes < nb) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (c->gsa_bytes < na) {
+            if (c->gsa) (void)hipFree(c->gsa);
+            c->gsa = nullptr; c->gsa_bytes = 0;
+            RR_CHECK_HIP(hipMalloc(&c->gsa, na));
+            c->gsa_bytes = na;
+        }
+        if (c->gsb_bytes < nb) {
+            if (c->gsb) (void)hipFree(c->gsb);
+            c->gsb = nullptr; c->gsb_bytes = 0;
+            RR_CHECK_HIP(hipMalloc(&c->gsb, nb));
+            c->gsb_bytes = nb;
+        }
+    }
+    return rr_launch_gemm_tn_bf16(c, c->gram_engine, A, lda, B, ldb, D, ldd, K, M, N, c->gsa, c->gsb, false);
+}
+
 // With WSs (kl_ld, Fp) = ws / (K L) on the device: fs, likelihood derivatives and sums, Ed = dfs Phi, EdPhi.
 static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *drowarg, int dtype, int lik,
                         double lik_param, int K, int L) {
@@ -1399,7 +1424,7 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     // Pt = P^T;  FSt (rows256, kl) = P WS^T
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
                        fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
-    int rc = fm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+    int rc = glm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
     if (rc != RR_OK) return rc;
     // dfs in place + per-component reductions
     if (dtype == RR_F32)
@@ -1408,12 +1433,12 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
     RR_CHECK_HIP(hipGetLastError());
     // Ed (kl, Fp) = dfs Phi
-    rc = fm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
+    rc = glm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
     if (rc != RR_OK) return rc;
     // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
                        s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
-    rc = fm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
+    rc = glm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
     if (rc != RR_OK) return rc;
     s.have_edphi = true;
     return RR_OK;

@@ -21,6 +21,8 @@ struct rr_ctx {
     int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
     int tile_map_nb = 0;
     int gram_engine = 0;      // f32 Gram: 0 = f32 MFMA, 3 / 4 = split-bf16 with 3 / 4 products (rr_set_gram_engine)
+    void *gsa = nullptr, *gsb = nullptr;  // K-blocked operand copies of the GLM step's GEMMs on the split engines, grow-only
+    size_t gsa_bytes = 0, gsb_bytes = 0;
     void *pb = nullptr;       // split-bf16 copy of the feature chunk (rr_syrk_bf16x3_kernel), grow-only
     size_t pb_bytes = 0;
     void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): rocBLAS handle + small device vectors

@@ -1523,8 +1523,8 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
-    int tdx = GEMM ? (int)blockIdx.x : (int)(blockIdx.x % p.ntiles);
-    const int ks = GEMM ? 0 : (int)(blockIdx.x / p.ntiles);
+    int tdx = (int)(blockIdx.x % p.ntiles);
+    const int ks = (int)(blockIdx.x / p.ntiles);  // GEMM: K-split too when there are few tiles (f32 atomics into D)
     int ta = 0, tb = 0;
     if (GEMM) {
         ta = tdx / p.nb;
@@ -1659,9 +1659,12 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (GEMM)
-                    p.D[gr * p.ldd + gc] = acc[i][j][e];
-                else if (gr <= gc && gc < F)
+                if (GEMM) {
+                    if (p.offdiag_only)  // GEMM mode reuses this field: 1 = several K-splits accumulate into a zeroed D
+                        unsafeAtomicAdd(&p.D[gr * p.ldd + gc], acc[i][j][e]);
+                    else
+                        p.D[gr * p.ldd + gc] = acc[i][j][e];
+                } else if (gr <= gc && gc < F)
                     unsafeAtomicAdd(&p.G[gr * F + gc], (double)(F16 ? acc[i][j][e] * p.out_scale : acc[i][j][e]));
             }
         }
@@ -1682,11 +1685,23 @@ int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, co
     a.P = (const float *)sa; a.ldp = lda; a.P2 = (const float *)sb; a.ldp2 = ldb; a.rows = K; a.rows_per_split = K;
     a.F = (int)N; a.nb = (int)(N / 256); a.ntiles = (int)((M / 256) * (N / 256)); a.G = nullptr; a.tile_map = nullptr;
     a.offdiag_only = 0; a.ablate = 0; a.D = D; a.ldd = ldd;
-    RR_REQUIRE((M / 256) * (N / 256) < (int64_t)1 << 31, "gemm: grid too large");
+    RR_REQUIRE((M / 256) * (N / 256) < (int64_t)1 << 24, "gemm: grid too large");
+    int64_t nsplit = 1;
+    if (a.ntiles < 2 * c->num_cu && K >= 2048) {  // too few tiles to fill the chip: split K (>= 512 rows each), f32 atomics
+        nsplit = (2 * (int64_t)c->num_cu + a.ntiles - 1) / a.ntiles;
+        if (nsplit > K / 512) nsplit = K / 512;
+        a.rows_per_split = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;
+        nsplit = (K + a.rows_per_split - 1) / a.rows_per_split;
+        if (nsplit > 1) {
+            a.offdiag_only = 1;
+            RR_CHECK_HIP(hipMemsetAsync(D, 0, (size_t)M * ldd * sizeof(float), c->stream));
+        }
+    }
+    const dim3 grid((unsigned)(a.ntiles * nsplit));
     if (nprod == 4)
-        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<4, true, false>), grid, dim3(256), 0, c->stream, a);
     else
-        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, true, false>), dim3((unsigned)a.ntiles), dim3(256), 0, c->stream, a);
+        hipLaunchKernelGGL((rr_syrk_b16w4_kernel<3, true, false>), grid, dim3(256), 0, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -211,3 +211,14 @@ def test_concat_second_pass_and_predict_on_the_engine(engine, chunk_rows):
     Gram and U = Phi C on the split-bf16 engine."""
     from test_gpu_slm import test_concat_second_pass_and_predict_vs_oracle as concat_case
     concat_case(chunk_rows)
+
+
+def test_glm_step_on_the_engine(engine, golden):
+    """With a split engine selected the three GEMMs of the SVI step (fs = ws Phi^T, dfs Phi with a K-split over the
+    rows, dfs^T ws) run on the 16-bit matrix pipe: the reference's golden minibatch ELBO / gradients, the concatenated
+    case and the config-5-sized additivity check at their usual tolerances."""
+    import test_gpu_glm as tg
+    for tag, lik in tg.CASES:
+        tg.test_minibatch_elbo_vs_reference(golden, tag, lik)
+    tg.test_minibatch_elbo_concat_and_generic_children_vs_oracle()
+    tg.test_config5_full_minibatch_is_additive_over_rows()
