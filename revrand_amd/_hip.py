@@ -6,6 +6,7 @@ library or a gfx950 device is missing, the calls raise.
 A device context is created lazily, once per *process* (sklearn may fork workers, SURVEY
 8b), and is never pickled.
 """
+import contextlib
 import ctypes
 import os
 import sys
@@ -428,6 +429,21 @@ def get_device(index=None):
         dev = Device(index)
         _devices[key] = dev
     return dev
+
+
+@contextlib.contextmanager
+def gram_engine_scope(name, index=None):
+    """Select the arithmetic of the f32 Gram / U = Phi C / GLM GEMMs (Device.set_gram_engine) for a block; None = leave
+    the context's setting (RR_SYRK_ENGINE or an earlier set_gram_engine) alone."""
+    if name is None:
+        yield
+        return
+    dev = get_device(index)
+    prev = dev.set_gram_engine(name)
+    try:
+        yield
+    finally:
+        dev.set_gram_engine(prev)
 
 
 def device_available():

@@ -28,6 +28,7 @@ from sklearn.base import BaseEstimator, RegressorMixin
 from sklearn.utils import check_random_state
 from sklearn.utils.validation import check_array, check_is_fitted, check_X_y
 
+from . import _hip
 from .basis_functions import LinearBasis, MinibatchFeatures
 from .btypes import Bound, Parameter, Positive
 from .likelihoods import Gaussian
@@ -58,7 +59,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         2 D K + O(d) numbers) and every rank applies the same update."""
 
     def __init__(self, likelihood=Gaussian(), basis=LinearBasis(), K=10, maxiter=3000, batch_size=10, updater=None,
-                 nsamples=50, nstarts=500, random_state=None, sampler="host", distributed=False):
+                 nsamples=50, nstarts=500, random_state=None, sampler="host", distributed=False, gram_engine=None):
         self.likelihood = likelihood
         self.basis = basis
         self.K = K
@@ -70,10 +71,15 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         self.random_state = random_state
         self.sampler = sampler
         self.distributed = distributed
+        self.gram_engine = gram_engine  # arithmetic of the step's GEMMs (see StandardLinearModel); None = context setting
         self.random_ = check_random_state(self.random_state)
 
     def fit(self, X, y, likelihood_args=()):
         """Learn the posterior mixture and the hyper-parameters (glm.py:141-203)."""
+        with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+            return self._fit(X, y, likelihood_args)
+
+    def _fit(self, X, y, likelihood_args=()):
         X, y = check_X_y(X, y)
         self._dev_seed = None  # the device sampler is re-keyed from random_ per fit
         N, _ = X.shape

@@ -222,3 +222,39 @@ def test_glm_step_on_the_engine(engine, golden):
         tg.test_minibatch_elbo_vs_reference(golden, tag, lik)
     tg.test_minibatch_elbo_concat_and_generic_children_vs_oracle()
     tg.test_config5_full_minibatch_is_additive_over_rows()
+
+
+def test_estimator_keyword_selects_the_engine_for_fit_and_predict():
+    """`gram_engine=` on the estimators scopes the setting to fit / predict_moments and survives sklearn's clone."""
+    from sklearn.base import clone
+    bs, Parameter, Positive, _hip = _imports()
+    from revrand_amd import StandardLinearModel, GeneralizedLinearModel
+    import revrand_amd.likelihoods as lk
+    dev = _hip.get_device()
+    assert dev.gram_engine == "f32"
+    rs = np.random.RandomState(0)
+    X = rs.randn(4000, 3)
+    y = np.sin(X[:, 0]) + 0.1 * rs.randn(4000)
+    seen = []
+    orig = bs.DeviceFitState.gram_device
+
+    def spy(self, *a, **k):
+        seen.append(dev.gram_engine)
+        return orig(self, *a, **k)
+    bs.DeviceFitState.gram_device = spy
+    try:
+        slm = StandardLinearModel(bs.RandomRBF(nbases=150, Xdim=3, random_state=1), maxiter=15, nstarts=0,
+                                  gram_engine="fp16x3")
+        assert clone(slm).get_params()["gram_engine"] == "fp16x3"
+        slm.fit(X, y)
+    finally:
+        bs.DeviceFitState.gram_device = orig
+    assert seen and set(seen) == {"fp16x3"} and dev.gram_engine == "f32"
+    Ey, Vy = slm.predict_moments(X[:500])
+    assert ((y[:500] - Ey) ** 2).mean() / y[:500].var() < 0.1 and dev.gram_engine == "f32"
+    glm = GeneralizedLinearModel(lk.Gaussian(), bs.RandomRBF(nbases=50, Xdim=3, random_state=1), maxiter=40, batch_size=500,
+                                 nstarts=0, random_state=1, gram_engine="bf16x3")
+    glm.fit(X, y)
+    assert dev.gram_engine == "f32" and np.isfinite(glm.predict(X[:50])).all()
+    with pytest.raises(ValueError):
+        StandardLinearModel(bs.RandomRBF(nbases=10, Xdim=3), gram_engine="int4").fit(X, y)
