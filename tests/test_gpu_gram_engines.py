@@ -258,3 +258,34 @@ def test_estimator_keyword_selects_the_engine_for_fit_and_predict():
     assert dev.gram_engine == "f32" and np.isfinite(glm.predict(X[:50])).all()
     with pytest.raises(ValueError):
         StandardLinearModel(bs.RandomRBF(nbases=10, Xdim=3), gram_engine="int4").fit(X, y)
+
+
+def test_random_shapes_agree_with_the_f32_engine():
+    """40 random (N, d, n): ragged rows (pad rows of the K-blocked layout), partial column blocks, d = 1..128, with and
+    without y -- each split engine against the f32 MFMA engine on the same input."""
+    bs, Parameter, Positive, _hip = _imports()
+    dev = _hip.get_device()
+    rs = np.random.RandomState(123)
+    # worst case per product (nothing averages at N = 1): bf16x3 3 * 2^-18, bf16x4 2 * 2^-18, fp16x3 ~2^-21, plus the
+    # f32 engine's own rounding
+    tol = {"fp16x3": 3e-6, "bf16x3": 2.5e-5, "bf16x4": 1.5e-5}
+    try:
+        for it in range(40):
+            N = int(rs.choice([1, 31, 63, 64, 65, 257, 1000, 4097, 9000]))
+            d = int(rs.choice([1, 2, 7, 8, 9, 16, 31, 33, 64, 100, 128]))
+            n = int(rs.choice([1, 5, 16, 31, 32, 33, 100, 128, 129, 300]))
+            X = rs.randn(N, d).astype(np.float32 if it % 2 else np.float64)
+            y = rs.randn(N) if it % 3 else None
+            b = bs.RandomMatern52(nbases=n, Xdim=d, random_state=it)
+            dev.set_gram_engine("f32")
+            Gf, bf, _ = b.gram(X, y, 1.1)
+            for eng in ("fp16x3", "bf16x3", "bf16x4"):
+                dev.set_gram_engine(eng)
+                G, bv, _ = b.gram(X, y, 1.1)
+                assert np.array_equal(G, G.T)
+                assert normwise(G, Gf) < tol[eng], (eng, N, d, n, normwise(G, Gf))
+                assert (bv is None) == (y is None)
+                if y is not None:
+                    assert normwise(bv, bf) < 1e-5, (eng, N, d, n)
+    finally:
+        dev.set_gram_engine("f32")
