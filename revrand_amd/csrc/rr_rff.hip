@@ -1451,10 +1451,10 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-// grid (ldp / 256, rows64 / 16), 256 threads: thread = column, 16 rows of it in registers; rows >= `rows` -> 0
+// grid (rows64 / 16, ldp / 256), 256 threads: thread = column, 16 rows of it in registers; rows >= `rows` -> 0
 __global__ void __launch_bounds__(256)
 rr_split_bf16_kernel(const float *__restrict__ P, int64_t rows, int64_t ldp, uintx4 *__restrict__ Pb) {
-    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x, kb = blockIdx.y;
+    const int64_t c = (int64_t)blockIdx.y * 256 + threadIdx.x, kb = blockIdx.x;  // k-steps on x: rows / 16 can exceed 65535
     const float *src = P + kb * 16 * ldp + c;
     const bool live = kb * 16 < rows;  // rows is a multiple of 32
     unsigned hi[8], lo[8];
@@ -1676,10 +1676,10 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
 // converted by an earlier call and is unchanged) and multiplied on the bf16 matrix pipe with nprod products.
 int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
                            int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready) {
-    hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(M / 256), (unsigned)(K / 16)), dim3(256), 0, c->stream, A, K, lda,
+    hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(K / 16), (unsigned)(M / 256)), dim3(256), 0, c->stream, A, K, lda,
                        (uintx4 *)sa);
     if (!sb_ready)
-        hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(N / 256), (unsigned)(K / 16)), dim3(256), 0, c->stream, B, K,
+        hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(K / 16), (unsigned)(N / 256)), dim3(256), 0, c->stream, B, K,
                            ldb, (uintx4 *)sb);
     SyrkArgs a;
     a.P = (const float *)sa; a.ldp = lda; a.P2 = (const float *)sb; a.ldp2 = ldb; a.rows = K; a.rows_per_split = K;
@@ -1737,7 +1737,7 @@ static int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void 
         c->pb_bytes = need;
     }
     if (!pb) {
-        hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(ldp / 256), (unsigned)(rows64 / 16)), dim3(256), 0, c->stream,
+        hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(rows64 / 16), (unsigned)(ldp / 256)), dim3(256), 0, c->stream,
                            P, rows, ldp, (uintx4 *)c->pb);
         pb = c->pb;
     }

@@ -289,3 +289,23 @@ def test_random_shapes_agree_with_the_f32_engine():
                     assert normwise(bv, bf) < 1e-5, (eng, N, d, n)
     finally:
         dev.set_gram_engine("f32")
+
+
+def test_conversion_path_beyond_65535_k_steps():
+    """1.1 M rows through the conversion kernel (Xdim > 128 -> f32 features -> K-blocked bf16): more 16-row k-steps than
+    a grid's y dimension holds."""
+    bs, Parameter, Positive, _hip = _imports()
+    dev = _hip.get_device()
+    N, d, n = 1_100_003, 130, 40
+    rng = np.random.default_rng(0)
+    X = (rng.standard_normal((N, d), dtype=np.float32) / 4).astype(np.float32)
+    y = rng.standard_normal(N, dtype=np.float32)
+    b = bs.RandomRBF(nbases=n, Xdim=d, random_state=3)
+    Gf, bf, _ = b.gram(X, y, 1.0)
+    prev = dev.set_gram_engine("bf16x3")
+    try:
+        G, bv, _ = b.gram(X, y, 1.0)
+    finally:
+        dev.set_gram_engine(prev)
+    assert normwise(G, Gf) < 1e-5 and normwise(bv, bf) < 1e-6
+    assert abs(np.trace(G) - N) < 1e-5 * N
