@@ -118,7 +118,7 @@ def test_slm_fit_on_256_dimensional_inputs():
     f = np.sin(X @ w) + 0.3 * (X @ w)
     y = f + 0.1 * rs.randn(N + 500)
     basis = bs.RandomRBF(nbases=256, Xdim=d, random_state=1, lenscale=Parameter(16.0, Positive())) + bs.LinearBasis(onescol=True)
-    slm = StandardLinearModel(basis, maxiter=60).fit(X[:N], y[:N])
+    slm = StandardLinearModel(basis, maxiter=60, random_state=0).fit(X[:N], y[:N])
     Ey = slm.predict(X[N:])
     smse = ((y[N:] - Ey) ** 2).mean() / y[N:].var()
     assert np.isfinite(Ey).all() and smse < 0.5, smse

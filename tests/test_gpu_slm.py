@@ -89,7 +89,7 @@ def test_fit_end_to_end_vs_reference(golden):
     basis = bs.RandomRBF(nbases=24, Xdim=3, random_state=31, lenscale=Parameter(1.2, Positive()),
                          regularizer=Parameter(1.5, Positive()))
     assert np.array_equal(basis.W, g["W"])
-    slm = SLM(basis, var=Parameter(0.5, Positive()), nstarts=0, maxiter=20).fit(X, y)
+    slm = SLM(basis, var=Parameter(0.5, Positive()), nstarts=0, maxiter=20, random_state=0).fit(X, y)
     Ey, Vy = slm.predict_moments(Xs)
     # L-BFGS trajectories are sensitive: compare at prediction level
     assert smse(g["Ey"], Ey) < 1e-3
@@ -404,7 +404,7 @@ def test_elbo_device_posterior_equals_host_posterior(monkeypatch):
         assert normwise(dev_r[4], host_r[4]) < 1e-5 and normwise(dev_r[5], host_r[5]) < 1e-5
     monkeypatch.setenv("RR_POSDEF", "device")
     basis = bs.RandomRBF(nbases=40, Xdim=d, random_state=3)
-    slm = SLM(basis, nstarts=0, maxiter=40)
+    slm = SLM(basis, nstarts=0, maxiter=40, random_state=0)
     best, orig = [], SLM._elbo_resident
 
     def recording(self, X_, y_, var, reg, hypers):   # parameters of the evaluation that set the best posterior
