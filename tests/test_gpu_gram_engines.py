@@ -243,8 +243,9 @@ def test_estimator_keyword_selects_the_engine_for_fit_and_predict():
         return orig(self, *a, **k)
     bs.DeviceFitState.gram_device = spy
     try:
-        slm = StandardLinearModel(bs.RandomRBF(nbases=150, Xdim=3, random_state=1), maxiter=15, nstarts=0,
-                                  gram_engine="fp16x3")
+        basis = bs.RandomRBF(nbases=150, Xdim=3, random_state=1, lenscale=Parameter(1.0, Positive()),
+                             regularizer=Parameter(1.0, Positive()))
+        slm = StandardLinearModel(basis, var=Parameter(0.5, Positive()), maxiter=30, nstarts=0, gram_engine="fp16x3")
         assert clone(slm).get_params()["gram_engine"] == "fp16x3"
         slm.fit(X, y)
     finally:
