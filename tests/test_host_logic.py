@@ -363,3 +363,17 @@ def test_poisson_log_factorial_table():
     rs = np.random.RandomState(1)
     for y in (rs.poisson(3.0, size=1000).astype(float), np.zeros(5), np.array([]), rs.rand(20) * 7, np.array([5000.0, 2.0])):
         assert abs(_sum_gammaln1p(y) - float(gammaln(y + 1).sum())) <= 1e-12 * max(1.0, abs(float(gammaln(y + 1).sum())))
+
+
+def test_gram_engine_keyword_is_a_plain_sklearn_parameter():
+    """No device needed: the keyword is stored verbatim, survives clone / get_params / set_params and pickling."""
+    import pickle
+    from sklearn.base import clone
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import StandardLinearModel, GeneralizedLinearModel
+    slm = StandardLinearModel(bs.LinearBasis(onescol=True), gram_engine="fp16x3")
+    assert slm.get_params()["gram_engine"] == "fp16x3" and clone(slm).gram_engine == "fp16x3"
+    assert StandardLinearModel().gram_engine is None
+    assert pickle.loads(pickle.dumps(slm)).gram_engine == "fp16x3"
+    glm = GeneralizedLinearModel(gram_engine="bf16x3")
+    assert clone(glm).set_params(gram_engine=None).gram_engine is None
