@@ -63,10 +63,19 @@ struct GemmArgs {
     int64_t lda, ldb, ldd;
     int K, ntb;  // ntb = N / 256 column tiles (fastest-varying in blockIdx)
     int kb_per_split = 0;  // > 0: blockIdx.y owns k-blocks [y * kb_per_split, ...) and ADDS into a zeroed D (f32 atomics)
+    // TRIG epilogue (random Fourier features of Xdim > 128, rr_rff.hip): the product is the phase matrix Z in
+    // revolutions; D is the feature matrix P: P[r][c] = cos(2 pi Z[r][c]) scale, P[r][n + c] = sin(..) scale for
+    // c < n, zero rows for nvalid <= r < nout, nothing beyond; bvec += P^T y.
+    int n = 0;
+    float scale = 0.f;
+    int64_t nvalid = 0, nout = 0;
+    const void *y = nullptr;
+    int y_f64 = 0;
+    double *bvec = nullptr;
 };
 
-__global__ void __launch_bounds__(GR_THREADS, 2)
-rr_gemm_tn_f32_kernel(const GemmArgs p) {
+template <bool TRIG>
+__device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
     __shared__ float lds[2 * GR_KB * GR_LD];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -115,22 +124,64 @@ rr_gemm_tn_f32_kernel(const GemmArgs p) {
     }
 
     const int hi = lane >> 5;
-    const bool atomic = p.kb_per_split > 0;  // wave-uniform
+    if constexpr (TRIG) {
+        float bc[2] = {0.f, 0.f}, bs[2] = {0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const bool valid = gr < p.nvalid;
+                float yv = 0.f;
+                if (p.y && valid) yv = p.y_f64 ? (float)((const double *)p.y)[gr] : ((const float *)p.y)[gr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int gc = cb + wc_ * 64 + j * 32 + (lane & 31);
+                    if (gc < p.n) {
+                        const float z = acc[i][j][e];
+                        const float fr = z - __builtin_rintf(z);
+                        const float cv = valid ? __builtin_amdgcn_cosf(fr) * p.scale : 0.f;
+                        const float sv = valid ? __builtin_amdgcn_sinf(fr) * p.scale : 0.f;
+                        if (gr < p.nout) {
+                            p.D[gr * p.ldd + gc] = cv;
+                            p.D[gr * p.ldd + p.n + gc] = sv;
+                        }
+                        bc[j] = fmaf(cv, yv, bc[j]);
+                        bs[j] = fmaf(sv, yv, bs[j]);
+                    }
+                }
+            }
+        if (p.y) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int gc = cb + wc_ * 64 + j * 32 + (lane & 31);
-                if (atomic)
-                    unsafeAtomicAdd(&p.D[gr * p.ldd + gc], acc[i][j][e]);
-                else
-                    p.D[gr * p.ldd + gc] = acc[i][j][e];
+                if (gc < p.n) {
+                    unsafeAtomicAdd(&p.bvec[gc], (double)bc[j]);
+                    unsafeAtomicAdd(&p.bvec[p.n + gc], (double)bs[j]);
+                }
             }
         }
+    } else {
+        const bool atomic = p.kb_per_split > 0;  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int gc = cb + wc_ * 64 + j * 32 + (lane & 31);
+                    if (atomic)
+                        unsafeAtomicAdd(&p.D[gr * p.ldd + gc], acc[i][j][e]);
+                    else
+                        p.D[gr * p.ldd + gc] = acc[i][j][e];
+                }
+            }
+    }
 }
+
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_tn_f32_kernel(const GemmArgs p) { rr_gemm_tn_f32_body<false>(p); }
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_trig_f32_kernel(const GemmArgs p) { rr_gemm_tn_f32_body<true>(p); }
 
 // ---------------------------------------------------------------------------------------------
 // Row reductions: one wave per row.
@@ -833,6 +884,19 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
 int rr_launch_gemm_tn_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd,
                           int64_t K, int64_t M, int64_t N) {  // D (M, N) = A^T B, A (K, M), B (K, N); M, N % 256 == 0, K % 32 == 0
     return fm_gemm(c, A, lda, B, ldb, D, ldd, K, M, N);
+}
+
+// The same product with the random Fourier feature epilogue (GemmArgs: TRIG): P (nout rows, ldp) <- cos / sin of the
+// phases A^T B, rows >= nvalid zero, bvec += P^T y (y: nvalid values, float or double; may be null).
+int rr_launch_gemm_trig_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int64_t M, int64_t N,
+                            float *P, int64_t ldp, int n, float scale, int64_t nvalid, int64_t nout, const void *y, int y_f64,
+                            double *bvec) {
+    GemmArgs g;
+    g.A = A; g.B = B; g.D = P; g.lda = lda; g.ldb = ldb; g.ldd = ldp; g.K = (int)K; g.ntb = (int)(N / 256);
+    g.n = n; g.scale = scale; g.nvalid = nvalid; g.nout = nout; g.y = y; g.y_f64 = y_f64; g.bvec = bvec;
+    hipLaunchKernelGGL(rr_gemm_trig_f32_kernel, dim3((unsigned)((M / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

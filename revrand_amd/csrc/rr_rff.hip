@@ -971,6 +971,9 @@ constexpr int64_t RR_LG_ROWS = 131072;
 
 int rr_launch_gemm_tn_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd,
                           int64_t K, int64_t M, int64_t N);  // rr_elbo.hip
+int rr_launch_gemm_trig_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, int64_t K, int64_t M, int64_t N,
+                            float *P, int64_t ldp, int n, float scale, int64_t nvalid, int64_t nout, const void *y, int y_f64,
+                            double *bvec);  // rr_elbo.hip: the same GEMM with the cos / sin / Phi^T y epilogue
 
 // Xt[c][r] = (float) X[r][c], c < dpad (grid.x = dpad / 64), r < rows256 (grid.y = rows256 / 64); rows >= `rows` -> 0
 template <typename TX>
@@ -1093,6 +1096,14 @@ static int large_features(rr_basis *b, const TX *X, const TX *y, int64_t m, int6
             if constexpr (F32) {
                 hipLaunchKernelGGL(rr_xt_kernel<TX>, dim3((unsigned)(b->dpad / 64), (unsigned)(r256 / 64)), dim3(256), 0,
                                    c->stream, Xs, rows_in, ldx, b->lg_xt, sub);
+                if constexpr (std::is_same<TO, float>::value) {
+                    // f32 features: cos / sin / Phi^T y in the GEMM's epilogue, the phase matrix never reaches HBM
+                    rc = rr_launch_gemm_trig_f32(c, b->lg_xt, sub, b->dWs32, b->npad, b->dpad, r256, b->npad, P + s0 * ldp, ldp,
+                                                 b->n, (float)scale, rows_in, rows_out, (y && db) ? (const void *)(y + s0) : nullptr,
+                                                 sizeof(TX) == 8, db);
+                    if (rc != RR_OK) return rc;
+                    continue;
+                }
                 rc = rr_launch_gemm_tn_f32(c, b->lg_xt, sub, b->dWs32, b->npad, (float *)Z, b->npad, b->dpad, r256, b->npad);
                 if (rc != RR_OK) return rc;
             } else {
