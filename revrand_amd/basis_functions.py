@@ -327,9 +327,12 @@ class DeviceFitState(_DevicePosterior):
     def second_pass(self, lenscale, m, C, var):
         sq, T = self.handle.elbo_pass2(self.dX, self.dy, lenscale, m, C)
         ls = np.atleast_1d(np.asarray(lenscale, dtype=float))
-        if ls.size == 1:  # the reference's isotropic gradient: input dimension 0 only
-            return sq, float((T[0] * self.W[0]).sum() / (var * ls[0] ** 2))
-        return sq, (T * self.W).sum(axis=1) / (var * ls ** 2)
+        # L-BFGS visits length scales up to the log-space bound (1e+100 and beyond): l^2 or T W may overflow to inf
+        # there, exactly as the reference's dPhi products do; the gradient is then 0 or inf, not a warning
+        with np.errstate(over="ignore", invalid="ignore"):
+            if ls.size == 1:  # the reference's isotropic gradient: input dimension 0 only
+                return sq, float((T[0] * self.W[0]).sum() / (var * ls[0] ** 2))
+            return sq, (T * self.W).sum(axis=1) / (var * ls ** 2)
 
     def release(self):
         self.dX.free()

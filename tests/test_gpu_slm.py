@@ -581,3 +581,70 @@ def test_gridsearch_in_worker_processes_like_reference_test_models():
     est = GridSearchCV(glm, {"batch_size": [10, 20]}, n_jobs=2, cv=3)
     est.fit(X, y)
     assert len(est.predict(Xs)) == len(ys)
+
+
+def _gloo_gpu_fit_worker(rank, world, port, q, n):
+    """One rank of a row-sharded fit with the REAL device state (both ranks share GPU 0, each with its own context);
+    gloo carries the two all-reduces of every `_elbo` on the host."""
+    import os
+    import torch.distributed as dist
+    from revrand_amd import parallel
+    bs, Parameter, Positive, SLM = _imports()
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(3)
+        N, d = 6001, 3
+        X = rs.randn(N, d)
+        y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.3 * rs.randn(N)
+        a, b = parallel.shard_bounds(N, rank, world)
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
+                             regularizer=Parameter(1.0, Positive()))
+        slm = SLM(basis, var=Parameter(0.1, Positive()), nstarts=0, maxiter=8, distributed=world > 1, random_state=0)
+        slm.obj_ = -np.inf
+        slm._state = slm._make_state(X[a:b], y[a:b])
+        assert slm._state is not None
+        ls = np.array([0.8, 1.1, 1.4])
+        f, (g_var, g_reg, g_hyp) = slm._elbo(X[a:b], y[a:b], 0.2, 1.3, ls)
+        ev = [float(f), float(g_var), float(g_reg)] + np.asarray(g_hyp).tolist() + slm.weights_[:8].tolist()
+        slm._state.release()
+        slm._state = None
+        slm.fit(X[a:b], y[a:b])
+        Ey = slm.predict(X[:50])
+        q.put((rank, ev, float(slm.var_), float(slm.regularizer_), np.asarray(slm.hypers_).tolist(), float(slm.obj_),
+               Ey.tolist()))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("n", [12, 160])
+def test_two_rank_gloo_fit_with_real_device_state(n):
+    """The distributed estimator with real kernels on both ranks (tests/test_dist_gloo.py runs the same protocol with a
+    NumPy stand-in on CPU): the ranks end bit-identical, and one sharded `_elbo` equals the single-process one to f32
+    accuracy.  n = 160 (F = 320) is above the device-posterior threshold, which a gloo group sends down the host route."""
+    import multiprocessing as pymp
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_gpu_fit_worker, args=(r, 2, port, q, n)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    q1 = pymp.Queue()
+    _gloo_gpu_fit_worker(0, 1, 0, q1, n)
+    single = q1.get(timeout=10)
+    assert res[0][1:] == res[1][1:]                       # identical statistics -> identical L-BFGS path on both ranks
+    assert np.allclose(res[0][1], single[1], rtol=2e-4, atol=2e-4 * np.abs(single[1]).max())
+    assert np.isfinite(res[0][5]) and np.isfinite(res[0][6]).all()
