@@ -300,3 +300,70 @@ def test_resident_minibatch_gather_equals_host_gather():
     # a basis that cannot stay resident (f64 arithmetic) declines, and nothing is kept
     c = MinibatchFeatures(bs.RandomRBF(nbases=8, Xdim=d, dtype="f64") + bs.LinearBasis())
     assert not c.make_resident(X)
+
+
+def _gloo_gpu_glm_worker(rank, world, port, q):
+    """One rank of the row-sharded SVI with the REAL device features (both ranks share GPU 0); gloo carries the one
+    all-reduce per step on the host.  Mirrors tests/test_dist_gloo.py::_glm_worker without its NumPy stand-in."""
+    import os
+    import torch.distributed as dist
+    from revrand_amd import parallel
+    from revrand_amd.optimize import Adam
+    bs, lk, Parameter, Positive, GLM = _imports()
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rs = np.random.RandomState(0)
+        N, d, n, K, L = 2400, 3, 40, 2, 6
+        X = rs.randn(N, d)
+        y = rs.poisson(np.exp(0.3 * np.sin(X[:, 0]))).astype(float)
+        a, b = parallel.shard_bounds(N, rank, world)
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
+                             regularizer=Parameter(1.5, Positive()))
+        glm = GLM(lk.Poisson(), basis, K=K, nsamples=L, batch_size=b - a, maxiter=6, nstarts=0, random_state=3,
+                  updater=Adam(alpha=0.05), distributed=world > 1)
+        glm.B_, glm.D_ = 1.0, 2 * n
+        glm._GeneralizedLinearModel__it = -1
+        m, C = 0.1 * rs.randn(2 * n, K), rs.gamma(2., 0.5, (2 * n, K))
+        f, (ndm, ndC, dL, dlp, dbp) = glm._elbo(m, C, 1.5, [], np.array([0.9, 1.1, 1.3]), X[a:b], y[a:b])
+        ev = [float(f), float(dL)] + ndm.ravel().tolist() + ndC.ravel().tolist() + np.asarray(dbp).tolist()
+        glm._release_features()
+        glm.random_ = np.random.RandomState(3)
+        glm.fit(X[a:b], y[a:b])
+        q.put((rank, ev, glm.weights_.ravel().tolist(), np.asarray(glm.basis_hypers_).tolist(), float(glm.regularizer_)))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_gloo_glm_with_real_device_features():
+    """Row-sharded SVI on two processes with real kernels: every rank's minibatch covers its shard, so the all-reduced
+    `_elbo` equals the single-process evaluation on all rows (same seed -> same draws) to f32 accuracy, and after a short
+    distributed `fit` both ranks hold identical parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_gpu_glm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    p1 = ctx.Process(target=_gloo_gpu_glm_worker, args=(0, 1, 0, q1))
+    p1.start()
+    single = q1.get(timeout=600)
+    p1.join(120)
+    assert res[0][1] == res[1][1]                                                # ranks agree exactly
+    ref = np.array(single[1])
+    assert np.abs(np.array(res[0][1]) - ref).max() < 2e-4 * np.abs(ref).max()    # and equal the all-rows evaluation
+    assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
