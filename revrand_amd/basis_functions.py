@@ -274,6 +274,10 @@ class _DevicePosterior(object):
         out = self.dev.download(self.acc, (F * F + F + 1,), np.float64)
         return out[:F * F].reshape(F, F), out[F * F:F * F + F].copy(), float(out[-1])
 
+    def b_host(self):
+        """Phi^T y of the last ``gram_device`` (F numbers)."""
+        return self.dev.download(self.acc, (self.F,), np.float64, offset_bytes=self.F * self.F * 8)
+
     def posterior(self, iL, var):
         """(m, diag C, log|iC|, sum(G o C)) from the statistics of the last ``gram_device``; C stays in ``self.dC``.
         None when the Cholesky is not safe (the estimator then takes the host SVD route)."""

@@ -44,10 +44,15 @@ def _random_start(fun, parameters, jac, args, nstarts, random_state):
         return flatten_values(_map(lambda p: p.value, parameters))
     log.info("Evaluating random starts...")
     best_obj, best = np.inf, None
+    # a function may offer a cheaper objective-only evaluation (the starts are ranked by the objective alone)
+    objective_only = getattr(fun, "objective_only", None)
     for _ in range(nstarts):
         cand = _map(lambda p: p.rvs(random_state), parameters)
-        res = fun(*(list(cand) + list(args)))
-        obj = res[0] if jac is True else res
+        if objective_only is not None:
+            obj = objective_only(*(list(cand) + list(args)))
+        else:
+            res = fun(*(list(cand) + list(args)))
+            obj = res[0] if jac is True else res
         if best is None or obj < best_obj:
             best_obj, best = obj, cand
     log.info("Best start found with objective = {}".format(best_obj))

@@ -648,3 +648,55 @@ def test_two_rank_gloo_fit_with_real_device_state(n):
     assert res[0][1:] == res[1][1:]                       # identical statistics -> identical L-BFGS path on both ranks
     assert np.allclose(res[0][1], single[1], rtol=2e-4, atol=2e-4 * np.abs(single[1]).max())
     assert np.isfinite(res[0][5]) and np.isfinite(res[0][6]).all()
+
+
+@pytest.mark.parametrize("n", [20, 160])
+def test_objective_only_evaluation_equals_full_elbo(n):
+    """`_elbo_objective` (statistics pass + posterior, no second data pass: sqErr from y^T y, m^T b and the posterior
+    identity) gives the objective of the full `_elbo`, for the host posterior (F = 40) and the device one (F = 320), a
+    single basis and a concatenation; `fit` ranks its random starts with it and only then runs full evaluations."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(1)
+    N, d = 5000, 4
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.2 * rs.randn(N)
+    for basis, hyp, reg in (
+            (bs.RandomRBF(nbases=n, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive())),
+             np.linspace(0.7, 1.4, d), 1.3),
+            (bs.RandomMatern32(nbases=n, Xdim=d, random_state=3) + bs.LinearBasis(onescol=True), [0.9], [1.1, 2.0])):
+        slm = SLM(basis)
+        slm.obj_ = -np.inf
+        slm._state = slm._make_state(X, y)
+        assert slm._state is not None
+        for var in (0.05, 0.7):
+            full = slm._elbo(X, y, var, reg, hyp)[0]
+            # sqErr = y^T y - m^T b - ... cancels ~1 digit per factor y^T y / sqErr of f32 statistics: far below what
+            # separates random starts
+            assert abs(slm._elbo_objective(X, y, var, reg, hyp) - full) < 5e-5 * abs(full)
+        slm._state.release()
+        slm._state = None
+    # fit: the random starts do not run the second pass
+    from revrand_amd.basis_functions import DeviceFitState
+    calls = {"second": 0, "gram": 0}
+    o2, og = DeviceFitState.second_pass, DeviceFitState.gram_device
+    og_host = DeviceFitState.gram
+
+    def spy2(self, *a, **k):
+        calls["second"] += 1
+        return o2(self, *a, **k)
+
+    def spyg(self, *a, **k):
+        calls["gram"] += 1
+        return og(self, *a, **k)
+
+    def spygh(self, *a, **k):
+        calls["gram"] += 1
+        return og_host(self, *a, **k)
+    DeviceFitState.second_pass, DeviceFitState.gram_device, DeviceFitState.gram = spy2, spyg, spygh
+    try:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=2)
+        slm = SLM(basis, nstarts=12, maxiter=5, random_state=4).fit(X, y)
+    finally:
+        DeviceFitState.second_pass, DeviceFitState.gram_device, DeviceFitState.gram = o2, og, og_host
+    assert calls["gram"] >= calls["second"] + 12 and calls["second"] >= 1
+    assert np.isfinite(slm.predict(X[:10])).all()
