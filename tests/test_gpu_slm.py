@@ -600,9 +600,12 @@ def _gloo_gpu_fit_worker(rank, world, port, q, n):
         X = rs.randn(N, d)
         y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.3 * rs.randn(N)
         a, b = parallel.shard_bounds(N, rank, world)
+        from scipy.stats import gamma
         basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
-                             regularizer=Parameter(1.0, Positive()))
-        slm = SLM(basis, var=Parameter(0.1, Positive()), nstarts=0, maxiter=8, distributed=world > 1, random_state=0)
+                             regularizer=Parameter(gamma(1.), Positive()))
+        # a random regulariser + nstarts: every rank ranks the same three starts (same seed) by the objective-only
+        # evaluation of the summed statistics
+        slm = SLM(basis, var=Parameter(0.1, Positive()), nstarts=3, maxiter=8, distributed=world > 1, random_state=0)
         slm.obj_ = -np.inf
         slm._state = slm._make_state(X[a:b], y[a:b])
         assert slm._state is not None
