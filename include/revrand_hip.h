@@ -232,7 +232,9 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
  * caller's own draws is the parity route): e ~ N(0, 1) per (sample, feature) from a counter-based generator keyed by
  * (seed, step), ws = m_k + sqrt(C_k) e.  m, C: host (F, K) float64 (the mixture means and diagonal covariances).
  * Outputs (host float64, (K, F) row-major): Edm = sum_l Edws / L (glm.py:309), EdC = sum_l Edws e / (L sqrt C) (:310);
- * llsum, aux as above.  EdPhi stays on the device as above. */
+ * llsum, aux as above.  EdPhi stays on the device as above.
+ * Edm == EdC == NULL (this entry point and rr_featmat_glm_step_draws): objective-only evaluation -- fs, the likelihood
+ * kernel and its sums (llsum, aux), none of the gradient GEMMs; what the random starts of the SGD front-end rank by. */
 int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik,
                                 double lik_param, const double *m, const double *C, int K, int L, uint64_t seed,
                                 uint64_t step, double *Edm, double *EdC, double *llsum, double *aux);

@@ -587,34 +587,40 @@ class FeatureMatrix(object):
                                                       aux.ctypes.data_as(ctypes.c_void_p)))
         return Edws, ll, aux
 
-    def glm_step_sampled(self, dy, drowarg, lik, lik_param, m, C, K, L, seed, step):
-        """(Edm (F, K), EdC (F, K), llsum (K,), aux (K,)) with the reparameterisation draws made on the device."""
+    def glm_step_sampled(self, dy, drowarg, lik, lik_param, m, C, K, L, seed, step, objective_only=False):
+        """(Edm (F, K), EdC (F, K), llsum (K,), aux (K,)) with the reparameterisation draws made on the device;
+        objective_only: (None, None, llsum, aux) without the gradient GEMMs."""
         m = np.ascontiguousarray(m, dtype=np.float64)
         C = np.ascontiguousarray(C, dtype=np.float64)
         if m.shape != (self.F, K) or C.shape != (self.F, K):
             raise ValueError("m and C must have shape (F, K)")
         Edm, EdC, ll, aux = np.empty((K, self.F)), np.empty((K, self.F)), np.empty(K), np.empty(K)
+        none = ctypes.c_void_p(None)
         _check(self.lib, self.lib.rr_featmat_glm_step_sampled(
             self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik), float(lik_param),
             m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L, int(seed), int(step),
-            Edm.ctypes.data_as(ctypes.c_void_p), EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
+            none if objective_only else Edm.ctypes.data_as(ctypes.c_void_p),
+            none if objective_only else EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
             aux.ctypes.data_as(ctypes.c_void_p)))
-        return Edm.T, EdC.T, ll, aux
+        return (None, None, ll, aux) if objective_only else (Edm.T, EdC.T, ll, aux)
 
-    def glm_step_draws(self, dy, drowarg, lik, lik_param, m, C, K, L, E):
-        """(Edm (F, K), EdC (F, K), llsum, aux) for the caller's standard-normal draws E (K*L, F)."""
+    def glm_step_draws(self, dy, drowarg, lik, lik_param, m, C, K, L, E, objective_only=False):
+        """(Edm (F, K), EdC (F, K), llsum, aux) for the caller's standard-normal draws E (K*L, F); objective_only as in
+        glm_step_sampled."""
         m = np.ascontiguousarray(m, dtype=np.float64)
         C = np.ascontiguousarray(C, dtype=np.float64)
         E = np.ascontiguousarray(E, dtype=np.float32)
         if m.shape != (self.F, K) or C.shape != (self.F, K) or E.shape != (K * L, self.F):
             raise ValueError("m, C must have shape (F, K) and E (K*L, F)")
         Edm, EdC, ll, aux = np.empty((K, self.F)), np.empty((K, self.F)), np.empty(K), np.empty(K)
+        none = ctypes.c_void_p(None)
         _check(self.lib, self.lib.rr_featmat_glm_step_draws(
             self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik), float(lik_param),
             m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L, E.ctypes.data_as(ctypes.c_void_p),
-            Edm.ctypes.data_as(ctypes.c_void_p), EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
+            none if objective_only else Edm.ctypes.data_as(ctypes.c_void_p),
+            none if objective_only else EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
             aux.ctypes.data_as(ctypes.c_void_p)))
-        return Edm.T, EdC.T, ll, aux
+        return (None, None, ll, aux) if objective_only else (Edm.T, EdC.T, ll, aux)
 
     def glm_rff(self, handle, dX, col0, dT):
         _check(self.lib, self.lib.rr_featmat_glm_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))

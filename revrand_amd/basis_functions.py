@@ -550,21 +550,23 @@ class MinibatchFeatures(object):
             if dn is not None:
                 dn.free()
 
-    def glm_step_sampled(self, y, rowarg, lik, lik_param, m, C, K, L, seed, step):
+    supports_objective_only = True  # glm_step_sampled / glm_step_draws take objective_only=True (no gradient GEMMs)
+
+    def glm_step_sampled(self, y, rowarg, lik, lik_param, m, C, K, L, seed, step, objective_only=False):
         dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
         dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
         try:
-            return self.fm.glm_step_sampled(dy, dn, lik, lik_param, m, C, K, L, seed, step)
+            return self.fm.glm_step_sampled(dy, dn, lik, lik_param, m, C, K, L, seed, step, objective_only)
         finally:
             dy.free()
             if dn is not None:
                 dn.free()
 
-    def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E):
+    def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E, objective_only=False):
         dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
         dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
         try:
-            return self.fm.glm_step_draws(dy, dn, lik, lik_param, m, C, K, L, E)
+            return self.fm.glm_step_draws(dy, dn, lik, lik_param, m, C, K, L, E, objective_only)
         finally:
             dy.free()
             if dn is not None:

@@ -1476,7 +1476,7 @@ static int glm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int6
 
 // With WSs (kl_ld, Fp) = ws / (K L) on the device: fs, likelihood derivatives and sums, Ed = dfs Phi, EdPhi.
 static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *drowarg, int dtype, int lik,
-                        double lik_param, int K, int L) {
+                        double lik_param, int K, int L, bool objective_only = false) {
     rr_ctx *c = fm->ctx;
     const int KL = K * L;
     const int64_t Fp = fm->ld, kl_ld = s.klp;
@@ -1496,6 +1496,10 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     else
         glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
     RR_CHECK_HIP(hipGetLastError());
+    if (objective_only) {  // the log-likelihood sums are all the objective needs: no gradient GEMMs
+        s.have_edphi = false;
+        return RR_OK;
+    }
     // Ed (kl, Fp) = dfs Phi
     rc = glm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
     if (rc != RR_OK) return rc;
@@ -1552,8 +1556,9 @@ static int glm_step_reduced(rr_featmat *fm, const void *dy, const void *drowarg,
                             const float *Ehost, double *Edm, double *EdC, double *llsum, double *aux) {
     int rc = glm_step_checks(fm, dy, drowarg, dtype, lik, lik_param, K, L, "rr_featmat_glm_step_sampled");
     if (rc != RR_OK) return rc;
-    RR_REQUIRE(m != nullptr && C != nullptr && Edm != nullptr && EdC != nullptr && llsum != nullptr && aux != nullptr,
-               "rr_featmat_glm_step_sampled: null argument");
+    const bool objective_only = (Edm == nullptr && EdC == nullptr);  // llsum / aux only (random starts)
+    RR_REQUIRE(m != nullptr && C != nullptr && (objective_only || (Edm != nullptr && EdC != nullptr)) && llsum != nullptr &&
+               aux != nullptr, "rr_featmat_glm_step_sampled: null argument");
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
     const int KL = K * L, F = fm->F;
@@ -1573,14 +1578,16 @@ static int glm_step_reduced(rr_featmat *fm, const void *dy, const void *drowarg,
     hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, c->stream, s.mc, s.mc + fk,
                        F, K, L, Fp, kl_ld, seed, step, Egiven, s.Ee, s.WSs);
     RR_CHECK_HIP(hipGetLastError());
-    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, lik_param, K, L);
+    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, lik_param, K, L, objective_only);
     if (rc != RR_OK) return rc;
-    hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, c->stream, s.Ed, s.Ee, s.mc + fk,
-                       F, K, L, Fp, s.mc + 2 * fk, s.mc + 3 * fk);
-    RR_CHECK_HIP(hipGetLastError());
     std::vector<double> acc((size_t)2 * s.kcap);
-    RR_CHECK_HIP(hipMemcpyAsync(Edm, s.mc + 2 * fk, fk * 8, hipMemcpyDeviceToHost, c->stream));
-    RR_CHECK_HIP(hipMemcpyAsync(EdC, s.mc + 3 * fk, fk * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!objective_only) {
+        hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, c->stream, s.Ed, s.Ee,
+                           s.mc + fk, F, K, L, Fp, s.mc + 2 * fk, s.mc + 3 * fk);
+        RR_CHECK_HIP(hipGetLastError());
+        RR_CHECK_HIP(hipMemcpyAsync(Edm, s.mc + 2 * fk, fk * 8, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipMemcpyAsync(EdC, s.mc + 3 * fk, fk * 8, hipMemcpyDeviceToHost, c->stream));
+    }
     RR_CHECK_HIP(hipMemcpyAsync(acc.data(), s.kacc, acc.size() * 8, hipMemcpyDeviceToHost, c->stream));
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     for (int k = 0; k < K; ++k) {

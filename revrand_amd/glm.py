@@ -107,8 +107,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if self.sampler == "device":
             # keyed here, so that `_elbo` never draws from random_ and the minibatches can be built one step ahead
             self._dev_seed, self._dev_step = int(self.random_.randint(0, 2 ** 31 - 1)), 0
+        from functools import partial
+        elbo = partial(GeneralizedLinearModel._elbo, self)
+        elbo.objective_only = partial(GeneralizedLinearModel._elbo, self, objective_only=True)  # random starts
         try:
-            res = nsgd(self._elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
+            res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
                        prefetch=self.sampler == "device")
         finally:
@@ -136,8 +139,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         state.pop("_mbf", None)
         return state
 
-    def _elbo(self, m, C, reg, lpars, bpars, X, y, *largs):
-        """-ELBO and its gradients on one minibatch (glm.py:205-294)."""
+    def _elbo(self, m, C, reg, lpars, bpars, X, y, *largs, objective_only=False):
+        """-ELBO and its gradients on one minibatch (glm.py:205-294).  objective_only (the random starts of `fit`):
+        -ELBO alone, from fs and the likelihood sums -- none of the gradient GEMMs, no basis gradients."""
         D, K = m.shape
         L_ = self.nsamples
         lpars_l = atleast_list(lpars)
@@ -149,11 +153,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         else:
             feats.assemble(X, atleast_list(bpars))                            # Phi (M x D) in HBM
         lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
+        objective_only = objective_only and getattr(feats, "supports_objective_only", False)
+        okw = {"objective_only": True} if objective_only else {}
         if self.sampler == "device":
             if self.__dict__.get("_dev_seed") is None:
                 self._dev_seed, self._dev_step = int(self.random_.randint(0, 2 ** 31 - 1)), 0
             Edm, EdC, llsum, aux = feats.glm_step_sampled(y, rowarg, lid, lpar, m, C, K, L_, self._dev_seed,
-                                                          self._dev_step)
+                                                          self._dev_step, **okw)
             self._dev_step += 1
         else:
             if self.sampler != "host":
@@ -163,10 +169,25 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             e = np.empty((K * L_, D), dtype=np.float32)
             for k in range(K):
                 e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
-            Edm, EdC, llsum, aux = feats.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L_, e)
+            Edm, EdC, llsum, aux = feats.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L_, e, **okw)
 
-        dbpars = feats.glm_basis_grads(X)                                     # -(EdPhi o dPhi).sum() per parameter
         nrows = float(len(y))
+        if objective_only:
+            if self.distributed:
+                from . import parallel
+                buf = parallel.allreduce_host(np.concatenate((llsum, [llconst])))
+                llsum, llconst = buf[:K], float(buf[K])
+            L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))
+            iL = 1. / L[:, np.newaxis]
+            logNkl = _qmatrix(m, C)
+            mx = logNkl.max(axis=0)
+            logzk = np.log(np.exp(logNkl - mx).sum(axis=0)) + mx
+            Ell = llsum / L_ + llconst
+            ELBO = (Ell.sum() * self.B_ - 0.5 * D * K * np.log(2 * np.pi) - 0.5 * K * np.log(L).sum()
+                    - 0.5 * ((m ** 2 + C) * iL).sum() - logzk.sum() + np.log(K)) / K
+            self.__it += 1
+            return -ELBO
+        dbpars = feats.glm_basis_grads(X)                                     # -(EdPhi o dPhi).sum() per parameter
         if self.distributed:  # one exchange per step: the per-rank Monte-Carlo sums
             from . import parallel
             from .utils import flatten_values

@@ -387,10 +387,14 @@ def structured_sgd(sgd):
             if any(flatten_values(_map(lambda p: float(p.is_random), parameters))):
                 log.info("Evaluating random starts...")
                 best_obj, best = np.inf, None
+                objective_only = getattr(fun, "objective_only", None)
                 for _ in range(nstarts):
                     batch = next(data_gen)
                     cand = _map(lambda p: p.rvs(random_state), parameters)
-                    obj = fun(*(list(cand) + list(batch) + list(args)))[0]
+                    if objective_only is not None:  # a cheaper objective-only evaluation, when the function offers one
+                        obj = objective_only(*(list(cand) + list(batch) + list(args)))
+                    else:
+                        obj = fun(*(list(cand) + list(batch) + list(args)))[0]
                     if best is None or obj < best_obj:
                         best_obj, best = obj, cand
                 log.info("Best start found with objective = {}".format(best_obj))

@@ -367,3 +367,33 @@ def test_two_rank_gloo_glm_with_real_device_features():
     ref = np.array(single[1])
     assert np.abs(np.array(res[0][1]) - ref).max() < 2e-4 * np.abs(ref).max()    # and equal the all-rows evaluation
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+
+
+@pytest.mark.parametrize("sampler", ["host", "device"])
+def test_objective_only_step_equals_full_objective(sampler):
+    """The random starts of `fit` rank candidates by -ELBO alone: the objective-only step (fs + likelihood sums, no
+    gradient GEMMs) returns the objective of the full step for the same draws, and a fit with random starts runs."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(2)
+    M, d, n, K, L = 3000, 4, 60, 3, 7
+    X = rs.randn(M, d)
+    y = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float)
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
+    D = 2 * n + d + 1
+    m, C = 0.1 * rs.randn(D, K), rs.gamma(2., 0.5, (D, K))
+    vals = []
+    for oo in (False, True):
+        glm = GLM(lk.Poisson(), basis, K=K, nsamples=L, random_state=11, sampler=sampler)
+        glm.B_, glm.D_ = 4.0, D
+        glm._GeneralizedLinearModel__it = -1
+        if sampler == "device":
+            glm._dev_seed, glm._dev_step = 12345, 3
+        r = glm._elbo(m, C, [1.2, 0.7], [], [np.linspace(0.8, 1.2, d)], X, y, objective_only=oo)
+        glm._release_features()
+        vals.append(r if oo else r[0])
+    assert abs(vals[0] - vals[1]) < 1e-9 * abs(vals[0])
+    glm = GLM(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1), K=K, nsamples=L, random_state=5, sampler=sampler,
+              nstarts=6, maxiter=20, batch_size=500)
+    glm.fit(X, y)
+    assert np.isfinite(glm.predict(X[:20])).all()

@@ -21,3 +21,20 @@ for mode in ("objective-only", "full _elbo"):
     slm.fit(X, y)
     dt = time.perf_counter() - t0
     print("%-15s %d random starts + maxiter=0: %.2f s" % (mode, NSTARTS, dt), flush=True)
+
+# --- GLM (config 5's shape): 40 random starts, batch 65 536, device sampler
+from revrand_amd import GeneralizedLinearModel
+import revrand_amd.likelihoods as lk
+import revrand_amd.optimize as opt
+X = X[:, :32]
+yc = np.random.RandomState(3).poisson(np.exp(0.3 * X[:, 0])).astype(float)
+for mode in ("objective-only", "full step"):
+    b = bs.RandomRBF(nbases=1024, Xdim=32, random_state=1, lenscale=Parameter(np.ones(32), Positive()))
+    glm = GeneralizedLinearModel(lk.Poisson(), b, K=10, nsamples=50, random_state=2, maxiter=1, batch_size=65536,
+                                 sampler="device", nstarts=40)
+    if mode == "full step":
+        orig = GeneralizedLinearModel._elbo
+        GeneralizedLinearModel._elbo = lambda self, *a, objective_only=False: (orig(self, *a)[0] if objective_only else orig(self, *a))
+    t0 = time.perf_counter()
+    glm.fit(X, yc)
+    print("GLM %-15s 40 random starts + 1 step: %.2f s" % (mode, time.perf_counter() - t0), flush=True)
