@@ -266,9 +266,27 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         return -ELBO, [-dvar, dL, dhypers]
 
     def predict(self, X):
-        """Predictive mean (slm.py:201-217)."""
-        Ey, _ = self.predict_moments(X)
+        """Predictive mean (slm.py:201-217).  The reference computes it through `predict_moments`, i.e. with the
+        N x F x F product of the variance; the mean alone is Phi m, formed here on the device without it (a 256-column
+        GEMM instead of an F-column one), falling back to `predict_moments` for bases that cannot."""
+        check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
+        X = check_array(X)
+        Ey = self._predict_mean(X)
+        if Ey is None:
+            Ey, _ = self.predict_moments(X)
         return Ey
+
+    def _predict_mean(self, X):
+        bases = getattr(self.basis, "bases", [self.basis])
+        if any(getattr(b, "dtype", "f32") != "f32" for b in bases):  # f64 arithmetic was asked for: keep it
+            return None
+        from .basis_functions import MinibatchFeatures
+        feats = MinibatchFeatures(self.basis)
+        try:
+            with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+                return feats.project(X, atleast_list(self.hypers_), np.asarray(self.weights_, dtype=float)[:, None])[:, 0]
+        finally:
+            feats.release()
 
     def predict_moments(self, X):
         """Predictive mean and variance (slm.py:219-244)."""

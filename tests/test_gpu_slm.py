@@ -703,3 +703,24 @@ def test_objective_only_evaluation_equals_full_elbo(n):
         DeviceFitState.second_pass, DeviceFitState.gram_device, DeviceFitState.gram = o2, og, og_host
     assert calls["gram"] >= calls["second"] + 12 and calls["second"] >= 1
     assert np.isfinite(slm.predict(X[:10])).all()
+
+
+def test_predict_is_the_mean_of_predict_moments_without_the_variance_product():
+    """`predict` forms Phi m alone on the device (the reference goes through `predict_moments`, slm.py:201-217): same
+    numbers as the mean of `predict_moments`, for a single basis, a concatenation with generic children and a purely
+    linear model; an f64 basis keeps the `predict_moments` route."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(0)
+    X = rs.randn(3000, 5)
+    y = np.sin(X[:, 0]) + 0.3 * X[:, 1] + 0.1 * rs.randn(3000)
+    Xs = rs.randn(777, 5)
+    for basis in (bs.RandomRBF(nbases=100, Xdim=5, random_state=1),
+                  bs.RandomMatern32(nbases=60, Xdim=2, random_state=2, apply_ind=[0, 1]) + bs.LinearBasis(onescol=True)
+                  + bs.FastFoodRBF(nbases=8, Xdim=2, random_state=3, apply_ind=[2, 3]),
+                  bs.LinearBasis(onescol=True),
+                  bs.RandomRBF(nbases=40, Xdim=5, random_state=1, dtype="f64")):
+        slm = SLM(basis, maxiter=15, nstarts=0, random_state=0).fit(X, y)
+        Em, _ = slm.predict_moments(Xs)
+        Ey = slm.predict(Xs)
+        assert Ey.shape == (777,) and normwise(Ey, Em) < 1e-5
+        assert ((slm.predict(X) - y) ** 2).mean() < 0.9 * y.var()
