@@ -312,6 +312,11 @@ int rr_rff_grad_contract(rr_basis *basis, const void *X, int x_dtype, int64_t N,
 int rr_rff_predict_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,
                        const double *lenscale, int n_ls, const double *m, const double *C, double *Ey,
                        double *Vf);
+/* The same with C (F, F) float64 resident on the DEVICE: a fitted estimator uploads its covariance once and
+ * serves many predict_moments calls (the host conversion + upload of C is 9 ms per call at F = 4096). */
+int rr_rff_predict_devc(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                        const double *lenscale, int n_ls, const double *m, const double *dC, double *Ey,
+                        double *Vf);
 
 /* ---- FastFood -------------------------------------------------------------------------
  * FastFoodRBF (basis_functions.py:1211-1383).  B (+-1, int64), G, PI (int64 permutations) and S are

@@ -125,6 +125,9 @@ SIGNATURES = {
     "rr_rff_predict_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_rff_predict_devc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_fastfood_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           _c_void_pp]),
@@ -856,17 +859,22 @@ class RffHandle(object):
         return float(sq[0]), T
 
     def predict(self, X, lenscale, m, C):
-        """(Ey, Vf) = (Phi m, rowsum((Phi C) o Phi)) for host query rows X."""
+        """(Ey, Vf) = (Phi m, rowsum((Phi C) o Phi)) for host query rows X.  C: host (F, F) array, or a DeviceBuffer
+        holding it in float64 on the device (uploaded once by the estimator)."""
         dX = self.upload(X)
         N = dX.shape[0]
         ls, lsp, nls = _lenscale_arg(lenscale)
         m = np.ascontiguousarray(m, dtype=np.float64)
-        C = np.ascontiguousarray(C, dtype=np.float64)
+        if isinstance(C, np.ndarray):
+            C = np.ascontiguousarray(C, dtype=np.float64)
+            fn, cp = self.lib.rr_rff_predict_dev, C.ctypes.data_as(ctypes.c_void_p)
+        else:
+            fn, cp = self.lib.rr_rff_predict_devc, _ptr(C)
         Ey, Vf = np.empty(N), np.empty(N)
         if N:
-            _check(self.lib, self.lib.rr_rff_predict_dev(self.h, dX.ptr, rr_dtype(dX.dtype), N, dX.ld, lsp, nls,
+            _check(self.lib, fn(self.h, dX.ptr, rr_dtype(dX.dtype), N, dX.ld, lsp, nls,
                                                          m.ctypes.data_as(ctypes.c_void_p),
-                                                         C.ctypes.data_as(ctypes.c_void_p),
+                                                         cp,
                                                          Ey.ctypes.data_as(ctypes.c_void_p),
                                                          Vf.ctypes.data_as(ctypes.c_void_p)))
         dX.free()

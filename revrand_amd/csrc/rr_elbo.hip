@@ -1335,6 +1335,18 @@ int rr_rff_predict_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int6
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, C, Ey, Vf);
 }
 
+int rr_rff_predict_devc(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                        int n_ls, const double *m, const double *dC, double *Ey, double *Vf) {
+    int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, dC, "rr_rff_predict_devc");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(Ey != nullptr && Vf != nullptr, "rr_rff_predict_devc: null argument");
+    if (b->compute == RR_F64)
+        return x_dtype == RR_F32 ? pass2_run64<float>(b, true, (const float *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true)
+                                 : pass2_run64<double>(b, true, (const double *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true);
+    return x_dtype == RR_F32 ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true)
+                             : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true);
+}
+
 static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool c_on_device) {
     RR_REQUIRE(fm != nullptr && m != nullptr && C != nullptr, "rr_featmat_pass2_begin: null argument");
     rr_ctx *c = fm->ctx;

@@ -724,3 +724,30 @@ def test_predict_is_the_mean_of_predict_moments_without_the_variance_product():
         Ey = slm.predict(Xs)
         assert Ey.shape == (777,) and normwise(Ey, Em) < 1e-5
         assert ((slm.predict(X) - y) ** 2).mean() < 0.9 * y.var()
+
+
+def test_serving_state_is_reused_and_invalidated():
+    """A fitted estimator keeps its covariance in HBM and its `predict` feature matrix between calls; the state is
+    rebuilt when `covariance_` is replaced, dropped by pickling and by a new fit."""
+    import pickle
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(0)
+    X = rs.randn(2000, 4)
+    y = np.sin(X[:, 0]) + 0.1 * rs.randn(2000)
+    slm = SLM(bs.RandomRBF(nbases=150, Xdim=4, random_state=1), nstarts=0, maxiter=10, random_state=0).fit(X, y)
+    Xs = rs.randn(50, 4)
+    Ey, Vy = slm.predict_moments(Xs)
+    srv = slm._serve
+    assert srv["cov"] is not None
+    Ey2, Vy2 = slm.predict_moments(Xs)
+    assert slm._serve is srv and np.array_equal(Ey, Ey2) and np.array_equal(Vy, Vy2)
+    assert normwise(slm.predict(Xs), Ey) < 1e-5 and slm._serve["feats"] is not None
+    Phi = orc.rff_transform(Xs, slm.basis.W, slm.hypers_)
+    assert normwise(Vy, (Phi @ slm.covariance_ * Phi).sum(axis=1) + slm.var_) < 1e-3
+    slm.covariance_ = 4.0 * slm.covariance_                    # replaced: the device copy must follow
+    _, Vy4 = slm.predict_moments(Xs)
+    assert slm._serve is not srv and normwise(Vy4 - slm.var_, 4.0 * (Vy - slm.var_)) < 1e-5
+    clone_ = pickle.loads(pickle.dumps(slm))
+    assert "_serve" not in clone_.__dict__ and normwise(clone_.predict_moments(Xs)[1], Vy4) < 1e-6
+    slm.fit(X, y)
+    assert "_serve" not in slm.__dict__
