@@ -295,7 +295,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         return s["cov"]
 
     def __getstate__(self):
-        state = dict(self.__dict__)
+        state = dict(super().__getstate__())  # sklearn's (adds its version tag)
         state.pop("_serve", None)
         return state
 
