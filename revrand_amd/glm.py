@@ -18,6 +18,7 @@ draws come from the host ``random_`` in the reference's order (``randn(nsamples,
 run consumes the same random stream as the reference.
 """
 import logging
+import os
 from itertools import chain
 from multiprocessing import Pool
 
@@ -81,6 +82,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
     def _fit(self, X, y, likelihood_args=()):
         X, y = check_X_y(X, y)
+        self._drop_serving()
         self._dev_seed = None  # the device sampler is re-keyed from random_ per fit
         N, _ = X.shape
         self.B_ = X.shape[0] / self.batch_size
@@ -135,9 +137,15 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             f.release()
 
     def __getstate__(self):
-        state = dict(self.__dict__)
+        state = dict(super().__getstate__())  # sklearn's (adds its version tag)
         state.pop("_mbf", None)
+        state.pop("_serve_feats", None)
         return state
+
+    def _drop_serving(self):
+        srv = self.__dict__.pop("_serve_feats", None)
+        if srv is not None and srv[0] == os.getpid():
+            srv[1].release()
 
     def _elbo(self, m, C, reg, lpars, bpars, X, y, *largs, objective_only=False):
         """-ELBO and its gradients on one minibatch (glm.py:205-294).  objective_only (the random starts of `fit`):
@@ -303,11 +311,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         D, K = self.weights_.shape
         k = self.random_.randint(0, K, size=(nsamples,))
         w = self.weights_[:, k] + self.random_.randn(D, nsamples) * np.sqrt(self.covariance_[:, k])
-        feats = MinibatchFeatures(self.basis)
-        try:
-            return feats.project(X, atleast_list(self.basis_hypers_), w)
-        finally:
-            feats.release()
+        # the feature matrix is kept between prediction calls (per process; dropped by fit and by pickling)
+        srv = self.__dict__.get("_serve_feats")
+        if srv is None or srv[0] != os.getpid():
+            srv = self.__dict__["_serve_feats"] = (os.getpid(), MinibatchFeatures(self.basis))
+        return srv[1].project(X, atleast_list(self.basis_hypers_), w)
 
     def _sample_func(self, X, nsamples, genaxis=1):
         """Generator over latent function samples, column-wise (genaxis=1) or per observation (genaxis=0)."""
