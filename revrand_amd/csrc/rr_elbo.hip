@@ -63,6 +63,7 @@ struct GemmArgs {
     int64_t lda, ldb, ldd;
     int K, ntb;  // ntb = N / 256 column tiles (fastest-varying in blockIdx)
     int kb_per_split = 0;  // > 0: blockIdx.y owns k-blocks [y * kb_per_split, ...) and ADDS into a zeroed D (f32 atomics)
+    int upper_b = 0;  // B (K, N) with K == N is upper triangular: column tile tb needs only k < 256 (tb + 1)
     // TRIG epilogue (random Fourier features of Xdim > 128, rr_rff.hip): the product is the phase matrix Z in
     // revolutions; D is the feature matrix P: P[r][c] = cos(2 pi Z[r][c]) scale, P[r][n + c] = sin(..) scale for
     // c < n, zero rows for nvalid <= r < nout, nothing beyond; bvec += P^T y.
@@ -81,7 +82,9 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t ta = blockIdx.x / p.ntb;
-    const int tb = blockIdx.x % p.ntb;
+    // upper_b: tile cost grows with tb and block b runs on XCD b % 8 -- rotate the column tiles by the row tile so that
+    // every XCD sees every cost
+    const int tb = p.upper_b ? (int)((blockIdx.x % p.ntb + ta) % p.ntb) : (int)(blockIdx.x % p.ntb);
     const int64_t ca = ta * GR_TC;
     const int cb = tb * GR_TC;
 
@@ -110,6 +113,10 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
     };
 
     int nkb = p.K / GR_KB, kb_first = 0;
+    if (p.upper_b) {
+        const int kmax = (tb + 1) * (GR_TC / GR_KB);
+        nkb = nkb < kmax ? nkb : kmax;
+    }
     if (p.kb_per_split > 0) {  // split-K: few output tiles, long K (Edws = dfs Phi)
         kb_first = blockIdx.y * p.kb_per_split;
         nkb = nkb - kb_first < p.kb_per_split ? nkb - kb_first : p.kb_per_split;
@@ -297,12 +304,16 @@ rr_grad_contract_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const 
 }
 
 // C32 (Fp, Fp) f32, zero padded  <-  C (F, F) f64 on the device (the posterior of rr_posterior_dev)
+// tri: the upper-triangular form of the (symmetric) matrix with doubled off-diagonal entries -- x^T C x == x^T Ctri x,
+// which is all predict_moments needs from C, and Phi Ctri costs half the k-blocks of Phi C (GemmArgs::upper_b)
 __global__ void __launch_bounds__(256)
-rr_c64_to_c32_kernel(const double *__restrict__ C, int64_t F, float *__restrict__ C32, int64_t Fp) {
+rr_c64_to_c32_kernel(const double *__restrict__ C, int64_t F, float *__restrict__ C32, int64_t Fp, int tri = 0) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Fp * Fp) return;
     const int64_t r = i / Fp, c = i % Fp;
-    C32[i] = (r < F && c < F) ? (float)C[r * F + c] : 0.f;
+    float v = (r < F && c < F) ? (float)C[r * F + c] : 0.f;
+    if (tri) v = r < c ? 2.f * v : (r == c ? v : 0.f);
+    C32[i] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -338,7 +349,8 @@ void rr_pass2_scratch_free(void *p) {
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              float *P, int64_t ldp, bool zero_pad_cols);  // rr_rff.hip
 int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
-                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready);  // rr_rff.hip
+                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready,
+                           bool upper_b = false);  // rr_syrk16.hip
 
 template <typename TX>
 static int launch_features_t(rr_basis *b, const TX *X, int64_t N, int64_t Npad, int64_t ldx, const float *m32,
@@ -454,15 +466,22 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         s.hm.resize(F);
         for (int i = 0; i < F; ++i) s.hm[i] = (float)mh[i];
         e = hipMemcpy(s.m32, s.hm.data(), (size_t)F * 4, hipMemcpyHostToDevice);
+        // prediction needs only the quadratic form phi^T C phi: C goes up in its upper-triangular form (doubled
+        // off-diagonals), and the GEMM skips the k-blocks below the diagonal -- half the product
         if (c_on_device) {
             hipLaunchKernelGGL(rr_c64_to_c32_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, Ch,
-                               (int64_t)F, s.C32, Fp);
+                               (int64_t)F, s.C32, Fp, pred ? 1 : 0);
         } else {
             s.hC.assign((size_t)Fp * Fp, 0.f);
             for (int i = 0; i < F; ++i) {
                 const double *src = Ch + (size_t)i * F;
                 float *dst = s.hC.data() + (size_t)i * Fp;
-                for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+                if (pred) {
+                    dst[i] = (float)src[i];
+                    for (int j = i + 1; j < F; ++j) dst[j] = 2.f * (float)src[j];
+                } else {
+                    for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+                }
             }
             if (e == hipSuccess) e = hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice);
         }
@@ -495,11 +514,12 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         if (rc != RR_OK) break;
         // U = P C  as  (Pt)^T C : A = Pt (K = Fp, M = mpad columns), B = C32 (K = Fp, N = Fp)
         if (c->gram_engine != 0) {
-            rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, chunk, s.C32, Fp, s.U, Fp, Fp, mpad, Fp, s.Ab, s.Cb, r0 > 0);
+            rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, chunk, s.C32, Fp, s.U, Fp, Fp, mpad, Fp, s.Ab, s.Cb, r0 > 0, pred);
             if (rc != RR_OK) break;
         } else {
             GemmArgs g;
             g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
+            g.upper_b = pred ? 1 : 0;
             hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
         }
         if (hipGetLastError() != hipSuccess) {

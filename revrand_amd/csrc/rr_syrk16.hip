@@ -103,6 +103,7 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
     if (GEMM) {
         ta = tdx / p.nb;
         tb = tdx % p.nb;
+        if (p.upper_b) tb = (tb + ta) % p.nb;  // tile cost grows with tb, block b runs on XCD b % 8: give every XCD every cost
     } else {
         if (p.tile_map) tdx = p.tile_map[tdx];
         const int od = p.offdiag_only;
@@ -116,7 +117,8 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
     const int64_t row_begin = (int64_t)ks * p.rows_per_split;
     int64_t row_end = row_begin + p.rows_per_split;
     if (row_end > p.rows) row_end = p.rows;
-    const int S = (int)((row_end - row_begin) / 16);  // k-steps, a multiple of 4
+    int S = (int)((row_end - row_begin) / 16);  // k-steps, a multiple of 4
+    if (GEMM && p.upper_b && S > (tb + 1) * 16) S = (tb + 1) * 16;  // upper-triangular B: nothing below the diagonal
 
     // DMA role: 32 instructions of 1 KiB per stage; wave w issues t = 8 w + k: waves 0-1 the A side, 2-3 the B side
     const int side = wave >> 1;
@@ -249,7 +251,7 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
 // converted to the K-blocked split-bf16 layout into caller scratch (sa: K*lda*4 bytes, sb: K*ldb*4; sb_ready: B was
 // converted by an earlier call and is unchanged) and multiplied on the bf16 matrix pipe with nprod products.
 int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
-                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready) {
+                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready, bool upper_b) {
     hipLaunchKernelGGL(rr_split_bf16_kernel, dim3((unsigned)(K / 16), (unsigned)(M / 256)), dim3(256), 0, c->stream, A, K, lda,
                        (uintx4 *)sa);
     if (!sb_ready)
@@ -259,9 +261,10 @@ int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, co
     a.P = (const float *)sa; a.ldp = lda; a.P2 = (const float *)sb; a.ldp2 = ldb; a.rows = K; a.rows_per_split = K;
     a.F = (int)N; a.nb = (int)(N / 256); a.ntiles = (int)((M / 256) * (N / 256)); a.G = nullptr; a.tile_map = nullptr;
     a.offdiag_only = 0; a.ablate = 0; a.D = D; a.ldd = ldd;
+    a.upper_b = (upper_b && K == N) ? 1 : 0;
     RR_REQUIRE((M / 256) * (N / 256) < (int64_t)1 << 24, "gemm: grid too large");
     int64_t nsplit = 1;
-    if (a.ntiles < 2 * c->num_cu && K >= 2048) {  // too few tiles to fill the chip: split K (>= 512 rows each), f32 atomics
+    if (!a.upper_b && a.ntiles < 2 * c->num_cu && K >= 2048) {  // too few tiles to fill the chip: split K (>= 512 rows each), f32 atomics
         nsplit = (2 * (int64_t)c->num_cu + a.ntiles - 1) / a.ntiles;
         if (nsplit > K / 512) nsplit = K / 512;
         a.rows_per_split = ((K + nsplit - 1) / nsplit + 63) / 64 * 64;

@@ -67,6 +67,7 @@ struct SyrkArgs {
     float *D = nullptr;   // (M, ldd) f32, plain stores
     int64_t ldd = 0;
     float out_scale = 1.f;  // fp16 operands: 1 / s^2 of the producer's store scale
+    int upper_b = 0;        // GEMM mode: B (K == N) is upper triangular, column tile tb needs only k < 256 (tb + 1)
 };
 
 // Greedy XCD-aware tile order of the SYRK kernels (rr_rff.hip)
@@ -76,4 +77,5 @@ void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map);
 int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void *pb, int64_t rows, int64_t ldp, int F, double *dG,
                         hipEvent_t mid, float f16_scale = 0.f);
 int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
-                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready);
+                           int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready,
+                           bool upper_b = false);
