@@ -86,7 +86,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", choices=["f32", "bf16x3", "bf16x4", "fp16x3"], default=None,
                     help="arithmetic of the Gram (default: f32 MFMA, or $RR_SYRK_ENGINE); see DESIGN.md 3.13")
-    ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational bf16x3 measurement")
+    ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational fp16x3 measurement")
+    ap.add_argument("--no-parity-check", action="store_true",
+                    help="skip the 2048-row oracle check before timing (profiling runs: keeps per-kernel averages clean)")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line (the JSON).  RCCL writes its version banner and warnings to file descriptor 1
@@ -189,7 +191,7 @@ def main():
     # ---- parity of the measured path on a slice, off-diagonal entries included: Gram of the first rows against the
     # oracle (checker only) before anything is timed ----
     parity_err = None
-    if rank == 0 and my_rows >= 2048:
+    if rank == 0 and my_rows >= 2048 and not args.no_parity_check:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import revrand_oracle as orc
         Xs, ys = gen_chunk(row0 // CH, min(CH, args.rows - (row0 // CH) * CH), d, wvec)

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 # ENGINE=bf16x3 sh tools/prof.sh profiles the split-bf16 engine instead (summarise with: summarize_prof.py <tag> rr_syrk_b16w4_kernel)
-EXTRA="--no-alt-engine ${ENGINE:+--engine $ENGINE}"
+EXTRA="--no-alt-engine --no-parity-check ${ENGINE:+--engine $ENGINE}"
 CMD="python bench.py --rows 2000000 --steps 3 --warmup 1 --no-cpu-baseline $EXTRA"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt_bench.json 2> $OUT/kt.err
 PMC="python bench.py --rows 2000000 --steps 1 --warmup 0 --no-cpu-baseline $EXTRA"
