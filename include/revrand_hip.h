@@ -207,6 +207,10 @@ int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, dou
  *   predict_rows(Ey, Vf)   Ey = P m, Vf = rowsum((P C) o P) for the current rows (host float64) */
 int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C);
 int rr_featmat_pass2_begin_devc(rr_featmat *fm, const double *m, const double *dC); /* C on the DEVICE */
+/* The same for rr_featmat_predict_rows only: C is kept in its upper-triangular form with doubled off-diagonal entries
+ * (phi^T C phi is all the variance needs) and the Phi C GEMM stops at the diagonal -- half the product.  c_on_device:
+ * C is a device pointer.  rr_featmat_pass2_rows / _rff must not follow this call. */
+int rr_featmat_predict_begin(rr_featmat *fm, const double *m, const double *C, int c_on_device);
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype);
 int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
                          double *dT);

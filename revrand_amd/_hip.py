@@ -119,6 +119,7 @@ SIGNATURES = {
                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_pass2_begin_devc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_predict_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "rr_rff_grad_contract": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                             ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                             ctypes.c_int, ctypes.c_int64, ctypes.c_void_p]),
@@ -546,19 +547,26 @@ class FeatureMatrix(object):
         _check(self.lib, self.lib.rr_featmat_put_host(self.h, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype),
                                                       Phi.shape[1], _ld(Phi), col0))
 
-    def pass2_begin(self, m, C):
-        """C: host (F, F) array or a device buffer / pointer (float64, rr_posterior_dev's output)."""
+    def pass2_begin(self, m, C, predict=False):
+        """C: host (F, F) array or a device buffer / pointer (float64, rr_posterior_dev's output).  predict: only
+        predict_rows follows (C is then kept in triangular form: half the Phi C product)."""
         m = np.ascontiguousarray(m, dtype=np.float64)
         if m.shape != (self.F,):
             raise ValueError("posterior shape does not match the feature matrix")
+        mp = m.ctypes.data_as(ctypes.c_void_p)
         if isinstance(C, np.ndarray):
             C = np.ascontiguousarray(C, dtype=np.float64)
             if C.shape != (self.F, self.F):
                 raise ValueError("posterior shape does not match the feature matrix")
-            _check(self.lib, self.lib.rr_featmat_pass2_begin(self.h, m.ctypes.data_as(ctypes.c_void_p),
-                                                             C.ctypes.data_as(ctypes.c_void_p)))
+            cp = C.ctypes.data_as(ctypes.c_void_p)
+            if predict:
+                _check(self.lib, self.lib.rr_featmat_predict_begin(self.h, mp, cp, 0))
+            else:
+                _check(self.lib, self.lib.rr_featmat_pass2_begin(self.h, mp, cp))
+        elif predict:
+            _check(self.lib, self.lib.rr_featmat_predict_begin(self.h, mp, _ptr(C), 1))
         else:
-            _check(self.lib, self.lib.rr_featmat_pass2_begin_devc(self.h, m.ctypes.data_as(ctypes.c_void_p), _ptr(C)))
+            _check(self.lib, self.lib.rr_featmat_pass2_begin_devc(self.h, mp, _ptr(C)))
 
     def pass2_rows(self, dy):
         _check(self.lib, self.lib.rr_featmat_pass2_rows(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0))

@@ -1146,7 +1146,7 @@ class BasisCat(object):
         Fp = (F + 255) // 256 * 256
         chunk = int(max(256, min(N, (24 << 30) // (12 * Fp))))
         fm = _hip.FeatureMatrix(chunk, F)
-        fm.pass2_begin(m, C)
+        fm.pass2_begin(m, C, predict=True)
         Ey, Vf = np.empty(N), np.empty(N)
         for r0 in range(0, N, chunk):
             Xc = X[r0:r0 + chunk]

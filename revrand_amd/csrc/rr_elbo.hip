@@ -779,6 +779,7 @@ struct FmPass2 {
     bool have_rows = false;
     void *Ab = nullptr, *Cb = nullptr;  // split-bf16 engine: K-blocked copies of Pt and C32
     bool cb_ready = false;              // Cb matches C32
+    bool tri_c = false;                 // prediction: C32 holds the upper-triangular form, the GEMM stops at the diagonal
     // GLM step / projection: FSt (max_rows, klp), its transpose DFS (klp, max_rows), the sample matrices
     float *FSt = nullptr, *DFS = nullptr, *WSt = nullptr, *WSs = nullptr, *Ed = nullptr, *Ee = nullptr;
     double *mc = nullptr;  // [m (F K) | C (F K) | Edm (K F) | EdC (K F)] of the device-sampled step
@@ -812,13 +813,14 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
             RR_CHECK_HIP(hipMalloc(&s.Cb, (size_t)fm->ld * fm->ld * 4));
         }
         int rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, fm->max_rows, s.C32, fm->ld, s.U, fm->ld, fm->ld, rows256,
-                                        fm->ld, s.Ab, s.Cb, s.cb_ready);
+                                        fm->ld, s.Ab, s.Cb, s.cb_ready, s.tri_c);
         s.cb_ready = true;
         return rc;
     }
     GemmArgs g;
     g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = fm->max_rows; g.ldb = fm->ld; g.ldd = fm->ld;
     g.K = (int)fm->ld; g.ntb = (int)(fm->ld / 256);
+    g.upper_b = s.tri_c ? 1 : 0;
     hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
@@ -1367,7 +1369,7 @@ int rr_rff_predict_devc(rr_basis *b, const void *dX, int x_dtype, int64_t N, int
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true);
 }
 
-static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool c_on_device) {
+static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool c_on_device, bool tri = false) {
     RR_REQUIRE(fm != nullptr && m != nullptr && C != nullptr, "rr_featmat_pass2_begin: null argument");
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
@@ -1384,25 +1386,34 @@ static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool
     RR_CHECK_HIP(hipMemcpy(s.m32, s.hm.data(), (size_t)Fp * 4, hipMemcpyHostToDevice));
     if (c_on_device) {
         hipLaunchKernelGGL(rr_c64_to_c32_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, C,
-                           (int64_t)F, s.C32, Fp);
+                           (int64_t)F, s.C32, Fp, tri ? 1 : 0);
         RR_CHECK_HIP(hipGetLastError());
     } else {
         s.hC.assign((size_t)Fp * Fp, 0.f);
         for (int i = 0; i < F; ++i) {
             const double *src = C + (size_t)i * F;
             float *dst = s.hC.data() + (size_t)i * Fp;
-            for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+            if (tri) {  // upper-triangular form with doubled off-diagonals: same quadratic form, half the product
+                dst[i] = (float)src[i];
+                for (int j = i + 1; j < F; ++j) dst[j] = 2.f * (float)src[j];
+            } else {
+                for (int j = 0; j < F; ++j) dst[j] = (float)src[j];
+            }
         }
         RR_CHECK_HIP(hipMemcpy(s.C32, s.hC.data(), s.hC.size() * 4, hipMemcpyHostToDevice));
     }
     RR_CHECK_HIP(hipMemsetAsync(s.sq, 0, 8, c->stream));
     s.have_rows = false;
     s.cb_ready = false;
+    s.tri_c = tri;
     return RR_OK;
 }
 
 int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) { return fm_pass2_begin(fm, m, C, false); }
 int rr_featmat_pass2_begin_devc(rr_featmat *fm, const double *m, const double *dC) { return fm_pass2_begin(fm, m, dC, true); }
+int rr_featmat_predict_begin(rr_featmat *fm, const double *m, const double *C, int c_on_device) {
+    return fm_pass2_begin(fm, m, C, c_on_device != 0, true);
+}
 
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_rows: call rr_featmat_pass2_begin first");
