@@ -4,23 +4,30 @@ bench.py -- feature-rows/sec of the hot path (Phi + Phi^T Phi + Phi^T y) on MI35
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json `metric`): RandomRBF, N = 10M rows, D = 32, F = 2*nbases = 4096,
-f32 arithmetic, synthetic Gaussian inputs resident in HBM before the timed region.  One
-"step" is one full pass of the fused kernel over this rank's rows: zero the (F,F)/(F,)
-accumulators, project + cos/sin + accumulate every row, (N>1: all-reduce the partial Gram
-over RCCL), mirror the triangle.  N>1 runs one process per GPU (torch.distributed.run sets
-RANK/LOCAL_RANK/WORLD_SIZE); rows are sharded across ranks (fixed global N -> "strong").
+Workload (BASELINE.json `metric`): RandomRBF, N = 10M rows, D = 32, F = 2*nbases = 4096, f32 arithmetic, synthetic
+Gaussian inputs resident in HBM before the timed region.  One "step" is one full pass of the path over this rank's rows:
+zero the (F,F)/(F,) accumulators, project + cos/sin + accumulate every row, (N>1: pack the upper triangle, ONE RCCL
+all-reduce of [tri G | b | yty | N], unpack) mirror the triangle.
+
+N > 1: one process per GPU, rows sharded across ranks (fixed global N -> "strong").  `python bench.py --gpus N` starts its
+own N ranks (RANK / LOCAL_RANK / WORLD_SIZE in the children's environment); under `python -m torch.distributed.run ...
+bench.py --gpus N` the launcher's environment is used as is.  Either way the exchange is RCCL bound directly through
+librevrand_hip.so's C ABI (rr_comm_*, revrand_amd/parallel.py) -- there is no torch in this process.
 
 Rank 0 prints ONE JSON line with the contract's keys plus
-  roofline     -- algorithmic flops of one launch / HIP-event time of the kernel, vs the
-                  f32 MFMA peak of gfx950 (157.3 TFLOP/s; MI355X_MICROARCH.md)
-  cpu_baseline -- the NumPy restatement of revrand's path (oracle/, kind "port") timed on
-                  this box's host cores over a bounded row sample (rank 0, N=1 only).
+  roofline     -- algorithmic flops of one launch / HIP-event time of the kernel, vs the f32 MFMA peak of gfx950
+                  (157.3 TFLOP/s; MI355X_MICROARCH.md)
+  cpu_baseline -- the NumPy restatement of revrand's path (oracle/, kind "port") timed on this box's host cores over a
+                  bounded row sample (rank 0, N=1 only), SURVEY 8d's recipe: 200 000 rows, median of 3
+  configs      -- BASELINE.json's other configurations on this GPU (N=1 only): C2, C3 (one GPU's share), C4, C5 and the
+                  headline shape in f64 arithmetic, each with its own roofline fraction and a bounded cpu sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -29,9 +36,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X_MICROARCH.md "Peak FP64 (matrix)"
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense (same rate for fp16)
+PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md HBM3E
 
-# HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools_prof.sh),
+# HBM-side traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (tools/prof.sh),
 # corrected as MI355X_MICROARCH.md prescribes; the committed summary is quoted, per launch.
 TRAFFIC = {}
 try:
@@ -41,8 +50,8 @@ except Exception:
     pass
 
 
-def flops_per_row(d, n):
-    F = 2 * n
+def flops_per_row(d, n, F=None):
+    F = 2 * n if F is None else F
     return 2.0 * d * n + F * (F + 1.0) + 2.0 * F  # projection + upper-tri Gram + Phi^T y
 
 
@@ -54,24 +63,399 @@ def gen_chunk(c, rows, d, wvec):
     return X, y.astype(np.float32)
 
 
-def cpu_baseline(d, n, W, wvec, sample_rows):
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import revrand_oracle as orc  # checker/baseline only -- never on the product path
-    X, y = gen_chunk(10 ** 6, sample_rows, d, wvec)
-    X64, y64 = X.astype(np.float64), y.astype(np.float64)
-    orc.rff_gram_chunked(X64[:2000], y64[:2000], W, 1.0, chunk=1000)  # warm BLAS
-    t0 = time.perf_counter()
-    orc.rff_gram_chunked(X64, y64, W, 1.0, chunk=10000)
-    dt = time.perf_counter() - t0
+    return orc
+
+
+def _blas_threads():
     threads = os.cpu_count()
+    info = None
     try:
         from threadpoolctl import threadpool_info
-        nt = [p.get("num_threads", 0) for p in threadpool_info() if p.get("user_api") == "blas"]
+        info = [{k: p.get(k) for k in ("user_api", "internal_api", "num_threads", "version")} for p in threadpool_info()]
+        nt = [p.get("num_threads", 0) for p in info if p.get("user_api") == "blas"]
         threads = max(nt) if nt else threads
     except Exception:
         pass
-    return {"value": sample_rows / dt, "unit": "feature-rows/s", "cores": int(threads), "kind": "port",
-            "sample": "%d rows of the same workload, f64, 10000-row chunks, %.1f s" % (sample_rows, dt)}
+    return int(threads), info
+
+
+def cpu_baseline(d, n, W, wvec, sample_rows, budget_s=100.0):
+    """the oracle's chunk-accumulated f64 path (10 000-row chunks) over a 200 000-row sample, wall-clock median
+    of 3 (fewer when the budget is exhausted -- said in `sample`), BLAS on all host cores."""
+    orc = _oracle()
+    X, y = gen_chunk(10 ** 6, sample_rows, d, wvec)
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    orc.rff_gram_chunked(X64[:2000], y64[:2000], W, 1.0, chunk=1000)  # warm BLAS
+    times, t_all = [], time.perf_counter()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        orc.rff_gram_chunked(X64, y64, W, 1.0, chunk=10000)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all + times[-1] > budget_s:
+            break
+    dt = float(np.median(times))
+    threads, info = _blas_threads()
+    sys.stderr.write("cpu_baseline: os.cpu_count()=%s threadpool_info=%s\n" % (os.cpu_count(), json.dumps(info)))
+    return {"value": sample_rows / dt, "unit": "feature-rows/s", "cores": threads, "kind": "port",
+            "sample": "%d rows of the same workload, f64, 10000-row chunks, median of %d runs (%s s)" % (
+                sample_rows, len(times), ", ".join("%.1f" % t for t in times)),
+            "os_cpu_count": os.cpu_count()}
+
+
+# ----------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without a launcher's environment starts its own N ranks
+# ----------------------------------------------------------------------------------------------------
+
+def launch(args, argv):
+    from revrand_amd import _hip
+    n = _hip.ctypes.c_int()
+    lib = _hip.load_library()
+    ndev = n.value if lib.rr_device_count(_hip.ctypes.byref(n)) == 0 else 0
+    if ndev <= 0:
+        raise SystemExit("bench.py: no HIP device visible (the hot path has no CPU fallback)")
+    world = args.gpus
+    rdzv_dir = tempfile.mkdtemp(prefix="rr_bench_")
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(r % ndev), "MASTER_ADDR": "127.0.0.1",
+                    "RR_COMM_RDZV": "file:" + os.path.join(rdzv_dir, "rccl.id"), "RR_BENCH_VISIBLE_GPUS": str(ndev)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world > ndev:
+            # fewer GPUs than ranks (plumbing runs on a 1-GPU box): RCCL refuses two ranks on one device of one host,
+            # so every rank claims its own host id and the exchange takes RCCL's socket transport
+            env["NCCL_HOSTID"] = "rr-bench-rank-%d" % r
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a rank failed: its peers would wait in the collective forever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        try:
+            for f in os.listdir(rdzv_dir):
+                os.unlink(os.path.join(rdzv_dir, f))
+            os.rmdir(rdzv_dir)
+        except OSError:
+            pass
+    raise SystemExit(rc)
+
+
+# ----------------------------------------------------------------------------------------------------
+# BASELINE.json's other configurations on this GPU (N = 1 only; never `value`)
+# ----------------------------------------------------------------------------------------------------
+
+def _timed(dev, fn, reps):
+    """Median wall-clock of fn() with the device idle before and after (ms)."""
+    ts = []
+    for _ in range(reps):
+        dev.sync()
+        t0 = time.perf_counter()
+        fn()
+        dev.sync()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return float(np.median(ts))
+
+
+def config_c2(dev, _hip, args):
+    """configs[1]: RandomRBF F=4096, D=32, N=1M fp32: Phi + Phi^T Phi (+ Phi^T y)."""
+    d, n, N = 32, 2048, 1_000_000
+    F = 2 * n
+    W = np.random.RandomState(42).randn(d, n)
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    basis = _hip.RffHandle(W, compute="f32")
+    X, y = gen_chunk(77, N, d, wvec)
+    dX, dy = basis.upload(X), dev.upload_vector(y)
+    acc = dev.zeros((F * F + F + 1) * 8)
+    p = [_hip.ctypes.c_void_p(acc.ptr.value + o * 8) for o in (0, F * F, F * F + F)]
+    kms = []
+
+    def step():
+        dev.memset(acc)
+        basis.gram_dev(dX, dy, 1.0, *p)
+        kms.append(basis.gram_timings())
+        basis.symmetrize_dev(p[0])
+    step()
+    kms.clear()
+    ms = _timed(dev, step, 3)
+    syrk = float(np.mean([k[1] + k[2] for k in kms]))
+    feat = float(np.mean([k[0] for k in kms]))
+    orc = _oracle()
+    ns = 40_000
+    t0 = time.perf_counter()
+    orc.rff_gram_chunked(X[:ns].astype(np.float64), y[:ns].astype(np.float64), W, 1.0, chunk=10000)
+    tc = time.perf_counter() - t0
+    for b in (dX, dy, acc):
+        b.free()
+    return {"workload": "RandomRBF nbases=2048 (F=4096), D=32, N=1M f32: features + MFMA Gram, resident", "rows": N,
+            "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32",
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "whole_path_achieved": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12,
+                         "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
+                         "syrk_frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "cpu_baseline": {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
+                             "sample": "%d rows, f64, 10000-row chunks, one run %.1f s" % (ns, tc)}}
+
+
+def config_f64(dev, _hip, args):
+    """The headline shape in the reference's own arithmetic (float64 features, f64 MFMA Gram)."""
+    d, n, N = 32, 2048, 500_000
+    F = 2 * n
+    W = np.random.RandomState(42).randn(d, n)
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    basis = _hip.RffHandle(W, compute="f64")
+    X, y = gen_chunk(78, N, d, wvec)
+    dX, dy = basis.upload(X.astype(np.float64)), dev.upload_vector(y.astype(np.float64))
+    acc = dev.zeros((F * F + F + 1) * 8)
+    p = [_hip.ctypes.c_void_p(acc.ptr.value + o * 8) for o in (0, F * F, F * F + F)]
+    kms = []
+
+    def step():
+        dev.memset(acc)
+        basis.gram_dev(dX, dy, 1.0, *p)
+        kms.append(basis.gram_timings())
+        basis.symmetrize_dev(p[0])
+    step()
+    kms.clear()
+    ms = _timed(dev, step, 3)
+    syrk = float(np.mean([k[1] + k[2] for k in kms]))
+    feat = float(np.mean([k[0] for k in kms]))
+    G = dev.download(acc, (F, F), np.float64)
+    trace_err = abs(float(np.trace(G)) - N) / N
+    # parity of this very pass on its first rows against the f64 oracle
+    orc = _oracle()
+    ns = 4096
+    dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value), (ns, d), dX.ld, np.float64)
+    dys = _hip.DeviceView(dy, 0, ns)
+    dev.memset(acc)
+    basis.gram_dev(dXs, dys, 1.0, *p)
+    basis.symmetrize_dev(p[0])
+    dXs.ptr = None
+    Gs = dev.download(acc, (F, F), np.float64)
+    Gr, _, _ = orc.rff_gram_chunked(X[:ns].astype(np.float64), y[:ns].astype(np.float64), W, 1.0)
+    perr = float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
+    assert perr < 1e-10, perr
+    for b in (dX, dy, acc):
+        b.free()
+    return {"workload": "RandomRBF nbases=2048 (F=4096), D=32, N=500k, float64 arithmetic end to end", "rows": N,
+            "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f64",
+            "trace_rel_err": trace_err, "parity_rel_err_4096_rows_vs_oracle": perr,
+            "roofline": {"bound": "mfma", "kernel": basis.gram_kernel_name(), "peak": PEAK_F64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
+                         "achieved": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12,
+                         "frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+
+
+def config_c3(dev, _hip, args):
+    """configs[2], one GPU's share: RandomMatern52 n=4096 + LinearBasis, D=64, N = 10M / 8 rows."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    d, n, N = 64, 4096, 1_250_000
+    rng = np.random.default_rng([20260928, 3])
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    w = rng.standard_normal(d, dtype=np.float32)
+    y = (np.sin(X @ w / np.sqrt(d)) + 0.1 * rng.standard_normal(N, dtype=np.float32)).astype(np.float32)
+    cat = bs.RandomMatern52(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
+    st = cat.device_fit_state(X, y)
+    F = st.F
+    hyp = [np.ones(d)]
+    st.gram_device(hyp)
+    ms = _timed(dev, lambda: st.gram_device(hyp), 3)
+    # size-independent property on the full-size result: trace of the random Fourier block == N
+    G, b, yty = st.stats_host()
+    tr = abs(float(np.trace(G[:2 * n, :2 * n])) - N) / N
+    assert tr < 1e-5 and G[2 * n, 2 * n] == N and np.array_equal(G, G.T), tr
+    st.release()
+    orc = _oracle()
+    ns = 8000
+    Xs, ys = X[:ns].astype(np.float64), y[:ns].astype(np.float64)
+    Wm = cat.bases[0].W
+    t0 = time.perf_counter()
+    Phi = np.hstack((orc.rff_transform(Xs, Wm, np.ones(d)), orc.linear_transform(Xs, True)))
+    orc.gram_stats(Phi, ys)
+    tc = time.perf_counter() - t0
+    fl = 2.0 * d * n + F * (F + 1.0) + 2.0 * F
+    return {"workload": "RandomMatern52 nbases=4096 + LinearBasis(onescol), D=64, F_tot=%d, N=1.25M (= 10M / 8 GPUs): "
+                        "device-side concatenation + MFMA Gram, resident" % F, "rows": N, "ms_per_pass": ms,
+            "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32", "trace_rel_err_rff_block": tr,
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "flops_per_row": fl,
+                         "achieved": fl * N / (ms * 1e-3) / 1e12, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "note": "whole pass (feature assembly + both SYRK kernels + mirror) on algorithmic flops"},
+            "exchange_bytes_per_evaluation": 8 * (F * (F + 1) // 2 + F + 2),
+            "cpu_baseline": {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
+                             "sample": "%d rows, f64 transform + hstack + Phi^T Phi, one run %.1f s" % (ns, tc)}}
+
+
+def config_c4(dev, _hip, args):
+    """configs[3]: FastFoodRBF nbases=8192, D=128 (F=16384): the Hadamard / permute / diagonal chain, Phi streamed in
+    262 144-row chunks into a two-slot device ring (Phi for N=4M is 262 GB in f32)."""
+    import revrand_amd.basis_functions as bs
+    d, nb, CH, NCH = 128, 8192, 262_144, 4
+    f = bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=1)
+    h = f._handles()[0]  # the chain kernel's handle (rr_fastfood_*)
+    F = 2 * h.n
+    rng = np.random.default_rng([20260928, 4])
+    X = rng.standard_normal((CH * NCH, d), dtype=np.float32)
+    dX = dev.upload_matrix(X)
+    ring = [dev.malloc(CH * F * 4) for _ in range(2)]
+
+    def pass_():
+        for c in range(NCH):
+            v = _hip.DeviceView(dX, c * CH, CH)
+            h.transform_dev(v, 1.0, ring[c & 1], np.float32)
+    pass_()
+    dev.sync()
+    dev.timer_start()
+    reps = 3
+    for _ in range(reps):
+        pass_()
+    kms = dev.timer_stop() / reps
+    N = CH * NCH
+    # parity of the last chunk's first rows against the oracle chain
+    orc = _oracle()
+    ns = 256
+    out = dev.download(ring[(NCH - 1) & 1], (ns, F), np.float32)
+    ref = orc.fastfood_transform(X[(NCH - 1) * CH:(NCH - 1) * CH + ns].astype(np.float64), f.B, f.G, f.PI, f.S, 1.0)
+    perr = float(np.abs(out - ref).max() / np.abs(ref).max())
+    assert perr < 1e-3, perr
+    # unit row norm: sum_j Phi_j^2 = 1 for every row (cos^2 + sin^2 over n frequencies, / n)
+    nrm = float(np.abs((out.astype(np.float64) ** 2).sum(axis=1) - 1.0).max())
+    assert nrm < 1e-4, nrm
+    t0 = time.perf_counter()
+    nc = 2000
+    orc.fastfood_transform(X[:nc].astype(np.float64), f.B, f.G, f.PI, f.S, 1.0)
+    tc = time.perf_counter() - t0
+    dX.free()
+    for r in ring:
+        r.free()
+    bytes_row = 4.0 * d + 4.0 * F
+    return {"workload": "FastFoodRBF nbases=8192, D=128 (F=%d), N=%d device-resident rows per pass in %d chunks of %d "
+                        "into a 2-slot ring, f32" % (F, N, NCH, CH), "rows": N, "ms_per_pass": kms,
+            "value": N / (kms * 1e-3), "unit": "feature-rows/s", "dtype": "f32", "parity_rel_err_256_rows_vs_oracle": perr,
+            "roofline": {"bound": "hbm", "kernel": "rr_fastfood16_kernel", "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                         "bytes_per_row": bytes_row, "rows_per_launch": CH, "avg_launch_ms": kms / NCH,
+                         "achieved": bytes_row * N / (kms * 1e-3) / 1e9,
+                         "frac": bytes_row * N / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS},
+            "cpu_baseline": {"value": nc / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
+                             "sample": "%d rows through the oracle's NumPy FWHT chain, %.1f s" % (nc, tc)}}
+
+
+def config_c5(dev, _hip, args):
+    """configs[4]: GLM Poisson, RandomRBF F=2048, D=32 ARD, N=2M resident, K=10, L=50, minibatch 65 536: one SVI
+    minibatch `_elbo` (Phi + ELBO gradients incl. the length-scale gradient)."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    N, d, n, K, L, M = 2_000_000, 32, 1024, 10, 50, 65536
+    F = 2 * n
+    rng = np.random.default_rng([20260928, 5])
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    y = rng.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(np.float64)
+    rs = np.random.RandomState(0)
+    m = 0.1 * rs.randn(F, K)
+    C = rs.gamma(2., 0.5, size=(F, K))
+    ls = np.linspace(0.8, 1.5, d)
+    out = {}
+    gemm_flops = 3 * 2.0 * K * L * M * F
+    for sampler in ("host", "device"):
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        glm = GeneralizedLinearModel(lk.Poisson(), basis, K=K, nsamples=L, batch_size=M, random_state=2, sampler=sampler)
+        glm.B_, glm.D_ = N / M, F
+        glm._GeneralizedLinearModel__it = 1  # a plain SGD iteration (no ELBO logging)
+        feats = glm._features()
+        glm._resident_fit = feats.make_resident(X)
+        assert glm._resident_fit
+        perm = rs.permutation(N)
+        Xstub = np.empty((M, 0))
+
+        def step(i):
+            idx = perm[(i * M) % (N - M):(i * M) % (N - M) + M]
+            return glm._elbo(m, C, 1.0, [], ls, Xstub, y[idx], idx)
+        step(0)
+        dev.sync()
+        reps = 8
+        t0 = time.perf_counter()
+        for i in range(reps):
+            step(i + 1)
+        dev.sync()
+        ms = 1e3 * (time.perf_counter() - t0) / reps
+        out[sampler] = {"elbo_step_ms": ms, "minibatch_rows_per_s": M / (ms * 1e-3)}
+        if sampler == "device":
+            # the device calls of one step alone (feature assembly, the step's kernels incl. its three MFMA GEMMs, the
+            # length-scale contraction, 0.6 MB back): wall-clock, so launch gaps and the small transfers are inside
+            idx = perm[:M]
+            t0 = time.perf_counter()
+            for i in range(reps):
+                feats.assemble_idx(idx, [ls])
+                feats.glm_step_sampled(y[idx], None, lk.RR_LIK_POISSON_EXP, 0.0, m, C, K, L, 7, i)
+                feats.glm_basis_grads(Xstub)
+            dev.sync()
+            dms = 1e3 * (time.perf_counter() - t0) / reps
+            out[sampler]["device_calls_ms"] = dms
+            out[sampler]["host_ms"] = ms - dms
+            out[sampler]["gemm_tflops_over_device_calls"] = gemm_flops / (dms * 1e-3) / 1e12
+        glm._resident_fit = False
+        glm._release_features()
+    orc = _oracle()
+    Mc = 1024
+    Xc, yc = X[:Mc].astype(np.float64), y[:Mc]
+    W = basis.W
+    e = rs.randn(K, L, F)
+    t0 = time.perf_counter()
+    Phi = orc.rff_transform(Xc, W, ls)
+    dP = orc.rff_grad(Xc, W, ls)
+    orc.glm_elbo(m, C, np.ones(F), slice(None), "poisson_exp", [], (), Phi, [dP[:, :, i] for i in range(d)], yc, e, N / M)
+    tc = time.perf_counter() - t0
+    best = out["device"]
+    return {"workload": "GeneralizedLinearModel Poisson, RandomRBF nbases=1024 (F=2048), D=32 ARD, N=2M resident, K=10, "
+                        "L=50, minibatch 65536: one SVI _elbo (Phi, ELBO gradients, length-scale gradient)",
+            "rows_per_step": M, "value": out["host"]["minibatch_rows_per_s"], "unit": "minibatch-rows/s", "dtype": "f32",
+            "sampler_host_reference_random_stream": out["host"], "sampler_device": out["device"],
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "gemm_flops_per_step": gemm_flops,
+                         "achieved": best["gemm_tflops_over_device_calls"],
+                         "frac": best["gemm_tflops_over_device_calls"] / PEAK_F32_MFMA_TFLOPS,
+                         "note": "the step's three (K L) x M x F GEMMs over the wall-clock of ALL device calls of a step "
+                                 "(features, likelihood kernel, contraction, launch gaps included); per-kernel times in "
+                                 "profiles/"},
+            "cpu_baseline": {"value": Mc / tc, "unit": "minibatch-rows/s", "cores": _blas_threads()[0], "kind": "port",
+                             "sample": "%d-row minibatch through the oracle (transform, (M, F, d) grad, glm_elbo), %.1f s"
+                                       % (Mc, tc)}}
+
+
+def extra_configs(dev, _hip, args):
+    res = {}
+    for name, fn in (("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
+                     ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
+                     ("C5_glm_poisson_svi_step", config_c5)):
+        if args.configs != "all" and name.split("_")[0].lower() not in args.configs.lower().split(","):
+            continue
+        t0 = time.perf_counter()
+        try:
+            res[name] = fn(dev, _hip, args)
+            res[name]["bench_seconds"] = time.perf_counter() - t0
+        except Exception as e:  # a failing side configuration must not take the headline line with it -- but it is said
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            sys.stderr.write("bench.py: config %s failed: %r\n" % (name, e))
+    return res
 
 
 def main():
@@ -82,14 +466,19 @@ def main():
     ap.add_argument("--rows", type=int, default=10_000_000, help="global N")
     ap.add_argument("--dim", type=int, default=32)
     ap.add_argument("--nbases", type=int, default=2048)
-    ap.add_argument("--cpu-sample", type=int, default=150000)
+    ap.add_argument("--cpu-sample", type=int, default=200000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", choices=["f32", "bf16x3", "bf16x4", "fp16x3"], default=None,
                     help="arithmetic of the Gram (default: f32 MFMA, or $RR_SYRK_ENGINE); see DESIGN.md 3.13")
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational fp16x3 measurement")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the 2048-row oracle check before timing (profiling runs: keeps per-kernel averages clean)")
+    ap.add_argument("--configs", default="all",
+                    help="BASELINE's other configurations to time after the headline at N=1: all | none | e.g. c3,c5,headline")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch(args, sys.argv[1:])
 
     # stdout carries exactly ONE line (the JSON).  RCCL writes its version banner and warnings to file descriptor 1
     # from its own threads, so fd 1 is pointed at stderr for the whole run and the JSON goes to a private duplicate.
@@ -101,27 +490,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch --gpus %d with: python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node %d --master-addr 127.0.0.1 bench.py --gpus %d ..." %
-                             (args.gpus, args.gpus, args.gpus))
         args.gpus = world
-
-    dist = None
-    torch = None
-    use_dist = world > 1 or os.environ.get("RR_BENCH_FORCE_DIST") == "1"  # the latter: plumbing check at N=1
-    if use_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout (one JSON line)
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner out of the logs
 
     from revrand_amd import _hip, parallel
     dev = _hip.get_device(local_rank)
+    use_comm = world > 1 or os.environ.get("RR_BENCH_FORCE_DIST") == "1"  # the latter: plumbing check at N=1
+    comm = parallel.init_rccl_from_env(device=local_rank) if use_comm else parallel.SingleComm()
+    parallel.set_comm(comm)
+    rank, world = comm.rank, comm.world  # as RCCL reports them
+
     d, n = args.dim, args.nbases
     F = 2 * n
     W = np.random.RandomState(42).randn(d, n)
@@ -152,19 +531,15 @@ def main():
         r0 += hi - lo
     assert r0 == my_rows
 
-    # ---- accumulators: [G (F*F) | b (F) | yty (1)] float64, one buffer so one all-reduce ----
+    # ---- accumulators: [G (F*F) | b (F) | yty (1)] float64 ----
     nacc = F * F + F + 1
-    if use_dist:
-        acc_t = torch.zeros(nacc, dtype=torch.float64, device="cuda:%d" % local_rank)
-        acc_ptr = acc_t.data_ptr()
-        torch.cuda.synchronize()
-    else:
-        acc_buf = dev.zeros(nacc * 8)
-        acc_ptr = acc_buf.ptr.value
+    acc_buf = dev.zeros(nacc * 8)
+    acc_ptr = acc_buf.ptr.value
     pG = _hip.ctypes.c_void_p(acc_ptr)
     pb = _hip.ctypes.c_void_p(acc_ptr + F * F * 8)
     pt = _hip.ctypes.c_void_p(acc_ptr + (F * F + F) * 8)
     kernel_ms = []
+    exch_ms = []
 
     def step(timed):
         _hip._check(dev.lib, dev.lib.rr_memset(dev.ctx, pG, 0, nacc * 8))
@@ -172,28 +547,27 @@ def main():
             basis.gram_dev(dX, dy, 1.0, pG, pb, pt)
             if timed:
                 kernel_ms.append(basis.gram_timings())  # HIP events on the kernels' own stream
-        dev.sync()
-        if use_dist:
-            if world > 1:
-                parallel.allreduce_packed(acc_t)  # RCCL over xGMI: the one exchange step of the path
-            else:
-                dist.all_reduce(acc_t)  # N=1 plumbing check only
-            torch.cuda.synchronize()
-        _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
+        if use_comm:
+            # the one exchange step of the path: pack the upper triangle, ncclAllReduce over xGMI, unpack + mirror --
+            # all on the context's stream behind the Gram kernels
+            if timed:
+                dev.timer_start()
+            comm.reduce_stats_device(F, pG, pb, pt, my_rows, wait=False)
+            if timed:
+                exch_ms.append(dev.timer_stop())
+        else:
+            _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, pG, F))
         dev.sync()
 
     def barrier():
         dev.sync()
-        if use_dist:
-            torch.cuda.synchronize()
-            dist.barrier()
+        comm.barrier()
 
     # ---- parity of the measured path on a slice, off-diagonal entries included: Gram of the first rows against the
     # oracle (checker only) before anything is timed ----
     parity_err = None
     if rank == 0 and my_rows >= 2048 and not args.no_parity_check:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import revrand_oracle as orc
+        orc = _oracle()
         Xs, ys = gen_chunk(row0 // CH, min(CH, args.rows - (row0 // CH) * CH), d, wvec)
         lo = row0 - (row0 // CH) * CH
         Xs, ys = Xs[lo:lo + 2048], ys[lo:lo + 2048]
@@ -208,10 +582,7 @@ def main():
             dev.sync()
             dXs.ptr = None
             dys.ptr = None
-            if use_dist:
-                Gs = acc_t[:F * F].view(F, F).cpu().numpy()
-            else:
-                Gs = dev.download(acc_buf, (F, F), np.float64)
+            Gs = dev.download(acc_buf, (F, F), np.float64)
             Gr, _, _ = orc.rff_gram_chunked(Xs.astype(np.float64), ys.astype(np.float64), W, 1.0)
             parity_err = float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
             assert parity_err < 1e-4 or os.environ.get("RR_GRAM_ABLATE"), parity_err
@@ -224,23 +595,18 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda:%d" % local_rank)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = float(comm.allreduce_host(np.array([elapsed]), op="max")[0])  # MAX over ranks
 
-    # sanity on the result of the last step: trace(G) == N (cos^2 + sin^2 = 1 per frequency)
-    if use_dist:
-        diag = acc_t[:F * F].view(F, F).diagonal().sum().item()
-    else:
-        G = dev.download(acc_buf, (F, F), np.float64)
-        diag = float(np.trace(G))
-        assert np.array_equal(G, G.T) or os.environ.get("RR_GRAM_ABLATE")
+    # sanity on the result of the last step (every rank holds the global statistics): trace(G) == N
+    # (cos^2 + sin^2 = 1 per frequency), exactly symmetric, summed row count == N
+    G = dev.download(acc_buf, (F, F), np.float64)
+    diag = float(np.trace(G))
+    assert np.array_equal(G, G.T) or os.environ.get("RR_GRAM_ABLATE")
     trace_err = abs(diag - args.rows) / args.rows
 
     # ---- informational: the same step on the split-fp16 engine (N=1 only; never `value`) ----
     alt = None
-    if world == 1 and not use_dist and engine == "f32" and not args.no_alt_engine and not os.environ.get("RR_GRAM_ABLATE"):
+    if world == 1 and not use_comm and engine == "f32" and not args.no_alt_engine and not os.environ.get("RR_GRAM_ABLATE"):
         dev.set_gram_engine("fp16x3")
         step(False)
         dev.sync()
@@ -253,7 +619,6 @@ def main():
         dev.sync()
         alt_elapsed = (time.perf_counter() - ta) / nalt
         G3 = dev.download(acc_buf, (F, F), np.float64)
-        Gr_alt = None
         alt = {"engine": "fp16x3", "value": args.rows / alt_elapsed, "unit": "feature-rows/s",
                "ms_per_step": 1e3 * alt_elapsed, "steps": nalt,
                "max_abs_diff_vs_f32_engine_over_max_G": float(np.abs(G3 - G).max() / np.abs(G).max()),
@@ -270,6 +635,7 @@ def main():
         alt["mfma_issued_frac_of_fp16_peak"] = alt["mfma_issued_tflops"] / PEAK_BF16_MFMA_TFLOPS
         alt["algorithmic_tflops"] = F * (F + 1.0) * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
         dev.set_gram_engine("f32")
+    del G
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
@@ -314,6 +680,14 @@ def main():
                          "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
                          / world / 1e12 / PEAK_F32_MFMA_TFLOPS},
         }
+        if use_comm:
+            cnt = parallel.stats_count(F)
+            out["exchange"] = {"transport": "RCCL ncclAllReduce(ncclDouble, ncclSum), bound directly (librevrand_hip rr_comm_*)",
+                               "rccl": dict(zip(("version", "library"), parallel.RcclComm.load())),
+                               "ranks_rccl_reports": world, "message_float64": cnt, "message_bytes": 8 * cnt,
+                               "ms_per_step_pack_allreduce_unpack": float(np.mean(exch_ms)) if exch_ms else None,
+                               "visible_gpus": int(os.environ.get("RR_BENCH_VISIBLE_GPUS", "0")) or None,
+                               "oversubscribed": bool(os.environ.get("NCCL_HOSTID", "").startswith("rr-bench-rank-"))}
         if engine != "f32":
             # split-bf16 engine: one SYRK kernel over all 136 tiles; the roofline is the bf16 matrix pipe, `achieved`
             # stays ALGORITHMIC flops (the kernel issues 3 or 4 bf16 products per f32 product: `issued_frac`)
@@ -336,11 +710,19 @@ def main():
             out["split_fp16_engine"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
+    ok = trace_err < (1e-6 if engine == "f32" else 1e-5) or os.environ.get("RR_GRAM_ABLATE")
+    if rank == 0 and world == 1 and not use_comm and args.configs != "none" and engine == "f32" and ok:
+        # free the headline's buffers first: C3 / C4 want tens of GB
+        for b in (dX, dy, acc_buf):
+            b.free()
+        del basis
+        out["configs"] = extra_configs(dev, _hip, args)
+    if rank == 0:
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
-    if use_dist:
-        dist.destroy_process_group()
-    assert trace_err < (1e-6 if engine == "f32" else 1e-5) or os.environ.get("RR_GRAM_ABLATE"), trace_err
+    comm.barrier()
+    comm.close()
+    assert ok, trace_err
 
 
 if __name__ == "__main__":

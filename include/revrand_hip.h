@@ -20,7 +20,8 @@
  *    *_dev calls take DEVICE pointers (from rr_malloc, or any hipMalloc'd memory
  *    of the same device, e.g. a torch tensor's data_ptr) and are asynchronous on
  *    the context's stream unless stated; rr_ctx_sync() waits for them.
- *  - One rr_ctx per process per GPU (one process per GPU is the scaling model).
+ *  - One rr_ctx per process per GPU (one process per GPU is the scaling model); the ranks'
+ *    partial statistics are summed with the rr_comm_* entry points (RCCL, bound directly).
  *  - There is no CPU fallback: without a usable gfx950 device rr_ctx_create fails
  *    with RR_ERR_NO_DEVICE.
  */
@@ -133,8 +134,10 @@ int rr_rff_transform_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N
                          int64_t ldphi);
 
 /* The metric's unit of work: for every row, project, cos/sin, scale and
- * accumulate   G += phi phi^T (F x F, F = 2n),  b += phi y,  yty += y^2
- * without ever writing Phi to HBM.  Replaces, for a random Fourier basis,
+ * accumulate   G += phi phi^T (F x F, F = 2n),  b += phi y,  yty += y^2.
+ * Two kernels per row chunk: the feature kernel writes the chunk's Phi into an f32 SCRATCH the basis owns
+ * (4 * Fp bytes per row, Fp = F rounded up to 256; never returned, never crossing PCIe) and the MFMA SYRK
+ * kernels reduce it (DESIGN.md 3.1 has the measurement behind that split).  Replaces, for a random Fourier basis,
  *   Phi = basis.transform(X, l)      slm.py:145 (basis_functions.py:859-864)
  *   PhiPhi = Phi.T.dot(Phi)          slm.py:146
  *   Phi.T.dot(y)                     slm.py:157
@@ -361,6 +364,53 @@ int rr_hadamard(rr_ctx *ctx, const void *Y, int dtype, int64_t rows, int64_t n, 
 
 /* Name of the dominant kernel the last rr_rff_gram_dev launched (for profiles). */
 const char *rr_rff_gram_kernel_name(rr_basis *basis);
+
+/* ---- multi-GPU: the one exchange step of the path --------------------------------
+ * Rows shard across GPUs, one process (and one rr_ctx) per GPU.  What is summed over the ranks is what
+ * slm.py:145-157 computes from ALL rows: PhiPhi = Phi.T.dot(Phi) (:146), Phi.T.dot(y) (:157), plus y^T y and N
+ * (the ELBO of :165-171 needs them), and after the replicated Cholesky the 1 + d numbers [sqErr | dhyp] of
+ * :161-162,193-197.  RCCL (librccl.so.1) is bound directly with dlopen -- no PyTorch in the process -- and the
+ * collectives run on the context's stream, ordered after the Gram kernels that produce their input.
+ *
+ *   rr_comm_unique_id      ncclGetUniqueId: 128 bytes that rank 0 hands to every other rank (file, socket, ...)
+ *   rr_comm_init_rank      ncclCommInitRank on ctx's device; collective over all `world` ranks
+ *   rr_comm_info           rank / world AS RCCL REPORTS THEM (ncclCommUserRank / ncclCommCount)
+ *   rr_comm_allreduce_dev  in-place ncclAllReduce(ncclDouble) of a DEVICE float64 buffer, asynchronous on the stream
+ *   rr_comm_allreduce_host the same for a small HOST vector (staged through HBM), synchronous
+ *   rr_comm_broadcast_host root's host bytes to every rank (random start points etc.), synchronous
+ *   rr_comm_barrier        all ranks arrived and their streams are idle
+ *   rr_comm_load           optional: path of the librccl to bind (default: $RR_RCCL_LIB, an already loaded
+ *                          librccl.so.1, /opt/rocm/lib/librccl.so.1); rr_comm_version reports version and path. */
+typedef struct rr_comm rr_comm;
+#define RR_COMM_ID_BYTES 128
+#define RR_COMM_SUM 0
+#define RR_COMM_MAX 1
+#define RR_COMM_MIN 2
+int rr_comm_load(const char *path);
+int rr_comm_version(int *version, char *path, size_t path_len);
+int rr_comm_unique_id(void *id /* RR_COMM_ID_BYTES */);
+int rr_comm_init_rank(rr_ctx *ctx, int rank, int world, const void *id, rr_comm **out);
+void rr_comm_destroy(rr_comm *comm);
+int rr_comm_info(rr_comm *comm, int *rank, int *world);
+int rr_comm_allreduce_dev(rr_comm *comm, double *dbuf, int64_t count, int op);
+int rr_comm_allreduce_host(rr_comm *comm, double *hbuf, int64_t count, int op);
+int rr_comm_broadcast_host(rr_comm *comm, void *hbuf, int64_t bytes, int root);
+int rr_comm_barrier(rr_comm *comm);
+
+/* The message of the exchange: [ upper triangle of G, row-major, row i = G[i][i..F) | b (F) | yty | nrows ],
+ * rr_stats_msg_count(F) = F (F + 1) / 2 + F + 2 float64 -- 67 MB at F = 4096 where the full square is 134 MB.
+ *   rr_stats_pack_dev    from the accumulators rr_rff_gram_dev / rr_featmat_gram wrote (upper triangle of dG valid);
+ *                        db / dyty may be NULL (zeros are sent)
+ *   rr_stats_unpack_dev  back into dG as the FULL symmetric matrix (mirrors like rr_symmetrize_dev), db, dyty
+ *   rr_comm_reduce_stats_dev   pack -> ncclAllReduce(sum) -> unpack on the context's stream; dmsg is a DEVICE scratch of
+ *                        rr_stats_msg_count(F) float64.  total_rows != NULL: waits and returns the summed N.
+ * All DEVICE pointers, asynchronous on the context's stream unless stated. */
+int64_t rr_stats_msg_count(int64_t F);
+int rr_stats_pack_dev(rr_ctx *ctx, int64_t F, const double *dG, const double *db, const double *dyty, double nrows,
+                      double *dmsg);
+int rr_stats_unpack_dev(rr_ctx *ctx, int64_t F, const double *dmsg, double *dG, double *db, double *dyty);
+int rr_comm_reduce_stats_dev(rr_comm *comm, int64_t F, double *dG, double *db, double *dyty, double nrows, double *dmsg,
+                             double *total_rows);
 
 #ifdef __cplusplus
 }

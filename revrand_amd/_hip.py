@@ -150,6 +150,24 @@ SIGNATURES = {
     "rr_hadamard": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_int, ctypes.c_void_p]),
     "rr_rff_gram_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
+    # multi-GPU exchange (RCCL bound directly; revrand_amd/parallel.py)
+    "rr_comm_load": (ctypes.c_int, [ctypes.c_char_p]),
+    "rr_comm_version": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int), ctypes.c_char_p, ctypes.c_size_t]),
+    "rr_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_comm_init_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, _c_void_pp]),
+    "rr_comm_destroy": (None, [ctypes.c_void_p]),
+    "rr_comm_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "rr_comm_allreduce_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
+    "rr_comm_allreduce_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
+    "rr_comm_broadcast_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]),
+    "rr_comm_barrier": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_stats_msg_count": (ctypes.c_int64, [ctypes.c_int64]),
+    "rr_stats_pack_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p]),
+    "rr_stats_unpack_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_comm_reduce_stats_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 
@@ -179,6 +197,17 @@ def _share_hip_runtime_with_torch():
             ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
         except OSError:
             pass  # fall back to the system runtime
+
+
+def rccl_library_path():
+    """The librccl that matches the HIP runtime this process runs on: $RR_RCCL_LIB; the copy bundled with an installed
+    torch wheel when its runtime was taken (see above); None = the library's own search (an already loaded
+    librccl.so.1, then /opt/rocm/lib)."""
+    if os.environ.get("RR_RCCL_LIB"):
+        return os.environ["RR_RCCL_LIB"]
+    if os.environ.get("RR_HIP_RUNTIME", "") == "system":
+        return None
+    return _torch_lib("librccl.so")
 
 
 def _torch_lib(name):

@@ -261,12 +261,14 @@ class _DevicePosterior(object):
         base, F = self.acc.ptr.value, self.F
         return tuple(_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
 
-    def _finish_stats(self, reduce=None):
-        if reduce is not None:  # row-sharded fit: sum the raw statistics of all ranks in place (RCCL)
-            self.dev.sync()
-            reduce(self.acc.ptr.value, self.F * self.F + self.F + 1)
-        pG, _, _ = self._stat_ptrs()
-        _hip._check(self.dev.lib, self.dev.lib.rr_symmetrize_dev(self.dev.ctx, pG, self.F))
+    def _finish_stats(self, reduce=None, nrows=0):
+        pG, pb, pt = self._stat_ptrs()
+        if reduce is not None:
+            # row-sharded fit: pack the upper triangle, ONE ncclAllReduce of [tri G | b | yty | N], unpack into the full
+            # symmetric G -- stream-ordered after the Gram kernels, nothing leaves HBM (parallel.RcclComm)
+            self.N_total = reduce(self.F, pG, pb, pt, nrows)
+        else:
+            _hip._check(self.dev.lib, self.dev.lib.rr_symmetrize_dev(self.dev.ctx, pG, self.F))
         return float(self.dev.download(self.acc, (1,), np.float64, offset_bytes=(self.F * self.F + self.F) * 8)[0])
 
     def stats_host(self):
@@ -326,7 +328,7 @@ class DeviceFitState(_DevicePosterior):
         self.dev.memset(self.acc)
         pG, pb, pt = self._stat_ptrs()
         self.handle.gram_dev(self.dX, self.dy, lenscale, pG, pb, pt)
-        return self._finish_stats(reduce)
+        return self._finish_stats(reduce, self.dX.shape[0])
 
     def second_pass(self, lenscale, m, C, var):
         sq, T = self.handle.elbo_pass2(self.dX, self.dy, lenscale, m, C)
@@ -658,7 +660,7 @@ class CatFitState(_DevicePosterior):
         for r0, rows in self._chunks():
             self._fill(r0, rows, hypers)
             self.fm.gram_into(_hip.DeviceView(self.dy, r0, rows), pG, pb, pt)
-        return self._finish_stats(reduce)
+        return self._finish_stats(reduce, self.N)
 
     def gram(self, hypers):
         self.gram_device(hypers)

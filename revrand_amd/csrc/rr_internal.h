@@ -25,7 +25,7 @@ struct rr_ctx {
     size_t gsa_bytes = 0, gsb_bytes = 0;
     void *pb = nullptr;       // split-bf16 copy of the feature chunk (rr_syrk_bf16x3_kernel), grow-only
     size_t pb_bytes = 0;
-    void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): rocBLAS handle + small device vectors
+    void *posdef = nullptr;  // PosdefScratch (rr_posdef.hip): work matrices + small device vectors of the blocked Cholesky
     void *pin[2] = {nullptr, nullptr};  // pinned host double buffer of rr_host_sink (grow-only)
     size_t pin_cap = 0;
     hipEvent_t pin_ev[2] = {nullptr, nullptr};

@@ -1,13 +1,31 @@
 """
-Row-sharded Gram assembly across processes (one process per GPU).
+Row-sharded Gram assembly across processes (one process per GPU) -- SURVEY 8e.
 
-The path shards embarrassingly over rows: every rank accumulates ``[G | b | y^T y | N]`` for its
-rows, then ONE all-reduce (torch.distributed: ``nccl`` = RCCL over xGMI on the GPUs, ``gloo`` in
-the CPU tests) sums the packed buffer, after which every rank holds the global statistics and
-runs the same host Cholesky.  torch is plumbing here (process group + collective); the arithmetic
-is the HIP library's.
+The path shards embarrassingly over rows: every rank accumulates the sufficient statistics of ITS rows -- what
+``revrand/slm.py:145-157`` computes from Phi (``Phi.T.dot(Phi)``, ``Phi.T.dot(y)``) plus ``y^T y`` and N -- then ONE
+all-reduce sums the message ``[upper triangle of G | b | y^T y | N]`` (F (F + 1) / 2 + F + 2 float64: 67 MB at
+F = 4096), after which every rank holds the global statistics and runs the same Cholesky.
+
+Transports (a ``Comm`` object; ``get_comm()`` picks one):
+
+* ``RcclComm``  -- the product transport: RCCL over xGMI, bound directly through the C ABI (``rr_comm_*`` in
+  ``include/revrand_hip.h``: ncclGetUniqueId / ncclCommInitRank / ncclAllReduce on the context's stream).  No PyTorch.
+  The 128-byte id goes from rank 0 to the others through a file or a TCP socket (``RR_COMM_RDZV``); under
+  ``torch.distributed.run`` / ``bench.py``'s own launcher the environment (RANK, WORLD_SIZE, LOCAL_RANK) is enough.
+* ``TorchComm`` -- the CPU test transport: a ``torch.distributed`` group the CALLER initialised (``gloo`` in
+  ``tests/test_dist_gloo.py``).  torch is only ever touched when such a group already exists in the process.
+* ``SingleComm`` -- one rank, every collective a no-op.
 """
+import ctypes
+import os
+import socket
+import sys
+import tempfile
+import time
+
 import numpy as np
+
+_OPS = {"sum": 0, "max": 1, "min": 2}
 
 
 def shard_bounds(N, rank, world):
@@ -17,93 +35,335 @@ def shard_bounds(N, rank, world):
     return start, start + base + (1 if rank < extra else 0)
 
 
+def stats_count(F):
+    """Length of the exchange message for an (F, F) Gram: upper triangle + b + y^T y + N."""
+    return F * (F + 1) // 2 + F + 2
+
+
 def pack_stats(G, b, yty, N):
-    """[G.ravel() | b | yty | N] as one float64 vector (one message)."""
+    """[G[i, i:] for every row i | b | yty | N] as one float64 vector (the message of the one exchange step)."""
     F = G.shape[0]
-    out = np.empty(F * F + F + 2)
-    out[:F * F] = G.ravel()
-    out[F * F:F * F + F] = b
+    out = np.empty(stats_count(F))
+    out[:F * (F + 1) // 2] = G[np.triu_indices(F)]
+    out[-F - 2:-2] = b
     out[-2] = yty
     out[-1] = N
     return out
 
 
 def unpack_stats(buf, F):
-    G = np.array(buf[:F * F]).reshape(F, F)
-    return G, np.array(buf[F * F:F * F + F]), float(buf[-2]), int(round(float(buf[-1])))
+    """(G full symmetric, b, yty, N) from a packed message."""
+    G = np.zeros((F, F))
+    iu = np.triu_indices(F)
+    G[iu] = buf[:F * (F + 1) // 2]
+    G = G + np.triu(G, 1).T
+    return G, np.array(buf[-F - 2:-2]), float(buf[-2]), int(round(float(buf[-1])))
 
 
-def allreduce_packed(buf, group=None):
-    """Sum a packed float64 buffer over the process group, in place.
+# ------------------------------------------------------------------------------------------------
+# transports
+# ------------------------------------------------------------------------------------------------
 
-    `buf` is a torch tensor (CUDA for nccl, CPU for gloo) or a NumPy array (wrapped without a
-    copy for gloo).  Returns the same object.  No-op when torch.distributed is not initialised.
-    """
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+class Comm(object):
+    """What the estimators and bench.py need from a process group."""
+    rank, world = 0, 1
+    device_reduce = False  # can sum a buffer in HBM in place (RCCL)
+    kind = "single"
+
+    def allreduce_host(self, buf, op="sum"):
+        return np.ascontiguousarray(buf, dtype=np.float64)
+
+    def broadcast_host(self, arr, root=0):
+        return arr
+
+    def barrier(self):
+        pass
+
+    def close(self):
+        pass
+
+
+class SingleComm(Comm):
+    pass
+
+
+class RcclComm(Comm):
+    """RCCL communicator of this process's GPU (rr_comm).  `ident`: the 128 bytes of ``unique_id()`` made by ONE rank
+    and handed to all (``exchange_id``)."""
+    device_reduce = True
+    kind = "rccl"
+
+    def __init__(self, rank, world, ident, device=None):
+        from . import _hip
+        self._hip = _hip
+        self.dev = _hip.get_device(device)
+        self.lib = self.dev.lib
+        if len(ident) != 128:
+            raise ValueError("an RCCL unique id has 128 bytes")
+        h = ctypes.c_void_p()
+        idbuf = ctypes.create_string_buffer(bytes(ident), 128)
+        _hip._check(self.lib, self.lib.rr_comm_init_rank(self.dev.ctx, int(rank), int(world), idbuf, ctypes.byref(h)))
+        self.h = h
+        r, w = ctypes.c_int(), ctypes.c_int()
+        _hip._check(self.lib, self.lib.rr_comm_info(h, ctypes.byref(r), ctypes.byref(w)))
+        self.rank, self.world = r.value, w.value  # as RCCL reports them
+        self._msg = None
+
+    @staticmethod
+    def load(path=None):
+        """Bind librccl (idempotent); returns (version, path)."""
+        from . import _hip
+        lib = _hip.load_library()
+        p = path or _hip.rccl_library_path()
+        _hip._check(lib, lib.rr_comm_load(p.encode() if p else None))
+        v, buf = ctypes.c_int(), ctypes.create_string_buffer(512)
+        _hip._check(lib, lib.rr_comm_version(ctypes.byref(v), buf, 512))
+        return v.value, buf.value.decode()
+
+    @staticmethod
+    def unique_id():
+        from . import _hip
+        RcclComm.load()
+        lib = _hip.load_library()
+        buf = ctypes.create_string_buffer(128)
+        _hip._check(lib, lib.rr_comm_unique_id(buf))
+        return buf.raw
+
+    def allreduce_host(self, buf, op="sum"):
+        buf = np.array(buf, dtype=np.float64, order="C", copy=True).ravel()
+        self._hip._check(self.lib, self.lib.rr_comm_allreduce_host(self.h, buf.ctypes.data_as(ctypes.c_void_p), buf.size,
+                                                                   _OPS[op]))
         return buf
-    t = torch.from_numpy(buf) if isinstance(buf, np.ndarray) else buf
-    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+
+    def allreduce_device(self, ptr, count, op="sum"):
+        """In place on a DEVICE float64 buffer, asynchronous on the context's stream."""
+        self._hip._check(self.lib, self.lib.rr_comm_allreduce_dev(self.h, self._hip._ptr(ptr), int(count), _OPS[op]))
+
+    def broadcast_host(self, arr, root=0):
+        arr = np.ascontiguousarray(arr)
+        self._hip._check(self.lib, self.lib.rr_comm_broadcast_host(self.h, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes,
+                                                                   int(root)))
+        return arr
+
+    def barrier(self):
+        self._hip._check(self.lib, self.lib.rr_comm_barrier(self.h))
+
+    def reduce_stats_device(self, F, pG, pb, pyty, nrows, wait=True):
+        """Sum [G | b | yty | N] over the ranks IN HBM: pack the upper triangle, one ncclAllReduce, unpack into the full
+        symmetric G -- all on the context's stream (no host synchronisation before it).  Returns the summed N (wait=True)."""
+        cnt = stats_count(F)
+        if self._msg is None or self._msg.nbytes < cnt * 8:
+            if self._msg is not None:
+                self.dev.sync()
+                self._msg.free()
+            self._msg = self.dev.malloc(cnt * 8)
+        tot = ctypes.c_double(float(nrows))
+        self._hip._check(self.lib, self.lib.rr_comm_reduce_stats_dev(
+            self.h, int(F), self._hip._ptr(pG), self._hip._ptr(pb), self._hip._ptr(pyty), float(nrows), self._msg.ptr,
+            ctypes.byref(tot) if wait else None))
+        return int(round(tot.value)) if wait else None
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            if self._msg is not None:
+                self._msg.free()
+                self._msg = None
+            self.lib.rr_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TorchComm(Comm):
+    """A torch.distributed group the caller initialised -- the CPU test transport (gloo).  Host vectors only."""
+    kind = "torch"
+
+    def __init__(self, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.kind = "torch-" + dist.get_backend(group)
+
+    def allreduce_host(self, buf, op="sum"):
+        buf = np.array(buf, dtype=np.float64, order="C", copy=True).ravel()
+        if self.world > 1:
+            rop = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}[op]
+            self._dist.all_reduce(self._torch.from_numpy(buf), op=rop, group=self.group)
+        return buf
+
+    def broadcast_host(self, arr, root=0):
+        arr = np.ascontiguousarray(arr)
+        if self.world > 1:
+            flat = arr.reshape(-1).view(np.uint8)
+            self._dist.broadcast(self._torch.from_numpy(flat), src=root, group=self.group)
+        return arr
+
+    def barrier(self):
+        if self.world > 1:
+            self._dist.barrier(group=self.group)
+
+
+# ------------------------------------------------------------------------------------------------
+# rendezvous of the RCCL id (rank 0 -> everyone): a file or a TCP socket
+# ------------------------------------------------------------------------------------------------
+
+def default_rendezvous():
+    """``RR_COMM_RDZV`` ("file:/path" or "tcp:host:port"), else a file name every worker of ONE launcher derives
+    identically: the launcher's pid (torch.distributed.run's agent, or bench.py's own launcher) + MASTER_PORT + restart
+    count, so a stale file of an earlier job can never be read."""
+    r = os.environ.get("RR_COMM_RDZV")
+    if r:
+        return r
+    key = "%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+    return "file:" + os.path.join(tempfile.gettempdir(), "rr_comm_%s.id" % key)
+
+
+def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
+    """Rank 0 calls make_id() and publishes the bytes; every other rank receives them."""
+    if world == 1:
+        return make_id()
+    rdzv = rendezvous or default_rendezvous()
+    kind, _, where = rdzv.partition(":")
+    deadline = time.time() + timeout
+    if kind == "file":
+        if rank == 0:
+            ident = make_id()
+            tmp = where + ".tmp%d" % os.getpid()
+            with open(tmp, "wb") as f:
+                f.write(ident)
+            os.replace(tmp, where)  # atomic: readers see all 128 bytes or nothing
+            return ident
+        while time.time() < deadline:
+            try:
+                with open(where, "rb") as f:
+                    ident = f.read()
+                if len(ident) == 128:
+                    return ident
+            except OSError:
+                pass
+            time.sleep(0.01)
+        raise TimeoutError("no RCCL id at %s after %.0f s" % (where, timeout))
+    if kind == "tcp":
+        host, _, port = where.rpartition(":")
+        if rank == 0:
+            ident = make_id()
+            srv = socket.socket()
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((host, int(port)))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                c, _ = srv.accept()
+                c.sendall(ident)
+                c.close()
+            srv.close()
+            return ident
+        while time.time() < deadline:
+            try:
+                c = socket.create_connection((host, int(port)), timeout=5.0)
+                ident = b""
+                while len(ident) < 128:
+                    part = c.recv(128 - len(ident))
+                    if not part:
+                        break
+                    ident += part
+                c.close()
+                if len(ident) == 128:
+                    return ident
+            except OSError:
+                pass
+            time.sleep(0.05)
+        raise TimeoutError("no RCCL id from %s after %.0f s" % (where, timeout))
+    raise ValueError("RR_COMM_RDZV must be file:<path> or tcp:<host>:<port>, got %r" % rdzv)
+
+
+def init_rccl_from_env(device=None, rendezvous=None):
+    """The RCCL communicator of a launcher-started process: RANK / WORLD_SIZE / LOCAL_RANK from the environment
+    (torch.distributed.run sets them; so does bench.py's own launcher), the id through ``default_rendezvous()``."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    rdzv = rendezvous or default_rendezvous()
+    ident = exchange_id(rank, world, RcclComm.unique_id, rdzv)
+    comm = RcclComm(rank, world, ident, device)
+    if rank == 0 and world > 1 and rdzv.startswith("file:"):
+        try:  # ncclCommInitRank returned: every rank has read it
+            os.unlink(rdzv[5:])
+        except OSError:
+            pass
+    return comm
+
+
+_comm = None
+
+
+def set_comm(comm):
+    """Install the process group the estimators use (None: back to auto-detection).  Returns the previous one."""
+    global _comm
+    prev, _comm = _comm, comm
+    return prev
+
+
+def _torch_group_initialised():
+    dist = sys.modules.get("torch.distributed")  # never imports torch
+    try:
+        return bool(dist is not None and dist.is_available() and dist.is_initialized())
+    except Exception:
+        return False
+
+
+def get_comm():
+    """The process group of this process: the one given to ``set_comm``; else a torch.distributed group the caller
+    initialised (gloo: the CPU test transport; nccl: only its store is used, to hand the RCCL id around); else RCCL
+    from the launcher's environment when WORLD_SIZE > 1; else a single rank."""
+    global _comm
+    if _comm is not None:
+        return _comm
+    if _torch_group_initialised():
+        dist = sys.modules["torch.distributed"]
+        if dist.get_backend() == "nccl":
+            box = [RcclComm.unique_id() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            _comm = RcclComm(dist.get_rank(), dist.get_world_size(), box[0])
+            return _comm
+        return TorchComm()  # not cached: the group may be destroyed and re-created (tests)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        _comm = init_rccl_from_env()
+        return _comm
+    return SingleComm()
+
+
+# ------------------------------------------------------------------------------------------------
+# what the estimators call
+# ------------------------------------------------------------------------------------------------
+
+def allreduce_host(buf, op="sum"):
+    """Sum (max, min) a host float64 vector over the ranks and return it."""
+    return get_comm().allreduce_host(buf, op)
+
+
+def allreduce_packed(buf):
+    """Sum a packed float64 NumPy message over the ranks, in place."""
+    buf[...] = get_comm().allreduce_host(buf).reshape(buf.shape)
     return buf
 
 
-def allreduce_host(buf, group=None):
-    """Sum a host float64 vector over the ranks and return it: directly with gloo; with nccl (= RCCL)
-    through a CUDA tensor on this process's GPU, since that backend reduces device memory only."""
-    import torch
-    import torch.distributed as dist
-    buf = np.ascontiguousarray(buf, dtype=np.float64)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return buf
-    if dist.get_backend(group) == "nccl":
-        t = torch.from_numpy(buf).cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        return t.cpu().numpy()
-    dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
-    return buf
+def device_allreduce_available():
+    """True when the ranks' statistics can be summed in HBM (an RCCL communicator)."""
+    return bool(get_comm().device_reduce)
 
 
-def sharded_gram(local_gram, X, y, rank, world, group=None):
+def sharded_gram(local_gram, X, y, rank, world):
     """Global (G, b, yty, N) from row shards.
 
     local_gram(X_rows, y_rows) -> (G, b, yty) is the per-rank device computation
     (e.g. ``lambda Xs, ys: basis.gram(Xs, ys, lenscale)``).  X, y are the FULL arrays (every rank
-    slices its own block) -- pass already-sliced data with rank=0, world=1 semantics by calling
-    ``allreduce_packed`` directly when the shards live in different processes' memory.
+    slices its own block).
     """
     start, stop = shard_bounds(X.shape[0], rank, world)
     G, b, yty = local_gram(X[start:stop], y[start:stop])
-    buf = allreduce_packed(pack_stats(G, b, yty, stop - start), group)
+    buf = get_comm().allreduce_host(pack_stats(G, b, yty, stop - start))
     return unpack_stats(buf, G.shape[0])
-
-
-class _DeviceSpan(object):
-    """A span of float64 device memory owned by librevrand_hip, exposed through ``__cuda_array_interface__`` so
-    that torch can wrap it WITHOUT a copy (torch and the library share one HIP runtime, see _hip.load_library)."""
-
-    def __init__(self, ptr, count):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def device_allreduce_available(group=None):
-    """True when a device buffer can be summed over the ranks in place: an initialised nccl (= RCCL) group."""
-    try:
-        import torch
-        import torch.distributed as dist
-    except ImportError:
-        return False
-    return bool(dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
-                and torch.cuda.is_available())
-
-
-def allreduce_device(ptr, count, group=None):
-    """Sum `count` float64 values at device address `ptr` over the ranks, in place, with RCCL.  The caller has
-    synchronised its own stream; on return the collective has completed (torch's stream is synchronised)."""
-    import torch
-    import torch.distributed as dist
-    t = torch.as_tensor(_DeviceSpan(ptr, count), device="cuda")
-    if dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    torch.cuda.synchronize()

@@ -43,9 +43,9 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
     ``maxiter``, ``nstarts``, ``random_state``, plus
 
     distributed : bool
-        Row-sharded fit, one process per GPU under ``torch.distributed``: every rank calls ``fit`` with
-        ITS rows; each ``_elbo`` sums the per-rank statistics ``[G | b | y^T y | N]`` and
-        ``[sqErr | dhyp]`` with one all-reduce each (RCCL on the GPUs), so all ranks walk the same
+        Row-sharded fit, one process per GPU (``revrand_amd.parallel``: RCCL bound directly, ranks from the
+        launcher's environment): every rank calls ``fit`` with ITS rows; each ``_elbo`` sums the per-rank
+        statistics ``[tri G | b | y^T y | N]`` and ``[sqErr | dhyp]`` with one all-reduce each, so all ranks walk the same
         L-BFGS path and end with identical parameters.  Needs a single random-feature basis (the
         device-resident path) and a fixed ``random_state`` shared by all ranks when ``nstarts > 0``.
     gram_engine : None | "f32" | "fp16x3" | "bf16x3" | "bf16x4"
@@ -139,23 +139,20 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         # posterior on the device (Cholesky + inverse + reductions in HBM) for F >= 256 unless RR_POSDEF=host or the
         # ranks' statistics cannot be summed in HBM (no RCCL group: gloo / CPU tests)
         on_dev = hasattr(st, "posterior") and _hip.posterior_available(getattr(st, "F", None))
-        if on_dev and self.distributed:
+        if self.distributed:
             from . import parallel
-            on_dev = parallel.device_allreduce_available()
+            comm = parallel.get_comm()
+            on_dev = on_dev and comm.device_reduce
         if on_dev:
-            reduce = None
-            if self.distributed:  # one exchange: [G | b | y^T y] of all row shards, summed in place over xGMI
-                reduce = parallel.allreduce_device
-                if getattr(st, "N_total", None) is None:
-                    st.N_total = int(round(float(parallel.allreduce_host(np.array([float(N)]))[0])))
+            # distributed: the one exchange -- [tri G | b | y^T y | N] of all row shards summed in HBM over RCCL / xGMI
+            yty = st.gram_device(hypers, comm.reduce_stats_device if self.distributed else None)
+            if self.distributed:
                 N = st.N_total
-            yty = st.gram_device(hypers, reduce)
             D = st.F
         else:
             PhiPhi, Phiy, yty = st.gram(hypers)
             D = PhiPhi.shape[0]
             if self.distributed:  # one exchange: the packed sufficient statistics of all row shards
-                from . import parallel
                 PhiPhi, Phiy, yty, N = parallel.unpack_stats(
                     self._allreduce(parallel.pack_stats(PhiPhi, Phiy, yty, N)), D)
         L, slices = self.basis.regularizer_diagonal(X, *atleast_list(reg))

@@ -28,8 +28,48 @@ def test_shard_bounds_cover_rows_exactly():
 def test_pack_roundtrip():
     rs = np.random.RandomState(0)
     G, b = rs.randn(5, 5), rs.randn(5)
-    G2, b2, t2, n2 = parallel.unpack_stats(parallel.pack_stats(G, b, 3.5, 17), 5)
+    G = G + G.T  # a Gram matrix: the message carries its upper triangle only
+    msg = parallel.pack_stats(G, b, 3.5, 17)
+    assert msg.shape == (parallel.stats_count(5),) == (5 * 6 // 2 + 5 + 2,)
+    assert np.array_equal(msg[:5], G[0]) and np.array_equal(msg[5:9], G[1, 1:])  # row i = G[i, i:]
+    G2, b2, t2, n2 = parallel.unpack_stats(msg, 5)
     assert np.array_equal(G, G2) and np.array_equal(b, b2) and t2 == 3.5 and n2 == 17
+
+
+def test_id_rendezvous_file_and_tcp(tmp_path):
+    """The 128-byte RCCL id goes from rank 0 to the others through a file or a TCP socket (no torch)."""
+    import threading
+    ident = bytes(range(128))
+    for rdzv in ("file:%s" % (tmp_path / "id"), None):
+        if rdzv is None:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            rdzv = "tcp:127.0.0.1:%d" % port
+        got = {}
+
+        def run(r):
+            got[r] = parallel.exchange_id(r, 3, lambda: ident, rdzv, timeout=60)
+        ts = [threading.Thread(target=run, args=(r,)) for r in (2, 1, 0)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join(60)
+        assert got == {0: ident, 1: ident, 2: ident}
+
+
+def test_get_comm_never_imports_torch():
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from revrand_amd import parallel\n"
+            "c = parallel.get_comm()\n"
+            "assert c.world == 1 and not c.device_reduce and c.allreduce_host([1.0, 2.0]).tolist() == [1.0, 2.0]\n"
+            "assert 'torch' not in sys.modules\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
 
 
 def _worker(rank, world, port, q):

@@ -1,0 +1,218 @@
+"""The multi-GPU exchange on real hardware: RCCL bound directly through the C ABI (rr_comm_*), no torch in the
+process.  The test box has ONE MI355X, so the two-rank cases run two processes on that GPU; RCCL refuses two ranks on
+one device of one host, hence every rank claims its own NCCL_HOSTID and the collective takes RCCL's socket transport --
+the product code path (id rendezvous, ncclCommInitRank, pack -> ncclAllReduce -> unpack on the context's stream, the
+estimators' use of it) is the one an 8-GPU node runs over xGMI."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_ranks(code, world, tmp_path, timeout=900, extra_env=None):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   RR_COMM_RDZV="file:%s" % (tmp_path / "rccl.id"), NCCL_HOSTID="rr-test-rank-%d" % r,
+                   NCCL_DEBUG="WARN", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((p.returncode, o, e))
+    for rc, o, e in outs:
+        assert rc == 0, (o[-1500:], e[-3000:])
+    res = []
+    for rc, o, e in outs:
+        line = [l for l in o.splitlines() if l.startswith("RESULT")]
+        assert line, (o[-1500:], e[-3000:])
+        res.append(json.loads(line[0][len("RESULT"):]))
+    return res
+
+
+def test_stats_pack_unpack_kernels_match_host_packing():
+    from revrand_amd import _hip, parallel
+    dev = _hip.get_device()
+    rs = np.random.RandomState(0)
+    for F in (1, 5, 256, 257, 700):
+        A = rs.randn(F, F)
+        G = np.triu(A)  # what the Gram kernels leave: the upper triangle only
+        b, yty = rs.randn(F), np.array([3.25])
+        dG, db, dt = dev.upload_vector(G.ravel()), dev.upload_vector(b), dev.upload_vector(yty)
+        cnt = parallel.stats_count(F)
+        assert dev.lib.rr_stats_msg_count(F) == cnt
+        dmsg = dev.zeros(cnt * 8)
+        _hip._check(dev.lib, dev.lib.rr_stats_pack_dev(dev.ctx, F, dG.ptr, db.ptr, dt.ptr, 17.0, dmsg.ptr))
+        msg = dev.download(dmsg, (cnt,), np.float64)
+        Gs = G + np.triu(G, 1).T
+        assert np.array_equal(msg, parallel.pack_stats(Gs, b, 3.25, 17))
+        dG2, db2, dt2 = dev.zeros(F * F * 8), dev.zeros(F * 8), dev.zeros(8)
+        _hip._check(dev.lib, dev.lib.rr_stats_unpack_dev(dev.ctx, F, dmsg.ptr, dG2.ptr, db2.ptr, dt2.ptr))
+        assert np.array_equal(dev.download(dG2, (F, F), np.float64), Gs)
+        assert np.array_equal(dev.download(db2, (F,), np.float64), b)
+        assert dev.download(dt2, (1,), np.float64)[0] == 3.25
+        G3, b3, t3, n3 = parallel.unpack_stats(msg, F)
+        assert np.array_equal(G3, Gs) and np.array_equal(b3, b) and t3 == 3.25 and n3 == 17
+
+
+_ONE_RANK = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["RR_POSDEF"] = "device"   # F = 120 here: below the default threshold for the device posterior
+from revrand_amd import parallel
+import revrand_amd.basis_functions as bs
+from revrand_amd.btypes import Parameter, Positive
+from revrand_amd.slm import StandardLinearModel as SLM
+comm = parallel.init_rccl_from_env()
+parallel.set_comm(comm)
+assert (comm.rank, comm.world, comm.kind) == (0, 1, "rccl") and parallel.device_allreduce_available()
+ver, path = parallel.RcclComm.load()
+rs = np.random.RandomState(0)
+X = rs.randn(3000, 5); y = np.sin(X @ rs.randn(5)) + 0.1 * rs.randn(3000)
+out = {"rccl": [ver, path]}
+for tag, distributed in (("dist", True), ("single", False)):
+    basis = bs.RandomRBF(nbases=60, Xdim=5, random_state=1, lenscale=Parameter(np.ones(5), Positive()))
+    slm = SLM(basis, distributed=distributed)
+    slm.obj_ = -np.inf
+    slm._state = basis.device_fit_state(X, y)
+    calls = []
+    orig = comm.reduce_stats_device
+    comm.reduce_stats_device = lambda F, *a, **k: (calls.append(F), orig(F, *a, **k))[1]
+    f, (gv, gr, gh) = slm._elbo(X, y, 0.3, 1.2, np.linspace(0.8, 1.3, 5))
+    comm.reduce_stats_device = orig
+    assert calls == ([120] if distributed else []), calls
+    slm._state.release()
+    out[tag] = [float(f), float(gv), float(gr)] + np.asarray(gh).tolist() + slm.weights_.tolist()
+assert "torch" not in sys.modules
+comm.close()
+print("RESULT" + json.dumps(out))
+'''
+
+
+def test_distributed_elbo_over_rccl_keeps_statistics_and_posterior_in_hbm(tmp_path):
+    """StandardLinearModel(distributed=True) on an RCCL communicator of one rank: the statistics are packed, all-reduced
+    and unpacked IN HBM on the context's stream and the posterior stays on the device; equal to the non-distributed
+    evaluation.  No torch in the process."""
+    res = _run_ranks(_ONE_RANK % ROOT, 1, tmp_path)[0]
+    assert normwise(np.array(res["dist"]), np.array(res["single"])) < 1e-6
+    assert res["rccl"][0] >= 20000 and "rccl" in res["rccl"][1]
+
+
+_TWO_RANKS = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, %r)
+os.environ["RR_POSDEF"] = "device"
+from revrand_amd import _hip, parallel
+import revrand_amd.basis_functions as bs
+from revrand_amd.btypes import Parameter, Positive
+from revrand_amd.slm import StandardLinearModel as SLM
+comm = parallel.init_rccl_from_env()
+parallel.set_comm(comm)
+rank, world = comm.rank, comm.world
+assert world == 2 and rank == int(os.environ["RANK"])
+out = {"rank": rank}
+# small host collectives
+out["sum"] = comm.allreduce_host(np.array([1.0 + rank, 10.0])).tolist()
+out["max"] = comm.allreduce_host(np.array([float(rank), -float(rank)]), op="max").tolist()
+out["min"] = comm.allreduce_host(np.array([float(rank), -float(rank)]), op="min").tolist()
+box = np.arange(7, dtype=np.int64) * (1 if rank == 0 else 0)
+out["bcast"] = comm.broadcast_host(box, root=0).tolist()
+comm.barrier()
+# the one exchange step: statistics of the two row shards summed in HBM == statistics of all rows
+rs = np.random.RandomState(0)
+N, d, n = 5001, 6, 160
+X = rs.randn(N, d).astype(np.float32); y = (np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+a, b = parallel.shard_bounds(N, rank, world)
+basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+st = basis.device_fit_state(X[a:b], y[a:b])
+yty = st.gram_device(np.ones(d), comm.reduce_stats_device)
+G, bb, yty2 = st.stats_host()
+st.release()
+Gf, bf, ytyf = basis.gram(X, y, np.ones(d))
+out["stats_err"] = [float(np.abs(G - Gf).max() / np.abs(Gf).max()), float(np.abs(bb - bf).max() / np.abs(bf).max()),
+                    abs(yty - ytyf) / ytyf, abs(yty2 - yty)]
+out["N_total"] = st.N_total
+out["G_sym"] = bool(np.array_equal(G, G.T))
+out["G_sum"] = float(G.sum())
+# one distributed _elbo and a short distributed fit: every rank walks the same path
+slm = SLM(basis, var=Parameter(0.1, Positive()), nstarts=0, maxiter=8, distributed=True, random_state=0)
+slm.obj_ = -np.inf
+slm._state = slm._make_state(X[a:b], y[a:b])
+f, (gv, gr, gh) = slm._elbo(X[a:b], y[a:b], 0.3, 1.2, np.linspace(0.8, 1.3, d))
+slm._state.release(); slm._state = None
+out["elbo"] = [float(f), float(gv), float(gr)] + np.asarray(gh).tolist()
+slm.fit(X[a:b], y[a:b])
+out["fit"] = [float(slm.var_), float(slm.regularizer_)] + np.asarray(slm.hypers_).tolist() + [float(slm.obj_)]
+if rank == 0:  # the same evaluation in one process on all rows
+    s1 = SLM(basis, var=Parameter(0.1, Positive()), nstarts=0, maxiter=8, random_state=0)
+    s1.obj_ = -np.inf
+    parallel.set_comm(parallel.SingleComm())
+    s1._state = s1._make_state(X, y)
+    f1, (gv1, gr1, gh1) = s1._elbo(X, y, 0.3, 1.2, np.linspace(0.8, 1.3, d))
+    s1._state.release(); s1._state = None
+    out["elbo_single"] = [float(f1), float(gv1), float(gr1)] + np.asarray(gh1).tolist()
+    parallel.set_comm(comm)
+assert "torch" not in sys.modules
+comm.barrier()
+comm.close()
+print("RESULT" + json.dumps(out))
+'''
+
+
+def test_two_rccl_ranks_sum_shard_statistics_and_fit_identically(tmp_path):
+    res = sorted(_run_ranks(_TWO_RANKS % ROOT, 2, tmp_path), key=lambda r: r["rank"])
+    assert [r["rank"] for r in res] == [0, 1]
+    for r in res:
+        assert r["sum"] == [3.0, 20.0] and r["max"] == [1.0, 0.0] and r["min"] == [0.0, -1.0]
+        assert r["bcast"] == list(range(7))
+        assert r["N_total"] == 5001 and r["G_sym"]
+        assert max(r["stats_err"][:3]) < 5e-6 and r["stats_err"][3] == 0.0, r["stats_err"]
+    assert res[0]["G_sum"] == res[1]["G_sum"]            # bitwise-identical reduced statistics on both ranks
+    assert res[0]["elbo"] == res[1]["elbo"] and res[0]["fit"] == res[1]["fit"]   # ... hence identical paths
+    assert normwise(np.array(res[0]["elbo"]), np.array(res[0]["elbo_single"])) < 2e-4   # f32 statistics, two orders
+
+
+def test_bench_two_ranks_as_the_driver_calls_it():
+    """`python bench.py --gpus 2` (no launcher): starts its own ranks, exits 0, ONE JSON line, n_gpus as RCCL reports."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--rows", "600000"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["exchange"]["ranks_rccl_reports"] == 2
+    assert out["exchange"]["message_bytes"] == 8 * (4096 * 4097 // 2 + 4096 + 2)
+    assert out["config"]["trace_rel_err"] < 1e-6 and out["value"] > 0
+
+
+def test_bench_under_torch_distributed_run_uses_rccl_directly():
+    """The driver's documented multi-GPU launch: `python -m torch.distributed.run ... bench.py --gpus N` (N = 1 here, with
+    the exchange forced on): the launcher's environment is used, the collective is still the library's own RCCL binding."""
+    pytest.importorskip("torch")
+    env = dict(os.environ, RR_BENCH_FORCE_DIST="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "1", "--warmup", "1", "--rows", "500000", "--no-cpu-baseline",
+                        "--configs", "none"], capture_output=True, text=True, timeout=1500, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["exchange"]["ranks_rccl_reports"] == 1 and out["config"]["trace_rel_err"] < 1e-6
