@@ -326,6 +326,60 @@ def gen_fit():
          Ey=Ey, Vy=Vy)
 
 
+def c1_data(N=10000, d=8, seed=11):
+    """Config 1's synthetic data set (BASELINE.json configs[0]: RandomRBF nbases=256, D=8, N=10k): regenerated from
+    the seed by the tests, so only the reference's OUTPUTS are stored."""
+    r = np.random.RandomState(seed)
+    X = r.randn(N, d)
+    w = np.array([1.0, -0.7, 0.5, 0.3, -0.2, 0.9, -0.4, 0.1])[:d]
+    y = np.sin(X @ w) + 0.1 * r.randn(N)
+    Xs = np.random.RandomState(seed + 1).randn(64, d)
+    return X, y, Xs
+
+
+def gen_fit_c1():
+    """BASELINE config 1 at its real shape through the reference's StandardLinearModel.fit (slm.py:74-140): nstarts=0,
+    fixed initial values, maxiter=20; and the small fit of gen_fit() again with a second seed / ARD length scales."""
+    X, y, Xs = c1_data()
+    # start values chosen so that the reference's L-BFGS-B makes progress: from (0.3, 1.0, 1.5) or (1, 1, 1) its first
+    # log-space step overshoots to var ~ 1e-100, the line search gives up and fit() returns the start point
+    b = rb.RandomRBF(nbases=256, Xdim=8, random_state=41, lenscale=Parameter(2.0, Positive()),
+                     regularizer=Parameter(10.0, Positive()))
+    slm = StandardLinearModel(b, var=Parameter(0.02, Positive()), nstarts=0, maxiter=20)
+    slm.fit(X, y)
+    assert abs(float(slm.var_) - 0.02) > 1e-3  # the optimiser moved
+    Ey, Vy = slm.predict_moments(Xs)
+    Phi = orc.rff_transform(Xs, b.W, np.asarray(slm.hypers_))
+    Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, float(slm.var_))
+    close(Ey, Eo, 1e-10)
+    close(Vy, Vo, 1e-10)
+    # one evaluation of the reference's _elbo AT its fitted point (weights_ / obj_ above belong to the best point SEEN,
+    # which need not be the optimiser's last): objective, all gradients, posterior -- what a tight comparison can use
+    fit_obj, fit_m = float(slm.obj_), slm.weights_.copy()
+    slm.obj_ = -np.inf
+    at = _elbo_case(b, X, y, float(slm.var_), float(slm.regularizer_), float(slm.hypers_))
+    slm.obj_, slm.weights_ = fit_obj, fit_m
+    out_at = dict(c1_at_elbo=np.array(at["elbo"]), c1_at_dvar=np.array(at["dvar"]), c1_at_dreg=at["dreg"],
+                  c1_at_dhyp=np.concatenate(at["dhyp"]), c1_at_m=at["m"], c1_at_Cdiag=at["C"].diagonal().copy())
+    out = dict(c1_W_head=b.W[:, :8].copy(), c1_var_=np.array(slm.var_), c1_reg_=np.array(slm.regularizer_),
+               c1_hyp_=np.array(slm.hypers_), c1_m=slm.weights_, c1_obj=np.array(slm.obj_), c1_Ey=Ey, c1_Vy=Vy,
+               c1_Cdiag=slm.covariance_.diagonal().copy(), c1_ys_true=np.sin(Xs @ np.array([1.0, -0.7, 0.5, 0.3, -0.2, 0.9, -0.4, 0.1])))
+    out.update(out_at)
+    # second seed of the small end-to-end case, ARD
+    N, d, n = 500, 4, 20
+    r = np.random.RandomState(17)
+    X2 = r.randn(N, d)
+    y2 = np.cos(X2 @ np.array([0.8, -0.3, 0.6, 0.2])) + 0.05 * r.randn(N)
+    Xs2 = np.random.RandomState(18).randn(16, d)
+    b2 = rb.RandomMatern32(nbases=n, Xdim=d, random_state=43, lenscale=Parameter(np.full(d, 1.3), Positive()),
+                           regularizer=Parameter(2.0, Positive()))
+    s2 = StandardLinearModel(b2, var=Parameter(0.4, Positive()), nstarts=0, maxiter=25)
+    s2.fit(X2, y2)
+    Ey2, Vy2 = s2.predict_moments(Xs2)
+    out.update(s2_X=X2, s2_y=y2, s2_Xs=Xs2, s2_W=b2.W, s2_var_=np.array(s2.var_), s2_reg_=np.array(s2.regularizer_),
+               s2_hyp_=np.array(s2.hypers_), s2_obj=np.array(s2.obj_), s2_Ey=Ey2, s2_Vy=Vy2)
+    save("fit_c1", **out)
+
 
 def gen_glm():
     """One minibatch `_elbo` of the reference's GeneralizedLinearModel (glm.py:205-322) per likelihood, with a
@@ -410,6 +464,10 @@ def gen_glm():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `make_golden.py fit_c1`
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     gen_weights()
     gen_rff()
     gen_hadamard()
@@ -419,5 +477,6 @@ if __name__ == "__main__":
     gen_elbo()
     gen_solve_posdef()
     gen_fit()
+    gen_fit_c1()
     gen_glm()
     print("oracle agrees with the reference on every fixture")

@@ -20,10 +20,8 @@ run consumes the same random stream as the reference.
 import logging
 import os
 from itertools import chain
-from multiprocessing import Pool
 
 import numpy as np
-from scipy.optimize import brentq
 from scipy.stats.distributions import gamma, norm
 from sklearn.base import BaseEstimator, RegressorMixin
 from sklearn.utils import check_random_state
@@ -112,10 +110,15 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         from functools import partial
         elbo = partial(GeneralizedLinearModel._elbo, self)
         elbo.objective_only = partial(GeneralizedLinearModel._elbo, self, objective_only=True)  # random starts
+        sync = None
+        if self.distributed:  # every rank starts from rank 0's candidates / start point
+            from . import parallel
+            comm = parallel.get_comm()
+            sync = lambda v: comm.broadcast_host(v, root=0)  # noqa: E731
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
-                       prefetch=self.sampler == "device")
+                       prefetch=self.sampler == "device", sync=sync)
         finally:
             self._resident_fit = False
             self._release_features()
@@ -287,22 +290,23 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         return ps.mean(axis=1), ps.min(axis=1), ps.max(axis=1)
 
     def predict_interval(self, X, percentile, nsamples=200, likelihood_args=(), multiproc=True):
-        """Predictive percentile interval by root finding on the sampled CDF (glm.py:497-570)."""
-        N = X.shape[0]
-        fs = self._sample_matrix(X, nsamples)
-        if len(likelihood_args) > 0:
-            likelihood_args = _reshape_likelihood_args(likelihood_args, N)
-        like_hypers = atleast_list(self.like_hypers_)
-        work = ((f[0], self.likelihood, like_hypers, f[1:], percentile) for f in zip(fs, *likelihood_args))
-        if multiproc:
-            pool = Pool()
-            res = pool.map(_star_rootfinding, work)
-            pool.close()
-            pool.join()
-        else:
-            res = [_rootfinding(*w) for w in work]
-        ql, qu = zip(*res)
-        return np.array(ql), np.array(qu)
+        """Central `percentile` interval of the predictive distribution, (lower, upper) per query row -- the quantiles
+        of the CDF averaged over the latent samples (glm.py:497-570).  The reference root-finds row by row in a process
+        pool; here every row is bisected at once on the (N, nsamples) sample matrix (`multiproc` is accepted and
+        ignored).  Same search bracket, and NaN where the bracket does not contain the quantile."""
+        fs = self._sample_matrix(X, nsamples)                                 # N x nsamples
+        N = fs.shape[0]
+        rowargs = [np.asarray(a, dtype=float).reshape(N, 1) for a in _reshape_likelihood_args(likelihood_args, N)
+                   if len(a)]
+        largs = atleast_list(self.like_hypers_) + rowargs
+        centre = self.likelihood.Ey(fs, *largs).mean(axis=1)
+        reach = 1000. * np.maximum(centre, 1.)
+
+        def sampled_cdf(q):
+            return self.likelihood.cdf(q[:, np.newaxis], fs, *largs).mean(axis=1)
+
+        tail = 0.5 * (1. - percentile)
+        return _bisect_quantile(sampled_cdf, tail, reach), _bisect_quantile(sampled_cdf, 1. - tail, reach)
 
     def _sample_matrix(self, X, nsamples):
         """Latent function samples f = Phi w, (N, nsamples), the product on the device (glm.py:572-620)."""
@@ -349,38 +353,28 @@ def _like_structure(template, flat):
 
 
 def _reshape_likelihood_args(likelihood_args, N):
-    reshape_args = []
-    for l in likelihood_args:
-        if np.isscalar(l):
-            l = l * np.ones(N)
-        if (np.shape(l)[0] != N) and (len(l) != 0):
+    """Per-observation likelihood arguments as length-N vectors: scalars are broadcast, empty sequences pass."""
+    out = []
+    for arg in likelihood_args:
+        vec = np.full(N, arg, dtype=float) if np.isscalar(arg) else arg
+        if len(vec) not in (0, N):
             raise ValueError("Likelihood arguments not a compatible shape!")
-        reshape_args.append(l)
-    return tuple(reshape_args)
+        out.append(vec)
+    return tuple(out)
 
 
-def _star_rootfinding(args):
-    return _rootfinding(*args)
-
-
-def _rootfinding(fn, likelihood, likelihood_hypers, likelihood_args, percentile):
-    """Lower / upper quantile of the sampled predictive CDF at one observation (glm.py:665-695)."""
-    def predCDF(q, fs, percent):
-        return (likelihood.cdf(q, fs, *chain(likelihood_hypers, likelihood_args))).mean() - percent
-
-    lpercent = (1 - percentile) / 2
-    upercent = 1 - lpercent
-    Eyn = likelihood.Ey(fn, *chain(likelihood_hypers, likelihood_args)).mean()
-    lb, ub = -1000 * max(Eyn, 1), 1000 * max(Eyn, 1)
-    try:
-        qln = brentq(predCDF, a=lb, b=ub, args=(fn, lpercent))
-    except ValueError:
-        qln = np.nan
-    try:
-        qun = brentq(predCDF, a=lb, b=ub, args=(fn, upercent))
-    except ValueError:
-        qun = np.nan
-    return qln, qun
+def _bisect_quantile(cdf, p, reach, iters=100):
+    """q with cdf(q) = p for every row, cdf monotone in q and evaluated for all rows at once: bisection on
+    [-reach, reach]; NaN for rows whose bracket does not straddle p."""
+    lo, hi = -reach, reach.copy()
+    with np.errstate(invalid="ignore"):
+        inside = (cdf(lo) <= p) & (cdf(hi) >= p)
+        for _ in range(iters):
+            mid = 0.5 * (lo + hi)
+            below = cdf(mid) < p
+            lo = np.where(below, mid, lo)
+            hi = np.where(below, hi, mid)
+    return np.where(inside, 0.5 * (lo + hi), np.nan)
 
 
 def _qmatrix(m, C):

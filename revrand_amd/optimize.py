@@ -377,11 +377,19 @@ def structured_sgd(sgd):
     ``batch_size`` is forwarded to `sgd`; the two agree at the reference's default batch_size=10.
     """
     def new_sgd(fun, parameters, data, eval_obj=False, batch_size=10, args=(), random_state=None, nstarts=100,
-                **sgd_kwargs):
+                sync=None, **sgd_kwargs):
         shapes = shapes_of(parameters, shape=lambda p: p.shape)
         nparams = len(shapes)
-        x0 = flatten_values(_map(lambda p: p.value, parameters))
+        # the start point is a DRAW of the random Parameters, as in the reference (its `flatten` ravels
+        # `parameter.rvs(random_state=None)`, btypes.py:351-371, decorators.py:216-220): NumPy's global stream, which
+        # leaves `random_state` -- the minibatch / reparameterisation stream -- exactly where the reference has it.
+        # (With all K mixture components at the distribution mean the GLM's mixture would start out degenerate.)
+        x0 = flatten_values(_map(lambda p: p.rvs(np.random.mtrand._rand), parameters))
         bounds = _flat_bounds(parameters)
+        # `sync` (row-sharded fits): every candidate and the start point are rank 0's -- the ranks' streams differ as
+        # soon as their shard sizes do (a permutation of N_local rows consumes N_local-dependent state)
+        share = (lambda v: np.asarray(sync(np.ascontiguousarray(v, dtype=float)))) if sync is not None else (lambda v: v)
+        x0 = share(x0)
         if eval_obj and nstarts > 0:
             data_gen = gen_batch(data, batch_size, random_state=random_state)
             if any(flatten_values(_map(lambda p: float(p.is_random), parameters))):
@@ -391,6 +399,8 @@ def structured_sgd(sgd):
                 for _ in range(nstarts):
                     batch = next(data_gen)
                     cand = _map(lambda p: p.rvs(random_state), parameters)
+                    if sync is not None:
+                        cand = unflatten(share(flatten_values(cand)), shapes)[:nparams]
                     if objective_only is not None:  # a cheaper objective-only evaluation, when the function offers one
                         obj = objective_only(*(list(cand) + list(batch) + list(args)))
                     else:

@@ -100,6 +100,7 @@ class RcclComm(Comm):
         self.lib = self.dev.lib
         if len(ident) != 128:
             raise ValueError("an RCCL unique id has 128 bytes")
+        RcclComm.load()  # every rank binds the SAME librccl (the one paired with this process's HIP runtime)
         h = ctypes.c_void_p()
         idbuf = ctypes.create_string_buffer(bytes(ident), 128)
         _hip._check(self.lib, self.lib.rr_comm_init_rank(self.dev.ctx, int(rank), int(world), idbuf, ctypes.byref(h)))

@@ -91,6 +91,11 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                        nstarts=self.nstarts)
             if self._state is not None and getattr(self._state, "best_on_device", False):
                 self.covariance_ = self._state.best_covariance()
+            if self.distributed:  # posteriors agree to the last bits only (see `_same_on_all_ranks`): ship rank 0's
+                from . import parallel
+                comm = parallel.get_comm()
+                self.weights_ = comm.broadcast_host(np.ascontiguousarray(self.weights_, dtype=np.float64), root=0)
+                self.covariance_ = comm.broadcast_host(np.ascontiguousarray(self.covariance_, dtype=np.float64), root=0)
         finally:
             self._defer_cov = False
             if self._state is not None:
@@ -179,6 +184,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             sqErr = yty - m.dot(bvec) - var * ((m ** 2) * iL).sum()
             ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
                            + ((m ** 2 + Cdiag) * iL).sum() - logdetC + np.log(L).sum() - D)
+            if self.distributed:
+                ELBO = float(comm.broadcast_host(np.array([ELBO]), root=0)[0])  # see `_same_on_all_ranks`
             return -ELBO
         sqErr, dhypers = st.second_pass(hypers, m, Cpass, var)
         if self.distributed:  # second exchange: 1 + (number of length scales) numbers
@@ -191,6 +198,14 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             dhypers = out if isinstance(dhypers, list) else out[0]
         ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
                        + ((m ** 2 + Cdiag) * iL).sum() - logdetC + np.log(L).sum() - D)
+        dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
+
+        def dreg(s):
+            return -0.5 * (((m[s] ** 2 + Cdiag[s]) * iL[s] ** 2).sum() - iL[s].sum())
+
+        dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
+        if self.distributed:
+            ELBO, dvar, dL, dhypers = self._same_on_all_ranks(comm, [ELBO, dvar, dL, dhypers])
         if ELBO > self.obj_:
             self.weights_ = m
             self.obj_ = ELBO
@@ -202,13 +217,17 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                 if not getattr(self, "_defer_cov", False):
                     self.covariance_ = st.best_covariance()
         log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
-        dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
-
-        def dreg(s):
-            return -0.5 * (((m[s] ** 2 + Cdiag[s]) * iL[s] ** 2).sum() - iL[s].sum())
-
-        dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
         return -ELBO, [-dvar, dL, dhypers]
+
+    @staticmethod
+    def _same_on_all_ranks(comm, values):
+        """Rank 0's numbers for every rank.  The ranks hold identical reduced statistics, but the posterior kernels sum
+        with f64 atomics whose order differs from run to run, so objective and gradients agree to the last bits only;
+        L-BFGS-B's line-search decisions must not depend on those bits (ranks taking different numbers of evaluations
+        would leave each other waiting in the next collective).  One broadcast of 3 + d numbers per evaluation."""
+        from .utils import flatten_values, shapes_of, unflatten
+        flat = comm.broadcast_host(flatten_values(values), root=0)
+        return unflatten(flat, shapes_of(values))
 
     def _elbo_objective(self, X, y, var, reg, hypers):
         """-ELBO only (what the random starts of `fit` rank by, decorators.py:541-583): with the data resident on the

@@ -312,3 +312,55 @@ def test_two_rank_distributed_glm_step_equals_single_process():
     assert np.allclose(res[0][1], res[1][1], rtol=0, atol=0)              # ranks agree exactly
     assert np.allclose(res[0][1], single[1], rtol=1e-9, atol=1e-10)        # and equal the all-rows evaluation
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3] and res[0][4] == res[1][4]
+
+
+def _glm_unequal_worker(rank, world, port, q):
+    """Shards that differ by one row AND random starts: the ranks' RandomStates drift apart (a permutation of N_local
+    rows consumes N_local-dependent state), so candidates and start point must be rank 0's (optimize.py)."""
+    import torch.distributed as dist
+    from revrand_amd.basis_functions import RandomRBF
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    from revrand_amd.likelihoods import Poisson
+    from revrand_amd.optimize import Adam
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        np.random.seed(1000 + rank)   # the ranks' GLOBAL streams differ, as in separately started processes
+        rs = np.random.RandomState(0)
+        N, d, n, K, L = 241, 3, 6, 2, 4
+        X = rs.randn(N, d)
+        y = rs.poisson(np.exp(0.3 * np.sin(X[:, 0]))).astype(float)
+        a, b = parallel.shard_bounds(N, rank, world)
+        assert (b - a) == (121 if rank == 0 else 120)
+        basis = RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
+                          regularizer=Parameter(1.5, Positive()))
+        glm = GeneralizedLinearModel(Poisson(), basis, K=K, nsamples=L, batch_size=50, maxiter=5, nstarts=4,
+                                     random_state=3, updater=Adam(alpha=0.05), distributed=True)
+        glm._features = lambda: glm.__dict__.setdefault("_mbf", _OracleFeatures(basis))
+        glm.fit(X[a:b], y[a:b])
+        q.put((rank, glm.weights_.ravel().tolist(), glm.covariance_.ravel().tolist(),
+               np.asarray(glm.basis_hypers_).tolist(), float(glm.regularizer_)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_glm_unequal_shards_with_random_starts_stay_identical():
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_glm_unequal_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=500) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1:] == res[1][1:]          # identical parameters on both ranks, bit for bit
+    assert len(set(np.round(res[0][1], 12))) > 4   # and the mixture did not start (or stay) degenerate

@@ -5,6 +5,7 @@ the product code path (id rendezvous, ncclCommInitRank, pack -> ncclAllReduce ->
 estimators' use of it) is the one an 8-GPU node runs over xGMI."""
 import json
 import os
+import re
 import subprocess
 import sys
 
@@ -39,9 +40,10 @@ def _run_ranks(code, world, tmp_path, timeout=900, extra_env=None):
         assert rc == 0, (o[-1500:], e[-3000:])
     res = []
     for rc, o, e in outs:
-        line = [l for l in o.splitlines() if l.startswith("RESULT")]
-        assert line, (o[-1500:], e[-3000:])
-        res.append(json.loads(line[0][len("RESULT"):]))
+        # RCCL writes its warnings to file descriptor 1 from its own threads: the marker may sit mid-line
+        m = re.search(r"RESULT(\{.*\})ENDRESULT", o, flags=re.S)
+        assert m, (o[-1500:], e[-3000:])
+        res.append(json.loads(m.group(1)))
     return res
 
 
@@ -101,7 +103,7 @@ for tag, distributed in (("dist", True), ("single", False)):
     out[tag] = [float(f), float(gv), float(gr)] + np.asarray(gh).tolist() + slm.weights_.tolist()
 assert "torch" not in sys.modules
 comm.close()
-print("RESULT" + json.dumps(out))
+sys.stdout.flush(); print("\nRESULT" + json.dumps(out) + "ENDRESULT", flush=True)
 '''
 
 
@@ -172,7 +174,7 @@ if rank == 0:  # the same evaluation in one process on all rows
 assert "torch" not in sys.modules
 comm.barrier()
 comm.close()
-print("RESULT" + json.dumps(out))
+sys.stdout.flush(); print("\nRESULT" + json.dumps(out) + "ENDRESULT", flush=True)
 '''
 
 

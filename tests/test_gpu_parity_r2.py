@@ -1,0 +1,155 @@
+"""
+Round-2 parity additions on the GPU:
+* BasisCat / apply_ind against the REFERENCE's own outputs (tests/golden/concat.npz; basis_functions.py:1599-1748 and
+  the apply_ind case of the reference's tests/test_bases.py:223-238);
+* StandardLinearModel.fit at BASELINE config 1's real shape against the reference's fit (tests/golden/fit_c1.npz);
+* the f32 hyper-gradient of the second data pass at config 2's size against the f64 path (both on the GPU).
+"""
+import numpy as np
+import pytest
+
+import revrand_oracle as orc
+from conftest import normwise
+from test_oracle_golden import c1_data
+
+pytestmark = pytest.mark.gpu
+
+
+def smse(y_true, y_pred):
+    return ((y_true - y_pred) ** 2).sum() / (len(y_true) * y_true.var())
+
+
+def _imports():
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    return bs, Parameter, Positive, StandardLinearModel
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_concat_transform_grad_regulariser_vs_reference(golden, dtype):
+    bs, Parameter, Positive, _ = _imports()
+    g = golden("concat")
+    X, ls = g["X"], g["ls"]
+    N, d = X.shape
+    n = 10
+    base = bs.RandomMatern52(nbases=n, Xdim=d, random_state=4, lenscale=Parameter(np.ones(d), Positive()), dtype=dtype) \
+        + bs.LinearBasis(onescol=True)
+    assert np.array_equal(base.bases[0].W, g["W"])
+    tol = 1e-3 if dtype == "f32" else 1e-5
+    P = base.transform(X, ls)
+    assert P.dtype == np.float64 and normwise(P, g["Phi"]) < tol
+    assert np.array_equal(P[:, 2 * n:], g["Phi"][:, 2 * n:])          # [1, X]: exact
+    grads = list(base.grad(X, ls))
+    assert len(grads) == 1 and grads[0].shape == g["dPhi"].shape
+    assert normwise(grads[0], g["dPhi"]) < tol
+    assert np.all(grads[0][:, 2 * n:, :] == 0)                         # zero padding to the full width
+    diag, slices = base.regularizer_diagonal(X, 2.5, 0.5)
+    assert np.array_equal(diag, g["regdiag"])
+    assert [[s.start, s.stop] for s in slices] == g["slices"].tolist()
+    assert base.get_dim(X) == int(g["get_dim"])
+
+
+def test_concat_apply_ind_vs_reference(golden):
+    bs, Parameter, Positive, _ = _imports()
+    g = golden("concat")
+    X = g["ai_X"]
+    base = bs.LinearBasis(onescol=False, apply_ind=[0]) \
+        + bs.RandomRBF(Xdim=1, nbases=1, apply_ind=[1], random_state=8) \
+        + bs.RandomRBF(Xdim=2, nbases=3, random_state=9, lenscale=Parameter(np.ones(2), Positive()), apply_ind=[1, 0])
+    assert np.array_equal(base.bases[1].W, g["ai_W1"]) and np.array_equal(base.bases[2].W, g["ai_W2"])
+    ls2 = np.array([0.8, 1.7])
+    P = base.transform(X, 1.5, ls2)
+    assert normwise(P, g["ai_Phi"]) < 1e-3 and np.array_equal(P[:, 0], X[:, 0])
+    g0, g1 = list(base.grad(X, 1.5, ls2))
+    assert g0.shape == (20, 9) and g1.shape == (20, 9, 2)
+    assert normwise(g0, g["ai_dPhi0"]) < 1e-3 and normwise(g1, g["ai_dPhi1"]) < 1e-3
+    # the same concatenation through the device feature matrix (what _elbo uses): Gram == Phi^T Phi of the reference
+    y = np.sin(X[:, 0])
+    G, b, yty = base.gram(X, y, 1.5, ls2)
+    Pr = g["ai_Phi"]
+    assert normwise(G, Pr.T @ Pr) < 1e-3 and normwise(b, Pr.T @ y) < 1e-3 and abs(yty - y @ y) < 1e-5 * (y @ y)
+
+
+def test_fit_config1_shape_vs_reference(golden):
+    """BASELINE configs[0]: RandomRBF nbases=256, D=8, N=10k through fit (slm.py:74-140), the reference's own start
+    values, nstarts=0, maxiter=20.  L-BFGS trajectories are sensitive: compared at prediction / objective
+    level; ONE evaluation at the reference's fitted point is compared tightly."""
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("fit_c1")
+    X, y, Xs = c1_data()
+    basis = bs.RandomRBF(nbases=256, Xdim=8, random_state=41, lenscale=Parameter(2.0, Positive()),
+                         regularizer=Parameter(10.0, Positive()))
+    assert np.array_equal(basis.W[:, :8], g["c1_W_head"])
+    # (1) ONE `_elbo` at the reference's fitted point, both data passes on the GPU, against the reference's own
+    # evaluation there: objective, every gradient, posterior weights and variances
+    for dtype, tol in (("f32", 1e-3), ("f64", 1e-7)):
+        bt = bs.RandomRBF(nbases=256, Xdim=8, random_state=41, lenscale=Parameter(2.0, Positive()),
+                          regularizer=Parameter(10.0, Positive()), dtype=dtype)
+        one = SLM(bt)
+        one.obj_ = -np.inf
+        one._state = one._make_state(X, y)
+        try:
+            nelbo, (ndvar, ndreg, ndhyp) = one._elbo(X, y, float(g["c1_var_"]), float(g["c1_reg_"]), float(g["c1_hyp_"]))
+        finally:
+            one._state.release()
+            one._state = None
+        assert abs(-nelbo - float(g["c1_at_elbo"])) < max(tol * 1e-1, 1e-9) * abs(float(g["c1_at_elbo"]))
+        assert normwise(one.weights_, g["c1_at_m"]) < tol
+        assert normwise(np.asarray(one.covariance_).diagonal(), g["c1_at_Cdiag"]) < tol
+        assert abs(-ndvar - float(g["c1_at_dvar"])) < tol * abs(float(g["c1_at_dvar"]))
+        assert normwise(-np.atleast_1d(ndreg), g["c1_at_dreg"]) < tol
+        assert normwise(-np.atleast_1d(ndhyp), g["c1_at_dhyp"]) < 2 * tol
+    # (2) the fit itself.  L-BFGS-B trajectories are chaotic here (the reference's own run ends unconverged after 20
+    # iterations with |dvar| ~ 4e5): this fit must predict like the reference's and reach an objective at least as good
+    slm = SLM(basis, var=Parameter(0.02, Positive()), nstarts=0, maxiter=20, random_state=0).fit(X, y)
+    Ey, Vy = slm.predict_moments(Xs)
+    assert smse(g["c1_Ey"], Ey) < 2e-2                      # same predictions as the reference's fit
+    assert abs(smse(g["c1_ys_true"], Ey) - smse(g["c1_ys_true"], g["c1_Ey"])) < 0.03   # ... and the same quality
+    assert slm.obj_ > float(g["c1_obj"]) - 0.02 * abs(float(g["c1_obj"]))
+    assert np.all(Vy > 0)
+
+
+def test_fit_second_seed_ard_matern_vs_reference(golden):
+    bs, Parameter, Positive, SLM = _imports()
+    g = golden("fit_c1")
+    X, y, Xs = g["s2_X"], g["s2_y"], g["s2_Xs"]
+    basis = bs.RandomMatern32(nbases=20, Xdim=4, random_state=43, lenscale=Parameter(np.full(4, 1.3), Positive()),
+                              regularizer=Parameter(2.0, Positive()))
+    assert np.array_equal(basis.W, g["s2_W"])
+    slm = SLM(basis, var=Parameter(0.4, Positive()), nstarts=0, maxiter=25, random_state=0).fit(X, y)
+    Ey, Vy = slm.predict_moments(Xs)
+    assert smse(g["s2_Ey"], Ey) < 5e-3
+    assert abs(slm.obj_ - float(g["s2_obj"])) < 0.02 * abs(float(g["s2_obj"]))
+    assert np.all(Vy > 0) and normwise(Vy, g["s2_Vy"]) < 0.3
+
+
+@pytest.mark.timeout(900)
+def test_hyper_gradient_f32_vs_f64_at_config2_size():
+    """the f32 second pass forms A = Err (Phi_c m_s - Phi_s m_c) - (Phi_c U_s - Phi_s U_c) with
+    cancellation; at N = 1M, F = 4096, D = 32 (config 2) its ARD hyper-gradient, objective and the other gradients
+    are compared with the float64 path on the same GPU (f64 features, f64 MFMA Gram, f64 posterior, f64 second pass)."""
+    bs, Parameter, Positive, SLM = _imports()
+    N, d, n = 1_000_000, 32, 2048
+    rng = np.random.default_rng(5)
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    w = rng.standard_normal(d).astype(np.float32)
+    y = (np.sin(X @ w / np.sqrt(d)) + 0.1 * rng.standard_normal(N, dtype=np.float32)).astype(np.float32)
+    ls = np.linspace(0.8, 1.6, d)
+    res = {}
+    for dtype in ("f32", "f64"):
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()), dtype=dtype)
+        slm = SLM(basis)
+        slm.obj_ = -np.inf
+        slm._state = basis.device_fit_state(X, y)
+        try:
+            f, (gv, gr, gh) = slm._elbo(X, y, 0.05, 2.0, ls)
+        finally:
+            slm._state.release()
+            slm._state = None
+        res[dtype] = (float(f), float(gv), float(gr), np.asarray(gh, dtype=float), slm.weights_.copy())
+    f32, f64 = res["f32"], res["f64"]
+    assert abs(f32[0] - f64[0]) < 1e-5 * abs(f64[0])
+    assert abs(f32[1] - f64[1]) < 1e-3 * abs(f64[1]) and abs(f32[2] - f64[2]) < 1e-3 * abs(f64[2])
+    assert normwise(f32[4], f64[4]) < 1e-3                  # posterior weights (north star: 1e-3 rel fp32)
+    assert normwise(f32[3], f64[3]) < 2e-3, normwise(f32[3], f64[3])   # the ARD length-scale gradient

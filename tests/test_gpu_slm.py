@@ -338,7 +338,12 @@ def test_concat_fit_runs_resident_and_predicts():
     # device predict_moments of the concatenation == host formulas on the transformed features
     Phi = cat.transform(Xs, *np.atleast_1d([slm.hypers_]) if np.ndim(slm.hypers_) == 0 else [slm.hypers_])
     Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
-    assert normwise(Ey, Eo) < 1e-3 and normwise(Vy, Vo) < 1e-2
+    assert normwise(Ey, Eo) < 1e-3
+    # phi^T C phi in f32: the error scales with |phi|^T |C| |phi| (cancellation when the optimiser ends at a badly scaled
+    # posterior -- its path varies in the last bits with the order of the f64 atomics), not with the result
+    C = slm.covariance_
+    bound = ((np.abs(Phi) @ np.abs(C)) * np.abs(Phi)).sum(axis=1)
+    assert np.all(np.abs(Vy - Vo) <= 1e-3 * Vo + 3e-6 * bound)
 
 
 @pytest.mark.parametrize("F", [1, 37, 128, 129, 512, 1300])

@@ -171,3 +171,72 @@ def test_sgd_updaters(golden, name):
     for i, grad in enumerate(g["upd_grads"]):
         x = orc.sgd_update(name, st, x, grad)
         assert normwise(x, g["upd_" + name][i]) < 1e-12
+
+
+def test_concat_transform_grad_regulariser(golden):
+    """BasisCat (RandomMatern52 + LinearBasis): hstack'ed Phi, the zero-padded gradient, the per-basis regulariser
+    diagonal + slices and get_dim as the REFERENCE returned them (basis_functions.py:1599-1748)."""
+    g = golden("concat")
+    X, ls, W = g["X"], g["ls"], g["W"]
+    N, d = X.shape
+    n = W.shape[1]
+    assert np.array_equal(orc.weights_matern(d, n, 4, 2), W)
+    Phi = np.hstack((orc.rff_transform(X, W, ls), orc.linear_transform(X, True)))
+    assert normwise(Phi, g["Phi"]) < 1e-12 and int(g["get_dim"]) == Phi.shape[1] == 2 * n + d + 1
+    dPhi = np.zeros((N, Phi.shape[1], d))
+    dPhi[:, :2 * n, :] = orc.rff_grad(X, W, ls)
+    assert normwise(dPhi, g["dPhi"]) < 1e-12
+    assert np.all(g["dPhi"][:, 2 * n:, :] == 0)  # the linear block has no hyper-parameter: exact zeros
+    assert g["slices"].tolist() == [[0, 2 * n], [2 * n, 2 * n + d + 1]]
+    assert np.array_equal(g["regdiag"], np.concatenate((np.full(2 * n, 2.5), np.full(d + 1, 0.5))))
+
+
+def test_concat_apply_ind(golden):
+    """The apply_ind case modelled on the reference's tests/test_bases.py:223-238: every basis sees its own column
+    subset (basis_functions.py:70-105), in the order the index list gives."""
+    g = golden("concat")
+    X, W1, W2 = g["ai_X"], g["ai_W1"], g["ai_W2"]
+    assert np.array_equal(orc.weights_rbf(1, 1, 8), W1) and np.array_equal(orc.weights_rbf(2, 3, 9), W2)
+    ls2 = np.array([0.8, 1.7])
+    Phi = np.hstack((X[:, [0]], orc.rff_transform(X[:, [1]], W1, 1.5), orc.rff_transform(X[:, [1, 0]], W2, ls2)))
+    assert normwise(Phi, g["ai_Phi"]) < 1e-12
+    g0 = np.zeros((X.shape[0], 9))
+    g0[:, 1:3] = orc.rff_grad(X[:, [1]], W1, 1.5)
+    g1 = np.zeros((X.shape[0], 9, 2))
+    g1[:, 3:9, :] = orc.rff_grad(X[:, [1, 0]], W2, ls2)
+    assert normwise(g0, g["ai_dPhi0"]) < 1e-12 and normwise(g1, g["ai_dPhi1"]) < 1e-12
+
+
+def c1_data(N=10000, d=8, seed=11):
+    """BASELINE config 1's data set, regenerated from the seed exactly as oracle/make_golden.py does."""
+    r = np.random.RandomState(seed)
+    X = r.randn(N, d)
+    w = np.array([1.0, -0.7, 0.5, 0.3, -0.2, 0.9, -0.4, 0.1])[:d]
+    y = np.sin(X @ w) + 0.1 * r.randn(N)
+    Xs = np.random.RandomState(seed + 1).randn(64, d)
+    return X, y, Xs
+
+
+def test_fit_c1_shape_prediction_mean(golden):
+    """Config 1 at its real shape (RandomRBF nbases=256, D=8, N=10k, fit by the reference): the predictive mean follows
+    from the stored posterior weights through the oracle's transform, and the fit is a fit (SMSE on noise-free targets)."""
+    g = golden("fit_c1")
+    _, _, Xs = c1_data()
+    W = orc.weights_rbf(8, 256, 41)
+    assert np.array_equal(W[:, :8], g["c1_W_head"])
+    Phi = orc.rff_transform(Xs, W, g["c1_hyp_"])
+    assert normwise(Phi @ g["c1_m"], g["c1_Ey"]) < 1e-10
+    smse = ((g["c1_ys_true"] - g["c1_Ey"]) ** 2).sum() / (64 * g["c1_ys_true"].var())
+    assert smse < 0.3 and np.all(g["c1_Vy"] > float(g["c1_var_"]))  # 256 bases in 8 dimensions: a coarse fit
+    # the reference's _elbo at its fitted point (N = 10k, F = 512): the oracle reproduces objective, gradients, posterior
+    X, y, _ = c1_data()
+    ls = float(g["c1_hyp_"])
+    o = orc.slm_elbo(orc.rff_transform(X, W, ls), y, float(g["c1_var_"]), np.full(512, float(g["c1_reg_"])), slice(None),
+                     [orc.rff_grad(X, W, ls)])
+    assert abs(o["elbo"] - float(g["c1_at_elbo"])) < 1e-10 * abs(float(g["c1_at_elbo"]))
+    assert normwise(o["m"], g["c1_at_m"]) < 1e-9 and normwise(o["C"].diagonal(), g["c1_at_Cdiag"]) < 1e-9
+    assert abs(o["dvar"] - float(g["c1_at_dvar"])) < 1e-8 * abs(float(g["c1_at_dvar"]))
+    assert normwise(np.atleast_1d(o["dhyp"]), g["c1_at_dhyp"]) < 1e-7
+    # second small fit (ARD Matern32): same consistency
+    Phi2 = orc.rff_transform(g["s2_Xs"], g["s2_W"], g["s2_hyp_"])
+    assert np.array_equal(orc.weights_matern(4, 20, 43, 1), g["s2_W"]) and Phi2.shape == (16, 40)
