@@ -169,10 +169,18 @@ int rr_rff_gram(rr_basis *basis, const void *X, const void *y, int x_dtype, int6
 /* G = Phi^T Phi (full symmetric, F x F), b = Phi^T y, yty = y^T y for an ARBITRARY host feature
  * matrix Phi (N, F) of `dtype` with leading dimension ldphi -- the Gram of concatenated or
  * non-random bases (BasisCat.transform output, LinearBasis, ...), i.e. `Phi.T.dot(Phi)` and
- * `Phi.T.dot(y)` of slm.py:146,157 for any basis.  Rows are repacked to f32 on the device and run
- * through the same MFMA SYRK kernel as the fused path.  y/b/yty may be NULL together. */
+ * `Phi.T.dot(y)` of slm.py:146,157 for any basis.  The arithmetic follows `dtype`: float32 rows go through the f32
+ * MFMA SYRK kernels of the fused path, float64 rows (the reference's dtype) through the f64 MFMA SYRK kernel.
+ * y/b/yty may be NULL together. */
 int rr_dense_gram(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi,
                   const void *y, double *G, double *b, double *yty);
+
+/* predict_moments (slm.py:240-244) for an ARBITRARY host feature matrix Phi (N, F) of `dtype` -- bases without a fused
+ * device route (LinearBasis alone, concatenations with float64 children, ...):  Ey = Phi m,  Vf = rowsum((Phi C) o Phi)
+ * with m (F) and C (F, F) host float64; float64 arithmetic (f64 MFMA GEMM) whatever `dtype`.  Host outputs of length N;
+ * the caller adds var to Vf. */
+int rr_dense_predict(rr_ctx *ctx, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi, const double *m,
+                     const double *C, double *Ey, double *Vf);
 
 /* Minibatch gather from resident data: ddst[r][0:ld_words] = dsrc[didx[r]][0:ld_words] for rows of ld_words 4-byte
  * words (float32 rows; float64 rows with ld_words = 2 * columns); didx is a DEVICE int32 vector.  Asynchronous. */

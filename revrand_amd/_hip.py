@@ -72,6 +72,8 @@ SIGNATURES = {
     "rr_dense_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+    "rr_dense_predict": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, _c_void_pp]),
     "rr_featmat_destroy": (None, [ctypes.c_void_p]),
     "rr_featmat_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
@@ -539,6 +541,22 @@ def dense_gram(Phi, y=None, device=None):
                                           G.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                           yty.ctypes.data_as(ctypes.c_void_p)))
     return G, b, float(yty[0])
+
+
+def dense_predict(Phi, m, C, device=None):
+    """(Phi m, rowsum((Phi C) o Phi)) of an arbitrary host feature matrix on the GPU in float64 (rr_dense_predict)."""
+    dev = get_device(device)
+    Phi = as_float_matrix(Phi)
+    N, F = Phi.shape
+    m = np.ascontiguousarray(m, dtype=np.float64)
+    C = np.ascontiguousarray(C, dtype=np.float64)
+    if m.shape != (F,) or C.shape != (F, F):
+        raise ValueError("posterior shape does not match the feature matrix")
+    Ey, Vf = np.empty(N), np.empty(N)
+    _check(dev.lib, dev.lib.rr_dense_predict(dev.ctx, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype), N, F,
+                                             _ld(Phi), m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p),
+                                             Ey.ctypes.data_as(ctypes.c_void_p), Vf.ctypes.data_as(ctypes.c_void_p)))
+    return Ey, Vf
 
 
 class FeatureMatrix(object):

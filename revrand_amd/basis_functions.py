@@ -1093,7 +1093,11 @@ class BasisCat(object):
         """(Phi^T Phi, Phi^T y, y^T y) of the concatenation with Phi assembled ON the device: every
         child writes its column block of one feature matrix (random Fourier / FastFood / linear bases
         by kernels, anything else by one upload of its host block), one MFMA SYRK reduces it
-        (slm.py:145-146,157 for a BasisCat).  f32 arithmetic."""
+        (slm.py:145-146,157 for a BasisCat).  f32 arithmetic -- so a concatenation with a ``dtype="f64"`` child
+        (e.g. RandomLaplace, whose heavy-tailed W needs it) DECLINES (returns None) and the estimator takes the float64
+        dense Gram of the transformed features instead."""
+        if any(getattr(b, "dtype", "f32") != "f32" for b in self.bases):
+            return None
         N = X.shape[0]
         F = int(self.get_dim(X))
         ends = self.__base_locations(X)

@@ -1250,6 +1250,17 @@ static void glm_launch_lik(rr_ctx *c, int lik, float *FSt, int64_t M, int64_t ro
 #undef RR_LK
 }
 
+// rows of a host feature matrix (f32 | f64) into the zero-padded f64 layout of the f64 GEMM
+template <typename TS>
+__global__ void __launch_bounds__(256)
+rr_pad_rows64_kernel(const TS *__restrict__ src, int64_t rows, int F, double *__restrict__ dst, int64_t ldp, int64_t rows_pad) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ldp) return;
+    const int64_t r0 = (int64_t)blockIdx.y * 64;
+    for (int64_t r = r0; r < r0 + 64 && r < rows_pad; ++r)
+        dst[r * ldp + c] = (r < rows && c < F) ? (double)src[r * (int64_t)F + c] : 0.0;
+}
+
 extern "C" {
 
 int rr_rff_grad_contract(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
@@ -1367,6 +1378,77 @@ int rr_rff_predict_devc(rr_basis *b, const void *dX, int x_dtype, int64_t N, int
                                  : pass2_run64<double>(b, true, (const double *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true);
     return x_dtype == RR_F32 ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true)
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true);
+}
+
+int rr_dense_predict(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi, const double *m,
+                     const double *C, double *Ey, double *Vf) {
+    RR_REQUIRE(c != nullptr && m != nullptr && C != nullptr && Ey != nullptr && Vf != nullptr, "rr_dense_predict: null argument");
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_dense_predict: bad dtype");
+    RR_REQUIRE(N >= 0 && F >= 1 && ldphi >= F && F < 46340, "rr_dense_predict: bad shape");
+    if (N == 0) return RR_OK;
+    RR_REQUIRE(Phi != nullptr, "rr_dense_predict: null Phi");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = dtype == RR_F32 ? 4 : 8;
+    const int64_t Fp = (F + 127) / 128 * 128;
+    int64_t chunk = (int64_t)(((size_t)2 << 30) / ((size_t)32 * Fp));  // raw rows + P, Pt, U in f64: ~2 GiB
+    if (chunk > N) chunk = N;
+    chunk = (chunk + 127) / 128 * 128;
+    void *raw = nullptr;
+    double *P = nullptr, *Pt = nullptr, *U = nullptr, *Cp = nullptr, *Craw = nullptr, *mv = nullptr, *dot = nullptr, *vf = nullptr;
+    hipError_t e = hipMalloc(&raw, (size_t)chunk * F * es);
+    if (e == hipSuccess) e = hipMalloc((void **)&P, (size_t)chunk * Fp * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&Pt, (size_t)Fp * chunk * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&U, (size_t)chunk * Fp * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&Cp, (size_t)Fp * Fp * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&Craw, (size_t)F * F * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&mv, (size_t)Fp * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&dot, (size_t)chunk * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&vf, (size_t)chunk * 8);
+    int rc = RR_OK;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_dense_predict: device allocation failed: %s", hipGetErrorString(e));
+        rc = RR_ERR_OOM;
+    }
+    auto hip_ok = [&](hipError_t he, const char *what) {
+        if (he != hipSuccess && rc == RR_OK) {
+            rr_set_error("rr_dense_predict: %s failed: %s", what, hipGetErrorString(he));
+            rc = RR_ERR_HIP;
+        }
+        return he == hipSuccess;
+    };
+    if (rc == RR_OK) {
+        hip_ok(hipMemsetAsync(mv, 0, (size_t)Fp * 8, c->stream), "memset");
+        hip_ok(hipMemcpyAsync(mv, m, (size_t)F * 8, hipMemcpyHostToDevice, c->stream), "upload of m");
+        hip_ok(hipMemcpyAsync(Craw, C, (size_t)F * F * 8, hipMemcpyHostToDevice, c->stream), "upload of C");
+        hipLaunchKernelGGL(rr_pad_c64_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, Craw, F, Cp, Fp);
+    }
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
+        const int64_t rows = (N - r0 < chunk) ? N - r0 : chunk;
+        const int64_t rpad = (rows + 127) / 128 * 128;
+        if (!hip_ok(hipMemcpy2DAsync(raw, (size_t)F * es, (const char *)Phi + (size_t)r0 * ldphi * es, (size_t)ldphi * es,
+                                     (size_t)F * es, (size_t)rows, hipMemcpyHostToDevice, c->stream), "upload of Phi")) break;
+        const dim3 pg((unsigned)((Fp + 255) / 256), (unsigned)((rpad + 63) / 64));
+        if (dtype == RR_F32)
+            hipLaunchKernelGGL(rr_pad_rows64_kernel<float>, pg, dim3(256), 0, c->stream, (const float *)raw, rows, (int)F, P, Fp, rpad);
+        else
+            hipLaunchKernelGGL(rr_pad_rows64_kernel<double>, pg, dim3(256), 0, c->stream, (const double *)raw, rows, (int)F, P, Fp, rpad);
+        hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rpad / 64)), dim3(256), 0, c->stream, P,
+                           rows, Fp, Pt, chunk);
+        rc = rr_launch_gemm_tn_f64(c, Pt, chunk, Cp, Fp, U, Fp, Fp, rpad, Fp, 0, 0);
+        if (rc != RR_OK) break;
+        hipLaunchKernelGGL(rr_rows64_kernel<1>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, c->stream, P, U, mv, rows, (int)F,
+                           Fp, dot, vf);
+        if (!hip_ok(hipGetLastError(), "kernel launch")) break;
+        hip_ok(hipMemcpyAsync(Ey + r0, dot, (size_t)rows * 8, hipMemcpyDeviceToHost, c->stream), "download");
+        hip_ok(hipMemcpyAsync(Vf + r0, vf, (size_t)rows * 8, hipMemcpyDeviceToHost, c->stream), "download");
+        hip_ok(hipStreamSynchronize(c->stream), "kernel");
+    }
+    (void)hipStreamSynchronize(c->stream);
+    void *q[] = {raw, P, Pt, U, Cp, Craw, mv, dot, vf};
+    for (void *x : q)
+        if (x) (void)hipFree(x);
+    return rc;
 }
 
 static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool c_on_device, bool tri = false) {

@@ -892,20 +892,20 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
 
 // Host feature matrices of ANY basis (concatenations, LinearBasis, ...) reach the SYRK kernel
 // through this repack: (rows, F) f32|f64 with leading dimension lds -> zero-padded f32 (rows_pad, ldp).
-template <typename TS>
+template <typename TS, typename TD = float>
 __global__ void __launch_bounds__(256) rr_pack_f32_kernel(const TS *__restrict__ src, int64_t rows, int F,
-                                                          int64_t lds_, float *__restrict__ dst, int64_t ldp,
+                                                          int64_t lds_, TD *__restrict__ dst, int64_t ldp,
                                                           int64_t rows_pad) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= ldp) return;
     const int64_t r0 = (int64_t)blockIdx.y * 64;
     for (int64_t r = r0; r < r0 + 64 && r < rows_pad; ++r)
-        dst[r * ldp + c] = (r < rows && c < F) ? (float)src[r * lds_ + c] : 0.f;
+        dst[r * ldp + c] = (r < rows && c < F) ? (TD)src[r * lds_ + c] : (TD)0;
 }
 
 // b += P^T y for a packed feature matrix (one column per thread, rows split over blockIdx.y)
-template <typename TY>
-__global__ void __launch_bounds__(256) rr_gemv_t_kernel(const float *__restrict__ P, const TY *__restrict__ y,
+template <typename TY, typename TP = float>
+__global__ void __launch_bounds__(256) rr_gemv_t_kernel(const TP *__restrict__ P, const TY *__restrict__ y,
                                                         int64_t rows, int F, int64_t ldp, double *__restrict__ bvec,
                                                         int rows_per_block) {
     const int c = blockIdx.x * 256 + threadIdx.x;
@@ -1991,19 +1991,24 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
     RR_REQUIRE(N == 0 || Phi != nullptr, "rr_dense_gram: null Phi");
     RR_CHECK_HIP(hipSetDevice(c->device));
     const size_t es = dtype_size(dtype);
-    const int64_t ldp = (F + GR_TC - 1) / GR_TC * GR_TC;
-    int64_t chunk = (int64_t)(((size_t)1 << 30) / ((size_t)ldp * 4 + (size_t)F * es));
+    // float64 input keeps float64 arithmetic (f64 features into the f64 MFMA SYRK): the reference's X^T X / Phi^T dPhi
+    // are float64, and unscaled linear features with large offsets do not survive a cast to f32
+    const bool f64 = dtype == RR_F64;
+    const int64_t tc = f64 ? G64_TC : GR_TC, kb = f64 ? G64_KB : GR_KB;
+    const size_t ps = f64 ? 8 : 4;
+    const int64_t ldp = (F + tc - 1) / tc * tc;
+    int64_t chunk = (int64_t)(((size_t)1 << 30) / ((size_t)ldp * ps + (size_t)F * es));
     if (chunk > N) chunk = N;
-    chunk = (chunk + GR_KB - 1) / GR_KB * GR_KB;
-    if (chunk < GR_KB) chunk = GR_KB;
+    chunk = (chunk + kb - 1) / kb * kb;
+    if (chunk < kb) chunk = kb;
     void *dRaw = nullptr, *dy = nullptr;
-    float *dP = nullptr;
+    void *dP = nullptr;
     double *dG = nullptr, *db = nullptr;
     int rc = RR_OK;
     hipError_t e = hipMalloc((void **)&dG, (size_t)F * F * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void **)&db, (size_t)(F + 1) * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&dRaw, (size_t)chunk * F * es);
-    if (e == hipSuccess) e = hipMalloc((void **)&dP, (size_t)chunk * ldp * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&dP, (size_t)chunk * ldp * ps);
     if (e == hipSuccess) e = hipMalloc(&dy, (size_t)chunk * es);
     if (e == hipSuccess) e = hipMemsetAsync(dG, 0, (size_t)F * F * sizeof(double), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(db, 0, (size_t)(F + 1) * sizeof(double), c->stream);
@@ -2014,7 +2019,7 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
     }
     for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
         const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
-        const int64_t mpad = (m + GR_KB - 1) / GR_KB * GR_KB;
+        const int64_t mpad = (m + kb - 1) / kb * kb;
         e = hipMemcpy2DAsync(dRaw, (size_t)F * es, (const char *)Phi + (size_t)r0 * ldphi * es, (size_t)ldphi * es,
                              (size_t)F * es, (size_t)m, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess && y)
@@ -2028,20 +2033,20 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
         const int rpb = 512;
         const dim3 gg((unsigned)((F + 255) / 256), (unsigned)((m + rpb - 1) / rpb));
         const int yb = (int)((m + 255) / 256) > c->num_cu * 8 ? c->num_cu * 8 : (int)((m + 255) / 256);
-        if (dtype == RR_F32) {
+        if (!f64) {
             hipLaunchKernelGGL(rr_pack_f32_kernel<float>, pg, dim3(256), 0, c->stream, (const float *)dRaw, m, (int)F, F,
-                               dP, ldp, mpad);
+                               (float *)dP, ldp, mpad);
             if (y) {
-                hipLaunchKernelGGL(rr_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, dP, (const float *)dy, m,
-                                   (int)F, ldp, db, rpb);
+                hipLaunchKernelGGL(rr_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, (const float *)dP,
+                                   (const float *)dy, m, (int)F, ldp, db, rpb);
                 hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, m, db + F);
             }
         } else {
-            hipLaunchKernelGGL(rr_pack_f32_kernel<double>, pg, dim3(256), 0, c->stream, (const double *)dRaw, m, (int)F,
-                               F, dP, ldp, mpad);
+            hipLaunchKernelGGL((rr_pack_f32_kernel<double, double>), pg, dim3(256), 0, c->stream, (const double *)dRaw, m,
+                               (int)F, F, (double *)dP, ldp, mpad);
             if (y) {
-                hipLaunchKernelGGL(rr_gemv_t_kernel<double>, gg, dim3(256), 0, c->stream, dP, (const double *)dy, m,
-                                   (int)F, ldp, db, rpb);
+                hipLaunchKernelGGL((rr_gemv_t_kernel<double, double>), gg, dim3(256), 0, c->stream, (const double *)dP,
+                                   (const double *)dy, m, (int)F, ldp, db, rpb);
                 hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, m,
                                    db + F);
             }
@@ -2051,7 +2056,8 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
             rc = RR_ERR_HIP;
             break;
         }
-        rc = rr_launch_syrk_f32(c, dP, mpad, ldp, (int)F, dG, nullptr);
+        rc = f64 ? rr_launch_syrk_f64(c, (const double *)dP, mpad, ldp, (int)F, dG)
+                 : rr_launch_syrk_f32(c, (const float *)dP, mpad, ldp, (int)F, dG, nullptr);
         if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
             rr_set_error("rr_dense_gram: kernel failed: %s", hipGetErrorString(e));
             rc = RR_ERR_HIP;

@@ -121,11 +121,11 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
     # -- device statistics -------------------------------------------------------------------
     def _gram(self, X, y, Phi, hyp):
         """(Phi^T Phi, Phi^T y) on the GPU: fused when the basis offers it, dense SYRK otherwise."""
-        if getattr(self.basis, "gram", None) is not None:
-            G, b, _ = self.basis.gram(X, y, *hyp)
-        else:
-            G, b, _ = _hip.dense_gram(Phi, y)
-        return G, b
+        gram = getattr(self.basis, "gram", None)
+        res = gram(X, y, *hyp) if gram is not None else None
+        if res is None:  # no fused route (or it declined: float64 children): Gram of Phi in Phi's own dtype
+            res = _hip.dense_gram(Phi, y)
+        return res[0], res[1]
 
     @staticmethod
     def _cross_gram(Phi, dPhi):
@@ -350,9 +350,10 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             res = self.basis.predict_moments(X, self.hypers_, self.weights_, self._device_covariance())
             if res is not None:
                 return res[0], res[1] + self.var_
+        # bases without a fused device route (LinearBasis alone, float64 children in a concatenation): their transform,
+        # then the N x F x F product on the GPU in float64 (rr_dense_predict) -- never on the host
         Phi = self.basis.transform(X, *atleast_list(self.hypers_))
-        Ey = Phi.dot(self.weights_)
-        Vf = (Phi.dot(self.covariance_) * Phi).sum(axis=1)
+        Ey, Vf = _hip.dense_predict(Phi, self.weights_, self.covariance_)
         return Ey, Vf + self.var_
 
     def __repr__(self):

@@ -153,3 +153,85 @@ def test_hyper_gradient_f32_vs_f64_at_config2_size():
     assert abs(f32[1] - f64[1]) < 1e-3 * abs(f64[1]) and abs(f32[2] - f64[2]) < 1e-3 * abs(f64[2])
     assert normwise(f32[4], f64[4]) < 1e-3                  # posterior weights (north star: 1e-3 rel fp32)
     assert normwise(f32[3], f64[3]) < 2e-3, normwise(f32[3], f64[3])   # the ARD length-scale gradient
+
+
+def test_dense_gram_float64_keeps_float64_arithmetic():
+    """rr_dense_gram with float64 input used to pack to f32.  Unscaled linear features with a large offset
+    lose their significant digits in f32; the float64 route (f64 MFMA SYRK) must not."""
+    from revrand_amd import _hip
+    rs = np.random.RandomState(0)
+    for N, F in ((1000, 9), (4097, 130), (300, 300)):
+        Phi = 1e4 + rs.randn(N, F)
+        y = rs.randn(N)
+        G, b, yty = _hip.dense_gram(Phi, y)
+        Gr = Phi.T @ Phi
+        assert normwise(G, Gr) < 1e-13 and np.array_equal(G, G.T)
+        # the informative part: the covariance around the offset survives (f32 would leave ~1e-1 relative here)
+        mu = Phi.mean(axis=0)
+        assert normwise(G / N - np.outer(mu, mu), Gr / N - np.outer(mu, mu)) < 1e-6
+        assert normwise(b, Phi.T @ y) < 1e-12 and abs(yty - y @ y) < 1e-12 * (y @ y)
+    G32, _, _ = _hip.dense_gram(Phi.astype(np.float32))   # float32 in: f32 arithmetic, as before
+    assert normwise(G32, Gr) < 1e-5
+
+
+def test_dense_predict_vs_numpy():
+    from revrand_amd import _hip
+    rs = np.random.RandomState(1)
+    for N, F in ((1, 1), (777, 9), (3000, 200)):
+        Phi, m = rs.randn(N, F), rs.randn(F)
+        A = rs.randn(F, F)
+        C = A @ A.T / F
+        Ey, Vf = _hip.dense_predict(Phi, m, C)
+        assert normwise(Ey, Phi @ m) < 1e-12 and normwise(Vf, ((Phi @ C) * Phi).sum(axis=1)) < 1e-12
+
+
+def test_concat_with_float64_child_uses_float64_statistics():
+    """RandomLaplace (dtype f64 by default: heavy-tailed W) + LinearBasis.  The f32 device feature matrix must
+    not be used for the Gram while Err / m / gradients come from the f64 transform: `_elbo` against the f64 oracle."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(2)
+    N, d, n = 600, 3, 40
+    X = rs.randn(N, d)
+    y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.1 * rs.randn(N)
+    cat = bs.RandomLaplace(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
+    assert cat.bases[0].dtype == "f64" and cat.gram(X, y, np.ones(d)) is None and cat.device_fit_state(X, y) is None
+    slm = SLM(cat)
+    slm.obj_ = -np.inf
+    ls = np.array([0.9, 1.2, 1.5])
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, 0.3, [1.5, 0.7], ls)
+    W = cat.bases[0].W
+    Phi = np.hstack((orc.rff_transform(X, W, ls), orc.linear_transform(X, True)))
+    F = Phi.shape[1]
+    dP = np.zeros((N, F, d))
+    dP[:, :2 * n, :] = orc.rff_grad(X, W, ls)
+    rd = np.concatenate((np.full(2 * n, 1.5), np.full(d + 1, 0.7)))
+    o = orc.slm_elbo(Phi, y, 0.3, rd, [slice(0, 2 * n), slice(2 * n, F)], [dP[:, :, i] for i in range(d)])
+    assert abs(-nelbo - o["elbo"]) < 1e-8 * abs(o["elbo"])
+    assert normwise(slm.weights_, o["m"]) < 1e-7 and normwise(slm.covariance_, o["C"]) < 1e-7
+    assert abs(-ndvar - o["dvar"]) < 1e-6 * abs(o["dvar"])
+    assert normwise(-np.asarray(ndreg), o["dreg"]) < 1e-6
+    assert normwise(-np.atleast_1d(ndhyp), np.array(o["dhyp"])) < 1e-5
+    # predict_moments of such a concatenation: float64 on the GPU (rr_dense_predict), not a host matrix product
+    slm.var_, slm.regularizer_, slm.hypers_ = 0.3, [1.5, 0.7], ls
+    Xs = rs.randn(50, d)
+    Ey, Vy = slm.predict_moments(Xs)
+    Ps = np.hstack((orc.rff_transform(Xs, W, ls), orc.linear_transform(Xs, True)))
+    Eo, Vo = orc.slm_predict_moments(Ps, o["m"], o["C"], 0.3)
+    assert normwise(Ey, Eo) < 1e-7 and normwise(Vy, Vo) < 1e-7
+
+
+def test_default_linear_basis_model_predicts_on_device():
+    """StandardLinearModel() (LinearBasis, slm.py:57) has no fused route: Gram and predict_moments still run on the GPU,
+    in float64, and equal the host formulas on data with a large offset."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(4)
+    X = 500.0 + rs.randn(400, 2)
+    y = 3.0 + X @ np.array([0.5, -0.25]) + 0.01 * rs.randn(400)
+    slm = SLM(bs.LinearBasis(onescol=True), nstarts=0, maxiter=50, random_state=0).fit(X, y)
+    Xs = 500.0 + rs.randn(30, 2)
+    Ey, Vy = slm.predict_moments(Xs)
+    Ps = orc.linear_transform(Xs, True)
+    Eo, Vo = orc.slm_predict_moments(Ps, slm.weights_, slm.covariance_, slm.var_)
+    assert normwise(Ey, Eo) < 1e-10 and normwise(Vy, Vo) < 1e-8
+    assert smse(3.0 + Xs @ np.array([0.5, -0.25]), Ey) < 1e-2
