@@ -195,22 +195,26 @@ def config_c2(dev, _hip, args):
     ms = _timed(dev, step, 3)
     syrk = float(np.mean([k[1] + k[2] for k in kms]))
     feat = float(np.mean([k[0] for k in kms]))
-    orc = _oracle()
-    ns = 40_000
-    t0 = time.perf_counter()
-    orc.rff_gram_chunked(X[:ns].astype(np.float64), y[:ns].astype(np.float64), W, 1.0, chunk=10000)
-    tc = time.perf_counter() - t0
+    cpu = None
+    if not args.no_cpu_baseline:
+        orc = _oracle()
+        ns = 40_000
+        t0 = time.perf_counter()
+        orc.rff_gram_chunked(X[:ns].astype(np.float64), y[:ns].astype(np.float64), W, 1.0, chunk=10000)
+        tc = time.perf_counter() - t0
+        cpu = {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
+               "sample": "%d rows, f64, 10000-row chunks, one run %.1f s" % (ns, tc)}
     for b in (dX, dy, acc):
         b.free()
     return {"workload": "RandomRBF nbases=2048 (F=4096), D=32, N=1M f32: features + MFMA Gram, resident", "rows": N,
+            "launches_per_pass": kms[0][3], "rows_per_launch": N // kms[0][3],
             "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32",
             "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "whole_path_achieved": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12,
                          "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
                          "syrk_frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
-            "cpu_baseline": {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
-                             "sample": "%d rows, f64, 10000-row chunks, one run %.1f s" % (ns, tc)}}
+            "cpu_baseline": cpu}
 
 
 def config_f64(dev, _hip, args):
@@ -254,6 +258,7 @@ def config_f64(dev, _hip, args):
     for b in (dX, dy, acc):
         b.free()
     return {"workload": "RandomRBF nbases=2048 (F=4096), D=32, N=500k, float64 arithmetic end to end", "rows": N,
+            "launches_per_pass": kms[0][3], "rows_per_launch": N // kms[0][3],
             "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f64",
             "trace_rel_err": trace_err, "parity_rel_err_4096_rows_vs_oracle": perr,
             "roofline": {"bound": "mfma", "kernel": basis.gram_kernel_name(), "peak": PEAK_F64_MFMA_TFLOPS,
@@ -277,6 +282,7 @@ def config_c3(dev, _hip, args):
     st = cat.device_fit_state(X, y)
     F = st.F
     hyp = [np.ones(d)]
+    chunk_rows = int(st.chunk)
     st.gram_device(hyp)
     ms = _timed(dev, lambda: st.gram_device(hyp), 3)
     # size-independent property on the full-size result: trace of the random Fourier block == N
@@ -284,14 +290,18 @@ def config_c3(dev, _hip, args):
     tr = abs(float(np.trace(G[:2 * n, :2 * n])) - N) / N
     assert tr < 1e-5 and G[2 * n, 2 * n] == N and np.array_equal(G, G.T), tr
     st.release()
-    orc = _oracle()
-    ns = 8000
-    Xs, ys = X[:ns].astype(np.float64), y[:ns].astype(np.float64)
-    Wm = cat.bases[0].W
-    t0 = time.perf_counter()
-    Phi = np.hstack((orc.rff_transform(Xs, Wm, np.ones(d)), orc.linear_transform(Xs, True)))
-    orc.gram_stats(Phi, ys)
-    tc = time.perf_counter() - t0
+    cpu = None
+    if not args.no_cpu_baseline:
+        orc = _oracle()
+        ns = 8000
+        Xs, ys = X[:ns].astype(np.float64), y[:ns].astype(np.float64)
+        Wm = cat.bases[0].W
+        t0 = time.perf_counter()
+        Phi = np.hstack((orc.rff_transform(Xs, Wm, np.ones(d)), orc.linear_transform(Xs, True)))
+        orc.gram_stats(Phi, ys)
+        tc = time.perf_counter() - t0
+        cpu = {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
+               "sample": "%d rows, f64 transform + hstack + Phi^T Phi, one run %.1f s" % (ns, tc)}
     fl = 2.0 * d * n + F * (F + 1.0) + 2.0 * F
     return {"workload": "RandomMatern52 nbases=4096 + LinearBasis(onescol), D=64, F_tot=%d, N=1.25M (= 10M / 8 GPUs): "
                         "device-side concatenation + MFMA Gram, resident" % F, "rows": N, "ms_per_pass": ms,
@@ -300,8 +310,7 @@ def config_c3(dev, _hip, args):
                          "achieved": fl * N / (ms * 1e-3) / 1e12, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "note": "whole pass (feature assembly + both SYRK kernels + mirror) on algorithmic flops"},
             "exchange_bytes_per_evaluation": 8 * (F * (F + 1) // 2 + F + 2),
-            "cpu_baseline": {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
-                             "sample": "%d rows, f64 transform + hstack + Phi^T Phi, one run %.1f s" % (ns, tc)}}
+            "rows_per_launch": chunk_rows, "launches_per_pass": -(-N // chunk_rows), "cpu_baseline": cpu}
 
 
 def config_c4(dev, _hip, args):
@@ -339,10 +348,14 @@ def config_c4(dev, _hip, args):
     # unit row norm: sum_j Phi_j^2 = 1 for every row (cos^2 + sin^2 over n frequencies, / n)
     nrm = float(np.abs((out.astype(np.float64) ** 2).sum(axis=1) - 1.0).max())
     assert nrm < 1e-4, nrm
-    t0 = time.perf_counter()
-    nc = 2000
-    orc.fastfood_transform(X[:nc].astype(np.float64), f.B, f.G, f.PI, f.S, 1.0)
-    tc = time.perf_counter() - t0
+    cpu = None
+    if not args.no_cpu_baseline:
+        t0 = time.perf_counter()
+        nc = 2000
+        orc.fastfood_transform(X[:nc].astype(np.float64), f.B, f.G, f.PI, f.S, 1.0)
+        tc = time.perf_counter() - t0
+        cpu = {"value": nc / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
+               "sample": "%d rows through the oracle's NumPy FWHT chain, %.1f s" % (nc, tc)}
     dX.free()
     for r in ring:
         r.free()
@@ -354,8 +367,7 @@ def config_c4(dev, _hip, args):
                          "bytes_per_row": bytes_row, "rows_per_launch": CH, "avg_launch_ms": kms / NCH,
                          "achieved": bytes_row * N / (kms * 1e-3) / 1e9,
                          "frac": bytes_row * N / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS},
-            "cpu_baseline": {"value": nc / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
-                             "sample": "%d rows through the oracle's NumPy FWHT chain, %.1f s" % (nc, tc)}}
+            "cpu_baseline": cpu}
 
 
 def config_c5(dev, _hip, args):
@@ -415,16 +427,20 @@ def config_c5(dev, _hip, args):
             out[sampler]["gemm_tflops_over_device_calls"] = gemm_flops / (dms * 1e-3) / 1e12
         glm._resident_fit = False
         glm._release_features()
-    orc = _oracle()
-    Mc = 1024
-    Xc, yc = X[:Mc].astype(np.float64), y[:Mc]
-    W = basis.W
-    e = rs.randn(K, L, F)
-    t0 = time.perf_counter()
-    Phi = orc.rff_transform(Xc, W, ls)
-    dP = orc.rff_grad(Xc, W, ls)
-    orc.glm_elbo(m, C, np.ones(F), slice(None), "poisson_exp", [], (), Phi, [dP[:, :, i] for i in range(d)], yc, e, N / M)
-    tc = time.perf_counter() - t0
+    cpu = None
+    if not args.no_cpu_baseline:
+        orc = _oracle()
+        Mc = 1024
+        Xc, yc = X[:Mc].astype(np.float64), y[:Mc]
+        W = basis.W
+        e = rs.randn(K, L, F)
+        t0 = time.perf_counter()
+        Phi = orc.rff_transform(Xc, W, ls)
+        dP = orc.rff_grad(Xc, W, ls)
+        orc.glm_elbo(m, C, np.ones(F), slice(None), "poisson_exp", [], (), Phi, [dP[:, :, i] for i in range(d)], yc, e, N / M)
+        tc = time.perf_counter() - t0
+        cpu = {"value": Mc / tc, "unit": "minibatch-rows/s", "cores": _blas_threads()[0], "kind": "port",
+               "sample": "%d-row minibatch through the oracle (transform, (M, F, d) grad, glm_elbo), %.1f s" % (Mc, tc)}
     best = out["device"]
     return {"workload": "GeneralizedLinearModel Poisson, RandomRBF nbases=1024 (F=2048), D=32 ARD, N=2M resident, K=10, "
                         "L=50, minibatch 65536: one SVI _elbo (Phi, ELBO gradients, length-scale gradient)",
@@ -436,9 +452,7 @@ def config_c5(dev, _hip, args):
                          "note": "the step's three (K L) x M x F GEMMs over the wall-clock of ALL device calls of a step "
                                  "(features, likelihood kernel, contraction, launch gaps included); per-kernel times in "
                                  "profiles/"},
-            "cpu_baseline": {"value": Mc / tc, "unit": "minibatch-rows/s", "cores": _blas_threads()[0], "kind": "port",
-                             "sample": "%d-row minibatch through the oracle (transform, (M, F, d) grad, glm_elbo), %.1f s"
-                                       % (Mc, tc)}}
+            "cpu_baseline": cpu}
 
 
 def extra_configs(dev, _hip, args):
