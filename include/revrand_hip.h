@@ -55,6 +55,10 @@ typedef enum rr_dtype { RR_F32 = 0, RR_F64 = 1 } rr_dtype;
 /* ---- library / context ------------------------------------------------- */
 
 int rr_abi_version(void);
+/* Bit mask describing the build: RR_BUILD_BOUNDS = `make debug` (-DRR_BOUNDS: guard bands around every device
+ * allocation, verified at rr_ctx_sync / rr_free, and index assertions inside the kernels). */
+#define RR_BUILD_BOUNDS 1
+int rr_build_flags(void);
 const char *rr_last_error(void);
 int rr_device_count(int *count);
 

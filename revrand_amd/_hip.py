@@ -27,6 +27,7 @@ _c_double_p = ctypes.POINTER(ctypes.c_double)
 # name -> (restype, argtypes); every symbol include/revrand_hip.h declares
 SIGNATURES = {
     "rr_abi_version": (ctypes.c_int, []),
+    "rr_build_flags": (ctypes.c_int, []),
     "rr_last_error": (ctypes.c_char_p, []),
     "rr_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "rr_ctx_create": (ctypes.c_int, [ctypes.c_int, _c_void_pp]),

@@ -16,9 +16,92 @@ void rr_set_error(const char *fmt, ...) {
     g_last_error = buf;
 }
 
+#ifdef RR_BOUNDS
+#include <map>
+#include <mutex>
+namespace {
+constexpr size_t RR_GUARD = 4096;
+constexpr unsigned char RR_GUARD_BYTE = 0xA5;
+struct GuardRec { size_t bytes; int device; };
+std::map<void *, GuardRec> g_guarded;  // user pointer -> record
+std::mutex g_guard_mu;
+}  // namespace
+
+hipError_t rr_guard_malloc(void **p, size_t bytes) {
+    char *base = nullptr;
+    hipError_t e = (hipMalloc)((void **)&base, bytes + 2 * RR_GUARD);
+    if (e != hipSuccess) return e;
+    (void)hipMemset(base, RR_GUARD_BYTE, RR_GUARD);
+    (void)hipMemset(base + RR_GUARD + bytes, RR_GUARD_BYTE, RR_GUARD);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guarded[base + RR_GUARD] = GuardRec{bytes, dev};
+    *p = base + RR_GUARD;
+    return hipSuccess;
+}
+
+static int guard_check_one(void *user, const GuardRec &r, const char *where) {
+    unsigned char h[2 * RR_GUARD];
+    char *base = (char *)user - RR_GUARD;
+    if (hipMemcpy(h, base, RR_GUARD, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(h + RR_GUARD, (char *)user + r.bytes, RR_GUARD, hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return RR_OK;  // the device is already in an error state: the caller reports that
+    }
+    for (size_t i = 0; i < 2 * RR_GUARD; ++i)
+        if (h[i] != RR_GUARD_BYTE) {
+            const long off = i < RR_GUARD ? (long)i - (long)RR_GUARD : (long)(r.bytes + (i - RR_GUARD));
+            rr_set_error("RR_BOUNDS: out-of-bounds write at byte offset %ld of a %zu-byte device allocation (%p), found at %s",
+                         off, r.bytes, user, where);
+            return RR_ERR_HIP;
+        }
+    return RR_OK;
+}
+
+int rr_guard_check(const char *where) {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    for (auto &kv : g_guarded)
+        if (kv.second.device == dev) {
+            int rc = guard_check_one(kv.first, kv.second, where);
+            if (rc != RR_OK) return rc;
+        }
+    return RR_OK;
+}
+
+hipError_t rr_guard_free(void *p) {
+    if (!p) return hipSuccess;
+    GuardRec r{0, 0};
+    bool mine = false;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guarded.find(p);
+        if (it != g_guarded.end()) {
+            r = it->second;
+            mine = true;
+            g_guarded.erase(it);
+        }
+    }
+    if (!mine) return (hipFree)(p);  // memory the caller allocated elsewhere
+    (void)hipDeviceSynchronize();
+    if (guard_check_one(p, r, "free") != RR_OK) fprintf(stderr, "%s\n", rr_last_error());
+    return (hipFree)((char *)p - RR_GUARD);
+}
+#endif
+
 extern "C" {
 
 int rr_abi_version(void) { return RR_ABI_VERSION; }
+
+int rr_build_flags(void) {
+#ifdef RR_BOUNDS
+    return RR_BUILD_BOUNDS;
+#else
+    return 0;
+#endif
+}
 
 const char *rr_last_error(void) { return g_last_error.c_str(); }
 
@@ -108,7 +191,11 @@ int rr_ctx_sync(rr_ctx *ctx) {
     RR_REQUIRE(ctx != nullptr, "rr_ctx_sync: null context");
     RR_CHECK_HIP(hipSetDevice(ctx->device));
     RR_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+#ifdef RR_BOUNDS
+    return rr_guard_check("rr_ctx_sync");
+#else
     return RR_OK;
+#endif
 }
 
 int rr_ctx_info(rr_ctx *ctx, char name[64], int *compute_units, uint64_t *hbm_bytes) {

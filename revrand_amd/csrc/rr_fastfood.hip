@@ -280,6 +280,9 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
     const bool active = j < k;
     const int n = D2 * k;
     const int e0 = l16 * R;                            // first element of this lane
+    // x rows hold d <= d2 elements; an output row holds n (VX) or 2 n (Phi) columns; every permutation entry stays
+    // inside its block
+    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo);
 
     float Lv[R], Gv[R], Sv[R];
     int Pv[R];
@@ -290,6 +293,7 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
         Gv[q] = Gm[idx];
         Sv[q] = Sm[idx];  // S * d2^-1.5 (/ 2 pi when PHI: phase in revolutions)
         Pv[q] = PIm[idx];
+        RR_DEV_ASSERT(Pv[q] >= 0 && Pv[q] < D2);
     }
     float sg[4];
 #pragma unroll

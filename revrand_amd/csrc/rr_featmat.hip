@@ -19,6 +19,7 @@ rr_linear_features_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int 
     if (i >= N * w) return;
     const int64_t r = i / w;
     const int c = (int)(i % w);
+    RR_DEV_ASSERT(w <= ldp && d <= ldx);
     P[r * ldp + c] = (onescol && c == 0) ? 1.f : (float)X[r * ldx + (c - onescol)];
 }
 
@@ -29,6 +30,7 @@ rr_copy_cols_kernel(const TS *__restrict__ src, int64_t N, int64_t lds_, int nco
     if (i >= N * ncols) return;
     const int64_t r = i / ncols;
     const int c = (int)(i % ncols);
+    RR_DEV_ASSERT(ncols <= ldp && ncols <= lds_);
     P[r * ldp + c] = (float)src[r * lds_ + c];
 }
 
@@ -68,6 +70,7 @@ rr_gather_rows_kernel(const uint32_t *__restrict__ src, const int *__restrict__ 
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * ld) return;
     const int64_t r = i / ld, c = i % ld;
+    RR_DEV_ASSERT(idx[r] >= 0);
     dst[i] = src[(int64_t)idx[r] * ld + c];
 }
 

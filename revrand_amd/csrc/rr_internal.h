@@ -70,6 +70,31 @@ struct rr_basis {
 
 void rr_set_error(const char *fmt, ...);
 
+// ---- debug build (make debug: -DRR_BOUNDS) --------------------------------------------------------
+// (1) every device allocation of the library sits between two 4 KiB guard bands filled with a pattern; rr_ctx_sync,
+//     rr_free and the library's own frees verify them, so an out-of-bounds WRITE of any kernel (padded-row stores,
+//     tile edges, 32-bit offset overflow) fails the next synchronisation with the allocation named;
+// (2) RR_DEV_ASSERT traps a kernel whose index arithmetic leaves the extents it was given (out-of-bounds READS of
+//     padded rows / tile edges in the feature, SYRK, feature-matrix and FastFood kernels).
+// The release build compiles both away.
+#ifdef RR_BOUNDS
+hipError_t rr_guard_malloc(void **p, size_t bytes);
+hipError_t rr_guard_free(void *p);
+int rr_guard_check(const char *where);  // RR_OK, or RR_ERR_HIP with the message set
+#define hipMalloc(p, n) rr_guard_malloc((void **)(p), (n))
+#define hipFree(p) rr_guard_free((void *)(p))
+#define RR_DEV_ASSERT(cond)                                                                         \
+    do {                                                                                            \
+        if (!(cond)) {                                                                              \
+            printf("RR_BOUNDS: %s failed at %s:%d (block %u thread %u)\n", #cond, __FILE__, __LINE__, \
+                   (unsigned)blockIdx.x, (unsigned)threadIdx.x);                                    \
+            __builtin_trap();                                                                       \
+        }                                                                                           \
+    } while (0)
+#else
+#define RR_DEV_ASSERT(cond) ((void)0)
+#endif
+
 #define RR_CHECK_HIP(expr)                                                            \
     do {                                                                              \
         hipError_t _e = (expr);                                                       \

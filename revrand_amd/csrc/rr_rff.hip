@@ -277,6 +277,11 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row tiles, hence store bases, are wave-uniform
     const int j = lane & 31, h = lane >> 5;
     const int c0 = blockIdx.x * (32 * CB);
+    // Ws rows are npad wide, X rows at least DMAX; P holds whole 32-row tiles of ldp columns and every store offset
+    // (a 32-bit byte offset from the tile base) must fit
+    RR_DEV_ASSERT(c0 + 32 * CB <= npad && DMAX <= ldx && Npad >= N);
+    RR_DEV_ASSERT((std::is_same<TO, rr_pb_t>::value || std::is_same<TO, rr_pf_t>::value) ||
+                  ((int64_t)2 * n <= ldp && (uint64_t)sizeof(TO) * 36u * (uint64_t)ldp < (1ull << 32)));
     float bw[CB][KS];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
@@ -472,6 +477,7 @@ __device__ __forceinline__ void syrk_dma_tile(const SyrkArgs &p, float *buf, int
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int lr = 4 * wave + k;
+        RR_DEV_ASSERT(kb0 + lr < p.rows && ca + GR_TC <= p.ldp && cb + GR_TC <= p.ldp);  // whole padded tiles only
         const float *src = p.P + (kb0 + lr) * p.ldp + 4 * lane;
         float *dst = buf + lr * GR_LD;  // wave-uniform
         __builtin_amdgcn_global_load_lds((gptr_t)(src + ca), (lptr_t)dst, 16, 0, 0);
@@ -521,6 +527,7 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int64_t nkb = (row_end - row_begin) / GR_KB;  // rows and splits are multiples of 32
+    RR_DEV_ASSERT(p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0 && tb < p.nb && p.nb * GR_TC == p.ldp);
     if (nkb > 0) {
         syrk_dma_tile(p, lds, row_begin, wave, lane, ca, cb);
         __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
@@ -625,6 +632,7 @@ __device__ __forceinline__ void syrk_diag_body(const SyrkArgs &p, float *lds, in
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int lr = 4 * wave + k;
+            RR_DEV_ASSERT(kb0 + lr < p.rows && ca + GR_TC <= p.ldp && p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0);
             const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * GR_TC), 16, 0, 0);
         }
@@ -787,6 +795,7 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
     };
 
     const int64_t nkb = (row_end - row_begin) / G64_KB;
+    RR_DEV_ASSERT(p.rows % G64_KB == 0 && p.rows_per_split % G64_KB == 0 && cb + G64_TC <= p.ldp && row_end <= p.rows);
     if (nkb > 0) {
         dma_tile(lds, row_begin);
         __syncthreads();

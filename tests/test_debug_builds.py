@@ -1,0 +1,87 @@
+"""The sanitizer / bounds-checking builds of the library (`make asan`, `make debug`), when they are built:
+* librevrand_hip_asan.so  -- host side of the C ABI under AddressSanitizer: the ABI checks (CPU) and the ragged-shape
+  parity tests (GPU) run against it in a subprocess with the ASan runtime preloaded;
+* librevrand_hip_debug.so -- -DRR_BOUNDS: guard bands around every device allocation + index assertions in the feature,
+  SYRK, feature-matrix and FastFood kernels; the ragged-shape tests run against it on the GPU, and a deliberate overrun
+  shows that the guards catch one."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+LIBDIR = os.path.join(ROOT, "revrand_amd", "lib")
+ASAN_LIB = os.path.join(LIBDIR, "librevrand_hip_asan.so")
+DEBUG_LIB = os.path.join(LIBDIR, "librevrand_hip_debug.so")
+RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "tests/test_gpu_rff.py::test_transform_shapes_vs_oracle",
+          "tests/test_gpu_rff.py::test_gram_vs_oracle", "tests/test_gpu_rff.py::test_gram_f64_vs_oracle",
+          "tests/test_gpu_fastfood.py", "tests/test_gpu_slm.py::test_concat_second_pass_and_predict_vs_oracle",
+          "tests/test_gpu_slm.py::test_second_pass_and_predict_vs_oracle", "tests/test_gpu_large_xdim.py"]
+
+
+def _asan_runtime():
+    for cc in ("/opt/rocm/bin/hipcc", "/opt/rocm/lib/llvm/bin/clang"):
+        if os.path.exists(cc):
+            p = subprocess.run([cc, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+            if os.path.isabs(p) and os.path.exists(p):
+                return p
+    return None
+
+
+def _pytest_with(lib, args, preload=None, timeout=1500):
+    env = dict(os.environ, REVRAND_HIP_LIB=lib)
+    if preload:
+        env.update(LD_PRELOAD=preload, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0:abort_on_error=1")
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def test_asan_build_passes_the_abi_checks():
+    rt = _asan_runtime()
+    if not os.path.exists(ASAN_LIB) or rt is None:
+        pytest.skip("make -C revrand_amd/csrc asan has not been run")
+    r = _pytest_with(ASAN_LIB, ["tests/test_abi.py", "-m", "not gpu"], preload=rt, timeout=900)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_asan_build_runs_the_ragged_shape_tests():
+    rt = _asan_runtime()
+    if not os.path.exists(ASAN_LIB) or rt is None:
+        pytest.skip("make -C revrand_amd/csrc asan has not been run")
+    r = _pytest_with(ASAN_LIB, RAGGED[:3] + RAGGED[4:5] + ["-m", "gpu"], preload=rt)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_bounds_build_runs_the_ragged_shape_tests():
+    if not os.path.exists(DEBUG_LIB):
+        pytest.skip("make -C revrand_amd/csrc debug has not been run")
+    r = _pytest_with(DEBUG_LIB, RAGGED + ["-m", "gpu"])
+    assert r.returncode == 0 and "RR_BOUNDS" not in (r.stdout + r.stderr), (r.stdout[-2500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bounds_build_catches_an_overrun():
+    if not os.path.exists(DEBUG_LIB):
+        pytest.skip("make -C revrand_amd/csrc debug has not been run")
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from revrand_amd import _hip\n"
+        "dev = _hip.get_device()\n"
+        "assert dev.lib.rr_build_flags() & 1\n"
+        "buf = dev.malloc(1000)\n"
+        "dev.memset(buf, 1000); dev.sync()            # in bounds: fine\n"
+        "_hip._check(dev.lib, dev.lib.rr_memset(dev.ctx, buf.ptr, 0, 1016))   # 16 bytes past the end\n"
+        "try:\n"
+        "    dev.sync()\n"
+        "except _hip.HipError as e:\n"
+        "    assert 'RR_BOUNDS' in str(e) and 'offset 1000' in str(e), str(e)\n"
+        "    print('caught')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVRAND_HIP_LIB=DEBUG_LIB), capture_output=True,
+                       text=True, timeout=600)
+    assert "caught" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
