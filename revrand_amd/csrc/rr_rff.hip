@@ -703,6 +703,7 @@ struct Syrk64Args {
     int F, nb, ntiles;
     int64_t rows_per_split;  // multiple of 16
     double *G;
+    int offdiag_only;  // 1: tiles ta < tb only (the diagonal tiles run in rr_syrk_f64_diag_kernel)
 };
 
 template <int OFF>
@@ -758,11 +759,12 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
     int tdx = blockIdx.x % p.ntiles;
     const int ks = blockIdx.x / p.ntiles;
     int ta = 0;
-    while (tdx >= p.nb - ta) {
-        tdx -= p.nb - ta;
+    const int od = p.offdiag_only;  // row ta then holds nb - ta - od tiles
+    while (tdx >= p.nb - ta - od) {
+        tdx -= p.nb - ta - od;
         ++ta;
     }
-    const int tb = ta + tdx;
+    const int tb = ta + tdx + od;
     const int ca = ta * G64_TC, cb = tb * G64_TC;
 
     const int64_t row_begin = (int64_t)ks * p.rows_per_split;
@@ -824,6 +826,146 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
                 if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], acc[i][j][e]);
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------
+// Diagonal tiles (ta == tb) of the f64 SYRK.  Of the 64 16x16 blocks of a diagonal 128x128 tile only the 36 with
+// block-row <= block-column are needed; the full-tile kernel computes all 64 and throws 28 away at the flush.  Here
+// the 36 are dealt 9 per wave (one wave per SIMD) in groups that share operands -- wave w reads the A-side operands
+// DA[w] and B-side operands DB[w] (7-8 ds_read_b64 per k-step instead of 8) and issues 9 instead of 16 MFMAs -- and
+// only ONE side of the tile is DMA'd (both operands come from the same 128 columns).  Launched after the
+// off-diagonal kernel with its own K-split count.
+//   wave 0: rows 0-2 x cols 0-3 (upper part)        wave 1: (3,3) + rows 0-1 x cols 4-7
+//   wave 2: rows 2-3 x cols 4-7 + (4,4)             wave 3: rows 4-7 x cols 5-7 (upper part)
+// ---------------------------------------------------------------------------------------
+constexpr int G64D_LDB = G64_TC * 8 + 128;  // LDS row stride of the one-sided tile (1024 + 128 pad: conflict-free as above)
+
+template <int W> struct Diag64 {};
+template <> struct Diag64<0> {
+    static constexpr int NA = 3, NBO = 4;
+    static constexpr int A[4] = {0, 1, 2, 0}, B[5] = {0, 1, 2, 3, 0};
+    static constexpr int QA[9] = {0, 0, 0, 0, 1, 1, 1, 2, 2}, QB[9] = {0, 1, 2, 3, 1, 2, 3, 2, 3};  // indices into A / B
+};
+template <> struct Diag64<1> {
+    static constexpr int NA = 3, NBO = 5;
+    static constexpr int A[4] = {0, 1, 3, 0}, B[5] = {3, 4, 5, 6, 7};
+    static constexpr int QA[9] = {2, 0, 0, 0, 0, 1, 1, 1, 1}, QB[9] = {0, 1, 2, 3, 4, 1, 2, 3, 4};
+};
+template <> struct Diag64<2> {
+    static constexpr int NA = 3, NBO = 4;
+    static constexpr int A[4] = {2, 3, 4, 0}, B[5] = {4, 5, 6, 7, 0};
+    static constexpr int QA[9] = {2, 0, 0, 0, 0, 1, 1, 1, 1}, QB[9] = {0, 0, 1, 2, 3, 0, 1, 2, 3};
+};
+template <> struct Diag64<3> {
+    static constexpr int NA = 4, NBO = 3;
+    static constexpr int A[4] = {4, 5, 6, 7}, B[5] = {5, 6, 7, 0, 0};
+    static constexpr int QA[9] = {0, 0, 0, 1, 1, 1, 2, 2, 3}, QB[9] = {0, 1, 2, 0, 1, 2, 1, 2, 2};
+};
+
+template <int W>
+struct KOps64D {
+    typedef Diag64<W> D;
+    double a[D::NA], b[D::NBO];
+    template <int T>
+    __device__ __forceinline__ void load(unsigned base) {
+        if constexpr (D::NA > 0) a[0] = lds_read_b64<4 * T * G64D_LDB + D::A[0] * 128>(base);
+        if constexpr (D::NA > 1) a[1] = lds_read_b64<4 * T * G64D_LDB + D::A[1] * 128>(base);
+        if constexpr (D::NA > 2) a[2] = lds_read_b64<4 * T * G64D_LDB + D::A[2] * 128>(base);
+        if constexpr (D::NA > 3) a[3] = lds_read_b64<4 * T * G64D_LDB + D::A[3] * 128>(base);
+        if constexpr (D::NBO > 0) b[0] = lds_read_b64<4 * T * G64D_LDB + D::B[0] * 128>(base);
+        if constexpr (D::NBO > 1) b[1] = lds_read_b64<4 * T * G64D_LDB + D::B[1] * 128>(base);
+        if constexpr (D::NBO > 2) b[2] = lds_read_b64<4 * T * G64D_LDB + D::B[2] * 128>(base);
+        if constexpr (D::NBO > 3) b[3] = lds_read_b64<4 * T * G64D_LDB + D::B[3] * 128>(base);
+        if constexpr (D::NBO > 4) b[4] = lds_read_b64<4 * T * G64D_LDB + D::B[4] * 128>(base);
+    }
+};
+
+template <int W, int FIRST, int LAST>
+__device__ __forceinline__ void gram64d_mfma(const KOps64D<W> &o, doublex4 (&acc)[9]) {
+    typedef Diag64<W> D;
+#pragma unroll
+    for (int q = FIRST; q < LAST; ++q)
+        acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[D::QA[q]], o.b[D::QB[q]], acc[q], 0, 0, 0);
+}
+
+#define RR_STEP64D(T, CUR, NXT)                            \
+    lds_wait();                                            \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    gram64d_mfma<W, 0, 1>(CUR, acc);                       \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    if ((T) + 1 < 4) NXT.template load<((T) + 1) & 3>(base); \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    gram64d_mfma<W, 1, 9>(CUR, acc);                       \
+    __builtin_amdgcn_sched_barrier(0);
+
+template <int W>
+__device__ __forceinline__ void syrk64_diag_body(const Syrk64Args &p, unsigned char *lds, int lane) {
+    typedef Diag64<W> D;
+    const int ta = blockIdx.x % p.nb;
+    const int ks = blockIdx.x / p.nb;
+    const int ca = ta * G64_TC;
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned off = (lane >> 4) * G64D_LDB + 8u * (lane & 15);
+    doublex4 acc[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[q][e] = 0.0;
+
+    // DMA: 16 row segments of 1 KiB per k-block; wave w moves rows 4w..4w+3
+    auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * W + k;
+            RR_DEV_ASSERT(kb0 + lr < p.rows && ca + G64_TC <= p.ldp);
+            const double *src = p.P + (kb0 + lr) * p.ldp + ca + 2 * lane;  // 16 B per lane
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * G64D_LDB), 16, 0, 0);
+        }
+    };
+
+    const int64_t nkb = (row_end - row_begin) / G64_KB;
+    if (nkb > 0) {
+        dma_tile(lds, row_begin);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (G64_KB * G64D_LDB), row_begin + (kb + 1) * G64_KB);
+            const unsigned base = lds0 + cbuf * (G64_KB * G64D_LDB) + off;
+            KOps64D<W> o0, o1;
+            o0.template load<0>(base);
+            RR_STEP64D(0, o0, o1) RR_STEP64D(1, o1, o0) RR_STEP64D(2, o0, o1) RR_STEP64D(3, o1, o0)
+            __syncthreads();
+        }
+    }
+
+    // flush (f64 C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg); the 8 blocks on the diagonal keep gr <= gc
+    const int64_t F = p.F;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int64_t gc = ca + 16 * D::B[D::QB[q]] + (lane & 15);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t gr = ca + 16 * D::A[D::QA[q]] + (lane >> 4) + 4 * e;
+            if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], acc[q][e]);
+        }
+    }
+}
+#undef RR_STEP64D
+
+__global__ void __launch_bounds__(G64_THREADS, 2)
+rr_syrk_f64_diag_kernel(const Syrk64Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G64_KB * G64D_LDB];  // 36 KiB
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {  // wave-uniform: all four paths hit the same barriers
+        case 0: syrk64_diag_body<0>(p, lds, lane); break;
+        case 1: syrk64_diag_body<1>(p, lds, lane); break;
+        case 2: syrk64_diag_body<2>(p, lds, lane); break;
+        default: syrk64_diag_body<3>(p, lds, lane); break;
+    }
 }
 
 // D[M][N] = A^T B in f64 (second pass of _elbo / predict_moments in f64 arithmetic): A (K, lda) with M columns,
@@ -1387,7 +1529,8 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
 
 int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG) {
     const int nb = (int)(ldp / G64_TC);
-    const int ntiles = nb * (nb + 1) / 2;
+    const int od = (nb >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
+    const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
     const int64_t slots = (int64_t)c->num_cu * 2;  // two workgroups per CU
     // equal-cost workgroups: make their count a multiple of the slots (no partial last round) while a split keeps
     // >= 2048 rows; otherwise ~4 rounds
@@ -1403,7 +1546,28 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
     RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
     Syrk64Args a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
+    a.offdiag_only = od;
     hipLaunchKernelGGL(rr_syrk_f64_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(G64_THREADS), 0, c->stream, a);
+    if (od) {
+        // the diagonal kernel's own K-split: nb equal-cost workgroups per split, up to 4 resident per CU (36 KiB of LDS
+        // each); pick the split count whose workgroup count fills whole rounds best while a split keeps >= 512 rows
+        const int64_t dslots = (int64_t)c->num_cu * 4;
+        int64_t best_ns = 1;
+        double best = -1.0;
+        for (int64_t ns = 1; ns <= 4 * dslots / nb + 1; ++ns) {
+            if (rows / ns < 512 && ns > 1) break;
+            const int64_t wg = ns * nb, rounds = (wg + dslots - 1) / dslots;
+            const double eff = (double)wg / (double)(rounds * dslots);
+            if (eff > best + 1e-9) {
+                best = eff;
+                best_ns = ns;
+            }
+        }
+        Syrk64Args ad = a;
+        ad.rows_per_split = ((rows + best_ns - 1) / best_ns + G64_KB - 1) / G64_KB * G64_KB;
+        const int64_t nsd = (rows + ad.rows_per_split - 1) / ad.rows_per_split;
+        hipLaunchKernelGGL(rr_syrk_f64_diag_kernel, dim3((unsigned)(nsd * nb)), dim3(G64_THREADS), 0, c->stream, ad);
+    }
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
