@@ -354,7 +354,7 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
                 if (jb * D2 + c < n) {
                     TO *o = orow + (half ? n : 0) + c;
 #pragma unroll
-                    for (int u = 0; u < VW; ++u) o[u] = (TO)val[u];
+                    for (int u = 0; u < VW; ++u) RR_STREAM_STORE(&o[u], (TO)val[u]);
                 }
             }
         }

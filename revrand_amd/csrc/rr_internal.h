@@ -70,6 +70,16 @@ struct rr_basis {
 
 void rr_set_error(const char *fmt, ...);
 
+// Stores of write-once streams (feature matrices: written by one kernel, read later by another).  RR_NT_STORES=1 marks
+// them non-temporal (A/B switch of the Makefile: `make NT=1`); RR_NT_ASM is the matching modifier of the asm stores.
+#if defined(RR_NT_STORES) && RR_NT_STORES
+#define RR_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#define RR_NT_ASM " nt"
+#else
+#define RR_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#define RR_NT_ASM ""
+#endif
+
 // ---- debug build (make debug: -DRR_BOUNDS) --------------------------------------------------------
 // (1) every device allocation of the library sits between two 4 KiB guard bands filled with a pattern; rr_ctx_sync,
 //     rr_free and the library's own frees verify them, so an out-of-bounds WRITE of any kernel (padded-row stores,

@@ -365,17 +365,17 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
                         else split_bf16x8(v, g_hi, g_lo);
                     };
                     split8(cvv);
-                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c) : "memory");
                     split8(cvv + 8);
-                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c1) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_c1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_c1) : "memory");
                     split8(svv);
-                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s) : "memory");
                     split8(svv + 8);
-                    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s1) : "memory");
-                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_hi), "s"(tile_s1) : "memory");
+                    asm volatile("global_store_dwordx4 %0, %1, %2 offset:32" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s1) : "memory");
                 }
             } else if (c0 + 32 * cb + j < n) {  // one divergent region per column block (ragged n only)
 #pragma unroll
@@ -387,12 +387,12 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
                     sv = rr < lim ? sv * scale : 0.f;
                     const unsigned off = lane_off + ES * (unsigned)rr * (unsigned)ldp;
                     if constexpr (ES == 4) {
-                        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
-                        asm volatile("global_store_dword %0, %1, %2 offset:%3" ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
                     } else {
                         const double cd = (double)cv, sd = (double)sv;
-                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(off), "v"(cd), "s"(tile_c), "i"(256 * cb) : "memory");
-                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" ::"v"(off), "v"(sd), "s"(tile_s), "i"(256 * cb) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(cd), "s"(tile_c), "i"(256 * cb) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(sd), "s"(tile_s), "i"(256 * cb) : "memory");
                     }
                     if (HAS_Y) {
                         bc[cb] = fmaf(cv, yv[e], bc[cb]);
