@@ -115,10 +115,15 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             from . import parallel
             comm = parallel.get_comm()
             sync = lambda v: comm.broadcast_host(v, root=0)  # noqa: E731
+        # minibatch t+1 is built on a worker thread while step t runs on the device.  With the device sampler `_elbo` never
+        # touches random_; with the reference's stream the worker also makes step t+1's draws right after cutting its
+        # batch -- the order in which a sequential run consumes the stream -- and hands them over with the batch, so
+        # the ~12 ms of randn per config-5 step overlap the kernels instead of preceding them.
+        prefetch = True if self.sampler == "device" else (self._draw_ahead if self._prefetch_draws else False)
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
-                       prefetch=self.sampler == "device", sync=sync)
+                       prefetch=prefetch, sync=sync)
         finally:
             self._resident_fit = False
             self._release_features()
@@ -126,6 +131,19 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         log.info("Finished! reg = {}, likelihood_hypers = {}, basis_hypers = {}, message: {}."
                  .format(self.regularizer_, self.like_hypers_, self.basis_hypers_, res.message))
         return self
+
+    _prefetch_draws = True  # False: `_elbo` draws for itself, strictly sequentially (what the tests compare against)
+
+    def _reference_draws(self):
+        """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component."""
+        K, L_, D = self.K, self.nsamples, self.D_
+        e = np.empty((K * L_, D), dtype=np.float32)
+        for k in range(K):
+            e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
+        return e
+
+    def _draw_ahead(self, batch):
+        return list(batch) + [_Draws(self._reference_draws())]
 
     # -- device features of one minibatch ------------------------------------------------------
     def _features(self):
@@ -157,6 +175,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         L_ = self.nsamples
         lpars_l = atleast_list(lpars)
 
+        draws = None
+        if largs and isinstance(largs[-1], _Draws):                          # made one step ahead (`_draw_ahead`)
+            draws, largs = largs[-1].e, largs[:-1]
         feats = self._features()
         if getattr(self, "_resident_fit", False):                            # rows by index from the resident data
             idx, largs = largs[-1], largs[:-1]
@@ -177,10 +198,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 raise ValueError("sampler must be 'host' or 'device'")
             # the reference's draws, in its order (glm.py:300): randn(L, D) per component; ws = m_k + sqrt(C_k) e and
             # the reductions over the samples (glm.py:309-310) happen on the device
-            e = np.empty((K * L_, D), dtype=np.float32)
-            for k in range(K):
-                e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
-            Edm, EdC, llsum, aux = feats.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L_, e, **okw)
+            if draws is None:
+                self.D_ = D
+                draws = self._reference_draws()
+            Edm, EdC, llsum, aux = feats.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L_, draws, **okw)
 
         nrows = float(len(y))
         if objective_only:
@@ -336,6 +357,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
 class GeneralisedLinearModel(GeneralizedLinearModel):
     """GB/AU spelling (glm.py:640-642)."""
+
+
+class _Draws(object):
+    """Standard-normal draws of one SVI step, riding along with its minibatch."""
+
+    def __init__(self, e):
+        self.e = e
 
 
 def _like_structure(template, flat):

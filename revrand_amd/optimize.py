@@ -290,10 +290,12 @@ def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
         yield (data[ind],) if not issequence(data) else [d[ind] for d in data]
 
 
-def _prefetched(batches):
+def _prefetched(batches, augment=None):
     """The same batches, each produced one step ahead on a worker thread: the device calls inside `fun` release the
     GIL, so the permutation draw and the row gather of step t+1 overlap the kernels of step t.  The order of the
-    batches, hence the generator's use of its RandomState, is unchanged."""
+    batches, hence the generator's use of its RandomState, is unchanged.  `augment(batch) -> batch` runs on the worker
+    right after a batch is cut (the GLM draws its step's standard normals there: batch_t, e_t, batch_t+1, e_t+1, ... is
+    exactly the order in which a sequential run consumes the stream)."""
     import queue
     import threading
     q, stop, END = queue.Queue(maxsize=1), threading.Event(), object()
@@ -310,6 +312,8 @@ def _prefetched(batches):
     def work():
         try:
             for item in batches:
+                if augment is not None:
+                    item = augment(item)
                 if not put(item):
                     return
             put(END)
@@ -334,7 +338,8 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
     """Stochastic gradient descent over minibatches of `data` (sgd.py:337-425): ``fun(x, *batch, *args)`` returns
     the gradient (or ``(objective, gradient)`` with eval_obj); bounded coordinates have outward gradients
     truncated and steps clipped.  `prefetch` (not in the reference): build each minibatch one step ahead on a worker
-    thread -- only valid when `fun` does not draw from `random_state` itself."""
+    thread -- only valid when `fun` does not draw from `random_state` itself; a callable is applied to every batch on
+    that thread (``_prefetched``)."""
     from scipy.optimize import OptimizeResult
     if updater is None:
         updater = Adam()
@@ -349,7 +354,7 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
         upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
     obj, objs, norms = None, [], []
     batches = gen_batch(data, batch_size, maxiter, random_state)
-    for batch in (_prefetched(batches) if prefetch else batches):
+    for batch in (_prefetched(batches, prefetch if callable(prefetch) else None) if prefetch else batches):
         if not eval_obj:
             grad = fun(x, *(list(batch) + list(args)))
         else:

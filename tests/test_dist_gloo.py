@@ -364,3 +364,32 @@ def test_two_rank_glm_unequal_shards_with_random_starts_stay_identical():
         assert p.exitcode == 0
     assert res[0][1:] == res[1][1:]          # identical parameters on both ranks, bit for bit
     assert len(set(np.round(res[0][1], 12))) > 4   # and the mixture did not start (or stay) degenerate
+
+
+def test_draws_made_one_step_ahead_consume_the_stream_like_a_sequential_run():
+    """GLM, reference random stream: the worker thread that builds minibatch t+1 also makes its standard-normal draws
+    (revrand_amd/glm.py `_draw_ahead`).  The fitted parameters must equal, bit for bit, those of a strictly sequential run in
+    which `_elbo` draws for itself (glm.py:300's order: batch_t, e_t, batch_t+1, ...), and random_ must end in the same state."""
+    from revrand_amd.basis_functions import RandomRBF
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    from revrand_amd.likelihoods import Poisson
+    from revrand_amd.optimize import Adam
+    rs = np.random.RandomState(0)
+    N, d, n, K, L = 230, 3, 6, 2, 4
+    X = rs.randn(N, d)
+    y = rs.poisson(np.exp(0.3 * np.sin(X[:, 0]))).astype(float)
+    out = []
+    for ahead in (True, False):
+        np.random.seed(7)  # the start point comes from the global stream
+        basis = RandomRBF(nbases=n, Xdim=d, random_state=5, lenscale=Parameter(np.ones(d), Positive()),
+                          regularizer=Parameter(1.5, Positive()))
+        glm = GeneralizedLinearModel(Poisson(), basis, K=K, nsamples=L, batch_size=60, maxiter=9, nstarts=3,
+                                     random_state=3, updater=Adam(alpha=0.05))
+        glm._prefetch_draws = ahead
+        glm._features = lambda g=glm, b=basis: g.__dict__.setdefault("_mbf", _OracleFeatures(b))
+        glm.fit(X, y)
+        out.append((glm.weights_.copy(), glm.covariance_.copy(), np.asarray(glm.basis_hypers_).copy(),
+                    glm.random_.randint(0, 2 ** 31 - 1)))
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
