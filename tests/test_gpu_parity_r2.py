@@ -235,3 +235,81 @@ def test_default_linear_basis_model_predicts_on_device():
     Eo, Vo = orc.slm_predict_moments(Ps, slm.weights_, slm.covariance_, slm.var_)
     assert normwise(Ey, Eo) < 1e-10 and normwise(Vy, Vo) < 1e-8
     assert smse(3.0 + Xs @ np.array([0.5, -0.25]), Ey) < 1e-2
+
+
+@pytest.mark.timeout(900)
+def test_config3_full_one_gpu_share_properties():
+    """BASELINE configs[2] at one GPU's full share (N = 10M / 8 = 1.25M rows, RandomMatern52 n=4096 + LinearBasis, D=64,
+    F_tot = 8257): size-independent properties of the device-side concatenation + Gram -- the oracle cannot run this size."""
+    bs, Parameter, Positive, _ = _imports()
+    N, d, n = 1_250_000, 64, 4096
+    rng = np.random.default_rng(11)
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    y = rng.standard_normal(N, dtype=np.float32)
+    cat = bs.RandomMatern52(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
+    hyp = [np.linspace(0.7, 1.9, d)]
+    st = cat.device_fit_state(X, y)
+    try:
+        yty = st.gram_device(hyp)
+        G, b, _ = st.stats_host()
+    finally:
+        st.release()
+    F = 2 * n + d + 1
+    assert G.shape == (F, F) and np.array_equal(G, G.T)
+    # cos^2 + sin^2 = 1 per frequency: trace of the random Fourier block is N
+    assert abs(np.trace(G[:2 * n, :2 * n]) - N) < 1e-5 * N
+    # the LinearBasis block is [1, X]^T [1, X]: exact count, column sums and second moments against float64 NumPy
+    X64 = X.astype(np.float64)
+    assert G[2 * n, 2 * n] == N
+    assert normwise(G[2 * n, 2 * n + 1:], X64.sum(axis=0)) < 1e-5
+    assert normwise(G[2 * n + 1:, 2 * n + 1:], X64.T @ X64) < 1e-5
+    assert normwise(b[2 * n:], np.concatenate(([y.astype(np.float64).sum()], X64.T @ y.astype(np.float64)))) < 1e-5
+    assert abs(yty - float((y.astype(np.float64) ** 2).sum())) < 1e-6 * N
+    # a slice of the cross block against the oracle's features of the first rows would need all rows; instead: additivity
+    # over row shards (what the multi-GPU exchange relies on) at full size
+    h = N // 2
+    parts = []
+    for lo, hi in ((0, h), (h, N)):
+        s2 = cat.device_fit_state(X[lo:hi], y[lo:hi])
+        try:
+            s2.gram_device(hyp)
+            parts.append(s2.stats_host())
+        finally:
+            s2.release()
+    assert normwise(parts[0][0] + parts[1][0], G) < 2e-6 and normwise(parts[0][1] + parts[1][1], b) < 1e-5
+
+
+@pytest.mark.timeout(900)
+def test_config4_full_size_stream_properties():
+    """BASELINE configs[3] at full size: FastFoodRBF nbases=8192, D=128 (F=16384), N = 4M rows streamed through a two-slot
+    device ring in 16 chunks of 262 144 rows (Phi would be 262 GB).  Every chunk: unit row norm (sum_j Phi_j^2 = 1) on
+    sampled rows and exact agreement with the oracle chain on a few of them."""
+    from revrand_amd import _hip
+    bs, _, _, _ = _imports()
+    d, nb, CH, NCH = 128, 8192, 262_144, 16
+    f = bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=1)
+    h = f._handles()[0]
+    F = 2 * h.n
+    assert F == 16384
+    dev = _hip.get_device()
+    rng = np.random.default_rng(12)
+    base = rng.standard_normal((CH, d), dtype=np.float32)
+    ring = [dev.malloc(CH * F * 4) for _ in range(2)]
+    dX = [dev.upload_matrix(base), dev.upload_matrix(base)]
+    rows = rng.integers(0, CH, size=48)
+    try:
+        for c in range(NCH):
+            scale = np.float32(1.0 + 0.05 * c)          # chunk c of the stream: a rescaled copy (generation is not the test)
+            Xc = base * scale
+            dev.upload_rows(dX[c & 1], 0, Xc)
+            h.transform_dev(dX[c & 1], 1.3, ring[c & 1], np.float32)
+            dev.sync()
+            out = np.stack([dev.download(ring[c & 1], (F,), np.float32, offset_bytes=int(r) * F * 4) for r in rows])
+            assert np.abs((out.astype(np.float64) ** 2).sum(axis=1) - 1.0).max() < 1e-4
+            if c in (0, NCH - 1):
+                ref = orc.fastfood_transform(Xc[rows[:8]].astype(np.float64), f.B, f.G, f.PI, f.S, 1.3)
+                assert normwise(out[:8], ref) < 1e-3
+    finally:
+        for bfr in ring + dX:
+            bfr.free()
