@@ -25,10 +25,7 @@ __device__ __forceinline__ void ff_sincos_rev<float>(float t, float &s, float &c
     c = __builtin_amdgcn_cosf(f);
 }
 template <>
-__device__ __forceinline__ void ff_sincos_rev<double>(double t, double &s, double &c) {
-    const double f = t - rint(t);
-    sincospi(2.0 * f, &s, &c);
-}
+__device__ __forceinline__ void ff_sincos_rev<double>(double t, double &s, double &c) { rr_sincos_rev_f64(t, s, c); }
 
 // Butterfly partner v[lane ^ M] without LDS traffic: DPP quad permutes (M = 1, 2), masked DPP row
 // shifts (M = 4, 8: lanes whose bit is clear read lane + M, the others lane - M, selected by bank

@@ -70,6 +70,37 @@ struct rr_basis {
 
 void rr_set_error(const char *fmt, ...);
 
+// sin(2 pi t), cos(2 pi t) in float64 for a phase t in REVOLUTIONS: the fraction f = t - rint(t) is exact, k = rint(4 f)
+// picks the quarter turn and the remainder |theta| <= pi / 4 goes through the classic minimax kernels (fdlibm's
+// coefficients: < 1 ulp each on that interval); branch-free, ~25 float64 operations instead of the generic sincospi's
+// reduction and special cases (the f64 feature kernels are bound by this arithmetic, not by HBM).
+#ifdef __HIPCC__
+__device__ __forceinline__ void rr_sincos_rev_f64(double t, double &s, double &c) {
+    const double f = t - rint(t);            // [-0.5, 0.5]
+    const double kq = rint(4.0 * f);         // -2 .. 2
+    const double th = (f - 0.25 * kq) * 6.283185307179586476925286766559;  // [-pi/4, pi/4]; f - kq/4 is exact
+    const double z = th * th;
+    double ps = 1.58969099521155010221e-10;
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);
+    const double sn = fma(th * z, ps, th);
+    double pc = -1.13596475577881948265e-11;
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);
+    const double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const int q = (int)kq & 3;               // quarter turns: (s, c) -> (c, -s) per +1
+    const double s1 = (q & 1) ? cs : sn, c1 = (q & 1) ? -sn : cs;
+    s = (q & 2) ? -s1 : s1;
+    c = (q & 2) ? -c1 : c1;
+}
+#endif
+
 // Stores of write-once streams (feature matrices: written by one kernel, read later by another).  RR_NT_STORES=1 marks
 // them non-temporal (A/B switch of the Makefile: `make NT=1`); RR_NT_ASM is the matching modifier of the asm stores.
 #if defined(RR_NT_STORES) && RR_NT_STORES

@@ -20,10 +20,7 @@ __device__ __forceinline__ void sincos_rev(float t, float &s, float &c) {
     c = __builtin_amdgcn_cosf(f);
 }
 
-__device__ __forceinline__ void sincos_rev(double t, double &s, double &c) {
-    const double f = t - rint(t);
-    sincospi(2.0 * f, &s, &c);
-}
+__device__ __forceinline__ void sincos_rev(double t, double &s, double &c) { rr_sincos_rev_f64(t, s, c); }
 
 // z = sum_i x[i] * w[i] with x wave-uniform (scalar loads) and w in registers.
 // GUARD == false: the row has at least DMAX readable, finite elements (the caller padded X with
