@@ -1499,6 +1499,7 @@ int rr_featmat_predict_begin(rr_featmat *fm, const double *m, const double *C, i
 
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_rows: call rr_featmat_pass2_begin first");
+    RR_FM_REQUIRE_FILLED(fm, "rr_featmat_pass2_rows");
     RR_REQUIRE(dy == nullptr || y_dtype == RR_F32 || y_dtype == RR_F64, "rr_featmat_pass2_rows: bad dtype");
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     s.have_rows = true;
@@ -1544,6 +1545,7 @@ int rr_featmat_pass2_end(rr_featmat *fm, double *sqErr) {
 
 int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_predict_rows: call rr_featmat_pass2_begin first");
+    RR_FM_REQUIRE_FILLED(fm, "rr_featmat_predict_rows");
     RR_REQUIRE(Ey != nullptr && Vf != nullptr, "rr_featmat_predict_rows: null output");
     if (fm->rows == 0) return RR_OK;
     rr_ctx *c = fm->ctx;
@@ -1565,6 +1567,7 @@ int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
 static int glm_step_checks(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param, int K,
                            int L, const char *who) {
     RR_REQUIRE(fm != nullptr && dy != nullptr, "%s: null argument", who);
+    RR_FM_REQUIRE_FILLED(fm, "rr_featmat_glm_step");
     RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "%s: bad dtype", who);
     RR_REQUIRE(lik >= RR_LIK_BERNOULLI && lik <= RR_LIK_POISSON_SOFTPLUS, "%s: unknown likelihood %d", who, lik);
     RR_REQUIRE(lik != RR_LIK_BINOMIAL || drowarg != nullptr, "%s: the binomial needs its per-row n", who);
@@ -1797,6 +1800,7 @@ int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E)
 
 int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
     RR_REQUIRE(fm != nullptr && W != nullptr && out != nullptr && S >= 1 && S < (1 << 24), "rr_featmat_project: bad argument");
+    RR_FM_REQUIRE_FILLED(fm, "rr_featmat_project");
     if (fm->rows == 0) return RR_OK;
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));

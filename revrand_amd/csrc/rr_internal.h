@@ -167,9 +167,14 @@ struct rr_featmat {
     float *P = nullptr;
     int64_t max_rows = 0, ld = 0, rows = 0, rows_pad = 0;
     int F = 0;
+    int64_t covered = 0;    // columns written by put_* since rr_featmat_begin (begin zeroes the padding only)
     void *pass2 = nullptr;  // FmPass2 scratch, grow-never (sized by max_rows, ld)
 };
 void rr_fm_pass2_free(void *p);
+// Consumers of the feature matrix call this first: every column of [0, F) must have been put since rr_featmat_begin.
+#define RR_FM_REQUIRE_FILLED(fm, who)                                                                              \
+    RR_REQUIRE((fm)->rows == 0 || (fm)->covered >= (fm)->F,                                                        \
+               who ": only %lld of the %d columns were written since rr_featmat_begin", (long long)(fm)->covered, (fm)->F)
 
 // Device -> caller's (pageable) host memory for the host-buffer entry points: chunk k is copied into one half of a
 // pinned double buffer (full PCIe rate, asynchronous) while chunk k-1 is spread into the caller's array by a few
