@@ -337,6 +337,19 @@ int rr_rff_predict_devc(rr_basis *basis, const void *dX, int x_dtype, int64_t N,
                         const double *lenscale, int n_ls, const double *m, const double *dC, double *Ey,
                         double *Vf);
 
+/* The variance of predict_moments without cancellation.  phi^T C phi in float32 loses digits when C is badly scaled
+ * (error ~ eps * |phi|^T |C| |phi|, which can exceed the result).  With C = M M^T (M upper triangular: the "UL" Cholesky
+ * factor, float64 on the device, hand-written blocked kernels of rr_posdef.hip) it is the sum of squares || phi^T M ||^2:
+ *   rr_variance_factor_dev   dC (F, F) float64 DEVICE  ->  dB (Fp, Fp) float32 DEVICE, Fp = F rounded up to 256.
+ *                            *form = 1: dB = M, Vf = rowsum((Phi dB)^2).  *form = 0 (C not safely positive definite, e.g.
+ *                            from the SVD route): dB = the triangular form of C, Vf = rowsum((Phi dB) o Phi) as before.
+ *                            Either way the product stops at the diagonal (half of Phi C).  Compute once per covariance.
+ *   rr_rff_predict_devb / rr_featmat_predict_begin_b   the prediction entry points taking that factor ("f32" bases). */
+int rr_variance_factor_dev(rr_ctx *ctx, int64_t F, const double *dC, float *dB, int *form);
+int rr_rff_predict_devb(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
+                        int n_ls, const double *m, const float *dB, int form, double *Ey, double *Vf);
+int rr_featmat_predict_begin_b(rr_featmat *fm, const double *m, const float *dB, int form);
+
 /* ---- FastFood -------------------------------------------------------------------------
  * FastFoodRBF (basis_functions.py:1211-1383).  B (+-1, int64), G, PI (int64 permutations) and S are
  * the host-sampled (k, d2) matrices of _init_matrices / _weightsamples (:1342-1354), row-major;

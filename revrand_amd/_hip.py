@@ -132,6 +132,12 @@ SIGNATURES = {
     "rr_rff_predict_devc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_variance_factor_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                              ctypes.POINTER(ctypes.c_int)]),
+    "rr_rff_predict_devb": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                           ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                           ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_predict_begin_b": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "rr_fastfood_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           _c_void_pp]),
@@ -317,6 +323,40 @@ class DeviceBuffer(object):
 
     def __del__(self):
         self.free()
+
+
+class DeviceCovariance(DeviceBuffer):
+    """A posterior covariance (F, F) float64 resident in HBM, with -- on first use -- its prediction factor
+    (rr_variance_factor_dev): C = M M^T, so that predict_moments' variance is the sum of squares ||phi^T M||^2 instead of
+    the float32 quadratic form phi^T C phi, whose error scales with |phi|^T |C| |phi| (cancellation for badly scaled C)."""
+
+    def __init__(self, dev, C):
+        C = np.ascontiguousarray(C, dtype=np.float64)
+        if C.ndim != 2 or C.shape[0] != C.shape[1]:
+            raise ValueError("a covariance is a square matrix")
+        buf = dev.upload_vector(C.ravel())
+        super().__init__(dev, buf.ptr, buf.nbytes)
+        buf.ptr = None  # ownership moved here
+        self.F = int(C.shape[0])
+        self.dtype = np.dtype(np.float64)
+        self._factor = None
+
+    def factor(self):
+        """(device float32 (Fp, Fp) upper-triangular factor, form): form 1 -> Vf = rowsum((Phi B)^2); form 0 (C not safely
+        positive definite) -> B is the triangular form of C and Vf = rowsum((Phi B) o Phi)."""
+        if self._factor is None:
+            Fp = (self.F + 255) // 256 * 256
+            B = self.dev.malloc(Fp * Fp * 4)
+            form = ctypes.c_int()
+            _check(self.dev.lib, self.dev.lib.rr_variance_factor_dev(self.dev.ctx, self.F, self.ptr, B.ptr, ctypes.byref(form)))
+            self._factor = (B, form.value)
+        return self._factor
+
+    def free(self):
+        f, self._factor = getattr(self, "_factor", None), None
+        if f is not None:
+            f[0].free()
+        super().free()
 
 
 class DeviceMatrix(DeviceBuffer):
@@ -602,6 +642,12 @@ class FeatureMatrix(object):
         if m.shape != (self.F,):
             raise ValueError("posterior shape does not match the feature matrix")
         mp = m.ctypes.data_as(ctypes.c_void_p)
+        if predict and isinstance(C, DeviceCovariance):  # variance as a sum of squares (rr_variance_factor_dev)
+            if C.F != self.F:
+                raise ValueError("posterior shape does not match the feature matrix")
+            B, form = C.factor()
+            _check(self.lib, self.lib.rr_featmat_predict_begin_b(self.h, mp, B.ptr, form))
+            return
         if isinstance(C, np.ndarray):
             C = np.ascontiguousarray(C, dtype=np.float64)
             if C.shape != (self.F, self.F):
@@ -921,12 +967,20 @@ class RffHandle(object):
         N = dX.shape[0]
         ls, lsp, nls = _lenscale_arg(lenscale)
         m = np.ascontiguousarray(m, dtype=np.float64)
+        Ey, Vf = np.empty(N), np.empty(N)
+        if N and isinstance(C, DeviceCovariance) and self.compute == RR_F32:
+            B, form = C.factor()  # f32 arithmetic: variance as a sum of squares, no cancellation
+            _check(self.lib, self.lib.rr_rff_predict_devb(self.h, dX.ptr, rr_dtype(dX.dtype), N, dX.ld, lsp, nls,
+                                                          m.ctypes.data_as(ctypes.c_void_p), B.ptr, form,
+                                                          Ey.ctypes.data_as(ctypes.c_void_p),
+                                                          Vf.ctypes.data_as(ctypes.c_void_p)))
+            dX.free()
+            return Ey, Vf
         if isinstance(C, np.ndarray):
             C = np.ascontiguousarray(C, dtype=np.float64)
             fn, cp = self.lib.rr_rff_predict_dev, C.ctypes.data_as(ctypes.c_void_p)
         else:
             fn, cp = self.lib.rr_rff_predict_devc, _ptr(C)
-        Ey, Vf = np.empty(N), np.empty(N)
         if N:
             _check(self.lib, fn(self.h, dX.ptr, rr_dtype(dX.dtype), N, dX.ld, lsp, nls,
                                                          m.ctypes.data_as(ctypes.c_void_p),

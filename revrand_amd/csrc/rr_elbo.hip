@@ -316,6 +316,10 @@ rr_c64_to_c32_kernel(const double *__restrict__ C, int64_t F, float *__restrict_
     C32[i] = v;
 }
 
+void rr_launch_c64_to_c32_tri(rr_ctx *c, const double *dC, int64_t F, float *dB, int64_t Fb) {
+    hipLaunchKernelGGL(rr_c64_to_c32_kernel, dim3((unsigned)((Fb * Fb + 255) / 256)), dim3(256), 0, c->stream, dC, F, dB, Fb, 1);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
@@ -413,9 +417,12 @@ __global__ void rr_rowvec_kernel(const float *__restrict__ P, const float *__res
 
 // Common driver.  MODE_ELBO: out = [sqErr | T(d*n)] accumulated over row chunks (host doubles).
 //                 MODE_PRED: Ey, Vf per row (host doubles, length N).
+// Bprep (pred only): a prepared DEVICE (Fp, Fp) f32 upper-triangular prediction factor (rr_variance_factor_dev) instead of
+// C; form 1: Vf = rowsum((Phi B)^2), form 0: B is the triangular form of C and Vf = rowsum((Phi B) o Phi).
 template <typename TX>
 static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t N, int64_t ldx, const double *mh,
-                     const double *Ch, double *out0, double *out1, bool c_on_device = false) {
+                     const double *Ch, double *out0, double *out1, bool c_on_device = false, const float *Bprep = nullptr,
+                     int form = 0) {
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n, n = b->n;
     const int64_t Fp = ((int64_t)F + 255) / 256 * 256;
@@ -468,7 +475,9 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         e = hipMemcpy(s.m32, s.hm.data(), (size_t)F * 4, hipMemcpyHostToDevice);
         // prediction needs only the quadratic form phi^T C phi: C goes up in its upper-triangular form (doubled
         // off-diagonals), and the GEMM skips the k-blocks below the diagonal -- half the product
-        if (c_on_device) {
+        if (Bprep) {
+            // nothing to convert
+        } else if (c_on_device) {
             hipLaunchKernelGGL(rr_c64_to_c32_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, Ch,
                                (int64_t)F, s.C32, Fp, pred ? 1 : 0);
         } else {
@@ -514,11 +523,12 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         if (rc != RR_OK) break;
         // U = P C  as  (Pt)^T C : A = Pt (K = Fp, M = mpad columns), B = C32 (K = Fp, N = Fp)
         if (c->gram_engine != 0) {
-            rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, chunk, s.C32, Fp, s.U, Fp, Fp, mpad, Fp, s.Ab, s.Cb, r0 > 0, pred);
+            rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, chunk, Bprep ? Bprep : s.C32, Fp, s.U, Fp, Fp, mpad, Fp, s.Ab, s.Cb,
+                                        r0 > 0, pred);
             if (rc != RR_OK) break;
         } else {
             GemmArgs g;
-            g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
+            g.A = s.Pt; g.B = Bprep ? Bprep : s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
             g.upper_b = pred ? 1 : 0;
             hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
         }
@@ -528,8 +538,8 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             break;
         }
         if (pred) {
-            hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.U, s.P, mrows,
-                               F, Fp, s.acc);
+            hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.U,
+                               (Bprep && form == 1) ? (const float *)s.U : (const float *)s.P, mrows, F, Fp, s.acc);
             std::vector<float> dot(mrows);
             e = hipMemcpyAsync(out1 + r0, s.acc, (size_t)mrows * 8, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(dot.data(), s.dot, (size_t)mrows * 4, hipMemcpyDeviceToHost, c->stream);
@@ -780,6 +790,7 @@ struct FmPass2 {
     void *Ab = nullptr, *Cb = nullptr;  // split-bf16 engine: K-blocked copies of Pt and C32
     bool cb_ready = false;              // Cb matches C32
     bool tri_c = false;                 // prediction: C32 holds the upper-triangular form, the GEMM stops at the diagonal
+    bool sq_form = false;               // prediction: C32 holds the factor M (C = M M^T): Vf = rowsum((P M)^2)
     // GLM step / projection: FSt (max_rows, klp), its transpose DFS (klp, max_rows), the sample matrices
     float *FSt = nullptr, *DFS = nullptr, *WSt = nullptr, *WSs = nullptr, *Ed = nullptr, *Ee = nullptr;
     double *mc = nullptr;  // [m (F K) | C (F K) | Edm (K F) | EdC (K F)] of the device-sampled step
@@ -1380,6 +1391,17 @@ int rr_rff_predict_devc(rr_basis *b, const void *dX, int x_dtype, int64_t N, int
                              : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, dC, Ey, Vf, true);
 }
 
+int rr_rff_predict_devb(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale, int n_ls,
+                        const double *m, const float *dB, int form, double *Ey, double *Vf) {
+    int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, (const double *)dB, "rr_rff_predict_devb");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(Ey != nullptr && Vf != nullptr && (form == 0 || form == 1), "rr_rff_predict_devb: bad argument");
+    RR_REQUIRE(b->compute == RR_F32, "rr_rff_predict_devb: float64 bases keep the float64 quadratic form (rr_rff_predict_devc)");
+    return x_dtype == RR_F32
+               ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, nullptr, Ey, Vf, true, dB, form)
+               : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, nullptr, Ey, Vf, true, dB, form);
+}
+
 int rr_dense_predict(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi, const double *m,
                      const double *C, double *Ey, double *Vf) {
     RR_REQUIRE(c != nullptr && m != nullptr && C != nullptr && Ey != nullptr && Vf != nullptr, "rr_dense_predict: null argument");
@@ -1488,6 +1510,7 @@ static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool
     s.have_rows = false;
     s.cb_ready = false;
     s.tri_c = tri;
+    s.sq_form = false;
     return RR_OK;
 }
 
@@ -1495,6 +1518,30 @@ int rr_featmat_pass2_begin(rr_featmat *fm, const double *m, const double *C) { r
 int rr_featmat_pass2_begin_devc(rr_featmat *fm, const double *m, const double *dC) { return fm_pass2_begin(fm, m, dC, true); }
 int rr_featmat_predict_begin(rr_featmat *fm, const double *m, const double *C, int c_on_device) {
     return fm_pass2_begin(fm, m, C, c_on_device != 0, true);
+}
+
+int rr_featmat_predict_begin_b(rr_featmat *fm, const double *m, const float *dB, int form) {
+    RR_REQUIRE(fm != nullptr && m != nullptr && dB != nullptr && (form == 0 || form == 1), "rr_featmat_predict_begin_b: bad argument");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int F = fm->F;
+    const int64_t Fp = fm->ld;
+    {
+        int rc0 = fm_pass2_scratch(fm);
+        if (rc0 != RR_OK) return rc0;
+    }
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.hm.assign((size_t)Fp, 0.f);
+    for (int i = 0; i < F; ++i) s.hm[i] = (float)m[i];
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(s.m32, s.hm.data(), (size_t)Fp * 4, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpyAsync(s.C32, dB, (size_t)Fp * Fp * 4, hipMemcpyDeviceToDevice, c->stream));
+    RR_CHECK_HIP(hipMemsetAsync(s.sq, 0, 8, c->stream));
+    s.have_rows = false;
+    s.cb_ready = false;
+    s.tri_c = true;
+    s.sq_form = form == 1;
+    return RR_OK;
 }
 
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
@@ -1553,8 +1600,8 @@ int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     int rc = fm_pass2_products(fm, s);
     if (rc != RR_OK) return rc;
-    hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, s.U, fm->P, fm->rows,
-                       fm->F, fm->ld, s.vf);
+    hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, s.U,
+                       s.sq_form ? (const float *)s.U : (const float *)fm->P, fm->rows, fm->F, fm->ld, s.vf);
     RR_CHECK_HIP(hipGetLastError());
     std::vector<float> dot((size_t)fm->rows);
     RR_CHECK_HIP(hipMemcpyAsync(Vf, s.vf, (size_t)fm->rows * 8, hipMemcpyDeviceToHost, c->stream));

@@ -140,6 +140,25 @@ __global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ 
         }
 }
 
+// W (Fp, Fp) = J C J in the top-left F x F (both index orders reversed), identity on the pad diagonal
+__global__ void __launch_bounds__(256)
+rr_reverse_pad_kernel(const double *__restrict__ C, int64_t F, int64_t Fp, double *__restrict__ W) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Fp * Fp) return;
+    const int64_t r = i / Fp, c = i % Fp;
+    W[i] = (r < F && c < F) ? C[(F - 1 - r) * F + (F - 1 - c)] : (r == c ? 1.0 : 0.0);
+}
+
+// B (Fb, Fb) f32 = M in the top-left F x F, zero elsewhere, where J C J = R^T R (R upper, in W) and
+// M[k][j] = R[F-1-j][F-1-k] (upper triangular): C = M M^T, so phi^T C phi = || phi^T M ||^2.
+__global__ void __launch_bounds__(256)
+rr_ul_factor_f32_kernel(const double *__restrict__ W, int64_t F, int64_t Fp, float *__restrict__ B, int64_t Fb) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Fb * Fb) return;
+    const int64_t k = i / Fb, j = i % Fb;
+    B[i] = (k <= j && j < F) ? (float)W[(F - 1 - j) * Fp + (F - 1 - k)] : 0.f;
+}
+
 // one wave per row r:  m[r] = (C[r,:] . b) / var,  tr += C[r,:] . G[r,:],  dg[r] = C[r][r]
 __global__ void __launch_bounds__(256)
 rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict__ G, const double *__restrict__ b,
@@ -187,18 +206,7 @@ void rr_posdef_scratch_free(void *p) {
     delete s;
 }
 
-extern "C" {
-
-int rr_posterior_available(void) { return 1; }
-
-int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, const double *iL, double var, double *dC,
-                     double *m, double *diagC, double *scal) {
-    RR_REQUIRE(c != nullptr && dG != nullptr && db != nullptr && iL != nullptr && dC != nullptr && m != nullptr &&
-                   diagC != nullptr && scal != nullptr,
-               "rr_posterior_dev: null argument");
-    RR_REQUIRE(F >= 1 && F < 46340 && var > 0.0 && std::isfinite(var), "rr_posterior_dev: bad F or var");
-    RR_CHECK_HIP(hipSetDevice(c->device));
-    const int64_t Fp = (F + PB - 1) / PB * PB, nblk = Fp / PB;
+static int posdef_scratch(rr_ctx *c, int64_t Fp, int64_t F, const char *who) {
     if (!c->posdef) c->posdef = new PosdefScratch();
     PosdefScratch &s = *(PosdefScratch *)c->posdef;
     if (s.Fp != Fp) {  // sized exactly: the matrices are dense (Fp, Fp)
@@ -213,20 +221,18 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         if (ea != hipSuccess) {
             (void)hipGetLastError();
             s.release();
-            rr_set_error("rr_posterior_dev: device allocation failed (F = %lld)", (long long)F);
+            rr_set_error("%s: device allocation failed (F = %lld)", who, (long long)F);
             return RR_ERR_OOM;
         }
         s.Fp = Fp;
     }
-    const int64_t ld = Fp;
-    const double ivar = 1.0 / var;
-    RR_CHECK_HIP(hipMemcpyAsync(s.diL, iL, (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
-    const unsigned eb = (unsigned)((Fp * Fp + 255) / 256);
-    hipLaunchKernelGGL(rr_assemble_ic_kernel, dim3(eb), dim3(256), 0, c->stream, dG, s.diL, ivar, F, Fp, s.W);
-    hipLaunchKernelGGL(rr_set_identity_kernel, dim3(eb), dim3(256), 0, c->stream, s.Y, Fp);
-    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// W = U^T U in place (upper triangle of the (Fp, Fp) matrix s.W); Uinv_j = U_jj^-1 on the side
+static int chol_upper_blocked(rr_ctx *c, PosdefScratch &s, int64_t Fp) {
+    const int64_t ld = Fp, nblk = Fp / PB;
     int rc = RR_OK;
-    // ---- factor: W = U^T U (upper triangle of W); Uinv_j = U_jj^-1 on the side ----
     for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
         double *Ujj = s.W + j * PB * (ld + 1);
         double *Uij = s.Uinv + j * PB * PB;
@@ -238,6 +244,78 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
             if (rc == RR_OK) rc = rr_launch_gemm_tn_f64(c, panel, ld, panel, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 1);
         }
     }
+    return rc;
+}
+
+void rr_launch_c64_to_c32_tri(rr_ctx *c, const double *dC, int64_t F, float *dB, int64_t Fb);  // rr_elbo.hip
+
+extern "C" {
+
+int rr_posterior_available(void) { return 1; }
+
+int rr_variance_factor_dev(rr_ctx *c, int64_t F, const double *dC, float *dB, int *form) {
+    RR_REQUIRE(c != nullptr && dC != nullptr && dB != nullptr && form != nullptr, "rr_variance_factor_dev: null argument");
+    RR_REQUIRE(F >= 1 && F < 46340, "rr_variance_factor_dev: bad F");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int64_t Fp = (F + PB - 1) / PB * PB, Fb = (F + 255) / 256 * 256;
+    int rc = posdef_scratch(c, Fp, F, "rr_variance_factor_dev");
+    if (rc != RR_OK) return rc;
+    PosdefScratch &s = *(PosdefScratch *)c->posdef;
+    hipLaunchKernelGGL(rr_reverse_pad_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, dC, F, Fp, s.W);
+    RR_CHECK_HIP(hipGetLastError());
+    rc = chol_upper_blocked(c, s, Fp);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_get_diag_kernel, dim3((unsigned)((Fp + 255) / 256)), dim3(256), 0, c->stream, s.W, Fp, Fp, s.dvec);
+    RR_CHECK_HIP(hipGetLastError());
+    std::vector<double> h((size_t)Fp);
+    RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)Fp * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    double lo = INFINITY, hi = 0.0;
+    for (int64_t i = 0; i < F; ++i) {
+        const double d = h[i];
+        if (!(d > 0.0) || !std::isfinite(d)) {
+            lo = -1.0;
+            break;
+        }
+        lo = d < lo ? d : lo;
+        hi = d > hi ? d : hi;
+    }
+    // a factor whose diagonal spans more than 1e7 is not worth its float32 copy: keep the quadratic form then
+    if (lo > 0.0 && lo > 1e-7 * hi) {
+        hipLaunchKernelGGL(rr_ul_factor_f32_kernel, dim3((unsigned)((Fb * Fb + 255) / 256)), dim3(256), 0, c->stream, s.W, F, Fp,
+                           dB, Fb);
+        RR_CHECK_HIP(hipGetLastError());
+        *form = 1;
+    } else {
+        rr_launch_c64_to_c32_tri(c, dC, F, dB, Fb);
+        RR_CHECK_HIP(hipGetLastError());
+        *form = 0;
+    }
+    return RR_OK;
+}
+
+int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, const double *iL, double var, double *dC,
+                     double *m, double *diagC, double *scal) {
+    RR_REQUIRE(c != nullptr && dG != nullptr && db != nullptr && iL != nullptr && dC != nullptr && m != nullptr &&
+                   diagC != nullptr && scal != nullptr,
+               "rr_posterior_dev: null argument");
+    RR_REQUIRE(F >= 1 && F < 46340 && var > 0.0 && std::isfinite(var), "rr_posterior_dev: bad F or var");
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int64_t Fp = (F + PB - 1) / PB * PB, nblk = Fp / PB;
+    {
+        int rc0 = posdef_scratch(c, Fp, F, "rr_posterior_dev");
+        if (rc0 != RR_OK) return rc0;
+    }
+    PosdefScratch &s = *(PosdefScratch *)c->posdef;
+    const int64_t ld = Fp;
+    const double ivar = 1.0 / var;
+    RR_CHECK_HIP(hipMemcpyAsync(s.diL, iL, (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
+    const unsigned eb = (unsigned)((Fp * Fp + 255) / 256);
+    hipLaunchKernelGGL(rr_assemble_ic_kernel, dim3(eb), dim3(256), 0, c->stream, dG, s.diL, ivar, F, Fp, s.W);
+    hipLaunchKernelGGL(rr_set_identity_kernel, dim3(eb), dim3(256), 0, c->stream, s.Y, Fp);
+    RR_CHECK_HIP(hipGetLastError());
+    // ---- factor: W = U^T U (upper triangle of W); Uinv_j = U_jj^-1 on the side ----
+    int rc = chol_upper_blocked(c, s, Fp);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(rr_get_diag_kernel, dim3((unsigned)((Fp + 255) / 256)), dim3(256), 0, c->stream, s.W, Fp, ld, s.dvec);
     // ---- Y = U^-T by block forward substitution on the identity (Y lower triangular) ----

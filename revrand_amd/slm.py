@@ -307,7 +307,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
     def _device_covariance(self):
         s = self._serving()
         if s["cov"] is None:
-            s["cov"] = _hip.get_device().upload_vector(np.ascontiguousarray(self.covariance_, dtype=np.float64).ravel())
+            s["cov"] = _hip.DeviceCovariance(_hip.get_device(), self.covariance_)
         return s["cov"]
 
     def __getstate__(self):

@@ -313,3 +313,52 @@ def test_config4_full_size_stream_properties():
     finally:
         for bfr in ring + dX:
             bfr.free()
+
+
+@pytest.mark.parametrize("kind", ["rff", "concat"])
+def test_predictive_variance_is_a_sum_of_squares_for_badly_scaled_covariances(kind):
+    """predict_moments' variance phi^T C phi (slm.py:242-243) in float32 loses its digits when C is badly scaled: the error
+    goes with |phi|^T |C| |phi|.  A fitted estimator therefore factors its covariance once (C = M M^T, float64, on the
+    device) and forms || phi^T M ||^2.  Here: the posterior of a vague prior and little noise; the estimator's variance must
+    match float64 NumPy to 1e-3 (the float32 quadratic form on the same inputs is printed next to it)."""
+    bs, Parameter, Positive, SLM = _imports()
+    from revrand_amd import _hip
+    rs = np.random.RandomState(0)
+    d, n = 4, 60
+    if kind == "rff":
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+    else:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+            + bs.LinearBasis(onescol=True)
+    Xs = rs.randn(700, d)
+    ls = np.linspace(0.8, 1.4, d)
+    Phi = basis.transform(Xs, ls)
+    F = Phi.shape[1]
+    # a posterior as a fit with a vague prior and little noise leaves it: C = (I / L + G / var)^-1 with L = 1e6, var = 1e-3.
+    # Directions the training features barely excite keep variances near L, the others fall to var / N: query features
+    # from the same distribution sit almost entirely in the latter, and phi^T C phi is the small difference of big terms.
+    Ptr = basis.transform(rs.randn(4000, d), ls)
+    G = Ptr.T @ Ptr
+    C = np.linalg.inv(np.eye(F) / 1e6 + G / 1e-3)
+    C = 0.5 * (C + C.T)
+    m = rs.randn(F)
+    slm = SLM(basis)
+    slm.var_, slm.regularizer_, slm.hypers_, slm.weights_, slm.covariance_ = 0.0, 1.0, ls, m, C
+    Ey, Vy = slm.predict_moments(Xs)
+    Eo, Vo = Phi @ m, ((Phi @ C) * Phi).sum(axis=1)
+    assert normwise(Ey, Eo) < 1e-4
+    assert np.all(np.abs(Vy - Vo) <= 1e-3 * Vo), float(np.abs(Vy / Vo - 1).max())
+    cov = slm._device_covariance()
+    assert isinstance(cov, _hip.DeviceCovariance) and cov.factor()[1] == 1
+    # the float32 quadratic form on the same inputs, for the record (host C -> triangular float32 form)
+    _, Vq = basis.predict_moments(Xs, ls, m, C)
+    print("max relative error of the variance: sum of squares %.2e, float32 quadratic form %.2e"
+          % (np.abs(Vy / Vo - 1).max(), np.abs(Vq / Vo - 1).max()))
+    assert np.abs(Vq / Vo - 1).max() > np.abs(Vy / Vo - 1).max()
+    # a covariance that is not positive definite (as the SVD route can return) keeps the quadratic form, and still works
+    Cn = C.copy()
+    Cn[0, 0] = -1.0
+    slm.covariance_ = Cn
+    _, Vn = slm.predict_moments(Xs)
+    assert slm._device_covariance().factor()[1] == 0
+    assert normwise(Vn, ((Phi @ Cn) * Phi).sum(axis=1)) < 5e-2
