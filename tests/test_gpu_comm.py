@@ -171,6 +171,34 @@ if rank == 0:  # the same evaluation in one process on all rows
     s1._state.release(); s1._state = None
     out["elbo_single"] = [float(f1), float(gv1), float(gr1)] + np.asarray(gh1).tolist()
     parallel.set_comm(comm)
+# BASELINE config 3's structure (RandomMatern52 + LinearBasis, rows sharded, RCCL Gram all-reduce) in miniature: one
+# distributed _elbo of the concatenation on both ranks, and the all-rows evaluation on rank 0
+cat = bs.RandomMatern52(nbases=150, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive())) \
+    + bs.LinearBasis(onescol=True)
+sc = SLM(cat, distributed=True)
+sc.obj_ = -np.inf
+sc._state = sc._make_state(X[a:b], y[a:b])
+assert type(sc._state).__name__ == "CatFitState"
+fc, (gvc, grc, ghc) = sc._elbo(X[a:b], y[a:b], 0.3, [1.2, 0.8], np.linspace(0.8, 1.3, d))
+sc._state.release(); sc._state = None
+out["cat_elbo"] = [float(fc), float(gvc)] + np.asarray(grc).tolist() + np.asarray(ghc).tolist()
+if rank == 0:
+    parallel.set_comm(parallel.SingleComm())
+    s3 = SLM(cat)
+    s3.obj_ = -np.inf
+    s3._state = s3._make_state(X, y)
+    f3, (gv3, gr3, gh3) = s3._elbo(X, y, 0.3, [1.2, 0.8], np.linspace(0.8, 1.3, d))
+    s3._state.release(); s3._state = None
+    out["cat_elbo_single"] = [float(f3), float(gv3)] + np.asarray(gr3).tolist() + np.asarray(gh3).tolist()
+    parallel.set_comm(comm)
+# the GLM's SVI over the same communicator: unequal shards (2501 / 2500 rows), random starts -> identical parameters
+from revrand_amd.glm import GeneralizedLinearModel
+from revrand_amd.likelihoods import Poisson
+yp = np.random.RandomState(5).poisson(np.exp(0.3 * np.sin(X[:, 0].astype(float)))).astype(float)
+glm = GeneralizedLinearModel(Poisson(), bs.RandomRBF(nbases=24, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())),
+                             K=2, nsamples=6, batch_size=300, maxiter=6, nstarts=3, random_state=4, distributed=True)
+glm.fit(X[a:b].astype(float), yp[a:b])
+out["glm"] = glm.weights_.ravel().tolist() + np.asarray(glm.basis_hypers_).tolist() + [float(glm.regularizer_)]
 assert "torch" not in sys.modules
 comm.barrier()
 comm.close()
@@ -189,6 +217,9 @@ def test_two_rccl_ranks_sum_shard_statistics_and_fit_identically(tmp_path):
     assert res[0]["G_sum"] == res[1]["G_sum"]            # bitwise-identical reduced statistics on both ranks
     assert res[0]["elbo"] == res[1]["elbo"] and res[0]["fit"] == res[1]["fit"]   # ... hence identical paths
     assert normwise(np.array(res[0]["elbo"]), np.array(res[0]["elbo_single"])) < 2e-4   # f32 statistics, two orders
+    assert res[0]["cat_elbo"] == res[1]["cat_elbo"]                                      # concatenation (config 3's form)
+    assert normwise(np.array(res[0]["cat_elbo"]), np.array(res[0]["cat_elbo_single"])) < 5e-4
+    assert res[0]["glm"] == res[1]["glm"] and len(set(np.round(res[0]["glm"], 10))) > 4  # SVI: ranks bit-identical
 
 
 def test_bench_two_ranks_as_the_driver_calls_it():
