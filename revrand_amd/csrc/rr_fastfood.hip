@@ -358,6 +358,151 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The lane-major layout in FLOAT64 arithmetic (dtype = "f64" bases; round 2): same data flow as rr_fastfood16_kernel --
+// one block per DPP row of 16 lanes x R registers, coalesced x through an LDS line, the gather and the output layout
+// change through per-wave LDS lines, 1 KiB-contiguous stores -- with float64 registers.  There is no 64-bit DPP ALU
+// operand, so a butterfly partner travels as two v_mov_b32_dpp (four for lane bits 2 and 3: masked row shifts both
+// ways) followed by one v_fma_f64; the register-level stages are plain adds.  The lane-minor kernel it replaces
+// (ds_bpermute butterflies through the LDS pipe) reached 2.66 TB/s of float64 Phi at config 4's shape.
+// ---------------------------------------------------------------------------------------------
+template <int M>
+__device__ __forceinline__ int dpp_partner32(int x) {
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);        // quad_perm:[1,0,3,2]
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm:[2,3,0,1]
+    else if constexpr (M == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);                  // row_shl:4, banks 0 and 2
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);                         // row_shr:4, banks 1 and 3
+    } else {
+        const int t = __builtin_amdgcn_update_dpp(0, x, 0x108, 0xf, 0x3, false);                  // row_shl:8, banks 0 and 1
+        return __builtin_amdgcn_update_dpp(t, x, 0x118, 0xf, 0xc, false);                         // row_shr:8, banks 2 and 3
+    }
+}
+
+template <int M>
+__device__ __forceinline__ double dpp_partner64(double v) {
+    const int lo = dpp_partner32<M>(__double2loint(v)), hi = dpp_partner32<M>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// unnormalised natural-order WHT of the 16 R elements of a block (element = lane16 * R + q), float64
+template <int R>
+__device__ __forceinline__ void row_fwht64(double (&v)[R], const double (&sg)[4]) {
+#pragma unroll
+    for (int st = 1; st < R; st <<= 1) {  // element bits below log2(R): register butterflies
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            if (!(q & st)) {
+                const double a = v[q], b = v[q | st];
+                v[q] = a + b;
+                v[q | st] = a - b;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = fma(sg[0], v[q], dpp_partner64<1>(v[q]));  // partner + sgn * v
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = fma(sg[1], v[q], dpp_partner64<2>(v[q]));
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = fma(sg[2], v[q], dpp_partner64<4>(v[q]));
+#pragma unroll
+    for (int q = 0; q < R; ++q) v[q] = fma(sg[3], v[q], dpp_partner64<8>(v[q]));
+}
+
+template <int R, bool PHI, typename TX, typename TO>
+__global__ void __launch_bounds__(256)
+rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int k, const double *__restrict__ Bm,
+                      const double *__restrict__ Gm, const int *__restrict__ PIm, const double *__restrict__ Sm,
+                      const double *__restrict__ invls, TO *__restrict__ out, int64_t ldo, double scale, int rows_per_block) {
+    constexpr int D2 = 16 * R;
+    constexpr int WC = 4 * D2;                          // output columns of a wave (its 4 blocks are adjacent)
+    constexpr int VW = (16 / (int)sizeof(TO)) < R ? (16 / (int)sizeof(TO)) : R;  // elements per lane and store (16 B)
+    constexpr int NT = R / VW;
+    __shared__ __attribute__((aligned(16))) double perm[4][WC];
+    __shared__ __attribute__((aligned(16))) TO stage[4][PHI ? 2 : 1][WC];
+    __shared__ __attribute__((aligned(16))) double xline[4][D2 < 64 ? 64 : D2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, sub = lane >> 4;
+    const int jb = (blockIdx.x * 4 + wave) * 4;
+    const int j = jb + sub;
+    const bool active = j < k;
+    const int n = D2 * k;
+    const int e0 = l16 * R;
+    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo);
+
+    double Lv[R], Gv[R], Sv[R];
+    int Pv[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const size_t idx = (size_t)(active ? j : 0) * D2 + e0 + q;
+        Lv[q] = (e0 + q < d ? invls[e0 + q] : 0.0) * Bm[idx];
+        Gv[q] = Gm[idx];
+        Sv[q] = Sm[idx];
+        Pv[q] = PIm[idx];
+    }
+    double sg[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) sg[b] = (l16 >> b) & 1 ? -1.0 : 1.0;
+    double *line = perm[wave] + sub * D2;
+
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > N) r1 = N;
+    constexpr int XL = (D2 + 63) / 64;
+    double xg[XL];
+#pragma unroll
+    for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d && r0 < r1) ? (double)X[r0 * ldx + u * 64 + lane] : 0.0;
+    double *xl = xline[wave];
+    for (int64_t r = r0; r < r1; ++r) {
+#pragma unroll
+        for (int u = 0; u < XL; ++u)
+            if (u * 64 + lane < D2) xl[u * 64 + lane] = xg[u];
+        if (r + 1 < r1) {
+#pragma unroll
+            for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d) ? (double)X[(r + 1) * ldx + u * 64 + lane] : 0.0;
+        }
+        double v[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = xl[e0 + q] * Lv[q];
+        row_fwht64<R>(v, sg);
+#pragma unroll
+        for (int q = 0; q < R; ++q) line[e0 + q] = v[q];
+        // same wave wrote and reads: LDS operations of a wave execute in order
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = line[Pv[q]] * Gv[q];
+        row_fwht64<R>(v, sg);
+        TO *st0 = stage[wave][0] + sub * D2 + e0;
+        if (PHI) {
+            TO *st1 = stage[wave][1] + sub * D2 + e0;
+#pragma unroll
+            for (int q = 0; q < R; ++q) {
+                double s1, c1;
+                rr_sincos_rev_f64(v[q] * Sv[q], s1, c1);
+                st0[q] = (TO)(c1 * scale);
+                st1[q] = (TO)(s1 * scale);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < R; ++q) st0[q] = (TO)(v[q] * Sv[q]);
+        }
+        TO *orow = out + r * ldo + (int64_t)jb * D2;
+        typedef TO tvec __attribute__((ext_vector_type(VW)));
+#pragma unroll
+        for (int half = 0; half < (PHI ? 2 : 1); ++half) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int c = (t * 64 + lane) * VW;
+                const tvec val = *reinterpret_cast<const tvec *>(stage[wave][half] + c);
+                if (jb * D2 + c < n) {
+                    TO *o = orow + (half ? n : 0) + c;
+#pragma unroll
+                    for (int u = 0; u < VW; ++u) o[u] = val[u];
+                }
+            }
+        }
+    }
+}
+
 // mathfun.linalg.hadamard: rows x n (n = 2^p <= 4096), natural order, normalised by 1/n; optional
 // sequency reordering (linalg.py:223-236).  One workgroup per row, butterflies in LDS.
 template <typename TC>
@@ -414,6 +559,32 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
     const TC *Sm = (const TC *)(f32 ? (void *)(PHI ? b->ffSrev32 : b->ffSrad32) : (void *)(PHI ? b->ffSrev64 : b->ffSrad64));
     const TC *Lm = (const TC *)(f32 ? (void *)b->ffL32 : (void *)b->ffL64);
     const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    if constexpr (sizeof(TC) == 8) {  // float64 arithmetic: the lane-major kernel with float64 registers
+        static const bool old_kernel64 = getenv("RR_FASTFOOD_OLD") != nullptr;
+        if (!old_kernel64 && d2 >= 16 && d2 <= 256) {
+            const unsigned gx16 = (unsigned)((k + 15) / 16);
+            const int64_t per = std::max<int64_t>(1, (int64_t)c->num_cu * 3 / gx16);  // ~52 KiB of LDS at d2 = 128: 3 per CU
+            const int64_t m = std::max<int64_t>(1, (N + per * 512 - 1) / (per * 512));
+            int64_t rp = (N + per * m - 1) / (per * m);
+            if (rp < 4) rp = 4;
+            if ((N + rp - 1) / rp > 65535) rp = (N + 65534) / 65535;
+            const dim3 g16(gx16, (unsigned)((N + rp - 1) / rp));
+#define RR_FF16D(RR)                                                                                                   \
+    hipLaunchKernelGGL((rr_fastfood16d_kernel<RR, PHI, TX, TO>), g16, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
+                       b->d, k, (const double *)Bm, (const double *)Gm, b->ffPI, (const double *)Sm, (const double *)Lm, \
+                       (TO *)dOut, ldo, (double)scale, (int)rp)
+            switch (d2 / 16) {
+                case 1: RR_FF16D(1); break;
+                case 2: RR_FF16D(2); break;
+                case 4: RR_FF16D(4); break;
+                case 8: RR_FF16D(8); break;
+                default: RR_FF16D(16); break;
+            }
+#undef RR_FF16D
+            RR_CHECK_HIP(hipGetLastError());
+            return RR_OK;
+        }
+    }
     if constexpr (sizeof(TC) == 4) {  // lane-major packed kernel: one block per DPP row of 16 lanes
         static const bool old_kernel = getenv("RR_FASTFOOD_OLD") != nullptr;
         if (!old_kernel && d2 >= 16 && d2 <= 256) {
