@@ -524,7 +524,7 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int64_t nkb = (row_end - row_begin) / GR_KB;  // rows and splits are multiples of 32
-    RR_DEV_ASSERT(p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0 && tb < p.nb && p.nb * GR_TC == p.ldp);
+    RR_DEV_ASSERT(p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0 && tb < p.nb && p.nb * GR_TC <= p.ldp);
     if (nkb > 0) {
         syrk_dma_tile(p, lds, row_begin, wave, lane, ca, cb);
         __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
@@ -555,6 +555,134 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
         }
     }
     (void)diag;
+}
+
+// ---------------------------------------------------------------------------------------
+// Ragged last column block (round 2).  When F is not a multiple of 256 the last column block holds only
+// w = F - 256 (nb - 1) valid columns, yet every tile (ta, last) costs a full 256x256 tile in the kernel above
+// (config 3: F = 8257, w = 65: 32 of 561 tiles, 4 % of the pass, three quarters of their MFMAs on zeros).  This kernel
+// computes those tiles TRANSPOSED: the ragged block is loaded as the A side, whose 256 columns are split over the waves
+// in 32-column blocks i (wave (wr, wc) owns blocks 4 wr + i), so a wave simply drops the blocks beyond w: NI = the
+// number of its blocks that hold valid columns (0..4; waves with NI = 0 only help with the DMA and the barriers).  A
+// SIMD then issues 2 NI_total MFMAs per k-step instead of 16 (config 3: 6), and the flush writes G[c_t][c_r] with the
+// roles of row and column exchanged.  Launched when w <= 192; the main kernel then enumerates the tiles among the
+// first nb - 1 blocks only.
+// ---------------------------------------------------------------------------------------
+template <int NI>
+struct KOpsR {
+    float2v a[NI], b[2];
+    template <int P>
+    __device__ __forceinline__ void load(const unsigned (&abase)[NI], const unsigned (&bbase)[2]) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[i] = lds_read2st64<32 * P, 32 * P + 16>(abase[i]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = lds_read2st64<32 * P, 32 * P + 16>(bbase[j]);
+    }
+};
+
+// MFMAs [FIRST, LAST) of the 4 NI of a k-step pair, in (s, i, j) order
+template <int NI, int FIRST, int LAST>
+__device__ __forceinline__ void gram_mfma_r(const KOpsR<NI> &o, floatx16 (&acc)[NI][2]) {
+#pragma unroll
+    for (int q = FIRST; q < LAST; ++q) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int s_ = q / (2 * NI), r_ = q % (2 * NI);
+        acc[r_ >> 1][r_ & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[r_ >> 1][s_], o.b[r_ & 1][s_], acc[r_ >> 1][r_ & 1], 0, 0, 0);
+    }
+}
+
+#define RR_PAIRR(P, CUR, NXT)                                  \
+    lds_wait();                                                \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_r<NI, 0, 1>(CUR, acc);                           \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase); \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_r<NI, 1, 4 * NI>(CUR, acc);                      \
+    __builtin_amdgcn_sched_barrier(0);
+
+template <int NI>
+__device__ __forceinline__ void syrk_ragged_loop(const SyrkArgs &p, float *lds, int wave, int lane, int ca, int cb,
+                                                 int64_t row_begin, int64_t nkb) {
+    const int wr = wave >> 2, wc_ = wave & 3;
+    const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
+    const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    constexpr int NA = NI > 0 ? NI : 1;
+    floatx16 acc[NA][2];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (nkb > 0) {
+        syrk_dma_tile(p, lds, row_begin, wave, lane, ca, cb);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) syrk_dma_tile(p, lds + (cbuf ^ 1) * (GR_KB * GR_LD), row_begin + (kb + 1) * GR_KB, wave, lane, ca, cb);
+            if constexpr (NI > 0) {
+                const unsigned cur = lds0 + cbuf * (4u * GR_KB * GR_LD);
+                unsigned abase[NI], bbase[2];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) abase[i] = cur + aoff + i * 128;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bbase[j] = cur + boff + j * 128;
+                KOpsR<NI> o0, o1;
+                o0.template load<0>(abase, bbase);
+                RR_PAIRR(0, o0, o1) RR_PAIRR(1, o1, o0) RR_PAIRR(2, o0, o1) RR_PAIRR(3, o1, o0)
+                RR_PAIRR(4, o0, o1) RR_PAIRR(5, o1, o0) RR_PAIRR(6, o0, o1) RR_PAIRR(7, o1, o0)
+            }
+            __syncthreads();
+        }
+    }
+    // flush, transposed: the A side is the ragged block (columns of G), the B side block ta (rows of G)
+    if constexpr (NI > 0) {
+        const int64_t F = p.F;
+        const int hi = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t grow = cb + wc_ * 64 + j * 32 + (lane & 31);  // row of G: a column of block ta (all valid)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t gcol = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (gcol < F) unsafeAtomicAdd(&p.G[grow * F + gcol], (double)acc[i][j][e]);
+                }
+            }
+        }
+    }
+}
+#undef RR_PAIRR
+
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_f32_ragged_kernel(const SyrkArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int last = p.nb - 1;
+    const int ta = blockIdx.x % last;
+    const int ks = blockIdx.x / last;
+    const int ca = last * GR_TC;  // A side: the ragged block
+    const int cb = ta * GR_TC;    // B side: block ta
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+    const int64_t nkb = (row_end - row_begin) / GR_KB;
+    RR_DEV_ASSERT(p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0 && p.nb * GR_TC == p.ldp && p.F > ca);
+    const int w = p.F - ca;                        // valid columns of the ragged block
+    int ni = (w - (wave >> 2) * 128 + 31) / 32;    // this wave's 32-column blocks with valid columns
+    ni = ni < 0 ? 0 : (ni > 4 ? 4 : ni);
+    switch (ni) {  // wave-uniform; every path runs the same barriers
+        case 0: syrk_ragged_loop<0>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
+        case 1: syrk_ragged_loop<1>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
+        case 2: syrk_ragged_loop<2>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
+        case 3: syrk_ragged_loop<3>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
+        default: syrk_ragged_loop<4>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1461,8 +1589,13 @@ void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
 
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
     if (c->gram_engine != 0) return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
-    const int nb = (int)(ldp / GR_TC);
-    const int od = (nb >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
+    const int nb_all = (int)(ldp / GR_TC);
+    const int od = (nb_all >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
+    // ragged last block (<= 192 valid columns): its off-diagonal tiles go to rr_syrk_f32_ragged_kernel, and the main
+    // kernel enumerates the tiles among the first nb_all - 1 blocks only
+    const int w_last = F - GR_TC * (nb_all - 1);
+    const int rg = (od && nb_all >= 3 && w_last <= 192 && !getenv("RR_SYRK_NO_RAGGED_KERNEL")) ? 1 : 0;
+    const int nb = nb_all - rg;
     const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
     const int nxcd = 8;
     const bool use_map = (ntiles % nxcd == 0) && !getenv("RR_GRAM_NO_TILE_MAP");
@@ -1479,7 +1612,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     // each kernel gets the split count that makes ITS workgroup count (close to) a multiple of the CU count:
     // exactly for the off-diagonal kernel (nsplit = k * CUs / gcd(CUs, ntiles), k minimal), by search for the
     // diagonal one (nb workgroups per split; an odd nb would otherwise force CUs splits on both).
-    const int64_t total_tiles = (int64_t)nb * (nb + 1) / 2;
+    const int64_t total_tiles = (int64_t)nb_all * (nb_all + 1) / 2;
     auto gcd64 = [](int64_t x, int64_t y) { while (y) { const int64_t u = x % y; x = y; y = u; } return x; };
     const int64_t min_splits = (rows + 32767) / 32768;
     auto rows_per = [&](int64_t ns) { return ((rows + ns - 1) / ns + GR_KB - 1) / GR_KB * GR_KB; };
@@ -1493,7 +1626,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         double best = -1.0;
         for (int64_t ns = min_splits; ns < min_splits + 96; ++ns) {
             if (rows / ns < 1024 && ns > 1) break;
-            const int64_t wg = ns * nb, rounds = (wg + c->num_cu - 1) / c->num_cu;
+            const int64_t wg = ns * nb_all, rounds = (wg + c->num_cu - 1) / c->num_cu;
             const double eff = (double)wg / (double)(rounds * c->num_cu);
             if (eff > best + 1e-9) {
                 best = eff;
@@ -1502,11 +1635,27 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         }
         rps_d = rows_per(nsplit_d);
     }
+    int64_t nsplit_r = nsplit, rps_r = rps;
+    if (rg) {  // nb_all - 1 equal-cost workgroups per split: the split count whose workgroups fill whole rounds best
+        double best = -1.0;
+        for (int64_t ns = min_splits; ns < min_splits + 96; ++ns) {
+            if (rows / ns < 1024 && ns > 1) break;
+            const int64_t wg = ns * (nb_all - 1), rounds = (wg + c->num_cu - 1) / c->num_cu;
+            const double eff = (double)wg / (double)(rounds * c->num_cu);
+            if (eff > best + 1e-9) {
+                best = eff;
+                nsplit_r = ns;
+            }
+        }
+        rps_r = rows_per(nsplit_r);
+    }
     const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
-    if (renv && atoll(renv) >= GR_KB) rps = rps_d = (atoll(renv) / GR_KB) * GR_KB;
+    if (renv && atoll(renv) >= GR_KB) rps = rps_d = rps_r = (atoll(renv) / GR_KB) * GR_KB;
     nsplit = (rows + rps - 1) / rps;
     nsplit_d = (rows + rps_d - 1) / rps_d;
-    RR_REQUIRE(nsplit * total_tiles < (int64_t)1 << 31 && nsplit_d * nb < (int64_t)1 << 31, "gram: grid too large");
+    nsplit_r = (rows + rps_r - 1) / rps_r;
+    RR_REQUIRE(nsplit * total_tiles < (int64_t)1 << 31 && nsplit_d * nb_all < (int64_t)1 << 31 &&
+                   nsplit_r * nb_all < (int64_t)1 << 31, "gram: grid too large");
     SyrkArgs a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
     a.tile_map = use_map ? c->tile_map : nullptr;
@@ -1514,11 +1663,18 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
     if (ntiles > 0)
         hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    if (rg) {
+        SyrkArgs ar = a;
+        ar.nb = nb_all;
+        ar.rows_per_split = rps_r;
+        hipLaunchKernelGGL(rr_syrk_f32_ragged_kernel, dim3((unsigned)(nsplit_r * (nb_all - 1))), dim3(GR_THREADS), 0, c->stream, ar);
+    }
     if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
     if (od) {
         SyrkArgs ad = a;
+        ad.nb = nb_all;
         ad.rows_per_split = rps_d;
-        hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb)), dim3(GR_THREADS), 0, c->stream, ad);
+        hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
     }
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;

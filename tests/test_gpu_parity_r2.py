@@ -362,3 +362,23 @@ def test_predictive_variance_is_a_sum_of_squares_for_badly_scaled_covariances(ki
     _, Vn = slm.predict_moments(Xs)
     assert slm._device_covariance().factor()[1] == 0
     assert normwise(Vn, ((Phi @ Cn) * Phi).sum(axis=1)) < 5e-2
+
+
+@pytest.mark.parametrize("n", [257, 288, 289, 321, 352, 353, 400])
+def test_gram_with_a_ragged_last_column_block(n):
+    """F = 2n not a multiple of 256: the tiles of the last column block run in rr_syrk_f32_ragged_kernel (transposed,
+    only the 32-column blocks that hold valid columns) when it has <= 192 valid columns.  Widths on both sides of every
+    boundary (2, 64, 66, 130, 192, 194 valid columns; 800 = 3 blocks + 32), ragged row counts, vs the float64 oracle."""
+    bs, Parameter, Positive, _ = _imports()
+    rs = np.random.RandomState(n)
+    N, d = 3000 + n, 7
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.randn(N).astype(np.float32)
+    b = bs.RandomRBF(nbases=n, Xdim=d, random_state=2)
+    G, bv, yty = b.gram(X, y, 1.1)
+    Gr, br, tr = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, 1.1)
+    assert np.array_equal(G, G.T)
+    assert normwise(G, Gr) < 2e-5 and normwise(bv, br) < 1e-4 and abs(yty - tr) < 1e-6 * tr
+    # the last block's columns specifically (a transposed flush that mixes up rows and columns shows here)
+    c0 = (2 * n - 1) // 256 * 256
+    assert normwise(G[:, c0:], Gr[:, c0:]) < 2e-5
