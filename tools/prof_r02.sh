@@ -1,6 +1,6 @@
 # Round-2 profiling recipe, run on the GPU box by gpurun (scratch under gpurun_out/prof_r02; tools/summarize_r02.py
 # copies the summaries to profiles/r02_*).  Kernel trace and every PMC pass are separate rocprofv3 runs.
-#   sh tools/prof_r02.sh [stage ...]     stages: counters headline configs hbm mall engine
+#   sh tools/prof_r02.sh [stage ...]     stages: counters default headline configs hbm mall engine
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -25,6 +25,10 @@ headline)
   pmc headline_fetch FETCH_SIZE --rows 2000000 --steps 1 --warmup 0 --configs none
   pmc headline_write WRITE_SIZE --rows 2000000 --steps 1 --warmup 0 --configs none
   pmc headline_sq "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE" --rows 2000000 --steps 1 --warmup 0 --configs none ;;
+default)
+  # the default bench command's headline part (N = 10M: 4 passes of 5 launches of 2M rows), without the CPU baseline, the
+  # 2048-row parity launch and the other configurations, which would mix other launch sizes into the kernel averages
+  kt default_kt --configs none ;;
 configs)
   for cfg in headline c3 c4 c5; do
     kt cfg_${cfg}_kt --rows 500000 --steps 1 --warmup 0 --configs $cfg

@@ -193,7 +193,11 @@ for tag, key in (("cfg_headline_kt", "headline_shape_f64"), ("cfg_c3_kt", "C3_ma
         w = [min(256, F - 256 * i) for i in range(nb)]
         off = 2.0 * sum(w[i] * w[j] for i in range(nb) for j in range(i + 1, nb))
         dg = float(sum(x * (x + 1) for x in w))
-        for prefix, fl in (("rr_syrk_f32_kernel(", off), ("rr_syrk_f32_diag_kernel(", dg)):
+        wl = F - 256 * (nb - 1)                      # valid columns of the ragged last block
+        rag = 2.0 * 256 * (nb - 1) * wl if wl <= 192 else 0.0   # its off-diagonal tiles: rr_syrk_f32_ragged_kernel
+        for prefix, fl in (("rr_syrk_f32_kernel(", off - rag), ("rr_syrk_f32_ragged_kernel(", rag), ("rr_syrk_f32_diag_kernel(", dg)):
+            if not any(n.startswith(prefix) for n, _ in trace):
+                continue
             # launches over the full 254 200-row chunks (the last chunk of a pass is the remainder)
             avg, nfull = top_avg([d for n, d in trace if n.startswith(prefix)])
             ks[prefix.rstrip("(")] = {"calls_full_chunk": nfull, "avg_ms": avg, "rows_per_launch": rows,
@@ -299,3 +303,19 @@ if b:
                                                   hbm_side_traffic=t, P_bytes_per_launch=rows * F * 4.0,
                                                   traffic_over_P=(t["fetch_bytes_per_launch"] + t["write_bytes_per_launch"]) / (rows * F * 4.0) if t else None)},
          "sq_counters_per_launch": sq})
+
+
+# ---- the default command (N = 10M) ----
+b = bench_line("default_kt")
+if b:
+    st = kernel_stats("default_kt")
+    rows = b["roofline"]["rows_per_step"] // max(b["roofline"]["launches_per_step"], 1)
+    k = find(st, "rr_syrk_f32_kernel(")
+    fl = b["roofline"]["flops_per_row"] * rows
+    put("r02_default10m", [(os.path.join(SRC, "default_kt", "kt_kernel_stats.csv"), "kernel_stats.csv"),
+                           (os.path.join(SRC, "default_kt.json"), "bench_under_rocprof.json")],
+        {"command": "python bench.py --no-cpu-baseline --no-alt-engine --no-parity-check --configs none (tools/prof_r02.sh default)",
+         "kernels": {"rr_syrk_f32_kernel": dict(st[k], rows_per_launch=rows, algorithmic_flops_per_launch=fl,
+                                                achieved_tflops=fl / (st[k]["avg_ms"] * 1e-3) / 1e12,
+                                                frac_of_peak=fl / (st[k]["avg_ms"] * 1e-3) / PEAK["f32"])},
+         "bench_line_avg_launch_ms": b["roofline"]["avg_launch_ms"], "bench_line_frac": b["roofline"]["frac"]})
