@@ -540,6 +540,7 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
     }
 
     // ---- flush: f32 partial -> f64 G (upper triangle only) ----
+    if (p.ablate & 4) return;  // RR_GRAM_ABLATE bit 2: measure the k-loop alone
     const int64_t F = p.F;
     const int hi = lane >> 5;
 #pragma unroll
