@@ -43,6 +43,31 @@ __device__ __forceinline__ void load_w(TC (&w)[DMAX], const TC *__restrict__ Ws,
     for (int i = 0; i < DMAX; ++i) w[i] = Ws[(size_t)i * npad + f];
 }
 
+// float64 kernels: rows of X staged through LDS, RS rows at a time (coalesced vector loads by the whole block, then
+// broadcast ds_reads).  Through the scalar cache -- as the f32 VALU kernels read x -- every new row is a miss the wave
+// waits out with nothing else to do (s_waitcnt lgkmcnt(0) admits no prefetch): the f64 feature kernel ran at 29 % of its
+// arithmetic, 2.6 TB/s of Phi.
+constexpr int RR_XS_ROWS = 16;
+template <int DMAX, typename TX, typename TC>
+__device__ __forceinline__ void stage_x_rows(TC (*xs)[DMAX], const TX *__restrict__ X, int64_t rb, int64_t rvalid, int64_t ldx) {
+    for (int e = threadIdx.x; e < RR_XS_ROWS * DMAX; e += 256) {
+        const int rr = e / DMAX, i = e % DMAX;
+        xs[rr][i] = (rb + rr < rvalid) ? (TC)X[(rb + rr) * ldx + i] : (TC)0;
+    }
+}
+template <int DMAX, typename TC>
+__device__ __forceinline__ TC project_lds(const TC *__restrict__ xr, const TC (&w)[DMAX]) {
+    TC z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+#pragma unroll
+    for (int i = 0; i < DMAX; i += 4) {
+        z0 = fma(xr[i], w[i], z0);
+        z1 = fma(xr[i + 1], w[i + 1], z1);
+        z2 = fma(xr[i + 2], w[i + 2], z2);
+        z3 = fma(xr[i + 3], w[i + 3], z3);
+    }
+    return (z0 + z1) + (z2 + z3);
+}
+
 // ---------------------------------------------------------------------------------------
 // Phi = [cos, sin] / sqrt(n)        (_RandomKernelBasis.transform, basis_functions.py:838-864)
 // grid.x = frequency blocks of 256, grid.y = row blocks; one frequency per thread, W column in
@@ -60,6 +85,25 @@ rr_rff_transform_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const 
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > N) r1 = N;
+    if constexpr (sizeof(TC) == 8 && DMAX >= 8) {
+        __shared__ TC xs[RR_XS_ROWS][DMAX];
+        for (int64_t rb = r0; rb < r1; rb += RR_XS_ROWS) {
+            __syncthreads();
+            stage_x_rows<DMAX, TX, TC>(xs, X, rb, r1, ldx);
+            __syncthreads();
+            const int nr = (int)(r1 - rb < RR_XS_ROWS ? r1 - rb : RR_XS_ROWS);
+            for (int rr = 0; rr < nr; ++rr) {
+                TC s, c;
+                sincos_rev(project_lds<DMAX, TC>(xs[rr], w), s, c);
+                if (fvalid) {
+                    TO *o = Phi + (rb + rr) * ldphi;
+                    o[f] = (TO)(c * scale);
+                    o[n + f] = (TO)(s * scale);
+                }
+            }
+        }
+        return;
+    }
     for (int64_t r = r0; r < r1; ++r) {
         const TC t = project_row<DMAX, false, TX, TC>(X + r * ldx, DMAX, w);
         TC s, c;
@@ -231,6 +275,38 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
     int64_t r1 = r0 + rows_per_block;
     if (r1 > Npad) r1 = Npad;
     TC bc = 0, bs = 0;
+    if constexpr (sizeof(TC) == 8 && DMAX >= 8) {
+        __shared__ TC xs[RR_XS_ROWS][DMAX];
+        for (int64_t rb = r0; rb < r1; rb += RR_XS_ROWS) {
+            __syncthreads();
+            stage_x_rows<DMAX, TX, TC>(xs, X, rb, N, ldx);
+            __syncthreads();
+            const int nr = (int)(r1 - rb < RR_XS_ROWS ? r1 - rb : RR_XS_ROWS);
+            for (int rr = 0; rr < nr; ++rr) {
+                const int64_t r = rb + rr;
+                TC c = 0, s = 0;
+                if (r < N) {  // uniform
+                    sincos_rev(project_lds<DMAX, TC>(xs[rr], w), s, c);
+                    c *= scale;
+                    s *= scale;
+                    if (HAS_Y) {
+                        const TC yv = (TC)y[r];
+                        bc = fma(c, yv, bc);
+                        bs = fma(s, yv, bs);
+                    }
+                }
+                if (fvalid) {
+                    P[r * ldp + f] = c;
+                    P[r * ldp + n + f] = s;
+                }
+            }
+        }
+        if (HAS_Y && fvalid) {
+            unsafeAtomicAdd(&bvec[f], (double)bc);
+            unsafeAtomicAdd(&bvec[n + f], (double)bs);
+        }
+        return;
+    }
     for (int64_t r = r0; r < r1; ++r) {
         TC c = 0, s = 0;
         if (r < N) {  // uniform
