@@ -256,37 +256,45 @@ __device__ __forceinline__ void row_fwht(float (&v)[R], const float (&sg)[4]) {
     row_stage<8, R>(v, sg[3]);
 }
 
-template <int R, bool PHI, typename TX, typename TO>
+// VEC: rows of X and of the output are aligned for VW-element vector accesses and d is a multiple of VW; FULL: k is a
+// multiple of 4 (every DPP row of every wave owns a block).  With both, the row loop is ONE basic block -- loads from
+// clamped addresses plus selects instead of guarded loads, unconditional stores -- so the compiler can count the
+// stores issued after the next row's x load and waits with vmcnt(stores) instead of vmcnt(0): a wave no longer drains
+// its own stores before it starts the next row.
+template <int R, bool PHI, bool VEC, bool FULL, typename TX, typename TO>
 __global__ void __launch_bounds__(256)
 rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int k, const float *__restrict__ Bm,
                      const float *__restrict__ Gm, const int *__restrict__ PIm, const float *__restrict__ Sm,
                      const float *__restrict__ invls, TO *__restrict__ out, int64_t ldo, float scale,
                      int rows_per_block) {
     constexpr int D2 = 16 * R;
-    constexpr int WC = 4 * D2;                 // output columns of a wave (its 4 blocks are adjacent)
-    constexpr int VW = R >= 4 ? 4 : R;         // floats per lane and store instruction
-    constexpr int NT = R / VW;                 // store instructions per lane and half (cos / sin)
+    constexpr int VW = R >= 4 ? 4 : R;         // contiguous elements per lane and group
+    constexpr int NG = R / VW;                 // groups: element(l16, q) = (q / VW) * 16 VW + l16 * VW + q % VW
+    typedef TX xvec __attribute__((ext_vector_type(VW)));
+    typedef TO ovec __attribute__((ext_vector_type(VW)));
     typedef float fvec __attribute__((ext_vector_type(VW)));
-    __shared__ __attribute__((aligned(16))) float perm[4][WC];
-    __shared__ __attribute__((aligned(16))) float stage[4][PHI ? 2 : 1][WC];
-    __shared__ __attribute__((aligned(16))) float xline[4][D2 < 64 ? 64 : D2];
+    __shared__ __attribute__((aligned(16))) float perm[4][4 * D2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, sub = lane >> 4;
     const int jb = (blockIdx.x * 4 + wave) * 4;        // first FastFood block of this wave
     const int j = jb + sub;                            // block of this DPP row
-    const bool active = j < k;
+    if (jb >= k) return;                               // (whole wave beyond the last block; the kernel has no barriers)
+    const bool active = FULL || j < k;
     const int n = D2 * k;
-    const int e0 = l16 * R;                            // first element of this lane
     // x rows hold d <= d2 elements; an output row holds n (VX) or 2 n (Phi) columns; every permutation entry stays
     // inside its block
-    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo);
+    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo && (!FULL || k % 4 == 0) &&
+                  (!VEC || (d % VW == 0 && ldx % VW == 0 && ldo % VW == 0)));
 
+    int el[R];  // element of register q
+#pragma unroll
+    for (int q = 0; q < R; ++q) el[q] = (q / VW) * (16 * VW) + l16 * VW + (q % VW);
     float Lv[R], Gv[R], Sv[R];
     int Pv[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const size_t idx = (size_t)(active ? j : 0) * D2 + e0 + q;
-        Lv[q] = (e0 + q < d ? invls[e0 + q] : 0.f) * Bm[idx];  // +-1 diagonal folded into 1/l
+        const size_t idx = (size_t)(active ? j : 0) * D2 + el[q];
+        Lv[q] = (el[q] < d ? invls[el[q]] : 0.f) * Bm[idx];  // +-1 diagonal folded into 1/l; 0 beyond d
         Gv[q] = Gm[idx];
         Sv[q] = Sm[idx];  // S * d2^-1.5 (/ 2 pi when PHI: phase in revolutions)
         Pv[q] = PIm[idx];
@@ -300,61 +308,102 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > N) r1 = N;
-    // x of a row is read once per wave, coalesced (lane i takes elements i, i + 64, ...: the 4 blocks of the wave
-    // share it), one row ahead, and handed to the lanes' R-element layout through an LDS line
-    constexpr int XL = (D2 + 63) / 64;
-    float xg[XL];
+    if (r0 >= r1) return;
+    // x: every lane loads its own elements (16 lanes x VW contiguous values per group, the 4 blocks of the wave the same
+    // addresses), one row ahead.  Elements >= d are read from a clamped address of the same row and meet Lv = 0 (no
+    // select on the loaded value: its first use stays a whole iteration away from the load; a non-finite x makes the
+    // whole output row non-finite either way, as in the reference)
+    int xoff[R];
 #pragma unroll
-    for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d && r0 < r1) ? (float)X[r0 * ldx + u * 64 + lane] : 0.f;
-    float *xl = xline[wave];
-    for (int64_t r = r0; r < r1; ++r) {
+    for (int q = 0; q < R; ++q) xoff[q] = el[q] < d ? el[q] : 0;
+    auto load_x = [&](int64_t r, float (&xg)[R]) {
+        const TX *xr = X + r * ldx;
 #pragma unroll
-        for (int u = 0; u < XL; ++u)
-            if (u * 64 + lane < D2) xl[u * 64 + lane] = xg[u];
-        if (r + 1 < r1) {
+        for (int g = 0; g < NG; ++g) {
+            if (VEC) {
+                const xvec t = *reinterpret_cast<const xvec *>(xr + xoff[g * VW]);  // d % VW == 0: a group is in or out
 #pragma unroll
-            for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d) ? (float)X[(r + 1) * ldx + u * 64 + lane] : 0.f;
+                for (int w = 0; w < VW; ++w) xg[g * VW + w] = (float)t[w];
+            } else {
+#pragma unroll
+                for (int w = 0; w < VW; ++w) xg[g * VW + w] = (float)xr[xoff[g * VW + w]];
+            }
         }
-        float v[R];
+    };
+    // x is loaded TWO rows ahead (two register sets, the row loop unrolled by two so that they swap roles without a
+    // copy).  On gfx950 loads and stores retire through one in-order counter: waiting for a row's x also waits for every
+    // store issued before that load, so the load of row r + 2 goes out at the top of row r and is consumed at the END of
+    // row r + 1 -- the stores of rows r and r + 1 stay in flight across it (vmcnt(10)), only row r - 1's must have landed
+    float xa[R], xb[R], v[R];
+    const int64_t rl = r1 - 1;
+    load_x(r0, xa);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = xl[e0 + q] * Lv[q];
+    for (int q = 0; q < R; ++q) v[q] = xa[q] * Lv[q];
+    load_x(r0 + 1 < rl ? r0 + 1 : rl, xa);
+    // s_waitcnt vmcnt(0): every table load above has landed before the loop.  The compiler's wait insertion is not path
+    // sensitive: a table register first used inside the loop would get a wait there that, on all later iterations,
+    // waits for the previous row's stores
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    auto one_row = [&](int64_t r, float (&cur)[R], float (&nxt)[R]) {
+        load_x(r + 2 < rl ? r + 2 : rl, nxt);
         row_fwht<R>(v, sg);
+        // the permutation: through an LDS line of the block (16 lanes x 16 B contiguous per group: no bank conflicts on
+        // the way in; the gather reads single words).  Same wave wrote and reads: LDS operations of a wave execute in order
 #pragma unroll
-        for (int q = 0; q < R; ++q) line[e0 + q] = v[q];
-        // same wave wrote and reads: LDS operations of a wave execute in order
+        for (int g = 0; g < NG; ++g) {
+            fvec t;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) t[w] = v[g * VW + w];
+            *reinterpret_cast<fvec *>(line + g * 16 * VW + l16 * VW) = t;
+        }
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = line[Pv[q]] * Gv[q];
         row_fwht<R>(v, sg);
-        // the lane's R contiguous outputs go through an LDS line of the wave so that every global store
-        // instruction writes 64 x VW contiguous floats instead of 16 separate R-float pieces
-        float *st0 = stage[wave][0] + sub * D2 + e0;
-        if (PHI) {
-            float *st1 = stage[wave][1] + sub * D2 + e0;
+        // a group of a lane is VW contiguous outputs, the 16 lanes of a block 16 VW contiguous ones: whole 128-byte lines
+        // straight from the registers, as non-temporal stores (a write-once stream far larger than the L2: 3.23 -> 3.00 ms
+        // per 262144 x 16384 chunk at config 4's shape)
+        float c1[R], s1[R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                float s1, c1;
-                ff_sincos_rev<float>(v[q] * Sv[q], s1, c1);
-                st0[q] = c1 * scale;
-                st1[q] = s1 * scale;
+        for (int q = 0; q < R; ++q) {
+            if (PHI) {
+                ff_sincos_rev<float>(v[q] * Sv[q], s1[q], c1[q]);
+                c1[q] *= scale;
+                s1[q] *= scale;
+            } else {
+                c1[q] = v[q] * Sv[q];
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < R; ++q) st0[q] = v[q] * Sv[q];
         }
-        TO *orow = out + r * ldo + (int64_t)jb * D2;
+        if (active) {
+            TO *orow = out + r * ldo + (int64_t)j * D2 + l16 * VW;
 #pragma unroll
-        for (int half = 0; half < (PHI ? 2 : 1); ++half) {
+            for (int half = 0; half < (PHI ? 2 : 1); ++half) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = (t * 64 + lane) * VW;
-                const fvec val = *reinterpret_cast<const fvec *>(stage[wave][half] + c);
-                if (jb * D2 + c < n) {
-                    TO *o = orow + (half ? n : 0) + c;
+                for (int g = 0; g < NG; ++g) {
+                    TO *o = orow + (half ? n : 0) + g * 16 * VW;
+                    if (VEC) {
+                        ovec t;
 #pragma unroll
-                    for (int u = 0; u < VW; ++u) RR_STREAM_STORE(&o[u], (TO)val[u]);
+                        for (int w = 0; w < VW; ++w) t[w] = (TO)(half ? s1[g * VW + w] : c1[g * VW + w]);
+                        __builtin_nontemporal_store(t, reinterpret_cast<ovec *>(o));
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < VW; ++w) __builtin_nontemporal_store((TO)(half ? s1[g * VW + w] : c1[g * VW + w]), &o[w]);
+                    }
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist the use of cur to just below its load)
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            v[q] = cur[q] * Lv[q];
+            asm volatile("" : "+v"(v[q]));  // the PRODUCT is what the next row carries (else the multiply sinks into the
+                                            // next iteration and the loaded registers are copied, i.e. waited for, here)
+        }
+    };
+    // an odd row count computes and stores its last row twice (same values) instead of branching inside the loop
+    for (int64_t r = r0; r < r1; r += 2) {
+        one_row(r, xa, xb);
+        one_row(r + 1 < rl ? r + 1 : rl, xb, xa);
     }
 }
 
@@ -409,36 +458,44 @@ __device__ __forceinline__ void row_fwht64(double (&v)[R], const double (&sg)[4]
     for (int q = 0; q < R; ++q) v[q] = fma(sg[3], v[q], dpp_partner64<8>(v[q]));
 }
 
-template <int R, bool PHI, typename TX, typename TO>
+template <int R, bool PHI, bool VEC, bool FULL, typename TX, typename TO>
 __global__ void __launch_bounds__(256)
 rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int k, const double *__restrict__ Bm,
                       const double *__restrict__ Gm, const int *__restrict__ PIm, const double *__restrict__ Sm,
                       const double *__restrict__ invls, TO *__restrict__ out, int64_t ldo, double scale, int rows_per_block) {
+    // same structure as rr_fastfood16_kernel (element layout in groups of VW contiguous values per lane, x straight from
+    // global memory two rows ahead, outputs straight from the registers, one basic block per row), with VW = 2: 16 bytes
+    // of float64 per lane and group, 256 contiguous bytes per block and group
     constexpr int D2 = 16 * R;
-    constexpr int WC = 4 * D2;                          // output columns of a wave (its 4 blocks are adjacent)
-    constexpr int VW = (16 / (int)sizeof(TO)) < R ? (16 / (int)sizeof(TO)) : R;  // elements per lane and store (16 B)
-    constexpr int NT = R / VW;
-    __shared__ __attribute__((aligned(16))) double perm[4][WC];
-    __shared__ __attribute__((aligned(16))) TO stage[4][PHI ? 2 : 1][WC];
-    __shared__ __attribute__((aligned(16))) double xline[4][D2 < 64 ? 64 : D2];
+    constexpr int VW = R >= 2 ? 2 : 1;
+    constexpr int NG = R / VW;
+    typedef TX xvec __attribute__((ext_vector_type(VW)));
+    typedef TO ovec __attribute__((ext_vector_type(VW)));
+    typedef double dvec __attribute__((ext_vector_type(VW)));
+    __shared__ __attribute__((aligned(16))) double perm[4][4 * D2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, sub = lane >> 4;
     const int jb = (blockIdx.x * 4 + wave) * 4;
     const int j = jb + sub;
-    const bool active = j < k;
+    if (jb >= k) return;
+    const bool active = FULL || j < k;
     const int n = D2 * k;
-    const int e0 = l16 * R;
-    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo);
+    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo && (!FULL || k % 4 == 0) &&
+                  (!VEC || (d % VW == 0 && ldx % VW == 0 && ldo % VW == 0)));
 
+    int el[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) el[q] = (q / VW) * (16 * VW) + l16 * VW + (q % VW);
     double Lv[R], Gv[R], Sv[R];
     int Pv[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const size_t idx = (size_t)(active ? j : 0) * D2 + e0 + q;
-        Lv[q] = (e0 + q < d ? invls[e0 + q] : 0.0) * Bm[idx];
+        const size_t idx = (size_t)(active ? j : 0) * D2 + el[q];
+        Lv[q] = (el[q] < d ? invls[el[q]] : 0.0) * Bm[idx];
         Gv[q] = Gm[idx];
         Sv[q] = Sm[idx];
         Pv[q] = PIm[idx];
+        RR_DEV_ASSERT(Pv[q] >= 0 && Pv[q] < D2);
     }
     double sg[4];
 #pragma unroll
@@ -448,58 +505,84 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > N) r1 = N;
-    constexpr int XL = (D2 + 63) / 64;
-    double xg[XL];
+    if (r0 >= r1) return;
+    int xoff[R];
 #pragma unroll
-    for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d && r0 < r1) ? (double)X[r0 * ldx + u * 64 + lane] : 0.0;
-    double *xl = xline[wave];
-    for (int64_t r = r0; r < r1; ++r) {
+    for (int q = 0; q < R; ++q) xoff[q] = el[q] < d ? el[q] : 0;
+    auto load_x = [&](int64_t r, double (&xg)[R]) {
+        const TX *xr = X + r * ldx;
 #pragma unroll
-        for (int u = 0; u < XL; ++u)
-            if (u * 64 + lane < D2) xl[u * 64 + lane] = xg[u];
-        if (r + 1 < r1) {
+        for (int g = 0; g < NG; ++g) {
+            if (VEC) {
+                const xvec t = *reinterpret_cast<const xvec *>(xr + xoff[g * VW]);
 #pragma unroll
-            for (int u = 0; u < XL; ++u) xg[u] = (u * 64 + lane < d) ? (double)X[(r + 1) * ldx + u * 64 + lane] : 0.0;
+                for (int w = 0; w < VW; ++w) xg[g * VW + w] = (double)t[w];
+            } else {
+#pragma unroll
+                for (int w = 0; w < VW; ++w) xg[g * VW + w] = (double)xr[xoff[g * VW + w]];
+            }
         }
-        double v[R];
+    };
+    double xa[R], xb[R], v[R];
+    const int64_t rl = r1 - 1;
+    load_x(r0, xa);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = xl[e0 + q] * Lv[q];
+    for (int q = 0; q < R; ++q) v[q] = xa[q] * Lv[q];
+    load_x(r0 + 1 < rl ? r0 + 1 : rl, xa);
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rr_fastfood16_kernel
+    auto one_row = [&](int64_t r, double (&cur)[R], double (&nxt)[R]) {
+        load_x(r + 2 < rl ? r + 2 : rl, nxt);
         row_fwht64<R>(v, sg);
 #pragma unroll
-        for (int q = 0; q < R; ++q) line[e0 + q] = v[q];
-        // same wave wrote and reads: LDS operations of a wave execute in order
+        for (int g = 0; g < NG; ++g) {
+            dvec t;
+#pragma unroll
+            for (int w = 0; w < VW; ++w) t[w] = v[g * VW + w];
+            *reinterpret_cast<dvec *>(line + g * 16 * VW + l16 * VW) = t;
+        }
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = line[Pv[q]] * Gv[q];
         row_fwht64<R>(v, sg);
-        TO *st0 = stage[wave][0] + sub * D2 + e0;
-        if (PHI) {
-            TO *st1 = stage[wave][1] + sub * D2 + e0;
+        double c1[R], s1[R];
 #pragma unroll
-            for (int q = 0; q < R; ++q) {
-                double s1, c1;
-                rr_sincos_rev_f64(v[q] * Sv[q], s1, c1);
-                st0[q] = (TO)(c1 * scale);
-                st1[q] = (TO)(s1 * scale);
+        for (int q = 0; q < R; ++q) {
+            if (PHI) {
+                rr_sincos_rev_f64(v[q] * Sv[q], s1[q], c1[q]);
+                c1[q] *= scale;
+                s1[q] *= scale;
+            } else {
+                c1[q] = v[q] * Sv[q];
             }
-        } else {
-#pragma unroll
-            for (int q = 0; q < R; ++q) st0[q] = (TO)(v[q] * Sv[q]);
         }
-        TO *orow = out + r * ldo + (int64_t)jb * D2;
-        typedef TO tvec __attribute__((ext_vector_type(VW)));
+        if (active) {
+            TO *orow = out + r * ldo + (int64_t)j * D2 + l16 * VW;
 #pragma unroll
-        for (int half = 0; half < (PHI ? 2 : 1); ++half) {
+            for (int half = 0; half < (PHI ? 2 : 1); ++half) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int c = (t * 64 + lane) * VW;
-                const tvec val = *reinterpret_cast<const tvec *>(stage[wave][half] + c);
-                if (jb * D2 + c < n) {
-                    TO *o = orow + (half ? n : 0) + c;
+                for (int g = 0; g < NG; ++g) {
+                    TO *o = orow + (half ? n : 0) + g * 16 * VW;
+                    if (VEC) {
+                        ovec t;
 #pragma unroll
-                    for (int u = 0; u < VW; ++u) o[u] = val[u];
+                        for (int w = 0; w < VW; ++w) t[w] = (TO)(half ? s1[g * VW + w] : c1[g * VW + w]);
+                        __builtin_nontemporal_store(t, reinterpret_cast<ovec *>(o));
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < VW; ++w) __builtin_nontemporal_store((TO)(half ? s1[g * VW + w] : c1[g * VW + w]), &o[w]);
+                    }
                 }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            v[q] = cur[q] * Lv[q];
+            asm volatile("" : "+v"(v[q]));
+        }
+    };
+    for (int64_t r = r0; r < r1; r += 2) {
+        one_row(r, xa, xb);
+        one_row(r + 1 < rl ? r + 1 : rl, xb, xa);
     }
 }
 
@@ -563,16 +646,34 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
         static const bool old_kernel64 = getenv("RR_FASTFOOD_OLD") != nullptr;
         if (!old_kernel64 && d2 >= 16 && d2 <= 256) {
             const unsigned gx16 = (unsigned)((k + 15) / 16);
-            const int64_t per = std::max<int64_t>(1, (int64_t)c->num_cu * 3 / gx16);  // ~52 KiB of LDS at d2 = 128: 3 per CU
-            const int64_t m = std::max<int64_t>(1, (N + per * 512 - 1) / (per * 512));
-            int64_t rp = (N + per * m - 1) / (per * m);
-            if (rp < 4) rp = 4;
-            if ((N + rp - 1) / rp > 65535) rp = (N + 65534) / 65535;
-            const dim3 g16(gx16, (unsigned)((N + rp - 1) / rp));
-#define RR_FF16D(RR)                                                                                                   \
-    hipLaunchKernelGGL((rr_fastfood16d_kernel<RR, PHI, TX, TO>), g16, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
-                       b->d, k, (const double *)Bm, (const double *)Gm, b->ffPI, (const double *)Sm, (const double *)Lm, \
-                       (TO *)dOut, ldo, (double)scale, (int)rp)
+            const int vw = d2 / 16 >= 2 ? 2 : 1;
+            const bool vec = (ldx % vw == 0) && (ldo % vw == 0) && (b->d % vw == 0) && ((uintptr_t)dX % (vw * sizeof(TX)) == 0) &&
+                             ((uintptr_t)dOut % (vw * sizeof(TO)) == 0) && !getenv("RR_FF_NO_VEC");
+            const bool full = (k % 4 == 0);
+            auto rows_per_wg = [&](int occ) {  // whole rounds of equal-cost workgroups, at most 512 rows each
+                const int64_t per = std::max<int64_t>(1, (int64_t)c->num_cu * occ / gx16);
+                const int64_t m = std::max<int64_t>(1, (N + per * 512 - 1) / (per * 512));
+                int64_t rp = (N + per * m - 1) / (per * m);
+                if (rp < 4) rp = 4;
+                if ((N + rp - 1) / rp > 65535) rp = (N + 65534) / 65535;
+                return rp;
+            };
+#define RR_FF16D_(RR, VEC, FULL)                                                                                     \
+    do {                                                                                                             \
+        auto kern = rr_fastfood16d_kernel<RR, PHI, VEC, FULL, TX, TO>;                                               \
+        static int occ = 0;                                                                                          \
+        if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0) != hipSuccess || occ < 1)) occ = 2; \
+        const int64_t rp = rows_per_wg(occ);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(gx16, (unsigned)((N + rp - 1) / rp)), dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
+                           b->d, k, (const double *)Bm, (const double *)Gm, b->ffPI, (const double *)Sm,             \
+                           (const double *)Lm, (TO *)dOut, ldo, (double)scale, (int)rp);                             \
+    } while (0)
+#define RR_FF16D(RR)                                \
+    do {                                            \
+        if (vec && full) RR_FF16D_(RR, true, true); \
+        else if (vec) RR_FF16D_(RR, true, false);   \
+        else RR_FF16D_(RR, false, false);           \
+    } while (0)
             switch (d2 / 16) {
                 case 1: RR_FF16D(1); break;
                 case 2: RR_FF16D(2); break;
@@ -581,6 +682,7 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
                 default: RR_FF16D(16); break;
             }
 #undef RR_FF16D
+#undef RR_FF16D_
             RR_CHECK_HIP(hipGetLastError());
             return RR_OK;
         }
@@ -589,18 +691,38 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
         static const bool old_kernel = getenv("RR_FASTFOOD_OLD") != nullptr;
         if (!old_kernel && d2 >= 16 && d2 <= 256) {
             const unsigned gx16 = (unsigned)((k + 15) / 16);
-            // whole rounds of workgroups: 6 fit a CU (~80 VGPRs, 26 KiB LDS at d2 = 128); rows per workgroup so that the grid is
-            // m x (CUs x 6) with at most 512 rows each
-            const int64_t per = std::max<int64_t>(1, (int64_t)c->num_cu * 6 / gx16);  // row blocks per round
-            const int64_t m = std::max<int64_t>(1, (N + per * 512 - 1) / (per * 512));
-            int64_t rp = (N + per * m - 1) / (per * m);
-            if (rp < 4) rp = 4;
-            if ((N + rp - 1) / rp > 65535) rp = (N + 65534) / 65535;
-            const dim3 g16(gx16, (unsigned)((N + rp - 1) / rp));
-#define RR_FF16(RR)                                                                                                  \
-    hipLaunchKernelGGL((rr_fastfood16_kernel<RR, PHI, TX, TO>), g16, dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
-                       b->d, k, (const float *)Bm, (const float *)Gm, b->ffPI, (const float *)Sm, (const float *)Lm, \
-                       (TO *)dOut, ldo, (float)scale, (int)rp)
+            // vector loads / stores of a lane's VW = min(4, d2 / 16) contiguous elements need that alignment of the rows
+            const int vw = d2 / 16 >= 4 ? 4 : d2 / 16;
+            const bool vec = (ldx % vw == 0) && (ldo % vw == 0) && (b->d % vw == 0) && ((uintptr_t)dX % (vw * sizeof(TX)) == 0) &&
+                             ((uintptr_t)dOut % (vw * sizeof(TO)) == 0) && !getenv("RR_FF_NO_VEC");
+            const bool full = (k % 4 == 0);
+            // whole rounds of equal-cost workgroups: occ of this instance fit a CU (its registers decide: 5 at d2 = 128);
+            // rows per workgroup so that the grid is m x (CUs x occ) with at most 512 rows each
+            auto rows_per_wg = [&](int occ) {
+                const int64_t per = std::max<int64_t>(1, (int64_t)c->num_cu * occ / gx16);  // row blocks per round
+                const int64_t m = std::max<int64_t>(1, (N + per * 512 - 1) / (per * 512));
+                int64_t rp = (N + per * m - 1) / (per * m);
+                if (rp < 4) rp = 4;
+                if (getenv("RR_FF_ROWS_PER_BLOCK")) rp = std::max(1, atoi(getenv("RR_FF_ROWS_PER_BLOCK")));  // measurement only
+                if ((N + rp - 1) / rp > 65535) rp = (N + 65534) / 65535;
+                return rp;
+            };
+#define RR_FF16_(RR, VEC, FULL)                                                                                      \
+    do {                                                                                                             \
+        auto kern = rr_fastfood16_kernel<RR, PHI, VEC, FULL, TX, TO>;                                                \
+        static int occ = 0;                                                                                          \
+        if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0) != hipSuccess || occ < 1)) occ = 4; \
+        const int64_t rp = rows_per_wg(occ);                                                                         \
+        hipLaunchKernelGGL(kern, dim3(gx16, (unsigned)((N + rp - 1) / rp)), dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
+                           b->d, k, (const float *)Bm, (const float *)Gm, b->ffPI, (const float *)Sm, (const float *)Lm, \
+                           (TO *)dOut, ldo, (float)scale, (int)rp);                                                  \
+    } while (0)
+#define RR_FF16(RR)                                \
+    do {                                           \
+        if (vec && full) RR_FF16_(RR, true, true); \
+        else if (vec) RR_FF16_(RR, true, false);   \
+        else RR_FF16_(RR, false, false);           \
+    } while (0)
             switch (d2 / 16) {
                 case 1: RR_FF16(1); break;
                 case 2: RR_FF16(2); break;
@@ -609,6 +731,7 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
                 default: RR_FF16(16); break;
             }
 #undef RR_FF16
+#undef RR_FF16_
             RR_CHECK_HIP(hipGetLastError());
             return RR_OK;
         }
