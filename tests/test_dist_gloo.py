@@ -120,6 +120,30 @@ def test_two_rank_gloo_allreduce():
     assert res[0][3] == res[1][3]  # bitwise-identical reduced statistics -> identical weights
 
 
+@pytest.mark.timeout(300)
+def test_three_rank_gloo_allreduce_uneven_shards():
+    """An odd world size with N = 1001 rows (shards of 334 / 334 / 333): the single packed exchange still reproduces the
+    one-process statistics on every rank."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[0] for r in res] == [0, 1, 2]
+    assert all(r[1] == 1001 for r in res)
+    assert all(r[2] < 1e-12 for r in res)
+    assert res[0][3] == res[1][3] == res[2][3]
+
+
 class _OracleState(object):
     """Test double for revrand_amd.basis_functions.DeviceFitState: the same interface, the per-rank
     device computation replaced by the NumPy oracle (no GPU here).  Everything around it -- the
