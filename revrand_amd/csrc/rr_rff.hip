@@ -21,6 +21,7 @@ __device__ __forceinline__ void sincos_rev(float t, float &s, float &c) {
 }
 
 __device__ __forceinline__ void sincos_rev(double t, double &s, double &c) { rr_sincos_rev_f64(t, s, c); }
+typedef double doublex4 __attribute__((ext_vector_type(4)));
 
 // z = sum_i x[i] * w[i] with x wave-uniform (scalar loads) and w in registers.
 // GUARD == false: the row has at least DMAX readable, finite elements (the caller padded X with
@@ -526,6 +527,154 @@ static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64
     return true;
 }
 
+// (A'') The float64 feature pass with the projection on the f64 matrix cores (round 2).  The VALU kernel above reads x
+// through LDS broadcast reads -- 16 ds_read_b128 per row and wave, which is what bounds it (the LDS pipe is shared by the
+// four SIMDs: 3.2 TB/s of float64 Phi, 36 % of the f64 VALU rate).  Here a wave keeps the Ws operands of CB column blocks
+// of 16 frequencies in registers (B of v_mfma_f64_16x16x4_f64: lane (j, g) holds Ws[g KS + t][c0 + j] for k-step t,
+// KS = DMAX / 4) and streams 16-row tiles of x (A: lane (i, g) holds x[r0 + i][g KS + t]: a quarter row per lane, vector
+// loads; any pairing of the k index works as long as A and B agree).  Per tile and column block KS MFMAs give the
+// phases of 16 x 16 (row, frequency) pairs, lane (j, g) owning frequency c0 + j and rows r0 + g + 4 e; the VALU is left
+// with the float64 sin / cos kernels only, and every store instruction writes 4 rows x 128 contiguous bytes.
+template <int DMAX, int CB, bool HAS_Y, typename TX, typename TO>
+__global__ void __launch_bounds__(256)
+rr_rff_features_mfma64_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad, int64_t ldx,
+                              const double *__restrict__ Ws, int n, int npad, TO *__restrict__ P, int64_t ldp,
+                              double *__restrict__ bvec, double scale, int tiles_per_block) {
+    constexpr int KS = DMAX / 4;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    const int c0 = blockIdx.x * (16 * CB);
+    RR_DEV_ASSERT(DMAX <= ldx && Npad >= N && (int64_t)2 * n <= ldp && (uint64_t)sizeof(TO) * 20u * (uint64_t)ldp < (1ull << 32));
+    double bw[CB][KS];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int col = c0 + 16 * cb + j;
+#pragma unroll
+        for (int t = 0; t < KS; ++t) bw[cb][t] = col < npad ? Ws[(size_t)(g * KS + t) * npad + col] : 0.0;
+    }
+    double bc[CB], bs[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) bc[cb] = bs[cb] = 0.0;
+    const int64_t ntiles = (Npad + 15) / 16;
+    const int64_t tile0 = (int64_t)blockIdx.y * tiles_per_block;
+    int64_t tile1 = tile0 + tiles_per_block;
+    if (tile1 > ntiles) tile1 = ntiles;
+    for (int64_t tl = tile0 + wave; tl < tile1; tl += 4) {
+        const int64_t r0 = tl * 16;
+        double a[KS];
+        {
+            const int64_t ra = r0 + j;
+            const TX *src = X + (ra < N ? ra : 0) * ldx + g * KS;  // KS contiguous elements
+#pragma unroll
+            for (int t = 0; t < KS; ++t) a[t] = (double)src[t];
+            if (ra >= N) {
+#pragma unroll
+                for (int t = 0; t < KS; ++t) a[t] = 0.0;
+            }
+        }
+        // this lane's rows are r0 + g + 4 e; data rows while g + 4 e < lim.  The scratch has whole 16-row tiles (caller
+        // contract), so pad rows are stored (as zeros) without a guard.
+        const int64_t d0 = N - r0;
+        const int lim = (int)(d0 > 16 ? 16 : (d0 < 0 ? 0 : d0));
+        double yv[4];
+        if (HAS_Y) {  // one coalesced load of the tile's 16 targets, then the lane's 4 rows by cross-lane reads
+            const int64_t ry = r0 + j;
+            double yt = (double)y[ry < N ? ry : N - 1];
+            yt = ry < N ? yt : 0.0;
+            const int lo = __double2loint(yt), hi = __double2hiint(yt);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int srcl = 4 * (g + 4 * e);  // byte address of lane g + 4 e (a lane of the first DPP row: holds y[r0 + g + 4 e])
+                yv[e] = __hiloint2double(__builtin_amdgcn_ds_bpermute(srcl, hi), __builtin_amdgcn_ds_bpermute(srcl, lo));
+            }
+        }
+        const char *tile_c = (const char *)(P + r0 * ldp + c0);
+        const char *tile_s = tile_c + (int64_t)n * (int64_t)sizeof(TO);
+        constexpr unsigned ES = sizeof(TO);
+        const unsigned lane_off = ES * ((unsigned)g * (unsigned)ldp + (unsigned)j);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            doublex4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int t = 0; t < KS; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bw[cb][t], acc, 0, 0, 0);
+            if (c0 + 16 * cb + j < n) {  // one divergent region per column block (ragged n only)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int rr = g + 4 * e;
+                    double sv, cv;
+                    rr_sincos_rev_f64(acc[e], sv, cv);
+                    cv = rr < lim ? cv * scale : 0.0;
+                    sv = rr < lim ? sv * scale : 0.0;
+                    const unsigned off = lane_off + ES * 4u * (unsigned)e * (unsigned)ldp;
+                    if constexpr (ES == 8) {  // non-temporal: +7 % for these 8-byte stores (3.52 -> 3.28 ms per 500k x 4096)
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
+                        asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
+                    } else {
+                        const float cf = (float)cv, sf = (float)sv;
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(cf), "s"(tile_c), "i"(64 * cb) : "memory");
+                        asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(sf), "s"(tile_s), "i"(64 * cb) : "memory");
+                    }
+                    if (HAS_Y) {
+                        bc[cb] = fma(cv, yv[e], bc[cb]);
+                        bs[cb] = fma(sv, yv[e], bs[cb]);
+                    }
+                }
+            }
+        }
+    }
+    if (HAS_Y) {
+        // the four lanes (j, g = 0..3) hold partial sums of the same frequency
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+#pragma unroll
+            for (int m = 16; m < 64; m <<= 1) {
+                bc[cb] += __hiloint2double(__shfl_xor(__double2hiint(bc[cb]), m, 64), __shfl_xor(__double2loint(bc[cb]), m, 64));
+                bs[cb] += __hiloint2double(__shfl_xor(__double2hiint(bs[cb]), m, 64), __shfl_xor(__double2loint(bs[cb]), m, 64));
+            }
+            const int col = c0 + 16 * cb + j;
+            if (g == 0 && col < n) {
+                unsafeAtomicAdd(&bvec[col], bc[cb]);
+                unsafeAtomicAdd(&bvec[n + col], bs[cb]);
+            }
+        }
+    }
+}
+
+// launch (A'') when its preconditions hold (x rows aligned for the lanes' vector loads); false = use the VALU kernel.
+// The output must have whole 16-row tiles.
+template <typename TX, typename TO>
+static bool rr_features_mfma64_launch(rr_basis *b, const TX *X, const TX *y, int64_t m, int64_t mpad, int64_t ldx, TO *P,
+                                      int64_t ldp, double *db, double scale) {
+    static const bool disabled = getenv("RR_FEATURES_NO_MFMA64") != nullptr;
+    if (disabled || b->large || ((ldx * sizeof(TX)) & 15) != 0 || ((uintptr_t)X & 15) != 0 || b->dpad < 8 || m < 1) return false;
+    if ((uint64_t)sizeof(TO) * 20u * (uint64_t)ldp >= (1ull << 32)) return false;
+    rr_ctx *c = b->ctx;
+    const int64_t ntiles = (mpad + 15) / 16;
+#define RR_FM64(DM, CBK)                                                                                            \
+    do {                                                                                                            \
+        const int cgroups = (b->n + 16 * CBK - 1) / (16 * CBK);                                                     \
+        int64_t tpb = 128;                                                                                          \
+        while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 8 * (int64_t)c->num_cu) tpb >>= 1;                 \
+        if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
+        const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
+        if (y) hipLaunchKernelGGL((rr_rff_features_mfma64_kernel<DM, CBK, true, TX, TO>), grid, dim3(256), 0, c->stream, \
+                                  X, y, m, mpad, ldx, b->dWs64, b->n, b->npad, P, ldp, db, scale, (int)tpb);        \
+        else hipLaunchKernelGGL((rr_rff_features_mfma64_kernel<DM, CBK, false, TX, TO>), grid, dim3(256), 0, c->stream, \
+                                X, y, m, mpad, ldx, b->dWs64, b->n, b->npad, P, ldp, db, scale, (int)tpb);          \
+    } while (0)
+    switch (b->dpad) {
+        case 8: RR_FM64(8, 4); break;
+        case 16: RR_FM64(16, 4); break;
+        case 32: RR_FM64(32, 4); break;
+        case 64: RR_FM64(64, 2); break;
+        case 128: RR_FM64(128, 1); break;
+        default: return false;
+    }
+#undef RR_FM64
+    return true;
+}
+
 // zero the pad columns [F, Fp) of a feature matrix (the feature kernels only write [0, F))
 template <typename TC>
 __global__ void __launch_bounds__(256) rr_zero_padcols_kernel(TC *P, int64_t rows, int64_t ldp, int F) {
@@ -897,7 +1046,6 @@ constexpr int G64_TC = 128;            // columns per tile side
 constexpr int G64_KB = 16;             // rows per k-block
 constexpr int G64_LDB = 2 * G64_TC * 8 + 128;  // LDS row stride in bytes (2048 + 128 pad)
 constexpr int G64_THREADS = 256;
-typedef double doublex4 __attribute__((ext_vector_type(4)));
 
 struct Syrk64Args {
     const double *P;  // (rows, ldp) f64 features, zero padded; rows % 16 == 0, ldp % 128 == 0
@@ -1522,6 +1670,16 @@ static int launch_transform(rr_basis *b, const void *dX, int64_t N, int64_t ldx,
             dPhi = (TO *)dPhi + full * ldphi;
             N -= full;
         }
+    } else {  // f64 arithmetic: whole 16-row tiles with the projection on the f64 MFMA
+        const int64_t full = N / 16 * 16;
+        if (full > 0 && rr_features_mfma64_launch<TX, TO>(b, (const TX *)dX, nullptr, full, full, ldx, (TO *)dPhi, ldphi,
+                                                          nullptr, (double)scale)) {
+            RR_CHECK_HIP(hipGetLastError());
+            if (full == N) return RR_OK;
+            dX = (const TX *)dX + full * ldx;
+            dPhi = (TO *)dPhi + full * ldphi;
+            N -= full;
+        }
     }
     const int fblocks = (b->n + 255) / 256;
     // enough row blocks to fill the chip a few times over, >= 16 rows each
@@ -1882,6 +2040,7 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
             if (rc != RR_OK) return rc;
             done_a = true;
         } else if constexpr (F32) done_a = rr_features_mfma_launch<TX, float>(b, Xc, yc, m, mpad, ldx, (float *)P, ldp, db, (float)scale);
+        else done_a = rr_features_mfma64_launch<TX, double>(b, Xc, yc, m, mpad, ldx, (double *)P, ldp, db, (double)scale);
         if (!done_a) {
             const int fblocks = (b->n + 255) / 256;
             int64_t rpb = 256;
@@ -1986,6 +2145,15 @@ int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m
     if (b->large)
         return x_dtype == RR_F32 ? large_features<float, double, double>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr)
                                  : large_features<double, double, double>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr);
+    if (mpad % 16 == 0) {  // projection on the f64 MFMA (whole 16-row tiles)
+        const bool done = x_dtype == RR_F32
+                              ? rr_features_mfma64_launch<float, double>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)
+                              : rr_features_mfma64_launch<double, double>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale);
+        if (done) {
+            RR_CHECK_HIP(hipGetLastError());
+            return RR_OK;
+        }
+    }
     const int fblocks = (b->n + 255) / 256;
     int64_t rpb = 256;
     if ((mpad + rpb - 1) / rpb > 65535) rpb = (mpad + 65534) / 65535;
