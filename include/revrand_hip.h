@@ -437,6 +437,18 @@ int rr_stats_unpack_dev(rr_ctx *ctx, int64_t F, const double *dmsg, double *dG, 
 int rr_comm_reduce_stats_dev(rr_comm *comm, int64_t F, double *dG, double *db, double *dyty, double nrows, double *dmsg,
                              double *total_rows);
 
+/* ---- host-side random stream of the GLM step ------------------------------ */
+
+/* Advance a NumPy legacy RandomState (MT19937 + polar Box-Muller with one cached value) by n standard normals and write
+ * them to `out` (RR_F32 or RR_F64; float32 is the round-to-nearest cast of the float64 value), bit for bit what
+ * `RandomState.randn(n)` returns and leaves behind.  Replaces `self.random_.randn(self.nsamples, D)` of
+ * revrand/glm.py:300 (`_reparam_k`), called K times per SVI step.  key: the 624 state words; pos: 0..624; has_gauss / gauss:
+ * the cached second value of the last pair (`RandomState.get_state()[3:5]`).  The MT19937 words and the accept / reject
+ * loop run on the calling thread, sqrt(-2 log(r2) / r2) of the accepted pairs on up to `threads` worker threads.  Host
+ * only: needs no device. */
+int rr_legacy_randn(uint32_t *key, int32_t *pos, int32_t *has_gauss, double *gauss, void *out, int out_dtype, int64_t n,
+                    int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,8 @@ _c_double_p = ctypes.POINTER(ctypes.c_double)
 SIGNATURES = {
     "rr_abi_version": (ctypes.c_int, []),
     "rr_build_flags": (ctypes.c_int, []),
+    "rr_legacy_randn": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     "rr_last_error": (ctypes.c_char_p, []),
     "rr_device_count": (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)]),
     "rr_ctx_create": (ctypes.c_int, [ctypes.c_int, _c_void_pp]),
@@ -505,6 +507,27 @@ def get_device(index=None):
         dev = Device(index)
         _devices[key] = dev
     return dev
+
+
+def legacy_randn(random_state, n, dtype=np.float32, threads=8):
+    """`random_state.randn(n)` (a NumPy legacy RandomState), bit for bit and leaving the same state behind, through
+    rr_legacy_randn: the sequential part of the generator on this thread, the square roots and logarithms on `threads`
+    worker threads.  Anything but a plain MT19937 RandomState falls back to NumPy itself (same values either way)."""
+    dtype = np.dtype(dtype)
+    try:
+        st = random_state.get_state(legacy=True)
+    except TypeError:
+        st = random_state.get_state()
+    if n <= 0 or not isinstance(st, tuple) or st[0] != "MT19937" or dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        return random_state.randn(n).astype(dtype, copy=False)
+    lib = load_library()
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos, has, g = ctypes.c_int32(int(st[2])), ctypes.c_int32(int(st[3])), ctypes.c_double(float(st[4]))
+    out = np.empty(n, dtype=dtype)
+    _check(lib, lib.rr_legacy_randn(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), ctypes.byref(has), ctypes.byref(g),
+                                    out.ctypes.data_as(ctypes.c_void_p), rr_dtype(dtype), n, threads))
+    random_state.set_state(("MT19937", key, pos.value, has.value, g.value))
+    return out
 
 
 @contextlib.contextmanager

@@ -137,10 +137,14 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     def _reference_draws(self):
         """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component."""
         K, L_, D = self.K, self.nsamples, self.D_
+        if self._native_draws:  # the same K consecutive randn(L, D) as one call of the library's generator (bit-identical)
+            return _hip.legacy_randn(self.random_, K * L_ * D, np.float32).reshape(K * L_, D)
         e = np.empty((K * L_, D), dtype=np.float32)
         for k in range(K):
             e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
         return e
+
+    _native_draws = True  # False: NumPy generates the draws (what tests compare the library's generator against)
 
     def _draw_ahead(self, batch):
         return list(batch) + [_Draws(self._reference_draws())]

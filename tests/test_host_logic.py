@@ -377,3 +377,28 @@ def test_gram_engine_keyword_is_a_plain_sklearn_parameter():
     assert pickle.loads(pickle.dumps(slm)).gram_engine == "fp16x3"
     glm = GeneralizedLinearModel(gram_engine="bf16x3")
     assert clone(glm).set_params(gram_engine=None).gram_engine is None
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_library_generator_reproduces_numpy_legacy_randn(dtype):
+    """rr_legacy_randn (MT19937 words + polar method on the calling thread, sqrt / log on worker threads) returns what
+    `RandomState.randn` returns, bit for bit, and leaves the same generator state: odd and even counts (the cached second
+    value of a pair), counts that cross the 624-word regeneration and the worker hand-over blocks, interleaved with other
+    draws of the same RandomState as the SVI loop interleaves minibatch permutations."""
+    from revrand_amd import _hip
+    for seed, sizes in [(0, [1, 2, 3, 7, 311, 312, 313, 1000, 65537, 200001]), (123, [5, 5, 4, 100000, 1, 131072 + 3])]:
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        for i, n in enumerate(sizes):
+            want = a.randn(n).astype(dtype)
+            got = _hip.legacy_randn(b, n, dtype, threads=4)
+            assert got.dtype == np.dtype(dtype) and np.array_equal(got, want), (seed, n)
+            if i % 2:  # other consumers of the stream in between
+                assert np.array_equal(a.permutation(17), b.permutation(17))
+                assert a.randint(0, 1000) == b.randint(0, 1000)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+    # the GLM's use: K calls of randn(L, D) == one call of K L D values
+    a, b = np.random.RandomState(9), np.random.RandomState(9)
+    want = np.concatenate([a.randn(5, 33) for _ in range(3)]).astype(dtype)
+    assert np.array_equal(_hip.legacy_randn(b, 3 * 5 * 33, dtype).reshape(15, 33), want)
+    assert a.randn() == b.randn()
