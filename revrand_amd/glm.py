@@ -192,9 +192,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         objective_only = objective_only and getattr(feats, "supports_objective_only", False)
         # the mixture-entropy terms depend on (m, C) only: a worker thread forms them while the device call below (which
         # releases the GIL) runs the step's kernels -- ~0.7 ms of a 6 ms config-5 step
-        # (only with the device sampler: with the reference's stream the step waits for the randn worker, and a second
-        # helper thread only takes the GIL away from it)
-        mixture = _submit(_mixture_terms, m, C) if (self.sampler == "device" and not objective_only) else None
+        # (with NumPy generating the reference's stream the step waits for the randn worker, and a second helper thread
+        # only takes the GIL away from it; the library's generator holds no GIL)
+        helper = self.sampler == "device" or self._native_draws
+        mixture = _submit(_mixture_terms, m, C) if (helper and not objective_only) else None
         okw = {"objective_only": True} if objective_only else {}
         if self.sampler == "device":
             if self.__dict__.get("_dev_seed") is None:
