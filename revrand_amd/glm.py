@@ -229,7 +229,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                     - 0.5 * ((m ** 2 + C) * iL).sum() - logzk.sum() + np.log(K)) / K
             self.__it += 1
             return -ELBO
-        dbpars = feats.glm_basis_grads(X)                                     # -(EdPhi o dPhi).sum() per parameter
+        # -(EdPhi o dPhi).sum() per parameter: a contraction kernel + a small download.  On the helper thread (the call
+        # holds no GIL) while this thread does the step's NumPy arithmetic below; joined where the value is needed
+        dbp = _submit(feats.glm_basis_grads, X) if (helper and not self.distributed) else None
+        dbpars = feats.glm_basis_grads(X) if dbp is None else None
         if self.distributed:  # one exchange per step: the per-rank Monte-Carlo sums
             from . import parallel
             from .utils import flatten_values
@@ -274,6 +277,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             log.info("{}Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
                      .format("Random starts: " if self.__it < 0 else "", self.__it, ELBO, reg, lpars, bpars))
         self.__it += 1
+        if dbp is not None:
+            dbpars = dbp.result()
         return -ELBO, [-dm, -dC, dL, dlpars, dbpars]
 
     # -- prediction -----------------------------------------------------------------------------
