@@ -20,6 +20,7 @@ New keyword on the HIP-backed bases: ``dtype`` = "f32" (default; the arithmetic 
 kernels, BASELINE config 2) or "f64".  Returned arrays are always float64, like the
 reference's.
 """
+import ctypes
 import inspect
 from functools import reduce, wraps
 from itertools import repeat
@@ -477,6 +478,33 @@ class MinibatchFeatures(object):
         self.is_cat = isinstance(basis, BasisCat)
         self.bases = basis.bases if self.is_cat else [basis]
         self.fm, self.children, self.dev = None, [], None
+        self._stage_bufs, self._targets = {}, None
+
+    def _stage(self, name, arr, dtype):
+        """`arr` in this object's grow-only device buffer `name` (no allocation, no free -- hipFree waits for the device --
+        per SVI step; the copy is ordered after everything queued on the stream, so the previous step is over)."""
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        dev = self.dev if self.dev is not None else _hip.get_device()
+        buf = self._stage_bufs.get(name)
+        if buf is None or buf.nbytes < arr.nbytes:
+            if buf is not None:
+                buf.free()
+            buf = self._stage_bufs[name] = dev.malloc(max(arr.nbytes, 4))
+        if arr.nbytes:
+            _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, buf.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+        buf.shape, buf.dtype = arr.shape, arr.dtype
+        return buf
+
+    def stage_targets(self, y, rowarg):
+        """Upload the step's targets (and per-row likelihood argument) BEFORE its features are launched: the copies
+        synchronise the stream, and behind the feature kernels they would make the host wait for them."""
+        self._targets = (self._stage("y", y, np.float32), None if rowarg is None else self._stage("rowarg", rowarg, np.float32))
+
+    def _take_targets(self, y, rowarg):
+        t, self._targets = self._targets, None
+        if t is None:
+            t = (self._stage("y", y, np.float32), None if rowarg is None else self._stage("rowarg", rowarg, np.float32))
+        return t
 
     def _ensure(self, rows, F):
         if self.fm is None or self.fm.max_rows < rows or self.fm.F != F:
@@ -512,7 +540,7 @@ class MinibatchFeatures(object):
         self.children = []
         M = len(idx)
         self._ensure(M, int(sum(self._dims)))
-        didx = self.dev.upload_vector(np.ascontiguousarray(idx, dtype=np.int32))
+        didx = self._stage("idx", idx, np.int32)
         self.fm.begin(M)
         args, col0 = list(hypers), 0
         for child, w in zip(self._kids, self._dims):
@@ -521,9 +549,7 @@ class MinibatchFeatures(object):
             child.put_batch(self.fm, M, col0, mine)
             self.children.append((child, col0, w))
             col0 += w
-        self.dev.sync()
-        didx.free()
-        self.M = M
+        self.M = M  # (no synchronisation: the gathers and feature kernels run while the host prepares the step)
 
     def assemble(self, X, hypers):
         self._drop_children()
@@ -543,36 +569,18 @@ class MinibatchFeatures(object):
         self.M = M
 
     def glm_step(self, y, rowarg, lik, lik_param, WS, K, L):
-        dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
-        dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
-        try:
-            return self.fm.glm_step(dy, dn, lik, lik_param, WS, K, L)
-        finally:
-            dy.free()
-            if dn is not None:
-                dn.free()
+        dy, dn = self._take_targets(y, rowarg)
+        return self.fm.glm_step(dy, dn, lik, lik_param, WS, K, L)
 
     supports_objective_only = True  # glm_step_sampled / glm_step_draws take objective_only=True (no gradient GEMMs)
 
     def glm_step_sampled(self, y, rowarg, lik, lik_param, m, C, K, L, seed, step, objective_only=False):
-        dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
-        dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
-        try:
-            return self.fm.glm_step_sampled(dy, dn, lik, lik_param, m, C, K, L, seed, step, objective_only)
-        finally:
-            dy.free()
-            if dn is not None:
-                dn.free()
+        dy, dn = self._take_targets(y, rowarg)
+        return self.fm.glm_step_sampled(dy, dn, lik, lik_param, m, C, K, L, seed, step, objective_only)
 
     def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E, objective_only=False):
-        dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
-        dn = None if rowarg is None else self.dev.upload_vector(np.ascontiguousarray(rowarg, dtype=np.float32))
-        try:
-            return self.fm.glm_step_draws(dy, dn, lik, lik_param, m, C, K, L, E, objective_only)
-        finally:
-            dy.free()
-            if dn is not None:
-                dn.free()
+        dy, dn = self._take_targets(y, rowarg)
+        return self.fm.glm_step_draws(dy, dn, lik, lik_param, m, C, K, L, E, objective_only)
 
     def glm_basis_grads(self, X):
         grads = []
@@ -613,6 +621,9 @@ class MinibatchFeatures(object):
                 k.release()
             self.resident = False
         self._drop_children()
+        for buf in self._stage_bufs.values():
+            buf.free()
+        self._stage_bufs, self._targets = {}, None
         self.fm = None
 
 

@@ -183,12 +183,17 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if largs and isinstance(largs[-1], _Draws):                          # made one step ahead (`_draw_ahead`)
             draws, largs = largs[-1].e, largs[:-1]
         feats = self._features()
-        if getattr(self, "_resident_fit", False):                            # rows by index from the resident data
+        resident = getattr(self, "_resident_fit", False)
+        if resident:                                                          # rows by index from the resident data
             idx, largs = largs[-1], largs[:-1]
+        # everything the step needs from the host goes first (likelihood constants, the targets' upload): the feature
+        # kernels launched next then run while the host gets to the step's own call, instead of being waited for
+        lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
+        if resident:
+            feats.stage_targets(y, rowarg)
             feats.assemble_idx(idx, atleast_list(bpars))
         else:
             feats.assemble(X, atleast_list(bpars))                            # Phi (M x D) in HBM
-        lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
         objective_only = objective_only and getattr(feats, "supports_objective_only", False)
         # the mixture-entropy terms depend on (m, C) only: a worker thread forms them while the device call below (which
         # releases the GIL) runs the step's kernels -- ~0.7 ms of a 6 ms config-5 step
