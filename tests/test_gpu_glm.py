@@ -177,6 +177,28 @@ def test_glm_poisson_large_minibatch():
     assert glm.weights_.shape == (200, 3) and np.all(glm.covariance_ > 0) and np.shape(glm.basis_hypers_) == (d,)
 
 
+def test_fit_with_the_library_generator_equals_fit_with_numpy_draws():
+    """The reference's random stream from rr_legacy_randn (sequential part on the caller, sqrt / log on a worker thread)
+    and from NumPy's RandomState are the same numbers, so a fit is the same fit: identical parameters after 12 SVI
+    steps (f32 atomics in the step's reductions allow last-bit differences only), and the RandomState ends in the same
+    state either way."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(4)
+    N, d = 6000, 5
+    X = rs.randn(N, d)
+    y = rs.poisson(np.exp(0.5 * np.sin(X[:, 0]) + 0.2 * X[:, 2])).astype(float)
+    out = []
+    for native in (True, False):
+        basis = bs.RandomRBF(nbases=64, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        glm = GLM(lk.Poisson(), basis, K=2, nsamples=7, batch_size=1000, maxiter=12, nstarts=2, random_state=11)
+        glm._native_draws = native
+        glm.fit(X, y)
+        out.append((glm.weights_.copy(), glm.covariance_.copy(), np.array(glm.basis_hypers_, dtype=float), glm.random_.randn()))
+    (wa, ca, ha, ra), (wb, cb, hb, rb) = out
+    assert normwise(wa, wb) < 1e-5 and normwise(ca, cb) < 1e-5 and normwise(ha, hb) < 1e-5
+    assert ra == rb
+
+
 def test_device_sampler_matches_host_sampler_in_expectation():
     """sampler="device": the reparameterisation draws come from the counter-based generator on the GPU.  With many
     samples the Monte-Carlo gradients agree with the host-sampled ones (same estimator, independent draws), the
