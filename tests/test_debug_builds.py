@@ -44,7 +44,9 @@ def test_asan_build_passes_the_abi_checks():
     rt = _asan_runtime()
     if not os.path.exists(ASAN_LIB) or rt is None:
         pytest.skip("make -C revrand_amd/csrc asan has not been run")
-    r = _pytest_with(ASAN_LIB, ["tests/test_abi.py", "-m", "not gpu"], preload=rt, timeout=900)
+    # the ABI checks, and the one host-only entry point with real work in it (rr_legacy_randn: worker threads, scratch)
+    r = _pytest_with(ASAN_LIB, ["tests/test_abi.py", "tests/test_host_logic.py::test_library_generator_reproduces_numpy_legacy_randn",
+                                "-m", "not gpu"], preload=rt, timeout=900)
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
 
 
