@@ -11,7 +11,9 @@
 //   mt19937_gen / mt19937_next / mt19937_next_double   numpy/random/src/mt19937/mt19937.{c,h}
 //   legacy_gauss (polar Box-Muller with one cached value)  numpy/random/src/legacy/legacy-distributions.c
 // `log` and `sqrt` are the C library's, as in NumPy's build; floating-point contraction is off so that x1 x1 + x2 x2
-// rounds twice as it does there.
+// rounds twice as it does there.  RandomState's stream is frozen by NumPy's compatibility policy (NEP 19), so one
+// restatement serves every NumPy the reference runs on; tests/test_host_logic.py compares against the installed one
+// (values, cached-value parity, interleaving with other draws, final state).
 #include <atomic>
 #include <cmath>
 #include <cstdint>
