@@ -324,6 +324,7 @@ void rr_basis_destroy(rr_basis *b) {
     }
     if (b->dWs32) (void)hipFree(b->dWs32);
     if (b->dWs64) (void)hipFree(b->dWs64);
+    if (b->dWraw) (void)hipFree(b->dWraw);
     if (b->dWt32) (void)hipFree(b->dWt32);
     if (b->dgfac32) (void)hipFree(b->dgfac32);
     if (b->dgfac64) (void)hipFree(b->dgfac64);
@@ -348,6 +349,34 @@ const char *rr_rff_gram_kernel_name(rr_basis *basis) { return basis ? basis->gra
 
 // Scale W by 1/(l_i * 2pi) in f64 on the host (d*n elements: tiny) and upload.  The kernels
 // then obtain the phase directly in revolutions, which is what v_sin_f32/v_cos_f32 consume.
+// The device copies of a random Fourier basis for new length scales, made ON the device (d <= 128): W stays resident as
+// given, the d length scales travel as kernel arguments, one launch rewrites Ws (f32, f64), its transpose and the gradient
+// factors -- the same float64 products and the same clamped float32 casts as the host loop below, without its five
+// synchronous copies (an SVI step changes the length scales every time: ~0.15 ms of a 5 ms step).
+struct LsArgs {
+    double ls[128];
+    int n_ls;
+};
+__global__ void __launch_bounds__(256)
+rr_scale_w_kernel(const double *__restrict__ W, const LsArgs a, int d, int n, int npad, int dpad, float *__restrict__ w32,
+                  double *__restrict__ w64, float *__restrict__ wt32, float *__restrict__ g32, double *__restrict__ g64) {
+    const double inv2pi = 0.15915494309189533576888, twopi = 6.283185307179586476925, wmax = 4611686018427387904.0;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)d * n) return;
+    const int i = (int)(t / n), f = (int)(t % n);
+    const double l = a.ls[a.n_ls == 1 ? 0 : i];
+    const double v = W[t] * (inv2pi / l);
+    const float vf = (float)(v > wmax ? wmax : (v < -wmax ? -wmax : v));
+    w64[(size_t)i * npad + f] = v;
+    w32[(size_t)i * npad + f] = vf;
+    wt32[(size_t)f * dpad + i] = vf;
+    if (f == 0) {
+        const double gf = twopi / l;
+        g64[i] = gf;
+        g32[i] = (float)(gf > 3.0e38 ? 3.0e38 : (gf < -3.0e38 ? -3.0e38 : gf));
+    }
+}
+
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     RR_REQUIRE(b != nullptr && lenscale != nullptr, "lenscale: null argument");
     RR_REQUIRE(n_ls == 1 || n_ls == b->d,
@@ -361,6 +390,31 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     const double inv2pi = 0.15915494309189533576888;
     const double twopi = 6.283185307179586476925;
     const int d = b->d, n = b->n, npad = b->npad;
+    static const bool host_scaling = getenv("RR_PREPARE_ON_HOST") != nullptr;
+    if (!b->large && d <= 128 && !host_scaling) {
+        rr_ctx *c = b->ctx;
+        RR_CHECK_HIP(hipSetDevice(c->device));
+        if (!b->dWraw) {  // first use: W up once, pad rows / columns of the derived copies zero for good
+            const size_t elems = (size_t)b->dpad * npad;
+            RR_CHECK_HIP(hipMalloc((void **)&b->dWraw, (size_t)d * n * sizeof(double)));
+            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+            RR_CHECK_HIP(hipMemcpy(b->dWraw, b->W.data(), (size_t)d * n * sizeof(double), hipMemcpyHostToDevice));
+            RR_CHECK_HIP(hipMemset(b->dWs32, 0, elems * sizeof(float)));
+            RR_CHECK_HIP(hipMemset(b->dWs64, 0, elems * sizeof(double)));
+            RR_CHECK_HIP(hipMemset(b->dWt32, 0, elems * sizeof(float)));
+            RR_CHECK_HIP(hipMemset(b->dgfac32, 0, (size_t)b->dpad * sizeof(float)));
+            RR_CHECK_HIP(hipMemset(b->dgfac64, 0, (size_t)b->dpad * sizeof(double)));
+            RR_CHECK_HIP(hipDeviceSynchronize());
+        }
+        LsArgs a;
+        for (int i = 0; i < 128; ++i) a.ls[i] = i < n_ls ? lenscale[i] : 1.0;
+        a.n_ls = n_ls;
+        hipLaunchKernelGGL(rr_scale_w_kernel, dim3((unsigned)(((int64_t)d * n + 255) / 256)), dim3(256), 0, c->stream, b->dWraw, a, d,
+                           n, npad, b->dpad, b->dWs32, b->dWs64, b->dWt32, b->dgfac32, b->dgfac64);
+        RR_CHECK_HIP(hipGetLastError());
+        b->ls_cache.assign(lenscale, lenscale + n_ls);
+        return RR_OK;
+    }
     std::vector<double> w64((size_t)b->dpad * npad, 0.0);
     std::vector<float> w32((size_t)b->dpad * npad, 0.0f);
     std::vector<float> wt32((size_t)npad * b->dpad, 0.0f);

@@ -49,6 +49,7 @@ struct rr_basis {
     std::vector<double> ls_cache; // lenscale the device copy was scaled with
     float *dWs32 = nullptr;       // (dpad, npad), zero padded: W[i][f] / (l_i * 2pi)   -> phase in revolutions
     double *dWs64 = nullptr;      // same in f64
+    double *dWraw = nullptr;      // (d, n) row-major: W as given, for the device-side rescaling of rr_basis_prepare (d <= 128)
     float *dWt32 = nullptr;       // (npad, dpad): the same weights transposed (feature-major kernels)
     float *dgfac32 = nullptr;     // (d,): 2pi / l_i  (grad kernels)
     float *dmu32 = nullptr;       // (dpad,): mean / 2pi of a spectral-mixture component (rr_gm_*)
