@@ -263,6 +263,12 @@ int rr_featmat_glm_step_sampled(rr_featmat *fm, const void *dy, const void *drow
 int rr_featmat_glm_step_draws(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik,
                               double lik_param, const double *m, const double *C, int K, int L, const float *E,
                               double *Edm, double *EdC, double *llsum, double *aux);
+/* The same with the draws already in DEVICE memory (float32 (K*L, F), contiguous): the caller uploaded them while the
+ * previous step ran (glm.py: the minibatch worker thread, on a context of its own), so the step starts without the
+ * 4 MB host-to-device copy of config 5. */
+int rr_featmat_glm_step_draws_dev(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik,
+                                  double lik_param, const double *m, const double *C, int K, int L, const float *dE,
+                                  double *Edm, double *EdC, double *llsum, double *aux);
 /* dT (d, n) float64 DEVICE buffer += X^T (E_s o P_c - E_c o P_s) for the random Fourier child at columns
  * [col0, col0 + 2n):  sum(EdPhi o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]  (glm.py:274-275 without basis.grad). */
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,

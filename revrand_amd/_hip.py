@@ -108,6 +108,10 @@ SIGNATURES = {
                                                  ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat_glm_step_draws_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_gather_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
                                       ctypes.c_void_p]),
     "rr_featmat_glm_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -738,14 +742,18 @@ class FeatureMatrix(object):
         glm_step_sampled."""
         m = np.ascontiguousarray(m, dtype=np.float64)
         C = np.ascontiguousarray(C, dtype=np.float64)
-        E = np.ascontiguousarray(E, dtype=np.float32)
-        if m.shape != (self.F, K) or C.shape != (self.F, K) or E.shape != (K * L, self.F):
+        on_device = isinstance(E, DeviceBuffer)  # float32 (K*L, F) uploaded ahead of the step (rr_featmat_glm_step_draws_dev)
+        if not on_device:
+            E = np.ascontiguousarray(E, dtype=np.float32)
+        if m.shape != (self.F, K) or C.shape != (self.F, K) or tuple(E.shape) != (K * L, self.F) or E.dtype != np.float32:
             raise ValueError("m, C must have shape (F, K) and E (K*L, F)")
         Edm, EdC, ll, aux = np.empty((K, self.F)), np.empty((K, self.F)), np.empty(K), np.empty(K)
         none = ctypes.c_void_p(None)
-        _check(self.lib, self.lib.rr_featmat_glm_step_draws(
+        step = self.lib.rr_featmat_glm_step_draws_dev if on_device else self.lib.rr_featmat_glm_step_draws
+        _check(self.lib, step(
             self.h, _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), int(lik), float(lik_param),
-            m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L, E.ctypes.data_as(ctypes.c_void_p),
+            m.ctypes.data_as(ctypes.c_void_p), C.ctypes.data_as(ctypes.c_void_p), K, L,
+            E.ptr if on_device else E.ctypes.data_as(ctypes.c_void_p),
             none if objective_only else Edm.ctypes.data_as(ctypes.c_void_p),
             none if objective_only else EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
             aux.ctypes.data_as(ctypes.c_void_p)))

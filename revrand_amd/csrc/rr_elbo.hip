@@ -1728,7 +1728,8 @@ int rr_featmat_glm_step(rr_featmat *fm, const void *dy, const void *drowarg, int
 
 static int glm_step_reduced(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
                             const double *m, const double *C, int K, int L, uint64_t seed, uint64_t step,
-                            const float *Ehost, double *Edm, double *EdC, double *llsum, double *aux) {
+                            const float *Ehost, double *Edm, double *EdC, double *llsum, double *aux,
+                            const float *Edev = nullptr) {
     int rc = glm_step_checks(fm, dy, drowarg, dtype, lik, lik_param, K, L, "rr_featmat_glm_step_sampled");
     if (rc != RR_OK) return rc;
     const bool objective_only = (Edm == nullptr && EdC == nullptr);  // llsum / aux only (random starts)
@@ -1749,6 +1750,8 @@ static int glm_step_reduced(rr_featmat *fm, const void *dy, const void *drowarg,
     if (Ehost) {  // the caller's draws go up as float32 (K L, F), staged in the (not yet used) Ed buffer
         RR_CHECK_HIP(hipMemcpyAsync(s.Ed, Ehost, (size_t)KL * F * 4, hipMemcpyHostToDevice, c->stream));
         Egiven = s.Ed;
+    } else if (Edev) {  // the caller's draws are on the device already
+        Egiven = Edev;
     }
     hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, c->stream, s.mc, s.mc + fk,
                        F, K, L, Fp, kl_ld, seed, step, Egiven, s.Ee, s.WSs);
@@ -1783,6 +1786,13 @@ int rr_featmat_glm_step_draws(rr_featmat *fm, const void *dy, const void *drowar
                               double *llsum, double *aux) {
     RR_REQUIRE(E != nullptr, "rr_featmat_glm_step_draws: null draws");
     return glm_step_reduced(fm, dy, drowarg, dtype, lik, lik_param, m, C, K, L, 0, 0, E, Edm, EdC, llsum, aux);
+}
+
+int rr_featmat_glm_step_draws_dev(rr_featmat *fm, const void *dy, const void *drowarg, int dtype, int lik, double lik_param,
+                                  const double *m, const double *C, int K, int L, const float *dE, double *Edm, double *EdC,
+                                  double *llsum, double *aux) {
+    RR_REQUIRE(dE != nullptr, "rr_featmat_glm_step_draws_dev: null draws");
+    return glm_step_reduced(fm, dy, drowarg, dtype, lik, lik_param, m, C, K, L, 0, 0, nullptr, Edm, EdC, llsum, aux, dE);
 }
 
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {

@@ -120,6 +120,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # batch -- the order in which a sequential run consumes the stream -- and hands them over with the batch, so
         # the ~12 ms of randn per config-5 step overlap the kernels instead of preceding them.
         prefetch = True if self.sampler == "device" else (self._draw_ahead if self._prefetch_draws else False)
+        # (RR_GLM_DRAW_UPLOAD=0: measurement switch, the step uploads its draws itself)
+        if callable(prefetch) and self._native_draws and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
+            self.__dict__["_draw_upload"] = (_hip.Device(_hip.get_device().index), [None, None, None], [0])
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
@@ -127,6 +130,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         finally:
             self._resident_fit = False
             self._release_features()
+            up = self.__dict__.pop("_draw_upload", None)
+            if up is not None:
+                for buf in up[1]:
+                    if buf is not None:
+                        buf.free()
         (self.weights_, self.covariance_, self.regularizer_, self.like_hypers_, self.basis_hypers_) = res.x
         log.info("Finished! reg = {}, likelihood_hypers = {}, basis_hypers = {}, message: {}."
                  .format(self.regularizer_, self.like_hypers_, self.basis_hypers_, res.message))
@@ -147,7 +155,24 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     _native_draws = True  # False: NumPy generates the draws (what tests compare the library's generator against)
 
     def _draw_ahead(self, batch):
-        return list(batch) + [_Draws(self._reference_draws())]
+        """On the minibatch worker thread: the step's draws, and their upload -- through a device context (stream) of this
+        thread's own, into one of THREE buffers in turn: the worker runs up to two steps ahead (one finished batch waits in
+        the queue while the next is being made) -- while earlier steps' kernels run; the step then starts from
+        device-resident draws (rr_featmat_glm_step_draws_dev)."""
+        e = self._reference_draws()
+        up = self.__dict__.get("_draw_upload")
+        if up is None:
+            return list(batch) + [_Draws(e)]
+        dev, bufs, turn = up
+        buf = bufs[turn[0] % 3]
+        if buf is None or buf.nbytes < e.nbytes:
+            if buf is not None:
+                buf.free()
+            buf = bufs[turn[0] % 3] = dev.malloc(e.nbytes)
+        _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, buf.ptr, e.ctypes.data_as(_hip.ctypes.c_void_p), e.nbytes))
+        buf.shape, buf.dtype = e.shape, e.dtype
+        turn[0] += 1
+        return list(batch) + [_Draws(buf)]
 
     # -- device features of one minibatch ------------------------------------------------------
     def _features(self):
@@ -165,6 +190,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         state = dict(super().__getstate__())  # sklearn's (adds its version tag)
         state.pop("_mbf", None)
         state.pop("_serve_feats", None)
+        state.pop("_draw_upload", None)
         return state
 
     def _drop_serving(self):

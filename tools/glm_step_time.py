@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Wall-clock per SVI step of fit() at config 5's shape (N = 1M resident): (time of 260 steps - time of 60 steps) / 200,
-for the reference's random stream ("host") and the device sampler."""
+for the reference's random stream ("host") and the device sampler.  SWITCH=<seconds> sets the interpreter's
+thread switch interval (no measurable effect: the run-to-run spread of the host-sampler number, 5.4 - 10 ms on one box,
+is larger than anything these switches move)."""
 import os, sys, time, logging
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,6 +11,8 @@ from revrand_amd import likelihoods as lk
 from revrand_amd.btypes import Parameter, Positive
 from revrand_amd.glm import GeneralizedLinearModel
 logging.getLogger("revrand_amd").setLevel(logging.ERROR)
+if os.environ.get("SWITCH"):
+    sys.setswitchinterval(float(os.environ["SWITCH"]))
 N, d, n, K, L, M = 1_000_000, 32, 1024, 10, 50, 65536
 rng = np.random.default_rng(5)
 X = rng.standard_normal((N, d), dtype=np.float32)
