@@ -573,6 +573,7 @@ class MinibatchFeatures(object):
         return self.fm.glm_step(dy, dn, lik, lik_param, WS, K, L)
 
     supports_objective_only = True  # glm_step_sampled / glm_step_draws take objective_only=True (no gradient GEMMs)
+    accepts_device_draws = True     # glm_step_draws takes E as a float32 (K L, F) DeviceBuffer as well
 
     def glm_step_sampled(self, y, rowarg, lik, lik_param, m, C, K, L, seed, step, objective_only=False):
         dy, dn = self._take_targets(y, rowarg)

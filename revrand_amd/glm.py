@@ -121,7 +121,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # the ~12 ms of randn per config-5 step overlap the kernels instead of preceding them.
         prefetch = True if self.sampler == "device" else (self._draw_ahead if self._prefetch_draws else False)
         # (RR_GLM_DRAW_UPLOAD=0: measurement switch, the step uploads its draws itself)
-        if callable(prefetch) and self._native_draws and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
+        if callable(prefetch) and self._native_draws and getattr(self._features(), "accepts_device_draws", False) \
+                and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
             self.__dict__["_draw_upload"] = (_hip.Device(_hip.get_device().index), [None, None, None], [0])
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
