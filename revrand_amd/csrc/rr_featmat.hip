@@ -6,7 +6,8 @@
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              float *P, int64_t ldp, bool zero_pad_cols);
-int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid);
+int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid,
+                       double *bcol = nullptr);
 
 
 // [1, X] or X (LinearBasis.transform, basis_functions.py:468-485) into columns [col0, col0 + d + onescol)
@@ -53,6 +54,14 @@ __global__ void __launch_bounds__(256) rr_fm_gemv_t_kernel(const float *__restri
     float acc = 0.f;
     for (int64_t r = r0; r < r1; ++r) acc = fmaf(P[r * ldp + c], (float)y[r], acc);
     unsafeAtomicAdd(&bvec[c], (double)acc);
+}
+
+// P[r][col] = y[r] (y == nullptr: 0) for r < rows
+template <typename TY>
+__global__ void __launch_bounds__(256) rr_fm_set_column_kernel(float *__restrict__ P, int64_t ld, int64_t col, const TY *__restrict__ y,
+                                                               int64_t rows) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < rows) P[r * ld + col] = y ? (float)y[r] : 0.f;
 }
 
 template <typename TY>
@@ -225,6 +234,28 @@ int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, dou
     if (fm->rows == 0) return RR_OK;
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
+    // Phi^T y: as a rider of the SYRK -- y written into the first pad column of P for the duration of the product (one
+    // pass over P instead of two; the f32 MFMA engine, a pad column to spare) -- or by its own kernel
+    static const bool no_rider = getenv("RR_FM_NO_RIDER") != nullptr;
+    const bool rider = dy != nullptr && c->gram_engine == 0 && fm->F < fm->ld && !no_rider;
+    if (rider) {
+        int yb = (int)((fm->rows + 255) / 256);
+        if (yb > c->num_cu * 8) yb = c->num_cu * 8;
+        const unsigned cb = (unsigned)((fm->rows + 255) / 256);
+        if (y_dtype == RR_F32) {
+            hipLaunchKernelGGL(rr_fm_set_column_kernel<float>, dim3(cb), dim3(256), 0, c->stream, fm->P, fm->ld, fm->F, (const float *)dy, fm->rows);
+            hipLaunchKernelGGL(rr_fm_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, fm->rows, dyty);
+        } else {
+            hipLaunchKernelGGL(rr_fm_set_column_kernel<double>, dim3(cb), dim3(256), 0, c->stream, fm->P, fm->ld, fm->F, (const double *)dy, fm->rows);
+            hipLaunchKernelGGL(rr_fm_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, fm->rows, dyty);
+        }
+        RR_CHECK_HIP(hipGetLastError());
+        const int rc = rr_launch_syrk_f32(c, fm->P, fm->rows_pad, fm->ld, fm->F, dG, nullptr, db);
+        // the pad column is zero again for every other consumer of P
+        hipLaunchKernelGGL(rr_fm_set_column_kernel<float>, dim3(cb), dim3(256), 0, c->stream, fm->P, fm->ld, fm->F, (const float *)nullptr, fm->rows);
+        RR_CHECK_HIP(hipGetLastError());
+        return rc;
+    }
     if (dy) {
         const int rpb = 512;
         const dim3 gg((unsigned)((fm->F + 255) / 256), (unsigned)((fm->rows + rpb - 1) / rpb));

@@ -776,11 +776,12 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[i][j][e]);
+                if (gr <= gc) rr_syrk_out(p, gr, gc, acc[i][j][e]);
             }
         }
     }
     (void)diag;
+    (void)F;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -866,7 +867,6 @@ __device__ __forceinline__ void syrk_ragged_loop(const SyrkArgs &p, float *lds, 
     }
     // flush, transposed: the A side is the ragged block (columns of G), the B side block ta (rows of G)
     if constexpr (NI > 0) {
-        const int64_t F = p.F;
         const int hi = lane >> 5;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -876,7 +876,7 @@ __device__ __forceinline__ void syrk_ragged_loop(const SyrkArgs &p, float *lds, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t gcol = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    if (gcol < F) unsafeAtomicAdd(&p.G[grow * F + gcol], (double)acc[i][j][e]);
+                    rr_syrk_out(p, grow, gcol, acc[i][j][e]);
                 }
             }
         }
@@ -899,7 +899,7 @@ rr_syrk_f32_ragged_kernel(const SyrkArgs p) {
     if (row_end > p.rows) row_end = p.rows;
     const int64_t nkb = (row_end - row_begin) / GR_KB;
     RR_DEV_ASSERT(p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0 && p.nb * GR_TC == p.ldp && p.F > ca);
-    const int w = p.F - ca;                        // valid columns of the ragged block
+    const int w = p.F + (p.bcol ? 1 : 0) - ca;     // valid columns of the ragged block (+ the rider column)
     int ni = (w - (wave >> 2) * 128 + 31) / 32;    // this wave's 32-column blocks with valid columns
     ni = ni < 0 ? 0 : (ni > 4 ? 4 : ni);
     switch (ni) {  // wave-uniform; every path runs the same barriers
@@ -1018,9 +1018,10 @@ __device__ __forceinline__ void syrk_diag_body(const SyrkArgs &p, float *lds, in
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int64_t gr = ca + 32 * bi[e] + (k & 3) + 8 * (k >> 2) + 4 * hi;
-            if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)acc[e][k]);
+            if (gr <= gc) rr_syrk_out(p, gr, gc, acc[e][k]);
         }
     }
+    (void)F;
 }
 #undef RR_PAIRD
 
@@ -1822,13 +1823,18 @@ void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
 
 // G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
 
-int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid) {
-    if (c->gram_engine != 0) return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
+int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid,
+                       double *bcol = nullptr) {
+    if (c->gram_engine != 0) {
+        RR_REQUIRE(bcol == nullptr, "gram: the rider column needs the f32 engine");
+        return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
+    }
+    RR_REQUIRE(bcol == nullptr || F < ldp, "gram: no pad column for the rider");
     const int nb_all = (int)(ldp / GR_TC);
     const int od = (nb_all >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
     // ragged last block (<= 192 valid columns): its off-diagonal tiles go to rr_syrk_f32_ragged_kernel, and the main
     // kernel enumerates the tiles among the first nb_all - 1 blocks only
-    const int w_last = F - GR_TC * (nb_all - 1);
+    const int w_last = F + (bcol ? 1 : 0) - GR_TC * (nb_all - 1);
     const int rg = (od && nb_all >= 3 && w_last <= 192 && !getenv("RR_SYRK_NO_RAGGED_KERNEL")) ? 1 : 0;
     const int nb = nb_all - rg;
     const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
@@ -1893,6 +1899,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
                    nsplit_r * nb_all < (int64_t)1 << 31, "gram: grid too large");
     SyrkArgs a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
+    a.bcol = bcol;
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;

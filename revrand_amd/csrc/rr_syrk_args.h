@@ -68,7 +68,19 @@ struct SyrkArgs {
     int64_t ldd = 0;
     float out_scale = 1.f;  // fp16 operands: 1 / s^2 of the producer's store scale
     int upper_b = 0;        // GEMM mode: B (K == N) is upper triangular, column tile tb needs only k < 256 (tb + 1)
+    // f32 SYRK kernels: column F of P (its first pad column) holds one more vector y; bcol[r] += P[:, r] . y for r < F
+    // (Phi^T y rides along with Phi^T Phi instead of costing its own pass over P)
+    double *bcol = nullptr;
 };
+
+#ifdef __HIPCC__
+// one accumulator of an f32 SYRK tile into the upper triangle of G, or -- column F, the rider -- into bcol
+__device__ __forceinline__ void rr_syrk_out(const SyrkArgs &p, int64_t gr, int64_t gc, float v) {
+    const int64_t F = p.F;
+    if (gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)v);
+    else if (gc == F && p.bcol != nullptr && gr < F) unsafeAtomicAdd(&p.bcol[gr], (double)v);
+}
+#endif
 
 // Greedy XCD-aware tile order of the SYRK kernels (rr_rff.hip)
 void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map);
