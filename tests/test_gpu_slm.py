@@ -213,6 +213,39 @@ def test_second_pass_and_predict_vs_oracle(shape):
     assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
 
 
+@pytest.mark.parametrize("n,extra", [(126, 3), (127, 1), (128, 0), (255, 2), (60, 5), (383, 1)])
+def test_concat_gram_phi_t_y_rider_and_fallback(n, extra):
+    """Phi^T y of a concatenation rides along with the SYRK in the first pad column of the device feature matrix when the
+    total width is not a multiple of 256 (F = 2n + extra: one spare column at 255 / 767, many at 123 / 512+), and falls
+    back to its own kernel when it is (F = 256, 512); N not a multiple of 32; two calls in a row and a y-less call
+    afterwards show the pad column is clean again."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(n + extra)
+    N, d = 2077, 5
+    X = rs.randn(N, d)
+    y = np.cos(X @ rs.randn(d)) + 0.05 * rs.randn(N)
+    ls = np.linspace(0.8, 1.3, d)
+    base = bs.RandomRBF(nbases=n, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive()))
+    cols = [orc.rff_transform(X, base.W, ls)]
+    if extra:
+        base = base + bs.LinearBasis(onescol=False, apply_ind=list(range(extra)))
+        cols.append(X[:, :extra])
+    else:
+        base = base + bs.LinearBasis(onescol=False, apply_ind=[0]) + bs.LinearBasis(onescol=False, apply_ind=[1])
+        cols += [X[:, :1], X[:, 1:2]]
+        base = bs.RandomRBF(nbases=n - 1, Xdim=d, random_state=2, lenscale=Parameter(np.ones(d), Positive())) \
+            + bs.LinearBasis(onescol=False, apply_ind=[0]) + bs.LinearBasis(onescol=False, apply_ind=[1])
+        cols[0] = orc.rff_transform(X, base.bases[0].W, ls)
+    ref = np.hstack(cols)
+    F = ref.shape[1]
+    for rep in range(2):
+        G, b, yty = base.gram(X, y, ls)
+        assert G.shape == (F, F) and np.array_equal(G, G.T)
+        assert normwise(G, ref.T @ ref) < 1e-4 and normwise(b, ref.T @ y) < 1e-4 and abs(yty - y @ y) < 1e-5 * (y @ y)
+    G2, b2, _ = base.gram(X, None, ls)
+    assert b2 is None and normwise(G2, ref.T @ ref) < 1e-4
+
+
 def test_concat_gram_on_device_vs_oracle():
     """BASELINE config 3 shape in miniature: RandomMatern52 + LinearBasis(onescol) (+ a generic basis),
     Phi assembled on the device, one SYRK."""
