@@ -351,7 +351,8 @@ void rr_pass2_scratch_free(void *p) {
 }
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             float *P, int64_t ldp, bool zero_pad_cols);  // rr_rff.hip
+                             float *P, int64_t ldp, bool zero_pad_cols, float *Pt = nullptr, int64_t ldt = 0,
+                             bool *pt_written = nullptr);  // rr_rff.hip
 int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
                            int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready,
                            bool upper_b = false);  // rr_syrk16.hip
@@ -800,6 +801,8 @@ struct FmPass2 {
     bool have_edphi = false;
 };
 
+float *rr_fm_pass2_pt(void *p) { return p ? ((FmPass2 *)p)->Pt : nullptr; }
+
 void rr_fm_pass2_free(void *p) {
     if (!p) return;
     FmPass2 *s = (FmPass2 *)p;
@@ -818,6 +821,7 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
                        fm->rows, fm->F, fm->ld, s.dot);
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(fm->ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0,
                        c->stream, fm->P, fm->rows, fm->ld, s.Pt, fm->max_rows);
+    fm->pt_rows = fm->rows;
     if (c->gram_engine != 0) {  // split-bf16 engine (rr_rff.hip)
         if (!s.Ab) {
             RR_CHECK_HIP(hipMalloc(&s.Ab, (size_t)fm->ld * fm->max_rows * 4));
@@ -1660,9 +1664,12 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     // WSt (Fp, kl_ld) = WSs^T (the 1 / (K L) scale is undone in the likelihood kernel's read of fs)
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
                        s.WSs, kl_ld, Fp, s.WSt, kl_ld);
-    // Pt = P^T;  FSt (rows256, kl) = P WS^T
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
-                       fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+    // Pt = P^T (unless every child wrote its block of it while writing P: rr_featmat_put_rff);  FSt (rows256, kl) = P WS^T
+    if (!(fm->pt_rows == fm->rows && fm->pt_covered >= fm->F)) {
+        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                           fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+        fm->pt_rows = fm->rows;  // P^T's padding is now laid out for this row count
+    }
     int rc = glm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
     if (rc != RR_OK) return rc;
     // dfs in place + per-component reductions
@@ -1875,6 +1882,7 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
     RR_CHECK_HIP(hipMemcpy(s.WSt, w.data(), w.size() * 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
                        fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+    fm->pt_rows = fm->rows;
     rc = fm_gemm(c, s.Pt, fm->max_rows, s.WSt, ldw, s.FSt, ldw, Fp, rows256, ldw);
     if (rc != RR_OK) return rc;
     s.have_edphi = false;

@@ -5,7 +5,8 @@
 #include "rr_internal.h"
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             float *P, int64_t ldp, bool zero_pad_cols);
+                             float *P, int64_t ldp, bool zero_pad_cols, float *Pt = nullptr, int64_t ldt = 0,
+                             bool *pt_written = nullptr);
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid,
                        double *bcol = nullptr);
 
@@ -144,6 +145,7 @@ int rr_featmat_begin(rr_featmat *fm, int64_t rows) {
     // whole matrix cost 1.5 ms per 254 200 x 8448 chunk of config 3 (1 % of its Gram pass).
     const int64_t rows256 = (rows + 255) / 256 * 256;
     fm->covered = 0;
+    fm->pt_covered = 0;
     if (rows256 > rows)
         RR_CHECK_HIP(hipMemsetAsync(fm->P + rows * fm->ld, 0, (size_t)(rows256 - rows) * fm->ld * sizeof(float), fm->ctx->stream));
     const int64_t w = fm->ld - fm->F;
@@ -167,7 +169,14 @@ int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype,
     RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
     // the feature kernel writes columns [0, 2n) relative to its base; pad handling is ours (begin())
     fm->covered += 2 * (int64_t)b->n;
-    return rr_features_rowmajor_f32(b, dX, x_dtype, fm->rows, fm->rows, ldx, fm->P + col0, fm->ld, false);
+    // the same block of P^T, if a transposing pass has laid out P^T's padding for this row count before
+    static const bool no_pt = getenv("RR_FM_NO_DIRECT_PT") != nullptr;
+    float *Pt = (fm->pt_rows == fm->rows && !no_pt) ? rr_fm_pass2_pt(fm->pass2) : nullptr;
+    bool wrote = false;
+    rc = rr_features_rowmajor_f32(b, dX, x_dtype, fm->rows, fm->rows, ldx, fm->P + col0, fm->ld, false,
+                                  Pt ? Pt + col0 * fm->max_rows : nullptr, fm->max_rows, &wrote);
+    if (wrote) fm->pt_covered += 2 * (int64_t)b->n;
+    return rc;
 }
 
 int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol, int64_t col0) {

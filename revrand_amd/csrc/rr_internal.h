@@ -170,8 +170,13 @@ struct rr_featmat {
     int F = 0;
     int64_t covered = 0;    // columns written by put_* since rr_featmat_begin (begin zeroes the padding only)
     void *pass2 = nullptr;  // FmPass2 scratch, grow-never (sized by max_rows, ld)
+    // P^T next to P (FmPass2::Pt, (ld, max_rows)): pt_rows = the row count whose padding a transposing pass last wrote
+    // there (-1: never); random Fourier children then write their blocks of P^T themselves while they write P
+    // (pt_covered columns since begin), and a consumer whose pt_covered == F skips its transposing pass
+    int64_t pt_rows = -1, pt_covered = 0;
 };
 void rr_fm_pass2_free(void *p);
+float *rr_fm_pass2_pt(void *p);  // FmPass2::Pt or null
 // Consumers of the feature matrix call this first: every column of [0, F) must have been put since rr_featmat_begin.
 #define RR_FM_REQUIRE_FILLED(fm, who)                                                                              \
     RR_REQUIRE((fm)->rows == 0 || (fm)->covered >= (fm)->F,                                                        \

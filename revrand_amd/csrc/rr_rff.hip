@@ -341,11 +341,15 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
 // rows r0 + (e & 3) + 8 (e >> 2) + 4 h; then rint / v_sin / v_cos / scale per value and two stores
 // whose half-waves each cover 128 contiguous bytes of one row of P.  Per (row, frequency) this costs
 // 1/64 of a 64-cycle MFMA instead of DMAX VALU FMAs.
-template <int DMAX, int CB, bool HAS_Y, typename TX, typename TO>
+// WT (plain f32 output): the same tile is ALSO written feature-major into Pt (rows = features, ldt floats per row):
+// lane (j, h) holds 4 consecutive data rows per e >> 2, i.e. one 16-byte store per group -- the consumer that needs both
+// layouts (the GLM step: P as the K-major operand of dfs Phi, P^T as the one of P WS^T) then skips its transposing pass.
+template <int DMAX, int CB, bool HAS_Y, bool WT, typename TX, typename TO>
 __global__ void __launch_bounds__(256, 2)
 rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad,
                             int64_t ldx, const float *__restrict__ Ws, int n, int npad, TO *__restrict__ P,
-                            int64_t ldp, double *__restrict__ bvec, float scale, int tiles_per_block) {
+                            int64_t ldp, double *__restrict__ bvec, float scale, int tiles_per_block,
+                            float *__restrict__ Pt, int64_t ldt) {
     constexpr int KS = DMAX / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row tiles, hence store bases, are wave-uniform
@@ -452,6 +456,7 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
                     asm volatile("global_store_dwordx4 %0, %1, %2 offset:32" RR_NT_ASM "\n\ts_nop 1" ::"v"(off), "v"(g_lo), "s"(tile_s1) : "memory");
                 }
             } else if (c0 + 32 * cb + j < n) {  // one divergent region per column block (ragged n only)
+                float ct[WT ? 16 : 1], st[WT ? 16 : 1];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int rr = (e & 3) + 8 * (e >> 2);
@@ -459,6 +464,10 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
                     sincos_rev(acc[e], sv, cv);
                     cv = rr < lim ? cv * scale : 0.f;
                     sv = rr < lim ? sv * scale : 0.f;
+                    if (WT) {
+                        ct[e] = cv;
+                        st[e] = sv;
+                    }
                     const unsigned off = lane_off + ES * (unsigned)rr * (unsigned)ldp;
                     if constexpr (ES == 4) {
                         asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
@@ -471,6 +480,16 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
                     if (HAS_Y) {
                         bc[cb] = fmaf(cv, yv[e], bc[cb]);
                         bs[cb] = fmaf(sv, yv[e], bs[cb]);
+                    }
+                }
+                if constexpr (WT) {
+                    typedef float float4v __attribute__((ext_vector_type(4)));
+                    float *tc = Pt + (int64_t)(c0 + 32 * cb + j) * ldt + r0 + 4 * h;  // feature row, this lane's first data row
+                    float *ts = tc + (int64_t)n * ldt;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        *reinterpret_cast<float4v *>(tc + 8 * g) = float4v{ct[4 * g], ct[4 * g + 1], ct[4 * g + 2], ct[4 * g + 3]};
+                        *reinterpret_cast<float4v *>(ts + 8 * g) = float4v{st[4 * g], st[4 * g + 1], st[4 * g + 2], st[4 * g + 3]};
                     }
                 }
             }
@@ -499,8 +518,11 @@ static bool rr_features_mfma_ok(rr_basis *b, const TX *X, int64_t m, int64_t ldx
 
 template <typename TX, typename TO>
 static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64_t m, int64_t mpad, int64_t ldx,
-                                    TO *P, int64_t ldp, double *db, float scale) {
+                                    TO *P, int64_t ldp, double *db, float scale, float *Pt = nullptr, int64_t ldt = 0) {
     if (!rr_features_mfma_ok<TX>(b, X, m, ldx)) return false;
+    // feature-major second output: plain f32 tiles without targets, 16-byte aligned rows of Pt
+    constexpr bool CAN_WT = std::is_same<TO, float>::value;
+    if (Pt != nullptr && (!CAN_WT || y != nullptr || (ldt & 3) != 0 || ((uintptr_t)Pt & 15) != 0)) return false;
     rr_ctx *c = b->ctx;
     const int64_t ntiles = (mpad + 31) / 32;
 #define RR_FM(DM, CBK)                                                                                              \
@@ -510,10 +532,13 @@ static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64
         while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 4 * (int64_t)c->num_cu) tpb >>= 1;                 \
         if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
         const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
-        if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true, TX, TO>), grid, dim3(256), 0, c->stream, \
-                                  X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);        \
-        else hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false, TX, TO>), grid, dim3(256), 0, c->stream, \
-                                X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb);          \
+        if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true, false, TX, TO>), grid, dim3(256), 0, c->stream, \
+                                  X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb, nullptr, 0); \
+        else if (CAN_WT && Pt)                                                                                      \
+            hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false, CAN_WT, TX, TO>), grid, dim3(256), 0, c->stream, \
+                               X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb, Pt, ldt);  \
+        else hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false, false, TX, TO>), grid, dim3(256), 0, c->stream, \
+                                X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb, nullptr, 0); \
     } while (0)
     switch (b->dpad) {
         case 8: RR_FM(8, 4); break;
@@ -2093,7 +2118,8 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
 
 // Row-major f32 features of a row block into a caller-provided scratch (used by the second _elbo pass).
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             float *P, int64_t ldp, bool zero_pad_cols) {
+                             float *P, int64_t ldp, bool zero_pad_cols, float *Pt, int64_t ldt, bool *pt_written) {
+    if (pt_written) *pt_written = false;
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n;
     const float scale = (float)(1.0 / sqrt((double)b->n));
@@ -2105,6 +2131,13 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
     if (b->large)
         return x_dtype == RR_F32 ? large_features<float, float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr)
                                  : large_features<double, float, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr);
+    if (Pt != nullptr && !b->large &&
+        (x_dtype == RR_F32 ? rr_features_mfma_launch<float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale, Pt, ldt)
+                           : rr_features_mfma_launch<double, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale, Pt, ldt))) {
+        RR_CHECK_HIP(hipGetLastError());
+        if (pt_written) *pt_written = true;
+        return RR_OK;
+    }
     if (x_dtype == RR_F32 ? rr_features_mfma_launch<float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)
                           : rr_features_mfma_launch<double, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, scale)) {
         RR_CHECK_HIP(hipGetLastError());

@@ -290,6 +290,41 @@ def test_config5_full_minibatch_is_additive_over_rows():
     assert normwise(g, np.array([-(EdPhi * dP[:, :, i]).sum() for i in range(d)])) < 5e-3
 
 
+def test_step_with_directly_written_transpose_equals_step_with_transposing_pass():
+    """From the second step of a given minibatch size on, the random Fourier children write their blocks of P^T while they
+    write P and the step skips its transposing pass: same step results as the first (transposing) step on the same
+    inputs, also after a step of another size in between (which falls back and lays the padding out again), and for a
+    concatenation with a linear child (never covered: always the transposing pass)."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    from revrand_amd.basis_functions import MinibatchFeatures
+    rs = np.random.RandomState(12)
+    N, d, K, L = 1500, 7, 2, 6
+    X = rs.randn(N, d)
+    y = rs.poisson(np.exp(0.4 * X[:, 1])).astype(float)
+    for basis, hyp in [(bs.RandomRBF(nbases=100, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())),
+                        [np.linspace(0.7, 1.2, d)]),
+                       (bs.RandomRBF(nbases=70, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+                        + bs.RandomMatern32(nbases=33, Xdim=d, random_state=4), [np.linspace(0.7, 1.2, d), 1.1]),
+                       (bs.RandomRBF(nbases=40, Xdim=d, random_state=3) + bs.LinearBasis(onescol=True), [0.9])]:
+        D = int(basis.get_dim(X))
+        WS = 0.1 * rs.randn(K * L, D)
+        f = MinibatchFeatures(basis)
+        out = []
+        for rows in (1000, 1000, 1000, 777, 1000, 1000):
+            f.assemble(X[:rows], hyp)
+            E, ll, _ = f.glm_step(y[:rows], None, lk.RR_LIK_POISSON_EXP, 0.0, WS, K, L)
+            g = f.glm_basis_grads(X[:rows])
+            out.append((rows, E.copy(), np.array(ll), np.concatenate([np.atleast_1d(np.asarray(v, dtype=float)).ravel()
+                                                                       for v in (g if isinstance(g, list) else [g])])))
+        f.release()
+        ref = out[0]
+        for rows, E, ll, g in out[1:]:
+            if rows == ref[0]:
+                assert normwise(E, ref[1]) < 1e-5 and normwise(ll, ref[2]) < 1e-6
+                if g.size:
+                    assert normwise(g, ref[3]) < 1e-4
+
+
 def test_resident_minibatch_gather_equals_host_gather():
     """fit() keeps X on the device and gathers minibatches there by index: the step on rows `idx` of the resident data
     equals the step on the host-gathered X[idx] (concatenation with Linear + Bias, column subsets)."""
