@@ -819,9 +819,11 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
     const int64_t rows256 = (fm->rows + 255) / 256 * 256;
     hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, s.m32,
                        fm->rows, fm->F, fm->ld, s.dot);
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(fm->ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0,
-                       c->stream, fm->P, fm->rows, fm->ld, s.Pt, fm->max_rows);
-    fm->pt_rows = fm->rows;
+    if (!(fm->pt_rows == fm->rows && fm->pt_covered >= fm->F)) {  // (else: the children wrote P^T next to P)
+        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(fm->ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0,
+                           c->stream, fm->P, fm->rows, fm->ld, s.Pt, fm->max_rows);
+        fm->pt_rows = fm->rows;
+    }
     if (c->gram_engine != 0) {  // split-bf16 engine (rr_rff.hip)
         if (!s.Ab) {
             RR_CHECK_HIP(hipMalloc(&s.Ab, (size_t)fm->ld * fm->max_rows * 4));

@@ -25,6 +25,20 @@ rr_linear_features_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int 
     P[r * ldp + c] = (onescol && c == 0) ? 1.f : (float)X[r * ldx + (c - onescol)];
 }
 
+// the same block feature-major: Pt[c][r] for r < Npad (zero for r >= N), coalesced along r
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_linear_features_t_kernel(const TX *__restrict__ X, int64_t N, int64_t Npad, int64_t ldx, int d, int onescol,
+                            float *__restrict__ Pt, int64_t ldt) {
+    const int w = d + onescol;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Npad * w) return;
+    const int c = (int)(i / Npad);
+    const int64_t r = i % Npad;
+    RR_DEV_ASSERT(Npad <= ldt && d <= ldx);
+    Pt[c * ldt + r] = r < N ? ((onescol && c == 0) ? 1.f : (float)X[r * ldx + (c - onescol)]) : 0.f;
+}
+
 template <typename TS>
 __global__ void __launch_bounds__(256)
 rr_copy_cols_kernel(const TS *__restrict__ src, int64_t N, int64_t lds_, int ncols, float *__restrict__ P, int64_t ldp) {
@@ -196,6 +210,19 @@ int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t l
     else
         hipLaunchKernelGGL(rr_linear_features_kernel<double>, grid, dim3(256), 0, fm->ctx->stream, (const double *)dX,
                            fm->rows, ldx, d, onescol ? 1 : 0, fm->P + col0, fm->ld);
+    // the same block of P^T (see rr_featmat_put_rff)
+    static const bool no_pt = getenv("RR_FM_NO_DIRECT_PT") != nullptr;
+    float *Pt = (fm->pt_rows == fm->rows && !no_pt) ? rr_fm_pass2_pt(fm->pass2) : nullptr;
+    if (Pt) {
+        const dim3 gt((unsigned)((fm->rows_pad * w + 255) / 256));
+        if (x_dtype == RR_F32)
+            hipLaunchKernelGGL(rr_linear_features_t_kernel<float>, gt, dim3(256), 0, fm->ctx->stream, (const float *)dX, fm->rows,
+                               fm->rows_pad, ldx, d, onescol ? 1 : 0, Pt + col0 * fm->max_rows, fm->max_rows);
+        else
+            hipLaunchKernelGGL(rr_linear_features_t_kernel<double>, gt, dim3(256), 0, fm->ctx->stream, (const double *)dX, fm->rows,
+                               fm->rows_pad, ldx, d, onescol ? 1 : 0, Pt + col0 * fm->max_rows, fm->max_rows);
+        fm->pt_covered += w;
+    }
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
