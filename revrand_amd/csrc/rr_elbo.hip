@@ -848,6 +848,7 @@ static int fm_pass2_scratch(rr_featmat *fm) {
     if (!fm->pass2) {
         FmPass2 *s = new FmPass2();
         fm->pass2 = s;
+        fm->pt_rows = -1;  // a fresh P^T: no padding laid out yet
         hipError_t ea = hipMalloc((void **)&s->Pt, (size_t)Fp * fm->max_rows * 4);
         if (ea == hipSuccess) ea = hipMalloc((void **)&s->U, (size_t)fm->max_rows * Fp * 4);
         if (ea == hipSuccess) ea = hipMalloc((void **)&s->C32, (size_t)Fp * Fp * 4);
