@@ -119,9 +119,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # touches random_; with the reference's stream the worker also makes step t+1's draws right after cutting its
         # batch -- the order in which a sequential run consumes the stream -- and hands them over with the batch, so
         # the ~12 ms of randn per config-5 step overlap the kernels instead of preceding them.
-        prefetch = True if self.sampler == "device" else (self._draw_ahead if self._prefetch_draws else False)
+        prefetch = self._ahead if (self.sampler == "device" or self._prefetch_draws) else False
         # (RR_GLM_DRAW_UPLOAD=0: measurement switch, the step uploads its draws itself)
-        if callable(prefetch) and self._native_draws and getattr(self._features(), "accepts_device_draws", False) \
+        if callable(prefetch) and self.sampler != "device" and self._prefetch_draws and self._native_draws \
+                and getattr(self._features(), "accepts_device_draws", False) \
                 and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
             self.__dict__["_draw_upload"] = (_hip.Device(_hip.get_device().index), [None, None, None], [0])
         try:
@@ -154,6 +155,18 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         return e
 
     _native_draws = True  # False: NumPy generates the draws (what tests compare the library's generator against)
+
+    def _ahead(self, batch):
+        """On the minibatch worker thread, for the batch it just cut: the likelihood's constants of that batch when they do
+        not depend on parameters (Poisson / binomial log-factorial sums: 0.15 ms of a 5 ms config-5 step), and -- with the
+        reference's random stream -- the step's draws (`_draw_ahead`)."""
+        batch = list(batch)
+        if getattr(self.likelihood, "spec_is_parameter_free", False):
+            extra = batch[2:-1] if getattr(self, "_resident_fit", False) else batch[2:]  # likelihood arguments of the batch
+            batch.append(_Spec(self.likelihood.device_spec(batch[1], [], extra)))
+        if self.sampler != "device" and self._prefetch_draws:
+            batch = self._draw_ahead(batch)
+        return batch
 
     def _draw_ahead(self, batch):
         """On the minibatch worker thread: the step's draws, and their upload -- through a device context (stream) of this
@@ -206,16 +219,20 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         L_ = self.nsamples
         lpars_l = atleast_list(lpars)
 
-        draws = None
-        if largs and isinstance(largs[-1], _Draws):                          # made one step ahead (`_draw_ahead`)
-            draws, largs = largs[-1].e, largs[:-1]
+        draws, spec = None, None
+        while largs and isinstance(largs[-1], (_Draws, _Spec)):              # made ahead on the worker (`_ahead`)
+            if isinstance(largs[-1], _Draws):
+                draws = largs[-1].e
+            else:
+                spec = largs[-1].spec
+            largs = largs[:-1]
         feats = self._features()
         resident = getattr(self, "_resident_fit", False)
         if resident:                                                          # rows by index from the resident data
             idx, largs = largs[-1], largs[:-1]
         # everything the step needs from the host goes first (likelihood constants, the targets' upload): the feature
         # kernels launched next then run while the host gets to the step's own call, instead of being waited for
-        lid, lpar, rowarg, llconst = self.likelihood.device_spec(y, lpars_l, largs)
+        lid, lpar, rowarg, llconst = spec if spec is not None else self.likelihood.device_spec(y, lpars_l, largs)
         if resident:
             feats.stage_targets(y, rowarg)
             feats.assemble_idx(idx, atleast_list(bpars))
@@ -421,6 +438,13 @@ def _submit(fn, *args):
         from concurrent.futures import ThreadPoolExecutor
         _pool = (os.getpid(), ThreadPoolExecutor(max_workers=1, thread_name_prefix="revrand-glm"))
     return _pool[1].submit(fn, *args)
+
+
+class _Spec(object):
+    """`likelihood.device_spec` of one minibatch, evaluated ahead of its step."""
+
+    def __init__(self, spec):
+        self.spec = spec
 
 
 class _Draws(object):

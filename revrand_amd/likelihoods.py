@@ -49,6 +49,10 @@ class Bernoulli(object):
     def cdf(self, y, f):
         return bernoulli.cdf(y, expit(f))
 
+    # device_spec does not look at the likelihood's parameters: the SVI loop may evaluate it for a minibatch before the
+    # step that uses it (glm.py, on the minibatch worker thread).  Gaussian overrides this.
+    spec_is_parameter_free = True
+
     def device_spec(self, y, lpars, largs):
         """(likelihood id, scalar parameter, per-row argument or None, host constant added to sum(loglike)
         per latent sample) for the fused SVI step."""
@@ -116,6 +120,8 @@ class Gaussian(Bernoulli):
     def cdf(self, y, f, var):
         var = self._check_param(var)
         return norm.cdf(y, loc=f, scale=np.sqrt(var))
+
+    spec_is_parameter_free = False
 
     def device_spec(self, y, lpars, largs):
         var = float(self._check_param(lpars[0] if len(lpars) else None))
