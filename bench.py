@@ -63,6 +63,17 @@ def gen_chunk(c, rows, d, wvec):
     return X, y.astype(np.float32)
 
 
+def runtime_info(_hip, parallel):
+    """Which HIP runtime and which librccl this process runs on (recorded in every line)."""
+    info = {"hip_runtime": _hip.hip_runtime_path(), "RR_HIP_RUNTIME": os.environ.get("RR_HIP_RUNTIME", "system (default)")}
+    try:
+        ver, path = parallel.RcclComm.load()
+        info["rccl"] = {"version": ver, "library": path}
+    except Exception as e:  # N = 1 needs no RCCL: say so instead of failing the line
+        info["rccl"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return info
+
+
 def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import revrand_oracle as orc  # checker/baseline only -- never on the product path
@@ -110,6 +121,9 @@ def cpu_baseline(d, n, W, wvec, sample_rows, budget_s=100.0):
 # ----------------------------------------------------------------------------------------------------
 
 def launch(args, argv):
+    """Start one rank per GPU (rank r on device r % visible GPUs), wait for all of them; a rank that fails -- or the whole
+    job exceeding --launch-timeout -- ends every rank, and the launcher exits non-zero with the tail of the failing
+    rank's stderr.  Rank 0's stdout (the ONE JSON line) passes through; every rank's stderr is forwarded."""
     from revrand_amd import _hip
     n = _hip.ctypes.c_int()
     lib = _hip.load_library()
@@ -118,18 +132,21 @@ def launch(args, argv):
         raise SystemExit("bench.py: no HIP device visible (the hot path has no CPU fallback)")
     world = args.gpus
     rdzv_dir = tempfile.mkdtemp(prefix="rr_bench_")
-    procs = []
+    procs, logs = [], []
     for r in range(world):
         env = dict(os.environ)
-        env.update({"RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(r % ndev), "MASTER_ADDR": "127.0.0.1",
-                    "RR_COMM_RDZV": "file:" + os.path.join(rdzv_dir, "rccl.id"), "RR_BENCH_VISIBLE_GPUS": str(ndev)})
+        env.update({"RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_RANK": str(r % ndev), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "RR_COMM_RDZV": "file:" + os.path.join(rdzv_dir, "rccl.id"),
+                    "RR_BENCH_VISIBLE_GPUS": str(ndev)})
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world > ndev:
             # fewer GPUs than ranks (plumbing runs on a 1-GPU box): RCCL refuses two ranks on one device of one host,
             # so every rank claims its own host id and the exchange takes RCCL's socket transport
             env["NCCL_HOSTID"] = "rr-bench-rank-%d" % r
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
-    rc = 0
+        logs.append(open(os.path.join(rdzv_dir, "rank%d.err" % r), "w+"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stderr=logs[-1]))
+    rc, failed, why = 0, None, ""
+    deadline = time.time() + args.launch_timeout
     try:
         pending = list(procs)
         while pending:
@@ -139,14 +156,32 @@ def launch(args, argv):
                     continue
                 pending.remove(p)
                 if code != 0 and rc == 0:
-                    rc = code
+                    rc, failed, why = code, procs.index(p), "exited with status %d" % code
                     for q in pending:  # a rank failed: its peers would wait in the collective forever
                         q.terminate()
+            if pending and rc == 0 and time.time() > deadline:
+                rc, failed = 124, procs.index(pending[0])
+                why = "still running after --launch-timeout %.0f s (%d of %d ranks unfinished)" % (
+                    args.launch_timeout, len(pending), world)
+                for q in pending:
+                    q.terminate()
             time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
-                p.kill()
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+        for r, f in enumerate(logs):
+            f.flush()
+            f.seek(0)
+            text = f.read()
+            f.close()
+            if text.strip():
+                sys.stderr.write("".join("[rank %d] %s\n" % (r, l) for l in text.splitlines()[-400:]))
+            if failed == r:
+                sys.stderr.write("bench.py: rank %d %s; its last output:\n%s\n" % (r, why, text[-3000:]))
         try:
             for f in os.listdir(rdzv_dir):
                 os.unlink(os.path.join(rdzv_dir, f))
@@ -289,6 +324,22 @@ def config_c3(dev, _hip, args):
     G, b, yty = st.stats_host()
     tr = abs(float(np.trace(G[:2 * n, :2 * n])) - N) / N
     assert tr < 1e-5 and G[2 * n, 2 * n] == N and np.array_equal(G, G.T), tr
+    del G
+    # the rest of one `_elbo` at this shape (slm.py:154-199): posterior of the F_tot x F_tot system in HBM, second pass
+    elbo = None
+    if _hip.posterior_available(F):
+        iL, var = np.full(F, 1.0), 0.5
+        st.posterior(iL, var)
+        t_post, post = _median_ms(lambda: st.posterior(iL, var), 2)
+        st.second_pass(hyp, post[0], st.dC, var)
+        t_p2, _ = _median_ms(lambda: st.second_pass(hyp, post[0], st.dC, var), 2)
+        fl_post, fl_p2 = F ** 3 / 3.0 + F ** 3, 2.0 * F * F + 4.0 * d * n
+        elbo = {"ms": {"statistics_pass": ms, "posterior": t_post, "second_pass": t_p2, "stage_sum": ms + t_post + t_p2},
+                "posterior_tflops_f64": fl_post / (t_post * 1e-3) / 1e12,
+                "posterior_frac_of_f64_mfma": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                "second_pass_frac_of_f32_mfma": fl_p2 * N / (t_p2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "frac_over_stage_sum": (2.0 * d * n + F * (F + 1.0) + 2.0 * F + fl_p2) * N / ((ms + t_post + t_p2) * 1e-3) / 1e12
+                / PEAK_F32_MFMA_TFLOPS}
     st.release()
     cpu = None
     if not args.no_cpu_baseline:
@@ -309,7 +360,7 @@ def config_c3(dev, _hip, args):
             "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "flops_per_row": fl,
                          "achieved": fl * N / (ms * 1e-3) / 1e12, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                          "note": "whole pass (feature assembly + both SYRK kernels + mirror) on algorithmic flops"},
-            "exchange_bytes_per_evaluation": 8 * (F * (F + 1) // 2 + F + 2),
+            "exchange_bytes_per_evaluation": 8 * (F * (F + 1) // 2 + F + 2), "elbo_eval_one_gpu_share": elbo,
             "rows_per_launch": chunk_rows, "launches_per_pass": -(-N // chunk_rows), "cpu_baseline": cpu}
 
 
@@ -317,12 +368,12 @@ def config_c4(dev, _hip, args):
     """configs[3]: FastFoodRBF nbases=8192, D=128 (F=16384): the Hadamard / permute / diagonal chain, Phi streamed in
     262 144-row chunks into a two-slot device ring (Phi for N=4M is 262 GB in f32)."""
     import revrand_amd.basis_functions as bs
-    d, nb, CH, NCH = 128, 8192, 262_144, 4
+    d, nb, CH, NCH = 128, 8192, 262_144, 16  # N = 4 194 304 = BASELINE's 4M
     f = bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=1)
     h = f._handles()[0]  # the chain kernel's handle (rr_fastfood_*)
     F = 2 * h.n
     rng = np.random.default_rng([20260928, 4])
-    X = rng.standard_normal((CH * NCH, d), dtype=np.float32)
+    X = rng.standard_normal((CH * NCH, d), dtype=np.float32)  # 2 GiB, resident before anything is timed
     dX = dev.upload_matrix(X)
     ring = [dev.malloc(CH * F * 4) for _ in range(2)]
 
@@ -333,7 +384,7 @@ def config_c4(dev, _hip, args):
     pass_()
     dev.sync()
     dev.timer_start()
-    reps = 3
+    reps = 2
     for _ in range(reps):
         pass_()
     kms = dev.timer_stop() / reps
@@ -472,9 +523,172 @@ def config_c5(dev, _hip, args):
             "cpu_baseline": cpu}
 
 
+def _median_ms(fn, reps=3):
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        r = fn()
+        ts.append(1e3 * (time.perf_counter() - t0))
+    return float(np.median(ts)), r
+
+
+def _elbo_parity(make_basis, X, y, var, reg, ls, rows=768):
+    """One `_elbo` of the product on the first `rows` rows (resident route, device posterior) against the oracle's
+    slm_elbo on the same rows in float64: (rel. error of -ELBO, normwise error of [dvar, dreg, dhyp])."""
+    from revrand_amd.slm import StandardLinearModel
+    orc = _oracle()
+    Xs, ys = np.ascontiguousarray(X[:rows]), np.ascontiguousarray(y[:rows])
+    basis = make_basis()
+    slm = StandardLinearModel(basis)
+    slm.obj_ = -np.inf
+    slm._state = basis.device_fit_state(Xs, ys)
+    f, (gv, gr, gh) = slm._elbo(Xs, ys, var, reg, ls)
+    slm._state.release()
+    slm._state = None
+    X64, y64 = Xs.astype(np.float64), ys.astype(np.float64)
+    W = basis.W
+    Phi = orc.rff_transform(X64, W, ls)
+    dP = orc.rff_grad(X64, W, ls)
+    ref = orc.slm_elbo(Phi, y64, var, np.full(Phi.shape[1], reg), slice(None), [dP[:, :, i] for i in range(dP.shape[2])])
+    got = np.concatenate(([gv], np.atleast_1d(gr), np.atleast_1d(gh)))
+    want = np.concatenate(([-ref["dvar"]], [-g for g in ref["dreg"]], [-g for g in ref["dhyp"]]))
+    return abs(f + ref["elbo"]) / abs(ref["elbo"]), float(np.linalg.norm(got - want) / np.linalg.norm(want))
+
+
+def config_elbo(dev, _hip, args, dtype="f32", N=1_000_000):
+    """One L-BFGS evaluation of StandardLinearModel._elbo (slm.py:142-199) at config 2's shape with the data resident:
+    statistics pass (features + Gram), posterior in HBM (blocked Cholesky + inverse + reductions), second pass (features,
+    U = Phi C, residual, hyper-gradient contraction).  Stage times are host wall-clock around calls that return numbers
+    (each ends with a synchronising copy), the whole evaluation is `_elbo` as the optimiser calls it."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    d, n = 32, 2048
+    F = 2 * n
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    X, y = gen_chunk(91, N, d, wvec)
+    if dtype == "f64":
+        X, y = X.astype(np.float64), y.astype(np.float64)
+
+    def make_basis():
+        return bs.RandomRBF(nbases=n, Xdim=d, random_state=42, lenscale=Parameter(np.ones(d), Positive()), dtype=dtype)
+    basis = make_basis()
+    slm = StandardLinearModel(basis)
+    slm.obj_ = -np.inf
+    st = slm._state = basis.device_fit_state(X, y)
+    ls, var, reg = np.linspace(0.8, 1.3, d), 0.5, 1.0
+    iL = np.full(F, 1.0 / reg)
+    assert _hip.posterior_available(F)
+    slm._elbo(X, y, var, reg, ls)  # warm: scratch allocations, posterior work space
+    t_stats, _ = _median_ms(lambda: st.gram_device(ls))
+    kt = st.handle.gram_timings()
+    t_post, post = _median_ms(lambda: st.posterior(iL, var))
+    m = post[0]
+    t_pass2, _ = _median_ms(lambda: st.second_pass(ls, m, st.dC, var))
+    t_eval, res = _median_ms(lambda: slm._elbo(X, y, var, reg, ls * 1.0))
+    st.release()
+    slm._state = None
+    peak = PEAK_F32_MFMA_TFLOPS if dtype == "f32" else PEAK_F64_MFMA_TFLOPS
+    fl_stats = flops_per_row(d, n)                    # 2dn + F(F+1) + 2F
+    fl_pass2 = 2.0 * F * F + 2.0 * d * n + 2.0 * d * n  # U = Phi C, the features again, the (d, n) contraction X^T A
+    fl_post = F ** 3 / 3.0 + F ** 3                   # Cholesky + inverse from the factor (f64 MFMA)
+    fl_row = fl_stats + fl_pass2
+    stage_sum = t_stats + t_post + t_pass2
+    perr = _elbo_parity(make_basis, X, y, var, reg, ls) if not args.no_parity_check else (None, None)
+    return {"workload": "StandardLinearModel._elbo, RandomRBF nbases=2048 (F=4096), D=32 ARD, N=%d resident, %s arithmetic: "
+                        "statistics pass + posterior on the device + second pass" % (N, dtype), "rows": N, "dtype": dtype,
+            "ms": {"statistics_pass": t_stats, "posterior": t_post, "second_pass": t_pass2, "stage_sum": stage_sum,
+                   "elbo_wall": t_eval, "statistics_kernels": {"features": kt[0], "syrk": kt[1], "syrk_diag": kt[2]}},
+            "value": N / (t_eval * 1e-3), "unit": "rows/s through one full _elbo evaluation",
+            "neg_elbo": float(res[0]),
+            "flops": {"per_row_statistics": fl_stats, "per_row_second_pass": fl_pass2, "per_row": fl_row,
+                      "posterior": fl_post, "formula": "F(F+1) + 2dn + 2F  |  2F^2 + 2dn + 2dn  |  F^3/3 + F^3"},
+            "roofline": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
+                         "statistics_pass_frac": fl_stats * N / (t_stats * 1e-3) / 1e12 / peak,
+                         "second_pass_frac": fl_pass2 * N / (t_pass2 * 1e-3) / 1e12 / peak,
+                         "posterior_tflops": fl_post / (t_post * 1e-3) / 1e12,
+                         "posterior_frac_of_f64_mfma": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "achieved_over_stage_sum": (fl_row * N) / (stage_sum * 1e-3) / 1e12,
+                         "frac_over_stage_sum": (fl_row * N) / (stage_sum * 1e-3) / 1e12 / peak,
+                         "frac_over_wall": (fl_row * N) / (t_eval * 1e-3) / 1e12 / peak,
+                         "note": "row flops only in the two *_over_* fractions (the posterior's F^3 flops run on the f64 "
+                                 "pipe and are reported on their own)"},
+            "parity_768_rows_vs_oracle": {"neg_elbo_rel_err": perr[0], "gradient_normwise_err": perr[1]}}
+
+
+def config_posterior(dev, _hip, args, F):
+    """rr_posterior_dev alone: C = (diag(1/L) + G / var)^-1 by blocked Cholesky + inverse on the f64 MFMA GEMMs, m, diag C,
+    log|iC| and sum(G o C), all in HBM; G = the Gram of 3 F random-feature rows (full rank, realistic spectrum)."""
+    rs = np.random.RandomState(F)
+    A = rs.standard_normal((3 * F, 16)) @ rs.standard_normal((16, F)) / 4.0
+    P = np.concatenate((np.cos(A), np.sin(A)), axis=1)[:, :F] / np.sqrt(F / 2.0)
+    G = P.T @ P
+    b = P.T @ rs.standard_normal(3 * F)
+    iL, var = np.full(F, 1.0), 0.5
+    acc = dev.upload_vector(np.concatenate((G.ravel(), b)))
+    dC = dev.malloc(F * F * 8)
+    pG, pb = _hip.ctypes.c_void_p(acc.ptr.value), _hip.ctypes.c_void_p(acc.ptr.value + F * F * 8)
+    dev.posterior(F, pG, pb, iL, var, dC)
+    ms, post = _median_ms(lambda: dev.posterior(F, pG, pb, iL, var, dC))
+    m, dg, logdet, tr = post
+    perr = None
+    if not args.no_parity_check:
+        orc = _oracle()
+        mh, Ch, ldC = orc.slm_posterior_from_stats(G, b, var, np.full(F, 1.0))
+        C = dev.download(dC, (F, F), np.float64)
+        perr = {"m": float(np.abs(m - mh).max() / np.abs(mh).max()), "C": float(np.abs(C - Ch).max() / np.abs(Ch).max()),
+                "logdet_abs": float(abs(logdet + ldC)), "trace_rel": float(abs(tr - (G * Ch).sum()) / abs((G * Ch).sum()))}
+    acc.free()
+    dC.free()
+    fl = F ** 3 / 3.0 + F ** 3
+    return {"workload": "rr_posterior_dev, F=%d, float64: Cholesky + inverse + m, diag C, log|iC|, sum(G o C) in HBM" % F,
+            "ms": ms, "flops": fl, "dtype": "f64",
+            "roofline": {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "achieved": fl / (ms * 1e-3) / 1e12,
+                         "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "note": "F^3/3 (factor) + F^3 (inverse) flops over the wall-clock of the whole call"},
+            "parity_vs_oracle_solve_posdef": perr}
+
+
+def config_predict(dev, _hip, args, N=300_000):
+    """StandardLinearModel.predict_moments (slm.py:219-244) for N query rows at F = 4096: host X in, (Ey, Vy) out."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    d, n = 32, 2048
+    F = 2 * n
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    X, y = gen_chunk(92, N, d, wvec)
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=42, lenscale=Parameter(1.0, Positive()))
+    slm = StandardLinearModel(basis, var=Parameter(0.5, Positive()), nstarts=0, maxiter=1).fit(X[:50000], y[:50000])
+    slm.predict_moments(X[:4096])
+    ms, (Ey, Vy) = _median_ms(lambda: slm.predict_moments(X))
+    ms_mean, _ = _median_ms(lambda: slm.predict(X))
+    perr = None
+    if not args.no_parity_check:
+        orc = _oracle()
+        Phi = orc.rff_transform(X[:512].astype(np.float64), basis.W, slm.hypers_)
+        Er, Vr = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
+        perr = {"Ey": float(np.abs(Ey[:512] - Er).max() / np.abs(Er).max()), "Vy": float(np.abs(Vy[:512] - Vr).max() / np.abs(Vr).max())}
+    slm._drop_serving()
+    fl = 2.0 * d * n + F * F + 2.0 * F  # features, phi^T B with the triangular factor (half of 2 F^2), phi . m
+    return {"workload": "StandardLinearModel.predict_moments, RandomRBF F=4096, D=32, N=%d host rows (upload, features, "
+                        "variance GEMM on the triangular factor, download)" % N, "rows": N, "dtype": "f32",
+            "ms": ms, "ms_predict_mean_only": ms_mean, "value": N / (ms * 1e-3), "unit": "rows/s",
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "flops_per_row": fl,
+                         "achieved": fl * N / (ms * 1e-3) / 1e12, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "note": "wall-clock of the call, PCIe upload of X and download of (Ey, Vy) included"},
+            "parity_512_rows_vs_oracle": perr}
+
+
+
 def extra_configs(dev, _hip, args):
     res = {}
     for name, fn in (("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
+                     ("C2_elbo_eval", config_elbo),
+                     ("C2f64_elbo_eval_n200k", lambda d_, h_, a_: config_elbo(d_, h_, a_, dtype="f64", N=200_000)),
+                     ("posterior_F4096", lambda d_, h_, a_: config_posterior(d_, h_, a_, 4096)),
+                     ("posterior_F8257", lambda d_, h_, a_: config_posterior(d_, h_, a_, 8257)),
+                     ("predict_moments_n300k", config_predict),
                      ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
                      ("C5_glm_poisson_svi_step", config_c5)):
         if args.configs != "all" and name.split("_")[0].lower() not in args.configs.lower().split(","):
@@ -504,6 +718,8 @@ def main():
     ap.add_argument("--no-alt-engine", action="store_true", help="skip the informational fp16x3 measurement")
     ap.add_argument("--no-parity-check", action="store_true",
                     help="skip the 2048-row oracle check before timing (profiling runs: keeps per-kernel averages clean)")
+    ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("RR_BENCH_LAUNCH_TIMEOUT", "3000")),
+                    help="seconds after which the self-launcher (--gpus N without a launcher) ends all ranks and fails")
     ap.add_argument("--configs", default="all",
                     help="BASELINE's other configurations to time after the headline at N=1: all | none | e.g. c3,c5,headline")
     args = ap.parse_args()
@@ -627,6 +843,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed = float(comm.allreduce_host(np.array([elapsed]), op="max")[0])  # MAX over ranks
+    # per-rank device time of one step's kernels (HIP events) and of the exchange: max / min / sum over the ranks
+    my_k = float(np.mean([k[0] + k[1] + k[2] for k in kernel_ms])) if kernel_ms else 0.0
+    my_x = float(np.mean(exch_ms)) if exch_ms else 0.0
+    k_max, x_max = comm.allreduce_host(np.array([my_k, my_x]), op="max")
+    k_min, x_min = comm.allreduce_host(np.array([my_k, my_x]), op="min")
+    k_sum = float(comm.allreduce_host(np.array([my_k]))[0])
 
     # sanity on the result of the last step (every rank holds the global statistics): trace(G) == N
     # (cos^2 + sin^2 = 1 per frequency), exactly symmetric, summed row count == N
@@ -694,7 +916,8 @@ def main():
             "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, features + MFMA Gram, rows sharded "
                                    "over %d GPU(s)" % (n, F, d, args.rows, world),
                        "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err,
-                       "gram_engine": engine, "parity_rel_err_2048_rows_vs_oracle": parity_err},
+                       "gram_engine": engine, "parity_rel_err_2048_rows_vs_oracle": parity_err,
+                       "runtime": runtime_info(_hip, parallel)},
             "roofline": {"bound": "mfma", "kernel": "rr_syrk_f32_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
@@ -717,8 +940,20 @@ def main():
                                "rccl": dict(zip(("version", "library"), parallel.RcclComm.load())),
                                "ranks_rccl_reports": world, "message_float64": cnt, "message_bytes": 8 * cnt,
                                "ms_per_step_pack_allreduce_unpack": float(np.mean(exch_ms)) if exch_ms else None,
+                               "ms_per_step_pack_allreduce_unpack_max_min_over_ranks": [float(x_max), float(x_min)],
                                "visible_gpus": int(os.environ.get("RR_BENCH_VISIBLE_GPUS", "0")) or None,
                                "oversubscribed": bool(os.environ.get("NCCL_HOSTID", "").startswith("rr-bench-rank-"))}
+        if world > 1:
+            # what the ranks' own clocks say: device time of a step's kernels on the slowest / fastest rank, and the model
+            # "largest shard's kernels + exchange" against the same kernels run back to back on one GPU (their sum)
+            model_ms = float(k_max) + float(x_max)
+            out["per_rank"] = {"kernel_ms_per_step_max_min_over_ranks": [float(k_max), float(k_min)],
+                               "kernel_ms_per_step_sum_over_ranks": k_sum,
+                               "expected_speedup_model": {"ms_per_step": model_ms,
+                                                          "speedup_vs_one_gpu": k_sum / model_ms if model_ms > 0 else None,
+                                                          "measured_ms_per_step": ms_per_step,
+                                                          "note": "max over ranks of (features + SYRK kernels) + exchange; "
+                                                                  "one GPU = the same kernels of all shards back to back"}}
         if engine != "f32":
             # split-bf16 engine: one SYRK kernel over all 136 tiles; the roofline is the bf16 matrix pipe, `achieved`
             # stays ALGORITHMIC flops (the kernel issues 3 or 4 bf16 products per f32 product: `issued_frac`)

@@ -198,31 +198,56 @@ _lib = None
 _lib_lock = threading.Lock()
 
 
-def _share_hip_runtime_with_torch():
-    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (same soname as
-    /opt/rocm's).  If torch is imported first the loader hands that copy to our library too; the other way
-    round torch would bring a SECOND runtime + HSA instance into the process and see no GPU.  So when torch is
-    installed but not yet imported, its copy is loaded first (no ``import torch``).  ``RR_HIP_RUNTIME=system``
-    keeps /opt/rocm's."""
-    if "torch" in sys.modules or os.environ.get("RR_HIP_RUNTIME", "") == "system":
+def _select_hip_runtime():
+    """One HIP runtime per process, and by default the one librevrand_hip.so was BUILT against (its RUNPATH:
+    /opt/rocm).  PyTorch-ROCm wheels bundle their own libamdhip64.so with the same soname: if torch is already imported
+    the loader hands that copy to our library too (nothing to do, and nothing we could do); if torch will be imported
+    LATER in this process, set ``RR_HIP_RUNTIME=torch`` (or import torch first) -- otherwise torch would bring a second
+    runtime + HSA instance into the process and see no GPU.  ``RR_HIP_RUNTIME=torch`` loads torch's bundled copy first
+    (no ``import torch``); ``RR_HIP_RUNTIME=system`` (the default) changes nothing."""
+    mode = os.environ.get("RR_HIP_RUNTIME", "system")
+    if mode not in ("system", "torch", ""):
+        raise ImportError("RR_HIP_RUNTIME must be 'system' or 'torch', got %r" % mode)
+    if mode != "torch" or "torch" in sys.modules:
         return
     cand = _torch_lib("libamdhip64.so")
-    if cand:
-        try:
-            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
-        except OSError:
-            pass  # fall back to the system runtime
+    if cand is None:
+        raise ImportError("RR_HIP_RUNTIME=torch, but no torch wheel with a bundled libamdhip64.so is installed")
+    ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+
+
+def _mapped(key):
+    """Paths of the shared objects mapped into this process whose file name contains `key`."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if key in line and "/" in line.split()[-1]})
+    except OSError:
+        return []
+
+
+def hip_runtime_path():
+    """The libamdhip64 this process runs on (after load_library()); several paths = a broken process, all are reported."""
+    paths = _mapped("libamdhip64")
+    return paths[0] if len(paths) == 1 else (paths or None)
+
+
+def _runtime_is_torchs():
+    cand = _torch_lib("libamdhip64.so")
+    if cand is None:
+        return False
+    tdir = os.path.realpath(os.path.dirname(cand))
+    return any(os.path.realpath(os.path.dirname(p)) == tdir for p in _mapped("libamdhip64"))
 
 
 def rccl_library_path():
-    """The librccl that matches the HIP runtime this process runs on: $RR_RCCL_LIB; the copy bundled with an installed
-    torch wheel when its runtime was taken (see above); None = the library's own search (an already loaded
-    librccl.so.1, then /opt/rocm/lib)."""
+    """The librccl that belongs to the HIP runtime this process runs on: $RR_RCCL_LIB; the copy bundled with the torch
+    wheel when (and only when) the process runs on that wheel's HIP runtime; None = the library's own search (an already
+    loaded librccl.so.1, then /opt/rocm/lib)."""
     if os.environ.get("RR_RCCL_LIB"):
         return os.environ["RR_RCCL_LIB"]
-    if os.environ.get("RR_HIP_RUNTIME", "") == "system":
-        return None
-    return _torch_lib("librccl.so")
+    if _runtime_is_torchs():
+        return _torch_lib("librccl.so")
+    return None
 
 
 def _torch_lib(name):
@@ -260,7 +285,7 @@ def load_library(path=None):
     with _lib_lock:
         if _lib is not None and path is None:
             return _lib
-        _share_hip_runtime_with_torch()
+        _select_hip_runtime()
         p = path or os.environ.get("REVRAND_HIP_LIB", LIB_PATH)
         if not os.path.exists(p):
             raise ImportError(

@@ -100,7 +100,7 @@ class RcclComm(Comm):
         self.lib = self.dev.lib
         if len(ident) != 128:
             raise ValueError("an RCCL unique id has 128 bytes")
-        RcclComm.load()  # every rank binds the SAME librccl (the one paired with this process's HIP runtime)
+        ver, path = RcclComm.load()  # the librccl paired with this process's HIP runtime
         h = ctypes.c_void_p()
         idbuf = ctypes.create_string_buffer(bytes(ident), 128)
         _hip._check(self.lib, self.lib.rr_comm_init_rank(self.dev.ctx, int(rank), int(world), idbuf, ctypes.byref(h)))
@@ -109,6 +109,22 @@ class RcclComm(Comm):
         _hip._check(self.lib, self.lib.rr_comm_info(h, ctypes.byref(r), ctypes.byref(w)))
         self.rank, self.world = r.value, w.value  # as RCCL reports them
         self._msg = None
+        self.rccl_version, self.rccl_library = ver, path
+        self._assert_same_rccl()
+
+    def _assert_same_rccl(self):
+        """Every rank must have bound the same librccl (version and file): a mixed job -- one rank on the torch wheel's
+        RCCL, another on /opt/rocm's -- may run, and then fail in a collective much later.  One tiny all-reduce."""
+        if self.world < 2:
+            return
+        import zlib
+        tag = float(zlib.crc32(os.path.realpath(self.rccl_library).encode()))
+        v = float(self.rccl_version)
+        hi = self.allreduce_host(np.array([v, -v, tag, -tag]), op="max")
+        if hi[0] != -hi[1] or hi[2] != -hi[3]:
+            raise RuntimeError("rank %d bound RCCL %d from %s, but the ranks of this job do not all use the same librccl "
+                               "(versions %d..%d): start every rank with the same RR_HIP_RUNTIME / RR_RCCL_LIB"
+                               % (self.rank, self.rccl_version, self.rccl_library, int(-hi[1]), int(hi[0])))
 
     @staticmethod
     def load(path=None):
@@ -213,19 +229,73 @@ class TorchComm(Comm):
 # rendezvous of the RCCL id (rank 0 -> everyone): a file or a TCP socket
 # ------------------------------------------------------------------------------------------------
 
+_ID_MAGIC = b"RRCCLID1"
+
+
+def _rdzv_dir():
+    """A directory only this user can write (0700, owned by us, not a symlink) for the id files."""
+    d = os.path.join(tempfile.gettempdir(), "rr_comm_%d" % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat as _stat
+    if not _stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise RuntimeError("rendezvous directory %s is not a private directory of uid %d" % (d, os.getuid()))
+    return d
+
+
+def _proc_start(pid):
+    """Start time (clock ticks since boot) of a live process, or None."""
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return None
+
+
 def default_rendezvous():
-    """``RR_COMM_RDZV`` ("file:/path" or "tcp:host:port"), else a file name every worker of ONE launcher derives
-    identically: the launcher's pid (torch.distributed.run's agent, or bench.py's own launcher) + MASTER_PORT + restart
-    count, so a stale file of an earlier job can never be read."""
+    """``RR_COMM_RDZV`` ("file:/path" or "tcp:host:port"), else
+    * ranks on more than one node (WORLD_SIZE > LOCAL_WORLD_SIZE): ``tcp:MASTER_ADDR:MASTER_PORT+1`` -- a file is node-local;
+    * one node: a file in a private per-user directory whose name every worker of ONE launcher derives identically (the
+      launcher's pid -- torch.distributed.run's agent, or bench.py's own launcher -- MASTER_PORT and the restart count).
+      The file carries the writer's pid and start time, and readers only accept the id of a LIVE writer (``exchange_id``),
+      so what an earlier, crashed job left behind is never used."""
     r = os.environ.get("RR_COMM_RDZV")
     if r:
         return r
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > local_world:
+        addr, port = os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")
+        if not addr or not port:
+            raise RuntimeError("ranks on several nodes need RR_COMM_RDZV=tcp:<host>:<port> (or MASTER_ADDR / MASTER_PORT)")
+        return "tcp:%s:%d" % (addr, int(port) + 1)
     key = "%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"), os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
-    return "file:" + os.path.join(tempfile.gettempdir(), "rr_comm_%s.id" % key)
+    return "file:" + os.path.join(_rdzv_dir(), "rr_comm_%s.id" % key)
+
+
+def _read_id_file(where):
+    """The 128-byte id in `where` if a live process wrote it; None otherwise (absent, partial, stale)."""
+    import struct
+    try:
+        fd = os.open(where, os.O_RDONLY | os.O_NOFOLLOW)
+    except OSError:
+        return None
+    with os.fdopen(fd, "rb") as f:
+        blob = f.read()
+    if len(blob) != 8 + 16 + 128 or blob[:8] != _ID_MAGIC:
+        return None
+    pid, start = struct.unpack("<qq", blob[8:24])
+    if _proc_start(pid) != start:  # the writer is gone (or its pid was recycled): an earlier job's file
+        return None
+    return blob[24:]
 
 
 def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
     """Rank 0 calls make_id() and publishes the bytes; every other rank receives them."""
+    import struct
     if world == 1:
         return make_id()
     rdzv = rendezvous or default_rendezvous()
@@ -233,40 +303,71 @@ def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
     deadline = time.time() + timeout
     if kind == "file":
         if rank == 0:
-            ident = make_id()
-            tmp = where + ".tmp%d" % os.getpid()
-            with open(tmp, "wb") as f:
-                f.write(ident)
-            os.replace(tmp, where)  # atomic: readers see all 128 bytes or nothing
-            return ident
-        while time.time() < deadline:
-            try:
-                with open(where, "rb") as f:
-                    ident = f.read()
-                if len(ident) == 128:
-                    return ident
+            try:  # whatever an earlier job left under this name
+                os.unlink(where)
             except OSError:
                 pass
+            ident = make_id()
+            tmp = where + ".tmp%d" % os.getpid()
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+            with os.fdopen(fd, "wb") as f:
+                f.write(_ID_MAGIC + struct.pack("<qq", os.getpid(), _proc_start(os.getpid()) or 0) + ident)
+            os.replace(tmp, where)  # atomic: readers see the whole record or nothing
+            return ident
+        while time.time() < deadline:
+            ident = _read_id_file(where)
+            if ident is not None:
+                return ident
             time.sleep(0.01)
-        raise TimeoutError("no RCCL id at %s after %.0f s" % (where, timeout))
+        raise TimeoutError("no RCCL id of a live rank 0 at %s after %.0f s" % (where, timeout))
     if kind == "tcp":
         host, _, port = where.rpartition(":")
+        token = struct.pack("<8sii", b"RRCCLREQ", int(world), 0)[:12]
         if rank == 0:
             ident = make_id()
             srv = socket.socket()
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            srv.bind((host, int(port)))
-            srv.listen(world)
-            srv.settimeout(timeout)
-            for _ in range(world - 1):
-                c, _ = srv.accept()
-                c.sendall(ident)
-                c.close()
+            # loopback names stay on loopback; any other name is rank 0's address as the OTHER nodes see it: all interfaces
+            srv.bind((host if host.startswith("127.") or host == "localhost" else "", int(port)))
+            srv.listen(max(world, 8))
+            served = set()
+            while len(served) < world - 1:  # one reply per DISTINCT valid rank; anything else is dropped
+                left = deadline - time.time()
+                if left <= 0:
+                    srv.close()
+                    raise TimeoutError("RCCL id server: only ranks %s of %d asked within %.0f s" % (sorted(served), world, timeout))
+                srv.settimeout(left)
+                try:
+                    c, _ = srv.accept()
+                except socket.timeout:
+                    continue
+                try:
+                    c.settimeout(5.0)
+                    req = b""
+                    while len(req) < 16:
+                        part = c.recv(16 - len(req))
+                        if not part:
+                            break
+                        req += part
+                    if len(req) == 16 and req[:12] == token:
+                        r = struct.unpack("<i", req[12:])[0]
+                        if 1 <= r < world and r not in served:
+                            c.sendall(ident)
+                            served.add(r)
+                except OSError:
+                    pass
+                finally:
+                    c.close()
             srv.close()
             return ident
         while time.time() < deadline:
             try:
                 c = socket.create_connection((host, int(port)), timeout=5.0)
+                c.sendall(token + struct.pack("<i", int(rank)))
                 ident = b""
                 while len(ident) < 128:
                     part = c.recv(128 - len(ident))

@@ -50,21 +50,41 @@ def test_product_does_not_import_oracle():
                 assert "/root/reference" not in text, f
 
 
-def test_single_hip_runtime_with_torch():
-    """Loading the library BEFORE torch must not leave two HIP/HSA runtimes in the process (torch would then
-    see no GPU): the loader shares torch's bundled runtime when torch is installed."""
+def _runtime_probe(env_mode, torch_first):
     import subprocess
     import sys
-    pytest.importorskip("torch")
     code = (
-        "import sys; sys.path.insert(0, %r)\n"
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "%s"
         "from revrand_amd import _hip\n"
         "_hip.load_library()\n"
-        "import torch\n"
+        "first = _hip.hip_runtime_path()\n"
+        "%s"
         "maps = open('/proc/self/maps').read().splitlines()\n"
         "for key in ('libamdhip64', 'libhsa-runtime64'):\n"
         "    paths = sorted({l.split()[-1] for l in maps if key in l})\n"
         "    assert len(paths) == 1, paths\n"
-        "print('ok')\n" % ROOT)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+        "print('RUNTIME', first, _hip.rccl_library_path())\n"
+        % (ROOT, "import torch\n" if torch_first else "", "" if torch_first or env_mode != "torch" else "import torch\n"))
+    env = dict(os.environ)
+    env.pop("RR_HIP_RUNTIME", None)
+    env.pop("RR_RCCL_LIB", None)
+    if env_mode:
+        env["RR_HIP_RUNTIME"] = env_mode
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RUNTIME" in r.stdout, r.stderr[-2000:]
+    _, runtime, rccl = r.stdout.strip().splitlines()[-1].split()
+    return runtime, rccl
+
+
+def test_hip_runtime_selection():
+    """by default the library runs on the HIP runtime it was built against (/opt/rocm), whether or
+    not a torch wheel is installed, and RCCL is then the system's; torch's bundled runtime (and its RCCL) only when torch
+    is already in the process or RR_HIP_RUNTIME=torch asks for it -- one runtime per process in every case."""
+    runtime, rccl = _runtime_probe(None, False)
+    assert os.path.realpath(runtime).startswith(os.path.realpath("/opt/rocm")), runtime
+    assert rccl == "None"
+    pytest.importorskip("torch")
+    for mode, torch_first in (("torch", False), (None, True)):
+        runtime, rccl = _runtime_probe(mode, torch_first)
+        assert "/torch/lib/" in runtime and "/torch/lib/" in rccl, (mode, torch_first, runtime, rccl)

@@ -59,6 +59,79 @@ def test_id_rendezvous_file_and_tcp(tmp_path):
         assert got == {0: ident, 1: ident, 2: ident}
 
 
+def test_id_rendezvous_ignores_what_a_dead_job_left_behind(tmp_path):
+    """a stale id file (its writer is gone) must never be handed to a reader; rank 0 replaces it."""
+    import struct
+    import subprocess
+    import sys
+    import threading
+    where = tmp_path / "id"
+    p = subprocess.Popen([sys.executable, "-c", "pass"])
+    p.wait()  # a pid that is certainly dead
+    stale = bytes([7]) * 128
+    where.write_bytes(parallel._ID_MAGIC + struct.pack("<qq", p.pid, 12345) + stale)
+    assert parallel._read_id_file(str(where)) is None
+    where.write_bytes(stale)  # the round-2 format (bare 128 bytes): not accepted either
+    assert parallel._read_id_file(str(where)) is None
+    with pytest.raises(TimeoutError):
+        parallel.exchange_id(1, 2, None, "file:%s" % where, timeout=0.3)
+    ident, got = bytes(range(128)), {}
+
+    def reader():
+        got[1] = parallel.exchange_id(1, 2, None, "file:%s" % where, timeout=30)
+    t = threading.Thread(target=reader)
+    t.start()
+    import time
+    time.sleep(0.2)  # the reader polls the stale file meanwhile
+    got[0] = parallel.exchange_id(0, 2, lambda: ident, "file:%s" % where, timeout=30)
+    t.join(30)
+    assert got == {0: ident, 1: ident}
+    # a symlink planted under the id's name is not followed by readers
+    where.unlink()
+    target = tmp_path / "elsewhere"
+    target.write_bytes(where.read_bytes() if where.exists() else b"x")
+    os.symlink(str(target), str(where))
+    assert parallel._read_id_file(str(where)) is None
+
+
+def test_id_rendezvous_tcp_serves_each_rank_once_and_ignores_strangers():
+    import threading
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    rdzv, ident, got = "tcp:127.0.0.1:%d" % port, bytes(range(128)), {}
+
+    def run(r):
+        got[r] = parallel.exchange_id(r, 3, lambda: ident, rdzv, timeout=60)
+    t0 = threading.Thread(target=run, args=(0,))
+    t0.start()
+    time.sleep(0.3)
+    for junk in (b"", b"GET / HTTP/1.0\r\n\r\n", b"RRCCLREQ" + bytes(8)):  # a port scanner, a wrong world size
+        c = socket.create_connection(("127.0.0.1", port), timeout=5)
+        c.sendall(junk)
+        c.close()
+    ts = [threading.Thread(target=run, args=(r,)) for r in (1, 2)]
+    for t in ts:
+        t.start()
+    for t in ts + [t0]:
+        t.join(60)
+    assert got == {0: ident, 1: ident, 2: ident}
+
+
+def test_default_rendezvous_is_private_and_goes_tcp_across_nodes(monkeypatch):
+    monkeypatch.delenv("RR_COMM_RDZV", raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    r = parallel.default_rendezvous()
+    assert r.startswith("file:") and os.stat(os.path.dirname(r[5:])).st_mode & 0o077 == 0
+    monkeypatch.setenv("WORLD_SIZE", "16")
+    monkeypatch.setenv("MASTER_ADDR", "node0")
+    monkeypatch.setenv("MASTER_PORT", "29500")
+    assert parallel.default_rendezvous() == "tcp:node0:29501"
+
+
 def test_get_comm_never_imports_torch():
     import subprocess
     import sys

@@ -249,3 +249,65 @@ def test_bench_under_torch_distributed_run_uses_rccl_directly():
     assert len(lines) == 1, r.stdout[-1500:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["exchange"]["ranks_rccl_reports"] == 1 and out["config"]["trace_rel_err"] < 1e-6
+
+
+def _bench(argv, env=None, timeout=1800):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                       timeout=timeout, env=env)
+    return r
+
+
+def _keys(o, prefix=""):
+    out = set()
+    if isinstance(o, dict):
+        for k, v in o.items():
+            out.add(prefix + k)
+            out |= _keys(v, prefix + k + ".")
+    return out
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
+    """`python bench.py --gpus 4` / `--gpus 8` exactly as the driver issues it, oversubscribed on this
+    box's one GPU (rank r -> device r % visible GPUs, 8-way file rendezvous, one RCCL all-reduce per step)."""
+    r = _bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", "800000"])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    F = 4096
+    assert out["n_gpus"] == world == out["exchange"]["ranks_rccl_reports"]
+    assert out["config"]["trace_rel_err"] < 1e-6
+    assert out["exchange"]["message_bytes"] == 8 * (F * (F + 1) // 2 + F + 2)
+    assert out["config"]["rows_per_gpu"] == 800000 // world and out["scaling"] == "strong" and out["value"] > 0
+    pr = out["per_rank"]
+    kmax, kmin = pr["kernel_ms_per_step_max_min_over_ranks"]
+    assert kmax >= kmin > 0 and pr["kernel_ms_per_step_sum_over_ranks"] >= kmax
+    assert pr["expected_speedup_model"]["speedup_vs_one_gpu"] > 0
+    assert out["exchange"]["ms_per_step_pack_allreduce_unpack"] > 0
+    rt = out["config"]["runtime"]
+    assert rt["hip_runtime"] and rt["rccl"]["library"] == out["exchange"]["rccl"]["library"] and rt["rccl"]["version"] >= 20000
+
+
+def test_bench_launcher_timeout_ends_all_ranks_and_says_which():
+    import time
+    t0 = time.time()
+    r = _bench(["--gpus", "2", "--steps", "1", "--warmup", "0", "--rows", "600000", "--launch-timeout", "0.5"], timeout=300)
+    assert r.returncode == 124 and time.time() - t0 < 120, (r.returncode, r.stderr[-2000:])
+    assert "still running after --launch-timeout" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_one_gpu_line_has_the_same_keys_under_a_launcher_environment():
+    """SCALE's N = 1 point (launcher environment, WORLD_SIZE = 1) must be the BENCH line: same keys, no exchange."""
+    argv = ["--gpus", "1", "--steps", "1", "--warmup", "1", "--rows", "500000", "--no-cpu-baseline", "--configs", "none",
+            "--no-alt-engine"]
+    plain = _bench(argv)
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", LOCAL_WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29544")
+    launched = _bench(argv, env=env)
+    for r in (plain, launched):
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    a, b = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]) for r in (plain, launched))
+    assert _keys(a) == _keys(b) and "exchange" not in a and a["n_gpus"] == b["n_gpus"] == 1
+    assert a["config"]["runtime"]["hip_runtime"] == b["config"]["runtime"]["hip_runtime"]
+    assert a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"]
