@@ -23,6 +23,7 @@ Rank 0 prints ONE JSON line with the contract's keys plus
                   headline shape in f64 arithmetic, each with its own roofline fraction and a bounded cpu sample.
 """
 import argparse
+import faulthandler
 import json
 import os
 import subprocess
@@ -301,6 +302,63 @@ def config_f64(dev, _hip, args):
                          "achieved": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12,
                          "frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                          "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+
+
+def config_laplace(dev, _hip, args):
+    """RandomLaplace (Cauchy frequencies, |W| up to ~1e5: phases of ~1e5 revolutions) at config 2's shape, in its default
+    arithmetic: the f32 pipeline behind float64 phases (RR_F32P64) -- X resident in float64, projection on the f64 matrix
+    cores, phase reduced in float64, float32 sin / cos, then the same f32 MFMA Gram as RandomRBF."""
+    import revrand_amd.basis_functions as bs
+    d, n, N = 32, 2048, 1_000_000
+    F = 2 * n
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    X, y = gen_chunk(79, N, d, wvec)
+    X64 = X.astype(np.float64) * (1.0 + 2.0 ** -30)  # not float32-representable, like real float64 data
+    y64 = y.astype(np.float64)
+    lap = bs.RandomLaplace(nbases=n, Xdim=d, random_state=42)
+    assert lap.dtype == "f32" and lap.phase64
+    basis = lap._handle()
+    dX, dy = basis.upload(X64), dev.upload_vector(y64)
+    acc = dev.zeros((F * F + F + 1) * 8)
+    p = [_hip.ctypes.c_void_p(acc.ptr.value + o * 8) for o in (0, F * F, F * F + F)]
+    kms = []
+
+    def step():
+        dev.memset(acc)
+        basis.gram_dev(dX, dy, 1.0, *p)
+        kms.append(basis.gram_timings())
+        basis.symmetrize_dev(p[0])
+    step()
+    kms.clear()
+    ms = _timed(dev, step, 3)
+    syrk = float(np.mean([k[1] + k[2] for k in kms]))
+    feat = float(np.mean([k[0] for k in kms]))
+    G = dev.download(acc, (F, F), np.float64)
+    trace_err = abs(float(np.trace(G)) - N) / N
+    del G
+    orc = _oracle()
+    ns = 4096
+    dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value), (ns, d), dX.ld, np.float64)
+    dev.memset(acc)
+    basis.gram_dev(dXs, _hip.DeviceView(dy, 0, ns), 1.0, *p)
+    basis.symmetrize_dev(p[0])
+    dXs.ptr = None
+    Gs = dev.download(acc, (F, F), np.float64)
+    Gr, _, _ = orc.rff_gram_chunked(X64[:ns], y64[:ns], lap.W, 1.0)
+    perr = float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
+    assert perr < 1e-4, perr
+    for b in (dX, dy, acc):
+        b.free()
+    return {"workload": "RandomLaplace nbases=2048 (F=4096, Cauchy W, max|W| = %.3g), D=32, N=1M float64 X resident: float64 "
+                        "phases on the f64 MFMA + f32 features + f32 MFMA Gram" % float(np.abs(lap.W).max()), "rows": N,
+            "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32 (float64 phases)",
+            "trace_rel_err": trace_err, "parity_rel_err_4096_rows_vs_oracle": perr,
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "whole_path_achieved": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12,
+                         "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
+                         "features_kernel": "rr_rff_features_mfma64_kernel<32, 4, true, double, float>",
+                         "features_write_TBps": 4.0 * F * N / (feat * 1e-3) / 1e12}}
 
 
 def config_c3(dev, _hip, args):
@@ -684,22 +742,33 @@ def config_predict(dev, _hip, args, N=300_000):
 def extra_configs(dev, _hip, args):
     res = {}
     for name, fn in (("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
-                     ("C2_elbo_eval", config_elbo),
+                     ("C2laplace_f64phase_n1m", config_laplace), ("C2_elbo_eval", config_elbo),
                      ("C2f64_elbo_eval_n200k", lambda d_, h_, a_: config_elbo(d_, h_, a_, dtype="f64", N=200_000)),
                      ("posterior_F4096", lambda d_, h_, a_: config_posterior(d_, h_, a_, 4096)),
                      ("posterior_F8257", lambda d_, h_, a_: config_posterior(d_, h_, a_, 8257)),
                      ("predict_moments_n300k", config_predict),
                      ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
                      ("C5_glm_poisson_svi_step", config_c5)):
-        if args.configs != "all" and name.split("_")[0].lower() not in args.configs.lower().split(","):
+        want = args.configs.lower().split(",")
+        if args.configs != "all" and name.split("_")[0].lower() not in want and name.lower() not in want:
             continue
         t0 = time.perf_counter()
+        sys.stderr.write("bench.py: config %s ...\n" % name)
+        sys.stderr.flush()
+        # a configuration that hangs says where: every thread's stack goes to stderr after --config-timeout seconds, and the
+        # process then exits non-zero (a hung HIP call cannot be interrupted from Python; the headline line is lost, but
+        # the log names the culprit instead of the driver's clock running out silently)
+        faulthandler.dump_traceback_later(args.config_timeout, exit=True)
         try:
             res[name] = fn(dev, _hip, args)
             res[name]["bench_seconds"] = time.perf_counter() - t0
         except Exception as e:  # a failing side configuration must not take the headline line with it -- but it is said
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             sys.stderr.write("bench.py: config %s failed: %r\n" % (name, e))
+        finally:
+            faulthandler.cancel_dump_traceback_later()
+        sys.stderr.write("bench.py: config %s done in %.1f s\n" % (name, time.perf_counter() - t0))
+        sys.stderr.flush()
     return res
 
 
@@ -720,6 +789,8 @@ def main():
                     help="skip the 2048-row oracle check before timing (profiling runs: keeps per-kernel averages clean)")
     ap.add_argument("--launch-timeout", type=float, default=float(os.environ.get("RR_BENCH_LAUNCH_TIMEOUT", "3000")),
                     help="seconds after which the self-launcher (--gpus N without a launcher) ends all ranks and fails")
+    ap.add_argument("--config-timeout", type=float, default=900.0,
+                    help="seconds one side configuration may take before every thread's stack is dumped and bench.py exits")
     ap.add_argument("--configs", default="all",
                     help="BASELINE's other configurations to time after the headline at N=1: all | none | e.g. c3,c5,headline")
     args = ap.parse_args()

@@ -51,6 +51,15 @@ typedef enum rr_status {
 } rr_status;
 
 typedef enum rr_dtype { RR_F32 = 0, RR_F64 = 1 } rr_dtype;
+/* A third ARITHMETIC mode of a random Fourier basis (rr_rff_create's `compute` only; never a buffer dtype):
+ * float32 features, Gram, products and outputs exactly as RR_F32, but the phase x . w / l is accumulated in float64 (on
+ * the f64 matrix cores) and reduced modulo one revolution in float64 before the float32 sin / cos.  For heavy-tailed
+ * frequencies -- RandomLaplace draws W from a Cauchy distribution (basis_functions.py:993-995): |x . w| reaches 1e5
+ * revolutions, of which a float32 accumulator keeps ~1e-2 rad -- this holds the 1e-3 tolerance of the f32 path where
+ * RR_F32 is 6e-2 off, and everything behind the feature kernel (SYRK, second pass, feature matrix, GLM step) is the
+ * f32 pipeline.  Pass X in float64 (device X resident in float64): rounding x to float32 alone would move such a phase
+ * by |x . w| 2^-24 revolutions.  transform / grad of such a basis run the RR_F64 kernels.  Xdim <= 128. */
+#define RR_F32P64 2
 
 /* ---- library / context ------------------------------------------------- */
 
@@ -92,7 +101,7 @@ int rr_timer_stop(rr_ctx *ctx, float *ms);
  * stays host-side NumPy.
  *
  * W: host, row-major (d, n) float64 -- the `self.W` of _RandomKernelBasis
- * (basis_functions.py:830-834).  compute: RR_F32 or RR_F64 arithmetic. */
+ * (basis_functions.py:830-834).  compute: RR_F32 or RR_F64 arithmetic, or RR_F32P64 (f32 pipeline, f64 phases). */
 int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_basis **out);
 void rr_basis_destroy(rr_basis *basis);
 
@@ -292,6 +301,22 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
                           * the bf16x3 split under this setting */
 int rr_set_gram_engine(rr_ctx *ctx, int engine);
 int rr_get_gram_engine(rr_ctx *ctx);
+
+/* ---- run-to-run reproducibility (opt-in) -----------------------------------------------------
+ * The reference's `Phi.T.dot(Phi)` (slm.py:146) gives the same bits every run.  By default the kernels here sum their
+ * workgroups' partial results into float64 accumulators with floating-point atomics, whose order -- and so the last
+ * bits of G, b, the ELBO and its gradients -- changes from run to run.  With rr_set_deterministic(ctx, 1) (or
+ * RR_DETERMINISTIC=1 in the environment of a new context) every such sum is made in a fixed order instead: workgroups
+ * store their partials (per K-split tiles of the SYRK kernels, per row-block vectors of Phi^T y / y^T y / sqErr / the
+ * hyper-gradient contraction, per row traces of the posterior), and a second kernel adds them in ascending order.
+ * Covered: rr_rff_gram[_dev], rr_dense_gram, rr_featmat_gram (f32 MFMA and f64 engines), rr_posterior_dev, the second
+ * pass (rr_rff_elbo_pass2_dev[c], rr_featmat_pass2_*), rr_rff_grad_contract -- i.e. `basis.gram` and a whole
+ * StandardLinearModel._elbo; two ranks holding the same reduced statistics then compute bit-identical objectives and
+ * gradients.  Not covered (still atomics): the split 16-bit Gram engines (refused in this mode), the GLM minibatch
+ * step, Xdim > 128.  Cost: scratch for the partials (nsplits x Fp^2 x 4 bytes for the f32 SYRK: 4.3 GB at F = 4096,
+ * 2M rows per chunk) and < 2 % time. */
+int rr_set_deterministic(rr_ctx *ctx, int on);
+int rr_get_deterministic(rr_ctx *ctx);
 
 /* ---- posterior of the standard linear model on the device -------------------
  * iC = diag(iL) + G / var,  C = iC^-1 by Cholesky (solve_posdef(iC, I), mathfun/linalg.py:84-125, as called at

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librevrand_hip.so")
 
 RR_F32, RR_F64 = 0, 1
+RR_F32P64 = 2  # rr_rff_create's compute only: f32 pipeline, float64 phases (include/revrand_hip.h)
 _NP2RR = {np.dtype(np.float32): RR_F32, np.dtype(np.float64): RR_F64}
 _RR2NP = {RR_F32: np.float32, RR_F64: np.float64}
 
@@ -121,6 +122,8 @@ SIGNATURES = {
     "rr_posterior_available": (ctypes.c_int, []),
     "rr_set_gram_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rr_get_gram_engine": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_set_deterministic": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
+    "rr_get_deterministic": (ctypes.c_int, [ctypes.c_void_p]),
     "rr_posterior_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                         ctypes.c_void_p]),
@@ -431,6 +434,25 @@ class Device(object):
         _check(self.lib, self.lib.rr_set_gram_engine(self.ctx, self.GRAM_ENGINES[name]))
         return prev
 
+    def close(self):
+        """Destroy the context (stream, events, scratch).  Buffers allocated through it must have been freed."""
+        ctx, self.ctx = self.ctx, None
+        if ctx is not None and self.pid == os.getpid():
+            self.lib.rr_ctx_destroy(ctx)
+
+    # -- run-to-run reproducibility (include/revrand_hip.h: rr_set_deterministic) ------------
+    @property
+    def deterministic(self):
+        return bool(self.lib.rr_get_deterministic(self.ctx))
+
+    def set_deterministic(self, on=True):
+        """Ordered partial sums instead of floating-point atomics in the Gram, posterior and second-pass kernels: the same
+        bits every run (and on every rank holding the same statistics).  Also RR_DETERMINISTIC=1.  Returns the previous
+        setting."""
+        prev = self.deterministic
+        _check(self.lib, self.lib.rr_set_deterministic(self.ctx, 1 if on else 0))
+        return prev
+
     # -- memory ---------------------------------------------------------------
     def malloc(self, nbytes):
         p = ctypes.c_void_p()
@@ -490,10 +512,10 @@ class Device(object):
         _check(self.lib, self.lib.rr_ctx_sync(self.ctx))
 
     def gather_rows(self, src, didx, rows, dst):
-        """dst[r] = src[didx[r]] for two float32 DeviceMatrix objects of the same leading dimension (async)."""
-        if src.ld != dst.ld or src.dtype != np.float32 or dst.dtype != np.float32:
-            raise ValueError("gather_rows: float32 matrices with equal leading dimensions expected")
-        _check(self.lib, self.lib.rr_gather_rows(self.ctx, src.ptr, _ptr(didx), rows, src.ld, dst.ptr))
+        """dst[r] = src[didx[r]] for two DeviceMatrix objects of the same dtype and leading dimension (async)."""
+        if src.ld != dst.ld or src.dtype != dst.dtype or src.dtype.itemsize not in (4, 8):
+            raise ValueError("gather_rows: float32 / float64 matrices of one dtype with equal leading dimensions expected")
+        _check(self.lib, self.lib.rr_gather_rows(self.ctx, src.ptr, _ptr(didx), rows, src.ld * (src.dtype.itemsize // 4), dst.ptr))
 
     def posterior(self, F, dG, db, iL, var, dC):
         """rr_posterior_dev: (m, diagC, log|iC|, sum(G o C)) with C left in the device buffer dC, or None when the
@@ -535,6 +557,20 @@ def get_device(index=None):
     if dev is None:
         dev = Device(index)
         _devices[key] = dev
+    return dev
+
+
+_upload_devices = {}
+
+
+def get_upload_device(index=None):
+    """A SECOND process-local context (own stream) on GPU `index`, for host threads that copy data up while the main
+    context's stream runs kernels (the GLM's draw uploads).  Created once per process and device, like `get_device`."""
+    index = default_device_index() if index is None else int(index)
+    key = (os.getpid(), index)
+    dev = _upload_devices.get(key)
+    if dev is None:
+        dev = _upload_devices[key] = Device(index)
     return dev
 
 
@@ -881,9 +917,14 @@ class RffHandle(object):
         self.lib = self.dev.lib
         W = np.ascontiguousarray(W, dtype=np.float64)
         self.d, self.n = W.shape
-        self.compute = {"f32": RR_F32, "f64": RR_F64}[compute]
+        # "f32p64" (RR_F32P64): the f32 pipeline with the phases accumulated and reduced in float64 -- heavy-tailed W
+        code = {"f32": RR_F32, "f64": RR_F64, "f32p64": RR_F32P64}[compute]
+        self.phase64 = code == RR_F32P64
+        self.compute = RR_F32 if self.phase64 else code  # arithmetic of every product behind the feature kernel
+        # what a resident X (and the y next to it) is kept in: float64 unless the whole pipeline is float32
+        self.x_dtype = np.dtype(np.float32 if code == RR_F32 else np.float64)
         h = ctypes.c_void_p()
-        _check(self.lib, self.lib.rr_rff_create(self.dev.ctx, self.compute, self.d, self.n,
+        _check(self.lib, self.lib.rr_rff_create(self.dev.ctx, code, self.d, self.n,
                                                 W.ctypes.data_as(ctypes.c_void_p), ctypes.byref(h)))
         self.h = h
         self.padded_dim = self.lib.rr_rff_padded_dim(h)

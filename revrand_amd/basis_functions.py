@@ -315,7 +315,8 @@ class DeviceFitState(_DevicePosterior):
 
     def __init__(self, handle, W, X, y, dtype="f32"):
         self.handle, self.W = handle, np.asarray(W, dtype=np.float64)
-        ft = np.float32 if dtype == "f32" else np.float64  # f64 bases keep X, y and every product in float64
+        # f64 bases keep X, y and every product in float64; float64-phase f32 bases (RandomLaplace) keep X and y in float64
+        ft = handle.x_dtype
         self.dX = handle.upload(np.ascontiguousarray(X, dtype=ft))
         self.dy = handle.dev.upload_vector(np.ascontiguousarray(y, dtype=ft))
         self._stats_init(handle.dev, 2 * handle.n)
@@ -402,7 +403,7 @@ class _ResidentRFF(object):
         self.basis = basis
         self.h, W = basis._dense_handle()
         self.W = np.asarray(W, dtype=np.float64)
-        self.dX = self.h.upload(np.ascontiguousarray(X, dtype=np.float32))
+        self.dX = self.h.upload(np.ascontiguousarray(X, dtype=self.h.x_dtype))
         self.dT = self.h.dev.zeros(self.W.size * 8)
 
     def put(self, fm, X, r0, rows, col0, params):
@@ -446,7 +447,7 @@ def _gather_batch(dX, dXb, didx, M):
     if dXb is None or dXb.shape[0] < M:
         if dXb is not None:
             dXb.free()
-        dXb = dev.empty_matrix(M, dX.shape[1], np.float32, ld_dev=dX.ld)
+        dXb = dev.empty_matrix(M, dX.shape[1], dX.dtype, ld_dev=dX.ld)
     dev.gather_rows(dX, didx, M, dXb)
     return dXb
 
@@ -498,13 +499,17 @@ class MinibatchFeatures(object):
     def stage_targets(self, y, rowarg):
         """Upload the step's targets (and per-row likelihood argument) BEFORE its features are launched: the copies
         synchronise the stream, and behind the feature kernels they would make the host wait for them."""
-        self._targets = (self._stage("y", y, np.float32), None if rowarg is None else self._stage("rowarg", rowarg, np.float32))
+        self._targets = None
+        staged = (self._stage("y", y, np.float32), None if rowarg is None else self._stage("rowarg", rowarg, np.float32))
+        self._targets = (id(y), len(y), rowarg is None) + staged
 
     def _take_targets(self, y, rowarg):
+        """The targets staged for THIS step's y (same array, same length, same kind of row argument); anything else --
+        targets left behind by a step that failed between staging and its kernels -- is uploaded afresh."""
         t, self._targets = self._targets, None
-        if t is None:
-            t = (self._stage("y", y, np.float32), None if rowarg is None else self._stage("rowarg", rowarg, np.float32))
-        return t
+        if t is not None and t[:3] == (id(y), len(y), rowarg is None):
+            return t[3], t[4]
+        return self._stage("y", y, np.float32), None if rowarg is None else self._stage("rowarg", rowarg, np.float32)
 
     def _ensure(self, rows, F):
         if self.fm is None or self.fm.max_rows < rows or self.fm.F != F:
@@ -552,6 +557,7 @@ class MinibatchFeatures(object):
         self.M = M  # (no synchronisation: the gathers and feature kernels run while the host prepares the step)
 
     def assemble(self, X, hypers):
+        self._targets = None  # this route never stages ahead
         self._drop_children()
         M = X.shape[0]
         dims = [int(b.get_dim(X)) for b in self.bases]
@@ -705,16 +711,23 @@ class _RandomKernelBasis(_LengthScaleBasis):
     """Phi = [cos(X W/l), sin(X W/l)]/sqrt(nbases); subclasses only sample W."""
 
     _default_dtype = "f32"
+    _heavy_tailed = False  # W drawn from a distribution without a variance (RandomLaplace): "f32" means "f32p64"
 
     @slice_init
     def __init__(self, nbases, Xdim, lenscale=Parameter(gamma(1.), Positive()), regularizer=None,
                  random_state=None, dtype=None):
         dtype = self._default_dtype if dtype is None else dtype
-        if dtype not in ("f32", "f64"):
-            raise ValueError("dtype must be 'f32' or 'f64'")
+        if dtype not in ("f32", "f64", "f32p64"):
+            raise ValueError("dtype must be 'f32', 'f64' or 'f32p64'")
         self.d = Xdim
         self.n = nbases
-        self.dtype = dtype
+        # "f32p64": the f32 pipeline (features, Gram, second pass, feature matrix, GLM step all float32) with the phase
+        # x . w / l accumulated and reduced in float64 (RR_F32P64).  `dtype` stays "f32" -- every f32 route takes the basis.
+        self.phase64 = dtype == "f32p64" or (dtype == "f32" and self._heavy_tailed and Xdim <= 128)
+        if self.phase64 and Xdim > 128:
+            raise ValueError("dtype 'f32p64' needs Xdim <= 128 (use 'f64')")
+        dtype = "f64" if (dtype == "f32" and self._heavy_tailed and not self.phase64) else dtype
+        self.dtype = "f32" if dtype == "f32p64" else dtype
         self.random_state = random_state  # for repr
         self._random = check_random_state(random_state)
         self.W = self._weightsamples()
@@ -725,7 +738,8 @@ class _RandomKernelBasis(_LengthScaleBasis):
     def _handle(self):
         h = self.__dict__.get("_hip_handle")
         if h is None or h[0] != _hip.os.getpid():
-            h = (_hip.os.getpid(), _hip.RffHandle(self.W, compute=self.dtype))
+            compute = "f32p64" if getattr(self, "phase64", False) else self.dtype
+            h = (_hip.os.getpid(), _hip.RffHandle(self.W, compute=compute))
             self.__dict__["_hip_handle"] = h
         return h[1]
 
@@ -764,7 +778,7 @@ class _RandomKernelBasis(_LengthScaleBasis):
     def _put_features(self, X, fm, col0, lenscale=None):
         lenscale = self._check_dim(X.shape[1], lenscale)
         h = self._handle()
-        dX = h.upload(np.ascontiguousarray(X, dtype=np.float32))
+        dX = h.upload(np.ascontiguousarray(X, dtype=h.x_dtype))
         fm.put_rff(h, dX, lenscale, col0)
         fm.dev.sync()
         dX.free()
@@ -820,10 +834,13 @@ class RandomLaplace(_RandomKernelBasis):
     """Laplace kernel features: W ~ Cauchy (basis_functions.py:957-995).
 
     Cauchy draws reach |W| ~ 1e5 at nbases = 2048, i.e. phases of ~1e5 revolutions, which an f32
-    accumulator resolves to only ~1e-2 rad: this class therefore defaults to ``dtype="f64"``
-    (measured: 6e-2 normwise error in f32 vs 1e-11 in f64 at d=32, nbases=2048).
+    accumulator resolves to only ~1e-2 rad (measured: 6e-2 normwise error of Phi at d=32, nbases=2048).  For this
+    class ``dtype="f32"`` (the default) therefore selects the float64-PHASE variant of the f32 pipeline (``"f32p64"``,
+    RR_F32P64: x . w / l accumulated on the f64 matrix cores and reduced modulo one revolution in float64, then float32
+    sin / cos): 2e-7 normwise error of Phi, and the basis takes every resident f32 route (fused Gram, concatenated fit
+    states, GLM step).  Resident X is kept in float64 for it.  ``dtype="f64"`` is the reference's arithmetic end to end.
     """
-    _default_dtype = "f64"
+    _heavy_tailed = True
 
     def _weightsamples(self):
         return self._random.standard_cauchy(size=(self.d, self.n))

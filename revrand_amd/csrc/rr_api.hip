@@ -151,6 +151,7 @@ int rr_ctx_create(int device, rr_ctx **out) {
         delete c;
         return RR_ERR_HIP;
     }
+    if (const char *det = getenv("RR_DETERMINISTIC")) c->deterministic = (atoi(det) != 0) ? 1 : 0;
     if (const char *eng = getenv("RR_SYRK_ENGINE")) c->gram_engine = !strcmp(eng, "bf16x3") ? 3 : !strcmp(eng, "bf16x4") ? 4 : !strcmp(eng, "fp16x3") ? 5 : 0;
     *out = c;
     return RR_OK;
@@ -166,14 +167,27 @@ int rr_set_gram_engine(rr_ctx *ctx, int engine) {
 
 int rr_get_gram_engine(rr_ctx *ctx) { return ctx ? ctx->gram_engine : -1; }
 
+int rr_set_deterministic(rr_ctx *ctx, int on) {
+    RR_REQUIRE(ctx != nullptr, "rr_set_deterministic: null context");
+    ctx->deterministic = on ? 1 : 0;
+    return RR_OK;
+}
+
+int rr_get_deterministic(rr_ctx *ctx) { return ctx ? ctx->deterministic : -1; }
+
 void rr_ctx_destroy(rr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
     if (ctx->tile_map) (void)hipFree(ctx->tile_map);
+    if (ctx->det) (void)hipFree(ctx->det);
     if (ctx->pb) (void)hipFree(ctx->pb);
     if (ctx->gsa) (void)hipFree(ctx->gsa);
     if (ctx->gsb) (void)hipFree(ctx->gsb);
@@ -182,6 +196,7 @@ void rr_ctx_destroy(rr_ctx *ctx) {
         if (ctx->pin[i]) (void)hipHostFree(ctx->pin[i]);
         if (ctx->pin_ev[i]) (void)hipEventDestroy(ctx->pin_ev[i]);
     }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -279,12 +294,17 @@ int rr_rff_create(rr_ctx *ctx, int compute, int d, int n, const double *W, rr_ba
     RR_REQUIRE(ctx != nullptr && out != nullptr && W != nullptr, "rr_rff_create: null argument");
     *out = nullptr;
     RR_REQUIRE(d >= 1 && n >= 1, "rr_rff_create: need d >= 1 and n >= 1 (got d=%d n=%d)", d, n);
-    RR_REQUIRE(compute == RR_F32 || compute == RR_F64, "rr_rff_create: bad compute dtype %d", compute);
+    RR_REQUIRE(compute == RR_F32 || compute == RR_F64 || compute == RR_F32P64, "rr_rff_create: bad compute dtype %d", compute);
+    if (compute == RR_F32P64 && d > 128) {
+        rr_set_error("rr_rff_create: RR_F32P64 (float64 phases) needs Xdim <= 128, got %d: use RR_F64", d);
+        return RR_ERR_UNSUPPORTED;
+    }
     RR_CHECK_HIP(hipSetDevice(ctx->device));
     rr_basis *b = new rr_basis();
     b->ctx = ctx;
     b->kind = RR_KIND_RFF;
-    b->compute = compute;
+    b->compute = compute == RR_F32P64 ? RR_F32 : compute;
+    b->phase64 = compute == RR_F32P64;
     b->d = d;
     b->n = n;
     b->npad = ((n + 127) / 128) * 128;
@@ -346,6 +366,42 @@ void rr_basis_destroy(rr_basis *b) {
 const char *rr_rff_gram_kernel_name(rr_basis *basis) { return basis ? basis->gram_kernel : ""; }
 
 }  // extern "C"
+
+// ---- deterministic mode: scratch of the ordered sums and their reduction (rr_internal.h) ----------------------
+int rr_det_scratch(rr_ctx *c, size_t bytes, void **out) {
+    if (c->det_bytes < bytes) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));  // an earlier reduction may still read the old scratch
+        if (c->det) (void)hipFree(c->det);
+        c->det = nullptr;
+        c->det_bytes = 0;
+        hipError_t e = hipMalloc(&c->det, bytes);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            rr_set_error("deterministic mode: could not allocate %zu bytes for the ordered partial sums", bytes);
+            return RR_ERR_OOM;
+        }
+        c->det_bytes = bytes;
+    }
+    *out = c->det;
+    return RR_OK;
+}
+
+__global__ void __launch_bounds__(256)
+rr_det_reduce_kernel(const double *__restrict__ part, int64_t nslots, int64_t stride, int64_t count, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int64_t k = 0; k < nslots; ++k) s += part[k * stride + i];
+    out[i] += s;
+}
+
+int rr_det_reduce(rr_ctx *c, const double *part, int64_t nslots, int64_t stride, int64_t count, double *out) {
+    if (count <= 0) return RR_OK;
+    hipLaunchKernelGGL(rr_det_reduce_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, c->stream, part, nslots, stride,
+                       count, out);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
 
 // Scale W by 1/(l_i * 2pi) in f64 on the host (d*n elements: tiny) and upload.  The kernels
 // then obtain the phase directly in revolutions, which is what v_sin_f32/v_cos_f32 consume.

@@ -212,7 +212,7 @@ rr_rowdot_kernel(const float *__restrict__ U, const float *__restrict__ P, int64
 template <typename TX>
 __global__ void __launch_bounds__(256)
 rr_err_kernel(const TX *__restrict__ y, const float *__restrict__ dot, int64_t N, float *__restrict__ err,
-              double *__restrict__ sq) {
+              double *__restrict__ sq, int64_t det = 0) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     float e = 0.f;
     if (r < N) {
@@ -225,7 +225,7 @@ rr_err_kernel(const TX *__restrict__ y, const float *__restrict__ dot, int64_t N
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(sq, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) rr_acc_out(sq, det, blockIdx.x, 0, part[0] + part[1] + part[2] + part[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -236,7 +236,7 @@ template <int DMAX, typename TX>
 __global__ void __launch_bounds__(256)
 rr_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ P,
                  const float *__restrict__ U, int64_t ldp, const float *__restrict__ err,
-                 const float *__restrict__ mvec, int n, int d, double *__restrict__ T, int rows_per_block) {
+                 const float *__restrict__ mvec, int n, int d, double *__restrict__ T, int rows_per_block, int64_t tdet = 0) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     const bool fvalid = f < n;
     const int fc = fvalid ? f : 0;
@@ -258,7 +258,7 @@ rr_grad_t_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *
     if (fvalid) {
 #pragma unroll
         for (int i = 0; i < DMAX; ++i)
-            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+            if (i < d) rr_acc_out(T, tdet, blockIdx.y, (int64_t)i * n + f, (double)t[i]);
     }
 }
 
@@ -272,7 +272,7 @@ template <int DMAX, typename TX, typename TE>
 __global__ void __launch_bounds__(256)
 rr_grad_contract_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ Ws,
                         const TE *__restrict__ E, int64_t lde, int n, int npad, int d, double *__restrict__ T,
-                        float scale, int rows_per_block) {
+                        float scale, int rows_per_block, int64_t tdet = 0) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     const bool fvalid = f < n;
     const int fc = fvalid ? f : 0;
@@ -299,7 +299,7 @@ rr_grad_contract_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const 
     if (fvalid) {
 #pragma unroll
         for (int i = 0; i < DMAX; ++i)
-            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+            if (i < d) rr_acc_out(T, tdet, blockIdx.y, (int64_t)i * n + f, (double)t[i]);
     }
 }
 
@@ -392,9 +392,19 @@ static int launch_grad_t(rr_basis *b, const TX *X, int64_t N, int64_t ldx, const
     if (rpb < 64) rpb = 64;
     if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
     const dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+    // deterministic mode: every row block stores its (d, n) partial into its own slot, added to T in order afterwards
+    const int64_t tcount = (int64_t)b->d * b->n, tdet = c->deterministic ? tcount : 0;
+    double *Tacc = T;
+    if (tdet) {
+        RR_REQUIRE(!b->large, "second pass: deterministic mode does not cover Xdim > 128");
+        void *part = nullptr;
+        int rc = rr_det_scratch(c, (size_t)grid.y * (size_t)tcount * 8, &part);
+        if (rc != RR_OK) return rc;
+        T = (double *)part;
+    }
 #define RR_GT(DM)                                                                                                 \
     hipLaunchKernelGGL((rr_grad_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, X, N, ldx, P, U, ldp, err, m32,   \
-                       b->n, b->d, T, (int)rpb)
+                       b->n, b->d, T, (int)rpb, tdet)
     switch (b->dpad) {
         case 8: RR_GT(8); break;
         case 16: RR_GT(16); break;
@@ -408,7 +418,7 @@ static int launch_grad_t(rr_basis *b, const TX *X, int64_t N, int64_t ldx, const
     }
 #undef RR_GT
     RR_CHECK_HIP(hipGetLastError());
-    return RR_OK;
+    return tdet ? rr_det_reduce(c, T, grid.y, tcount, tcount, Tacc) : RR_OK;
 }
 
 __global__ void rr_transpose_f32_kernel(const float *__restrict__ P, int64_t rows, int64_t ldp, float *__restrict__ Pt,
@@ -513,7 +523,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         // row-major P (epilogues) and feature-major Pt + Phi m (GEMM operand)
         rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp, true);
         if (rc != RR_OK) break;
-        if (b->large) {
+        if (b->large || b->phase64) {  // no feature-major kernel for these: transpose the row-major features
             hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
                                s.P, mrows, Fp, s.Pt, chunk);
             hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.m32, mrows,
@@ -553,8 +563,18 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             for (int64_t i = 0; i < mrows; ++i) out0[r0 + i] = (double)dot[i];
         } else {
             const TX *yc = dy + r0;
-            hipLaunchKernelGGL(rr_err_kernel<TX>, dim3((unsigned)(mpad / 256)), dim3(256), 0, c->stream, yc, s.dot, mrows,
-                               s.err, s.acc);
+            if (c->deterministic) {
+                void *part = nullptr;
+                rc = rr_det_scratch(c, (size_t)(mpad / 256) * 8, &part);
+                if (rc != RR_OK) break;
+                hipLaunchKernelGGL(rr_err_kernel<TX>, dim3((unsigned)(mpad / 256)), dim3(256), 0, c->stream, yc, s.dot, mrows,
+                                   s.err, (double *)part, (int64_t)1);
+                rc = rr_det_reduce(c, (const double *)part, mpad / 256, 1, 1, s.acc);
+                if (rc != RR_OK) break;
+            } else {
+                hipLaunchKernelGGL(rr_err_kernel<TX>, dim3((unsigned)(mpad / 256)), dim3(256), 0, c->stream, yc, s.dot, mrows,
+                                   s.err, s.acc);
+            }
             rc = launch_grad_t<TX>(b, Xc, mrows, ldx, s.P, s.U, Fp, s.err, s.m32, s.acc + 1);
             if (rc == RR_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
                 rr_set_error("pass2: kernel failed: %s", hipGetErrorString(e));
@@ -992,7 +1012,7 @@ rr_rows64_kernel(const double *__restrict__ P, const double *__restrict__ U, con
 template <typename TX>
 __global__ void __launch_bounds__(256)
 rr_err64_kernel(const TX *__restrict__ y, const double *__restrict__ dot, int64_t N, double *__restrict__ err,
-                double *__restrict__ sq) {
+                double *__restrict__ sq, int64_t det = 0) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double e = 0.0;
     if (r < N) {
@@ -1005,14 +1025,14 @@ rr_err64_kernel(const TX *__restrict__ y, const double *__restrict__ dot, int64_
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(sq, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) rr_acc_out(sq, det, blockIdx.x, 0, part[0] + part[1] + part[2] + part[3]);
 }
 
 template <int DMAX, typename TX>
 __global__ void __launch_bounds__(256)
 rr_grad_t64_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const double *__restrict__ P,
                    const double *__restrict__ U, int64_t ldp, const double *__restrict__ err,
-                   const double *__restrict__ mvec, int n, int d, double *__restrict__ T, int rows_per_block) {
+                   const double *__restrict__ mvec, int n, int d, double *__restrict__ T, int rows_per_block, int64_t tdet = 0) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     const bool fvalid = f < n;
     const int fc = fvalid ? f : 0;
@@ -1034,7 +1054,7 @@ rr_grad_t64_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const doubl
     if (fvalid) {
 #pragma unroll
         for (int i = 0; i < DMAX; ++i)
-            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], t[i]);
+            if (i < d) rr_acc_out(T, tdet, blockIdx.y, (int64_t)i * n + f, t[i]);
     }
 }
 
@@ -1138,16 +1158,40 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
         } else {
             hipLaunchKernelGGL(rr_rows64_kernel<0>, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.U, s.m,
                                mrows, F, Fp, s.dot, s.acc);
-            hipLaunchKernelGGL(rr_err64_kernel<TX>, dim3((unsigned)((mrows + 255) / 256)), dim3(256), 0, c->stream, dy + r0,
-                               s.dot, mrows, s.err, s.acc);
+            const int64_t eb = (mrows + 255) / 256;
+            if (c->deterministic) {
+                void *part = nullptr;
+                rc = rr_det_scratch(c, (size_t)eb * 8, &part);
+                if (rc != RR_OK) break;
+                hipLaunchKernelGGL(rr_err64_kernel<TX>, dim3((unsigned)eb), dim3(256), 0, c->stream, dy + r0, s.dot, mrows, s.err,
+                                   (double *)part, (int64_t)1);
+                rc = rr_det_reduce(c, (const double *)part, eb, 1, 1, s.acc);
+                if (rc != RR_OK) break;
+            } else {
+                hipLaunchKernelGGL(rr_err64_kernel<TX>, dim3((unsigned)eb), dim3(256), 0, c->stream, dy + r0, s.dot, mrows, s.err,
+                                   s.acc);
+            }
             const int fblocks = (n + 255) / 256;
             int64_t rpb = (mrows * fblocks + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
             if (rpb < 64) rpb = 64;
             if ((mrows + rpb - 1) / rpb > 65535) rpb = (mrows + 65534) / 65535;
             const dim3 grid(fblocks, (unsigned)((mrows + rpb - 1) / rpb));
+            const int64_t tcount = (int64_t)b->d * n, tdet = c->deterministic ? tcount : 0;
+            double *Tdst = s.acc + 1;
+            if (tdet) {
+                if (b->large) {
+                    rr_set_error("second pass: deterministic mode does not cover Xdim > 128");
+                    rc = RR_ERR_UNSUPPORTED;
+                    break;
+                }
+                void *part = nullptr;
+                rc = rr_det_scratch(c, (size_t)grid.y * (size_t)tcount * 8, &part);
+                if (rc != RR_OK) break;
+                Tdst = (double *)part;
+            }
 #define RR_GT64(DM)                                                                                               \
     hipLaunchKernelGGL((rr_grad_t64_kernel<DM, TX>), grid, dim3(256), 0, c->stream, Xc, mrows, ldx, s.P, s.U, Fp, s.err, \
-                       s.m, n, b->d, s.acc + 1, (int)rpb)
+                       s.m, n, b->d, Tdst, (int)rpb, tdet)
             switch (b->dpad) {
                 case 8: RR_GT64(8); break;
                 case 16: RR_GT64(16); break;
@@ -1162,6 +1206,10 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
             }
 #undef RR_GT64
             RR_CHECK_HIP(hipGetLastError());
+            if (tdet) {
+                rc = rr_det_reduce(c, Tdst, grid.y, tcount, tcount, s.acc + 1);
+                if (rc != RR_OK) break;
+            }
             RR_CHECK_HIP(hipStreamSynchronize(c->stream));
         }
     }
@@ -1179,7 +1227,8 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
 template <int DMAX, typename TX, typename TE>
 __global__ void __launch_bounds__(256)
 rr_grad_contract_p_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, const float *__restrict__ P, int64_t ldp,
-                          const TE *__restrict__ E, int64_t lde, int n, int d, double *__restrict__ T, int rows_per_block) {
+                          const TE *__restrict__ E, int64_t lde, int n, int d, double *__restrict__ T, int rows_per_block,
+                          int64_t tdet = 0) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     const bool fvalid = f < n;
     const int fc = fvalid ? f : 0;
@@ -1198,7 +1247,7 @@ rr_grad_contract_p_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, cons
     if (fvalid) {
 #pragma unroll
         for (int i = 0; i < DMAX; ++i)
-            if (i < d) unsafeAtomicAdd(&T[(size_t)i * n + f], (double)t[i]);
+            if (i < d) rr_acc_out(T, tdet, blockIdx.y, (int64_t)i * n + f, (double)t[i]);
     }
 }
 
@@ -1222,9 +1271,39 @@ static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ld
     if (rpb < 32) rpb = 32;
     if ((N + rpb - 1) / rpb > 65535) rpb = (N + 65534) / 65535;
     const dim3 grid(fblocks, (unsigned)((N + rpb - 1) / rpb));
+    const int64_t tcount = (int64_t)b->d * b->n, tdet = c->deterministic ? tcount : 0;
+    double *Tacc = dT;
+    if (tdet) {
+        RR_REQUIRE(!b->large, "rr_rff_grad_contract: deterministic mode does not cover Xdim > 128");
+        void *part = nullptr;
+        int rc = rr_det_scratch(c, (size_t)grid.y * (size_t)tcount * 8, &part);
+        if (rc != RR_OK) return rc;
+        dT = (double *)part;
+    }
+    if (b->phase64) {  // RR_F32P64: features by the float64-phase kernel first (row-major f32 scratch), then the contraction
+        const int64_t ldp = 2 * (int64_t)b->n;
+        const int64_t Npad = (N + 31) / 32 * 32;
+        int rc = large_scratch(b, (size_t)Npad * ldp * 4);
+        if (rc == RR_OK)
+            rc = rr_features_rowmajor_f32(b, dX, sizeof(TX) == 4 ? RR_F32 : RR_F64, N, N, ldx, (float *)b->zbuf, ldp, false);
+        if (rc != RR_OK) return rc;
+#define RR_GCP(DM)                                                                                                  \
+    hipLaunchKernelGGL((rr_grad_contract_p_kernel<DM, TX, TE>), grid, dim3(256), 0, c->stream, dX, N, ldx,            \
+                       (const float *)b->zbuf, ldp, dE, lde, b->n, b->d, dT, (int)rpb, tdet)
+        switch (b->dpad) {
+            case 8: RR_GCP(8); break;
+            case 16: RR_GCP(16); break;
+            case 32: RR_GCP(32); break;
+            case 64: RR_GCP(64); break;
+            default: RR_GCP(128); break;
+        }
+#undef RR_GCP
+        RR_CHECK_HIP(hipGetLastError());
+        return tdet ? rr_det_reduce(c, dT, grid.y, tcount, tcount, Tacc) : RR_OK;
+    }
 #define RR_GC(DM)                                                                                              \
     hipLaunchKernelGGL((rr_grad_contract_kernel<DM, TX, TE>), grid, dim3(256), 0, c->stream, dX, N, ldx, b->dWs32, \
-                       dE, lde, b->n, b->npad, b->d, dT, scale, (int)rpb)
+                       dE, lde, b->n, b->npad, b->d, dT, scale, (int)rpb, tdet)
     switch (b->dpad) {
         case 8: RR_GC(8); break;
         case 16: RR_GC(16); break;
@@ -1245,7 +1324,7 @@ static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ld
     }
 #undef RR_GC
     RR_CHECK_HIP(hipGetLastError());
-    return RR_OK;
+    return tdet ? rr_det_reduce(c, dT, grid.y, tcount, tcount, Tacc) : RR_OK;
 }
 
 template <typename TY>
@@ -1563,12 +1642,20 @@ int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
     int rc = fm_pass2_products(fm, s);
     if (rc != RR_OK || dy == nullptr) return rc;
     const dim3 grid((unsigned)((fm->rows + 255) / 256));
+    double *sq = s.sq;
+    const int64_t det = c->deterministic ? 1 : 0;
+    if (det) {
+        void *part = nullptr;
+        rc = rr_det_scratch(c, (size_t)grid.x * 8, &part);
+        if (rc != RR_OK) return rc;
+        sq = (double *)part;
+    }
     if (y_dtype == RR_F32)
-        hipLaunchKernelGGL(rr_err_kernel<float>, grid, dim3(256), 0, c->stream, (const float *)dy, s.dot, fm->rows, s.err, s.sq);
+        hipLaunchKernelGGL(rr_err_kernel<float>, grid, dim3(256), 0, c->stream, (const float *)dy, s.dot, fm->rows, s.err, sq, det);
     else
-        hipLaunchKernelGGL(rr_err_kernel<double>, grid, dim3(256), 0, c->stream, (const double *)dy, s.dot, fm->rows, s.err, s.sq);
+        hipLaunchKernelGGL(rr_err_kernel<double>, grid, dim3(256), 0, c->stream, (const double *)dy, s.dot, fm->rows, s.err, sq, det);
     RR_CHECK_HIP(hipGetLastError());
-    return RR_OK;
+    return det ? rr_det_reduce(c, sq, grid.x, 1, 1, s.sq) : RR_OK;
 }
 
 int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {

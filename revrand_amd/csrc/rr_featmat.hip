@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) rr_fm_zero_padcols_kernel(float *P, int64
 template <typename TY>
 __global__ void __launch_bounds__(256) rr_fm_gemv_t_kernel(const float *__restrict__ P, const TY *__restrict__ y,
                                                            int64_t rows, int F, int64_t ldp, double *__restrict__ bvec,
-                                                           int rows_per_block) {
+                                                           int rows_per_block, int64_t bdet = 0) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) rr_fm_gemv_t_kernel(const float *__restri
     if (c >= F) return;
     float acc = 0.f;
     for (int64_t r = r0; r < r1; ++r) acc = fmaf(P[r * ldp + c], (float)y[r], acc);
-    unsafeAtomicAdd(&bvec[c], (double)acc);
+    rr_acc_out(bvec, bdet, blockIdx.y, c, (double)acc);
 }
 
 // P[r][col] = y[r] (y == nullptr: 0) for r < rows
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) rr_fm_set_column_kernel(float *__restrict
 }
 
 template <typename TY>
-__global__ void __launch_bounds__(256) rr_fm_yty_kernel(const TY *__restrict__ y, int64_t N, double *out) {
+__global__ void __launch_bounds__(256) rr_fm_yty_kernel(const TY *__restrict__ y, int64_t N, double *out, int64_t det = 0) {
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
         const double v = (double)y[i];
@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(256) rr_fm_yty_kernel(const TY *__restrict__ y
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) rr_acc_out(out, det, blockIdx.x, 0, part[0] + part[1] + part[2] + part[3]);
 }
 
 // dst[r][:] = src[idx[r]][:] for rows of ld 4-byte elements (minibatch gather from resident data)
@@ -160,6 +160,7 @@ int rr_featmat_begin(rr_featmat *fm, int64_t rows) {
     const int64_t rows256 = (rows + 255) / 256 * 256;
     fm->covered = 0;
     fm->pt_covered = 0;
+    fm->spans.clear();
     if (rows256 > rows)
         RR_CHECK_HIP(hipMemsetAsync(fm->P + rows * fm->ld, 0, (size_t)(rows256 - rows) * fm->ld * sizeof(float), fm->ctx->stream));
     const int64_t w = fm->ld - fm->F;
@@ -170,6 +171,24 @@ int rr_featmat_begin(rr_featmat *fm, int64_t rows) {
     }
     return RR_OK;
 }
+
+}  // extern "C"
+
+// Record that columns [col0, col0 + width) are written; refuses a block that overlaps one put since rr_featmat_begin (a
+// child put twice, or wrong offsets, would otherwise satisfy a width count while another block keeps stale data).
+int rr_fm_claim(rr_featmat *fm, int64_t col0, int64_t width, const char *who) {
+    const int64_t c1 = col0 + width;
+    size_t pos = 0;
+    while (pos < fm->spans.size() && fm->spans[pos].first < col0) ++pos;
+    const bool clash = (pos > 0 && fm->spans[pos - 1].second > col0) || (pos < fm->spans.size() && fm->spans[pos].first < c1);
+    RR_REQUIRE(!clash, "%s: columns [%lld, %lld) overlap a block already written since rr_featmat_begin", who,
+               (long long)col0, (long long)c1);
+    fm->spans.insert(fm->spans.begin() + (std::ptrdiff_t)pos, std::make_pair(col0, c1));
+    fm->covered += width;
+    return RR_OK;
+}
+
+extern "C" {
 
 int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale,
                        int n_ls, int64_t col0) {
@@ -182,7 +201,8 @@ int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype,
     RR_REQUIRE(dX != nullptr, "rr_featmat_put_rff: null X");
     RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
     // the feature kernel writes columns [0, 2n) relative to its base; pad handling is ours (begin())
-    fm->covered += 2 * (int64_t)b->n;
+    rc = rr_fm_claim(fm, col0, 2 * (int64_t)b->n, "rr_featmat_put_rff");
+    if (rc != RR_OK) return rc;
     // the same block of P^T, if a transposing pass has laid out P^T's padding for this row count before
     static const bool no_pt = getenv("RR_FM_NO_DIRECT_PT") != nullptr;
     float *Pt = (fm->pt_rows == fm->rows && !no_pt) ? rr_fm_pass2_pt(fm->pass2) : nullptr;
@@ -202,7 +222,10 @@ int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t l
     RR_REQUIRE(dX != nullptr, "rr_featmat_put_linear: null X");
     RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
     const int64_t cnt = fm->rows * w;
-    fm->covered += w;
+    {
+        const int rcc = rr_fm_claim(fm, col0, w, "rr_featmat_put_linear");
+        if (rcc != RR_OK) return rcc;
+    }
     const dim3 grid((unsigned)((cnt + 255) / 256));
     if (x_dtype == RR_F32)
         hipLaunchKernelGGL(rr_linear_features_kernel<float>, grid, dim3(256), 0, fm->ctx->stream, (const float *)dX,
@@ -257,8 +280,25 @@ int rr_featmat_put_host(rr_featmat *fm, const void *Phi, int dtype, int64_t ncol
         rr_set_error("rr_featmat_put_host: copy failed: %s", hipGetErrorString(e));
         return RR_ERR_HIP;
     }
-    fm->covered += ncols;
-    return RR_OK;
+    return rr_fm_claim(fm, col0, ncols, "rr_featmat_put_host");
+}
+
+// y^T y into *dyty: atomics, or (deterministic mode) per-block partials added in order
+static int fm_yty(rr_ctx *c, const void *dy, int y_dtype, int64_t rows, double *dyty) {
+    int yb = (int)((rows + 255) / 256);
+    if (yb > c->num_cu * 8) yb = c->num_cu * 8;
+    double *dst = dyty;
+    const int64_t det = c->deterministic ? 1 : 0;
+    if (det) {
+        void *part = nullptr;
+        int rc = rr_det_scratch(c, (size_t)yb * 8, &part);
+        if (rc != RR_OK) return rc;
+        dst = (double *)part;
+    }
+    if (y_dtype == RR_F32) hipLaunchKernelGGL(rr_fm_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, rows, dst, det);
+    else hipLaunchKernelGGL(rr_fm_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, rows, dst, det);
+    RR_CHECK_HIP(hipGetLastError());
+    return det ? rr_det_reduce(c, dst, yb, 1, 1, dyty) : RR_OK;
 }
 
 int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty) {
@@ -275,18 +315,15 @@ int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, dou
     static const bool no_rider = getenv("RR_FM_NO_RIDER") != nullptr;
     const bool rider = dy != nullptr && c->gram_engine == 0 && fm->F < fm->ld && !no_rider;
     if (rider) {
-        int yb = (int)((fm->rows + 255) / 256);
-        if (yb > c->num_cu * 8) yb = c->num_cu * 8;
         const unsigned cb = (unsigned)((fm->rows + 255) / 256);
-        if (y_dtype == RR_F32) {
+        if (y_dtype == RR_F32)
             hipLaunchKernelGGL(rr_fm_set_column_kernel<float>, dim3(cb), dim3(256), 0, c->stream, fm->P, fm->ld, fm->F, (const float *)dy, fm->rows);
-            hipLaunchKernelGGL(rr_fm_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, fm->rows, dyty);
-        } else {
+        else
             hipLaunchKernelGGL(rr_fm_set_column_kernel<double>, dim3(cb), dim3(256), 0, c->stream, fm->P, fm->ld, fm->F, (const double *)dy, fm->rows);
-            hipLaunchKernelGGL(rr_fm_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, fm->rows, dyty);
-        }
         RR_CHECK_HIP(hipGetLastError());
-        const int rc = rr_launch_syrk_f32(c, fm->P, fm->rows_pad, fm->ld, fm->F, dG, nullptr, db);
+        int rc = fm_yty(c, dy, y_dtype, fm->rows, dyty);
+        if (rc != RR_OK) return rc;
+        rc = rr_launch_syrk_f32(c, fm->P, fm->rows_pad, fm->ld, fm->F, dG, nullptr, db);
         // the pad column is zero again for every other consumer of P
         hipLaunchKernelGGL(rr_fm_set_column_kernel<float>, dim3(cb), dim3(256), 0, c->stream, fm->P, fm->ld, fm->F, (const float *)nullptr, fm->rows);
         RR_CHECK_HIP(hipGetLastError());
@@ -295,18 +332,24 @@ int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, dou
     if (dy) {
         const int rpb = 512;
         const dim3 gg((unsigned)((fm->F + 255) / 256), (unsigned)((fm->rows + rpb - 1) / rpb));
-        int yb = (int)((fm->rows + 255) / 256);
-        if (yb > c->num_cu * 8) yb = c->num_cu * 8;
-        if (y_dtype == RR_F32) {
-            hipLaunchKernelGGL(rr_fm_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, fm->P, (const float *)dy, fm->rows,
-                               fm->F, fm->ld, db, rpb);
-            hipLaunchKernelGGL(rr_fm_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, fm->rows, dyty);
-        } else {
-            hipLaunchKernelGGL(rr_fm_gemv_t_kernel<double>, gg, dim3(256), 0, c->stream, fm->P, (const double *)dy, fm->rows,
-                               fm->F, fm->ld, db, rpb);
-            hipLaunchKernelGGL(rr_fm_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, fm->rows, dyty);
+        double *bdst = db;
+        const int64_t bdet = c->deterministic ? fm->F : 0;
+        if (bdet) {
+            void *part = nullptr;
+            int rc = rr_det_scratch(c, (size_t)gg.y * (size_t)fm->F * 8, &part);
+            if (rc != RR_OK) return rc;
+            bdst = (double *)part;
         }
+        if (y_dtype == RR_F32)
+            hipLaunchKernelGGL(rr_fm_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, fm->P, (const float *)dy, fm->rows,
+                               fm->F, fm->ld, bdst, rpb, bdet);
+        else
+            hipLaunchKernelGGL(rr_fm_gemv_t_kernel<double>, gg, dim3(256), 0, c->stream, fm->P, (const double *)dy, fm->rows,
+                               fm->F, fm->ld, bdst, rpb, bdet);
         RR_CHECK_HIP(hipGetLastError());
+        int rc = bdet ? rr_det_reduce(c, bdst, gg.y, fm->F, fm->F, db) : RR_OK;
+        if (rc == RR_OK) rc = fm_yty(c, dy, y_dtype, fm->rows, dyty);
+        if (rc != RR_OK) return rc;
     }
     return rr_launch_syrk_f32(c, fm->P, fm->rows_pad, fm->ld, fm->F, dG, nullptr);
 }

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/revrand_hip.h"
@@ -15,12 +16,17 @@
 struct rr_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second stream (created on first use): chunk k+1's feature kernel under chunk k's SYRK
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_fork = nullptr;   // orders stream2 behind the context's stream at the start of an overlapped Gram call
     hipDeviceProp_t prop;
     int num_cu = 0;
     int *tile_map = nullptr;  // XCD-aware tile order of the SYRK kernel for tile_map_nb column blocks
     int tile_map_nb = 0;
     int gram_engine = 0;      // f32 Gram: 0 = f32 MFMA, 3 / 4 = split-bf16 with 3 / 4 products (rr_set_gram_engine)
+    int deterministic = 0;    // rr_set_deterministic: ordered partial sums instead of floating-point atomics
+    void *det = nullptr;      // scratch of the ordered sums (partials of the kernel in flight), grow-only
+    size_t det_bytes = 0;
     void *gsa = nullptr, *gsb = nullptr;  // K-blocked operand copies of the GLM step's GEMMs on the split engines, grow-only
     size_t gsa_bytes = 0, gsb_bytes = 0;
     void *pb = nullptr;       // split-bf16 copy of the feature chunk (rr_syrk_bf16x3_kernel), grow-only
@@ -38,6 +44,7 @@ struct rr_basis {
     rr_ctx *ctx = nullptr;
     int kind = RR_KIND_RFF;
     int compute = RR_F32;
+    bool phase64 = false;         // RR_F32P64: compute == RR_F32 for every product, phases through the f64 MFMA feature kernel
     int d = 0, n = 0;
     int dpad = 0;                 // d rounded up to 8/16/32/64/128 (large: a multiple of 128): rows of Ws, row length kernels read
     int npad = 0;                 // n rounded up to a multiple of 128 (large: 256) (device Ws row length)
@@ -57,7 +64,7 @@ struct rr_basis {
     double *dgfac64 = nullptr;
     void *zbuf = nullptr;         // feature scratch of the Gram path (f32 or f64), grow-only
     size_t zbuf_bytes = 0;
-    std::vector<hipEvent_t> events;  // 4 per row chunk of the last Gram call
+    std::vector<hipEvent_t> events;  // 5 per row chunk of the last Gram call: features begin / end, SYRK begin / mid / end
     size_t events_used = 0;
     const char *gram_kernel = "";
     void *pass2 = nullptr;        // scratch of the second _elbo pass (rr_elbo.hip), grow-only
@@ -70,6 +77,25 @@ struct rr_basis {
 };
 
 void rr_set_error(const char *fmt, ...);
+
+// ---- deterministic mode (rr_set_deterministic) ------------------------------------------------------------
+// Every cross-workgroup sum of the library is "each workgroup (or thread) adds ITS partial to an f64 accumulator with
+// unsafeAtomicAdd" -- the order of those additions changes from run to run, and with it the last bits of the result.
+// In deterministic mode a kernel instead STORES its partial into slot s of a scratch array (s = a function of its
+// block / wave index only) and a second kernel adds the slots of each accumulator element in ascending s -- one thread
+// per element, plain read-modify-write, launches ordered by the stream: the same bits every run.
+//   rr_acc_out(dst, det_stride, slot, idx, v): the kernels' side (det_stride == 0: the atomic path, dst = accumulator;
+//                                              else dst = scratch of nslots * det_stride doubles)
+//   rr_det_scratch / rr_det_reduce:            the launchers' side
+#ifdef __HIPCC__
+__device__ __forceinline__ void rr_acc_out(double *dst, int64_t det_stride, int64_t slot, int64_t idx, double v) {
+    if (det_stride) dst[slot * det_stride + idx] = v;
+    else unsafeAtomicAdd(&dst[idx], v);
+}
+#endif
+int rr_det_scratch(rr_ctx *c, size_t bytes, void **out);
+// out[i] += sum_{s < nslots} part[s * stride + i], i < count, in ascending s (on the context's stream)
+int rr_det_reduce(rr_ctx *c, const double *part, int64_t nslots, int64_t stride, int64_t count, double *out);
 
 // sin(2 pi t), cos(2 pi t) in float64 for a phase t in REVOLUTIONS: the fraction f = t - rint(t) is exact, k = rint(4 f)
 // picks the quarter turn and the remainder |theta| <= pi / 4 goes through the classic minimax kernels (fdlibm's
@@ -174,12 +200,16 @@ struct rr_featmat {
     // there (-1: never); random Fourier children then write their blocks of P^T themselves while they write P
     // (pt_covered columns since begin), and a consumer whose pt_covered == F skips its transposing pass
     int64_t pt_rows = -1, pt_covered = 0;
+    // the column intervals [c0, c1) put since rr_featmat_begin, kept sorted: a put that overlaps an earlier one is refused
+    // (rr_fm_claim), so `covered == F` means every column was written exactly once -- not merely that widths add up
+    std::vector<std::pair<int64_t, int64_t>> spans;
 };
+int rr_fm_claim(rr_featmat *fm, int64_t col0, int64_t width, const char *who);  // rr_featmat.hip
 void rr_fm_pass2_free(void *p);
 float *rr_fm_pass2_pt(void *p);  // FmPass2::Pt or null
 // Consumers of the feature matrix call this first: every column of [0, F) must have been put since rr_featmat_begin.
 #define RR_FM_REQUIRE_FILLED(fm, who)                                                                              \
-    RR_REQUIRE((fm)->rows == 0 || (fm)->covered >= (fm)->F,                                                        \
+    RR_REQUIRE((fm)->rows == 0 || (fm)->covered == (fm)->F,                                                        \
                who ": only %lld of the %d columns were written since rr_featmat_begin", (long long)(fm)->covered, (fm)->F)
 
 // Device -> caller's (pageable) host memory for the host-buffer entry points: chunk k is copied into one half of a

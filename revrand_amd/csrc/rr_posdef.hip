@@ -162,7 +162,8 @@ rr_ul_factor_f32_kernel(const double *__restrict__ W, int64_t F, int64_t Fp, flo
 // one wave per row r:  m[r] = (C[r,:] . b) / var,  tr += C[r,:] . G[r,:],  dg[r] = C[r][r]
 __global__ void __launch_bounds__(256)
 rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict__ G, const double *__restrict__ b,
-                         double ivar, int64_t F, double *__restrict__ m, double *__restrict__ dg, double *__restrict__ tr) {
+                         double ivar, int64_t F, double *__restrict__ m, double *__restrict__ dg, double *__restrict__ tr,
+                         int64_t det = 0) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= F) return;
@@ -181,7 +182,7 @@ rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict_
     if (lane == 0) {
         m[r] = am * ivar;
         dg[r] = cr[r];
-        unsafeAtomicAdd(tr, at);
+        rr_acc_out(tr, det, r, 0, at);  // deterministic mode: one slot per row, added in row order afterwards
     }
 }
 
@@ -359,8 +360,18 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     hipLaunchKernelGGL(rr_extract_kernel, dim3((unsigned)((F * F + 255) / 256)), dim3(256), 0, c->stream, s.Cp, Fp, dC, F);
     double *dm = s.dvec + Fp, *ddg = s.dvec + 2 * Fp, *dtr = s.dvec + 3 * Fp;
     RR_CHECK_HIP(hipMemsetAsync(dtr, 0, 8, c->stream));
-    hipLaunchKernelGGL(rr_posterior_rows_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream, dC, dG, db, ivar, F,
-                       dm, ddg, dtr);
+    if (c->deterministic) {
+        void *part = nullptr;
+        rc = rr_det_scratch(c, (size_t)F * 8, &part);
+        if (rc != RR_OK) return rc;
+        hipLaunchKernelGGL(rr_posterior_rows_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream, dC, dG, db, ivar, F,
+                           dm, ddg, (double *)part, (int64_t)1);
+        rc = rr_det_reduce(c, (const double *)part, F, 1, 1, dtr);
+        if (rc != RR_OK) return rc;
+    } else {
+        hipLaunchKernelGGL(rr_posterior_rows_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream, dC, dG, db, ivar, F,
+                           dm, ddg, dtr);
+    }
     RR_CHECK_HIP(hipGetLastError());
     RR_CHECK_HIP(hipMemcpyAsync(h.data() + Fp, dm, (size_t)(2 * Fp + 1) * 8, hipMemcpyDeviceToHost, c->stream));
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));

@@ -267,7 +267,7 @@ template <int DMAX, bool HAS_Y, typename TX, typename TC>
 __global__ void __launch_bounds__(256)
 rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad,
                        int64_t ldx, const TC *__restrict__ Ws, int n, int npad, TC *__restrict__ P,
-                       int64_t ldp, double *__restrict__ bvec, TC scale, int rows_per_block) {
+                       int64_t ldp, double *__restrict__ bvec, TC scale, int rows_per_block, int64_t bdet = 0) {
     const int f = blockIdx.x * 256 + threadIdx.x;
     const bool fvalid = f < n;
     TC w[DMAX];
@@ -303,8 +303,8 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
             }
         }
         if (HAS_Y && fvalid) {
-            unsafeAtomicAdd(&bvec[f], (double)bc);
-            unsafeAtomicAdd(&bvec[n + f], (double)bs);
+            rr_acc_out(bvec, bdet, blockIdx.y, f, (double)bc);
+            rr_acc_out(bvec, bdet, blockIdx.y, n + f, (double)bs);
         }
         return;
     }
@@ -327,8 +327,8 @@ rr_rff_features_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64
         }
     }
     if (HAS_Y && fvalid) {
-        unsafeAtomicAdd(&bvec[f], (double)bc);
-        unsafeAtomicAdd(&bvec[n + f], (double)bs);
+        rr_acc_out(bvec, bdet, blockIdx.y, f, (double)bc);
+        rr_acc_out(bvec, bdet, blockIdx.y, n + f, (double)bs);
     }
 }
 
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(256, 2)
 rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad,
                             int64_t ldx, const float *__restrict__ Ws, int n, int npad, TO *__restrict__ P,
                             int64_t ldp, double *__restrict__ bvec, float scale, int tiles_per_block,
-                            float *__restrict__ Pt, int64_t ldt) {
+                            float *__restrict__ Pt, int64_t ldt, int64_t bdet = 0) {
     constexpr int KS = DMAX / 2;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // row tiles, hence store bases, are wave-uniform
@@ -500,9 +500,9 @@ rr_rff_features_mfma_kernel(const TX *__restrict__ X, const TX *__restrict__ y, 
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             const int col = c0 + 32 * cb + j;
-            if (col < n) {
-                unsafeAtomicAdd(&bvec[col], (double)bc[cb]);
-                unsafeAtomicAdd(&bvec[n + col], (double)bs[cb]);
+            if (col < n) {  // deterministic mode: one slot per (row block, wave, half-wave)
+                rr_acc_out(bvec, bdet, ((int64_t)blockIdx.y * 4 + wave) * 2 + h, col, (double)bc[cb]);
+                rr_acc_out(bvec, bdet, ((int64_t)blockIdx.y * 4 + wave) * 2 + h, n + col, (double)bs[cb]);
             }
         }
     }
@@ -532,7 +532,14 @@ static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64
         while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 4 * (int64_t)c->num_cu) tpb >>= 1;                 \
         if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
         const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
-        if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true, false, TX, TO>), grid, dim3(256), 0, c->stream, \
+        if (y && c->deterministic) {                                                                                \
+            void *part = nullptr;                                                                                   \
+            const int64_t nslots = (int64_t)grid.y * 8, F2 = 2 * (int64_t)b->n;                                     \
+            if (rr_det_scratch(c, (size_t)nslots * F2 * 8, &part) != RR_OK) return false;                           \
+            hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true, false, TX, TO>), grid, dim3(256), 0, c->stream, \
+                               X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, (double *)part, scale, (int)tpb, nullptr, 0, F2); \
+            if (rr_det_reduce(c, (const double *)part, nslots, F2, F2, db) != RR_OK) return false;                  \
+        } else if (y) hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, true, false, TX, TO>), grid, dim3(256), 0, c->stream, \
                                   X, y, m, mpad, ldx, b->dWs32, b->n, b->npad, P, ldp, db, scale, (int)tpb, nullptr, 0); \
         else if (CAN_WT && Pt)                                                                                      \
             hipLaunchKernelGGL((rr_rff_features_mfma_kernel<DM, CBK, false, CAN_WT, TX, TO>), grid, dim3(256), 0, c->stream, \
@@ -564,7 +571,7 @@ template <int DMAX, int CB, bool HAS_Y, typename TX, typename TO>
 __global__ void __launch_bounds__(256)
 rr_rff_features_mfma64_kernel(const TX *__restrict__ X, const TX *__restrict__ y, int64_t N, int64_t Npad, int64_t ldx,
                               const double *__restrict__ Ws, int n, int npad, TO *__restrict__ P, int64_t ldp,
-                              double *__restrict__ bvec, double scale, int tiles_per_block) {
+                              double *__restrict__ bvec, double scale, int tiles_per_block, int64_t bdet = 0) {
     constexpr int KS = DMAX / 4;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -627,22 +634,32 @@ rr_rff_features_mfma64_kernel(const TX *__restrict__ X, const TX *__restrict__ y
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int rr = g + 4 * e;
-                    double sv, cv;
-                    rr_sincos_rev_f64(acc[e], sv, cv);
-                    cv = rr < lim ? cv * scale : 0.0;
-                    sv = rr < lim ? sv * scale : 0.0;
                     const unsigned off = lane_off + ES * 4u * (unsigned)e * (unsigned)ldp;
                     if constexpr (ES == 8) {  // non-temporal: +7 % for these 8-byte stores (3.52 -> 3.28 ms per 500k x 4096)
+                        double sv, cv;
+                        rr_sincos_rev_f64(acc[e], sv, cv);
+                        cv = rr < lim ? cv * scale : 0.0;
+                        sv = rr < lim ? sv * scale : 0.0;
                         asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" ::"v"(off), "v"(cv), "s"(tile_c), "i"(128 * cb) : "memory");
                         asm volatile("global_store_dwordx2 %0, %1, %2 offset:%3 nt" ::"v"(off), "v"(sv), "s"(tile_s), "i"(128 * cb) : "memory");
+                        if (HAS_Y) {
+                            bc[cb] = fma(cv, yv[e], bc[cb]);
+                            bs[cb] = fma(sv, yv[e], bs[cb]);
+                        }
                     } else {
-                        const float cf = (float)cv, sf = (float)sv;
+                        // RR_F32P64: the float64 phase loses its whole revolutions in float64 (exact), what is left in
+                        // [-0.5, 0.5] goes through the float32 hardware sin / cos like every f32 feature (2^-24 revolutions)
+                        const float fr = (float)(acc[e] - rint(acc[e]));
+                        const float fs = (float)scale;
+                        float cf = __builtin_amdgcn_cosf(fr), sf = __builtin_amdgcn_sinf(fr);
+                        cf = rr < lim ? cf * fs : 0.f;
+                        sf = rr < lim ? sf * fs : 0.f;
                         asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(cf), "s"(tile_c), "i"(64 * cb) : "memory");
                         asm volatile("global_store_dword %0, %1, %2 offset:%3" RR_NT_ASM ::"v"(off), "v"(sf), "s"(tile_s), "i"(64 * cb) : "memory");
-                    }
-                    if (HAS_Y) {
-                        bc[cb] = fma(cv, yv[e], bc[cb]);
-                        bs[cb] = fma(sv, yv[e], bs[cb]);
+                        if (HAS_Y) {
+                            bc[cb] = fma((double)cf, yv[e], bc[cb]);
+                            bs[cb] = fma((double)sf, yv[e], bs[cb]);
+                        }
                     }
                 }
             }
@@ -658,9 +675,9 @@ rr_rff_features_mfma64_kernel(const TX *__restrict__ X, const TX *__restrict__ y
                 bs[cb] += __hiloint2double(__shfl_xor(__double2hiint(bs[cb]), m, 64), __shfl_xor(__double2loint(bs[cb]), m, 64));
             }
             const int col = c0 + 16 * cb + j;
-            if (g == 0 && col < n) {
-                unsafeAtomicAdd(&bvec[col], bc[cb]);
-                unsafeAtomicAdd(&bvec[n + col], bs[cb]);
+            if (g == 0 && col < n) {  // deterministic mode: one slot per (row block, wave)
+                rr_acc_out(bvec, bdet, (int64_t)blockIdx.y * 4 + wave, col, bc[cb]);
+                rr_acc_out(bvec, bdet, (int64_t)blockIdx.y * 4 + wave, n + col, bs[cb]);
             }
         }
     }
@@ -683,7 +700,14 @@ static bool rr_features_mfma64_launch(rr_basis *b, const TX *X, const TX *y, int
         while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 8 * (int64_t)c->num_cu) tpb >>= 1;                 \
         if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
         const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
-        if (y) hipLaunchKernelGGL((rr_rff_features_mfma64_kernel<DM, CBK, true, TX, TO>), grid, dim3(256), 0, c->stream, \
+        if (y && c->deterministic) {                                                                                \
+            void *part = nullptr;                                                                                   \
+            const int64_t nslots = (int64_t)grid.y * 4, F2 = 2 * (int64_t)b->n;                                     \
+            if (rr_det_scratch(c, (size_t)nslots * F2 * 8, &part) != RR_OK) return false;                           \
+            hipLaunchKernelGGL((rr_rff_features_mfma64_kernel<DM, CBK, true, TX, TO>), grid, dim3(256), 0, c->stream, \
+                               X, y, m, mpad, ldx, b->dWs64, b->n, b->npad, P, ldp, (double *)part, scale, (int)tpb, F2); \
+            if (rr_det_reduce(c, (const double *)part, nslots, F2, F2, db) != RR_OK) return false;                  \
+        } else if (y) hipLaunchKernelGGL((rr_rff_features_mfma64_kernel<DM, CBK, true, TX, TO>), grid, dim3(256), 0, c->stream, \
                                   X, y, m, mpad, ldx, b->dWs64, b->n, b->npad, P, ldp, db, scale, (int)tpb);        \
         else hipLaunchKernelGGL((rr_rff_features_mfma64_kernel<DM, CBK, false, TX, TO>), grid, dim3(256), 0, c->stream, \
                                 X, y, m, mpad, ldx, b->dWs64, b->n, b->npad, P, ldp, db, scale, (int)tpb);          \
@@ -801,7 +825,7 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (gr <= gc) rr_syrk_out(p, gr, gc, acc[i][j][e]);
+                if (gr <= gc) rr_syrk_out(p, ks, gr, gc, acc[i][j][e]);
             }
         }
     }
@@ -856,7 +880,7 @@ __device__ __forceinline__ void gram_mfma_r(const KOpsR<NI> &o, floatx16 (&acc)[
 
 template <int NI>
 __device__ __forceinline__ void syrk_ragged_loop(const SyrkArgs &p, float *lds, int wave, int lane, int ca, int cb,
-                                                 int64_t row_begin, int64_t nkb) {
+                                                 int64_t row_begin, int64_t nkb, int ks) {
     const int wr = wave >> 2, wc_ = wave & 3;
     const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
     const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
@@ -901,7 +925,7 @@ __device__ __forceinline__ void syrk_ragged_loop(const SyrkArgs &p, float *lds, 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int64_t gcol = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                    rr_syrk_out(p, grow, gcol, acc[i][j][e]);
+                    rr_syrk_out(p, ks, grow, gcol, acc[i][j][e]);
                 }
             }
         }
@@ -928,11 +952,11 @@ rr_syrk_f32_ragged_kernel(const SyrkArgs p) {
     int ni = (w - (wave >> 2) * 128 + 31) / 32;    // this wave's 32-column blocks with valid columns
     ni = ni < 0 ? 0 : (ni > 4 ? 4 : ni);
     switch (ni) {  // wave-uniform; every path runs the same barriers
-        case 0: syrk_ragged_loop<0>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
-        case 1: syrk_ragged_loop<1>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
-        case 2: syrk_ragged_loop<2>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
-        case 3: syrk_ragged_loop<3>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
-        default: syrk_ragged_loop<4>(p, lds, wave, lane, ca, cb, row_begin, nkb); break;
+        case 0: syrk_ragged_loop<0>(p, lds, wave, lane, ca, cb, row_begin, nkb, ks); break;
+        case 1: syrk_ragged_loop<1>(p, lds, wave, lane, ca, cb, row_begin, nkb, ks); break;
+        case 2: syrk_ragged_loop<2>(p, lds, wave, lane, ca, cb, row_begin, nkb, ks); break;
+        case 3: syrk_ragged_loop<3>(p, lds, wave, lane, ca, cb, row_begin, nkb, ks); break;
+        default: syrk_ragged_loop<4>(p, lds, wave, lane, ca, cb, row_begin, nkb, ks); break;
     }
 }
 
@@ -1043,7 +1067,7 @@ __device__ __forceinline__ void syrk_diag_body(const SyrkArgs &p, float *lds, in
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int64_t gr = ca + 32 * bi[e] + (k & 3) + 8 * (k >> 2) + 4 * hi;
-            if (gr <= gc) rr_syrk_out(p, gr, gc, acc[e][k]);
+            if (gr <= gc) rr_syrk_out(p, ks, gr, gc, acc[e][k]);
         }
     }
     (void)F;
@@ -1080,7 +1104,28 @@ struct Syrk64Args {
     int64_t rows_per_split;  // multiple of 16
     double *G;
     int offdiag_only;  // 1: tiles ta < tb only (the diagonal tiles run in rr_syrk_f64_diag_kernel)
+    double *part = nullptr;  // deterministic mode: slab ks (part_stride = ldp * ldp doubles) takes K-split ks' partials
+    int64_t part_stride = 0;
 };
+
+__device__ __forceinline__ void rr_syrk64_out(const Syrk64Args &p, int64_t ks, int64_t gr, int64_t gc, double v) {
+    if (p.part != nullptr) p.part[ks * p.part_stride + gr * p.ldp + gc] = v;
+    else unsafeAtomicAdd(&p.G[gr * (int64_t)p.F + gc], v);
+}
+
+// deterministic mode: G[gr][gc] (gr <= gc < F; gc == F: bcol[gr]) += sum over the K-splits' slabs in ascending order
+template <typename T>
+__global__ void __launch_bounds__(256)
+rr_syrk_det_reduce_kernel(const T *__restrict__ part, int64_t stride, int64_t ldp, int F, int nsplit, double *__restrict__ G,
+                          double *__restrict__ bcol) {
+    const int64_t gc = (int64_t)blockIdx.x * 256 + threadIdx.x, gr = blockIdx.y;
+    if (gc < gr || gc > F || (gc == F && bcol == nullptr)) return;
+    const T *q = part + gr * ldp + gc;
+    double s = 0.0;
+    for (int k = 0; k < nsplit; ++k) s += (double)q[(int64_t)k * stride];
+    if (gc < F) G[gr * (int64_t)F + gc] += s;
+    else bcol[gr] += s;
+}
 
 template <int OFF>
 __device__ __forceinline__ double lds_read_b64(unsigned addr) {
@@ -1199,7 +1244,7 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int64_t gr = ca + wr * 64 + i * 16 + (lane >> 4) + 4 * e;
-                if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], acc[i][j][e]);
+                if (gr <= gc && gc < F) rr_syrk64_out(p, ks, gr, gc, acc[i][j][e]);
             }
         }
 }
@@ -1325,7 +1370,7 @@ __device__ __forceinline__ void syrk64_diag_body(const Syrk64Args &p, unsigned c
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int64_t gr = ca + 16 * D::A[D::QA[q]] + (lane >> 4) + 4 * e;
-            if (gr <= gc && gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], acc[q][e]);
+            if (gr <= gc && gc < F) rr_syrk64_out(p, ks, gr, gc, acc[q][e]);
         }
     }
 }
@@ -1434,7 +1479,7 @@ __global__ void __launch_bounds__(256) rr_pack_f32_kernel(const TS *__restrict__
 template <typename TY, typename TP = float>
 __global__ void __launch_bounds__(256) rr_gemv_t_kernel(const TP *__restrict__ P, const TY *__restrict__ y,
                                                         int64_t rows, int F, int64_t ldp, double *__restrict__ bvec,
-                                                        int rows_per_block) {
+                                                        int rows_per_block, int64_t bdet = 0) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
@@ -1442,12 +1487,12 @@ __global__ void __launch_bounds__(256) rr_gemv_t_kernel(const TP *__restrict__ P
     if (c >= F) return;
     double acc = 0.0;
     for (int64_t r = r0; r < r1; ++r) acc += (double)P[r * ldp + c] * (double)y[r];
-    unsafeAtomicAdd(&bvec[c], acc);
+    rr_acc_out(bvec, bdet, blockIdx.y, c, acc);
 }
 
 // y^T y (slm.py:161-162 via sqErr = yty - 2 m.b + m G m)
 template <typename TX>
-__global__ void __launch_bounds__(256) rr_yty_kernel(const TX *__restrict__ y, int64_t N, double *out) {
+__global__ void __launch_bounds__(256) rr_yty_kernel(const TX *__restrict__ y, int64_t N, double *out, int64_t det = 0) {
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -1459,7 +1504,7 @@ __global__ void __launch_bounds__(256) rr_yty_kernel(const TX *__restrict__ y, i
     __shared__ double part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) rr_acc_out(out, det, blockIdx.x, 0, part[0] + part[1] + part[2] + part[3]);
 }
 
 // lower triangle <- upper triangle, 32x32 tiles through LDS so both sides stay coalesced
@@ -1792,12 +1837,12 @@ static size_t dtype_size(int t) { return t == RR_F32 ? 4 : 8; }
 
 static int transform_dev_impl(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx,
                               void *dPhi, int out_dtype, int64_t ldphi) {
-    RR_DISPATCH3(launch_transform, x_dtype, b->compute, out_dtype, b, dX, N, ldx, dPhi, ldphi);
+    RR_DISPATCH3(launch_transform, x_dtype, (b->phase64 ? (int)RR_F64 : b->compute), out_dtype, b, dX, N, ldx, dPhi, ldphi);
 }
 
 static int grad_dev_impl(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, void *dOut,
                          int out_dtype, int nout) {
-    RR_DISPATCH3(launch_grad, x_dtype, b->compute, out_dtype, b, dX, N, ldx, dOut, nout);
+    RR_DISPATCH3(launch_grad, x_dtype, (b->phase64 ? (int)RR_F64 : b->compute), out_dtype, b, dX, N, ldx, dOut, nout);
 }
 
 // Feature scratch: grow-only, owned by the basis (freed in rr_basis_destroy).
@@ -1852,6 +1897,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
                        double *bcol = nullptr) {
     if (c->gram_engine != 0) {
         RR_REQUIRE(bcol == nullptr, "gram: the rider column needs the f32 engine");
+        RR_REQUIRE(!c->deterministic, "gram: deterministic mode (rr_set_deterministic) needs the f32 engine, not a split 16-bit one");
         return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
     }
     RR_REQUIRE(bcol == nullptr || F < ldp, "gram: no pad column for the rider");
@@ -1917,6 +1963,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     }
     const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
     if (renv && atoll(renv) >= GR_KB) rps = rps_d = rps_r = (atoll(renv) / GR_KB) * GR_KB;
+    if (c->deterministic) rps_d = rps_r = rps;  // one slab per K-split, shared by the three kernels
     nsplit = (rows + rps - 1) / rps;
     nsplit_d = (rows + rps_d - 1) / rps_d;
     nsplit_r = (rows + rps_r - 1) / rps_r;
@@ -1928,6 +1975,13 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
+    if (c->deterministic) {
+        void *slabs = nullptr;
+        int rc = rr_det_scratch(c, (size_t)nsplit * (size_t)ldp * (size_t)ldp * sizeof(float), &slabs);
+        if (rc != RR_OK) return rc;
+        a.part = (float *)slabs;
+        a.part_stride = ldp * ldp;
+    }
     if (ntiles > 0)
         hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     if (rg) {
@@ -1943,6 +1997,9 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         ad.rows_per_split = rps_d;
         hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
     }
+    if (a.part)
+        hipLaunchKernelGGL(rr_syrk_det_reduce_kernel<float>, dim3((unsigned)((F + 1 + 255) / 256), (unsigned)F), dim3(256), 0,
+                           c->stream, a.part, a.part_stride, ldp, F, (int)nsplit, dG, bcol);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -1967,7 +2024,15 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
     Syrk64Args a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
     a.offdiag_only = od;
-    hipLaunchKernelGGL(rr_syrk_f64_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(G64_THREADS), 0, c->stream, a);
+    if (c->deterministic) {
+        void *slabs = nullptr;
+        int rc = rr_det_scratch(c, (size_t)nsplit * (size_t)ldp * (size_t)ldp * sizeof(double), &slabs);
+        if (rc != RR_OK) return rc;
+        a.part = (double *)slabs;
+        a.part_stride = ldp * ldp;
+    }
+    if (ntiles > 0)
+        hipLaunchKernelGGL(rr_syrk_f64_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(G64_THREADS), 0, c->stream, a);
     if (od) {
         // the diagonal kernel's own K-split: nb equal-cost workgroups per split, up to 4 resident per CU (36 KiB of LDS
         // each); pick the split count whose workgroup count fills whole rounds best while a split keeps >= 512 rows
@@ -1985,9 +2050,13 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
         }
         Syrk64Args ad = a;
         ad.rows_per_split = ((rows + best_ns - 1) / best_ns + G64_KB - 1) / G64_KB * G64_KB;
+        if (c->deterministic) ad.rows_per_split = rps;  // one slab per K-split, shared by both kernels
         const int64_t nsd = (rows + ad.rows_per_split - 1) / ad.rows_per_split;
         hipLaunchKernelGGL(rr_syrk_f64_diag_kernel, dim3((unsigned)(nsd * nb)), dim3(G64_THREADS), 0, c->stream, ad);
     }
+    if (a.part)
+        hipLaunchKernelGGL(rr_syrk_det_reduce_kernel<double>, dim3((unsigned)((F + 255) / 256), (unsigned)F), dim3(256), 0,
+                           c->stream, a.part, a.part_stride, ldp, F, (int)nsplit, dG, (double *)nullptr);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }
@@ -2022,35 +2091,68 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
     if (chunk > N) chunk = N;
     // split-bf16 engine with the MFMA feature kernel: the features are produced directly in the SYRK's K-blocked
     // bf16 hi/lo layout (same 4 bytes per value), whole 64-row groups
-    const bool fused_pb = F32 && c->gram_engine != 0 && rr_features_mfma_ok<TX>(b, (const TX *)dX, N, ldx);
+    const bool fused_pb = F32 && !b->phase64 && c->gram_engine != 0 && rr_features_mfma_ok<TX>(b, (const TX *)dX, N, ldx);
     const int KBR = fused_pb ? 64 : KB;
     chunk = (chunk + KBR - 1) / KBR * KBR;
-    int rc = ensure_zbuf(b, (size_t)chunk * ldp * sizeof(TC));
+    // More than one chunk: chunk k+1's feature kernel (VALU trig + HBM writes) runs on a second stream while chunk k's SYRK
+    // (LDS-DMA + MFMA) runs on the context's, into the other half of a double-buffered scratch -- the SYRK kernels never
+    // wait for features except for the first chunk.  RR_GRAM_OVERLAP=0 switches it off (A/B runs); the deterministic mode's
+    // shared scratch of ordered partial sums (rr_internal.h) is single-stream, so it does too.
+    static const bool overlap_off = getenv("RR_GRAM_OVERLAP") != nullptr && atoi(getenv("RR_GRAM_OVERLAP")) == 0;
+    const bool overlap = N > chunk && !overlap_off && !c->deterministic;
+    const int nbuf = overlap ? 2 : 1;
+    int rc = ensure_zbuf(b, (size_t)nbuf * (size_t)chunk * ldp * sizeof(TC));
     if (rc != RR_OK) return rc;
     TC *P = (TC *)b->zbuf;
+    if (overlap && !c->stream2) {
+        RR_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        RR_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    }
+    hipStream_t fstream = overlap ? c->stream2 : c->stream;  // the stream the feature kernels go to
+    const hipStream_t main_stream = c->stream;
     if (fused_pb && ldp > F) {
-        const int64_t cnt = (chunk / 16) * (ldp - F) * 4;
+        const int64_t cnt = (nbuf * chunk / 16) * (ldp - F) * 4;
         hipLaunchKernelGGL(rr_zero_padcols_pb_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
-                           (uintx4 *)P, chunk / 16, ldp, F);
+                           (uintx4 *)P, nbuf * chunk / 16, ldp, F);
         RR_CHECK_HIP(hipGetLastError());
     } else if (ldp > F) {  // pad columns are never written by the feature kernel: zero them once per call
-        const int64_t cnt = chunk * (ldp - F);
+        const int64_t cnt = nbuf * chunk * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<TC>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream,
-                           P, chunk, ldp, F);
+                           P, nbuf * chunk, ldp, F);
         RR_CHECK_HIP(hipGetLastError());
     }
 
+    TC *const Pbase = P;
+    struct StreamGuard {  // an error return between the two stream switches must not leave the context on the second stream
+        rr_ctx *c;
+        hipStream_t s;
+        ~StreamGuard() { c->stream = s; }
+    } guard{c, main_stream};
     for (int64_t r0 = 0; r0 < N; r0 += chunk) {
         const int64_t m = (N - r0 < chunk) ? N - r0 : chunk;
         const int64_t mpad = (m + KBR - 1) / KBR * KBR;
         const TX *Xc = (const TX *)dX + r0 * ldx;
         const TX *yc = dy ? (const TX *)dy + r0 : nullptr;
-        // four events per chunk bracket the kernels (read back by rr_rff_gram_timings)
-        const size_t e0 = (size_t)(r0 / chunk) * 4;
-        while (b->events.size() < e0 + 4) {
+        const int64_t kchunk = r0 / chunk;
+        P = Pbase + (overlap ? (kchunk & 1) * chunk * ldp : 0);
+        // five events per chunk bracket the kernels (read back by rr_rff_gram_timings): features begin / end (on the
+        // feature stream), SYRK begin / mid / end (on the context's stream)
+        const size_t e0 = (size_t)kchunk * 5;
+        while (b->events.size() < e0 + 5) {
             hipEvent_t ev;
             RR_CHECK_HIP(hipEventCreate(&ev));
             b->events.push_back(ev);
+        }
+        if (overlap) {
+            // the feature stream starts behind whatever the context's stream holds at entry (zeroed accumulators, the
+            // pad columns), and reuses a buffer only after the SYRK that read it (chunk k - 2) has finished
+            if (kchunk == 0) {
+                RR_CHECK_HIP(hipEventRecord(c->ev_fork, main_stream));
+                RR_CHECK_HIP(hipStreamWaitEvent(fstream, c->ev_fork, 0));
+            } else if (kchunk >= 2) {
+                RR_CHECK_HIP(hipStreamWaitEvent(fstream, b->events[e0 - 10 + 4], 0));
+            }
+            c->stream = fstream;  // the feature launchers below take the stream from the context (restored by `guard`)
         }
         RR_CHECK_HIP(hipEventRecord(b->events[e0], c->stream));
         // (A) features (+ Phi^T y): MFMA projection for f32 X, else the VALU kernel
@@ -2067,7 +2169,15 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
             }
         }
         if (done_a) {
+        } else if (F32 && b->phase64) {
+            if constexpr (F32)
+                done_a = rr_features_mfma64_launch<TX, float>(b, Xc, yc, m, mpad, ldx, (float *)P, ldp, db, 1.0 / sqrt((double)b->n));
+            if (!done_a) {
+                rr_set_error("gram: a float64-phase basis (RR_F32P64) needs 16-byte aligned rows of X");
+                return RR_ERR_UNSUPPORTED;
+            }
         } else if (b->large) {
+            RR_REQUIRE(!c->deterministic || yc == nullptr, "gram: deterministic mode does not cover Xdim > 128");
             rc = large_features<TX, TC, TC>(b, Xc, yc, m, mpad, ldx, P, ldp, db);
             if (rc != RR_OK) return rc;
             done_a = true;
@@ -2080,7 +2190,15 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
             const dim3 grid(fblocks, (unsigned)((mpad + rpb - 1) / rpb));
 #define RR_LPH(DM)                                                                                               \
     do {                                                                                                         \
-        if (yc) hipLaunchKernelGGL((rr_rff_features_kernel<DM, true, TX, TC>), grid, dim3(256), 0, c->stream, Xc, \
+        if (yc && c->deterministic) {                                                                            \
+            void *part = nullptr;                                                                                \
+            rc = rr_det_scratch(c, (size_t)grid.y * F * 8, &part);                                               \
+            if (rc != RR_OK) return rc;                                                                          \
+            hipLaunchKernelGGL((rr_rff_features_kernel<DM, true, TX, TC>), grid, dim3(256), 0, c->stream, Xc, yc, \
+                               m, mpad, ldx, Ws, b->n, b->npad, P, ldp, (double *)part, scale, (int)rpb, (int64_t)F); \
+            rc = rr_det_reduce(c, (const double *)part, grid.y, F, F, db);                                        \
+            if (rc != RR_OK) return rc;                                                                          \
+        } else if (yc) hipLaunchKernelGGL((rr_rff_features_kernel<DM, true, TX, TC>), grid, dim3(256), 0, c->stream, Xc, \
                                    yc, m, mpad, ldx, Ws, b->n, b->npad, P, ldp, db, scale, (int)rpb);            \
         else hipLaunchKernelGGL((rr_rff_features_kernel<DM, false, TX, TC>), grid, dim3(256), 0, c->stream, Xc,  \
                                 yc, m, mpad, ldx, Ws, b->n, b->npad, P, ldp, db, scale, (int)rpb);               \
@@ -2097,20 +2215,25 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
         }
         RR_CHECK_HIP(hipGetLastError());
         RR_CHECK_HIP(hipEventRecord(b->events[e0 + 1], c->stream));
+        if (overlap) {
+            c->stream = main_stream;
+            RR_CHECK_HIP(hipStreamWaitEvent(main_stream, b->events[e0 + 1], 0));
+        }
+        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
         // (B) G += P^T P
         if constexpr (F32) {
             if (fused_pb)
-                rc = rr_launch_syrk_bf16(c, c->gram_engine, nullptr, (const void *)P, mpad, ldp, F, dG, b->events[e0 + 2],
+                rc = rr_launch_syrk_bf16(c, c->gram_engine, nullptr, (const void *)P, mpad, ldp, F, dG, b->events[e0 + 3],
                                          c->gram_engine == RR_GRAM_FP16X3 ? f16_store_scale((float)scale) : 0.f);
             else
-                rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG, b->events[e0 + 2]);
+                rc = rr_launch_syrk_f32(c, P, mpad, ldp, F, dG, b->events[e0 + 3]);
         } else {
             rc = rr_launch_syrk_f64(c, P, mpad, ldp, F, dG);
-            if (rc == RR_OK) RR_CHECK_HIP(hipEventRecord(b->events[e0 + 2], c->stream));
+            if (rc == RR_OK) RR_CHECK_HIP(hipEventRecord(b->events[e0 + 3], c->stream));
         }
         if (rc != RR_OK) return rc;
-        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 3], c->stream));
-        b->events_used = e0 + 4;
+        RR_CHECK_HIP(hipEventRecord(b->events[e0 + 4], c->stream));
+        b->events_used = e0 + 5;
     }
     b->gram_kernel = !F32 ? "rr_syrk_f64_kernel" : c->gram_engine == 0 ? "rr_syrk_f32_kernel" : "rr_syrk_b16w4_kernel";
     return RR_OK;
@@ -2127,6 +2250,18 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
         const int64_t cnt = mpad * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
+    }
+    if (b->phase64) {  // RR_F32P64: phases on the f64 matrix cores, float32 features out; no direct P^T (consumers transpose)
+        const double sc = 1.0 / sqrt((double)b->n);
+        const bool done = x_dtype == RR_F32
+                              ? rr_features_mfma64_launch<float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, sc)
+                              : rr_features_mfma64_launch<double, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, sc);
+        if (!done) {
+            rr_set_error("features: a float64-phase basis (RR_F32P64) needs 16-byte aligned rows of X");
+            return RR_ERR_UNSUPPORTED;
+        }
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
     }
     if (b->large)
         return x_dtype == RR_F32 ? large_features<float, float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr)
@@ -2464,7 +2599,7 @@ static int launch_gm(rr_basis *b, bool grad, const void *dX, int64_t N, int64_t 
 
 static int gm_dev_impl(rr_basis *b, bool grad, const void *dX, int x_dtype, int64_t N, int64_t ldx, void *o0, void *o1,
                        int out_dtype, int64_t ldo) {
-    RR_DISPATCH3(launch_gm, x_dtype, b->compute, out_dtype, b, grad, dX, N, ldx, o0, o1, ldo);
+    RR_DISPATCH3(launch_gm, x_dtype, (b->phase64 ? (int)RR_F64 : b->compute), out_dtype, b, grad, dX, N, ldx, o0, o1, ldo);
 }
 
 // host-buffer driver shared by rr_gm_transform / rr_gm_grad
@@ -2562,11 +2697,24 @@ int rr_rff_gram_dev(rr_basis *b, const void *dX, const void *dy, int x_dtype, in
     if (dy) {
         int blocks = (int)((N + 255) / 256);
         if (blocks > c->num_cu * 8) blocks = c->num_cu * 8;
+        double *ydst = dyty;
+        if (c->deterministic) {
+            void *part = nullptr;
+            rc = rr_det_scratch(c, (size_t)blocks * 8, &part);
+            if (rc != RR_OK) return rc;
+            ydst = (double *)part;
+        }
         if (x_dtype == RR_F32)
-            hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(blocks), dim3(256), 0, c->stream, (const float *)dy, N, dyty);
+            hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(blocks), dim3(256), 0, c->stream, (const float *)dy, N, ydst,
+                               (int64_t)(c->deterministic ? 1 : 0));
         else
-            hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(blocks), dim3(256), 0, c->stream, (const double *)dy, N, dyty);
+            hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(blocks), dim3(256), 0, c->stream, (const double *)dy, N, ydst,
+                               (int64_t)(c->deterministic ? 1 : 0));
         RR_CHECK_HIP(hipGetLastError());
+        if (c->deterministic) {
+            rc = rr_det_reduce(c, ydst, blocks, 1, 1, dyty);
+            if (rc != RR_OK) return rc;
+        }
     }
     return RR_OK;
 }
@@ -2576,19 +2724,19 @@ int rr_rff_gram_timings(rr_basis *b, float *features_ms, float *syrk_ms, float *
     RR_CHECK_HIP(hipSetDevice(b->ctx->device));
     RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
     float pa = 0.f, pg = 0.f, pd = 0.f;
-    for (size_t i = 0; i + 4 <= b->events_used; i += 4) {
+    for (size_t i = 0; i + 5 <= b->events_used; i += 5) {
         float t = 0.f;
         RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i], b->events[i + 1]));
         pa += t;
-        RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i + 1], b->events[i + 2]));
-        pg += t;
         RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i + 2], b->events[i + 3]));
+        pg += t;
+        RR_CHECK_HIP(hipEventElapsedTime(&t, b->events[i + 3], b->events[i + 4]));
         pd += t;
     }
     if (features_ms) *features_ms = pa;
     if (syrk_ms) *syrk_ms = pg;
     if (diag_ms) *diag_ms = pd;
-    if (launches) *launches = (int)(b->events_used / 4);
+    if (launches) *launches = (int)(b->events_used / 5);
     return RR_OK;
 }
 
@@ -2647,7 +2795,17 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
         if (!f64) {
             hipLaunchKernelGGL(rr_pack_f32_kernel<float>, pg, dim3(256), 0, c->stream, (const float *)dRaw, m, (int)F, F,
                                (float *)dP, ldp, mpad);
-            if (y) {
+            if (y && c->deterministic) {  // ordered partial sums (rr_internal.h): each kernel, then its reduction
+                void *part = nullptr;
+                rc = rr_det_scratch(c, (size_t)(gg.y > (unsigned)yb ? gg.y : (unsigned)yb) * (size_t)(F + 1) * 8, &part);
+                if (rc != RR_OK) break;
+                hipLaunchKernelGGL(rr_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, (const float *)dP,
+                                   (const float *)dy, m, (int)F, ldp, (double *)part, rpb, (int64_t)F);
+                rc = rr_det_reduce(c, (const double *)part, gg.y, F, F, db);
+                hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, m, (double *)part, (int64_t)1);
+                if (rc == RR_OK) rc = rr_det_reduce(c, (const double *)part, yb, 1, 1, db + F);
+                if (rc != RR_OK) break;
+            } else if (y) {
                 hipLaunchKernelGGL(rr_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, (const float *)dP,
                                    (const float *)dy, m, (int)F, ldp, db, rpb);
                 hipLaunchKernelGGL(rr_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, m, db + F);
@@ -2655,7 +2813,17 @@ int rr_dense_gram(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, i
         } else {
             hipLaunchKernelGGL((rr_pack_f32_kernel<double, double>), pg, dim3(256), 0, c->stream, (const double *)dRaw, m,
                                (int)F, F, (double *)dP, ldp, mpad);
-            if (y) {
+            if (y && c->deterministic) {
+                void *part = nullptr;
+                rc = rr_det_scratch(c, (size_t)(gg.y > (unsigned)yb ? gg.y : (unsigned)yb) * (size_t)(F + 1) * 8, &part);
+                if (rc != RR_OK) break;
+                hipLaunchKernelGGL((rr_gemv_t_kernel<double, double>), gg, dim3(256), 0, c->stream, (const double *)dP,
+                                   (const double *)dy, m, (int)F, ldp, (double *)part, rpb, (int64_t)F);
+                rc = rr_det_reduce(c, (const double *)part, gg.y, F, F, db);
+                hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, m, (double *)part, (int64_t)1);
+                if (rc == RR_OK) rc = rr_det_reduce(c, (const double *)part, yb, 1, 1, db + F);
+                if (rc != RR_OK) break;
+            } else if (y) {
                 hipLaunchKernelGGL((rr_gemv_t_kernel<double, double>), gg, dim3(256), 0, c->stream, (const double *)dP,
                                    (const double *)dy, m, (int)F, ldp, db, rpb);
                 hipLaunchKernelGGL(rr_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, m,

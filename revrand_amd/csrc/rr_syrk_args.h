@@ -71,12 +71,21 @@ struct SyrkArgs {
     // f32 SYRK kernels: column F of P (its first pad column) holds one more vector y; bcol[r] += P[:, r] . y for r < F
     // (Phi^T y rides along with Phi^T Phi instead of costing its own pass over P)
     double *bcol = nullptr;
+    // deterministic mode (rr_set_deterministic): K-split ks stores its tile partials into slab ks of `part` (part_stride
+    // = ldp * ldp floats each, element [gr][gc] at gr * ldp + gc) instead of adding them to G; rr_syrk_det_reduce_kernel
+    // then adds the slabs of every element in ascending ks
+    float *part = nullptr;
+    int64_t part_stride = 0;
 };
 
 #ifdef __HIPCC__
-// one accumulator of an f32 SYRK tile into the upper triangle of G, or -- column F, the rider -- into bcol
-__device__ __forceinline__ void rr_syrk_out(const SyrkArgs &p, int64_t gr, int64_t gc, float v) {
+// one accumulator of an f32 SYRK tile (K-split ks) into the upper triangle of G, or -- column F, the rider -- into bcol
+__device__ __forceinline__ void rr_syrk_out(const SyrkArgs &p, int64_t ks, int64_t gr, int64_t gc, float v) {
     const int64_t F = p.F;
+    if (p.part != nullptr) {
+        if (gc < F || (gc == F && p.bcol != nullptr && gr < F)) p.part[ks * p.part_stride + gr * p.ldp + gc] = v;
+        return;
+    }
     if (gc < F) unsafeAtomicAdd(&p.G[gr * F + gc], (double)v);
     else if (gc == F && p.bcol != nullptr && gr < F) unsafeAtomicAdd(&p.bcol[gr], (double)v);
 }

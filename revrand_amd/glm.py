@@ -124,7 +124,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if callable(prefetch) and self.sampler != "device" and self._prefetch_draws and self._native_draws \
                 and getattr(self._features(), "accepts_device_draws", False) \
                 and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
-            self.__dict__["_draw_upload"] = (_hip.Device(_hip.get_device().index), [None, None, None], [0])
+            # (one upload context per process and device, shared by every fit: a context is a stream and two events, and a
+            # cross-validation loop must not accumulate them)
+            self.__dict__["_draw_upload"] = (_hip.get_upload_device(_hip.get_device().index), [None, None, None], [0])
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,

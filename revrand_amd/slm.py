@@ -91,7 +91,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                        nstarts=self.nstarts)
             if self._state is not None and getattr(self._state, "best_on_device", False):
                 self.covariance_ = self._state.best_covariance()
-            if self.distributed:  # posteriors agree to the last bits only (see `_same_on_all_ranks`): ship rank 0's
+            if self.distributed and not self._ranks_bit_identical():
+                # posteriors agree to the last bits only (see `_same_on_all_ranks`): ship rank 0's
                 from . import parallel
                 comm = parallel.get_comm()
                 self.weights_ = comm.broadcast_host(np.ascontiguousarray(self.weights_, dtype=np.float64), root=0)
@@ -184,7 +185,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             sqErr = yty - m.dot(bvec) - var * ((m ** 2) * iL).sum()
             ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
                            + ((m ** 2 + Cdiag) * iL).sum() - logdetC + np.log(L).sum() - D)
-            if self.distributed:
+            if self.distributed and not self._ranks_bit_identical():
                 ELBO = float(comm.broadcast_host(np.array([ELBO]), root=0)[0])  # see `_same_on_all_ranks`
             return -ELBO
         sqErr, dhypers = st.second_pass(hypers, m, Cpass, var)
@@ -204,7 +205,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             return -0.5 * (((m[s] ** 2 + Cdiag[s]) * iL[s] ** 2).sum() - iL[s].sum())
 
         dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
-        if self.distributed:
+        if self.distributed and not self._ranks_bit_identical():
             ELBO, dvar, dL, dhypers = self._same_on_all_ranks(comm, [ELBO, dvar, dL, dhypers])
         if ELBO > self.obj_:
             self.weights_ = m
@@ -218,6 +219,13 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                     self.covariance_ = st.best_covariance()
         log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
         return -ELBO, [-dvar, dL, dhypers]
+
+    def _ranks_bit_identical(self):
+        """In deterministic mode (Device.set_deterministic / RR_DETERMINISTIC=1) the posterior and every reduction are
+        summed in a fixed order: ranks holding the same all-reduced statistics compute the same bits, and the evaluation
+        needs its two exchanges only ([tri G | b | y^T y | N], then [sqErr | dhyp]) -- no broadcast of the results."""
+        dev = getattr(getattr(self, "_state", None), "dev", None)  # the fit state's device context, if it has one
+        return bool(dev is not None and getattr(dev, "deterministic", False))
 
     @staticmethod
     def _same_on_all_ranks(comm, values):

@@ -186,14 +186,14 @@ def test_dense_predict_vs_numpy():
 
 
 def test_concat_with_float64_child_uses_float64_statistics():
-    """RandomLaplace (dtype f64 by default: heavy-tailed W) + LinearBasis.  The f32 device feature matrix must
+    """a float64 child (RandomLaplace with dtype="f64") + LinearBasis.  The f32 device feature matrix must
     not be used for the Gram while Err / m / gradients come from the f64 transform: `_elbo` against the f64 oracle."""
     bs, Parameter, Positive, SLM = _imports()
     rs = np.random.RandomState(2)
     N, d, n = 600, 3, 40
     X = rs.randn(N, d)
     y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.1 * rs.randn(N)
-    cat = bs.RandomLaplace(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())) \
+    cat = bs.RandomLaplace(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()), dtype="f64") \
         + bs.LinearBasis(onescol=True)
     assert cat.bases[0].dtype == "f64" and cat.gram(X, y, np.ones(d)) is None and cat.device_fit_state(X, y) is None
     slm = SLM(cat)
@@ -219,6 +219,68 @@ def test_concat_with_float64_child_uses_float64_statistics():
     Ps = np.hstack((orc.rff_transform(Xs, W, ls), orc.linear_transform(Xs, True)))
     Eo, Vo = orc.slm_predict_moments(Ps, o["m"], o["C"], 0.3)
     assert normwise(Ey, Eo) < 1e-7 and normwise(Vy, Vo) < 1e-7
+
+
+def test_laplace_float64_phase_basis_takes_the_resident_f32_routes():
+    """RandomLaplace (Cauchy W, phases of ~1e5 revolutions) in its default dtype -- the f32 pipeline with
+    float64 phases (RR_F32P64) -- takes the resident concatenated fit state, and its `_elbo`, fused Gram and
+    predict_moments match the float64 oracle at the f32 path's tolerance (1e-3; the plain f32 phase is 6e-2 off)."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(2)
+    N, d, n = 3000, 32, 192
+    X = rs.randn(N, d)  # NOT float32-representable: the resident copy must stay float64
+    y = np.sin(X @ rs.randn(d) / 3.0) + 0.1 * rs.randn(N)
+    lap = bs.RandomLaplace(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+    assert lap.dtype == "f32" and lap.phase64 and np.abs(lap.W).max() > 1e3
+    ls = np.linspace(0.8, 1.4, d)
+    W = lap.W
+    Phi_l = orc.rff_transform(X, W, ls)
+    # fused single-basis Gram and the resident single-basis _elbo
+    G, b, yty = lap.gram(X, y, ls)
+    Go, bo, _ = orc.gram_stats(Phi_l, y)
+    assert normwise(G, Go) < 1e-5 and normwise(b, bo) < 1e-5
+    cat = lap + bs.LinearBasis(onescol=True)
+    st = cat.device_fit_state(X, y)
+    assert type(st).__name__ == "CatFitState" and st.children[0].dX.dtype == np.float64
+    st.release()
+    Gc, bc, _ = cat.gram(X, y, ls)
+    Phi = np.hstack((Phi_l, orc.linear_transform(X, True)))
+    assert normwise(Gc, Phi.T @ Phi) < 1e-5 and normwise(bc, Phi.T @ y) < 1e-5
+    F = Phi.shape[1]
+    dP = np.zeros((N, F, d))
+    dP[:, :2 * n, :] = orc.rff_grad(X, W, ls)
+    rd = np.concatenate((np.full(2 * n, 1.5), np.full(d + 1, 0.7)))
+    o = orc.slm_elbo(Phi, y, 0.3, rd, [slice(0, 2 * n), slice(2 * n, F)], [dP[:, :, i] for i in range(d)])
+    for basis, reg, ref in ((cat, [1.5, 0.7], o), (lap, 1.5, None)):
+        slm = SLM(basis)
+        slm.obj_ = -np.inf
+        slm._state = slm._make_state(X, y)
+        assert slm._state is not None
+        nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, 0.3, reg, ls)
+        slm._state.release()
+        slm._state = None
+        if ref is None:
+            dPl = orc.rff_grad(X, W, ls)
+            ref = orc.slm_elbo(Phi_l, y, 0.3, np.full(2 * n, 1.5), slice(None), [dPl[:, :, i] for i in range(d)])
+        assert abs(-nelbo - ref["elbo"]) < 1e-5 * abs(ref["elbo"])
+        assert normwise(slm.weights_, ref["m"]) < 1e-3
+        assert abs(-ndvar - ref["dvar"]) < 1e-3 * abs(ref["dvar"])
+        assert normwise(-np.atleast_1d(ndreg), np.array(ref["dreg"])) < 1e-3
+        assert normwise(-np.atleast_1d(ndhyp), np.array(ref["dhyp"])) < 2e-3
+    # predictions of the concatenation, covariance resident, variance as a sum of squares
+    slm = SLM(cat)
+    slm.var_, slm.regularizer_, slm.hypers_, slm.weights_, slm.covariance_ = 0.3, [1.5, 0.7], ls, o["m"], o["C"]
+    Xs = rs.randn(300, d)
+    Ey, Vy = slm.predict_moments(Xs)
+    Ps = np.hstack((orc.rff_transform(Xs, W, ls), orc.linear_transform(Xs, True)))
+    Eo, Vo = orc.slm_predict_moments(Ps, o["m"], o["C"], 0.3)
+    assert normwise(Ey, Eo) < 1e-3 and normwise(Vy, Vo) < 1e-3
+    assert normwise(slm.predict(Xs), Eo) < 1e-3
+    # the contraction entry point (glm.py:274-275) on the same basis
+    E = rs.randn(200, 2 * n)
+    dPl = orc.rff_grad(X[:200], W, ls)
+    want = np.array([(E * dPl[:, :, i]).sum() for i in range(d)])
+    assert normwise(lap.grad_contract(X[:200], E, ls), want) < 1e-3
 
 
 def test_default_linear_basis_model_predicts_on_device():
