@@ -2091,6 +2091,8 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
     if (chunk > N) chunk = N;
     // split-bf16 engine with the MFMA feature kernel: the features are produced directly in the SYRK's K-blocked
     // bf16 hi/lo layout (same 4 bytes per value), whole 64-row groups
+    RR_REQUIRE(!(F32 && c->deterministic && c->gram_engine != 0),
+               "gram: deterministic mode (rr_set_deterministic) needs the f32 engine, not a split 16-bit one");
     const bool fused_pb = F32 && !b->phase64 && c->gram_engine != 0 && rr_features_mfma_ok<TX>(b, (const TX *)dX, N, ldx);
     const int KBR = fused_pb ? 64 : KB;
     chunk = (chunk + KBR - 1) / KBR * KBR;
