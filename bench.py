@@ -609,7 +609,7 @@ def _median_ms(fn, reps=3):
     return float(np.median(ts)), r
 
 
-def _elbo_parity(make_basis, X, y, var, reg, ls, rows=512):
+def _elbo_parity(make_basis, X, y, var, reg, ls, rows=256):
     """One `_elbo` of the product on the first `rows` rows (resident route, device posterior) against the oracle's
     slm_elbo on the same rows in float64: (rel. error of -ELBO, normwise error of [dvar, dreg, dhyp])."""
     from revrand_amd.slm import StandardLinearModel
@@ -690,7 +690,7 @@ def config_elbo(dev, _hip, args, dtype="f32", N=1_000_000):
                          "frac_over_wall": (fl_row * N) / (t_eval * 1e-3) / 1e12 / peak,
                          "note": "row flops only in the two *_over_* fractions (the posterior's F^3 flops run on the f64 "
                                  "pipe and are reported on their own)"},
-            "parity_512_rows_vs_oracle": {"neg_elbo_rel_err": perr[0], "gradient_normwise_err": perr[1]}}
+            "parity_256_rows_vs_oracle": {"neg_elbo_rel_err": perr[0], "gradient_normwise_err": perr[1]}}
 
 
 def config_posterior(dev, _hip, args, F):

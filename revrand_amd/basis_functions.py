@@ -359,10 +359,10 @@ class _ResidentHost(object):
     def put(self, fm, X, r0, rows, col0, params):
         fm.put_host(self.basis.transform(X[r0:r0 + rows]), col0)
 
-    def gather(self, didx, M):
+    def gather(self, didx, M, dev=None, slot=None):
         pass
 
-    def put_batch(self, fm, M, col0, params):
+    def put_batch(self, fm, M, col0, params, slot=None):
         fm.put_host(self.basis.transform(np.zeros((M, self.ncols))), col0)  # a constant column: only the row count matters
 
     def release(self):
@@ -381,16 +381,15 @@ class _ResidentLinear(object):
     def put(self, fm, X, r0, rows, col0, params):
         fm.put_linear(_hip.DeviceView(self.dX, r0, rows), self.onescol, col0)
 
-    def gather(self, didx, M):
-        self.dXb = _gather_batch(self.dX, getattr(self, "dXb", None), didx, M)
+    def gather(self, didx, M, dev=None, slot=None):
+        _gather_slot(self, didx, M, dev, slot)
 
-    def put_batch(self, fm, M, col0, params):
-        fm.put_linear(_hip.DeviceView(self.dXb, 0, M), self.onescol, col0)
+    def put_batch(self, fm, M, col0, params, slot=None):
+        fm.put_linear(_hip.DeviceView(_batch_buffer(self, slot), 0, M), self.onescol, col0)
 
     def release(self):
         self.dX.free()
-        if getattr(self, "dXb", None) is not None:
-            self.dXb.free()
+        _free_batches(self)
 
 
 class _ResidentRFF(object):
@@ -410,16 +409,17 @@ class _ResidentRFF(object):
         self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
         fm.put_rff(self.h, _hip.DeviceView(self.dX, r0, rows), self.ls, col0)
 
-    def gather(self, didx, M):
-        self.dXb = _gather_batch(self.dX, getattr(self, "dXb", None), didx, M)
+    def gather(self, didx, M, dev=None, slot=None):
+        _gather_slot(self, didx, M, dev, slot)
 
-    def put_batch(self, fm, M, col0, params):
+    def put_batch(self, fm, M, col0, params, slot=None):
         self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
-        fm.put_rff(self.h, _hip.DeviceView(self.dXb, 0, M), self.ls, col0)
+        fm.put_rff(self.h, _hip.DeviceView(_batch_buffer(self, slot), 0, M), self.ls, col0)
 
     def batch(self, M):
         """The rows the feature matrix was last filled from: the gathered minibatch, or the first M resident rows."""
-        return _hip.DeviceView(self.dXb if getattr(self, "dXb", None) is not None else self.dX, 0, M)
+        cur = getattr(self, "_cur", None)
+        return _hip.DeviceView(cur if cur is not None else self.dX, 0, M)
 
     def reset(self):
         self.h.dev.memset(self.dT)
@@ -437,19 +437,42 @@ class _ResidentRFF(object):
     def release(self):
         self.dX.free()
         self.dT.free()
-        if getattr(self, "dXb", None) is not None:
-            self.dXb.free()
+        _free_batches(self)
 
 
-def _gather_batch(dX, dXb, didx, M):
-    """Rows didx of the resident matrix dX into a (grow-only) batch matrix of the same layout."""
-    dev = dX.dev
+def _gather_batch(dX, dXb, didx, M, dev=None):
+    """Rows didx of the resident matrix dX into a (grow-only) batch matrix of the same layout; on `dev`'s stream (default:
+    the context the data were uploaded through)."""
+    dev = dX.dev if dev is None else dev
     if dXb is None or dXb.shape[0] < M:
         if dXb is not None:
             dXb.free()
-        dXb = dev.empty_matrix(M, dX.shape[1], dX.dtype, ld_dev=dX.ld)
+        dXb = dX.dev.empty_matrix(M, dX.shape[1], dX.dtype, ld_dev=dX.ld)
     dev.gather_rows(dX, didx, M, dXb)
     return dXb
+
+
+# A resident child's gathered minibatches: `dXb` (the step gathers for itself) or, when the minibatch worker gathers
+# ahead of the step on its own stream, one of a few buffers in turn (`slot`); `_cur` = what the feature matrix was last
+# filled from (the gradient contraction of the same step reads it again).
+def _gather_slot(child, didx, M, dev, slot):
+    if slot is None:
+        child.dXb = _gather_batch(child.dX, getattr(child, "dXb", None), didx, M, dev)
+    else:
+        slots = child.__dict__.setdefault("_slots", {})
+        slots[slot] = _gather_batch(child.dX, slots.get(slot), didx, M, dev)
+
+
+def _batch_buffer(child, slot):
+    child._cur = child.dXb if slot is None else child._slots[slot]
+    return child._cur
+
+
+def _free_batches(child):
+    for buf in [getattr(child, "dXb", None)] + list(child.__dict__.get("_slots", {}).values()):
+        if buf is not None:
+            buf.free()
+    child.dXb, child._slots, child._cur = None, {}, None
 
 
 class _ResidentGeneric(object):
@@ -540,21 +563,62 @@ class MinibatchFeatures(object):
         self.resident = True
         return True
 
-    def assemble_idx(self, idx, hypers):
-        """`assemble` for rows `idx` of the resident data."""
+    def assemble_idx(self, idx, hypers, gathered=None):
+        """`assemble` for rows `idx` of the resident data; `gathered`: the token of `prefetch_batch` for these rows (the
+        index upload and the gathers are done already, in buffer set `gathered.slot`)."""
         self.children = []
         M = len(idx)
         self._ensure(M, int(sum(self._dims)))
-        didx = self._stage("idx", idx, np.int32)
+        slot = None if gathered is None else gathered.slot
+        didx = self._stage("idx", idx, np.int32) if gathered is None else None
         self.fm.begin(M)
         args, col0 = list(hypers), 0
         for child, w in zip(self._kids, self._dims):
             mine, args = args[:child.nparams], args[child.nparams:]
-            child.gather(didx, M)
-            child.put_batch(self.fm, M, col0, mine)
+            if gathered is None:
+                child.gather(didx, M)
+            child.put_batch(self.fm, M, col0, mine, slot=slot)
             self.children.append((child, col0, w))
             col0 += w
         self.M = M  # (no synchronisation: the gathers and feature kernels run while the host prepares the step)
+
+    PREFETCH_SLOTS = 3  # the worker runs up to two steps ahead of the step on the device
+
+    def prefetch_batch(self, updev, idx, y, rowarg):
+        """On the minibatch worker thread, for a FUTURE step: upload the row indices, gather every child's rows and upload
+        the targets -- on the upload context's stream (`updev`, a second context of the same GPU), into one of
+        PREFETCH_SLOTS buffer sets in turn, finished before this returns.  The step then starts with its feature kernels:
+        none of these copies (each synchronises a stream) is left on its critical path."""
+        slot = self.__dict__.get("_pf_turn", 0) % self.PREFETCH_SLOTS
+        self._pf_turn = self.__dict__.get("_pf_turn", 0) + 1
+        M = len(idx)
+
+        def stage(name, arr, dtype):
+            arr = np.ascontiguousarray(arr, dtype=dtype)
+            key = (name, slot)
+            buf = self._stage_bufs.get(key)
+            if buf is None or buf.nbytes < arr.nbytes:
+                if buf is not None:
+                    buf.free()
+                buf = self._stage_bufs[key] = updev.malloc(max(arr.nbytes, 4))
+            if arr.nbytes:
+                _hip._check(updev.lib, updev.lib.rr_memcpy_h2d(updev.ctx, buf.ptr, arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+            buf.shape, buf.dtype = arr.shape, arr.dtype
+            return buf
+        didx = stage("idx", idx, np.int32)
+        for child in self._kids:
+            child.gather(didx, M, dev=updev, slot=slot)
+        dy = stage("y", y, np.float32)
+        dn = None if rowarg is None else stage("rowarg", rowarg, np.float32)
+        updev.sync()
+        return _Gathered(slot, M, dy, dn, id(y), rowarg is None)
+
+    def take_prefetched_targets(self, gathered, y, rowarg):
+        """The step's targets are the ones `prefetch_batch` uploaded (checked: same array, same kind of row argument)."""
+        if gathered.key != (id(y), len(y), rowarg is None):
+            return False  # not this step's arrays (a wrapper copied them): the step uploads its own
+        self._targets = gathered.key + (gathered.dy, gathered.dn)
+        return True
 
     def assemble(self, X, hypers):
         self._targets = None  # this route never stages ahead
@@ -632,6 +696,14 @@ class MinibatchFeatures(object):
             buf.free()
         self._stage_bufs, self._targets = {}, None
         self.fm = None
+
+
+class _Gathered(object):
+    """A minibatch made ready on the device ahead of its step (MinibatchFeatures.prefetch_batch)."""
+
+    def __init__(self, slot, M, dy, dn, yid, no_rowarg):
+        self.slot, self.M, self.dy, self.dn = slot, M, dy, dn
+        self.key = (yid, M, no_rowarg)
 
 
 class CatFitState(_DevicePosterior):

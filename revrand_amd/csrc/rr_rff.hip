@@ -2096,12 +2096,13 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
     const bool fused_pb = F32 && !b->phase64 && c->gram_engine != 0 && rr_features_mfma_ok<TX>(b, (const TX *)dX, N, ldx);
     const int KBR = fused_pb ? 64 : KB;
     chunk = (chunk + KBR - 1) / KBR * KBR;
-    // More than one chunk: chunk k+1's feature kernel (VALU trig + HBM writes) runs on a second stream while chunk k's SYRK
-    // (LDS-DMA + MFMA) runs on the context's, into the other half of a double-buffered scratch -- the SYRK kernels never
-    // wait for features except for the first chunk.  RR_GRAM_OVERLAP=0 switches it off (A/B runs); the deterministic mode's
-    // shared scratch of ordered partial sums (rr_internal.h) is single-stream, so it does too.
-    static const bool overlap_off = getenv("RR_GRAM_OVERLAP") != nullptr && atoi(getenv("RR_GRAM_OVERLAP")) == 0;
-    const bool overlap = N > chunk && !overlap_off && !c->deterministic;
+    // RR_GRAM_OVERLAP=1 (opt-in; measured in round 3, profiles/r03_overlap): with more than one chunk, chunk k+1's feature
+    // kernel runs on a second stream while chunk k's SYRK runs on the context's, into the other half of a double-buffered
+    // scratch.  It does not pay on gfx950: the feature kernel's VALU / MFMA issue comes straight out of the co-resident SYRK
+    // waves' MFMA issue (no co-execution), so the SYRK kernel slows by what the features save (1095 -> 1120 ms
+    // per 10M rows against 31 ms of hidden features).  Off by default; never in deterministic mode (single-stream scratch).
+    static const bool overlap_on = getenv("RR_GRAM_OVERLAP") != nullptr && atoi(getenv("RR_GRAM_OVERLAP")) != 0;
+    const bool overlap = N > chunk && overlap_on && !c->deterministic;
     const int nbuf = overlap ? 2 : 1;
     int rc = ensure_zbuf(b, (size_t)nbuf * (size_t)chunk * ldp * sizeof(TC));
     if (rc != RR_OK) return rc;

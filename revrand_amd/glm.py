@@ -127,6 +127,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             # (one upload context per process and device, shared by every fit: a context is a stream and two events, and a
             # cross-validation loop must not accumulate them)
             self.__dict__["_draw_upload"] = (_hip.get_upload_device(_hip.get_device().index), [None, None, None], [0])
+        # (RR_GLM_BATCH_PREFETCH=0: measurement switch, the step uploads its indices / targets and gathers its rows itself)
+        if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0":
+            self.__dict__["_batch_upload"] = _hip.get_upload_device(_hip.get_device().index)
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
@@ -134,6 +137,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         finally:
             self._resident_fit = False
             self._release_features()
+            self.__dict__.pop("_batch_upload", None)
             up = self.__dict__.pop("_draw_upload", None)
             if up is not None:
                 for buf in up[1]:
@@ -163,9 +167,22 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         not depend on parameters (Poisson / binomial log-factorial sums: 0.15 ms of a 5 ms config-5 step), and -- with the
         reference's random stream -- the step's draws (`_draw_ahead`)."""
         batch = list(batch)
+        resident = getattr(self, "_resident_fit", False)
+        spec = None
         if getattr(self.likelihood, "spec_is_parameter_free", False):
-            extra = batch[2:-1] if getattr(self, "_resident_fit", False) else batch[2:]  # likelihood arguments of the batch
-            batch.append(_Spec(self.likelihood.device_spec(batch[1], [], extra)))
+            extra = batch[2:-1] if resident else batch[2:]  # likelihood arguments of the batch
+            spec = self.likelihood.device_spec(batch[1], [], extra)
+        # resident data: the batch's index upload, row gathers and target upload happen here too, on the upload context's
+        # stream, while an earlier step runs (the per-row likelihood argument is known ahead unless it depends on parameters)
+        gathered = None
+        up = self.__dict__.get("_batch_upload")
+        if resident and up is not None and (spec is not None or isinstance(self.likelihood, Gaussian)):
+            rowarg = spec[2] if spec is not None else None
+            gathered = _Batch(self._features().prefetch_batch(up, batch[-1], batch[1], rowarg))
+        if spec is not None:
+            batch.append(_Spec(spec))
+        if gathered is not None:
+            batch.append(gathered)
         if self.sampler != "device" and self._prefetch_draws:
             batch = self._draw_ahead(batch)
         return batch
@@ -207,6 +224,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         state.pop("_mbf", None)
         state.pop("_serve_feats", None)
         state.pop("_draw_upload", None)
+        state.pop("_batch_upload", None)
         return state
 
     def _drop_serving(self):
@@ -222,9 +240,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         lpars_l = atleast_list(lpars)
 
         draws, spec = None, None
-        while largs and isinstance(largs[-1], (_Draws, _Spec)):              # made ahead on the worker (`_ahead`)
+        gathered = None
+        while largs and isinstance(largs[-1], (_Draws, _Spec, _Batch)):      # made ahead on the worker (`_ahead`)
             if isinstance(largs[-1], _Draws):
                 draws = largs[-1].e
+            elif isinstance(largs[-1], _Batch):
+                gathered = largs[-1].token
             else:
                 spec = largs[-1].spec
             largs = largs[:-1]
@@ -235,7 +256,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # everything the step needs from the host goes first (likelihood constants, the targets' upload): the feature
         # kernels launched next then run while the host gets to the step's own call, instead of being waited for
         lid, lpar, rowarg, llconst = spec if spec is not None else self.likelihood.device_spec(y, lpars_l, largs)
-        if resident:
+        if resident and gathered is not None:
+            if not feats.take_prefetched_targets(gathered, y, rowarg):
+                feats.stage_targets(y, rowarg)
+            feats.assemble_idx(idx, atleast_list(bpars), gathered)
+        elif resident:
             feats.stage_targets(y, rowarg)
             feats.assemble_idx(idx, atleast_list(bpars))
         else:
@@ -440,6 +465,13 @@ def _submit(fn, *args):
         from concurrent.futures import ThreadPoolExecutor
         _pool = (os.getpid(), ThreadPoolExecutor(max_workers=1, thread_name_prefix="revrand-glm"))
     return _pool[1].submit(fn, *args)
+
+
+class _Batch(object):
+    """A minibatch gathered on the device ahead of its step, riding behind the batch's arguments (`_ahead`)."""
+
+    def __init__(self, token):
+        self.token = token
 
 
 class _Spec(object):

@@ -60,7 +60,8 @@ def test_asan_build_runs_the_ragged_shape_tests():
     # every test passed, and no ASan report has a frame of this library in it.  (The HSA runtime bundled with torch
     # occasionally trips ASan inside libhsa-runtime64.so while the process exits, after the summary line: not ours.)
     import re
-    assert re.search(r"\b\d+ passed\b", r.stdout) and not re.search(r"\b(failed|error)\b", r.stdout), r.stdout[-2500:]
+    assert re.search(r"\b\d+ passed\b", r.stdout) and not re.search(r"\b(failed|error)\b", r.stdout), \
+        (r.stdout[-2500:], r.stderr[-4000:])
     reports = (r.stdout + r.stderr).split("ERROR: AddressSanitizer")[1:]
     assert not any("librevrand_hip" in rep for rep in reports), (r.stdout + r.stderr)[-4000:]
 

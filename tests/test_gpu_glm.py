@@ -359,6 +359,42 @@ def test_resident_minibatch_gather_equals_host_gather():
     assert not c.make_resident(X)
 
 
+def test_minibatches_gathered_ahead_on_the_worker_equal_minibatches_gathered_by_the_step(monkeypatch):
+    """with the data resident, the minibatch worker uploads a future step's row indices and targets and
+    gathers its rows on a second stream while the current step runs (three buffer sets in turn).  Same batches, same
+    draws: the fit equals the fit whose steps do all of that themselves (RR_GLM_BATCH_PREFETCH=0), to the rounding of the
+    step's atomic sums; binomial (a per-row likelihood argument) and Gaussian (parameter-dependent spec) included."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    from revrand_amd.basis_functions import MinibatchFeatures
+    rs = np.random.RandomState(5)
+    N, d = 6000, 5
+    X = rs.randn(N, d)
+    f = 0.8 * np.sin(X[:, 0]) + 0.3 * X[:, 1]
+    cases = [(lk.Poisson(), rs.poisson(np.exp(f)).astype(float), ()),
+             (lk.Binomial(), rs.binomial(7, 1 / (1 + np.exp(-f))).astype(float), (7 * np.ones(N),)),
+             (lk.Gaussian(), f + 0.1 * rs.randn(N), ())]
+    calls = []
+    orig = MinibatchFeatures.prefetch_batch
+
+    def counting(self, updev, idx, y, rowarg):
+        calls.append(len(idx))
+        return orig(self, updev, idx, y, rowarg)
+    monkeypatch.setattr(MinibatchFeatures, "prefetch_batch", counting)
+    for lik, y, largs in cases:
+        fits = []
+        for pf in ("1", "0"):
+            monkeypatch.setenv("RR_GLM_BATCH_PREFETCH", pf)
+            calls.clear()
+            basis = bs.RandomRBF(nbases=40, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+                + bs.LinearBasis(onescol=True)
+            glm = GLM(lik, basis, K=2, nsamples=8, batch_size=500, maxiter=12, nstarts=2, random_state=3)
+            glm.fit(X, y, likelihood_args=largs)
+            assert (len(calls) > 10) == (pf == "1"), (pf, len(calls))
+            fits.append(np.concatenate((glm.weights_.ravel(), glm.covariance_.ravel(),
+                                        np.concatenate([np.atleast_1d(h) for h in glm.basis_hypers_ if np.size(h)]))))
+        assert normwise(fits[0], fits[1]) < 1e-5, type(lik).__name__
+
+
 def _gloo_gpu_glm_worker(rank, world, port, q):
     """One rank of the row-sharded SVI with the REAL device features (both ranks share GPU 0); gloo carries the one
     all-reduce per step on the host.  Mirrors tests/test_dist_gloo.py::_glm_worker without its NumPy stand-in."""

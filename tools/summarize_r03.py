@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Copy the rocprofv3 summaries of a tools/prof_r03.sh run (gpurun_out/prof_r03) into profiles/r03_<name>/ and derive a
+summary.json per profile: every kernel's calls / average / total from rocprofv3's own stats, and -- for the kernels that
+carry the flops or bytes of the profiled configuration -- rows per launch, algorithmic work per launch, the achieved rate
+from rocprofv3's average duration of the FULL-SIZE launches and the fraction of the peak that bounds them.
+
+    python tools/summarize_r03.py
+"""
+import csv
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r03")
+PEAK = {"f32": 157.3e12, "f64": 78.6e12, "hbm": 8.0e12}
+
+
+def bench_line(tag):
+    p = os.path.join(SRC, tag + ".json")
+    if not os.path.exists(p):
+        return None
+    lines = [l for l in open(p) if l.startswith("{")]
+    return json.loads(lines[-1]) if lines else None
+
+
+def kernel_stats(tag):
+    p = os.path.join(SRC, tag, "kt_kernel_stats.csv")
+    out = {}
+    if os.path.exists(p):
+        for r in csv.DictReader(open(p)):
+            out[r["Name"]] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                              "total_ms": float(r["TotalDurationNs"]) / 1e6, "min_ms": float(r["MinNs"]) / 1e6,
+                              "max_ms": float(r["MaxNs"]) / 1e6}
+    return out
+
+
+def kernel_trace(tag):
+    p = os.path.join(SRC, tag, "kt_kernel_trace.csv")
+    out = []
+    if os.path.exists(p):
+        for r in csv.DictReader(open(p)):
+            out.append((r["Kernel_Name"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6,
+                        int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    return out
+
+
+def full_size(durs, frac=0.9):
+    """(average, count) over the launches within `frac` of the longest-half median: the full-size ones."""
+    durs = sorted(durs)
+    if not durs:
+        return None, 0
+    ref = durs[len(durs) // 2:]
+    ref = ref[len(ref) // 2]
+    top = [d for d in durs if d > frac * ref and d < ref / frac]
+    return sum(top) / len(top), len(top)
+
+
+def put(name, tag, summary, extra=()):
+    dst = os.path.join(ROOT, "profiles", name)
+    os.makedirs(dst, exist_ok=True)
+    files = [(os.path.join(SRC, tag, "kt_kernel_stats.csv"), "kernel_stats.csv"),
+             (os.path.join(SRC, tag + ".json"), "bench_under_rocprof.json")] + list(extra)
+    for src, dname in files:
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(dst, dname))
+    json.dump(summary, open(os.path.join(dst, "summary.json"), "w"), indent=1)
+    print(name, json.dumps(summary)[:400])
+
+
+def annotate(trace, prefix, work, peak, unit, rows=None, what=""):
+    durs = [d for n, d, _, _ in trace if n.replace("void ", "").startswith(prefix)]
+    avg, nfull = full_size(durs)
+    if avg is None:
+        return None
+    rate = work / (avg * 1e-3)
+    return {"full_size_launches": nfull, "all_launches": len(durs), "avg_ms_full_size": avg, "rows_per_launch": rows,
+            "algorithmic_work_per_launch": work, "unit": unit, "achieved": rate / (1e12 if unit == "flop" else 1e9),
+            "achieved_unit": "TFLOP/s" if unit == "flop" else "GB/s", "frac_of_peak": rate / peak, "what": what}
+
+
+F, d, n = 4096, 32, 2048
+
+# ---- headline: N = 10M, 5 launches of 2M rows per pass ----
+for tag, name in (("headline_kt", "r03_headline"), ("overlap_off_kt", "r03_overlap"), ("det_kt", "r03_deterministic")):
+    b = bench_line(tag)
+    if not b:
+        continue
+    st, tr = kernel_stats(tag), kernel_trace(tag)
+    rows = b["roofline"]["rows_per_step"] // max(b["roofline"]["launches_per_step"], 1)
+    off = b["roofline"]["flops_per_row"]
+    ks = {"rr_syrk_f32_kernel": annotate(tr, "rr_syrk_f32_kernel(", off * rows, PEAK["f32"], "flop", rows, "off-diagonal 256x256 tiles of Phi^T Phi"),
+          "rr_syrk_f32_diag_kernel": annotate(tr, "rr_syrk_f32_diag_kernel(", (F * (F + 1.0) - off) * rows, PEAK["f32"], "flop", rows, "diagonal tiles"),
+          "rr_rff_features_mfma_kernel": annotate(tr, "rr_rff_features_mfma_kernel", rows * (4.0 * d + 4.0 + 4.0 * F), PEAK["hbm"], "byte", rows,
+                                                  "X Ws on MFMA + sin / cos -> P (HBM write), Phi^T y")}
+    summary = {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps %d --warmup %d --configs none (tools/prof_r03.sh)" % (b["steps"], b["warmup"]),
+               "bench_line": {k: b[k] for k in ("value", "ms_per_step", "roofline")}, "kernels": ks, "all_kernels": st}
+    if tag == "headline_kt" and tr:
+        # how much of the feature kernels' time ran UNDER a SYRK kernel (second stream): overlap of the intervals
+        feats = [(s, e) for nme, _, s, e in tr if "rr_rff_features_mfma_kernel" in nme]
+        syrk = [(s, e) for nme, _, s, e in tr if "rr_syrk_f32" in nme]
+        hidden = sum(max(0, min(e, e2) - max(s, s2)) for s, e in feats for s2, e2 in syrk) / 1e6
+        summary["feature_kernel_ms_total"] = sum(e - s for s, e in feats) / 1e6
+        summary["feature_kernel_ms_under_a_syrk_kernel"] = hidden
+    extra = []
+    if tag == "overlap_off_kt":
+        ab = {}
+        for arm in ("off", "on"):
+            vals = []
+            for rep in (1, 2):
+                bl = bench_line("overlap_%s_%d" % (arm, rep))
+                if bl:
+                    vals.append({"value": bl["value"], "ms_per_step": bl["ms_per_step"], "whole_path_frac": bl["roofline"]["whole_path_frac"],
+                                 "syrk_ms": bl["roofline"]["kernel_ms_per_step"], "other": bl["roofline"]["other_kernels_ms_per_step"]})
+            ab["RR_GRAM_OVERLAP=%d" % (arm == "on")] = vals
+        summary["ab_unprofiled_bench_lines"] = ab
+    put(name, tag, summary, extra)
+
+# ---- one _elbo evaluation (f32, N = 1M; f64, N = 200k) ----
+for tag, name, key, peak, es in (("elbo_kt", "r03_elbo", "C2_elbo_eval", PEAK["f32"], 4), ("elbo64_kt", "r03_elbo_f64", "C2f64_elbo_eval_n200k", PEAK["f64"], 8)):
+    b = bench_line(tag)
+    if not b or key not in b.get("configs", {}) or "error" in b["configs"][key]:
+        continue
+    cfg, st, tr = b["configs"][key], kernel_stats(tag), kernel_trace(tag)
+    N = cfg["rows"]
+    Fp = F
+    p2rows = min(N, ((24 << 30) // (12 * Fp) + 255) // 256 * 256) if es == 4 else None
+    ks = {}
+    if es == 4:
+        ks["rr_syrk_f32_kernel"] = annotate(tr, "rr_syrk_f32_kernel(", (F * (F + 1.0) - 16 * 256 * 257.0) * N, peak, "flop", N, "statistics pass")
+        ks["rr_gemm_tn_f32_kernel"] = annotate(tr, "rr_gemm_tn_f32_kernel", 2.0 * F * F * p2rows, peak, "flop", p2rows, "second pass: U = Phi C")
+        ks["rr_grad_t_kernel"] = annotate(tr, "rr_grad_t_kernel", 2.0 * d * n * p2rows, PEAK["f32"], "flop", p2rows, "second pass: X^T A contraction (VALU)")
+    else:
+        ks["rr_syrk_f64_kernel"] = annotate(tr, "rr_syrk_f64_kernel(", (F * F - 128.0 * F) * N, peak, "flop", N, "statistics pass (off-diagonal tiles)")
+        ks["rr_gemm_tn_f64_kernel"] = annotate(tr, "rr_gemm_tn_f64_kernel", 2.0 * F * F * N, peak, "flop", N, "second pass: U = Phi C (largest launches; the posterior's trailing updates use the same kernel)")
+    put(name, tag, {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --rows 1000000 --steps 1 --warmup 0 --configs %s" % key.lower(),
+                    "config": cfg, "kernels": ks, "all_kernels": st})
+
+# ---- the rest: stats + the bench entry ----
+for tag, name, keys in (("posdef_kt", "r03_posdef", ("posterior_F4096", "posterior_F8257")), ("predict_kt", "r03_predict", ("predict_moments_n300k",)),
+                        ("laplace_kt", "r03_laplace", ("C2laplace_f64phase_n1m",)), ("c4_kt", "r03_c4_fastfood", ("C4_fastfood_f16384",)),
+                        ("c5_kt", "r03_c5_glm", ("C5_glm_poisson_svi_step",)), ("c3_kt", "r03_c3", ("C3_matern52_linear_concat_one_gpu_share",))):
+    b = bench_line(tag)
+    if not b:
+        continue
+    st, tr = kernel_stats(tag), kernel_trace(tag)
+    cfgs = {k: b.get("configs", {}).get(k) for k in keys}
+    ks = {}
+    if name == "r03_laplace" and cfgs[keys[0]]:
+        N = cfgs[keys[0]]["rows"]
+        ks["rr_rff_features_mfma64_kernel"] = annotate(tr, "rr_rff_features_mfma64_kernel", N * (8.0 * d + 8.0 + 4.0 * F), PEAK["hbm"], "byte", N,
+                                                       "float64 X in, float64 phases on the f64 MFMA, float32 sin / cos, float32 P out")
+        ks["rr_syrk_f32_kernel"] = annotate(tr, "rr_syrk_f32_kernel(", (F * (F + 1.0) - 16 * 256 * 257.0) * N, PEAK["f32"], "flop", N, "same SYRK as RandomRBF")
+    if name == "r03_predict" and cfgs[keys[0]]:
+        ks["rr_gemm_tn_f32_kernel"] = annotate(tr, "rr_gemm_tn_f32_kernel", 1.0 * F * F * 65536 * 1.0, PEAK["f32"], "flop", 65536,
+                                               "Phi B with the upper-triangular factor B: F^2 flop per row (half of 2 F^2)")
+    if name == "r03_c4_fastfood" and cfgs[keys[0]]:
+        r = cfgs[keys[0]]["roofline"]
+        ks["rr_fastfood16_kernel"] = annotate(tr, "rr_fastfood16_kernel", r["bytes_per_row"] * r["rows_per_launch"], PEAK["hbm"], "byte", r["rows_per_launch"],
+                                              "FastFood chain -> Phi (HBM write)")
+    put(name, tag, {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --rows 1000000 --steps 1 --warmup 0 --configs %s" % ",".join(k.lower() for k in keys),
+                    "configs": cfgs, "kernels": ks, "all_kernels": st})
