@@ -652,6 +652,7 @@ def config_elbo(dev, _hip, args, dtype="f32", N=1_000_000):
     basis = make_basis()
     slm = StandardLinearModel(basis)
     slm.obj_ = -np.inf
+    slm._defer_cov = True  # as inside fit(): the best posterior covariance stays in HBM until the optimiser is done
     st = slm._state = basis.device_fit_state(X, y)
     ls, var, reg = np.linspace(0.8, 1.3, d), 0.5, 1.0
     iL = np.full(F, 1.0 / reg)

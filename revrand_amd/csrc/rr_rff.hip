@@ -1086,6 +1086,169 @@ rr_syrk_f32_diag_kernel(const SyrkArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
+// The diagonal-tile kernel with the eight DIAGONAL 32x32 blocks of a tile done as 16x16 sub-blocks (round 3).  Every wave
+// of the kernel above owns exactly one block on the tile's diagonal (block-row == block-column), of which only the upper
+// triangle is needed; as one v_mfma_f32_32x32x2_f32 per k-step it is computed whole (the "89 % bound" of DESIGN 9.4).
+// v_mfma_f32_16x16x4_f32 has the same rate per flop (32 cycles for 16 x 16 x 4), so the block is split into its three
+// upper 16x16 sub-blocks (0,0), (0,1), (1,1): 3 x 32 = 96 cycles per four rows instead of 2 x 64 = 128.  Its operands are
+// one float per lane (lane l: row 4P + (l >> 4) of the k-step pair, column c + (l & 15)) and serve as A and B alike:
+//   X0 = columns [c, c + 16), X1 = columns [c + 16, c + 32):  D00 += X0^T X0, D01 += X0^T X1, D11 += X1^T X1.
+// A SIMD (waves w, w + 4) then issues 1088 instead of 1152 MFMA cycles per k-step pair (-5.6 %).  ED = the position of
+// the diagonal block in the wave's list (RR_DIAG_I / RR_DIAG_J): compile time, one instantiation per distinct (NB, ED).
+// ---------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+template <int OFF>
+__device__ __forceinline__ float lds_read_b32_off(unsigned addr) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(OFF));
+    return r;
+}
+
+template <int NB, int ED>
+struct KOpsD16 {
+    float2v a[NB], b[NB];  // entry ED is not used
+    float x0, x1;
+    template <int P>
+    __device__ __forceinline__ void load(const unsigned (&abase)[NB], const unsigned (&bbase)[NB], unsigned xbase) {
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            if (e != ED) a[e] = lds_read2st64<16 * P, 16 * P + 8>(abase[e]);
+#pragma unroll
+        for (int e = 0; e < NB; ++e)
+            if (e != ED) b[e] = lds_read2st64<16 * P, 16 * P + 8>(bbase[e]);
+        x0 = lds_read_b32_off<4096 * P>(xbase);       // rows 4P + (lane >> 4): 4 rows of 1 KiB per k-step pair
+        x1 = lds_read_b32_off<4096 * P + 64>(xbase);  // 16 columns to the right
+    }
+};
+
+// MFMAs [FIRST, LAST) of a k-step pair: the NB - 1 off-diagonal blocks' first k-step, the diagonal block's three 16x16x4
+// products (both k-steps at once), the off-diagonal blocks' second k-step
+template <int NB, int ED, int FIRST, int LAST>
+__device__ __forceinline__ void gram_mfma_d16(const KOpsD16<NB, ED> &o, floatx16 (&acc)[NB], floatx4 (&dd)[3]) {
+#pragma unroll
+    for (int q = FIRST; q < LAST; ++q) {
+        if (q < NB - 1 || q >= NB + 2) {
+            const int s_ = q < NB - 1 ? 0 : 1;
+            const int r_ = q < NB - 1 ? q : q - (NB + 2);
+            const int e = r_ < ED ? r_ : r_ + 1;
+            acc[e] = __builtin_amdgcn_mfma_f32_32x32x2f32(o.a[e][s_], o.b[e][s_], acc[e], 0, 0, 0);
+        } else {
+            const int t = q - (NB - 1);  // 0: (0,0)  1: (0,1)  2: (1,1)
+            dd[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(t == 2 ? o.x1 : o.x0, t == 0 ? o.x0 : o.x1, dd[t], 0, 0, 0);
+        }
+    }
+}
+
+#define RR_PAIRD16(P, CUR, NXT)                                \
+    lds_wait();                                                \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_d16<NB, ED, 0, 1>(CUR, acc, dd);                 \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase, xbase); \
+    __builtin_amdgcn_sched_barrier(0);                         \
+    gram_mfma_d16<NB, ED, 1, 2 * NB + 1>(CUR, acc, dd);        \
+    __builtin_amdgcn_sched_barrier(0);
+
+template <int NB, int ED>
+__device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, int wave, int lane) {
+    const int ta = blockIdx.x % p.nb;
+    const int ks = blockIdx.x / p.nb;
+    const int ca = ta * GR_TC;
+    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_end = row_begin + p.rows_per_split;
+    if (row_end > p.rows) row_end = p.rows;
+
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned lane_off = 4u * ((lane >> 5) * GR_TC + (lane & 31));  // 32x32x2 operands: row stride 1024 B
+    int bi[NB], bj[NB];
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        bi[e] = RR_DIAG_I[wave][e];
+        bj[e] = RR_DIAG_J[wave][e];
+    }
+    RR_DEV_ASSERT(bi[ED] == bj[ED]);
+    const unsigned lane_off16 = 4u * ((lane >> 4) * GR_TC + 32 * bi[ED] + (lane & 15));  // 16x16x4 operands
+    floatx16 acc[NB];
+    floatx4 dd[3];
+#pragma unroll
+    for (int e = 0; e < NB; ++e)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[e][k] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dd[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    auto dma_tile = [&](float *buf, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            RR_DEV_ASSERT(kb0 + lr < p.rows && ca + GR_TC <= p.ldp && p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0);
+            const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * GR_TC), 16, 0, 0);
+        }
+    };
+
+    const int64_t nkb = (row_end - row_begin) / GR_KB;
+    if (nkb > 0) {
+        dma_tile(lds, row_begin);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_TC), row_begin + (kb + 1) * GR_KB);
+            unsigned abase[NB], bbase[NB];
+#pragma unroll
+            for (int e = 0; e < NB; ++e) {
+                abase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bi[e];
+                bbase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bj[e];
+            }
+            const unsigned xbase = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off16;
+            KOpsD16<NB, ED> o0, o1;
+            o0.template load<0>(abase, bbase, xbase);
+            RR_PAIRD16(0, o0, o1) RR_PAIRD16(1, o1, o0) RR_PAIRD16(2, o0, o1) RR_PAIRD16(3, o1, o0)
+            RR_PAIRD16(4, o0, o1) RR_PAIRD16(5, o1, o0) RR_PAIRD16(6, o0, o1) RR_PAIRD16(7, o1, o0)
+            __syncthreads();
+        }
+    }
+
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+        if (e == ED) continue;
+        const int64_t gc = ca + 32 * bj[e] + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int64_t gr = ca + 32 * bi[e] + (k & 3) + 8 * (k >> 2) + 4 * hi;
+            if (gr <= gc) rr_syrk_out(p, ks, gr, gc, acc[e][k]);
+        }
+    }
+    // the diagonal block's three 16x16 sub-blocks (C/D of the 16x16 forms: column = lane & 15, row = 4 (lane >> 4) + register)
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+        const int64_t gc = ca + 32 * bi[ED] + (t >= 1 ? 16 : 0) + (lane & 15);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t gr = ca + 32 * bi[ED] + (t == 2 ? 16 : 0) + 4 * (lane >> 4) + k;
+            if (gr <= gc) rr_syrk_out(p, ks, gr, gc, dd[t][k]);
+        }
+    }
+}
+#undef RR_PAIRD16
+
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_f32_diag16_kernel(const SyrkArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_TC];  // 64 KiB: two [32][256] tiles (A side only)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    switch (wave) {  // wave-uniform: every path runs the same barriers; (NB, ED) as laid out in RR_DIAG_I / RR_DIAG_J
+        case 0: case 1: case 2: case 3: syrk_diag16_body<5, 0>(p, lds, wave, lane); break;
+        case 4: syrk_diag16_body<4, 3>(p, lds, wave, lane); break;
+        case 5: syrk_diag16_body<4, 2>(p, lds, wave, lane); break;
+        case 6: syrk_diag16_body<4, 1>(p, lds, wave, lane); break;
+        default: syrk_diag16_body<4, 0>(p, lds, wave, lane); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // f64 Gram: G(upper) += P^T P with v_mfma_f64_16x16x4_f64 (78.6 TFLOP/s peak).  Same structure
 // as the f32 kernel at half the tile: 128x128 block of G per workgroup of 4 waves (64x64 per
 // wave = 16 accumulators of 4 f64), k-blocks of 16 rows arriving by LDS-DMA as [16][128 | 128]
@@ -1995,7 +2158,12 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         SyrkArgs ad = a;
         ad.nb = nb_all;
         ad.rows_per_split = rps_d;
-        hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
+        // diagonal blocks as 16x16 sub-blocks (round 3); RR_SYRK_NO_DIAG16=1: the whole-block kernel of round 2 (A/B runs)
+        static const bool no_diag16 = getenv("RR_SYRK_NO_DIAG16") != nullptr;
+        if (no_diag16)
+            hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
+        else
+            hipLaunchKernelGGL(rr_syrk_f32_diag16_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
     }
     if (a.part)
         hipLaunchKernelGGL(rr_syrk_det_reduce_kernel<float>, dim3((unsigned)((F + 1 + 255) / 256), (unsigned)F), dim3(256), 0,
