@@ -447,7 +447,9 @@ def _gather_batch(dX, dXb, didx, M, dev=None):
     if dXb is None or dXb.shape[0] < M:
         if dXb is not None:
             dXb.free()
-        dXb = dX.dev.empty_matrix(M, dX.shape[1], dX.dtype, ld_dev=dX.ld)
+        # allocated (and zero-filled) through the context whose stream gathers into it: a fill queued on another stream
+        # could land after the gather
+        dXb = dev.empty_matrix(M, dX.shape[1], dX.dtype, ld_dev=dX.ld)
     dev.gather_rows(dX, didx, M, dXb)
     return dXb
 

@@ -36,6 +36,15 @@ def _pytest_with(lib, args, preload=None, timeout=1500):
     env = dict(os.environ, REVRAND_HIP_LIB=lib)
     if preload:
         env.update(LD_PRELOAD=preload, ASAN_OPTIONS="detect_leaks=0:protect_shadow_gap=0:abort_on_error=1")
+        # The (uninstrumented) HIP runtime must tolerate a preloaded ASan runtime: the copy bundled with the torch wheel
+        # does; /opt/rocm's aborts inside its own initialisation under the preload (ROCm ships separate ASan builds of its
+        # libraries for that).  What is under test is the host side of librevrand_hip_asan.so, not the runtime.
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                env["RR_HIP_RUNTIME"] = "torch"
+        except (ImportError, ValueError):
+            pass
     return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT, env=env,
                           capture_output=True, text=True, timeout=timeout)
 
