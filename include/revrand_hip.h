@@ -221,6 +221,30 @@ int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t l
 int rr_featmat_put_host(rr_featmat *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0);
 int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty);
 
+/* ---- the same in FLOAT64: the feature matrix of a concatenation with a dtype="f64" child -------------------
+ * BasisCat.transform's hstack (basis_functions.py:1599-1627) in float64 in HBM, reduced by the f64 MFMA SYRK
+ * (slm.py:146,157) and consumed by the second pass of _elbo (slm.py:160-197) and predict_moments (slm.py:240-244) in
+ * float64 -- the reference's arithmetic end to end (north star: 1e-5 relative in fp64) for a resident concatenated fit.
+ * Same protocol as rr_featmat_*: begin(rows); every child puts its column block (random Fourier children are evaluated in
+ * float64 whatever their own arithmetic); gram accumulates into DEVICE f64 buffers; pass2_begin(m, C) -> pass2_rows(dy) ->
+ * pass2_rff per random Fourier child -> pass2_end(&sqErr), or pass2_begin -> predict_rows(Ey, Vf).  C: host (F, F) or,
+ * with c_on_device != 0, a device pointer (rr_posterior_dev's output).  No GLM step, no split engines. */
+typedef struct rr_featmat64 rr_featmat64;
+int rr_featmat64_create(rr_ctx *ctx, int64_t max_rows, int64_t F, rr_featmat64 **out);
+void rr_featmat64_destroy(rr_featmat64 *fm);
+int rr_featmat64_begin(rr_featmat64 *fm, int64_t rows);
+int rr_featmat64_put_rff(rr_featmat64 *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx,
+                         const double *lenscale, int n_ls, int64_t col0);
+int rr_featmat64_put_linear(rr_featmat64 *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol, int64_t col0);
+int rr_featmat64_put_host(rr_featmat64 *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0);
+int rr_featmat64_gram(rr_featmat64 *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty);
+int rr_featmat64_pass2_begin(rr_featmat64 *fm, const double *m, const double *C, int c_on_device);
+int rr_featmat64_pass2_rows(rr_featmat64 *fm, const void *dy, int y_dtype);
+int rr_featmat64_pass2_rff(rr_featmat64 *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
+                           double *dT);
+int rr_featmat64_pass2_end(rr_featmat64 *fm, double *sqErr);
+int rr_featmat64_predict_rows(rr_featmat64 *fm, double *Ey, double *Vf);
+
 /* Second data pass of _elbo / predict_moments for a concatenated basis (slm.py:160-162,193-197,240-244),
  * over the rows currently in the matrix (after rr_featmat_begin + put_*):
  *   pass2_begin(m, C)      posterior (host float64, (F) and (F, F) row-major) to the device; sqErr = 0

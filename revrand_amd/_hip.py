@@ -89,6 +89,23 @@ SIGNATURES = {
                                            ctypes.c_int64, ctypes.c_int64]),
     "rr_featmat_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat64_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, _c_void_pp]),
+    "rr_featmat64_destroy": (None, [ctypes.c_void_p]),
+    "rr_featmat64_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64]),
+    "rr_featmat64_put_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
+    "rr_featmat64_put_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                               ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "rr_featmat64_put_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.c_int64]),
+    "rr_featmat64_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat64_pass2_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rr_featmat64_pass2_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rr_featmat64_pass2_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat64_pass2_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_featmat64_predict_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_rff_elbo_pass2_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
@@ -841,6 +858,81 @@ class FeatureMatrix(object):
     def gram_into(self, dy, dG, db=None, dyty=None):
         _check(self.lib, self.lib.rr_featmat_gram(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0,
                                                   _ptr(dG), _ptr(db), _ptr(dyty)))
+
+
+class FeatureMatrix64(object):
+    """The float64 device feature matrix of a concatenated basis (rr_featmat64): the subset of FeatureMatrix a resident fit
+    needs -- children put column blocks, Gram, second pass, prediction -- in the reference's arithmetic."""
+
+    dtype = np.dtype(np.float64)
+
+    def __init__(self, max_rows, F, device=None):
+        self.dev = get_device(device)
+        self.lib = self.dev.lib
+        self.F, self.max_rows = int(F), int(max_rows)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_featmat64_create(self.dev.ctx, self.max_rows, self.F, ctypes.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            try:
+                self.lib.rr_featmat64_destroy(h)
+            except Exception:
+                pass
+
+    def begin(self, rows):
+        _check(self.lib, self.lib.rr_featmat64_begin(self.h, rows))
+
+    def put_rff(self, handle, dX, lenscale, col0):
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, self.lib.rr_featmat64_put_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, lsp, nls, col0))
+
+    def put_linear(self, dX, onescol, col0):
+        _check(self.lib, self.lib.rr_featmat64_put_linear(self.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, dX.shape[1],
+                                                          1 if onescol else 0, col0))
+
+    def put_host(self, Phi, col0):
+        Phi = as_float_matrix(Phi)
+        _check(self.lib, self.lib.rr_featmat64_put_host(self.h, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype),
+                                                        Phi.shape[1], _ld(Phi), col0))
+
+    def gram_into(self, dy, dG, db=None, dyty=None):
+        _check(self.lib, self.lib.rr_featmat64_gram(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0,
+                                                    _ptr(dG), _ptr(db), _ptr(dyty)))
+
+    def pass2_begin(self, m, C, predict=False):
+        """C: host (F, F) array or a device buffer / pointer (float64).  (`predict` is accepted for symmetry: the float64
+        product is always the full one.)"""
+        m = np.ascontiguousarray(m, dtype=np.float64)
+        if m.shape != (self.F,):
+            raise ValueError("posterior shape does not match the feature matrix")
+        mp = m.ctypes.data_as(ctypes.c_void_p)
+        if isinstance(C, np.ndarray):
+            C = np.ascontiguousarray(C, dtype=np.float64)
+            if C.shape != (self.F, self.F):
+                raise ValueError("posterior shape does not match the feature matrix")
+            _check(self.lib, self.lib.rr_featmat64_pass2_begin(self.h, mp, C.ctypes.data_as(ctypes.c_void_p), 0))
+        else:
+            _check(self.lib, self.lib.rr_featmat64_pass2_begin(self.h, mp, _ptr(C), 1))
+
+    def pass2_rows(self, dy):
+        _check(self.lib, self.lib.rr_featmat64_pass2_rows(self.h, _ptr(dy), rr_dtype(dy.dtype)))
+
+    def pass2_rff(self, handle, dX, col0, dT):
+        _check(self.lib, self.lib.rr_featmat64_pass2_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))
+
+    def pass2_end(self):
+        sq = np.zeros(1)
+        _check(self.lib, self.lib.rr_featmat64_pass2_end(self.h, sq.ctypes.data_as(ctypes.c_void_p)))
+        return float(sq[0])
+
+    def predict_rows(self, rows):
+        Ey, Vf = np.empty(rows), np.empty(rows)
+        _check(self.lib, self.lib.rr_featmat64_predict_rows(self.h, Ey.ctypes.data_as(ctypes.c_void_p),
+                                                            Vf.ctypes.data_as(ctypes.c_void_p)))
+        return Ey, Vf
 
 
 def hadamard(Y, ordering=True, device=None):

@@ -965,7 +965,7 @@ int rr_launch_gemm_trig_f32(rr_ctx *c, const float *A, int64_t lda, const float 
 // is bound by the GEMM.
 // ---------------------------------------------------------------------------------------------
 int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             double *P, int64_t ldp);  // rr_rff.hip
+                             double *P, int64_t ldp, bool zero_pad_cols = true);  // rr_rff.hip
 int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
                           int64_t K, int64_t M, int64_t N, int subtract, int upper_only);
 
@@ -1980,6 +1980,438 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     RR_CHECK_HIP(hipMemcpy2D(h.data(), (size_t)S * 4, s.FSt, (size_t)ldw * 4, (size_t)S * 4, (size_t)fm->rows, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < h.size(); ++i) out[i] = (double)h[i];
+    return RR_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// The float64 feature matrix of a concatenated basis (round 3): BasisCat.transform's hstack (basis_functions.py:1599-1627)
+// in float64 in HBM, reduced to Phi^T Phi / Phi^T y (slm.py:146,157) by the f64 MFMA SYRK and consumed by the second pass
+// of _elbo (slm.py:160-197) and predict_moments (slm.py:240-244) in float64 -- the reference's arithmetic end to end for
+// concatenations with a dtype="f64" child (north star: 1e-5 relative in fp64).  The same data flow as rr_featmat /
+// pass2_run64: every child writes its column block, P^T by a transposing pass, U = P C on rr_gemm_tn_f64_kernel, the
+// float64 epilogue kernels above.  Written for the resident fit (CatFitState): no GLM step, no split engines.
+// =============================================================================================
+int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG);  // rr_rff.hip
+
+struct rr_featmat64 {
+    rr_ctx *ctx = nullptr;
+    double *P = nullptr;
+    int64_t max_rows = 0, ld = 0, rows = 0, rows_pad = 0;  // ld % 128 == 0; rows_pad = rows rounded up to 128
+    int F = 0;
+    int64_t covered = 0;
+    std::vector<std::pair<int64_t, int64_t>> spans;  // column intervals put since begin (overlaps refused)
+    // second pass / prediction scratch (allocated by the first pass2_begin)
+    double *Pt = nullptr, *U = nullptr, *Cp = nullptr, *Craw = nullptr, *m = nullptr, *dot = nullptr, *err = nullptr,
+           *sq = nullptr, *vf = nullptr;
+    bool have_rows = false;
+};
+
+template <typename TX>
+__global__ void __launch_bounds__(256)
+rr_fm64_linear_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int onescol, double *__restrict__ P, int64_t ldp) {
+    const int w = d + onescol;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * w) return;
+    const int64_t r = i / w;
+    const int c = (int)(i % w);
+    P[r * ldp + c] = (onescol && c == 0) ? 1.0 : (double)X[r * ldx + (c - onescol)];
+}
+
+template <typename TS>
+__global__ void __launch_bounds__(256)
+rr_fm64_copy_cols_kernel(const TS *__restrict__ src, int64_t N, int64_t lds_, int ncols, double *__restrict__ P, int64_t ldp) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * ncols) return;
+    P[(i / ncols) * ldp + (i % ncols)] = (double)src[(i / ncols) * lds_ + (i % ncols)];
+}
+
+__global__ void __launch_bounds__(256) rr_fm64_zero_padcols_kernel(double *P, int64_t rows, int64_t ld, int F) {
+    const int64_t w = ld - F;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < rows * w) P[(i / w) * ld + F + (i % w)] = 0.0;
+}
+
+template <typename TY>
+__global__ void __launch_bounds__(256)
+rr_fm64_gemv_t_kernel(const double *__restrict__ P, const TY *__restrict__ y, int64_t rows, int F, int64_t ldp,
+                      double *__restrict__ bvec, int rows_per_block, int64_t bdet) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    if (c >= F) return;
+    double acc = 0.0;
+    for (int64_t r = r0; r < r1; ++r) acc = fma(P[r * ldp + c], (double)y[r], acc);
+    rr_acc_out(bvec, bdet, blockIdx.y, c, acc);
+}
+
+template <typename TY>
+__global__ void __launch_bounds__(256) rr_fm64_yty_kernel(const TY *__restrict__ y, int64_t N, double *out, int64_t det) {
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const double v = (double)y[i];
+        acc = fma(v, v, acc);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) rr_acc_out(out, det, blockIdx.x, 0, part[0] + part[1] + part[2] + part[3]);
+}
+
+static int fm64_claim(rr_featmat64 *fm, int64_t col0, int64_t width, const char *who) {
+    const int64_t c1 = col0 + width;
+    size_t pos = 0;
+    while (pos < fm->spans.size() && fm->spans[pos].first < col0) ++pos;
+    const bool clash = (pos > 0 && fm->spans[pos - 1].second > col0) || (pos < fm->spans.size() && fm->spans[pos].first < c1);
+    RR_REQUIRE(!clash, "%s: columns [%lld, %lld) overlap a block already written since rr_featmat64_begin", who, (long long)col0,
+               (long long)c1);
+    fm->spans.insert(fm->spans.begin() + (std::ptrdiff_t)pos, std::make_pair(col0, c1));
+    fm->covered += width;
+    return RR_OK;
+}
+#define RR_FM64_REQUIRE_FILLED(fm, who)                                                                             \
+    RR_REQUIRE((fm)->rows == 0 || (fm)->covered == (fm)->F,                                                         \
+               who ": only %lld of the %d columns were written since rr_featmat64_begin", (long long)(fm)->covered, (fm)->F)
+
+static void fm64_free_scratch(rr_featmat64 *fm) {
+    void *q[] = {fm->Pt, fm->U, fm->Cp, fm->Craw, fm->m, fm->dot, fm->err, fm->sq, fm->vf};
+    for (void *x : q)
+        if (x) (void)hipFree(x);
+    fm->Pt = fm->U = fm->Cp = fm->Craw = fm->m = fm->dot = fm->err = fm->sq = fm->vf = nullptr;
+}
+
+static int fm64_scratch(rr_featmat64 *fm) {
+    if (fm->Pt) return RR_OK;
+    const int64_t Fp = fm->ld;
+    hipError_t ea = hipMalloc((void **)&fm->Pt, (size_t)Fp * fm->max_rows * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->U, (size_t)fm->max_rows * Fp * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->Cp, (size_t)Fp * Fp * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->Craw, (size_t)fm->F * fm->F * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->m, (size_t)Fp * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->dot, (size_t)fm->max_rows * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->err, (size_t)fm->max_rows * 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->sq, 8);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&fm->vf, (size_t)fm->max_rows * 8);
+    if (ea != hipSuccess) {
+        (void)hipGetLastError();
+        fm64_free_scratch(fm);
+        rr_set_error("float64 feature matrix: device allocation of the second pass' scratch failed");
+        return RR_ERR_OOM;
+    }
+    return RR_OK;
+}
+
+// dot = P m, P^T, U = P C for the rows currently in the matrix
+static int fm64_products(rr_featmat64 *fm) {
+    rr_ctx *c = fm->ctx;
+    const int64_t Fp = fm->ld, rp = fm->rows_pad;
+    hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rp / 64)), dim3(256), 0, c->stream, fm->P,
+                       fm->rows, Fp, fm->Pt, fm->max_rows);
+    RR_CHECK_HIP(hipGetLastError());
+    return rr_launch_gemm_tn_f64(c, fm->Pt, fm->max_rows, fm->Cp, Fp, fm->U, Fp, Fp, rp, Fp, 0, 0);
+}
+
+extern "C" {
+
+int rr_featmat64_create(rr_ctx *ctx, int64_t max_rows, int64_t F, rr_featmat64 **out) {
+    RR_REQUIRE(ctx != nullptr && out != nullptr, "rr_featmat64_create: null argument");
+    *out = nullptr;
+    RR_REQUIRE(max_rows >= 1 && F >= 1 && F < 46340, "rr_featmat64_create: bad shape");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    rr_featmat64 *fm = new rr_featmat64();
+    fm->ctx = ctx;
+    fm->F = (int)F;
+    fm->ld = (F + 127) / 128 * 128;
+    fm->max_rows = (max_rows + 127) / 128 * 128;
+    if (hipMalloc((void **)&fm->P, (size_t)fm->max_rows * fm->ld * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_featmat64_create: hipMalloc(%zu bytes) failed", (size_t)fm->max_rows * fm->ld * 8);
+        delete fm;
+        return RR_ERR_OOM;
+    }
+    *out = fm;
+    return RR_OK;
+}
+
+void rr_featmat64_destroy(rr_featmat64 *fm) {
+    if (!fm) return;
+    (void)hipSetDevice(fm->ctx->device);
+    (void)hipStreamSynchronize(fm->ctx->stream);
+    if (fm->P) (void)hipFree(fm->P);
+    fm64_free_scratch(fm);
+    delete fm;
+}
+
+int rr_featmat64_begin(rr_featmat64 *fm, int64_t rows) {
+    RR_REQUIRE(fm != nullptr && rows >= 0 && rows <= fm->max_rows, "rr_featmat64_begin: rows out of range");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    fm->rows = rows;
+    fm->rows_pad = (rows + 127) / 128 * 128;
+    fm->covered = 0;
+    fm->spans.clear();
+    fm->have_rows = false;
+    // the children overwrite every column of [0, F) for the rows [0, rows) (checked by the consumers); the padding is ours:
+    // pad rows up to the next multiple of 128 (SYRK k-blocks, GEMM tiles) and the pad columns [F, ld) of the data rows
+    if (fm->rows_pad > rows)
+        RR_CHECK_HIP(hipMemsetAsync(fm->P + rows * fm->ld, 0, (size_t)(fm->rows_pad - rows) * fm->ld * 8, c->stream));
+    const int64_t w = fm->ld - fm->F;
+    if (w > 0 && rows > 0) {
+        hipLaunchKernelGGL(rr_fm64_zero_padcols_kernel, dim3((unsigned)((rows * w + 255) / 256)), dim3(256), 0, c->stream, fm->P, rows,
+                           fm->ld, fm->F);
+        RR_CHECK_HIP(hipGetLastError());
+    }
+    return RR_OK;
+}
+
+int rr_featmat64_put_rff(rr_featmat64 *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale,
+                         int n_ls, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && b != nullptr && b->kind == RR_KIND_RFF, "rr_featmat64_put_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat64_put_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat64_put_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad, "rr_featmat64_put_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
+    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    if (rc != RR_OK || fm->rows == 0) return rc;
+    RR_REQUIRE(dX != nullptr, "rr_featmat64_put_rff: null X");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    rc = fm64_claim(fm, col0, 2 * (int64_t)b->n, "rr_featmat64_put_rff");
+    if (rc != RR_OK) return rc;
+    // float64 features whatever the basis' own arithmetic (its W is resident in float64 as well); whole 16-row tiles: the
+    // rows up to the next multiple of 16 are written as zeros, like begin() left them
+    return rr_features_rowmajor_f64(b, dX, x_dtype, fm->rows, (fm->rows + 15) / 16 * 16, ldx, fm->P + col0, fm->ld, false);
+}
+
+int rr_featmat64_put_linear(rr_featmat64 *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && d >= 1 && ldx >= d, "rr_featmat64_put_linear: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat64_put_linear: bad dtype");
+    const int w = d + (onescol ? 1 : 0);
+    RR_REQUIRE(col0 >= 0 && col0 + w <= fm->F, "rr_featmat64_put_linear: columns out of range");
+    if (fm->rows == 0) return RR_OK;
+    RR_REQUIRE(dX != nullptr, "rr_featmat64_put_linear: null X");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    int rc = fm64_claim(fm, col0, w, "rr_featmat64_put_linear");
+    if (rc != RR_OK) return rc;
+    const dim3 grid((unsigned)((fm->rows * w + 255) / 256));
+    if (x_dtype == RR_F32)
+        hipLaunchKernelGGL(rr_fm64_linear_kernel<float>, grid, dim3(256), 0, fm->ctx->stream, (const float *)dX, fm->rows, ldx, d,
+                           onescol ? 1 : 0, fm->P + col0, fm->ld);
+    else
+        hipLaunchKernelGGL(rr_fm64_linear_kernel<double>, grid, dim3(256), 0, fm->ctx->stream, (const double *)dX, fm->rows, ldx, d,
+                           onescol ? 1 : 0, fm->P + col0, fm->ld);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_featmat64_put_host(rr_featmat64 *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && ncols >= 1 && ldphi >= ncols, "rr_featmat64_put_host: bad argument");
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_featmat64_put_host: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + ncols <= fm->F, "rr_featmat64_put_host: columns out of range");
+    if (fm->rows == 0) return RR_OK;
+    RR_REQUIRE(Phi != nullptr, "rr_featmat64_put_host: null Phi");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const size_t es = dtype == RR_F32 ? 4 : 8;
+    void *raw = nullptr;
+    RR_CHECK_HIP(hipMalloc(&raw, (size_t)fm->rows * ncols * es));
+    hipError_t e = hipMemcpy2DAsync(raw, (size_t)ncols * es, Phi, (size_t)ldphi * es, (size_t)ncols * es, (size_t)fm->rows,
+                                    hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const dim3 grid((unsigned)((fm->rows * ncols + 255) / 256));
+        if (dtype == RR_F32)
+            hipLaunchKernelGGL(rr_fm64_copy_cols_kernel<float>, grid, dim3(256), 0, c->stream, (const float *)raw, fm->rows, ncols,
+                               (int)ncols, fm->P + col0, fm->ld);
+        else
+            hipLaunchKernelGGL(rr_fm64_copy_cols_kernel<double>, grid, dim3(256), 0, c->stream, (const double *)raw, fm->rows, ncols,
+                               (int)ncols, fm->P + col0, fm->ld);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(raw);
+    if (e != hipSuccess) {
+        rr_set_error("rr_featmat64_put_host: copy failed: %s", hipGetErrorString(e));
+        return RR_ERR_HIP;
+    }
+    return fm64_claim(fm, col0, ncols, "rr_featmat64_put_host");
+}
+
+int rr_featmat64_gram(rr_featmat64 *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty) {
+    RR_REQUIRE(fm != nullptr && dG != nullptr, "rr_featmat64_gram: null argument");
+    RR_REQUIRE((dy == nullptr) == (db == nullptr) && (dy == nullptr) == (dyty == nullptr),
+               "rr_featmat64_gram: y, b and yty must be given together");
+    RR_REQUIRE(dy == nullptr || y_dtype == RR_F32 || y_dtype == RR_F64, "rr_featmat64_gram: bad dtype");
+    RR_FM64_REQUIRE_FILLED(fm, "rr_featmat64_gram");
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = RR_OK;
+    if (dy) {
+        const int rpb = 512;
+        const dim3 gg((unsigned)((fm->F + 255) / 256), (unsigned)((fm->rows + rpb - 1) / rpb));
+        int yb = (int)((fm->rows + 255) / 256);
+        if (yb > c->num_cu * 8) yb = c->num_cu * 8;
+        const bool det = c->deterministic != 0;
+        double *bdst = db, *ydst = dyty;
+        void *part = nullptr;
+        if (det) {
+            rc = rr_det_scratch(c, (size_t)gg.y * (size_t)fm->F * 8, &part);
+            if (rc != RR_OK) return rc;
+            bdst = (double *)part;
+        }
+        if (y_dtype == RR_F32)
+            hipLaunchKernelGGL(rr_fm64_gemv_t_kernel<float>, gg, dim3(256), 0, c->stream, fm->P, (const float *)dy, fm->rows, fm->F,
+                               fm->ld, bdst, rpb, (int64_t)(det ? fm->F : 0));
+        else
+            hipLaunchKernelGGL(rr_fm64_gemv_t_kernel<double>, gg, dim3(256), 0, c->stream, fm->P, (const double *)dy, fm->rows, fm->F,
+                               fm->ld, bdst, rpb, (int64_t)(det ? fm->F : 0));
+        RR_CHECK_HIP(hipGetLastError());
+        if (det) {
+            rc = rr_det_reduce(c, bdst, gg.y, fm->F, fm->F, db);
+            if (rc == RR_OK) rc = rr_det_scratch(c, (size_t)yb * 8, &part);
+            if (rc != RR_OK) return rc;
+            ydst = (double *)part;
+        }
+        if (y_dtype == RR_F32)
+            hipLaunchKernelGGL(rr_fm64_yty_kernel<float>, dim3(yb), dim3(256), 0, c->stream, (const float *)dy, fm->rows, ydst,
+                               (int64_t)(det ? 1 : 0));
+        else
+            hipLaunchKernelGGL(rr_fm64_yty_kernel<double>, dim3(yb), dim3(256), 0, c->stream, (const double *)dy, fm->rows, ydst,
+                               (int64_t)(det ? 1 : 0));
+        RR_CHECK_HIP(hipGetLastError());
+        if (det) {
+            rc = rr_det_reduce(c, ydst, yb, 1, 1, dyty);
+            if (rc != RR_OK) return rc;
+        }
+    }
+    return rr_launch_syrk_f64(c, fm->P, fm->rows_pad, fm->ld, fm->F, dG);
+}
+
+// m: host (F); C: host (F, F) or -- c_on_device -- device (F, F), float64
+int rr_featmat64_pass2_begin(rr_featmat64 *fm, const double *m, const double *C, int c_on_device) {
+    RR_REQUIRE(fm != nullptr && m != nullptr && C != nullptr, "rr_featmat64_pass2_begin: null argument");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = fm64_scratch(fm);
+    if (rc != RR_OK) return rc;
+    const int64_t F = fm->F, Fp = fm->ld;
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemset(fm->m, 0, (size_t)Fp * 8));
+    RR_CHECK_HIP(hipMemcpy(fm->m, m, (size_t)F * 8, hipMemcpyHostToDevice));
+    const double *Csrc = C;
+    if (!c_on_device) {
+        RR_CHECK_HIP(hipMemcpy(fm->Craw, C, (size_t)F * F * 8, hipMemcpyHostToDevice));
+        Csrc = fm->Craw;
+    }
+    hipLaunchKernelGGL(rr_pad_c64_kernel, dim3((unsigned)((Fp * Fp + 255) / 256)), dim3(256), 0, c->stream, Csrc, F, fm->Cp, Fp);
+    RR_CHECK_HIP(hipGetLastError());
+    RR_CHECK_HIP(hipMemsetAsync(fm->sq, 0, 8, c->stream));
+    fm->have_rows = false;
+    return RR_OK;
+}
+
+int rr_featmat64_pass2_rows(rr_featmat64 *fm, const void *dy, int y_dtype) {
+    RR_REQUIRE(fm != nullptr && fm->Pt != nullptr, "rr_featmat64_pass2_rows: call rr_featmat64_pass2_begin first");
+    RR_FM64_REQUIRE_FILLED(fm, "rr_featmat64_pass2_rows");
+    RR_REQUIRE(dy != nullptr && (y_dtype == RR_F32 || y_dtype == RR_F64), "rr_featmat64_pass2_rows: bad y");
+    fm->have_rows = true;
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = fm64_products(fm);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_rows64_kernel<0>, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, fm->U, fm->m,
+                       fm->rows, fm->F, fm->ld, fm->dot, fm->vf);
+    const int64_t eb = (fm->rows + 255) / 256;
+    double *sq = fm->sq;
+    const int64_t det = c->deterministic ? 1 : 0;
+    if (det) {
+        void *part = nullptr;
+        rc = rr_det_scratch(c, (size_t)eb * 8, &part);
+        if (rc != RR_OK) return rc;
+        sq = (double *)part;
+    }
+    if (y_dtype == RR_F32)
+        hipLaunchKernelGGL(rr_err64_kernel<float>, dim3((unsigned)eb), dim3(256), 0, c->stream, (const float *)dy, fm->dot, fm->rows,
+                           fm->err, sq, det);
+    else
+        hipLaunchKernelGGL(rr_err64_kernel<double>, dim3((unsigned)eb), dim3(256), 0, c->stream, (const double *)dy, fm->dot, fm->rows,
+                           fm->err, sq, det);
+    RR_CHECK_HIP(hipGetLastError());
+    return det ? rr_det_reduce(c, sq, eb, 1, 1, fm->sq) : RR_OK;
+}
+
+// dT (d, n) += X^T A for the random Fourier child at columns [col0, col0 + 2n): its hyper-gradient contraction
+int rr_featmat64_pass2_rff(rr_featmat64 *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    RR_REQUIRE(fm != nullptr && fm->Pt != nullptr && fm->have_rows, "rr_featmat64_pass2_rff: call rr_featmat64_pass2_rows first");
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr, "rr_featmat64_pass2_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat64_pass2_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat64_pass2_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad && !b->large, "rr_featmat64_pass2_rff: device X needs ldx >= rr_rff_padded_dim() = %d, Xdim <= 128", b->dpad);
+    if (fm->rows == 0) return RR_OK;
+    RR_REQUIRE(dX != nullptr, "rr_featmat64_pass2_rff: null X");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int n = b->n;
+    const int64_t mrows = fm->rows;
+    const int fblocks = (n + 255) / 256;
+    int64_t rpb = (mrows * fblocks + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
+    if (rpb < 64) rpb = 64;
+    if ((mrows + rpb - 1) / rpb > 65535) rpb = (mrows + 65534) / 65535;
+    const dim3 grid(fblocks, (unsigned)((mrows + rpb - 1) / rpb));
+    const int64_t tcount = (int64_t)b->d * n, tdet = c->deterministic ? tcount : 0;
+    double *Tdst = dT;
+    if (tdet) {
+        void *part = nullptr;
+        int rc = rr_det_scratch(c, (size_t)grid.y * (size_t)tcount * 8, &part);
+        if (rc != RR_OK) return rc;
+        Tdst = (double *)part;
+    }
+#define RR_FGT(DM, TX)                                                                                                    \
+    hipLaunchKernelGGL((rr_grad_t64_kernel<DM, TX>), grid, dim3(256), 0, c->stream, (const TX *)dX, mrows, ldx, fm->P + col0, \
+                       fm->U + col0, fm->ld, fm->err, fm->m + col0, n, b->d, Tdst, (int)rpb, tdet)
+#define RR_FGTD(DM)                          \
+    if (x_dtype == RR_F32) RR_FGT(DM, float); \
+    else RR_FGT(DM, double)
+    switch (b->dpad) {
+        case 8: RR_FGTD(8); break;
+        case 16: RR_FGTD(16); break;
+        case 32: RR_FGTD(32); break;
+        case 64: RR_FGTD(64); break;
+        default: RR_FGTD(128); break;
+    }
+#undef RR_FGTD
+#undef RR_FGT
+    RR_CHECK_HIP(hipGetLastError());
+    return tdet ? rr_det_reduce(c, Tdst, grid.y, tcount, tcount, dT) : RR_OK;
+}
+
+int rr_featmat64_pass2_end(rr_featmat64 *fm, double *sqErr) {
+    RR_REQUIRE(fm != nullptr && fm->Pt != nullptr && sqErr != nullptr, "rr_featmat64_pass2_end: bad argument");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    RR_CHECK_HIP(hipMemcpyAsync(sqErr, fm->sq, 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return RR_OK;
+}
+
+// (Ey, Vf) = (P m, rowsum((P C) o P)) for the rows currently in the matrix (after rr_featmat64_pass2_begin), host float64
+int rr_featmat64_predict_rows(rr_featmat64 *fm, double *Ey, double *Vf) {
+    RR_REQUIRE(fm != nullptr && fm->Pt != nullptr && Ey != nullptr && Vf != nullptr, "rr_featmat64_predict_rows: bad argument");
+    RR_FM64_REQUIRE_FILLED(fm, "rr_featmat64_predict_rows");
+    if (fm->rows == 0) return RR_OK;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = fm64_products(fm);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_rows64_kernel<1>, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, fm->U, fm->m,
+                       fm->rows, fm->F, fm->ld, fm->dot, fm->vf);
+    RR_CHECK_HIP(hipGetLastError());
+    RR_CHECK_HIP(hipMemcpyAsync(Ey, fm->dot, (size_t)fm->rows * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipMemcpyAsync(Vf, fm->vf, (size_t)fm->rows * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     return RR_OK;
 }
 

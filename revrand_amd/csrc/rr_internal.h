@@ -27,6 +27,8 @@ struct rr_ctx {
     int deterministic = 0;    // rr_set_deterministic: ordered partial sums instead of floating-point atomics
     void *det = nullptr;      // scratch of the ordered sums (partials of the kernel in flight), grow-only
     size_t det_bytes = 0;
+    double *det2 = nullptr;   // second stage of rr_det_reduce when there are many slots (64 group sums per element), grow-only
+    size_t det2_count = 0;
     void *gsa = nullptr, *gsb = nullptr;  // K-blocked operand copies of the GLM step's GEMMs on the split engines, grow-only
     size_t gsa_bytes = 0, gsb_bytes = 0;
     void *pb = nullptr;       // split-bf16 copy of the feature chunk (rr_syrk_bf16x3_kernel), grow-only

@@ -2479,11 +2479,11 @@ int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m
 
 // Row-major f64 features of a row block (second pass in f64 arithmetic): VALU feature kernel, sincospi.
 int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             double *P, int64_t ldp) {
+                             double *P, int64_t ldp, bool zero_pad_cols) {
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n;
     const double scale = 1.0 / sqrt((double)b->n);
-    if (ldp > F) {
+    if (zero_pad_cols && ldp > F) {
         const int64_t cnt = mpad * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<double>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
