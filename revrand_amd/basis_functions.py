@@ -145,8 +145,9 @@ class Basis(object):
         # generic bases: host transform, one upload of their (usually narrow) column block
         fm.put_host(self.transform(X, *params), col0)
 
-    def _resident_child(self, X):
-        """This basis' share of a concatenated device-resident fit (CatFitState); None = not supported."""
+    def _resident_child(self, X, dtype=None):
+        """This basis' share of a concatenated device-resident fit (CatFitState); None = not supported.  dtype="f64": the
+        state's feature matrix is float64 (a child asked for the reference's arithmetic)."""
         return None
 
     def _grad_popargs(self, X, *args):
@@ -187,7 +188,7 @@ class BiasBasis(Basis):
     def transform(self, X):
         return np.ones((len(X), 1)) * self.offset
 
-    def _resident_child(self, X):
+    def _resident_child(self, X, dtype=None):
         return _ResidentHost(self, X.shape[1])
 
     def __repr__(self):
@@ -215,8 +216,8 @@ class LinearBasis(Basis):
         dX.free()
 
     @slice_transform
-    def _resident_child(self, X):
-        return _ResidentLinear(self, X)
+    def _resident_child(self, X, dtype=None):
+        return _ResidentLinear(self, X, dtype)
 
     def __repr__(self):
         return "{}(onescol={}, regularizer={})".format(type(self).__name__, self.onescol, self.regularizer)
@@ -374,9 +375,9 @@ class _ResidentLinear(object):
 
     nparams = 0
 
-    def __init__(self, basis, X):
+    def __init__(self, basis, X, dtype=None):
         self.onescol = basis.onescol
-        self.dX = _hip.get_device().upload_matrix(np.ascontiguousarray(X, dtype=np.float32))
+        self.dX = _hip.get_device().upload_matrix(np.ascontiguousarray(X, dtype=np.float64 if dtype == "f64" else np.float32))
 
     def put(self, fm, X, r0, rows, col0, params):
         fm.put_linear(_hip.DeviceView(self.dX, r0, rows), self.onescol, col0)
@@ -713,18 +714,20 @@ class CatFitState(_DevicePosterior):
     device feature matrix per row chunk; same ``gram`` / ``second_pass`` / ``release`` interface, ``dhyp``
     structured like ``apply_grad(f, cat.grad(X, *hypers))``."""
 
-    def __init__(self, cat, children, X, y, chunk_rows=None):
+    def __init__(self, cat, children, X, y, chunk_rows=None, dtype="f32"):
         self.X, self.N = X, X.shape[0]
         self.children = children
+        self.dtype = dtype  # "f64": float64 feature matrix, statistics and second pass (rr_featmat64_*)
         self.F = int(cat.get_dim(X))
         self.ends = [int(e) for e in np.cumsum([0] + [int(b.get_dim(X)) for b in cat.bases])]
         self.dev = _hip.get_device()
-        self.dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float32))
+        es = 8 if dtype == "f64" else 4
+        self.dy = self.dev.upload_vector(np.ascontiguousarray(y, dtype=np.float64 if dtype == "f64" else np.float32))
         Fp = (self.F + 255) // 256 * 256
-        if chunk_rows is None:  # P, its transpose and U = P C: 12 Fp bytes per row, within ~24 GiB
-            chunk_rows = (24 << 30) // (12 * Fp)
+        if chunk_rows is None:  # P, its transpose and U = P C: 3 Fp elements per row, within ~24 GiB
+            chunk_rows = (24 << 30) // (3 * es * Fp)
         self.chunk = int(max(256, min(self.N, chunk_rows)))
-        self.fm = _hip.FeatureMatrix(self.chunk, self.F)
+        self.fm = (_hip.FeatureMatrix64 if dtype == "f64" else _hip.FeatureMatrix)(self.chunk, self.F)
         self._filled = None
         self._stats_init(self.dev, self.F)
 
@@ -881,8 +884,9 @@ class _RandomKernelBasis(_LengthScaleBasis):
         return self._handle(), self.W
 
     @slice_transform
-    def _resident_child(self, X):
-        if self.dtype != "f32" or X.shape[1] != self.d:
+    def _resident_child(self, X, dtype=None):
+        # float64 bases join a float64 state only; f32 bases join either (a float64 feature matrix evaluates them in float64)
+        if (self.dtype != "f32" and dtype != "f64") or X.shape[1] != self.d or (dtype == "f64" and self.d > 128):
             return None
         return _ResidentRFF(self, X)
 
@@ -1229,11 +1233,14 @@ class BasisCat(object):
         return G, out[F * F:F * F + F].copy(), float(out[-1])
 
     def device_fit_state(self, X, y):
-        """(X, y) resident for a whole fit when every child can take part (f32 random Fourier / FastFood,
-        Linear, Bias); None otherwise (the estimator then uses transform / grad)."""
+        """(X, y) resident for a whole fit when every child can take part (random Fourier / FastFood, Linear, Bias);
+        None otherwise (the estimator then uses transform / grad)."""
+        # a child that asks for float64 arithmetic end to end makes the whole state float64 (rr_featmat64: float64 feature
+        # matrix, f64 MFMA Gram and second pass -- the reference's arithmetic, north star's 1e-5)
+        dtype = "f64" if any(getattr(b, "dtype", "f32") == "f64" for b in self.bases) else "f32"
         children = []
         for b in self.bases:
-            c = b._resident_child(X)
+            c = b._resident_child(X, dtype=dtype)
             if c is None:
                 for done in children:
                     done.release()
@@ -1243,7 +1250,7 @@ class BasisCat(object):
             for done in children:
                 done.release()
             return None
-        return CatFitState(self, children, X, y)
+        return CatFitState(self, children, X, y, dtype=dtype)
 
     def predict_moments(self, X, hypers, m, C):
         """(Phi m, rowsum((Phi C) o Phi)) with Phi assembled on the device (slm.py:240-243); None when a child

@@ -195,7 +195,7 @@ def test_concat_with_float64_child_uses_float64_statistics():
     y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.1 * rs.randn(N)
     cat = bs.RandomLaplace(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()), dtype="f64") \
         + bs.LinearBasis(onescol=True)
-    assert cat.bases[0].dtype == "f64" and cat.gram(X, y, np.ones(d)) is None and cat.device_fit_state(X, y) is None
+    assert cat.bases[0].dtype == "f64" and cat.gram(X, y, np.ones(d)) is None
     slm = SLM(cat)
     slm.obj_ = -np.inf
     ls = np.array([0.9, 1.2, 1.5])
@@ -219,6 +219,68 @@ def test_concat_with_float64_child_uses_float64_statistics():
     Ps = np.hstack((orc.rff_transform(Xs, W, ls), orc.linear_transform(Xs, True)))
     Eo, Vo = orc.slm_predict_moments(Ps, o["m"], o["C"], 0.3)
     assert normwise(Ey, Eo) < 1e-7 and normwise(Vy, Vo) < 1e-7
+
+
+def test_concat_with_float64_child_fits_resident_in_float64(monkeypatch):
+    """a concatenation with a dtype="f64" child keeps (X, y) resident in a FLOAT64 feature matrix
+    (rr_featmat64_*): f64 MFMA Gram, posterior, float64 second pass -- `_elbo` against the float64 oracle at the float64
+    tolerances (north star: 1e-5 relative in fp64), host and device posterior, one chunk and several, an f32 child alongside,
+    and bitwise reproducible in deterministic mode."""
+    bs, Parameter, Positive, SLM = _imports()
+    from revrand_amd import _hip
+    from revrand_amd.basis_functions import CatFitState
+    rs = np.random.RandomState(7)
+    N, d, n = 1500, 5, 150
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    cat = bs.RandomLaplace(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()), dtype="f64") \
+        + bs.LinearBasis(onescol=True) + bs.BiasBasis(offset=0.5) \
+        + bs.RandomRBF(nbases=20, Xdim=d, random_state=4, lenscale=Parameter(1.0, Positive()))   # an f32 child, isotropic
+    st = cat.device_fit_state(X, y)
+    assert isinstance(st, CatFitState) and st.dtype == "f64" and type(st.fm).__name__ == "FeatureMatrix64"
+    assert st.children[0].dX.dtype == np.float64 and st.children[1].dX.dtype == np.float64
+    st.release()
+    ls0, ls3 = np.linspace(0.8, 1.4, d), 1.3
+    W0, W3 = cat.bases[0].W, cat.bases[3].W
+    Phi = np.hstack((orc.rff_transform(X, W0, ls0), orc.linear_transform(X, True), np.full((N, 1), 0.5),
+                     orc.rff_transform(X, W3, ls3)))
+    F = Phi.shape[1]
+    e = [0, 2 * n, 2 * n + d + 1, 2 * n + d + 2, F]
+    dP0 = np.zeros((N, F, d))
+    dP0[:, :2 * n, :] = orc.rff_grad(X, W0, ls0)
+    dP3 = np.zeros((N, F))
+    dP3[:, e[3]:] = orc.rff_grad(X, W3, ls3)       # isotropic: the reference's dimension-0-only gradient
+    regs = [1.5, 0.7, 2.0, 1.1]
+    rd = np.concatenate([np.full(e[i + 1] - e[i], regs[i]) for i in range(4)])
+    o = orc.slm_elbo(Phi, y, 0.3, rd, [slice(e[i], e[i + 1]) for i in range(4)], [dP0[:, :, i] for i in range(d)] + [dP3])
+    want_h = np.concatenate((o["dhyp"][:d], [o["dhyp"][d]]))
+    dev = _hip.get_device()
+    results = []
+    for posdef, chunk, det in (("host", None, False), ("device", None, False), ("device", 384, False), ("device", 384, True),
+                               ("device", 384, True)):
+        monkeypatch.setenv("RR_POSDEF", posdef)
+        prev = dev.set_deterministic(det)
+        try:
+            slm = SLM(cat)
+            slm.obj_ = -np.inf
+            kids = [b._resident_child(X, dtype="f64") for b in cat.bases]
+            slm._state = CatFitState(cat, kids, X, y, chunk_rows=chunk, dtype="f64")
+            nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, 0.3, regs, [ls0, ls3])
+            C = slm._state.best_covariance() if slm._state.best_on_device else slm.covariance_
+            slm._state.release()
+        finally:
+            dev.set_deterministic(prev)
+        assert abs(-nelbo - o["elbo"]) < 1e-9 * abs(o["elbo"]), (posdef, chunk)
+        assert normwise(slm.weights_, o["m"]) < 1e-8 and normwise(C, o["C"]) < 1e-8
+        assert abs(-ndvar - o["dvar"]) < 1e-8 * abs(o["dvar"])
+        assert normwise(-np.asarray(ndreg), np.array(o["dreg"])) < 1e-8
+        got_h = np.concatenate((np.atleast_1d(ndhyp[0]), [ndhyp[1]]))
+        assert normwise(-got_h, want_h) < 1e-7, (posdef, chunk)
+        results.append(np.concatenate(([nelbo, ndvar], np.asarray(ndreg), got_h, slm.weights_)))
+    assert np.array_equal(results[3], results[4])          # deterministic mode: the same bits twice
+    # a short fit through the estimator takes the float64 state by itself
+    slm = SLM(cat, var=Parameter(0.3, Positive()), nstarts=0, maxiter=5, random_state=0).fit(X, y)
+    assert np.isfinite(slm.obj_) and slm.weights_.shape == (F,)
 
 
 def test_laplace_float64_phase_basis_takes_the_resident_f32_routes():
