@@ -1145,12 +1145,15 @@ __device__ __forceinline__ void gram_mfma_d16(const KOpsD16<NB, ED> &o, floatx16
     __builtin_amdgcn_sched_barrier(0);                         \
     gram_mfma_d16<NB, ED, 0, 1>(CUR, acc, dd);                 \
     __builtin_amdgcn_sched_barrier(0);                         \
-    if ((P) + 1 < 8) NXT.template load<((P) + 1) & 7>(abase, bbase, xbase); \
+    if ((P) + 1 < KB / 4) NXT.template load<((P) + 1) & (KB / 4 - 1)>(abase, bbase, xbase); \
     __builtin_amdgcn_sched_barrier(0);                         \
     gram_mfma_d16<NB, ED, 1, 2 * NB + 1>(CUR, acc, dd);        \
     __builtin_amdgcn_sched_barrier(0);
 
-template <int NB, int ED>
+// KB = rows per k-block (32 or 64).  The diagonal kernel's k-block carries half the MFMA cycles of the off-diagonal
+// kernel's (one side of the tile, 36 of 64 blocks), so the per-k-block barrier + DMA burst weighs twice as much; with 64-row
+// k-blocks (128 KiB of LDS -- the kernel runs one workgroup per CU either way: 152 VGPRs) there are half as many.
+template <int NB, int ED, int KB>
 __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, int wave, int lane) {
     const int ta = blockIdx.x % p.nb;
     const int ks = blockIdx.x / p.nb;
@@ -1178,34 +1181,38 @@ __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, 
 #pragma unroll
     for (int t = 0; t < 3; ++t) dd[t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    auto dma_tile = [&](float *buf, int64_t kb0) {
+    auto dma_tile = [&](float *buf, int64_t kb0) {  // KB row segments of 1 KiB per k-block; wave w moves rows (KB/8) w ...
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lr = 4 * wave + k;
-            RR_DEV_ASSERT(kb0 + lr < p.rows && ca + GR_TC <= p.ldp && p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0);
+        for (int k = 0; k < KB / 8; ++k) {
+            const int lr = (KB / 8) * wave + k;
+            RR_DEV_ASSERT(kb0 + lr < p.rows && ca + GR_TC <= p.ldp && p.rows % KB == 0 && p.rows_per_split % KB == 0);
             const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * GR_TC), 16, 0, 0);
         }
     };
 
-    const int64_t nkb = (row_end - row_begin) / GR_KB;
+    const int64_t nkb = (row_end - row_begin) / KB;
     if (nkb > 0) {
         dma_tile(lds, row_begin);
         __syncthreads();
         for (int64_t kb = 0; kb < nkb; ++kb) {
             const int cbuf = (int)(kb & 1);
-            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_TC), row_begin + (kb + 1) * GR_KB);
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (KB * GR_TC), row_begin + (kb + 1) * KB);
             unsigned abase[NB], bbase[NB];
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
-                abase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bi[e];
-                bbase[e] = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off + 128u * bj[e];
+                abase[e] = lds0 + cbuf * (4u * KB * GR_TC) + lane_off + 128u * bi[e];
+                bbase[e] = lds0 + cbuf * (4u * KB * GR_TC) + lane_off + 128u * bj[e];
             }
-            const unsigned xbase = lds0 + cbuf * (4u * GR_KB * GR_TC) + lane_off16;
+            const unsigned xbase = lds0 + cbuf * (4u * KB * GR_TC) + lane_off16;
             KOpsD16<NB, ED> o0, o1;
             o0.template load<0>(abase, bbase, xbase);
             RR_PAIRD16(0, o0, o1) RR_PAIRD16(1, o1, o0) RR_PAIRD16(2, o0, o1) RR_PAIRD16(3, o1, o0)
             RR_PAIRD16(4, o0, o1) RR_PAIRD16(5, o1, o0) RR_PAIRD16(6, o0, o1) RR_PAIRD16(7, o1, o0)
+            if constexpr (KB == 64) {
+                RR_PAIRD16(8, o0, o1) RR_PAIRD16(9, o1, o0) RR_PAIRD16(10, o0, o1) RR_PAIRD16(11, o1, o0)
+                RR_PAIRD16(12, o0, o1) RR_PAIRD16(13, o1, o0) RR_PAIRD16(14, o0, o1) RR_PAIRD16(15, o1, o0)
+            }
             __syncthreads();
         }
     }
@@ -1234,17 +1241,18 @@ __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, 
 }
 #undef RR_PAIRD16
 
+template <int KB>
 __global__ void __launch_bounds__(GR_THREADS, 2)
 rr_syrk_f32_diag16_kernel(const SyrkArgs p) {
-    __shared__ float lds[2 * GR_KB * GR_TC];  // 64 KiB: two [32][256] tiles (A side only)
+    __shared__ float lds[2 * KB * GR_TC];  // two [KB][256] tiles (A side only): 64 / 128 KiB
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {  // wave-uniform: every path runs the same barriers; (NB, ED) as laid out in RR_DIAG_I / RR_DIAG_J
-        case 0: case 1: case 2: case 3: syrk_diag16_body<5, 0>(p, lds, wave, lane); break;
-        case 4: syrk_diag16_body<4, 3>(p, lds, wave, lane); break;
-        case 5: syrk_diag16_body<4, 2>(p, lds, wave, lane); break;
-        case 6: syrk_diag16_body<4, 1>(p, lds, wave, lane); break;
-        default: syrk_diag16_body<4, 0>(p, lds, wave, lane); break;
+        case 0: case 1: case 2: case 3: syrk_diag16_body<5, 0, KB>(p, lds, wave, lane); break;
+        case 4: syrk_diag16_body<4, 3, KB>(p, lds, wave, lane); break;
+        case 5: syrk_diag16_body<4, 2, KB>(p, lds, wave, lane); break;
+        case 6: syrk_diag16_body<4, 1, KB>(p, lds, wave, lane); break;
+        default: syrk_diag16_body<4, 0, KB>(p, lds, wave, lane); break;
     }
 }
 
@@ -2109,6 +2117,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
             }
         }
         rps_d = rows_per(nsplit_d);
+        if (rows % 64 == 0) rps_d = (rps_d + 63) / 64 * 64;  // whole 64-row k-blocks for rr_syrk_f32_diag16_kernel<64>
     }
     int64_t nsplit_r = nsplit, rps_r = rps;
     if (rg) {  // nb_all - 1 equal-cost workgroups per split: the split count whose workgroups fill whole rounds best
@@ -2160,10 +2169,14 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         ad.rows_per_split = rps_d;
         // diagonal blocks as 16x16 sub-blocks (round 3); RR_SYRK_NO_DIAG16=1: the whole-block kernel of round 2 (A/B runs)
         static const bool no_diag16 = getenv("RR_SYRK_NO_DIAG16") != nullptr;
+        // 64-row k-blocks when every K-split holds whole ones (RR_SYRK_DIAG_KB=32: the 32-row form, A/B runs)
+        static const bool kb32 = getenv("RR_SYRK_DIAG_KB") != nullptr && atoi(getenv("RR_SYRK_DIAG_KB")) == 32;
         if (no_diag16)
             hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
+        else if (!kb32 && rows % 64 == 0 && ad.rows_per_split % 64 == 0)
+            hipLaunchKernelGGL(rr_syrk_f32_diag16_kernel<64>, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
         else
-            hipLaunchKernelGGL(rr_syrk_f32_diag16_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
+            hipLaunchKernelGGL(rr_syrk_f32_diag16_kernel<32>, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
     }
     if (a.part)
         hipLaunchKernelGGL(rr_syrk_det_reduce_kernel<float>, dim3((unsigned)((F + 1 + 255) / 256), (unsigned)F), dim3(256), 0,
