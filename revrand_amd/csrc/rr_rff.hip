@@ -1150,9 +1150,10 @@ __device__ __forceinline__ void gram_mfma_d16(const KOpsD16<NB, ED> &o, floatx16
     gram_mfma_d16<NB, ED, 1, 2 * NB + 1>(CUR, acc, dd);        \
     __builtin_amdgcn_sched_barrier(0);
 
-// KB = rows per k-block (32 or 64).  The diagonal kernel's k-block carries half the MFMA cycles of the off-diagonal
-// kernel's (one side of the tile, 36 of 64 blocks), so the per-k-block barrier + DMA burst weighs twice as much; with 64-row
-// k-blocks (128 KiB of LDS -- the kernel runs one workgroup per CU either way: 152 VGPRs) there are half as many.
+// KB = rows per k-block: 32 (default) or 64 (RR_SYRK_DIAG_KB=64, an experiment kept for A/B runs).  The diagonal kernel's
+// k-block carries half the MFMA cycles of the off-diagonal kernel's (one side of the tile, 36 of 64 blocks), so the
+// per-k-block barrier + DMA burst should weigh twice as much; 64-row k-blocks (128 KiB of LDS -- the kernel runs one
+// workgroup per CU either way: 152 VGPRs) halve their number -- and change nothing (87.9 vs 86.6 ms per 10M rows).
 template <int NB, int ED, int KB>
 __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, int wave, int lane) {
     const int ta = blockIdx.x % p.nb;
@@ -2117,7 +2118,8 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
             }
         }
         rps_d = rows_per(nsplit_d);
-        if (rows % 64 == 0) rps_d = (rps_d + 63) / 64 * 64;  // whole 64-row k-blocks for rr_syrk_f32_diag16_kernel<64>
+        if (rows % 64 == 0 && getenv("RR_SYRK_DIAG_KB") != nullptr && atoi(getenv("RR_SYRK_DIAG_KB")) == 64)
+            rps_d = (rps_d + 63) / 64 * 64;  // whole 64-row k-blocks for rr_syrk_f32_diag16_kernel<64>
     }
     int64_t nsplit_r = nsplit, rps_r = rps;
     if (rg) {  // nb_all - 1 equal-cost workgroups per split: the split count whose workgroups fill whole rounds best
@@ -2169,11 +2171,12 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         ad.rows_per_split = rps_d;
         // diagonal blocks as 16x16 sub-blocks (round 3); RR_SYRK_NO_DIAG16=1: the whole-block kernel of round 2 (A/B runs)
         static const bool no_diag16 = getenv("RR_SYRK_NO_DIAG16") != nullptr;
-        // 64-row k-blocks when every K-split holds whole ones (RR_SYRK_DIAG_KB=32: the 32-row form, A/B runs)
-        static const bool kb32 = getenv("RR_SYRK_DIAG_KB") != nullptr && atoi(getenv("RR_SYRK_DIAG_KB")) == 32;
+        // RR_SYRK_DIAG_KB=64 (A/B runs): 64-row k-blocks when every K-split holds whole ones.  Measured in round 3 and not
+        // adopted: 87.7-88.1 vs 86.3-86.9 ms per 10M rows -- half the barriers buy nothing (DESIGN Appendix A.2)
+        static const bool kb64 = getenv("RR_SYRK_DIAG_KB") != nullptr && atoi(getenv("RR_SYRK_DIAG_KB")) == 64;
         if (no_diag16)
             hipLaunchKernelGGL(rr_syrk_f32_diag_kernel, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
-        else if (!kb32 && rows % 64 == 0 && ad.rows_per_split % 64 == 0)
+        else if (kb64 && rows % 64 == 0 && ad.rows_per_split % 64 == 0)
             hipLaunchKernelGGL(rr_syrk_f32_diag16_kernel<64>, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
         else
             hipLaunchKernelGGL(rr_syrk_f32_diag16_kernel<32>, dim3((unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, ad);
