@@ -431,9 +431,11 @@ class _ResidentRFF(object):
     def dhyp(self, var):
         T = self.h.dev.download(self.dT, self.W.shape, np.float64)
         ls = np.atleast_1d(np.asarray(self.ls, dtype=float))
-        if ls.size == 1:  # the reference's isotropic gradient: input dimension 0 only
-            return float((T[0] * self.W[0]).sum() / (var * ls[0] ** 2))
-        return (T * self.W).sum(axis=1) / (var * ls ** 2)
+        # (L-BFGS visits length scales up to the log-space bound: l^2 or T W may overflow there, as in DeviceFitState)
+        with np.errstate(over="ignore", invalid="ignore"):
+            if ls.size == 1:  # the reference's isotropic gradient: input dimension 0 only
+                return float((T[0] * self.W[0]).sum() / (var * ls[0] ** 2))
+            return (T * self.W).sum(axis=1) / (var * ls ** 2)
 
     def release(self):
         self.dX.free()

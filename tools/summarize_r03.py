@@ -99,7 +99,7 @@ for tag, name in (("headline_kt", "r03_headline"), ("overlap_off_kt", "r03_overl
     off = b["roofline"]["flops_per_row"]
     # a 10M-row pass is 4 launches of 2 097 152 rows (32 GiB of P) and one of 1 611 392: ALL launches are averaged, on the
     # average launch's rows (= rows per step / launches per step, as the bench line's HIP events do)
-    dk = "rr_syrk_f32_diag16_kernel(" if any(nm.startswith("rr_syrk_f32_diag16_kernel(") for nm, _, _, _ in tr) else "rr_syrk_f32_diag_kernel("
+    dk = "rr_syrk_f32_diag16_kernel" if any("rr_syrk_f32_diag16_kernel" in nm for nm, _, _, _ in tr) else "rr_syrk_f32_diag_kernel("
     ks = {"rr_syrk_f32_kernel": annotate(tr, "rr_syrk_f32_kernel(", off * rows, PEAK["f32"], "flop", rows, "off-diagonal 256x256 tiles of Phi^T Phi", "all"),
           dk.rstrip("("): annotate(tr, dk, (F * (F + 1.0) - off) * rows, PEAK["f32"], "flop", rows, "diagonal tiles", "all"),
           "rr_rff_features_mfma_kernel": annotate(tr, "rr_rff_features_mfma_kernel", rows * (4.0 * d + 4.0 + 4.0 * F), PEAK["hbm"], "byte", rows,
