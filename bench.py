@@ -759,7 +759,10 @@ def config_predict(dev, _hip, args, N=300_000):
 
 
 
-def extra_configs(dev, _hip, args):
+def extra_configs(dev, _hip, args, emit=None):
+    """`emit(configs)`: writes the bench line with the configurations finished so far -- called by the watchdog below when
+    one of them hangs, so that the headline measurement is never lost to a side configuration."""
+    import threading
     res = {}
     for name, fn in (("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
                      ("C2laplace_f64phase_n1m", config_laplace), ("C2_elbo_eval", config_elbo),
@@ -775,18 +778,32 @@ def extra_configs(dev, _hip, args):
         t0 = time.perf_counter()
         sys.stderr.write("bench.py: config %s ...\n" % name)
         sys.stderr.flush()
-        # a configuration that hangs says where: every thread's stack goes to stderr after --config-timeout seconds, and the
-        # process then exits non-zero (a hung HIP call cannot be interrupted from Python; the headline line is lost, but
-        # the log names the culprit instead of the driver's clock running out silently)
-        faulthandler.dump_traceback_later(args.config_timeout, exit=True)
+        # a configuration that hangs (a HIP call or a BLAS call that never returns cannot be interrupted from Python) says
+        # where and does not take the headline with it: after --config-timeout seconds a watchdog thread dumps every
+        # thread's stack to stderr, writes the bench line with the configurations finished so far -- this one marked as
+        # timed out -- and ends the process
+        def on_timeout(name=name):
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            res[name] = {"error": "timed out after %.0f s (stacks on stderr); the remaining configurations were not run"
+                                  % args.config_timeout}
+            sys.stderr.write("bench.py: config %s timed out\n" % name)
+            sys.stderr.flush()
+            if emit is not None:
+                emit(res)
+            os._exit(0 if emit is not None else 1)
+        dog = threading.Timer(args.config_timeout, on_timeout)
+        dog.daemon = True
+        dog.start()
         try:
+            if os.environ.get("RR_BENCH_TEST_HANG", "").lower() == name.lower():  # tests/test_gpu_comm.py: the watchdog's own test
+                time.sleep(1e6)
             res[name] = fn(dev, _hip, args)
             res[name]["bench_seconds"] = time.perf_counter() - t0
         except Exception as e:  # a failing side configuration must not take the headline line with it -- but it is said
             res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
             sys.stderr.write("bench.py: config %s failed: %r\n" % (name, e))
         finally:
-            faulthandler.cancel_dump_traceback_later()
+            dog.cancel()
         sys.stderr.write("bench.py: config %s done in %.1f s\n" % (name, time.perf_counter() - t0))
         sys.stderr.flush()
     return res
@@ -1073,8 +1090,12 @@ def main():
         for b in (dX, dy, acc_buf):
             b.free()
         del basis
-        out["configs"] = extra_configs(dev, _hip, args)
-    if rank == 0:
+        def emit(configs):
+            out["configs"] = configs
+            json_out.write(json.dumps(out) + "\n")
+            json_out.flush()
+        emit(extra_configs(dev, _hip, args, emit))
+    elif rank == 0:
         json_out.write(json.dumps(out) + "\n")
         json_out.flush()
     comm.barrier()

@@ -311,3 +311,19 @@ def test_bench_one_gpu_line_has_the_same_keys_under_a_launcher_environment():
     assert _keys(a) == _keys(b) and "exchange" not in a and a["n_gpus"] == b["n_gpus"] == 1
     assert a["config"]["runtime"]["hip_runtime"] == b["config"]["runtime"]["hip_runtime"]
     assert a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"]
+
+
+def test_bench_side_configuration_that_hangs_does_not_take_the_headline_line():
+    """A side configuration stuck in a call that never returns: the watchdog dumps the stacks, writes the ONE JSON line with
+    the headline and the configurations finished so far, marks the hung one, and the process exits 0."""
+    env = dict(os.environ, RR_BENCH_TEST_HANG="posterior_F8257")
+    r = _bench(["--rows", "300000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-alt-engine", "--no-parity-check",
+                "--configs", "posterior_f4096,posterior_f8257,predict_moments_n300k", "--config-timeout", "5"], env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["config"]["trace_rel_err"] < 1e-6
+    assert out["configs"]["posterior_F4096"]["ms"] > 0
+    assert "timed out" in out["configs"]["posterior_F8257"]["error"] and "predict_moments_n300k" not in out["configs"]
+    assert "bench.py: config posterior_F8257 timed out" in r.stderr and "Thread" in r.stderr
