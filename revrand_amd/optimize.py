@@ -320,7 +320,8 @@ def _prefetched(batches, augment=None):
         except BaseException as e:  # surfaces in the consumer
             put(e)
 
-    threading.Thread(target=work, daemon=True).start()
+    worker = threading.Thread(target=work, daemon=True)
+    worker.start()
     try:
         while True:
             item = q.get()
@@ -331,6 +332,9 @@ def _prefetched(batches, augment=None):
             yield item
     finally:
         stop.set()
+        # the worker may be in the middle of a batch (`augment` uploads and gathers on the device for the GLM): let it finish
+        # that one before the caller frees what it writes to
+        worker.join(timeout=60.0)
 
 
 def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, updater=None, eval_obj=False,
