@@ -50,3 +50,8 @@ c3)
 esac; done
 find $OUT -name "*.csv" | wc -l
 du -sh $OUT
+# (appended) clock / pipe-busy counters of the GEMM kernel in the GLM step vs the SLM second pass:  sh tools/prof_r03.sh gemmclk
+case " $* " in *" gemmclk "*)
+  pmc c5_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" --rows 1000000 --steps 1 --warmup 0 --configs c5
+  pmc elbo_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" --rows 1000000 --steps 1 --warmup 0 --configs c2_elbo_eval ;;
+esac

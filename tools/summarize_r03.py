@@ -182,3 +182,48 @@ for tag, name, keys in (("posdef_kt", "r03_posdef", ("posterior_F4096", "posteri
                                               "FastFood chain -> Phi (HBM write)")
     put(name, tag, {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --rows 1000000 --steps 1 --warmup 0 --configs %s" % ",".join(k.lower() for k in keys),
                     "configs": cfgs, "kernels": ks, "all_kernels": st})
+
+
+# ---- the GEMM kernel's clock and cycle efficiency in the GLM step vs the SLM second pass (PMC pass: tools/prof_r03.sh gemmclk) ----
+def gemm_clock(tag, min_us, ideal_cycles):
+    import collections
+    pth = os.path.join(SRC, tag, "p_counter_collection.csv")
+    if not os.path.exists(pth):
+        return None
+    d, t = collections.defaultdict(lambda: collections.defaultdict(float)), {}
+    for r in csv.DictReader(open(pth)):
+        if r["Kernel_Name"].startswith("rr_gemm_tn_f32"):
+            d[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"])
+            t[r["Dispatch_Id"]] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    sel = [k for k in d if t[k] >= min_us and (ideal_cycles is None or t[k] < 3000)] if ideal_cycles else [k for k in d if t[k] >= min_us]
+    if not sel:
+        return None
+    ghz = [d[k]["GRBM_GUI_ACTIVE"] / 8.0 / (t[k] * 1e3) for k in sel]
+    cyc = [d[k]["GRBM_GUI_ACTIVE"] / 8.0 for k in sel]
+    return {"launches": len(sel), "avg_us": sum(t[k] for k in sel) / len(sel), "clock_GHz_avg": sum(ghz) / len(ghz),
+            "clock_GHz_min_max": [min(ghz), max(ghz)], "cycles_per_launch_avg": sum(cyc) / len(cyc),
+            "note": "clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel duration (MI355X_MICROARCH.md, DVFS)"}
+
+
+g5 = gemm_clock("c5_sq", 800.0, 1)
+ge = gemm_clock("elbo_sq", 120000.0, None)  # the 524 288-row launches (the 475 712-row remainder launches take 112 ms)
+if g5 and ge:
+    # ideal MFMA cycles per launch: k-blocks x 16 k-steps x 16 MFMAs x 64 cycles per SIMD, rounds of 256 workgroups
+    g5["ideal_cycles"] = 2 * 64 * 16384.0          # 512 tiles = 2 rounds, K = 2048 = 64 k-blocks
+    g5["cycle_efficiency"] = g5["ideal_cycles"] / g5["cycles_per_launch_avg"]
+    rounds = ge["avg_us"]  # placeholder to keep the structure simple below
+    ge["ideal_cycles"] = 128 * 128 * 16384.0       # 32 768 tiles = 128 rounds, K = 4096 = 128 k-blocks (524 288-row launches)
+    ge["cycle_efficiency"] = ge["ideal_cycles"] / ge["cycles_per_launch_avg"]
+    out = {"what": "rr_gemm_tn_f32_kernel in one SVI step of config 5 (three launches per step) against the same kernel in the SLM "
+                   "second pass: the GLM launches run at a LOWER CLOCK (the chip's DVFS under a bursty 4 ms step) and lose a few "
+                   "more cycles to their two-round, short-K shape",
+           "glm_step_gemms": g5, "slm_second_pass_gemm": ge,
+           "time_ratio_explained": {"clock": ge["clock_GHz_avg"] / g5["clock_GHz_avg"], "cycles": ge["cycle_efficiency"] / g5["cycle_efficiency"]}}
+    dst = os.path.join(ROOT, "profiles", "r03_c5_glm")
+    os.makedirs(dst, exist_ok=True)
+    json.dump(out, open(os.path.join(dst, "gemm_clock.json"), "w"), indent=1)
+    for tag, name in (("c5_sq", "pmc_sq_c5.csv"), ("elbo_sq", "pmc_sq_elbo.csv")):
+        src = os.path.join(SRC, tag, "p_counter_collection.csv")
+        if os.path.getsize(src) < 3 << 20:
+            shutil.copy(src, os.path.join(dst, name))
+    print("r03_c5_glm/gemm_clock.json", json.dumps(out)[:600])
