@@ -273,48 +273,73 @@ def test_config2_full_size_properties():
     assert normwise(P[:256], orc.rff_transform(X[sl][:256], b.W, 1.0)) < 1e-3
 
 
-def test_external_device_pointers_torch():
-    """The *_dev entry points take ANY device memory of the GPU: here torch CUDA tensors (what bench.py does
-    for the RCCL all-reduce).  Also: the padded-layout contract is enforced."""
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    from revrand_amd import _hip
-    N, d, n = 5000, 32, 256
-    F = 2 * n
-    rs = np.random.RandomState(0)
-    X = rs.randn(N, d).astype(np.float32)
-    y = rs.randn(N).astype(np.float32)
-    b = _make("RandomRBF", d, n, 3, False, "f32")
-    h = b._handle()
-    tX = torch.from_numpy(X).cuda()
-    ty = torch.from_numpy(y).cuda()
-    acc = torch.zeros(F * F + F + 1, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    dX = _hip.DeviceMatrix(h.dev, _hip.ctypes.c_void_p(tX.data_ptr()), (N, d), d, np.float32)
-    dy = _hip.DeviceBuffer(h.dev, _hip.ctypes.c_void_p(ty.data_ptr()), N * 4)
+_TORCH_POINTERS = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import revrand_oracle as orc
+from revrand_amd import _hip
+import revrand_amd.basis_functions as bs
+_hip.load_library()            # before torch: RR_HIP_RUNTIME=torch makes it the wheel's runtime, one per process
+import torch
+assert torch.cuda.is_available(), "torch sees no GPU although the library runs on torch's HIP runtime"
+assert "/torch/lib/" in _hip.hip_runtime_path()
+N, d, n = 5000, 32, 256
+F = 2 * n
+rs = np.random.RandomState(0)
+X = rs.randn(N, d).astype(np.float32)
+y = rs.randn(N).astype(np.float32)
+b = bs.RandomRBF(nbases=n, Xdim=d, random_state=3)
+h = b._handle()
+tX = torch.from_numpy(X).cuda()
+ty = torch.from_numpy(y).cuda()
+acc = torch.zeros(F * F + F + 1, dtype=torch.float64, device="cuda")
+torch.cuda.synchronize()
+dX = _hip.DeviceMatrix(h.dev, _hip.ctypes.c_void_p(tX.data_ptr()), (N, d), d, np.float32)
+dy = _hip.DeviceBuffer(h.dev, _hip.ctypes.c_void_p(ty.data_ptr()), N * 4)
+nw = lambda a, r: np.abs(a - r).max() / np.abs(r).max()
+try:
+    p0 = acc.data_ptr()
+    h.gram_dev(dX, dy, 1.0, p0, p0 + F * F * 8, p0 + (F * F + F) * 8)
+    h.symmetrize_dev(p0)
+    h.dev.sync()
+    out = acc.cpu().numpy()
+    Gr, br, tr = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, 1.0)
+    assert nw(out[:F * F].reshape(F, F), Gr) < 2e-5 and nw(out[F * F:F * F + F], br) < 2e-5
+    assert abs(out[-1] - tr) < 1e-6 * tr
+    # a basis with d = 21 needs 32 padded columns: an unpadded device X is refused, not misread
+    b21 = bs.RandomRBF(nbases=64, Xdim=21, random_state=3)
+    t21 = torch.zeros(100, 21, dtype=torch.float32, device="cuda")
+    bad = _hip.DeviceMatrix(h.dev, _hip.ctypes.c_void_p(t21.data_ptr()), (100, 21), 21, np.float32)
     try:
-        p0 = acc.data_ptr()
-        h.gram_dev(dX, dy, 1.0, p0, p0 + F * F * 8, p0 + (F * F + F) * 8)
-        h.symmetrize_dev(p0)
-        h.dev.sync()
-        out = acc.cpu().numpy()
-        Gr, br, tr = orc.rff_gram_chunked(X.astype(np.float64), y.astype(np.float64), b.W, 1.0)
-        assert normwise(out[:F * F].reshape(F, F), Gr) < 2e-5 and normwise(out[F * F:F * F + F], br) < 2e-5
-        assert abs(out[-1] - tr) < 1e-6 * tr
-        # a basis with d = 21 needs 32 padded columns: an unpadded device X is refused, not misread
-        b21 = _make("RandomRBF", 21, 64, 3, False, "f32")
-        t21 = torch.zeros(100, 21, dtype=torch.float32, device="cuda")
-        bad = _hip.DeviceMatrix(h.dev, _hip.ctypes.c_void_p(t21.data_ptr()), (100, 21), 21, np.float32)
-        with pytest.raises(_hip.HipError, match="padded"):
-            b21._handle().gram_dev(bad, None, 1.0, p0)
-        bad.ptr = None
-    finally:
-        dX.ptr = None  # torch owns the memory
-        dy.ptr = None
+        b21._handle().gram_dev(bad, None, 1.0, p0)
+        raise SystemExit("an unpadded device X was accepted")
+    except _hip.HipError as e:
+        assert "padded" in str(e), str(e)
+    bad.ptr = None
+finally:
+    dX.ptr = None   # torch owns the memory
+    dy.ptr = None
+print("TORCH_POINTERS_OK")
+'''
 
 
-@pytest.mark.parametrize("ard", [False, True])
+def test_external_device_pointers_torch():
+    """The *_dev entry points take ANY device memory of the GPU: here torch CUDA tensors.  Also: the padded-layout contract
+    is enforced.  In a process of its own with RR_HIP_RUNTIME=torch: since round 3 the library runs on the HIP runtime it was
+    built against by default, and a process that imports torch AFTER loading the library must say so (one runtime per
+    process, DESIGN 5)."""
+    import os
+    import subprocess
+    import sys
+    pytest.importorskip("torch")
+    from conftest import ROOT
+    code = _TORCH_POINTERS % (ROOT, os.path.join(ROOT, "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RR_HIP_RUNTIME="torch"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0 and "TORCH_POINTERS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_grad_contract_vs_materialised_gradient(ard):
     """sum(E o dPhi_i) through rr_rff_grad_contract == the same contraction of the oracle's dPhi tensor
     (the GLM's basis-gradient consumer, glm.py:274-275), incl. the isotropic dimension-0 quirk."""
