@@ -191,6 +191,7 @@ struct PosdefScratch {
     double *diL = nullptr, *dvec = nullptr;            // dvec: [chol diag (Fp) | m (F) | diagC (F) | tr (1)]
     double *Uinv = nullptr;                            // (Fp / 128) blocks of 128 x 128: U_jj^-1
     int64_t Fp = 0;
+    std::vector<hipEvent_t> ev;                        // "block row j of the factor is final" (+ one for the join), grow-only
     void release() {
         void *q[] = {W, Y, Cp, diL, dvec, Uinv};
         for (void *x : q)
@@ -315,21 +316,79 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     hipLaunchKernelGGL(rr_assemble_ic_kernel, dim3(eb), dim3(256), 0, c->stream, dG, s.diL, ivar, F, Fp, s.W);
     hipLaunchKernelGGL(rr_set_identity_kernel, dim3(eb), dim3(256), 0, c->stream, s.Y, Fp);
     RR_CHECK_HIP(hipGetLastError());
-    // ---- factor: W = U^T U (upper triangle of W); Uinv_j = U_jj^-1 on the side ----
-    int rc = chol_upper_blocked(c, s, Fp);
-    if (rc != RR_OK) return rc;
-    hipLaunchKernelGGL(rr_get_diag_kernel, dim3((unsigned)((Fp + 255) / 256)), dim3(256), 0, c->stream, s.W, Fp, ld, s.dvec);
-    // ---- Y = U^-T by block forward substitution on the identity (Y lower triangular) ----
-    for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
-        const double *Ujj = s.W + j * PB * (ld + 1);
-        double *Yj = s.Y + j * PB * ld;
-        const int64_t width = (j + 1) * PB;  // non-zero columns of block row j
-        rc = rr_launch_gemm_tn_f64(c, s.Uinv + j * PB * PB, PB, Yj, ld, Yj, ld, PB, PB, width, 0, 0);  // Y_j <- U_jj^-T Y_j
-        const int64_t rest = Fp - (j + 1) * PB;
-        if (rc == RR_OK && rest > 0)
-            rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+    // ---- factor: W = U^T U (upper triangle of W), Uinv_j = U_jj^-1 on the side, and -- interleaved panel by panel --
+    // ---- Y = U^-T by block forward substitution on the identity (Y lower triangular).
+    // Step j of the substitution needs U_jj^-1 and the finished block row j of the factor only, not the trailing update
+    // that follows it: it runs on the context's second stream while the factorisation goes on to panel j + 1 (round 3).
+    // Both chains are sequences of small launches (a 128-column panel is 1-32 tiles), so running them side by side
+    // shortens the call from 2 x 32 to ~32 dependent panel steps.  RR_POSDEF_OVERLAP=0: one stream, factor first (A/B).
+    static const bool no_overlap = getenv("RR_POSDEF_OVERLAP") != nullptr && atoi(getenv("RR_POSDEF_OVERLAP")) == 0;
+    const bool overlap = !no_overlap && nblk > 1;
+    if (overlap && !c->stream2) {
+        RR_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+        RR_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     }
-    if (rc != RR_OK) return rc;
+    if (overlap && (int64_t)s.ev.size() < nblk + 1) {
+        while ((int64_t)s.ev.size() < nblk + 1) {
+            hipEvent_t e;
+            RR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            s.ev.push_back(e);
+        }
+    }
+    const hipStream_t main_stream = c->stream;
+    struct StreamGuard {  // rr_launch_gemm_tn_f64 takes the stream from the context: never leave it on the second one
+        rr_ctx *c;
+        hipStream_t s;
+        ~StreamGuard() { c->stream = s; }
+    } guard{c, main_stream};
+    int rc = RR_OK;
+    if (overlap) {  // the second stream starts behind everything queued so far (W and Y assembled)
+        RR_CHECK_HIP(hipEventRecord(c->ev_fork, main_stream));
+        RR_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
+    for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
+        double *Ujj = s.W + j * PB * (ld + 1);
+        double *Uij = s.Uinv + j * PB * PB;
+        const int64_t rest = Fp - (j + 1) * PB;
+        // factor, panel j (context's stream)
+        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, main_stream, Ujj, ld, Uij);
+        if (rest > 0) rc = rr_launch_gemm_tn_f64(c, Uij, PB, Ujj + PB, ld, Ujj + PB, ld, PB, PB, rest, 0, 0);  // panel <- U_jj^-T panel
+        if (rc != RR_OK) break;
+        if (overlap) RR_CHECK_HIP(hipEventRecord(s.ev[j], main_stream));  // block row j of the factor is final
+        if (rest > 0)
+            rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Ujj + PB, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 1);  // trailing update
+        if (rc != RR_OK) break;
+        // substitution, step j (second stream, or behind the whole factorisation when not overlapped: see below)
+        if (overlap) {
+            RR_CHECK_HIP(hipStreamWaitEvent(c->stream2, s.ev[j], 0));
+            c->stream = c->stream2;
+            double *Yj = s.Y + j * PB * ld;
+            const int64_t width = (j + 1) * PB;  // non-zero columns of block row j
+            rc = rr_launch_gemm_tn_f64(c, Uij, PB, Yj, ld, Yj, ld, PB, PB, width, 0, 0);  // Y_j <- U_jj^-T Y_j
+            if (rc == RR_OK && rest > 0) rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+            c->stream = main_stream;
+        }
+    }
+    if (rc != RR_OK) {
+        if (overlap) (void)hipStreamSynchronize(c->stream2);  // nothing of this call may outlive it on the second stream
+        return rc;
+    }
+    hipLaunchKernelGGL(rr_get_diag_kernel, dim3((unsigned)((Fp + 255) / 256)), dim3(256), 0, main_stream, s.W, Fp, ld, s.dvec);
+    if (overlap) {  // the context's stream continues behind the substitution
+        RR_CHECK_HIP(hipEventRecord(s.ev[nblk], c->stream2));
+        RR_CHECK_HIP(hipStreamWaitEvent(main_stream, s.ev[nblk], 0));
+    } else {
+        for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
+            const double *Ujj = s.W + j * PB * (ld + 1);
+            double *Yj = s.Y + j * PB * ld;
+            const int64_t width = (j + 1) * PB;
+            rc = rr_launch_gemm_tn_f64(c, s.Uinv + j * PB * PB, PB, Yj, ld, Yj, ld, PB, PB, width, 0, 0);
+            const int64_t rest = Fp - (j + 1) * PB;
+            if (rc == RR_OK && rest > 0)
+                rc = rr_launch_gemm_tn_f64(c, Ujj + PB, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+        }
+        if (rc != RR_OK) return rc;
+    }
     RR_CHECK_HIP(hipGetLastError());
     // the diagonal decides before the rest is worth computing
     std::vector<double> h((size_t)3 * Fp + 1);
