@@ -340,6 +340,7 @@ def test_external_device_pointers_torch():
     assert r.returncode == 0 and "TORCH_POINTERS_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("ard", [False, True])
 def test_grad_contract_vs_materialised_gradient(ard):
     """sum(E o dPhi_i) through rr_rff_grad_contract == the same contraction of the oracle's dPhi tensor
     (the GLM's basis-gradient consumer, glm.py:274-275), incl. the isotropic dimension-0 quirk."""
