@@ -98,19 +98,13 @@ __global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ 
                 app = 1.0;
             }
             const double dp = sqrt(app), inv = 1.0 / dp;
-            // Element (r, c), r > p, is updated by -U[p][r] v with v = U[p][c] where it belongs to the Cholesky work matrix
-            // (c >= r) and v = T[p][c] where it belongs to W of the substitution (c < r; T[p][c] = 0 for c > p).  Which of
-            // the two an element is does not depend on p: above / below the diagonal sub-block by its (i, j), inside it by
-            // tx >= ty -- so the 64 updates of a step are plain FMAs on two prepared vectors (round 3; before: a
-            // three-way runtime predicate per element, 89 us per block).  Rows r <= p get a zero multiplier.
-            double ur[8], vc[8], vt[8];
+            double ur[8], vc[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ur[i] = (16 * i + ty > p) ? rb[16 * i + ty] * inv : 0.0;  // U[p][r], rows r > p only
+            for (int i = 0; i < 8; ++i) ur[i] = rb[16 * i + ty] * inv;  // U[p][r] for this thread's rows r > p
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c = 16 * j + tx;
-                vc[j] = c == p ? inv : rb[c] * inv;      // U[p][c] (c > p), T[p][p], T[p][c] (c < p)
-                vt[j] = c <= p ? vc[j] : 0.0;            // T[p][c]: zero right of the pivot
+                vc[j] = c == p ? inv : rb[c] * inv;  // U[p][c] (c > p), T[p][p], T[p][c] (c < p)
             }
             if (ty == pk) {  // row p becomes final: U[p][c], and T[p][c] in the lower slots
 #pragma unroll
@@ -119,14 +113,14 @@ __global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ 
                     a[pi][j] = c == p ? dp : vc[j];
                 }
             }
-            const bool dsel = tx >= ty;  // inside a diagonal 16 x 16 sub-block: this thread's element is on / above the diagonal
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if (i < pi) continue;  // rows 16 i + ty <= p
+                const int r = 16 * i + ty;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const double v = j > i ? vc[j] : (j < i ? vt[j] : (dsel ? vc[j] : vt[j]));
-                    a[i][j] = fma(-ur[i], v, a[i][j]);
+                    const int c = 16 * j + tx;
+                    if (r > p && (c >= r || c <= p)) a[i][j] = fma(-ur[i], vc[j], a[i][j]);
                 }
             }
         }
