@@ -2272,6 +2272,14 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
     int64_t chunk = (int64_t)(((size_t)32 << 30) / ((size_t)ldp * sizeof(TC)));
     const char *cenv = getenv("RR_GRAM_CHUNK_ROWS");
     if (cenv && atoll(cenv) >= KB) chunk = atoll(cenv);
+    else if (N > chunk) {
+        // several chunks: equal ones (10M rows at F = 4096: 5 x 2 000 000 instead of 4 x 2 097 152 + 1 611 392).  Besides the
+        // balance, 2^21-row launches put the K-splits of the SYRK exactly 2^15 rows = 512 MiB apart, and the concurrently
+        // running workgroups of different splits then alias in the L2: 107 instead of 83 KB/row of L2->fabric fetch
+        // (profiles/r03_headline; no change in time, the kernel is MFMA-bound, but 30 % more fabric traffic for nothing)
+        const int64_t nchunks = (N + chunk - 1) / chunk;
+        chunk = (N + nchunks - 1) / nchunks;
+    }
     if (chunk > N) chunk = N;
     // split-bf16 engine with the MFMA feature kernel: the features are produced directly in the SYRK's K-blocked
     // bf16 hi/lo layout (same 4 bytes per value), whole 64-row groups

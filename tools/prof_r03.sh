@@ -55,3 +55,16 @@ case " $* " in *" gemmclk "*)
   pmc c5_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" --rows 1000000 --steps 1 --warmup 0 --configs c5
   pmc elbo_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" --rows 1000000 --steps 1 --warmup 0 --configs c2_elbo_eval ;;
 esac
+# (appended) L2->fabric traffic of the headline kernels, separate PMC passes:  sh tools/prof_r03.sh hbm
+case " $* " in *" hbm "*)
+  pmc headline_fetch FETCH_SIZE --rows 2097152 --steps 1 --warmup 0 --configs none
+  pmc headline_write WRITE_SIZE --rows 2097152 --steps 1 --warmup 0 --configs none ;;
+esac
+# (appended) the same with the default command's own chunking (N = 10M), one pass:  sh tools/prof_r03.sh hbm10m
+case " $* " in *" hbm10m "*)
+  pmc headline10m_fetch FETCH_SIZE --steps 1 --warmup 0 --configs none
+  for rep in 1 2; do
+    RR_GRAM_CHUNK_ROWS=2097152 python bench.py $Q --steps 3 --warmup 1 --configs none > $OUT/chunk_pow2_$rep.json 2> $OUT/chunk_pow2_$rep.err
+    python bench.py $Q --steps 3 --warmup 1 --configs none > $OUT/chunk_equal_$rep.json 2> $OUT/chunk_equal_$rep.err
+  done ;;
+esac
