@@ -539,7 +539,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             if (rc != RR_OK) break;
         } else {
             GemmArgs g;
-            g.A = s.Pt; g.B = Bprep ? Bprep : s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)Fp; g.ntb = (int)(Fp / 256);
+            g.A = s.Pt; g.B = Bprep ? Bprep : s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)(((int64_t)F + GR_KB - 1) / GR_KB * GR_KB); g.ntb = (int)(Fp / 256);  // K: the valid feature rows only (the rest of Fp is zero padding)
             g.upper_b = pred ? 1 : 0;
             hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
         }
@@ -856,7 +856,8 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
     }
     GemmArgs g;
     g.A = s.Pt; g.B = s.C32; g.D = s.U; g.lda = fm->max_rows; g.ldb = fm->ld; g.ldd = fm->ld;
-    g.K = (int)fm->ld; g.ntb = (int)(fm->ld / 256);
+    g.K = (int)(((int64_t)fm->F + GR_KB - 1) / GR_KB * GR_KB);  // the valid feature rows only: F = 8257 -> 8288 of the 8448 padded ones
+    g.ntb = (int)(fm->ld / 256);
     g.upper_b = s.tri_c ? 1 : 0;
     hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
@@ -1147,7 +1148,7 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
         if (rc != RR_OK) break;
         hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
                            s.P, mrows, Fp, s.Pt, chunk);
-        rc = rr_launch_gemm_tn_f64(c, s.Pt, chunk, s.Cp, Fp, s.U, Fp, Fp, mpad, Fp, 0, 0);
+        rc = rr_launch_gemm_tn_f64(c, s.Pt, chunk, s.Cp, Fp, s.U, Fp, ((int64_t)F + 15) / 16 * 16, mpad, Fp, 0, 0);
         if (rc != RR_OK) break;
         if (pred) {
             hipLaunchKernelGGL(rr_rows64_kernel<1>, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.U, s.m,
@@ -2112,7 +2113,7 @@ static int fm64_products(rr_featmat64 *fm) {
     hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rp / 64)), dim3(256), 0, c->stream, fm->P,
                        fm->rows, Fp, fm->Pt, fm->max_rows);
     RR_CHECK_HIP(hipGetLastError());
-    return rr_launch_gemm_tn_f64(c, fm->Pt, fm->max_rows, fm->Cp, Fp, fm->U, Fp, Fp, rp, Fp, 0, 0);
+    return rr_launch_gemm_tn_f64(c, fm->Pt, fm->max_rows, fm->Cp, Fp, fm->U, Fp, ((int64_t)fm->F + 15) / 16 * 16, rp, Fp, 0, 0);
 }
 
 extern "C" {
