@@ -306,6 +306,14 @@ int rr_featmat_glm_step_draws_dev(rr_featmat *fm, const void *dy, const void *dr
  * [col0, col0 + 2n):  sum(EdPhi o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]  (glm.py:274-275 without basis.grad). */
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
                        double *dT);
+/* Announce, BEFORE a step, the rr_featmat_glm_rff call that will follow it (same arguments; dT zeroed by the caller).
+ * When the whole matrix is this child's [cos | sin] block (col0 == 0, 2n == F, n % 256 == 0, d <= 32, float32 X, f32
+ * engine, not deterministic mode) the step contracts every 256x256 block of EdPhi = dfs^T ws / (K L) (glm.py:311) with
+ * P and X while it is still in registers and adds the result to dT (rr_gemm_gradt_f32_kernel): EdPhi is neither written
+ * nor read back, and the rr_featmat_glm_rff call that follows returns at once.  Otherwise the plan is dropped and
+ * nothing changes.  A plan holds for ONE step.  RR_GLM_NO_FUSE=1 drops every plan (A/B runs). */
+int rr_featmat_glm_plan_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
+                            double *dT);
 /* EdPhi[:, col0:col0+ncols] to the host (rows, ncols) float64, for bases whose gradient is formed on the host. */
 int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E);
 /* out (rows, S) = P W for a host (F, S) float64 matrix: the latent function samples of glm.py:572-620. */

@@ -134,6 +134,8 @@ SIGNATURES = {
                                       ctypes.c_void_p]),
     "rr_featmat_glm_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat_glm_plan_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_project": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "rr_posterior_available": (ctypes.c_int, []),
@@ -836,6 +838,10 @@ class FeatureMatrix(object):
             none if objective_only else EdC.ctypes.data_as(ctypes.c_void_p), ll.ctypes.data_as(ctypes.c_void_p),
             aux.ctypes.data_as(ctypes.c_void_p)))
         return (None, None, ll, aux) if objective_only else (Edm.T, EdC.T, ll, aux)
+
+    def glm_plan_rff(self, handle, dX, col0, dT):
+        """Announce the glm_rff call that follows the next step (the step may then contract EdPhi itself)."""
+        _check(self.lib, self.lib.rr_featmat_glm_plan_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))
 
     def glm_rff(self, handle, dX, col0, dT):
         _check(self.lib, self.lib.rr_featmat_glm_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))

@@ -643,8 +643,21 @@ class MinibatchFeatures(object):
             col0 += w
         self.M = M
 
+    def _plan_basis_grads(self, objective_only=False):
+        """A lone random Fourier child: tell the step which contraction `glm_basis_grads` will ask for, so that it can
+        form it from the blocks of EdPhi while they are in registers (rr_featmat_glm_plan_rff); dT is zeroed here."""
+        self._planned = False
+        if objective_only or len(self.children) != 1:
+            return
+        child, col0, _ = self.children[0]
+        if isinstance(child, _ResidentRFF):
+            child.reset()
+            self.fm.glm_plan_rff(child.h, child.batch(self.M), col0, child.dT)
+            self._planned = True
+
     def glm_step(self, y, rowarg, lik, lik_param, WS, K, L):
         dy, dn = self._take_targets(y, rowarg)
+        self._plan_basis_grads()
         return self.fm.glm_step(dy, dn, lik, lik_param, WS, K, L)
 
     supports_objective_only = True  # glm_step_sampled / glm_step_draws take objective_only=True (no gradient GEMMs)
@@ -652,17 +665,20 @@ class MinibatchFeatures(object):
 
     def glm_step_sampled(self, y, rowarg, lik, lik_param, m, C, K, L, seed, step, objective_only=False):
         dy, dn = self._take_targets(y, rowarg)
+        self._plan_basis_grads(objective_only)
         return self.fm.glm_step_sampled(dy, dn, lik, lik_param, m, C, K, L, seed, step, objective_only)
 
     def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E, objective_only=False):
         dy, dn = self._take_targets(y, rowarg)
+        self._plan_basis_grads(objective_only)
         return self.fm.glm_step_draws(dy, dn, lik, lik_param, m, C, K, L, E, objective_only)
 
     def glm_basis_grads(self, X):
         grads = []
         for child, col0, w in self.children:
             if isinstance(child, _ResidentRFF):
-                child.reset()
+                if not self.__dict__.pop("_planned", False):  # (planned: dT was zeroed before the step, which may have
+                    child.reset()                              # accumulated it already -- glm_rff then returns at once)
                 self.fm.glm_rff(child.h, child.batch(self.M), col0, child.dT)
                 g = [child.dhyp(1.0)]   # -(E o dPhi_i).sum() = +(1/l_i^2) W[i,:].T[i,:]
             elif child.nparams:

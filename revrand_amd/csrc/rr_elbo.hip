@@ -191,6 +191,145 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_tn_f32_kernel(const Gem
 __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_trig_f32_kernel(const GemmArgs p) { rr_gemm_tn_f32_body<true>(p); }
 
 // ---------------------------------------------------------------------------------------------
+// The GLM step's third product WITH its consumer (glm.py:275-283 for a random Fourier basis): the 256x256 block of
+//   EdPhi = A^T B   (A = dfs^T (K = kl, rows), B = ws / (K L) (kl, F = 2n))
+// never leaves the registers.  Column block cb of the cos half (cb < n) pairs with the sin half of P and vice versa:
+//   R[r][c] = -EdPhi[r][c] P[r][c + n]  (c < n),   R[r][c] = +EdPhi[r][c] P[r][c - n]  (c >= n)
+//   T[i][c mod n] += sum_r X[r][i] R[r][c]                                  (what rr_glm_grad_t_kernel forms from HBM)
+// The accumulator layout of v_mfma_f32_32x32x2_f32 IS its B-operand layout for the row pair (r, r + 4): element e of
+// lane l is row (e & 3) + 8 (e >> 2) + 4 (l >> 5), column l & 31 -- so R goes straight back into the matrix pipe as B
+// with A = X[r + 4 (l >> 5)][l & 31] (one coalesced 128-byte row per half wave): 128 MFMAs per wave and tile (one
+// k-block's worth beside the tile's K / 32), no LDS, no barrier.  A workgroup keeps its column block and walks over
+// row tiles g, g + G, ..: T stays in 32 registers per lane until one f64 atomic flush at the end.
+// Saves EdPhi's write (rows x F floats), its re-read and P's second read by the contraction kernel.
+// ---------------------------------------------------------------------------------------------
+typedef __amdgpu_buffer_rsrc_t rr_rsrc_t;
+typedef unsigned rr_u4_t __attribute__((ext_vector_type(4)));
+// raw buffer descriptor over `bytes` bytes at a WAVE-UNIFORM address (made provably uniform for the compiler)
+__device__ __forceinline__ rr_rsrc_t rr_make_rsrc(const void *base, unsigned bytes) {
+    const uint64_t a = (uint64_t)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes),
+                                             0x00020000);
+}
+
+struct GradtArgs {
+    const float *A, *B;
+    int64_t lda, ldb;
+    int K, ntb, nta;  // k rows; column tiles of B (= 2n / 256); row tiles of A
+    const float *P;   // feature matrix (rows, ldp), columns [0, 2n)
+    int64_t ldp;
+    const float *X;   // the child's inputs (rows, ldx), d <= 32 valid columns
+    int64_t ldx, rows;
+    int n, d;
+    double *T;        // (d, n), accumulated into
+};
+
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const GradtArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % p.ntb));
+    const int g0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / p.ntb)), G = __builtin_amdgcn_readfirstlane((int)(gridDim.x / p.ntb));
+    const int cb = tb * GR_TC;
+    const bool cosblk = cb < p.n;
+    const int pcol = cosblk ? cb + p.n : cb - p.n;  // partner column block in P
+    const int tcol = cosblk ? cb : cb - p.n;        // column block in T
+    const float sgn = cosblk ? -1.f : 1.f;
+
+    const int wr = wave >> 2, wc_ = wave & 3;
+    const int hi = lane >> 5, l31 = lane & 31;
+    const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
+    const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const int nkb = p.K / GR_KB;
+    const bool xlane = l31 < p.d;
+    const float xmask = xlane ? 1.f : 0.f;
+
+    floatx16 tacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) tacc[j][e] = 0.f;
+
+    auto dma_tile = [&](float *buf, int64_t ca, int kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
+            const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
+            float *dst = buf + lr * GR_LD;
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
+        }
+    };
+
+    if (g0 < p.nta) dma_tile(lds, (int64_t)g0 * GR_TC, 0);
+    for (int ta = g0; ta < p.nta; ta += G) {
+        const int64_t ca = (int64_t)ta * GR_TC;
+        floatx16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        __syncthreads();  // k-block 0 of this tile has landed (requested before the previous tile's epilogue)
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cbuf = kb & 1;
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB);
+            gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+            __syncthreads();
+        }
+        // the next tile's first k-block flies under this tile's epilogue (nkb is even or odd: buffer 0 is free either way
+        // after the barrier above)
+        if (ta + G < p.nta) dma_tile(lds, (int64_t)(ta + G) * GR_TC, 0);
+
+        // The tile's block of P (partner columns) and its rows of X through buffer descriptors: base and row steps are
+        // wave-uniform (SGPRs), the lane part is one 32-bit offset per tile, and rows past the end of a partial last
+        // tile fall outside the descriptor's extent and read as zero (their EdPhi is zero as well: dfs^T holds zero
+        // columns there).  48 loads are in flight per lane and batch before the first product needs one.
+        const unsigned tr = (unsigned)(p.rows - ca < GR_TC ? p.rows - ca : GR_TC);  // rows of this tile that exist
+        const rr_rsrc_t prs = rr_make_rsrc(p.P + ca * p.ldp + pcol, (tr * (unsigned)p.ldp - (unsigned)pcol) * 4u);
+        const rr_rsrc_t xrs = rr_make_rsrc(p.X + ca * p.ldx, tr * (unsigned)p.ldx * 4u);
+        const unsigned ldp4 = (unsigned)p.ldp * 4u, ldx4 = (unsigned)p.ldx * 4u;
+        unsigned pofs = (unsigned)(wr * 128 + 4 * hi) * ldp4 + (unsigned)(wc_ * 64 + l31) * 4u;
+        unsigned xofs = (unsigned)(wr * 128 + 4 * hi) * ldx4 + (unsigned)(xlane ? l31 : 0) * 4u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float xv[16], pv[2][16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2));
+                xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xofs, ro * ldx4, 0));
+                pv[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs, ro * ldp4, 0));
+                pv[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs + 128u, ro * ldp4, 0));
+            }
+            __builtin_amdgcn_sched_barrier(0);  // all of the batch's loads are issued before its first product
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float xe = xv[e] * xmask;  // (a multiply, not a select: the loads stay unconditional and batched)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, acc[i][j][e] * pv[j][e], tacc[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            pofs += 32u * ldp4;
+            xofs += 32u * ldx4;
+        }
+    }
+
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
+            if (i < p.d) unsafeAtomicAdd(&p.T[(size_t)i * p.n + tcol + wc_ * 64 + j * 32 + l31], (double)(sgn * tacc[j][e]));
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Row reductions: one wave per row.
 //   MODE 0:  out[r] = sum_j U[r][j] P[r][j]                        (Vf of predict_moments)
 //   MODE 1:  err[r] = y[r] - dot[r];  *sq += sum_r err[r]^2         (Err, sqErr of _elbo)
@@ -718,6 +857,191 @@ rr_glm_lik_kernel(float *__restrict__ FSt, int64_t M, int64_t rows256, int64_t l
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The step's first product WITH the likelihood kernel above as its epilogue: the 256x256 block of fs = P WS^T turns into
+// dfs in the accumulators and is stored twice -- row-major (the A operand of Ed = dfs Phi) and transposed (kl, rows: the
+// A operand of EdPhi = dfs^T ws), four consecutive rows of a column as one 16-byte store -- and the per-component sums
+// go through LDS to one f64 atomic per component and workgroup.  Saves the likelihood kernel's read + write of fs and
+// the transposing pass over dfs (three passes over rows x kl floats).  Whole K per workgroup (no split-K).
+// ---------------------------------------------------------------------------------------------
+// d loglike / d f and the log-likelihood term of one element (the formulas of rr_glm_lik_kernel)
+template <int LIK>
+__device__ __forceinline__ void rr_lik_elem(float f, float yr, float nn, float ipar, float &df, float &ll) {
+    if (LIK == RR_LIK_BERNOULLI) {
+        df = yr - rr_expit(f);
+        ll = yr * f - rr_softplus(f);
+    } else if (LIK == RR_LIK_BINOMIAL) {
+        df = yr - nn * rr_expit(f);
+        ll = yr * f - nn * rr_softplus(f);
+    } else if (LIK == RR_LIK_GAUSSIAN) {
+        const float er = yr - f;
+        df = er * ipar;
+        ll = er * er;
+    } else if (LIK == RR_LIK_POISSON_EXP) {
+        const float g = __expf(f);
+        df = yr - g;
+        ll = yr * f - g;
+    } else {  // Poisson, softplus link
+        const float g = fmaxf(rr_softplus(f), 1e-37f);
+        df = rr_expit(f) * (yr / g - 1.f);
+        ll = yr * __logf(g) - g;
+    }
+}
+
+struct GemmLikArgs {
+    const float *A, *B;   // A = P^T (K = Fp, rows), B = WS^T (Fp, kl)
+    float *D, *Dt;        // dfs (rows256, ldd) and dfs^T (kl, ldt); BOTH null: objective only, nothing stored
+    int64_t lda, ldb, ldd, ldt;
+    int K, ntb;
+    const void *y, *rowarg;
+    int y_f64;
+    int64_t M;            // valid rows
+    float par, fscale;
+    int KL, L;
+    double *llsum, *aux;
+};
+
+template <int LIK, bool ST>  // ST: store dfs and dfs^T (false: objective only)
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_lik_f32_kernel(const GemmLikArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t ta = blockIdx.x / p.ntb;
+    const int tb = (int)(blockIdx.x % p.ntb);
+    const int64_t ca = ta * GR_TC;
+    const int cb = tb * GR_TC;
+    const int wr = wave >> 2, wc_ = wave & 3;
+    const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
+    const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto dma_tile = [&](float *buf, int kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
+            const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
+            float *dst = buf + lr * GR_LD;
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
+        }
+    };
+    const int nkb = p.K / GR_KB;
+    dma_tile(lds, 0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cbuf = kb & 1;
+        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB);
+        gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+        __syncthreads();
+    }
+
+    // the tile buffers are free now: [0, 258) per-component sums, [512, 768) the tile's targets, [768, 1024) its row
+    // argument, [1024, 1280) 1 / 0 for rows that exist / do not
+    float *sacc = lds, *sy = lds + 512, *sn = lds + 768, *sm = lds + 1024;
+    for (int t = tid; t < 258; t += GR_THREADS) sacc[t] = 0.f;
+    if (tid < GR_TC) {
+        const int64_t r = ca + tid;
+        float yv = 0.f, nv = 0.f;
+        sm[tid] = r < p.M ? 1.f : 0.f;
+        if (r < p.M) {
+            yv = p.y_f64 ? (float)((const double *)p.y)[r] : ((const float *)p.y)[r];
+            if (LIK == RR_LIK_BINOMIAL) nv = p.y_f64 ? (float)((const double *)p.rowarg)[r] : ((const float *)p.rowarg)[r];
+        }
+        sy[tid] = yv;
+        sn[tid] = nv;
+    }
+    __syncthreads();
+
+    const int hi = lane >> 5, l31 = lane & 31;
+    constexpr int lik = LIK;
+    const float ipar = lik == RR_LIK_GAUSSIAN ? 1.f / p.par : 0.f;
+    float red[2] = {0.f, 0.f};
+    const int rl0 = wr * 128 + 4 * hi;
+    const float cm[2] = {cb + wc_ * 64 + l31 < p.KL ? 1.f : 0.f, cb + wc_ * 64 + 32 + l31 < p.KL ? 1.f : 0.f};
+    // Four rows of a column block at a time: likelihood terms, one 16-byte store into dfs^T, four 4-byte stores into dfs --
+    // through buffer descriptors (tile bases and row steps in SGPRs, one 32-bit lane offset each).  The accumulators are
+    // only read.  Row / column validity are weights (1 / 0), not predicates: 128 lane masks would live in SGPR pairs.
+    typedef float float4v __attribute__((ext_vector_type(4)));
+    constexpr bool st = ST;
+    const unsigned ldd4 = (unsigned)p.ldd * 4u, ldt4 = (unsigned)p.ldt * 4u;
+    rr_rsrc_t drs, trs;
+    unsigned dofs = 0, tofs = 0;
+    if (st) {
+        drs = rr_make_rsrc(p.D + ca * p.ldd + cb, 256u * ldd4 - (unsigned)cb * 4u);
+        trs = rr_make_rsrc(p.Dt + (int64_t)cb * p.ldt + ca, 256u * ldt4 - (unsigned)ca * 4u);
+        dofs = (unsigned)(wr * 128 + 4 * hi) * ldd4 + (unsigned)(wc_ * 64 + l31) * 4u;
+        tofs = (unsigned)(wc_ * 64 + l31) * ldt4 + (unsigned)(wr * 128 + 4 * hi) * 4u;
+    }
+    // (the targets / weights come through asm reads pinned in program order: instruction selection otherwise emits all 48
+    // LDS reads of the epilogue first -- 192 registers -- and spills)
+    const unsigned srow = lds0 + 4u * (unsigned)rl0;  // byte address of lds[rl0]; sy / sn / sm sit 2048 / 3072 / 4096 bytes on
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4v y4, m4, n4 = {0.f, 0.f, 0.f, 0.f};  // rows rl0 + 32 i + 8 q + (0..3)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(y4) : "v"(srow), "i"(2048 + 4 * (32 * i + 8 * q)));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m4) : "v"(srow), "i"(4096 + 4 * (32 * i + 8 * q)));
+            if (LIK == RR_LIK_BINOMIAL)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(n4) : "v"(srow), "i"(3072 + 4 * (32 * i + 8 * q)));
+            lds_wait();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float4v v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float df, ll;
+                    rr_lik_elem<LIK>(acc[i][j][4 * q + r] * p.fscale, y4[r], n4[r], ipar, df, ll);  // fs was formed with ws / (K L)
+                    const float w = m4[r] * cm[j];
+                    v[r] = df * w;
+                    red[j] = fmaf(ll, w, red[j]);
+                }
+                // (pinned before the next group's reads: the scheduler otherwise sinks all 128 log-likelihood terms to the
+                // end of the epilogue and spills their inputs)
+                asm volatile("" : "+v"(red[j]));
+                if (st) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rr_u4_t, v), trs, tofs + (unsigned)(8 * q) * 4u,
+                                                           (unsigned)(j * 32) * ldt4, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[r]), drs, dofs + (unsigned)(j * 128),
+                                                              (unsigned)(r + 8 * q) * ldd4, 0);
+                }
+            }
+        }
+        dofs += 32u * ldd4;
+        tofs += 128u;
+    }
+    // per-component sums: LDS first (the tile's 256 columns span at most 256 / L + 2 components), then one atomic each
+    const int k0 = cb / p.L;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int gc = cb + wc_ * 64 + j * 32 + l31;
+        if (gc < p.KL) atomicAdd(&sacc[gc / p.L - k0], red[j]);
+    }
+    __syncthreads();
+    const int klast = cb + 255 < p.KL ? cb + 255 : p.KL - 1;
+    const int nk = klast >= cb ? klast / p.L - k0 + 1 : 0;
+    for (int t = tid; t < nk; t += GR_THREADS) {
+        const double v = (double)sacc[t];
+        if (lik == RR_LIK_GAUSSIAN) {
+            unsafeAtomicAdd(&p.aux[k0 + t], v);
+            unsafeAtomicAdd(&p.llsum[k0 + t], -0.5 * v * (double)ipar);
+        } else {
+            unsafeAtomicAdd(&p.llsum[k0 + t], v);
+        }
+    }
+}
+
 // T[i][f] += sum_r x[r][i] * (E[r][n+f] P[r][f] - E[r][f] P[r][n+f]):  sum(E o dPhi_i) = -(1/l_i^2) W[i,:].T[i,:]
 template <int DMAX, typename TX>
 __global__ void __launch_bounds__(256)
@@ -819,6 +1143,15 @@ struct FmPass2 {
     int64_t klp = 0;
     int kcap = 0;
     bool have_edphi = false;
+    // rr_featmat_glm_plan_rff: the next step's EdPhi product may contract itself with this child (rr_gemm_gradt_f32_kernel)
+    struct {
+        rr_basis *b = nullptr;
+        const void *dX = nullptr;
+        int64_t ldx = 0, col0 = 0;
+        double *dT = nullptr;
+        bool armed = false;  // planned, not yet consumed by a step
+        bool done = false;   // the last step accumulated dT itself: rr_featmat_glm_rff for this child has nothing left to do
+    } fuse;
 };
 
 float *rr_fm_pass2_pt(void *p) { return p ? ((FmPass2 *)p)->Pt : nullptr; }
@@ -1751,6 +2084,15 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     const int KL = K * L;
     const int64_t Fp = fm->ld, kl_ld = s.klp;
     const int64_t rows256 = (fm->rows + 255) / 256 * 256;
+    // a plan is good for one step; it is taken when the whole matrix is that child's [cos | sin] block in whole tiles
+    // (RR_GLM_NO_FUSE=1: never -- the EdPhi GEMM and rr_glm_grad_t_kernel as separate passes, for A/B runs)
+    const char *nf = getenv("RR_GLM_NO_FUSE");
+    const bool no_fuse = nf && atoi(nf) != 0;
+    const bool fuse = s.fuse.armed && !objective_only && !no_fuse && c->gram_engine == 0 && !c->deterministic &&
+                      s.fuse.col0 == 0 && 2 * (int64_t)s.fuse.b->n == fm->F && fm->F == Fp && s.fuse.b->n % 256 == 0 &&
+                      s.fuse.b->d <= 32 && Fp < (1 << 21) && s.fuse.ldx < (1 << 21);
+    s.fuse.armed = false;
+    s.fuse.done = false;
     RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
     // WSt (Fp, kl_ld) = WSs^T (the 1 / (K L) scale is undone in the likelihood kernel's read of fs)
     hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
@@ -1761,14 +2103,44 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
                            fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
         fm->pt_rows = fm->rows;  // P^T's padding is now laid out for this row count
     }
-    int rc = glm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
-    if (rc != RR_OK) return rc;
-    // dfs in place + per-component reductions
-    if (dtype == RR_F32)
-        glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
-    else
-        glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
-    RR_CHECK_HIP(hipGetLastError());
+    int rc = RR_OK;
+    // With enough output tiles to fill the chip without a K-split, the product's epilogue IS the likelihood kernel and
+    // stores dfs in both layouts (rr_gemm_lik_f32_kernel); RR_GLM_FUSE_LIK=force takes that route for any shape (tests).
+    const char *fl = getenv("RR_GLM_FUSE_LIK");
+    const int64_t tiles1 = (rows256 / 256) * (kl_ld / 256);
+    const bool lik_force = fl && !strcmp(fl, "force"), lik_off = fl && !strcmp(fl, "0");
+    const bool lik_auto = tiles1 >= 2 * (int64_t)c->num_cu || Fp / GR_KB < 16;  // (fm_gemm would not split K)
+    // (the Gaussian and the exp-link Poisson: with the logistic / softplus likelihoods' log1p code hipcc refuses to unroll
+    // the epilogue over a lane's 128 accumulator elements -- they keep rr_glm_lik_kernel)
+    const bool fuse_lik = !no_fuse && c->gram_engine == 0 && !c->deterministic && !lik_off && (lik_force || lik_auto) &&
+                          (lik == RR_LIK_GAUSSIAN || lik == RR_LIK_POISSON_EXP) && fm->max_rows < (1 << 20) && kl_ld < (1 << 20);
+    if (fuse_lik) {
+        GemmLikArgs g;
+        g.A = s.Pt; g.lda = fm->max_rows; g.B = s.WSt; g.ldb = kl_ld; g.K = (int)Fp; g.ntb = (int)(kl_ld / 256);
+        g.D = objective_only ? nullptr : s.FSt; g.ldd = kl_ld;
+        g.Dt = objective_only ? nullptr : s.DFS; g.ldt = fm->max_rows;
+        g.y = dy; g.rowarg = drowarg; g.y_f64 = dtype == RR_F64; g.M = fm->rows;
+        g.par = (float)lik_param; g.fscale = (float)KL; g.KL = KL; g.L = L; g.llsum = s.kacc; g.aux = s.kacc + s.kcap;
+#define RR_GL(ID, ST) hipLaunchKernelGGL((rr_gemm_lik_f32_kernel<ID, ST>), dim3((unsigned)tiles1), dim3(GR_THREADS), 0, c->stream, g)
+        if (lik == RR_LIK_GAUSSIAN) {
+            if (objective_only) RR_GL(RR_LIK_GAUSSIAN, false);
+            else RR_GL(RR_LIK_GAUSSIAN, true);
+        } else {
+            if (objective_only) RR_GL(RR_LIK_POISSON_EXP, false);
+            else RR_GL(RR_LIK_POISSON_EXP, true);
+        }
+#undef RR_GL
+        RR_CHECK_HIP(hipGetLastError());
+    } else {
+        rc = glm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+        if (rc != RR_OK) return rc;
+        // dfs in place + per-component reductions
+        if (dtype == RR_F32)
+            glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+        else
+            glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+        RR_CHECK_HIP(hipGetLastError());
+    }
     if (objective_only) {  // the log-likelihood sums are all the objective needs: no gradient GEMMs
         s.have_edphi = false;
         return RR_OK;
@@ -1777,8 +2149,24 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     rc = glm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
     if (rc != RR_OK) return rc;
     // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
-                       s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
+    if (!fuse_lik)
+        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                           s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
+    if (fuse) {  // ... or contracted with the one random Fourier child block by block, without ever reaching HBM
+        GradtArgs g;
+        g.A = s.DFS; g.lda = fm->max_rows; g.B = s.WSs; g.ldb = Fp; g.K = (int)kl_ld;
+        g.ntb = (int)(Fp / 256); g.nta = (int)(rows256 / 256);
+        g.P = fm->P; g.ldp = Fp; g.X = (const float *)s.fuse.dX; g.ldx = s.fuse.ldx; g.rows = fm->rows;
+        g.n = s.fuse.b->n; g.d = s.fuse.b->d; g.T = s.fuse.dT;
+        int G = c->num_cu / g.ntb;  // one workgroup per CU, each keeps its column block and walks over row tiles
+        if (G < 1) G = 1;
+        if (G > g.nta) G = g.nta;
+        hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+        RR_CHECK_HIP(hipGetLastError());
+        s.have_edphi = false;
+        s.fuse.done = true;
+        return RR_OK;
+    }
     rc = glm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
     if (rc != RR_OK) return rc;
     s.have_edphi = true;
@@ -1893,7 +2281,31 @@ int rr_featmat_glm_step_draws_dev(rr_featmat *fm, const void *dy, const void *dr
     return glm_step_reduced(fm, dy, drowarg, dtype, lik, lik_param, m, C, K, L, 0, 0, nullptr, Edm, EdC, llsum, aux, dE);
 }
 
+int rr_featmat_glm_plan_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    RR_REQUIRE(fm != nullptr, "rr_featmat_glm_plan_rff: null feature matrix");
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr && dX != nullptr, "rr_featmat_glm_plan_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_glm_plan_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_glm_plan_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad, "rr_featmat_glm_plan_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    int rc = fm_pass2_scratch(fm);
+    if (rc != RR_OK) return rc;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.fuse.armed = false;
+    if (x_dtype != RR_F32 || b->large) return RR_OK;  // (declined: the step forms EdPhi and rr_featmat_glm_rff contracts it)
+    s.fuse.b = b; s.fuse.dX = dX; s.fuse.ldx = ldx; s.fuse.col0 = col0; s.fuse.dT = dT;
+    s.fuse.armed = true;
+    return RR_OK;
+}
+
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    if (fm != nullptr && fm->pass2 != nullptr) {
+        FmPass2 &sf = *(FmPass2 *)fm->pass2;
+        if (sf.fuse.done && sf.fuse.b == b && sf.fuse.dX == dX && sf.fuse.col0 == col0 && sf.fuse.dT == dT) {
+            sf.fuse.done = false;  // the step's fused product has added this child's contraction to dT already
+            return RR_OK;
+        }
+    }
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr && ((FmPass2 *)fm->pass2)->have_edphi,
                "rr_featmat_glm_rff: call rr_featmat_glm_step first");
     RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr && dX != nullptr, "rr_featmat_glm_rff: bad argument");

@@ -290,6 +290,68 @@ def test_config5_full_minibatch_is_additive_over_rows():
     assert normwise(g, np.array([-(EdPhi * dP[:, :, i]).sum() for i in range(d)])) < 5e-3
 
 
+@pytest.mark.parametrize("d,n,rows,ard", [(5, 256, 1500, True), (5, 256, 1500, False), (32, 512, 700, True),
+                                          (17, 256, 256, True), (3, 768, 2049, False)])
+def test_edphi_product_fused_with_its_contraction_equals_the_two_pass_route(monkeypatch, d, n, rows, ard):
+    """A lone random Fourier child whose [cos | sin] block fills whole 256-column tiles: the step contracts every block
+    of EdPhi = dfs^T ws / (K L) (glm.py:311) with P and X while it is in registers (rr_featmat_glm_plan_rff /
+    rr_gemm_gradt_f32_kernel) instead of writing EdPhi and reading it back.  Same length-scale gradients as the two-pass
+    route (RR_GLM_NO_FUSE=1: GEMM, then rr_glm_grad_t_kernel) and as the oracle's -(EdPhi o dPhi_i).sum() (glm.py:274-275),
+    with partial last row tiles, d < 32, isotropic (the reference's dimension-0 quirk) and ARD length scales, on the
+    host-sample route and on both reduced routes."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    from revrand_amd.basis_functions import MinibatchFeatures
+    rs = np.random.RandomState(100 + d + n)
+    K, L = 3, 7
+    X = rs.randn(rows, d).astype(np.float32).astype(np.float64)
+    y = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float)
+    if ard:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        ls = np.linspace(0.8, 1.4, d)
+    else:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1)
+        ls = 1.1
+    WS = 0.05 * rs.randn(K * L, 2 * n)
+    m, C = 0.05 * rs.randn(2 * n, K), 0.01 + 0.01 * rs.rand(2 * n, K)
+    E = rs.randn(K * L, 2 * n).astype(np.float32)
+
+    def run():
+        f = MinibatchFeatures(basis)
+        out = []
+        for route in ("samples", "draws", "sampled"):
+            f.assemble(X, [ls])
+            if route == "samples":
+                f.glm_step(y, None, lk.RR_LIK_POISSON_EXP, 0.0, WS, K, L)
+            elif route == "draws":
+                f.glm_step_draws(y, None, lk.RR_LIK_POISSON_EXP, 0.0, m, C, K, L, E)
+            else:
+                f.glm_step_sampled(y, None, lk.RR_LIK_POISSON_EXP, 0.0, m, C, K, L, 7, 3)
+            out.append(np.atleast_1d(np.asarray(f.glm_basis_grads(X), dtype=float)))
+        # an objective-only step in between leaves no plan behind for the next one
+        f.assemble(X, [ls])
+        f.glm_step_draws(y, None, lk.RR_LIK_POISSON_EXP, 0.0, m, C, K, L, E, objective_only=True)
+        f.assemble(X, [ls])
+        f.glm_step(y, None, lk.RR_LIK_POISSON_EXP, 0.0, WS, K, L)
+        out.append(np.atleast_1d(np.asarray(f.glm_basis_grads(X), dtype=float)))
+        f.release()
+        return out
+
+    monkeypatch.delenv("RR_GLM_NO_FUSE", raising=False)
+    fused = run()
+    monkeypatch.setenv("RR_GLM_NO_FUSE", "1")
+    plain = run()
+    for a, b in zip(fused, plain):
+        assert a.shape == b.shape and normwise(a, b) < 2e-4
+    assert normwise(fused[3], fused[0]) < 1e-5
+    # the host-sample route against the oracle's formulas
+    Phi = orc.rff_transform(X, basis.W, ls)
+    dfs = orc.lik_df("poisson_exp", y, WS @ Phi.T)
+    EdPhi = dfs.T @ WS / (K * L)
+    dP = orc.rff_grad(X, basis.W, ls)
+    want = np.array([-(EdPhi * dP[:, :, i]).sum() for i in range(d)]) if ard else np.array([-(EdPhi * dP).sum()])
+    assert normwise(fused[0], want) < 5e-3
+
+
 def test_step_with_directly_written_transpose_equals_step_with_transposing_pass():
     """From the second step of a given minibatch size on, the random Fourier children write their blocks of P^T while they
     write P and the step skips its transposing pass: same step results as the first (transposing) step on the same
