@@ -223,8 +223,13 @@ struct GradtArgs {
     int64_t ldx, rows;
     int n, d;
     double *T;        // (d, n), accumulated into
+    // ERR (the linear model's second pass, slm.py:193-195): the product is U = Phi C and what is contracted is
+    // A = Err m^T - U, i.e. R = -(U[r][c] - err[r] mvec[c]) P[r][partner] with the signs above: sign = -1
+    const float *err = nullptr, *mvec = nullptr;
+    float sign = 1.f;
 };
 
+template <bool ERR>
 __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const GradtArgs p) {
     __shared__ float lds[2 * GR_KB * GR_LD];
     const int tid = threadIdx.x;
@@ -236,7 +241,7 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
     const bool cosblk = cb < p.n;
     const int pcol = cosblk ? cb + p.n : cb - p.n;  // partner column block in P
     const int tcol = cosblk ? cb : cb - p.n;        // column block in T
-    const float sgn = cosblk ? -1.f : 1.f;
+    const float sgn = (cosblk ? -1.f : 1.f) * p.sign;
 
     const int wr = wave >> 2, wc_ = wave & 3;
     const int hi = lane >> 5, l31 = lane & 31;
@@ -252,6 +257,11 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) tacc[j][e] = 0.f;
+    float mcol[2] = {0.f, 0.f};  // ERR: the lane's two entries of mvec, the same for every row tile
+    if (ERR) {
+        mcol[0] = p.mvec[cb + wc_ * 64 + l31];
+        mcol[1] = p.mvec[cb + wc_ * 64 + 32 + l31];
+    }
 
     auto dma_tile = [&](float *buf, int64_t ca, int kb0) {
 #pragma unroll
@@ -296,27 +306,40 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         const unsigned ldp4 = (unsigned)p.ldp * 4u, ldx4 = (unsigned)p.ldx * 4u;
         unsigned pofs = (unsigned)(wr * 128 + 4 * hi) * ldp4 + (unsigned)(wc_ * 64 + l31) * 4u;
         unsigned xofs = (unsigned)(wr * 128 + 4 * hi) * ldx4 + (unsigned)(xlane ? l31 : 0) * 4u;
+        rr_rsrc_t ers;
+        unsigned eofs = (unsigned)(wr * 128 + 4 * hi) * 4u;
+        if (ERR) ers = rr_make_rsrc(p.err + ca, tr * 4u);
+        constexpr int EB = ERR ? 8 : 16;  // elements per batch (ERR: a fourth load per element -- 8 keep it within 256 registers)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float xv[16], pv[2][16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2));
-                xv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xofs, ro * ldx4, 0));
-                pv[0][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs, ro * ldp4, 0));
-                pv[1][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs + 128u, ro * ldp4, 0));
+            for (int h = 0; h < 16 / EB; ++h) {
+                float xv[EB], pv[2][EB], ev[EB];
+#pragma unroll
+                for (int k = 0; k < EB; ++k) {
+                    const int e = h * EB + k;
+                    const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2));
+                    xv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xofs, ro * ldx4, 0));
+                    pv[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs, ro * ldp4, 0));
+                    pv[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs + 128u, ro * ldp4, 0));
+                    if (ERR) ev[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ers, eofs + ro * 4u, 0, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);  // all of the batch's loads are issued before its first product
+#pragma unroll
+                for (int k = 0; k < EB; ++k) {
+                    const int e = h * EB + k;
+                    const float xe = xv[k] * xmask;  // (a multiply, not a select: the loads stay unconditional and batched)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float a = ERR ? fmaf(-ev[k], mcol[j], acc[i][j][e]) : acc[i][j][e];
+                        tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, a * pv[j][k], tacc[j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);  // all of the batch's loads are issued before its first product
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float xe = xv[e] * xmask;  // (a multiply, not a select: the loads stay unconditional and batched)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, acc[i][j][e] * pv[j][e], tacc[j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
             pofs += 32u * ldp4;
             xofs += 32u * ldx4;
+            eofs += 128u;
         }
     }
 
@@ -619,6 +642,9 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
     chunk = s.chunk;  // the allocated leading dimension of Pt
     hipError_t e = hipSuccess;
     int rc = RR_OK;
+    const char *nfz = getenv("RR_PASS2_NO_FUSE");
+    const bool fuse_t = !pred && sizeof(TX) == 4 && c->gram_engine == 0 && !c->deterministic && !b->large && !b->phase64 &&
+                        n % 256 == 0 && b->d <= 32 && Fp < (1 << 21) && ldx < (1 << 21) && !(nfz && atoi(nfz) != 0);
     {   // posterior to the device in f32: m (F), C padded to (Fp, Fp)
         s.hm.resize(F);
         for (int i = 0; i < F; ++i) s.hm[i] = (float)mh[i];
@@ -671,6 +697,28 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             rc = launch_features_t<TX>(b, Xc, mrows, mpad, ldx, s.m32, s.Pt, chunk, s.dot);
         }
         if (rc != RR_OK) break;
+        // The gradient pass with whole [cos | sin] tiles: Err first, then U = P C contracts itself with P, Err m^T and X
+        // block by block (rr_gemm_gradt_f32_kernel<true>) -- U is neither written nor read back, P is read once.
+        if (fuse_t) {
+            const TX *yc = dy + r0;
+            hipLaunchKernelGGL(rr_err_kernel<TX>, dim3((unsigned)(mpad / 256)), dim3(256), 0, c->stream, yc, s.dot, mrows, s.err,
+                               s.acc);
+            GradtArgs g;
+            g.A = s.Pt; g.lda = chunk; g.B = s.C32; g.ldb = Fp; g.K = (int)(((int64_t)F + GR_KB - 1) / GR_KB * GR_KB);
+            g.ntb = (int)(Fp / 256); g.nta = (int)(mpad / 256);
+            g.P = s.P; g.ldp = Fp; g.X = (const float *)Xc; g.ldx = ldx; g.rows = mrows;
+            g.n = n; g.d = b->d; g.T = s.acc + 1; g.err = s.err; g.mvec = s.m32; g.sign = -1.f;
+            int G = c->num_cu / g.ntb;
+            if (G < 1) G = 1;
+            if (G > g.nta) G = g.nta;
+            hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel<true>, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+            if (hipGetLastError() != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+                rr_set_error("pass2: fused gemm failed");
+                rc = RR_ERR_HIP;
+                break;
+            }
+            continue;
+        }
         // U = P C  as  (Pt)^T C : A = Pt (K = Fp, M = mpad columns), B = C32 (K = Fp, N = Fp)
         if (c->gram_engine != 0) {
             rc = rr_launch_gemm_tn_bf16(c, c->gram_engine, s.Pt, chunk, Bprep ? Bprep : s.C32, Fp, s.U, Fp, Fp, mpad, Fp, s.Ab, s.Cb,
@@ -993,7 +1041,9 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_lik_f32_kernel(const Ge
             asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(m4) : "v"(srow), "i"(4096 + 4 * (32 * i + 8 * q)));
             if (LIK == RR_LIK_BINOMIAL)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(n4) : "v"(srow), "i"(3072 + 4 * (32 * i + 8 * q)));
-            lds_wait();
+            // (the wait names the registers it is for: the compiler does not count asm loads, and nothing else keeps their
+            // first use behind it)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(y4), "+v"(m4), "+v"(n4)::"memory");
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float4v v;
@@ -1264,7 +1314,11 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
     const int64_t tiles = (Md / 256) * g.ntb, nkb = Kd / GR_KB;
     unsigned splits = 1;
     if (tiles < 2 * (int64_t)c->num_cu && nkb >= 16) {  // too few tiles to fill the chip: split K, >= 8 k-blocks each
-        int64_t want = (2 * (int64_t)c->num_cu + tiles - 1) / tiles;
+        // workgroups for RR_GEMM_SPLIT_ROUNDS rounds over the CUs (default 1: one K-split per CU and half the atomic
+        // flushes of two rounds -- config 5's Ed = dfs Phi: 1.17 -> 1.12 ms)
+        const char *sr = getenv("RR_GEMM_SPLIT_ROUNDS");
+        const int64_t rounds = sr && atoi(sr) >= 1 ? atoi(sr) : 1;
+        int64_t want = (rounds * (int64_t)c->num_cu + tiles - 1) / tiles;
         if (want > nkb / 8) want = nkb / 8;
         g.kb_per_split = (int)((nkb + want - 1) / want);
         splits = (unsigned)((nkb + g.kb_per_split - 1) / g.kb_per_split);
@@ -2161,7 +2215,7 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         int G = c->num_cu / g.ntb;  // one workgroup per CU, each keeps its column block and walks over row tiles
         if (G < 1) G = 1;
         if (G > g.nta) G = g.nta;
-        hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+        hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel<false>, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
         RR_CHECK_HIP(hipGetLastError());
         s.have_edphi = false;
         s.fuse.done = true;

@@ -213,6 +213,42 @@ def test_second_pass_and_predict_vs_oracle(shape):
     assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
 
 
+@pytest.mark.parametrize("N,d,n,ard,chunk", [(3000, 5, 256, True, None), (1500, 32, 256, False, None), (2100, 7, 512, True, 768)])
+def test_second_pass_product_fused_with_its_contraction_equals_the_two_pass_route(monkeypatch, N, d, n, ard, chunk):
+    """With the [cos | sin] block in whole 256-column tiles the second pass' U = Phi C (slm.py:193-195) contracts itself
+    with Phi, Err m^T and X block by block in registers (rr_gemm_gradt_f32_kernel<true>) -- U is neither stored nor read
+    back.  Same sqErr and hyper-gradient as the GEMM + rr_grad_t_kernel route (RR_PASS2_NO_FUSE=1) and as the oracle's
+    dPhi-based formulas; partial last row tiles, several row chunks, isotropic (dimension-0 quirk) and ARD."""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(N + n)
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    if ard:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+        ls = np.linspace(0.7, 1.5, d)
+    else:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3)
+        ls = 1.2
+    var, reg = 0.3, 1.4
+    Phi = orc.rff_transform(X, basis.W, ls)
+    dP = orc.rff_grad(X, basis.W, ls)
+    o = orc.slm_elbo(Phi, y, var, np.full(2 * n, reg), slice(None), [dP[:, :, i] for i in range(d)] if ard else [dP])
+    if chunk:
+        monkeypatch.setenv("RR_PASS2_CHUNK_ROWS", str(chunk))
+    out = []
+    for nofuse in ("0", "1"):
+        monkeypatch.setenv("RR_PASS2_NO_FUSE", nofuse)
+        st = basis.device_fit_state(X, y)
+        sq, dh = st.second_pass(ls, o["m"], o["C"], var)
+        st.release()
+        out.append((sq, np.atleast_1d(np.asarray(dh, dtype=float))))
+    err = y - Phi @ o["m"]
+    for sq, dh in out:
+        assert abs(sq - err @ err) < 1e-4 * (err @ err)
+        assert normwise(dh, -np.atleast_1d(np.array(o["dhyp"], dtype=float)).ravel()) < 2e-3
+    assert normwise(out[0][1], out[1][1]) < 2e-4
+
+
 @pytest.mark.parametrize("n,extra", [(126, 3), (127, 1), (128, 0), (255, 2), (60, 5), (383, 1)])
 def test_concat_gram_phi_t_y_rider_and_fallback(n, extra):
     """Phi^T y of a concatenation rides along with the SYRK in the first pad column of the device feature matrix when the
