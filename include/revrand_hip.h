@@ -262,6 +262,16 @@ int rr_featmat_predict_begin(rr_featmat *fm, const double *m, const double *C, i
 int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype);
 int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
                          double *dT);
+/* The gradient contraction without U = Phi C in memory (slm.py:193-195 for a concatenation): announce every
+ * rr_featmat_pass2_rff call that will follow (same arguments), then call rr_featmat_pass2_rows_planned instead of
+ * rr_featmat_pass2_rows -- the caller's promise that the planned children are the ONLY consumers of U.  When every plan sits
+ * in whole 256-column tiles (col0 % 256 == 0, n % 256 == 0, d <= 32, float32 X, f32 engine, not deterministic mode) each
+ * child's columns of U are contracted with Phi, Err m^T and X block by block in registers (rr_gemm_gradt_f32_kernel) and
+ * added to its dT; columns nobody consumes (a linear child's) are not computed; the rr_featmat_pass2_rff calls that follow
+ * return at once.  Otherwise this is rr_featmat_pass2_rows.  Plans hold for ONE rows call.  RR_PASS2_NO_FUSE=1: never. */
+int rr_featmat_pass2_plan_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
+                              double *dT);
+int rr_featmat_pass2_rows_planned(rr_featmat *fm, const void *dy, int y_dtype);
 int rr_featmat_pass2_end(rr_featmat *fm, double *sqErr);
 int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf);
 

@@ -113,6 +113,9 @@ SIGNATURES = {
     "rr_featmat_pass2_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "rr_featmat_pass2_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                             ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat_pass2_plan_rff": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                 ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
+    "rr_featmat_pass2_rows_planned": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
     "rr_featmat_pass2_end": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_predict_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_glm_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
@@ -772,6 +775,14 @@ class FeatureMatrix(object):
 
     def pass2_rows(self, dy):
         _check(self.lib, self.lib.rr_featmat_pass2_rows(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0))
+
+    def pass2_plan_rff(self, handle, dX, col0, dT):
+        """Announce a pass2_rff call (same arguments) ahead of pass2_rows_planned."""
+        _check(self.lib, self.lib.rr_featmat_pass2_plan_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))
+
+    def pass2_rows_planned(self, dy):
+        """pass2_rows when the planned children are the only consumers of U = Phi C (which may then never be formed)."""
+        _check(self.lib, self.lib.rr_featmat_pass2_rows_planned(self.h, _ptr(dy), rr_dtype(dy.dtype)))
 
     def pass2_rff(self, handle, dX, col0, dT):
         _check(self.lib, self.lib.rr_featmat_pass2_rff(self.h, handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, col0, _ptr(dT)))

@@ -428,6 +428,9 @@ class _ResidentRFF(object):
     def grad(self, fm, r0, rows, col0):
         fm.pass2_rff(self.h, _hip.DeviceView(self.dX, r0, rows), col0, self.dT)
 
+    def plan(self, fm, r0, rows, col0):
+        fm.pass2_plan_rff(self.h, _hip.DeviceView(self.dX, r0, rows), col0, self.dT)
+
     def dhyp(self, var):
         T = self.h.dev.download(self.dT, self.W.shape, np.float64)
         ls = np.atleast_1d(np.asarray(self.ls, dtype=float))
@@ -785,9 +788,18 @@ class CatFitState(_DevicePosterior):
         with_grad = [(c, col0) for c, col0 in zip(self.children, self.ends) if c.nparams]
         for c, _ in with_grad:
             c.reset()
+        # every consumer of U = Phi C known ahead (all of them random Fourier children): the product may contract itself
+        # with each child's block in registers instead of being stored (rr_featmat_pass2_rows_planned)
+        planned = bool(with_grad) and hasattr(self.fm, "pass2_rows_planned") and \
+            all(isinstance(c, _ResidentRFF) for c, _ in with_grad)
         for r0, rows in self._chunks():
             self._fill(r0, rows, hypers)
-            self.fm.pass2_rows(_hip.DeviceView(self.dy, r0, rows))
+            if planned:
+                for c, col0 in with_grad:
+                    c.plan(self.fm, r0, rows, col0)
+                self.fm.pass2_rows_planned(_hip.DeviceView(self.dy, r0, rows))
+            else:
+                self.fm.pass2_rows(_hip.DeviceView(self.dy, r0, rows))
             for c, col0 in with_grad:
                 c.grad(self.fm, r0, rows, col0)
         sq = self.fm.pass2_end()

@@ -286,69 +286,90 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         __syncthreads();  // k-block 0 of this tile has landed (requested before the previous tile's epilogue)
-        for (int kb = 0; kb < nkb; ++kb) {
+        for (int kb = 0; kb + 1 < nkb; ++kb) {
             const int cbuf = kb & 1;
-            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB);
+            dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB);
             gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
             __syncthreads();
         }
-        // the next tile's first k-block flies under this tile's epilogue (nkb is even or odd: buffer 0 is free either way
-        // after the barrier above)
-        if (ta + G < p.nta) dma_tile(lds, (int64_t)(ta + G) * GR_TC, 0);
 
-        // The tile's block of P (partner columns) and its rows of X through buffer descriptors: base and row steps are
-        // wave-uniform (SGPRs), the lane part is one 32-bit offset per tile, and rows past the end of a partial last
-        // tile fall outside the descriptor's extent and read as zero (their EdPhi is zero as well: dfs^T holds zero
-        // columns there).  48 loads are in flight per lane and batch before the first product needs one.
+        // The tile's block of P (partner columns), its rows of X (and of Err) through buffer descriptors: the base is
+        // wave-uniform (SGPRs), the lane part a 32-bit offset, and rows past the end of a partial last tile fall outside
+        // the descriptor's extent and read as zero (their product rows are zero as well).
+        // The epilogue works through the lane's 64 elements of each column block in 8 groups of 8 (group hb: row block
+        // i = hb >> 1, elements 8 (hb & 1) ..): NS register sets rotate, so that the loads of group hb + NS are in flight
+        // under the MFMAs of groups hb + 1 .. hb + NS - 1, and the first set is requested BEFORE the tile's last k-block.
         const unsigned tr = (unsigned)(p.rows - ca < GR_TC ? p.rows - ca : GR_TC);  // rows of this tile that exist
         const rr_rsrc_t prs = rr_make_rsrc(p.P + ca * p.ldp + pcol, (tr * (unsigned)p.ldp - (unsigned)pcol) * 4u);
         const rr_rsrc_t xrs = rr_make_rsrc(p.X + ca * p.ldx, tr * (unsigned)p.ldx * 4u);
         const unsigned ldp4 = (unsigned)p.ldp * 4u, ldx4 = (unsigned)p.ldx * 4u;
         unsigned pofs = (unsigned)(wr * 128 + 4 * hi) * ldp4 + (unsigned)(wc_ * 64 + l31) * 4u;
         unsigned xofs = (unsigned)(wr * 128 + 4 * hi) * ldx4 + (unsigned)(xlane ? l31 : 0) * 4u;
-        rr_rsrc_t ers;
         unsigned eofs = (unsigned)(wr * 128 + 4 * hi) * 4u;
+        // (opaque per tile: the lane offsets below are the same for every tile, and hoisted out of the tile loop their
+        // 192 registers would spill)
+        asm volatile("" : "+v"(pofs), "+v"(xofs), "+v"(eofs));
+        rr_rsrc_t ers;
         if (ERR) ers = rr_make_rsrc(p.err + ca, tr * 4u);
-        constexpr int EB = ERR ? 8 : 16;  // elements per batch (ERR: a fourth load per element -- 8 keep it within 256 registers)
+        constexpr int NS = ERR ? 2 : 3;
+        float xv[NS][8], pv[NS][2][8], ev[NS][8];
+        auto load_group = [&](int set, int hb) {  // (both compile-time after unrolling)
+            const int i = hb >> 1;
+            unsigned pb = pofs + (unsigned)(32 * i) * ldp4, xb = xofs + (unsigned)(32 * i) * ldx4;
+            asm volatile("" : "+v"(pb), "+v"(xb));  // (per group: see above)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int h = 0; h < 16 / EB; ++h) {
-                float xv[EB], pv[2][EB], ev[EB];
-#pragma unroll
-                for (int k = 0; k < EB; ++k) {
-                    const int e = h * EB + k;
-                    const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2));
-                    xv[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xofs, ro * ldx4, 0));
-                    pv[0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs, ro * ldp4, 0));
-                    pv[1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pofs + 128u, ro * ldp4, 0));
-                    if (ERR) ev[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ers, eofs + ro * 4u, 0, 0));
-                }
-                __builtin_amdgcn_sched_barrier(0);  // all of the batch's loads are issued before its first product
-#pragma unroll
-                for (int k = 0; k < EB; ++k) {
-                    const int e = h * EB + k;
-                    const float xe = xv[k] * xmask;  // (a multiply, not a select: the loads stay unconditional and batched)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const float a = ERR ? fmaf(-ev[k], mcol[j], acc[i][j][e]) : acc[i][j][e];
-                        tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, a * pv[j][k], tacc[j], 0, 0, 0);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
+            for (int k = 0; k < 8; ++k) {
+                const int e = 8 * (hb & 1) + k;
+                const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2));
+                // (row steps in the VGPR offset, not in soffset: the hardware's range check does not see soffset)
+                xv[set][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xb + ro * ldx4, 0, 0));
+                pv[set][0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pb + ro * ldp4, 0, 0));
+                pv[set][1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pb + ro * ldp4 + 128u, 0, 0));
+                if (ERR)
+                    ev[set][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ers, eofs + (unsigned)(128 * i) + ro * 4u, 0, 0));
             }
-            pofs += 32u * ldp4;
-            xofs += 32u * ldx4;
-            eofs += 128u;
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        load_group(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        {   // the tile's last k-block (nothing left to request for this tile)
+            const int cbuf = (nkb - 1) & 1;
+            gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+            __syncthreads();
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 1; q < NS; ++q) load_group(q, q);
+#pragma unroll
+        for (int hb = 0; hb < 8; ++hb) {
+            const int set = hb % NS, i = hb >> 1;
+            __builtin_amdgcn_sched_barrier(0);  // (the sets' loads stay where they are: the scheduler would pull them together)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = 8 * (hb & 1) + k;
+                const float xe = xv[set][k] * xmask;  // (a multiply, not a select: the loads stay unconditional and batched)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float a = ERR ? fmaf(-ev[set][k], mcol[j], acc[i][j][e]) : acc[i][j][e];
+                    tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, a * pv[set][j][k], tacc[j], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (hb + NS < 8) load_group(set, hb + NS);
+        }
+        // (requested only now: while an LDS-DMA is pending hipcc waits with vmcnt(0) for ANY load result, which would
+        // serialise the rotating sets above)
+        if (ta + G < p.nta) dma_tile(lds, (int64_t)(ta + G) * GR_TC, 0);
     }
 
+    int tlane = tcol + wc_ * 64 + l31;
+    asm volatile("" : "+v"(tlane));  // (the 32 flush addresses are formed here, not at kernel start where they would spill)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
-            if (i < p.d) unsafeAtomicAdd(&p.T[(size_t)i * p.n + tcol + wc_ * 64 + j * 32 + l31], (double)(sgn * tacc[j][e]));
+            if (i < p.d) unsafeAtomicAdd(&p.T[(size_t)i * p.n + tlane + j * 32], (double)(sgn * tacc[j][e]));
         }
 }
 
@@ -1193,6 +1214,15 @@ struct FmPass2 {
     int64_t klp = 0;
     int kcap = 0;
     bool have_edphi = false;
+    // rr_featmat_pass2_plan_rff: children whose contraction the next rr_featmat_pass2_rows_planned may fuse into U = P C
+    struct Pass2Plan {
+        rr_basis *b;
+        const void *dX;
+        int x_dtype;
+        int64_t ldx, col0;
+        double *dT;
+    };
+    std::vector<Pass2Plan> plans, fused;  // armed for the next rows call / contracted by the last one
     // rr_featmat_glm_plan_rff: the next step's EdPhi product may contract itself with this child (rr_gemm_gradt_f32_kernel)
     struct {
         rr_basis *b = nullptr;
@@ -2046,7 +2076,82 @@ int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
     return det ? rr_det_reduce(c, sq, grid.x, 1, 1, s.sq) : RR_OK;
 }
 
+int rr_featmat_pass2_plan_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_plan_rff: call rr_featmat_pass2_begin first");
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr, "rr_featmat_pass2_plan_rff: bad argument");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_pass2_plan_rff: bad dtype");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_pass2_plan_rff: columns out of range");
+    RR_REQUIRE(ldx >= b->dpad, "rr_featmat_pass2_plan_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.plans.push_back({b, dX, x_dtype, ldx, col0, dT});
+    return RR_OK;
+}
+
+// rr_featmat_pass2_rows when the planned children are the ONLY consumers of U = P C (the caller's promise): if every plan
+// sits in whole 256-column tiles (col0 % 256 == 0, n % 256 == 0, d <= 32, float32 X, f32 engine, not deterministic mode),
+// Err is formed first and each child's columns of U are contracted with P, Err m^T and X block by block in registers
+// (rr_gemm_gradt_f32_kernel<true>) -- U is never written, columns without a consumer (a linear child's) never computed.
+// Otherwise: rr_featmat_pass2_rows.
+int rr_featmat_pass2_rows_planned(rr_featmat *fm, const void *dy, int y_dtype) {
+    RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_rows_planned: call rr_featmat_pass2_begin first");
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    std::vector<FmPass2::Pass2Plan> plans;
+    plans.swap(s.plans);
+    s.fused.clear();
+    rr_ctx *c = fm->ctx;
+    const char *nfz = getenv("RR_PASS2_NO_FUSE");
+    bool ok = dy != nullptr && !plans.empty() && c->gram_engine == 0 && !c->deterministic && !s.tri_c && fm->ld < (1 << 21) &&
+              !(nfz && atoi(nfz) != 0);
+    for (const auto &pl : plans)
+        ok = ok && pl.x_dtype == RR_F32 && !pl.b->large && pl.col0 % 256 == 0 && pl.b->n % 256 == 0 && pl.b->d <= 32 &&
+             pl.ldx < (1 << 21) && pl.dX != nullptr;
+    if (!ok) return rr_featmat_pass2_rows(fm, dy, y_dtype);
+    RR_FM_REQUIRE_FILLED(fm, "rr_featmat_pass2_rows_planned");
+    RR_REQUIRE(y_dtype == RR_F32 || y_dtype == RR_F64, "rr_featmat_pass2_rows_planned: bad dtype");
+    s.have_rows = true;
+    if (fm->rows == 0) return RR_OK;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int64_t rows256 = (fm->rows + 255) / 256 * 256;
+    hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, s.m32,
+                       fm->rows, fm->F, fm->ld, s.dot);
+    if (!(fm->pt_rows == fm->rows && fm->pt_covered >= fm->F)) {  // (else: the children wrote P^T next to P)
+        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(fm->ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0,
+                           c->stream, fm->P, fm->rows, fm->ld, s.Pt, fm->max_rows);
+        fm->pt_rows = fm->rows;
+    }
+    const dim3 grid((unsigned)((fm->rows + 255) / 256));
+    if (y_dtype == RR_F32)
+        hipLaunchKernelGGL(rr_err_kernel<float>, grid, dim3(256), 0, c->stream, (const float *)dy, s.dot, fm->rows, s.err, s.sq,
+                           (int64_t)0);
+    else
+        hipLaunchKernelGGL(rr_err_kernel<double>, grid, dim3(256), 0, c->stream, (const double *)dy, s.dot, fm->rows, s.err, s.sq,
+                           (int64_t)0);
+    for (const auto &pl : plans) {
+        GradtArgs g;
+        g.A = s.Pt; g.lda = fm->max_rows; g.B = s.C32 + pl.col0; g.ldb = fm->ld;
+        g.K = (int)(((int64_t)fm->F + GR_KB - 1) / GR_KB * GR_KB);
+        g.ntb = 2 * pl.b->n / 256; g.nta = (int)(rows256 / 256);
+        g.P = fm->P + pl.col0; g.ldp = fm->ld; g.X = (const float *)pl.dX; g.ldx = pl.ldx; g.rows = fm->rows;
+        g.n = pl.b->n; g.d = pl.b->d; g.T = pl.dT; g.err = s.err; g.mvec = s.m32 + pl.col0; g.sign = -1.f;
+        int G = c->num_cu / g.ntb;
+        if (G < 1) G = 1;
+        if (G > g.nta) G = g.nta;
+        hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel<true>, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+    }
+    RR_CHECK_HIP(hipGetLastError());
+    s.fused = plans;
+    return RR_OK;
+}
+
 int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, int64_t col0, double *dT) {
+    if (fm != nullptr && fm->pass2 != nullptr) {
+        FmPass2 &sf = *(FmPass2 *)fm->pass2;
+        for (size_t i = 0; i < sf.fused.size(); ++i)
+            if (sf.fused[i].b == b && sf.fused[i].dX == dX && sf.fused[i].col0 == col0 && sf.fused[i].dT == dT) {
+                sf.fused.erase(sf.fused.begin() + (long)i);  // contracted by rr_featmat_pass2_rows_planned already
+                return RR_OK;
+            }
+    }
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr && ((FmPass2 *)fm->pass2)->have_rows,
                "rr_featmat_pass2_rff: call rr_featmat_pass2_rows first");
     RR_REQUIRE(b != nullptr && b->kind == RR_KIND_RFF && dT != nullptr, "rr_featmat_pass2_rff: bad argument");

@@ -100,13 +100,25 @@ def test_fit_config1_shape_vs_reference(golden):
         assert abs(-ndvar - float(g["c1_at_dvar"])) < tol * abs(float(g["c1_at_dvar"]))
         assert normwise(-np.atleast_1d(ndreg), g["c1_at_dreg"]) < tol
         assert normwise(-np.atleast_1d(ndhyp), g["c1_at_dhyp"]) < 2 * tol
-    # (2) the fit itself.  L-BFGS-B trajectories are chaotic here (the reference's own run ends unconverged after 20
-    # iterations with |dvar| ~ 4e5): this fit must predict like the reference's and reach an objective at least as good
+    # (2) the fit itself.  In float64 arithmetic the optimiser walks the reference's own trajectory: same end point, same
+    # objective, same predictions.
+    b64 = bs.RandomRBF(nbases=256, Xdim=8, random_state=41, lenscale=Parameter(2.0, Positive()),
+                       regularizer=Parameter(10.0, Positive()), dtype="f64")
+    s64 = SLM(b64, var=Parameter(0.02, Positive()), nstarts=0, maxiter=20, random_state=0).fit(X, y)
+    Ey64, Vy64 = s64.predict_moments(Xs)
+    assert abs(s64.obj_ - float(g["c1_obj"])) < 1e-5 * abs(float(g["c1_obj"]))
+    assert abs(s64.var_ - float(g["c1_var_"])) < 1e-6 * float(g["c1_var_"])
+    assert abs(float(np.atleast_1d(s64.hypers_)[0]) - float(g["c1_hyp_"])) < 1e-6 * float(g["c1_hyp_"])
+    assert smse(g["c1_Ey"], Ey64) < 1e-5 and np.all(Vy64 > 0)
+    # In float32 the trajectory is the same to 7 digits up to the reference's end point -- where L-BFGS-B's line search
+    # stalls (the reference's own run ends unconverged after 20 iterations with |dvar| ~ 4e5, and evaluates that point
+    # seven more times) and whether a later trial step escapes depends on the last bits of the objective (stored and fused
+    # second pass, both 5e-7 off the float64 gradient there, end at different points: tools/diag_traj.py).  What holds for
+    # every such end point: an objective at least as good as the reference's, and predictions of its quality.
     slm = SLM(basis, var=Parameter(0.02, Positive()), nstarts=0, maxiter=20, random_state=0).fit(X, y)
     Ey, Vy = slm.predict_moments(Xs)
-    assert smse(g["c1_Ey"], Ey) < 2e-2                      # same predictions as the reference's fit
-    assert abs(smse(g["c1_ys_true"], Ey) - smse(g["c1_ys_true"], g["c1_Ey"])) < 0.03   # ... and the same quality
     assert slm.obj_ > float(g["c1_obj"]) - 0.02 * abs(float(g["c1_obj"]))
+    assert smse(g["c1_ys_true"], Ey) < smse(g["c1_ys_true"], g["c1_Ey"]) + 0.03
     assert np.all(Vy > 0)
 
 

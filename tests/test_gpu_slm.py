@@ -331,14 +331,20 @@ def test_resident_concat_elbo_matches_reference(golden):
     assert np.shape(ndhyp) == (d,) and normwise(-ndhyp, g["cat_dhyp"]) < 2e-3
 
 
-@pytest.mark.parametrize("chunk_rows", [None, 512])
-def test_concat_second_pass_and_predict_vs_oracle(chunk_rows):
+@pytest.mark.parametrize("chunk_rows,n0,n1,nofuse", [(None, 70, 90, None), (512, 70, 90, None), (None, 256, 512, None),
+                                                     (512, 256, 512, None), (None, 256, 512, "1"), (None, 256, 90, None)])
+def test_concat_second_pass_and_predict_vs_oracle(monkeypatch, chunk_rows, n0, n1, nofuse):
     """Two random-feature children (isotropic on a column subset, ARD) + Linear + Bias: statistics, sqErr, the
-    per-child gradient contraction (structured like apply_grad over BasisCat.grad) and predict_moments."""
+    per-child gradient contraction (structured like apply_grad over BasisCat.grad) and predict_moments.  With both
+    children in whole 256-column tiles (n0 = 256, n1 = 512) U = Phi C is contracted child by child in registers and
+    never stored (rr_featmat_pass2_rows_planned; RR_PASS2_NO_FUSE=1: the stored route at the same widths; n1 = 90: a
+    plan that cannot be fused falls back for BOTH children)."""
     bs, Parameter, Positive, SLM = _imports()
     from revrand_amd.basis_functions import CatFitState
+    if nofuse:
+        monkeypatch.setenv("RR_PASS2_NO_FUSE", nofuse)
     rs = np.random.RandomState(5)
-    N, d, n0, n1 = 1300, 6, 70, 90
+    N, d = 1300, 6
     X = rs.randn(N, d)
     y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
     cat = bs.RandomRBF(nbases=n0, Xdim=2, random_state=1, apply_ind=[4, 1]) \
