@@ -265,7 +265,7 @@ int rr_featmat_pass2_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_
 /* The gradient contraction without U = Phi C in memory (slm.py:193-195 for a concatenation): announce every
  * rr_featmat_pass2_rff call that will follow (same arguments), then call rr_featmat_pass2_rows_planned instead of
  * rr_featmat_pass2_rows -- the caller's promise that the planned children are the ONLY consumers of U.  When every plan sits
- * in whole 256-column tiles (col0 % 256 == 0, n % 256 == 0, d <= 32, float32 X, f32 engine, not deterministic mode) each
+ * in whole 256-column tiles (col0 % 256 == 0, n % 256 == 0, d <= 128, float32 X, f32 engine, not deterministic mode) each
  * child's columns of U are contracted with Phi, Err m^T and X block by block in registers (rr_gemm_gradt_f32_kernel) and
  * added to its dT; columns nobody consumes (a linear child's) are not computed; the rr_featmat_pass2_rff calls that follow
  * return at once.  Otherwise this is rr_featmat_pass2_rows.  Plans hold for ONE rows call.  RR_PASS2_NO_FUSE=1: never. */
@@ -317,7 +317,7 @@ int rr_featmat_glm_step_draws_dev(rr_featmat *fm, const void *dy, const void *dr
 int rr_featmat_glm_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dtype, int64_t ldx, int64_t col0,
                        double *dT);
 /* Announce, BEFORE a step, the rr_featmat_glm_rff call that will follow it (same arguments; dT zeroed by the caller).
- * When the whole matrix is this child's [cos | sin] block (col0 == 0, 2n == F, n % 256 == 0, d <= 32, float32 X, f32
+ * When the whole matrix is this child's [cos | sin] block (col0 == 0, 2n == F, n % 256 == 0, d <= 128, float32 X, f32
  * engine, not deterministic mode) the step contracts every 256x256 block of EdPhi = dfs^T ws / (K L) (glm.py:311) with
  * P and X while it is still in registers and adds the result to dT (rr_gemm_gradt_f32_kernel): EdPhi is neither written
  * nor read back, and the rr_featmat_glm_rff call that follows returns at once.  Otherwise the plan is dropped and

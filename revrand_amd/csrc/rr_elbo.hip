@@ -219,7 +219,7 @@ struct GradtArgs {
     int K, ntb, nta;  // k rows; column tiles of B (= 2n / 256); row tiles of A
     const float *P;   // feature matrix (rows, ldp), columns [0, 2n)
     int64_t ldp;
-    const float *X;   // the child's inputs (rows, ldx), d <= 32 valid columns
+    const float *X;   // the child's inputs (rows, ldx), d <= 128 valid columns
     int64_t ldx, rows;
     int n, d;
     double *T;        // (d, n), accumulated into
@@ -229,7 +229,9 @@ struct GradtArgs {
     float sign = 1.f;
 };
 
-template <bool ERR>
+// NXB: 32-column blocks of X (d <= 32 NXB).  NXB == 1: T stays in registers over all of a workgroup's row tiles; NXB > 1:
+// the epilogue runs once per block of X (P's block is read again -- from L2 / the Infinity Cache) and T is flushed per tile.
+template <bool ERR, int NXB>
 __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const GradtArgs p) {
     __shared__ float lds[2 * GR_KB * GR_LD];
     const int tid = threadIdx.x;
@@ -249,8 +251,23 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
     const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const int nkb = p.K / GR_KB;
-    const bool xlane = l31 < p.d;
-    const float xmask = xlane ? 1.f : 0.f;
+    float xmask[NXB];  // 1 for the lanes whose column of X exists
+#pragma unroll
+    for (int xb = 0; xb < NXB; ++xb) xmask[xb] = l31 + 32 * xb < p.d ? 1.f : 0.f;
+    int tlane = tcol + wc_ * 64 + l31;
+    auto flush = [&](floatx16 (&t)[2], int xb) {  // T[32 xb + i][tlane + 32 j] += t[j][e]
+        int tl = tlane, dl = p.d - 32 * xb - 4 * hi;  // rows of this block that exist, seen from the lane's first row
+        // (opaque: the 32 addresses and 32 lane masks are formed here -- hoisted to the kernel's start they would spill)
+        asm volatile("" : "+v"(tl), "+v"(dl));
+        double *Tb = p.T + (size_t)(32 * xb + 4 * hi) * p.n + tl;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int i = (e & 3) + 8 * (e >> 2);
+                if (i < dl) unsafeAtomicAdd(&Tb[(size_t)i * p.n + j * 32], (double)(sgn * t[j][e]));
+            }
+    };
 
     floatx16 tacc[2];
 #pragma unroll
@@ -304,7 +321,7 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         const rr_rsrc_t xrs = rr_make_rsrc(p.X + ca * p.ldx, tr * (unsigned)p.ldx * 4u);
         const unsigned ldp4 = (unsigned)p.ldp * 4u, ldx4 = (unsigned)p.ldx * 4u;
         unsigned pofs = (unsigned)(wr * 128 + 4 * hi) * ldp4 + (unsigned)(wc_ * 64 + l31) * 4u;
-        unsigned xofs = (unsigned)(wr * 128 + 4 * hi) * ldx4 + (unsigned)(xlane ? l31 : 0) * 4u;
+        unsigned xofs = (unsigned)(wr * 128 + 4 * hi) * ldx4 + (unsigned)(l31 < p.d ? l31 : 0) * 4u;
         unsigned eofs = (unsigned)(wr * 128 + 4 * hi) * 4u;
         // (opaque per tile: the lane offsets below are the same for every tile, and hoisted out of the tile loop their
         // 192 registers would spill)
@@ -313,16 +330,17 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         if (ERR) ers = rr_make_rsrc(p.err + ca, tr * 4u);
         constexpr int NS = ERR ? 2 : 3;
         float xv[NS][8], pv[NS][2][8], ev[NS][8];
-        auto load_group = [&](int set, int hb) {  // (both compile-time after unrolling)
+        auto load_group = [&](int set, int hb, int xb) {  // (all compile-time after unrolling)
             const int i = hb >> 1;
-            unsigned pb = pofs + (unsigned)(32 * i) * ldp4, xb = xofs + (unsigned)(32 * i) * ldx4;
-            asm volatile("" : "+v"(pb), "+v"(xb));  // (per group: see above)
+            // (X's block xb: lanes past d re-read a valid column and are masked in the product)
+            unsigned pb = pofs + (unsigned)(32 * i) * ldp4, xo = xofs + (unsigned)(32 * i) * ldx4 + (xmask[xb] != 0.f ? 128u * xb : 0u);
+            asm volatile("" : "+v"(pb), "+v"(xo));  // (per group: see above)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int e = 8 * (hb & 1) + k;
                 const unsigned ro = (unsigned)((e & 3) + 8 * (e >> 2));
                 // (row steps in the VGPR offset, not in soffset: the hardware's range check does not see soffset)
-                xv[set][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xb + ro * ldx4, 0, 0));
+                xv[set][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo + ro * ldx4, 0, 0));
                 pv[set][0][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pb + ro * ldp4, 0, 0));
                 pv[set][1][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(prs, pb + ro * ldp4 + 128u, 0, 0));
                 if (ERR)
@@ -330,47 +348,72 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
             }
         };
         __builtin_amdgcn_sched_barrier(0);
-        load_group(0, 0);
+        load_group(0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         {   // the tile's last k-block (nothing left to request for this tile)
             const int cbuf = (nkb - 1) & 1;
             gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
             __syncthreads();
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 1; q < NS; ++q) load_group(q, q);
-#pragma unroll
-        for (int hb = 0; hb < 8; ++hb) {
-            const int set = hb % NS, i = hb >> 1;
-            __builtin_amdgcn_sched_barrier(0);  // (the sets' loads stay where they are: the scheduler would pull them together)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int e = 8 * (hb & 1) + k;
-                const float xe = xv[set][k] * xmask;  // (a multiply, not a select: the loads stay unconditional and batched)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const float a = ERR ? fmaf(-ev[set][k], mcol[j], acc[i][j][e]) : acc[i][j][e];
-                    tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, a * pv[set][j][k], tacc[j], 0, 0, 0);
-                }
-            }
+        for (int xb = 0; xb < NXB; ++xb) {
             __builtin_amdgcn_sched_barrier(0);
-            if (hb + NS < 8) load_group(set, hb + NS);
+            if (xb > 0) load_group(0, 0, xb);
+#pragma unroll
+            for (int q = 1; q < NS; ++q) load_group(q, q, xb);
+#pragma unroll
+            for (int hb = 0; hb < 8; ++hb) {
+                const int set = hb % NS, i = hb >> 1;
+                __builtin_amdgcn_sched_barrier(0);  // (the sets' loads stay where they are: the scheduler would pull them together)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = 8 * (hb & 1) + k;
+                    const float xe = xv[set][k] * xmask[xb];  // (a multiply, not a select: the loads stay unconditional and batched)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const float a = ERR ? fmaf(-ev[set][k], mcol[j], acc[i][j][e]) : acc[i][j][e];
+                        tacc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xe, a * pv[set][j][k], tacc[j], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (hb + NS < 8) load_group(set, hb + NS, xb);
+            }
+            if (NXB > 1) {  // this block of T leaves per tile (the registers serve the next block of X)
+                flush(tacc, xb);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) tacc[j][e] = 0.f;
+            }
         }
         // (requested only now: while an LDS-DMA is pending hipcc waits with vmcnt(0) for ANY load result, which would
         // serialise the rotating sets above)
         if (ta + G < p.nta) dma_tile(lds, (int64_t)(ta + G) * GR_TC, 0);
     }
 
-    int tlane = tcol + wc_ * 64 + l31;
-    asm volatile("" : "+v"(tlane));  // (the 32 flush addresses are formed here, not at kernel start where they would spill)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int i = (e & 3) + 8 * (e >> 2) + 4 * hi;
-            if (i < p.d) unsafeAtomicAdd(&p.T[(size_t)i * p.n + tlane + j * 32], (double)(sgn * tacc[j][e]));
-        }
+    if (NXB == 1) flush(tacc, 0);
+}
+
+// one workgroup per CU: each keeps its column block and walks over row tiles (d <= 128)
+static int launch_gemm_gradt(rr_ctx *c, const GradtArgs &g) {
+    int G = c->num_cu / g.ntb;
+    if (G < 1) G = 1;
+    if (G > g.nta) G = g.nta;
+    const dim3 grid((unsigned)(G * g.ntb));
+#define RR_GT2(E, X) hipLaunchKernelGGL((rr_gemm_gradt_f32_kernel<E, X>), grid, dim3(GR_THREADS), 0, c->stream, g)
+    const int nxb = (g.d + 31) / 32;
+    if (g.err) {
+        if (nxb <= 1) RR_GT2(true, 1);
+        else if (nxb == 2) RR_GT2(true, 2);
+        else RR_GT2(true, 4);
+    } else {
+        if (nxb <= 1) RR_GT2(false, 1);
+        else if (nxb == 2) RR_GT2(false, 2);
+        else RR_GT2(false, 4);
+    }
+#undef RR_GT2
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -665,7 +708,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
     int rc = RR_OK;
     const char *nfz = getenv("RR_PASS2_NO_FUSE");
     const bool fuse_t = !pred && sizeof(TX) == 4 && c->gram_engine == 0 && !c->deterministic && !b->large && !b->phase64 &&
-                        n % 256 == 0 && b->d <= 32 && Fp < (1 << 21) && ldx < (1 << 21) && !(nfz && atoi(nfz) != 0);
+                        n % 256 == 0 && b->d <= 128 && Fp < (1 << 21) && ldx < (1 << 21) && !(nfz && atoi(nfz) != 0);
     {   // posterior to the device in f32: m (F), C padded to (Fp, Fp)
         s.hm.resize(F);
         for (int i = 0; i < F; ++i) s.hm[i] = (float)mh[i];
@@ -719,7 +762,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         }
         if (rc != RR_OK) break;
         // The gradient pass with whole [cos | sin] tiles: Err first, then U = P C contracts itself with P, Err m^T and X
-        // block by block (rr_gemm_gradt_f32_kernel<true>) -- U is neither written nor read back, P is read once.
+        // block by block (rr_gemm_gradt_f32_kernel<true, ..>) -- U is neither written nor read back, P is read once.
         if (fuse_t) {
             const TX *yc = dy + r0;
             hipLaunchKernelGGL(rr_err_kernel<TX>, dim3((unsigned)(mpad / 256)), dim3(256), 0, c->stream, yc, s.dot, mrows, s.err,
@@ -729,11 +772,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             g.ntb = (int)(Fp / 256); g.nta = (int)(mpad / 256);
             g.P = s.P; g.ldp = Fp; g.X = (const float *)Xc; g.ldx = ldx; g.rows = mrows;
             g.n = n; g.d = b->d; g.T = s.acc + 1; g.err = s.err; g.mvec = s.m32; g.sign = -1.f;
-            int G = c->num_cu / g.ntb;
-            if (G < 1) G = 1;
-            if (G > g.nta) G = g.nta;
-            hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel<true>, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
-            if (hipGetLastError() != hipSuccess || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
+            if (launch_gemm_gradt(c, g) != RR_OK || (e = hipStreamSynchronize(c->stream)) != hipSuccess) {
                 rr_set_error("pass2: fused gemm failed");
                 rc = RR_ERR_HIP;
                 break;
@@ -2088,9 +2127,9 @@ int rr_featmat_pass2_plan_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x
 }
 
 // rr_featmat_pass2_rows when the planned children are the ONLY consumers of U = P C (the caller's promise): if every plan
-// sits in whole 256-column tiles (col0 % 256 == 0, n % 256 == 0, d <= 32, float32 X, f32 engine, not deterministic mode),
+// sits in whole 256-column tiles (col0 % 256 == 0, n % 256 == 0, d <= 128, float32 X, f32 engine, not deterministic mode),
 // Err is formed first and each child's columns of U are contracted with P, Err m^T and X block by block in registers
-// (rr_gemm_gradt_f32_kernel<true>) -- U is never written, columns without a consumer (a linear child's) never computed.
+// (rr_gemm_gradt_f32_kernel<true, ..>) -- U is never written, columns without a consumer (a linear child's) never computed.
 // Otherwise: rr_featmat_pass2_rows.
 int rr_featmat_pass2_rows_planned(rr_featmat *fm, const void *dy, int y_dtype) {
     RR_REQUIRE(fm != nullptr && fm->pass2 != nullptr, "rr_featmat_pass2_rows_planned: call rr_featmat_pass2_begin first");
@@ -2103,7 +2142,7 @@ int rr_featmat_pass2_rows_planned(rr_featmat *fm, const void *dy, int y_dtype) {
     bool ok = dy != nullptr && !plans.empty() && c->gram_engine == 0 && !c->deterministic && !s.tri_c && fm->ld < (1 << 21) &&
               !(nfz && atoi(nfz) != 0);
     for (const auto &pl : plans)
-        ok = ok && pl.x_dtype == RR_F32 && !pl.b->large && pl.col0 % 256 == 0 && pl.b->n % 256 == 0 && pl.b->d <= 32 &&
+        ok = ok && pl.x_dtype == RR_F32 && !pl.b->large && pl.col0 % 256 == 0 && pl.b->n % 256 == 0 && pl.b->d <= 128 &&
              pl.ldx < (1 << 21) && pl.dX != nullptr;
     if (!ok) return rr_featmat_pass2_rows(fm, dy, y_dtype);
     RR_FM_REQUIRE_FILLED(fm, "rr_featmat_pass2_rows_planned");
@@ -2133,12 +2172,9 @@ int rr_featmat_pass2_rows_planned(rr_featmat *fm, const void *dy, int y_dtype) {
         g.ntb = 2 * pl.b->n / 256; g.nta = (int)(rows256 / 256);
         g.P = fm->P + pl.col0; g.ldp = fm->ld; g.X = (const float *)pl.dX; g.ldx = pl.ldx; g.rows = fm->rows;
         g.n = pl.b->n; g.d = pl.b->d; g.T = pl.dT; g.err = s.err; g.mvec = s.m32 + pl.col0; g.sign = -1.f;
-        int G = c->num_cu / g.ntb;
-        if (G < 1) G = 1;
-        if (G > g.nta) G = g.nta;
-        hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel<true>, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+        int rcg = launch_gemm_gradt(c, g);
+        if (rcg != RR_OK) return rcg;
     }
-    RR_CHECK_HIP(hipGetLastError());
     s.fused = plans;
     return RR_OK;
 }
@@ -2249,7 +2285,7 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     const bool no_fuse = nf && atoi(nf) != 0;
     const bool fuse = s.fuse.armed && !objective_only && !no_fuse && c->gram_engine == 0 && !c->deterministic &&
                       s.fuse.col0 == 0 && 2 * (int64_t)s.fuse.b->n == fm->F && fm->F == Fp && s.fuse.b->n % 256 == 0 &&
-                      s.fuse.b->d <= 32 && Fp < (1 << 21) && s.fuse.ldx < (1 << 21);
+                      s.fuse.b->d <= 128 && Fp < (1 << 21) && s.fuse.ldx < (1 << 21);
     s.fuse.armed = false;
     s.fuse.done = false;
     RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
@@ -2317,11 +2353,8 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         g.ntb = (int)(Fp / 256); g.nta = (int)(rows256 / 256);
         g.P = fm->P; g.ldp = Fp; g.X = (const float *)s.fuse.dX; g.ldx = s.fuse.ldx; g.rows = fm->rows;
         g.n = s.fuse.b->n; g.d = s.fuse.b->d; g.T = s.fuse.dT;
-        int G = c->num_cu / g.ntb;  // one workgroup per CU, each keeps its column block and walks over row tiles
-        if (G < 1) G = 1;
-        if (G > g.nta) G = g.nta;
-        hipLaunchKernelGGL(rr_gemm_gradt_f32_kernel<false>, dim3((unsigned)(G * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
-        RR_CHECK_HIP(hipGetLastError());
+        rc = launch_gemm_gradt(c, g);
+        if (rc != RR_OK) return rc;
         s.have_edphi = false;
         s.fuse.done = true;
         return RR_OK;

@@ -291,14 +291,15 @@ def test_config5_full_minibatch_is_additive_over_rows():
 
 
 @pytest.mark.parametrize("d,n,rows,ard", [(5, 256, 1500, True), (5, 256, 1500, False), (32, 512, 700, True),
-                                          (17, 256, 256, True), (3, 768, 2049, False)])
+                                          (17, 256, 256, True), (3, 768, 2049, False), (40, 256, 600, True),
+                                          (64, 256, 300, True), (100, 256, 777, True)])
 def test_edphi_product_fused_with_its_contraction_equals_the_two_pass_route(monkeypatch, d, n, rows, ard):
     """A lone random Fourier child whose [cos | sin] block fills whole 256-column tiles: the step contracts every block
     of EdPhi = dfs^T ws / (K L) (glm.py:311) with P and X while it is in registers (rr_featmat_glm_plan_rff /
     rr_gemm_gradt_f32_kernel) instead of writing EdPhi and reading it back.  Same length-scale gradients as the two-pass
     route (RR_GLM_NO_FUSE=1: GEMM, then rr_glm_grad_t_kernel) and as the oracle's -(EdPhi o dPhi_i).sum() (glm.py:274-275),
-    with partial last row tiles, d < 32, isotropic (the reference's dimension-0 quirk) and ARD length scales, on the
-    host-sample route and on both reduced routes."""
+    with partial last row tiles, d below 32 and above (two / four 32-column blocks of X), isotropic (the reference's
+    dimension-0 quirk) and ARD length scales, on the host-sample route and on both reduced routes."""
     bs, lk, Parameter, Positive, GLM = _imports()
     from revrand_amd.basis_functions import MinibatchFeatures
     rs = np.random.RandomState(100 + d + n)

@@ -213,7 +213,8 @@ def test_second_pass_and_predict_vs_oracle(shape):
     assert normwise(Ey, Eo) < 1e-4 and normwise(Vf, Vo) < 1e-3
 
 
-@pytest.mark.parametrize("N,d,n,ard,chunk", [(3000, 5, 256, True, None), (1500, 32, 256, False, None), (2100, 7, 512, True, 768)])
+@pytest.mark.parametrize("N,d,n,ard,chunk", [(3000, 5, 256, True, None), (1500, 32, 256, False, None), (2100, 7, 512, True, 768),
+                                             (1500, 64, 256, True, None), (900, 100, 256, True, 512)])
 def test_second_pass_product_fused_with_its_contraction_equals_the_two_pass_route(monkeypatch, N, d, n, ard, chunk):
     """With the [cos | sin] block in whole 256-column tiles the second pass' U = Phi C (slm.py:193-195) contracts itself
     with Phi, Err m^T and X block by block in registers (rr_gemm_gradt_f32_kernel<true>) -- U is neither stored nor read
