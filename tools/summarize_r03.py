@@ -144,6 +144,11 @@ for tag, name, key, peak, es in (("elbo_kt", "r03_elbo", "C2_elbo_eval", PEAK["f
                                                "the 256-row parity slice runs the same kernel)", "full", 50.0)
         ks["rr_grad_t_kernel"] = annotate(tr, "rr_grad_t_kernel", (4.0 * d + 8.0 * F) * p2rows, PEAK["hbm"], "byte", p2rows,
                                           "second pass: T = X^T A, reads P and U once (HBM read bound)", "full", 1.0)
+        # since the third session of round 3 the two kernels above are ONE: U = Phi C contracted in registers
+        ks["rr_gemm_gradt_f32_kernel"] = annotate(tr, "rr_gemm_gradt_f32_kernel", (2.0 * F * F + 2.0 * d * F) * p2rows, peak, "flop", p2rows,
+                                                  "second pass: U = Phi C and T = X^T ((Err m^T - U) o dPhi-pattern) in one kernel, one launch "
+                                                  "per 524 288-row chunk: 2 F^2 + 2 d F flop per row", "full", 50.0)
+        ks = {k: v for k, v in ks.items() if v is not None}
         # the posterior's kernels: totals per rr_posterior_dev call
         npost = max(st.get("rr_posterior_rows_kernel(double const*, double const*, double const*, double, long, double*, double*, double*, long)", {}).get("calls", 0), 1)
         ks["posterior_kernels_ms_per_call"] = {k.split("(")[0]: v["total_ms"] / npost for k, v in st.items()
@@ -176,6 +181,23 @@ for tag, name, keys in (("posdef_kt", "r03_posdef", ("posterior_F4096", "posteri
         ks["rr_gemm_tn_f32_kernel"] = annotate(tr, "rr_gemm_tn_f32_kernel", 1.0 * F * F * Np, PEAK["f32"], "flop", Np,
                                                "Phi B with the upper-triangular factor B, ONE launch per predict_moments call: F^2 flop per "
                                                "row (half of 2 F^2; the three longest launches = the three timed calls)", "top3")
+    if name == "r03_c5_glm" and cfgs[keys[0]]:
+        M5, F5, KL5, d5 = 65536, 2048, 500, 32
+        gf = 2.0 * M5 * F5 * KL5
+        for kn, what, work in (("rr_gemm_lik_f32_kernel", "fs = Phi ws^T with the likelihood terms as its epilogue (dfs stored in both layouts)", gf),
+                               ("rr_gemm_tn_f32_kernel", "Ed = dfs Phi (K-split over the minibatch rows, f32 atomics)", gf),
+                               ("rr_gemm_gradt_f32_kernel", "EdPhi = dfs^T ws contracted with P and X in registers (never stored)", gf + 2.0 * d5 * F5 * M5)):
+            a = annotate(tr, kn, work, PEAK["f32"], "flop", M5, what, "all", 0.5)
+            if a:
+                ks[kn] = a
+    if name == "r03_c3" and cfgs[keys[0]]:
+        Ft, n3, d3 = 8257, 4096, 64
+        rows3 = cfgs[keys[0]].get("rows_per_launch", 254200)
+        a = annotate(tr, "rr_gemm_gradt_f32_kernel", (2.0 * Ft * 2 * n3 + 2.0 * d3 * 2 * n3) * rows3, PEAK["f32"], "flop", rows3,
+                     "second pass: the random Fourier child's 32 column tiles of U = Phi C (K = all 8257 features) contracted in "
+                     "registers; the linear child's columns are not computed", "full", 50.0)
+        if a:
+            ks["rr_gemm_gradt_f32_kernel"] = a
     if name == "r03_c4_fastfood" and cfgs[keys[0]]:
         r = cfgs[keys[0]]["roofline"]
         ks["rr_fastfood16_kernel"] = annotate(tr, "rr_fastfood16_kernel", r["bytes_per_row"] * r["rows_per_launch"], PEAK["hbm"], "byte", r["rows_per_launch"],
