@@ -2027,6 +2027,8 @@ static int fm_pass2_begin(rr_featmat *fm, const double *m, const double *C, bool
         if (rc0 != RR_OK) return rc0;
     }
     FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.plans.clear();  // (plans hold for one rows call of ONE pass)
+    s.fused.clear();
     s.hm.assign((size_t)Fp, 0.f);
     for (int i = 0; i < F; ++i) s.hm[i] = (float)m[i];
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -2074,6 +2076,8 @@ int rr_featmat_predict_begin_b(rr_featmat *fm, const double *m, const float *dB,
         if (rc0 != RR_OK) return rc0;
     }
     FmPass2 &s = *(FmPass2 *)fm->pass2;
+    s.plans.clear();  // (plans hold for one rows call of ONE pass)
+    s.fused.clear();
     s.hm.assign((size_t)Fp, 0.f);
     for (int i = 0; i < F; ++i) s.hm[i] = (float)m[i];
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
@@ -2093,6 +2097,8 @@ int rr_featmat_pass2_rows(rr_featmat *fm, const void *dy, int y_dtype) {
     RR_REQUIRE(dy == nullptr || y_dtype == RR_F32 || y_dtype == RR_F64, "rr_featmat_pass2_rows: bad dtype");
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     s.have_rows = true;
+    s.plans.clear();  // (announced, but the caller took the stored route: nothing is left armed)
+    s.fused.clear();
     if (fm->rows == 0) return RR_OK;
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));

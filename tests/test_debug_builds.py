@@ -20,7 +20,11 @@ RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "test
           "tests/test_gpu_fastfood.py", "tests/test_gpu_slm.py::test_concat_second_pass_and_predict_vs_oracle",
           "tests/test_gpu_slm.py::test_second_pass_and_predict_vs_oracle", "tests/test_gpu_large_xdim.py",
           "tests/test_gpu_parity_r2.py::test_gram_with_a_ragged_last_column_block",
-          "tests/test_gpu_parity_r2.py::test_predictive_variance_is_a_sum_of_squares_for_badly_scaled_covariances"]
+          "tests/test_gpu_parity_r2.py::test_predictive_variance_is_a_sum_of_squares_for_badly_scaled_covariances",
+          # round 3: the products fused with their consumers (partial row tiles, Xdim below / above 32)
+          "tests/test_gpu_slm.py::test_second_pass_product_fused_with_its_contraction_equals_the_two_pass_route",
+          "tests/test_gpu_glm.py::test_edphi_product_fused_with_its_contraction_equals_the_two_pass_route",
+          "tests/test_gpu_glm.py::test_first_product_with_the_likelihood_terms_as_its_epilogue_equals_the_three_pass_route"]
 
 
 def _asan_runtime():

@@ -206,11 +206,13 @@ def test_f64_gram_is_unaffected(engine):
 
 
 @pytest.mark.parametrize("chunk_rows", [None, 512])
-def test_concat_second_pass_and_predict_on_the_engine(engine, chunk_rows):
+def test_concat_second_pass_and_predict_on_the_engine(engine, chunk_rows, monkeypatch):
     """The concatenated-basis case of test_gpu_slm.py (statistics, sqErr, per-child gradients, predict_moments) with the
-    Gram and U = Phi C on the split-bf16 engine."""
+    Gram and U = Phi C on the split-bf16 engine (whose second pass keeps the stored route at every width)."""
     from test_gpu_slm import test_concat_second_pass_and_predict_vs_oracle as concat_case
-    concat_case(chunk_rows)
+    concat_case(monkeypatch, chunk_rows, 70, 90, None)
+    if chunk_rows is None:
+        concat_case(monkeypatch, None, 256, 512, None)
 
 
 def test_glm_step_on_the_engine(engine, golden):
