@@ -899,7 +899,14 @@ rr_rowvec_kernel(const float *__restrict__ P, const float *__restrict__ mvec, in
 // samples >= K*L are written as zero so the following GEMMs can run over the padded shapes.
 // likelihoods.py: Bernoulli :46-104, Binomial :171-233, Gaussian :298-396, Poisson :456-521.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ float rr_softplus(float f) { return fmaxf(f, 0.f) + log1pf(__expf(-fabsf(f))); }
+// log(1 + t) for 0 <= t <= 1 without the library's log1pf (whose code keeps hipcc from unrolling the tile epilogue of
+// rr_gemm_lik_f32_kernel over a lane's 128 elements): log(u) t / (u - 1) with u = fl(1 + t) undoes the rounding of 1 + t
+// (u - 1 is exact), and t itself where u == 1
+__device__ __forceinline__ float rr_log1p01(float t) {
+    const float u = 1.f + t, dd = u - 1.f;
+    return dd == 0.f ? t : __logf(u) * __fdividef(t, dd);
+}
+__device__ __forceinline__ float rr_softplus(float f) { return fmaxf(f, 0.f) + rr_log1p01(__expf(-fabsf(f))); }
 __device__ __forceinline__ float rr_expit(float f) {
     const float t = __expf(-fabsf(f));
     return f >= 0.f ? 1.f / (1.f + t) : t / (1.f + t);
@@ -2311,10 +2318,8 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
     const int64_t tiles1 = (rows256 / 256) * (kl_ld / 256);
     const bool lik_force = fl && !strcmp(fl, "force"), lik_off = fl && !strcmp(fl, "0");
     const bool lik_auto = tiles1 >= 2 * (int64_t)c->num_cu || Fp / GR_KB < 16;  // (fm_gemm would not split K)
-    // (the Gaussian and the exp-link Poisson: with the logistic / softplus likelihoods' log1p code hipcc refuses to unroll
-    // the epilogue over a lane's 128 accumulator elements -- they keep rr_glm_lik_kernel)
     const bool fuse_lik = !no_fuse && c->gram_engine == 0 && !c->deterministic && !lik_off && (lik_force || lik_auto) &&
-                          (lik == RR_LIK_GAUSSIAN || lik == RR_LIK_POISSON_EXP) && fm->max_rows < (1 << 20) && kl_ld < (1 << 20);
+                          fm->max_rows < (1 << 20) && kl_ld < (1 << 20);
     if (fuse_lik) {
         GemmLikArgs g;
         g.A = s.Pt; g.lda = fm->max_rows; g.B = s.WSt; g.ldb = kl_ld; g.K = (int)Fp; g.ntb = (int)(kl_ld / 256);
@@ -2323,13 +2328,17 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         g.y = dy; g.rowarg = drowarg; g.y_f64 = dtype == RR_F64; g.M = fm->rows;
         g.par = (float)lik_param; g.fscale = (float)KL; g.KL = KL; g.L = L; g.llsum = s.kacc; g.aux = s.kacc + s.kcap;
 #define RR_GL(ID, ST) hipLaunchKernelGGL((rr_gemm_lik_f32_kernel<ID, ST>), dim3((unsigned)tiles1), dim3(GR_THREADS), 0, c->stream, g)
-        if (lik == RR_LIK_GAUSSIAN) {
-            if (objective_only) RR_GL(RR_LIK_GAUSSIAN, false);
-            else RR_GL(RR_LIK_GAUSSIAN, true);
-        } else {
-            if (objective_only) RR_GL(RR_LIK_POISSON_EXP, false);
-            else RR_GL(RR_LIK_POISSON_EXP, true);
+#define RR_GLS(ID)                         \
+    if (objective_only) RR_GL(ID, false);  \
+    else RR_GL(ID, true)
+        switch (lik) {
+            case RR_LIK_BERNOULLI: RR_GLS(RR_LIK_BERNOULLI); break;
+            case RR_LIK_BINOMIAL: RR_GLS(RR_LIK_BINOMIAL); break;
+            case RR_LIK_GAUSSIAN: RR_GLS(RR_LIK_GAUSSIAN); break;
+            case RR_LIK_POISSON_EXP: RR_GLS(RR_LIK_POISSON_EXP); break;
+            default: RR_GLS(RR_LIK_POISSON_SOFTPLUS); break;
         }
+#undef RR_GLS
 #undef RR_GL
         RR_CHECK_HIP(hipGetLastError());
     } else {

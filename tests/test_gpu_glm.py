@@ -353,14 +353,14 @@ def test_edphi_product_fused_with_its_contraction_equals_the_two_pass_route(monk
     assert normwise(fused[0], want) < 5e-3
 
 
-@pytest.mark.parametrize("likname", ["poisson_exp", "gaussian"])
+@pytest.mark.parametrize("likname", ["poisson_exp", "gaussian", "bernoulli", "binomial", "poisson_softplus"])
 @pytest.mark.parametrize("rows,n,K,L", [(700, 100, 3, 7), (1024, 128, 2, 150), (300, 40, 1, 5)])
 def test_first_product_with_the_likelihood_terms_as_its_epilogue_equals_the_three_pass_route(monkeypatch, likname, rows, n, K, L):
     """fs = Phi ws^T, the likelihood derivatives and dfs^T as ONE kernel (rr_gemm_lik_f32_kernel: the 256x256 block of fs
     turns into dfs in registers and is stored in both layouts) against GEMM + rr_glm_lik_kernel + transposing pass
     (RR_GLM_FUSE_LIK=0): every output of the step (glm.py:296-322), the objective-only evaluation, partial row tiles,
-    K L below / above one 256-column tile.  (The fused route is taken by itself from 2 x CU-count output tiles on --
-    config 5 -- and forced here.)"""
+    K L below / above one 256-column tile.  All five likelihoods (the logistic / softplus ones through rr_log1p01).  (The
+    fused route is taken by itself from 2 x CU-count output tiles on -- config 5 -- and forced here.)"""
     bs, lk, Parameter, Positive, GLM = _imports()
     from revrand_amd.basis_functions import MinibatchFeatures
     rs = np.random.RandomState(rows + n)
@@ -368,10 +368,17 @@ def test_first_product_with_the_likelihood_terms_as_its_epilogue_equals_the_thre
     X = rs.randn(rows, d)
     basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
     ls = np.linspace(0.8, 1.4, d)
+    rowarg, oargs = None, []
     if likname == "gaussian":
-        y, lid, lpar = np.sin(X[:, 0]) + 0.1 * rs.randn(rows), lk.RR_LIK_GAUSSIAN, 0.3
+        y, lid, lpar, oargs = np.sin(X[:, 0]) + 0.1 * rs.randn(rows), lk.RR_LIK_GAUSSIAN, 0.3, [0.3]
+    elif likname == "bernoulli":
+        y, lid, lpar = (rs.rand(rows) < 0.5 + 0.3 * np.sin(X[:, 0])).astype(float), lk.RR_LIK_BERNOULLI, 0.0
+    elif likname == "binomial":
+        rowarg = rs.randint(1, 9, size=rows).astype(float)
+        y, lid, lpar, oargs = rs.binomial(rowarg.astype(int), 0.5 + 0.3 * np.sin(X[:, 0])).astype(float), lk.RR_LIK_BINOMIAL, 0.0, [rowarg]
     else:
-        y, lid, lpar = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float), lk.RR_LIK_POISSON_EXP, 0.0
+        y = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float)
+        lid, lpar = (lk.RR_LIK_POISSON_EXP if likname == "poisson_exp" else lk.RR_LIK_POISSON_SOFTPLUS), 0.0
     WS = 0.05 * rs.randn(K * L, 2 * n)
     m, C = 0.05 * rs.randn(2 * n, K), 0.01 + 0.01 * rs.rand(2 * n, K)
     E = rs.randn(K * L, 2 * n).astype(np.float32)
@@ -379,11 +386,11 @@ def test_first_product_with_the_likelihood_terms_as_its_epilogue_equals_the_thre
     def run():
         f = MinibatchFeatures(basis)
         f.assemble(X, [ls])
-        a = f.glm_step(y, None, lid, lpar, WS, K, L) + (np.asarray(f.glm_basis_grads(X)),)
+        a = f.glm_step(y, rowarg, lid, lpar, WS, K, L) + (np.asarray(f.glm_basis_grads(X)),)
         f.assemble(X, [ls])
-        b = f.glm_step_draws(y, None, lid, lpar, m, C, K, L, E) + (np.asarray(f.glm_basis_grads(X)),)
+        b = f.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L, E) + (np.asarray(f.glm_basis_grads(X)),)
         f.assemble(X, [ls])
-        c = f.glm_step_draws(y, None, lid, lpar, m, C, K, L, E, objective_only=True)[2:]
+        c = f.glm_step_draws(y, rowarg, lid, lpar, m, C, K, L, E, objective_only=True)[2:]
         f.release()
         return list(a) + list(b) + list(c)
 
@@ -397,7 +404,7 @@ def test_first_product_with_the_likelihood_terms_as_its_epilogue_equals_the_thre
     # and against the oracle's formulas for the host-sample route
     Phi = orc.rff_transform(X, basis.W, ls)
     fs = WS @ Phi.T
-    dfs = orc.lik_df(likname, y, fs, *([lpar] if likname == "gaussian" else []))
+    dfs = orc.lik_df(likname, y, fs, *oargs)
     assert normwise(fused[0], dfs @ Phi) < 1e-3
 
 
