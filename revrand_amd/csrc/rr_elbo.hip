@@ -73,6 +73,10 @@ struct GemmArgs {
     const void *y = nullptr;
     int y_f64 = 0;
     double *bvec = nullptr;
+    // prediction with the factor form (Vf = rowsum((Phi B)^2), slm.py:240-244): rowsq[r] += sum over the block's columns of
+    // D[r][c]^2 and D is NOT stored (rowsq zeroed by the caller; rows >= rowsq_rows skipped)
+    double *rowsq = nullptr;
+    int64_t rowsq_rows = 0;
 };
 
 template <bool TRIG>
@@ -168,6 +172,19 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
                 }
             }
         }
+    } else if (p.rowsq) {
+        // 32 lanes of a half wave hold the 32 columns of a row: squares summed over the lane's two column blocks, then over
+        // the half wave (xor butterfly), one f64 atomic per row, half wave and column quarter
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = fmaf(acc[i][0][e], acc[i][0][e], acc[i][1][e] * acc[i][1][e]);
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if ((lane & 31) == 0 && gr < p.rowsq_rows) unsafeAtomicAdd(&p.rowsq[gr], (double)v);
+            }
     } else {
         const bool atomic = p.kb_per_split > 0;  // wave-uniform
 #pragma unroll
@@ -749,6 +766,7 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         const int64_t mrows = (N - r0 < chunk) ? N - r0 : chunk;
         const int64_t mpad = (mrows + 255) / 256 * 256;
         const TX *Xc = dX + r0 * ldx;
+        bool fused_vf = false;
         // row-major P (epilogues) and feature-major Pt + Phi m (GEMM operand)
         rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp, true);
         if (rc != RR_OK) break;
@@ -788,6 +806,12 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             GemmArgs g;
             g.A = s.Pt; g.B = Bprep ? Bprep : s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)(((int64_t)F + GR_KB - 1) / GR_KB * GR_KB); g.ntb = (int)(Fp / 256);  // K: the valid feature rows only (the rest of Fp is zero padding)
             g.upper_b = pred ? 1 : 0;
+            if (pred && Bprep && form == 1 && !c->deterministic && !getenv("RR_PREDICT_NO_FUSE")) {  // Vf = rowsum((Phi B)^2) summed in the product's epilogue
+                e = hipMemsetAsync(s.acc, 0, (size_t)mrows * 8, c->stream);
+                g.rowsq = s.acc;
+                g.rowsq_rows = mrows;
+                fused_vf = true;
+            }
             hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
         }
         if (hipGetLastError() != hipSuccess) {
@@ -796,8 +820,9 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             break;
         }
         if (pred) {
-            hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.U,
-                               (Bprep && form == 1) ? (const float *)s.U : (const float *)s.P, mrows, F, Fp, s.acc);
+            if (!fused_vf)
+                hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.U,
+                                   (Bprep && form == 1) ? (const float *)s.U : (const float *)s.P, mrows, F, Fp, s.acc);
             std::vector<float> dot(mrows);
             e = hipMemcpyAsync(out1 + r0, s.acc, (size_t)mrows * 8, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipMemcpyAsync(dot.data(), s.dot, (size_t)mrows * 4, hipMemcpyDeviceToHost, c->stream);
@@ -1293,7 +1318,7 @@ void rr_fm_pass2_free(void *p) {
 }
 
 // Err-independent part for the rows currently in the matrix: dot = P m, Pt = P^T, U = P C.
-static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
+static int fm_pass2_products(rr_featmat *fm, FmPass2 &s, double *rowsq = nullptr) {
     rr_ctx *c = fm->ctx;
     const int64_t rows256 = (fm->rows + 255) / 256 * 256;
     hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, s.m32,
@@ -1318,6 +1343,8 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s) {
     g.K = (int)(((int64_t)fm->F + GR_KB - 1) / GR_KB * GR_KB);  // the valid feature rows only: F = 8257 -> 8288 of the 8448 padded ones
     g.ntb = (int)(fm->ld / 256);
     g.upper_b = s.tri_c ? 1 : 0;
+    g.rowsq = rowsq;
+    g.rowsq_rows = fm->rows;
     hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
@@ -2234,10 +2261,13 @@ int rr_featmat_predict_rows(rr_featmat *fm, double *Ey, double *Vf) {
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
     FmPass2 &s = *(FmPass2 *)fm->pass2;
-    int rc = fm_pass2_products(fm, s);
+    const bool fused_vf = s.sq_form && c->gram_engine == 0 && !c->deterministic && !getenv("RR_PREDICT_NO_FUSE");  // (see GemmArgs::rowsq)
+    if (fused_vf) RR_CHECK_HIP(hipMemsetAsync(s.vf, 0, (size_t)fm->rows * 8, c->stream));
+    int rc = fm_pass2_products(fm, s, fused_vf ? s.vf : nullptr);
     if (rc != RR_OK) return rc;
-    hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, s.U,
-                       s.sq_form ? (const float *)s.U : (const float *)fm->P, fm->rows, fm->F, fm->ld, s.vf);
+    if (!fused_vf)
+        hipLaunchKernelGGL(rr_rowdot_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, s.U,
+                           s.sq_form ? (const float *)s.U : (const float *)fm->P, fm->rows, fm->F, fm->ld, s.vf);
     RR_CHECK_HIP(hipGetLastError());
     std::vector<float> dot((size_t)fm->rows);
     RR_CHECK_HIP(hipMemcpyAsync(Vf, s.vf, (size_t)fm->rows * 8, hipMemcpyDeviceToHost, c->stream));
