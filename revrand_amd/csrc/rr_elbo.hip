@@ -1457,6 +1457,9 @@ int rr_launch_gemm_trig_f32(rr_ctx *c, const float *A, int64_t lda, const float 
 // ---------------------------------------------------------------------------------------------
 int rr_features_rowmajor_f64(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              double *P, int64_t ldp, bool zero_pad_cols = true);  // rr_rff.hip
+int rr_launch_gemm_gradt_f64(rr_ctx *c, const double *Pt, int64_t lda, const double *C, int64_t ldb, int64_t K, int64_t mpad,
+                             int64_t Fp, const double *P, int64_t ldp, const double *X, int64_t ldx, int64_t rows, int n, int d,
+                             const double *err, const double *mvec, double *T);  // rr_rff.hip
 int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
                           int64_t K, int64_t M, int64_t N, int subtract, int upper_only);
 
@@ -1630,6 +1633,12 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
     if (!pred) RR_CHECK_HIP(hipMemsetAsync(s.acc, 0, nacc * 8, c->stream));
     RR_CHECK_HIP(hipGetLastError());
     int rc = RR_OK;
+    // (opt-in, RR_PASS2_FUSE_F64=1: measured equal to the stored route -- 103.1 vs 102.6 ms per 200 000 x 4096 second pass; the
+    // float64 tile loop runs two workgroups per CU, which already hide each other's store epilogues and the 2.3 ms
+    // contraction pass is paid back by the fused epilogue's exposed loads)
+    const char *fz64 = getenv("RR_PASS2_FUSE_F64");
+    const bool fuse_t64 = !pred && sizeof(TX) == 8 && !c->deterministic && !b->large && n % 128 == 0 && b->d <= 32 &&
+                          fz64 && atoi(fz64) != 0;
     for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
         const int64_t mrows = (N - r0 < chunk) ? N - r0 : chunk;
         const int64_t mpad = (mrows + 127) / 128 * 128;
@@ -1638,6 +1647,19 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
         if (rc != RR_OK) break;
         hipLaunchKernelGGL(rr_transpose_f64_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
                            s.P, mrows, Fp, s.Pt, chunk);
+        // The gradient pass with whole [cos | sin] tiles, float64 X: Phi m and Err first, then U = Phi C contracts itself with
+        // Phi, Err m^T and X in registers (rr_gemm_gradt_f64_kernel, rr_rff.hip) -- U is neither written nor read back.
+        if (fuse_t64) {
+            hipLaunchKernelGGL(rr_rows64_kernel<0>, dim3((unsigned)((mrows + 3) / 4)), dim3(256), 0, c->stream, s.P, s.U, s.m,
+                               mrows, F, Fp, s.dot, s.acc);
+            hipLaunchKernelGGL(rr_err64_kernel<TX>, dim3((unsigned)((mrows + 255) / 256)), dim3(256), 0, c->stream, dy + r0, s.dot,
+                               mrows, s.err, s.acc);
+            rc = rr_launch_gemm_gradt_f64(c, s.Pt, chunk, s.Cp, Fp, ((int64_t)F + 15) / 16 * 16, mpad, Fp, s.P, Fp, (const double *)Xc,
+                                          ldx, mrows, n, b->d, s.err, s.m, s.acc + 1);
+            if (rc != RR_OK) break;
+            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+            continue;
+        }
         rc = rr_launch_gemm_tn_f64(c, s.Pt, chunk, s.Cp, Fp, s.U, Fp, ((int64_t)F + 15) / 16 * 16, mpad, Fp, 0, 0);
         if (rc != RR_OK) break;
         if (pred) {

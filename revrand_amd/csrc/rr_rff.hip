@@ -1632,6 +1632,170 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
             }
         }
 }
+// ---------------------------------------------------------------------------------------------
+// The float64 second pass' U = Phi C contracted with Phi, Err m^T and X block by block in registers (the float64
+// counterpart of rr_gemm_gradt_f32_kernel, rr_elbo.hip; slm.py:193-195): the accumulator layout of
+// v_mfma_f64_16x16x4_f64 -- element e of lane l is row 4 e + (l >> 4), column l & 15 -- is its B-operand layout for the
+// four rows 4 e .. 4 e + 3, so   R[r][c] = +-(U[r][c] - err[r] m[c]) P[r][c +- n]   (formed in place of U) goes back into
+// the matrix pipe with A = X[4 e + (l >> 4)][16 ib + (l & 15)]:  T[i][c mod n] += sum_r X[r][i] R[r][c].  A workgroup keeps
+// its 128-column block and walks over row tiles g, g + G, ..; T (d <= 32: two 16-row blocks x four column blocks per wave)
+// stays in registers until one f64-atomic flush.  Two workgroups per CU cover each other's epilogues.  U is never stored.
+// ---------------------------------------------------------------------------------------------
+struct Gradt64Args {
+    const double *A, *B;  // A = Phi^T (K, lda): feature-major; B = C (K, ldb)
+    int64_t lda, ldb;
+    int K, ntb, nta;      // ntb = 2n / 128 column tiles, nta row tiles
+    const double *P;      // (rows, ldp) row-major features
+    int64_t ldp;
+    const double *X;      // (rows, ldx), d <= 32 valid columns
+    int64_t ldx, rows;
+    int n, d;
+    const double *err, *mvec;
+    double *T;            // (d, n), accumulated into
+};
+
+__global__ void __launch_bounds__(G64_THREADS, 2)
+rr_gemm_gradt_f64_kernel(const Gradt64Args p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * G64_KB * G64_LDB];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tb = __builtin_amdgcn_readfirstlane((int)(blockIdx.x % p.ntb));
+    const int g0 = __builtin_amdgcn_readfirstlane((int)(blockIdx.x / p.ntb)), G = __builtin_amdgcn_readfirstlane((int)(gridDim.x / p.ntb));
+    const int cb = tb * G64_TC;
+    const bool cosblk = cb < p.n;
+    const int pcol = cosblk ? cb + p.n : cb - p.n;  // partner column block in P
+    const int tcol = cosblk ? cb : cb - p.n;        // column block in T
+    const double sgn = cosblk ? 1.0 : -1.0;         // (A = Err m^T - U: see rr_grad_t64_kernel)
+    const int wr = wave >> 1, wc_ = wave & 1;
+    const int lq = lane >> 4, l15 = lane & 15;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
+    const unsigned aoff = (lane >> 4) * G64_LDB + 8u * (wr * 64 + (lane & 15));
+    const unsigned boff = (lane >> 4) * G64_LDB + 8u * (G64_TC + wc_ * 64 + (lane & 15));
+    const int nkb = p.K / G64_KB;
+
+    doublex4 tacc[2][4];
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tacc[ib][j][e] = 0.0;
+    double mcol[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mcol[j] = p.mvec[cb + wc_ * 64 + j * 16 + l15];
+    double xm[2];  // 1 for the lanes whose column of X exists
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) xm[ib] = 16 * ib + l15 < p.d ? 1.0 : 0.0;
+
+    auto dma_tile = [&](unsigned char *buf, int64_t ca, int64_t kb0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int lr = 4 * wave + k;
+            const double *sa = p.A + (kb0 + lr) * p.lda + ca + 2 * lane;
+            const double *sb = p.B + (kb0 + lr) * p.ldb + cb + 2 * lane;
+            unsigned char *dst = buf + lr * G64_LDB;
+            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + G64_TC * 8), 16, 0, 0);
+        }
+    };
+
+    for (int ta = g0; ta < p.nta; ta += G) {
+        const int64_t ca = (int64_t)ta * G64_TC;
+        doublex4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+        dma_tile(lds, ca, 0);
+        __syncthreads();
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cbuf = kb & 1;
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (G64_KB * G64_LDB), ca, (int64_t)(kb + 1) * G64_KB);
+            const unsigned abase = lds0 + cbuf * (G64_KB * G64_LDB) + aoff;
+            const unsigned bbase = lds0 + cbuf * (G64_KB * G64_LDB) + boff;
+            KOps64 o0, o1;
+            o0.load<0>(abase, bbase);
+            RR_STEP64(0, o0, o1) RR_STEP64(1, o1, o0) RR_STEP64(2, o0, o1) RR_STEP64(3, o1, o0)
+            __syncthreads();
+        }
+        // rows of this tile that exist; a row past the end reads row 0 of the tile instead (its U and Err are masked to 0)
+        const int64_t trows = p.rows - ca < G64_TC ? p.rows - ca : G64_TC;
+        const double *Pt = p.P + ca * p.ldp + pcol + wc_ * 64 + l15;
+        const double *Xt = p.X + ca * p.ldx;
+        const double *Et = p.err + ca;
+        // R in place of U, one 16-row block at a time (its 16 + 4 loads are issued before their first use)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double pv[4][4], ev[4];
+            int64_t ro[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t r = wr * 64 + i * 16 + 4 * e + lq;
+                ro[e] = r < trows ? r : -1;
+                const int64_t rc = r < trows ? r : 0;
+                ev[e] = Et[rc];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pv[e][j] = Pt[rc * p.ldp + j * 16];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const double w = ro[e] >= 0 ? sgn : 0.0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j][e] = w * fma(-ev[e], mcol[j], acc[i][j][e]) * pv[e][j];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // T += X^T R: per 16-row block and 16-column block of X, four products over the lane's column blocks
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double xv[2][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t r = wr * 64 + i * 16 + 4 * e + lq;
+                const int64_t rc = r < trows ? r : 0;
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib) xv[ib][e] = Xt[rc * p.ldx + (xm[ib] != 0.0 ? 16 * ib + l15 : 0)] * xm[ib];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        tacc[ib][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xv[ib][e], acc[i][j][e], tacc[ib][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int i = 16 * ib + 4 * e + lq;
+                if (i < p.d) unsafeAtomicAdd(&p.T[(size_t)i * p.n + tcol + wc_ * 64 + j * 16 + l15], tacc[ib][j][e]);
+            }
+}
+
+int rr_launch_gemm_gradt_f64(rr_ctx *c, const double *Pt, int64_t lda, const double *C, int64_t ldb, int64_t K, int64_t mpad,
+                             int64_t Fp, const double *P, int64_t ldp, const double *X, int64_t ldx, int64_t rows, int n, int d,
+                             const double *err, const double *mvec, double *T) {
+    Gradt64Args g;
+    g.A = Pt; g.lda = lda; g.B = C; g.ldb = ldb; g.K = (int)K; g.ntb = (int)(Fp / G64_TC); g.nta = (int)(mpad / G64_TC);
+    g.P = P; g.ldp = ldp; g.X = X; g.ldx = ldx; g.rows = rows; g.n = n; g.d = d; g.err = err; g.mvec = mvec; g.T = T;
+    int G = 2 * c->num_cu / g.ntb;  // two workgroups per CU, each keeps its column block
+    if (G < 1) G = 1;
+    if (G > g.nta) G = g.nta;
+    hipLaunchKernelGGL(rr_gemm_gradt_f64_kernel, dim3((unsigned)(G * g.ntb)), dim3(G64_THREADS), 0, c->stream, g);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
 #undef RR_STEP64
 
 // Host feature matrices of ANY basis (concatenations, LinearBasis, ...) reach the SYRK kernel

@@ -250,6 +250,41 @@ def test_second_pass_product_fused_with_its_contraction_equals_the_two_pass_rout
     assert normwise(out[0][1], out[1][1]) < 2e-4
 
 
+@pytest.mark.parametrize("N,d,n,ard", [(3000, 5, 128, True), (1100, 32, 256, False), (700, 17, 384, True)])
+def test_float64_second_pass_product_fused_with_its_contraction(monkeypatch, N, d, n, ard):
+    """The float64 pipeline's second pass (dtype="f64" bases) with U = Phi C contracted in registers on the f64 matrix
+    cores (rr_gemm_gradt_f64_kernel, 128-column tiles): sqErr and hyper-gradient against the float64 oracle at float64
+    tolerances, and against the stored route; partial last row tiles, isotropic and ARD.  (Opt-in, RR_PASS2_FUSE_F64=1: as fast as
+    the stored route, not faster -- DESIGN 3.16.)"""
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(N + n)
+    X = rs.randn(N, d)
+    y = np.sin(X @ rs.randn(d)) + 0.1 * rs.randn(N)
+    if ard:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()), dtype="f64")
+        ls = np.linspace(0.7, 1.5, d)
+    else:
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, dtype="f64")
+        ls = 1.2
+    var, reg = 0.3, 1.4
+    Phi = orc.rff_transform(X, basis.W, ls)
+    dP = orc.rff_grad(X, basis.W, ls)
+    o = orc.slm_elbo(Phi, y, var, np.full(2 * n, reg), slice(None), [dP[:, :, i] for i in range(d)] if ard else [dP])
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("RR_PASS2_FUSE_F64", fuse)
+        st = basis.device_fit_state(X, y)
+        sq, dh = st.second_pass(ls, o["m"], o["C"], var)
+        st.release()
+        out.append((sq, np.atleast_1d(np.asarray(dh, dtype=float))))
+    err = y - Phi @ o["m"]
+    want = -np.atleast_1d(np.array(o["dhyp"], dtype=float)).ravel()
+    for sq, dh in out:
+        assert abs(sq - err @ err) < 1e-10 * (err @ err)
+        assert normwise(dh, want) < 1e-8
+    assert normwise(out[0][1], out[1][1]) < 1e-10
+
+
 @pytest.mark.parametrize("n,extra", [(126, 3), (127, 1), (128, 0), (255, 2), (60, 5), (383, 1)])
 def test_concat_gram_phi_t_y_rider_and_fallback(n, extra):
     """Phi^T y of a concatenation rides along with the SYRK in the first pad column of the device feature matrix when the
