@@ -77,6 +77,7 @@ struct GemmArgs {
     // D[r][c]^2 and D is NOT stored (rowsq zeroed by the caller; rows >= rowsq_rows skipped)
     double *rowsq = nullptr;
     int64_t rowsq_rows = 0;
+    int spread = rr_dma_spread_env();  // rr_dma_slot
 };
 
 template <bool TRIG>
@@ -104,16 +105,9 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const unsigned voff = 16u * lane;  // the requests' lane part; everything else is scalar (rr_dma_kblock)
     auto dma_tile = [&](float *buf, int kb0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lr = 4 * wave + k;
-            const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
-            const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
-            float *dst = buf + lr * GR_LD;
-            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
-        }
+        rr_dma_kblock(p.A + (int64_t)kb0 * p.lda + ca, p.lda, p.B + (int64_t)kb0 * p.ldb + cb, p.ldb, buf, wave, voff);
     };
 
     int nkb = p.K / GR_KB, kb_first = 0;
@@ -129,8 +123,9 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const int cbuf = kb & 1;
-        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb_first + kb + 1) * GR_KB);
-        gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+        gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, rr_dma_slot(wave, p.spread), [&]() {
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb_first + kb + 1) * GR_KB);
+        });
         __syncthreads();
     }
 
@@ -220,16 +215,6 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_trig_f32_kernel(const G
 // row tiles g, g + G, ..: T stays in 32 registers per lane until one f64 atomic flush at the end.
 // Saves EdPhi's write (rows x F floats), its re-read and P's second read by the contraction kernel.
 // ---------------------------------------------------------------------------------------------
-typedef __amdgpu_buffer_rsrc_t rr_rsrc_t;
-typedef unsigned rr_u4_t __attribute__((ext_vector_type(4)));
-// raw buffer descriptor over `bytes` bytes at a WAVE-UNIFORM address (made provably uniform for the compiler)
-__device__ __forceinline__ rr_rsrc_t rr_make_rsrc(const void *base, unsigned bytes) {
-    const uint64_t a = (uint64_t)base;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)(((uint64_t)hi << 32) | lo), 0, (int)__builtin_amdgcn_readfirstlane(bytes),
-                                             0x00020000);
-}
-
 struct GradtArgs {
     const float *A, *B;
     int64_t lda, ldb;
@@ -244,6 +229,7 @@ struct GradtArgs {
     // A = Err m^T - U, i.e. R = -(U[r][c] - err[r] mvec[c]) P[r][partner] with the signs above: sign = -1
     const float *err = nullptr, *mvec = nullptr;
     float sign = 1.f;
+    int spread = rr_dma_spread_env();  // rr_dma_slot
 };
 
 // NXB: 32-column blocks of X (d <= 32 NXB).  NXB == 1: T stays in registers over all of a workgroup's row tiles; NXB > 1:
@@ -297,15 +283,24 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         mcol[1] = p.mvec[cb + wc_ * 64 + 32 + l31];
     }
 
+    // NXB == 1: buffer-descriptor requests, staggered (rr_dma_kblock).  NXB > 1 (config 3's shape: K = 8288, 1 MB row stride of
+    // A): measured 5 % SLOWER that way (254 vs 242 ms per 254 200-row launch) -- those variants keep the flat requests right
+    // after the barrier.
+    constexpr bool BUFDMA = NXB == 1;
+    const unsigned voff = 16u * lane;  // the requests' lane part; everything else is scalar
     auto dma_tile = [&](float *buf, int64_t ca, int kb0) {
+        if constexpr (BUFDMA) {
+            rr_dma_kblock(p.A + (int64_t)kb0 * p.lda + ca, p.lda, p.B + (int64_t)kb0 * p.ldb + cb, p.ldb, buf, wave, voff);
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lr = 4 * wave + k;
-            const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
-            const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
-            float *dst = buf + lr * GR_LD;
-            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
+            for (int k = 0; k < 4; ++k) {
+                const int lr = 4 * wave + k;
+                const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
+                const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
+                float *dst = buf + lr * GR_LD;
+                __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
+            }
         }
     };
 
@@ -322,8 +317,13 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         __syncthreads();  // k-block 0 of this tile has landed (requested before the previous tile's epilogue)
         for (int kb = 0; kb + 1 < nkb; ++kb) {
             const int cbuf = kb & 1;
-            dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB);
-            gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+            if constexpr (BUFDMA) {
+                gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, rr_dma_slot(wave, p.spread),
+                                       [&]() { dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB); });
+            } else {
+                dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB);
+                gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+            }
             __syncthreads();
         }
 
@@ -1039,6 +1039,7 @@ struct GemmLikArgs {
     float par, fscale;
     int KL, L;
     double *llsum, *aux;
+    int spread = rr_dma_spread_env();  // rr_dma_slot
 };
 
 template <int LIK, bool ST>  // ST: store dfs and dfs^T (false: objective only)
@@ -1063,24 +1064,18 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_lik_f32_kernel(const Ge
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    const unsigned voff = 16u * lane;  // the requests' lane part; everything else is scalar (rr_dma_kblock)
     auto dma_tile = [&](float *buf, int kb0) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int lr = 4 * wave + k;
-            const float *sa = p.A + (int64_t)(kb0 + lr) * p.lda + ca + 4 * lane;
-            const float *sb = p.B + (int64_t)(kb0 + lr) * p.ldb + cb + 4 * lane;
-            float *dst = buf + lr * GR_LD;
-            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + GR_TC), 16, 0, 0);
-        }
+        rr_dma_kblock(p.A + (int64_t)kb0 * p.lda + ca, p.lda, p.B + (int64_t)kb0 * p.ldb + cb, p.ldb, buf, wave, voff);
     };
     const int nkb = p.K / GR_KB;
     dma_tile(lds, 0);
     __syncthreads();
     for (int kb = 0; kb < nkb; ++kb) {
         const int cbuf = kb & 1;
-        if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB);
-        gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+        gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, rr_dma_slot(wave, p.spread), [&]() {
+            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB);
+        });
         __syncthreads();
     }
 

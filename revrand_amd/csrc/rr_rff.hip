@@ -756,8 +756,11 @@ __device__ __forceinline__ void syrk_dma_tile(const SyrkArgs &p, float *buf, int
     }
 }
 
-__global__ void __launch_bounds__(GR_THREADS, 2)
-rr_syrk_f32_kernel(const SyrkArgs p) {
+// MODE 0: flat LDS-DMA right after the barrier (rounds 1-2).  1: the same, staggered over the first k-step pairs.
+// 2: buffer-descriptor LDS-DMA (rr_dma_kblock) right after the barrier.  3: buffer-descriptor LDS-DMA, staggered (the default).
+template <int MODE>
+__device__ __forceinline__ void rr_syrk_f32_body(const SyrkArgs &p) {
+    constexpr bool STAG = (MODE & 1) != 0, BUF = (MODE & 2) != 0;
     __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB: two [32][512] tiles
 
     const int tid = threadIdx.x;
@@ -799,7 +802,26 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
 
     const int64_t nkb = (row_end - row_begin) / GR_KB;  // rows and splits are multiples of 32
     RR_DEV_ASSERT(p.rows % GR_KB == 0 && p.rows_per_split % GR_KB == 0 && tb < p.nb && p.nb * GR_TC <= p.ldp);
-    if (nkb > 0) {
+    if (BUF && nkb > 0) {
+        const unsigned voff = 16u * lane;
+        const float *Pa = p.P + row_begin * p.ldp + ca, *Pb = p.P + row_begin * p.ldp + cb;  // (wave-uniform)
+        rr_dma_kblock(Pa, p.ldp, Pb, p.ldp, lds, wave, voff);
+        __syncthreads();
+        for (int64_t kb = 0; kb < nkb; ++kb) {
+            const int cbuf = (int)(kb & 1);
+            float *nxt = lds + (cbuf ^ 1) * (GR_KB * GR_LD);
+            const int64_t ro = (kb + 1) * GR_KB * p.ldp;
+            if (STAG) {
+                gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, rr_dma_slot(wave, p.spread), [&]() {
+                    if (kb + 1 < nkb) rr_dma_kblock(Pa + ro, p.ldp, Pb + ro, p.ldp, nxt, wave, voff);
+                });
+            } else {
+                if (kb + 1 < nkb) rr_dma_kblock(Pa + ro, p.ldp, Pb + ro, p.ldp, nxt, wave, voff);
+                gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
+            }
+            __syncthreads();
+        }
+    } else if (nkb > 0) {
         syrk_dma_tile(p, lds, row_begin, wave, lane, ca, cb);
         __syncthreads();  // drains the DMA (vmcnt(0)) and publishes tile 0
         for (int64_t kb = 0; kb < nkb; ++kb) {
@@ -807,6 +829,14 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
             float *nxt = lds + (cbuf ^ 1) * (GR_KB * GR_LD);
             // tile kb+1 flies while tile kb is consumed (its buffer was last read before the
             // barrier that ended iteration kb-1)
+            if (STAG) {  // the waves' DMA bursts staggered over the first k-step pairs
+                const int slot = (wave < 4) ? wave : ((wave + 2) & 3);
+                gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, slot, [&]() {
+                    if (kb + 1 < nkb) syrk_dma_tile(p, nxt, row_begin + (kb + 1) * GR_KB, wave, lane, ca, cb);
+                });
+                __syncthreads();
+                continue;
+            }
             if (kb + 1 < nkb && !(p.ablate & 1)) syrk_dma_tile(p, nxt, row_begin + (kb + 1) * GR_KB, wave, lane, ca, cb);
             gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
             if (!(p.ablate & 2)) __syncthreads();
@@ -832,6 +862,11 @@ rr_syrk_f32_kernel(const SyrkArgs p) {
     (void)diag;
     (void)F;
 }
+
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_kernel(const SyrkArgs p) { rr_syrk_f32_body<0>(p); }
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_stag_kernel(const SyrkArgs p) { rr_syrk_f32_body<1>(p); }
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_buf_kernel(const SyrkArgs p) { rr_syrk_f32_body<2>(p); }
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_bufstag_kernel(const SyrkArgs p) { rr_syrk_f32_body<3>(p); }
 
 // ---------------------------------------------------------------------------------------
 // Ragged last column block (round 2).  When F is not a multiple of 256 the last column block holds only
@@ -2313,6 +2348,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     a.tile_map = use_map ? c->tile_map : nullptr;
     a.offdiag_only = od;
     a.ablate = getenv("RR_GRAM_ABLATE") ? atoi(getenv("RR_GRAM_ABLATE")) : 0;
+    a.spread = rr_dma_spread_env();
     if (c->deterministic) {
         void *slabs = nullptr;
         int rc = rr_det_scratch(c, (size_t)nsplit * (size_t)ldp * (size_t)ldp * sizeof(float), &slabs);
@@ -2320,8 +2356,19 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         a.part = (float *)slabs;
         a.part_stride = ldp * ldp;
     }
-    if (ntiles > 0)
-        hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    // RR_SYRK_STAGGER = 0 / 1 / 2: the flat LDS-DMA of rounds 1-2 / the same staggered / buffer-descriptor requests right after
+    // the barrier (A/B runs: 217.8 / 245 / 214.4 ms per 2M-row launch against 211.1 ms for the default, 3)
+    static const int syrk_mode = getenv("RR_SYRK_STAGGER") ? atoi(getenv("RR_SYRK_STAGGER")) : 3;
+    if (ntiles > 0) {
+        if (syrk_mode == 1 && !a.ablate)
+            hipLaunchKernelGGL(rr_syrk_f32_stag_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        else if (syrk_mode == 2 && !a.ablate)
+            hipLaunchKernelGGL(rr_syrk_f32_buf_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        else if (syrk_mode == 3 && !a.ablate)
+            hipLaunchKernelGGL(rr_syrk_f32_bufstag_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        else
+            hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+    }
     if (rg) {
         SyrkArgs ar = a;
         ar.nb = nb_all;

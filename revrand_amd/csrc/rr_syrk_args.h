@@ -61,6 +61,7 @@ struct SyrkArgs {
     const int *tile_map;  // optional (ntiles): position in dispatch order -> tile id (XCD-aware), or null
     int offdiag_only;     // 1: enumerate only tiles with ta < tb (the diagonal ones go to the diag kernel)
     int ablate;  // debug (RR_GRAM_ABLATE): bit0 = no in-loop DMA, bit1 = no in-loop barrier
+    int spread = 2;  // rr_dma_slot (RR_DMA_SPREAD)
     // GEMM mode of rr_syrk_b16w4_kernel (D = A^T B over K-blocked operands): B side matrix, output
     const float *P2 = nullptr;
     int64_t ldp2 = 0;
