@@ -1217,13 +1217,16 @@ __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, 
 #pragma unroll
     for (int t = 0; t < 3; ++t) dd[t] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    auto dma_tile = [&](float *buf, int64_t kb0) {  // KB row segments of 1 KiB per k-block; wave w moves rows (KB/8) w ...
+    // KB row segments of 1 KiB per k-block; wave w moves rows (KB/8) w ...; requests through a buffer descriptor (one constant
+    // VGPR, scalar row offsets: no vector instruction per request, see rr_dma_kblock)
+    const unsigned voff = 16u * lane, ldp4 = (unsigned)p.ldp * 4u;
+    auto dma_tile = [&](float *buf, int64_t kb0) {
+        RR_DEV_ASSERT(kb0 + KB <= p.rows && ca + GR_TC <= p.ldp && p.rows % KB == 0 && p.rows_per_split % KB == 0);
+        const rr_rsrc_t ra = rr_make_rsrc(p.P + kb0 * p.ldp + ca, 0x7fffffffu);
 #pragma unroll
         for (int k = 0; k < KB / 8; ++k) {
             const int lr = (KB / 8) * wave + k;
-            RR_DEV_ASSERT(kb0 + lr < p.rows && ca + GR_TC <= p.ldp && p.rows % KB == 0 && p.rows_per_split % KB == 0);
-            const float *src = p.P + (kb0 + lr) * p.ldp + ca + 4 * lane;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(buf + lr * GR_TC), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(buf + lr * GR_TC), 16, voff, (unsigned)lr * ldp4, 0, 0);
         }
     };
 
@@ -1233,7 +1236,11 @@ __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, 
         __syncthreads();
         for (int64_t kb = 0; kb < nkb; ++kb) {
             const int cbuf = (int)(kb & 1);
-            if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (KB * GR_TC), row_begin + (kb + 1) * KB);
+            const int slot = p.spread ? rr_dma_slot(wave, p.spread) : 0;  // (staggered like the off-diagonal kernel's)
+            auto dma_next = [&]() {
+                if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (KB * GR_TC), row_begin + (kb + 1) * KB);
+            };
+            if (slot == 0) dma_next();
             unsigned abase[NB], bbase[NB];
 #pragma unroll
             for (int e = 0; e < NB; ++e) {
@@ -1243,7 +1250,13 @@ __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, 
             const unsigned xbase = lds0 + cbuf * (4u * KB * GR_TC) + lane_off16;
             KOpsD16<NB, ED> o0, o1;
             o0.template load<0>(abase, bbase, xbase);
-            RR_PAIRD16(0, o0, o1) RR_PAIRD16(1, o1, o0) RR_PAIRD16(2, o0, o1) RR_PAIRD16(3, o1, o0)
+            RR_PAIRD16(0, o0, o1)
+            if (slot == 1) dma_next();
+            RR_PAIRD16(1, o1, o0)
+            if (slot == 2) dma_next();
+            RR_PAIRD16(2, o0, o1)
+            if (slot == 3) dma_next();
+            RR_PAIRD16(3, o1, o0)
             RR_PAIRD16(4, o0, o1) RR_PAIRD16(5, o1, o0) RR_PAIRD16(6, o0, o1) RR_PAIRD16(7, o1, o0)
             if constexpr (KB == 64) {
                 RR_PAIRD16(8, o0, o1) RR_PAIRD16(9, o1, o0) RR_PAIRD16(10, o0, o1) RR_PAIRD16(11, o1, o0)
