@@ -1426,14 +1426,16 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
 
     // DMA: 16 rows x 2 sides = 32 row segments of 1 KiB; wave w moves rows 4w..4w+3
+    // (requests through buffer descriptors: one constant VGPR, scalar row offsets -- see rr_dma_kblock)
+    const unsigned voff = 16u * lane, ldp8 = (unsigned)p.ldp * 8u;
     auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
+        const rr_rsrc_t ra = rr_make_rsrc(p.P + kb0 * p.ldp + ca, 0x7fffffffu), rb = rr_make_rsrc(p.P + kb0 * p.ldp + cb, 0x7fffffffu);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int lr = 4 * wave + k;
-            const double *src = p.P + (kb0 + lr) * p.ldp + 2 * lane;  // 16 B per lane
             unsigned char *dst = buf + lr * G64_LDB;
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + ca), (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + cb), (lptr_t)(dst + G64_TC * 8), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, voff, (unsigned)lr * ldp8, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(dst + G64_TC * 8), 16, voff, (unsigned)lr * ldp8, 0, 0);
         }
     };
 
@@ -1641,15 +1643,16 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+    // (requests through buffer descriptors: one constant VGPR, scalar row offsets -- see rr_dma_kblock)
+    const unsigned voff = 16u * lane, lda8 = (unsigned)p.lda * 8u, ldb8 = (unsigned)p.ldb * 8u;
     auto dma_tile = [&](unsigned char *buf, int64_t kb0) {
+        const rr_rsrc_t ra = rr_make_rsrc(p.A + kb0 * p.lda + ca, 0x7fffffffu), rb = rr_make_rsrc(p.B + kb0 * p.ldb + cb, 0x7fffffffu);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int lr = 4 * wave + k;
-            const double *sa = p.A + (kb0 + lr) * p.lda + ca + 2 * lane;
-            const double *sb = p.B + (kb0 + lr) * p.ldb + cb + 2 * lane;
             unsigned char *dst = buf + lr * G64_LDB;
-            __builtin_amdgcn_global_load_lds((gptr_t)sa, (lptr_t)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t)sb, (lptr_t)(dst + G64_TC * 8), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)dst, 16, voff, (unsigned)lr * lda8, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(dst + G64_TC * 8), 16, voff, (unsigned)lr * ldb8, 0, 0);
         }
     };
     const int nkb = p.K / G64_KB;
