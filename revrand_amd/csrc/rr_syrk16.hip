@@ -1,6 +1,7 @@
 // Split 16-bit Gram / GEMM engine for gfx950 (MI355X, CDNA4): bf16 or fp16 hi + lo operands on the 16-bit matrix pipe,
 // f32 accumulation (RR_GRAM_BF16X3 / BF16X4 / FP16X3, include/revrand_hip.h).
 #include "rr_syrk_args.h"
+#include "rr_mfma_tile.h"  // rr_make_rsrc
 #include <cstring>
 
 // ---------------------------------------------------------------------------------------
@@ -125,8 +126,11 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
     const int tt0 = (wave & 1) * 8;
     const unsigned lane_src = (unsigned)((lane >> 2) * 64 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
     const int64_t ld_side = (GEMM && side) ? p.ldp2 : p.ldp;
-    const char *src0 = (const char *)((GEMM && side) ? p.P2 : p.P) + ((row_begin / 16) * ld_side + (side ? cb : ca)) * 64 +
-                       tt0 * 1024 + lane_src;
+    // (requests through a buffer descriptor: the lane part is one constant VGPR, the stage / segment step a scalar offset --
+    // no vector instruction per request in the MFMA stream; see rr_dma_kblock, rr_mfma_tile.h)
+    // (Gram mode only: a GEMM operand's stages are ld * 64 bytes apart with ld = rows per chunk -- beyond a 32-bit offset)
+    const char *src0 = (const char *)((GEMM && side) ? p.P2 : p.P) + ((row_begin / 16) * ld_side + (side ? cb : ca)) * 64 + tt0 * 1024;
+    const rr_rsrc_t srs = rr_make_rsrc(src0, 0x7fffffffu);
     const int64_t stage_stride = ld_side * 64;
     char *dst0 = lds + side * 16384 + tt0 * 1024;
 
@@ -154,8 +158,13 @@ rr_syrk_b16w4_kernel(const SyrkArgs p) {
     constexpr int NM = NPROD * 16;
     if (S > 0) {
         auto dma_one = [&](int g, int buf, int k) {  // g is clamped: past the end the last k-step is fetched again
-            const char *src = src0 + (int64_t)(g < S ? g : S - 1) * stage_stride + k * 1024;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst0 + buf * B16_STAGE + k * 1024), 16, 0, 0);
+            if constexpr (!GEMM) {
+                const unsigned so = (unsigned)(g < S ? g : S - 1) * (unsigned)stage_stride + (unsigned)(k * 1024);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srs, (lptr_t)(dst0 + buf * B16_STAGE + k * 1024), 16, lane_src, so, 0, 0);
+            } else {
+                const char *src = src0 + lane_src + (int64_t)(g < S ? g : S - 1) * stage_stride + k * 1024;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst0 + buf * B16_STAGE + k * 1024), 16, 0, 0);
+            }
         };
 #pragma unroll
         for (int st = 0; st < 4; ++st)
