@@ -863,10 +863,10 @@ __device__ __forceinline__ void rr_syrk_f32_body(const SyrkArgs &p) {
     (void)F;
 }
 
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_kernel(const SyrkArgs p) { rr_syrk_f32_body<0>(p); }
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_stag_kernel(const SyrkArgs p) { rr_syrk_f32_body<1>(p); }
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_kernel(const SyrkArgs p) { rr_syrk_f32_body<3>(p); }  // the default
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_flat_kernel(const SyrkArgs p) { rr_syrk_f32_body<0>(p); }
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_flatstag_kernel(const SyrkArgs p) { rr_syrk_f32_body<1>(p); }
 __global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_buf_kernel(const SyrkArgs p) { rr_syrk_f32_body<2>(p); }
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_bufstag_kernel(const SyrkArgs p) { rr_syrk_f32_body<3>(p); }
 
 // ---------------------------------------------------------------------------------------
 // Ragged last column block (round 2).  When F is not a multiple of 256 the last column block holds only
@@ -2377,11 +2377,11 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     static const int syrk_mode = getenv("RR_SYRK_STAGGER") ? atoi(getenv("RR_SYRK_STAGGER")) : 3;
     if (ntiles > 0) {
         if (syrk_mode == 1 && !a.ablate)
-            hipLaunchKernelGGL(rr_syrk_f32_stag_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+            hipLaunchKernelGGL(rr_syrk_f32_flatstag_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
         else if (syrk_mode == 2 && !a.ablate)
             hipLaunchKernelGGL(rr_syrk_f32_buf_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
-        else if (syrk_mode == 3 && !a.ablate)
-            hipLaunchKernelGGL(rr_syrk_f32_bufstag_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
+        else if (syrk_mode == 0 || a.ablate)  // (the ablation switches live in the flat variant)
+            hipLaunchKernelGGL(rr_syrk_f32_flat_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
         else
             hipLaunchKernelGGL(rr_syrk_f32_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
     }
