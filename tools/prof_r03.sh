@@ -68,3 +68,8 @@ case " $* " in *" hbm10m "*)
     python bench.py $Q --steps 3 --warmup 1 --configs none > $OUT/chunk_equal_$rep.json 2> $OUT/chunk_equal_$rep.err
   done ;;
 esac
+# (appended) matrix-pipe busy cycles and clock of the headline kernels, one 2M-row launch each:  sh tools/prof_r03.sh sq
+case " $* " in *" sq "*)
+  pmc headline_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" --rows 2000000 --steps 1 --warmup 0 --configs none
+  pmc elbo_sq2 "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32" --rows 1000000 --steps 1 --warmup 0 --configs c2_elbo_eval ;;
+esac
