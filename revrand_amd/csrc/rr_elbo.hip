@@ -1347,6 +1347,10 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s, double *rowsq = nullptr
 
 static int fm_pass2_scratch(rr_featmat *fm) {
     const int64_t Fp = fm->ld;
+    // (rr_dma_kblock: 31 rows x 4 ld bytes of a k-block must stay inside a 32-bit scalar offset)
+    RR_REQUIRE(fm->max_rows < (1 << 25) && Fp < (1 << 25),
+               "feature matrix: second pass / GLM step support up to 2^25 rows per matrix (%lld): process the data in row chunks",
+               (long long)fm->max_rows);
     if (!fm->pass2) {
         FmPass2 *s = new FmPass2();
         fm->pass2 = s;
@@ -1407,6 +1411,7 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
 
 static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd, int64_t Kd,
                    int64_t Md, int64_t Nd) {
+    RR_REQUIRE(lda < (1 << 25) && ldb < (1 << 25), "GEMM: leading dimensions up to 2^25 floats (rr_dma_kblock's 32-bit row offsets)");
     GemmArgs g;
     g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)Kd; g.ntb = (int)(Nd / 256);
     const int64_t tiles = (Md / 256) * g.ntb, nkb = Kd / GR_KB;
