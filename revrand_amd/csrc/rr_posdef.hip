@@ -140,6 +140,152 @@ __global__ void __launch_bounds__(256) rr_chol_diag_kernel(double *__restrict__ 
         }
 }
 
+// sqrt(x) and 1 / sqrt(x) of a positive, normal x from ONE v_rsq_f64 and two coupled Newton (Goldschmidt) steps, each
+// result with a final correction (both within an ulp or two): half the dependent chain of sqrt() followed by a division.
+__device__ __forceinline__ void rr_sqrt_and_rsqrt(double x, double &s, double &inv) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    double t = h + h;
+    t = fma(t, fma(-g, t, 1.0), t);
+    s = g;
+    inv = t;
+}
+
+// One step q = 16 QI + qk of rr_chol_diag_pipe_kernel (below).  LAST: qk == 15, the next pivot row lives in slot QI + 1.
+template <int QI, bool LAST>
+__device__ __forceinline__ void rr_chol_pipe_step(double (&a)[8][8], double (&ur)[8], double (&vc)[8], double (*rowbuf)[PB],
+                                                  const int qk, const int ty, const int tx, int &badflag) {
+    const int q = 16 * QI + qk;
+    __syncthreads();  // row q is in rowbuf[q & 1]; everybody is done with rowbuf[(q + 1) & 1]
+    const double *rb = rowbuf[q & 1];
+    double app = rb[q];
+    double rr[8], rc[8];
+#pragma unroll
+    for (int i = QI; i < 8; ++i) rr[i] = rb[16 * i + ty];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rc[j] = rb[16 * j + tx];
+    // ---- the rest of step q - 1: slots below the pivot row's (every row of them is > q - 1); its own slot was updated
+    // ---- before row q was published.  Columns: c <= q - 1 (W part) or c >= r (U part), nothing in between.
+    {
+        const double vq = tx < qk ? vc[QI] : 0.0;
+#pragma unroll
+        for (int i = QI + 1; i < 8; ++i) {
+            const double vd = tx >= ty ? vc[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j > QI && j < i) continue;
+                const double v = j == QI ? vq : (j == i ? vd : vc[j]);
+                a[i][j] = fma(-ur[i], v, a[i][j]);
+            }
+        }
+    }
+    // ---- pivot q
+    const bool ok = app > 0.0 && app < INFINITY;  // uniform (every thread reads the same value)
+    badflag |= ok ? 0 : 1;
+    app = ok ? app : 1.0;
+    double dp, inv;
+    rr_sqrt_and_rsqrt(app, dp, inv);
+    double urn[8], vcn[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) urn[i] = i >= QI ? rr[i] * inv : 0.0;  // U[q][r] for this thread's rows
+#pragma unroll
+    for (int j = 0; j < 8; ++j) vcn[j] = 16 * j + tx == q ? inv : rc[j] * inv;  // U[q][c] (c > q), T[q][q], T[q][c] (c < q)
+    if (ty == qk) {  // row q becomes final
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[QI][j] = 16 * j + tx == q ? dp : vcn[j];
+    }
+    // ---- step q on the slot that holds row q + 1, and row q + 1 on its way to the others
+    if constexpr (!LAST) {
+        const double ue = ty > qk ? urn[QI] : 0.0;
+        const double vm = (tx <= qk || tx >= ty) ? vcn[QI] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[QI][j] = fma(-ue, j == QI ? vm : vcn[j], a[QI][j]);
+        if (ty == qk + 1) {
+            double *wb = rowbuf[(q + 1) & 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wb[16 * j + tx] = a[QI][j];
+        }
+    } else if constexpr (QI < 7) {
+        const double vd = tx >= ty ? vcn[QI + 1] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[QI + 1][j] = fma(-urn[QI + 1], j == QI + 1 ? vd : vcn[j], a[QI + 1][j]);
+        if (ty == 0) {
+            double *wb = rowbuf[(q + 1) & 1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wb[16 * j + tx] = a[QI + 1][j];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        ur[i] = urn[i];
+        vc[i] = vcn[i];
+    }
+}
+
+// rr_chol_diag_kernel with its steps software-pipelined (round 3, last session).  The kernel above is bound by the
+// LATENCY of a step's dependent chain -- row p to LDS, barrier, LDS reads, sqrt and division, scaling -- with one wave
+// per SIMD and nothing to overlap it: ~1650 cycles per step for ~500 cycles of issue.  Here step q's rank-1 update is
+// split: the slot (8 register elements per thread) that holds row q + 1 is updated FIRST and row q + 1 published, and
+// the update of the other slots runs in step q + 1 under its LDS reads and pivot chain.  The per-element predicates
+// become compile-time column ranges plus three selected row vectors per step (no v_cndmask pair per FMA, no FMAs on
+// the columns strictly between the pivot and the row), and sqrt + division one v_rsq_f64 with coupled Newton steps.
+// Same layout, same outputs (the factor to an ulp or two of the kernel above).  tools/chol_diag_emu.py is the NumPy
+// model of this schedule.
+__global__ void __launch_bounds__(256) rr_chol_diag_pipe_kernel(double *__restrict__ A, int64_t ld, double *__restrict__ Uinv) {
+    __shared__ double rowbuf[2][PB];
+    const int tid = threadIdx.x;
+    const int ty = tid >> 4, tx = tid & 15;
+    double a[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * i + ty, c = 16 * j + tx;
+            a[i][j] = c >= r ? A[(int64_t)r * ld + c] : 0.0;  // lower slots: W = strictly lower part of I
+        }
+    if (ty == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) rowbuf[0][16 * j + tx] = a[0][j];
+    }
+    double ur[8], vc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ur[i] = vc[i] = 0.0;
+    int badflag = 0;
+#define RR_CHOL_BLOCK(QI)                                                                              \
+    for (int qk = 0; qk < 15; ++qk) rr_chol_pipe_step<QI, false>(a, ur, vc, rowbuf, qk, ty, tx, badflag); \
+    rr_chol_pipe_step<QI, true>(a, ur, vc, rowbuf, 15, ty, tx, badflag);
+    RR_CHOL_BLOCK(0) RR_CHOL_BLOCK(1) RR_CHOL_BLOCK(2) RR_CHOL_BLOCK(3)
+    RR_CHOL_BLOCK(4) RR_CHOL_BLOCK(5) RR_CHOL_BLOCK(6) RR_CHOL_BLOCK(7)
+#undef RR_CHOL_BLOCK
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = 16 * i + ty, c = 16 * j + tx;
+            double u = c >= r ? a[i][j] : 0.0;
+            if (badflag && r == c) u = -1.0;
+            A[(int64_t)r * ld + c] = u;
+            if (c < r) Uinv[c * PB + r] = a[i][j];
+            else Uinv[c * PB + r] = (c == r) ? 1.0 / a[i][j] : 0.0;
+        }
+}
+
+// RR_CHOL_DIAG=0: the unpipelined kernel (A/B runs)
+static void launch_chol_diag(hipStream_t stream, double *Ujj, int64_t ld, double *Uij) {
+    static const bool plain = getenv("RR_CHOL_DIAG") != nullptr && atoi(getenv("RR_CHOL_DIAG")) == 0;
+    if (plain)
+        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, stream, Ujj, ld, Uij);
+    else
+        hipLaunchKernelGGL(rr_chol_diag_pipe_kernel, dim3(1), dim3(256), 0, stream, Ujj, ld, Uij);
+}
+
 // W (Fp, Fp) = J C J in the top-left F x F (both index orders reversed), identity on the pad diagonal
 __global__ void __launch_bounds__(256)
 rr_reverse_pad_kernel(const double *__restrict__ C, int64_t F, int64_t Fp, double *__restrict__ W) {
@@ -238,7 +384,7 @@ static int chol_upper_blocked(rr_ctx *c, PosdefScratch &s, int64_t Fp) {
     for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
         double *Ujj = s.W + j * PB * (ld + 1);
         double *Uij = s.Uinv + j * PB * PB;
-        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, c->stream, Ujj, ld, Uij);
+        launch_chol_diag(c->stream, Ujj, ld, Uij);
         const int64_t rest = Fp - (j + 1) * PB;
         if (rest > 0) {
             double *panel = Ujj + PB;  // block row j, columns right of the diagonal block
@@ -351,7 +497,7 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         double *Uij = s.Uinv + j * PB * PB;
         const int64_t rest = Fp - (j + 1) * PB;
         // factor, panel j (context's stream)
-        hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, main_stream, Ujj, ld, Uij);
+        launch_chol_diag(main_stream, Ujj, ld, Uij);
         if (rest > 0) rc = rr_launch_gemm_tn_f64(c, Uij, PB, Ujj + PB, ld, Ujj + PB, ld, PB, PB, rest, 0, 0);  // panel <- U_jj^-T panel
         if (rc != RR_OK) break;
         if (overlap) RR_CHECK_HIP(hipEventRecord(s.ev[j], main_stream));  // block row j of the factor is final
