@@ -182,6 +182,10 @@ void rr_ctx_destroy(rr_ctx *ctx) {
         (void)hipStreamSynchronize(ctx->stream2);
         (void)hipStreamDestroy(ctx->stream2);
     }
+    if (ctx->stream3) {
+        (void)hipStreamSynchronize(ctx->stream3);
+        (void)hipStreamDestroy(ctx->stream3);
+    }
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);

@@ -17,6 +17,7 @@ struct rr_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // second stream (created on first use): chunk k+1's feature kernel under chunk k's SYRK
+    hipStream_t stream3 = nullptr;  // third stream (created on first use): the look-ahead Cholesky's bulk updates (rr_posdef.hip)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_fork = nullptr;   // orders stream2 behind the context's stream at the start of an overlapped Gram call
     hipDeviceProp_t prop;

@@ -351,6 +351,7 @@ void rr_posdef_scratch_free(void *p) {
     if (!p) return;
     PosdefScratch *s = (PosdefScratch *)p;
     s->release();
+    for (hipEvent_t e : s->ev) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -474,8 +475,20 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         RR_CHECK_HIP(hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         RR_CHECK_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     }
-    if (overlap && (int64_t)s.ev.size() < nblk + 1) {
-        while ((int64_t)s.ev.size() < nblk + 1) {
+    // Look-ahead (round 3, last session; RR_POSDEF_LOOKAHEAD=0 for A/B runs).  The dependent chain of a panel step was
+    // chol(j) -> solve of the whole block row -> update of the whole trailing matrix -> chol(j + 1), although chol(j + 1)
+    // needs one 128 x 128 block of each.  Now the context's stream runs chol(j) -> solve of block (j, j + 1) -> update of
+    // block (j + 1, j + 1) -> chol(j + 1), one-tile launches, and a third stream the rest of the row's solve and of the
+    // trailing update (upper_only = 2: without the block done ahead) under the next diagonal block's factorisation.
+    static const bool no_lookahead = getenv("RR_POSDEF_LOOKAHEAD") != nullptr && atoi(getenv("RR_POSDEF_LOOKAHEAD")) == 0;
+    const bool lookahead = overlap && !no_lookahead && nblk > 2;
+    if (lookahead && !c->stream3) RR_CHECK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
+    const int64_t nev = lookahead ? 4 * nblk + 1 : nblk + 1;
+    // events: [j] first block of row j solved (without look-ahead: the whole row) | [nblk] join | then per panel:
+    // diagonal block factored, rest of the row solved, rest of the trailing matrix updated
+    const int64_t E_JOIN = nblk, E_CHOL = nblk + 1, E_SOLVE = 2 * nblk + 1, E_TRAIL = 3 * nblk + 1;
+    if (overlap && (int64_t)s.ev.size() < nev) {
+        while ((int64_t)s.ev.size() < nev) {
             hipEvent_t e;
             RR_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             s.ev.push_back(e);
@@ -491,11 +504,49 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     if (overlap) {  // the second stream starts behind everything queued so far (W and Y assembled)
         RR_CHECK_HIP(hipEventRecord(c->ev_fork, main_stream));
         RR_CHECK_HIP(hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        if (lookahead) RR_CHECK_HIP(hipStreamWaitEvent(c->stream3, c->ev_fork, 0));
     }
     for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
         double *Ujj = s.W + j * PB * (ld + 1);
         double *Uij = s.Uinv + j * PB * PB;
         const int64_t rest = Fp - (j + 1) * PB;
+        if (lookahead) {
+            double *row = Ujj + PB;  // block row j right of the diagonal block
+            launch_chol_diag(main_stream, Ujj, ld, Uij);
+            RR_CHECK_HIP(hipEventRecord(s.ev[E_CHOL + j], main_stream));
+            if (rest > 0) {
+                // block (j, j + 1) carries the third stream's update of step j - 1
+                if (j > 0) RR_CHECK_HIP(hipStreamWaitEvent(main_stream, s.ev[E_TRAIL + j - 1], 0));
+                rc = rr_launch_gemm_tn_f64(c, Uij, PB, row, ld, row, ld, PB, PB, PB, 0, 0);
+                if (rc != RR_OK) break;
+                RR_CHECK_HIP(hipEventRecord(s.ev[j], main_stream));
+                rc = rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, PB, PB, 1, 1);  // block (j+1, j+1)
+                if (rc != RR_OK) break;
+                if (rest > PB) {
+                    c->stream = c->stream3;
+                    RR_CHECK_HIP(hipStreamWaitEvent(c->stream3, s.ev[E_CHOL + j], 0));
+                    rc = rr_launch_gemm_tn_f64(c, Uij, PB, row + PB, ld, row + PB, ld, PB, PB, rest - PB, 0, 0);
+                    if (rc == RR_OK) {
+                        RR_CHECK_HIP(hipEventRecord(s.ev[E_SOLVE + j], c->stream3));
+                        RR_CHECK_HIP(hipStreamWaitEvent(c->stream3, s.ev[j], 0));
+                        rc = rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 2);
+                    }
+                    if (rc == RR_OK) RR_CHECK_HIP(hipEventRecord(s.ev[E_TRAIL + j], c->stream3));
+                    c->stream = main_stream;
+                    if (rc != RR_OK) break;
+                }
+            }
+            // substitution, step j (second stream): U_jj^-1 and the whole of block row j
+            RR_CHECK_HIP(hipStreamWaitEvent(c->stream2, s.ev[rest > 0 ? j : E_CHOL + j], 0));
+            if (rest > PB) RR_CHECK_HIP(hipStreamWaitEvent(c->stream2, s.ev[E_SOLVE + j], 0));
+            c->stream = c->stream2;
+            double *Yj = s.Y + j * PB * ld;
+            const int64_t width = (j + 1) * PB;
+            rc = rr_launch_gemm_tn_f64(c, Uij, PB, Yj, ld, Yj, ld, PB, PB, width, 0, 0);
+            if (rc == RR_OK && rest > 0) rc = rr_launch_gemm_tn_f64(c, row, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+            c->stream = main_stream;
+            continue;
+        }
         // factor, panel j (context's stream)
         launch_chol_diag(main_stream, Ujj, ld, Uij);
         if (rest > 0) rc = rr_launch_gemm_tn_f64(c, Uij, PB, Ujj + PB, ld, Ujj + PB, ld, PB, PB, rest, 0, 0);  // panel <- U_jj^-T panel
@@ -516,13 +567,14 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         }
     }
     if (rc != RR_OK) {
-        if (overlap) (void)hipStreamSynchronize(c->stream2);  // nothing of this call may outlive it on the second stream
+        if (overlap) (void)hipStreamSynchronize(c->stream2);  // nothing of this call may outlive it on the other streams
+        if (lookahead) (void)hipStreamSynchronize(c->stream3);
         return rc;
     }
     hipLaunchKernelGGL(rr_get_diag_kernel, dim3((unsigned)((Fp + 255) / 256)), dim3(256), 0, main_stream, s.W, Fp, ld, s.dvec);
     if (overlap) {  // the context's stream continues behind the substitution
-        RR_CHECK_HIP(hipEventRecord(s.ev[nblk], c->stream2));
-        RR_CHECK_HIP(hipStreamWaitEvent(main_stream, s.ev[nblk], 0));
+        RR_CHECK_HIP(hipEventRecord(s.ev[E_JOIN], c->stream2));  // (the third stream's work is behind it: every E_SOLVE / E_TRAIL was waited for)
+        RR_CHECK_HIP(hipStreamWaitEvent(main_stream, s.ev[E_JOIN], 0));
     } else {
         for (int64_t j = 0; j < nblk && rc == RR_OK; ++j) {
             const double *Ujj = s.W + j * PB * (ld + 1);

@@ -1620,7 +1620,8 @@ struct Gemm64Args {
     int64_t lda, ldb, ldd;
     int K, ntb;  // ntb = N / 128
     int subtract;    // 1: D -= A^T B (blocked Cholesky updates) instead of D = A^T B
-    int upper_only;  // 1: only tiles with column tile >= row tile (symmetric trailing update, upper triangle kept)
+    int upper_only;  // 1: only tiles with column tile >= row tile (symmetric trailing update, upper triangle kept);
+                     // 2: the same without tile (0, 0) (look-ahead Cholesky: that block is updated ahead, rr_posdef.hip)
 };
 
 __global__ void __launch_bounds__(G64_THREADS, 2)
@@ -1631,7 +1632,7 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t ca = (int64_t)(blockIdx.x / p.ntb) * G64_TC;
     const int cb = (int)(blockIdx.x % p.ntb) * G64_TC;
-    if (p.upper_only && cb < ca) return;  // workgroup-uniform
+    if (p.upper_only && (cb < ca || (p.upper_only == 2 && ca == 0 && cb == 0))) return;  // workgroup-uniform
     const int wr = wave >> 1, wc_ = wave & 1;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned aoff = (lane >> 4) * G64_LDB + 8u * (wr * 64 + (lane & 15));
