@@ -1684,6 +1684,70 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
             }
         }
 }
+// K = M = 128 (the blocked Cholesky's "block row <- U_jj^-T block row" and its one-tile updates, rr_posdef.hip): the
+// products on the factorisation's dependent chain are ONE tile of the kernel above -- 8 double-buffered k-blocks behind
+// each other in a single workgroup, ~19 us for 4 MFLOP.  Here a workgroup owns 32 columns of B / D (N / 32 workgroups),
+// wave w the 32 rows 32 w .. of D; every wave loads its operands for the WHOLE K straight into registers in the MFMA
+// operand layout (2 + 2 values per k-step, 128 B per 16 lanes; A and B come from L2), no LDS, no k-loop barrier: one
+// memory latency, then 128 MFMAs.  In place (D == B) is safe because a workgroup reads and writes whole columns: the
+// barrier before the stores is behind every wave's last MFMA, i.e. behind its last load.
+__global__ void __launch_bounds__(G64_THREADS)
+rr_gemm_tn_f64_k128_kernel(const Gemm64Args p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.x * 32;
+    const int lq = lane >> 4, l15 = lane & 15;
+    const double *Ap = p.A + (int64_t)lq * p.lda + wave * 32 + l15;  // rows 4 T + lq, columns 32 wave + 16 i + l15
+    const double *Bp = p.B + (int64_t)lq * p.ldb + cb + l15;
+    double a[32][2], b[32][2];
+#pragma unroll
+    for (int t = 0; t < 32; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            a[t][i] = Ap[(int64_t)(4 * t) * p.lda + 16 * i];
+            b[t][i] = Bp[(int64_t)(4 * t) * p.ldb + 16 * i];
+        }
+    __builtin_amdgcn_sched_barrier(0);  // every load is requested before the first MFMA (hipcc otherwise keeps ~20 in flight)
+    doublex4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t][i], b[t][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);  // the barrier stays behind the last MFMA, i.e. behind vmcnt(0) of every wave's operand loads
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    double *Dp = p.D + (int64_t)(32 * wave + lq) * p.ldd + cb + l15;  // element (i, j, e): + (16 i + 4 e) ldd + 16 j
+    if (p.subtract) {  // all 16 reads of D before the first store (one round trip, not 16)
+        double dv[2][2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dv[i][j][e] = Dp[(int64_t)(16 * i + 4 * e) * p.ldd + 16 * j];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = dv[i][j][e] - acc[i][j][e];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Dp[(int64_t)(16 * i + 4 * e) * p.ldd + 16 * j] = acc[i][j][e];
+}
 // ---------------------------------------------------------------------------------------------
 // The float64 second pass' U = Phi C contracted with Phi, Err m^T and X block by block in registers (the float64
 // counterpart of rr_gemm_gradt_f32_kernel, rr_elbo.hip; slm.py:193-195): the accumulator layout of
@@ -2479,6 +2543,14 @@ int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double 
     g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)K; g.ntb = (int)(N / G64_TC);
     g.subtract = subtract;
     g.upper_only = upper_only;
+    // RR_GEMM64_K128=0: the tile kernel for these shapes too (A/B runs)
+    static const bool no_k128 = getenv("RR_GEMM64_K128") != nullptr && atoi(getenv("RR_GEMM64_K128")) == 0;
+    if (!no_k128 && K == 128 && M == 128 && N % 32 == 0 && (upper_only == 0 || (upper_only == 1 && N == 128))) {
+        // (upper_only = 1 on a single tile: the whole tile, as the tile kernel does)
+        hipLaunchKernelGGL(rr_gemm_tn_f64_k128_kernel, dim3((unsigned)(N / 32)), dim3(G64_THREADS), 0, c->stream, g);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
     hipLaunchKernelGGL(rr_gemm_tn_f64_kernel, dim3((unsigned)((M / G64_TC) * g.ntb)), dim3(G64_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
