@@ -2665,7 +2665,7 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
 // pass2_run64: every child writes its column block, P^T by a transposing pass, U = P C on rr_gemm_tn_f64_kernel, the
 // float64 epilogue kernels above.  Written for the resident fit (CatFitState): no GLM step, no split engines.
 // =============================================================================================
-int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG);  // rr_rff.hip
+int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG, int lower_tri = 0);  // rr_rff.hip
 
 struct rr_featmat64 {
     rr_ctx *ctx = nullptr;

@@ -17,7 +17,7 @@
 
 int rr_launch_gemm_tn_f64(rr_ctx *c, const double *A, int64_t lda, const double *B, int64_t ldb, double *D, int64_t ldd,
                           int64_t K, int64_t M, int64_t N, int subtract, int upper_only);             // rr_rff.hip
-int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG);  // rr_rff.hip
+int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG, int lower_tri = 0);  // rr_rff.hip
 
 constexpr int PB = 128;  // panel width = the f64 GEMM tile
 
@@ -610,7 +610,7 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     }
     // ---- C = Y^T Y ----
     RR_CHECK_HIP(hipMemsetAsync(s.Cp, 0, (size_t)Fp * Fp * 8, c->stream));
-    rc = rr_launch_syrk_f64(c, s.Y, Fp, ld, (int)Fp, s.Cp);  // upper triangle of the (Fp, Fp) product
+    rc = rr_launch_syrk_f64(c, s.Y, Fp, ld, (int)Fp, s.Cp, 1);  // upper triangle of the (Fp, Fp) product; Y is lower triangular
     if (rc != RR_OK) return rc;
     rc = rr_symmetrize_dev(c, s.Cp, Fp);
     if (rc != RR_OK) return rc;

@@ -1324,6 +1324,8 @@ struct Syrk64Args {
     int64_t rows_per_split;  // multiple of 16
     double *G;
     int offdiag_only;  // 1: tiles ta < tb only (the diagonal tiles run in rr_syrk_f64_diag_kernel)
+    int lower_tri = 0;  // 1: P is square and lower triangular (C = Y^T Y of rr_posdef.hip): rows above a tile's last column
+                        // block are zero in it, its k-loop starts at that block
     double *part = nullptr;  // deterministic mode: slab ks (part_stride = ldp * ldp doubles) takes K-split ks' partials
     int64_t part_stride = 0;
 };
@@ -1408,9 +1410,11 @@ rr_syrk_f64_kernel(const Syrk64Args p) {
     const int tb = ta + tdx + od;
     const int ca = ta * G64_TC, cb = tb * G64_TC;
 
-    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_begin = (int64_t)ks * p.rows_per_split;
     int64_t row_end = row_begin + p.rows_per_split;
     if (row_end > p.rows) row_end = p.rows;
+    if (p.lower_tri && row_begin < cb) row_begin = cb;
+    if (row_begin >= row_end && p.part == nullptr) return;  // nothing to add (deterministic mode still writes its zeros)
 
     // wave (wr, wc): rows [wr*64, +64) of side A x cols [wc*64, +64) of side B
     const int wr = wave >> 1, wc_ = wave & 1;
@@ -1547,9 +1551,11 @@ __device__ __forceinline__ void syrk64_diag_body(const Syrk64Args &p, unsigned c
     const int ta = blockIdx.x % p.nb;
     const int ks = blockIdx.x / p.nb;
     const int ca = ta * G64_TC;
-    const int64_t row_begin = (int64_t)ks * p.rows_per_split;
+    int64_t row_begin = (int64_t)ks * p.rows_per_split;
     int64_t row_end = row_begin + p.rows_per_split;
     if (row_end > p.rows) row_end = p.rows;
+    if (p.lower_tri && row_begin < ca) row_begin = ca;
+    if (row_begin >= row_end && p.part == nullptr) return;  // (the same for all four waves)
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char *)lds;
     const unsigned off = (lane >> 4) * G64D_LDB + 8u * (lane & 15);
     doublex4 acc[9];
@@ -2480,7 +2486,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     return RR_OK;
 }
 
-int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG) {
+int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, int F, double *dG, int lower_tri = 0) {
     const int nb = (int)(ldp / G64_TC);
     const int od = (nb >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
     const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
@@ -2500,6 +2506,8 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
     Syrk64Args a;
     a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps; a.G = dG;
     a.offdiag_only = od;
+    static const bool no_tri = getenv("RR_SYRK64_TRI") != nullptr && atoi(getenv("RR_SYRK64_TRI")) == 0;  // A/B runs
+    a.lower_tri = lower_tri && !no_tri && rows == ldp ? 1 : 0;
     if (c->deterministic) {
         void *slabs = nullptr;
         int rc = rr_det_scratch(c, (size_t)nsplit * (size_t)ldp * (size_t)ldp * sizeof(double), &slabs);
