@@ -737,7 +737,11 @@ def config_posterior(dev, _hip, args, F):
             "ms": ms, "flops": fl, "dtype": "f64",
             "roofline": {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "achieved": fl / (ms * 1e-3) / 1e12,
                          "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                         "note": "F^3/3 (factor) + F^3 (inverse) flops over the wall-clock of the whole call"},
+                         "frac_potrf_potri_count": float(F) ** 3 / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "note": "F^3/3 (factor) + F^3 (inverse, the count of rounds 2-3: substitution on the identity + a "
+                                 "dense Y^T Y) flops over the wall-clock of the whole call; since the round's last session the "
+                                 "k-loops of Y^T Y skip the zero blocks of the triangular Y, so the work actually issued is "
+                                 "nearer LAPACK's potrf + potri count F^3 -- `frac_potrf_potri_count` prices the call with that"},
             "parity_vs_oracle_solve_posdef": perr}
 
 

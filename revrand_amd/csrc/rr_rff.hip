@@ -1675,20 +1675,29 @@ rr_gemm_tn_f64_kernel(const Gemm64Args p) {
         RR_STEP64(0, o0, o1) RR_STEP64(1, o1, o0) RR_STEP64(2, o0, o1) RR_STEP64(3, o1, o0)
         __syncthreads();
     }
+    // (subtract: the 16 reads of a block row of D are requested together -- written element by element hipcc serialises
+    // 64 load -> wait -> store round trips per lane, ~100 us per tile against 7 us of MFMAs at K = 128)
+    double *Dp = p.D + (ca + wr * 64 + (lane >> 4)) * p.ldd + cb + wc_ * 64 + (lane & 15);  // (i, j, e): + (16 i + 4 e) ldd + 16 j
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+        if (p.subtract) {
+            double dv[4][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gc = cb + wc_ * 64 + j * 16 + (lane & 15);
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t gr = ca + wr * 64 + i * 16 + (lane >> 4) + 4 * e;
-                if (p.subtract)
-                    p.D[gr * p.ldd + gc] -= acc[i][j][e];
-                else
-                    p.D[gr * p.ldd + gc] = acc[i][j][e];
-            }
+                for (int e = 0; e < 4; ++e) dv[j][e] = Dp[(int64_t)(16 * i + 4 * e) * p.ldd + 16 * j];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = dv[j][e] - acc[i][j][e];
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) Dp[(int64_t)(16 * i + 4 * e) * p.ldd + 16 * j] = acc[i][j][e];
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 // K = M = 128 (the blocked Cholesky's "block row <- U_jj^-T block row" and its one-tile updates, rr_posdef.hip): the
 // products on the factorisation's dependent chain are ONE tile of the kernel above -- 8 double-buffered k-blocks behind
