@@ -133,13 +133,22 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
     if constexpr (TRIG) {
         float bc[2] = {0.f, 0.f}, bs[2] = {0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) {
+            // the 16 targets of a row block are requested together (read one by one between the stores below, hipcc waits
+            // for each before the next store: 64 serialised round trips per lane)
+            float yrow[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                yrow[e] = 0.f;
+                if (p.y && gr < p.nvalid) yrow[e] = p.y_f64 ? (float)((const double *)p.y)[gr] : ((const float *)p.y)[gr];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 const bool valid = gr < p.nvalid;
-                float yv = 0.f;
-                if (p.y && valid) yv = p.y_f64 ? (float)((const double *)p.y)[gr] : ((const float *)p.y)[gr];
+                const float yv = yrow[e];
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int gc = cb + wc_ * 64 + j * 32 + (lane & 31);
@@ -157,6 +166,7 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
                     }
                 }
             }
+        }
         if (p.y) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
