@@ -1,6 +1,7 @@
 """CPU tests of the host-side mirror: parameter types, W sampling against the golden vectors,
 concatenation bookkeeping, optimiser front-ends.  Modelled on the reference's
 tests/test_bases.py, test_btypes.py and test_optimize.py (no device needed)."""
+import os
 import pickle
 
 import numpy as np
@@ -402,3 +403,13 @@ def test_library_generator_reproduces_numpy_legacy_randn(dtype):
     want = np.concatenate([a.randn(5, 33) for _ in range(3)]).astype(dtype)
     assert np.array_equal(_hip.legacy_randn(b, 3 * 5 * 33, dtype).reshape(15, 33), want)
     assert a.randn() == b.randn()
+
+
+def test_schedule_model_of_the_pipelined_diagonal_block_cholesky():
+    """tools/chol_diag_emu.py restates rr_chol_diag_pipe_kernel's schedule in NumPy (slots, early update of the slot that
+    holds the next pivot row, deferred rest of the rank-1 update, compile-time column ranges, forward substitution in the
+    lower slots): factor and inverse factor of a 128 x 128 block agree with numpy.linalg, and the next pivot is known from
+    a running diagonal before its row arrives (the variant measured in DESIGN 3.10)."""
+    import runpy
+    ns = runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chol_diag_emu.py"))
+    assert ns["ERR_U"] < 1e-13 and ns["ERR_UINV"] < 1e-13

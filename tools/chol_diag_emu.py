@@ -1,3 +1,9 @@
+"""NumPy model of rr_chol_diag_pipe_kernel's schedule (revrand_amd/csrc/rr_posdef.hip): the 128 x 128 diagonal block in the
+registers of a 16 x 16 thread grid (8 x 8 elements per thread, slot (i, j) = element (16 i + ty, 16 j + tx)), the pivot row
+through a double-buffered LDS row, step q's rank-1 update split into the slot that holds row q + 1 (done first, so that
+row q + 1 can be published) and the rest (done in step q + 1, under its LDS reads and pivot chain); the strict lower slots
+carry the forward substitution U^T T = I.  Prints the error of U and of U^-1 against numpy.linalg; the kernel was written
+from this model, and tests/test_host_logic.py runs it."""
 import numpy as np
 rs = np.random.RandomState(0)
 M = rs.randn(128, 300); A = M @ M.T / 300 + np.eye(128) * 0.5
@@ -69,4 +75,6 @@ for i in range(8):
         U[r, c] = np.where(c >= r, a[i, j], 0.0)
         Ui[c, r] = np.where(c < r, a[i, j], np.where(c == r, 1.0 / a[i, j], 0.0))
 Ur = np.linalg.cholesky(A).T
-print("U err", np.abs(U - Ur).max(), "Uinv err", np.abs(Ui - np.linalg.inv(Ur)).max(), np.abs(Ui).max())
+ERR_U, ERR_UINV = np.abs(U - Ur).max(), np.abs(Ui - np.linalg.inv(Ur)).max()
+if __name__ == "__main__":
+    print("U err", ERR_U, "Uinv err", ERR_UINV, np.abs(Ui).max())
