@@ -94,6 +94,57 @@ def _blas_threads():
     return int(threads), info
 
 
+# ----------------------------------------------------------------------------------------------------
+# the ONE JSON line: numbers only, under 8 KB (the driver keeps a 9 KB tail of stdout); prose lives in DESIGN.md 6
+# ----------------------------------------------------------------------------------------------------
+
+def _sig(x, digits=5):
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")):
+        return None
+    return float("%.*g" % (digits, x))
+
+
+def lean(obj):
+    """What goes on stdout: keys starting with "_" (and everything below them) dropped, floats to 5 significant digits.
+    The unabridged record -- every per-kernel time, sample description and note -- goes to --full-json."""
+    if isinstance(obj, dict):
+        return {k: lean(v) for k, v in obj.items() if not k.startswith("_")}
+    if isinstance(obj, (list, tuple)):
+        return [lean(v) for v in obj]
+    if isinstance(obj, (np.floating,)):
+        return _sig(float(obj))
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    return _sig(obj)
+
+
+def full(obj):
+    """The unabridged record: the same tree with the "_" prefixes removed."""
+    if isinstance(obj, dict):
+        return {k.lstrip("_"): full(v) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [full(v) for v in obj]
+    if isinstance(obj, (np.floating,)):
+        return float(obj)
+    if isinstance(obj, (np.integer,)):
+        return int(obj)
+    return obj
+
+
+class ParityError(AssertionError):
+    pass
+
+
+def parity(what, err, tol):
+    """A side configuration whose result is off is not a measurement: it becomes {"error": ...} in the line (the headline
+    asserts its own)."""
+    if not (err <= tol):
+        raise ParityError("parity: %s = %.3g exceeds its tolerance %.1g" % (what, err, tol))
+    return float(err)
+
+
 def cpu_baseline(d, n, W, wvec, sample_rows, budget_s=100.0):
     """the oracle's chunk-accumulated f64 path (10 000-row chunks) over a 200 000-row sample, wall-clock median
     of 3 (fewer when the budget is exhausted -- said in `sample`), BLAS on all host cores."""
@@ -208,15 +259,12 @@ def _timed(dev, fn, reps):
     return float(np.median(ts))
 
 
-def config_c2(dev, _hip, args):
-    """configs[1]: RandomRBF F=4096, D=32, N=1M fp32: Phi + Phi^T Phi (+ Phi^T y)."""
-    d, n, N = 32, 2048, 1_000_000
-    F = 2 * n
-    W = np.random.RandomState(42).randn(d, n)
-    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
-    basis = _hip.RffHandle(W, compute="f32")
-    X, y = gen_chunk(77, N, d, wvec)
-    dX, dy = basis.upload(X), dev.upload_vector(y)
+def _cpu(value, unit, sample):
+    return {"value": value, "unit": unit, "cores": _blas_threads()[0], "kind": "port", "_sample": sample}
+
+
+def _gram_step(dev, _hip, basis, dX, dy, F):
+    """(step(), kernel timings list, stat pointers, accumulator) of one resident Gram pass: zero, features + SYRK, mirror."""
     acc = dev.zeros((F * F + F + 1) * 8)
     p = [_hip.ctypes.c_void_p(acc.ptr.value + o * 8) for o in (0, F * F, F * F + F)]
     kms = []
@@ -226,11 +274,44 @@ def config_c2(dev, _hip, args):
         basis.gram_dev(dX, dy, 1.0, *p)
         kms.append(basis.gram_timings())
         basis.symmetrize_dev(p[0])
+    return step, kms, p, acc
+
+
+def _gram_slice_parity(dev, _hip, basis, dX, dy, acc, p, F, X64, y64, W, ns, dtype):
+    """The Gram of the first `ns` resident rows against the oracle's on the same rows (max-norm relative error)."""
+    orc = _oracle()
+    dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value), (ns, X64.shape[1]), dX.ld, dtype)
+    dev.memset(acc)
+    basis.gram_dev(dXs, _hip.DeviceView(dy, 0, ns), 1.0, *p)
+    basis.symmetrize_dev(p[0])
+    dXs.ptr = None
+    Gs = dev.download(acc, (F, F), np.float64)
+    Gr, _, _ = orc.rff_gram_chunked(X64[:ns], y64[:ns], W, 1.0)
+    return float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
+
+
+def config_c2(dev, _hip, args):
+    """configs[1]: RandomRBF F=4096, D=32, N=1M fp32: Phi + Phi^T Phi (+ Phi^T y)."""
+    d, n, N = 32, 2048, 1_000_000
+    F = 2 * n
+    W = np.random.RandomState(42).randn(d, n)
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    basis = _hip.RffHandle(W, compute="f32")
+    X, y = gen_chunk(77, N, d, wvec)
+    dX, dy = basis.upload(X), dev.upload_vector(y)
+    step, kms, p, acc = _gram_step(dev, _hip, basis, dX, dy, F)
     step()
     kms.clear()
     ms = _timed(dev, step, 3)
     syrk = float(np.mean([k[1] + k[2] for k in kms]))
     feat = float(np.mean([k[0] for k in kms]))
+    G = dev.download(acc, (F, F), np.float64)
+    trace_err = parity("trace(G)/N - 1", abs(float(np.trace(G)) - N) / N, 1e-6)
+    del G
+    perr = None
+    if not args.no_parity_check:
+        perr = parity("Gram of 4096 rows vs oracle", _gram_slice_parity(
+            dev, _hip, basis, dX, dy, acc, p, F, X.astype(np.float64), y.astype(np.float64), W, 4096, np.float32), 1e-4)
     cpu = None
     if not args.no_cpu_baseline:
         orc = _oracle()
@@ -238,18 +319,18 @@ def config_c2(dev, _hip, args):
         t0 = time.perf_counter()
         orc.rff_gram_chunked(X[:ns].astype(np.float64), y[:ns].astype(np.float64), W, 1.0, chunk=10000)
         tc = time.perf_counter() - t0
-        cpu = {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
-               "sample": "%d rows, f64, 10000-row chunks, one run %.1f s" % (ns, tc)}
+        cpu = _cpu(ns / tc, "rows/s", "%d rows, f64, 10000-row chunks, one run %.1f s" % (ns, tc))
     for b in (dX, dy, acc):
         b.free()
-    return {"workload": "RandomRBF nbases=2048 (F=4096), D=32, N=1M f32: features + MFMA Gram, resident", "rows": N,
-            "launches_per_pass": kms[0][3], "rows_per_launch": N // kms[0][3],
-            "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32",
-            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "whole_path_achieved": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12,
-                         "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
-                         "syrk_frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+    fl = flops_per_row(d, n)
+    return {"workload": "RandomRBF F=4096 D=32 N=1M f32 resident: features + Gram", "rows": N,
+            "ms": ms, "value": N / (ms * 1e-3), "unit": "rows/s", "dtype": "f32",
+            "_launches_per_pass": kms[0][3], "_rows_per_launch": N // kms[0][3],
+            "parity": {"gram_4096_rows": perr, "trace": trace_err},
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "syrk_frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "_whole_path_achieved": fl * N / (ms * 1e-3) / 1e12, "_syrk_kernels_ms": syrk,
+                         "_features_kernel_ms": feat},
             "cpu_baseline": cpu}
 
 
@@ -261,47 +342,29 @@ def config_f64(dev, _hip, args):
     wvec = np.random.RandomState(1).randn(d).astype(np.float32)
     basis = _hip.RffHandle(W, compute="f64")
     X, y = gen_chunk(78, N, d, wvec)
-    dX, dy = basis.upload(X.astype(np.float64)), dev.upload_vector(y.astype(np.float64))
-    acc = dev.zeros((F * F + F + 1) * 8)
-    p = [_hip.ctypes.c_void_p(acc.ptr.value + o * 8) for o in (0, F * F, F * F + F)]
-    kms = []
-
-    def step():
-        dev.memset(acc)
-        basis.gram_dev(dX, dy, 1.0, *p)
-        kms.append(basis.gram_timings())
-        basis.symmetrize_dev(p[0])
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    dX, dy = basis.upload(X64), dev.upload_vector(y64)
+    step, kms, p, acc = _gram_step(dev, _hip, basis, dX, dy, F)
     step()
     kms.clear()
     ms = _timed(dev, step, 3)
     syrk = float(np.mean([k[1] + k[2] for k in kms]))
     feat = float(np.mean([k[0] for k in kms]))
     G = dev.download(acc, (F, F), np.float64)
-    trace_err = abs(float(np.trace(G)) - N) / N
-    # parity of this very pass on its first rows against the f64 oracle
-    orc = _oracle()
-    ns = 4096
-    dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value), (ns, d), dX.ld, np.float64)
-    dys = _hip.DeviceView(dy, 0, ns)
-    dev.memset(acc)
-    basis.gram_dev(dXs, dys, 1.0, *p)
-    basis.symmetrize_dev(p[0])
-    dXs.ptr = None
-    Gs = dev.download(acc, (F, F), np.float64)
-    Gr, _, _ = orc.rff_gram_chunked(X[:ns].astype(np.float64), y[:ns].astype(np.float64), W, 1.0)
-    perr = float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
-    assert perr < 1e-10, perr
+    trace_err = parity("trace(G)/N - 1", abs(float(np.trace(G)) - N) / N, 1e-12)
+    del G
+    perr = parity("Gram of 4096 rows vs oracle",
+                  _gram_slice_parity(dev, _hip, basis, dX, dy, acc, p, F, X64, y64, W, 4096, np.float64), 1e-10)
     for b in (dX, dy, acc):
         b.free()
-    return {"workload": "RandomRBF nbases=2048 (F=4096), D=32, N=500k, float64 arithmetic end to end", "rows": N,
-            "launches_per_pass": kms[0][3], "rows_per_launch": N // kms[0][3],
-            "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f64",
-            "trace_rel_err": trace_err, "parity_rel_err_4096_rows_vs_oracle": perr,
-            "roofline": {"bound": "mfma", "kernel": basis.gram_kernel_name(), "peak": PEAK_F64_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
-                         "achieved": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12,
-                         "frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                         "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+    return {"workload": "RandomRBF F=4096 D=32 N=500k float64 end to end: features + f64 MFMA Gram", "rows": N,
+            "ms": ms, "value": N / (ms * 1e-3), "unit": "rows/s", "dtype": "f64",
+            "_launches_per_pass": kms[0][3], "_rows_per_launch": N // kms[0][3],
+            "parity": {"gram_4096_rows": perr, "trace": trace_err},
+            "roofline": {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS,
+                         "frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "syrk_frac": F * (F + 1.0) * N / (syrk * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "_kernel": basis.gram_kernel_name(), "_syrk_kernels_ms": syrk, "_features_kernel_ms": feat}}
 
 
 def config_laplace(dev, _hip, args):
@@ -319,69 +382,60 @@ def config_laplace(dev, _hip, args):
     assert lap.dtype == "f32" and lap.phase64
     basis = lap._handle()
     dX, dy = basis.upload(X64), dev.upload_vector(y64)
-    acc = dev.zeros((F * F + F + 1) * 8)
-    p = [_hip.ctypes.c_void_p(acc.ptr.value + o * 8) for o in (0, F * F, F * F + F)]
-    kms = []
-
-    def step():
-        dev.memset(acc)
-        basis.gram_dev(dX, dy, 1.0, *p)
-        kms.append(basis.gram_timings())
-        basis.symmetrize_dev(p[0])
+    step, kms, p, acc = _gram_step(dev, _hip, basis, dX, dy, F)
     step()
     kms.clear()
     ms = _timed(dev, step, 3)
     syrk = float(np.mean([k[1] + k[2] for k in kms]))
     feat = float(np.mean([k[0] for k in kms]))
     G = dev.download(acc, (F, F), np.float64)
-    trace_err = abs(float(np.trace(G)) - N) / N
+    trace_err = parity("trace(G)/N - 1", abs(float(np.trace(G)) - N) / N, 1e-5)
     del G
-    orc = _oracle()
-    ns = 4096
-    dXs = _hip.DeviceMatrix(dev, _hip.ctypes.c_void_p(dX.ptr.value), (ns, d), dX.ld, np.float64)
-    dev.memset(acc)
-    basis.gram_dev(dXs, _hip.DeviceView(dy, 0, ns), 1.0, *p)
-    basis.symmetrize_dev(p[0])
-    dXs.ptr = None
-    Gs = dev.download(acc, (F, F), np.float64)
-    Gr, _, _ = orc.rff_gram_chunked(X64[:ns], y64[:ns], lap.W, 1.0)
-    perr = float(np.abs(Gs - Gr).max() / np.abs(Gr).max())
-    assert perr < 1e-4, perr
+    perr = parity("Gram of 4096 rows vs oracle",
+                  _gram_slice_parity(dev, _hip, basis, dX, dy, acc, p, F, X64, y64, lap.W, 4096, np.float64), 1e-4)
     for b in (dX, dy, acc):
         b.free()
-    return {"workload": "RandomLaplace nbases=2048 (F=4096, Cauchy W, max|W| = %.3g), D=32, N=1M float64 X resident: float64 "
-                        "phases on the f64 MFMA + f32 features + f32 MFMA Gram" % float(np.abs(lap.W).max()), "rows": N,
-            "ms_per_pass": ms, "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32 (float64 phases)",
-            "trace_rel_err": trace_err, "parity_rel_err_4096_rows_vs_oracle": perr,
-            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "whole_path_achieved": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12,
-                         "whole_path_frac": flops_per_row(d, n) * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "syrk_kernels_ms": syrk, "features_kernel_ms": feat,
-                         "features_kernel": "rr_rff_features_mfma64_kernel<32, 4, true, double, float>",
-                         "features_write_TBps": 4.0 * F * N / (feat * 1e-3) / 1e12}}
+    fl = flops_per_row(d, n)
+    return {"workload": "RandomLaplace F=4096 D=32 N=1M (max|W| %.2g): f64 phases, f32 features + Gram" % float(np.abs(lap.W).max()),
+            "rows": N, "ms": ms, "value": N / (ms * 1e-3), "unit": "rows/s", "dtype": "f32 (f64 phases)",
+            "parity": {"gram_4096_rows": perr, "trace": trace_err},
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "features_write_TBps": 4.0 * F * N / (feat * 1e-3) / 1e12,
+                         "_syrk_kernels_ms": syrk, "_features_kernel_ms": feat,
+                         "_features_kernel": "rr_rff_features_mfma64_kernel<32, 4, true, double, float>"}}
+
+
+def _c3_data(rows, d, stream):
+    """Rows of config 3's synthetic data set (chunk `stream` of it): X ~ N(0,1), y = sin(X w / sqrt(d)) + 0.1 eps."""
+    w = np.random.default_rng([20260928, 3]).standard_normal(d, dtype=np.float32)
+    rng = np.random.default_rng([20260928, 3, stream])
+    X = rng.standard_normal((rows, d), dtype=np.float32)
+    y = (np.sin(X @ w / np.sqrt(d)) + 0.1 * rng.standard_normal(rows, dtype=np.float32)).astype(np.float32)
+    return X, y
+
+
+def _c3_basis(d=64, n=4096):
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    return bs.RandomMatern52(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
+        + bs.LinearBasis(onescol=True)
 
 
 def config_c3(dev, _hip, args):
     """configs[2], one GPU's share: RandomMatern52 n=4096 + LinearBasis, D=64, N = 10M / 8 rows."""
-    import revrand_amd.basis_functions as bs
-    from revrand_amd.btypes import Parameter, Positive
     d, n, N = 64, 4096, 1_250_000
-    rng = np.random.default_rng([20260928, 3])
-    X = rng.standard_normal((N, d), dtype=np.float32)
-    w = rng.standard_normal(d, dtype=np.float32)
-    y = (np.sin(X @ w / np.sqrt(d)) + 0.1 * rng.standard_normal(N, dtype=np.float32)).astype(np.float32)
-    cat = bs.RandomMatern52(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())) \
-        + bs.LinearBasis(onescol=True)
+    X, y = _c3_data(N, d, 0)
+    cat = _c3_basis(d, n)
     st = cat.device_fit_state(X, y)
     F = st.F
     hyp = [np.ones(d)]
-    chunk_rows = int(st.chunk)
+    chunks = [rows for _, rows in st._chunks()]
     st.gram_device(hyp)
     ms = _timed(dev, lambda: st.gram_device(hyp), 3)
     # size-independent property on the full-size result: trace of the random Fourier block == N
     G, b, yty = st.stats_host()
-    tr = abs(float(np.trace(G[:2 * n, :2 * n])) - N) / N
-    assert tr < 1e-5 and G[2 * n, 2 * n] == N and np.array_equal(G, G.T), tr
+    tr = parity("trace of the Fourier block / N - 1", abs(float(np.trace(G[:2 * n, :2 * n])) - N) / N, 1e-5)
+    assert G[2 * n, 2 * n] == N and np.array_equal(G, G.T)
     del G
     # the rest of one `_elbo` at this shape (slm.py:154-199): posterior of the F_tot x F_tot system in HBM, second pass
     elbo = None
@@ -392,11 +446,10 @@ def config_c3(dev, _hip, args):
         st.second_pass(hyp, post[0], st.dC, var)
         t_p2, _ = _median_ms(lambda: st.second_pass(hyp, post[0], st.dC, var), 2)
         fl_post, fl_p2 = F ** 3 / 3.0 + F ** 3, 2.0 * F * F + 4.0 * d * n
-        elbo = {"ms": {"statistics_pass": ms, "posterior": t_post, "second_pass": t_p2, "stage_sum": ms + t_post + t_p2},
-                "posterior_tflops_f64": fl_post / (t_post * 1e-3) / 1e12,
-                "posterior_frac_of_f64_mfma": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                "second_pass_frac_of_f32_mfma": fl_p2 * N / (t_p2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "frac_over_stage_sum": (2.0 * d * n + F * (F + 1.0) + 2.0 * F + fl_p2) * N / ((ms + t_post + t_p2) * 1e-3) / 1e12
+        elbo = {"ms": {"statistics": ms, "posterior": t_post, "second_pass": t_p2},
+                "posterior_frac_f64": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                "second_pass_frac": fl_p2 * N / (t_p2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "frac": (2.0 * d * n + F * (F + 1.0) + 2.0 * F + fl_p2) * N / ((ms + t_post + t_p2) * 1e-3) / 1e12
                 / PEAK_F32_MFMA_TFLOPS}
     st.release()
     cpu = None
@@ -409,17 +462,15 @@ def config_c3(dev, _hip, args):
         Phi = np.hstack((orc.rff_transform(Xs, Wm, np.ones(d)), orc.linear_transform(Xs, True)))
         orc.gram_stats(Phi, ys)
         tc = time.perf_counter() - t0
-        cpu = {"value": ns / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
-               "sample": "%d rows, f64 transform + hstack + Phi^T Phi, one run %.1f s" % (ns, tc)}
+        cpu = _cpu(ns / tc, "rows/s", "%d rows, f64 transform + hstack + Phi^T Phi, one run %.1f s" % (ns, tc))
     fl = 2.0 * d * n + F * (F + 1.0) + 2.0 * F
-    return {"workload": "RandomMatern52 nbases=4096 + LinearBasis(onescol), D=64, F_tot=%d, N=1.25M (= 10M / 8 GPUs): "
-                        "device-side concatenation + MFMA Gram, resident" % F, "rows": N, "ms_per_pass": ms,
-            "value": N / (ms * 1e-3), "unit": "feature-rows/s", "dtype": "f32", "trace_rel_err_rff_block": tr,
-            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "flops_per_row": fl,
-                         "achieved": fl * N / (ms * 1e-3) / 1e12, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "note": "whole pass (feature assembly + both SYRK kernels + mirror) on algorithmic flops"},
-            "exchange_bytes_per_evaluation": 8 * (F * (F + 1) // 2 + F + 2), "elbo_eval_one_gpu_share": elbo,
-            "rows_per_launch": chunk_rows, "launches_per_pass": -(-N // chunk_rows), "cpu_baseline": cpu}
+    return {"workload": "RandomMatern52 n=4096 + LinearBasis D=64 F=%d N=1.25M (1/8 of 10M): concat + Gram, resident" % F,
+            "rows": N, "ms": ms, "value": N / (ms * 1e-3), "unit": "rows/s", "dtype": "f32",
+            "parity": {"trace_fourier_block": tr},
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "_flops_per_row": fl},
+            "exchange_bytes": 8 * (F * (F + 1) // 2 + F + 2), "elbo_eval": elbo,
+            "rows_per_launch": chunks, "cpu_baseline": cpu}
 
 
 def config_c4(dev, _hip, args):
@@ -452,30 +503,26 @@ def config_c4(dev, _hip, args):
     ns = 256
     out = dev.download(ring[(NCH - 1) & 1], (ns, F), np.float32)
     ref = orc.fastfood_transform(X[(NCH - 1) * CH:(NCH - 1) * CH + ns].astype(np.float64), f.B, f.G, f.PI, f.S, 1.0)
-    perr = float(np.abs(out - ref).max() / np.abs(ref).max())
-    assert perr < 1e-3, perr
+    perr = parity("Phi of 256 rows vs oracle chain", float(np.abs(out - ref).max() / np.abs(ref).max()), 1e-3)
     # unit row norm: sum_j Phi_j^2 = 1 for every row (cos^2 + sin^2 over n frequencies, / n)
-    nrm = float(np.abs((out.astype(np.float64) ** 2).sum(axis=1) - 1.0).max())
-    assert nrm < 1e-4, nrm
+    nrm = parity("row norm - 1", float(np.abs((out.astype(np.float64) ** 2).sum(axis=1) - 1.0).max()), 1e-4)
     cpu = None
     if not args.no_cpu_baseline:
         t0 = time.perf_counter()
         nc = 2000
         orc.fastfood_transform(X[:nc].astype(np.float64), f.B, f.G, f.PI, f.S, 1.0)
         tc = time.perf_counter() - t0
-        cpu = {"value": nc / tc, "unit": "feature-rows/s", "cores": _blas_threads()[0], "kind": "port",
-               "sample": "%d rows through the oracle's NumPy FWHT chain, %.1f s" % (nc, tc)}
+        cpu = _cpu(nc / tc, "rows/s", "%d rows through the oracle's NumPy FWHT chain, %.1f s" % (nc, tc))
     dX.free()
     for r in ring:
         r.free()
     bytes_row = 4.0 * d + 4.0 * F
-    return {"workload": "FastFoodRBF nbases=8192, D=128 (F=%d), N=%d device-resident rows per pass in %d chunks of %d "
-                        "into a 2-slot ring, f32" % (F, N, NCH, CH), "rows": N, "ms_per_pass": kms,
-            "value": N / (kms * 1e-3), "unit": "feature-rows/s", "dtype": "f32", "parity_rel_err_256_rows_vs_oracle": perr,
+    return {"workload": "FastFoodRBF nbases=8192 D=128 F=%d N=%d resident, %d chunks of %d into a 2-slot ring, f32" % (F, N, NCH, CH),
+            "rows": N, "ms": kms, "value": N / (kms * 1e-3), "unit": "rows/s", "dtype": "f32",
+            "parity": {"phi_256_rows": perr, "row_norm": nrm},
             "roofline": {"bound": "hbm", "kernel": "rr_fastfood16_kernel", "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
-                         "bytes_per_row": bytes_row, "rows_per_launch": CH, "avg_launch_ms": kms / NCH,
-                         "achieved": bytes_row * N / (kms * 1e-3) / 1e9,
-                         "frac": bytes_row * N / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS},
+                         "achieved": bytes_row * N / (kms * 1e-3) / 1e9, "frac": bytes_row * N / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                         "bytes_per_row": bytes_row, "avg_launch_ms": kms / NCH, "_rows_per_launch": CH},
             "cpu_baseline": cpu}
 
 
@@ -495,12 +542,10 @@ def config_c5(dev, _hip, args):
     m = 0.1 * rs.randn(F, K)
     C = rs.gamma(2., 0.5, size=(F, K))
     ls = np.linspace(0.8, 1.5, d)
-    out = {}
     gemm_flops = 3 * 2.0 * K * L * M * F
-    # Sessions: host, device, host again.  Whichever sampler's session comes FIRST after a configuration that freed tens of GB
-    # runs ~0.5 ms per step slower than the same session a few seconds later (tools/r3_c5_order.sh: with the order swapped
-    # it is the device sampler's) -- where its buffers land, not what it computes -- so the default route is measured
-    # before AND after the other one and every time is the better of its sessions.
+    # Sessions: host, device, host again (a session that comes first after a configuration that freed tens of GB runs
+    # ~0.5 ms per step slower than the same session a few seconds later: where its buffers land, not what it computes --
+    # tools/ab.sh c5order).  EVERY session is reported; each route's figure is the MEDIAN of its sessions.
     sessions = {}
     for sampler in os.environ.get("RR_BENCH_C5_ORDER", "host,device,host").split(","):
         basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
@@ -571,15 +616,15 @@ def config_c5(dev, _hip, args):
             t0 = time.perf_counter()
             g2.fit(X, y)
             tfit[iters] = time.perf_counter() - t0
-        fms = 1e3 * (tfit[40] - tfit[8]) / 32
-        raw["fit_step_ms"] = fms
+        raw["fit_step_ms"] = 1e3 * (tfit[40] - tfit[8]) / 32
         sessions.setdefault(sampler, []).append(raw)
+    out = {}
     for sampler, runs in sessions.items():
-        ms, dms, fms = (min(r[k] for r in runs) for k in ("elbo_step_ms", "device_calls_ms", "fit_step_ms"))
-        out[sampler] = {"elbo_step_ms": ms, "minibatch_rows_per_s": M / (ms * 1e-3), "device_calls_ms": dms, "host_ms": ms - dms,
-                        "gemm_tflops_over_device_calls": gemm_flops / (dms * 1e-3) / 1e12,
-                        "gemm_frac_over_device_calls": gemm_flops / (dms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                        "fit_step_ms": fms, "fit_minibatch_rows_per_s": M / (fms * 1e-3), "sessions": runs}
+        ms, dms, fms = (float(np.median([r[k] for r in runs])) for k in ("elbo_step_ms", "device_calls_ms", "fit_step_ms"))
+        out[sampler] = {"fit_step_ms": fms, "device_calls_ms": dms, "elbo_step_ms": ms,
+                        "device_calls_frac": gemm_flops / (dms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "fit_step_frac": gemm_flops / (fms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "sessions_fit_dev_ms": [[r["fit_step_ms"], r["device_calls_ms"]] for r in runs], "_sessions": runs}
     cpu = None
     if not args.no_cpu_baseline:
         orc = _oracle()
@@ -592,25 +637,15 @@ def config_c5(dev, _hip, args):
         dP = orc.rff_grad(Xc, W, ls)
         orc.glm_elbo(m, C, np.ones(F), slice(None), "poisson_exp", [], (), Phi, [dP[:, :, i] for i in range(d)], yc, e, N / M)
         tc = time.perf_counter() - t0
-        cpu = {"value": Mc / tc, "unit": "minibatch-rows/s", "cores": _blas_threads()[0], "kind": "port",
-               "sample": "%d-row minibatch through the oracle (transform, (M, F, d) grad, glm_elbo), %.1f s" % (Mc, tc)}
+        cpu = _cpu(Mc / tc, "minibatch-rows/s", "%d-row minibatch through the oracle (transform, (M, F, d) grad, glm_elbo), %.1f s" % (Mc, tc))
     dflt = out["host"]  # the estimator's default route: the reference's random stream
-    for k in out:
-        out[k]["fit_gemm_frac"] = gemm_flops / (out[k]["fit_step_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS
-    return {"workload": "GeneralizedLinearModel Poisson, RandomRBF nbases=1024 (F=2048), D=32 ARD, N=2M resident, K=10, "
-                        "L=50, minibatch 65536: one SVI _elbo (Phi, ELBO gradients, length-scale gradient)",
-            "rows_per_step": M, "value": dflt["fit_minibatch_rows_per_s"], "unit": "minibatch-rows/s", "dtype": "f32",
-            "value_is": "SVI steps of fit() on the default route, sampler='host' (the reference's random stream); `roofline` "
-                        "is the same route's device calls; both routes in full under `samplers` (every time the better of the route's "
-                        "sessions: the session that comes first after the previous configuration's buffers were freed runs slower, "
-                        "whichever route it is)",
-            "samplers": {"host_reference_random_stream": out["host"], "device": out["device"]},
-            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "gemm_flops_per_step": gemm_flops,
-                         "sampler": "host", "achieved": dflt["gemm_tflops_over_device_calls"],
-                         "frac": dflt["gemm_frac_over_device_calls"], "frac_over_fit_step": dflt["fit_gemm_frac"],
-                         "note": "the step's three (K L) x M x F GEMMs over the wall-clock of ALL device calls of a step "
-                                 "(features, likelihood kernel, contraction, launch gaps included); per-kernel times in "
-                                 "profiles/"},
+    return {"workload": "GLM Poisson, RandomRBF F=2048 D=32 ARD, N=2M resident, K=10 L=50, minibatch 65536: SVI step of fit()",
+            "rows_per_step": M, "ms": dflt["fit_step_ms"], "value": M / (dflt["fit_step_ms"] * 1e-3), "unit": "minibatch-rows/s",
+            "dtype": "f32", "samplers": {"host": out["host"], "device": out.get("device")},
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": dflt["device_calls_frac"],
+                         "frac_over_fit_step": dflt["fit_step_frac"], "_gemm_flops_per_step": gemm_flops,
+                         "_what": "the step's three (K L) x M x F GEMMs over the wall-clock of ALL device calls of a step, default "
+                                  "route (sampler='host', the reference's random stream), median of its sessions"},
             "cpu_baseline": cpu}
 
 
@@ -623,9 +658,28 @@ def _median_ms(fn, reps=3):
     return float(np.median(ts)), r
 
 
-def _elbo_parity(make_basis, X, y, var, reg, ls, rows=256):
-    """One `_elbo` of the product on the first `rows` rows (resident route, device posterior) against the oracle's
-    slm_elbo on the same rows in float64: (rel. error of -ELBO, normwise error of [dvar, dreg, dhyp])."""
+def _oracle_features(basis, X64, hyp):
+    """(Phi, [dPhi slabs], reg slices helper) of a random Fourier basis or of `that + LinearBasis` through the oracle."""
+    orc = _oracle()
+    bases = getattr(basis, "bases", [basis])
+    ls = np.asarray(hyp[0] if isinstance(hyp, list) else hyp, dtype=float)
+    Phi_r = orc.rff_transform(X64, bases[0].W, ls)
+    dP = orc.rff_grad(X64, bases[0].W, ls)
+    blocks = [Phi_r] + [orc.linear_transform(X64, True) for _ in bases[1:]]
+    Phi = np.hstack(blocks)
+    slabs = []
+    for i in range(dP.shape[2]):
+        full_ = np.zeros_like(Phi)
+        full_[:, :Phi_r.shape[1]] = dP[:, :, i]
+        slabs.append(full_)
+    ends = np.cumsum([0] + [b.shape[1] for b in blocks])
+    return Phi, slabs, [slice(int(ends[i]), int(ends[i + 1])) for i in range(len(blocks))]
+
+
+def _elbo_parity(make_basis, X, y, var, reg, hyp, rows=256):
+    """One `_elbo` of the product on the first `rows` rows (resident route, device posterior, ONE process) against the
+    oracle's slm_elbo on the same rows in float64: (rel. error of -ELBO, normwise error of [dvar, dreg, dhyp])."""
+    from revrand_amd import parallel
     from revrand_amd.slm import StandardLinearModel
     orc = _oracle()
     Xs, ys = np.ascontiguousarray(X[:rows]), np.ascontiguousarray(y[:rows])
@@ -633,14 +687,13 @@ def _elbo_parity(make_basis, X, y, var, reg, ls, rows=256):
     slm = StandardLinearModel(basis)
     slm.obj_ = -np.inf
     slm._state = basis.device_fit_state(Xs, ys)
-    f, (gv, gr, gh) = slm._elbo(Xs, ys, var, reg, ls)
+    f, (gv, gr, gh) = slm._elbo(Xs, ys, var, reg, hyp)
     slm._state.release()
     slm._state = None
-    X64, y64 = Xs.astype(np.float64), ys.astype(np.float64)
-    W = basis.W
-    Phi = orc.rff_transform(X64, W, ls)
-    dP = orc.rff_grad(X64, W, ls)
-    ref = orc.slm_elbo(Phi, y64, var, np.full(Phi.shape[1], reg), slice(None), [dP[:, :, i] for i in range(dP.shape[2])])
+    Phi, slabs, slices = _oracle_features(basis, Xs.astype(np.float64), hyp)
+    regs = np.atleast_1d(np.asarray(reg, dtype=float))
+    diag = np.concatenate([np.full(s.stop - s.start, regs[min(i, len(regs) - 1)]) for i, s in enumerate(slices)])
+    ref = orc.slm_elbo(Phi, ys.astype(np.float64), var, diag, slices if len(slices) > 1 else slices[0], slabs)
     got = np.concatenate(([gv], np.atleast_1d(gr), np.atleast_1d(gh)))
     want = np.concatenate(([-ref["dvar"]], [-g for g in ref["dreg"]], [-g for g in ref["dhyp"]]))
     return abs(f + ref["elbo"]) / abs(ref["elbo"]), float(np.linalg.norm(got - want) / np.linalg.norm(want))
@@ -685,27 +738,23 @@ def config_elbo(dev, _hip, args, dtype="f32", N=1_000_000):
     fl_pass2 = 2.0 * F * F + 2.0 * d * n + 2.0 * d * n  # U = Phi C, the features again, the (d, n) contraction X^T A
     fl_post = F ** 3 / 3.0 + F ** 3                   # Cholesky + inverse from the factor (f64 MFMA)
     fl_row = fl_stats + fl_pass2
-    stage_sum = t_stats + t_post + t_pass2
-    perr = _elbo_parity(make_basis, X, y, var, reg, ls) if not args.no_parity_check else (None, None)
-    return {"workload": "StandardLinearModel._elbo, RandomRBF nbases=2048 (F=4096), D=32 ARD, N=%d resident, %s arithmetic: "
-                        "statistics pass + posterior on the device + second pass" % (N, dtype), "rows": N, "dtype": dtype,
-            "ms": {"statistics_pass": t_stats, "posterior": t_post, "second_pass": t_pass2, "stage_sum": stage_sum,
-                   "elbo_wall": t_eval, "statistics_kernels": {"features": kt[0], "syrk": kt[1], "syrk_diag": kt[2]}},
-            "value": N / (t_eval * 1e-3), "unit": "rows/s through one full _elbo evaluation",
-            "neg_elbo": float(res[0]),
-            "flops": {"per_row_statistics": fl_stats, "per_row_second_pass": fl_pass2, "per_row": fl_row,
-                      "posterior": fl_post, "formula": "F(F+1) + 2dn + 2F  |  2F^2 + 2dn + 2dn  |  F^3/3 + F^3"},
-            "roofline": {"bound": "mfma", "peak": peak, "unit": "TFLOP/s",
-                         "statistics_pass_frac": fl_stats * N / (t_stats * 1e-3) / 1e12 / peak,
+    perr = (None, None)
+    if not args.no_parity_check:
+        perr = _elbo_parity(make_basis, X, y, var, reg, ls)
+        tol = (1e-4, 2e-3) if dtype == "f32" else (1e-10, 1e-9)
+        parity("-ELBO of 256 rows vs oracle", perr[0], tol[0])
+        parity("gradient of 256 rows vs oracle (normwise)", perr[1], tol[1])
+    return {"workload": "StandardLinearModel._elbo, RandomRBF F=4096 D=32 ARD, N=%d resident, %s" % (N, dtype), "rows": N,
+            "dtype": dtype, "ms": t_eval, "value": N / (t_eval * 1e-3), "unit": "rows/s per _elbo",
+            "stage_ms": {"statistics": t_stats, "posterior": t_post, "second_pass": t_pass2},
+            "_statistics_kernels_ms": {"features": kt[0], "syrk": kt[1], "syrk_diag": kt[2]}, "_neg_elbo": float(res[0]),
+            "_flops": {"per_row_statistics": fl_stats, "per_row_second_pass": fl_pass2, "per_row": fl_row, "posterior": fl_post},
+            "parity": {"neg_elbo_256_rows": perr[0], "gradient_256_rows": perr[1]},
+            "roofline": {"bound": "mfma", "peak": peak, "frac": (fl_row * N) / (t_eval * 1e-3) / 1e12 / peak,
+                         "statistics_frac": fl_stats * N / (t_stats * 1e-3) / 1e12 / peak,
                          "second_pass_frac": fl_pass2 * N / (t_pass2 * 1e-3) / 1e12 / peak,
-                         "posterior_tflops": fl_post / (t_post * 1e-3) / 1e12,
-                         "posterior_frac_of_f64_mfma": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                         "achieved_over_stage_sum": (fl_row * N) / (stage_sum * 1e-3) / 1e12,
-                         "frac_over_stage_sum": (fl_row * N) / (stage_sum * 1e-3) / 1e12 / peak,
-                         "frac_over_wall": (fl_row * N) / (t_eval * 1e-3) / 1e12 / peak,
-                         "note": "row flops only in the two *_over_* fractions (the posterior's F^3 flops run on the f64 "
-                                 "pipe and are reported on their own)"},
-            "parity_256_rows_vs_oracle": {"neg_elbo_rel_err": perr[0], "gradient_normwise_err": perr[1]}}
+                         "posterior_frac_f64": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                         "_frac_over_stage_sum": (fl_row * N) / ((t_stats + t_post + t_pass2) * 1e-3) / 1e12 / peak}}
 
 
 def config_posterior(dev, _hip, args, F):
@@ -714,8 +763,10 @@ def config_posterior(dev, _hip, args, F):
     rs = np.random.RandomState(F)
     A = rs.standard_normal((3 * F, 16)) @ rs.standard_normal((16, F)) / 4.0
     P = np.concatenate((np.cos(A), np.sin(A)), axis=1)[:, :F] / np.sqrt(F / 2.0)
+    del A
     G = P.T @ P
     b = P.T @ rs.standard_normal(3 * F)
+    del P
     iL, var = np.full(F, 1.0), 0.5
     acc = dev.upload_vector(np.concatenate((G.ravel(), b)))
     dC = dev.malloc(F * F * 8)
@@ -728,21 +779,21 @@ def config_posterior(dev, _hip, args, F):
         orc = _oracle()
         mh, Ch, ldC = orc.slm_posterior_from_stats(G, b, var, np.full(F, 1.0))
         C = dev.download(dC, (F, F), np.float64)
-        perr = {"m": float(np.abs(m - mh).max() / np.abs(mh).max()), "C": float(np.abs(C - Ch).max() / np.abs(Ch).max()),
-                "logdet_abs": float(abs(logdet + ldC)), "trace_rel": float(abs(tr - (G * Ch).sum()) / abs((G * Ch).sum()))}
+        trh = float((G * Ch).sum())
+        perr = {"m": parity("m vs oracle solve_posdef", float(np.abs(m - mh).max() / np.abs(mh).max()), 1e-9),
+                "C": parity("C vs oracle solve_posdef", float(np.abs(C - Ch).max() / np.abs(Ch).max()), 1e-9),
+                "logdet_abs": parity("log|iC| vs oracle", float(abs(logdet + ldC)), 1e-8),
+                "trace": parity("sum(G o C) vs oracle", float(abs(tr - trh) / abs(trh)), 1e-9)}
+        del C, Ch
     acc.free()
     dC.free()
     fl = F ** 3 / 3.0 + F ** 3
-    return {"workload": "rr_posterior_dev, F=%d, float64: Cholesky + inverse + m, diag C, log|iC|, sum(G o C) in HBM" % F,
-            "ms": ms, "flops": fl, "dtype": "f64",
-            "roofline": {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "achieved": fl / (ms * 1e-3) / 1e12,
-                         "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
+    return {"workload": "rr_posterior_dev F=%d f64: Cholesky + inverse + m, diag C, log|iC|, sum(G o C) in HBM" % F,
+            "ms": ms, "dtype": "f64", "parity": perr,
+            "roofline": {"bound": "mfma", "peak": PEAK_F64_MFMA_TFLOPS, "frac": fl / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                          "frac_potrf_potri_count": float(F) ** 3 / (ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
-                         "note": "F^3/3 (factor) + F^3 (inverse, the count of rounds 2-3: substitution on the identity + a "
-                                 "dense Y^T Y) flops over the wall-clock of the whole call; since the round's last session the "
-                                 "k-loops of Y^T Y skip the zero blocks of the triangular Y, so the work actually issued is "
-                                 "nearer LAPACK's potrf + potri count F^3 -- `frac_potrf_potri_count` prices the call with that"},
-            "parity_vs_oracle_solve_posdef": perr}
+                         "_flops": fl, "_what": "F^3/3 + F^3 (rounds 2-3's count) over the wall-clock of the whole call; "
+                                                "frac_potrf_potri_count prices it with LAPACK's potrf + potri count F^3"}}
 
 
 def config_predict(dev, _hip, args, N=300_000):
@@ -764,29 +815,220 @@ def config_predict(dev, _hip, args, N=300_000):
         orc = _oracle()
         Phi = orc.rff_transform(X[:512].astype(np.float64), basis.W, slm.hypers_)
         Er, Vr = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
-        perr = {"Ey": float(np.abs(Ey[:512] - Er).max() / np.abs(Er).max()), "Vy": float(np.abs(Vy[:512] - Vr).max() / np.abs(Vr).max())}
+        perr = {"Ey": parity("Ey of 512 rows vs oracle", float(np.abs(Ey[:512] - Er).max() / np.abs(Er).max()), 1e-3),
+                "Vy": parity("Vy of 512 rows vs oracle", float(np.abs(Vy[:512] - Vr).max() / np.abs(Vr).max()), 1e-3)}
     slm._drop_serving()
     fl = 2.0 * d * n + F * F + 2.0 * F  # features, phi^T B with the triangular factor (half of 2 F^2), phi . m
-    return {"workload": "StandardLinearModel.predict_moments, RandomRBF F=4096, D=32, N=%d host rows (upload, features, "
-                        "variance GEMM on the triangular factor, download)" % N, "rows": N, "dtype": "f32",
-            "ms": ms, "ms_predict_mean_only": ms_mean, "value": N / (ms * 1e-3), "unit": "rows/s",
-            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "flops_per_row": fl,
-                         "achieved": fl * N / (ms * 1e-3) / 1e12, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                         "note": "wall-clock of the call, PCIe upload of X and download of (Ey, Vy) included"},
-            "parity_512_rows_vs_oracle": perr}
+    return {"workload": "predict_moments, RandomRBF F=4096 D=32, N=%d HOST rows in, (Ey, Vy) out (PCIe inside)" % N,
+            "rows": N, "dtype": "f32", "ms": ms, "ms_predict_mean_only": ms_mean, "value": N / (ms * 1e-3), "unit": "rows/s",
+            "parity": perr,
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "_flops_per_row": fl}}
 
+
+# ----------------------------------------------------------------------------------------------------
+# N > 1: BASELINE config 3 and the C2-shape `_elbo` with the rows sharded over the ranks (slm.py:142-199 over all shards)
+# ----------------------------------------------------------------------------------------------------
+
+def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var=0.5, reps=2):
+    """One distributed `_elbo` evaluation, every stage on the ranks' clocks (barrier before, MAX over ranks after):
+      statistics   this rank's features + Gram kernels (no exchange)
+      exchange     pack the upper triangle, ONE ncclAllReduce of [tri G | b | y^T y | N], unpack + mirror  (HIP events)
+      posterior    replicated rr_posterior_dev of the summed statistics
+      second_pass  this rank's rows again (Err, U = Phi C in registers, X^T A) + the all-reduce of [sqErr | dhyp]
+      ms           StandardLinearModel(distributed=True)._elbo as the optimiser calls it
+    `gen(rows, stream)` makes chunk `stream` of the data set (250 000-row chunks, so the data do not depend on the world
+    size); every rank takes its contiguous shard."""
+    from revrand_amd import parallel
+    from revrand_amd.slm import StandardLinearModel
+    rank, world = comm.rank, comm.world
+    CH = 250_000
+    r0, r1 = parallel.shard_bounds(N, rank, world)
+    Xs, ys = [], []
+    for c in range(r0 // CH, (r1 + CH - 1) // CH if r1 > r0 else 0):
+        Xc, yc = gen(min(CH, N - c * CH), c)
+        lo, hi = max(r0, c * CH) - c * CH, min(r1, (c + 1) * CH) - c * CH
+        Xs.append(Xc[lo:hi])
+        ys.append(yc[lo:hi])
+    X, y = np.ascontiguousarray(np.concatenate(Xs)), np.ascontiguousarray(np.concatenate(ys))
+    del Xs, ys
+    rows = r1 - r0
+    basis = make_basis()
+    slm = StandardLinearModel(basis, distributed=True)
+    slm.obj_ = -np.inf
+    slm._defer_cov = True
+    st = slm._state = slm._make_state(X, y)
+    F = st.F
+    regs = reg if isinstance(reg, list) else [reg]
+    L, _ = basis.regularizer_diagonal(X, *regs)
+    iL = 1.0 / L
+
+    def rank_max(ms):
+        return float(comm.allreduce_host(np.array([ms]), op="max")[0])
+
+    def stage(fn, reps_=reps):
+        ts, out = [], None
+        for _ in range(reps_):
+            dev.sync()
+            comm.barrier()
+            t0 = time.perf_counter()
+            out = fn()
+            dev.sync()
+            ts.append(rank_max(1e3 * (time.perf_counter() - t0)))
+        return float(np.median(ts)), out
+
+    f0, _ = slm._elbo(X, y, var, reg, hyp)  # warm: scratch, posterior work space, RCCL channels
+    t_stats, _ = stage(lambda: st.gram_device(hyp))
+    # the exchange alone, on the context's stream between HIP events (the statistics are re-made afterwards)
+    pG, pb, pt = st._stat_ptrs()
+    xs = []
+    for _ in range(reps):
+        dev.sync()
+        comm.barrier()
+        dev.timer_start()
+        comm.reduce_stats_device(F, pG, pb, pt, rows, wait=False)
+        xs.append(rank_max(dev.timer_stop()))
+    t_x = float(np.median(xs))
+    st.gram_device(hyp, comm.reduce_stats_device)
+    N_tot = st.N_total
+    # size-independent properties of the summed statistics: every rank holds all N rows' worth; trace of the Fourier
+    # block == N (cos^2 + sin^2 = 1 per frequency)
+    G, _, _ = st.stats_host()
+    tr = abs(float(np.trace(G[:2 * n_rff, :2 * n_rff])) - N) / N
+    sym = bool(np.array_equal(G, G.T))
+    del G
+    t_post, post = stage(lambda: st.posterior(iL, var))
+    assert post is not None, "posterior not positive definite"
+    m = post[0]
+
+    def pass2():
+        sq, dh = st.second_pass(hyp, m, st.dC, var)
+        parts = dh if isinstance(dh, list) else [dh]
+        return comm.allreduce_host(np.concatenate([[sq]] + [np.atleast_1d(p) for p in parts]))
+    t_p2, _ = stage(pass2)
+    t_eval, res = stage(lambda: slm._elbo(X, y, var, reg, hyp))
+    # every rank walked to the same numbers (rank 0's are broadcast unless the reductions are deterministic)
+    flat = np.concatenate([[res[0]], np.atleast_1d(res[1][0]), np.ravel(np.atleast_1d(res[1][1])),
+                           np.ravel(np.concatenate([np.atleast_1d(h) for h in (res[1][2] if isinstance(res[1][2], list) else [res[1][2]])]))])
+    same = bool(np.array_equal(comm.allreduce_host(flat, op="max"), comm.allreduce_host(flat, op="min")))
+    st.release()
+    slm._state = None
+    perr = (None, None)
+    if rank == 0 and not args.no_parity_check:  # the same evaluation in ONE process on 256 rows against the oracle
+        prev = parallel.get_comm()
+        parallel.set_comm(parallel.SingleComm())
+        try:
+            perr = _elbo_parity(make_basis, X, y, var, reg, hyp)
+        finally:
+            parallel.set_comm(prev)
+    d_ = d
+    fl_stats = 2.0 * d_ * n_rff + F * (F + 1.0) + 2.0 * F
+    fl_p2 = 2.0 * F * F + 4.0 * d_ * n_rff
+    peak = world * PEAK_F32_MFMA_TFLOPS
+    out = {"rows": N, "rows_per_gpu": rows, "F": F, "dtype": "f32", "ms": t_eval, "value": N / (t_eval * 1e-3),
+           "unit": "rows/s per _elbo",
+           "stage_ms": {"statistics": t_stats, "exchange": t_x, "posterior": t_post, "second_pass": t_p2},
+           "exchange_bytes": 8 * parallel.stats_count(F),
+           "exchange_GBps_busbw": 2.0 * (world - 1) / world * 8 * parallel.stats_count(F) / (t_x * 1e-3) / 1e9 if t_x > 0 else None,
+           "parity": {"trace_fourier_block": tr, "G_symmetric": sym, "N_total": N_tot, "ranks_identical": same,
+                      "neg_elbo_256_rows": perr[0], "gradient_256_rows": perr[1]},
+           "roofline": {"bound": "mfma", "peak": peak, "frac": (fl_stats + fl_p2) * N / (t_eval * 1e-3) / 1e12 / peak,
+                        "statistics_frac": fl_stats * N / (t_stats * 1e-3) / 1e12 / peak,
+                        "second_pass_frac": fl_p2 * N / (t_p2 * 1e-3) / 1e12 / peak,
+                        "posterior_frac_f64_one_gpu": (F ** 3 / 3.0 + F ** 3) / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS},
+           # one GPU = every shard's row passes back to back + one posterior; N GPUs = the largest shard + the exchanges +
+           # the (replicated, serial) posterior
+           "speedup_model": {"one_gpu_ms": world * (t_stats + t_p2) + t_post, "n_gpu_ms": t_stats + t_x + t_post + t_p2,
+                             "speedup": (world * (t_stats + t_p2) + t_post) / (t_stats + t_x + t_post + t_p2)},
+           "_neg_elbo": float(res[0])}
+    if rank == 0:
+        parity("trace of the Fourier block / N - 1", tr, 1e-5)
+        assert sym and N_tot == N and same, (sym, N_tot, same)
+        if perr[0] is not None:
+            parity("-ELBO of 256 rows vs oracle", perr[0], 1e-4)
+            parity("gradient of 256 rows vs oracle (normwise)", perr[1], 2e-3)
+    return out
+
+
+def dist_configs(dev, _hip, comm, args, emit=None):
+    """BASELINE config 3 (RandomMatern52 + LinearBasis, F_tot = 8257, D = 64, N = 10M, "8 GPUs N-sharded with RCCL Gram
+    all-reduce") and the headline shape's `_elbo` (RandomRBF F = 4096, D = 32, N = 10M), rows sharded over the ranks."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    res = {}
+    want = args.configs.lower().split(",")
+
+    def rbf_gen(rows, c):
+        return gen_chunk(c, rows, 32, np.random.RandomState(1).randn(32).astype(np.float32))
+
+    jobs = (("C3_matern52_linear_dist", lambda: dist_elbo(
+                dev, _hip, comm, args, lambda: _c3_basis(64, 4096), lambda rows, c: _c3_data(rows, 64, c),
+                args.dist_rows, 64, 4096, [np.ones(64)], [1.0, 1.0])),
+            ("elbo_rbf_f4096_dist", lambda: dist_elbo(
+                dev, _hip, comm, args, lambda: bs.RandomRBF(nbases=2048, Xdim=32, random_state=42,
+                                                            lenscale=Parameter(np.ones(32), Positive())),
+                rbf_gen, args.dist_rows, 32, 2048, np.linspace(0.8, 1.3, 32), 1.0)))
+    for name, fn in jobs:
+        if args.configs != "all" and name.split("_")[0].lower() not in want and name.lower() not in want:
+            continue
+        t0 = time.perf_counter()
+        sys.stderr.write("bench.py: [rank %d] config %s ...\n" % (comm.rank, name))
+        sys.stderr.flush()
+        # A rank that fails inside a stage leaves its peers waiting in the next collective: every rank arms a watchdog
+        # that, after --config-timeout, writes the line with what is finished (rank 0) and ends the process.
+        dog = _watchdog(args, name, res, emit)
+        try:
+            out, err, fatal = fn(), None, 0.0
+        except ParityError as e:  # raised after the configuration's last collective: the ranks are still in step
+            out, err, fatal = None, str(e), 0.0
+        except Exception as e:
+            out, err, fatal = None, "%s: %s" % (type(e).__name__, e), 1.0
+            sys.stderr.write("bench.py: [rank %d] config %s failed: %r\n" % (comm.rank, name, e))
+        try:
+            fatal = float(comm.allreduce_host(np.array([fatal]), op="max")[0])
+        finally:
+            dog.cancel()
+        res[name] = out if err is None else {"error": err}
+        if out is not None:
+            out["_bench_seconds"] = time.perf_counter() - t0
+        sys.stderr.write("bench.py: [rank %d] config %s done in %.1f s\n" % (comm.rank, name, time.perf_counter() - t0))
+        if fatal:
+            break
+    return res
+
+
+def _watchdog(args, name, res, emit):
+    """A configuration that hangs (a HIP call, a collective or a BLAS call that never returns cannot be interrupted from
+    Python) says where and does not take the headline with it: after --config-timeout seconds every thread's stack goes to
+    stderr, the bench line is written with the configurations finished so far -- this one marked as timed out -- and
+    the process ends."""
+    import threading
+
+    def on_timeout():
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        res[name] = {"error": "timed out after %.0f s (stacks on stderr); the remaining configurations were not run"
+                              % args.config_timeout}
+        sys.stderr.write("bench.py: config %s timed out\n" % name)
+        sys.stderr.flush()
+        if emit is not None:
+            emit(res)
+        os._exit(0 if emit is not None else 1)
+    dog = threading.Timer(args.config_timeout, on_timeout)
+    dog.daemon = True
+    dog.start()
+    return dog
 
 
 def extra_configs(dev, _hip, args, emit=None):
-    """`emit(configs)`: writes the bench line with the configurations finished so far -- called by the watchdog below when
+    """`emit(configs)`: writes the bench line with the configurations finished so far -- called by the watchdog when
     one of them hangs, so that the headline measurement is never lost to a side configuration."""
-    import threading
     res = {}
     for name, fn in (("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
                      ("C2laplace_f64phase_n1m", config_laplace), ("C2_elbo_eval", config_elbo),
                      ("C2f64_elbo_eval_n200k", lambda d_, h_, a_: config_elbo(d_, h_, a_, dtype="f64", N=200_000)),
                      ("posterior_F4096", lambda d_, h_, a_: config_posterior(d_, h_, a_, 4096)),
                      ("posterior_F8257", lambda d_, h_, a_: config_posterior(d_, h_, a_, 8257)),
+                     ("posterior_F16384", lambda d_, h_, a_: config_posterior(d_, h_, a_, 16384)),
                      ("predict_moments_n300k", config_predict),
                      ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
                      ("C5_glm_poisson_svi_step", config_c5)):
@@ -796,29 +1038,14 @@ def extra_configs(dev, _hip, args, emit=None):
         t0 = time.perf_counter()
         sys.stderr.write("bench.py: config %s ...\n" % name)
         sys.stderr.flush()
-        # a configuration that hangs (a HIP call or a BLAS call that never returns cannot be interrupted from Python) says
-        # where and does not take the headline with it: after --config-timeout seconds a watchdog thread dumps every
-        # thread's stack to stderr, writes the bench line with the configurations finished so far -- this one marked as
-        # timed out -- and ends the process
-        def on_timeout(name=name):
-            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
-            res[name] = {"error": "timed out after %.0f s (stacks on stderr); the remaining configurations were not run"
-                                  % args.config_timeout}
-            sys.stderr.write("bench.py: config %s timed out\n" % name)
-            sys.stderr.flush()
-            if emit is not None:
-                emit(res)
-            os._exit(0 if emit is not None else 1)
-        dog = threading.Timer(args.config_timeout, on_timeout)
-        dog.daemon = True
-        dog.start()
+        dog = _watchdog(args, name, res, emit)
         try:
             if os.environ.get("RR_BENCH_TEST_HANG", "").lower() == name.lower():  # tests/test_gpu_comm.py: the watchdog's own test
                 time.sleep(1e6)
             res[name] = fn(dev, _hip, args)
-            res[name]["bench_seconds"] = time.perf_counter() - t0
+            res[name]["_bench_seconds"] = time.perf_counter() - t0
         except Exception as e:  # a failing side configuration must not take the headline line with it -- but it is said
-            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e) if not isinstance(e, ParityError) else str(e)}
             sys.stderr.write("bench.py: config %s failed: %r\n" % (name, e))
         finally:
             dog.cancel()
@@ -847,7 +1074,13 @@ def main():
     ap.add_argument("--config-timeout", type=float, default=900.0,
                     help="seconds one side configuration may take before every thread's stack is dumped and bench.py exits")
     ap.add_argument("--configs", default="all",
-                    help="BASELINE's other configurations to time after the headline at N=1: all | none | e.g. c3,c5,headline")
+                    help="BASELINE's other configurations to time after the headline: all | none | e.g. c3,c5,headline (N=1); "
+                         "c3,elbo (N>1: the row-sharded _elbo evaluations)")
+    ap.add_argument("--dist-rows", type=int, default=10_000_000,
+                    help="global N of the N>1 configurations (BASELINE config 3: 10M; rehearsals on one GPU pass fewer)")
+    ap.add_argument("--full-json", default=os.environ.get("RR_BENCH_FULL_JSON"),
+                    help="where rank 0 writes the unabridged record (default: gpurun_out/bench_full_n<N>.json when that "
+                         "directory exists)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -998,24 +1231,23 @@ def main():
         dev.sync()
         alt_elapsed = (time.perf_counter() - ta) / nalt
         G3 = dev.download(acc_buf, (F, F), np.float64)
-        alt = {"engine": "fp16x3", "value": args.rows / alt_elapsed, "unit": "feature-rows/s",
-               "ms_per_step": 1e3 * alt_elapsed, "steps": nalt,
-               "max_abs_diff_vs_f32_engine_over_max_G": float(np.abs(G3 - G).max() / np.abs(G).max()),
-               "kernel": "rr_syrk_b16w4_kernel<3, false, true>",
-               "kernel_ms_per_step": float(np.mean([k[1] + k[2] for k in alt_ms])),
-               "features_ms_per_step": float(np.mean([k[0] for k in alt_ms])),
-               "trace_rel_err": abs(float(np.trace(G3)) - args.rows) / args.rows,
-               "note": "features scaled into [-1, 1] and split into fp16 hi + lo (22 mantissa bits), 3 products on the "
-                       "fp16 matrix pipe, f32 accumulation: same error against the float64 oracle as the f32 MFMA engine "
-                       "(tests/test_gpu_gram_engines.py); opt-in (Device.set_gram_engine / RR_SYRK_ENGINE), DESIGN.md 3.13"}
+        kms_alt = float(np.mean([k[1] + k[2] for k in alt_ms]))
+        nbk = len(range(0, F, 256))
         # 136 full 256x256 tiles x 3 products are issued for F (F + 1) algorithmic flops per row
-        alt["mfma_issued_tflops"] = 3.0 * 2.0 * 256 * 256 * (len(range(0, F, 256)) * (len(range(0, F, 256)) + 1) // 2) \
-            * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
-        alt["mfma_issued_frac_of_fp16_peak"] = alt["mfma_issued_tflops"] / PEAK_BF16_MFMA_TFLOPS
-        alt["algorithmic_tflops"] = F * (F + 1.0) * my_rows / (alt["kernel_ms_per_step"] * 1e-3) / 1e12
+        issued = 3.0 * 2.0 * 256 * 256 * (nbk * (nbk + 1) // 2) * my_rows / (kms_alt * 1e-3) / 1e12
+        alt = {"engine": "fp16x3", "value": args.rows / alt_elapsed, "ms_per_step": 1e3 * alt_elapsed, "steps": nalt,
+               "max_diff_vs_f32_engine": float(np.abs(G3 - G).max() / np.abs(G).max()),
+               "trace_rel_err": abs(float(np.trace(G3)) - args.rows) / args.rows,
+               "kernel_ms_per_step": kms_alt, "mfma_issued_frac_of_fp16_peak": issued / PEAK_BF16_MFMA_TFLOPS,
+               "algorithmic_tflops": F * (F + 1.0) * my_rows / (kms_alt * 1e-3) / 1e12,
+               "_kernel": "rr_syrk_b16w4_kernel<3, false, true>", "_mfma_issued_tflops": issued,
+               "_features_ms_per_step": float(np.mean([k[0] for k in alt_ms])),
+               "_what": "opt-in engine (Device.set_gram_engine / RR_SYRK_ENGINE), DESIGN.md 3.13: features scaled into [-1, 1] "
+                        "and split into fp16 hi + lo, 3 products on the fp16 matrix pipe, f32 accumulation"}
         dev.set_gram_engine("f32")
     del G
 
+    out = None
     if rank == 0:
         ms_per_step = 1e3 * elapsed / max(args.steps, 1)
         value = args.rows / (elapsed / max(args.steps, 1))
@@ -1033,6 +1265,7 @@ def main():
         assert off_flops + diag_flops == F * (F + 1.0)
         achieved = off_flops * my_rows / (syrk_ms * 1e-3) / 1e12 if kernel_ms else float("nan")
         gram_tf = (off_flops + diag_flops) * my_rows / ((syrk_ms + diag_ms) * 1e-3) / 1e12 if kernel_ms else float("nan")
+        rt = runtime_info(_hip, parallel)
         out = {
             "metric": "feature-rows/sec (Phi + PhiT Phi + PhiT y) at N=%s D=%d F=%d" % (
                 "10M" if args.rows == 10_000_000 else args.rows, d, F),
@@ -1041,16 +1274,18 @@ def main():
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, features + MFMA Gram, rows sharded "
                                    "over %d GPU(s)" % (n, F, d, args.rows, world),
-                       "rows_per_gpu": my_rows, "device": dev.name, "trace_rel_err": trace_err,
+                       "rows_per_gpu": my_rows, "device": dev.name.strip(), "trace_rel_err": trace_err,
                        "gram_engine": engine, "parity_rel_err_2048_rows_vs_oracle": parity_err,
-                       "runtime": runtime_info(_hip, parallel)},
+                       "runtime": {"hip_runtime": os.path.basename(rt["hip_runtime"] or ""),
+                                   "rccl": rt["rccl"].get("version", rt["rccl"].get("error"))},
+                       "_runtime": rt},
             "roofline": {"bound": "mfma", "kernel": "rr_syrk_f32_kernel", "achieved": achieved,
                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                          # bytes per launch: the profiled launch's bytes/row x this run's rows per launch
                          "traffic": (TRAFFIC["hbm_bytes"] / TRAFFIC["rows_per_launch"] * my_rows / max(launches, 1)
                                      if TRAFFIC else None),
-                         "traffic_note": TRAFFIC.get("note"),
+                         "_traffic_note": TRAFFIC.get("note"),
                          "kernel_ms_per_step": syrk_ms, "launches_per_step": launches,
                          "avg_launch_ms": syrk_ms / max(launches, 1),
                          "flops_per_row": off_flops, "rows_per_step": my_rows,
@@ -1062,11 +1297,13 @@ def main():
         }
         if use_comm:
             cnt = parallel.stats_count(F)
-            out["exchange"] = {"transport": "RCCL ncclAllReduce(ncclDouble, ncclSum), bound directly (librevrand_hip rr_comm_*)",
+            xm = float(np.mean(exch_ms)) if exch_ms else None
+            out["exchange"] = {"transport": "RCCL ncclAllReduce(f64, sum), bound directly (rr_comm_*)",
                                "rccl": dict(zip(("version", "library"), parallel.RcclComm.load())),
                                "ranks_rccl_reports": world, "message_float64": cnt, "message_bytes": 8 * cnt,
-                               "ms_per_step_pack_allreduce_unpack": float(np.mean(exch_ms)) if exch_ms else None,
+                               "ms_per_step_pack_allreduce_unpack": xm,
                                "ms_per_step_pack_allreduce_unpack_max_min_over_ranks": [float(x_max), float(x_min)],
+                               "busbw_GBps": 2.0 * (world - 1) / world * 8 * cnt / (float(x_max) * 1e-3) / 1e9 if x_max > 0 else None,
                                "visible_gpus": int(os.environ.get("RR_BENCH_VISIBLE_GPUS", "0")) or None,
                                "oversubscribed": bool(os.environ.get("NCCL_HOSTID", "").startswith("rr-bench-rank-"))}
         if world > 1:
@@ -1078,8 +1315,8 @@ def main():
                                "expected_speedup_model": {"ms_per_step": model_ms,
                                                           "speedup_vs_one_gpu": k_sum / model_ms if model_ms > 0 else None,
                                                           "measured_ms_per_step": ms_per_step,
-                                                          "note": "max over ranks of (features + SYRK kernels) + exchange; "
-                                                                  "one GPU = the same kernels of all shards back to back"}}
+                                                          "_what": "max over ranks of (features + SYRK kernels) + exchange; "
+                                                                   "one GPU = the same kernels of all shards back to back"}}
         if engine != "f32":
             # split-bf16 engine: one SYRK kernel over all 136 tiles; the roofline is the bf16 matrix pipe, `achieved`
             # stays ALGORITHMIC flops (the kernel issues 3 or 4 bf16 products per f32 product: `issued_frac`)
@@ -1103,19 +1340,40 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(d, n, W, wvec, args.cpu_sample)
     ok = trace_err < (1e-6 if engine == "f32" else 1e-5) or os.environ.get("RR_GRAM_ABLATE")
-    if rank == 0 and world == 1 and not use_comm and args.configs != "none" and engine == "f32" and ok:
+
+    def emit(configs=None):
+        """Rank 0: THE line (numbers, < 8 KB) on stdout; the unabridged record to --full-json."""
+        if rank != 0:
+            return
+        if configs is not None:
+            out["configs"] = configs
+        line = json.dumps(lean(out), separators=(",", ":"))
+        if len(line) > 8000:
+            sys.stderr.write("bench.py: WARNING: the JSON line has %d bytes (driver keeps a 9 KB tail)\n" % len(line))
+        json_out.write(line + "\n")
+        json_out.flush()
+        path = args.full_json
+        if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            path = os.path.join(ROOT, "gpurun_out", "bench_full_n%d.json" % world)
+        if path:
+            try:
+                with open(path, "w") as f:
+                    json.dump(full(out), f, indent=1)
+            except OSError as e:
+                sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
+
+    side = args.configs != "none" and engine == "f32" and ok and not os.environ.get("RR_GRAM_ABLATE")
+    if side and (world > 1 or rank == 0):
         # free the headline's buffers first: C3 / C4 want tens of GB
         for b in (dX, dy, acc_buf):
             b.free()
         del basis
-        def emit(configs):
-            out["configs"] = configs
-            json_out.write(json.dumps(out) + "\n")
-            json_out.flush()
+    if side and world == 1 and not use_comm:
         emit(extra_configs(dev, _hip, args, emit))
-    elif rank == 0:
-        json_out.write(json.dumps(out) + "\n")
-        json_out.flush()
+    elif side and world > 1:
+        emit(dist_configs(dev, _hip, comm, args, emit))
+    else:
+        emit()
     comm.barrier()
     comm.close()
     assert ok, trace_err

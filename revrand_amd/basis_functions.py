@@ -748,6 +748,11 @@ class CatFitState(_DevicePosterior):
         if chunk_rows is None:  # P, its transpose and U = P C: 3 Fp elements per row, within ~24 GiB
             chunk_rows = (24 << 30) // (3 * es * Fp)
         self.chunk = int(max(256, min(self.N, chunk_rows)))
+        if self.N > self.chunk:
+            # several chunks: equal ones (config 3's 1.25M-row shard: 5 x 250 000 instead of 4 x 254 200 + 233 200), like the
+            # single-basis passes (rr_rff.hip gram_run, rr_elbo.hip pass2_run)
+            nchunks = -(-self.N // self.chunk)
+            self.chunk = -(-self.N // nchunks)
         self.fm = (_hip.FeatureMatrix64 if dtype == "f64" else _hip.FeatureMatrix)(self.chunk, self.F)
         self._filled = None
         self._stats_init(self.dev, self.F)

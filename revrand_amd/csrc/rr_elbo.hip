@@ -694,6 +694,13 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
     int64_t chunk = (int64_t)(((size_t)24 << 30) / ((size_t)12 * Fp));
     const char *cenv = getenv("RR_PASS2_CHUNK_ROWS");
     if (cenv && atoll(cenv) >= 256) chunk = atoll(cenv);
+    else if (N > chunk) {
+        // several chunks: equal ones, like the Gram pass' (N = 1M at F = 4096: 2 x 500 000 instead of 524 288 + 475 712).
+        // Besides the balance, a 2^19-row chunk makes the leading dimension of Pt exactly 2 MiB: the K rows of one operand
+        // tile then sit a power of two apart and alias in the L2
+        const int64_t nchunks = (N + chunk - 1) / chunk;
+        chunk = (N + nchunks - 1) / nchunks;
+    }
     if (chunk > N) chunk = N;
     chunk = (chunk + 255) / 256 * 256;
     if (!b->pass2) b->pass2 = new Pass2Scratch();
@@ -730,7 +737,8 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             return RR_ERR_OOM;
         }
     }
-    chunk = s.chunk;  // the allocated leading dimension of Pt
+    const int64_t step = chunk;  // rows per launch; a scratch kept from a larger call does not change the partition
+    chunk = s.chunk;             // the allocated leading dimension of Pt
     hipError_t e = hipSuccess;
     int rc = RR_OK;
     const char *nfz = getenv("RR_PASS2_NO_FUSE");
@@ -772,8 +780,8 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             rc = RR_ERR_HIP;
         }
     }
-    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
-        const int64_t mrows = (N - r0 < chunk) ? N - r0 : chunk;
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += step) {
+        const int64_t mrows = (N - r0 < step) ? N - r0 : step;
         const int64_t mpad = (mrows + 255) / 256 * 256;
         const TX *Xc = dX + r0 * ldx;
         bool fused_vf = false;
@@ -1602,6 +1610,10 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
     int64_t chunk = (int64_t)(((size_t)24 << 30) / ((size_t)24 * Fp));  // P, Pt, U in f64
     const char *cenv = getenv("RR_PASS2_CHUNK_ROWS");
     if (cenv && atoll(cenv) >= 128) chunk = atoll(cenv);
+    else if (N > chunk) {  // equal chunks (see the f32 driver)
+        const int64_t nchunks = (N + chunk - 1) / chunk;
+        chunk = (N + nchunks - 1) / nchunks;
+    }
     if (chunk > N) chunk = N;
     chunk = (chunk + 127) / 128 * 128;
     if (!b->pass2d) b->pass2d = new Pass2Scratch64();
@@ -1629,6 +1641,7 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
         s.Fp = Fp;
         s.nacc = nacc;
     }
+    const int64_t step = chunk;  // rows per launch (see the f32 driver)
     chunk = s.chunk;
     RR_CHECK_HIP(hipStreamSynchronize(c->stream));
     RR_CHECK_HIP(hipMemset(s.m, 0, (size_t)Fp * 8));
@@ -1649,8 +1662,8 @@ static int pass2_run64(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64
     const char *fz64 = getenv("RR_PASS2_FUSE_F64");
     const bool fuse_t64 = !pred && sizeof(TX) == 8 && !c->deterministic && !b->large && n % 128 == 0 && b->d <= 32 &&
                           fz64 && atoi(fz64) != 0;
-    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += chunk) {
-        const int64_t mrows = (N - r0 < chunk) ? N - r0 : chunk;
+    for (int64_t r0 = 0; r0 < N && rc == RR_OK; r0 += step) {
+        const int64_t mrows = (N - r0 < step) ? N - r0 : step;
         const int64_t mpad = (mrows + 127) / 128 * 128;
         const TX *Xc = dX + r0 * ldx;
         rc = rr_features_rowmajor_f64(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp);

@@ -91,7 +91,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                        nstarts=self.nstarts)
             if self._state is not None and getattr(self._state, "best_on_device", False):
                 self.covariance_ = self._state.best_covariance()
-            if self.distributed and not self._ranks_bit_identical():
+            if self.distributed and not self._ranks_bit_identical(getattr(self._state, "best_on_device", False)):
                 # posteriors agree to the last bits only (see `_same_on_all_ranks`): ship rank 0's
                 from . import parallel
                 comm = parallel.get_comm()
@@ -185,7 +185,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             sqErr = yty - m.dot(bvec) - var * ((m ** 2) * iL).sum()
             ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var
                            + ((m ** 2 + Cdiag) * iL).sum() - logdetC + np.log(L).sum() - D)
-            if self.distributed and not self._ranks_bit_identical():
+            if self.distributed and not self._ranks_bit_identical(post is not None):
                 ELBO = float(comm.broadcast_host(np.array([ELBO]), root=0)[0])  # see `_same_on_all_ranks`
             return -ELBO
         sqErr, dhypers = st.second_pass(hypers, m, Cpass, var)
@@ -205,7 +205,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             return -0.5 * (((m[s] ** 2 + Cdiag[s]) * iL[s] ** 2).sum() - iL[s].sum())
 
         dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
-        if self.distributed and not self._ranks_bit_identical():
+        if self.distributed and not self._ranks_bit_identical(post is not None):
             ELBO, dvar, dL, dhypers = self._same_on_all_ranks(comm, [ELBO, dvar, dL, dhypers])
         if ELBO > self.obj_:
             self.weights_ = m
@@ -220,12 +220,28 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
         return -ELBO, [-dvar, dL, dhypers]
 
-    def _ranks_bit_identical(self):
-        """In deterministic mode (Device.set_deterministic / RR_DETERMINISTIC=1) the posterior and every reduction are
-        summed in a fixed order: ranks holding the same all-reduced statistics compute the same bits, and the evaluation
-        needs its two exchanges only ([tri G | b | y^T y | N], then [sqErr | dhyp]) -- no broadcast of the results."""
-        dev = getattr(getattr(self, "_state", None), "dev", None)  # the fit state's device context, if it has one
-        return bool(dev is not None and getattr(dev, "deterministic", False))
+    def _ranks_bit_identical(self, posterior_on_device):
+        """In deterministic mode (Device.set_deterministic / RR_DETERMINISTIC=1) the posterior kernels and every device
+        reduction sum in a fixed order: ranks holding the same all-reduced statistics compute the same bits, and the
+        evaluation needs its two exchanges only ([tri G | b | y^T y | N], then [sqErr | dhyp]) -- no broadcast of the results.
+        That claim covers the DEVICE kernels only, and only when EVERY rank runs them that way:
+        * the flag is per process (an environment variable), so the ranks agree on it ONCE per fit state -- an all-reduce
+          (min) of the flag, cached on the state -- instead of each trusting its own: a rank that skipped a broadcast its
+          peers entered would hang the job in the next collective;
+        * a step whose posterior came from the HOST route (solve_posdef / LAPACK after RR_ERR_NOT_POSDEF, or RR_POSDEF=host)
+          keeps the broadcast: different CPUs / BLAS builds need not agree to the last bit.  (With identical statistics and
+          deterministic device kernels every rank takes the host route on the same steps, so the ranks still agree on
+          WHETHER to broadcast.)"""
+        st = getattr(self, "_state", None)
+        dev = getattr(st, "dev", None)  # the fit state's device context, if it has one
+        if st is None or dev is None:
+            return False
+        agreed = getattr(st, "_deterministic_on_all_ranks", None)
+        if agreed is None:
+            from . import parallel
+            mine = 1.0 if getattr(dev, "deterministic", False) else 0.0
+            agreed = st._deterministic_on_all_ranks = bool(parallel.get_comm().allreduce_host(np.array([mine]), op="min")[0] > 0.5)
+        return bool(agreed and posterior_on_device)
 
     @staticmethod
     def _same_on_all_ranks(comm, values):

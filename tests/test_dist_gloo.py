@@ -302,6 +302,48 @@ def test_two_rank_distributed_fit_equals_single_process():
     assert res[0][5] > -1e6 and np.isfinite(res[0][2])    # the fit moved to a finite optimum
 
 
+def _detflag_worker(rank, world, port, q):
+    import types
+    import torch.distributed as dist
+    from revrand_amd.slm import StandardLinearModel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        out = []
+        for flags in ((True, True), (True, False), (False, False)):
+            slm = StandardLinearModel(distributed=True)
+            slm._state = types.SimpleNamespace(dev=types.SimpleNamespace(deterministic=flags[rank]))
+            # asked twice: the agreement is made once (one all-reduce) and cached on the fit state
+            out.append([slm._ranks_bit_identical(True), slm._ranks_bit_identical(True), slm._ranks_bit_identical(False),
+                        slm._state._deterministic_on_all_ranks])
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_ranks_agree_on_the_deterministic_flag_before_dropping_the_result_broadcast():
+    """RR_DETERMINISTIC is per process.  The broadcast of rank 0's objective / gradients / posterior is dropped
+    only when EVERY rank runs the deterministic device kernels (an all-reduced minimum of the flag, made once per fit
+    state) and the step's posterior came from the device -- a rank deciding alone would leave its peers in a collective."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_detflag_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == [[True, True, False, True], [False, False, False, False], [False, False, False, False]]
+
+
 # -- row-sharded SVI of the generalised linear model -------------------------------------------------
 
 class _OracleFeatures(object):

@@ -225,7 +225,7 @@ def test_two_rccl_ranks_sum_shard_statistics_and_fit_identically(tmp_path):
 def test_bench_two_ranks_as_the_driver_calls_it():
     """`python bench.py --gpus 2` (no launcher): starts its own ranks, exits 0, ONE JSON line, n_gpus as RCCL reports."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--rows", "600000"], capture_output=True, text=True, timeout=1500)
+                        "--rows", "600000", "--dist-rows", "20000", "--configs", "elbo"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -233,6 +233,7 @@ def test_bench_two_ranks_as_the_driver_calls_it():
     assert out["n_gpus"] == 2 and out["exchange"]["ranks_rccl_reports"] == 2
     assert out["exchange"]["message_bytes"] == 8 * (4096 * 4097 // 2 + 4096 + 2)
     assert out["config"]["trace_rel_err"] < 1e-6 and out["value"] > 0
+    assert out["configs"]["elbo_rbf_f4096_dist"]["parity"]["ranks_identical"] and "C3_matern52_linear_dist" not in out["configs"]
 
 
 def test_bench_under_torch_distributed_run_uses_rccl_directly():
@@ -268,12 +269,15 @@ def _keys(o, prefix=""):
 
 @pytest.mark.parametrize("world", [4, 8])
 def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
-    """`python bench.py --gpus 4` / `--gpus 8` exactly as the driver issues it, oversubscribed on this
-    box's one GPU (rank r -> device r % visible GPUs, 8-way file rendezvous, one RCCL all-reduce per step)."""
-    r = _bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", "800000"])
+    """`python bench.py --gpus 4` / `--gpus 8` exactly as the driver issues it, oversubscribed on this box's one GPU (rank r ->
+    device r % visible GPUs, 8-way file rendezvous, one RCCL all-reduce per step) -- with fewer rows than BASELINE's: after the
+    headline the ranks time BASELINE config 3 (RandomMatern52 + LinearBasis, F_tot = 8257, the 273 MB exchange) and the
+    RandomRBF F = 4096 `_elbo`, rows sharded (slm.py:142-199 over all shards), every stage on the ranks' clocks."""
+    r = _bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", "800000", "--dist-rows", "48000"])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
+    assert len(lines[0]) < 8192, len(lines[0])          # the driver keeps a 9 KB tail of stdout
     out = json.loads(lines[0])
     F = 4096
     assert out["n_gpus"] == world == out["exchange"]["ranks_rccl_reports"]
@@ -286,7 +290,19 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
     assert pr["expected_speedup_model"]["speedup_vs_one_gpu"] > 0
     assert out["exchange"]["ms_per_step_pack_allreduce_unpack"] > 0
     rt = out["config"]["runtime"]
-    assert rt["hip_runtime"] and rt["rccl"]["library"] == out["exchange"]["rccl"]["library"] and rt["rccl"]["version"] >= 20000
+    assert rt["hip_runtime"] and rt["rccl"] == out["exchange"]["rccl"]["version"] >= 20000
+    # the row-sharded evaluations
+    for name, Ft in (("C3_matern52_linear_dist", 8257), ("elbo_rbf_f4096_dist", 4096)):
+        c = out["configs"][name]
+        assert "error" not in c, c
+        assert c["rows"] == 48000 and c["rows_per_gpu"] == 48000 // world and c["F"] == Ft
+        assert c["exchange_bytes"] == 8 * (Ft * (Ft + 1) // 2 + Ft + 2)
+        st = c["stage_ms"]
+        assert all(st[k] > 0 for k in ("statistics", "exchange", "posterior", "second_pass")) and c["ms"] > 0
+        par = c["parity"]
+        assert par["N_total"] == 48000 and par["G_symmetric"] and par["ranks_identical"]
+        assert par["trace_fourier_block"] < 1e-5 and par["neg_elbo_256_rows"] < 1e-5 and par["gradient_256_rows"] < 1e-3
+        assert 0 < c["roofline"]["frac"] < 1 and c["speedup_model"]["speedup"] > 0
 
 
 def test_bench_launcher_timeout_ends_all_ranks_and_says_which():
@@ -309,7 +325,7 @@ def test_bench_one_gpu_line_has_the_same_keys_under_a_launcher_environment():
         assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     a, b = (json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0]) for r in (plain, launched))
     assert _keys(a) == _keys(b) and "exchange" not in a and a["n_gpus"] == b["n_gpus"] == 1
-    assert a["config"]["runtime"]["hip_runtime"] == b["config"]["runtime"]["hip_runtime"]
+    assert a["config"]["runtime"]["hip_runtime"] == b["config"]["runtime"]["hip_runtime"] != ""
     assert a["metric"] == b["metric"] and a["config"]["workload"] == b["config"]["workload"]
 
 

@@ -413,3 +413,27 @@ def test_schedule_model_of_the_pipelined_diagonal_block_cholesky():
     import runpy
     ns = runpy.run_path(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "chol_diag_emu.py"))
     assert ns["ERR_U"] < 1e-13 and ns["ERR_UINV"] < 1e-13
+
+
+def test_bench_line_is_numbers_only_and_small():
+    """bench.py's ONE JSON line: keys starting with "_" (notes, samples, per-kernel detail) go to the full record only,
+    floats carry 5 significant digits, a parity figure above its tolerance is an error -- never a measurement."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("rr_bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = {"value": 8461234.56789, "n": np.int64(3), "x": np.float64(1.0) / 3, "nan": float("nan"), "flag": True,
+           "_note": "prose " * 100, "roofline": {"frac": 0.94312345, "_what": "long", "list": [1.23456789e-7, 2]},
+           "configs": {"a": {"_sample": "s", "ms": 12.3456789}}}
+    line = json.dumps(bench.lean(rec))
+    back = json.loads(line)
+    assert back == {"value": 8461200.0, "n": 3, "x": 0.33333, "nan": None, "flag": True,
+                    "roofline": {"frac": 0.94312, "list": [1.2346e-07, 2]}, "configs": {"a": {"ms": 12.346}}}
+    fullrec = bench.full(rec)
+    assert fullrec["note"].startswith("prose") and fullrec["configs"]["a"]["sample"] == "s" and fullrec["value"] == rec["value"]
+    assert bench.parity("x", 1e-7, 1e-6) == 1e-7
+    with pytest.raises(bench.ParityError, match="exceeds its tolerance"):
+        bench.parity("Gram of 4096 rows vs oracle", 0.3, 1e-4)
+    with pytest.raises(bench.ParityError):
+        bench.parity("x", float("nan"), 1e-4)
