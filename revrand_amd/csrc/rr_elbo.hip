@@ -264,21 +264,25 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
     const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const int nkb = p.K / GR_KB;
-    float xmask[NXB];  // 1 for the lanes whose column of X exists
-#pragma unroll
-    for (int xb = 0; xb < NXB; ++xb) xmask[xb] = l31 + 32 * xb < p.d ? 1.f : 0.f;
-    int tlane = tcol + wc_ * 64 + l31;
-    auto flush = [&](floatx16 (&t)[2], int xb) {  // T[32 xb + i][tlane + 32 j] += t[j][e]
-        int tl = tlane, dl = p.d - 32 * xb - 4 * hi;  // rows of this block that exist, seen from the lane's first row
-        // (opaque: the 32 addresses and 32 lane masks are formed here -- hoisted to the kernel's start they would spill)
-        asm volatile("" : "+v"(tl), "+v"(dl));
-        double *Tb = p.T + (size_t)(32 * xb + 4 * hi) * p.n + tl;
+    const int tlane = tcol + wc_ * 64 + l31;
+    // T[32 xb + i][tlane + 32 j] += t[j][e] as f64 atomics through a buffer descriptor over the (d, n) matrix: the rows of a
+    // partial last block (32 xb + i >= d) fall outside its extent and the hardware drops them -- no branch and no lane mask
+    // per element.  (With `if (i < dl) unsafeAtomicAdd(..)` hipcc formed the 16 lane masks of a flush up front: 32 SGPRs,
+    // which inside the tile loop of the NXB > 1 variants pushed the k-loop's scalars out into VGPR lanes.)
+    const rr_rsrc_t trs = rr_make_rsrc(p.T, (unsigned)p.d * (unsigned)p.n * 8u);
+    const unsigned n8 = (unsigned)p.n * 8u;
+    auto flush = [&](floatx16 (&t)[2], int xb) {
+        unsigned to = (unsigned)(32 * xb + 4 * hi) * n8 + (unsigned)tlane * 8u;
+        // (opaque: the 32 offsets are formed here -- hoisted to the kernel's start they would spill)
+        asm volatile("" : "+v"(to));
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int i = (e & 3) + 8 * (e >> 2);
-                if (i < dl) unsafeAtomicAdd(&Tb[(size_t)i * p.n + j * 32], (double)(sgn * t[j][e]));
+                const unsigned i = (unsigned)((e & 3) + 8 * (e >> 2));
+                const double v = (double)(sgn * t[j][e]);
+                const unsigned off = to + i * n8 + (unsigned)(j * 256);
+                asm volatile("buffer_atomic_add_f64 %0, %1, %2, 0 offen" : : "v"(v), "v"(off), "s"(trs) : "memory");
             }
     };
 
@@ -293,14 +297,33 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         mcol[1] = p.mvec[cb + wc_ * 64 + 32 + l31];
     }
 
-    // NXB == 1: buffer-descriptor requests, staggered (rr_dma_kblock).  NXB > 1 (config 3's shape: K = 8288, 1 MB row stride of
-    // A): measured 5 % SLOWER that way (254 vs 242 ms per 254 200-row launch) -- those variants keep the flat requests right
-    // after the barrier.
+    // LDS-DMA requests through buffer descriptors, staggered (rr_dma_kblock's scheme) with as little scalar state as it takes:
+    // the wave's four rows of a k-block start at (A + ca + 4 w lda) + kb (32 lda) -- ONE descriptor per side, rebuilt per
+    // k-block by scalar instructions, the row step k lda in the scalar offset -- and the slot is made provably uniform, so
+    // that its tests are s_cmp and not four precomputed lane masks.  (Round 3 kept the flat requests for NXB > 1: with
+    // rr_dma_kblock's eight row offsets and the masks the kernel ran out of SGPRs and read them back with v_readlane between
+    // the MFMAs -- 254 instead of 242 ms per launch at config 3's shape.)
+#ifndef RR_GT_FLATDMA
+    constexpr bool BUFDMA = true;
+#else
     constexpr bool BUFDMA = NXB == 1;
+#endif
     const unsigned voff = 16u * lane;  // the requests' lane part; everything else is scalar
+    const unsigned lda4 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)p.lda * 4u));
+    const unsigned ldb4 = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)p.ldb * 4u));
+    const int slot = __builtin_amdgcn_readfirstlane(rr_dma_slot(wave, p.spread));
+    const uint64_t bw = (uint64_t)(p.B + cb) + (uint64_t)(4 * wave) * ldb4;  // this wave's first row of B's k-block 0
     auto dma_tile = [&](float *buf, int64_t ca, int kb0) {
         if constexpr (BUFDMA) {
-            rr_dma_kblock(p.A + (int64_t)kb0 * p.lda + ca, p.lda, p.B + (int64_t)kb0 * p.ldb + cb, p.ldb, buf, wave, voff);
+            const uint64_t aw = (uint64_t)(p.A + ca) + (uint64_t)(4 * wave) * lda4 + (uint64_t)(unsigned)kb0 * lda4;
+            const rr_rsrc_t ra = rr_make_rsrc((const void *)aw, 0x7fffffffu);
+            const rr_rsrc_t rb = rr_make_rsrc((const void *)(bw + (uint64_t)(unsigned)kb0 * ldb4), 0x7fffffffu);
+            float *dst = buf + 4 * wave * GR_LD;  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lptr_t)(dst + k * GR_LD), 16, voff, (unsigned)k * lda4, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lptr_t)(dst + k * GR_LD + GR_TC), 16, voff, (unsigned)k * ldb4, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -328,7 +351,7 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         for (int kb = 0; kb + 1 < nkb; ++kb) {
             const int cbuf = kb & 1;
             if constexpr (BUFDMA) {
-                gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, rr_dma_slot(wave, p.spread),
+                gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, slot,
                                        [&]() { dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB); });
             } else {
                 dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), ca, (kb + 1) * GR_KB);
@@ -357,10 +380,15 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
         if (ERR) ers = rr_make_rsrc(p.err + ca, tr * 4u);
         constexpr int NS = ERR ? 2 : 3;
         float xv[NS][8], pv[NS][2][8], ev[NS][8];
-        auto load_group = [&](int set, int hb, int xb) {  // (all compile-time after unrolling)
+        // X's 32-column block xb (a RUN-TIME loop for NXB > 1: unrolled, the blocks' epilogues together want more registers
+        // than there are, and what hipcc spills then are the k-loop's lane offsets -- reloaded with `s_waitcnt vmcnt(0)`
+        // behind every LDS-DMA request): xm = 1 for the lanes whose column of X exists (the others re-read a valid column
+        // and are masked in the product), xadd = the block's byte offset in a row of X
+        float xm = l31 < p.d ? 1.f : 0.f;
+        unsigned xadd = 0;
+        auto load_group = [&](int set, int hb) {  // (set, hb: compile-time after unrolling)
             const int i = hb >> 1;
-            // (X's block xb: lanes past d re-read a valid column and are masked in the product)
-            unsigned pb = pofs + (unsigned)(32 * i) * ldp4, xo = xofs + (unsigned)(32 * i) * ldx4 + (xmask[xb] != 0.f ? 128u * xb : 0u);
+            unsigned pb = pofs + (unsigned)(32 * i) * ldp4, xo = xofs + (unsigned)(32 * i) * ldx4 + xadd;
             asm volatile("" : "+v"(pb), "+v"(xo));  // (per group: see above)
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -375,19 +403,23 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
             }
         };
         __builtin_amdgcn_sched_barrier(0);
-        load_group(0, 0, 0);
+        load_group(0, 0);
         __builtin_amdgcn_sched_barrier(0);
         {   // the tile's last k-block (nothing left to request for this tile)
             const int cbuf = (nkb - 1) & 1;
             gram_consume(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff);
             __syncthreads();
         }
-#pragma unroll
+#pragma unroll 1
         for (int xb = 0; xb < NXB; ++xb) {
             __builtin_amdgcn_sched_barrier(0);
-            if (xb > 0) load_group(0, 0, xb);
+            if (xb > 0) {
+                xm = l31 + 32 * xb < p.d ? 1.f : 0.f;
+                xadd = xm != 0.f ? 128u * (unsigned)xb : 0u;
+                load_group(0, 0);
+            }
 #pragma unroll
-            for (int q = 1; q < NS; ++q) load_group(q, q, xb);
+            for (int q = 1; q < NS; ++q) load_group(q, q);
 #pragma unroll
             for (int hb = 0; hb < 8; ++hb) {
                 const int set = hb % NS, i = hb >> 1;
@@ -395,7 +427,7 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int e = 8 * (hb & 1) + k;
-                    const float xe = xv[set][k] * xmask[xb];  // (a multiply, not a select: the loads stay unconditional and batched)
+                    const float xe = xv[set][k] * xm;  // (a multiply, not a select: the loads stay unconditional and batched)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const float a = ERR ? fmaf(-ev[set][k], mcol[j], acc[i][j][e]) : acc[i][j][e];
@@ -403,7 +435,7 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_gradt_f32_kernel(const 
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (hb + NS < 8) load_group(set, hb + NS, xb);
+                if (hb + NS < 8) load_group(set, hb + NS);
             }
             if (NXB > 1) {  // this block of T leaves per tile (the registers serve the next block of X)
                 flush(tacc, xb);
