@@ -240,3 +240,24 @@ def test_fit_c1_shape_prediction_mean(golden):
     # second small fit (ARD Matern32): same consistency
     Phi2 = orc.rff_transform(g["s2_Xs"], g["s2_W"], g["s2_hyp_"])
     assert np.array_equal(orc.weights_matern(4, 20, 43, 1), g["s2_W"]) and Phi2.shape == (16, 40)
+
+
+def test_converged_fit_fixture_is_a_stationary_point_of_the_oracles_elbo(golden):
+    """tests/golden/fit_converged.npz (a reference fit that CONVERGED: config 1's shape, ARD length scales): the oracle's
+    ELBO at the stored optimum equals the reference's objective, its posterior mean the reference's weights, and the point
+    is stationary -- the gradient in log-space (what L-BFGS-B sees through the log trick) is below 1e-4 of the objective
+    there."""
+    g = golden("fit_converged")
+    X, y, Xs = c1_data()
+    W = orc.weights_rbf(8, 256, 41)
+    assert np.array_equal(W[:, :8], g["W_head"]) and int(g["nit"]) < 100
+    ls, var, reg = g["hyp_"], float(g["var_"]), float(g["reg_"])
+    dP = orc.rff_grad(X, W, ls)
+    o = orc.slm_elbo(orc.rff_transform(X, W, ls), y, var, np.full(512, reg), slice(None), [dP[:, :, i] for i in range(8)])
+    assert abs(o["elbo"] - float(g["obj"])) < 1e-9 * abs(float(g["obj"]))
+    assert normwise(o["m"], g["m"]) < 1e-8 and normwise(o["C"].diagonal(), g["Cdiag"]) < 1e-8
+    glog = np.concatenate(([o["dvar"] * var], [o["dreg"][0] * reg], np.asarray(o["dhyp"]) * ls))
+    assert np.abs(glog).max() < 1e-4 * abs(float(g["obj"])), glog   # (0.15 against an objective of 5448; L-BFGS-B stopped on ftol)
+    Phi = orc.rff_transform(Xs, W, ls)
+    assert normwise(Phi @ g["m"], g["Ey"]) < 1e-10
+    assert abs(float(g["smse"]) - ((g["ys_true"] - g["Ey"]) ** 2).mean() / g["ys_true"].var()) < 1e-12 and float(g["smse"]) < 0.03
