@@ -526,6 +526,81 @@ def config_c4(dev, _hip, args):
             "cpu_baseline": cpu}
 
 
+def config_ff_elbo(dev, _hip, args, N=524_288):
+    """configs[3] WITH the Gram (SURVEY 8 a-11 "C4-with-Gram", f-4's width): one `_elbo` of StandardLinearModel on FastFoodRBF
+    nbases=8192, D=128 ARD (F = 16384) over one GPU's share of N = 4M rows (4 194 304 / 8), resident: the statistics pass
+    runs the chain kernel into the device feature matrix and the MFMA SYRK at F = 16384, the posterior is the 128-panel
+    Cholesky + inverse in HBM, the second pass contracts X^T A against the same features (basis_functions.py:1263-1289,
+    slm.py:142-199)."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    d, nb = 128, 8192
+    rng = np.random.default_rng([20260928, 44])
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    w = rng.standard_normal(d, dtype=np.float32)
+    y = (np.sin(X @ w / np.sqrt(d)) + 0.1 * rng.standard_normal(N, dtype=np.float32)).astype(np.float32)
+
+    def make_basis():
+        return bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+    f = make_basis()
+    F = 2 * f.n
+    slm = StandardLinearModel(f)
+    slm.obj_ = -np.inf
+    slm._defer_cov = True
+    st = slm._state = f.device_fit_state(X, y)
+    assert type(st).__name__ == "CatFitState" and _hip.posterior_available(F)
+    ls, var, reg = np.linspace(0.8, 1.3, d), 0.5, 1.0
+    iL = np.full(F, 1.0 / reg)
+    slm._elbo(X, y, var, reg, ls)  # warm: scratch allocations, posterior work space
+    t_stats, _ = _median_ms(lambda: st.gram_device([ls]), 2)
+    G, _, _ = st.stats_host()
+    tr = parity("trace(G)/N - 1", abs(float(np.trace(G)) - N) / N, 1e-5)
+    del G
+    t_post, post = _median_ms(lambda: st.posterior(iL, var), 2)
+    t_pass2, _ = _median_ms(lambda: st.second_pass([ls], post[0], st.dC, var), 2)
+    t_eval, res = _median_ms(lambda: slm._elbo(X, y, var, reg, ls * 1.0), 2)
+    chunks = [rows for _, rows in st._chunks()]
+    st.release()
+    slm._state = None
+    perr = (None, None)
+    if not args.no_parity_check:
+        # the same evaluation on 64 rows against the oracle's FWHT chain in float64: -ELBO, dvar, dreg and the first 8 of
+        # the 128 length-scale gradients (each is an F x N x F product on the host)
+        orc = _oracle()
+        ns, nh = 64, 8
+        Xs, ys = np.ascontiguousarray(X[:ns]), np.ascontiguousarray(y[:ns])
+        fb = make_basis()
+        s2 = StandardLinearModel(fb)
+        s2.obj_ = -np.inf
+        s2._state = fb.device_fit_state(Xs, ys)
+        nel, (gv, gr, gh) = s2._elbo(Xs, ys, var, reg, ls)
+        s2._state.release()
+        s2._state = None
+        X64 = Xs.astype(np.float64)
+        Phi = orc.fastfood_transform(X64, fb.B, fb.G, fb.PI, fb.S, ls)
+        dP = orc.fastfood_grad(X64, fb.B, fb.G, fb.PI, fb.S, ls)
+        ref = orc.slm_elbo(Phi, ys.astype(np.float64), var, np.full(F, reg), slice(None), [dP[:, :, i] for i in range(nh)])
+        del dP
+        got = np.concatenate(([gv], np.atleast_1d(gr), np.atleast_1d(gh)[:nh]))
+        want = np.concatenate(([-ref["dvar"]], [-g for g in ref["dreg"]], [-g for g in ref["dhyp"]]))
+        perr = (parity("-ELBO of 64 rows vs the oracle's chain", abs(nel + ref["elbo"]) / abs(ref["elbo"]), 1e-5),
+                parity("gradient of 64 rows vs the oracle's chain (normwise)", float(np.linalg.norm(got - want) / np.linalg.norm(want)), 1e-3))
+    fl_stats = F * (F + 1.0) + 2.0 * F + f.k * (2.0 * f.d2 * np.log2(f.d2) + 3.0 * f.d2)
+    fl_pass2 = 2.0 * F * F + 2.0 * d * F
+    fl_post = F ** 3 / 3.0 + F ** 3
+    return {"workload": "StandardLinearModel._elbo, FastFoodRBF nbases=8192 D=128 ARD (F=%d), N=%d (1/8 of 4M) resident, f32" % (F, N),
+            "rows": N, "dtype": "f32", "ms": t_eval, "value": N / (t_eval * 1e-3), "unit": "rows/s per _elbo",
+            "stage_ms": {"statistics": t_stats, "posterior": t_post, "second_pass": t_pass2}, "_rows_per_launch": chunks,
+            "_neg_elbo": float(res[0]),
+            "parity": {"trace": tr, "neg_elbo_64_rows": perr[0], "gradient_64_rows": perr[1]},
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS,
+                         "frac": (fl_stats + fl_pass2) * N / (t_eval * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "statistics_frac": fl_stats * N / (t_stats * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "second_pass_frac": fl_pass2 * N / (t_pass2 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "posterior_frac_f64": fl_post / (t_post * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS}}
+
+
 def config_c5(dev, _hip, args):
     """configs[4]: GLM Poisson, RandomRBF F=2048, D=32 ARD, N=2M resident, K=10, L=50, minibatch 65 536: one SVI
     minibatch `_elbo` (Phi + ELBO gradients incl. the length-scale gradient)."""
@@ -1031,7 +1106,7 @@ def extra_configs(dev, _hip, args, emit=None):
                      ("posterior_F16384", lambda d_, h_, a_: config_posterior(d_, h_, a_, 16384)),
                      ("predict_moments_n300k", config_predict),
                      ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
-                     ("C5_glm_poisson_svi_step", config_c5)):
+                     ("C4elbo_fastfood_f16384", config_ff_elbo), ("C5_glm_poisson_svi_step", config_c5)):
         want = args.configs.lower().split(",")
         if args.configs != "all" and name.split("_")[0].lower() not in want and name.lower() not in want:
             continue

@@ -206,6 +206,7 @@ int rr_gather_rows(rr_ctx *ctx, const void *dsrc, const int *didx, int64_t rows,
  *   rr_featmat_begin(rows)      start a row block (zeroes the matrix)
  *   rr_featmat_put_rff          [cos | sin] / sqrt(n) of a random Fourier basis at columns [col0, col0 + 2n)
  *   rr_featmat_put_linear       LinearBasis.transform ([1, X] or X, basis_functions.py:468-485) at col0
+ *   rr_featmat_put_fastfood     FastFoodRBF.transform (the chain kernel, basis_functions.py:1263-1289) at col0
  *   rr_featmat_put_host         any other basis: a host (rows, ncols) block at col0
  *   rr_featmat_gram             G(upper) += P^T P, b += P^T y, yty += y^T y into DEVICE f64 buffers
  * dX / dy are device pointers (dX in the padded layout for put_rff); all calls asynchronous on the
@@ -218,6 +219,10 @@ int rr_featmat_put_rff(rr_featmat *fm, rr_basis *basis, const void *dX, int x_dt
                        const double *lenscale, int n_ls, int64_t col0);
 int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol,
                           int64_t col0);
+/* FastFoodRBF.transform (basis_functions.py:1263-1289) of the rows of the current rr_featmat_begin at columns
+ * [col0, col0 + 2 d2 k): the Hadamard / permute / diagonal chain writes Phi straight into the feature matrix (f32). */
+int rr_featmat_put_fastfood(rr_featmat *fm, rr_basis *fastfood, const void *dX, int x_dtype, int64_t ldx,
+                            const double *lenscale, int n_ls, int64_t col0);
 int rr_featmat_put_host(rr_featmat *fm, const void *Phi, int dtype, int64_t ncols, int64_t ldphi, int64_t col0);
 int rr_featmat_gram(rr_featmat *fm, const void *dy, int y_dtype, double *dG, double *db, double *dyty);
 

@@ -85,6 +85,8 @@ SIGNATURES = {
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "rr_featmat_put_linear": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                              ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+    "rr_featmat_put_fastfood": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                               ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "rr_featmat_put_host": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
                                            ctypes.c_int64, ctypes.c_int64]),
     "rr_featmat_gram": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
@@ -740,6 +742,11 @@ class FeatureMatrix(object):
     def put_linear(self, dX, onescol, col0):
         _check(self.lib, self.lib.rr_featmat_put_linear(self.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, dX.shape[1],
                                                         1 if onescol else 0, col0))
+
+    def put_fastfood(self, ff_handle, dX, lenscale, col0):
+        """FastFoodRBF's Phi of the rows dX by the chain kernel (rr_fastfood16_kernel) into columns [col0, col0 + 2 d2 k)."""
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        _check(self.lib, self.lib.rr_featmat_put_fastfood(self.h, ff_handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, lsp, nls, col0))
 
     def put_host(self, Phi, col0):
         Phi = as_float_matrix(Phi)

@@ -446,6 +446,25 @@ class _ResidentRFF(object):
         _free_batches(self)
 
 
+class _ResidentFastFood(_ResidentRFF):
+    """FastFoodRBF child: Phi comes from the Hadamard / permute / diagonal chain itself (rr_fastfood16_kernel writes it
+    straight into the feature matrix, basis_functions.py:1263-1289); the length-scale gradient's contraction T = X^T A
+    needs X and Phi only, and meets the dense equivalent W = _makeVX(I_d) on the host in `dhyp` -- the chain is linear
+    in x."""
+
+    def __init__(self, basis, X):
+        super().__init__(basis, X)
+        self.ff = basis._handles()[0]
+
+    def put(self, fm, X, r0, rows, col0, params):
+        self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
+        fm.put_fastfood(self.ff, _hip.DeviceView(self.dX, r0, rows), self.ls, col0)
+
+    def put_batch(self, fm, M, col0, params, slot=None):
+        self.ls = self.basis._check_dim(self.basis.d, params[0] if params else None)
+        fm.put_fastfood(self.ff, _hip.DeviceView(_batch_buffer(self, slot), 0, M), self.ls, col0)
+
+
 def _gather_batch(dX, dXb, didx, M, dev=None):
     """Rows didx of the resident matrix dX into a (grow-only) batch matrix of the same layout; on `dev`'s stream (default:
     the context the data were uploaded through)."""
@@ -1117,9 +1136,24 @@ class FastFoodRBF(_LengthScaleBasis):
         return lazy.get(), lazy.V
 
     @slice_transform
+    def _resident_child(self, X, dtype=None):
+        """This basis' share of a device-resident fit (f32 states): features by the chain kernel."""
+        if self.dtype != "f32" or dtype == "f64" or X.shape[1] != self.d or type(self)._resident_via_chain is False:
+            return None
+        return _ResidentFastFood(self, X)
+
+    _resident_via_chain = True
+
+    @slice_transform
     def device_fit_state(self, X, y):
+        """(X, y) resident for a whole fit.  f32: the statistics pass runs the CHAIN (rr_fastfood16_kernel -> feature matrix
+        -> MFMA SYRK) and the second pass contracts X^T A against the same features -- a one-child CatFitState.  f64 (or
+        RR_FASTFOOD_FIT=dense, A/B runs): the dense equivalent W through the random Fourier kernels."""
         if X.shape[1] != self.d:
             return None
+        if self.dtype == "f32" and self._resident_via_chain and _hip.os.environ.get("RR_FASTFOOD_FIT", "chain") != "dense":
+            import types
+            return CatFitState(types.SimpleNamespace(get_dim=self.get_dim, bases=[self]), [_ResidentFastFood(self, X)], X, y)
         return DeviceFitState(*self._dense_handle(), X=X, y=y, dtype=self.dtype)
 
     def __repr__(self):

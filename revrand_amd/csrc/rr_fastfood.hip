@@ -778,7 +778,13 @@ static int ff_prepare_lenscale(rr_basis *b, const double *lenscale, int n_ls) {
         const double l = lenscale[n_ls == 1 ? 0 : i];
         RR_REQUIRE(l != 0.0 && l == l, "lenscale[%d] is %g", i, l);
         l64[i] = 1.0 / l;
-        l32[i] = (float)l64[i];
+        // The f32 copy is clamped to a finite range (like the random Fourier kernels' scaled W, rr_api.hip): the optimiser's
+        // log-space bounds let a length scale reach 1e-100 (optimize/decorators.py:18), where the reference's float64 phases
+        // are finite noise; a float32 phase from x / l beyond 2^24 has no fractional part left either way, but 1 / l = inf
+        // would turn the whole chain into inf - inf = NaN.  2^40 leaves the chain's intermediates (x d2 |G| d2 S sqrt(d2))
+        // far inside the float32 range.
+        const double lim = 1099511627776.0;  // 2^40
+        l32[i] = (float)(l64[i] > lim ? lim : (l64[i] < -lim ? -lim : l64[i]));
     }
     RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
     RR_CHECK_HIP(hipMemcpy(b->ffL64, l64.data(), l64.size() * 8, hipMemcpyHostToDevice));
@@ -903,6 +909,26 @@ int rr_fastfood_transform_dev(rr_basis *b, const void *dX, int x_dtype, int64_t 
     if (rc != RR_OK || N == 0) return rc;
     RR_REQUIRE(dX != nullptr && dPhi != nullptr, "rr_fastfood_transform_dev: null buffer");
     return ff_dispatch<true>(b, dX, x_dtype, N, ldx, dPhi, out_dtype, ldphi);
+}
+
+// The chain's Phi straight into a device feature matrix, columns [col0, col0 + 2n) (a FastFood child of a resident fit:
+// `_elbo` statistics of FastFoodRBF, basis_functions.py:1263-1289 feeding slm.py:145-157).  The rows of the current
+// rr_featmat_begin; f32 arithmetic (the feature matrix is float32).  P^T is not written here: consumers that want it run
+// their transposing pass.
+int rr_featmat_put_fastfood(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale,
+                            int n_ls, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && b != nullptr && b->kind == RR_KIND_FASTFOOD, "rr_featmat_put_fastfood: not a FastFood basis");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_put_fastfood: bad dtype");
+    RR_REQUIRE(b->ctx == fm->ctx, "rr_featmat_put_fastfood: basis and feature matrix live on different device contexts");
+    RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_put_fastfood: columns out of range");
+    RR_REQUIRE(ldx >= b->d, "rr_featmat_put_fastfood: bad shape");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    int rc = ff_prepare_lenscale(b, lenscale, n_ls);
+    if (rc != RR_OK || fm->rows == 0) return rc;
+    RR_REQUIRE(dX != nullptr, "rr_featmat_put_fastfood: null X");
+    rc = rr_fm_claim(fm, col0, 2 * (int64_t)b->n, "rr_featmat_put_fastfood");
+    if (rc != RR_OK) return rc;
+    return ff_dispatch<true>(b, dX, x_dtype, fm->rows, ldx, fm->P + col0, RR_F32, fm->ld);
 }
 
 int rr_fastfood_vx(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale, int n_ls,

@@ -229,3 +229,101 @@ def test_fastfood_wide_input():
     assert normwise(f.transform(X, 1.7), want) < 1e-3
     Gm, bv, _ = f.gram(X, y, 1.7)
     assert normwise(Gm, want.T @ want) < 1e-3 and normwise(bv, want.T @ y) < 1e-3
+
+
+def _oracle_ff_elbo(f, X, y, var, reg, ls, extra=None):
+    """slm_elbo of the oracle on FastFood features (+ an optional block of parameter-free columns)."""
+    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    Phi = orc.fastfood_transform(X64, f.B, f.G, f.PI, f.S, ls)
+    dP = orc.fastfood_grad(X64, f.B, f.G, f.PI, f.S, ls)
+    slabs = [dP] if dP.ndim == 2 else [dP[:, :, i] for i in range(dP.shape[2])]
+    regs = np.atleast_1d(np.asarray(reg, dtype=float))
+    if extra is None:
+        return orc.slm_elbo(Phi, y64, var, np.full(Phi.shape[1], regs[0]), slice(None), slabs)
+    full = np.hstack((Phi, extra))
+    pad = [np.hstack((s, np.zeros_like(extra))) for s in slabs]
+    diag = np.concatenate((np.full(Phi.shape[1], regs[0]), np.full(extra.shape[1], regs[1])))
+    return orc.slm_elbo(full, y64, var, diag, [slice(0, Phi.shape[1]), slice(Phi.shape[1], full.shape[1])], pad)
+
+
+@pytest.mark.parametrize("shape", [(700, 5, 16, True), (515, 3, 40, False), (1300, 20, 256, True), (900, 128, 512, True),
+                                   (600, 100, 300, True)])
+def test_fastfood_resident_elbo_runs_the_chain_and_matches_the_oracle(shape, monkeypatch):
+    """StandardLinearModel._elbo on a FastFoodRBF basis with (X, y) resident (basis_functions.py:1263-1289 feeding
+    slm.py:142-199): the statistics pass is the chain kernel writing Phi into the device feature matrix + the MFMA SYRK,
+    the second pass contracts X^T A against the same features (n % 256 == 0: fused in registers; otherwise the stored
+    route), the dense equivalent W only meets T on the host.  Against the oracle's FWHT chain in float64, and against the
+    dense-equivalent route (RR_FASTFOOD_FIT=dense) the fit used before."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.slm import StandardLinearModel
+    N, d, nb, ard = shape
+    rs = np.random.RandomState(N + d)
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X @ rs.randn(d) / np.sqrt(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+    f = _ff(d, nb, ard, "f32")
+    ls = np.linspace(0.8, 1.4, d) if ard else 1.2
+    var, reg = 0.3, 1.5
+    out = {}
+    for route in ("chain", "dense"):
+        monkeypatch.setenv("RR_FASTFOOD_FIT", route)
+        slm = StandardLinearModel(f)
+        slm.obj_ = -np.inf
+        slm._state = slm._make_state(X, y)
+        assert type(slm._state).__name__ == ("CatFitState" if route == "chain" else "DeviceFitState")
+        try:
+            nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, var, reg, ls)
+            C = slm._state.best_covariance() if getattr(slm._state, "best_on_device", False) else slm.covariance_
+        finally:
+            slm._state.release()
+            slm._state = None
+        out[route] = (nelbo, ndvar, ndreg, np.atleast_1d(ndhyp), slm.weights_.copy(), np.array(C))
+    ref = _oracle_ff_elbo(f, X, y, var, reg, ls)
+    for route, (nelbo, ndvar, ndreg, ndhyp, m, C) in out.items():
+        assert abs(-nelbo - ref["elbo"]) < 1e-4 * abs(ref["elbo"]), route
+        assert abs(-ndvar - ref["dvar"]) < 1e-3 * abs(ref["dvar"]) and abs(-ndreg - ref["dreg"][0]) < 1e-3 * abs(ref["dreg"][0])
+        assert normwise(-ndhyp, np.array(ref["dhyp"])) < 2e-3, route
+        assert normwise(m, ref["m"]) < 1e-3 and normwise(C, ref["C"]) < 1e-3
+    assert normwise(out["chain"][3], out["dense"][3]) < 2e-3
+
+
+def test_fastfood_child_of_a_concatenation_is_resident():
+    """BasisCat(FastFoodRBF + LinearBasis): the FastFood child takes part in the device-resident fit (its block of the
+    feature matrix from the chain kernel); `_elbo` against the oracle on the hstacked features."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    rs = np.random.RandomState(9)
+    N, d, nb = 800, 6, 256
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X[:, 0]) + 0.3 * X[:, 1] + 0.1 * rs.randn(N)).astype(np.float32)
+    f = bs.FastFoodRBF(nbases=nb, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+    cat = f + bs.LinearBasis(onescol=True)
+    slm = StandardLinearModel(cat)
+    slm.obj_ = -np.inf
+    slm._state = slm._make_state(X, y)
+    assert type(slm._state).__name__ == "CatFitState" and type(slm._state.children[0]).__name__ == "_ResidentFastFood"
+    ls = np.linspace(0.9, 1.3, d)
+    try:
+        nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, 0.4, [1.2, 0.7], ls)
+    finally:
+        slm._state.release()
+        slm._state = None
+    ref = _oracle_ff_elbo(f, X, y, 0.4, [1.2, 0.7], ls, extra=orc.linear_transform(X.astype(np.float64), True))
+    assert abs(-nelbo - ref["elbo"]) < 1e-4 * abs(ref["elbo"])
+    assert normwise(-np.asarray(ndreg), np.array(ref["dreg"])) < 1e-3 and normwise(-np.asarray(ndhyp), np.array(ref["dhyp"])) < 2e-3
+    assert normwise(slm.weights_, ref["m"]) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_fastfood_extreme_length_scales_give_finite_features_like_the_reference(dtype):
+    """The optimiser's log-space bounds let L-BFGS-B try length scales of 1e-100 and 1e+100 (optimize/decorators.py:18):
+    the reference's float64 chain returns finite noise / the constant features there, and so must the kernels -- a NaN in
+    Phi becomes a NaN objective and scipy's Cholesky raises instead of the line search backing off."""
+    f = _ff(3, 20, False, dtype)
+    X = np.random.RandomState(4).randn(300, 3)
+    for ls in (9.99999999999989e-101, 1e100):
+        P = f.transform(X, ls)
+        ref = orc.fastfood_transform(X, f.B, f.G, f.PI, f.S, ls)
+        assert np.isfinite(ref).all() and np.isfinite(P).all() and np.abs(P).max() <= 1.0 / np.sqrt(f.n) * (1 + 1e-6)
+        assert np.abs((P ** 2).sum(axis=1) - 1.0).max() < 1e-5   # cos^2 + sin^2 over n frequencies, / n
+    assert normwise(f.transform(X, 1e100), orc.fastfood_transform(X, f.B, f.G, f.PI, f.S, 1e100)) < 1e-6
