@@ -944,11 +944,15 @@ class _RandomKernelBasis(_LengthScaleBasis):
             return None
         return _ResidentRFF(self, X)
 
+    _predict_checks_rows = True  # `predict_moments` runs the caller's row validation itself (chunk by chunk, under the GPU's work)
+
     @slice_transform
-    def predict_moments(self, X, lenscale, m, C):
-        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243), in the basis' arithmetic."""
+    def predict_moments(self, X, lenscale, m, C, check_rows=None):
+        """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243), in the basis' arithmetic.  `check_rows`: the
+        estimator's validation of the query rows (`check_array`), applied here -- to the row chunks of a large query as they
+        are uploaded, see RffHandle.predict."""
         lenscale = self._check_dim(X.shape[1], lenscale)
-        return self._dense_handle()[0].predict(X, lenscale, m, C)
+        return self._dense_handle()[0].predict(X, lenscale, m, C, check_rows=check_rows)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(

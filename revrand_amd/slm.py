@@ -35,6 +35,11 @@ from .utils import atleast_list, issequence
 
 log = logging.getLogger(__name__)
 
+import inspect as _inspect
+# sklearn renamed check_array's `force_all_finite` to `ensure_all_finite` (1.6)
+_NO_FINITE_CHECK = {("ensure_all_finite" if "ensure_all_finite" in _inspect.signature(check_array).parameters
+                     else "force_all_finite"): False}
+
 
 class StandardLinearModel(BaseEstimator, RegressorMixin):
     """Bayesian linear regression on a basis; hyper-parameters by L-BFGS-B on the ELBO.
@@ -368,12 +373,19 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
 
     def _predict_moments(self, X):
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
-        X = check_array(X)
+        # A basis whose device route validates the rows itself gets them unchecked for finiteness here (shape and dtype only):
+        # `check_array` costs as much as the upload of a large query, and runs chunk by chunk under the GPU's work instead
+        # (same exception, raised before anything is returned)
+        deferred = getattr(self.basis, "_predict_checks_rows", False) and getattr(self.basis, "predict_moments", None) is not None
+        X = check_array(X, **(_NO_FINITE_CHECK if deferred else {}))
         if getattr(self.basis, "predict_moments", None) is not None:
             # on the GPU, with the covariance already resident there
-            res = self.basis.predict_moments(X, self.hypers_, self.weights_, self._device_covariance())
+            kw = {"check_rows": check_array} if deferred else {}
+            res = self.basis.predict_moments(X, self.hypers_, self.weights_, self._device_covariance(), **kw)
             if res is not None:
                 return res[0], res[1] + self.var_
+        if deferred:
+            check_array(X)
         # bases without a fused device route (LinearBasis alone, float64 children in a concatenation): their transform,
         # then the N x F x F product on the GPU in float64 (rr_dense_predict) -- never on the host
         Phi = self.basis.transform(X, *atleast_list(self.hypers_))

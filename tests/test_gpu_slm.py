@@ -816,3 +816,42 @@ def test_serving_state_is_reused_and_invalidated():
     assert "_serve" not in clone_.__dict__ and normwise(clone_.predict_moments(Xs)[1], Vy4) < 1e-6
     slm.fit(X, y)
     assert "_serve" not in slm.__dict__
+
+
+def test_predict_moments_of_a_large_query_is_pipelined_and_equal_to_one_shot(monkeypatch):
+    """predict_moments (slm.py:219-244) of a query above RffHandle.PREDICT_PIPELINE_ROWS: four row chunks, chunk k + 1
+    validated and uploaded by a host thread while chunk k is on the GPU -- the same numbers as the one-shot route, the same
+    exception for a non-finite row (sklearn's check_array, whichever chunk holds it), nothing left on the device."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import _hip
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    rs = np.random.RandomState(12)
+    d, n, N = 7, 96, 150_001                      # ragged: chunks of 37 632 rows, the last one 37 105
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X[:, 0]) + 0.1 * rs.randn(N)).astype(np.float32)
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(1.1, Positive()))
+    slm = StandardLinearModel(basis, var=Parameter(0.3, Positive()), nstarts=0, maxiter=2).fit(X[:5000], y[:5000])
+    calls = []
+    orig = _hip.RffHandle._predict_pipelined
+    monkeypatch.setattr(_hip.RffHandle, "_predict_pipelined", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    Ey, Vy = slm.predict_moments(X)
+    assert calls == [1]
+    monkeypatch.setenv("RR_PREDICT_PIPELINE", "0")
+    Ey1, Vy1 = slm.predict_moments(X)
+    assert calls == [1] and np.array_equal(Ey, Ey1) and normwise(Vy, Vy1) < 1e-6
+    Phi = orc.rff_transform(X[-300:].astype(np.float64), basis.W, slm.hypers_)
+    Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
+    assert normwise(Ey[-300:], Eo) < 1e-3 and normwise(Vy[-300:], Vo) < 1e-3
+    monkeypatch.delenv("RR_PREDICT_PIPELINE")
+    for bad_row in (5, 120_000, N - 1):           # first chunk, a later chunk, the ragged last chunk
+        Xb = X.copy()
+        Xb[bad_row, 2] = np.nan
+        with pytest.raises(ValueError, match="NaN"):
+            slm.predict_moments(Xb)
+    Ey2, _ = slm.predict_moments(X)               # the handle is fine after the failed calls
+    assert np.array_equal(Ey2, Ey)
+    # small queries keep the one-shot route and its up-front validation
+    with pytest.raises(ValueError, match="NaN"):
+        slm.predict_moments(Xb[N - 10:])
+    assert calls == [1, 1, 1, 1, 1]

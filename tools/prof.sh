@@ -1,18 +1,48 @@
-# Profiling recipe run on the GPU box by gpurun (outputs under gpurun_out/prof, summaries are then
-# copied to profiles/).  Kernel trace and each PMC pass are separate rocprofv3 runs.
+# Profiling recipe, run on the GPU box by gpurun; scratch under gpurun_out/prof_$ROUND (default r04), summarised into
+# profiles/${ROUND}_* by tools/summarize.py.  Kernel traces and PMC passes are SEPARATE rocprofv3 runs (gpurun refuses
+# --pmc together with the hip / hsa / memory-copy trace domains).
+#   sh tools/prof.sh [stage ...]
+# stages (kernel trace + stats of `python bench.py --configs <that configuration>`):
+#   headline  elbo  elbo64  c3  ffelbo  posdef  predict  laplace  c4  c5
+# counter passes:
+#   sq     matrix-pipe busy cycles + clock of the headline kernels and of the two second-pass kernels
+#   hbm    FETCH_SIZE / WRITE_SIZE of the headline command's launches (profiles/traffic.json)
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-OUT=gpurun_out/prof
-rm -rf $OUT; mkdir -p $OUT
-# ENGINE=bf16x3 sh tools/prof.sh profiles the split-bf16 engine instead (summarise with: summarize_prof.py <tag> rr_syrk_b16w4_kernel)
-EXTRA="--no-alt-engine --no-parity-check ${ENGINE:+--engine $ENGINE}"
-CMD="python bench.py --rows 2000000 --steps 3 --warmup 1 --no-cpu-baseline $EXTRA"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $CMD > $OUT/kt_bench.json 2> $OUT/kt.err
-PMC="python bench.py --rows 2000000 --steps 1 --warmup 0 --no-cpu-baseline $EXTRA"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o p -- $PMC > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.err
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o p -- $PMC > $OUT/pmc_write.json 2> $OUT/pmc_write.err
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -o p -- $PMC > $OUT/pmc_sq.json 2> $OUT/pmc_sq.err
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_VALU SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_lds -o p -- $PMC > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err
-find $OUT -name "*.csv" | head -40
+ROUND=${ROUND:-r04}
+OUT=gpurun_out/prof_$ROUND
+mkdir -p $OUT
+STAGES="${*:-headline elbo c3 ffelbo}"
+Q="--no-cpu-baseline --no-alt-engine --no-parity-check --config-timeout 600"
+S="--rows 1000000 --steps 1 --warmup 0"
+kt() {  # kt <tag> <bench args...>: kernel trace + stats; the bench's unabridged record next to it
+  tag=$1; shift
+  timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$tag -o kt -- python bench.py $Q --full-json $OUT/$tag.full.json "$@" > $OUT/$tag.json 2> $OUT/$tag.err
+}
+pmc() {  # pmc <tag> "<counters>" <bench args...>
+  tag=$1; ctr=$2; shift; shift
+  timeout 1200 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/$tag -o p -- python bench.py $Q --full-json $OUT/$tag.full.json "$@" > $OUT/$tag.json 2> $OUT/$tag.err
+}
+SQ="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32"
+for st in $STAGES; do case $st in
+headline) kt headline_kt --steps 3 --warmup 1 --configs none ;;
+elbo)     kt elbo_kt $S --configs c2_elbo_eval ;;
+elbo64)   kt elbo64_kt $S --configs c2f64_elbo_eval_n200k ;;
+c3)       kt c3_kt $S --configs c3 ;;
+ffelbo)   kt ffelbo_kt $S --configs c4elbo ;;
+posdef)   kt posdef_kt $S --configs posterior_f4096,posterior_f8257,posterior_f16384 ;;
+predict)  kt predict_kt $S --configs predict_moments_n300k ;;
+laplace)  kt laplace_kt $S --configs c2laplace_f64phase_n1m ;;
+c4)       kt c4_kt $S --configs c4 ;;
+c5)       kt c5_kt $S --configs c5 ;;
+sq)
+  pmc headline_sq "$SQ" --rows 2000000 --steps 1 --warmup 0 --configs none
+  pmc elbo_sq "$SQ" $S --configs c2_elbo_eval
+  pmc c3_sq "$SQ" $S --configs c3 ;;
+hbm)
+  pmc headline_fetch FETCH_SIZE --steps 1 --warmup 0 --configs none
+  pmc headline_write WRITE_SIZE --steps 1 --warmup 0 --configs none ;;
+esac; done
+find $OUT -name "*.csv" | wc -l
 du -sh $OUT
