@@ -1174,25 +1174,44 @@ class RffHandle(object):
                             T.ctypes.data_as(ctypes.c_void_p)))
         return float(sq[0]), T
 
-    PREDICT_PIPELINE_ROWS = 131072   # from this many query rows on, `predict` works in row chunks (see below)
+    PREDICT_CONCURRENT_CHECK_ROWS = 32768   # from this many query rows on, `predict` validates them on a second host thread
 
     def predict(self, X, lenscale, m, C, check_rows=None):
         """(Ey, Vf) = (Phi m, rowsum((Phi C) o Phi)) for host query rows X.  C: host (F, F) array, or a DeviceBuffer
         holding it in float64 on the device (uploaded once by the estimator).
 
         `check_rows`: the caller's validation of the rows (sklearn's `check_array`: finiteness), run by this method instead
-        of before it.  Many rows on the f32 route are then worked through in four row chunks: a host thread validates and
-        uploads chunk k + 1 (a second device context, its own stream) while the GPU computes chunk k -- the 3-4 ms of
-        `check_array` and the 2-3 ms of the pageable copy of a 300 000 x 32 query are then under the variance product instead
-        of in front of it, and the GPU does not sit idle (and clock down) before its 40 ms of MFMA work."""
+        of before it: for a large query on a host thread WHILE the rows are uploaded and the GPU works on them (3-4 ms for
+        300 000 x 32 values, as much as their upload); its exception is raised before anything is returned.  (Also tried in
+        round 4 and removed: the query in four row chunks, chunk k + 1 validated and uploaded under chunk k's product --
+        53.7 ms against 47.9 ms per 300 000-row call: the per-call host work of four product calls and their shorter
+        launches cost more than the hidden copy saves.)"""
         ls, lsp, nls = _lenscale_arg(lenscale)
         m = np.ascontiguousarray(m, dtype=np.float64)
         N = X.shape[0]
         f32_factor = isinstance(C, DeviceCovariance) and self.compute == RR_F32
-        if f32_factor and N >= self.PREDICT_PIPELINE_ROWS and os.environ.get("RR_PREDICT_PIPELINE", "1") != "0":
-            return self._predict_pipelined(X, lsp, nls, m, C, check_rows)
-        if check_rows is not None:
+        checker = None
+        if check_rows is not None and N >= self.PREDICT_CONCURRENT_CHECK_ROWS:
+            failed = []
+
+            def run_check():
+                try:
+                    check_rows(X)
+                except BaseException as e:
+                    failed.append(e)
+            checker = threading.Thread(target=run_check, name="rr-predict-check", daemon=True)
+            checker.start()
+        elif check_rows is not None:
             check_rows(X)
+        try:
+            return self._predict(X, N, lsp, nls, m, C, f32_factor)
+        finally:
+            if checker is not None:
+                checker.join()
+                if failed:
+                    raise failed[0]
+
+    def _predict(self, X, N, lsp, nls, m, C, f32_factor):
         dX = self.upload(X)
         Ey, Vf = np.empty(N), np.empty(N)
         if N and f32_factor:
@@ -1215,66 +1234,6 @@ class RffHandle(object):
                                                          Ey.ctypes.data_as(ctypes.c_void_p),
                                                          Vf.ctypes.data_as(ctypes.c_void_p)))
         dX.free()
-        return Ey, Vf
-
-    def _predict_pipelined(self, X, lsp, nls, m, C, check_rows, nchunks=4):
-        import queue
-        import threading
-        N = X.shape[0]
-        rows_per = (-(-N // nchunks) + 255) // 256 * 256
-        up = get_upload_device(self.dev.index)
-        B, form = C.factor()
-        Ey, Vf = np.empty(N), np.empty(N)
-        q = queue.Queue(maxsize=2)   # at most three chunks of X on the device
-        stop = threading.Event()
-
-        def producer():
-            try:
-                for r0 in range(0, N, rows_per):
-                    if stop.is_set():
-                        return
-                    Xc = X[r0:r0 + rows_per]
-                    if check_rows is not None:
-                        check_rows(Xc)
-                    dXc = up.upload_matrix(Xc, ld_dev=self.padded_dim)
-                    up.sync()
-                    q.put((r0, dXc))
-                q.put(None)
-            except BaseException as e:  # handed to the consumer, which raises it in the caller's thread
-                q.put(e)
-
-        t = threading.Thread(target=producer, name="rr-predict-upload", daemon=True)
-        t.start()
-        try:
-            while True:
-                item = q.get()
-                if item is None:
-                    break
-                if isinstance(item, BaseException):
-                    raise item
-                r0, dXc = item
-                rows = dXc.shape[0]
-                try:
-                    _check(self.lib, self.lib.rr_rff_predict_devb(self.h, dXc.ptr, rr_dtype(dXc.dtype), rows, dXc.ld, lsp, nls,
-                                                                  m.ctypes.data_as(ctypes.c_void_p), B.ptr, form,
-                                                                  Ey[r0:r0 + rows].ctypes.data_as(ctypes.c_void_p),
-                                                                  Vf[r0:r0 + rows].ctypes.data_as(ctypes.c_void_p)))
-                finally:
-                    dXc.free()
-        finally:
-            stop.set()
-            while t.is_alive():       # a failed call: let the producer finish its chunk and free what it queued
-                try:
-                    item = q.get(timeout=0.05)
-                    if isinstance(item, tuple):
-                        item[1].free()
-                except queue.Empty:
-                    pass
-            t.join()
-            while not q.empty():
-                item = q.get_nowait()
-                if isinstance(item, tuple):
-                    item[1].free()
         return Ey, Vf
 
     def gram_timings(self):

@@ -340,8 +340,16 @@ int rr_launch_syrk_bf16(rr_ctx *c, int nprod, const float *P, const void *pb, in
     int64_t rps = ((rows64 + nsplit - 1) / nsplit + 63) / 64 * 64;
     const char *renv = getenv("RR_GRAM_ROWS_PER_SPLIT");
     if (renv && atoll(renv) >= 64) rps = (atoll(renv) / 64) * 64;
+    else
+        while (rps > 64 && (rps / 16) * ldp * 64 + 32768 >= (int64_t)1 << 31) rps = (rps / 2 + 63) / 64 * 64;  // (see the check below)
     nsplit = (rows64 + rps - 1) / rps;
     RR_REQUIRE(nsplit * ntiles < (int64_t)1 << 31, "gram: grid too large");
+    // the kernel's LDS-DMA addresses a K-split's stages through ONE buffer descriptor with 32-bit offsets: stage g of the
+    // split sits g * ldp * 64 bytes behind its first (a wide matrix or a large RR_GRAM_ROWS_PER_SPLIT would wrap
+    // silently and the Gram would be wrong)
+    RR_REQUIRE((rps / 16) * ldp * 64 + 32768 < (int64_t)1 << 31,
+               "gram (split 16-bit engine): %lld rows per K-split of a %lld-column feature matrix exceed the kernel's 32-bit "
+               "stage offsets: lower RR_GRAM_ROWS_PER_SPLIT", (long long)rps, (long long)ldp);
     SyrkArgs a;
     a.P = (const float *)pb; a.rows = rows64; a.ldp = ldp; a.F = F; a.nb = nb; a.ntiles = ntiles; a.rows_per_split = rps;
     a.G = dG;

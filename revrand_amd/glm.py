@@ -135,10 +135,17 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
                        prefetch=prefetch, sync=sync)
         finally:
+            # (sgd has stopped and joined its prefetch worker by now, also when `_elbo` raised; what the worker queued on the
+            # upload context's stream must have landed before the buffers it wrote to are freed)
+            upb = self.__dict__.pop("_batch_upload", None)
+            up = self.__dict__.pop("_draw_upload", None)
+            for ctx in {id(c): c for c in (upb, up[0] if up is not None else None) if c is not None}.values():
+                try:
+                    ctx.sync()
+                except Exception:  # the original exception, if any, is the one to report
+                    log.exception("synchronising the upload context failed")
             self._resident_fit = False
             self._release_features()
-            self.__dict__.pop("_batch_upload", None)
-            up = self.__dict__.pop("_draw_upload", None)
             if up is not None:
                 for buf in up[1]:
                     if buf is not None:

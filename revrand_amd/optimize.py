@@ -333,8 +333,12 @@ def _prefetched(batches, augment=None):
     finally:
         stop.set()
         # the worker may be in the middle of a batch (`augment` uploads and gathers on the device for the GLM): let it finish
-        # that one before the caller frees what it writes to
+        # that one before the caller frees what it writes to.  (`sgd` closes this generator explicitly when its objective
+        # raises: the traceback would otherwise keep it -- and the worker -- alive past the caller's cleanup.)
         worker.join(timeout=60.0)
+        if worker.is_alive():
+            log.error("the minibatch prefetch worker is still running 60 s after it was told to stop: device buffers it "
+                      "writes to may be freed under it")
 
 
 def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, updater=None, eval_obj=False,
@@ -358,21 +362,26 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
         upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
     obj, objs, norms = None, [], []
     batches = gen_batch(data, batch_size, maxiter, random_state)
-    for batch in (_prefetched(batches, prefetch if callable(prefetch) else None) if prefetch else batches):
-        if not eval_obj:
-            grad = fun(x, *(list(batch) + list(args)))
-        else:
-            obj, grad = fun(x, *(list(batch) + list(args)))
-            objs.append(obj)
-        norms.append(float(np.sqrt(np.square(grad).sum())))  # np.linalg.norm, without a threaded BLAS call per step
-        if bounds is not None:
-            xlower = x <= lower
-            grad[xlower] = np.minimum(grad[xlower], 0)
-            xupper = x >= upper
-            grad[xupper] = np.maximum(grad[xupper], 0)
-        x = updater(x, grad)
-        if bounds is not None:
-            x = np.clip(x, lower, upper)
+    ahead = _prefetched(batches, prefetch if callable(prefetch) else None) if prefetch else None
+    try:
+        for batch in (ahead if ahead is not None else batches):
+            if not eval_obj:
+                grad = fun(x, *(list(batch) + list(args)))
+            else:
+                obj, grad = fun(x, *(list(batch) + list(args)))
+                objs.append(obj)
+            norms.append(float(np.sqrt(np.square(grad).sum())))  # np.linalg.norm, without a threaded BLAS call per step
+            if bounds is not None:
+                xlower = x <= lower
+                grad[xlower] = np.minimum(grad[xlower], 0)
+                xupper = x >= upper
+                grad[xupper] = np.maximum(grad[xupper], 0)
+            x = updater(x, grad)
+            if bounds is not None:
+                x = np.clip(x, lower, upper)
+    finally:
+        if ahead is not None:
+            ahead.close()  # stops and joins the worker NOW: the caller frees what the worker's batches write to next
     return OptimizeResult(x=x, norms=norms, message='maxiter reached', fun=obj, objs=objs)
 
 

@@ -17,6 +17,7 @@ Transports (a ``Comm`` object; ``get_comm()`` picks one):
 * ``SingleComm`` -- one rank, every collective a no-op.
 """
 import ctypes
+import logging
 import os
 import socket
 import sys
@@ -24,6 +25,8 @@ import tempfile
 import time
 
 import numpy as np
+
+log = logging.getLogger(__name__)
 
 _OPS = {"sum": 0, "max": 1, "min": 2}
 
@@ -113,18 +116,25 @@ class RcclComm(Comm):
         self._assert_same_rccl()
 
     def _assert_same_rccl(self):
-        """Every rank must have bound the same librccl (version and file): a mixed job -- one rank on the torch wheel's
-        RCCL, another on /opt/rocm's -- may run, and then fail in a collective much later.  One tiny all-reduce."""
+        """Every rank must have bound the same RCCL VERSION: a mixed job -- one rank on the torch wheel's RCCL, another on
+        /opt/rocm's -- may run, and then fail in a collective much later.  One tiny all-reduce.  Only a version mismatch is
+        fatal: the same build installed under different prefixes on different nodes (per-node virtualenvs, /opt/rocm-X.Y
+        symlink targets) is fine, so differing library FILE NAMES are a logged warning, and an unknown path (the loader
+        resolved a bare soname) is not compared at all."""
         if self.world < 2:
             return
         import zlib
-        tag = float(zlib.crc32(os.path.realpath(self.rccl_library).encode()))
+        name = os.path.basename(self.rccl_library) if self.rccl_library else ""
+        tag = float(zlib.crc32(name.encode())) if name else 0.0
         v = float(self.rccl_version)
         hi = self.allreduce_host(np.array([v, -v, tag, -tag]), op="max")
-        if hi[0] != -hi[1] or hi[2] != -hi[3]:
-            raise RuntimeError("rank %d bound RCCL %d from %s, but the ranks of this job do not all use the same librccl "
-                               "(versions %d..%d): start every rank with the same RR_HIP_RUNTIME / RR_RCCL_LIB"
-                               % (self.rank, self.rccl_version, self.rccl_library, int(-hi[1]), int(hi[0])))
+        if hi[0] != -hi[1]:
+            raise RuntimeError("rank %d bound RCCL %d from %s, but the ranks of this job do not all use the same RCCL version "
+                               "(%d..%d): start every rank with the same RR_HIP_RUNTIME / RR_RCCL_LIB"
+                               % (self.rank, self.rccl_version, self.rccl_library or "(unknown path)", int(-hi[1]), int(hi[0])))
+        if hi[2] != -hi[3] and self.rank == 0:
+            log.warning("the ranks bound RCCL %d from library files of different names (rank 0: %s): the same version, "
+                        "so the job goes on", self.rccl_version, name or "(unknown)")
 
     @staticmethod
     def load(path=None):
@@ -230,6 +240,7 @@ class TorchComm(Comm):
 # ------------------------------------------------------------------------------------------------
 
 _ID_MAGIC = b"RRCCLID1"
+_ID_ACK = b"\x06"
 
 
 def _rdzv_dir():
@@ -335,7 +346,11 @@ def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
             srv.bind((host if host.startswith("127.") or host == "localhost" else "", int(port)))
             srv.listen(max(world, 8))
             served = set()
-            while len(served) < world - 1:  # one reply per DISTINCT valid rank; anything else is dropped
+            # A rank counts as served when it ACKNOWLEDGED the id (one byte back), not when sendall() returned: a client
+            # whose 5 s receive timeout fired while this single-threaded server was held up by junk connections has closed
+            # its socket, the send into it may still "succeed", and its retry must then be answered -- so requests of
+            # already-served ranks are answered as well, and only distinct acknowledged ranks end the loop.
+            while len(served) < world - 1:
                 left = deadline - time.time()
                 if left <= 0:
                     srv.close()
@@ -355,9 +370,10 @@ def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
                         req += part
                     if len(req) == 16 and req[:12] == token:
                         r = struct.unpack("<i", req[12:])[0]
-                        if 1 <= r < world and r not in served:
+                        if 1 <= r < world:
                             c.sendall(ident)
-                            served.add(r)
+                            if c.recv(1) == _ID_ACK:
+                                served.add(r)
                 except OSError:
                     pass
                 finally:
@@ -374,9 +390,11 @@ def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
                     if not part:
                         break
                     ident += part
-                c.close()
                 if len(ident) == 128:
+                    c.sendall(_ID_ACK)
+                    c.close()
                     return ident
+                c.close()
             except OSError:
                 pass
             time.sleep(0.05)

@@ -112,6 +112,12 @@ def test_id_rendezvous_tcp_serves_each_rank_once_and_ignores_strangers():
         c = socket.create_connection(("127.0.0.1", port), timeout=5)
         c.sendall(junk)
         c.close()
+    #  a client whose receive timed out: it asked as rank 1, got no chance to read the reply and hung up without
+    # acknowledging -- rank 1 is NOT served by that, its retry below must still be answered
+    import struct
+    c = socket.create_connection(("127.0.0.1", port), timeout=5)
+    c.sendall(struct.pack("<8sii", b"RRCCLREQ", 3, 0)[:12] + struct.pack("<i", 1))
+    c.close()
     ts = [threading.Thread(target=run, args=(r,)) for r in (1, 2)]
     for t in ts:
         t.start()

@@ -818,40 +818,40 @@ def test_serving_state_is_reused_and_invalidated():
     assert "_serve" not in slm.__dict__
 
 
-def test_predict_moments_of_a_large_query_is_pipelined_and_equal_to_one_shot(monkeypatch):
-    """predict_moments (slm.py:219-244) of a query above RffHandle.PREDICT_PIPELINE_ROWS: four row chunks, chunk k + 1
-    validated and uploaded by a host thread while chunk k is on the GPU -- the same numbers as the one-shot route, the same
-    exception for a non-finite row (sklearn's check_array, whichever chunk holds it), nothing left on the device."""
+def test_predict_moments_validates_a_large_query_while_the_gpu_works_on_it(monkeypatch):
+    """predict_moments (slm.py:219-244) of a query above RffHandle.PREDICT_CONCURRENT_CHECK_ROWS: sklearn's check_array runs on
+    a host thread while the rows are uploaded and the GPU works on them -- the same numbers as validating first, the same
+    exception for a non-finite row, raised before anything is returned; small queries are validated up front."""
+    import threading
     import revrand_amd.basis_functions as bs
     from revrand_amd import _hip
     from revrand_amd.btypes import Parameter, Positive
     from revrand_amd.slm import StandardLinearModel
     rs = np.random.RandomState(12)
-    d, n, N = 7, 96, 150_001                      # ragged: chunks of 37 632 rows, the last one 37 105
+    d, n, N = 7, 96, 150_001
     X = rs.randn(N, d).astype(np.float32)
     y = (np.sin(X[:, 0]) + 0.1 * rs.randn(N)).astype(np.float32)
     basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(1.1, Positive()))
     slm = StandardLinearModel(basis, var=Parameter(0.3, Positive()), nstarts=0, maxiter=2).fit(X[:5000], y[:5000])
-    calls = []
-    orig = _hip.RffHandle._predict_pipelined
-    monkeypatch.setattr(_hip.RffHandle, "_predict_pipelined", lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1])
+    names = []
+    orig = _hip.RffHandle._predict
+    monkeypatch.setattr(_hip.RffHandle, "_predict",
+                        lambda self, *a, **k: (names.append([t.name for t in threading.enumerate()]), orig(self, *a, **k))[1])
     Ey, Vy = slm.predict_moments(X)
-    assert calls == [1]
-    monkeypatch.setenv("RR_PREDICT_PIPELINE", "0")
+    assert len(names) == 1 and "rr-predict-check" in names[0]
+    monkeypatch.setattr(_hip.RffHandle, "PREDICT_CONCURRENT_CHECK_ROWS", 10 ** 9)   # validate first
     Ey1, Vy1 = slm.predict_moments(X)
-    assert calls == [1] and np.array_equal(Ey, Ey1) and normwise(Vy, Vy1) < 1e-6
+    assert "rr-predict-check" not in names[1] and np.array_equal(Ey, Ey1) and np.array_equal(Vy, Vy1)
     Phi = orc.rff_transform(X[-300:].astype(np.float64), basis.W, slm.hypers_)
     Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
     assert normwise(Ey[-300:], Eo) < 1e-3 and normwise(Vy[-300:], Vo) < 1e-3
-    monkeypatch.delenv("RR_PREDICT_PIPELINE")
-    for bad_row in (5, 120_000, N - 1):           # first chunk, a later chunk, the ragged last chunk
+    monkeypatch.undo()
+    for bad_row in (5, N - 1):
         Xb = X.copy()
-        Xb[bad_row, 2] = np.nan
-        with pytest.raises(ValueError, match="NaN"):
+        Xb[bad_row, 2] = np.inf
+        with pytest.raises(ValueError, match="infinity"):
             slm.predict_moments(Xb)
-    Ey2, _ = slm.predict_moments(X)               # the handle is fine after the failed calls
+        with pytest.raises(ValueError, match="infinity"):
+            slm.predict_moments(Xb[bad_row - 5 if bad_row > 5 else 0:][:64])   # a small query: validated up front
+    Ey2, _ = slm.predict_moments(X)               # nothing is left behind by the failed calls
     assert np.array_equal(Ey2, Ey)
-    # small queries keep the one-shot route and its up-front validation
-    with pytest.raises(ValueError, match="NaN"):
-        slm.predict_moments(Xb[N - 10:])
-    assert calls == [1, 1, 1, 1, 1]

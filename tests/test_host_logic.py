@@ -437,3 +437,34 @@ def test_bench_line_is_numbers_only_and_small():
         bench.parity("Gram of 4096 rows vs oracle", 0.3, 1e-4)
     with pytest.raises(bench.ParityError):
         bench.parity("x", float("nan"), 1e-4)
+
+
+def test_sgd_stops_its_prefetch_worker_before_an_exception_of_the_objective_leaves_it():
+    """when `fun` raises inside `sgd`, the traceback keeps the prefetching generator -- and its worker thread -- alive
+    past the caller's cleanup (glm.fit frees the device buffers the worker's next batch writes to).  `sgd` closes the
+    generator itself: by the time the exception reaches the caller the worker has been told to stop and has been joined."""
+    import threading
+    import time
+    from revrand_amd.optimize import sgd
+    started, slow = [], threading.Event()
+
+    def augment(batch):          # runs on the worker thread, one batch ahead of the step
+        started.append(threading.current_thread())
+        if len(started) >= 3:
+            slow.set()
+            time.sleep(0.3)      # the worker is in the middle of a batch when the objective raises
+        return batch
+
+    def fun(x, Xb):
+        if slow.wait(5.0):
+            raise RuntimeError("objective failed")
+        return np.zeros_like(x)
+
+    X = np.arange(200.0).reshape(100, 2)
+    with pytest.raises(RuntimeError, match="objective failed"):
+        sgd(fun, np.zeros(3), X, batch_size=10, maxiter=50, prefetch=augment, random_state=np.random.RandomState(0))
+    assert started and not started[0].is_alive()
+    # and a run that finishes normally leaves no worker either
+    res = sgd(lambda x, Xb: np.ones_like(x), np.zeros(3), X, batch_size=10, maxiter=5, prefetch=lambda b: b,
+              random_state=np.random.RandomState(0))
+    assert res.x.shape == (3,) and threading.active_count() <= 2
