@@ -759,9 +759,8 @@ __device__ __forceinline__ void syrk_dma_tile(const SyrkArgs &p, float *buf, int
 // MODE 0: flat LDS-DMA right after the barrier (rounds 1-2).  1: the same, staggered over the first k-step pairs.
 // 2: buffer-descriptor LDS-DMA (rr_dma_kblock) right after the barrier.  3: buffer-descriptor LDS-DMA, staggered (the default).
 template <int MODE>
-__device__ __forceinline__ void rr_syrk_f32_body(const SyrkArgs &p) {
+__device__ __forceinline__ void rr_syrk_f32_body(const SyrkArgs &p, float *lds, const unsigned bid) {  // lds: two [32][512] tiles (128 KiB)
     constexpr bool STAG = (MODE & 1) != 0, BUF = (MODE & 2) != 0;
-    __shared__ float lds[2 * GR_KB * GR_LD];  // 128 KiB: two [32][512] tiles
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -770,8 +769,8 @@ __device__ __forceinline__ void rr_syrk_f32_body(const SyrkArgs &p) {
     // tile (ta <= tb) and K-split of this workgroup.  Workgroups are dispatched round-robin over
     // the 8 XCDs (block b -> XCD b % 8, observed); tile_map orders the tiles so that the ones an
     // XCD receives share column blocks of P and its 4 MiB L2 fetches each of them once.
-    int tdx = blockIdx.x % p.ntiles;
-    const int ks = blockIdx.x / p.ntiles;
+    int tdx = bid % p.ntiles;
+    const int ks = bid / p.ntiles;
     if (p.tile_map) tdx = p.tile_map[tdx];
     int ta = 0;
     const int od = p.offdiag_only;  // row ta then holds nb - ta - od tiles
@@ -863,10 +862,16 @@ __device__ __forceinline__ void rr_syrk_f32_body(const SyrkArgs &p) {
     (void)F;
 }
 
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_kernel(const SyrkArgs p) { rr_syrk_f32_body<3>(p); }  // the default
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_flat_kernel(const SyrkArgs p) { rr_syrk_f32_body<0>(p); }
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_flatstag_kernel(const SyrkArgs p) { rr_syrk_f32_body<1>(p); }
-__global__ void __launch_bounds__(GR_THREADS, 2) rr_syrk_f32_buf_kernel(const SyrkArgs p) { rr_syrk_f32_body<2>(p); }
+#define RR_SYRK_KERNEL(NAME, MODE)                                                       \
+    __global__ void __launch_bounds__(GR_THREADS, 2) NAME(const SyrkArgs p) {             \
+        __shared__ float lds[2 * GR_KB * GR_LD];                                          \
+        rr_syrk_f32_body<MODE>(p, lds, blockIdx.x);                                       \
+    }
+RR_SYRK_KERNEL(rr_syrk_f32_kernel, 3)  // the default
+RR_SYRK_KERNEL(rr_syrk_f32_flat_kernel, 0)
+RR_SYRK_KERNEL(rr_syrk_f32_flatstag_kernel, 1)
+RR_SYRK_KERNEL(rr_syrk_f32_buf_kernel, 2)
+#undef RR_SYRK_KERNEL
 
 // ---------------------------------------------------------------------------------------
 // Ragged last column block (round 2).  When F is not a multiple of 256 the last column block holds only
@@ -1190,9 +1195,9 @@ __device__ __forceinline__ void gram_mfma_d16(const KOpsD16<NB, ED> &o, floatx16
 // per-k-block barrier + DMA burst should weigh twice as much; 64-row k-blocks (128 KiB of LDS -- the kernel runs one
 // workgroup per CU either way: 152 VGPRs) halve their number -- and change nothing (87.9 vs 86.6 ms per 10M rows).
 template <int NB, int ED, int KB>
-__device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, int wave, int lane) {
-    const int ta = blockIdx.x % p.nb;
-    const int ks = blockIdx.x / p.nb;
+__device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, int wave, int lane, const unsigned bid) {
+    const int ta = bid % p.nb;
+    const int ks = bid / p.nb;
     const int ca = ta * GR_TC;
     const int64_t row_begin = (int64_t)ks * p.rows_per_split;
     int64_t row_end = row_begin + p.rows_per_split;
@@ -1291,18 +1296,32 @@ __device__ __forceinline__ void syrk_diag16_body(const SyrkArgs &p, float *lds, 
 #undef RR_PAIRD16
 
 template <int KB>
-__global__ void __launch_bounds__(GR_THREADS, 2)
-rr_syrk_f32_diag16_kernel(const SyrkArgs p) {
-    __shared__ float lds[2 * KB * GR_TC];  // two [KB][256] tiles (A side only): 64 / 128 KiB
+__device__ __forceinline__ void syrk_diag16_dispatch(const SyrkArgs &p, float *lds, const unsigned bid) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     switch (wave) {  // wave-uniform: every path runs the same barriers; (NB, ED) as laid out in RR_DIAG_I / RR_DIAG_J
-        case 0: case 1: case 2: case 3: syrk_diag16_body<5, 0, KB>(p, lds, wave, lane); break;
-        case 4: syrk_diag16_body<4, 3, KB>(p, lds, wave, lane); break;
-        case 5: syrk_diag16_body<4, 2, KB>(p, lds, wave, lane); break;
-        case 6: syrk_diag16_body<4, 1, KB>(p, lds, wave, lane); break;
-        default: syrk_diag16_body<4, 0, KB>(p, lds, wave, lane); break;
+        case 0: case 1: case 2: case 3: syrk_diag16_body<5, 0, KB>(p, lds, wave, lane, bid); break;
+        case 4: syrk_diag16_body<4, 3, KB>(p, lds, wave, lane, bid); break;
+        case 5: syrk_diag16_body<4, 2, KB>(p, lds, wave, lane, bid); break;
+        case 6: syrk_diag16_body<4, 1, KB>(p, lds, wave, lane, bid); break;
+        default: syrk_diag16_body<4, 0, KB>(p, lds, wave, lane, bid); break;
     }
+}
+
+template <int KB>
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_f32_diag16_kernel(const SyrkArgs p) {
+    __shared__ float lds[2 * KB * GR_TC];  // two [KB][256] tiles (A side only): 64 / 128 KiB
+    syrk_diag16_dispatch<KB>(p, lds, blockIdx.x);
+}
+
+// Experiment of round 4 (RR_SYRK_MERGE_DIAG=1): ONE launch for the whole Gram -- the off-diagonal tiles'
+// workgroups first, the diagonal tiles' (their own K-splits, their own code path) behind them in the same grid.
+__global__ void __launch_bounds__(GR_THREADS, 2)
+rr_syrk_f32_merged_kernel(const SyrkArgs p, const SyrkArgs pd, const unsigned n_off) {
+    __shared__ float lds[2 * GR_KB * GR_LD];
+    if (blockIdx.x < n_off) rr_syrk_f32_body<3>(p, lds, blockIdx.x);
+    else syrk_diag16_dispatch<32>(pd, lds, blockIdx.x - n_off);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2455,6 +2474,20 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     // RR_SYRK_STAGGER = 0 / 1 / 2: the flat LDS-DMA of rounds 1-2 / the same staggered / buffer-descriptor requests right after
     // the barrier (A/B runs: 217.8 / 245 / 214.4 ms per 2M-row launch against 211.1 ms for the default, 3)
     static const int syrk_mode = getenv("RR_SYRK_STAGGER") ? atoi(getenv("RR_SYRK_STAGGER")) : 3;
+    static const bool merge_diag = getenv("RR_SYRK_MERGE_DIAG") != nullptr && atoi(getenv("RR_SYRK_MERGE_DIAG")) != 0;
+    if (merge_diag && od && !rg && ntiles > 0 && syrk_mode == 3 && !a.ablate && !getenv("RR_SYRK_NO_DIAG16")) {
+        SyrkArgs ad = a;
+        ad.nb = nb_all;
+        ad.rows_per_split = rps_d;
+        const unsigned n_off = (unsigned)(nsplit * ntiles);
+        hipLaunchKernelGGL(rr_syrk_f32_merged_kernel, dim3(n_off + (unsigned)(nsplit_d * nb_all)), dim3(GR_THREADS), 0, c->stream, a, ad, n_off);
+        if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
+        if (a.part)
+            hipLaunchKernelGGL(rr_syrk_det_reduce_kernel<float>, dim3((unsigned)((F + 1 + 255) / 256), (unsigned)F), dim3(256), 0,
+                               c->stream, a.part, a.part_stride, ldp, F, (int)nsplit, dG, bcol);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
     if (ntiles > 0) {
         if (syrk_mode == 1 && !a.ablate)
             hipLaunchKernelGGL(rr_syrk_f32_flatstag_kernel, dim3((unsigned)(nsplit * ntiles)), dim3(GR_THREADS), 0, c->stream, a);
