@@ -2,7 +2,7 @@
 # Same-box A/B runs of bench.py under environment switches (every gpurun call lands on a different box, and boxes differ by
 # 1-2 %: only runs of ONE call compare).  One script for every measurement switch of DESIGN.md 8.1 / docs/KERNELS.md:
 #
-#   sh tools/ab.sh <name> "<arm>|<arm>|..." "<bench.py arguments>" [reps] [pytest selection run under every arm first]
+#   bash tools/ab.sh <name> "<arm>|<arm>|..." "<bench.py arguments>" [reps] [pytest selection run under every arm first]
 #
 # an arm is a list of VAR=value settings ("" = the default build); arms alternate rep by rep; every run's unabridged record
 # goes to gpurun_out/ab_<name>/<arm index>_<rep>.json and a table of the numbers that matter is printed at the end.
@@ -21,7 +21,7 @@
 #   posterior  "RR_POSDEF_LOOKAHEAD=0|RR_GEMM64_K128=0|RR_SYRK64_TRI=0|RR_CHOL_DIAG=0|RR_POSDEF_OVERLAP=0|" \
 #              "--no-parity-check --rows 1000000 --steps 1 --warmup 0 --configs posterior_f4096,posterior_f8257,posterior_f16384"
 #   fastfood   "RR_FASTFOOD_FIT=dense|"                               "--rows 1000000 --steps 1 --warmup 0 --configs c4elbo"
-#   det        "RR_DETERMINISTIC=1|"                                  "--steps 3 --warmup 1 --configs c2_elbo_eval"
+"  |"                                  "--steps 3 --warmup 1 --configs c2_elbo_eval"
 name=${1:?name}; arms=${2:?arms}; args=${3:?bench arguments}; reps=${4:-2}; tests=$5
 cd ${GRAFT_REPO_ROOT:-.}
 out=gpurun_out/ab_$name
