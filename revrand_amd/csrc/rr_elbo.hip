@@ -64,6 +64,7 @@ struct GemmArgs {
     int K, ntb;  // ntb = N / 256 column tiles (fastest-varying in blockIdx)
     int kb_per_split = 0;  // > 0: blockIdx.y owns k-blocks [y * kb_per_split, ...) and ADDS into a zeroed D (f32 atomics)
     int upper_b = 0;  // B (K, N) with K == N is upper triangular: column tile tb needs only k < 256 (tb + 1)
+    int pair_upper = 0;  // with upper_b: rr_gemm_pair_f32_kernel, one workgroup per PAIR of column tiles (ntb - 1 - q, q)
     // TRIG epilogue (random Fourier features of Xdim > 128, rr_rff.hip): the product is the phase matrix Z in
     // revolutions; D is the feature matrix P: P[r][c] = cos(2 pi Z[r][c]) scale, P[r][n + c] = sin(..) scale for
     // c < n, zero rows for nvalid <= r < nout, nothing beyond; bvec += P^T y.
@@ -211,6 +212,86 @@ __device__ __forceinline__ void rr_gemm_tn_f32_body(const GemmArgs &p) {
 
 __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_tn_f32_kernel(const GemmArgs p) { rr_gemm_tn_f32_body<false>(p); }
 __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_trig_f32_kernel(const GemmArgs p) { rr_gemm_tn_f32_body<true>(p); }
+
+// Prediction's triangular product (B upper triangular: column tile tb needs k < 256 (tb + 1) only) with EQUAL-COST workgroups:
+// a workgroup owns the column tiles ntb - 1 - q and q of its row tile -- their k-ranges add up to the same for every q.  With
+// one tile per workgroup the costs spread 1 : ntb, and the dispatcher, which hands workgroups to the 8 XCDs strictly in turn,
+// left CUs idle behind XCDs still busy with long tiles: the matrix pipe was 94 % busy on the CUs that had work, yet the launch
+// reached 0.84 of the peak on its issued MFMAs (profiles/r04_predict).  The second tile's first k-block is requested before
+// the first tile's epilogue.  Epilogue: row sums of squares (p.rowsq) or a plain store.
+__global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_pair_f32_kernel(const GemmArgs p) {
+    __shared__ float lds[2 * GR_KB * GR_LD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nq = (p.ntb + 1) / 2;
+    const int64_t ta = blockIdx.x / nq;
+    const int q = (int)((blockIdx.x % nq + ta) % nq);  // (rotated by the row tile: neighbouring blocks share B's column tiles in L2)
+    const int ntile = p.ntb - 1 - q > q ? 2 : 1;
+    const int64_t ca = ta * GR_TC;
+    const int wr = wave >> 2, wc_ = wave & 3, hi = lane >> 5;
+    const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
+    const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
+    const unsigned voff = 16u * lane;
+    const int slot = __builtin_amdgcn_readfirstlane(rr_dma_slot(wave, p.spread));
+    const int nkb_all = p.K / GR_KB;
+    auto dma_tile = [&](float *buf, int kb0, int cbt) {
+        rr_dma_kblock(p.A + (int64_t)kb0 * p.lda + ca, p.lda, p.B + (int64_t)kb0 * p.ldb + cbt, p.ldb, buf, wave, voff);
+    };
+    dma_tile(lds, 0, (ntile == 2 ? p.ntb - 1 - q : q) * GR_TC);
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+        const int tb = (t == 0 && ntile == 2) ? p.ntb - 1 - q : q;  // the long tile first
+        const int cb = tb * GR_TC;
+        int nkb = (tb + 1) * (GR_TC / GR_KB);
+        nkb = nkb < nkb_all ? nkb : nkb_all;
+        floatx16 acc[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        __syncthreads();  // this tile's first k-block has landed
+        for (int kb = 0; kb < nkb; ++kb) {
+            const int cbuf = kb & 1;
+            gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, slot, [&]() {
+                if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB, cb);
+            });
+            __syncthreads();
+        }
+        if (t + 1 < ntile) dma_tile(lds, 0, q * GR_TC);  // (every wave is past the last barrier: both buffers are free)
+        if (p.rowsq) {
+            // one f64 atomic per row and half wave through a buffer descriptor over rowsq: lanes that do not hold a row's sum
+            // and rows past the end get an offset outside its extent and the hardware drops them (no lane mask per element:
+            // 64 of them would push the k-loop's scalars out of the SGPR file, see rr_gemm_gradt_f32_kernel's flush)
+            const rr_rsrc_t qrs = rr_make_rsrc(p.rowsq, (unsigned)p.rowsq_rows * 8u);
+            unsigned qo = (lane & 31) == 0 ? (unsigned)(ca + wr * 128 + 4 * hi) * 8u : 0x40000000u;
+            asm volatile("" : "+v"(qo));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = fmaf(acc[i][0][e], acc[i][0][e], acc[i][1][e] * acc[i][1][e]);
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                    const double dv = (double)v;
+                    const unsigned off = qo + (unsigned)(i * 32 + (e & 3) + 8 * (e >> 2)) * 8u;
+                    asm volatile("buffer_atomic_add_f64 %0, %1, %2, 0 offen" : : "v"(dv), "v"(off), "s"(qrs) : "memory");
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int64_t gr = ca + wr * 128 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) p.D[gr * p.ldd + cb + wc_ * 64 + j * 32 + (lane & 31)] = acc[i][j][e];
+                }
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // The GLM step's third product WITH its consumer (glm.py:275-283 for a random Fourier basis): the 256x256 block of
@@ -817,8 +898,12 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
         const int64_t mpad = (mrows + 255) / 256 * 256;
         const TX *Xc = dX + r0 * ldx;
         bool fused_vf = false;
+        // prediction in the factor form sums the squares of Phi B in the product's epilogue: nothing reads the row-major P
+        static const bool no_predict_fuse = getenv("RR_PREDICT_NO_FUSE") != nullptr;
+        const bool will_fuse_vf = pred && Bprep && form == 1 && !c->deterministic && c->gram_engine == 0 && !no_predict_fuse;
+        const bool need_p = !(will_fuse_vf && !b->large && !b->phase64);
         // row-major P (epilogues) and feature-major Pt + Phi m (GEMM operand)
-        rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp, true);
+        if (need_p) rc = rr_features_rowmajor_f32(b, Xc, sizeof(TX) == 4 ? RR_F32 : RR_F64, mrows, mpad, ldx, s.P, Fp, true);
         if (rc != RR_OK) break;
         if (b->large || b->phase64) {  // no feature-major kernel for these: transpose the row-major features
             hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(mpad / 64)), dim3(256), 0, c->stream,
@@ -856,13 +941,17 @@ static int pass2_run(rr_basis *b, bool pred, const TX *dX, const TX *dy, int64_t
             GemmArgs g;
             g.A = s.Pt; g.B = Bprep ? Bprep : s.C32; g.D = s.U; g.lda = chunk; g.ldb = Fp; g.ldd = Fp; g.K = (int)(((int64_t)F + GR_KB - 1) / GR_KB * GR_KB); g.ntb = (int)(Fp / 256);  // K: the valid feature rows only (the rest of Fp is zero padding)
             g.upper_b = pred ? 1 : 0;
-            if (pred && Bprep && form == 1 && !c->deterministic && !getenv("RR_PREDICT_NO_FUSE")) {  // Vf = rowsum((Phi B)^2) summed in the product's epilogue
+            if (will_fuse_vf) {  // Vf = rowsum((Phi B)^2) summed in the product's epilogue
                 e = hipMemsetAsync(s.acc, 0, (size_t)mrows * 8, c->stream);
                 g.rowsq = s.acc;
                 g.rowsq_rows = mrows;
                 fused_vf = true;
             }
-            hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+            static const bool no_pair = getenv("RR_PREDICT_NO_PAIR") != nullptr;
+            g.pair_upper = (g.upper_b && !no_pair) ? 1 : 0;
+            const int64_t wg_per_row_tile = g.pair_upper ? (g.ntb + 1) / 2 : g.ntb;
+            if (g.pair_upper) hipLaunchKernelGGL(rr_gemm_pair_f32_kernel, dim3((unsigned)((mpad / 256) * wg_per_row_tile)), dim3(GR_THREADS), 0, c->stream, g);
+            else hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((mpad / 256) * wg_per_row_tile)), dim3(GR_THREADS), 0, c->stream, g);
         }
         if (hipGetLastError() != hipSuccess) {
             rr_set_error("pass2: gemm launch failed");
@@ -1390,7 +1479,11 @@ static int fm_pass2_products(rr_featmat *fm, FmPass2 &s, double *rowsq = nullptr
     g.upper_b = s.tri_c ? 1 : 0;
     g.rowsq = rowsq;
     g.rowsq_rows = fm->rows;
-    hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * g.ntb)), dim3(GR_THREADS), 0, c->stream, g);
+    static const bool no_pair = getenv("RR_PREDICT_NO_PAIR") != nullptr;
+    g.pair_upper = (g.upper_b && !no_pair) ? 1 : 0;  // equal-cost workgroups: column tiles (q, ntb - 1 - q) together
+    const int64_t wg_per_row_tile = g.pair_upper ? (g.ntb + 1) / 2 : g.ntb;
+    if (g.pair_upper) hipLaunchKernelGGL(rr_gemm_pair_f32_kernel, dim3((unsigned)((rows256 / 256) * wg_per_row_tile)), dim3(GR_THREADS), 0, c->stream, g);
+    else hipLaunchKernelGGL(rr_gemm_tn_f32_kernel, dim3((unsigned)((rows256 / 256) * wg_per_row_tile)), dim3(GR_THREADS), 0, c->stream, g);
     RR_CHECK_HIP(hipGetLastError());
     return RR_OK;
 }

@@ -21,7 +21,9 @@
 #   posterior  "RR_POSDEF_LOOKAHEAD=0|RR_GEMM64_K128=0|RR_SYRK64_TRI=0|RR_CHOL_DIAG=0|RR_POSDEF_OVERLAP=0|" \
 #              "--no-parity-check --rows 1000000 --steps 1 --warmup 0 --configs posterior_f4096,posterior_f8257,posterior_f16384"
 #   fastfood   "RR_FASTFOOD_FIT=dense|"                               "--rows 1000000 --steps 1 --warmup 0 --configs c4elbo"
-"  |"                                  "--steps 3 --warmup 1 --configs c2_elbo_eval"
+#   mergediag  "RR_SYRK_MERGE_DIAG=1|"                                "--steps 3 --warmup 1 --configs none"   (profiles/r04_diag)
+#   predictpair "RR_PREDICT_NO_PAIR=1|"                               "--rows 1000000 --steps 1 --warmup 0 --configs predict_moments_n300k"
+#   det        "RR_DETERMINISTIC=1|"                                  "--steps 3 --warmup 1 --configs c2_elbo_eval"
 name=${1:?name}; arms=${2:?arms}; args=${3:?bench arguments}; reps=${4:-2}; tests=$5
 cd ${GRAFT_REPO_ROOT:-.}
 out=gpurun_out/ab_$name

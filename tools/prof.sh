@@ -5,7 +5,7 @@
 # stages (kernel trace + stats of `python bench.py --configs <that configuration>`):
 #   headline  elbo  elbo64  c3  ffelbo  posdef  predict  laplace  c4  c5
 # counter passes:
-#   sq     matrix-pipe busy cycles + clock of the headline kernels and of the two second-pass kernels
+#   sq     matrix-pipe busy cycles + clock of the headline kernels and of the two second-pass kernels (predictsq: predict_moments' product)
 #   hbm    FETCH_SIZE / WRITE_SIZE of the headline command's launches (profiles/traffic.json)
 set -x
 cd $GRAFT_REPO_ROOT
@@ -40,6 +40,7 @@ sq)
   pmc headline_sq "$SQ" --rows 2000000 --steps 1 --warmup 0 --configs none
   pmc elbo_sq "$SQ" $S --configs c2_elbo_eval
   pmc c3_sq "$SQ" $S --configs c3 ;;
+predictsq) pmc predict_sq "$SQ" $S --configs predict_moments_n300k ;;
 hbm)
   pmc headline_fetch FETCH_SIZE --steps 1 --warmup 0 --configs none
   pmc headline_write WRITE_SIZE --steps 1 --warmup 0 --configs none ;;

@@ -248,8 +248,8 @@ def sq_summary(tag, prefixes, min_ms):
     return out or None
 
 
-for tag, name in (("headline_sq", "headline"), ("elbo_sq", "elbo"), ("c3_sq", "c3")):
-    sq = sq_summary(tag, ("rr_syrk_f32_kernel", "rr_syrk_f32_diag16_kernel", "rr_gemm_gradt_f32_kernel"), 5.0)
+for tag, name in (("headline_sq", "headline"), ("elbo_sq", "elbo"), ("c3_sq", "c3"), ("predict_sq", "predict")):
+    sq = sq_summary(tag, ("rr_syrk_f32_kernel", "rr_syrk_f32_diag16_kernel", "rr_gemm_gradt_f32_kernel", "rr_gemm_tn_f32_kernel"), 5.0)
     if sq:
         dst = os.path.join(ROOT, "profiles", "%s_%s" % (ROUND, name))
         os.makedirs(dst, exist_ok=True)
