@@ -1176,6 +1176,17 @@ def main():
         os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner out of the logs
 
     from revrand_amd import _hip, parallel
+    if world > 1 and "RR_BENCH_VISIBLE_GPUS" not in os.environ:
+        # started by a launcher (torch.distributed.run) on a box with fewer GPUs than ranks -- a rehearsal: the same mapping
+        # and host ids as bench.py's own launcher gives (rank r on device r % visible GPUs; RCCL refuses two ranks on one
+        # device of one host).  On a node with a GPU per rank nothing changes.
+        nvis = _hip.ctypes.c_int()
+        ndev = nvis.value if _hip.load_library().rr_device_count(_hip.ctypes.byref(nvis)) == 0 else 0
+        if 0 < ndev < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+            local_rank %= ndev
+            os.environ["LOCAL_RANK"] = str(local_rank)  # what revrand_amd's default device follows
+            os.environ["NCCL_HOSTID"] = "rr-bench-rank-%d" % rank
+            os.environ["RR_BENCH_VISIBLE_GPUS"] = str(ndev)
     dev = _hip.get_device(local_rank)
     use_comm = world > 1 or os.environ.get("RR_BENCH_FORCE_DIST") == "1"  # the latter: plumbing check at N=1
     comm = parallel.init_rccl_from_env(device=local_rank) if use_comm else parallel.SingleComm()

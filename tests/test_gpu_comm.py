@@ -252,6 +252,25 @@ def test_bench_under_torch_distributed_run_uses_rccl_directly():
     assert out["n_gpus"] == 1 and out["exchange"]["ranks_rccl_reports"] == 1 and out["config"]["trace_rel_err"] < 1e-6
 
 
+def test_bench_two_ranks_under_torch_distributed_run_as_the_driver_launches_n_gpus():
+    """The driver's N > 1 launch: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` with N = 2 (on this box's one GPU: rank r on device r % 1, socket transport):
+    ONE JSON line from rank 0, n_gpus as RCCL reports, the row-sharded `_elbo` after the headline."""
+    pytest.importorskip("torch")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "600000", "--dist-rows", "20000",
+                        "--configs", "elbo"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 == out["exchange"]["ranks_rccl_reports"] and out["config"]["trace_rel_err"] < 1e-6
+    assert out["config"]["rows_per_gpu"] == 300000 and out["exchange"]["oversubscribed"]
+    c = out["configs"]["elbo_rbf_f4096_dist"]
+    assert "error" not in c and c["parity"]["ranks_identical"] and c["parity"]["N_total"] == 20000
+
+
 def _bench(argv, env=None, timeout=1800):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
                        timeout=timeout, env=env)
