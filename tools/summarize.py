@@ -213,6 +213,12 @@ for tag, name, keys in (("posdef_kt", "posdef", ("posterior_F4096", "posterior_F
         c = cfgs[keys[0]]
         ks["rr_fastfood16_kernel"] = by_totals(st, tr, "rr_fastfood16_kernel", c["roofline"]["bytes_per_row"], c["rows"], 16, PEAK["hbm"], "byte",
                                                "FastFood chain -> Phi (HBM write), 16 launches of 262 144 rows per pass")
+    if name == "predict" and cfgs[keys[0]] and "error" not in cfgs[keys[0]]:
+        Fq = 4096
+        ks["rr_gemm_pair_f32_kernel"] = by_totals(st, tr, "rr_gemm_pair_f32_kernel", 1.0 * Fq * Fq, cfgs[keys[0]]["rows"], 1, PEAK["f32"], "flop",
+                                                  "Phi B with the upper-triangular factor B, column tiles paired into equal-cost workgroups, row sums of "
+                                                  "squares in the epilogue: F^2 algorithmic flop per row (1.0625 F^2 issued: the diagonal blocks are full "
+                                                  "squares); the full-size calls", min_grid="max")
     put(name, tag, {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --rows 1000000 --steps 1 --warmup 0 --configs %s (tools/prof.sh)" % ",".join(k.lower() for k in keys),
                     "configs": cfgs, "kernels": {k: v for k, v in ks.items() if v}, "all_kernels": st})
 
@@ -249,7 +255,7 @@ def sq_summary(tag, prefixes, min_ms):
 
 
 for tag, name in (("headline_sq", "headline"), ("elbo_sq", "elbo"), ("c3_sq", "c3"), ("predict_sq", "predict")):
-    sq = sq_summary(tag, ("rr_syrk_f32_kernel", "rr_syrk_f32_diag16_kernel", "rr_gemm_gradt_f32_kernel", "rr_gemm_tn_f32_kernel"), 5.0)
+    sq = sq_summary(tag, ("rr_syrk_f32_kernel", "rr_syrk_f32_diag16_kernel", "rr_gemm_gradt_f32_kernel", "rr_gemm_tn_f32_kernel", "rr_gemm_pair_f32_kernel"), 5.0)
     if sq:
         dst = os.path.join(ROOT, "profiles", "%s_%s" % (ROUND, name))
         os.makedirs(dst, exist_ok=True)
@@ -261,3 +267,47 @@ for tag, name in (("headline_sq", "headline"), ("elbo_sq", "elbo"), ("c3_sq", "c
                    "kernels": sq},
                   open(os.path.join(dst, "pmc_sq.json"), "w"), indent=1)
         print(name, "pmc_sq", {k: (round(v["mfma_busy_frac"], 4), round(v["clock_GHz"], 3)) for k, v in sq.items()})
+
+
+# ---- L2 -> fabric traffic of the headline kernels (tools/prof.sh hbm): profiles/traffic.json, quoted by bench.py ----
+def _per_dispatch(tag, prefix, ctr):
+    import collections
+    pth = os.path.join(SRC, tag, "p_counter_collection.csv")
+    vals = collections.OrderedDict()
+    if os.path.exists(pth):
+        for r in csv.DictReader(open(pth)):
+            if r["Kernel_Name"].replace("void ", "").startswith(prefix) and r["Counter_Name"] == ctr:
+                vals[r["Dispatch_Id"]] = vals.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return list(vals.values())
+
+
+fv, wv = _per_dispatch("headline_fetch", "rr_syrk_f32_kernel(", "FETCH_SIZE"), _per_dispatch("headline_write", "rr_syrk_f32_kernel(", "WRITE_SIZE")
+bf = bench_record("headline_fetch")
+if fv and wv and bf:
+    rows = bf["roofline"]["rows_per_step"] // max(bf["roofline"]["launches_per_step"], 1)
+    # MI355X_MICROARCH.md, HBM / rocprofv3 section: FETCH_SIZE and WRITE_SIZE are in KiB; gfx950 counts wide coalesced reads at
+    # half their size (x 2 on the fetch side); separate --pmc passes; per launch
+    fetch, write = sum(fv) / len(fv) * 1024 * 2, sum(wv) / len(wv) * 1024
+    tr = {"kernel": "rr_syrk_f32_kernel", "rows_per_launch": rows, "fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
+          "fetch_bytes_of_each_launch": [x * 2048 for x in fv], "bytes_per_row": (fetch + write) / rows,
+          "feature_matrix_bytes_per_launch": rows * 4096 * 4.0,
+          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, round-4 binaries, the default command's own %d-row launches, "
+                  "average of a pass' launches); FETCH_SIZE*1024*2 (gfx950 half-count correction of wide coalesced reads, "
+                  "MI355X_MICROARCH.md) + WRITE_SIZE*1024; L2->fabric side: requests the Infinity Cache serves are counted too "
+                  "(profiles/r02_mall has the probe); profiles/%s_headline" % (rows, ROUND)}
+    json.dump(tr, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    extra = {}
+    for pref in ("rr_syrk_f32_diag16_kernel", "rr_rff_features_mfma_kernel"):
+        f2, w2 = _per_dispatch("headline_fetch", pref, "FETCH_SIZE"), _per_dispatch("headline_write", pref, "WRITE_SIZE")
+        if f2 and w2:
+            extra[pref] = {"fetch_bytes_per_launch": sum(f2) / len(f2) * 2048, "write_bytes_per_launch": sum(w2) / len(w2) * 1024}
+    p2 = os.path.join(ROOT, "profiles", "%s_headline" % ROUND, "summary.json")
+    if os.path.exists(p2):
+        sm = json.load(open(p2))
+        sm["hbm_side_traffic"] = {"rr_syrk_f32_kernel": tr, **extra}
+        json.dump(sm, open(p2, "w"), indent=1)
+    for tag, name in (("headline_fetch", "pmc_fetch.csv"), ("headline_write", "pmc_write.csv")):
+        src = os.path.join(SRC, tag, "p_counter_collection.csv")
+        if os.path.exists(src) and os.path.getsize(src) < 4 << 20:
+            shutil.copy(src, os.path.join(ROOT, "profiles", "%s_headline" % ROUND, name))
+    print("traffic.json", {k: tr[k] for k in ("rows_per_launch", "fetch_bytes", "write_bytes", "bytes_per_row")})
