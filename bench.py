@@ -836,11 +836,12 @@ def config_posterior(dev, _hip, args, F):
     """rr_posterior_dev alone: C = (diag(1/L) + G / var)^-1 by blocked Cholesky + inverse on the f64 MFMA GEMMs, m, diag C,
     log|iC| and sum(G o C), all in HBM; G = the Gram of 3 F random-feature rows (full rank, realistic spectrum)."""
     rs = np.random.RandomState(F)
-    A = rs.standard_normal((3 * F, 16)) @ rs.standard_normal((16, F)) / 4.0
+    nrows = 3 * F if F < 16384 else F // 4  # (F = 16384: the host's P^T P of 3 F rows alone would take half a minute)
+    A = rs.standard_normal((nrows, 16)) @ rs.standard_normal((16, F)) / 4.0
     P = np.concatenate((np.cos(A), np.sin(A)), axis=1)[:, :F] / np.sqrt(F / 2.0)
     del A
     G = P.T @ P
-    b = P.T @ rs.standard_normal(3 * F)
+    b = P.T @ rs.standard_normal(nrows)
     del P
     iL, var = np.full(F, 1.0), 0.5
     acc = dev.upload_vector(np.concatenate((G.ravel(), b)))
@@ -850,7 +851,7 @@ def config_posterior(dev, _hip, args, F):
     ms, post = _median_ms(lambda: dev.posterior(F, pG, pb, iL, var, dC))
     m, dg, logdet, tr = post
     perr = None
-    if not args.no_parity_check:
+    if not args.no_parity_check and F < 16384:
         orc = _oracle()
         mh, Ch, ldC = orc.slm_posterior_from_stats(G, b, var, np.full(F, 1.0))
         C = dev.download(dC, (F, F), np.float64)
@@ -860,6 +861,25 @@ def config_posterior(dev, _hip, args, F):
                 "logdet_abs": parity("log|iC| vs oracle", float(abs(logdet + ldC)), 1e-8),
                 "trace": parity("sum(G o C) vs oracle", float(abs(tr - trh) / abs(trh)), 1e-9)}
         del C, Ch
+    elif not args.no_parity_check:
+        # F = 16384: the oracle's full inverse takes the better part of a minute on the host (tests/test_gpu_posterior.py does
+        # that comparison); here the size-independent properties of the SAME quantities, in host float64: iC C = I on 64
+        # random columns, iC m = b / var, log|iC| from the host's Cholesky factor alone, sum(G o C) from the downloaded C
+        import scipy.linalg as sla
+        iC = G / var
+        iC[np.diag_indices(F)] += iL
+        C = dev.download(dC, (F, F), np.float64)
+        cols = rs.choice(F, 64, replace=False)
+        R = iC @ C[:, cols]
+        R[cols, np.arange(64)] -= 1.0
+        ldh = 2.0 * float(np.log(sla.cholesky(iC, lower=False, overwrite_a=False, check_finite=False).diagonal()).sum())
+        trh = float((G * C).sum())
+        perr = {"iC_C_minus_I_64_cols": parity("max|iC C - I| on 64 columns", float(np.abs(R).max()), 1e-9),
+                "m": parity("|iC m - b / var| / |b / var|", float(np.abs(iC @ m - b / var).max() / np.abs(b / var).max()), 1e-9),
+                "logdet_abs": parity("log|iC| vs the host's Cholesky", float(abs(logdet - ldh) / abs(ldh)), 1e-10),
+                "trace": parity("sum(G o C) vs host sum over the downloaded C", float(abs(tr - trh) / abs(trh)), 1e-9),
+                "C_symmetric": bool(np.array_equal(C, C.T))}
+        del C, iC, R
     acc.free()
     dC.free()
     fl = F ** 3 / 3.0 + F ** 3
