@@ -614,6 +614,7 @@ def legacy_randn(random_state, n, dtype=np.float32, threads=2):
     key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
     pos, has, g = ctypes.c_int32(int(st[2])), ctypes.c_int32(int(st[3])), ctypes.c_double(float(st[4]))
     out = np.empty(n, dtype=dtype)
+    threads = int(os.environ.get("RR_RANDN_THREADS", threads))  # (measurement switch)
     _check(lib, lib.rr_legacy_randn(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), ctypes.byref(has), ctypes.byref(g),
                                     out.ctypes.data_as(ctypes.c_void_p), rr_dtype(dtype), n, threads))
     random_state.set_state(("MT19937", key, pos.value, has.value, g.value))

@@ -36,6 +36,34 @@ from .utils import atleast_list, issequence
 
 log = logging.getLogger(__name__)
 
+
+class _RowIndex(object):
+    """`np.arange(N)` as far as the batch generator is concerned (`shape[0]`, fancy indexing) without the 65 536-row gather per
+    step that `np.arange(N)[ind]` costs on the minibatch worker: `self[ind]` is `ind`."""
+
+    def __init__(self, N):
+        self.shape = (N,)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, ind):
+        return ind
+
+
+class _RowStub(object):
+    """The zero-width stand-in for X of a resident fit: `self[ind]` is an (len(ind), 0) array."""
+
+    def __init__(self, N):
+        self.shape = (N, 0)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, ind):
+        return np.empty((len(ind), 0))
+
+
 WGTRND = norm()                  # sampling distribution over mixture weights        glm.py:40
 COVRND = gamma(a=2, scale=0.5)   # sampling distribution over mixture covariances    glm.py:41
 LOGITER = 500                    # SGD iterations between ELBO log lines             glm.py:42
@@ -95,7 +123,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # shuffles row INDICES (the same permutation stream) and a zero-width stand-in for X
         self._resident_fit = self._features().make_resident(X)
         if self._resident_fit:
-            data = (np.empty((N, 0)), y) + likelihood_args + (np.arange(N),)
+            data = (_RowStub(N), y) + likelihood_args + (_RowIndex(N),)
         params = [Parameter(WGTRND, Bound(), shape=(self.D_, self.K)),
                   Parameter(COVRND, Positive(), shape=(self.D_, self.K)),
                   self.basis.regularizer,
