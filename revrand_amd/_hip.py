@@ -600,9 +600,11 @@ def get_upload_device(index=None):
 
 def legacy_randn(random_state, n, dtype=np.float32, threads=2):
     """`random_state.randn(n)` (a NumPy legacy RandomState), bit for bit and leaving the same state behind, through
-    rr_legacy_randn: the sequential part of the generator on this thread, the square roots and logarithms on `threads`
-    worker threads (one keeps up with the sequential part on the GPU box's host: 4.4 ms per 1 024 000 values against NumPy's
-    9.9; more only spin).  Anything but a plain MT19937 RandomState falls back to NumPy itself (same values either way)."""
+    rr_legacy_randn: the MT19937 words, the polar method's candidate pairs and their accept count on this thread (array loops,
+    AVX2 where the host has it), the pick of the accepted pairs with their square roots and logarithms on `threads` worker
+    threads (two keep up on the GPU box's host: 2.2 ms median per 1 024 000 values against NumPy's 9.3; rounds 2-3, with the
+    accept / reject walk on this thread: 4.4).  Anything but a plain MT19937 RandomState falls back to NumPy itself (same
+    values either way)."""
     dtype = np.dtype(dtype)
     try:
         st = random_state.get_state(legacy=True)

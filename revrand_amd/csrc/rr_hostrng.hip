@@ -3,9 +3,9 @@
 // The reference draws the step's standard normals from a NumPy legacy RandomState (glm.py:300: `random_.randn(L, D)` per
 // mixture component).  Parity runs must consume exactly that stream, and at config 5's size it is 1 024 000 normals per
 // step: ~10 ms of single-threaded NumPy against a 5 ms device step.  rr_legacy_randn advances the same generator state
-// and returns the same values bit for bit, faster: the part that is inherently sequential (MT19937 words, the polar
-// method's accept / reject) runs on the calling thread, the part that is not (sqrt(-2 log(r2) / r2) per accepted pair, the
-// expensive part) on worker threads, block by block behind it.
+// and returns the same values bit for bit, faster: the calling thread draws the MT19937 words, forms the candidate pairs of
+// the polar method and counts the accepted ones; worker threads pick the accepted candidates and compute
+// sqrt(-2 log(r2) / r2) per pair, batch by batch behind it.
 //
 // Algorithm restated from NumPy's published sources, which the reference pins through its `numpy` dependency:
 //   mt19937_gen / mt19937_next / mt19937_next_double   numpy/random/src/mt19937/mt19937.{c,h}
@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <cstring>
 #include <thread>
 #include <vector>
 
@@ -30,10 +31,11 @@ namespace {
 constexpr int MT_N = 624, MT_M = 397;
 
 struct Mt {
-    uint32_t *key;
+    uint32_t key[MT_N];  // a COPY of the caller's state (copied back at the end): through a pointer the compiler must assume
+                         // that key, buf and the output alias, and the refill loops stay scalar
     int pos;
     uint32_t buf[MT_N];  // tempered outputs of key[pos .. 624)
-    void temper_from(int p0) {
+    __attribute__((always_inline)) void temper_from(int p0) {
         for (int i = p0; i < MT_N; ++i) {
             uint32_t y = key[i];
             y ^= (y >> 11);
@@ -43,7 +45,7 @@ struct Mt {
             buf[i] = y;
         }
     }
-    void gen() {
+    __attribute__((always_inline)) void gen() {  // (inlined into mt_fill's clones: the AVX2 build of the refill)
         uint32_t y;
         int i;
         for (i = 0; i < MT_N - MT_M; i++) {
@@ -69,36 +71,82 @@ struct Mt {
     }
 };
 
-struct Pair {
-    double x1, x2;
-};
+// Host code only; the refill and the candidate loop are built a second time for AVX2 hosts and picked at load time.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+#define RR_HOST_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define RR_HOST_CLONES
+#endif
 
-constexpr int64_t BLOCK = 16384;  // accepted pairs per hand-over
+constexpr int64_t BATCH = 2048;  // candidates per hand-over
 
-template <typename T>
-void finish_pairs(const Pair *p, int64_t np, T *out, int64_t nout) {  // out[2 i] = f x2, out[2 i + 1] = f x1
-    for (int64_t i = 0; i < np; ++i) {
-        const double r2 = p[i].x1 * p[i].x1 + p[i].x2 * p[i].x2;  // the value the accept test saw
-        const double f = sqrt(-2.0 * log(r2) / r2);
-        out[2 * i] = (T)(f * p[i].x2);
-        if (2 * i + 1 < nout) out[2 * i + 1] = (T)(f * p[i].x1);
+// n tempered words of the stream into w
+RR_HOST_CLONES void mt_fill(Mt &mt, uint32_t *w, int64_t n) {
+    while (n > 0) {
+        if (mt.pos == MT_N) mt.gen();
+        int64_t c = MT_N - mt.pos;
+        if (c > n) c = n;
+        for (int64_t i = 0; i < c; ++i) w[i] = mt.buf[mt.pos + i];
+        mt.pos += (int)c;
+        w += c;
+        n -= c;
     }
 }
 
-struct PairBuf {  // grow-only scratch of the calling thread (12 MB at config 5's size: not worth re-faulting every step)
-    Pair *p = nullptr;
+// c candidates from 4 c words: (x1, x2) = (2 u - 1, 2 u' - 1) with u, u' = mt19937_next_double, and whether legacy_gauss's loop
+// would accept them; returns how many it would -- straight loops over arrays
+RR_HOST_CLONES int64_t candidates(const uint32_t *w, int64_t c, double *x1o, double *x2o, unsigned char *ok) {
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < c; ++i) {
+        const int32_t a1 = (int32_t)(w[4 * i] >> 5), b1 = (int32_t)(w[4 * i + 1] >> 6);
+        const int32_t a2 = (int32_t)(w[4 * i + 2] >> 5), b2 = (int32_t)(w[4 * i + 3] >> 6);
+        const double x1 = 2.0 * ((a1 * 67108864.0 + b1) / 9007199254740992.0) - 1.0;
+        const double x2 = 2.0 * ((a2 * 67108864.0 + b2) / 9007199254740992.0) - 1.0;
+        const double r2 = x1 * x1 + x2 * x2;
+        const unsigned char acc = (unsigned char)((r2 < 1.0) & (r2 != 0.0));
+        x1o[i] = x1;
+        x2o[i] = x2;
+        ok[i] = acc;
+        cnt += acc;
+    }
+    return cnt;
+}
+
+// out[2 i] = f x2, out[2 i + 1] = f x1 for accepted pair number i (legacy_gauss returns f x2 first and caches f x1)
+template <typename T>
+inline void emit_pair(double x1, double x2, int64_t i, T *o, int64_t nout, double *gauss_last) {
+    const double r2 = x1 * x1 + x2 * x2;  // the value the accept test saw
+    const double f = sqrt(-2.0 * log(r2) / r2);
+    o[2 * i] = (T)(f * x2);
+    if (2 * i + 1 < nout) o[2 * i + 1] = (T)(f * x1);
+    else *gauss_last = f * x1;  // odd count: the last pair's second value stays cached
+}
+
+struct CandBuf {  // grow-only scratch of the calling thread (candidates of one call: 17 bytes each)
+    double *x1 = nullptr, *x2 = nullptr;
+    unsigned char *ok = nullptr;
     size_t cap = 0;
-    ~PairBuf() { free(p); }
-    Pair *get(size_t n) {
-        if (n > cap) {
-            free(p);
-            p = (Pair *)malloc(n * sizeof(Pair));
-            cap = p ? n : 0;
-        }
-        return p;
+    ~CandBuf() { free(x1); free(x2); free(ok); }
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        free(x1); free(x2); free(ok);
+        x1 = (double *)malloc(n * 8); x2 = (double *)malloc(n * 8); ok = (unsigned char *)malloc(n);
+        cap = (x1 && x2 && ok) ? n : 0;
+        return cap != 0;
     }
 };
 
+struct Batch {
+    int64_t cand0, c, pair0;  // its candidates [cand0, cand0 + c), the number of its first accepted pair
+};
+
+// The stream is consumed candidate by candidate (four words each) until `npairs` are accepted -- not one word more, or the
+// generator's state would differ from NumPy's afterwards.  A batch of c candidates yields at most c pairs, so batches of
+// min(pairs still missing, BATCH) candidates can never overshoot; the last < 64 pairs go one by one.  The calling thread
+// draws the words, forms the candidates and COUNTS the accepted ones (loops over arrays: no per-candidate dependency);
+// worker threads walk the batches behind it, pick the accepted candidates and write sqrt(-2 log(r2) / r2) (x2, x1) straight
+// to their places.  (Rounds 2-3: the calling thread also compacted the accepted pairs one by one, a store-to-load chain of
+// ~7 ns per candidate: 4.3 of the call's 4.4 ms on the GPU box's host.)
 template <typename T>
 int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, int threads) {
     int64_t done = 0;
@@ -107,64 +155,72 @@ int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, i
         *has_gauss = 0;
         *gauss = 0.0;
     }
-    const int64_t npairs = (n - done + 1) / 2;
+    const int64_t nout = n - done, npairs = (nout + 1) / 2;
     if (npairs == 0) return RR_OK;
-    static thread_local PairBuf scratch;
-    Pair *pairs = scratch.get((size_t)npairs);
-    if (!pairs) {
-        rr_set_error("rr_legacy_randn: out of host memory");
-        return RR_ERR_OOM;
-    }
-    const int64_t nblocks = (npairs + BLOCK - 1) / BLOCK;
-    std::atomic<int64_t> ready(0), claim(0);
     T *o = out + done;
-    const int64_t nout = n - done;
-    auto worker = [&]() {
-        for (;;) {
-            const int64_t b = claim.fetch_add(1);
-            if (b >= nblocks) return;
-            while (ready.load(std::memory_order_acquire) <= b) std::this_thread::yield();
-            const int64_t p0 = b * BLOCK, p1 = p0 + BLOCK < npairs ? p0 + BLOCK : npairs;
-            finish_pairs<T>(pairs + p0, p1 - p0, o + 2 * p0, nout - 2 * p0);
+    double gauss_last = 0.0;
+    int64_t cnt = 0;  // accepted pairs so far
+    if (npairs >= 64) {
+        // room for twice the pairs in candidates (78.5 % are accepted); should a stream ever need more, the rest goes one by one
+        const size_t cap = (size_t)(2 * npairs + BATCH);
+        static thread_local CandBuf scratch;
+        if (!scratch.reserve(cap)) {
+            rr_set_error("rr_legacy_randn: out of host memory");
+            return RR_ERR_OOM;
         }
-    };
-    if (threads < 1) threads = 1;
-    if ((int64_t)threads > nblocks) threads = (int)nblocks;
-    std::vector<std::thread> pool;
-    if (npairs >= 4 * BLOCK)
-        for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
-    // accept / reject without a data-dependent branch while that cannot overshoot: a batch of c candidates (4 words each,
-    // accepted or not) yields at most c pairs, so batches of min(remaining, 2048) candidates are safe; every candidate is
-    // written to the next free slot and the slot advances only if it was accepted.  The last < 64 pairs one by one.
-    int64_t cnt = 0;
-    while (cnt < npairs) {
-        const int64_t remaining = npairs - cnt;
-        if (remaining >= 64) {
-            const int64_t c = remaining < 2048 ? remaining : 2048;
-            for (int64_t i = 0; i < c; ++i) {
-                const double x1 = 2.0 * mt.next_double() - 1.0;
-                const double x2 = 2.0 * mt.next_double() - 1.0;
-                const double r2 = x1 * x1 + x2 * x2;
-                pairs[cnt] = {x1, x2};
-                cnt += (int64_t)((r2 < 1.0) & (r2 != 0.0));
+        // (the workers must see THIS thread's buffers: a thread_local named inside their lambda would be their own, empty one)
+        double *const X1 = scratch.x1, *const X2 = scratch.x2;
+        unsigned char *const OK = scratch.ok;
+        std::vector<Batch> batches;
+        batches.reserve((size_t)(cap / 64 + 16));  // (never reallocated while workers read it)
+        std::atomic<int64_t> ready(0), claim(0);
+        std::atomic<bool> closed(false);
+        auto worker = [&]() {
+            for (;;) {
+                const int64_t j = claim.fetch_add(1);
+                while (ready.load(std::memory_order_acquire) <= j) {
+                    if (closed.load(std::memory_order_acquire) && ready.load(std::memory_order_acquire) <= j) return;
+                    std::this_thread::yield();
+                }
+                const Batch &b = batches[(size_t)j];
+                const double *x1 = X1 + b.cand0, *x2 = X2 + b.cand0;
+                const unsigned char *ok = OK + b.cand0;
+                int64_t i = b.pair0;
+                for (int64_t q = 0; q < b.c; ++q)
+                    if (ok[q]) emit_pair<T>(x1[q], x2[q], i++, o, nout, &gauss_last);
             }
-        } else {
-            double x1, x2, r2;
-            do {
-                x1 = 2.0 * mt.next_double() - 1.0;
-                x2 = 2.0 * mt.next_double() - 1.0;
-                r2 = x1 * x1 + x2 * x2;
-            } while (r2 >= 1.0 || r2 == 0.0);
-            pairs[cnt++] = {x1, x2};
+        };
+        if (threads < 1) threads = 1;
+        std::vector<std::thread> pool;
+        if (npairs >= 16 * BATCH)
+            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+        uint32_t w[4 * BATCH];
+        int64_t cand = 0;
+        while (npairs - cnt >= 64 && (size_t)(cand + BATCH) <= cap && batches.size() < batches.capacity()) {
+            const int64_t c = npairs - cnt < BATCH ? npairs - cnt : BATCH;
+            mt_fill(mt, w, 4 * c);
+            const int64_t acc = candidates(w, c, X1 + cand, X2 + cand, OK + cand);
+            batches.push_back({cand, c, cnt});
+            ready.store((int64_t)batches.size(), std::memory_order_release);
+            cand += c;
+            cnt += acc;
         }
-        ready.store(cnt == npairs ? nblocks : cnt / BLOCK, std::memory_order_release);
+        closed.store(true, std::memory_order_release);
+        if (pool.empty()) worker();
+        for (auto &t : pool) t.join();
     }
-    if (pool.empty()) worker();
-    for (auto &t : pool) t.join();
-    if (nout & 1) {  // the last pair's second value stays cached, as in legacy_gauss
-        const Pair &l = pairs[npairs - 1];
-        const double r2 = l.x1 * l.x1 + l.x2 * l.x2;
-        *gauss = sqrt(-2.0 * log(r2) / r2) * l.x1;
+    // the last pairs (fewer than 64, or all of a short request) one by one, as legacy_gauss does
+    while (cnt < npairs) {
+        double x1, x2, r2;
+        do {
+            x1 = 2.0 * mt.next_double() - 1.0;
+            x2 = 2.0 * mt.next_double() - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        emit_pair<T>(x1, x2, cnt++, o, nout, &gauss_last);
+    }
+    if (nout & 1) {
+        *gauss = gauss_last;
         *has_gauss = 1;
     }
     return RR_OK;
@@ -179,11 +235,12 @@ extern "C" int rr_legacy_randn(uint32_t *key, int32_t *pos, int32_t *has_gauss, 
     RR_REQUIRE(n >= 0 && (n == 0 || out != nullptr), "rr_legacy_randn: bad output");
     RR_REQUIRE(out_dtype == RR_F32 || out_dtype == RR_F64, "rr_legacy_randn: bad dtype");
     Mt mt;
-    mt.key = key;
+    memcpy(mt.key, key, sizeof(mt.key));
     mt.pos = (int)*pos;
     mt.temper_from(mt.pos);
     const int rc = out_dtype == RR_F32 ? legacy_randn<float>(mt, has_gauss, gauss, (float *)out, n, threads)
                                        : legacy_randn<double>(mt, has_gauss, gauss, (double *)out, n, threads);
+    memcpy(key, mt.key, sizeof(mt.key));
     *pos = mt.pos;
     return rc;
 }
