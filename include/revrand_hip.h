@@ -415,6 +415,12 @@ int rr_rff_predict_devc(rr_basis *basis, const void *dX, int x_dtype, int64_t N,
                         const double *lenscale, int n_ls, const double *m, const double *dC, double *Ey,
                         double *Vf);
 
+/* `predict` (slm.py:201-217) asks for the mean only -- the reference forms it through predict_moments, variance and all;
+ * here Ey = Phi m comes from the feature kernel alone (no N x F x F product, no feature matrix in HBM).  float32 bases
+ * of Xdim <= 128 (RR_ERR_UNSUPPORTED otherwise: use rr_rff_predict_dev and drop Vf). */
+int rr_rff_predict_mean_dev(rr_basis *basis, const void *dX, int x_dtype, int64_t N, int64_t ldx,
+                            const double *lenscale, int n_ls, const double *m, double *Ey);
+
 /* The variance of predict_moments without cancellation.  phi^T C phi in float32 loses digits when C is badly scaled
  * (error ~ eps * |phi|^T |C| |phi|, which can exceed the result).  With C = M M^T (M upper triangular: the "UL" Cholesky
  * factor, float64 on the device, hand-written blocked kernels of rr_posdef.hip) it is the sum of squares || phi^T M ||^2:

@@ -171,6 +171,8 @@ SIGNATURES = {
                                            ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                            ctypes.c_void_p, ctypes.c_void_p]),
     "rr_featmat_predict_begin_b": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]),
+    "rr_rff_predict_mean_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
     "rr_fastfood_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                           _c_void_pp]),
@@ -1181,7 +1183,8 @@ class RffHandle(object):
 
     def predict(self, X, lenscale, m, C, check_rows=None):
         """(Ey, Vf) = (Phi m, rowsum((Phi C) o Phi)) for host query rows X.  C: host (F, F) array, or a DeviceBuffer
-        holding it in float64 on the device (uploaded once by the estimator).
+        holding it in float64 on the device (uploaded once by the estimator).  C = None: the mean alone, (Ey, None), from
+        the feature kernel without the N x F x F product (`mean_only_ok` bases).
 
         `check_rows`: the caller's validation of the rows (sklearn's `check_array`: finiteness), run by this method instead
         of before it: for a large query on a host thread WHILE the rows are uploaded and the GPU works on them (3-4 ms for
@@ -1214,8 +1217,23 @@ class RffHandle(object):
                 if failed:
                     raise failed[0]
 
+    @property
+    def mean_only_ok(self):
+        """rr_rff_predict_mean_dev serves this basis (float32 arithmetic and phases, Xdim <= 128)."""
+        return self.compute == RR_F32 and not self.phase64 and self.d <= 128
+
     def _predict(self, X, N, lsp, nls, m, C, f32_factor):
         dX = self.upload(X)
+        if C is None:
+            Ey = np.empty(N)
+            try:
+                if N:
+                    _check(self.lib, self.lib.rr_rff_predict_mean_dev(self.h, dX.ptr, rr_dtype(dX.dtype), N, dX.ld, lsp, nls,
+                                                                      m.ctypes.data_as(ctypes.c_void_p),
+                                                                      Ey.ctypes.data_as(ctypes.c_void_p)))
+            finally:
+                dX.free()
+            return Ey, None
         Ey, Vf = np.empty(N), np.empty(N)
         if N and f32_factor:
             B, form = C.factor()  # f32 arithmetic: variance as a sum of squares, no cancellation

@@ -950,9 +950,13 @@ class _RandomKernelBasis(_LengthScaleBasis):
     def predict_moments(self, X, lenscale, m, C, check_rows=None):
         """(Phi m, rowsum((Phi C) o Phi)) on the device (slm.py:240-243), in the basis' arithmetic.  `check_rows`: the
         estimator's validation of the query rows (`check_array`), applied here -- to the row chunks of a large query as they
-        are uploaded, see RffHandle.predict."""
+        are uploaded, see RffHandle.predict.  C = None asks for the mean alone: (Phi m, None), or None when the basis'
+        arithmetic has no such route (float64, float64 phases, Xdim > 128)."""
         lenscale = self._check_dim(X.shape[1], lenscale)
-        return self._dense_handle()[0].predict(X, lenscale, m, C, check_rows=check_rows)
+        h = self._dense_handle()[0]
+        if C is None and not h.mean_only_ok:
+            return None
+        return h.predict(X, lenscale, m, C, check_rows=check_rows)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, lenscale={}, regularizer={}, random_state={})".format(

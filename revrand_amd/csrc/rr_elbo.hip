@@ -16,7 +16,8 @@
 // ---------------------------------------------------------------------------------------------
 // Feature-major features:  Pt[f][r] = cos/sqrt(n), Pt[n+f][r] = sin/sqrt(n)  (GEMM operand, K-major),
 // and per row  dot[r] = Phi_r . m.  One row per thread (x in registers), frequencies looped with the
-// transposed weights Wt[f][DMAX] and m through the scalar cache, stores coalesced along r.
+// transposed weights Wt[f][DMAX] and m through the scalar cache, stores coalesced along r.  Pt == nullptr: the dot
+// products only (the predictive mean without the variance, rr_rff_predict_mean_dev).
 // ---------------------------------------------------------------------------------------------
 template <int DMAX, typename TX>
 __global__ void __launch_bounds__(256)
@@ -37,7 +38,7 @@ rr_rff_features_t_kernel(const TX *__restrict__ X, int64_t N, int64_t Npad, int6
         const float fr = z - __builtin_rintf(z);
         const float c = valid ? __builtin_amdgcn_cosf(fr) * scale : 0.f;
         const float s = valid ? __builtin_amdgcn_sinf(fr) * scale : 0.f;
-        if (r < Npad) {
+        if (Pt && r < Npad) {
             Pt[(size_t)f * ldt + r] = c;
             Pt[(size_t)(n + f) * ldt + r] = s;
         }
@@ -2147,6 +2148,44 @@ int rr_rff_predict_devb(rr_basis *b, const void *dX, int x_dtype, int64_t N, int
     return x_dtype == RR_F32
                ? pass2_run<float>(b, true, (const float *)dX, nullptr, N, ldx, m, nullptr, Ey, Vf, true, dB, form)
                : pass2_run<double>(b, true, (const double *)dX, nullptr, N, ldx, m, nullptr, Ey, Vf, true, dB, form);
+}
+
+int rr_rff_predict_mean_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *lenscale, int n_ls,
+                            const double *m, double *Ey) {
+    int rc = pass2_checks(b, dX, x_dtype, N, ldx, lenscale, n_ls, m, m, "rr_rff_predict_mean_dev");
+    if (rc != RR_OK) return rc;
+    RR_REQUIRE(Ey != nullptr, "rr_rff_predict_mean_dev: null argument");
+    if (b->compute != RR_F32 || b->large || b->phase64) {
+        rr_set_error("rr_rff_predict_mean_dev: f32 bases of Xdim <= 128 only (the others: rr_rff_predict_dev)");
+        return RR_ERR_UNSUPPORTED;
+    }
+    rr_ctx *c = b->ctx;
+    const int F = 2 * b->n;
+    const int64_t Npad = (N + 255) / 256 * 256;
+    float *buf = nullptr;  // [m (F) | Phi m (Npad)]
+    if (hipMalloc((void **)&buf, ((size_t)F + (size_t)Npad) * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        rr_set_error("rr_rff_predict_mean_dev: device allocation failed");
+        return RR_ERR_OOM;
+    }
+    std::vector<float> h((size_t)(F > N ? F : N));
+    for (int i = 0; i < F; ++i) h[i] = (float)m[i];
+    hipError_t e = hipMemcpyAsync(buf, h.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // h is reused for the result
+    if (e == hipSuccess) {
+        rc = x_dtype == RR_F32 ? launch_features_t<float>(b, (const float *)dX, N, Npad, ldx, buf, nullptr, 0, buf + F)
+                               : launch_features_t<double>(b, (const double *)dX, N, Npad, ldx, buf, nullptr, 0, buf + F);
+        if (rc == RR_OK) e = hipMemcpyAsync(h.data(), buf + F, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    if (rc != RR_OK) return rc;
+    if (e != hipSuccess) {
+        rr_set_error("rr_rff_predict_mean_dev: %s", hipGetErrorString(e));
+        return RR_ERR_HIP;
+    }
+    for (int64_t i = 0; i < N; ++i) Ey[i] = (double)h[i];
+    return RR_OK;
 }
 
 int rr_dense_predict(rr_ctx *c, const void *Phi, int dtype, int64_t N, int64_t F, int64_t ldphi, const double *m,

@@ -346,9 +346,17 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
 
     def predict(self, X):
         """Predictive mean (slm.py:201-217).  The reference computes it through `predict_moments`, i.e. with the
-        N x F x F product of the variance; the mean alone is Phi m, formed here on the device without it (a 256-column
-        GEMM instead of an F-column one), falling back to `predict_moments` for bases that cannot."""
+        N x F x F product of the variance; the mean alone is Phi m: for a random kernel basis straight out of the feature
+        kernel (rr_rff_predict_mean_dev: no product at all, no feature matrix in HBM, the rows validated on a second host
+        thread during their upload), for the other f32 bases a 256-column GEMM instead of an F-column one; `predict_moments`
+        for bases that can do neither."""
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
+        if getattr(self.basis, "_predict_checks_rows", False) and getattr(self.basis, "predict_moments", None) is not None:
+            Xs = check_array(X, **_NO_FINITE_CHECK)
+            with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+                res = self.basis.predict_moments(Xs, self.hypers_, self.weights_, None, check_rows=check_array)
+            if res is not None:
+                return res[0]
         X = check_array(X)
         Ey = self._predict_mean(X)
         if Ey is None:

@@ -791,6 +791,60 @@ def test_predict_is_the_mean_of_predict_moments_without_the_variance_product():
         assert ((slm.predict(X) - y) ** 2).mean() < 0.9 * y.var()
 
 
+def test_predict_of_a_random_kernel_basis_comes_from_the_feature_kernel_alone(monkeypatch):
+    """`predict` (slm.py:201-217) of a single f32 random kernel basis: rr_rff_predict_mean_dev -- the very dot products
+    `predict_moments` returns as Ey (same kernel, same bits), with no covariance on the device and no feature matrix; ragged
+    row counts, f32 / f64 queries, `apply_ind`, ARD; validation of a large query on the second host thread with sklearn's
+    exception for a non-finite row; float64-phase and Xdim > 128 bases keep the GEMM route."""
+    import threading
+    from revrand_amd import _hip
+    bs, Parameter, Positive, SLM = _imports()
+    rs = np.random.RandomState(5)
+    calls = []
+    orig = _hip.RffHandle._predict
+    monkeypatch.setattr(_hip.RffHandle, "_predict",
+                        lambda self, X, N, lsp, nls, m, C, f: (calls.append((C is None, [t.name for t in threading.enumerate()])),
+                                                                orig(self, X, N, lsp, nls, m, C, f))[1])
+    for d, n, ard, ai, xdt in ((5, 100, False, None, np.float64), (9, 129, True, None, np.float32), (3, 64, False, [4, 0, 2], np.float64)):
+        X = rs.randn(4000, 5 if ai else d).astype(xdt)
+        y = (np.sin(X[:, 0]) + 0.1 * rs.randn(4000)).astype(xdt)
+        ls = Parameter(np.full(d, 1.3), Positive()) if ard else Parameter(1.3, Positive())
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=ls, apply_ind=ai)
+        slm = SLM(basis, maxiter=8, nstarts=0, random_state=0).fit(X, y)
+        for N in (1, 255, 257, 4000):
+            del calls[:]
+            Ey = slm.predict(X[:N])
+            assert calls == [(True, calls[0][1])] and "_serve" not in slm.__dict__   # nothing uploaded for it
+            Em, _ = slm.predict_moments(X[:N])
+            assert Ey.shape == (N,) and np.array_equal(Ey, Em)
+            slm._drop_serving()
+        Xa = X[:, ai] if ai else X
+        Phi = orc.rff_transform(Xa[:500].astype(np.float64), basis.W, slm.hypers_)
+        assert normwise(slm.predict(X[:500]), Phi @ slm.weights_) < 1e-4
+    # a large query: validated while it is uploaded
+    XL = np.tile(X, (10, 1))
+    del calls[:]
+    EL = slm.predict(XL)
+    assert calls[0][0] and "rr-predict-check" in calls[0][1] and np.array_equal(EL[:4000], slm.predict(X))
+    for bad_row in (0, len(XL) - 1):
+        Xb = XL.copy()
+        Xb[bad_row, 2] = np.nan
+        with pytest.raises(ValueError, match="NaN"):
+            slm.predict(Xb)
+        with pytest.raises(ValueError, match="NaN"):
+            slm.predict(Xb[bad_row:][:1] if bad_row == 0 else Xb[-3:])
+    with pytest.raises((ValueError, IndexError)):
+        slm.predict(XL[:, :2])          # wrong width: the basis' own check (apply_ind's IndexError here, as in the reference)
+    # bases without the route: the 256-column product, same numbers as predict_moments' mean
+    for basis in (bs.RandomLaplace(nbases=64, Xdim=5, random_state=2), bs.RandomRBF(nbases=32, Xdim=130, random_state=3)):
+        Xw = rs.randn(1500, basis.d)
+        slm = SLM(basis, maxiter=5, nstarts=0, random_state=0).fit(Xw, np.sin(Xw[:, 0]))
+        del calls[:]
+        Ey = slm.predict(Xw)
+        assert not any(c[0] for c in calls) and slm._serve["feats"] is not None
+        assert normwise(Ey, slm.predict_moments(Xw)[0]) < 1e-5
+
+
 def test_serving_state_is_reused_and_invalidated():
     """A fitted estimator keeps its covariance in HBM and its `predict` feature matrix between calls; the state is
     rebuilt when `covariance_` is replaced, dropped by pickling and by a new fit."""
@@ -806,7 +860,7 @@ def test_serving_state_is_reused_and_invalidated():
     assert srv["cov"] is not None
     Ey2, Vy2 = slm.predict_moments(Xs)
     assert slm._serve is srv and np.array_equal(Ey, Ey2) and np.array_equal(Vy, Vy2)
-    assert normwise(slm.predict(Xs), Ey) < 1e-5 and slm._serve["feats"] is not None
+    assert np.array_equal(slm.predict(Xs), Ey) and slm._serve["feats"] is None   # the feature kernel alone: no feature matrix
     Phi = orc.rff_transform(Xs, slm.basis.W, slm.hypers_)
     assert normwise(Vy, (Phi @ slm.covariance_ * Phi).sum(axis=1) + slm.var_) < 1e-3
     slm.covariance_ = 4.0 * slm.covariance_                    # replaced: the device copy must follow
