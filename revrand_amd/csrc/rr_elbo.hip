@@ -66,6 +66,7 @@ struct GemmArgs {
     int kb_per_split = 0;  // > 0: blockIdx.y owns k-blocks [y * kb_per_split, ...) and ADDS into a zeroed D (f32 atomics)
     int upper_b = 0;  // B (K, N) with K == N is upper triangular: column tile tb needs only k < 256 (tb + 1)
     int pair_upper = 0;  // with upper_b: rr_gemm_pair_f32_kernel, one workgroup per PAIR of column tiles (ntb - 1 - q, q)
+    int diag_skip = getenv("RR_PREDICT_NO_DIAG_SKIP") ? 0 : 1;  // that kernel: no MFMAs on the zero quarters of the diagonal blocks
     // TRIG epilogue (random Fourier features of Xdim > 128, rr_rff.hip): the product is the phase matrix Z in
     // revolutions; D is the feature matrix P: P[r][c] = cos(2 pi Z[r][c]) scale, P[r][n + c] = sin(..) scale for
     // c < n, zero rows for nvalid <= r < nout, nothing beyond; bvec += P^T y.
@@ -230,13 +231,18 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_pair_f32_kernel(const G
     const int q = (int)((blockIdx.x % nq + ta) % nq);  // (rotated by the row tile: neighbouring blocks share B's column tiles in L2)
     const int ntile = p.ntb - 1 - q > q ? 2 : 1;
     const int64_t ca = ta * GR_TC;
-    const int wr = wave >> 2, wc_ = wave & 3, hi = lane >> 5;
+    // The two waves of a SIMD (w, w + 4) take the column quarters wc and 3 - wc: in a tile's DIAGONAL block (its last 8
+    // k-blocks) the quarter wc of the upper-triangular B is zero from k-block 2 (wc + 1) on, a wave skips those k-blocks, and
+    // with complementary quarters every SIMD is left with one wave in the block's second half (10 of its 16 wave x k-block
+    // units of MFMAs; with equal quarters the SIMD of quarter 3 would keep all 16 and set the pace at the barriers).
+    const int wr = wave >> 2, wc_ = __builtin_amdgcn_readfirstlane(p.diag_skip ? (wr ? 3 - (wave & 3) : (wave & 3)) : (wave & 3)), hi = lane >> 5;
     const unsigned aoff = 4u * ((lane >> 5) * GR_LD + wr * 128 + (lane & 31));
     const unsigned boff = 4u * ((lane >> 5) * GR_LD + GR_TC + wc_ * 64 + (lane & 31));
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float *)lds;
     const unsigned voff = 16u * lane;
     const int slot = __builtin_amdgcn_readfirstlane(rr_dma_slot(wave, p.spread));
     const int nkb_all = p.K / GR_KB;
+    const int kskip = p.diag_skip ? 2 * (wc_ + 1) : 1 << 30;  // k-blocks of a diagonal block this wave's quarter is non-zero in
     auto dma_tile = [&](float *buf, int kb0, int cbt) {
         rr_dma_kblock(p.A + (int64_t)kb0 * p.lda + ca, p.lda, p.B + (int64_t)kb0 * p.ldb + cbt, p.ldb, buf, wave, voff);
     };
@@ -255,11 +261,16 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_pair_f32_kernel(const G
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
         __syncthreads();  // this tile's first k-block has landed
+        const int klim = tb * (GR_TC / GR_KB) + kskip;  // (wave-uniform) first k-block whose MFMAs would only add zeros
         for (int kb = 0; kb < nkb; ++kb) {
             const int cbuf = kb & 1;
-            gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, slot, [&]() {
-                if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB, cb);
-            });
+            if (kb < klim) {
+                gram_consume_staggered(lds0 + cbuf * (4u * GR_KB * GR_LD), acc, aoff, boff, slot, [&]() {
+                    if (kb + 1 < nkb) dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB, cb);
+                });
+            } else if (kb + 1 < nkb) {
+                dma_tile(lds + (cbuf ^ 1) * (GR_KB * GR_LD), (kb + 1) * GR_KB, cb);
+            }
             __syncthreads();
         }
         if (t + 1 < ntile) dma_tile(lds, 0, q * GR_TC);  // (every wave is past the last barrier: both buffers are free)

@@ -217,8 +217,8 @@ for tag, name, keys in (("posdef_kt", "posdef", ("posterior_F4096", "posterior_F
         Fq = 4096
         ks["rr_gemm_pair_f32_kernel"] = by_totals(st, tr, "rr_gemm_pair_f32_kernel", 1.0 * Fq * Fq, cfgs[keys[0]]["rows"], 1, PEAK["f32"], "flop",
                                                   "Phi B with the upper-triangular factor B, column tiles paired into equal-cost workgroups, row sums of "
-                                                  "squares in the epilogue: F^2 algorithmic flop per row (1.0625 F^2 issued: the diagonal blocks are full "
-                                                  "squares); the full-size calls", min_grid="max")
+                                                  "squares in the epilogue: F^2 algorithmic flop per row (1.016 F^2 issued: in a diagonal block a wave skips the "
+                                                  "k-blocks its column quarter of B is zero in; 1.0625 F^2 before that); the full-size calls", min_grid="max")
     put(name, tag, {"command": "rocprofv3 --kernel-trace --stats -- python bench.py --rows 1000000 --steps 1 --warmup 0 --configs %s (tools/prof.sh)" % ",".join(k.lower() for k in keys),
                     "configs": cfgs, "kernels": {k: v for k, v in ks.items() if v}, "all_kernels": st})
 
