@@ -5,7 +5,8 @@
 # stages (kernel trace + stats of `python bench.py --configs <that configuration>`):
 #   headline  elbo  elbo64  c3  ffelbo  posdef  predict  laplace  c4  c5
 # counter passes:
-#   sq     matrix-pipe busy cycles + clock of the headline kernels and of the two second-pass kernels (predictsq: predict_moments' product)
+#   sq     matrix-pipe busy cycles + clock of the headline kernels and of the two second-pass kernels (predictsq: predict_moments' product;
+#          c5sq: the GLM step's three products)
 #   hbm    FETCH_SIZE / WRITE_SIZE of the headline command's launches (profiles/traffic.json)
 set -x
 cd $GRAFT_REPO_ROOT
@@ -41,6 +42,7 @@ sq)
   pmc elbo_sq "$SQ" $S --configs c2_elbo_eval
   pmc c3_sq "$SQ" $S --configs c3 ;;
 predictsq) pmc predict_sq "$SQ" $S --configs predict_moments_n300k ;;
+c5sq) pmc c5_sq "$SQ" $S --configs c5 ;;
 hbm)
   pmc headline_fetch FETCH_SIZE --steps 1 --warmup 0 --configs none
   pmc headline_write WRITE_SIZE --steps 1 --warmup 0 --configs none ;;

@@ -213,6 +213,15 @@ for tag, name, keys in (("posdef_kt", "posdef", ("posterior_F4096", "posterior_F
         c = cfgs[keys[0]]
         ks["rr_fastfood16_kernel"] = by_totals(st, tr, "rr_fastfood16_kernel", c["roofline"]["bytes_per_row"], c["rows"], 16, PEAK["hbm"], "byte",
                                                "FastFood chain -> Phi (HBM write), 16 launches of 262 144 rows per pass")
+    if name == "c5_glm" and cfgs[keys[0]] and "error" not in cfgs[keys[0]]:
+        KL, Fq, Mq = 500, 2048, cfgs[keys[0]]["rows_per_step"]
+        # rr_gemm_tn_f32_kernel also serves the posterior-free statistics part of the bench's headline (other grids): the step's
+        # launches are the kernel's most frequent grid
+        for kn, sel, what in (("rr_gemm_lik_f32_kernel", None, "fs = Phi ws^T, likelihood terms as the epilogue, dfs stored in both layouts"),
+                              ("rr_gemm_tn_f32_kernel", "mode", "Ed = dfs Phi: 16 output tiles, K = 65 536 minibatch rows split 16 ways (f32 atomics)"),
+                              ("rr_gemm_gradt_f32_kernel", None, "EdPhi = dfs^T ws contracted with P and X in registers (never stored)")):
+            ks[kn] = by_totals(st, tr, kn, 2.0 * KL * Fq, Mq, 1, PEAK["f32"], "flop",
+                               what + "; 2 K L F algorithmic flop per minibatch row and launch (K L = 500 sample columns, 512 issued)", min_grid=sel)
     if name == "predict" and cfgs[keys[0]] and "error" not in cfgs[keys[0]]:
         Fq = 4096
         ks["rr_gemm_pair_f32_kernel"] = by_totals(st, tr, "rr_gemm_pair_f32_kernel", 1.0 * Fq * Fq, cfgs[keys[0]]["rows"], 1, PEAK["f32"], "flop",
@@ -254,8 +263,11 @@ def sq_summary(tag, prefixes, min_ms):
     return out or None
 
 
-for tag, name in (("headline_sq", "headline"), ("elbo_sq", "elbo"), ("c3_sq", "c3"), ("predict_sq", "predict")):
-    sq = sq_summary(tag, ("rr_syrk_f32_kernel", "rr_syrk_f32_diag16_kernel", "rr_gemm_gradt_f32_kernel", "rr_gemm_tn_f32_kernel", "rr_gemm_pair_f32_kernel"), 5.0)
+for tag, name in (("headline_sq", "headline"), ("elbo_sq", "elbo"), ("c3_sq", "c3"), ("predict_sq", "predict"), ("c5_sq", "c5_glm")):
+    if name == "c5_glm":  # the GLM step's three products: ~1 ms launches, K = 2048 or a 1/16 K-split of 65 536
+        sq = sq_summary(tag, ("rr_gemm_lik_f32_kernel", "rr_gemm_gradt_f32_kernel", "rr_gemm_tn_f32_kernel"), 0.5)
+    else:
+        sq = sq_summary(tag, ("rr_syrk_f32_kernel", "rr_syrk_f32_diag16_kernel", "rr_gemm_gradt_f32_kernel", "rr_gemm_tn_f32_kernel", "rr_gemm_pair_f32_kernel"), 5.0)
     if sq:
         dst = os.path.join(ROOT, "profiles", "%s_%s" % (ROUND, name))
         os.makedirs(dst, exist_ok=True)
