@@ -43,6 +43,7 @@ sq)
   pmc c3_sq "$SQ" $S --configs c3 ;;
 predictsq) pmc predict_sq "$SQ" $S --configs predict_moments_n300k ;;
 c5sq) pmc c5_sq "$SQ" $S --configs c5 ;;
+elbo64sq) pmc elbo64_sq "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64" $S --configs c2f64_elbo_eval_n200k,headline_shape_f64 ;;
 hbm)
   pmc headline_fetch FETCH_SIZE --steps 1 --warmup 0 --configs none
   pmc headline_write WRITE_SIZE --steps 1 --warmup 0 --configs none ;;
