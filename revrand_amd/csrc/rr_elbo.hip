@@ -2829,6 +2829,27 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
     const int F = fm->F;
+    if (S == 1 && fm->max_rows >= 2) {
+        // one vector (the estimator's `predict`: Phi m): a dot product per row, no transposing pass and no GEMM.  m and the
+        // result sit in the product scratch U, which every product overwrites anyway
+        int rc1 = fm_pass2_scratch(fm);
+        if (rc1 != RR_OK) return rc1;
+        FmPass2 &s1 = *(FmPass2 *)fm->pass2;
+        float *mv = s1.U, *dv = s1.U + fm->ld;
+        std::vector<float> h((size_t)(F > fm->rows ? F : fm->rows));
+        for (int j = 0; j < F; ++j) h[j] = (float)W[j];
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        s1.have_rows = false;
+        s1.have_edphi = false;
+        RR_CHECK_HIP(hipMemcpy(mv, h.data(), (size_t)F * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(rr_rowvec_kernel, dim3((unsigned)((fm->rows + 3) / 4)), dim3(256), 0, c->stream, fm->P, mv, fm->rows, F,
+                           fm->ld, dv);
+        RR_CHECK_HIP(hipGetLastError());
+        RR_CHECK_HIP(hipMemcpyAsync(h.data(), dv, (size_t)fm->rows * 4, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        for (int64_t i = 0; i < fm->rows; ++i) out[i] = (double)h[i];
+        return RR_OK;
+    }
     const int64_t sp = ((int64_t)S + 255) / 256 * 256, Fp = fm->ld;
     const int64_t rows256 = (fm->rows + 255) / 256 * 256;
     int rc = fm_glm_scratch(fm, sp, 1);

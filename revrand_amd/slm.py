@@ -348,8 +348,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         """Predictive mean (slm.py:201-217).  The reference computes it through `predict_moments`, i.e. with the
         N x F x F product of the variance; the mean alone is Phi m: for a random kernel basis straight out of the feature
         kernel (rr_rff_predict_mean_dev: no product at all, no feature matrix in HBM, the rows validated on a second host
-        thread during their upload), for the other f32 bases a 256-column GEMM instead of an F-column one; `predict_moments`
-        for bases that can do neither."""
+        thread during their upload), for the other f32 bases a dot product per row of the assembled feature matrix
+        (rr_featmat_project with one vector); `predict_moments` for bases that can do neither."""
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
         if getattr(self.basis, "_predict_checks_rows", False) and getattr(self.basis, "predict_moments", None) is not None:
             Xs = check_array(X, **_NO_FINITE_CHECK)
