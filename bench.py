@@ -921,6 +921,36 @@ def config_predict(dev, _hip, args, N=300_000):
                          "_flops_per_row": fl}}
 
 
+def config_predict_c3(dev, _hip, args, N=300_000):
+    """The same call for config 3's concatenation (RandomMatern52 n=4096 + LinearBasis, F_tot = 8257, D = 64):
+    BasisCat.predict_moments assembles Phi child by child in 65 536-row chunks of the host query."""
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    from revrand_amd.utils import atleast_list
+    d, n = 64, 4096
+    X, y = _c3_data(N, d, 7)
+    basis = _c3_basis(d, n)
+    slm = StandardLinearModel(basis, var=Parameter(0.5, Positive()), nstarts=0, maxiter=1).fit(X[:50000], y[:50000])
+    F = slm.weights_.shape[0]
+    slm.predict_moments(X[:4096])
+    ms, (Ey, Vy) = _median_ms(lambda: slm.predict_moments(X))
+    ms_mean, _ = _median_ms(lambda: slm.predict(X))
+    perr = None
+    if not args.no_parity_check:
+        orc = _oracle()
+        Phi, _, _ = _oracle_features(basis, X[:256].astype(np.float64), atleast_list(slm.hypers_))
+        Er, Vr = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
+        perr = {"Ey": parity("Ey of 256 rows vs oracle", float(np.abs(Ey[:256] - Er).max() / np.abs(Er).max()), 1e-3),
+                "Vy": parity("Vy of 256 rows vs oracle", float(np.abs(Vy[:256] - Vr).max() / np.abs(Vr).max()), 1e-3)}
+    slm._drop_serving()
+    fl = 2.0 * d * n + float(F) * F + 2.0 * F
+    return {"workload": "predict_moments, RandomMatern52 n=4096 + LinearBasis F_tot=%d D=64, N=%d HOST rows in (PCIe inside)" % (F, N),
+            "rows": N, "dtype": "f32", "ms": ms, "ms_predict_mean_only": ms_mean, "value": N / (ms * 1e-3), "unit": "rows/s",
+            "parity": perr,
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "frac": fl * N / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "_flops_per_row": fl}}
+
+
 # ----------------------------------------------------------------------------------------------------
 # N > 1: BASELINE config 3 and the C2-shape `_elbo` with the rows sharded over the ranks (slm.py:142-199 over all shards)
 # ----------------------------------------------------------------------------------------------------
@@ -1124,7 +1154,7 @@ def extra_configs(dev, _hip, args, emit=None):
                      ("posterior_F4096", lambda d_, h_, a_: config_posterior(d_, h_, a_, 4096)),
                      ("posterior_F8257", lambda d_, h_, a_: config_posterior(d_, h_, a_, 8257)),
                      ("posterior_F16384", lambda d_, h_, a_: config_posterior(d_, h_, a_, 16384)),
-                     ("predict_moments_n300k", config_predict),
+                     ("predict_moments_n300k", config_predict), ("predictc3_moments_n300k", config_predict_c3),
                      ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
                      ("C4elbo_fastfood_f16384", config_ff_elbo), ("C5_glm_poisson_svi_step", config_c5)):
         want = args.configs.lower().split(",")
