@@ -550,6 +550,21 @@ def _gloo_gpu_glm_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(900)
+def _join_or_kill(procs, timeout=120):
+    """Every worker must have exited cleanly within `timeout` s of delivering its result; one that has not is ended (it
+    would otherwise be joined forever by multiprocessing's exit handler) and fails the test."""
+    codes = []
+    for p in procs:
+        p.join(timeout)
+        if p.is_alive():
+            p.kill()
+            p.join(10)
+            codes.append("still running %d s after its result (killed)" % timeout)
+        else:
+            codes.append(p.exitcode)
+    assert all(c == 0 for c in codes), codes
+
+
 def test_two_rank_gloo_glm_with_real_device_features():
     """Row-sharded SVI on two processes with real kernels: every rank's minibatch covers its shard, so the all-reduced
     `_elbo` equals the single-process evaluation on all rows (same seed -> same draws) to f32 accuracy, and after a short
@@ -565,15 +580,17 @@ def test_two_rank_gloo_glm_with_real_device_features():
     procs = [ctx.Process(target=_gloo_gpu_glm_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=600) for _ in procs])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=600) for _ in procs])
+    finally:
+        _join_or_kill(procs)
     q1 = ctx.Queue()
     p1 = ctx.Process(target=_gloo_gpu_glm_worker, args=(0, 1, 0, q1))
     p1.start()
-    single = q1.get(timeout=600)
-    p1.join(120)
+    try:
+        single = q1.get(timeout=600)
+    finally:
+        _join_or_kill([p1])
     assert res[0][1] == res[1][1]                                                # ranks agree exactly
     ref = np.array(single[1])
     assert np.abs(np.array(res[0][1]) - ref).max() < 2e-4 * np.abs(ref).max()    # and equal the all-rows evaluation

@@ -646,6 +646,9 @@ def test_gridsearch_in_worker_processes_like_reference_test_models():
     est = GridSearchCV(glm, {"batch_size": [10, 20]}, n_jobs=2, cv=3)
     est.fit(X, y)
     assert len(est.predict(Xs)) == len(ys)
+    # joblib keeps its worker processes for reuse, each with a device context on the one GPU: ended with the test
+    from joblib.externals.loky import get_reusable_executor
+    get_reusable_executor().shutdown(wait=True, kill_workers=True)
 
 
 def _gloo_gpu_fit_worker(rank, world, port, q, n):
@@ -706,10 +709,17 @@ def test_two_rank_gloo_fit_with_real_device_state(n):
     procs = [ctx.Process(target=_gloo_gpu_fit_worker, args=(r, 2, port, q, n)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    try:
+        res = sorted(q.get(timeout=600) for _ in procs)
+    finally:  # a worker that has not exited 120 s after its result is ended and fails the test (never joined forever at exit)
+        codes = []
+        for p in procs:
+            p.join(timeout=120)
+            if p.is_alive():
+                p.kill()
+                p.join(10)
+            codes.append(p.exitcode)
+        assert codes == [0, 0], codes
     q1 = pymp.Queue()
     _gloo_gpu_fit_worker(0, 1, 0, q1, n)
     single = q1.get(timeout=10)
