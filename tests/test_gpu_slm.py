@@ -832,10 +832,20 @@ def test_predict_of_a_random_kernel_basis_comes_from_the_feature_kernel_alone(mo
         Phi = orc.rff_transform(Xa[:500].astype(np.float64), basis.W, slm.hypers_)
         assert normwise(slm.predict(X[:500]), Phi @ slm.weights_) < 1e-4
     # a large query: validated while it is uploaded
+    # (the validation of 40 000 x 5 values can be over before the wrapper above looks at the running threads: what is
+    # recorded is that the thread was MADE)
     XL = np.tile(X, (10, 1))
     del calls[:]
+    made, plain_thread = [], threading.Thread
+
+    class RecordingThread(plain_thread):
+        def __init__(self, *a, **k):
+            made.append(k.get("name"))
+            super().__init__(*a, **k)
+    monkeypatch.setattr(_hip.threading, "Thread", RecordingThread)
     EL = slm.predict(XL)
-    assert calls[0][0] and "rr-predict-check" in calls[0][1] and np.array_equal(EL[:4000], slm.predict(X))
+    monkeypatch.setattr(_hip.threading, "Thread", plain_thread)
+    assert calls[0][0] and "rr-predict-check" in made and np.array_equal(EL[:4000], slm.predict(X))
     for bad_row in (0, len(XL) - 1):
         Xb = XL.copy()
         Xb[bad_row, 2] = np.nan
@@ -897,15 +907,20 @@ def test_predict_moments_validates_a_large_query_while_the_gpu_works_on_it(monke
     y = (np.sin(X[:, 0]) + 0.1 * rs.randn(N)).astype(np.float32)
     basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(1.1, Positive()))
     slm = StandardLinearModel(basis, var=Parameter(0.3, Positive()), nstarts=0, maxiter=2).fit(X[:5000], y[:5000])
-    names = []
-    orig = _hip.RffHandle._predict
-    monkeypatch.setattr(_hip.RffHandle, "_predict",
-                        lambda self, *a, **k: (names.append([t.name for t in threading.enumerate()]), orig(self, *a, **k))[1])
+    # (which threads the call MAKES is recorded, not which are running when the upload starts: a fast host can be through
+    # with the validation by then)
+    made, plain_thread = [], threading.Thread
+
+    class RecordingThread(plain_thread):
+        def __init__(self, *a, **k):
+            made.append(k.get("name"))
+            super().__init__(*a, **k)
+    monkeypatch.setattr(_hip.threading, "Thread", RecordingThread)
     Ey, Vy = slm.predict_moments(X)
-    assert len(names) == 1 and "rr-predict-check" in names[0]
+    assert made.count("rr-predict-check") == 1
     monkeypatch.setattr(_hip.RffHandle, "PREDICT_CONCURRENT_CHECK_ROWS", 10 ** 9)   # validate first
     Ey1, Vy1 = slm.predict_moments(X)
-    assert "rr-predict-check" not in names[1] and np.array_equal(Ey, Ey1) and np.array_equal(Vy, Vy1)
+    assert made.count("rr-predict-check") == 1 and np.array_equal(Ey, Ey1) and np.array_equal(Vy, Vy1)
     Phi = orc.rff_transform(X[-300:].astype(np.float64), basis.W, slm.hypers_)
     Eo, Vo = orc.slm_predict_moments(Phi, slm.weights_, slm.covariance_, slm.var_)
     assert normwise(Ey[-300:], Eo) < 1e-3 and normwise(Vy[-300:], Vo) < 1e-3
