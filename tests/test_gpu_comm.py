@@ -353,7 +353,7 @@ def test_bench_side_configuration_that_hangs_does_not_take_the_headline_line():
     the headline and the configurations finished so far, marks the hung one, and the process exits 0."""
     env = dict(os.environ, RR_BENCH_TEST_HANG="posterior_F8257")
     r = _bench(["--rows", "300000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-alt-engine", "--no-parity-check",
-                "--configs", "posterior_f4096,posterior_f8257,predict_moments_n300k", "--config-timeout", "40"], env=env, timeout=900)
+                "--configs", "posterior_f4096,posterior_f8257,predict_moments_n300k", "--config-timeout", "20"], env=env, timeout=900)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
