@@ -521,6 +521,42 @@ int rr_stats_unpack_dev(rr_ctx *ctx, int64_t F, const double *dmsg, double *dG, 
 int rr_comm_reduce_stats_dev(rr_comm *comm, int64_t F, double *dG, double *db, double *dyty, double nrows, double *dmsg,
                              double *total_rows);
 
+/* ---- ONE process, several GPUs: the estimator's own call (rr_init(n_devices, device_ids, ...)) ----------
+ * The reference's fit is one call in one process (slm.py:74-140), driven by sklearn Pipelines / GridSearchCV
+ * (tests/test_models.py:39-80) that cannot be wrapped in a per-GPU launcher.  For that caller the row shards live in n
+ * contexts of the SAME process (rr_ctx_create once per member; two members may share a device), every member accumulates
+ * the statistics of ITS rows on its own stream, and one host thread sums them over the members:
+ *   rr_comm_init_all            n communicators, member i bound to ctxs[i] (rank i of n).  transport:
+ *                               RR_TRANSPORT_RCCL  ncclCommInitAll over the members' devices (all distinct); collectives are
+ *                                                  ncclGroupStart / per-member call on its stream / ncclGroupEnd
+ *                               RR_TRANSPORT_PEER  no library: after hipDeviceEnablePeerAccess member i's kernels load the
+ *                                                  other members' buffers directly over the xGMI mesh -- reduce-scatter
+ *                                                  (member i combines slice i of all buffers, in member order) then
+ *                                                  all-gather; bit-identical on every member, the same bits every run;
+ *                                                  also the transport of members that SHARE a device
+ *                               RR_TRANSPORT_AUTO  RCCL when every member has its own device and librccl loads, else PEER
+ *                                                  ($RR_COMM_TRANSPORT = rccl | peer overrides)
+ *   rr_comm_transport           the transport chosen
+ *   rr_comm_group_allreduce_dev in-place reduction of the members' DEVICE float64 buffers dbufs[i] (count each),
+ *                               asynchronous: ordered on every member's stream behind what produced its buffer; work queued
+ *                               afterwards on any member's stream sees the result
+ *   rr_comm_group_broadcast_dev dbufs[root]'s bytes (a multiple of 8) into every member's buffer, same ordering
+ *   rr_comm_group_reduce_stats_dev   rr_comm_reduce_stats_dev for the group: pack -> all-reduce -> unpack + mirror on every
+ *                               member; nrows[i] = member i's row count; total_rows != NULL: waits for member 0 and returns
+ *                               the summed N
+ * The per-rank collectives (rr_comm_allreduce_dev / _host, rr_comm_broadcast_host, rr_comm_barrier) refuse a member of a
+ * group of more than one: entered member by member from one thread they would wait for their peers forever.
+ * rr_comm_destroy frees a member; the group's shared record goes with its last member. */
+#define RR_TRANSPORT_AUTO 0
+#define RR_TRANSPORT_RCCL 1
+#define RR_TRANSPORT_PEER 2
+int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out /* n */);
+int rr_comm_transport(rr_comm *comm);
+int rr_comm_group_allreduce_dev(rr_comm *const *comms, int n, double *const *dbufs, int64_t count, int op);
+int rr_comm_group_broadcast_dev(rr_comm *const *comms, int n, void *const *dbufs, int64_t bytes, int root);
+int rr_comm_group_reduce_stats_dev(rr_comm *const *comms, int n, int64_t F, double *const *dG, double *const *db,
+                                   double *const *dyty, const double *nrows, double *const *dmsg, double *total_rows);
+
 /* ---- host-side random stream of the GLM step ------------------------------ */
 
 /* Advance a NumPy legacy RandomState (MT19937 + polar Box-Muller with one cached value) by n standard normals and write

@@ -212,6 +212,13 @@ SIGNATURES = {
                                            ctypes.c_void_p, ctypes.c_void_p]),
     "rr_comm_reduce_stats_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                                 ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+    # one process, several GPUs (revrand_amd/multigpu.py)
+    "rr_comm_init_all": (ctypes.c_int, [ctypes.c_int, _c_void_pp, ctypes.c_int, _c_void_pp]),
+    "rr_comm_transport": (ctypes.c_int, [ctypes.c_void_p]),
+    "rr_comm_group_allreduce_dev": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_void_pp, ctypes.c_int64, ctypes.c_int]),
+    "rr_comm_group_broadcast_dev": (ctypes.c_int, [_c_void_pp, ctypes.c_int, _c_void_pp, ctypes.c_int64, ctypes.c_int]),
+    "rr_comm_group_reduce_stats_dev": (ctypes.c_int, [_c_void_pp, ctypes.c_int, ctypes.c_int64, _c_void_pp, _c_void_pp,
+                                                      _c_void_pp, _c_double_p, _c_void_pp, _c_double_p]),
 }
 
 
@@ -430,10 +437,13 @@ class DeviceMatrix(DeviceBuffer):
 class Device(object):
     """One rr_ctx: a GPU, a stream, and helpers.  Use get_device()."""
 
+    _uids = iter(range(1, 1 << 62))
+
     def __init__(self, index):
         self.lib = load_library()
         self.index = index
         self.pid = os.getpid()
+        self.uid = ("ctx", next(Device._uids))  # distinguishes two contexts on one GPU (device_key)
         ctx = ctypes.c_void_p()
         _check(self.lib, self.lib.rr_ctx_create(index, ctypes.byref(ctx)))
         self.ctx = ctx
@@ -566,6 +576,27 @@ class Device(object):
 
 
 _devices = {}
+_tls = threading.local()  # .dev: the Device every `device=None` lookup of THIS thread resolves to (device_scope)
+
+
+@contextlib.contextmanager
+def device_scope(dev):
+    """Make `dev` (a Device) the default device of the calling thread for a block: every handle, buffer and fit state
+    created inside with `device=None` lives on it.  How the members of an in-process device group (multigpu.DeviceGroup:
+    one host thread per member) run the single-device classes unchanged."""
+    prev = getattr(_tls, "dev", None)
+    _tls.dev = dev
+    try:
+        yield dev
+    finally:
+        _tls.dev = prev
+
+
+def device_key():
+    """(pid, context id) of the calling thread's default device: the key of per-process, per-context caches (a basis'
+    device handles), so that a basis used on several members of a device group holds one handle per member."""
+    dev = getattr(_tls, "dev", None)
+    return (os.getpid(), dev.uid if dev is not None else ("default", default_device_index()))
 
 
 def default_device_index():
@@ -577,6 +608,12 @@ def default_device_index():
 
 def get_device(index=None):
     """The process-local Device for GPU `index` (default: $REVRAND_HIP_DEVICE, $LOCAL_RANK, 0)."""
+    if isinstance(index, Device):
+        return index
+    if index is None:
+        cur = getattr(_tls, "dev", None)
+        if cur is not None and cur.pid == os.getpid():
+            return cur
     index = default_device_index() if index is None else int(index)
     key = (os.getpid(), index)
     dev = _devices.get(key)
@@ -628,16 +665,18 @@ def legacy_randn(random_state, n, dtype=np.float32, threads=2):
 @contextlib.contextmanager
 def gram_engine_scope(name, index=None):
     """Select the arithmetic of the f32 Gram / U = Phi C / GLM GEMMs (Device.set_gram_engine) for a block; None = leave
-    the context's setting (RR_SYRK_ENGINE or an earlier set_gram_engine) alone."""
+    the context's setting (RR_SYRK_ENGINE or an earlier set_gram_engine) alone.  index: a GPU index, a Device, or a list
+    of Devices (the members of a device group)."""
     if name is None:
         yield
         return
-    dev = get_device(index)
-    prev = dev.set_gram_engine(name)
+    devs = list(index) if isinstance(index, (list, tuple)) else [get_device(index)]
+    prev = [dev.set_gram_engine(name) for dev in devs]
     try:
         yield
     finally:
-        dev.set_gram_engine(prev)
+        for dev, p in zip(devs, prev):
+            dev.set_gram_engine(p)
 
 
 def device_available():

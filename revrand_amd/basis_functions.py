@@ -249,6 +249,31 @@ class _LengthScaleBasis(Basis):
 # Random Fourier feature bases on the GPU (reference: basis_functions.py:818-1208)
 # --------------------------------------------------------------------------------------
 
+def _sharded_gram(basis, X, y, params, devices):
+    """``basis.gram(X, y, *params, devices=...)``: the statistics of all rows with the row shards resident on the GPUs of
+    ``devices`` (one process; revrand_amd/multigpu.py)."""
+    from . import multigpu
+    if isinstance(basis, BasisCat):
+        hyp = list(params) or basis.params_values()
+    else:  # one length-scale basis: validated as its own `gram` would (apply_ind slicing happens in device_fit_state)
+        hyp = basis._check_dim(basis.d, params[0] if params else None)
+    res = multigpu.gram(basis, X, y, hyp, devices)
+    if res is None:  # no device-resident route for this basis: its one-GPU statistics
+        return basis.gram(X, y, *params)
+    return res
+
+
+def _handle_cache(basis, name="_hip_handle"):
+    """(cache, key) of a basis' device handles: one per process AND per device context (`_hip.device_key`) -- a basis
+    whose rows are sharded over the members of a device group (multigpu.ShardedFitState) holds W once on every member.
+    Entries of another process (a fork) are dropped; the cache is never pickled."""
+    cache = basis.__dict__.get(name)
+    key = _hip.device_key()
+    if not isinstance(cache, dict) or any(k[0] != key[0] for k in cache):
+        cache = basis.__dict__[name] = {}
+    return cache, key
+
+
 class _DevicePosterior(object):
     """Mixin of the fit states: the sufficient statistics [G | b | y^T y] of the last Gram pass and the posterior
     covariance stay in HBM (rr_posterior_dev), so an `_elbo` evaluation moves O(F) numbers over PCIe."""
@@ -328,10 +353,19 @@ class DeviceFitState(_DevicePosterior):
     def gram_device(self, lenscale, reduce=None):
         """Statistics of this length scale into the resident buffer (summed over ranks by `reduce`); returns
         y^T y."""
+        self.gram_launch(lenscale)
+        return self._finish_stats(reduce, self.dX.shape[0])
+
+    def gram_launch(self, lenscale):
+        """The asynchronous part of ``gram_device``: this state's rows into its (zeroed) accumulators, nothing waited for --
+        a device group queues it on every member before it sums the members' statistics (multigpu.ShardedFitState)."""
         self.dev.memset(self.acc)
         pG, pb, pt = self._stat_ptrs()
         self.handle.gram_dev(self.dX, self.dy, lenscale, pG, pb, pt)
-        return self._finish_stats(reduce, self.dX.shape[0])
+
+    @property
+    def nrows(self):
+        return self.dX.shape[0]
 
     def second_pass(self, lenscale, m, C, var):
         sq, T = self.handle.elbo_pass2(self.dX, self.dy, lenscale, m, C)
@@ -794,13 +828,21 @@ class CatFitState(_DevicePosterior):
     def gram_device(self, hypers, reduce=None):
         """Statistics of these hyper-parameters into the resident buffer (summed over ranks by `reduce`);
         returns y^T y."""
+        self.gram_launch(hypers)
+        return self._finish_stats(reduce, self.N)
+
+    def gram_launch(self, hypers):
+        """The part of ``gram_device`` before the statistics are summed / mirrored (see DeviceFitState.gram_launch)."""
         hypers = atleast_list(hypers)
         self.dev.memset(self.acc)
         pG, pb, pt = self._stat_ptrs()
         for r0, rows in self._chunks():
             self._fill(r0, rows, hypers)
             self.fm.gram_into(_hip.DeviceView(self.dy, r0, rows), pG, pb, pt)
-        return self._finish_stats(reduce, self.N)
+
+    @property
+    def nrows(self):
+        return self.N
 
     def gram(self, hypers):
         self.gram_device(hypers)
@@ -867,12 +909,12 @@ class _RandomKernelBasis(_LengthScaleBasis):
 
     # device handle: created on first use in this process, never pickled
     def _handle(self):
-        h = self.__dict__.get("_hip_handle")
-        if h is None or h[0] != _hip.os.getpid():
+        cache, key = _handle_cache(self)
+        h = cache.get(key)
+        if h is None:
             compute = "f32p64" if getattr(self, "phase64", False) else self.dtype
-            h = (_hip.os.getpid(), _hip.RffHandle(self.W, compute=compute))
-            self.__dict__["_hip_handle"] = h
-        return h[1]
+            h = cache[key] = _hip.RffHandle(self.W, compute=compute)
+        return h
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -898,9 +940,15 @@ class _RandomKernelBasis(_LengthScaleBasis):
         lenscale = self._check_dim(D, lenscale)
         return self._handle().grad(X, lenscale)
 
+    def gram(self, X, y=None, lenscale=None, devices=None):
+        """Fused (Phi^T Phi, Phi^T y, y^T y) without materialising Phi (slm.py:145-146,157).  devices: row shards on
+        several GPUs of this process, summed in HBM (multigpu.gram; same result to float64 rounding)."""
+        if devices is not None:
+            return _sharded_gram(self, X, y, [lenscale], devices)
+        return self._gram_one(X, y, lenscale)
+
     @slice_transform
-    def gram(self, X, y=None, lenscale=None):
-        """Fused (Phi^T Phi, Phi^T y, y^T y) without materialising Phi (slm.py:145-146,157)."""
+    def _gram_one(self, X, y=None, lenscale=None):
         N, D = X.shape
         lenscale = self._check_dim(D, lenscale)
         return self._handle().gram(X, y, lenscale)
@@ -1087,19 +1135,19 @@ class FastFoodRBF(_LengthScaleBasis):
         def get(self):
             if self.rff is None:
                 self.V = self.ff.vx(np.eye(self.owner.d), 1.0)  # (d, n): dense equivalent of the chain
-                self.rff = _hip.RffHandle(self.V, compute=self.owner.dtype)
+                self.rff = _hip.RffHandle(self.V, compute=self.owner.dtype, device=self.ff.dev)
             return self.rff
 
         def __getattr__(self, name):  # h.grad(...), h.gram(...), h.upload(...), ... on the dense handle
             return getattr(self.get(), name)
 
     def _handles(self):
-        h = self.__dict__.get("_hip_handle")
-        if h is None or h[0] != _hip.os.getpid():
+        cache, key = _handle_cache(self)
+        h = cache.get(key)
+        if h is None:
             ff = _hip.FastFoodHandle(self.d, self.d2, self.k, self.B, self.G, self.PI, self.S, compute=self.dtype)
-            h = (_hip.os.getpid(), ff, FastFoodRBF._LazyDense(self, ff))
-            self.__dict__["_hip_handle"] = h
-        return h[1], h[2]
+            h = cache[key] = (ff, FastFoodRBF._LazyDense(self, ff))
+        return h
 
     def __getstate__(self):
         state = dict(self.__dict__)
@@ -1125,8 +1173,13 @@ class FastFoodRBF(_LengthScaleBasis):
         lenscale = self._check_dim(X.shape[1], lenscale)
         return self._handles()[1].grad(X, lenscale)
 
+    def gram(self, X, y=None, lenscale=None, devices=None):
+        if devices is not None:
+            return _sharded_gram(self, X, y, [lenscale], devices)
+        return self._gram_one(X, y, lenscale)
+
     @slice_transform
-    def gram(self, X, y=None, lenscale=None):
+    def _gram_one(self, X, y=None, lenscale=None):
         lenscale = self._check_dim(X.shape[1], lenscale)
         return self._handles()[1].gram(X, y, lenscale)
 
@@ -1273,7 +1326,7 @@ class BasisCat(object):
                 full[:, ends[i]:ends[i + 1]] = gg
                 yield full
 
-    def gram(self, X, y=None, *params):
+    def gram(self, X, y=None, *params, devices=None):
         """(Phi^T Phi, Phi^T y, y^T y) of the concatenation with Phi assembled ON the device: every
         child writes its column block of one feature matrix (random Fourier / FastFood / linear bases
         by kernels, anything else by one upload of its host block), one MFMA SYRK reduces it
@@ -1282,6 +1335,10 @@ class BasisCat(object):
         dense Gram of the transformed features instead."""
         if any(getattr(b, "dtype", "f32") != "f32" for b in self.bases):
             return None
+        if devices is not None:  # row shards on several GPUs of this process (resident children), summed in HBM
+            res = _sharded_gram(self, X, y, list(params), devices)
+            if res is not None:
+                return res
         N = X.shape[0]
         F = int(self.get_dim(X))
         ends = self.__base_locations(X)
@@ -1341,11 +1398,11 @@ class BasisCat(object):
         # -- allocating 16 GB of them per call cost 0.6 s at N = 300 k, F = 4129, ten times the arithmetic
         chunk = int(max(256, min(N, 65536, (24 << 30) // (12 * Fp))))
         chunk = (chunk + 255) // 256 * 256
-        cached = self.__dict__.get("_pm_fm")
-        if cached is None or cached[0] != _hip.os.getpid() or cached[1].F != F or cached[1].max_rows < chunk:
-            self.__dict__["_pm_fm"] = None  # free the old one first
-            cached = self.__dict__["_pm_fm"] = (_hip.os.getpid(), _hip.FeatureMatrix(chunk, F))
-        fm = cached[1]
+        cache, key = _handle_cache(self, "_pm_fm")
+        fm = cache.get(key)
+        if fm is None or fm.F != F or fm.max_rows < chunk:
+            cache[key] = fm = None  # free the old one first
+            fm = cache[key] = _hip.FeatureMatrix(chunk, F)
         fm.pass2_begin(m, C, predict=True)
         Ey, Vf = np.empty(N), np.empty(N)
         for r0 in range(0, N, chunk):

@@ -53,6 +53,12 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         statistics ``[tri G | b | y^T y | N]`` and ``[sqErr | dhyp]`` with one all-reduce each, so all ranks walk the same
         L-BFGS path and end with identical parameters.  Needs a single random-feature basis (the
         device-resident path) and a fixed ``random_state`` shared by all ranks when ``nstarts > 0``.
+    devices : None | sequence of GPU indices | int | "all"
+        Several GPUs behind THIS call, in this process (``revrand_amd.multigpu``): the rows of ``fit`` / ``predict_moments``
+        are sharded over the listed GPUs (an int n: GPUs 0..n-1; "all": every visible one; an index may repeat), the
+        per-GPU statistics are summed in HBM by one in-process collective (RCCL, or the library's peer kernels over xGMI)
+        and the posterior is replicated.  No launcher, no environment: what a ``Pipeline`` / ``GridSearchCV`` caller of the
+        reference (one ``fit`` call, slm.py:74-140) can use.  None: one GPU (``REVRAND_HIP_DEVICE`` / 0).
     gram_engine : None | "f32" | "fp16x3" | "bf16x3" | "bf16x4"
         Arithmetic of ``Phi^T Phi`` and ``Phi C`` for "f32" bases during ``fit`` / ``predict_moments``
         (``include/revrand_hip.h``, RR_GRAM_*): None keeps the device context's setting (exact f32 MFMA unless
@@ -60,9 +66,10 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
     """
 
     def __init__(self, basis=LinearBasis(), var=Parameter(gamma(1.), Positive()), tol=1e-8, maxiter=1000,
-                 nstarts=100, random_state=None, distributed=False, gram_engine=None):
+                 nstarts=100, random_state=None, distributed=False, gram_engine=None, devices=None):
         self.basis = basis
         self.gram_engine = gram_engine
+        self.devices = devices
         self.var = var
         self.tol = tol
         self.maxiter = maxiter
@@ -73,8 +80,19 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
 
     def fit(self, X, y):
         """Learn (var, regularizer, basis hyper-parameters); returns self (slm.py:74-140)."""
-        with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+        with self._engine_scope():
             return self._fit(X, y)
+
+    def _group(self):
+        """The device group of ``devices=`` (None: the single default device)."""
+        if getattr(self, "devices", None) is None:
+            return None
+        from . import multigpu
+        return multigpu.get_group(self.devices)
+
+    def _engine_scope(self):
+        g = self._group()
+        return _hip.gram_engine_scope(getattr(self, "gram_engine", None), None if g is None else g.members)
 
     def _fit(self, X, y):
         X, y = check_X_y(X, y)
@@ -114,6 +132,16 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
 
     def _make_state(self, X, y):
         """(X, y) resident on the device for the whole optimisation, when the basis supports it."""
+        group = self._group()
+        if group is not None:
+            if self.distributed:
+                raise ValueError("devices= (several GPUs in this process) and distributed=True (one process per GPU) "
+                                 "cannot be combined")
+            from . import multigpu
+            st = multigpu.ShardedFitState.make(self.basis, X, y, group)
+            if st is not None:
+                return st
+            log.info("devices=%s: this basis / row count has no sharded device-resident fit; one GPU is used", self.devices)
         make = getattr(self.basis, "device_fit_state", None)
         return make(X, y) if make is not None else None
 
@@ -322,7 +350,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         s = self.__dict__.get("_serve")
         if s is None or s["pid"] != os.getpid() or s["key"] != key:
             self._drop_serving()
-            s = self.__dict__["_serve"] = {"pid": os.getpid(), "key": key, "cov": None, "feats": None}
+            s = self.__dict__["_serve"] = {"pid": os.getpid(), "key": key, "cov": {}, "feats": None}
         return s
 
     def _drop_serving(self):
@@ -330,14 +358,16 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         if s is not None and s["pid"] == os.getpid():
             if s["feats"] is not None:
                 s["feats"].release()
-            if s["cov"] is not None:
-                s["cov"].free()
+            for cov in s["cov"].values():
+                cov.free()
 
     def _device_covariance(self):
+        """The posterior covariance in the HBM of the calling thread's device (uploaded once per device context)."""
         s = self._serving()
-        if s["cov"] is None:
-            s["cov"] = _hip.DeviceCovariance(_hip.get_device(), self.covariance_)
-        return s["cov"]
+        key = _hip.device_key()
+        if key not in s["cov"]:
+            s["cov"][key] = _hip.DeviceCovariance(_hip.get_device(), self.covariance_)
+        return s["cov"][key]
 
     def __getstate__(self):
         state = dict(super().__getstate__())  # sklearn's (adds its version tag)
@@ -353,8 +383,10 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
         if getattr(self.basis, "_predict_checks_rows", False) and getattr(self.basis, "predict_moments", None) is not None:
             Xs = check_array(X, **_NO_FINITE_CHECK)
-            with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
-                res = self.basis.predict_moments(Xs, self.hypers_, self.weights_, None, check_rows=check_array)
+            # the deferred validation sees the caller's WHOLE rows, whatever columns the basis' `apply_ind` keeps (the
+            # reference validates X before any slicing, slm.py:214)
+            with self._engine_scope():
+                res = self._sharded_moments(Xs, None, deferred=True)
             if res is not None:
                 return res[0]
         X = check_array(X)
@@ -371,13 +403,30 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         srv = self._serving()
         if srv["feats"] is None:
             srv["feats"] = MinibatchFeatures(self.basis)
-        with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+        with self._engine_scope():
             return srv["feats"].project(X, atleast_list(self.hypers_), np.asarray(self.weights_, dtype=float)[:, None])[:, 0]
 
     def predict_moments(self, X):
         """Predictive mean and variance (slm.py:219-244)."""
-        with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+        with self._engine_scope():
             return self._predict_moments(X)
+
+    def _sharded_moments(self, X, with_cov, deferred):
+        """``basis.predict_moments`` of the query rows -- on the one default device, or row-sharded over the members of
+        ``devices=`` (every member uploads the covariance once and serves its rows; rows are independent, so the result is
+        the single-device one bit for bit).  with_cov None: the mean alone.  deferred: the basis validates the rows itself
+        (finiteness, under the GPU's work); it is handed a check of the caller's whole rows, not of its column slice."""
+        pm = self.basis.predict_moments
+        hyp, w = self.hypers_, self.weights_
+
+        def serve(Xr):
+            kw = {"check_rows": (lambda _sliced, Xr=Xr: check_array(Xr))} if deferred else {}
+            return pm(Xr, hyp, w, self._device_covariance() if with_cov else None, **kw)
+        group = self._group()
+        if group is None or X.shape[0] < 2 * group.n:
+            return serve(X)
+        from . import multigpu
+        return multigpu.map_rows(group, X.shape[0], lambda i, s, e: serve(X[s:e]))
 
     def _predict_moments(self, X):
         check_is_fitted(self, ["var_", "regularizer_", "weights_", "covariance_", "hypers_"])
@@ -387,9 +436,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         deferred = getattr(self.basis, "_predict_checks_rows", False) and getattr(self.basis, "predict_moments", None) is not None
         X = check_array(X, **(_NO_FINITE_CHECK if deferred else {}))
         if getattr(self.basis, "predict_moments", None) is not None:
-            # on the GPU, with the covariance already resident there
-            kw = {"check_rows": check_array} if deferred else {}
-            res = self.basis.predict_moments(X, self.hypers_, self.weights_, self._device_covariance(), **kw)
+            # on the GPU(s), with the covariance already resident there
+            res = self._sharded_moments(X, True, deferred)
             if res is not None:
                 return res[0], res[1] + self.var_
         if deferred:
