@@ -751,7 +751,7 @@ def _oracle_features(basis, X64, hyp):
     return Phi, slabs, [slice(int(ends[i]), int(ends[i + 1])) for i in range(len(blocks))]
 
 
-def _elbo_parity(make_basis, X, y, var, reg, hyp, rows=256):
+def _elbo_parity(make_basis, X, y, var, reg, hyp, rows=256, devices=None):
     """One `_elbo` of the product on the first `rows` rows (resident route, device posterior, ONE process) against the
     oracle's slm_elbo on the same rows in float64: (rel. error of -ELBO, normwise error of [dvar, dreg, dhyp])."""
     from revrand_amd import parallel
@@ -759,9 +759,9 @@ def _elbo_parity(make_basis, X, y, var, reg, hyp, rows=256):
     orc = _oracle()
     Xs, ys = np.ascontiguousarray(X[:rows]), np.ascontiguousarray(y[:rows])
     basis = make_basis()
-    slm = StandardLinearModel(basis)
+    slm = StandardLinearModel(basis, devices=devices)
     slm.obj_ = -np.inf
-    slm._state = basis.device_fit_state(Xs, ys)
+    slm._state = slm._make_state(Xs, ys)
     f, (gv, gr, gh) = slm._elbo(Xs, ys, var, reg, hyp)
     slm._state.release()
     slm._state = None
@@ -772,6 +772,90 @@ def _elbo_parity(make_basis, X, y, var, reg, hyp, rows=256):
     got = np.concatenate(([gv], np.atleast_1d(gr), np.atleast_1d(gh)))
     want = np.concatenate(([-ref["dvar"]], [-g for g in ref["dreg"]], [-g for g in ref["dhyp"]]))
     return abs(f + ref["elbo"]) / abs(ref["elbo"]), float(np.linalg.norm(got - want) / np.linalg.norm(want))
+
+
+def config_c1(dev, _hip, args):
+    """BASELINE configs[0] -- RandomRBF nbases = 256, D = 8, N = 10k through StandardLinearModel (slm.py:74-199) -- as a
+    LATENCY line: what a GridSearchCV user waits for per `_elbo` and per `fit` in the launch-bound regime, next to the same
+    call of the oracle port on this box's host cores (0.375 s per `_elbo`, 21.1 s per fit for the
+    reference in the survey container).  Data and start values are those of tests/golden/fit_c1.npz (oracle/make_golden.py
+    c1_data / gen_fit_c1); parity: one `_elbo` at the reference's fitted point against the reference's own evaluation."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    orc = _oracle()
+    N, d, n = 10_000, 8, 256
+    r = np.random.RandomState(11)
+    X = r.randn(N, d)
+    y = np.sin(X @ np.array([1.0, -0.7, 0.5, 0.3, -0.2, 0.9, -0.4, 0.1])) + 0.1 * r.randn(N)
+    with np.load(os.path.join(ROOT, "tests", "golden", "fit_c1.npz")) as z:
+        g = {k: z[k] for k in z.files}
+
+    def make(dtype="f32"):
+        return bs.RandomRBF(nbases=n, Xdim=d, random_state=41, lenscale=Parameter(2.0, Positive()),
+                            regularizer=Parameter(10.0, Positive()), dtype=dtype)
+    var, reg, hyp = float(g["c1_var_"]), float(g["c1_reg_"]), float(g["c1_hyp_"])
+    out = {}
+    for dtype in ("f32", "f64"):
+        slm = StandardLinearModel(make(dtype))
+        slm.obj_ = -np.inf
+        slm._defer_cov = True
+        slm._state = slm._make_state(X, y)
+        f, grads = slm._elbo(X, y, var, reg, hyp)  # warm; and the parity evaluation
+        tol = 1e-3 if dtype == "f32" else 1e-7
+        parity("%s: -ELBO at the reference's fitted point" % dtype, abs(-f - float(g["c1_at_elbo"])) / abs(float(g["c1_at_elbo"])), tol * 0.1)
+        parity("%s: posterior weights there" % dtype, float(np.abs(slm.weights_ - g["c1_at_m"]).max() / np.abs(g["c1_at_m"]).max()), tol)
+        ts = []
+        for k in range(30):
+            t0 = time.perf_counter()
+            slm._elbo(X, y, var, reg, hyp * (1.0 + 1e-6 * k))  # a new length scale every call, as the optimiser's
+            ts.append(1e3 * (time.perf_counter() - t0))
+        slm._state.release()
+        slm._state = None
+        t_fit = []
+        nev = 0
+        for _ in range(3):
+            est = StandardLinearModel(make(dtype), var=Parameter(0.02, Positive()), nstarts=0, maxiter=20, random_state=0)
+            calls = [0]
+            inner = StandardLinearModel._elbo_resident
+
+            def counted(self_, *a, **k):
+                calls[0] += 1
+                return inner(self_, *a, **k)
+            StandardLinearModel._elbo_resident = counted
+            try:
+                t0 = time.perf_counter()
+                est.fit(X, y)
+                t_fit.append(time.perf_counter() - t0)
+            finally:
+                StandardLinearModel._elbo_resident = inner
+            nev = calls[0]
+        out[dtype] = {"elbo_ms": float(np.median(ts)), "elbo_ms_min": float(np.min(ts)), "fit_s": float(np.median(t_fit)),
+                      "fit_elbo_evaluations": nev, "fit_obj": float(est.obj_)}
+    # the same `_elbo` of the oracle port (features, Gram, Cholesky, gradients: NumPy / BLAS on the host cores)
+    W = make().W
+    t_cpu = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        Phi = orc.rff_transform(X, W, hyp)
+        dP = orc.rff_grad(X, W, hyp)
+        orc.slm_elbo(Phi, y, var, np.full(2 * n, reg), slice(None), [dP])
+        t_cpu.append(time.perf_counter() - t0)
+    threads, _ = _blas_threads()
+    cpu_ms = 1e3 * float(np.median(t_cpu))
+    F = 2 * n
+    fl = (flops_per_row(d, n) + 2.0 * F * F + 4.0 * d * n) * N + F ** 3 * 4.0 / 3.0
+    return {"workload": "StandardLinearModel, RandomRBF nbases=256 D=8 N=10k (BASELINE configs[0]): one resident _elbo and "
+                        "fit(nstarts=0, maxiter=20)", "rows": N, "dtype": "f32",
+            "ms": out["f32"]["elbo_ms"], "value": 1e3 / out["f32"]["elbo_ms"], "unit": "_elbo evaluations/s",
+            "f32": out["f32"], "f64": out["f64"],
+            "cpu_baseline": {"value": 1e3 / cpu_ms, "unit": "_elbo evaluations/s", "ms": cpu_ms, "cores": threads, "kind": "port",
+                             "sample": "the same evaluation (features, gradient tensor, Gram, Cholesky) by oracle/revrand_oracle.py, f64, "
+                                       "median of 3; BASELINE.md section 3 quotes 375 ms for the reference in the survey container"},
+            "parity": {"fit_obj_vs_reference_f64": abs(out["f64"]["fit_obj"] - float(g["c1_obj"])) / abs(float(g["c1_obj"]))},
+            "roofline": {"bound": "launch latency", "peak": PEAK_F32_MFMA_TFLOPS,
+                         "frac": fl / (out["f32"]["elbo_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                         "_note": "0.11 GFLOP per evaluation: 0.7 us of the matrix pipe; the call is host + launch latency"}}
 
 
 def config_elbo(dev, _hip, args, dtype="f32", N=1_000_000):
@@ -1148,7 +1232,7 @@ def extra_configs(dev, _hip, args, emit=None):
     """`emit(configs)`: writes the bench line with the configurations finished so far -- called by the watchdog when
     one of them hangs, so that the headline measurement is never lost to a side configuration."""
     res = {}
-    for name, fn in (("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
+    for name, fn in (("C1_elbo_latency", config_c1), ("C2_rbf_f4096_n1m", config_c2), ("headline_shape_f64", config_f64),
                      ("C2laplace_f64phase_n1m", config_laplace), ("C2_elbo_eval", config_elbo),
                      ("C2f64_elbo_eval_n200k", lambda d_, h_, a_: config_elbo(d_, h_, a_, dtype="f64", N=200_000)),
                      ("posterior_F4096", lambda d_, h_, a_: config_posterior(d_, h_, a_, 4096)),
@@ -1179,6 +1263,347 @@ def extra_configs(dev, _hip, args, emit=None):
     return res
 
 
+# ----------------------------------------------------------------------------------------------------
+# where the GPUs sit, and what the link between them moves -- measured before anything is timed
+# ----------------------------------------------------------------------------------------------------
+
+XGMI_LINK_GBPS = 153.0  # MI355X_MICROARCH.md: per-link, per-direction xGMI bandwidth of the 8-GPU mesh (7 links per GPU)
+
+
+def placement(dev, pin=True):
+    """PCI bus id and host memory node of a context's GPU; pin: the calling process's threads go to that node's CPUs (a
+    rank's staging copies and its launch thread then sit next to its GPU).  Never fatal."""
+    info = {"device": dev.index}
+    try:
+        info["pci"] = dev.pci_bus_id
+        info["numa"] = dev.numa_node
+        cpus = dev.numa_cpus()
+        if pin and cpus and hasattr(os, "sched_setaffinity") and os.environ.get("RR_BENCH_NO_PIN") != "1":
+            allowed = os.sched_getaffinity(0) & cpus
+            if allowed:
+                os.sched_setaffinity(0, allowed)
+                info["pinned_cpus"] = len(allowed)
+    except Exception as e:  # a container without /sys, a restricted cpuset, ...
+        info["_error"] = "%s: %s" % (type(e).__name__, e)
+    return info
+
+
+def exchange_model_ms(nbytes, world):
+    """DESIGN 5's model of one all-reduce of S bytes over the xGMI mesh: 2 (n-1)/n S per GPU at one link's rate (a ring; the
+    direct peer algorithm spreads the same bytes over all n-1 links)."""
+    return 2.0 * (world - 1) / world * nbytes / (XGMI_LINK_GBPS * 1e9) * 1e3 if world > 1 else 0.0
+
+
+def preflight_exchange(reduce_fn, sync_fn, timer_dev, count, world, reps=3):
+    """One warm-up and `reps` timed in-place all-reduces of `count` float64 (config 3's 273 MB message by default) BEFORE
+    anything else is timed: the first collective over a transport this repository has never been measured on must not be
+    inside a timed region, and its bus bandwidth says at once whether the ranks talk over xGMI (P2P), PCIe or sockets."""
+    nbytes = 8 * count
+    reduce_fn()
+    sync_fn()
+    ms = []
+    for _ in range(reps):
+        sync_fn()
+        timer_dev.timer_start()
+        reduce_fn()
+        ms.append(timer_dev.timer_stop())
+        sync_fn()
+    best = float(min(ms))
+    busbw = 2.0 * (world - 1) / world * nbytes / (best * 1e-3) / 1e9 if world > 1 and best > 0 else None
+    model = exchange_model_ms(nbytes, world)
+    return {"message_bytes": nbytes, "ms": best, "ms_all": [float(m) for m in ms], "busbw_GBps": busbw,
+            "model_ms_at_one_xgmi_link": model, "busbw_frac_of_one_link": (busbw / XGMI_LINK_GBPS) if busbw else None}
+
+
+# ----------------------------------------------------------------------------------------------------
+# --single-process: the same step, N GPUs behind ONE process (StandardLinearModel(devices=...)'s machinery)
+# ----------------------------------------------------------------------------------------------------
+
+def single_process(args, json_out):
+    """`python bench.py --gpus N --single-process`: the headline step with the row shards on the members of an in-process
+    device group (revrand_amd/multigpu.py: one context and one host thread per GPU, ONE collective per step through
+    rr_comm_group_reduce_stats_dev) -- what `StandardLinearModel(basis, devices=N).fit` runs -- then one `_elbo` of that
+    estimator.  Same line shape as the one-process-per-GPU run.  With fewer GPUs than members (the 1-GPU test box) members
+    share devices: plumbing only, flagged "oversubscribed"."""
+    from revrand_amd import _hip, multigpu, parallel
+    ndev = multigpu.visible_devices()
+    world = args.gpus
+    devices = list(range(world)) if ndev >= world else [r % ndev for r in range(world)]
+    group = multigpu.get_group(devices)
+    d, n = args.dim, args.nbases
+    F = 2 * n
+    W = np.random.RandomState(42).randn(d, n)
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    if args.engine:
+        group.set_gram_engine(args.engine)
+    place = [{"device": m.index, "pci": m.pci_bus_id, "numa": m.numa_node} for m in group.members]
+    peers_ok = all(a.can_access_peer(b.index) for a in group.members for b in group.members)
+    CH = 250_000
+    bounds = [parallel.shard_bounds(args.rows, i, world) for i in range(world)]
+    nacc = F * F + F + 1
+
+    class Shard(object):
+        pass
+
+    def build(i):
+        dev = _hip.get_device()  # member i's context (this is its thread)
+        sh = Shard()
+        sh.dev = dev
+        sh.basis = _hip.RffHandle(W, compute="f32")
+        row0, row1 = bounds[i]
+        sh.rows = row1 - row0
+        sh.dX = dev.empty_matrix(sh.rows, d, np.float32, ld_dev=sh.basis.padded_dim)
+        sh.dy = dev.malloc(max(sh.rows, 1) * 4)
+        sh.dy.dtype = np.dtype(np.float32)
+        r0 = 0
+        for c in range(row0 // CH, (row1 + CH - 1) // CH if sh.rows else 0):
+            c0 = c * CH
+            Xc, yc = gen_chunk(c, min(CH, args.rows - c0), d, wvec)
+            lo, hi = max(row0, c0) - c0, min(row1, c0 + CH) - c0
+            Xc, yc = np.ascontiguousarray(Xc[lo:hi]), np.ascontiguousarray(yc[lo:hi])
+            dev.upload_rows(sh.dX, r0, Xc)
+            _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, _hip.ctypes.c_void_p(sh.dy.ptr.value + r0 * 4),
+                                                       yc.ctypes.data_as(_hip.ctypes.c_void_p), yc.nbytes))
+            r0 += hi - lo
+        sh.acc = dev.zeros(nacc * 8)
+        base = sh.acc.ptr.value
+        sh.ptrs = tuple(_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
+        return sh
+    shards = group.map(build)
+    m0 = group.members[0]
+
+    # ---- preflight: config 3's message through the group's collective, before anything is timed ----
+    cnt3 = parallel.stats_count(8257)
+    pre_bufs = group.map(lambda i: _hip.get_device().zeros(cnt3 * 8))
+    pre = preflight_exchange(lambda: group.allreduce_device(pre_bufs, cnt3), group.sync, m0, cnt3, world)
+    for b in pre_bufs:
+        b.free()
+
+    kernel_ms, exch_ms = [], []
+
+    def launch(i):
+        sh = shards[i]
+        _hip._check(sh.dev.lib, sh.dev.lib.rr_memset(sh.dev.ctx, sh.ptrs[0], 0, nacc * 8))
+        if sh.rows:
+            sh.basis.gram_dev(sh.dX, sh.dy, 1.0, *sh.ptrs)
+
+    def step(timed):
+        group.map(launch)
+        if timed:
+            m0.timer_start()
+        group.reduce_stats(F, [sh.ptrs for sh in shards], [sh.rows for sh in shards], wait=False)
+        if timed:
+            exch_ms.append(m0.timer_stop())
+        group.sync()
+        if timed:
+            kernel_ms.append([sh.basis.gram_timings() for sh in shards])
+
+    for _ in range(args.warmup):
+        step(False)
+    group.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    group.sync()
+    elapsed = time.perf_counter() - t0
+    Gs = [sh.dev.download(sh.acc, (F, F), np.float64) for sh in shards]
+    G = Gs[0]
+    trace_err = abs(float(np.trace(G)) - args.rows) / args.rows
+    members_identical = all(np.array_equal(G, Gi) for Gi in Gs[1:])
+    assert np.array_equal(G, G.T)
+    del Gs, G
+    per_member = [float(np.mean([k[i][0] + k[i][1] + k[i][2] for k in kernel_ms])) for i in range(world)]
+    syrk0 = float(np.mean([k[0][1] for k in kernel_ms]))
+    launches = kernel_ms[0][0][3]
+    widths = [min(256, F - 256 * i) for i in range((F + 255) // 256)]
+    off_flops = 2.0 * sum(widths[i] * widths[j] for i in range(len(widths)) for j in range(i + 1, len(widths)))
+    achieved = off_flops * shards[0].rows / (syrk0 * 1e-3) / 1e12
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    cnt = parallel.stats_count(F)
+    xm = float(np.mean(exch_ms))
+    rt = runtime_info(_hip, parallel)
+    out = {
+        "metric": "feature-rows/sec (Phi + PhiT Phi + PhiT y) at N=%s D=%d F=%d" % (
+            "10M" if args.rows == 10_000_000 else args.rows, d, F),
+        "value": args.rows / (elapsed / max(args.steps, 1)), "unit": "feature-rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "RandomRBF nbases=%d (F=%d), D=%d, N=%d f32, features + MFMA Gram, rows sharded over %d GPU(s) "
+                               "of ONE process (devices=%s)" % (n, F, d, args.rows, world, devices),
+                   "single_process": True, "rows_per_gpu": shards[0].rows, "device": m0.name.strip(), "trace_rel_err": trace_err,
+                   "members_bit_identical": bool(members_identical), "gram_engine": m0.gram_engine,
+                   "runtime": {"hip_runtime": os.path.basename(rt["hip_runtime"] or ""),
+                               "rccl": rt["rccl"].get("version", rt["rccl"].get("error"))}},
+        "roofline": {"bound": "mfma", "kernel": "rr_syrk_f32_kernel", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                     "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                     "kernel_ms_per_step": syrk0, "launches_per_step": launches, "avg_launch_ms": syrk0 / max(launches, 1),
+                     "flops_per_row": off_flops, "rows_per_step": shards[0].rows,
+                     "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1)) / world / 1e12
+                     / PEAK_F32_MFMA_TFLOPS},
+        "exchange": {"transport": group.transport, "message_float64": cnt, "message_bytes": 8 * cnt,
+                     "ms_per_step_pack_allreduce_unpack": xm,
+                     "busbw_GBps": 2.0 * (world - 1) / world * 8 * cnt / (xm * 1e-3) / 1e9 if world > 1 and xm > 0 else None,
+                     "model_ms_at_one_xgmi_link": exchange_model_ms(8 * cnt, world),
+                     "visible_gpus": ndev, "distinct_gpus": len(set(devices)), "oversubscribed": len(set(devices)) < world,
+                     "peer_access": bool(peers_ok), "preflight": pre, "placement": place},
+        "per_rank": {"kernel_ms_per_step_max_min_over_members": [max(per_member), min(per_member)],
+                     "kernel_ms_per_step_sum_over_members": float(sum(per_member)),
+                     "expected_speedup_model": {"ms_per_step": max(per_member) + xm,
+                                                "speedup_vs_one_gpu": float(sum(per_member)) / (max(per_member) + xm),
+                                                "measured_ms_per_step": ms_per_step}},
+    }
+    ok = trace_err < 1e-6 and members_identical
+
+    def emit(configs=None):
+        if configs is not None:
+            out["configs"] = configs
+        json_out.write(json.dumps(lean(out), separators=(",", ":")) + "\n")
+        json_out.flush()
+        path = args.full_json
+        if path is None and os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+            path = os.path.join(ROOT, "gpurun_out", "bench_full_sp%d.json" % world)
+        if path:
+            try:
+                with open(path, "w") as f:
+                    json.dump(full(out), f, indent=1)
+            except OSError as e:
+                sys.stderr.write("bench.py: could not write %s: %s\n" % (path, e))
+
+    def free(i):
+        sh = shards[i]
+        for b in (sh.dX, sh.dy, sh.acc):
+            b.free()
+        sh.basis = None
+    group.map(free)
+    configs = {}
+    if args.configs != "none" and ok:
+        dog = _watchdog(args, "elbo_rbf_f4096_single_process", configs, emit)
+        try:
+            configs["elbo_rbf_f4096_single_process"] = single_process_elbo(args, devices, group)
+        except Exception as e:  # noqa: BLE001 -- the line still goes out, with the failure named
+            configs["elbo_rbf_f4096_single_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
+    emit(configs or None)
+    assert ok, (trace_err, members_identical)
+
+
+def single_process_elbo(args, devices, group):
+    """`StandardLinearModel(RandomRBF F = 4096, devices=...)._elbo` as the optimiser calls it, --dist-rows rows sharded over
+    the members: per-stage wall-clock (statistics incl. the in-process exchange, replicated posterior, second pass), and the
+    same evaluation on 256 rows against the oracle."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import _hip
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    d, n = 32, 2048
+    F = 2 * n
+    N = args.dist_rows
+    wvec = np.random.RandomState(1).randn(d).astype(np.float32)
+    CH = 250_000
+    parts = [gen_chunk(c, min(CH, N - c * CH), d, wvec) for c in range((N + CH - 1) // CH)]
+    X = np.concatenate([p[0] for p in parts])
+    y = np.concatenate([p[1] for p in parts])
+    del parts
+
+    def make_basis():
+        return bs.RandomRBF(nbases=n, Xdim=d, random_state=42, lenscale=Parameter(np.ones(d), Positive()))
+    slm = StandardLinearModel(make_basis(), devices=devices)
+    slm.obj_ = -np.inf
+    slm._defer_cov = True
+    st = slm._state = slm._make_state(X, y)
+    assert st is not None and hasattr(st, "states")
+    ls, var, reg = np.linspace(0.8, 1.3, d), 0.5, 1.0
+    iL = np.full(F, 1.0 / reg)
+    slm._elbo(X, y, var, reg, ls)  # warm: scratch, posterior work space on every member
+    t_stats, _ = _median_ms(lambda: st.gram_device(ls), reps=2)
+    t_post, post = _median_ms(lambda: st.posterior(iL, var), reps=2)
+    t_pass2, _ = _median_ms(lambda: st.second_pass(ls, post[0], st.dC, var), reps=2)
+    t_eval, res = _median_ms(lambda: slm._elbo(X, y, var, reg, ls * 1.0), reps=2)
+    G0 = st.states[0].stats_host()[0]
+    identical = all(np.array_equal(G0, s.stats_host()[0]) for s in st.states[1:])
+    trace_err = abs(float(np.trace(G0)) - N) / N
+    del G0
+    st.release()
+    slm._state = None
+    world = len(devices)
+    fl_stats = flops_per_row(d, n)
+    fl_pass2 = 2.0 * F * F + 4.0 * d * n
+    perr = (None, None)
+    if not args.no_parity_check:
+        perr = _elbo_parity(make_basis, X, y, var, reg, ls, devices=devices)
+        parity("-ELBO of 256 rows vs oracle", perr[0], 1e-4)
+        parity("gradient of 256 rows vs oracle (normwise)", perr[1], 2e-3)
+    parity("trace(G) / N - 1", trace_err, 1e-6)
+    if not identical:
+        raise ParityError("the members' reduced statistics differ")
+    return {"workload": "StandardLinearModel(devices=%d)._elbo, RandomRBF F=4096 D=32 ARD, N=%d sharded in ONE process" % (world, N),
+            "rows": N, "dtype": "f32", "ms": t_eval, "value": N / (t_eval * 1e-3), "unit": "rows/s per _elbo",
+            "stage_ms": {"statistics_and_exchange": t_stats, "posterior": t_post, "second_pass": t_pass2},
+            "_neg_elbo": float(res[0]), "transport": group.transport,
+            "parity": {"neg_elbo_256_rows": perr[0], "gradient_256_rows": perr[1], "trace_rel_err": trace_err,
+                       "members_bit_identical": bool(identical)},
+            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS * world,
+                         "frac": (fl_stats + fl_pass2) * N / (t_eval * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
+
+
+def single_process_under_ranks(args, comm, rank, world):
+    """Inside the one-process-per-GPU run: once the ranks are done, rank 0 starts `bench.py --gpus N --single-process` as a
+    CHILD (the same N GPUs behind one process: the in-process device group of StandardLinearModel(devices=N)) and reports
+    its numbers next to the ranks' own -- one driver command then measures both ways of using the node.  The other ranks
+    wait on the host (a file, not a collective: a GPU spinning in an RCCL barrier would disturb the measurement); a child
+    that fails or hangs costs this entry only."""
+    tag = "rr_bench_sp_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
+    flag = os.path.join(tempfile.gettempdir(), tag)
+    comm.barrier()  # every rank has freed its buffers and is idle
+    res = None
+    if rank == 0:
+        try:
+            os.unlink(flag)
+        except OSError:
+            pass
+        env = {k: v for k, v in os.environ.items() if k not in (
+            "RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "NCCL_HOSTID", "RR_COMM_RDZV", "REVRAND_HIP_DEVICE",
+            "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", str(min(args.steps, 5)),
+               "--warmup", str(min(args.warmup, 2)), "--rows", str(args.rows), "--dist-rows", str(args.dist_rows),
+               "--config-timeout", str(args.config_timeout)]
+        if args.no_parity_check:
+            cmd.append("--no-parity-check")
+        try:
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.config_timeout + 120)
+            lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+            if p.returncode != 0 or not lines:
+                res = {"error": "child exited %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-600:])}
+            else:
+                d = json.loads(lines[-1])
+                ex, el = d.get("exchange", {}), (d.get("configs") or {}).get("elbo_rbf_f4096_single_process", {})
+                res = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                       "n_gpus": d["n_gpus"], "frac": d["roofline"].get("whole_path_frac"),
+                       "exchange": {k: ex.get(k) for k in ("transport", "ms_per_step_pack_allreduce_unpack", "busbw_GBps",
+                                                           "distinct_gpus", "oversubscribed", "peer_access")},
+                       "preflight_busbw_GBps": (ex.get("preflight") or {}).get("busbw_GBps"),
+                       "speedup_model": (d.get("per_rank") or {}).get("expected_speedup_model", {}).get("speedup_vs_one_gpu"),
+                       "members_bit_identical": d["config"].get("members_bit_identical"),
+                       "elbo": {k: el.get(k) for k in ("ms", "stage_ms", "parity", "error") if k in el}}
+        except subprocess.TimeoutExpired:
+            res = {"error": "child still running after %.0f s" % (args.config_timeout + 120)}
+        except Exception as e:  # noqa: BLE001
+            res = {"error": "%s: %s" % (type(e).__name__, e)}
+        with open(flag, "w") as f:
+            f.write("done\n")
+    else:
+        deadline = time.time() + args.config_timeout + 180
+        while not os.path.exists(flag) and time.time() < deadline:
+            time.sleep(0.2)
+    comm.barrier()
+    if rank == 0:
+        try:
+            os.unlink(flag)
+        except OSError:
+            pass
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1206,7 +1631,18 @@ def main():
     ap.add_argument("--full-json", default=os.environ.get("RR_BENCH_FULL_JSON"),
                     help="where rank 0 writes the unabridged record (default: gpurun_out/bench_full_n<N>.json when that "
                          "directory exists)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs behind ONE process: the in-process device group of StandardLinearModel(devices=N) "
+                         "(revrand_amd/multigpu.py) instead of one rank per GPU; same line shape")
     args = ap.parse_args()
+
+    if args.single_process:
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)  # RCCL's banner and warnings go to stderr: stdout carries the ONE line
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"
+        return single_process(args, json_out)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch(args, sys.argv[1:])
@@ -1236,12 +1672,40 @@ def main():
             local_rank %= ndev
             os.environ["LOCAL_RANK"] = str(local_rank)  # what revrand_amd's default device follows
             os.environ["NCCL_HOSTID"] = "rr-bench-rank-%d" % rank
+        if ndev > 0:
             os.environ["RR_BENCH_VISIBLE_GPUS"] = str(ndev)
     dev = _hip.get_device(local_rank)
     use_comm = world > 1 or os.environ.get("RR_BENCH_FORCE_DIST") == "1"  # the latter: plumbing check at N=1
     comm = parallel.init_rccl_from_env(device=local_rank) if use_comm else parallel.SingleComm()
     parallel.set_comm(comm)
     rank, world = comm.rank, comm.world  # as RCCL reports them
+
+    # ---- preflight (N > 1): where every rank's GPU sits, whether the ranks have a GPU each, and config 3's 273 MB message
+    # through the communicator BEFORE anything is timed -- the first collective between two physical devices must not sit
+    # in a timed region, and its bus bandwidth tells xGMI / PCIe / sockets apart at a glance ----
+    place, pre, placements = placement(dev, pin=world > 1), None, None  # (N = 1: the cpu_baseline keeps all host cores)
+    if use_comm:
+        def pci_numbers(s):
+            try:
+                dom, bus, rest = s.split(":")
+                dv, fn = rest.split(".")
+                return [int(dom, 16), int(bus, 16), int(dv, 16), int(fn, 16)]
+            except Exception:
+                return [-1, -1, -1, -1]
+        row = np.zeros((world, 7))
+        row[rank] = pci_numbers(place.get("pci", "")) + [place.get("numa") if place.get("numa") is not None else -1,
+                                                         place.get("pinned_cpus", 0), local_rank]
+        table = comm.allreduce_host(row.ravel()).reshape(world, 7).astype(int)
+        placements = [{"rank": r, "pci": "%04x:%02x:%02x.%x" % tuple(t[:4]) if t[0] >= 0 else None, "numa": int(t[4]) if t[4] >= 0 else None,
+                       "pinned_cpus": int(t[5]), "device": int(t[6])} for r, t in enumerate(table)]
+        cnt3 = parallel.stats_count(8257)
+        pre_buf = dev.zeros(cnt3 * 8)
+        pre = preflight_exchange(lambda: comm.allreduce_device(pre_buf, cnt3), dev.sync, dev, cnt3, world)
+        pre_buf.free()
+        pre["ms"] = float(comm.allreduce_host(np.array([pre["ms"]]), op="max")[0])  # the slowest rank's
+        if world > 1 and pre["ms"] > 0:
+            pre["busbw_GBps"] = 2.0 * (world - 1) / world * pre["message_bytes"] / (pre["ms"] * 1e-3) / 1e9
+            pre["busbw_frac_of_one_link"] = pre["busbw_GBps"] / XGMI_LINK_GBPS
 
     d, n = args.dim, args.nbases
     F = 2 * n
@@ -1421,11 +1885,13 @@ def main():
                          # bytes per launch: the profiled launch's bytes/row x this run's rows per launch
                          "traffic": (TRAFFIC["hbm_bytes"] / TRAFFIC["rows_per_launch"] * my_rows / max(launches, 1)
                                      if TRAFFIC else None),
+                         # (not observed in this run: counters need their own rocprofv3 --pmc passes)
+                         "traffic_source": "profiles/traffic.json" if TRAFFIC else None,
                          "_traffic_note": TRAFFIC.get("note"),
                          "kernel_ms_per_step": syrk_ms, "launches_per_step": launches,
                          "avg_launch_ms": syrk_ms / max(launches, 1),
                          "flops_per_row": off_flops, "rows_per_step": my_rows,
-                         "other_kernels_ms_per_step": {"rr_syrk_f32_diag_kernel": diag_ms,
+                         "other_kernels_ms_per_step": {"rr_syrk_f32_diag16_kernel<32>": diag_ms,
                                                        "rr_rff_features_mfma_kernel": feat_ms},
                          "gram_both_kernels_frac": gram_tf / PEAK_F32_MFMA_TFLOPS,
                          "whole_path_frac": flops_per_row(d, n) * args.rows / (elapsed / max(args.steps, 1))
@@ -1440,8 +1906,11 @@ def main():
                                "ms_per_step_pack_allreduce_unpack": xm,
                                "ms_per_step_pack_allreduce_unpack_max_min_over_ranks": [float(x_max), float(x_min)],
                                "busbw_GBps": 2.0 * (world - 1) / world * 8 * cnt / (float(x_max) * 1e-3) / 1e9 if x_max > 0 else None,
+                               "model_ms_at_one_xgmi_link": exchange_model_ms(8 * cnt, world),
                                "visible_gpus": int(os.environ.get("RR_BENCH_VISIBLE_GPUS", "0")) or None,
-                               "oversubscribed": bool(os.environ.get("NCCL_HOSTID", "").startswith("rr-bench-rank-"))}
+                               "distinct_gpus": len({p["pci"] for p in placements}) if placements else None,
+                               "oversubscribed": bool(os.environ.get("NCCL_HOSTID", "").startswith("rr-bench-rank-")),
+                               "preflight": pre, "placement": placements}
         if world > 1:
             # what the ranks' own clocks say: device time of a step's kernels on the slowest / fastest rank, and the model
             # "largest shard's kernels + exchange" against the same kernels run back to back on one GPU (their sum)
@@ -1507,7 +1976,10 @@ def main():
     if side and world == 1 and not use_comm:
         emit(extra_configs(dev, _hip, args, emit))
     elif side and world > 1:
-        emit(dist_configs(dev, _hip, comm, args, emit))
+        cfgs = dist_configs(dev, _hip, comm, args, emit)
+        if isinstance(cfgs, dict) and os.environ.get("RR_BENCH_NO_SINGLE_PROCESS") != "1":
+            cfgs["single_process"] = single_process_under_ranks(args, comm, rank, world)
+        emit(cfgs)
     else:
         emit()
     comm.barrier()

@@ -20,8 +20,9 @@
  *    *_dev calls take DEVICE pointers (from rr_malloc, or any hipMalloc'd memory
  *    of the same device, e.g. a torch tensor's data_ptr) and are asynchronous on
  *    the context's stream unless stated; rr_ctx_sync() waits for them.
- *  - One rr_ctx per process per GPU (one process per GPU is the scaling model); the ranks'
- *    partial statistics are summed with the rr_comm_* entry points (RCCL, bound directly).
+ *  - Two scaling models over the row shards, the same exchange message in both: one process per GPU (one rr_ctx each),
+ *    the ranks' partial statistics summed with rr_comm_init_rank + rr_comm_* (RCCL, bound directly); or ONE process
+ *    holding a context per GPU and summing them with rr_comm_init_all + rr_comm_group_* (the estimator's own call).
  *  - There is no CPU fallback: without a usable gfx950 device rr_ctx_create fails
  *    with RR_ERR_NO_DEVICE.
  */
@@ -79,6 +80,11 @@ int rr_ctx_sync(rr_ctx *ctx);
 int rr_ctx_info(rr_ctx *ctx, char name[64], int *compute_units, uint64_t *hbm_bytes);
 /* The context's hipStream_t as an opaque pointer (for event timing by callers). */
 void *rr_ctx_stream(rr_ctx *ctx);
+/* Where the context's GPU sits: its PCI bus id ("0000:c1:00.0"; /sys/bus/pci/devices/<id>/numa_node names the host
+ * memory node next to it, which is where a rank's threads and staging buffers belong) and its HIP device index;
+ * rr_peer_access: can kernels on `device` load `peer`'s memory directly (an xGMI / PCIe peer link)? */
+int rr_ctx_pci_bus_id(rr_ctx *ctx, char id[32], int *device);
+int rr_peer_access(int device, int peer, int *can_access);
 
 /* ---- device memory (keeps X, y resident across optimiser iterations) ---- */
 

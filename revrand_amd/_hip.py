@@ -39,6 +39,8 @@ SIGNATURES = {
     "rr_ctx_info": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int),
                                    ctypes.POINTER(ctypes.c_uint64)]),
     "rr_ctx_stream": (ctypes.c_void_p, [ctypes.c_void_p]),
+    "rr_ctx_pci_bus_id": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int)]),
+    "rr_peer_access": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]),
     "rr_malloc": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, _c_void_pp]),
     "rr_free": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
     "rr_memset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t]),
@@ -452,6 +454,45 @@ class Device(object):
         hbm = ctypes.c_uint64()
         _check(self.lib, self.lib.rr_ctx_info(ctx, name, ctypes.byref(cus), ctypes.byref(hbm)))
         self.name, self.compute_units, self.hbm_bytes = name.value.decode(), cus.value, hbm.value
+
+    # -- where the GPU sits (bench.py's preflight, multi-GPU placement) ------------------
+    @property
+    def pci_bus_id(self):
+        buf = ctypes.create_string_buffer(32)
+        _check(self.lib, self.lib.rr_ctx_pci_bus_id(self.ctx, buf, None))
+        return buf.value.decode()
+
+    @property
+    def numa_node(self):
+        """Host memory node next to this GPU (None when the platform does not say)."""
+        try:
+            with open("/sys/bus/pci/devices/%s/numa_node" % self.pci_bus_id.lower()) as f:
+                node = int(f.read().strip())
+            return node if node >= 0 else None
+        except (OSError, ValueError):
+            return None
+
+    def numa_cpus(self):
+        """The CPUs of that node (a set), or None."""
+        node = self.numa_node
+        if node is None:
+            return None
+        try:
+            with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+                text = f.read().strip()
+        except OSError:
+            return None
+        cpus = set()
+        for part in text.split(","):
+            if part:
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+        return cpus or None
+
+    def can_access_peer(self, other_index):
+        can = ctypes.c_int()
+        _check(self.lib, self.lib.rr_peer_access(self.index, int(other_index), ctypes.byref(can)))
+        return bool(can.value)
 
     # -- arithmetic of the f32 Gram (include/revrand_hip.h: RR_GRAM_*) -------------
     GRAM_ENGINES = {"f32": 0, "bf16x3": 3, "bf16x4": 4, "fp16x3": 5}

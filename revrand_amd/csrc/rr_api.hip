@@ -230,6 +230,23 @@ int rr_ctx_info(rr_ctx *ctx, char name[64], int *compute_units, uint64_t *hbm_by
 
 void *rr_ctx_stream(rr_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
+int rr_ctx_pci_bus_id(rr_ctx *ctx, char id[32], int *device) {
+    RR_REQUIRE(ctx != nullptr && id != nullptr, "rr_ctx_pci_bus_id: null argument");
+    RR_CHECK_HIP(hipDeviceGetPCIBusId(id, 32, ctx->device));
+    if (device) *device = ctx->device;
+    return RR_OK;
+}
+
+int rr_peer_access(int device, int peer, int *can_access) {
+    RR_REQUIRE(can_access != nullptr, "rr_peer_access: null output");
+    int n = 0;
+    RR_CHECK_HIP(hipGetDeviceCount(&n));
+    RR_REQUIRE(device >= 0 && device < n && peer >= 0 && peer < n, "rr_peer_access: devices %d, %d out of range [0,%d)", device, peer, n);
+    *can_access = 1;
+    if (device != peer) RR_CHECK_HIP(hipDeviceCanAccessPeer(can_access, device, peer));
+    return RR_OK;
+}
+
 int rr_malloc(rr_ctx *ctx, size_t bytes, void **dptr) {
     RR_REQUIRE(ctx != nullptr && dptr != nullptr, "rr_malloc: null argument");
     *dptr = nullptr;

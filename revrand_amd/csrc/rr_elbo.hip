@@ -706,16 +706,20 @@ struct Pass2Scratch {
     float *P = nullptr, *Pt = nullptr, *U = nullptr, *C32 = nullptr, *m32 = nullptr, *dot = nullptr, *err = nullptr;
     void *Ab = nullptr, *Cb = nullptr;  // split-bf16 engine: K-blocked copies of Pt and C32 (rr_launch_gemm_tn_bf16)
     double *acc = nullptr;  // [sqErr | T (d*n)] or Vf
+    float *mean = nullptr;  // rr_rff_predict_mean_dev: [m (F) | Phi m (rows)], grow-only -- no hipMalloc / hipFree (a
+    size_t mean_count = 0;  // device-wide synchronisation) per `predict` call
     int64_t chunk = 0, Fp = 0;
     size_t nacc = 0;
     std::vector<float> hC, hm;  // host staging for the f64 -> f32 posterior
     void release() {
-        void *q[] = {P, Pt, U, C32, m32, dot, err, acc, Ab, Cb};
+        void *q[] = {P, Pt, U, C32, m32, dot, err, acc, Ab, Cb, mean};
         for (void *x : q)
             if (x) (void)hipFree(x);
         P = Pt = U = C32 = m32 = dot = err = nullptr;
         Ab = Cb = nullptr;
         acc = nullptr;
+        mean = nullptr;
+        mean_count = 0;
         chunk = Fp = 0;
         nacc = 0;
     }
@@ -2173,23 +2177,35 @@ int rr_rff_predict_mean_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N,
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n;
     const int64_t Npad = (N + 255) / 256 * 256;
-    float *buf = nullptr;  // [m (F) | Phi m (Npad)]
-    if (hipMalloc((void **)&buf, ((size_t)F + (size_t)Npad) * 4) != hipSuccess) {
-        (void)hipGetLastError();
-        rr_set_error("rr_rff_predict_mean_dev: device allocation failed");
-        return RR_ERR_OOM;
+    // [m (F) | Phi m (Npad)] in the basis' grow-only scratch: a hipMalloc / hipFree pair per call would synchronise the
+    // whole device -- other contexts' streams too -- on the one route meant for small, frequent queries
+    if (!b->pass2) b->pass2 = new Pass2Scratch();
+    Pass2Scratch &ps = *(Pass2Scratch *)b->pass2;
+    const size_t want = (size_t)F + (size_t)Npad;
+    if (ps.mean_count < want) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (ps.mean) (void)hipFree(ps.mean);
+        ps.mean = nullptr;
+        ps.mean_count = 0;
+        const size_t grow = want + want / 4;
+        if (hipMalloc((void **)&ps.mean, grow * 4) != hipSuccess) {
+            (void)hipGetLastError();
+            rr_set_error("rr_rff_predict_mean_dev: device allocation failed");
+            return RR_ERR_OOM;
+        }
+        ps.mean_count = grow;
     }
-    std::vector<float> h((size_t)(F > N ? F : N));
-    for (int i = 0; i < F; ++i) h[i] = (float)m[i];
-    hipError_t e = hipMemcpyAsync(buf, h.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);  // h is reused for the result
+    float *buf = ps.mean;
+    std::vector<float> hmv((size_t)F), h((size_t)N);  // separate staging: the weights need not have landed before the result
+    for (int i = 0; i < F; ++i) hmv[i] = (float)m[i];
+    hipError_t e = hipMemcpyAsync(buf, hmv.data(), (size_t)F * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         rc = x_dtype == RR_F32 ? launch_features_t<float>(b, (const float *)dX, N, Npad, ldx, buf, nullptr, 0, buf + F)
                                : launch_features_t<double>(b, (const double *)dX, N, Npad, ldx, buf, nullptr, 0, buf + F);
         if (rc == RR_OK) e = hipMemcpyAsync(h.data(), buf + F, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    (void)hipFree(buf);
+    else (void)hipStreamSynchronize(c->stream);
     if (rc != RR_OK) return rc;
     if (e != hipSuccess) {
         rr_set_error("rr_rff_predict_mean_dev: %s", hipGetErrorString(e));

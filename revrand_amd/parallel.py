@@ -373,6 +373,10 @@ def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
                         if 1 <= r < world:
                             c.sendall(ident)
                             if c.recv(1) == _ID_ACK:
+                                # the client holds the id and said so; tell it that its acknowledgement ARRIVED -- a client
+                                # that does not hear this (it was descheduled past our receive timeout and we gave up on
+                                # it) asks again instead of walking off while we wait for it
+                                c.sendall(_ID_ACK)
                                 served.add(r)
                 except OSError:
                     pass
@@ -382,19 +386,18 @@ def exchange_id(rank, world, make_id, rendezvous=None, timeout=600.0):
             return ident
         while time.time() < deadline:
             try:
-                c = socket.create_connection((host, int(port)), timeout=5.0)
-                c.sendall(token + struct.pack("<i", int(rank)))
-                ident = b""
-                while len(ident) < 128:
-                    part = c.recv(128 - len(ident))
-                    if not part:
-                        break
-                    ident += part
-                if len(ident) == 128:
-                    c.sendall(_ID_ACK)
-                    c.close()
-                    return ident
-                c.close()
+                with socket.create_connection((host, int(port)), timeout=5.0) as c:  # closed on every path
+                    c.sendall(token + struct.pack("<i", int(rank)))
+                    ident = b""
+                    while len(ident) < 128:
+                        part = c.recv(128 - len(ident))
+                        if not part:
+                            break
+                        ident += part
+                    if len(ident) == 128:
+                        c.sendall(_ID_ACK)
+                        if c.recv(1) == _ID_ACK:  # the server counted us: done.  Otherwise ask again (it answers repeats)
+                            return ident
             except OSError:
                 pass
             time.sleep(0.05)

@@ -322,6 +322,19 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
         assert par["N_total"] == 48000 and par["G_symmetric"] and par["ranks_identical"]
         assert par["trace_fourier_block"] < 1e-5 and par["neg_elbo_256_rows"] < 1e-5 and par["gradient_256_rows"] < 1e-3
         assert 0 < c["roofline"]["frac"] < 1 and c["speedup_model"]["speedup"] > 0
+    # the preflight: where every rank's GPU sits, config 3's message through the communicator before anything is timed
+    ex = out["exchange"]
+    assert ex["oversubscribed"] and ex["distinct_gpus"] == 1 and len(ex["placement"]) == world
+    assert all(p["pci"] == ex["placement"][0]["pci"] and p["rank"] == r for r, p in enumerate(ex["placement"]))
+    assert ex["preflight"]["message_bytes"] == 8 * (8257 * 8258 // 2 + 8257 + 2) and ex["preflight"]["busbw_GBps"] > 0
+    # the same GPUs behind ONE process (StandardLinearModel(devices=N)'s device group), run by rank 0 as a child once the
+    # ranks are done: here the members share the one GPU and take the peer transport
+    sp = out["configs"]["single_process"]
+    assert "error" not in sp, sp
+    assert sp["n_gpus"] == world and sp["value"] > 0 and sp["members_bit_identical"]
+    assert sp["exchange"]["transport"] == "peer" and sp["exchange"]["oversubscribed"]
+    assert sp["elbo"]["parity"]["neg_elbo_256_rows"] < 1e-5 and sp["elbo"]["parity"]["gradient_256_rows"] < 1e-3
+    assert sp["elbo"]["parity"]["members_bit_identical"]
 
 
 def test_bench_launcher_timeout_ends_all_ranks_and_says_which():

@@ -115,12 +115,15 @@ def test_fit_config1_shape_vs_reference(golden):
     # (basis_functions.py:866-901), its run ends "ABNORMAL" after one or two iterations from every start (oracle/make_golden.py
     # gen_fit_converged) and evaluates that point seven more times; whether a later trial step escapes depends on the last
     # bits of the objective.  What holds wherever it ends: an objective -- the quantity being optimised -- at least as good
-    # as the reference's, and a model at least as good on held-out data (SMSE within 5 % of the reference's 0.19 or better).
-    # The float32 estimator is held to a CONVERGED reference fit by test_fit_converges_to_the_references_optimum below.
+    # as the reference's, and a model, not noise, on the 64 held-out points (SMSE < 0.6; where the float32 run walks on to
+    # a HIGHER objective than the reference's end point it measured 0.44 against the reference's 0.19 there: the ELBO is
+    # a training objective).  Held-out quality against a reference fit that CONVERGED -- within 5 % of its SMSE -- is what
+    # test_fit_converges_to_the_references_optimum below asserts for the float32 estimator.
     slm = SLM(basis, var=Parameter(0.02, Positive()), nstarts=0, maxiter=20, random_state=0).fit(X, y)
     Ey, Vy = slm.predict_moments(Xs)
     assert slm.obj_ > float(g["c1_obj"]) - 1e-6 * abs(float(g["c1_obj"]))
     assert np.all(Vy > 0)
+    assert smse(g["c1_ys_true"], Ey) < 0.6
 
 
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-5), ("f32", 1e-3)])

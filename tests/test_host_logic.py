@@ -15,6 +15,8 @@ from revrand_amd.linalg import solve_posdef
 from revrand_amd.optimize import logtrick_minimizer, structured_minimizer
 from revrand_amd.utils import flatten_values, unflatten
 
+import revrand_oracle as orc  # the checker (tests only)
+
 CLASSES = ["RandomRBF", "RandomLaplace", "RandomCauchy", "RandomMatern32", "RandomMatern52", "OrthogonalRBF"]
 
 
@@ -468,3 +470,87 @@ def test_sgd_stops_its_prefetch_worker_before_an_exception_of_the_objective_leav
     res = sgd(lambda x, Xb: np.ones_like(x), np.zeros(3), X, batch_size=10, maxiter=5, prefetch=lambda b: b,
               random_state=np.random.RandomState(0))
     assert res.x.shape == (3,) and threading.active_count() <= 2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# "revrand_amd's bases work under the REFERENCE's unmodified estimator".  The reference is not
+# on the GPU box and there is no GPU here, so the claim is tested at the protocol: the driver below makes exactly the
+# calls revrand/slm.py makes on its basis -- :113 `basis.regularizer`, `basis.params`; :145 `basis.transform(X, *hypers)`;
+# :150 `basis.regularizer_diagonal(X, *reg)`; :197 `apply_grad(dhyps, basis.grad(X, *hypers))`; :240 `basis.transform` of
+# predict_moments -- and nothing else, on revrand_amd bases whose DEVICE handle is a stub that evaluates the oracle's
+# formulas (what the kernels are tested against on the GPU).  Results: the reference's own `_elbo` outputs (golden).
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _OracleRffHandle(object):
+    """Stands in for _hip.RffHandle: same constructor and method signatures, the oracle's arithmetic."""
+    calls = []
+
+    def __init__(self, W, compute="f32", device=None):
+        self.W = np.asarray(W, dtype=float)
+        self.d, self.n = self.W.shape
+
+    def transform(self, X, lenscale, out_dtype=np.float64):
+        _OracleRffHandle.calls.append("transform")
+        return orc.rff_transform(np.asarray(X, dtype=float), self.W, np.asarray(lenscale, dtype=float).squeeze())
+
+    def grad(self, X, lenscale, out_dtype=np.float64):
+        _OracleRffHandle.calls.append("grad")
+        return orc.rff_grad(np.asarray(X, dtype=float), self.W, np.asarray(lenscale, dtype=float).squeeze())
+
+
+def _reference_shaped_elbo(basis, X, y, var, reg, hypers):
+    """revrand/slm.py:142-199, statement for statement in its use of `basis` (NumPy for everything else)."""
+    from revrand_amd.basis_functions import apply_grad
+    from revrand_amd.utils import atleast_list, issequence
+    Phi = basis.transform(X, *atleast_list(hypers))                      # :145
+    PhiPhi = Phi.T.dot(Phi)
+    N, D = Phi.shape
+    L, slices = basis.regularizer_diagonal(X, *atleast_list(reg))        # :150
+    iL = 1. / L
+    C = np.linalg.inv(np.diag(iL) + PhiPhi / var)
+    m = C.dot(Phi.T.dot(y)) / var
+    TrPhiPhiC = (PhiPhi * C).sum()
+    Err = y - Phi.dot(m)
+    sqErr = (Err ** 2).sum()
+    logdetC = np.linalg.slogdet(C)[1]
+    ELBO = -0.5 * (N * np.log(2 * np.pi * var) + sqErr / var + TrPhiPhiC / var + ((m ** 2 + C.diagonal()) * iL).sum()
+                   - logdetC + np.log(L).sum() - D)
+    dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
+
+    def dreg(s):
+        return -0.5 * (((m[s] ** 2 + C[s, s].diagonal()) * iL[s] ** 2).sum() - iL[s].sum())
+    dL = list(map(dreg, slices)) if issequence(slices) else dreg(slices)
+
+    def dhyps(dPhi):
+        return -(m.T.dot(Err.dot(dPhi)) - (dPhi.T.dot(Phi) * C).sum()) / var
+    dhypers = apply_grad(dhyps, basis.grad(X, *atleast_list(hypers)))    # :197
+    return ELBO, dvar, dL, dhypers, m, C
+
+
+def test_bases_under_the_reference_estimators_call_sequence(golden, monkeypatch):
+    import revrand_amd.basis_functions as bsm
+    from revrand_amd import _hip
+    monkeypatch.setattr(_hip, "RffHandle", _OracleRffHandle)
+    g = golden("elbo")
+    X, y, var = g["X"], g["y"], float(g["var"])
+    d, n = X.shape[1], g["iso_W"].shape[1]
+    cases = [("iso", bsm.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=Parameter(1., Positive())), 1.7, float(g["iso_ls"])),
+             ("ard", bsm.RandomRBF(nbases=n, Xdim=d, random_state=21, lenscale=Parameter(np.ones(d), Positive())), 1.7, g["ard_ls"]),
+             ("cat", bsm.RandomMatern52(nbases=n, Xdim=d, random_state=22, lenscale=Parameter(np.ones(d), Positive()))
+              + bsm.LinearBasis(onescol=True), [1.7, 0.6], g["cat_ls"])]
+    for tag, basis, reg, hyp in cases:
+        # :113 -- what the reference's fit hands to its optimiser
+        params = [Parameter(1.0, Positive()), basis.regularizer, basis.params]
+        assert len(params) == 3 and (tag != "cat" or len(basis.regularizer) == 2)
+        _OracleRffHandle.calls.clear()
+        ELBO, dvar, dL, dhyp, m, C = _reference_shaped_elbo(basis, X, y, var, reg, hyp)
+        assert _OracleRffHandle.calls == ["transform", "grad"]           # one device call per protocol call, in its order
+        assert abs(ELBO - float(g[tag + "_elbo"])) < 1e-10 * abs(float(g[tag + "_elbo"]))
+        assert abs(dvar - float(g[tag + "_dvar"])) < 1e-8 * abs(float(g[tag + "_dvar"]))
+        # (the fixtures hold the NEGATED entries of the list `_elbo` returns: [-dvar, dL, dhypers], slm.py:199)
+        assert np.allclose(-np.atleast_1d(dL), g[tag + "_dreg"], rtol=1e-8)
+        assert np.allclose(-np.atleast_1d(dhyp), g[tag + "_dhyp"], rtol=1e-7, atol=1e-9)
+        assert np.allclose(m, g[tag + "_m"], rtol=1e-7, atol=1e-10) and np.allclose(C, g[tag + "_C"], rtol=1e-7, atol=1e-10)
+        # :240-243 -- predict_moments' use of the basis
+        Phi = basis.transform(X[:7], *([hyp] if tag != "cat" else [hyp]))
+        assert Phi.shape == (7, m.size) and np.all(np.isfinite((Phi.dot(C) * Phi).sum(axis=1)))
