@@ -1051,6 +1051,13 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
     from revrand_amd import parallel
     from revrand_amd.slm import StandardLinearModel
     rank, world = comm.rank, comm.world
+    t_last = [time.perf_counter()]
+
+    def tick(what):  # RR_BENCH_TRACE=1: where a configuration's wall-clock goes (stderr)
+        if os.environ.get("RR_BENCH_TRACE") == "1" and rank == 0:
+            now = time.perf_counter()
+            sys.stderr.write("bench.py: trace: %-28s %8.2f s\n" % (what, now - t_last[0]))
+            t_last[0] = now
     CH = 250_000
     r0, r1 = parallel.shard_bounds(N, rank, world)
     Xs, ys = [], []
@@ -1062,6 +1069,7 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
     X, y = np.ascontiguousarray(np.concatenate(Xs)), np.ascontiguousarray(np.concatenate(ys))
     del Xs, ys
     rows = r1 - r0
+    tick("data")
     basis = make_basis()
     slm = StandardLinearModel(basis, distributed=True)
     slm.obj_ = -np.inf
@@ -1087,7 +1095,9 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
         return float(np.median(ts)), out
 
     f0, _ = slm._elbo(X, y, var, reg, hyp)  # warm: scratch, posterior work space, RCCL channels
+    tick("state + warm _elbo")
     t_stats, _ = stage(lambda: st.gram_device(hyp))
+    tick("statistics")
     # the exchange alone, on the context's stream between HIP events (the statistics are re-made afterwards)
     pG, pb, pt = st._stat_ptrs()
     xs = []
@@ -1102,24 +1112,29 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
     N_tot = st.N_total
     # size-independent properties of the summed statistics: every rank holds all N rows' worth; trace of the Fourier
     # block == N (cos^2 + sin^2 = 1 per frequency)
+    tick("exchange")
     G, _, _ = st.stats_host()
     tr = abs(float(np.trace(G[:2 * n_rff, :2 * n_rff])) - N) / N
     sym = bool(np.array_equal(G, G.T))
     del G
+    tick("stats_host + trace")
     t_post, post = stage(lambda: st.posterior(iL, var))
     assert post is not None, "posterior not positive definite"
     m = post[0]
 
+    tick("posterior")
     def pass2():
         sq, dh = st.second_pass(hyp, m, st.dC, var)
         parts = dh if isinstance(dh, list) else [dh]
         return comm.allreduce_host(np.concatenate([[sq]] + [np.atleast_1d(p) for p in parts]))
     t_p2, _ = stage(pass2)
+    tick("second pass")
     t_eval, res = stage(lambda: slm._elbo(X, y, var, reg, hyp))
     # every rank walked to the same numbers (rank 0's are broadcast unless the reductions are deterministic)
     flat = np.concatenate([[res[0]], np.atleast_1d(res[1][0]), np.ravel(np.atleast_1d(res[1][1])),
                            np.ravel(np.concatenate([np.atleast_1d(h) for h in (res[1][2] if isinstance(res[1][2], list) else [res[1][2]])]))])
     same = bool(np.array_equal(comm.allreduce_host(flat, op="max"), comm.allreduce_host(flat, op="min")))
+    tick("_elbo + identity")
     st.release()
     slm._state = None
     perr = (None, None)
@@ -1130,6 +1145,7 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
             perr = _elbo_parity(make_basis, X, y, var, reg, hyp)
         finally:
             parallel.set_comm(prev)
+    tick("oracle parity")
     d_ = d
     fl_stats = 2.0 * d_ * n_rff + F * (F + 1.0) + 2.0 * F
     fl_p2 = 2.0 * F * F + 4.0 * d_ * n_rff
@@ -1283,6 +1299,11 @@ def placement(dev, pin=True):
             if allowed:
                 os.sched_setaffinity(0, allowed)
                 info["pinned_cpus"] = len(allowed)
+                try:  # BLAS made its thread pool for every CPU of the box at import: as many as the pinned CPUs now
+                    from threadpoolctl import threadpool_limits
+                    threadpool_limits(limits=len(allowed))
+                except Exception:
+                    pass
     except Exception as e:  # a container without /sys, a restricted cpuset, ...
         info["_error"] = "%s: %s" % (type(e).__name__, e)
     return info

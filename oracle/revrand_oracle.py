@@ -386,9 +386,16 @@ def slm_elbo(Phi, y, var, reg_diag, slices, dPhis):
     sl = slices if isinstance(slices, (list, tuple)) else [slices]
     dreg = [0.5 * (((m[s] ** 2 + C[s, s].diagonal()) * iL[s] ** 2).sum()
                    - iL[s].sum()) for s in sl]
-    # (strided views of an (N, F, d) gradient tensor would take NumPy's non-BLAS matmul path: 80 s instead of 1 s per slab
-    # at F = 4096; a contiguous copy first -- same numbers)
-    dhyp = [(m @ (err @ dP) - ((dP.T @ Phi) * C).sum()) / var for dP in map(np.ascontiguousarray, dPhis)]
+    # slm.py:193-195 has (dPhi.T.dot(Phi) * C).sum() per slab -- an (F, F) product per length scale: 1 s per slab at
+    # F = 4096, 28 s of a 32-slab check.  The same number by the trace identity
+    #     sum((dPhi^T Phi) o C) = sum_r dPhi_r . (C Phi_r) = sum(dPhi o (Phi C))          (C symmetric)
+    # with Phi C formed ONCE; small cases keep the reference's own expression (tests/test_oracle_golden.py holds both to the
+    # reference's outputs).
+    if F <= 512:
+        dhyp = [(m @ (err @ dP) - ((dP.T @ Phi) * C).sum()) / var for dP in map(np.ascontiguousarray, dPhis)]
+    else:
+        PC = Phi @ C
+        dhyp = [(m @ (err @ dP) - (dP * PC).sum()) / var for dP in dPhis]
     return dict(elbo=elbo, m=m, C=C, logdetC=logdetC, dvar=dvar, dreg=dreg,
                 dhyp=dhyp, G=G, b=Phi.T @ y)
 

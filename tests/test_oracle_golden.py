@@ -261,3 +261,17 @@ def test_converged_fit_fixture_is_a_stationary_point_of_the_oracles_elbo(golden)
     Phi = orc.rff_transform(Xs, W, ls)
     assert normwise(Phi @ g["m"], g["Ey"]) < 1e-10
     assert abs(float(g["smse"]) - ((g["ys_true"] - g["Ey"]) ** 2).mean() / g["ys_true"].var()) < 1e-12 and float(g["smse"]) < 0.03
+
+
+def test_oracle_gradient_trace_identity_above_its_size_switch():
+    """oracle.slm_elbo forms sum((dPhi^T Phi) o C) -- slm.py:193-195 as written -- up to F = 512 and through the identity
+    sum(dPhi o (Phi C)) above (one product instead of one per length scale): the two are the same number."""
+    rs = np.random.RandomState(3)
+    N, F, d = 300, 600, 3
+    Phi = rs.randn(N, F) / np.sqrt(F)
+    y = rs.randn(N)
+    dPs = [rs.randn(N, F) / np.sqrt(F) for _ in range(d)]
+    o = orc.slm_elbo(Phi, y, 0.4, np.full(F, 1.3), slice(None), dPs)
+    err = y - Phi @ o["m"]
+    want = [(o["m"] @ (err @ dP) - ((dP.T @ Phi) * o["C"]).sum()) / 0.4 for dP in dPs]
+    assert np.allclose(o["dhyp"], want, rtol=1e-11, atol=1e-12)
