@@ -526,6 +526,92 @@ def config_c4(dev, _hip, args):
             "cpu_baseline": cpu}
 
 
+def config_c4gm(dev, _hip, args, N_elbo=131_072):
+    """FastFoodGM (one Gaussian spectral-mixture component, basis_functions.py:1386-1562) at config 4's width: nbases = 4096,
+    D = 128 -> n = 4096, F = 4 n = 16384.  (a) the features by the chain kernel's mixture mode, streamed like config 4
+    (HBM-write bound: 4 D + 4 F bytes per row); (b) one resident `_elbo`: chain -> MFMA SYRK at F = 16384 -> posterior ->
+    second pass contracting BOTH gradients (mean, lenscale) on the device, against the oracle chain on 64 rows."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Bound, Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    orc = _oracle()
+    d, nb, CH, NCH = 128, 4096, 262_144, 8
+
+    def make():
+        return bs.FastFoodGM(nbases=nb, Xdim=d, random_state=1, mean=Parameter(np.zeros(d), Bound()),
+                             lenscale=Parameter(np.ones(d), Positive()))
+    f = make()
+    h = f._handles()[0]
+    F = 4 * h.n
+    rng = np.random.default_rng([20260928, 44])
+    X = rng.standard_normal((CH * NCH, d), dtype=np.float32)
+    mean, ls = 0.3 * np.random.RandomState(2).randn(d), np.linspace(0.8, 1.3, d)
+    dX = dev.upload_matrix(X)
+    ring = [dev.malloc(CH * F * 4) for _ in range(2)]
+
+    def pass_():
+        for c in range(NCH):
+            h.gm_transform_dev(_hip.DeviceView(dX, c * CH, CH), mean, ls, ring[c & 1], np.float32)
+    pass_()
+    dev.sync()
+    dev.timer_start()
+    reps = 2
+    for _ in range(reps):
+        pass_()
+    kms = dev.timer_stop() / reps
+    N = CH * NCH
+    ns = 256
+    out = dev.download(ring[(NCH - 1) & 1], (ns, F), np.float32)
+    ref = orc.fastfood_gm_transform(X[(NCH - 1) * CH:(NCH - 1) * CH + ns].astype(np.float64), f.B, f.G, f.PI, f.S, mean, ls)
+    perr = parity("Phi of 256 rows vs oracle chain", float(np.abs(out - ref).max() / np.abs(ref).max()), 1e-3)
+    nrm = parity("row norm - 1", float(np.abs((out.astype(np.float64) ** 2).sum(axis=1) - 1.0).max()), 1e-4)
+    dX.free()
+    for r in ring:
+        r.free()
+    # (b) one resident _elbo
+    Xe = X[:N_elbo]
+    ye = (np.sin(Xe @ np.random.RandomState(1).randn(d).astype(np.float32) / np.sqrt(d)) + 0.1 * rng.standard_normal(N_elbo, dtype=np.float32)).astype(np.float32)
+    var, reg = 0.5, 1.0
+    slm = StandardLinearModel(f)
+    slm.obj_ = -np.inf
+    slm._defer_cov = True
+    st = slm._state = slm._make_state(Xe, ye)
+    assert type(st).__name__ == "CatFitState"
+    slm._elbo(Xe, ye, var, reg, [mean, ls])  # warm
+    t_eval, res = _median_ms(lambda: slm._elbo(Xe, ye, var, reg, [mean, ls * 1.0]), reps=2)
+    st.release()
+    slm._state = None
+    e_err = g_err = None
+    if not args.no_parity_check:
+        rows = 64
+        Xs, ys = np.ascontiguousarray(Xe[:rows]), np.ascontiguousarray(ye[:rows])
+        one = StandardLinearModel(make())
+        one.obj_ = -np.inf
+        one._state = one._make_state(Xs, ys)
+        fn, (gv, gr, gh) = one._elbo(Xs, ys, var, reg, [mean, ls])
+        one._state.release()
+        one._state = None
+        X64 = Xs.astype(np.float64)
+        Phi = orc.fastfood_gm_transform(X64, f.B, f.G, f.PI, f.S, mean, ls)
+        dM, dL = orc.fastfood_gm_grad(X64, f.B, f.G, f.PI, f.S, mean, ls)
+        slabs = [np.ascontiguousarray(dM[:, :, i]) for i in range(d)] + [np.ascontiguousarray(dL[:, :, i]) for i in range(d)]
+        o = orc.slm_elbo(Phi, ys.astype(np.float64), var, np.full(F, reg), slice(None), slabs)
+        got = np.concatenate(([gv], np.atleast_1d(gr), gh[0], gh[1]))
+        want = np.concatenate(([-o["dvar"]], [-g for g in o["dreg"]], [-g for g in o["dhyp"]]))
+        e_err = parity("-ELBO of 64 rows vs oracle chain", abs(fn + o["elbo"]) / abs(o["elbo"]), 1e-4)
+        g_err = parity("gradient of 64 rows vs oracle chain (normwise)", float(np.linalg.norm(got - want) / np.linalg.norm(want)), 2e-3)
+    bytes_row = 4.0 * d + 4.0 * F
+    fl_row = F * (F + 1.0) + 2.0 * F + 2.0 * F * F + 4.0 * d * F / 2  # Gram + Phi^T y + U = Phi C + the two (d, n) contractions of each half
+    return {"workload": "FastFoodGM nbases=4096 D=128 F=%d: chain features N=%d in %d chunks; resident _elbo N=%d" % (F, N, NCH, N_elbo),
+            "rows": N, "ms": kms, "value": N / (kms * 1e-3), "unit": "rows/s", "dtype": "f32",
+            "elbo": {"rows": N_elbo, "ms": t_eval, "_neg_elbo": float(res[0]),
+                     "frac_f32_mfma": fl_row * N_elbo / (t_eval * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS},
+            "parity": {"phi_256_rows": perr, "row_norm": nrm, "neg_elbo_64_rows": e_err, "gradient_64_rows": g_err},
+            "roofline": {"bound": "hbm", "kernel": "rr_fastfood16_kernel<..., GM>", "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+                         "achieved": bytes_row * N / (kms * 1e-3) / 1e9, "frac": bytes_row * N / (kms * 1e-3) / 1e12 / PEAK_HBM_TBS,
+                         "bytes_per_row": bytes_row, "avg_launch_ms": kms / NCH, "_rows_per_launch": CH}}
+
+
 def config_ff_elbo(dev, _hip, args, N=524_288):
     """configs[3] WITH the Gram (SURVEY 8 a-11 "C4-with-Gram", f-4's width): one `_elbo` of StandardLinearModel on FastFoodRBF
     nbases=8192, D=128 ARD (F = 16384) over one GPU's share of N = 4M rows (4 194 304 / 8), resident: the statistics pass
@@ -1256,7 +1342,7 @@ def extra_configs(dev, _hip, args, emit=None):
                      ("posterior_F16384", lambda d_, h_, a_: config_posterior(d_, h_, a_, 16384)),
                      ("predict_moments_n300k", config_predict), ("predictc3_moments_n300k", config_predict_c3),
                      ("C3_matern52_linear_concat_one_gpu_share", config_c3), ("C4_fastfood_f16384", config_c4),
-                     ("C4elbo_fastfood_f16384", config_ff_elbo), ("C5_glm_poisson_svi_step", config_c5)):
+                     ("C4elbo_fastfood_f16384", config_ff_elbo), ("C4gm_fastfoodgm_f16384", config_c4gm), ("C5_glm_poisson_svi_step", config_c5)):
         want = args.configs.lower().split(",")
         if args.configs != "all" and name.split("_")[0].lower() not in want and name.lower() not in want:
             continue
@@ -1299,9 +1385,13 @@ def placement(dev, pin=True):
             if allowed:
                 os.sched_setaffinity(0, allowed)
                 info["pinned_cpus"] = len(allowed)
-                try:  # BLAS made its thread pool for every CPU of the box at import: as many as the pinned CPUs now
-                    from threadpoolctl import threadpool_limits
-                    threadpool_limits(limits=len(allowed))
+                try:  # BLAS made its thread pool for every CPU of the box at import: as many as the pinned CPUs now.
+                    # Only ever LOWERED: a launcher may have started us with OMP_NUM_THREADS=1 (torch.distributed.run does),
+                    # and OpenBLAS asked for more threads than it was initialised with crashes in its next LAPACK call
+                    from threadpoolctl import threadpool_info, threadpool_limits
+                    cur = max([p_.get("num_threads", 1) for p_ in threadpool_info()] or [1])
+                    if cur > len(allowed):
+                        threadpool_limits(limits=len(allowed))
                 except Exception:
                     pass
     except Exception as e:  # a container without /sys, a restricted cpuset, ...
@@ -1656,6 +1746,7 @@ def main():
                     help="N GPUs behind ONE process: the in-process device group of StandardLinearModel(devices=N) "
                          "(revrand_amd/multigpu.py) instead of one rank per GPU; same line shape")
     args = ap.parse_args()
+    faulthandler.enable()  # a crash inside a library call leaves the Python stack on stderr
 
     if args.single_process:
         sys.stdout.flush()

@@ -472,6 +472,22 @@ int rr_gm_transform(rr_basis *basis, const void *X, int x_dtype, int64_t N, int6
 int rr_gm_grad(rr_basis *basis, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
                const double *lenscale, int n_ls, void *dmean, void *dlen, int out_dtype);
 
+/* The same features by the Hadamard / permute / diagonal CHAIN itself, on an rr_fastfood_create handle (16 <= d2 <= 256;
+ * RR_ERR_UNSUPPORTED otherwise -- the dense route above serves those):  VX from the chain kernel, mX = x . mean reduced in
+ * registers next to it, four trig blocks of width n = d2 k scaled by 1 / sqrt(2 n) -- no dense (d, n) equivalent, no
+ * (N, n) intermediate.  Host buffers (N, 4n) / device buffers / straight into a device feature matrix at columns
+ * [col0, col0 + 4n), where the block pairs [cos | sin](VX + mX) at col0 and [cos | sin](VX - mX) at col0 + 2n look like
+ * two random Fourier children to the second pass: with T+ / T- from rr_featmat_pass2_rff at the two offsets (on the dense
+ * handle, for its n and padded X layout),
+ *     sum(E o dPhi/dmean_i) = sum_f (T+ - T-)[i][f],     sum(E o dPhi/dl_i) = -(1 / l_i^2) sum_f V[i][f] (T+ + T-)[i][f]
+ * (basis_functions.py:1477-1537 without the two (N, 4n, d) tensors; V = _makeVX(I_d)). */
+int rr_fastfood_gm_transform(rr_basis *fastfood, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                             const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi);
+int rr_fastfood_gm_transform_dev(rr_basis *fastfood, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                                 const double *lenscale, int n_ls, void *dPhi, int out_dtype, int64_t ldphi);
+int rr_featmat_put_fastfood_gm(rr_featmat *fm, rr_basis *fastfood, const void *dX, int x_dtype, int64_t ldx,
+                               const double *mean, const double *lenscale, int n_ls, int64_t col0);
+
 /* mathfun.linalg.hadamard (mathfun/linalg.py:182-236): natural-order Walsh-Hadamard transform of each
  * row of host Y (rows, n), n = 2^p <= 4096, normalised by 1/n; ordering != 0 applies the sequency
  * permutation.  out has Y's dtype and shape. */

@@ -193,6 +193,14 @@ SIGNATURES = {
     "rr_gm_grad": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
                                   ctypes.c_int]),
+    "rr_fastfood_gm_transform": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int64]),
+    "rr_fastfood_gm_transform_dev": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                                    ctypes.c_int64]),
+    "rr_featmat_put_fastfood_gm": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64,
+                                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]),
     "rr_hadamard": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                    ctypes.c_int, ctypes.c_void_p]),
     "rr_rff_gram_kernel_name": (ctypes.c_char_p, [ctypes.c_void_p]),
@@ -833,6 +841,13 @@ class FeatureMatrix(object):
         ls, lsp, nls = _lenscale_arg(lenscale)
         _check(self.lib, self.lib.rr_featmat_put_fastfood(self.h, ff_handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, lsp, nls, col0))
 
+    def put_fastfood_gm(self, ff_handle, dX, mean, lenscale, col0):
+        """FastFoodGM's four blocks of the rows dX by the chain kernel into columns [col0, col0 + 4 d2 k)."""
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        mu = np.ascontiguousarray(mean, dtype=np.float64)
+        _check(self.lib, self.lib.rr_featmat_put_fastfood_gm(self.h, ff_handle.h, dX.ptr, rr_dtype(dX.dtype), dX.ld,
+                                                             mu.ctypes.data_as(ctypes.c_void_p), lsp, nls, col0))
+
     def put_host(self, Phi, col0):
         Phi = as_float_matrix(Phi)
         _check(self.lib, self.lib.rr_featmat_put_host(self.h, Phi.ctypes.data_as(ctypes.c_void_p), rr_dtype(Phi.dtype),
@@ -1108,6 +1123,31 @@ class FastFoodHandle(object):
 
     def vx(self, X, lenscale=1.0, out_dtype=np.float64):
         return self._call(self.lib.rr_fastfood_vx, X, lenscale, self.n, out_dtype)
+
+    def gm_transform_dev(self, dX, mean, lenscale, dOut, out_dtype=np.float32, ldphi=None):
+        """Device-resident X (DeviceMatrix) -> the mixture component's (rows, 4n) features in dOut (asynchronous)."""
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        mu = np.ascontiguousarray(mean, dtype=np.float64)
+        _check(self.lib, self.lib.rr_fastfood_gm_transform_dev(self.h, dX.ptr, rr_dtype(dX.dtype), dX.shape[0], dX.ld,
+                                                               mu.ctypes.data_as(ctypes.c_void_p), lsp, nls, _ptr(dOut),
+                                                               rr_dtype(np.dtype(out_dtype)), 4 * self.n if ldphi is None else ldphi))
+
+    @property
+    def gm_chain_ok(self):
+        """The chain kernels' mixture-component mode serves this block size (16 <= d2 <= 256)."""
+        return 16 <= self.d2 <= 256
+
+    def gm_transform(self, X, mean, lenscale, out_dtype=np.float64):
+        """FastFoodGM.transform by the chain kernel: (N, 4n) = [cos | sin](VX + mX), [cos | sin](VX - mX), / sqrt(2n)."""
+        X = as_float_matrix(X)
+        N = X.shape[0]
+        out = np.empty((N, 4 * self.n), dtype=out_dtype)
+        ls, lsp, nls = _lenscale_arg(lenscale)
+        mu = np.ascontiguousarray(mean, dtype=np.float64)
+        _check(self.lib, self.lib.rr_fastfood_gm_transform(self.h, X.ctypes.data_as(ctypes.c_void_p), rr_dtype(X.dtype), N, _ld(X),
+                                                           mu.ctypes.data_as(ctypes.c_void_p), lsp, nls,
+                                                           out.ctypes.data_as(ctypes.c_void_p), rr_dtype(out.dtype), 4 * self.n))
+        return out
 
 
 class RffHandle(object):

@@ -499,6 +499,72 @@ class _ResidentFastFood(_ResidentRFF):
         fm.put_fastfood(self.ff, _hip.DeviceView(_batch_buffer(self, slot), 0, M), self.ls, col0)
 
 
+class _ResidentFastFoodGM(_ResidentRFF):
+    """FastFoodGM child (basis_functions.py:1386-1562): the four trig blocks come from the chain kernel's mixture mode
+    (rr_featmat_put_fastfood_gm); to the second pass they are two random-Fourier shaped children side by side --
+    [cos | sin](VX + mX) at col0 and [cos | sin](VX - mX) at col0 + 2n -- whose contractions T+ / T- = X^T A+- give both
+    gradients without the two (N, 4n, d) tensors of :1477-1537:
+        sum(E o dPhi/dmean_i) = sum_f (T+ - T-)[i, f],      sum(E o dPhi/dl_i) = -(1 / l_i^2) sum_f V[i, f] (T+ + T-)[i, f]
+    with V = _makeVX(I_d) the dense equivalent of the chain (only its d x n numbers, on the host)."""
+
+    nparams = 2
+
+    def __init__(self, basis, X):
+        super().__init__(basis, X)  # self.h: the dense handle (n, padded layout of X); self.W = V; self.dT = T+
+        self.ff = basis._handles()[0]
+        self.dTm = self.h.dev.zeros(self.W.size * 8)
+        self.n = self.h.n
+
+    def _params(self, params):
+        d = self.basis.d
+        self.mean = self.basis._check_dim(d, params[0] if len(params) > 0 else None, paramind=0)
+        self.ls = self.basis._check_dim(d, params[1] if len(params) > 1 else None, paramind=1)
+
+    def put(self, fm, X, r0, rows, col0, params):
+        self._params(params)
+        fm.put_fastfood_gm(self.ff, _hip.DeviceView(self.dX, r0, rows), self.mean, self.ls, col0)
+
+    def put_batch(self, fm, M, col0, params, slot=None):
+        self._params(params)
+        fm.put_fastfood_gm(self.ff, _hip.DeviceView(_batch_buffer(self, slot), 0, M), self.mean, self.ls, col0)
+
+    def reset(self):
+        self.h.dev.memset(self.dT)
+        self.h.dev.memset(self.dTm)
+
+    def grad(self, fm, r0, rows, col0):
+        view = _hip.DeviceView(self.dX, r0, rows)
+        fm.pass2_rff(self.h, view, col0, self.dT)
+        fm.pass2_rff(self.h, view, col0 + 2 * self.n, self.dTm)
+
+    def plan(self, fm, r0, rows, col0):
+        view = _hip.DeviceView(self.dX, r0, rows)
+        fm.pass2_plan_rff(self.h, view, col0, self.dT)
+        fm.pass2_plan_rff(self.h, view, col0 + 2 * self.n, self.dTm)
+
+    def glm_grad(self, fm, M, col0):
+        """The same two contractions against EdPhi of a GLM minibatch step (glm.py:274-275)."""
+        view = self.batch(M)
+        fm.glm_rff(self.h, view, col0, self.dT)
+        fm.glm_rff(self.h, view, col0 + 2 * self.n, self.dTm)
+
+    def dhyp(self, var):
+        """[d/dmean, d/dlenscale] as ``apply_grad(dhyps, basis.grad(X, mean, lenscale))`` would return them."""
+        Tp = self.h.dev.download(self.dT, self.W.shape, np.float64)
+        Tm = self.h.dev.download(self.dTm, self.W.shape, np.float64)
+        ls = np.atleast_1d(np.asarray(self.ls, dtype=float))
+        with np.errstate(over="ignore", invalid="ignore"):
+            dmean = -(Tp - Tm).sum(axis=1) / var
+            dlen = ((Tp + Tm) * self.W).sum(axis=1) / (var * ls ** 2)
+        if self.basis.d == 1:  # the reference's d == 1 gradients are 2-d arrays: scalars out of apply_grad
+            return [float(dmean[0]), float(dlen[0])]
+        return [dmean, dlen]
+
+    def release(self):
+        super().release()
+        self.dTm.free()
+
+
 def _gather_batch(dX, dXb, didx, M, dev=None):
     """Rows didx of the resident matrix dX into a (grow-only) batch matrix of the same layout; on `dev`'s stream (default:
     the context the data were uploaded through)."""
@@ -706,7 +772,7 @@ class MinibatchFeatures(object):
         if objective_only or len(self.children) != 1:
             return
         child, col0, _ = self.children[0]
-        if isinstance(child, _ResidentRFF):
+        if isinstance(child, _ResidentRFF) and not isinstance(child, _ResidentFastFoodGM):
             child.reset()
             self.fm.glm_plan_rff(child.h, child.batch(self.M), col0, child.dT)
             self._planned = True
@@ -732,7 +798,11 @@ class MinibatchFeatures(object):
     def glm_basis_grads(self, X):
         grads = []
         for child, col0, w in self.children:
-            if isinstance(child, _ResidentRFF):
+            if isinstance(child, _ResidentFastFoodGM):
+                child.reset()
+                child.glm_grad(self.fm, self.M, col0)
+                g = child.dhyp(1.0)
+            elif isinstance(child, _ResidentRFF):
                 if not self.__dict__.pop("_planned", False):  # (planned: dT was zeroed before the step, which may have
                     child.reset()                              # accumulated it already -- glm_rff then returns at once)
                 self.fm.glm_rff(child.h, child.batch(self.M), col0, child.dT)
@@ -869,7 +939,10 @@ class CatFitState(_DevicePosterior):
             for c, col0 in with_grad:
                 c.grad(self.fm, r0, rows, col0)
         sq = self.fm.pass2_end()
-        grads = [c.dhyp(var) for c, _ in with_grad]
+        grads = []
+        for c, _ in with_grad:  # in concatenation order, one entry per parameter (a mixture component has two)
+            g = c.dhyp(var)
+            grads.extend(g) if isinstance(g, list) else grads.append(g)
         return sq, (grads if len(grads) != 1 else grads[0])
 
     def release(self):
@@ -1259,10 +1332,15 @@ class FastFoodGM(FastFoodRBF):
 
     @slice_transform
     def transform(self, X, mean=None, lenscale=None):
-        """(N, 4*n) float64 (basis_functions.py:1443-1475)."""
+        """(N, 4*n) float64 (basis_functions.py:1443-1475): the chain kernel's mixture mode (VX by the Hadamard / permute /
+        diagonal chain, mX = X . mean next to it in registers); block sizes it does not serve (d2 < 16, i.e. Xdim <= 8) go
+        through the dense equivalent of the chain."""
         mean = self._check_dim(X.shape[1], mean, paramind=0)
         lenscale = self._check_dim(X.shape[1], lenscale, paramind=1)
-        return self._handles()[1].gm_transform(X, mean, lenscale)
+        ff, dense = self._handles()
+        if ff.gm_chain_ok:
+            return ff.gm_transform(X, mean, lenscale)
+        return dense.gm_transform(X, mean, lenscale)
 
     @slice_transform
     def grad(self, X, mean=None, lenscale=None):
@@ -1271,12 +1349,49 @@ class FastFoodGM(FastFoodRBF):
         lenscale = self._check_dim(X.shape[1], lenscale, paramind=1)
         return self._handles()[1].gm_grad(X, mean, lenscale)
 
-    # the fused statistics / resident paths of FastFoodRBF do not apply to the 4-block features
-    gram = None
-    device_fit_state = None
-    predict_moments = None
-    _put_features = Basis._put_features
-    _resident_child = Basis._resident_child
+    # -- the fused statistics / resident paths (round 5): the four blocks written by the chain kernel into the device
+    #    feature matrix, both gradients contracted on the device (_ResidentFastFoodGM) ------------------------------
+    def _chain_fit_ok(self):
+        return self.dtype == "f32" and self._handles()[0].gm_chain_ok
+
+    @slice_transform
+    def _resident_child(self, X, dtype=None):
+        if not self._chain_fit_ok() or dtype == "f64" or X.shape[1] != self.d:
+            return None
+        return _ResidentFastFoodGM(self, X)
+
+    @slice_transform
+    def device_fit_state(self, X, y):
+        """(X, y) resident for a whole fit: a one-child CatFitState whose child writes the four blocks with the chain kernel."""
+        if not self._chain_fit_ok() or X.shape[1] != self.d:
+            return None
+        import types
+        return CatFitState(types.SimpleNamespace(get_dim=self.get_dim, bases=[self]), [_ResidentFastFoodGM(self, X)], X, y)
+
+    @slice_transform
+    def _put_features(self, X, fm, col0, mean=None, lenscale=None):
+        mean = self._check_dim(X.shape[1], mean, paramind=0)
+        lenscale = self._check_dim(X.shape[1], lenscale, paramind=1)
+        ff, dense = self._handles()
+        if not ff.gm_chain_ok or self.dtype != "f32":
+            return fm.put_host(dense.gm_transform(X, mean, lenscale), col0)
+        dX = fm.dev.upload_matrix(np.ascontiguousarray(X, dtype=np.float32))
+        fm.put_fastfood_gm(ff, dX, mean, lenscale, col0)
+        fm.dev.sync()
+        dX.free()
+
+    def gram(self, X, y=None, mean=None, lenscale=None, devices=None):
+        """(Phi^T Phi, Phi^T y, y^T y) with Phi assembled on the device by the chain kernel (slm.py:145-146,157); None when
+        this basis' arithmetic has no such route (float64, d2 < 16): the estimator then takes the dense Gram of `transform`."""
+        if self.dtype != "f32":
+            return None
+        return BasisCat._of([self]).gram(X, y, mean, lenscale, devices=devices)
+
+    def predict_moments(self, X, hypers, m, C):
+        """(Phi m, rowsum((Phi C) o Phi)) with Phi assembled on the device (slm.py:240-243); hypers = [mean, lenscale]."""
+        if self.dtype != "f32":
+            return None
+        return BasisCat._of([self]).predict_moments(X, hypers, m, C)
 
     def __repr__(self):
         return "{}(nbases={}, Xdim={}, mean={}, lenscale={}, regularizer={}, random_state={})".format(
@@ -1304,6 +1419,14 @@ class BasisCat(object):
         self.__dims = None
         self.__baseinds = None
         self.__slices = None
+
+    @classmethod
+    def _of(cls, bases):
+        """A concatenation of exactly these bases (the constructor's `reduce` needs two to make a list)."""
+        cat = cls.__new__(cls)
+        cat.bases = list(bases)
+        cat.__dims = cat.__baseinds = cat.__slices = None
+        return cat
 
     def transform(self, X, *params):
         Phi, args = [], list(params)
@@ -1439,7 +1562,15 @@ class BasisCat(object):
 
     @property
     def params(self):
-        plist = [b.params for b in self.bases if b.params.has_value]
+        """All Parameter objects in concatenation order (basis_functions.py:1750-1763).  A child with SEVERAL parameters
+        (FastFoodGM: mean and lenscale) contributes them one after the other, matching how `transform(X, *params)` routes
+        them; the reference's version asks the child's LIST for `.has_value` and raises AttributeError, so a spectral
+        mixture (several FastFoodGM components concatenated, as its docstring :1394-1396 recommends) cannot be fitted there."""
+        plist = []
+        for b in self.bases:
+            for p in atleast_list(b.params):
+                if p.has_value:
+                    plist.append(p)
         if len(plist) == 0:
             return Parameter()
         return plist if len(plist) > 1 else plist[0]

@@ -203,6 +203,26 @@ __device__ __forceinline__ float row_add_partner(float v, float t) {
     return d;
 }
 
+// Sum of a value over the 16 lanes of its DPP row, in every lane: four butterfly adds.  ONE asm statement, wait states
+// included -- as separate statements the compiler is free to sink the instruction that PRODUCES the input between an
+// s_nop and the DPP read it protects (it did, in the mixture mode's prologue: a v_fma one instruction ahead of the read).
+__device__ __forceinline__ float row_allreduce16(float a) {
+    float b;
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %1, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %1, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_f32_dpp %1, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+                 "s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shl:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_f32_dpp %0, %1, %1 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "s_nop 1"
+                 : "+v"(a), "=&v"(b));
+    return a;
+}
+
 // stage on lane bit M: v <- partner + sgn * v  (sgn = -1 on lanes whose bit is set)
 template <int M, int R>
 __device__ __forceinline__ void row_stage(float (&v)[R], float sgn) {
@@ -261,12 +281,18 @@ __device__ __forceinline__ void row_fwht(float (&v)[R], const float (&sg)[4]) {
 // clamped addresses plus selects instead of guarded loads, unconditional stores -- so the compiler can count the
 // stores issued after the next row's x load and waits with vmcnt(stores) instead of vmcnt(0): a wave no longer drains
 // its own stores before it starts the next row.
-template <int R, bool PHI, bool VEC, bool FULL, typename TX, typename TO>
+//
+// GM (PHI only): one Gaussian spectral-mixture component, FastFoodGM.transform (basis_functions.py:1443-1475) --
+//   out (N, 4 n) = [cos(VX + mX) | sin(VX + mX) | cos(VX - mX) | sin(VX - mX)] * scale,   mX = x . mean
+// with `mrev` = mean / 2 pi (d2 entries, zero beyond d).  mX of a row is a 16-lane DPP-row reduction of x o mrev on the RAW x
+// (not on x / l: a length scale beyond the float32 range must not reach it), carried one row ahead next to v.
+template <int R, bool PHI, bool VEC, bool FULL, typename TX, typename TO, bool GM = false>
 __global__ void __launch_bounds__(256)
 rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int k, const float *__restrict__ Bm,
                      const float *__restrict__ Gm, const int *__restrict__ PIm, const float *__restrict__ Sm,
                      const float *__restrict__ invls, TO *__restrict__ out, int64_t ldo, float scale,
-                     int rows_per_block) {
+                     int rows_per_block, const float *__restrict__ mrev = nullptr) {
+    static_assert(!GM || PHI, "the mixture component has features only");
     constexpr int D2 = 16 * R;
     constexpr int VW = R >= 4 ? 4 : R;         // contiguous elements per lane and group
     constexpr int NG = R / VW;                 // groups: element(l16, q) = (q / VW) * 16 VW + l16 * VW + q % VW
@@ -283,13 +309,13 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
     const int n = D2 * k;
     // x rows hold d <= d2 elements; an output row holds n (VX) or 2 n (Phi) columns; every permutation entry stays
     // inside its block
-    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo && (!FULL || k % 4 == 0) &&
+    RR_DEV_ASSERT(d <= D2 && d <= ldx && (GM ? 4 : PHI ? 2 : 1) * (int64_t)n <= ldo && (!FULL || k % 4 == 0) &&
                   (!VEC || (d % VW == 0 && ldx % VW == 0 && ldo % VW == 0)));
 
     int el[R];  // element of register q
 #pragma unroll
     for (int q = 0; q < R; ++q) el[q] = (q / VW) * (16 * VW) + l16 * VW + (q % VW);
-    float Lv[R], Gv[R], Sv[R];
+    float Lv[R], Gv[R], Sv[R], Mv[GM ? R : 1];
     int Pv[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -298,6 +324,7 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
         Gv[q] = Gm[idx];
         Sv[q] = Sm[idx];  // S * d2^-1.5 (/ 2 pi when PHI: phase in revolutions)
         Pv[q] = PIm[idx];
+        if (GM) Mv[q] = el[q] < d ? mrev[el[q]] : 0.f;
         RR_DEV_ASSERT(Pv[q] >= 0 && Pv[q] < D2);
     }
     float sg[4];
@@ -335,10 +362,18 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
     // store issued before that load, so the load of row r + 2 goes out at the top of row r and is consumed at the END of
     // row r + 1 -- the stores of rows r and r + 1 stay in flight across it (vmcnt(10)), only row r - 1's must have landed
     float xa[R], xb[R], v[R];
+    float mx = 0.f;  // GM: x . mean / 2 pi of the row v belongs to (every lane of the DPP row holds the sum)
+    auto row_dot_mean = [&](const float (&xr)[R]) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < R; ++q) t = fmaf(xr[q], Mv[GM ? q : 0], t);
+        return row_allreduce16(t);
+    };
     const int64_t rl = r1 - 1;
     load_x(r0, xa);
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = xa[q] * Lv[q];
+    if (GM) mx = row_dot_mean(xa);
     load_x(r0 + 1 < rl ? r0 + 1 : rl, xa);
     // s_waitcnt vmcnt(0): every table load above has landed before the loop.  The compiler's wait insertion is not path
     // sensitive: a table register first used inside the loop would get a wait there that, on all later iterations,
@@ -362,10 +397,18 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
         // a group of a lane is VW contiguous outputs, the 16 lanes of a block 16 VW contiguous ones: whole 128-byte lines
         // straight from the registers, as non-temporal stores (a write-once stream far larger than the L2: 3.23 -> 3.00 ms
         // per 262144 x 16384 chunk at config 4's shape)
-        float c1[R], s1[R];
+        float c1[R], s1[R], c2[GM ? R : 1], s2[GM ? R : 1];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            if (PHI) {
+            if (GM) {
+                const float ph = v[q] * Sv[q];
+                ff_sincos_rev<float>(ph + mx, s1[q], c1[q]);
+                ff_sincos_rev<float>(ph - mx, s2[q], c2[q]);
+                c1[q] *= scale;
+                s1[q] *= scale;
+                c2[q] *= scale;
+                s2[q] *= scale;
+            } else if (PHI) {
                 ff_sincos_rev<float>(v[q] * Sv[q], s1[q], c1[q]);
                 c1[q] *= scale;
                 s1[q] *= scale;
@@ -375,21 +418,26 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
         }
         if (active) {
             TO *orow = out + r * ldo + (int64_t)j * D2 + l16 * VW;
-#pragma unroll
-            for (int half = 0; half < (PHI ? 2 : 1); ++half) {
+            auto store_block = [&](int half, const auto &src) {  // one [D2]-wide block of column block `half` of the row
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    TO *o = orow + (half ? n : 0) + g * 16 * VW;
+                    TO *o = orow + (int64_t)half * n + g * 16 * VW;
                     if (VEC) {
                         ovec t;
 #pragma unroll
-                        for (int w = 0; w < VW; ++w) t[w] = (TO)(half ? s1[g * VW + w] : c1[g * VW + w]);
+                        for (int w = 0; w < VW; ++w) t[w] = (TO)src[g * VW + w];
                         __builtin_nontemporal_store(t, reinterpret_cast<ovec *>(o));
                     } else {
 #pragma unroll
-                        for (int w = 0; w < VW; ++w) __builtin_nontemporal_store((TO)(half ? s1[g * VW + w] : c1[g * VW + w]), &o[w]);
+                        for (int w = 0; w < VW; ++w) __builtin_nontemporal_store((TO)src[g * VW + w], &o[w]);
                     }
                 }
+            };
+            store_block(0, c1);
+            if constexpr (PHI) store_block(1, s1);
+            if constexpr (GM) {
+                store_block(2, c2);
+                store_block(3, s2);
             }
         }
         __builtin_amdgcn_sched_barrier(0);  // (the scheduler would hoist the use of cur to just below its load)
@@ -399,6 +447,7 @@ rr_fastfood16_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, in
             asm volatile("" : "+v"(v[q]));  // the PRODUCT is what the next row carries (else the multiply sinks into the
                                             // next iteration and the loaded registers are copied, i.e. waited for, here)
         }
+        if (GM) mx = row_dot_mean(cur);
     };
     // an odd row count computes and stores its last row twice (same values) instead of branching inside the loop
     for (int64_t r = r0; r < r1; r += 2) {
@@ -458,11 +507,13 @@ __device__ __forceinline__ void row_fwht64(double (&v)[R], const double (&sg)[4]
     for (int q = 0; q < R; ++q) v[q] = fma(sg[3], v[q], dpp_partner64<8>(v[q]));
 }
 
-template <int R, bool PHI, bool VEC, bool FULL, typename TX, typename TO>
+template <int R, bool PHI, bool VEC, bool FULL, typename TX, typename TO, bool GM = false>
 __global__ void __launch_bounds__(256)
 rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, int k, const double *__restrict__ Bm,
                       const double *__restrict__ Gm, const int *__restrict__ PIm, const double *__restrict__ Sm,
-                      const double *__restrict__ invls, TO *__restrict__ out, int64_t ldo, double scale, int rows_per_block) {
+                      const double *__restrict__ invls, TO *__restrict__ out, int64_t ldo, double scale, int rows_per_block,
+                      const double *__restrict__ mrev = nullptr) {
+    static_assert(!GM || PHI, "the mixture component has features only");
     // same structure as rr_fastfood16_kernel (element layout in groups of VW contiguous values per lane, x straight from
     // global memory two rows ahead, outputs straight from the registers, one basic block per row), with VW = 2: 16 bytes
     // of float64 per lane and group, 256 contiguous bytes per block and group
@@ -480,13 +531,13 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
     if (jb >= k) return;
     const bool active = FULL || j < k;
     const int n = D2 * k;
-    RR_DEV_ASSERT(d <= D2 && d <= ldx && (PHI ? 2 : 1) * (int64_t)n <= ldo && (!FULL || k % 4 == 0) &&
+    RR_DEV_ASSERT(d <= D2 && d <= ldx && (GM ? 4 : PHI ? 2 : 1) * (int64_t)n <= ldo && (!FULL || k % 4 == 0) &&
                   (!VEC || (d % VW == 0 && ldx % VW == 0 && ldo % VW == 0)));
 
     int el[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) el[q] = (q / VW) * (16 * VW) + l16 * VW + (q % VW);
-    double Lv[R], Gv[R], Sv[R];
+    double Lv[R], Gv[R], Sv[R], Mv[GM ? R : 1];
     int Pv[R];
 #pragma unroll
     for (int q = 0; q < R; ++q) {
@@ -495,6 +546,7 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
         Gv[q] = Gm[idx];
         Sv[q] = Sm[idx];
         Pv[q] = PIm[idx];
+        if (GM) Mv[q] = el[q] < d ? mrev[el[q]] : 0.0;
         RR_DEV_ASSERT(Pv[q] >= 0 && Pv[q] < D2);
     }
     double sg[4];
@@ -524,10 +576,22 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
         }
     };
     double xa[R], xb[R], v[R];
+    double mx = 0.0;  // GM: x . mean / 2 pi of the row v belongs to (see rr_fastfood16_kernel)
+    auto row_dot_mean = [&](const double (&xr)[R]) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < R; ++q) t = fma(xr[q], Mv[GM ? q : 0], t);
+        t += dpp_partner64<1>(t);
+        t += dpp_partner64<2>(t);
+        t += dpp_partner64<4>(t);
+        t += dpp_partner64<8>(t);
+        return t;
+    };
     const int64_t rl = r1 - 1;
     load_x(r0, xa);
 #pragma unroll
     for (int q = 0; q < R; ++q) v[q] = xa[q] * Lv[q];
+    if (GM) mx = row_dot_mean(xa);
     load_x(r0 + 1 < rl ? r0 + 1 : rl, xa);
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see rr_fastfood16_kernel
     auto one_row = [&](int64_t r, double (&cur)[R], double (&nxt)[R]) {
@@ -543,10 +607,18 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = line[Pv[q]] * Gv[q];
         row_fwht64<R>(v, sg);
-        double c1[R], s1[R];
+        double c1[R], s1[R], c2[GM ? R : 1], s2[GM ? R : 1];
 #pragma unroll
         for (int q = 0; q < R; ++q) {
-            if (PHI) {
+            if (GM) {
+                const double ph = v[q] * Sv[q];
+                rr_sincos_rev_f64(ph + mx, s1[q], c1[q]);
+                rr_sincos_rev_f64(ph - mx, s2[q], c2[q]);
+                c1[q] *= scale;
+                s1[q] *= scale;
+                c2[q] *= scale;
+                s2[q] *= scale;
+            } else if (PHI) {
                 rr_sincos_rev_f64(v[q] * Sv[q], s1[q], c1[q]);
                 c1[q] *= scale;
                 s1[q] *= scale;
@@ -556,21 +628,26 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
         }
         if (active) {
             TO *orow = out + r * ldo + (int64_t)j * D2 + l16 * VW;
-#pragma unroll
-            for (int half = 0; half < (PHI ? 2 : 1); ++half) {
+            auto store_block = [&](int half, const auto &src) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
-                    TO *o = orow + (half ? n : 0) + g * 16 * VW;
+                    TO *o = orow + (int64_t)half * n + g * 16 * VW;
                     if (VEC) {
                         ovec t;
 #pragma unroll
-                        for (int w = 0; w < VW; ++w) t[w] = (TO)(half ? s1[g * VW + w] : c1[g * VW + w]);
+                        for (int w = 0; w < VW; ++w) t[w] = (TO)src[g * VW + w];
                         __builtin_nontemporal_store(t, reinterpret_cast<ovec *>(o));
                     } else {
 #pragma unroll
-                        for (int w = 0; w < VW; ++w) __builtin_nontemporal_store((TO)(half ? s1[g * VW + w] : c1[g * VW + w]), &o[w]);
+                        for (int w = 0; w < VW; ++w) __builtin_nontemporal_store((TO)src[g * VW + w], &o[w]);
                     }
                 }
+            };
+            store_block(0, c1);
+            if constexpr (PHI) store_block(1, s1);
+            if constexpr (GM) {
+                store_block(2, c2);
+                store_block(3, s2);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -579,6 +656,7 @@ rr_fastfood16d_kernel(const TX *__restrict__ X, int64_t N, int64_t ldx, int d, i
             v[q] = cur[q] * Lv[q];
             asm volatile("" : "+v"(v[q]));
         }
+        if (GM) mx = row_dot_mean(cur);
     };
     for (int64_t r = r0; r < r1; r += 2) {
         one_row(r, xa, xb);
@@ -623,7 +701,7 @@ rr_hadamard_kernel(const TC *__restrict__ Y, int64_t rows, int n, int ordering, 
 // ---------------------------------------------------------------------------------------------
 static size_t ff_dtype_size(int t) { return t == RR_F32 ? 4 : 8; }
 
-template <bool PHI, typename TX, typename TC, typename TO>
+template <bool PHI, typename TX, typename TC, typename TO, bool GM = false>
 static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *dOut, int64_t ldo) {
     rr_ctx *c = b->ctx;
     const int d2 = b->ff_d2, k = b->ff_k;
@@ -641,10 +719,15 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
     const TC *Gm = (const TC *)(f32 ? (void *)b->ffG32 : (void *)b->ffG64);
     const TC *Sm = (const TC *)(f32 ? (void *)(PHI ? b->ffSrev32 : b->ffSrad32) : (void *)(PHI ? b->ffSrev64 : b->ffSrad64));
     const TC *Lm = (const TC *)(f32 ? (void *)b->ffL32 : (void *)b->ffL64);
-    const TC scale = (TC)(1.0 / sqrt((double)b->n));
+    const TC *Mm = (const TC *)(f32 ? (void *)b->dmu32 : (void *)b->dmu64);  // GM: mean / 2 pi (ff_prepare_mean)
+    const TC scale = (TC)(1.0 / sqrt((GM ? 2.0 : 1.0) * (double)b->n));
+    if (GM && (d2 < 16 || d2 > 256)) {
+        rr_set_error("fastfood: the mixture-component chain kernel serves 16 <= d2 <= 256 (d2 = %d: use the dense route)", d2);
+        return RR_ERR_UNSUPPORTED;
+    }
     if constexpr (sizeof(TC) == 8) {  // float64 arithmetic: the lane-major kernel with float64 registers
         static const bool old_kernel64 = getenv("RR_FASTFOOD_OLD") != nullptr;
-        if (!old_kernel64 && d2 >= 16 && d2 <= 256) {
+        if ((GM || !old_kernel64) && d2 >= 16 && d2 <= 256) {
             const unsigned gx16 = (unsigned)((k + 15) / 16);
             const int vw = d2 / 16 >= 2 ? 2 : 1;
             const bool vec = (ldx % vw == 0) && (ldo % vw == 0) && (b->d % vw == 0) && ((uintptr_t)dX % (vw * sizeof(TX)) == 0) &&
@@ -660,13 +743,13 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
             };
 #define RR_FF16D_(RR, VEC, FULL)                                                                                     \
     do {                                                                                                             \
-        auto kern = rr_fastfood16d_kernel<RR, PHI, VEC, FULL, TX, TO>;                                               \
+        auto kern = rr_fastfood16d_kernel<RR, PHI, VEC, FULL, TX, TO, GM>;                                           \
         static int occ = 0;                                                                                          \
         if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0) != hipSuccess || occ < 1)) occ = 2; \
         const int64_t rp = rows_per_wg(occ);                                                                         \
         hipLaunchKernelGGL(kern, dim3(gx16, (unsigned)((N + rp - 1) / rp)), dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
                            b->d, k, (const double *)Bm, (const double *)Gm, b->ffPI, (const double *)Sm,             \
-                           (const double *)Lm, (TO *)dOut, ldo, (double)scale, (int)rp);                             \
+                           (const double *)Lm, (TO *)dOut, ldo, (double)scale, (int)rp, (const double *)Mm);         \
     } while (0)
 #define RR_FF16D(RR)                                \
     do {                                            \
@@ -689,7 +772,7 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
     }
     if constexpr (sizeof(TC) == 4) {  // lane-major packed kernel: one block per DPP row of 16 lanes
         static const bool old_kernel = getenv("RR_FASTFOOD_OLD") != nullptr;
-        if (!old_kernel && d2 >= 16 && d2 <= 256) {
+        if ((GM || !old_kernel) && d2 >= 16 && d2 <= 256) {
             const unsigned gx16 = (unsigned)((k + 15) / 16);
             // vector loads / stores of a lane's VW = min(4, d2 / 16) contiguous elements need that alignment of the rows
             const int vw = d2 / 16 >= 4 ? 4 : d2 / 16;
@@ -709,13 +792,13 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
             };
 #define RR_FF16_(RR, VEC, FULL)                                                                                      \
     do {                                                                                                             \
-        auto kern = rr_fastfood16_kernel<RR, PHI, VEC, FULL, TX, TO>;                                                \
+        auto kern = rr_fastfood16_kernel<RR, PHI, VEC, FULL, TX, TO, GM>;                                            \
         static int occ = 0;                                                                                          \
         if (!occ && (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, 256, 0) != hipSuccess || occ < 1)) occ = 4; \
         const int64_t rp = rows_per_wg(occ);                                                                         \
         hipLaunchKernelGGL(kern, dim3(gx16, (unsigned)((N + rp - 1) / rp)), dim3(256), 0, c->stream, (const TX *)dX, N, ldx, \
                            b->d, k, (const float *)Bm, (const float *)Gm, b->ffPI, (const float *)Sm, (const float *)Lm, \
-                           (TO *)dOut, ldo, (float)scale, (int)rp);                                                  \
+                           (TO *)dOut, ldo, (float)scale, (int)rp, (const float *)Mm);                               \
     } while (0)
 #define RR_FF16(RR)                                \
     do {                                           \
@@ -750,22 +833,42 @@ static int ff_launch(rr_basis *b, const void *dX, int64_t N, int64_t ldx, void *
     return RR_OK;
 }
 
-template <bool PHI>
+template <bool PHI, bool GM = false>
 static int ff_dispatch(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, void *dOut, int out_dtype,
                        int64_t ldo) {
     const int key = x_dtype * 4 + b->compute * 2 + out_dtype;
     switch (key) {
-        case 0: return ff_launch<PHI, float, float, float>(b, dX, N, ldx, dOut, ldo);
-        case 1: return ff_launch<PHI, float, float, double>(b, dX, N, ldx, dOut, ldo);
-        case 2: return ff_launch<PHI, float, double, float>(b, dX, N, ldx, dOut, ldo);
-        case 3: return ff_launch<PHI, float, double, double>(b, dX, N, ldx, dOut, ldo);
-        case 4: return ff_launch<PHI, double, float, float>(b, dX, N, ldx, dOut, ldo);
-        case 5: return ff_launch<PHI, double, float, double>(b, dX, N, ldx, dOut, ldo);
-        case 6: return ff_launch<PHI, double, double, float>(b, dX, N, ldx, dOut, ldo);
-        case 7: return ff_launch<PHI, double, double, double>(b, dX, N, ldx, dOut, ldo);
+        case 0: return ff_launch<PHI, float, float, float, GM>(b, dX, N, ldx, dOut, ldo);
+        case 1: return ff_launch<PHI, float, float, double, GM>(b, dX, N, ldx, dOut, ldo);
+        case 2: return ff_launch<PHI, float, double, float, GM>(b, dX, N, ldx, dOut, ldo);
+        case 3: return ff_launch<PHI, float, double, double, GM>(b, dX, N, ldx, dOut, ldo);
+        case 4: return ff_launch<PHI, double, float, float, GM>(b, dX, N, ldx, dOut, ldo);
+        case 5: return ff_launch<PHI, double, float, double, GM>(b, dX, N, ldx, dOut, ldo);
+        case 6: return ff_launch<PHI, double, double, float, GM>(b, dX, N, ldx, dOut, ldo);
+        case 7: return ff_launch<PHI, double, double, double, GM>(b, dX, N, ldx, dOut, ldo);
     }
     rr_set_error("fastfood: bad dtype combination");
     return RR_ERR_INVALID;
+}
+
+// upload mean / 2 pi (per input dimension, zero beyond d) for the mixture-component mode of the chain kernels
+static int ff_prepare_mean(rr_basis *b, const double *mean) {
+    RR_REQUIRE(mean != nullptr, "mean: null argument");
+    const double inv2pi = 0.15915494309189533576888;
+    std::vector<double> m64(b->ff_d2, 0.0);
+    std::vector<float> m32(b->ff_d2, 0.f);
+    for (int i = 0; i < b->d; ++i) {
+        RR_REQUIRE(mean[i] == mean[i], "mean[%d] is NaN", i);
+        m64[i] = mean[i] * inv2pi;
+        const double lim = 3.0e38;  // (an infinite mean: the reference's features are NaN there; keep float32 finite)
+        m32[i] = (float)(m64[i] > lim ? lim : (m64[i] < -lim ? -lim : m64[i]));
+    }
+    if (!b->dmu32) RR_CHECK_HIP(hipMalloc((void **)&b->dmu32, (size_t)b->ff_d2 * 4));
+    if (!b->dmu64) RR_CHECK_HIP(hipMalloc((void **)&b->dmu64, (size_t)b->ff_d2 * 8));
+    RR_CHECK_HIP(hipStreamSynchronize(b->ctx->stream));
+    RR_CHECK_HIP(hipMemcpy(b->dmu64, m64.data(), m64.size() * 8, hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemcpy(b->dmu32, m32.data(), m32.size() * 4, hipMemcpyHostToDevice));
+    return RR_OK;
 }
 
 // upload 1/l_i (per input dimension) for the FWHT kernels
@@ -793,16 +896,17 @@ static int ff_prepare_lenscale(rr_basis *b, const double *lenscale, int n_ls) {
 }
 
 // common host-buffer driver: stream rows up, run the kernel, stream the output down
-template <bool PHI>
+template <bool PHI, bool GM = false>
 static int ff_host_call(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale,
-                        int n_ls, void *out, int out_dtype, int64_t ldo, const char *who) {
+                        int n_ls, void *out, int out_dtype, int64_t ldo, const char *who, const double *mean = nullptr) {
     RR_REQUIRE(b != nullptr && b->kind == RR_KIND_FASTFOOD, "%s: not a FastFood basis", who);
     RR_REQUIRE((x_dtype == RR_F32 || x_dtype == RR_F64) && (out_dtype == RR_F32 || out_dtype == RR_F64), "%s: bad dtype", who);
-    const int64_t width = PHI ? 2 * (int64_t)b->n : (int64_t)b->n;
+    const int64_t width = (GM ? 4 : PHI ? 2 : 1) * (int64_t)b->n;
     RR_REQUIRE(N >= 0 && ldx >= b->d && ldo >= width, "%s: bad shape", who);
     rr_ctx *c = b->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
     int rc = ff_prepare_lenscale(b, lenscale, n_ls);
+    if (rc == RR_OK && GM) rc = ff_prepare_mean(b, mean);
     if (rc != RR_OK || N == 0) return rc;
     RR_REQUIRE(X != nullptr && out != nullptr, "%s: null buffer", who);
     const size_t xs = ff_dtype_size(x_dtype), os = ff_dtype_size(out_dtype);
@@ -827,7 +931,7 @@ static int ff_host_call(rr_basis *b, const void *X, int x_dtype, int64_t N, int6
             rc = RR_ERR_HIP;
             break;
         }
-        rc = ff_dispatch<PHI>(b, dX, x_dtype, m, b->d, dO, out_dtype, width);
+        rc = ff_dispatch<PHI, GM>(b, dX, x_dtype, m, b->d, dO, out_dtype, width);
         if (rc != RR_OK) break;
         rc = rr_sink_push(&sink, dO, (char *)out + (size_t)r0 * ldo * os, (size_t)m, (size_t)width * os, (size_t)ldo * os);
     }
@@ -929,6 +1033,45 @@ int rr_featmat_put_fastfood(rr_featmat *fm, rr_basis *b, const void *dX, int x_d
     rc = rr_fm_claim(fm, col0, 2 * (int64_t)b->n, "rr_featmat_put_fastfood");
     if (rc != RR_OK) return rc;
     return ff_dispatch<true>(b, dX, x_dtype, fm->rows, ldx, fm->P + col0, RR_F32, fm->ld);
+}
+
+int rr_fastfood_gm_transform(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                             const double *lenscale, int n_ls, void *Phi, int out_dtype, int64_t ldphi) {
+    return ff_host_call<true, true>(b, X, x_dtype, N, ldx, lenscale, n_ls, Phi, out_dtype, ldphi, "rr_fastfood_gm_transform", mean);
+}
+
+int rr_fastfood_gm_transform_dev(rr_basis *b, const void *dX, int x_dtype, int64_t N, int64_t ldx, const double *mean,
+                                 const double *lenscale, int n_ls, void *dPhi, int out_dtype, int64_t ldphi) {
+    RR_REQUIRE(b != nullptr && b->kind == RR_KIND_FASTFOOD, "rr_fastfood_gm_transform_dev: not a FastFood basis");
+    RR_REQUIRE((x_dtype == RR_F32 || x_dtype == RR_F64) && (out_dtype == RR_F32 || out_dtype == RR_F64),
+               "rr_fastfood_gm_transform_dev: bad dtype");
+    RR_REQUIRE(N >= 0 && ldx >= b->d && ldphi >= 4 * (int64_t)b->n, "rr_fastfood_gm_transform_dev: bad shape");
+    RR_CHECK_HIP(hipSetDevice(b->ctx->device));
+    int rc = ff_prepare_lenscale(b, lenscale, n_ls);
+    if (rc == RR_OK) rc = ff_prepare_mean(b, mean);
+    if (rc != RR_OK || N == 0) return rc;
+    RR_REQUIRE(dX != nullptr && dPhi != nullptr, "rr_fastfood_gm_transform_dev: null buffer");
+    return ff_dispatch<true, true>(b, dX, x_dtype, N, ldx, dPhi, out_dtype, ldphi);
+}
+
+// The mixture component's four blocks straight into a device feature matrix, columns [col0, col0 + 4n): block pair
+// [cos | sin](VX + mX) at col0 and [cos | sin](VX - mX) at col0 + 2n -- to the consumers of the matrix two random-Fourier
+// shaped children side by side (rr_featmat_pass2_rff / rr_featmat_glm_rff at either offset).
+int rr_featmat_put_fastfood_gm(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *mean,
+                               const double *lenscale, int n_ls, int64_t col0) {
+    RR_REQUIRE(fm != nullptr && b != nullptr && b->kind == RR_KIND_FASTFOOD, "rr_featmat_put_fastfood_gm: not a FastFood basis");
+    RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_put_fastfood_gm: bad dtype");
+    RR_REQUIRE(b->ctx == fm->ctx, "rr_featmat_put_fastfood_gm: basis and feature matrix live on different device contexts");
+    RR_REQUIRE(col0 >= 0 && col0 + 4 * (int64_t)b->n <= fm->F, "rr_featmat_put_fastfood_gm: columns out of range");
+    RR_REQUIRE(ldx >= b->d, "rr_featmat_put_fastfood_gm: bad shape");
+    RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
+    int rc = ff_prepare_lenscale(b, lenscale, n_ls);
+    if (rc == RR_OK) rc = ff_prepare_mean(b, mean);
+    if (rc != RR_OK || fm->rows == 0) return rc;
+    RR_REQUIRE(dX != nullptr, "rr_featmat_put_fastfood_gm: null X");
+    rc = rr_fm_claim(fm, col0, 4 * (int64_t)b->n, "rr_featmat_put_fastfood_gm");
+    if (rc != RR_OK) return rc;
+    return ff_dispatch<true, true>(b, dX, x_dtype, fm->rows, ldx, fm->P + col0, RR_F32, fm->ld);
 }
 
 int rr_fastfood_vx(rr_basis *b, const void *X, int x_dtype, int64_t N, int64_t ldx, const double *lenscale, int n_ls,

@@ -327,3 +327,138 @@ def test_fastfood_extreme_length_scales_give_finite_features_like_the_reference(
         assert np.isfinite(ref).all() and np.isfinite(P).all() and np.abs(P).max() <= 1.0 / np.sqrt(f.n) * (1 + 1e-6)
         assert np.abs((P ** 2).sum(axis=1) - 1.0).max() < 1e-5   # cos^2 + sin^2 over n frequencies, / n
     assert normwise(f.transform(X, 1e100), orc.fastfood_transform(X, f.B, f.G, f.PI, f.S, 1e100)) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# FastFoodGM as a first-class basis (reference: basis_functions.py:1386-1562)
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _gm(d, nb, dtype="f32", seed=5):
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Bound, Parameter, Positive
+    return bs.FastFoodGM(nbases=nb, Xdim=d, random_state=seed, mean=Parameter(np.zeros(d), Bound()),
+                         lenscale=Parameter(np.ones(d), Positive()), dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("d,nb,N", [(16, 64, 1001), (100, 1024, 777), (128, 8192, 131), (9, 40, 64)])
+def test_fastfood_gm_chain_vs_oracle_at_scale(d, nb, N, dtype):
+    """FastFoodGM.transform through the chain kernel's mixture mode (transform :1443-1475) against the oracle's FWHT chain
+    in float64 at the sizes the configurations use -- d2 = 16 / 128 (ragged d = 100: x padded in registers) / 128 with
+    k = 64 blocks, odd row counts -- with mean shifts of several revolutions (|x . mean| ~ 2 pi x 5 at d = 128: the
+    float32 phase of VX +- mX is reduced modulo one revolution AFTER the shift is added), and against the dense-equivalent
+    route (rr_gm_transform) it replaces."""
+    rs = np.random.RandomState(d + nb)
+    b = _gm(d, nb, dtype)
+    X = rs.randn(N, d).astype(np.float32 if dtype == "f32" else np.float64)
+    mean, ls = 0.8 * rs.randn(d), np.linspace(0.7, 1.6, d)
+    ff, dense = b._handles()
+    assert ff.gm_chain_ok
+    P = b.transform(X, mean, ls)
+    ref = orc.fastfood_gm_transform(X.astype(np.float64), b.B, b.G, b.PI, b.S, mean, ls)
+    assert P.shape == ref.shape == (N, 4 * b.n)
+    assert np.abs(X.astype(np.float64) @ mean).max() > 6.0        # the shift is worth more than a revolution
+    assert normwise(P, ref) < TOL[dtype]
+    assert normwise(dense.gm_transform(X, mean, ls), ref) < TOL[dtype] * (10 if dtype == "f32" else 1)
+    # zero mean: the two halves coincide and equal FastFoodRBF's features / sqrt(2)
+    P0 = b.transform(X, np.zeros(d), ls)
+    n = b.n
+    assert np.array_equal(P0[:, :2 * n], P0[:, 2 * n:])
+    assert normwise(P0[:, :2 * n] * np.sqrt(2.0), orc.fastfood_transform(X.astype(np.float64), b.B, b.G, b.PI, b.S, ls)) < TOL[dtype]
+
+
+def _oracle_gm_elbo(b, X, y, var, reg, mean, ls):
+    X64 = X.astype(np.float64)
+    Phi = orc.fastfood_gm_transform(X64, b.B, b.G, b.PI, b.S, mean, ls)
+    dM, dL = orc.fastfood_gm_grad(X64, b.B, b.G, b.PI, b.S, mean, ls)
+    slabs = [np.ascontiguousarray(dM[:, :, i]) for i in range(b.d)] + [np.ascontiguousarray(dL[:, :, i]) for i in range(b.d)]
+    return orc.slm_elbo(Phi, y.astype(np.float64), var, np.full(Phi.shape[1], reg), slice(None), slabs)
+
+
+@pytest.mark.parametrize("shape", [(64, 16, 256), (300, 20, 70), (1000, 32, 512)])
+def test_fastfood_gm_resident_elbo_matches_the_oracle_chain(shape):
+    """`_elbo` (slm.py:142-199) on a FastFoodGM basis with (X, y) resident: the statistics pass is the chain kernel's four
+    blocks in the device feature matrix + the MFMA SYRK; the second pass contracts BOTH gradients (mean and lenscale,
+    basis_functions.py:1477-1537) on the device as two random-Fourier shaped children (n % 256 == 0: in registers; else the
+    stored route) -- no (N, 4n, d) tensor.  Against the oracle's chain + slm_elbo in float64."""
+    from revrand_amd.slm import StandardLinearModel
+    N, d, nb = shape
+    rs = np.random.RandomState(N + d)
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(X @ rs.randn(d) / np.sqrt(d)) + 0.1 * rs.randn(N)).astype(np.float32)
+    b = _gm(d, nb)
+    mean, ls = 0.3 * rs.randn(d), np.linspace(0.8, 1.4, d)
+    var, reg = 0.3, 1.5
+    slm = StandardLinearModel(b)
+    slm.obj_ = -np.inf
+    slm._state = slm._make_state(X, y)
+    assert type(slm._state).__name__ == "CatFitState" and type(slm._state.children[0]).__name__ == "_ResidentFastFoodGM"
+    try:
+        nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, var, reg, [mean, ls])
+        C = slm._state.best_covariance() if getattr(slm._state, "best_on_device", False) else slm.covariance_
+    finally:
+        slm._state.release()
+        slm._state = None
+    ref = _oracle_gm_elbo(b, X, y, var, reg, mean, ls)
+    assert isinstance(ndhyp, list) and len(ndhyp) == 2 and ndhyp[0].shape == ndhyp[1].shape == (d,)
+    assert abs(-nelbo - ref["elbo"]) < 1e-4 * abs(ref["elbo"])
+    assert abs(-ndvar - ref["dvar"]) < 1e-3 * abs(ref["dvar"]) and abs(-ndreg - ref["dreg"][0]) < 1e-3 * abs(ref["dreg"][0])
+    assert normwise(-ndhyp[0], np.array(ref["dhyp"][:d])) < 2e-3      # d ELBO / d mean
+    assert normwise(-ndhyp[1], np.array(ref["dhyp"][d:])) < 2e-3      # d ELBO / d lenscale
+    assert normwise(slm.weights_, ref["m"]) < 1e-3 and normwise(C, ref["C"]) < 1e-3
+    # the fused statistics and the prediction route, against the same oracle features
+    G, bv, yty = b.gram(X, y, mean, ls)
+    Phi = orc.fastfood_gm_transform(X.astype(np.float64), b.B, b.G, b.PI, b.S, mean, ls)
+    assert normwise(G, Phi.T @ Phi) < 1e-3 and normwise(bv, Phi.T @ y.astype(np.float64)) < 1e-3
+    Ey, Vf = b.predict_moments(X[:50], [mean, ls], ref["m"], ref["C"])
+    Eo, Vo = orc.slm_predict_moments(Phi[:50], ref["m"], ref["C"], 0.0)
+    assert normwise(Ey, Eo) < 1e-3 and normwise(Vf, Vo) < 1e-3
+
+
+def test_fastfood_gm_fits_alone_and_in_a_spectral_mixture():
+    """A spectral mixture as the reference builds it (basis_functions.py:1394-1396: "concatenate as many of these objects
+    as desired"): two FastFoodGM components + a LinearBasis fit device-resident (every child takes part), gradients of the
+    concatenation in the reference's order [mean_1, ls_1, mean_2, ls_2]; a lone component fits too; sklearn can clone it."""
+    import revrand_amd.basis_functions as bs
+    from sklearn.base import clone
+    from revrand_amd.slm import StandardLinearModel
+    rs = np.random.RandomState(4)
+    N, d = 4000, 16
+    X = rs.randn(N, d).astype(np.float32)
+    y = (np.sin(2.0 * X[:, 0]) * np.cos(X[:, 1]) + 0.1 * rs.randn(N)).astype(np.float32)
+    cat = _gm(d, 64, seed=1) + _gm(d, 64, seed=2) + bs.LinearBasis(onescol=True)
+    slm = StandardLinearModel(cat, nstarts=0, maxiter=12, random_state=0)
+    slm.obj_ = -np.inf
+    slm._state = slm._make_state(X, y)
+    assert type(slm._state).__name__ == "CatFitState"
+    hyp = [0.2 * rs.randn(d), np.ones(d), -0.2 * rs.randn(d), 1.3 * np.ones(d)]
+    nelbo, (ndvar, ndreg, ndhyp) = slm._elbo(X, y, 0.5, [1.0, 1.2, 0.7], hyp)
+    slm._state.release()
+    slm._state = None
+    assert len(ndhyp) == 4 and all(g.shape == (d,) for g in ndhyp)
+    # against the oracle on 4n + 4n + (d + 1) hstacked features
+    X64 = X.astype(np.float64)
+    blocks, slabs = [], []
+    for gm, (mu, ls) in zip(cat.bases[:2], (hyp[:2], hyp[2:])):
+        blocks.append(orc.fastfood_gm_transform(X64, gm.B, gm.G, gm.PI, gm.S, mu, ls))
+    blocks.append(orc.linear_transform(X64, True))
+    Phi = np.hstack(blocks)
+    ends = np.cumsum([0] + [bl.shape[1] for bl in blocks])
+    for i, (gm, (mu, ls)) in enumerate(zip(cat.bases[:2], (hyp[:2], hyp[2:]))):
+        for dP in orc.fastfood_gm_grad(X64, gm.B, gm.G, gm.PI, gm.S, mu, ls):
+            for k in range(d):
+                full = np.zeros_like(Phi)
+                full[:, ends[i]:ends[i + 1]] = dP[:, :, k]
+                slabs.append(full)
+    diag = np.concatenate([np.full(ends[i + 1] - ends[i], r) for i, r in enumerate([1.0, 1.2, 0.7])])
+    ref = orc.slm_elbo(Phi, y.astype(np.float64), 0.5, diag, [slice(int(ends[i]), int(ends[i + 1])) for i in range(3)], slabs)
+    assert abs(-nelbo - ref["elbo"]) < 1e-4 * abs(ref["elbo"])
+    assert normwise(-np.concatenate(ndhyp), np.array(ref["dhyp"])) < 2e-3
+    assert normwise(-np.array(ndreg), np.array(ref["dreg"])) < 1e-3
+    # end to end
+    fitted = clone(slm).fit(X, y)
+    assert np.isfinite(fitted.obj_) and ((fitted.predict(X) - y) ** 2).mean() < 0.8 * y.var()
+    Ey, Vy = fitted.predict_moments(X[:100])
+    assert np.all(np.isfinite(Ey)) and np.all(Vy > 0)
+    lone = StandardLinearModel(_gm(d, 128, seed=3), nstarts=0, maxiter=10, random_state=0).fit(X, y)
+    assert np.isfinite(lone.obj_) and len(lone.hypers_) == 2
