@@ -482,6 +482,9 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     // trailing update (upper_only = 2: without the block done ahead) under the next diagonal block's factorisation.
     static const bool no_lookahead = getenv("RR_POSDEF_LOOKAHEAD") != nullptr && atoi(getenv("RR_POSDEF_LOOKAHEAD")) == 0;
     const bool lookahead = overlap && !no_lookahead && nblk > 2;
+    static const bool no_pair = getenv("RR_POSDEF_PAIR") != nullptr && atoi(getenv("RR_POSDEF_PAIR")) == 0;
+    const bool pair_on = lookahead && !no_pair;
+    static const int64_t pair_min = getenv("RR_POSDEF_PAIR_MIN") ? atoll(getenv("RR_POSDEF_PAIR_MIN")) : 4096;
     if (lookahead && !c->stream3) RR_CHECK_HIP(hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking));
     const int64_t nev = lookahead ? 4 * nblk + 1 : nblk + 1;
     // events: [j] first block of row j solved (without look-ahead: the whole row) | [nblk] join | then per panel:
@@ -512,6 +515,18 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         const int64_t rest = Fp - (j + 1) * PB;
         if (lookahead) {
             double *row = Ujj + PB;  // block row j right of the diagonal block
+            // Panels in PAIRS (round 5; RR_POSDEF_PAIR=0 for A/B runs).  The bulk trailing update of a panel is a K = 128
+            // product: every 128 x 128 block of the trailing matrix is read and written around a 128-deep k-loop (~40 % of
+            // the f64 MFMA peak, tools/timeline.py).  Panel j (even) therefore updates only what panel j + 1 needs -- its
+            // diagonal block (this stream) and the rest of its block row (a 128-row strip, third stream) -- and panel j + 1
+            // updates everything below with BOTH block rows at once, K = 256: half the passes over the trailing matrix,
+            // twice the k-loop per pass.
+            // ... while the trailing matrix is LARGE: below pair_min columns a panel step lasts as long as its dependent
+            // chain (diagonal block -> one-tile solve -> one-tile update), which pairing lengthens (the second panel's
+            // one-tile update is a K = 256 product): F = 4096 measured 4.2 -> 4.65 ms with every panel paired
+            const bool first = pair_on && (j % 2 == 0) && rest > PB && rest >= pair_min;
+            const bool second = pair_on && (j % 2 == 1) && rest > 0 && rest + PB >= pair_min;
+            double *row2 = s.W + (j - 1) * PB * ld + (j + 1) * PB;  // second: block rows j - 1 and j, columns right of block j
             launch_chol_diag(main_stream, Ujj, ld, Uij);
             RR_CHECK_HIP(hipEventRecord(s.ev[E_CHOL + j], main_stream));
             if (rest > 0) {
@@ -520,7 +535,9 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
                 rc = rr_launch_gemm_tn_f64(c, Uij, PB, row, ld, row, ld, PB, PB, PB, 0, 0);
                 if (rc != RR_OK) break;
                 RR_CHECK_HIP(hipEventRecord(s.ev[j], main_stream));
-                rc = rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, PB, PB, 1, 1);  // block (j+1, j+1)
+                // block (j + 1, j + 1): from this block row, or (second of a pair) from both block rows of the pair
+                rc = second ? rr_launch_gemm_tn_f64(c, row2, ld, row2, ld, Ujj + PB * (ld + 1), ld, 2 * PB, PB, PB, 1, 1)
+                            : rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, PB, PB, 1, 1);
                 if (rc != RR_OK) break;
                 if (rest > PB) {
                     c->stream = c->stream3;
@@ -529,7 +546,12 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
                     if (rc == RR_OK) {
                         RR_CHECK_HIP(hipEventRecord(s.ev[E_SOLVE + j], c->stream3));
                         RR_CHECK_HIP(hipStreamWaitEvent(c->stream3, s.ev[j], 0));
-                        rc = rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 2);
+                        if (first)        // the strip: block row j + 1 right of its diagonal block
+                            rc = rr_launch_gemm_tn_f64(c, row, ld, row + PB, ld, Ujj + PB * (ld + 1) + PB, ld, PB, PB, rest - PB, 1, 0);
+                        else if (second)  // everything below the pair, K = 256
+                            rc = rr_launch_gemm_tn_f64(c, row2, ld, row2, ld, Ujj + PB * (ld + 1), ld, 2 * PB, rest, rest, 1, 2);
+                        else
+                            rc = rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, rest, rest, 1, 2);
                     }
                     if (rc == RR_OK) RR_CHECK_HIP(hipEventRecord(s.ev[E_TRAIL + j], c->stream3));
                     c->stream = main_stream;
@@ -543,7 +565,11 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
             double *Yj = s.Y + j * PB * ld;
             const int64_t width = (j + 1) * PB;
             rc = rr_launch_gemm_tn_f64(c, Uij, PB, Yj, ld, Yj, ld, PB, PB, width, 0, 0);
-            if (rc == RR_OK && rest > 0) rc = rr_launch_gemm_tn_f64(c, row, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
+            // the same pairing for Y: the first panel of a pair updates block row j + 1 of Y alone, the second everything
+            // below with both block rows (K = 256; block row j - 1 of Y is zero in the columns block row j adds)
+            if (rc == RR_OK && first) rc = rr_launch_gemm_tn_f64(c, row, ld, Yj, ld, Yj + PB * ld, ld, PB, PB, width, 1, 0);
+            else if (rc == RR_OK && second) rc = rr_launch_gemm_tn_f64(c, row2, ld, Yj - PB * ld, ld, Yj + PB * ld, ld, 2 * PB, rest, width, 1, 0);
+            else if (rc == RR_OK && rest > 0) rc = rr_launch_gemm_tn_f64(c, row, ld, Yj, ld, Yj + PB * ld, ld, PB, rest, width, 1, 0);
             c->stream = main_stream;
             continue;
         }

@@ -6,6 +6,7 @@
 // t - rint(t) in [-0.5, 0.5] the hardware v_sin_f32 / v_cos_f32 (which take revolutions)
 // give sin/cos directly.
 #include "rr_syrk_args.h"
+#include <algorithm>
 #include <type_traits>
 
 
@@ -2416,14 +2417,27 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     auto rows_per = [&](int64_t ns) { return ((rows + ns - 1) / ns + GR_KB - 1) / GR_KB * GR_KB; };
     const int64_t unit = ntiles > 0 ? c->num_cu / gcd64(c->num_cu, ntiles) : 1;
     int64_t nsplit = (min_splits + unit - 1) / unit * unit;
-    if (rows / nsplit < 1024) nsplit = (rows + 1023) / 1024;  // small inputs: just cover the rows
+    // small inputs: just cover the rows, >= 1024 per split -- unless that leaves most CUs without a workgroup (few tiles:
+    // config 1's F = 512 is ONE off-diagonal tile and two diagonal ones, 10 splits of its 10 000 rows = 10 workgroups of
+    // 32 k-blocks at one CU's rate each): then down to 256 rows per split, until the tiles x splits fill the CUs
+    // (config 1's `_elbo`: 1.42 -> 1.13 ms)
+    auto floor_rows = [&](int64_t tiles_per_split) {
+        return tiles_per_split * ((rows + 1023) / 1024) < c->num_cu ? (int64_t)256 : (int64_t)1024;
+    };
+    auto small_split = [&](int64_t tiles_per_split) {
+        const int64_t fr = floor_rows(tiles_per_split);
+        if (fr == 1024) return (rows + 1023) / 1024;
+        const int64_t want = (c->num_cu + tiles_per_split - 1) / std::max<int64_t>(tiles_per_split, 1);
+        return std::min((rows + fr - 1) / fr, std::max((rows + 1023) / 1024, want));
+    };
+    if (rows / nsplit < 1024) nsplit = small_split(std::max(ntiles, 1));
     if (nsplit < 1) nsplit = 1;
     int64_t rps = rows_per(nsplit);
     int64_t nsplit_d = nsplit, rps_d = rps;
     if (od) {
         double best = -1.0;
         for (int64_t ns = min_splits; ns < min_splits + 96; ++ns) {
-            if (rows / ns < 1024 && ns > 1) break;
+            if (rows / ns < floor_rows(nb_all) && ns > 1) break;
             const int64_t wg = ns * nb_all, rounds = (wg + c->num_cu - 1) / c->num_cu;
             const double eff = (double)wg / (double)(rounds * c->num_cu);
             if (eff > best + 1e-9) {
@@ -2439,7 +2453,7 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     if (rg) {  // nb_all - 1 equal-cost workgroups per split: the split count whose workgroups fill whole rounds best
         double best = -1.0;
         for (int64_t ns = min_splits; ns < min_splits + 96; ++ns) {
-            if (rows / ns < 1024 && ns > 1) break;
+            if (rows / ns < floor_rows(nb_all - 1) && ns > 1) break;
             const int64_t wg = ns * (nb_all - 1), rounds = (wg + c->num_cu - 1) / c->num_cu;
             const double eff = (double)wg / (double)(rounds * c->num_cu);
             if (eff > best + 1e-9) {
