@@ -1,9 +1,9 @@
-# Profiling recipe, run on the GPU box by gpurun; scratch under gpurun_out/prof_$ROUND (default r04), summarised into
+# Profiling recipe, run on the GPU box by gpurun; scratch under gpurun_out/prof_$ROUND (default r05), summarised into
 # profiles/${ROUND}_* by tools/summarize.py.  Kernel traces and PMC passes are SEPARATE rocprofv3 runs (gpurun refuses
 # --pmc together with the hip / hsa / memory-copy trace domains).
 #   sh tools/prof.sh [stage ...]
 # stages (kernel trace + stats of `python bench.py --configs <that configuration>`):
-#   headline  elbo  elbo64  c3  ffelbo  posdef  predict  laplace  c4  c5
+#   headline  elbo  elbo64  c3  ffelbo  posdef  predict  laplace  c4  c5  c1  c4gm  sp (bench.py --gpus 2 --single-process)
 # counter passes:
 #   sq     matrix-pipe busy cycles + clock of the headline kernels and of the two second-pass kernels (predictsq: predict_moments' product;
 #          c5sq: the GLM step's three products)
@@ -11,7 +11,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-ROUND=${ROUND:-r04}
+ROUND=${ROUND:-r05}
 OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT
 STAGES="${*:-headline elbo c3 ffelbo}"
@@ -37,6 +37,9 @@ predict)  kt predict_kt $S --configs predict_moments_n300k ;;
 laplace)  kt laplace_kt $S --configs c2laplace_f64phase_n1m ;;
 c4)       kt c4_kt $S --configs c4 ;;
 c5)       kt c5_kt $S --configs c5 ;;
+c1)       kt c1_kt $S --configs c1 ;;
+c4gm)     kt c4gm_kt $S --configs c4gm ;;
+sp)       timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sp_kt -o kt -- python bench.py --gpus 2 --single-process --steps 3 --warmup 1 --rows 4000000 --dist-rows 1000000 --no-parity-check --full-json $OUT/sp_kt.full.json > $OUT/sp_kt.json 2> $OUT/sp_kt.err ;;
 sq)
   pmc headline_sq "$SQ" --rows 2000000 --steps 1 --warmup 0 --configs none
   pmc elbo_sq "$SQ" $S --configs c2_elbo_eval

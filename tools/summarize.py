@@ -12,7 +12,7 @@ duration (round 3's summary priced a 475 712-row remainder launch as a 524 288-r
 0.949).  Where a configuration's kernel also serves another stage (the f64 GEMM: second pass and posterior), launches are
 selected by GRID SIZE from the kernel trace, and the selection is written into the summary.
 
-    python tools/summarize.py [round]          (default r04)
+    python tools/summarize.py [round]          (default r05)
 """
 import csv
 import json
@@ -21,7 +21,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 PEAK = {"f32": 157.3e12, "f64": 78.6e12, "hbm": 8.0e12}
 MAX_CLOCK_FRAC = 1.0  # a fraction above clock / 2.40 GHz cannot be right: checked below against 1.0
@@ -62,7 +62,7 @@ def kernel_trace(tag):
     return out
 
 
-def by_totals(stats, trace, prefix, work_per_row, rows_per_pass, launches_per_pass, peak, unit="flop", what="", min_grid=None):
+def by_totals(stats, trace, prefix, work_per_row, rows_per_pass, launches_per_pass, peak, unit="flop", what="", min_grid=None, first_n=None):
     """The kernel's fraction of `peak` over ALL its launches (or, with min_grid, over the launches of at least that grid)."""
     names = [k for k in stats if k.replace("void ", "").startswith(prefix)]
     if not names:
@@ -82,8 +82,11 @@ def by_totals(stats, trace, prefix, work_per_row, rows_per_pass, launches_per_pa
         elif min_grid == "mode":  # the configuration's equal row chunks; the bench's (small) headline part launched the same kernel once
             min_grid, exact = max(set(grids), key=grids.count), True
         d = [ms for n, ms, g, _ in trace if n.startswith(prefix) and (g == min_grid if exact else g >= min_grid)]
+        if first_n is not None:  # the configuration's streaming passes come first in the trace; later launches of the same grid belong to another stage
+            d = d[:first_n]
         calls, total, lo, hi = len(d), sum(d), min(d), max(d)
-        sel = "launches with grid (X x Y x Z work-items) %s %d (kernel trace; %d launches of the kernel in all)" % ("==" if exact else ">=", min_grid, len(grids))
+        sel = "launches with grid (X x Y x Z work-items) %s %d%s (kernel trace; %d launches of the kernel in all)" % (
+            "==" if exact else ">=", min_grid, "" if first_n is None else ", the first %d in launch order" % first_n, len(grids))
     passes = calls / float(launches_per_pass)
     assert abs(passes - round(passes)) < 1e-9, (prefix, calls, launches_per_pass)
     rows = rows_per_pass * passes
@@ -202,7 +205,9 @@ if b and "error" not in b.get("configs", {}).get(key, {"error": 1}):
 # ---- the rest: stats + the bench entry ----
 for tag, name, keys in (("posdef_kt", "posdef", ("posterior_F4096", "posterior_F8257", "posterior_F16384")),
                         ("predict_kt", "predict", ("predict_moments_n300k",)), ("laplace_kt", "laplace", ("C2laplace_f64phase_n1m",)),
-                        ("c4_kt", "c4_fastfood", ("C4_fastfood_f16384",)), ("c5_kt", "c5_glm", ("C5_glm_poisson_svi_step",))):
+                        ("c4_kt", "c4_fastfood", ("C4_fastfood_f16384",)), ("c5_kt", "c5_glm", ("C5_glm_poisson_svi_step",)),
+                        ("c1_kt", "c1_latency", ("C1_elbo_latency",)), ("c4gm_kt", "c4gm", ("C4gm_fastfoodgm_f16384",)),
+                        ("sp_kt", "single_process", ())):
     b = bench_record(tag)
     if not b:
         continue
@@ -213,6 +218,19 @@ for tag, name, keys in (("posdef_kt", "posdef", ("posterior_F4096", "posterior_F
         c = cfgs[keys[0]]
         ks["rr_fastfood16_kernel"] = by_totals(st, tr, "rr_fastfood16_kernel", c["roofline"]["bytes_per_row"], c["rows"], 16, PEAK["hbm"], "byte",
                                                "FastFood chain -> Phi (HBM write), 16 launches of 262 144 rows per pass")
+    if name == "c4gm" and cfgs[keys[0]] and "error" not in cfgs[keys[0]]:
+        c = cfgs[keys[0]]
+        ks["rr_fastfood16_kernel<..., GM>"] = by_totals(st, tr, "rr_fastfood16_kernel", c["roofline"]["bytes_per_row"], c["rows"], 8, PEAK["hbm"], "byte",
+                                                        "FastFoodGM: the chain's mixture mode -> four trig blocks (HBM write), 8 launches of 262 144 rows "
+                                                        "per pass, three passes (warm-up + 2 timed) -- the first 24 launches of the kernel's most frequent grid; the "
+                                                        "_elbo part that follows launches it on 131 072 rows", min_grid="mode", first_n=24)
+    if name == "single_process" and b.get("config", {}).get("single_process"):
+        off, dg = off_diag_flops(4096)
+        rows, lp, n = b["roofline"]["rows_per_step"], b["roofline"]["launches_per_step"], b["n_gpus"]
+        ks["rr_syrk_f32_kernel"] = by_totals(st, tr, "rr_syrk_f32_kernel(", off, rows * n, lp * n, PEAK["f32"], "flop",
+                                             "headline step of bench.py --single-process: every member's launches (members share the one GPU of "
+                                             "the box, so their kernels time-share it: fraction of ONE GPU's peak)", min_grid="max")
+        cfgs = {"line": {k: b.get(k) for k in ("value", "ms_per_step", "n_gpus", "exchange", "per_rank")}, "configs": b.get("configs")}
     if name == "c5_glm" and cfgs[keys[0]] and "error" not in cfgs[keys[0]]:
         KL, Fq, Mq = 500, 2048, cfgs[keys[0]]["rows_per_step"]
         # rr_gemm_tn_f32_kernel also serves the posterior-free statistics part of the bench's headline (other grids): the step's
@@ -303,7 +321,7 @@ if fv and wv and bf:
     tr = {"kernel": "rr_syrk_f32_kernel", "rows_per_launch": rows, "fetch_bytes": fetch, "write_bytes": write, "hbm_bytes": fetch + write,
           "fetch_bytes_of_each_launch": [x * 2048 for x in fv], "bytes_per_row": (fetch + write) / rows,
           "feature_matrix_bytes_per_launch": rows * 4096 * 4.0,
-          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, round-4 binaries, the default command's own %d-row launches, "
+          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, the round's binaries, the default command's own %d-row launches, "
                   "average of a pass' launches); FETCH_SIZE*1024*2 (gfx950 half-count correction of wide coalesced reads, "
                   "MI355X_MICROARCH.md) + WRITE_SIZE*1024; L2->fabric side: requests the Infinity Cache serves are counted too "
                   "(profiles/r02_mall has the probe); profiles/%s_headline" % (rows, ROUND)}
