@@ -1489,7 +1489,6 @@ def single_process(args, json_out):
     pre = preflight_exchange(lambda: group.allreduce_device(pre_bufs, cnt3), group.sync, m0, cnt3, world)
     for b in pre_bufs:
         b.free()
-
     kernel_ms, exch_ms = [], []
 
     def launch(i):
@@ -1517,6 +1516,34 @@ def single_process(args, json_out):
         step(True)
     group.sync()
     elapsed = time.perf_counter() - t0
+    # every member on its own GPU: the same message through the library's OWN transport too (reduce-scatter + all-gather
+    # kernels loading the peers' HBM over the xGMI mesh) -- a second group of contexts on the same GPUs, after the timed
+    # steps, on a thread that is given 90 s: a transport that has never run between two GPUs must not take the line with it
+    pre_peer, peer_hung = None, False
+    if (group.transport == "rccl" or os.environ.get("RR_BENCH_FORCE_PEER_PREFLIGHT") == "1") \
+            and os.environ.get("RR_BENCH_NO_PEER_PREFLIGHT") != "1":
+        import threading
+        box = {}
+
+        def peer_preflight():
+            try:
+                pg = multigpu.get_group(devices, transport="peer")
+                pb = pg.map(lambda i: _hip.get_device().zeros(cnt3 * 8))
+                res = preflight_exchange(lambda: pg.allreduce_device(pb, cnt3), pg.sync, pg.members[0], cnt3, world)
+                ones = pg.map(lambda i: _hip.get_device().upload_vector(np.full(4099, float(i + 1))))
+                pg.allreduce_device(ones, 4099)
+                got = [m.download(o, (4099,), np.float64) for m, o in zip(pg.members, ones)]
+                res["sum_exact"] = bool(all(np.array_equal(g_, np.full(4099, world * (world + 1) / 2.0)) for g_ in got))
+                for b_ in pb + ones:
+                    b_.free()
+                box["res"] = res
+            except Exception as e:  # noqa: BLE001 -- the line says so
+                box["res"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        th = threading.Thread(target=peer_preflight, name="rr-peer-preflight", daemon=True)
+        th.start()
+        th.join(90.0)
+        peer_hung = th.is_alive()
+        pre_peer = {"error": "no result after 90 s"} if peer_hung else box.get("res")
     Gs = [sh.dev.download(sh.acc, (F, F), np.float64) for sh in shards]
     G = Gs[0]
     trace_err = abs(float(np.trace(G)) - args.rows) / args.rows
@@ -1556,7 +1583,7 @@ def single_process(args, json_out):
                      "busbw_GBps": 2.0 * (world - 1) / world * 8 * cnt / (xm * 1e-3) / 1e9 if world > 1 and xm > 0 else None,
                      "model_ms_at_one_xgmi_link": exchange_model_ms(8 * cnt, world),
                      "visible_gpus": ndev, "distinct_gpus": len(set(devices)), "oversubscribed": len(set(devices)) < world,
-                     "peer_access": bool(peers_ok), "preflight": pre, "placement": place},
+                     "peer_access": bool(peers_ok), "preflight": pre, "preflight_peer_transport": pre_peer, "placement": place},
         "per_rank": {"kernel_ms_per_step_max_min_over_members": [max(per_member), min(per_member)],
                      "kernel_ms_per_step_sum_over_members": float(sum(per_member)),
                      "expected_speedup_model": {"ms_per_step": max(per_member) + xm,
@@ -1596,6 +1623,8 @@ def single_process(args, json_out):
         dog.cancel()
     emit(configs or None)
     assert ok, (trace_err, members_identical)
+    if peer_hung:
+        os._exit(0)  # (a device call that never returns would hold the interpreter's exit)
 
 
 def single_process_elbo(args, devices, group):
@@ -1663,6 +1692,7 @@ def single_process_under_ranks(args, comm, rank, world):
     its numbers next to the ranks' own -- one driver command then measures both ways of using the node.  The other ranks
     wait on the host (a file, not a collective: a GPU spinning in an RCCL barrier would disturb the measurement); a child
     that fails or hangs costs this entry only."""
+    child_limit = min(args.config_timeout, 420.0)  # the child needs ~1 minute at BASELINE's sizes; a stuck one must not cost the line
     tag = "rr_bench_sp_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid())
     flag = os.path.join(tempfile.gettempdir(), tag)
     comm.barrier()  # every rank has freed its buffers and is idle
@@ -1681,7 +1711,7 @@ def single_process_under_ranks(args, comm, rank, world):
         if args.no_parity_check:
             cmd.append("--no-parity-check")
         try:
-            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.config_timeout + 120)
+            p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=child_limit)
             lines = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
             if p.returncode != 0 or not lines:
                 res = {"error": "child exited %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-600:])}
@@ -1693,17 +1723,19 @@ def single_process_under_ranks(args, comm, rank, world):
                        "exchange": {k: ex.get(k) for k in ("transport", "ms_per_step_pack_allreduce_unpack", "busbw_GBps",
                                                            "distinct_gpus", "oversubscribed", "peer_access")},
                        "preflight_busbw_GBps": (ex.get("preflight") or {}).get("busbw_GBps"),
+                       "preflight_peer_transport": {k: (ex.get("preflight_peer_transport") or {}).get(k) for k in ("busbw_GBps", "ms", "sum_exact", "error")
+                                                    if k in (ex.get("preflight_peer_transport") or {})} or None,
                        "speedup_model": (d.get("per_rank") or {}).get("expected_speedup_model", {}).get("speedup_vs_one_gpu"),
                        "members_bit_identical": d["config"].get("members_bit_identical"),
                        "elbo": {k: el.get(k) for k in ("ms", "stage_ms", "parity", "error") if k in el}}
         except subprocess.TimeoutExpired:
-            res = {"error": "child still running after %.0f s" % (args.config_timeout + 120)}
+            res = {"error": "child still running after %.0f s" % child_limit}
         except Exception as e:  # noqa: BLE001
             res = {"error": "%s: %s" % (type(e).__name__, e)}
         with open(flag, "w") as f:
             f.write("done\n")
     else:
-        deadline = time.time() + args.config_timeout + 180
+        deadline = time.time() + child_limit + 60
         while not os.path.exists(flag) and time.time() < deadline:
             time.sleep(0.2)
     comm.barrier()

@@ -481,6 +481,7 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
     // device -- or a box without a loadable librccl -- take the in-process peer transport
     if (transport == RR_TRANSPORT_RCCL)
         RR_REQUIRE(distinct || n == 1, "rr_comm_init_all: RCCL needs one member per device; members share a device -- use RR_TRANSPORT_PEER");
+    const bool was_auto = transport == RR_TRANSPORT_AUTO;
     if (transport == RR_TRANSPORT_AUTO) transport = (distinct && n > 1 && rccl_load(nullptr) == RR_OK) ? RR_TRANSPORT_RCCL : RR_TRANSPORT_PEER;
     std::vector<ncclComm_t> nc((size_t)n, nullptr);
     if (transport == RR_TRANSPORT_RCCL) {
@@ -488,8 +489,21 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
         if (rc != RR_OK) return rc;
         std::vector<int> devs((size_t)n);
         for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
-        RR_CHECK_NCCL(g_rccl.CommInitAll(nc.data(), n, devs.data()));
-    } else {
+        const ncclResult_t r = g_rccl.CommInitAll(nc.data(), n, devs.data());
+        if (r != ncclSuccess) {
+            if (!was_auto) {
+                rr_set_error("ncclCommInitAll over %d devices failed: %s", n, g_rccl.GetErrorString(r));
+                return RR_ERR_HIP;
+            }
+            // RR_TRANSPORT_AUTO: a node whose RCCL cannot make this communicator still has its peer links
+            fprintf(stderr, "librevrand_hip: ncclCommInitAll over %d devices failed (%s): the device group uses the peer transport\n", n,
+                    g_rccl.GetErrorString(r));
+            (void)hipGetLastError();
+            for (auto &x : nc) x = nullptr;
+            transport = RR_TRANSPORT_PEER;
+        }
+    }
+    if (transport == RR_TRANSPORT_PEER) {
         int rc = peer_enable(n, ctxs);
         if (rc != RR_OK) return rc;
     }

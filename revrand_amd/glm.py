@@ -83,10 +83,16 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         Row-sharded SVI, one process per GPU under ``torch.distributed``: every rank calls ``fit`` with ITS rows and
         the same integer ``random_state``; per step each rank takes a minibatch of its shard, the Monte-Carlo sums
         ``[Edm | EdC | sum loglike | likelihood sums | basis gradient | batch rows]`` are all-reduced (one message,
-        2 D K + O(d) numbers) and every rank applies the same update."""
+        2 D K + O(d) numbers) and every rank applies the same update.
+    devices : None | sequence of GPU indices | int | "all"
+        Several GPUs behind THIS call, in this process (``revrand_amd.multigpu``): the rows of X stay resident sharded over
+        the listed GPUs, every member serves the rows of a minibatch that fall into its shard, and the step's Monte-Carlo
+        sums are added over the members on the host.  The minibatch stream, the draws and the optimiser are the single-GPU
+        run's; minibatches of fewer than 2048 rows per member are not split."""
 
     def __init__(self, likelihood=Gaussian(), basis=LinearBasis(), K=10, maxiter=3000, batch_size=10, updater=None,
-                 nsamples=50, nstarts=500, random_state=None, sampler="host", distributed=False, gram_engine=None):
+                 nsamples=50, nstarts=500, random_state=None, sampler="host", distributed=False, gram_engine=None,
+                 devices=None):
         self.likelihood = likelihood
         self.basis = basis
         self.K = K
@@ -99,12 +105,25 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         self.sampler = sampler
         self.distributed = distributed
         self.gram_engine = gram_engine  # arithmetic of the step's GEMMs (see StandardLinearModel); None = context setting
+        self.devices = devices          # several GPUs behind this call, in this process (see StandardLinearModel; multigpu.py)
         self.random_ = check_random_state(self.random_state)
 
     def fit(self, X, y, likelihood_args=()):
         """Learn the posterior mixture and the hyper-parameters (glm.py:141-203)."""
-        with _hip.gram_engine_scope(getattr(self, "gram_engine", None)):
+        with self._engine_scope():
             return self._fit(X, y, likelihood_args)
+
+    def _group(self):
+        if getattr(self, "devices", None) is None:
+            return None
+        if self.distributed:
+            raise ValueError("devices= (several GPUs in this process) and distributed=True (one process per GPU) cannot be combined")
+        from . import multigpu
+        return multigpu.get_group(self.devices)
+
+    def _engine_scope(self):
+        g = self._group()
+        return _hip.gram_engine_scope(getattr(self, "gram_engine", None), None if g is None else g.members)
 
     def _fit(self, X, y, likelihood_args=()):
         X, y = check_X_y(X, y)
@@ -156,7 +175,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             # cross-validation loop must not accumulate them)
             self.__dict__["_draw_upload"] = (_hip.get_upload_device(_hip.get_device().index), [None, None, None], [0])
         # (RR_GLM_BATCH_PREFETCH=0: measurement switch, the step uploads its indices / targets and gathers its rows itself)
-        if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0":
+        if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
+                and self._group() is None:  # (a device group's members gather for themselves, on their own threads)
             self.__dict__["_batch_upload"] = _hip.get_upload_device(_hip.get_device().index)
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
@@ -246,7 +266,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     def _features(self):
         f = self.__dict__.get("_mbf")
         if f is None:
-            f = self.__dict__["_mbf"] = MinibatchFeatures(self.basis)
+            g = self._group()
+            if g is not None:
+                from . import multigpu
+                f = multigpu.ShardedMinibatchFeatures(self.basis, g, batch_size=self.batch_size)
+            else:
+                f = MinibatchFeatures(self.basis)
+            self.__dict__["_mbf"] = f
         return f
 
     def _release_features(self):
@@ -457,7 +483,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # the feature matrix is kept between prediction calls (per process; dropped by fit and by pickling)
         srv = self.__dict__.get("_serve_feats")
         if srv is None or srv[0] != os.getpid():
-            srv = self.__dict__["_serve_feats"] = (os.getpid(), MinibatchFeatures(self.basis))
+            g = self._group()
+            if g is not None:
+                from . import multigpu
+                served = multigpu.ShardedMinibatchFeatures(self.basis, g)
+            else:
+                served = MinibatchFeatures(self.basis)
+            srv = self.__dict__["_serve_feats"] = (os.getpid(), served)
         return srv[1].project(X, atleast_list(self.basis_hypers_), w)
 
     def _sample_func(self, X, nsamples, genaxis=1):

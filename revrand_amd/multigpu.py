@@ -338,12 +338,133 @@ def gram(basis, X, y, hypers, devices):
     return (G, None, None) if y is None else (G, b, yty)
 
 
-def map_rows(group, N, fn):
+def map_rows(group, N, fn, n=None):
     """Concatenated results of fn(i, start, stop) over contiguous row shards, member i's on its thread.  fn returns a tuple
     of arrays with one entry per row (or None: not served -- then None is returned)."""
-    n = max(1, min(group.n, N))
+    n = max(1, min(group.n if n is None else n, N))
     bounds = [shard_bounds(N, i, n) for i in range(n)]
     parts = group.map(lambda i: fn(i, *bounds[i]), members=range(n))
     if any(p is None for p in parts):
         return None
     return tuple(None if parts[0][k] is None else np.concatenate([p[k] for p in parts]) for k in range(len(parts[0])))
+
+
+class ShardedMinibatchFeatures(object):
+    """``basis_functions.MinibatchFeatures`` -- what ``GeneralizedLinearModel._elbo`` programs against -- with the resident
+    rows of X sharded over the members of a device group (``GeneralizedLinearModel(devices=[...])``).
+
+    A minibatch is the optimiser's own: row INDICES into all rows (``gen_batch``'s permutation stream, unchanged); member i
+    serves the indices that fall into its shard -- its features (gathered from its resident rows), ``fs = Phi ws``, the
+    likelihood terms and the three products of the step on ITS rows -- and everything a step returns is a sum over rows
+    (``Edm``, ``EdC``, the log-likelihood sums, ``-(EdPhi o dPhi).sum()`` per parameter: glm.py:229-311), added here over the
+    members in member order.  The reparameterisation draws do not depend on rows: every member gets the same ones (the host
+    array, or the device generator's (seed, step) key).  Minibatches too small to be worth splitting (fewer than
+    ``MIN_ROWS_PER_MEMBER`` rows per member: the reference's default batch_size is 10) go to as few members as that allows."""
+
+    MIN_ROWS_PER_MEMBER = 2048
+    supports_objective_only = True
+    accepts_device_draws = False   # a draw buffer lives on ONE device; members take the host array
+
+    def __init__(self, basis, group, batch_size=None):
+        from .basis_functions import MinibatchFeatures
+        self.basis, self.group = basis, group
+        # members that take part: as many as leave MIN_ROWS_PER_MEMBER rows of a minibatch each (all of them for prediction)
+        self.n_use = group.n if batch_size is None else max(1, min(group.n, int(batch_size) // self.MIN_ROWS_PER_MEMBER))
+        self.feats = group.map(lambda i: MinibatchFeatures(basis), members=range(self.n_use))
+        self.resident = False
+        self._parts, self._part_targets = None, {}
+
+    # -- which member serves which rows of a minibatch ---------------------------------------------------
+    def make_resident(self, X):
+        N = X.shape[0]
+        if N < self.n_use * 2:
+            return False
+        self.bounds = [shard_bounds(N, i, self.n_use) for i in range(self.n_use)]
+        self.ends = np.array([e for _, e in self.bounds])
+        ok = self.group.map(lambda i: self.feats[i].make_resident(X[self.bounds[i][0]:self.bounds[i][1]]), members=range(self.n_use))
+        if not all(ok):
+            self.group.map(lambda i: self.feats[i]._drop_children(), members=range(self.n_use))
+            return False
+        self.resident = True
+        return True
+
+    def _split_idx(self, idx):
+        """[(member, positions in the minibatch, member-local row indices)] for the members that get rows."""
+        idx = np.asarray(idx)
+        owner = np.searchsorted(self.ends, idx, side="right")
+        parts = []
+        for i in range(self.n_use):
+            pos = np.nonzero(owner == i)[0]
+            if pos.size:
+                parts.append((i, pos, idx[pos] - self.bounds[i][0]))
+        return parts
+
+    def _split_rows(self, M):
+        """Contiguous chunks of a minibatch that is NOT resident (its rows arrive with the step)."""
+        n = max(1, min(self.n_use, M // self.MIN_ROWS_PER_MEMBER))
+        return [(i, np.arange(*shard_bounds(M, i, n)), None) for i in range(n)]
+
+    def _take(self, arr, pos):
+        return None if arr is None else np.ascontiguousarray(np.asarray(arr)[pos])
+
+    # -- the step ------------------------------------------------------------------------------------------
+    def stage_targets(self, y, rowarg):
+        self._staged = (y, rowarg)
+
+    def take_prefetched_targets(self, gathered, y, rowarg):
+        return False
+
+    def assemble_idx(self, idx, hypers, gathered=None):
+        self._parts = self._split_idx(idx)
+        y, rowarg = self.__dict__.pop("_staged", (None, None))
+        self._part_targets = {}
+
+        def run(k):
+            i, pos, local = self._parts[k]
+            if y is not None:  # the member's targets go up before its feature kernels (the same arrays meet its step below)
+                t = self._part_targets[k] = (id(y), self._take(y, pos), self._take(rowarg, pos))
+                self.feats[i].stage_targets(t[1], t[2])
+            self.feats[i].assemble_idx(local, hypers)
+        self._on_parts(run)
+
+    def assemble(self, X, hypers):
+        self._parts, self._part_targets = self._split_rows(X.shape[0]), {}
+        self._on_parts(lambda k: self.feats[self._parts[k][0]].assemble(X[self._parts[k][1]], hypers))
+
+    def _on_parts(self, fn):
+        """fn(k) for every part k, on its member's thread."""
+        members = [p[0] for p in self._parts]
+        order = {m: k for k, m in enumerate(members)}
+        return self.group.map(lambda i: fn(order[i]), members=members)
+
+    def _step(self, name, y, rowarg, args, kwargs):
+        def run(k):
+            i, pos, _ = self._parts[k]
+            t = self._part_targets.get(k)
+            yk, rk = (t[1], t[2]) if (t is not None and t[0] == id(y)) else (self._take(y, pos), self._take(rowarg, pos))
+            return getattr(self.feats[i], name)(yk, rk, *args, **kwargs)
+        res = self._on_parts(run)
+        Edm = None if res[0][0] is None else _tree_sum([r[0] for r in res])
+        EdC = None if res[0][1] is None else _tree_sum([r[1] for r in res])
+        return Edm, EdC, _tree_sum([r[2] for r in res]), _tree_sum([r[3] for r in res])
+
+    def glm_step_sampled(self, y, rowarg, lik, lik_param, m, C, K, L, seed, step, objective_only=False):
+        return self._step("glm_step_sampled", y, rowarg, (lik, lik_param, m, C, K, L, seed, step), {"objective_only": objective_only})
+
+    def glm_step_draws(self, y, rowarg, lik, lik_param, m, C, K, L, E, objective_only=False):
+        return self._step("glm_step_draws", y, rowarg, (lik, lik_param, m, C, K, L, E), {"objective_only": objective_only})
+
+    def glm_basis_grads(self, X):
+        def run(k):
+            i, pos, local = self._parts[k]
+            return self.feats[i].glm_basis_grads(X if local is not None else X[pos])
+        return _tree_sum(self._on_parts(run))
+
+    # -- prediction: latent function samples Phi(X) W, rows sharded --------------------------------------------
+    def project(self, X, hypers, W):
+        out = map_rows(self.group, X.shape[0], lambda i, s, e: (self.feats[i].project(X[s:e], hypers, W),), n=self.n_use)
+        return out[0]
+
+    def release(self):
+        self.group.map(lambda i: self.feats[i].release(), members=range(self.n_use))
+        self.resident = False

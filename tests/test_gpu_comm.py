@@ -224,8 +224,10 @@ def test_two_rccl_ranks_sum_shard_statistics_and_fit_identically(tmp_path):
 
 def test_bench_two_ranks_as_the_driver_calls_it():
     """`python bench.py --gpus 2` (no launcher): starts its own ranks, exits 0, ONE JSON line, n_gpus as RCCL reports."""
+    # (the single-process run inside the N > 1 line is rehearsed at 4 and 8 ranks below and by test_gpu_multigpu.py)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--rows", "600000", "--dist-rows", "20000", "--configs", "elbo"], capture_output=True, text=True, timeout=1500)
+                        "--rows", "600000", "--dist-rows", "20000", "--configs", "elbo"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, RR_BENCH_NO_SINGLE_PROCESS="1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -260,7 +262,8 @@ def test_bench_two_ranks_under_torch_distributed_run_as_the_driver_launches_n_gp
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29577", os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "600000", "--dist-rows", "20000",
-                        "--configs", "elbo"], capture_output=True, text=True, timeout=1500)
+                        "--configs", "elbo"], capture_output=True, text=True, timeout=1500,
+                       env=dict(os.environ, RR_BENCH_NO_SINGLE_PROCESS="1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-1500:]

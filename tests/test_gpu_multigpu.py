@@ -255,3 +255,90 @@ def test_sklearn_protocol_with_devices():
     # fewer rows than members can share: one GPU, quietly
     tiny = SLM(bs.RandomRBF(nbases=8, Xdim=4, random_state=0), nstarts=0, maxiter=3, devices=[0, 0, 0, 0]).fit(X[:6], y[:6])
     assert np.all(np.isfinite(tiny.weights_))
+
+
+def test_bench_single_process_line():
+    """`python bench.py --gpus 2 --single-process`: ONE JSON line of the contract's shape, the headline step on an in-process
+    device group (members share this box's GPU: "oversubscribed", peer transport), the sharded `_elbo` with its oracle parity,
+    the preflight of config 3's message -- and (forced here; on a node with a GPU per member it runs by itself next to RCCL)
+    the same message through the library's own peer transport with its exact-sum check."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, RR_BENCH_FORCE_PEER_PREFLIGHT="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--single-process", "--steps", "2",
+                        "--warmup", "1", "--rows", "600000", "--dist-rows", "40000"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 8192, lines
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 2 and out["config"]["single_process"] and out["config"]["members_bit_identical"]
+    assert out["config"]["trace_rel_err"] < 1e-6 and out["value"] > 0
+    ex = out["exchange"]
+    assert ex["transport"] == "peer" and ex["oversubscribed"] and ex["distinct_gpus"] == 1 and ex["peer_access"]
+    assert ex["message_bytes"] == 8 * (4096 * 4097 // 2 + 4096 + 2) and ex["preflight"]["busbw_GBps"] > 0
+    pp = ex["preflight_peer_transport"]
+    assert "error" not in pp and pp["sum_exact"] and pp["busbw_GBps"] > 0
+    c = out["configs"]["elbo_rbf_f4096_single_process"]
+    assert "error" not in c, c
+    assert c["parity"]["members_bit_identical"] and c["parity"]["neg_elbo_256_rows"] < 1e-5 and c["parity"]["gradient_256_rows"] < 1e-3
+
+
+def test_glm_with_devices_matches_the_one_context_run():
+    """`GeneralizedLinearModel(devices=[...])`: the resident rows of X sharded over the members, every minibatch served by
+    the members its row indices fall on, the step's sums added over them (glm.py:205-322).  Same seed -> the same minibatch
+    stream and the same draws as the one-context run: ONE `_elbo` agrees to float32 rounding (the row sums regroup), and a
+    short `fit` walks to the same parameters; latent-function samples of the fitted model shard over the query rows."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    from revrand_amd.utils import flatten_values
+    rs = np.random.RandomState(3)
+    N, d, n, K, L, M = 40_000, 6, 64, 4, 20, 8192
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.poisson(np.exp(0.4 * X[:, 0] - 0.2 * X[:, 1])).astype(np.float64)
+    F = 2 * n
+    m, C = 0.1 * rs.randn(F, K), rs.gamma(2., 0.5, size=(F, K))
+    ls = np.linspace(0.8, 1.5, d)
+
+    def make(devices, maxiter=25):
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        return GeneralizedLinearModel(lk.Poisson(), basis, K=K, nsamples=L, batch_size=M, maxiter=maxiter, nstarts=0,
+                                      random_state=2, devices=devices)
+    evals = {}
+    for devices in (None, [0, 0], [0, 0, 0, 0]):
+        glm = make(devices)
+        glm.B_, glm.D_ = N / M, F
+        glm._GeneralizedLinearModel__it = 0   # (a logging iteration: the objective is evaluated, not only its gradient)
+        feats = glm._features()
+        assert type(feats).__name__ == ("MinibatchFeatures" if devices is None else "ShardedMinibatchFeatures")
+        glm._resident_fit = feats.make_resident(X)
+        assert glm._resident_fit
+        idx = np.random.RandomState(5).permutation(N)[:M]
+        f, g = glm._elbo(m, C, 1.3, [], ls, np.empty((M, 0)), y[idx], idx)
+        evals[str(devices)] = np.concatenate(([f], flatten_values(g)))
+        if devices is not None:
+            assert feats.n_use == min(len(devices), M // feats.MIN_ROWS_PER_MEMBER) and len(feats._parts) == feats.n_use
+        glm._resident_fit = False
+        glm._release_features()
+    ref = evals["None"]
+    for k, v in evals.items():
+        assert abs(v[0] - ref[0]) < 1e-5 * abs(ref[0]) and normwise(v[1:], ref[1:]) < 2e-4, k
+    # (the start point of a fit is a draw from NumPy's GLOBAL stream, as in the reference: decorators.py:216-220)
+    np.random.seed(77)
+    one = make(None).fit(X, y)
+    np.random.seed(77)
+    two = make([0, 0]).fit(X, y)
+    assert normwise(two.weights_, one.weights_) < 5e-3 and normwise(two.covariance_, one.covariance_) < 5e-3
+    assert normwise(np.atleast_1d(two.basis_hypers_), np.atleast_1d(one.basis_hypers_)) < 5e-3
+    Xq = rs.randn(9001, d).astype(np.float32)
+    two.random_ = np.random.RandomState(9)
+    one.random_ = np.random.RandomState(9)
+    one.weights_, one.covariance_, one.basis_hypers_ = two.weights_, two.covariance_, two.basis_hypers_
+    assert np.array_equal(two.predict(Xq, nsamples=20), one.predict(Xq, nsamples=20))   # rows are independent

@@ -4,6 +4,8 @@ ragged last one) and 16384 (config 4's width, 128 panels) -- against the ORACLE'
 atomics) and the deterministic reduction mode; and its failure path: a matrix that stops being positive definite in a LATE
 panel, with the look-ahead streams in flight, must come back as RR_ERR_NOT_POSDEF (`None`) with every stream drained, like
 the reference's `if np.any(U.diagonal() < CHOLTHRESH)` (linalg.py:110-123) before its SVD route."""
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,11 @@ import revrand_oracle as orc
 from conftest import normwise
 
 pytestmark = pytest.mark.gpu
+
+# The largest size: 96 panels (F = 12288) by default -- the paired-panel schedule of round 5 (trailing matrix >= 4096 columns)
+# over most of its panels, the oracle's inverse in ~10 s -- and config 4's full width F = 16384 (128 panels, ~half a minute of
+# host LAPACK per case) with RR_TEST_FULL=1; bench.py's `posterior_F16384` line checks iC C = I at that width in every run.
+F_LARGE = 16384 if os.environ.get("RR_TEST_FULL") == "1" else 12288
 
 _CASES = {}
 
@@ -46,7 +53,7 @@ def _posterior(dev, _hip, F, G, b, iL, var):
 
 @pytest.mark.timeout(1800)
 @pytest.mark.parametrize("mode", ["default", "deterministic"])
-@pytest.mark.parametrize("F", [4096, 8257, 16384])
+@pytest.mark.parametrize("F", [4096, 8257, F_LARGE])
 def test_posterior_vs_oracle_solve_posdef(F, mode):
     from revrand_amd import _hip
     dev = _hip.get_device()
