@@ -1960,6 +1960,41 @@ def main():
     assert np.array_equal(G, G.T) or os.environ.get("RR_GRAM_ABLATE")
     trace_err = abs(diag - args.rows) / args.rows
 
+    # ---- full-size parity (N = 1): EVERY entry of the timed step's G and b, over all rows, against the same statistics in
+    # float64 arithmetic (rr_syrk_f64_kernel over float64 features of float64 X -- the route tests/test_gpu_rff.py holds to the
+    # oracle at 1e-5): what the 2048-row oracle slice and the trace cannot see at N = 10M.  Untimed. ----
+    full_check = None
+    if world == 1 and not use_comm and engine == "f32" and not args.no_parity_check and not os.environ.get("RR_GRAM_ABLATE") \
+            and my_rows <= 20_000_000 and os.environ.get("RR_BENCH_NO_FULL_CHECK") != "1":
+        t_fc = time.perf_counter()
+        b64 = _hip.RffHandle(W, compute="f64", device=local_rank)
+        dX64 = dev.empty_matrix(my_rows, d, np.float64, ld_dev=b64.padded_dim)
+        dy64 = dev.malloc(max(my_rows, 1) * 8)
+        dy64.dtype = np.dtype(np.float64)
+        r0 = 0
+        for c in range((my_rows + CH - 1) // CH):
+            Xc, yc = gen_chunk(c, min(CH, args.rows - c * CH), d, wvec)
+            dev.upload_rows(dX64, r0, Xc.astype(np.float64))
+            yc = yc.astype(np.float64)
+            _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, _hip.ctypes.c_void_p(dy64.ptr.value + r0 * 8),
+                                                       yc.ctypes.data_as(_hip.ctypes.c_void_p), yc.nbytes))
+            r0 += len(yc)
+        acc64 = dev.zeros(nacc * 8)
+        q = acc64.ptr.value
+        b64.gram_dev(dX64, dy64, 1.0, _hip.ctypes.c_void_p(q), _hip.ctypes.c_void_p(q + F * F * 8), _hip.ctypes.c_void_p(q + (F * F + F) * 8))
+        _hip._check(dev.lib, dev.lib.rr_symmetrize_dev(dev.ctx, _hip.ctypes.c_void_p(q), F))
+        dev.sync()
+        G64 = dev.download(acc64, (F, F), np.float64)
+        bv = dev.download(acc_buf, (F,), np.float64, offset_bytes=F * F * 8)
+        bv64 = dev.download(acc64, (F,), np.float64, offset_bytes=F * F * 8)
+        full_check = {"rows": my_rows, "G_max_rel_diff_f32_vs_f64": float(np.abs(G - G64).max() / np.abs(G64).max()),
+                      "b_max_rel_diff_f32_vs_f64": float(np.abs(bv - bv64).max() / np.abs(bv64).max()),
+                      "_seconds": time.perf_counter() - t_fc}
+        for buf in (dX64, dy64, acc64):
+            buf.free()
+        del b64, G64
+        assert full_check["G_max_rel_diff_f32_vs_f64"] < 1e-4 and full_check["b_max_rel_diff_f32_vs_f64"] < 1e-4, full_check
+
     # ---- informational: the same step on the split-fp16 engine (N=1 only; never `value`) ----
     alt = None
     if world == 1 and not use_comm and engine == "f32" and not args.no_alt_engine and not os.environ.get("RR_GRAM_ABLATE"):
@@ -2020,6 +2055,7 @@ def main():
                                    "over %d GPU(s)" % (n, F, d, args.rows, world),
                        "rows_per_gpu": my_rows, "device": dev.name.strip(), "trace_rel_err": trace_err,
                        "gram_engine": engine, "parity_rel_err_2048_rows_vs_oracle": parity_err,
+                       "parity_all_rows_f32_vs_f64": full_check,
                        "runtime": {"hip_runtime": os.path.basename(rt["hip_runtime"] or ""),
                                    "rccl": rt["rccl"].get("version", rt["rccl"].get("error"))},
                        "_runtime": rt},
