@@ -1355,6 +1355,13 @@ def extra_configs(dev, _hip, args, emit=None):
                 time.sleep(1e6)
             res[name] = fn(dev, _hip, args)
             res[name]["_bench_seconds"] = time.perf_counter() - t0
+            # the line carries numbers (the driver keeps a 9 KB tail): a side configuration's prose -- what it ran, what its
+            # cpu sample was -- goes to the unabridged record (--full-json); the configuration's NAME says which it is
+            if "workload" in res[name]:
+                res[name]["_workload"] = res[name].pop("workload")
+            cb = res[name].get("cpu_baseline")
+            if isinstance(cb, dict) and "sample" in cb:
+                cb["_sample"] = cb.pop("sample")
         except Exception as e:  # a failing side configuration must not take the headline line with it -- but it is said
             res[name] = {"error": "%s: %s" % (type(e).__name__, e) if not isinstance(e, ParityError) else str(e)}
             sys.stderr.write("bench.py: config %s failed: %r\n" % (name, e))
