@@ -277,13 +277,209 @@ __global__ void __launch_bounds__(256) rr_chol_diag_pipe_kernel(double *__restri
         }
 }
 
-// RR_CHOL_DIAG=0: the unpipelined kernel (A/B runs)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same block, factored in 16-column SUB-PANELS with the f64 matrix cores (round 5).  The two kernels above spend ~1000
+// cycles per column: every one of the 128 pivots is a workgroup-wide round trip (row to LDS, barrier, LDS reads, rsqrt,
+// up to 64 FMAs per thread).  Here the work matrix lives in LDS (128 x 130 f64) and, per sub-panel kb of 16 columns:
+//   P1  wave 0      R = chol(S[kb][kb]) and T_kb = R^-T, pivot by pivot, the 16 x 16 block in the MFMA accumulator layout
+//                   (chol16_pivots: ~340 cycles per pivot, the only serial part)
+//   P2  all waves   S[kb][jb] <- R^-T S[kb][jb], jb > kb                    4 v_mfma_f64_16x16x4 per 16 x 16 block
+//   P3  wave 0      S[kb+1][kb+1] -= S[kb][kb+1]^T S[kb][kb+1], then straight on to P1 of sub-panel kb + 1 -- while
+//       waves 1-3   the other trailing blocks S[ib][jb] -= S[kb][ib]^T S[kb][jb] and block row kb of T = U^-T by forward
+//                   substitution, T[kb][jb] = -T_kb sum_{i = jb .. kb-1} U[i][kb]^T T[i][jb] (T goes into the unused lower blocks)
+// so that the MFMA work of a sub-panel hides under the next sub-panel's pivots.  Outputs as rr_chol_diag_kernel's (factor to
+// rounding; a non-positive pivot is replaced by 1 and flagged through -1 on the diagonal; Uinv = T^T).
+// Measured (box K, 128 launches per F = 4096 posterior): 61 us (pipelined kernel above) -> 40 us with P1 - P3 in sequence
+// -> see docs/KERNELS.md 3.24 for the overlapped form.  RR_CHOL_DIAG=1: the pipelined kernel above, =0: the plain one.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef double doublex4_ __attribute__((ext_vector_type(4)));
+constexpr int CB = 16;    // sub-panel width
+constexpr int SLD = 130;  // LDS row stride of the work matrix (f64): column-direction operand reads stay off one bank
+constexpr int RLD = 18;   // row stride of a 16 x 16 diagonal T block / of a wave's scratch block
+
+__device__ __forceinline__ double rr_readlane_f64(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// P1 (one wave): the 16 x 16 diagonal sub-block kb in the MFMA accumulator layout -- lane (g, c) holds rows g, g + 4, g + 8,
+// g + 12 of column c; U: the Cholesky work block (upper part meaningful), Wb: W of the substitution R^T T = I (lower part; T =
+// R^-T comes out in it).  Four pivots at a time: pivot p = 4 s + q sits in register s of lane group q.  Per pivot only the rest
+// of its own 4-row strip is updated (one FMA per block; the row's values travel by ds_bpermute, the multipliers by
+// v_readlane); the rows below get all four pivots at once: the registers that hold the strip ARE the A and B operands of a
+// 16x16x4 MFMA -- a rank-4 update without moving anything.  (First version: lane = column, 16 rows in registers, every
+// multiplier by v_readlane: 590 cycles per pivot.)
+__device__ __forceinline__ void chol16_pivots(double *S, double *Rv, int *flag, const int kb, const int lane) {
+    const int c = lane & 15, g = lane >> 4, k0 = kb * CB;
+    doublex4_ U, Wb = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) U[e] = S[(k0 + g + 4 * e) * SLD + k0 + c];
+    int bad = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+        for (int q_ = 0; q_ < 4; ++q_) {
+            const int p = 4 * s_ + q_;
+            double app = rr_readlane_f64(U[s_], 16 * q_ + p);
+            const bool ok = app > 0.0 && app < INFINITY;
+            bad |= ok ? 0 : 1;
+            app = ok ? app : 1.0;
+            double dp, inv;
+            rr_sqrt_and_rsqrt(app, dp, inv);
+            const bool mine = g == q_;
+            const double us = U[s_] * inv, ws = Wb[s_] * inv;
+            U[s_] = mine ? (c == p ? dp : us) : U[s_];       // row p: U[p][c] (c > p), the diagonal entry
+            Wb[s_] = mine ? (c == p ? inv : ws) : Wb[s_];    // T[p][c] (c < p), T[p][p]; zero beyond (W is lower triangular)
+            if (q_ < 3) {  // the rest of the strip: rows 4 s + q' (q' > q), one per lane group
+                const double urow = __shfl(U[s_], 16 * q_ + c, 64), wrow = __shfl(Wb[s_], 16 * q_ + c, 64);
+                double ur = 0.0;
+#pragma unroll
+                for (int gr = q_ + 1; gr < 4; ++gr) {
+                    const double u1 = rr_readlane_f64(U[s_], 16 * q_ + 4 * s_ + gr);  // U[p][4 s + gr]
+                    ur = g == gr ? u1 : ur;
+                }
+                U[s_] = fma(-ur, urow, U[s_]);    // (groups <= q: ur = 0)
+                Wb[s_] = fma(-ur, wrow, Wb[s_]);
+            }
+        }
+        if (s_ < 3) {  // rows 4 s + 4 .. 15: all four pivots of the strip at once
+            const double an = c >= 4 * s_ + 4 ? -U[s_] : 0.0;  // A[i = c][k = g] = -U[4 s + g][c], rows above untouched
+            U = __builtin_amdgcn_mfma_f64_16x16x4f64(an, U[s_], U, 0, 0, 0);
+            Wb = __builtin_amdgcn_mfma_f64_16x16x4f64(an, Wb[s_], Wb, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = g + 4 * e;
+        S[(k0 + r) * SLD + k0 + c] = r <= c ? U[e] : 0.0;
+        Rv[(k0 + r) * RLD + c] = r >= c ? Wb[e] : 0.0;  // T_kb = R^-T (lower triangular), row-major
+    }
+    if (bad && lane == 0) *flag = 1;
+}
+
+// S[ib][jb] -= S[kb][ib]^T S[kb][jb]  (one wave)
+__device__ __forceinline__ void chol16_update(double *S, const int kb, const int ib, const int jb, const int lane) {
+    const int c = lane & 15, g = lane >> 4, k0 = kb * CB;
+    doublex4_ acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double a = S[(k0 + g + 4 * t) * SLD + ib * CB + c];
+        const double b = S[(k0 + g + 4 * t) * SLD + jb * CB + c];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[(ib * CB + g + 4 * e) * SLD + jb * CB + c] -= acc[e];
+}
+
+// T[kb][jb] = -T_kb sum_{i = jb .. kb-1} U[i][kb]^T T[i][jb]  into the lower block (kb, jb) of S  (one wave; T[jb][jb] = T_jb in Rv)
+__device__ __forceinline__ void chol16_trow(double *S, const double *Rv, double *T, const int kb, const int jb, const int lane) {
+    const int c = lane & 15, g = lane >> 4;
+    doublex4_ acc = {0.0, 0.0, 0.0, 0.0};
+    for (int i = jb; i < kb; ++i) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const double a = S[(i * CB + g + 4 * t) * SLD + kb * CB + c];                          // U[i][kb][k][a = c]
+            const double b = i == jb ? Rv[(jb * CB + g + 4 * t) * RLD + c] : S[(i * CB + g + 4 * t) * SLD + jb * CB + c];  // T[i][jb][k][b = c]
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) T[(g + 4 * e) * RLD + c] = acc[e];
+    doublex4_ acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const double a = Rv[(kb * CB + c) * RLD + g + 4 * t];  // T_kb[a = c][k]
+        const double b = T[(g + 4 * t) * RLD + c];
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) S[(kb * CB + g + 4 * e) * SLD + jb * CB + c] = -acc2[e];
+}
+
+__global__ void __launch_bounds__(256) rr_chol_diag_mfma_kernel(double *__restrict__ A, int64_t ld, double *__restrict__ Uinv) {
+    __shared__ double S[PB * SLD];          // 133 120 B
+    __shared__ double Rv[8 * CB * RLD];     //  18 432 B: T_kb = R_kb^-T, row-major 16 x 16 each
+    __shared__ double Tw[4 * CB * RLD];     //   9 216 B: one scratch block per wave
+    __shared__ int flag;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    {   // thread -> column tid & 127, rows (tid >> 7) + 2 it: all 64 loads of a thread in flight together (as a rolled loop
+        // every iteration waits a global-memory round trip: the first version of this kernel spent 50 us here)
+        const int cc = tid & 127, r0 = tid >> 7;
+        double v[64];
+#pragma unroll
+        for (int it = 0; it < 64; ++it) v[it] = A[(int64_t)(r0 + 2 * it) * ld + cc];
+#pragma unroll
+        for (int it = 0; it < 64; ++it) S[(r0 + 2 * it) * SLD + cc] = cc >= r0 + 2 * it ? v[it] : 0.0;
+    }
+    if (tid == 0) flag = 0;
+    __syncthreads();
+    for (int kb = -1; kb < 8; ++kb) {
+        if (kb >= 0) {
+            // ---- P2: block row kb right of the diagonal: S[kb][jb] <- R^-T S[kb][jb] = T_kb S[kb][jb]
+            const int k0 = kb * CB;
+            for (int jb = kb + 1 + wave; jb < 8; jb += 4) {
+                doublex4_ acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const double a = Rv[(k0 + c) * RLD + g + 4 * t];              // (R^-1)[k][i = c] = T_kb[i][k]
+                    const double b = S[(k0 + g + 4 * t) * SLD + jb * CB + c];     // S[kb][jb][k][j = c]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) S[(k0 + g + 4 * e) * SLD + jb * CB + c] = acc[e];
+            }
+            __syncthreads();
+        }
+        // ---- P3 of sub-panel kb next to P1 of sub-panel kb + 1
+        const bool chain = wave == 0 && kb < 7;  // wave 0: the next diagonal block first, then its pivots
+        if (chain) {
+            if (kb >= 0) chol16_update(S, kb, kb + 1, kb + 1, lane);
+            chol16_pivots(S, Rv, &flag, kb + 1, lane);
+        }
+        if (kb >= 0 && !chain) {
+            // the other waves (all four behind the last sub-panel): block row kb of T, longest sums first, then the trailing blocks
+            const int nw = kb < 7 ? 3 : 4, me = kb < 7 ? wave - 1 : wave;
+            int q = 0;
+            for (int jb = 0; jb < kb; ++jb, ++q)
+                if (q % nw == me) chol16_trow(S, Rv, Tw + wave * CB * RLD, kb, jb, lane);
+            for (int ib = kb + 1; ib < 8; ++ib)
+                for (int jb = ib; jb < 8; ++jb) {
+                    if (ib == kb + 1 && jb == kb + 1) continue;  // (wave 0's)
+                    if (q++ % nw == me) chol16_update(S, kb, ib, jb, lane);
+                }
+        }
+        __syncthreads();
+    }
+    const int isbad = flag;
+    {   // U (upper) back to A; Uinv = T^T: Uinv[r][cc] = T[cc][r]
+        const int cc = tid & 127, r0 = tid >> 7, bj = cc >> 4;
+#pragma unroll 16
+        for (int it = 0; it < 64; ++it) {
+            const int r = r0 + 2 * it, bi = r >> 4;
+            double u = cc >= r ? S[r * SLD + cc] : 0.0;
+            if (isbad && r == cc) u = -1.0;
+            A[(int64_t)r * ld + cc] = u;
+            double xi = 0.0;
+            if (bi < bj) xi = S[cc * SLD + r];
+            else if (bi == bj) xi = Rv[(bi * CB + (cc & 15)) * RLD + (r & 15)];
+            Uinv[r * PB + cc] = xi;
+        }
+    }
+}
+
+// RR_CHOL_DIAG=0: the unpipelined kernel, =1: the pipelined one (A/B runs); default: the sub-panel / MFMA kernel
 static void launch_chol_diag(hipStream_t stream, double *Ujj, int64_t ld, double *Uij) {
-    static const bool plain = getenv("RR_CHOL_DIAG") != nullptr && atoi(getenv("RR_CHOL_DIAG")) == 0;
-    if (plain)
+    static const int which = getenv("RR_CHOL_DIAG") != nullptr ? atoi(getenv("RR_CHOL_DIAG")) : 2;
+    if (which == 0)
         hipLaunchKernelGGL(rr_chol_diag_kernel, dim3(1), dim3(256), 0, stream, Ujj, ld, Uij);
-    else
+    else if (which == 1)
         hipLaunchKernelGGL(rr_chol_diag_pipe_kernel, dim3(1), dim3(256), 0, stream, Ujj, ld, Uij);
+    else
+        hipLaunchKernelGGL(rr_chol_diag_mfma_kernel, dim3(1), dim3(256), 0, stream, Ujj, ld, Uij);
 }
 
 // W (Fp, Fp) = J C J in the top-left F x F (both index orders reversed), identity on the pad diagonal
