@@ -7,6 +7,8 @@
 // give sin/cos directly.
 #include "rr_syrk_args.h"
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 
@@ -2354,7 +2356,23 @@ static int ensure_zbuf(rr_basis *b, size_t bytes) {
 // Greedy XCD-aware tile order: dispatch position q goes to XCD q % 8, so XCD x receives positions
 // x, x+8, ...; fill each XCD's quota with tiles that add the fewest new column blocks to the set it
 // already reads.  Only used when ntiles is a multiple of 8 (equal quotas keep the load balanced).
+static void rr_build_tile_map_uncached(int nb, int od, int nxcd, std::vector<int> &map);
+
 void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
+    static std::mutex mu;
+    static std::map<int, std::vector<int>> cache;  // contexts of one process (device groups, alternating bases) share the maps
+    std::lock_guard<std::mutex> lk(mu);
+    const int key = (nb * 2 + od) * 64 + nxcd;
+    auto it = cache.find(key);
+    if (it == cache.end()) {
+        std::vector<int> m;
+        rr_build_tile_map_uncached(nb, od, nxcd, m);
+        it = cache.emplace(key, std::move(m)).first;
+    }
+    map = it->second;
+}
+
+static void rr_build_tile_map_uncached(int nb, int od, int nxcd, std::vector<int> &map) {
     const int ntiles = od ? nb * (nb - 1) / 2 : nb * (nb + 1) / 2;
     map.assign(ntiles, 0);
     std::vector<int> ta(ntiles), tb(ntiles);
@@ -2362,6 +2380,8 @@ void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
         for (int b2 = a + od; b2 < nb; ++b2, ++t) { ta[t] = a; tb[t] = b2; }
     std::vector<char> used(ntiles, 0);
     const int quota = ntiles / nxcd;
+    std::vector<int> part(ntiles, 0);  // tile -> XCD
+    // greedy start: every XCD in turn takes the tiles that add the fewest new column blocks to what it already reads
     for (int x = 0; x < nxcd; ++x) {
         std::vector<char> have(nb, 0);
         for (int s = 0; s < quota; ++s) {
@@ -2373,9 +2393,68 @@ void rr_build_tile_map(int nb, int od, int nxcd, std::vector<int> &map) {
             }
             used[best] = 1;
             have[ta[best]] = have[tb[best]] = 1;
-            map[s * nxcd + x] = best;
+            part[best] = x;
         }
     }
+    // ... improved by annealing over tile SWAPS between XCDs (round 5; RR_GRAM_TILE_ANNEAL=0: the greedy map).  The cost is
+    // what the eight L2s read per row split: the number of distinct column blocks of P each XCD's tiles touch, summed --
+    // 65 for the greedy partition of F = 4096's 120 off-diagonal tiles, 57 after annealing (a (16, 6, 1) design, 48, does not
+    // exist); 141 -> 130 at 32 column blocks.  Deterministic (fixed seed); made once per process and tile count (cache below).
+    static const bool anneal = !(getenv("RR_GRAM_TILE_ANNEAL") && atoi(getenv("RR_GRAM_TILE_ANNEAL")) == 0);
+    if (anneal && nxcd > 1 && ntiles >= 2 * nxcd && nb <= 128) {
+        std::vector<int> cnt((size_t)nxcd * nb, 0);
+        auto add = [&](int x, int t, int d) {
+            cnt[(size_t)x * nb + ta[t]] += d;
+            if (tb[t] != ta[t]) cnt[(size_t)x * nb + tb[t]] += d;
+        };
+        for (int t = 0; t < ntiles; ++t) add(part[t], t, 1);
+        auto cost_of = [&]() {
+            int c2 = 0;
+            for (size_t i = 0; i < cnt.size(); ++i) c2 += cnt[i] > 0;
+            return c2;
+        };
+        // blocks of XCD x in use if tile `out` leaves and tile `in` joins
+        auto delta_one = [&](int x, int out, int in) {
+            int before = 0, after = 0;
+            const int bl[4] = {ta[out], tb[out], ta[in], tb[in]};
+            for (int i = 0; i < 4; ++i) {
+                bool seen = false;
+                for (int j = 0; j < i; ++j) seen = seen || bl[j] == bl[i];
+                if (seen) continue;
+                const int b = bl[i];
+                const int c0 = cnt[(size_t)x * nb + b];
+                const int c1 = c0 - ((ta[out] == b) || (tb[out] == b) ? 1 : 0) + ((ta[in] == b) || (tb[in] == b) ? 1 : 0);
+                before += c0 > 0;
+                after += c1 > 0;
+            }
+            return after - before;
+        };
+        uint64_t rng = 0x9E3779B97F4A7C15ull;
+        auto next = [&]() {
+            rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17;
+            return rng;
+        };
+        int cur = cost_of(), best = cur;
+        std::vector<int> best_part = part;
+        const int64_t iters = std::min<int64_t>((int64_t)20000 * ntiles, 6000000);  // 0.1 s at F = 4096, 0.3 s at most
+        for (int64_t it = 0; it < iters; ++it) {
+            const int t1 = (int)(next() % (uint64_t)ntiles), t2 = (int)(next() % (uint64_t)ntiles);
+            const int x = part[t1], y = part[t2];
+            if (x == y) continue;
+            const int d = delta_one(x, t1, t2) + delta_one(y, t2, t1);
+            const double temp = 0.4 * (1.0 - (double)it / (double)iters) + 0.05;
+            if (d <= 0 || (double)(next() >> 11) / 9007199254740992.0 < exp(-(double)d / temp)) {
+                add(x, t1, -1); add(y, t2, -1); add(x, t2, 1); add(y, t1, 1);
+                part[t1] = y; part[t2] = x;
+                cur += d;
+                if (cur < best) { best = cur; best_part = part; }
+            }
+        }
+        part = best_part;
+    }
+    // launch order: workgroup s * nxcd + x runs on XCD x; an XCD's tiles in (a, b) order, so that neighbours in time share blocks
+    std::vector<int> fill(nxcd, 0);
+    for (int t = 0; t < ntiles; ++t) map[(size_t)fill[part[t]]++ * nxcd + part[t]] = t;
 }
 
 // G(upper) += P^T P for a zero-padded f32 feature matrix (rows % 32 == 0, ldp % 256 == 0).
