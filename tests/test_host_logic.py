@@ -554,3 +554,97 @@ def test_bases_under_the_reference_estimators_call_sequence(golden, monkeypatch)
         # :240-243 -- predict_moments' use of the basis
         Phi = basis.transform(X[:7], *([hyp] if tag != "cat" else [hyp]))
         assert Phi.shape == (7, m.size) and np.all(np.isfinite((Phi.dot(C) * Phi).sum(axis=1)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# revrand_amd/multigpu.py: the host logic of the in-process device group (no GPU: stub group / stub states)
+# ---------------------------------------------------------------------------------------------------------------------
+
+class _StubGroup(object):
+    """DeviceGroup's interface without devices: `map` runs fn(i) in member order on this thread."""
+
+    def __init__(self, n):
+        import threading
+        self.n, self._lock = n, threading.RLock()
+        self.reduced = []
+
+    def map(self, fn, members=None):
+        return [fn(i) for i in (range(self.n) if members is None else members)]
+
+    def reduce_stats(self, F, ptrs, nrows, wait=True):
+        self.reduced.append((F, list(nrows)))
+        return int(sum(nrows))
+
+
+class _StubState(object):
+    """A fit state over a row shard that computes with NumPy what the device state would (Phi given)."""
+
+    def __init__(self, Phi, y):
+        self.Phi, self.y, self.F, self.dev = Phi, y, Phi.shape[1], None
+        self.acc = None
+        self.dC = "C%d" % id(self)
+
+    nrows = property(lambda self: self.Phi.shape[0])
+
+    def gram_launch(self, hypers):
+        self.launched = hypers
+
+    def _stat_ptrs(self):
+        return (None, None, None)
+
+    def posterior(self, iL, var):
+        return ("m", "dg", 1.0, 2.0)
+
+    def second_pass(self, hypers, m, C, var):
+        assert C == self.dC  # every member is handed ITS copy of the covariance
+        r = self.y - self.Phi @ m
+        return float(r @ r), [np.array([self.Phi.sum(), 1.0]), float(len(self.y))]
+
+    def keep_best(self):
+        self.kept = True
+
+    def release(self):
+        self.released = True
+
+
+def test_multigpu_host_logic_shards_sums_and_routes():
+    from revrand_amd import multigpu
+    assert multigpu.resolve_devices([0, 0, 1]) == (0, 0, 1) and multigpu.resolve_devices(3) == (0, 1, 2)
+    with pytest.raises(ValueError):
+        multigpu.resolve_devices("some")
+    with pytest.raises(ValueError):
+        multigpu.resolve_devices(0)
+    assert multigpu._tree_sum([[1.0, np.array([1.0, 2.0])], [2.0, np.array([3.0, 4.0])]])[1].tolist() == [4.0, 6.0]
+    # ShardedFitState over stub states: contiguous shards equal to within a row, sums in member order, per-member covariance
+    rs = np.random.RandomState(0)
+    N, F, n = 103, 5, 4
+    Phi, y, m = rs.randn(N, F), rs.randn(N), rs.randn(F)
+    g = _StubGroup(n)
+    bounds = [multigpu.shard_bounds(N, i, n) for i in range(n)]
+    assert bounds[0][0] == 0 and bounds[-1][1] == N and max(e - s for s, e in bounds) - min(e - s for s, e in bounds) <= 1
+    states = [_StubState(Phi[s:e], y[s:e]) for s, e in bounds]
+    st = multigpu.ShardedFitState(g, states, bounds)
+    assert st.N_total == N and st.F == F
+    sq, dh = st.second_pass([1.0], m, st.dC, 0.5)
+    assert abs(sq - float((y - Phi @ m) @ (y - Phi @ m))) < 1e-9
+    assert abs(dh[0][0] - Phi.sum()) < 1e-9 and dh[0][1] == n and dh[1] == N
+    assert st.posterior(np.ones(F), 0.5) == ("m", "dg", 1.0, 2.0)
+    st.keep_best()
+    assert st.best_on_device and all(s.kept for s in states)
+    with pytest.raises(ValueError):
+        st.gram_device([1.0], reduce=lambda *a: None)   # a process group on top of a device group: refused
+    st.release()
+    assert all(s.released for s in states)
+    # minibatch routing of the sharded GLM features: every index goes to the member whose shard holds it, positions kept
+    smf = multigpu.ShardedMinibatchFeatures.__new__(multigpu.ShardedMinibatchFeatures)
+    smf.group, smf.n_use = g, 3
+    smf.bounds = [multigpu.shard_bounds(1000, i, 3) for i in range(3)]
+    smf.ends = np.array([e for _, e in smf.bounds])
+    idx = rs.permutation(1000)[:200]
+    parts = smf._split_idx(idx)
+    seen = np.concatenate([pos for _, pos, _ in parts])
+    assert sorted(seen.tolist()) == list(range(200))
+    for i, pos, local in parts:
+        s, e = smf.bounds[i]
+        assert np.all((idx[pos] >= s) & (idx[pos] < e)) and np.array_equal(local, idx[pos] - s)
+    assert [p[0] for p in smf._split_rows(5000)] == [0, 1] and [p[0] for p in smf._split_rows(100)] == [0]
