@@ -260,13 +260,24 @@ class ShardedFitState(object):
         bounds = [shard_bounds(N, i, group.n) for i in range(group.n)]
         y = np.asarray(y)
 
+        states = [None] * group.n
+
         def build(i):
             s, e = bounds[i]
-            return make(X[s:e], y[s:e])
+            states[i] = make(X[s:e], y[s:e])
+
+        def drop(i):
+            st, states[i] = states[i], None
+            if st is not None:
+                st.release()
         with group._lock:
-            states = group.map(build)
+            try:
+                group.map(build)
+            except BaseException:  # a member that failed (out of memory, ...) must not leave the others' shards resident
+                group.map(drop)
+                raise
             if any(st is None for st in states):
-                group.map(lambda i: states[i].release() if states[i] is not None else None)
+                group.map(drop)
                 return None
         return cls(group, states, bounds)
 
