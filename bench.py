@@ -1712,6 +1712,8 @@ def single_process_under_ranks(args, comm, rank, world):
         env = {k: v for k, v in os.environ.items() if k not in (
             "RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "NCCL_HOSTID", "RR_COMM_RDZV", "REVRAND_HIP_DEVICE",
             "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+        if env.get("OMP_NUM_THREADS") == "1":  # torch.distributed.run's per-rank default; the child is ONE process for the node
+            env.pop("OMP_NUM_THREADS")
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--single-process", "--steps", str(min(args.steps, 5)),
                "--warmup", str(min(args.warmup, 2)), "--rows", str(args.rows), "--dist-rows", str(args.dist_rows),
                "--config-timeout", str(args.config_timeout)]
