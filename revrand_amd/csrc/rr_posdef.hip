@@ -717,9 +717,10 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
             // diagonal block (this stream) and the rest of its block row (a 128-row strip, third stream) -- and panel j + 1
             // updates everything below with BOTH block rows at once, K = 256: half the passes over the trailing matrix,
             // twice the k-loop per pass.
-            // ... while the trailing matrix is LARGE: below pair_min columns a panel step lasts as long as its dependent
-            // chain (diagonal block -> one-tile solve -> one-tile update), which pairing lengthens (the second panel's
-            // one-tile update is a K = 256 product): F = 4096 measured 4.2 -> 4.65 ms with every panel paired
+            // ... while the trailing matrix is wide (pair_min): below that a panel step lasts as long as its dependent chain
+            // (diagonal block -> one-tile solve -> one-tile update), and pairing only adds launches.  (A first form had the
+            // second panel update block (j + 1, j + 1) with both block rows at once -- a K = 256 one-tile product ON the chain:
+            // F = 4096 measured 4.2 -> 4.65 ms with every panel paired; now the first panel's part comes from the third stream)
             const bool first = pair_on && (j % 2 == 0) && rest > PB && rest >= pair_min;
             const bool second = pair_on && (j % 2 == 1) && rest > 0 && rest + PB >= pair_min;
             double *row2 = s.W + (j - 1) * PB * ld + (j + 1) * PB;  // second: block rows j - 1 and j, columns right of block j
@@ -731,9 +732,9 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
                 rc = rr_launch_gemm_tn_f64(c, Uij, PB, row, ld, row, ld, PB, PB, PB, 0, 0);
                 if (rc != RR_OK) break;
                 RR_CHECK_HIP(hipEventRecord(s.ev[j], main_stream));
-                // block (j + 1, j + 1): from this block row, or (second of a pair) from both block rows of the pair
-                rc = second ? rr_launch_gemm_tn_f64(c, row2, ld, row2, ld, Ujj + PB * (ld + 1), ld, 2 * PB, PB, PB, 1, 1)
-                            : rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, PB, PB, 1, 1);
+                // block (j + 1, j + 1) gets THIS block row's part here, on the chain (one K = 128 tile as without pairs); for the
+                // second panel of a pair the first one's part was applied by the third stream during the first panel (below)
+                rc = rr_launch_gemm_tn_f64(c, row, ld, row, ld, Ujj + PB * (ld + 1), ld, PB, PB, PB, 1, 1);
                 if (rc != RR_OK) break;
                 if (rest > PB) {
                     c->stream = c->stream3;
@@ -742,8 +743,12 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
                     if (rc == RR_OK) {
                         RR_CHECK_HIP(hipEventRecord(s.ev[E_SOLVE + j], c->stream3));
                         RR_CHECK_HIP(hipStreamWaitEvent(c->stream3, s.ev[j], 0));
-                        if (first)        // the strip: block row j + 1 right of its diagonal block
+                        if (first) {      // the strip: block row j + 1 right of its diagonal block ...
                             rc = rr_launch_gemm_tn_f64(c, row, ld, row + PB, ld, Ujj + PB * (ld + 1) + PB, ld, PB, PB, rest - PB, 1, 0);
+                            // ... and this block row's part of block (j + 2, j + 2), which the pair's K = 256 update leaves out
+                            if (rc == RR_OK)
+                                rc = rr_launch_gemm_tn_f64(c, row + PB, ld, row + PB, ld, Ujj + 2 * PB * (ld + 1), ld, PB, PB, PB, 1, 1);
+                        }
                         else if (second)  // everything below the pair, K = 256
                             rc = rr_launch_gemm_tn_f64(c, row2, ld, row2, ld, Ujj + PB * (ld + 1), ld, 2 * PB, rest, rest, 1, 2);
                         else
