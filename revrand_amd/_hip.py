@@ -145,6 +145,16 @@ SIGNATURES = {
                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_project": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
+    "rr_glm_sgd_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
+    "rr_glm_sgd_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
+    "rr_glm_sgd_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_int64)]),
+    "rr_glm_sgd_objective": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]),
+    "rr_glm_sgd_destroy": (None, [ctypes.c_void_p]),
     "rr_posterior_available": (ctypes.c_int, []),
     "rr_set_gram_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rr_get_gram_engine": (ctypes.c_int, [ctypes.c_void_p]),
@@ -982,6 +992,61 @@ class FeatureMatrix(object):
     def gram_into(self, dy, dG, db=None, dyty=None):
         _check(self.lib, self.lib.rr_featmat_gram(self.h, _ptr(dy), rr_dtype(dy.dtype) if dy is not None else 0,
                                                   _ptr(dG), _ptr(db), _ptr(dyty)))
+
+
+UPDATER_IDS = {"SGDUpdater": 0, "AdaDelta": 1, "AdaGrad": 2, "Momentum": 3, "Adam": 4}   # RR_UPD_*
+
+
+class ResidentSgd(object):
+    """The SVI loop with its parameters in HBM (rr_glm_sgd): `step` queues one whole SGD step and returns at once."""
+
+    def __init__(self, fm, handle, K, n_lik, n_ls, z0, lower, upper, is_log, updater_id, updater_par, maxiter):
+        self.fm, self.handle, self.lib = fm, handle, fm.lib      # (both kept alive for as long as the loop)
+        z0 = np.ascontiguousarray(z0, dtype=np.float64)
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        is_log = np.ascontiguousarray(is_log, dtype=np.uint8)
+        self.np_ = 2 * fm.F * K + 1 + n_lik + n_ls
+        if not (z0.shape == lower.shape == upper.shape == is_log.shape == (self.np_,)):
+            raise ValueError("z0, lower, upper, is_log must have 2 F K + 1 + n_lik + n_ls = %d entries" % self.np_)
+        par = np.zeros(4)
+        par[:len(updater_par)] = updater_par
+        self.maxiter = int(maxiter)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_glm_sgd_create(fm.h, handle.h, K, n_lik, n_ls, z0.ctypes.data_as(ctypes.c_void_p),
+                                                    lower.ctypes.data_as(ctypes.c_void_p), upper.ctypes.data_as(ctypes.c_void_p),
+                                                    is_log.ctypes.data_as(ctypes.c_void_p), int(updater_id),
+                                                    par.ctypes.data_as(ctypes.c_void_p), self.maxiter, ctypes.byref(h)))
+        self.h = h
+
+    def step(self, dX, rows, dy, drowarg, lik, llconst, bmag, L, dE=None, seed=0, key=0):
+        _check(self.lib, self.lib.rr_glm_sgd_step(self.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, int(rows), _ptr(dy), _ptr(drowarg),
+                                                  rr_dtype(dy.dtype), int(lik), float(llconst), float(bmag), int(L),
+                                                  None if dE is None else dE.ptr, int(seed), int(key)))
+
+    def objective(self, step):
+        v = ctypes.c_double()
+        _check(self.lib, self.lib.rr_glm_sgd_objective(self.h, int(step), ctypes.byref(v)))
+        return v.value
+
+    def read(self):
+        """(z, objs, norms) after waiting for every queued step."""
+        z, objs, norms = np.empty(self.np_), np.empty(self.maxiter), np.empty(self.maxiter)
+        n = ctypes.c_int64()
+        _check(self.lib, self.lib.rr_glm_sgd_read(self.h, z.ctypes.data_as(ctypes.c_void_p), objs.ctypes.data_as(ctypes.c_void_p),
+                                                  norms.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+        return z, objs[:n.value], norms[:n.value]
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.rr_glm_sgd_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class FeatureMatrix64(object):

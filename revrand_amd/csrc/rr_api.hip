@@ -490,6 +490,61 @@ rr_scale_w_kernel(const double *__restrict__ W, const LsArgs a, int d, int n, in
     }
 }
 
+// The same rescaling with the length scales in DEVICE memory (the resident SVI loop: they are the optimiser's own
+// coordinates and never visit the host between steps).
+__global__ void __launch_bounds__(256)
+rr_scale_w_dev_kernel(const double *__restrict__ W, const double *__restrict__ ls, int n_ls, int d, int n, int npad, int dpad,
+                      float *__restrict__ w32, double *__restrict__ w64, float *__restrict__ wt32, float *__restrict__ g32,
+                      double *__restrict__ g64) {
+    const double inv2pi = 0.15915494309189533576888, twopi = 6.283185307179586476925, wmax = 4611686018427387904.0;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)d * n) return;
+    const int i = (int)(t / n), f = (int)(t % n);
+    const double l = ls[n_ls == 1 ? 0 : i];
+    const double v = W[t] * (inv2pi / l);
+    const float vf = (float)(v > wmax ? wmax : (v < -wmax ? -wmax : v));
+    w64[(size_t)i * npad + f] = v;
+    w32[(size_t)i * npad + f] = vf;
+    wt32[(size_t)f * dpad + i] = vf;
+    if (f == 0) {
+        const double gf = twopi / l;
+        g64[i] = gf;
+        g32[i] = (float)(gf > 3.0e38 ? 3.0e38 : (gf < -3.0e38 ? -3.0e38 : gf));
+    }
+}
+
+static int basis_raw_w(rr_basis *b) {  // first use: W up once, pad rows / columns of the derived copies zero for good
+    if (b->dWraw) return RR_OK;
+    rr_ctx *c = b->ctx;
+    const int d = b->d, n = b->n;
+    const size_t elems = (size_t)b->dpad * b->npad;
+    RR_CHECK_HIP(hipMalloc((void **)&b->dWraw, (size_t)d * n * sizeof(double)));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(b->dWraw, b->W.data(), (size_t)d * n * sizeof(double), hipMemcpyHostToDevice));
+    RR_CHECK_HIP(hipMemset(b->dWs32, 0, elems * sizeof(float)));
+    RR_CHECK_HIP(hipMemset(b->dWs64, 0, elems * sizeof(double)));
+    RR_CHECK_HIP(hipMemset(b->dWt32, 0, elems * sizeof(float)));
+    RR_CHECK_HIP(hipMemset(b->dgfac32, 0, (size_t)b->dpad * sizeof(float)));
+    RR_CHECK_HIP(hipMemset(b->dgfac64, 0, (size_t)b->dpad * sizeof(double)));
+    RR_CHECK_HIP(hipDeviceSynchronize());
+    return RR_OK;
+}
+
+int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls) {
+    RR_REQUIRE(b != nullptr && dls != nullptr, "lenscale: null argument");
+    RR_REQUIRE(n_ls == 1 || n_ls == b->d, "Dimension of input parameter is inconsistent! (n_ls=%d, d=%d)", n_ls, b->d);
+    RR_REQUIRE(!b->large && b->d <= 128, "device-resident length scales need Xdim <= 128");
+    rr_ctx *c = b->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    int rc = basis_raw_w(b);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_scale_w_dev_kernel, dim3((unsigned)(((int64_t)b->d * b->n + 255) / 256)), dim3(256), 0, c->stream,
+                       b->dWraw, dls, n_ls, b->d, b->n, b->npad, b->dpad, b->dWs32, b->dWs64, b->dWt32, b->dgfac32, b->dgfac64);
+    RR_CHECK_HIP(hipGetLastError());
+    b->ls_cache.clear();  // the host does not know these values: the next rr_basis_prepare rescales
+    return RR_OK;
+}
+
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     RR_REQUIRE(b != nullptr && lenscale != nullptr, "lenscale: null argument");
     RR_REQUIRE(n_ls == 1 || n_ls == b->d,
@@ -507,17 +562,9 @@ int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls) {
     if (!b->large && d <= 128 && !host_scaling) {
         rr_ctx *c = b->ctx;
         RR_CHECK_HIP(hipSetDevice(c->device));
-        if (!b->dWraw) {  // first use: W up once, pad rows / columns of the derived copies zero for good
-            const size_t elems = (size_t)b->dpad * npad;
-            RR_CHECK_HIP(hipMalloc((void **)&b->dWraw, (size_t)d * n * sizeof(double)));
-            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
-            RR_CHECK_HIP(hipMemcpy(b->dWraw, b->W.data(), (size_t)d * n * sizeof(double), hipMemcpyHostToDevice));
-            RR_CHECK_HIP(hipMemset(b->dWs32, 0, elems * sizeof(float)));
-            RR_CHECK_HIP(hipMemset(b->dWs64, 0, elems * sizeof(double)));
-            RR_CHECK_HIP(hipMemset(b->dWt32, 0, elems * sizeof(float)));
-            RR_CHECK_HIP(hipMemset(b->dgfac32, 0, (size_t)b->dpad * sizeof(float)));
-            RR_CHECK_HIP(hipMemset(b->dgfac64, 0, (size_t)b->dpad * sizeof(double)));
-            RR_CHECK_HIP(hipDeviceSynchronize());
+        {
+            const int rcw = basis_raw_w(b);
+            if (rcw != RR_OK) return rcw;
         }
         LsArgs a;
         for (int i = 0; i < 128; ++i) a.ls[i] = i < n_ls ? lenscale[i] : 1.0;

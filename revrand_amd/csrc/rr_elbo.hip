@@ -1096,7 +1096,8 @@ template <int LIK, typename TY>
 __global__ void __launch_bounds__(256)
 rr_glm_lik_kernel(float *__restrict__ FSt, int64_t M, int64_t rows256, int64_t ld, const TY *__restrict__ y,
                   const TY *__restrict__ rowarg, float par, float fscale, int KL, int L, double *__restrict__ llsum,
-                  double *__restrict__ aux, int rows_per_block) {
+                  double *__restrict__ aux, int rows_per_block, const double *__restrict__ par_dev = nullptr) {
+    if (LIK == RR_LIK_GAUSSIAN && par_dev) par = (float)par_dev[0];  // the variance is an optimiser coordinate in HBM (resident SVI loop)
     const int kl = blockIdx.x * 256 + threadIdx.x;
     const bool kvalid = kl < KL;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
@@ -1195,6 +1196,7 @@ struct GemmLikArgs {
     int KL, L;
     double *llsum, *aux;
     int spread = rr_dma_spread_env();  // rr_dma_slot
+    const double *par_dev = nullptr;   // Gaussian: the variance in device memory instead of `par` (resident SVI loop)
 };
 
 template <int LIK, bool ST>  // ST: store dfs and dfs^T (false: objective only)
@@ -1253,7 +1255,7 @@ __global__ void __launch_bounds__(GR_THREADS, 2) rr_gemm_lik_f32_kernel(const Ge
 
     const int hi = lane >> 5, l31 = lane & 31;
     constexpr int lik = LIK;
-    const float ipar = lik == RR_LIK_GAUSSIAN ? 1.f / p.par : 0.f;
+    const float ipar = lik == RR_LIK_GAUSSIAN ? 1.f / (p.par_dev ? (float)p.par_dev[0] : p.par) : 0.f;
     float red[2] = {0.f, 0.f};
     const int rl0 = wr * 128 + 4 * hi;
     const float cm[2] = {cb + wc_ * 64 + l31 < p.KL ? 1.f : 0.f, cb + wc_ * 64 + 32 + l31 < p.KL ? 1.f : 0.f};
@@ -2006,14 +2008,14 @@ static int launch_grad_contract(rr_basis *b, const TX *dX, int64_t N, int64_t ld
 
 template <typename TY>
 static void glm_launch_lik(rr_ctx *c, int lik, float *FSt, int64_t M, int64_t rows256, int64_t klp, const void *dy,
-                           const void *drow, float par, int KL, int L, double *llsum, double *aux) {
+                           const void *drow, float par, int KL, int L, double *llsum, double *aux, const double *par_dev = nullptr) {
     int64_t rpb = (rows256 * (klp / 256) + (int64_t)c->num_cu * 8 - 1) / ((int64_t)c->num_cu * 8);
     if (rpb < 16) rpb = 16;
     if ((rows256 + rpb - 1) / rpb > 65535) rpb = (rows256 + 65534) / 65535;
     const dim3 grid((unsigned)(klp / 256), (unsigned)((rows256 + rpb - 1) / rpb));
 #define RR_LK(ID)                                                                                                   \
     hipLaunchKernelGGL((rr_glm_lik_kernel<ID, TY>), grid, dim3(256), 0, c->stream, FSt, M, rows256, klp, (const TY *)dy, \
-                       (const TY *)drow, par, (float)KL, KL, L, llsum, aux, (int)rpb)
+                       (const TY *)drow, par, (float)KL, KL, L, llsum, aux, (int)rpb, par_dev)
     switch (lik) {
         case RR_LIK_BERNOULLI: RR_LK(RR_LIK_BERNOULLI); break;
         case RR_LIK_BINOMIAL: RR_LK(RR_LIK_BINOMIAL); break;
@@ -2553,7 +2555,7 @@ static int glm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int6
 
 // With WSs (kl_ld, Fp) = ws / (K L) on the device: fs, likelihood derivatives and sums, Ed = dfs Phi, EdPhi.
 static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *drowarg, int dtype, int lik,
-                        double lik_param, int K, int L, bool objective_only = false) {
+                        double lik_param, int K, int L, bool objective_only = false, const double *par_dev = nullptr) {
     rr_ctx *c = fm->ctx;
     const int KL = K * L;
     const int64_t Fp = fm->ld, kl_ld = s.klp;
@@ -2593,6 +2595,7 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         g.Dt = objective_only ? nullptr : s.DFS; g.ldt = fm->max_rows;
         g.y = dy; g.rowarg = drowarg; g.y_f64 = dtype == RR_F64; g.M = fm->rows;
         g.par = (float)lik_param; g.fscale = (float)KL; g.KL = KL; g.L = L; g.llsum = s.kacc; g.aux = s.kacc + s.kcap;
+        g.par_dev = par_dev;
 #define RR_GL(ID, ST) hipLaunchKernelGGL((rr_gemm_lik_f32_kernel<ID, ST>), dim3((unsigned)tiles1), dim3(GR_THREADS), 0, c->stream, g)
 #define RR_GLS(ID)                         \
     if (objective_only) RR_GL(ID, false);  \
@@ -2612,9 +2615,9 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         if (rc != RR_OK) return rc;
         // dfs in place + per-component reductions
         if (dtype == RR_F32)
-            glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+            glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap, par_dev);
         else
-            glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap);
+            glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap, par_dev);
         RR_CHECK_HIP(hipGetLastError());
     }
     if (objective_only) {  // the log-likelihood sums are all the objective needs: no gradient GEMMs
@@ -2888,6 +2891,396 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
     RR_CHECK_HIP(hipMemcpy2D(h.data(), (size_t)S * 4, s.FSt, (size_t)ldw * 4, (size_t)S * 4, (size_t)fm->rows, hipMemcpyDeviceToHost));
     for (size_t i = 0; i < h.size(); ++i) out[i] = (double)h[i];
     return RR_OK;
+}
+
+}  // extern "C"
+
+// =============================================================================================
+// The SVI loop of GeneralizedLinearModel.fit with its PARAMETERS RESIDENT (round 5; glm.py:141-203 and :205-294,
+// optimize/sgd.py:337-425, optimize/decorators.py:329-408).  The step above returns (Edm, EdC, sums, dT) to the host, which
+// forms the mixture-entropy terms, assembles the gradient, applies the log trick, the bounds and the updater, and sends the new
+// (m, C, length scales) back: ~1.2 ms of serial host work and two synchronisations around 3.6 ms of kernels at config 5.
+// Here the optimiser's vector z = [m (F, K) | C (F, K) | reg | likelihood parameter (Gaussian: variance) | length scales]
+// (the flat vector of structured_sgd, Positive coordinates in log space) lives in HBM together with the updater's state:
+//   rr_glm_sgd_from_log_kernel   x = from_log(z)                                           decorators.py:377-381
+//   rr_scale_w_dev_kernel, feature kernel, the step's kernels (glm_pipeline) with m, C, lengths read from x
+//   rr_glm_sgd_sums_kernel       the K(K+1)/2 mixture cross terms of _qmatrix, sum(m^2 + C), W[i,:].T[i,:]   glm.py:697-712,265
+//   rr_glm_sgd_update_kernel     log N_kl, log z_k, alpha; dm, dC, dreg, dlik, dl (glm.py:238-283); the chain rule of the log
+//                                trick; |grad|^2 partials; bound truncation, updater, clip (sgd.py:404-420)
+//   rr_glm_sgd_finish_kernel     the gradient norm and -ELBO of the step (glm.py:285-292) into per-step arrays
+// Nothing is read back and the host never waits for a step: it queues step t while t - 1 runs (at most two in flight: the
+// caller's minibatch buffers are reused in turn).  Float64 throughout, multiply-add contraction off: the arithmetic of the
+// NumPy expressions it stands for, reduction order aside.
+// =============================================================================================
+#define RR_SGD_MAXK 32
+
+struct rr_glm_sgd {
+    rr_featmat *fm = nullptr;
+    rr_basis *b = nullptr;
+    int K = 0, F = 0, n_ls = 0, n_lik = 0, updater = 0;
+    int64_t fk = 0, np = 0, maxiter = 0, t = 0;
+    double up[4] = {0, 0, 0, 0};
+    double *z = nullptr, *x = nullptr, *s1 = nullptr, *s2 = nullptr, *lower = nullptr, *upper = nullptr;
+    unsigned char *islog = nullptr;
+    double *red = nullptr;    // [Q (K, K) | R | H (d)]
+    double *npart = nullptr;  // |grad|^2 per block of the update kernel
+    double *objs = nullptr, *norms = nullptr;
+    double *dT = nullptr;     // (d, n): X^T (E_s o P_c - E_c o P_s) of the step
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+
+__global__ void __launch_bounds__(256)
+rr_glm_sgd_from_log_kernel(const double *__restrict__ z, const unsigned char *__restrict__ islog, int64_t np, double *__restrict__ x) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p < np) x[p] = islog[p] ? exp(z[p]) : z[p];
+}
+
+__device__ __forceinline__ double rr_block_sum256(double v, double *sh) {  // fixed tree: the same bits every launch
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if (tid < w) sh[tid] += sh[tid + w];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, const double *__restrict__ T, const double *__restrict__ W,
+                       int n, int nh, double *__restrict__ red) {
+#pragma clang fp contract(off)
+    __shared__ double sh[256];
+    const int npairs = K * (K + 1) / 2, tid = threadIdx.x;
+    const int64_t fk = (int64_t)F * K;
+    int bid = blockIdx.x;
+    double acc = 0.0;
+    if (bid < npairs) {  // sum_f log(C_fk + C_fl) + (m_fk - m_fl)^2 / (C_fk + C_fl)
+        int k = 0;
+        while (bid >= K - k) {
+            bid -= K - k;
+            ++k;
+        }
+        const int l = k + bid;
+        for (int f = tid; f < F; f += 256) {
+            const double dc = x[fk + (int64_t)f * K + k] + x[fk + (int64_t)f * K + l];
+            const double dm = x[(int64_t)f * K + k] - x[(int64_t)f * K + l];
+            acc += log(dc) + dm * dm / dc;
+        }
+        const double q = rr_block_sum256(acc, sh);
+        if (tid == 0) red[k * K + l] = red[l * K + k] = q;
+    } else if (bid == npairs) {  // sum (m^2 + C)
+        for (int64_t p = tid; p < fk; p += 256) acc += x[p] * x[p] + x[fk + p];
+        const double r = rr_block_sum256(acc, sh);
+        if (tid == 0) red[K * K] = r;
+    } else {  // W[i, :] . T[i, :]
+        const int i = bid - npairs - 1;
+        if (i < nh) {
+            for (int f = tid; f < n; f += 256) acc += T[(int64_t)i * n + f] * W[(int64_t)i * n + f];
+            const double h = rr_block_sum256(acc, sh);
+            if (tid == 0) red[K * K + 1 + i] = h;
+        }
+    }
+}
+
+struct SgdUpdArgs {
+    const double *x, *red, *Edm, *EdC, *aux, *lower, *upper;
+    const unsigned char *islog;
+    double *z, *s1, *s2, *npart;
+    int F, K, n_lik, n_ls, updater, L;
+    int64_t np;
+    double bmag, nrows, up[4], b1t, b2t;
+};
+
+__global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs a) {
+#pragma clang fp contract(off)
+    __shared__ double logN[RR_SGD_MAXK * RR_SGD_MAXK], alpha[RR_SGD_MAXK * RR_SGD_MAXK], logz[RR_SGD_MAXK], sh[256];
+    const int tid = threadIdx.x, K = a.K, F = a.F;
+    const int64_t fk = (int64_t)F * K;
+    for (int i = tid; i < K * K; i += 256) logN[i] = -0.5 * ((double)F * 1.8378770664093453 + a.red[i]);  // log(2 pi)
+    __syncthreads();
+    if (tid < K) {  // logsumexp over the first index (glm.py:222)
+        double mx = -INFINITY;
+        for (int j = 0; j < K; ++j) mx = fmax(mx, logN[j * K + tid]);
+        double sm = 0.0;
+        for (int j = 0; j < K; ++j) sm += exp(logN[j * K + tid] - mx);
+        logz[tid] = log(sm) + mx;
+    }
+    __syncthreads();
+    for (int i = tid; i < K * K; i += 256) {
+        const int k = i / K, l = i % K;
+        alpha[i] = exp(logN[l * K + k] - logz[k]) + exp(logN[l * K + k] - logz[l]);
+    }
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+    double g = 0.0;
+    const bool live = p < a.np;
+    if (live) {
+        const double reg = a.x[2 * fk], iL = 1.0 / reg;
+        if (p < 2 * fk) {
+            const bool cov = p >= fk;
+            const int64_t q = cov ? p - fk : p;
+            const int f = (int)(q / K), k = (int)(q % K);
+            const double mk = a.x[q], Ck = a.x[fk + q];
+            double mix = 0.0;
+            for (int l = 0; l < K; ++l) {
+                const double ic = 1.0 / (Ck + a.x[fk + (int64_t)f * K + l]);
+                const double dm = mk - a.x[(int64_t)f * K + l];
+                const double e = dm * ic;
+                mix += (cov ? ic - e * e : ic * dm) * alpha[k * K + l];
+            }
+            if (!cov) g = -((a.bmag * a.Edm[(int64_t)k * F + f] - mk / reg + mix) / K);
+            else g = -((a.bmag * a.EdC[(int64_t)k * F + f] - 1.0 / reg + mix) / (2 * K));
+        } else if (p == 2 * fk) {
+            g = -(0.5 * (a.red[K * K] * (iL * iL) / K - (double)F * iL));
+        } else if (p < 2 * fk + 1 + a.n_lik) {  // Gaussian variance: dp = ((y - f)^2 / var^2 - 1 / var) / 2  (likelihoods.py:360-381)
+            const double ivar = 1.0 / a.x[p];
+            double sm = 0.0;
+            for (int k = 0; k < K; ++k) sm += 0.5 * (a.aux[k] * ivar * ivar - ivar * a.nrows * a.L) / a.L;
+            g = 0.0 - sm / K;
+        } else {  // -(EdPhi o dPhi_i).sum() = W[i,:].T[i,:] / l_i^2; isotropic: input dimension 0 only, as the reference
+            const int i = (int)(p - (2 * fk + 1 + a.n_lik));
+            const double l = a.x[p];
+            g = a.red[K * K + 1 + i] / (1.0 * (l * l));
+        }
+        if (a.islog[p]) g *= a.x[p];  // d/dz through x = exp(z)
+    }
+    const double n2 = rr_block_sum256(live ? g * g : 0.0, sh);
+    if (tid == 0) a.npart[blockIdx.x] = n2;
+    if (!live) return;
+    const double zz = a.z[p], lo = a.lower[p], hi = a.upper[p];
+    if (zz <= lo) g = (g <= 0.0 || g != g) ? g : 0.0;  // np.minimum(grad, 0) on a coordinate sitting on its lower bound
+    if (zz >= hi) g = (g >= 0.0 || g != g) ? g : 0.0;
+    double zn;
+    switch (a.updater) {
+        case RR_UPD_SGD: zn = zz - a.up[0] * g; break;
+        case RR_UPD_ADADELTA: {  // up = (rho, epsilon); s1 = E[g^2], s2 = E[dx^2]
+            const double eg2 = a.up[0] * a.s1[p] + (1 - a.up[0]) * (g * g);
+            const double dx = -g * sqrt(a.s2[p] + a.up[1]) / sqrt(eg2 + a.up[1]);
+            a.s1[p] = eg2;
+            a.s2[p] = a.up[0] * a.s2[p] + (1 - a.up[0]) * (dx * dx);
+            zn = zz + dx;
+        } break;
+        case RR_UPD_ADAGRAD: {  // up = (eta, epsilon); s1 = sum g^2
+            const double h = a.s1[p] + g * g;
+            a.s1[p] = h;
+            zn = zz - a.up[0] * g / (a.up[1] + sqrt(h));
+        } break;
+        case RR_UPD_MOMENTUM: {  // up = (rho, eta); s1 = dx
+            const double dx = a.up[0] * a.s1[p] - a.up[1] * g;
+            a.s1[p] = dx;
+            zn = zz + dx;
+        } break;
+        default: {  // Adam: up = (alpha, beta1, beta2, epsilon); b1t = 1 - beta1^t, b2t = 1 - beta2^t
+            const double m = a.up[1] * a.s1[p] + (1 - a.up[1]) * g;
+            const double v = a.up[2] * a.s2[p] + (1 - a.up[2]) * (g * g);
+            a.s1[p] = m;
+            a.s2[p] = v;
+            zn = zz - a.up[0] * (m / a.b1t) / (sqrt(v / a.b2t) + a.up[3]);
+        }
+    }
+    a.z[p] = zn < lo ? lo : (zn > hi ? hi : zn);
+}
+
+__global__ void __launch_bounds__(256)
+rr_glm_sgd_finish_kernel(const double *__restrict__ x, const double *__restrict__ red, const double *__restrict__ llsum,
+                         const double *__restrict__ npart, int nblocks, int F, int K, int L, int n_lik, double llconst, double nrows,
+                         double bmag, double *__restrict__ obj, double *__restrict__ norm) {
+#pragma clang fp contract(off)
+    __shared__ double sh[256];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int i = tid; i < nblocks; i += 256) acc += npart[i];
+    const double n2 = rr_block_sum256(acc, sh);
+    double lz = 0.0;
+    if (tid < K) {
+        double mx = -INFINITY;
+        for (int j = 0; j < K; ++j) mx = fmax(mx, -0.5 * ((double)F * 1.8378770664093453 + red[j * K + tid]));
+        double sm = 0.0;
+        for (int j = 0; j < K; ++j) sm += exp(-0.5 * ((double)F * 1.8378770664093453 + red[j * K + tid]) - mx);
+        lz = log(sm) + mx;
+    }
+    const double logzsum = rr_block_sum256(lz, sh);
+    if (tid == 0) {
+        const int64_t fk = (int64_t)F * K;
+        const double reg = x[2 * fk];
+        if (n_lik) llconst = -0.5 * log(2.0 * 3.141592653589793 * x[2 * fk + 1]) * nrows;  // Gaussian (likelihoods.py:295-317)
+        double ell = 0.0;
+        for (int k = 0; k < K; ++k) ell += llsum[k] / L + llconst;
+        const double elbo = (ell * bmag - 0.5 * F * K * 1.8378770664093453 - 0.5 * K * ((double)F * log(reg)) - 0.5 * (red[K * K] / reg) -
+                             logzsum + log((double)K)) / K;
+        *obj = -elbo;
+        *norm = sqrt(n2);
+    }
+}
+
+static void sgd_free(rr_glm_sgd *o) {
+    void *q[] = {o->z, o->x, o->s1, o->s2, o->lower, o->upper, o->islog, o->red, o->npart, o->objs, o->norms, o->dT};
+    for (void *v : q)
+        if (v) (void)hipFree(v);
+    for (hipEvent_t e : o->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete o;
+}
+
+extern "C" {
+
+int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, const double *z0, const double *lower,
+                      const double *upper, const unsigned char *is_log, int updater, const double *upd_par, int64_t maxiter,
+                      rr_glm_sgd **out) {
+    RR_REQUIRE(fm != nullptr && b != nullptr && out != nullptr && z0 != nullptr && lower != nullptr && upper != nullptr &&
+               is_log != nullptr && upd_par != nullptr, "rr_glm_sgd_create: null argument");
+    *out = nullptr;
+    RR_REQUIRE(b->kind == RR_KIND_RFF && !b->large && b->d <= 128 && 2 * (int64_t)b->n == fm->F && b->ctx == fm->ctx,
+               "rr_glm_sgd_create: the feature matrix must be one random Fourier basis of Xdim <= 128 on the same context");
+    RR_REQUIRE(K >= 1 && K <= RR_SGD_MAXK, "rr_glm_sgd_create: 1 <= K <= %d", RR_SGD_MAXK);
+    RR_REQUIRE(n_lik == 0 || n_lik == 1, "rr_glm_sgd_create: at most one likelihood parameter");
+    RR_REQUIRE(n_ls == 1 || n_ls == b->d, "rr_glm_sgd_create: %d length scales for Xdim = %d", n_ls, b->d);
+    RR_REQUIRE(updater >= RR_UPD_SGD && updater <= RR_UPD_ADAM, "rr_glm_sgd_create: unknown updater %d", updater);
+    RR_REQUIRE(maxiter >= 1 && maxiter < ((int64_t)1 << 31), "rr_glm_sgd_create: bad maxiter");
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    rr_glm_sgd *o = new rr_glm_sgd();
+    o->fm = fm; o->b = b; o->K = K; o->F = fm->F; o->n_ls = n_ls; o->n_lik = n_lik; o->updater = updater;
+    o->fk = (int64_t)fm->F * K;
+    o->np = 2 * o->fk + 1 + n_lik + n_ls;
+    o->maxiter = maxiter;
+    for (int i = 0; i < 4; ++i) o->up[i] = upd_par[i];
+    const size_t nb = (size_t)o->np * 8, nblocks = (size_t)((o->np + 255) / 256);
+    hipError_t e = hipMalloc((void **)&o->z, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->x, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->s1, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->s2, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->lower, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->upper, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->islog, (size_t)o->np);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->red, (size_t)(K * K + 1 + b->d) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->npart, nblocks * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->objs, (size_t)maxiter * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->norms, (size_t)maxiter * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->dT, (size_t)b->d * b->n * 8);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[0], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[1], hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        sgd_free(o);
+        rr_set_error("rr_glm_sgd_create: device allocation failed");
+        return RR_ERR_OOM;
+    }
+    hipError_t h = hipStreamSynchronize(c->stream);
+    if (h == hipSuccess) h = hipMemcpy(o->z, z0, nb, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemcpy(o->lower, lower, nb, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemcpy(o->upper, upper, nb, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemcpy(o->islog, is_log, (size_t)o->np, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemset(o->s1, 0, nb);
+    if (h == hipSuccess) h = hipMemset(o->s2, 0, nb);
+    if (h == hipSuccess) h = hipMemset(o->objs, 0, (size_t)maxiter * 8);
+    if (h == hipSuccess) h = hipMemset(o->norms, 0, (size_t)maxiter * 8);
+    if (h == hipSuccess) h = hipDeviceSynchronize();
+    if (h != hipSuccess) {
+        (void)hipGetLastError();
+        sgd_free(o);
+        rr_set_error("rr_glm_sgd_create: %s", hipGetErrorString(h));
+        return RR_ERR_HIP;
+    }
+    *out = o;
+    return RR_OK;
+}
+
+int rr_glm_sgd_step(rr_glm_sgd *o, const void *dX, int x_dtype, int64_t ldx, int64_t rows, const void *dy, const void *drowarg,
+                    int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed, uint64_t key) {
+    RR_REQUIRE(o != nullptr && dX != nullptr && dy != nullptr, "rr_glm_sgd_step: null argument");
+    RR_REQUIRE(o->t < o->maxiter, "rr_glm_sgd_step: all %lld steps of this loop are done", (long long)o->maxiter);
+    RR_REQUIRE((lik == RR_LIK_GAUSSIAN) == (o->n_lik == 1), "rr_glm_sgd_step: likelihood %d with %d likelihood parameter(s)", lik, o->n_lik);
+    RR_REQUIRE(rows >= 1 && rows <= o->fm->max_rows, "rr_glm_sgd_step: rows out of range");
+    rr_featmat *fm = o->fm;
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int K = o->K, F = o->F;
+    const int64_t fk = o->fk;
+    // at most two steps in flight: the event of step t - 2
+    if (o->t >= 2) RR_CHECK_HIP(hipEventSynchronize(o->ev[o->t & 1]));
+    const unsigned nblocks = (unsigned)((o->np + 255) / 256);
+    hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nblocks), dim3(256), 0, c->stream, o->z, o->islog, o->np, o->x);
+    RR_CHECK_HIP(hipGetLastError());
+    const double *xls = o->x + 2 * fk + 1 + o->n_lik, *xpar = o->n_lik ? o->x + 2 * fk + 1 : nullptr;
+    int rc = rr_featmat_begin(fm, rows);
+    if (rc != RR_OK) return rc;
+    rc = rr_fm_put_rff_dev(fm, o->b, dX, x_dtype, ldx, xls, o->n_ls, 0);
+    if (rc != RR_OK) return rc;
+    rc = glm_step_checks(fm, dy, drowarg, dtype, lik, 1.0, K, L, "rr_glm_sgd_step");
+    if (rc != RR_OK) return rc;
+    const int KL = K * L;
+    const int64_t klp = ((int64_t)KL + 255) / 256 * 256, Fp = fm->ld;
+    rc = fm_glm_scratch(fm, klp, K);
+    if (rc != RR_OK) return rc;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    const int64_t kl_ld = s.klp;
+    RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->b->d * o->b->n * 8, c->stream));
+    rc = rr_featmat_glm_plan_rff(fm, o->b, dX, x_dtype, ldx, 0, o->dT);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, c->stream, o->x, o->x + fk, F, K,
+                       L, Fp, kl_ld, seed, key, dE, s.Ee, s.WSs);
+    RR_CHECK_HIP(hipGetLastError());
+    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar);
+    if (rc != RR_OK) return rc;
+    double *Edm = s.mc + 2 * fk, *EdC = s.mc + 3 * fk;
+    hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, c->stream, s.Ed, s.Ee, o->x + fk, F, K,
+                       L, Fp, Edm, EdC);
+    RR_CHECK_HIP(hipGetLastError());
+    rc = rr_featmat_glm_rff(fm, o->b, dX, x_dtype, ldx, 0, o->dT);  // (returns at once when the step contracted EdPhi itself)
+    if (rc != RR_OK) return rc;
+    const int nh = o->n_ls == 1 ? 1 : o->b->d;
+    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)(K * (K + 1) / 2 + 1 + nh)), dim3(256), 0, c->stream, o->x, F, K, o->dT,
+                       o->b->dWraw, o->b->n, nh, o->red);
+    RR_CHECK_HIP(hipGetLastError());
+    SgdUpdArgs a;
+    a.x = o->x; a.red = o->red; a.Edm = Edm; a.EdC = EdC; a.aux = s.kacc + s.kcap; a.lower = o->lower; a.upper = o->upper;
+    a.islog = o->islog; a.z = o->z; a.s1 = o->s1; a.s2 = o->s2; a.npart = o->npart;
+    a.F = F; a.K = K; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = L; a.np = o->np;
+    a.bmag = bmag; a.nrows = (double)rows;
+    for (int i = 0; i < 4; ++i) a.up[i] = o->up[i];
+    const double tt = (double)(o->t + 1);
+    a.b1t = 1.0 - pow(o->up[1], tt);
+    a.b2t = 1.0 - pow(o->up[2], tt);
+    hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nblocks), dim3(256), 0, c->stream, a);
+    RR_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rr_glm_sgd_finish_kernel, dim3(1), dim3(256), 0, c->stream, o->x, o->red, s.kacc, o->npart, (int)nblocks, F, K, L,
+                       o->n_lik, llconst, (double)rows, bmag, o->objs + o->t, o->norms + o->t);
+    RR_CHECK_HIP(hipGetLastError());
+    RR_CHECK_HIP(hipEventRecord(o->ev[o->t & 1], c->stream));
+    o->t += 1;
+    return RR_OK;
+}
+
+int rr_glm_sgd_read(rr_glm_sgd *o, double *z, double *objs, double *norms, int64_t *steps) {
+    RR_REQUIRE(o != nullptr, "rr_glm_sgd_read: null argument");
+    rr_ctx *c = o->fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (z) RR_CHECK_HIP(hipMemcpy(z, o->z, (size_t)o->np * 8, hipMemcpyDeviceToHost));
+    if (objs && o->t) RR_CHECK_HIP(hipMemcpy(objs, o->objs, (size_t)o->t * 8, hipMemcpyDeviceToHost));
+    if (norms && o->t) RR_CHECK_HIP(hipMemcpy(norms, o->norms, (size_t)o->t * 8, hipMemcpyDeviceToHost));
+    if (steps) *steps = o->t;
+    return RR_OK;
+}
+
+int rr_glm_sgd_objective(rr_glm_sgd *o, int64_t step, double *obj) {
+    RR_REQUIRE(o != nullptr && obj != nullptr && step >= 0 && step < o->t, "rr_glm_sgd_objective: no such step");
+    rr_ctx *c = o->fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    RR_CHECK_HIP(hipMemcpy(obj, o->objs + step, 8, hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+void rr_glm_sgd_destroy(rr_glm_sgd *o) {
+    if (!o) return;
+    (void)hipSetDevice(o->fm->ctx->device);
+    (void)hipStreamSynchronize(o->fm->ctx->stream);
+    sgd_free(o);
 }
 
 }  // extern "C"

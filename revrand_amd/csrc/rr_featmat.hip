@@ -203,15 +203,14 @@ int rr_fm_claim(rr_featmat *fm, int64_t col0, int64_t width, const char *who) {
     return RR_OK;
 }
 
-extern "C" {
-
-int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale,
-                       int n_ls, int64_t col0) {
+// lenscale: host values, or (ls_on_device) the same in device memory -- rr_basis_prepare_dev, the resident SVI loop
+static int fm_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale, int n_ls,
+                      int64_t col0, bool ls_on_device) {
     RR_REQUIRE(fm != nullptr && b != nullptr && b->kind == RR_KIND_RFF, "rr_featmat_put_rff: bad argument");
     RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_put_rff: bad dtype");
     RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_put_rff: columns out of range");
     RR_REQUIRE(ldx >= b->dpad, "rr_featmat_put_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
-    int rc = rr_basis_prepare(b, lenscale, n_ls);
+    int rc = ls_on_device ? rr_basis_prepare_dev(b, lenscale, n_ls) : rr_basis_prepare(b, lenscale, n_ls);
     if (rc != RR_OK || fm->rows == 0) return rc;
     RR_REQUIRE(dX != nullptr, "rr_featmat_put_rff: null X");
     RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
@@ -226,6 +225,18 @@ int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype,
                                   Pt ? Pt + col0 * fm->max_rows : nullptr, fm->max_rows, &wrote);
     if (wrote) fm->pt_covered += 2 * (int64_t)b->n;
     return rc;
+}
+
+int rr_fm_put_rff_dev(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *dls, int n_ls,
+                      int64_t col0) {
+    return fm_put_rff(fm, b, dX, x_dtype, ldx, dls, n_ls, col0, true);
+}
+
+extern "C" {
+
+int rr_featmat_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale,
+                       int n_ls, int64_t col0) {
+    return fm_put_rff(fm, b, dX, x_dtype, ldx, lenscale, n_ls, col0, false);
 }
 
 int rr_featmat_put_linear(rr_featmat *fm, const void *dX, int x_dtype, int64_t ldx, int d, int onescol, int64_t col0) {

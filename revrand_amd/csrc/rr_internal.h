@@ -186,6 +186,7 @@ int rr_guard_check(const char *where);  // RR_OK, or RR_ERR_HIP with the message
 
 // Upload W scaled by the given lenscale (cached); implemented in rr_api.hip.
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
+int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls);  // length scales in device memory (d <= 128)
 int rr_pick_dmax(int d);
 void rr_pass2_scratch_free(void *p);
 void rr_pass2d_scratch_free(void *p);
@@ -208,6 +209,9 @@ struct rr_featmat {
     std::vector<std::pair<int64_t, int64_t>> spans;
 };
 int rr_fm_claim(rr_featmat *fm, int64_t col0, int64_t width, const char *who);  // rr_featmat.hip
+// rr_featmat_put_rff with the length scales in device memory (rr_featmat.hip; the resident SVI loop of rr_elbo.hip)
+int rr_fm_put_rff_dev(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *dls, int n_ls,
+                      int64_t col0);
 void rr_fm_pass2_free(void *p);
 float *rr_fm_pass2_pt(void *p);  // FmPass2::Pt or null
 // Consumers of the feature matrix call this first: every column of [0, F) must have been put since rr_featmat_begin.

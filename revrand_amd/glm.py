@@ -30,7 +30,7 @@ from sklearn.utils.validation import check_array, check_is_fitted, check_X_y
 from . import _hip
 from .basis_functions import LinearBasis, MinibatchFeatures
 from .btypes import Bound, Parameter, Positive
-from .likelihoods import Gaussian
+from .likelihoods import Bernoulli, Binomial, Gaussian, Poisson
 from .optimize import logtrick_sgd, sgd, structured_sgd
 from .utils import atleast_list, issequence
 
@@ -148,6 +148,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                   self.basis.regularizer,
                   self.likelihood.params,
                   self.basis.params]
+        loop = self._resident_loop(params)
+        if loop is not None:  # (decided before the upload contexts' buffer rings are sized)
+            self.__dict__["_draw_buffers"] = 6
+            self._features().PREFETCH_SLOTS = 6
         log.info("Optimising parameters...")
         self.__it = -self.nstarts
         nsgd = structured_sgd(logtrick_sgd(sgd))
@@ -173,7 +177,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
             # (one upload context per process and device, shared by every fit: a context is a stream and two events, and a
             # cross-validation loop must not accumulate them)
-            self.__dict__["_draw_upload"] = (_hip.get_upload_device(_hip.get_device().index), [None, None, None], [0])
+            self.__dict__["_draw_upload"] = (_hip.get_upload_device(_hip.get_device().index), [None] * self._draw_buffers, [0])
         # (RR_GLM_BATCH_PREFETCH=0: measurement switch, the step uploads its indices / targets and gathers its rows itself)
         if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
                 and self._group() is None:  # (a device group's members gather for themselves, on their own threads)
@@ -181,7 +185,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
-                       prefetch=prefetch, sync=sync)
+                       prefetch=prefetch, sync=sync, **({} if loop is None else {"device_loop": loop}))
         finally:
             # (sgd has stopped and joined its prefetch worker by now, also when `_elbo` raised; what the worker queued on the
             # upload context's stream must have landed before the buffers it wrote to are freed)
@@ -193,6 +197,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 except Exception:  # the original exception, if any, is the one to report
                     log.exception("synchronising the upload context failed")
             self._resident_fit = False
+            self.__dict__.pop("_draw_buffers", None)
             self._release_features()
             if up is not None:
                 for buf in up[1]:
@@ -204,6 +209,33 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         return self
 
     _prefetch_draws = True  # False: `_elbo` draws for itself, strictly sequentially (what the tests compare against)
+    _draw_buffers = 3
+    _resident_sgd = True    # False (or RR_GLM_RESIDENT_SGD=0): always the host loop around `_elbo` (tests, A/B runs)
+
+    def _resident_loop(self, params):
+        """The SGD loop with parameters, updater state and gradient in device memory (`_ResidentLoop`, rr_glm_sgd) when this
+        fit is one it covers: minibatches gathered on the device, ONE random Fourier basis (Xdim <= 128) with a scalar
+        regulariser, one of the reference's likelihoods and updaters, K <= 32, one process and one GPU.  None otherwise --
+        the host loop around `_elbo` then runs, with the same results."""
+        from . import optimize as opt
+        from .basis_functions import _ResidentRFF
+        if not self._resident_sgd or os.environ.get("RR_GLM_RESIDENT_SGD", "1") == "0":
+            return None
+        feats = self._features()
+        if not getattr(self, "_resident_fit", False) or self.distributed or self._group() is not None \
+                or type(feats) is not MinibatchFeatures or self.sampler not in ("host", "device"):
+            return None
+        kids = getattr(feats, "_kids", [])
+        if len(kids) != 1 or type(kids[0]) is not _ResidentRFF or self.basis.d > 128 or not 1 <= self.K <= 32:
+            return None
+        if self.updater is not None and type(self.updater) not in (opt.SGDUpdater, opt.AdaDelta, opt.AdaGrad, opt.Momentum, opt.Adam):
+            return None
+        if type(self.likelihood) not in (Bernoulli, Binomial, Gaussian, Poisson):
+            return None
+        n_reg, n_lik, n_ls = (int(np.prod(p.shape, dtype=int)) if not isinstance(p, list) else -1 for p in params[2:5])
+        if n_reg != 1 or n_lik != (1 if type(self.likelihood) is Gaussian else 0) or n_ls not in (1, self.basis.d):
+            return None
+        return _ResidentLoop(self, feats, n_lik, n_ls)
 
     def _reference_draws(self):
         """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component."""
@@ -246,17 +278,18 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         """On the minibatch worker thread: the step's draws, and their upload -- through a device context (stream) of this
         thread's own, into one of THREE buffers in turn: the worker runs up to two steps ahead (one finished batch waits in
         the queue while the next is being made) -- while earlier steps' kernels run; the step then starts from
-        device-resident draws (rr_featmat_glm_step_draws_dev)."""
+        device-resident draws (rr_featmat_glm_step_draws_dev).  (SIX buffers under the resident loop, whose host queues
+        steps up to two ahead of the device on top of that: `_draw_buffers`.)"""
         e = self._reference_draws()
         up = self.__dict__.get("_draw_upload")
         if up is None:
             return list(batch) + [_Draws(e)]
         dev, bufs, turn = up
-        buf = bufs[turn[0] % 3]
+        buf = bufs[turn[0] % len(bufs)]
         if buf is None or buf.nbytes < e.nbytes:
             if buf is not None:
                 buf.free()
-            buf = bufs[turn[0] % 3] = dev.malloc(e.nbytes)
+            buf = bufs[turn[0] % len(bufs)] = dev.malloc(e.nbytes)
         _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, buf.ptr, e.ctypes.data_as(_hip.ctypes.c_void_p), e.nbytes))
         buf.shape, buf.dtype = e.shape, e.dtype
         turn[0] += 1
@@ -283,6 +316,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     def __getstate__(self):
         state = dict(super().__getstate__())  # sklearn's (adds its version tag)
         state.pop("_mbf", None)
+        state.pop("_draw_buffers", None)
         state.pop("_serve_feats", None)
         state.pop("_draw_upload", None)
         state.pop("_batch_upload", None)
@@ -532,6 +566,107 @@ def _submit(fn, *args):
         from concurrent.futures import ThreadPoolExecutor
         _pool = (os.getpid(), ThreadPoolExecutor(max_workers=1, thread_name_prefix="revrand-glm"))
     return _pool[1].submit(fn, *args)
+
+
+class _ResidentLoop(object):
+    """`optimize.sgd`'s loop (sgd.py:337-425) for GeneralizedLinearModel.fit with everything resident: the flat vector
+    [m | C | reg | likelihood parameter | length scales] of structured_sgd (log space on the Positive coordinates, set by
+    logtrick_sgd as `log_coordinates`), the updater's state and the gradient live in HBM; a step is ONE library call that
+    queues from_log, the features, the SVI step, the mixture terms, the gradient, the chain rule, the bounds and the update
+    (rr_glm_sgd_step) and returns without waiting -- the host's part of a step is taking the next minibatch (made on the
+    worker thread: indices, gathered rows, targets and draws already on the device) off the queue.  `_elbo` is not called;
+    what it would have logged every LOGITER iterations is logged from the device's objective."""
+
+    log_coordinates = None
+
+    def __init__(self, glm, feats, n_lik, n_ls):
+        self.glm, self.feats, self.n_lik, self.n_ls = glm, feats, n_lik, n_ls
+        self.sgd = None
+
+    def begin(self, z0, lower, upper, updater, maxiter):
+        from . import optimize as opt
+        g, feats = self.glm, self.feats
+        updater = opt.Adam() if updater is None else updater
+        kind = type(updater).__name__
+        par = {"SGDUpdater": lambda u: [u.eta], "AdaDelta": lambda u: [u.rho, u.epsilon], "AdaGrad": lambda u: [u.eta, u.epsilon],
+               "Momentum": lambda u: [u.rho, u.eta], "Adam": lambda u: [u.alpha, u.beta1, u.beta2, u.epsilon]}[kind](updater)
+        if not np.isfinite(maxiter):
+            raise ValueError("the resident loop needs a finite maxiter")
+        pos = self.log_coordinates if self.log_coordinates is not None else np.zeros(len(z0), dtype=bool)
+        self.pos = np.asarray(pos, dtype=bool)
+        self.t = 0
+        self._make = lambda M: _hip.ResidentSgd(feats.fm, feats._kids[0].h, g.K, self.n_lik, self.n_ls, z0, lower, upper, self.pos,
+                                                _hip.UPDATER_IDS[kind], par, max(1, int(maxiter)))
+        self._z0 = np.array(z0, dtype=float)
+
+    def _start(self, M):
+        """with the first minibatch: the feature matrix of M rows and the device loop on it"""
+        self.feats._ensure(M, int(self.glm.D_))
+        self.sgd = self._make(M)
+
+    def _values(self):
+        """(reg, likelihood parameters, basis parameters) as the host loop's log line prints them"""
+        z = self.sgd.read()[0]
+        x = np.where(self.pos, np.exp(np.where(self.pos, z, 0.0)), z)
+        o = 2 * self.glm.D_ * self.glm.K
+        ls = x[o + 1 + self.n_lik:]
+        return x[o], ([x[o + 1]] if self.n_lik else []), (ls[0] if self.n_ls == 1 else ls)
+
+    def step(self, batch):
+        g, feats = self.glm, self.feats
+        y, largs = batch[1], list(batch[2:])
+        draws = spec = gathered = None
+        while largs and isinstance(largs[-1], (_Draws, _Spec, _Batch)):      # made ahead on the worker (`_ahead`)
+            last = largs.pop()
+            if isinstance(last, _Draws):
+                draws = last.e
+            elif isinstance(last, _Batch):
+                gathered = last.token
+            else:
+                spec = last.spec
+        idx = largs.pop()
+        if self.n_lik:   # Gaussian: the variance is a coordinate of z, its constant is formed on the device
+            from .likelihoods import RR_LIK_GAUSSIAN
+            lid, rowarg, llconst = RR_LIK_GAUSSIAN, None, 0.0
+        else:
+            lid, _, rowarg, llconst = spec if spec is not None else g.likelihood.device_spec(y, [], largs)
+        it = g._GeneralizedLinearModel__it
+        dolog = (it % LOGITER == 0) or (it == g.maxiter - 1)
+        if self.sgd is None:
+            self._start(len(idx))
+        shown = self._values() if dolog else None   # (waits for the queue: twice per LOGITER steps)
+        if gathered is not None and gathered.key == (id(y), len(y), rowarg is None):  # uploaded by the worker with the rows
+            dy, dn = gathered.dy, gathered.dn
+        else:
+            dy, dn = feats._stage("y", y, np.float32), None if rowarg is None else feats._stage("rowarg", rowarg, np.float32)
+        dX = feats.batch_rows(idx, gathered)
+        dE, seed, key = None, 0, 0
+        if g.sampler == "device":
+            seed, key = g._dev_seed, g._dev_step
+            g._dev_step += 1
+        else:
+            if draws is None:
+                draws = g._reference_draws()
+            dE = draws if isinstance(draws, _hip.DeviceBuffer) else feats._stage("E", draws, np.float32)
+        self.sgd.step(dX, len(idx), dy, dn, lid, llconst, g.B_, g.nsamples, dE, seed, key)
+        if dolog:
+            log.info("Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
+                     .format(it, -self.sgd.objective(self.t), shown[0], shown[1], shown[2]))
+        self.t += 1
+        g._GeneralizedLinearModel__it = it + 1
+
+    def end(self):
+        if self.sgd is None:   # no step was taken (maxiter = 0)
+            return self._z0, np.empty(0), np.empty(0)
+        z, objs, norms = self.sgd.read()
+        self.abort()
+        return z, objs, norms
+
+    def abort(self):
+        sgd, self.sgd = self.sgd, None
+        if sgd is not None:
+            sgd.close()
+        self.feats.__dict__.pop("PREFETCH_SLOTS", None)
 
 
 class _Batch(object):

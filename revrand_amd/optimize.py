@@ -342,12 +342,15 @@ def _prefetched(batches, augment=None):
 
 
 def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, updater=None, eval_obj=False,
-        random_state=None, prefetch=False):
+        random_state=None, prefetch=False, device_loop=None):
     """Stochastic gradient descent over minibatches of `data` (sgd.py:337-425): ``fun(x, *batch, *args)`` returns
     the gradient (or ``(objective, gradient)`` with eval_obj); bounded coordinates have outward gradients
     truncated and steps clipped.  `prefetch` (not in the reference): build each minibatch one step ahead on a worker
     thread -- only valid when `fun` does not draw from `random_state` itself; a callable is applied to every batch on
-    that thread (``_prefetched``)."""
+    that thread (``_prefetched``).  `device_loop` (not in the reference): an object that runs THIS loop with x, the updater's
+    state and the gradient in device memory -- ``begin(x0, lower, upper, updater, maxiter)``, ``step(batch + args)`` per
+    minibatch (queues the step, returns at once), ``end() -> (x, objs, norms)``, ``abort()``; `fun` is not called then
+    (GeneralizedLinearModel's resident SVI loop: rr_glm_sgd, glm._ResidentLoop)."""
     from scipy.optimize import OptimizeResult
     if updater is None:
         updater = Adam()
@@ -363,6 +366,22 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
     obj, objs, norms = None, [], []
     batches = gen_batch(data, batch_size, maxiter, random_state)
     ahead = _prefetched(batches, prefetch if callable(prefetch) else None) if prefetch else None
+    if device_loop is not None:
+        if bounds is None:
+            lower, upper = np.full(x.shape, -np.inf), np.full(x.shape, np.inf)
+        try:
+            device_loop.begin(x, lower, upper, updater, maxiter)
+            for batch in (ahead if ahead is not None else batches):
+                device_loop.step(list(batch) + list(args))
+            x, objs, norms = device_loop.end()
+        except BaseException:
+            device_loop.abort()
+            raise
+        finally:
+            if ahead is not None:
+                ahead.close()
+        objs, norms = [float(o) for o in objs], [float(v) for v in norms]
+        return OptimizeResult(x=x, norms=norms, message='maxiter reached', fun=objs[-1] if objs else None, objs=objs)
     try:
         for batch in (ahead if ahead is not None else batches):
             if not eval_obj:
@@ -451,6 +470,8 @@ def logtrick_sgd(sgd):
         if bounds is None:
             return sgd(fun, x0, data, bounds=bounds, eval_obj=eval_obj, **sgd_kwargs)
         pos = np.array([isinstance(b, Positive) for b in bounds], dtype=bool)
+        if sgd_kwargs.get("device_loop") is not None:  # the device loop applies from_log / the chain rule itself
+            sgd_kwargs["device_loop"].log_coordinates = pos
         # the Positive coordinates as contiguous RUNS (a (D, K) covariance block is one run of D K entries): exp over slices
         # instead of boolean-mask gathers and scatters of the whole vector -- same values, 0.25 ms less host time per SGD
         # step at config 5's 41 000 coordinates, where the step's serial host part is what the GPU waits for

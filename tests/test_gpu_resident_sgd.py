@@ -1,0 +1,175 @@
+"""The SVI loop of GeneralizedLinearModel.fit with its parameters resident in HBM (rr_glm_sgd, glm._ResidentLoop) against
+the host loop it replaces -- optimize.sgd o logtrick_sgd o structured_sgd around `_elbo` (reference: optimize/sgd.py:337-425,
+optimize/decorators.py:133-252,329-408, glm.py:205-294), itself held to the reference's golden `_elbo` outputs by
+test_gpu_glm.py.  Same seeds -> same minibatches, same draws, same start point: the two loops must produce the same fit."""
+import logging
+
+import numpy as np
+import pytest
+
+from conftest import normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _imports():
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd import optimize as opt
+    from revrand_amd.btypes import Bound, Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    return bs, lk, opt, Bound, Parameter, Positive, GeneralizedLinearModel
+
+
+def _data(lik, N=6000, d=5, seed=4):
+    rs = np.random.RandomState(seed)
+    X = rs.randn(N, d)
+    f = 0.5 * np.sin(X[:, 0]) + 0.2 * X[:, 2]
+    if lik == "poisson" or lik == "poisson_softplus":
+        return X, rs.poisson(np.exp(f)).astype(float), ()
+    if lik == "bernoulli":
+        return X, (rs.rand(N) < 1 / (1 + np.exp(-3 * f))).astype(float), ()
+    if lik == "binomial":
+        n = rs.randint(5, 30, size=N).astype(float)
+        return X, rs.binomial(n.astype(int), 1 / (1 + np.exp(-3 * f))).astype(float), (n,)
+    return X, f + 0.1 * rs.randn(N), ()
+
+
+def _fit(resident, lik="poisson", updater=None, iso=False, sampler="host", maxiter=20, K=3, L=8, batch=1500, nstarts=2,
+         lenscale=None, monkeypatch=None, nbases=64, count=None):
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    from revrand_amd import _hip
+    X, y, largs = _data(lik)
+    d = X.shape[1]
+    if lenscale is None:
+        lenscale = Parameter(1.0, Positive()) if iso else Parameter(np.ones(d), Positive())
+    basis = bs.RandomRBF(nbases=nbases, Xdim=d, random_state=1, lenscale=lenscale)
+    like = {"poisson": lambda: lk.Poisson(), "poisson_softplus": lambda: lk.Poisson("softplus"), "bernoulli": lk.Bernoulli,
+            "binomial": lk.Binomial, "gaussian": lk.Gaussian}[lik]()
+    glm = GLM(like, basis, K=K, nsamples=L, batch_size=batch, maxiter=maxiter, nstarts=nstarts, random_state=11,
+              updater=updater() if updater is not None else None, sampler=sampler)
+    glm._resident_sgd = resident
+    steps = [0]
+    if monkeypatch is not None:
+        real = _hip.ResidentSgd.step
+
+        def spy(self, *a, **k):
+            steps[0] += 1
+            return real(self, *a, **k)
+        monkeypatch.setattr(_hip.ResidentSgd, "step", spy)
+    np.random.seed(3)  # (the start point is a draw from NumPy's global stream, as in the reference)
+    glm.fit(X, y, likelihood_args=largs)
+    if count is not None:
+        count.append(steps[0])
+    return (glm.weights_.copy(), glm.covariance_.copy(), np.atleast_1d(np.array(glm.regularizer_, dtype=float)),
+            np.atleast_1d(np.array(glm.like_hypers_, dtype=float)), np.atleast_1d(np.array(glm.basis_hypers_, dtype=float)),
+            glm.random_.randn())
+
+
+def _same(a, b, tol):
+    for u, v in zip(a[:5], b[:5]):
+        assert u.shape == v.shape
+        if u.size:
+            assert normwise(u, v) < tol, (normwise(u, v), tol)
+    assert a[5] == b[5]  # the RandomState ends in the same state: same minibatches, same draws consumed
+
+
+@pytest.mark.parametrize("lik", ["poisson", "poisson_softplus", "bernoulli", "binomial", "gaussian"])
+def test_resident_loop_equals_host_loop(lik, monkeypatch):
+    """20 Adam steps from the same start on the same minibatches with the same draws: every fitted block agrees (the step's
+    float32 K-split atomics allow last-bit differences per step, as between two host-loop runs)."""
+    count = []
+    dev = _fit(True, lik, monkeypatch=monkeypatch, count=count)
+    assert count == [20]  # every step went through rr_glm_sgd_step ...
+    monkeypatch.undo()
+    host = _fit(False, lik, monkeypatch=monkeypatch, count=count)
+    assert count[1] == 0   # ... and none of the host loop's did
+    _same(dev, host, 2e-5)
+
+
+def test_isotropic_length_scale_takes_dimension_zero_only_like_the_reference():
+    _same(_fit(True, iso=True), _fit(False, iso=True), 2e-5)
+
+
+@pytest.mark.parametrize("name", ["SGDUpdater", "AdaDelta", "AdaGrad", "Momentum", "Adam"])
+def test_every_updater_of_the_reference(name):
+    """sgd.py:14-330: the five update rules, state in HBM."""
+    opt = _imports()[2]
+    # (AdaGrad's default eta = 1 makes the first step a unit step along sign(grad) in every coordinate: chaos, not arithmetic)
+    mk = {"SGDUpdater": lambda: opt.SGDUpdater(eta=1e-4), "Momentum": lambda: opt.Momentum(rho=0.5, eta=1e-4),
+          "AdaGrad": lambda: opt.AdaGrad(eta=1e-2)}.get(name, getattr(opt, name))
+    _same(_fit(True, updater=mk, maxiter=12), _fit(False, updater=mk, maxiter=12), 2e-5)
+
+
+def test_three_steps_agree_to_the_noise_of_the_steps_float32_atomics():
+    """Three Adam steps: the loops' own arithmetic is float64 on both sides (they differ in the order of the sums of the
+    mixture terms and the regulariser gradient, 1e-16); what is left is the last-bit noise of the step's float32 K-split
+    atomics (1e-7 of a gradient entry) times Adam's step length 0.01: 1e-9 of the parameters -- measured 7e-10."""
+    _same(_fit(True, maxiter=3), _fit(False, maxiter=3), 1e-8)
+
+
+def test_bounded_coordinates_are_truncated_and_clipped():
+    """A length scale with a plain Bound (no log trick) that the optimiser pushes into its bound: sgd.py:404-420."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    mk = lambda: Parameter(np.full(5, 1.0), Bound(0.97, 1.02))  # noqa: E731
+    a, b = _fit(True, lenscale=mk(), maxiter=15), _fit(False, lenscale=mk(), maxiter=15)
+    _same(a, b, 2e-5)
+    assert np.all(a[4] >= 0.97) and np.all(a[4] <= 1.02) and (np.any(a[4] == 0.97) or np.any(a[4] == 1.02))
+
+
+def test_device_sampler_and_the_log_lines(caplog):
+    """sampler="device": same fit from both loops (the draws are a function of (seed, step)); the `Iter n: ELBO` lines of
+    glm.py:287-290 come from the device's objective."""
+    with caplog.at_level(logging.INFO, logger="revrand_amd.glm"):
+        a = _fit(True, sampler="device", maxiter=10)
+    dev_lines = [r.getMessage() for r in caplog.records if r.getMessage().startswith("Iter ")]
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="revrand_amd.glm"):
+        b = _fit(False, sampler="device", maxiter=10)
+    host_lines = [r.getMessage() for r in caplog.records if r.getMessage().startswith("Iter ")]
+    _same(a, b, 2e-5)
+    assert len(dev_lines) == len(host_lines) == 2  # iterations 0 and maxiter - 1
+
+    def elbo(line):
+        return float(line.split("ELBO = ")[1].split(",")[0])
+    for u, v in zip(dev_lines, host_lines):
+        assert u.split(":")[0] == v.split(":")[0]
+        assert abs(elbo(u) - elbo(v)) < 1e-5 * abs(elbo(v))
+
+
+def test_fits_the_loop_does_not_cover_take_the_host_loop(monkeypatch):
+    """A concatenation, a custom updater, K > 32: `_resident_loop` declines and `fit` is what it was."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    from revrand_amd import _hip
+    monkeypatch.setattr(_hip.ResidentSgd, "step", lambda *a, **k: (_ for _ in ()).throw(AssertionError("resident loop used")))
+    X, y, _ = _data("poisson", N=1200)
+    d = X.shape[1]
+
+    class MyAdam(opt.Adam):
+        pass
+    for basis, kw in ((bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {}),
+                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"updater": MyAdam()}),
+                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"K": 33})):
+        glm = GLM(lk.Poisson(), basis, nsamples=4, batch_size=300, maxiter=3, nstarts=0, random_state=1, **{"K": 2, **kw})
+        glm.fit(X, y)
+        assert np.all(np.isfinite(glm.weights_))
+
+
+def test_config5_shape_runs_the_fused_contraction_and_improves_the_objective():
+    """F = 2048, D = 32 ARD, K L = 500, minibatch 16 384 (config 5 with a quarter of its rows per step): the plan that contracts
+    EdPhi in registers is taken inside the resident loop; 30 steps from the same start give the host loop's parameters."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(0)
+    N, d, n = 60000, 32, 1024
+    X = rs.randn(N, d).astype(np.float32)
+    y = rs.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(float)
+    out = []
+    for resident in (True, False):
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        glm = GLM(lk.Poisson(), basis, K=10, nsamples=50, batch_size=16384, maxiter=30, nstarts=0, random_state=2)
+        glm._resident_sgd = resident
+        np.random.seed(5)
+        glm.fit(X, y)
+        out.append((glm.weights_.copy(), glm.covariance_.copy(), np.array(glm.basis_hypers_), float(glm.regularizer_)))
+    (wa, ca, ha, ra), (wb, cb, hb, rb) = out
+    assert normwise(wa, wb) < 1e-4 and normwise(ca, cb) < 1e-4 and normwise(ha, hb) < 1e-4 and abs(ra - rb) < 1e-4 * rb
