@@ -769,22 +769,35 @@ def config_c5(dev, _hip, args):
         # one-off upload of X drops out
         import logging
         logging.getLogger("revrand_amd").setLevel(logging.ERROR)
-        tfit = {}
-        for iters in (8, 40):
-            g2 = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1,
-                                                                   lenscale=Parameter(np.ones(d), Positive())),
-                                        K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler)
-            t0 = time.perf_counter()
-            g2.fit(X, y)
-            tfit[iters] = time.perf_counter() - t0
-        raw["fit_step_ms"] = 1e3 * (tfit[40] - tfit[8]) / 32
+        # `fit` as the estimator runs it: the RESIDENT loop (rr_glm_sgd: parameters, updater state and gradient in HBM, a step
+        # queued per library call, nothing read back) and, beside it, the host loop around `_elbo` it replaces (the same fit:
+        # tests/test_gpu_resident_sgd.py) -- each from two fits of different length, so that the upload of X drops out
+        for key, resident, (short, long_) in (("fit_step_ms", True, (8, 72)), ("fit_step_host_loop_ms", False, (8, 40))):
+            tfit, fitted = {}, {}
+            for iters in (short, long_):
+                g2 = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1,
+                                                                       lenscale=Parameter(np.ones(d), Positive())),
+                                            K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler)
+                g2._resident_sgd = resident
+                np.random.seed(20260930)  # (the start point is a draw from NumPy's global stream)
+                t0 = time.perf_counter()
+                g2.fit(X, y)
+                tfit[iters] = time.perf_counter() - t0
+                fitted[iters] = np.concatenate((g2.weights_.ravel(), g2.covariance_.ravel(), np.atleast_1d(g2.basis_hypers_)))
+            raw[key] = 1e3 * (tfit[long_] - tfit[short]) / (long_ - short)
+            raw.setdefault("_fit8", []).append(fitted[short])
+        a8, b8 = raw.pop("_fit8")
+        raw["resident_vs_host_loop_8_steps"] = parity("C5 %s: parameters after 8 steps, resident loop vs host loop (normwise)" % sampler,
+                                                      float(np.linalg.norm(a8 - b8) / np.linalg.norm(b8)), 1e-4)
         sessions.setdefault(sampler, []).append(raw)
     out = {}
     for sampler, runs in sessions.items():
-        ms, dms, fms = (float(np.median([r[k] for r in runs])) for k in ("elbo_step_ms", "device_calls_ms", "fit_step_ms"))
-        out[sampler] = {"fit_step_ms": fms, "device_calls_ms": dms, "elbo_step_ms": ms,
+        ms, dms, fms, hms = (float(np.median([r[k] for r in runs])) for k in ("elbo_step_ms", "device_calls_ms", "fit_step_ms",
+                                                                             "fit_step_host_loop_ms"))
+        out[sampler] = {"fit_step_ms": fms, "fit_step_host_loop_ms": hms, "device_calls_ms": dms, "elbo_step_ms": ms,
                         "device_calls_frac": gemm_flops / (dms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                         "fit_step_frac": gemm_flops / (fms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "resident_vs_host_loop_8_steps": max(r["resident_vs_host_loop_8_steps"] for r in runs),
                         "sessions_fit_dev_ms": [[r["fit_step_ms"], r["device_calls_ms"]] for r in runs], "_sessions": runs}
     cpu = None
     if not args.no_cpu_baseline:

@@ -182,6 +182,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
                 and self._group() is None:  # (a device group's members gather for themselves, on their own threads)
             self.__dict__["_batch_upload"] = _hip.get_upload_device(_hip.get_device().index)
+        if callable(prefetch) and self.sampler != "device" and os.environ.get("RR_GLM_PREFETCH_STAGES", "2") != "1":
+            # two workers in a row: the draws (2.5 ms of MT19937 + polar method per config-5 step, on the thread that cuts the
+            # batches -- one RandomState, the reference's order -- next to its 0.4 ms of y[idx] and, once per epoch, 18 ms of
+            # permutation(N)), then the uploads and gathers (1.1 ms): one worker doing both needed 4 ms per step, more than the
+            # step's 3.4 ms of kernels under the resident loop
+            prefetch = [self._draw_ahead, lambda batch: self._ahead(batch, draws=False)]
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
@@ -249,11 +255,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
     _native_draws = True  # False: NumPy generates the draws (what tests compare the library's generator against)
 
-    def _ahead(self, batch):
+    def _ahead(self, batch, draws=True):
         """On the minibatch worker thread, for the batch it just cut: the likelihood's constants of that batch when they do
         not depend on parameters (Poisson / binomial log-factorial sums: 0.15 ms of a 5 ms config-5 step), and -- with the
         reference's random stream -- the step's draws (`_draw_ahead`)."""
         batch = list(batch)
+        made = batch.pop() if (batch and isinstance(batch[-1], _Draws)) else None   # (by an earlier pipeline stage)
         resident = getattr(self, "_resident_fit", False)
         spec = None
         if getattr(self.likelihood, "spec_is_parameter_free", False):
@@ -270,20 +277,28 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             batch.append(_Spec(spec))
         if gathered is not None:
             batch.append(gathered)
-        if self.sampler != "device" and self._prefetch_draws:
-            batch = self._draw_ahead(batch)
+        if made is not None:
+            batch.append(self._upload_draws(made))
+        elif draws and self.sampler != "device" and self._prefetch_draws:
+            batch = self._draw_ahead(batch, upload=True)
         return batch
 
-    def _draw_ahead(self, batch):
-        """On the minibatch worker thread: the step's draws, and their upload -- through a device context (stream) of this
+    def _draw_ahead(self, batch, upload=False):
+        """On a minibatch worker thread, right after the batch is cut: the step's draws from `random_` in the reference's
+        order (batch_t, e_t, batch_t+1, ...); `upload`: also `_upload_draws` (a single-stage pipeline)."""
+        d = _Draws(self._reference_draws())
+        return list(batch) + [self._upload_draws(d) if upload else d]
+
+    def _upload_draws(self, d):
+        """On a minibatch worker thread: the draws' upload -- through a device context (stream) of this
         thread's own, into one of THREE buffers in turn: the worker runs up to two steps ahead (one finished batch waits in
         the queue while the next is being made) -- while earlier steps' kernels run; the step then starts from
         device-resident draws (rr_featmat_glm_step_draws_dev).  (SIX buffers under the resident loop, whose host queues
         steps up to two ahead of the device on top of that: `_draw_buffers`.)"""
-        e = self._reference_draws()
         up = self.__dict__.get("_draw_upload")
         if up is None:
-            return list(batch) + [_Draws(e)]
+            return d
+        e = d.e
         dev, bufs, turn = up
         buf = bufs[turn[0] % len(bufs)]
         if buf is None or buf.nbytes < e.nbytes:
@@ -293,7 +308,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, buf.ptr, e.ctypes.data_as(_hip.ctypes.c_void_p), e.nbytes))
         buf.shape, buf.dtype = e.shape, e.dtype
         turn[0] += 1
-        return list(batch) + [_Draws(buf)]
+        return _Draws(buf)
 
     # -- device features of one minibatch ------------------------------------------------------
     def _features(self):

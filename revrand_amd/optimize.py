@@ -295,12 +295,17 @@ def _prefetched(batches, augment=None):
     GIL, so the permutation draw and the row gather of step t+1 overlap the kernels of step t.  The order of the
     batches, hence the generator's use of its RandomState, is unchanged.  `augment(batch) -> batch` runs on the worker
     right after a batch is cut (the GLM draws its step's standard normals there: batch_t, e_t, batch_t+1, e_t+1, ... is
-    exactly the order in which a sequential run consumes the stream)."""
+    exactly the order in which a sequential run consumes the stream).  A LIST of callables is a pipeline: the first runs on
+    the thread that cuts the batches, every further one on a thread of its own behind a one-batch queue (the GLM: draws on
+    the first -- they share the RandomState with the permutations -- uploads and gathers on the second; the slower of the
+    two, not their sum, bounds the rate at which batches arrive)."""
     import queue
     import threading
-    q, stop, END = queue.Queue(maxsize=1), threading.Event(), object()
+    stages = [f for f in (augment if isinstance(augment, (list, tuple)) else [augment]) if f is not None] or [None]
+    qs = [queue.Queue(maxsize=1) for _ in stages]
+    stop, END = threading.Event(), object()
 
-    def put(item):
+    def put(q, item):
         while not stop.is_set():
             try:
                 q.put(item, timeout=0.1)
@@ -309,22 +314,44 @@ def _prefetched(batches, augment=None):
                 pass
         return False
 
-    def work():
+    def get(q):
+        while not stop.is_set():
+            try:
+                return q.get(timeout=0.1)
+            except queue.Empty:
+                pass
+        return END
+
+    def first():
         try:
             for item in batches:
-                if augment is not None:
-                    item = augment(item)
-                if not put(item):
+                if stages[0] is not None:
+                    item = stages[0](item)
+                if not put(qs[0], item):
                     return
-            put(END)
+            put(qs[0], END)
         except BaseException as e:  # surfaces in the consumer
-            put(e)
+            put(qs[0], e)
 
-    worker = threading.Thread(target=work, daemon=True)
-    worker.start()
+    def later(i):
+        try:
+            while True:
+                item = get(qs[i - 1])
+                if item is END or isinstance(item, BaseException):
+                    put(qs[i], item)
+                    return
+                if not put(qs[i], stages[i](item)):
+                    return
+        except BaseException as e:
+            put(qs[i], e)
+
+    workers = [threading.Thread(target=first, daemon=True)] + \
+              [threading.Thread(target=later, args=(i,), daemon=True) for i in range(1, len(stages))]
+    for w in workers:
+        w.start()
     try:
         while True:
-            item = q.get()
+            item = qs[-1].get()
             if item is END:
                 return
             if isinstance(item, BaseException):
@@ -332,13 +359,14 @@ def _prefetched(batches, augment=None):
             yield item
     finally:
         stop.set()
-        # the worker may be in the middle of a batch (`augment` uploads and gathers on the device for the GLM): let it finish
+        # a worker may be in the middle of a batch (`augment` uploads and gathers on the device for the GLM): let it finish
         # that one before the caller frees what it writes to.  (`sgd` closes this generator explicitly when its objective
-        # raises: the traceback would otherwise keep it -- and the worker -- alive past the caller's cleanup.)
-        worker.join(timeout=60.0)
-        if worker.is_alive():
-            log.error("the minibatch prefetch worker is still running 60 s after it was told to stop: device buffers it "
-                      "writes to may be freed under it")
+        # raises: the traceback would otherwise keep it -- and the workers -- alive past the caller's cleanup.)
+        for w in workers:
+            w.join(timeout=60.0)
+            if w.is_alive():
+                log.error("a minibatch prefetch worker is still running 60 s after it was told to stop: device buffers it "
+                          "writes to may be freed under it")
 
 
 def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, updater=None, eval_obj=False,
@@ -365,7 +393,7 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
         upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
     obj, objs, norms = None, [], []
     batches = gen_batch(data, batch_size, maxiter, random_state)
-    ahead = _prefetched(batches, prefetch if callable(prefetch) else None) if prefetch else None
+    ahead = _prefetched(batches, prefetch if (callable(prefetch) or isinstance(prefetch, (list, tuple))) else None) if prefetch else None
     if device_loop is not None:
         if bounds is None:
             lower, upper = np.full(x.shape, -np.inf), np.full(x.shape, np.inf)

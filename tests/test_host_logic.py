@@ -360,6 +360,77 @@ def test_sgd_prefetch_changes_nothing_but_the_thread():
     assert threading.active_count() <= before
 
 
+def test_prefetch_pipeline_of_several_stages_keeps_order_and_surfaces_errors():
+    """A list of callables is a pipeline -- the first on the thread that cuts the batches, each further one on its own thread:
+    every batch passes every stage once, in order; a stage's exception reaches the consumer; an abandoned run ends all workers;
+    `sgd` takes the list as `prefetch` and its device-loop protocol (begin / step / end) sees the augmented batches."""
+    import threading
+    import time
+    from revrand_amd.optimize import sgd, _prefetched
+    seen = [[], []]
+
+    def a(x):
+        seen[0].append((threading.get_ident(), x))
+        return x * 2
+
+    def b(x):
+        time.sleep(0.001)
+        seen[1].append((threading.get_ident(), x))
+        return x + 1
+    out = list(_prefetched(iter(range(50)), [a, b]))
+    assert out == [2 * i + 1 for i in range(50)]
+    assert [x for _, x in seen[0]] == list(range(50)) and [x for _, x in seen[1]] == [2 * i for i in range(50)]
+    assert len({t for t, _ in seen[0]}) == 1 and len({t for t, _ in seen[1]}) == 1 and seen[0][0][0] != seen[1][0][0]
+    assert threading.get_ident() not in {seen[0][0][0], seen[1][0][0]}
+
+    def bad(x):
+        if x == 6:
+            raise ValueError("stage two")
+        return x
+    it = _prefetched(iter(range(50)), [a, bad])
+    assert [next(it) for _ in range(3)] == [0, 2, 4]
+    with pytest.raises(ValueError, match="stage two"):
+        next(it)
+    before = threading.active_count()
+    it = _prefetched(iter(range(10 ** 6)), [a, b, b])
+    assert next(it) == 2
+    it.close()
+    for _ in range(50):
+        if threading.active_count() <= before:
+            break
+        time.sleep(0.05)
+    assert threading.active_count() <= before
+
+    class Loop(object):  # the protocol of glm._ResidentLoop
+        def begin(self, x0, lower, upper, updater, maxiter):
+            self.x, self.batches, self.maxiter = np.array(x0), [], maxiter
+            assert np.all(lower == -1.0) and np.all(upper == np.inf)
+
+        def step(self, batch):
+            self.batches.append(batch)
+            self.x = self.x + 1
+
+        def end(self):
+            return self.x, np.arange(len(self.batches), dtype=float), np.ones(len(self.batches))
+
+        def abort(self):
+            self.aborted = True
+    X = np.arange(40.0).reshape(20, 2)
+    loop = Loop()
+    res = sgd(None, np.zeros(2), [X], bounds=[(-1.0, None)] * 2, batch_size=5, maxiter=7, random_state=np.random.RandomState(1),
+              prefetch=[lambda bt: list(bt) + ["drawn"], lambda bt: list(bt) + ["uploaded"]], args=("arg",), device_loop=loop)
+    assert np.array_equal(res.x, [7.0, 7.0]) and res.objs == list(range(7)) and res.fun == 6.0 and len(res.norms) == 7
+    assert all(bt[1:] == ["drawn", "uploaded", "arg"] and bt[0].shape == (5, 2) for bt in loop.batches)
+
+    class Failing(Loop):
+        def step(self, batch):
+            raise RuntimeError("device step")
+    bad_loop = Failing()
+    with pytest.raises(RuntimeError, match="device step"):
+        sgd(None, np.zeros(2), [X], bounds=[(-1.0, None)] * 2, batch_size=5, maxiter=7, prefetch=True, device_loop=bad_loop)
+    assert bad_loop.aborted
+
+
 def test_poisson_log_factorial_table():
     from scipy.special import gammaln
     from revrand_amd.likelihoods import _sum_gammaln1p

@@ -1,0 +1,33 @@
+"""Config 5's `fit` through the resident SVI loop (rr_glm_sgd), for rocprofv3: two fits of different length, the per-step
+wall-clock from their difference.  `python tools/c5_resident.py [host|device] [resident|hostloop] [short long]`."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import revrand_amd.basis_functions as bs  # noqa: E402
+from revrand_amd import likelihoods as lk  # noqa: E402
+from revrand_amd.btypes import Parameter, Positive  # noqa: E402
+from revrand_amd.glm import GeneralizedLinearModel  # noqa: E402
+
+sampler = sys.argv[1] if len(sys.argv) > 1 else "host"
+resident = (sys.argv[2] if len(sys.argv) > 2 else "resident") == "resident"
+short, long_ = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (8, 72)
+N, d, n, K, L, M = 2_000_000, 32, 1024, 10, 50, 65536
+rng = np.random.default_rng([20260928, 5])
+X = rng.standard_normal((N, d), dtype=np.float32)
+y = rng.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(np.float64)
+t = {}
+for rep in range(2):
+    for iters in (short, long_):
+        g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
+                                   K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler)
+        g._resident_sgd = resident
+        np.random.seed(1)
+        t0 = time.perf_counter()
+        g.fit(X, y)
+        t[iters] = time.perf_counter() - t0
+    print("%s sampler, %s: %.3f ms per step (fits of %d and %d steps: %.3f s, %.3f s)"
+          % (sampler, "resident loop" if resident else "host loop", 1e3 * (t[long_] - t[short]) / (long_ - short), short, long_, t[short], t[long_]))
