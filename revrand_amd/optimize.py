@@ -302,7 +302,10 @@ def _prefetched(batches, augment=None):
     import queue
     import threading
     stages = [f for f in (augment if isinstance(augment, (list, tuple)) else [augment]) if f is not None] or [None]
-    qs = [queue.Queue(maxsize=1) for _ in stages]
+    # (one finished batch waits behind every stage; behind the FIRST stage of a pipeline, eight: what it makes lives in host
+    # memory, and the thread that cuts the batches stalls for a whole permutation(N) at every epoch boundary -- 18 ms at
+    # N = 2M, five steps' worth at config 5 -- which the later stages and the consumer then do not notice)
+    qs = [queue.Queue(maxsize=8 if (i == 0 and len(stages) > 1) else 1) for i in range(len(stages))]
     stop, END = threading.Event(), object()
 
     def put(q, item):

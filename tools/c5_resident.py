@@ -20,7 +20,9 @@ rng = np.random.default_rng([20260928, 5])
 X = rng.standard_normal((N, d), dtype=np.float32)
 y = rng.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(np.float64)
 t = {}
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
+    if os.environ.get("ALTERNATE"):
+        sampler = ("host", "device")[rep % 2]
     for iters in (short, long_):
         g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
                                    K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler)

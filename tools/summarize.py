@@ -275,6 +275,10 @@ def sq_summary(tag, prefixes, min_ms):
         e["clock_GHz"].append(ghz)
         e["mfma_busy_frac"].append(busy)
     for e in out.values():
+        # (the clock of ~1 ms launches follows the chip's power state: a burst after an idle gap runs at ~2.4 GHz, a sustained
+        # queue of MFMA-bound launches at ~2.1 GHz -- the range is part of the evidence)
+        e["clock_GHz_min_max"] = [min(e["clock_GHz"]), max(e["clock_GHz"])]
+        e["ms_min_max"] = [min(e["ms"]), max(e["ms"])]
         for key in ("ms", "clock_GHz", "mfma_busy_frac"):
             e[key] = sum(e[key]) / len(e[key])
         e["ceiling_frac_of_nominal_peak"] = e["mfma_busy_frac"] * e["clock_GHz"] / 2.4
