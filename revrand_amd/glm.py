@@ -13,9 +13,12 @@ MI355X with Phi of the minibatch assembled in HBM and never returned to the host
 * ``Edws = dfs.dot(Phi)``, ``EdPhi = dfs.T.dot(ws)``      -> MFMA GEMMs                                   glm.py:308,311
 * ``-(EdPhi * dPhi).sum()`` over ``basis.grad``           -> contraction kernel, no (M, F, d) tensor      glm.py:274-275
 
-The O(F K^2) mixture-entropy terms and the optimiser stay on the host, as in the reference.  The standard-normal
-draws come from the host ``random_`` in the reference's order (``randn(nsamples, D)`` per component), so a seeded
-run consumes the same random stream as the reference.
+When the model is one random Fourier basis over minibatches gathered on the device, the whole SGD loop around these
+products -- from_log, the O(F K^2) mixture-entropy terms, the gradient, the log trick's chain rule, the bounds and the
+updater (optimize/sgd.py:337-425, decorators.py:329-408) -- runs with its parameters resident in HBM as well, one library
+call per step and nothing read back until the fit ends (``_ResidentLoop``, rr_glm_sgd_*); otherwise those parts stay on
+the host, as in the reference.  The standard-normal draws come from the host ``random_`` in the reference's order
+(``randn(nsamples, D)`` per component), so a seeded run consumes the same random stream as the reference.
 """
 import logging
 import os
