@@ -627,6 +627,10 @@ int rr_comm_group_reduce_stats_dev(rr_comm *const *comms, int n, int64_t F, doub
  * only: needs no device. */
 int rr_legacy_randn(uint32_t *key, int32_t *pos, int32_t *has_gauss, double *gauss, void *out, int out_dtype, int64_t n,
                     int threads);
+/* random_state.permutation(n) of the same generator (the minibatch index stream of optimize/sgd.py:428-470 through
+ * utils/rand.py:7-31), bit for bit and leaving the same state: out = n int64 values.  NumPy's own loop holds the GIL (18 ms at
+ * n = 2M, once per epoch) -- every Python thread of the fit stalls with it; this one does not.  n <= 2^32. */
+int rr_legacy_permutation(uint32_t *key, int32_t *pos, int64_t n, int64_t *out);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ _c_double_p = ctypes.POINTER(ctypes.c_double)
 SIGNATURES = {
     "rr_abi_version": (ctypes.c_int, []),
     "rr_build_flags": (ctypes.c_int, []),
+    "rr_legacy_permutation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rr_legacy_randn": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_int, ctypes.c_int64, ctypes.c_int]),
     "rr_last_error": (ctypes.c_char_p, []),
@@ -696,28 +697,64 @@ def get_upload_device(index=None):
     return dev
 
 
-def legacy_randn(random_state, n, dtype=np.float32, threads=2):
+def legacy_randn(random_state, n, dtype=np.float32, threads=2, out=None):
     """`random_state.randn(n)` (a NumPy legacy RandomState), bit for bit and leaving the same state behind, through
     rr_legacy_randn: the MT19937 words, the polar method's candidate pairs and their accept count on this thread (array loops,
     AVX2 where the host has it), the pick of the accepted pairs with their square roots and logarithms on `threads` worker
     threads (two keep up on the GPU box's host: 2.2 ms median per 1 024 000 values against NumPy's 9.3; rounds 2-3, with the
     accept / reject walk on this thread: 4.4).  Anything but a plain MT19937 RandomState falls back to NumPy itself (same
-    values either way)."""
+    values either way).  out: a contiguous array of n values of `dtype` to fill instead of a new one (a caller drawing 4 MB per SVI
+    step keeps a ring of them: fresh arrays of that size are mapped and unmapped by the allocator, and in a process with
+    hundreds of threads the page faults and TLB shootdowns of that stall every thread for tens of milliseconds at a time)."""
     dtype = np.dtype(dtype)
     try:
         st = random_state.get_state(legacy=True)
     except TypeError:
         st = random_state.get_state()
+    if out is not None and not (isinstance(out, np.ndarray) and out.dtype == dtype and out.size == n and out.flags.c_contiguous):
+        raise ValueError("out must be a contiguous array of n values of the requested dtype")
     if n <= 0 or not isinstance(st, tuple) or st[0] != "MT19937" or dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
-        return random_state.randn(n).astype(dtype, copy=False)
+        vals = random_state.randn(n).astype(dtype, copy=False)
+        if out is None:
+            return vals
+        out.reshape(-1)[:] = vals
+        return out
     lib = load_library()
     key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
     pos, has, g = ctypes.c_int32(int(st[2])), ctypes.c_int32(int(st[3])), ctypes.c_double(float(st[4]))
-    out = np.empty(n, dtype=dtype)
+    out = np.empty(n, dtype=dtype) if out is None else out
     threads = int(os.environ.get("RR_RANDN_THREADS", threads))  # (measurement switch)
     _check(lib, lib.rr_legacy_randn(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), ctypes.byref(has), ctypes.byref(g),
                                     out.ctypes.data_as(ctypes.c_void_p), rr_dtype(dtype), n, threads))
     random_state.set_state(("MT19937", key, pos.value, has.value, g.value))
+    return out
+
+
+def legacy_permutation(random_state, n, out=None):
+    """`random_state.permutation(n)` for an integer n (a NumPy legacy RandomState), bit for bit and leaving the same state
+    behind, through rr_legacy_permutation -- WITHOUT the GIL, which NumPy's shuffle loop holds throughout (18 ms at n = 2M: the
+    epoch boundary of config 5's minibatch stream, where every thread of the fit stood still).  Anything but a plain MT19937
+    RandomState, and short permutations, go to NumPy itself (same values either way).  out: an int64 array of n entries to fill
+    (see legacy_randn)."""
+    n = int(n)
+    if out is not None and not (isinstance(out, np.ndarray) and out.dtype == np.int64 and out.shape == (n,) and out.flags.c_contiguous):
+        raise ValueError("out must be a contiguous int64 array of n entries")
+    try:
+        st = random_state.get_state(legacy=True)
+    except TypeError:
+        st = random_state.get_state()
+    if n < 4096 or n > (1 << 32) or not isinstance(st, tuple) or st[0] != "MT19937":
+        vals = random_state.permutation(n)
+        if out is None:
+            return vals
+        out[:] = vals
+        return out
+    lib = load_library()
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    out = np.empty(n, dtype=np.int64) if out is None else out
+    _check(lib, lib.rr_legacy_permutation(key.ctypes.data_as(ctypes.c_void_p), ctypes.byref(pos), n, out.ctypes.data_as(ctypes.c_void_p)))
+    random_state.set_state(("MT19937", key, pos.value, int(st[3]), float(st[4])))
     return out
 
 

@@ -228,6 +228,64 @@ int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, i
 
 }  // namespace
 
+// RandomState.permutation(n) (numpy/random/mtrand.pyx: `arr = arange(n); shuffle(arr)`; _shuffle_raw: for i = n-1 .. 1:
+// j = random_interval(i), swap(arr[i], arr[j]); random_interval, numpy/random/src/distributions/distributions.c: the smallest
+// bit mask >= max, 32-bit words masked and rejected while > max).  NumPy runs this loop holding the GIL -- 18 ms at n = 2M, during
+// which no other Python thread (the SVI loop's consumer among them) advances; here it runs without it.
+extern "C" int rr_legacy_permutation(uint32_t *key, int32_t *pos, int64_t n, int64_t *out) {
+    RR_REQUIRE(key != nullptr && pos != nullptr, "rr_legacy_permutation: null state");
+    RR_REQUIRE(*pos >= 0 && *pos <= MT_N, "rr_legacy_permutation: position %d outside the MT19937 state", (int)*pos);
+    RR_REQUIRE(n >= 0 && n <= ((int64_t)1 << 32) && (n == 0 || out != nullptr), "rr_legacy_permutation: 0 <= n <= 2^32");
+    Mt mt;
+    memcpy(mt.key, key, sizeof(mt.key));
+    mt.pos = (int)*pos;
+    mt.temper_from(mt.pos);
+    // The swap chain is a walk of random addresses (cache misses, one after the other).  The partners j do not depend on the
+    // array, so they are drawn a block ahead and the lines they name are prefetched a few swaps before they are needed; below
+    // 2^31 entries the walk is over 32-bit values (half the footprint: 8 MB at n = 2M) in a grow-only scratch of the calling
+    // thread, widened into `out` at the end.
+    constexpr int JB = 512, AHEAD = 24;
+    uint64_t J[JB];
+    auto walk = [&](auto *a) {
+        for (int64_t i = 0; i < n; ++i) a[i] = (decltype(a[0] + 0))i;
+        int64_t i = n - 1;
+        while (i >= 1) {
+            const int c = (int)(i < JB ? i : JB);
+            for (int q = 0; q < c; ++q) {
+                const uint64_t ii = (uint64_t)(i - q);
+                uint64_t mask = ii;
+                mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16; mask |= mask >> 32;
+                uint64_t j;
+                do {
+                    j = (uint64_t)mt.next() & mask;
+                } while (j > ii);
+                J[q] = j;
+            }
+            for (int q = 0; q < AHEAD && q < c; ++q) __builtin_prefetch(&a[J[q]], 1);
+            for (int q = 0; q < c; ++q) {
+                if (q + AHEAD < c) __builtin_prefetch(&a[J[q + AHEAD]], 1);
+                const int64_t u = i - q;
+                const auto t = a[J[q]];
+                a[J[q]] = a[u];
+                a[u] = t;
+            }
+            i -= c;
+        }
+    };
+    if (n < ((int64_t)1 << 31) && n >= 65536) {
+        static thread_local std::vector<uint32_t> scratch;
+        if ((int64_t)scratch.size() < n) scratch.resize((size_t)n);
+        uint32_t *a = scratch.data();
+        walk(a);
+        for (int64_t i = 0; i < n; ++i) out[i] = (int64_t)a[i];
+    } else {
+        walk(out);
+    }
+    memcpy(key, mt.key, sizeof(mt.key));
+    *pos = mt.pos;
+    return RR_OK;
+}
+
 extern "C" int rr_legacy_randn(uint32_t *key, int32_t *pos, int32_t *has_gauss, double *gauss, void *out, int out_dtype,
                                int64_t n, int threads) {
     RR_REQUIRE(key != nullptr && pos != nullptr && has_gauss != nullptr && gauss != nullptr, "rr_legacy_randn: null state");

@@ -22,6 +22,7 @@ the host, as in the reference.  The standard-normal draws come from the host ``r
 """
 import logging
 import os
+import time
 from itertools import chain
 
 import numpy as np
@@ -52,6 +53,37 @@ class _RowIndex(object):
 
     def __getitem__(self, ind):
         return ind
+
+
+class _LazyRows(object):
+    """Targets / per-row likelihood arguments of a resident fit as the batch generator sees them: `self[ind]` only NOTES the
+    rows (`_PendingRows`); whoever handles the batch next -- the pipeline's upload stage, else the step -- gathers them
+    (`_gathered`).  The thread that cuts the batches also draws the step's 1 024 000 normals at config 5 and is the slowest
+    stage of the pipeline: the 0.4 ms gather per step is better spent elsewhere."""
+
+    def __init__(self, arr):
+        self.arr, self.shape = arr, arr.shape
+
+    def __len__(self):
+        return self.shape[0]
+
+    def __getitem__(self, ind):
+        return _PendingRows(self.arr, ind)
+
+
+class _PendingRows(object):
+    def __init__(self, arr, ind):
+        self.arr, self.ind = arr, ind
+
+    def __len__(self):
+        return len(self.ind)
+
+    def get(self):
+        return self.arr[self.ind]
+
+
+def _gathered(items):
+    return [b.get() if isinstance(b, _PendingRows) else b for b in items]
 
 
 class _RowStub(object):
@@ -145,7 +177,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # shuffles row INDICES (the same permutation stream) and a zero-width stand-in for X
         self._resident_fit = self._features().make_resident(X)
         if self._resident_fit:
-            data = (_RowStub(N), y) + likelihood_args + (_RowIndex(N),)
+            lazy = tuple(_LazyRows(a) if (isinstance(a, np.ndarray) and len(a) == N) else a for a in (y,) + likelihood_args)
+            data = (_RowStub(N),) + lazy + (_RowIndex(N),)
         params = [Parameter(WGTRND, Bound(), shape=(self.D_, self.K)),
                   Parameter(COVRND, Positive(), shape=(self.D_, self.K)),
                   self.basis.regularizer,
@@ -185,12 +218,14 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
                 and self._group() is None:  # (a device group's members gather for themselves, on their own threads)
             self.__dict__["_batch_upload"] = _hip.get_upload_device(_hip.get_device().index)
-        if callable(prefetch) and self.sampler != "device" and os.environ.get("RR_GLM_PREFETCH_STAGES", "2") != "1":
+        if callable(prefetch) and os.environ.get("RR_GLM_PREFETCH_STAGES", "2") != "1":
             # two workers in a row: the draws (2.5 ms of MT19937 + polar method per config-5 step, on the thread that cuts the
             # batches -- one RandomState, the reference's order -- next to its 0.4 ms of y[idx] and, once per epoch, 18 ms of
             # permutation(N)), then the uploads and gathers (1.1 ms): one worker doing both needed 4 ms per step, more than the
-            # step's 3.4 ms of kernels under the resident loop
-            prefetch = [self._draw_ahead, lambda batch: self._ahead(batch, draws=False)]
+            # step's 3.4 ms of kernels under the resident loop.  With the device sampler the first stage only cuts the batches:
+            # what it buys is the eight batches of slack behind it, which hide the permutation at an epoch boundary
+            first = self._draw_ahead if self.sampler != "device" else (lambda batch: list(batch))
+            prefetch = [first, lambda batch: self._ahead(batch, draws=False)]
         try:
             res = nsgd(elbo, params, data, eval_obj=True, maxiter=self.maxiter, updater=self.updater,
                        batch_size=self.batch_size, random_state=self.random_, nstarts=self.nstarts,
@@ -207,6 +242,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                     log.exception("synchronising the upload context failed")
             self._resident_fit = False
             self.__dict__.pop("_draw_buffers", None)
+            self.__dict__.pop("_draw_ring", None)
             self._release_features()
             if up is not None:
                 for buf in up[1]:
@@ -246,12 +282,13 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             return None
         return _ResidentLoop(self, feats, n_lik, n_ls)
 
-    def _reference_draws(self):
-        """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component."""
+    def _reference_draws(self, out=None):
+        """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component.
+        out: a (K L, D) float32 array to fill (the minibatch pipeline's ring, `_draw_ahead`)."""
         K, L_, D = self.K, self.nsamples, self.D_
         if self._native_draws:  # the same K consecutive randn(L, D) as one call of the library's generator (bit-identical)
-            return _hip.legacy_randn(self.random_, K * L_ * D, np.float32).reshape(K * L_, D)
-        e = np.empty((K * L_, D), dtype=np.float32)
+            return _hip.legacy_randn(self.random_, K * L_ * D, np.float32, out=out).reshape(K * L_, D)
+        e = np.empty((K * L_, D), dtype=np.float32) if out is None else out
         for k in range(K):
             e[k * L_:(k + 1) * L_] = self.random_.randn(L_, D)
         return e
@@ -262,7 +299,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         """On the minibatch worker thread, for the batch it just cut: the likelihood's constants of that batch when they do
         not depend on parameters (Poisson / binomial log-factorial sums: 0.15 ms of a 5 ms config-5 step), and -- with the
         reference's random stream -- the step's draws (`_draw_ahead`)."""
-        batch = list(batch)
+        batch = _gathered(batch)
         made = batch.pop() if (batch and isinstance(batch[-1], _Draws)) else None   # (by an earlier pipeline stage)
         resident = getattr(self, "_resident_fit", False)
         spec = None
@@ -289,7 +326,20 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     def _draw_ahead(self, batch, upload=False):
         """On a minibatch worker thread, right after the batch is cut: the step's draws from `random_` in the reference's
         order (batch_t, e_t, batch_t+1, ...); `upload`: also `_upload_draws` (a single-stage pipeline)."""
-        d = _Draws(self._reference_draws())
+        # (into one of 16 host arrays in turn: fewer than that many batches are alive between this stage and the step that
+        # consumes them -- eight in the queue behind it, one in each later stage and queue -- and 4 MB arrays allocated and
+        # freed per step are mapped and unmapped by the allocator: `_hip.legacy_randn`)
+        ring = self.__dict__.setdefault("_draw_ring", [[], 0])
+        shape = (self.K * self.nsamples, self.D_)
+        if len(ring[0]) < 16 or ring[0][0].shape != shape:
+            if ring[0] and ring[0][0].shape != shape:
+                ring[0].clear()
+            ring[0].append(np.empty(shape, dtype=np.float32))
+            out = ring[0][-1]
+        else:
+            out = ring[0][ring[1] % 16]
+        ring[1] += 1
+        d = _Draws(self._reference_draws(out))
         return list(batch) + [self._upload_draws(d) if upload else d]
 
     def _upload_draws(self, d):
@@ -335,6 +385,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         state = dict(super().__getstate__())  # sklearn's (adds its version tag)
         state.pop("_mbf", None)
         state.pop("_draw_buffers", None)
+        state.pop("_draw_ring", None)
+        state.pop("_resident_clock", None)
         state.pop("_serve_feats", None)
         state.pop("_draw_upload", None)
         state.pop("_batch_upload", None)
@@ -351,6 +403,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         D, K = m.shape
         L_ = self.nsamples
         lpars_l = atleast_list(lpars)
+        if isinstance(y, _PendingRows) or any(isinstance(a, _PendingRows) for a in largs):  # (no pipeline stage gathered them)
+            y, largs = y.get() if isinstance(y, _PendingRows) else y, tuple(_gathered(largs))
 
         draws, spec = None, None
         gathered = None
@@ -613,6 +667,7 @@ class _ResidentLoop(object):
         pos = self.log_coordinates if self.log_coordinates is not None else np.zeros(len(z0), dtype=bool)
         self.pos = np.asarray(pos, dtype=bool)
         self.t = 0
+        self.clock = []   # host time at which each step was queued (the queue is two deep: it follows the device's pace)
         self._make = lambda M: _hip.ResidentSgd(feats.fm, feats._kids[0].h, g.K, self.n_lik, self.n_ls, z0, lower, upper, self.pos,
                                                 _hip.UPDATER_IDS[kind], par, max(1, int(maxiter)))
         self._z0 = np.array(z0, dtype=float)
@@ -632,6 +687,7 @@ class _ResidentLoop(object):
 
     def step(self, batch):
         g, feats = self.glm, self.feats
+        batch = _gathered(batch)
         y, largs = batch[1], list(batch[2:])
         draws = spec = gathered = None
         while largs and isinstance(largs[-1], (_Draws, _Spec, _Batch)):      # made ahead on the worker (`_ahead`)
@@ -667,6 +723,7 @@ class _ResidentLoop(object):
                 draws = g._reference_draws()
             dE = draws if isinstance(draws, _hip.DeviceBuffer) else feats._stage("E", draws, np.float32)
         self.sgd.step(dX, len(idx), dy, dn, lid, llconst, g.B_, g.nsamples, dE, seed, key)
+        self.clock.append(time.perf_counter())
         if dolog:
             log.info("Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
                      .format(it, -self.sgd.objective(self.t), shown[0], shown[1], shown[2]))
@@ -677,6 +734,8 @@ class _ResidentLoop(object):
         if self.sgd is None:   # no step was taken (maxiter = 0)
             return self._z0, np.empty(0), np.empty(0)
         z, objs, norms = self.sgd.read()
+        self.clock.append(time.perf_counter())
+        self.glm.__dict__["_resident_clock"] = np.array(self.clock)   # (measurement: bench.py, tools/c5_resident.py)
         self.abort()
         return z, objs, norms
 

@@ -264,6 +264,13 @@ def _len_data(data):
     return N
 
 
+def _legacy_permutation(generator, N, out=None):
+    if N < 4096 or not isinstance(generator, np.random.RandomState):
+        return generator.permutation(N)
+    from . import _hip
+    return _hip.legacy_permutation(generator, N, out=out)
+
+
 def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
     """Minibatches by sweeping random permutations of the rows (sgd.py:428-470).
 
@@ -276,12 +283,21 @@ def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
     N = _len_data(data)
     perm, pos = np.empty(0, dtype=int), 0
     it = 0
+    # Long epochs (N >= 16 batches): the permutations go into three arrays in turn instead of a fresh 8 N bytes per epoch -- a
+    # batch is a VIEW of its permutation, and fewer than 16 batches are ever alive at once (the prefetch pipeline's queues).
+    # The allocator maps and unmaps arrays of that size; in a process with hundreds of threads the page faults and TLB
+    # shootdowns of that stalled every thread of config 5's fit for 15-30 ms at each epoch boundary.
+    ring = [np.empty(N, dtype=np.int64) for _ in range(3)] if (N >= 4096 and N >= 16 * batch_size) else None
+    turn = 0
     while it < maxiter:
         it += 1
         parts, need = [], batch_size
         while need > 0:
             if pos == len(perm):
-                perm, pos = generator.permutation(N), 0
+                # (the library's restatement of RandomState.permutation: same values, same state, but outside the GIL -- NumPy's
+                # loop holds it for 18 ms at N = 2M, and the thread consuming the batches stands still with it)
+                perm, pos = _legacy_permutation(generator, N, None if ring is None else ring[turn % 3]), 0
+                turn += 1
             take = min(need, len(perm) - pos)
             parts.append(perm[pos:pos + take])
             pos += take

@@ -478,6 +478,38 @@ def test_library_generator_reproduces_numpy_legacy_randn(dtype):
     assert a.randn() == b.randn()
 
 
+def test_library_generator_reproduces_numpy_legacy_permutation():
+    """rr_legacy_permutation returns what `RandomState.permutation(n)` returns, bit for bit, and leaves the same generator
+    state (position, cached Gaussian): lengths around powers of two (the mask of random_interval changes there), around the
+    block the partners are drawn in, interleaved with randn as the SVI loop interleaves them; and the minibatch stream of
+    `gen_batch` built on it is the stream built on NumPy's own."""
+    from revrand_amd import _hip
+    from revrand_amd import optimize as opt
+    for seed in (0, 77):
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        for n in (4096, 4097, 5000, 8191, 8192, 8193, 65537, 300001):
+            assert a.randn(3).tolist() == b.randn(3).tolist()   # an odd count: a cached Gaussian must survive the call
+            want, got = a.permutation(n), _hip.legacy_permutation(b, n)
+            assert got.dtype == want.dtype and np.array_equal(got, want), (seed, n)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+    assert np.array_equal(_hip.legacy_permutation(np.random.RandomState(3), 100), np.random.RandomState(3).permutation(100))  # short: NumPy's
+    N, M = 10000, 3000   # batches that straddle epoch boundaries
+    ra, rb = np.random.RandomState(5), np.random.RandomState(5)
+    data = [np.arange(N)]
+    ref_perm, pos, want = np.empty(0, dtype=int), 0, []
+    for _ in range(12):
+        parts, need = [], M
+        while need:
+            if pos == len(ref_perm):
+                ref_perm, pos = ra.permutation(N), 0
+            take = min(need, len(ref_perm) - pos)
+            parts.append(ref_perm[pos:pos + take]); pos += take; need -= take
+        want.append(np.concatenate(parts))
+    got = [bt[0] for bt in opt.gen_batch(data, M, 12, rb)]
+    assert all(np.array_equal(u, v) for u, v in zip(got, want)) and ra.randn() == rb.randn()
+
+
 def test_schedule_model_of_the_pipelined_diagonal_block_cholesky():
     """tools/chol_diag_emu.py restates rr_chol_diag_pipe_kernel's schedule in NumPy (slots, early update of the slot that
     holds the next pivot row, deferred rest of the rank-1 update, compile-time column ranges, forward substitution in the

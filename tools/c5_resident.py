@@ -27,9 +27,39 @@ for rep in range(int(os.environ.get("REPS", "2"))):
         g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
                                    K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler)
         g._resident_sgd = resident
+        marks = {"A": [], "B": []}
+        if os.environ.get("STAGES"):   # when did each pipeline stage finish each batch?
+            import gc
+            gc.callbacks.append(lambda phase, info: marks.setdefault("gc", []).append((phase, info.get("generation"), time.perf_counter())))
+            da, ah = g._draw_ahead, g._ahead
+
+            def draw_ahead(batch, upload=False, da=da):
+                t0 = time.perf_counter(); r = da(batch, upload); marks["A"].append((t0, time.perf_counter())); return r
+
+            def ahead(batch, draws=True, ah=ah):
+                t0 = time.perf_counter(); r = ah(batch, draws); marks["B"].append((t0, time.perf_counter())); return r
+            g._draw_ahead, g._ahead = draw_ahead, ahead
         np.random.seed(1)
         t0 = time.perf_counter()
         g.fit(X, y)
         t[iters] = time.perf_counter() - t0
+        ck = g.__dict__.get("_resident_clock")
+        if ck is not None and len(ck) > 40:
+            dt = 1e3 * np.diff(ck[8:])   # (the last interval ends when the queue has drained)
+            print("   %d steps: intervals mean %.3f median %.3f p90 %.3f max %.2f ms; over 5 ms: %s"
+                  % (iters, dt.mean(), np.median(dt), np.percentile(dt, 90), dt.max(),
+                     ["%d:%.1f" % (i + 8, v) for i, v in enumerate(dt) if v > 5.0]))
+            for i, v in enumerate(dt):
+                if v > 10.0 and os.environ.get("STAGES"):
+                    k = i + 8
+                    t_a, t_b = ck[k], ck[k + 1]
+                    print("      stall before step %d queued [%.1f ms]:" % (k + 1, v))
+                    for nm in ("A", "B"):
+                        for q, (u0, u1) in enumerate(marks[nm]):
+                            if u1 > t_a - 0.005 and u0 < t_b + 0.005:
+                                print("        stage %s batch %d: start %+.1f ms, took %.1f ms" % (nm, q, 1e3 * (u0 - t_a), 1e3 * (u1 - u0)))
+                    for ph, gen, tt in marks.get("gc", []):
+                        if t_a - 0.005 < tt < t_b + 0.005:
+                            print("        gc %s gen %s at %+.1f ms" % (ph, gen, 1e3 * (tt - t_a)))
     print("%s sampler, %s: %.3f ms per step (fits of %d and %d steps: %.3f s, %.3f s)"
           % (sampler, "resident loop" if resident else "host loop", 1e3 * (t[long_] - t[short]) / (long_ - short), short, long_, t[short], t[long_]))
