@@ -1454,6 +1454,7 @@ struct FmPass2 {
         double *dT = nullptr;
         bool armed = false;  // planned, not yet consumed by a step
         bool done = false;   // the last step accumulated dT itself: rr_featmat_glm_rff for this child has nothing left to do
+        bool take = false, take_lik = false;  // glm_pipeline's decisions of its first phase, for the later ones
     } fuse;
 };
 
@@ -2554,98 +2555,107 @@ static int glm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int6
 }
 
 // With WSs (kl_ld, Fp) = ws / (K L) on the device: fs, likelihood derivatives and sums, Ed = dfs Phi, EdPhi.
+// phases: 1 = fs and the likelihood kernel (dfs), 2 = Ed = dfs Phi, 4 = EdPhi (stored, or contracted with the planned random
+// Fourier child) -- 7: all three in this order; the resident SVI loop runs 1, 4, 2 as separate calls (the length scales'
+// gradient first, so that the next step's features can be made while Ed is formed).
 static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *drowarg, int dtype, int lik,
-                        double lik_param, int K, int L, bool objective_only = false, const double *par_dev = nullptr) {
+                        double lik_param, int K, int L, bool objective_only = false, const double *par_dev = nullptr,
+                        int phases = 7) {
     rr_ctx *c = fm->ctx;
     const int KL = K * L;
     const int64_t Fp = fm->ld, kl_ld = s.klp;
     const int64_t rows256 = (fm->rows + 255) / 256 * 256;
-    // a plan is good for one step; it is taken when the whole matrix is that child's [cos | sin] block in whole tiles
-    // (RR_GLM_NO_FUSE=1: never -- the EdPhi GEMM and rr_glm_grad_t_kernel as separate passes, for A/B runs)
-    const char *nf = getenv("RR_GLM_NO_FUSE");
-    const bool no_fuse = nf && atoi(nf) != 0;
-    const bool fuse = s.fuse.armed && !objective_only && !no_fuse && c->gram_engine == 0 && !c->deterministic &&
+    int rc = RR_OK;
+    if (phases & 1) {
+        // a plan is good for one step; it is taken when the whole matrix is that child's [cos | sin] block in whole tiles
+        // (RR_GLM_NO_FUSE=1: never -- the EdPhi GEMM and rr_glm_grad_t_kernel as separate passes, for A/B runs)
+        const char *nf = getenv("RR_GLM_NO_FUSE");
+        const bool no_fuse = nf && atoi(nf) != 0;
+        s.fuse.take = s.fuse.armed && !objective_only && !no_fuse && c->gram_engine == 0 && !c->deterministic &&
                       s.fuse.col0 == 0 && 2 * (int64_t)s.fuse.b->n == fm->F && fm->F == Fp && s.fuse.b->n % 256 == 0 &&
                       s.fuse.b->d <= 128 && Fp < (1 << 21) && s.fuse.ldx < (1 << 21);
-    s.fuse.armed = false;
-    s.fuse.done = false;
-    RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
-    // WSt (Fp, kl_ld) = WSs^T (the 1 / (K L) scale is undone in the likelihood kernel's read of fs)
-    hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
-                       s.WSs, kl_ld, Fp, s.WSt, kl_ld);
-    // Pt = P^T (unless every child wrote its block of it while writing P: rr_featmat_put_rff);  FSt (rows256, kl) = P WS^T
-    if (!(fm->pt_rows == fm->rows && fm->pt_covered >= fm->F)) {
-        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
-                           fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
-        fm->pt_rows = fm->rows;  // P^T's padding is now laid out for this row count
-    }
-    int rc = RR_OK;
-    // With enough output tiles to fill the chip without a K-split, the product's epilogue IS the likelihood kernel and
-    // stores dfs in both layouts (rr_gemm_lik_f32_kernel); RR_GLM_FUSE_LIK=force takes that route for any shape (tests).
-    const char *fl = getenv("RR_GLM_FUSE_LIK");
-    const int64_t tiles1 = (rows256 / 256) * (kl_ld / 256);
-    const bool lik_force = fl && !strcmp(fl, "force"), lik_off = fl && !strcmp(fl, "0");
-    const bool lik_auto = tiles1 >= 2 * (int64_t)c->num_cu || Fp / GR_KB < 16;  // (fm_gemm would not split K)
-    const bool fuse_lik = !no_fuse && c->gram_engine == 0 && !c->deterministic && !lik_off && (lik_force || lik_auto) &&
+        s.fuse.armed = false;
+        s.fuse.done = false;
+        RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, c->stream));
+        // WSt (Fp, kl_ld) = WSs^T (the 1 / (K L) scale is undone in the likelihood kernel's read of fs)
+        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(kl_ld / 64)), dim3(256), 0, c->stream,
+                           s.WSs, kl_ld, Fp, s.WSt, kl_ld);
+        // Pt = P^T (unless every child wrote its block of it while writing P: rr_featmat_put_rff);  FSt (rows256, kl) = P WS^T
+        if (!(fm->pt_rows == fm->rows && fm->pt_covered >= fm->F)) {
+            hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(Fp / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                               fm->P, fm->rows, Fp, s.Pt, fm->max_rows);
+            fm->pt_rows = fm->rows;  // P^T's padding is now laid out for this row count
+        }
+        // With enough output tiles to fill the chip without a K-split, the product's epilogue IS the likelihood kernel and
+        // stores dfs in both layouts (rr_gemm_lik_f32_kernel); RR_GLM_FUSE_LIK=force takes that route for any shape (tests).
+        const char *fl = getenv("RR_GLM_FUSE_LIK");
+        const int64_t tiles1 = (rows256 / 256) * (kl_ld / 256);
+        const bool lik_force = fl && !strcmp(fl, "force"), lik_off = fl && !strcmp(fl, "0");
+        const bool lik_auto = tiles1 >= 2 * (int64_t)c->num_cu || Fp / GR_KB < 16;  // (fm_gemm would not split K)
+        s.fuse.take_lik = !no_fuse && c->gram_engine == 0 && !c->deterministic && !lik_off && (lik_force || lik_auto) &&
                           fm->max_rows < (1 << 20) && kl_ld < (1 << 20);
-    if (fuse_lik) {
-        GemmLikArgs g;
-        g.A = s.Pt; g.lda = fm->max_rows; g.B = s.WSt; g.ldb = kl_ld; g.K = (int)Fp; g.ntb = (int)(kl_ld / 256);
-        g.D = objective_only ? nullptr : s.FSt; g.ldd = kl_ld;
-        g.Dt = objective_only ? nullptr : s.DFS; g.ldt = fm->max_rows;
-        g.y = dy; g.rowarg = drowarg; g.y_f64 = dtype == RR_F64; g.M = fm->rows;
-        g.par = (float)lik_param; g.fscale = (float)KL; g.KL = KL; g.L = L; g.llsum = s.kacc; g.aux = s.kacc + s.kcap;
-        g.par_dev = par_dev;
+        if (s.fuse.take_lik) {
+            GemmLikArgs g;
+            g.A = s.Pt; g.lda = fm->max_rows; g.B = s.WSt; g.ldb = kl_ld; g.K = (int)Fp; g.ntb = (int)(kl_ld / 256);
+            g.D = objective_only ? nullptr : s.FSt; g.ldd = kl_ld;
+            g.Dt = objective_only ? nullptr : s.DFS; g.ldt = fm->max_rows;
+            g.y = dy; g.rowarg = drowarg; g.y_f64 = dtype == RR_F64; g.M = fm->rows;
+            g.par = (float)lik_param; g.fscale = (float)KL; g.KL = KL; g.L = L; g.llsum = s.kacc; g.aux = s.kacc + s.kcap;
+            g.par_dev = par_dev;
 #define RR_GL(ID, ST) hipLaunchKernelGGL((rr_gemm_lik_f32_kernel<ID, ST>), dim3((unsigned)tiles1), dim3(GR_THREADS), 0, c->stream, g)
 #define RR_GLS(ID)                         \
     if (objective_only) RR_GL(ID, false);  \
     else RR_GL(ID, true)
-        switch (lik) {
-            case RR_LIK_BERNOULLI: RR_GLS(RR_LIK_BERNOULLI); break;
-            case RR_LIK_BINOMIAL: RR_GLS(RR_LIK_BINOMIAL); break;
-            case RR_LIK_GAUSSIAN: RR_GLS(RR_LIK_GAUSSIAN); break;
-            case RR_LIK_POISSON_EXP: RR_GLS(RR_LIK_POISSON_EXP); break;
-            default: RR_GLS(RR_LIK_POISSON_SOFTPLUS); break;
-        }
+            switch (lik) {
+                case RR_LIK_BERNOULLI: RR_GLS(RR_LIK_BERNOULLI); break;
+                case RR_LIK_BINOMIAL: RR_GLS(RR_LIK_BINOMIAL); break;
+                case RR_LIK_GAUSSIAN: RR_GLS(RR_LIK_GAUSSIAN); break;
+                case RR_LIK_POISSON_EXP: RR_GLS(RR_LIK_POISSON_EXP); break;
+                default: RR_GLS(RR_LIK_POISSON_SOFTPLUS); break;
+            }
 #undef RR_GLS
 #undef RR_GL
-        RR_CHECK_HIP(hipGetLastError());
-    } else {
-        rc = glm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+            RR_CHECK_HIP(hipGetLastError());
+        } else {
+            rc = glm_gemm(c, s.Pt, fm->max_rows, s.WSt, kl_ld, s.FSt, kl_ld, Fp, rows256, kl_ld);
+            if (rc != RR_OK) return rc;
+            // dfs in place + per-component reductions
+            if (dtype == RR_F32)
+                glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap, par_dev);
+            else
+                glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap, par_dev);
+            RR_CHECK_HIP(hipGetLastError());
+        }
+        if (objective_only) {  // the log-likelihood sums are all the objective needs: no gradient GEMMs
+            s.have_edphi = false;
+            return RR_OK;
+        }
+    }
+    if (phases & 2) {  // Ed (kl, Fp) = dfs Phi
+        rc = glm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
         if (rc != RR_OK) return rc;
-        // dfs in place + per-component reductions
-        if (dtype == RR_F32)
-            glm_launch_lik<float>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap, par_dev);
-        else
-            glm_launch_lik<double>(c, lik, s.FSt, fm->rows, rows256, kl_ld, dy, drowarg, (float)lik_param, KL, L, s.kacc, s.kacc + s.kcap, par_dev);
-        RR_CHECK_HIP(hipGetLastError());
     }
-    if (objective_only) {  // the log-likelihood sums are all the objective needs: no gradient GEMMs
-        s.have_edphi = false;
-        return RR_OK;
+    if (phases & 4) {
+        // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
+        if (!s.fuse.take_lik)
+            hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
+                               s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
+        if (s.fuse.take) {  // ... or contracted with the one random Fourier child block by block, without ever reaching HBM
+            GradtArgs g;
+            g.A = s.DFS; g.lda = fm->max_rows; g.B = s.WSs; g.ldb = Fp; g.K = (int)kl_ld;
+            g.ntb = (int)(Fp / 256); g.nta = (int)(rows256 / 256);
+            g.P = fm->P; g.ldp = Fp; g.X = (const float *)s.fuse.dX; g.ldx = s.fuse.ldx; g.rows = fm->rows;
+            g.n = s.fuse.b->n; g.d = s.fuse.b->d; g.T = s.fuse.dT;
+            rc = launch_gemm_gradt(c, g);
+            if (rc != RR_OK) return rc;
+            s.have_edphi = false;
+            s.fuse.done = true;
+        } else {
+            rc = glm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
+            if (rc != RR_OK) return rc;
+            s.have_edphi = true;
+        }
     }
-    // Ed (kl, Fp) = dfs Phi
-    rc = glm_gemm(c, s.FSt, kl_ld, fm->P, Fp, s.Ed, Fp, rows256, kl_ld, Fp);
-    if (rc != RR_OK) return rc;
-    // EdPhi (rows256, Fp) = dfs^T ws / (K L), kept in U for the gradient contraction
-    if (!fuse_lik)
-        hipLaunchKernelGGL(rr_transpose_f32_kernel, dim3((unsigned)(kl_ld / 64), (unsigned)(rows256 / 64)), dim3(256), 0, c->stream,
-                           s.FSt, rows256, kl_ld, s.DFS, fm->max_rows);
-    if (fuse) {  // ... or contracted with the one random Fourier child block by block, without ever reaching HBM
-        GradtArgs g;
-        g.A = s.DFS; g.lda = fm->max_rows; g.B = s.WSs; g.ldb = Fp; g.K = (int)kl_ld;
-        g.ntb = (int)(Fp / 256); g.nta = (int)(rows256 / 256);
-        g.P = fm->P; g.ldp = Fp; g.X = (const float *)s.fuse.dX; g.ldx = s.fuse.ldx; g.rows = fm->rows;
-        g.n = s.fuse.b->n; g.d = s.fuse.b->d; g.T = s.fuse.dT;
-        rc = launch_gemm_gradt(c, g);
-        if (rc != RR_OK) return rc;
-        s.have_edphi = false;
-        s.fuse.done = true;
-        return RR_OK;
-    }
-    rc = glm_gemm(c, s.DFS, fm->max_rows, s.WSs, Fp, s.U, Fp, kl_ld, rows256, Fp);
-    if (rc != RR_OK) return rc;
-    s.have_edphi = true;
     return RR_OK;
 }
 
@@ -2911,6 +2921,10 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
 // Nothing is read back and the host never waits for a step: it queues step t while t - 1 runs (at most two in flight: the
 // caller's minibatch buffers are reused in turn).  Float64 throughout, multiply-add contraction off: the arithmetic of the
 // NumPy expressions it stands for, reduction order aside.
+// Order within a step, and the second stream: the length scales' gradient comes from the EdPhi product alone, (m, C)'s from
+// Ed = dfs Phi.  So the step runs fs -> EdPhi (contracted) -> the LENGTH SCALES' update -> Ed -> the rest of the update, and as
+// soon as the length scales of step t + 1 exist its features (an HBM-write-bound 0.2 ms at config 5) are made on a second
+// stream into the OTHER of two feature matrices while the matrix cores form step t's Ed.
 // =============================================================================================
 #define RR_SGD_MAXK 32
 
@@ -2923,10 +2937,15 @@ struct rr_glm_sgd {
     double *z = nullptr, *x = nullptr, *s1 = nullptr, *s2 = nullptr, *lower = nullptr, *upper = nullptr;
     unsigned char *islog = nullptr;
     double *red = nullptr;    // [Q (K, K) | R | H (d)]
-    double *npart = nullptr;  // |grad|^2 per block of the update kernel
+    double *npart = nullptr;  // |grad|^2 per block of the update kernel: [main blocks | length-scale blocks]
     double *objs = nullptr, *norms = nullptr;
     double *dT = nullptr;     // (d, n): X^T (E_s o P_c - E_c o P_s) of the step
     hipEvent_t ev[2] = {nullptr, nullptr};
+    rr_featmat *fm2 = nullptr;                  // steps alternate between fm and fm2 (owned)
+    hipStream_t sfeat = nullptr;                // features of the next step
+    hipEvent_t e_ls[2] = {nullptr, nullptr};    // step t's length scales are updated (recorded on the context's stream)
+    hipEvent_t e_feat[2] = {nullptr, nullptr};  // step t's features are in its matrix (recorded on s1)
+    bool overlap = true;                        // RR_GLM_SGD_OVERLAP=0: one stream, one matrix (A/B runs)
 };
 
 __global__ void __launch_bounds__(256)
@@ -2950,12 +2969,12 @@ __device__ __forceinline__ double rr_block_sum256(double v, double *sh) {  // fi
 
 __global__ void __launch_bounds__(256)
 rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, const double *__restrict__ T, const double *__restrict__ W,
-                       int n, int nh, double *__restrict__ red) {
+                       int n, int nh, double *__restrict__ red, int first_block) {
 #pragma clang fp contract(off)
     __shared__ double sh[256];
     const int npairs = K * (K + 1) / 2, tid = threadIdx.x;
     const int64_t fk = (int64_t)F * K;
-    int bid = blockIdx.x;
+    int bid = blockIdx.x + first_block;  // blocks [0, npairs]: the mixture's sums; (npairs, npairs + nh]: the length scales'
     double acc = 0.0;
     if (bid < npairs) {  // sum_f log(C_fk + C_fl) + (m_fk - m_fl)^2 / (C_fk + C_fl)
         int k = 0;
@@ -2990,7 +3009,7 @@ struct SgdUpdArgs {
     const unsigned char *islog;
     double *z, *s1, *s2, *npart;
     int F, K, n_lik, n_ls, updater, L;
-    int64_t np;
+    int64_t np, p0, p1;  // all coordinates; this launch's are [p0, p1)
     double bmag, nrows, up[4], b1t, b2t;
 };
 
@@ -2999,24 +3018,26 @@ __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs
     __shared__ double logN[RR_SGD_MAXK * RR_SGD_MAXK], alpha[RR_SGD_MAXK * RR_SGD_MAXK], logz[RR_SGD_MAXK], sh[256];
     const int tid = threadIdx.x, K = a.K, F = a.F;
     const int64_t fk = (int64_t)F * K;
-    for (int i = tid; i < K * K; i += 256) logN[i] = -0.5 * ((double)F * 1.8378770664093453 + a.red[i]);  // log(2 pi)
-    __syncthreads();
-    if (tid < K) {  // logsumexp over the first index (glm.py:222)
-        double mx = -INFINITY;
-        for (int j = 0; j < K; ++j) mx = fmax(mx, logN[j * K + tid]);
-        double sm = 0.0;
-        for (int j = 0; j < K; ++j) sm += exp(logN[j * K + tid] - mx);
-        logz[tid] = log(sm) + mx;
+    if (a.p0 < 2 * fk) {  // (a launch over the length scales alone needs none of the mixture's terms)
+        for (int i = tid; i < K * K; i += 256) logN[i] = -0.5 * ((double)F * 1.8378770664093453 + a.red[i]);  // log(2 pi)
+        __syncthreads();
+        if (tid < K) {  // logsumexp over the first index (glm.py:222)
+            double mx = -INFINITY;
+            for (int j = 0; j < K; ++j) mx = fmax(mx, logN[j * K + tid]);
+            double sm = 0.0;
+            for (int j = 0; j < K; ++j) sm += exp(logN[j * K + tid] - mx);
+            logz[tid] = log(sm) + mx;
+        }
+        __syncthreads();
+        for (int i = tid; i < K * K; i += 256) {
+            const int k = i / K, l = i % K;
+            alpha[i] = exp(logN[l * K + k] - logz[k]) + exp(logN[l * K + k] - logz[l]);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int i = tid; i < K * K; i += 256) {
-        const int k = i / K, l = i % K;
-        alpha[i] = exp(logN[l * K + k] - logz[k]) + exp(logN[l * K + k] - logz[l]);
-    }
-    __syncthreads();
-    const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+    const int64_t p = a.p0 + (int64_t)blockIdx.x * 256 + tid;
     double g = 0.0;
-    const bool live = p < a.np;
+    const bool live = p < a.p1;
     if (live) {
         const double reg = a.x[2 * fk], iL = 1.0 / reg;
         if (p < 2 * fk) {
@@ -3120,8 +3141,10 @@ static void sgd_free(rr_glm_sgd *o) {
     void *q[] = {o->z, o->x, o->s1, o->s2, o->lower, o->upper, o->islog, o->red, o->npart, o->objs, o->norms, o->dT};
     for (void *v : q)
         if (v) (void)hipFree(v);
-    for (hipEvent_t e : o->ev)
+    for (hipEvent_t e : {o->ev[0], o->ev[1], o->e_ls[0], o->e_ls[1], o->e_feat[0], o->e_feat[1]})
         if (e) (void)hipEventDestroy(e);
+    if (o->sfeat) (void)hipStreamDestroy(o->sfeat);
+    if (o->fm2) rr_featmat_destroy(o->fm2);
     delete o;
 }
 
@@ -3148,7 +3171,9 @@ int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, c
     o->np = 2 * o->fk + 1 + n_lik + n_ls;
     o->maxiter = maxiter;
     for (int i = 0; i < 4; ++i) o->up[i] = upd_par[i];
-    const size_t nb = (size_t)o->np * 8, nblocks = (size_t)((o->np + 255) / 256);
+    const size_t nb = (size_t)o->np * 8, nblocks = (size_t)((o->np + 255) / 256) + 1;  // (main and length-scale launches)
+    const char *ov = getenv("RR_GLM_SGD_OVERLAP");
+    o->overlap = !(ov && atoi(ov) == 0);
     hipError_t e = hipMalloc((void **)&o->z, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->x, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->s1, nb);
@@ -3163,11 +3188,23 @@ int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, c
     if (e == hipSuccess) e = hipMalloc((void **)&o->dT, (size_t)b->d * b->n * 8);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[1], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipEventCreateWithFlags(&o->e_ls[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&o->e_feat[i], hipEventDisableTiming);
+    }
+    if (e == hipSuccess && o->overlap) e = hipStreamCreateWithFlags(&o->sfeat, hipStreamNonBlocking);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         sgd_free(o);
         rr_set_error("rr_glm_sgd_create: device allocation failed");
         return RR_ERR_OOM;
+    }
+    if (o->overlap) {
+        const int rc2 = rr_featmat_create(c, fm->max_rows, fm->F, &o->fm2);
+        if (rc2 != RR_OK) {
+            sgd_free(o);
+            return rc2;
+        }
     }
     hipError_t h = hipStreamSynchronize(c->stream);
     if (h == hipSuccess) h = hipMemcpy(o->z, z0, nb, hipMemcpyHostToDevice);
@@ -3200,16 +3237,33 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *dX, int x_dtype, int64_t ldx, int
     RR_CHECK_HIP(hipSetDevice(c->device));
     const int K = o->K, F = o->F;
     const int64_t fk = o->fk;
-    // at most two steps in flight: the event of step t - 2
+    // at most two steps in flight: the event of step t - 2 (which also was the last user of this step's feature matrix)
     if (o->t >= 2) RR_CHECK_HIP(hipEventSynchronize(o->ev[o->t & 1]));
-    const unsigned nblocks = (unsigned)((o->np + 255) / 256);
-    hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nblocks), dim3(256), 0, c->stream, o->z, o->islog, o->np, o->x);
+    const int par = (int)(o->t & 1);
+    if (o->overlap && par) fm = o->fm2;
+    const int64_t n_main = 2 * fk + 1 + o->n_lik;
+    const unsigned nb_main = (unsigned)((n_main + 255) / 256), nb_ls = (unsigned)((o->n_ls + 255) / 256);
+    const double *xls = o->x + n_main, *xpar = o->n_lik ? o->x + 2 * fk + 1 : nullptr;
+    int rc = RR_OK;
+    // ---- this step's features: after the previous step's length-scale update, on the second stream, into this step's
+    //      matrix -- while the previous step's Ed product runs on the first
+    hipStream_t s0 = c->stream, sf = o->overlap ? o->sfeat : s0;
+    if (o->overlap && o->t >= 1) RR_CHECK_HIP(hipStreamWaitEvent(sf, o->e_ls[1 - par], 0));
+    c->stream = sf;  // (every launch helper below reads the context's stream when it is called)
+    hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, sf, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
+                       o->x + n_main);
+    rc = rr_featmat_begin(fm, rows);
+    if (rc == RR_OK) rc = rr_fm_put_rff_dev(fm, o->b, dX, x_dtype, ldx, xls, o->n_ls, 0);
+    c->stream = s0;
+    if (rc != RR_OK) return rc;
     RR_CHECK_HIP(hipGetLastError());
-    const double *xls = o->x + 2 * fk + 1 + o->n_lik, *xpar = o->n_lik ? o->x + 2 * fk + 1 : nullptr;
-    int rc = rr_featmat_begin(fm, rows);
-    if (rc != RR_OK) return rc;
-    rc = rr_fm_put_rff_dev(fm, o->b, dX, x_dtype, ldx, xls, o->n_ls, 0);
-    if (rc != RR_OK) return rc;
+    if (o->overlap) {
+        RR_CHECK_HIP(hipEventRecord(o->e_feat[par], sf));
+        RR_CHECK_HIP(hipStreamWaitEvent(s0, o->e_feat[par], 0));
+    }
+    // ---- the step proper
+    hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_main), dim3(256), 0, s0, o->z, o->islog, n_main, o->x);
+    RR_CHECK_HIP(hipGetLastError());
     rc = glm_step_checks(fm, dy, drowarg, dtype, lik, 1.0, K, L, "rr_glm_sgd_step");
     if (rc != RR_OK) return rc;
     const int KL = K * L;
@@ -3218,36 +3272,46 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *dX, int x_dtype, int64_t ldx, int
     if (rc != RR_OK) return rc;
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     const int64_t kl_ld = s.klp;
-    RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->b->d * o->b->n * 8, c->stream));
+    RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->b->d * o->b->n * 8, s0));
     rc = rr_featmat_glm_plan_rff(fm, o->b, dX, x_dtype, ldx, 0, o->dT);
     if (rc != RR_OK) return rc;
-    hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, c->stream, o->x, o->x + fk, F, K,
+    hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, s0, o->x, o->x + fk, F, K,
                        L, Fp, kl_ld, seed, key, dE, s.Ee, s.WSs);
     RR_CHECK_HIP(hipGetLastError());
-    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar);
+    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 1);      // fs, likelihood terms
+    if (rc == RR_OK) rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 4);  // EdPhi, contracted or stored
     if (rc != RR_OK) return rc;
-    double *Edm = s.mc + 2 * fk, *EdC = s.mc + 3 * fk;
-    hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, c->stream, s.Ed, s.Ee, o->x + fk, F, K,
-                       L, Fp, Edm, EdC);
-    RR_CHECK_HIP(hipGetLastError());
     rc = rr_featmat_glm_rff(fm, o->b, dX, x_dtype, ldx, 0, o->dT);  // (returns at once when the step contracted EdPhi itself)
     if (rc != RR_OK) return rc;
-    const int nh = o->n_ls == 1 ? 1 : o->b->d;
-    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)(K * (K + 1) / 2 + 1 + nh)), dim3(256), 0, c->stream, o->x, F, K, o->dT,
-                       o->b->dWraw, o->b->n, nh, o->red);
-    RR_CHECK_HIP(hipGetLastError());
     SgdUpdArgs a;
+    double *Edm = s.mc + 2 * fk, *EdC = s.mc + 3 * fk;
     a.x = o->x; a.red = o->red; a.Edm = Edm; a.EdC = EdC; a.aux = s.kacc + s.kcap; a.lower = o->lower; a.upper = o->upper;
-    a.islog = o->islog; a.z = o->z; a.s1 = o->s1; a.s2 = o->s2; a.npart = o->npart;
+    a.islog = o->islog; a.z = o->z; a.s1 = o->s1; a.s2 = o->s2;
     a.F = F; a.K = K; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = L; a.np = o->np;
     a.bmag = bmag; a.nrows = (double)rows;
     for (int i = 0; i < 4; ++i) a.up[i] = o->up[i];
     const double tt = (double)(o->t + 1);
     a.b1t = 1.0 - pow(o->up[1], tt);
     a.b2t = 1.0 - pow(o->up[2], tt);
-    hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nblocks), dim3(256), 0, c->stream, a);
+    // the length scales: W[i,:].T[i,:], their gradient, their update -- and the next step's features may start
+    const int nh = o->n_ls == 1 ? 1 : o->b->d, npairs = K * (K + 1) / 2;
+    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)nh), dim3(256), 0, s0, o->x, F, K, o->dT, o->b->dWraw, o->b->n, nh,
+                       o->red, npairs + 1);
+    a.p0 = n_main; a.p1 = o->np; a.npart = o->npart + nb_main;
+    hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_ls), dim3(256), 0, s0, a);
     RR_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(rr_glm_sgd_finish_kernel, dim3(1), dim3(256), 0, c->stream, o->x, o->red, s.kacc, o->npart, (int)nblocks, F, K, L,
+    RR_CHECK_HIP(hipEventRecord(o->e_ls[par], s0));
+    // Ed = dfs Phi, its reductions over the samples, the mixture's sums, the update of (m, C, reg, variance)
+    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 2);
+    if (rc != RR_OK) return rc;
+    hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, s0, s.Ed, s.Ee, o->x + fk, F, K,
+                       L, Fp, Edm, EdC);
+    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)(npairs + 1)), dim3(256), 0, s0, o->x, F, K, o->dT, o->b->dWraw, o->b->n,
+                       nh, o->red, 0);
+    a.p0 = 0; a.p1 = n_main; a.npart = o->npart;
+    hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_main), dim3(256), 0, s0, a);
+    RR_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(rr_glm_sgd_finish_kernel, dim3(1), dim3(256), 0, s0, o->x, o->red, s.kacc, o->npart, (int)(nb_main + nb_ls), F, K, L,
                        o->n_lik, llconst, (double)rows, bmag, o->objs + o->t, o->norms + o->t);
     RR_CHECK_HIP(hipGetLastError());
     RR_CHECK_HIP(hipEventRecord(o->ev[o->t & 1], c->stream));
