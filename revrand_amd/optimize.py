@@ -271,7 +271,7 @@ def _legacy_permutation(generator, N, out=None):
     return _hip.legacy_permutation(generator, N, out=out)
 
 
-def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
+def gen_batch(data, batch_size, maxiter=np.inf, random_state=None, _reuse=False):
     """Minibatches by sweeping random permutations of the rows (sgd.py:428-470).
 
     The index stream is exactly ``endless_permutations`` (utils/rand.py:7-31) -- a new ``permutation(N)`` is drawn
@@ -287,7 +287,8 @@ def gen_batch(data, batch_size, maxiter=np.inf, random_state=None):
     # batch is a VIEW of its permutation, and fewer than 16 batches are ever alive at once (the prefetch pipeline's queues).
     # The allocator maps and unmaps arrays of that size; in a process with hundreds of threads the page faults and TLB
     # shootdowns of that stalled every thread of config 5's fit for 15-30 ms at each epoch boundary.
-    ring = [np.empty(N, dtype=np.int64) for _ in range(3)] if (N >= 4096 and N >= 16 * batch_size) else None
+    # (`_reuse`: only for a consumer that holds fewer than 16 batches at a time -- `sgd`; anybody else may keep every batch)
+    ring = [np.empty(N, dtype=np.int64) for _ in range(3)] if (_reuse and N >= 4096 and N >= 16 * batch_size) else None
     turn = 0
     while it < maxiter:
         it += 1
@@ -411,7 +412,7 @@ def sgd(fun, x0, data, args=(), bounds=None, batch_size=10, maxiter=5000, update
         lower = np.array([-np.inf if b[0] is None else b[0] for b in bounds], dtype=float)
         upper = np.array([np.inf if b[1] is None else b[1] for b in bounds], dtype=float)
     obj, objs, norms = None, [], []
-    batches = gen_batch(data, batch_size, maxiter, random_state)
+    batches = gen_batch(data, batch_size, maxiter, random_state, _reuse=True)
     ahead = _prefetched(batches, prefetch if (callable(prefetch) or isinstance(prefetch, (list, tuple))) else None) if prefetch else None
     if device_loop is not None:
         if bounds is None:

@@ -508,6 +508,40 @@ def test_library_generator_reproduces_numpy_legacy_permutation():
         want.append(np.concatenate(parts))
     got = [bt[0] for bt in opt.gen_batch(data, M, 12, rb)]
     assert all(np.array_equal(u, v) for u, v in zip(got, want)) and ra.randn() == rb.randn()
+    # long epochs under `sgd`: the permutations go into three arrays in turn, and a batch of an index-like data item (the
+    # GLM's resident fit) is a VIEW of its permutation -- through a prefetch pipeline that holds its full complement of batches
+    # (eight behind the first stage, one in and behind the second) every batch still arrives intact, epoch after epoch
+    from revrand_amd.glm import _RowIndex
+    N, M, steps = 70000, 4096, 75   # 17 batches per epoch, 4.4 epochs
+    ra = np.random.RandomState(8)
+    ref_perm, pos, want = np.empty(0, dtype=int), 0, []
+    for _ in range(steps):
+        parts, need = [], M
+        while need:
+            if pos == len(ref_perm):
+                ref_perm, pos = ra.permutation(N), 0
+            take = min(need, len(ref_perm) - pos)
+            parts.append(ref_perm[pos:pos + take]); pos += take; need -= take
+        want.append(np.concatenate(parts))
+
+    class Loop(object):
+        def begin(self, *a):
+            self.seen = []
+
+        def step(self, batch):
+            import time
+            time.sleep(0.002)   # a slow consumer: the queues fill up
+            self.seen.append(np.array(batch[0], copy=True))
+
+        def end(self):
+            return np.zeros(1), np.zeros(len(self.seen)), np.zeros(len(self.seen))
+
+        def abort(self):
+            pass
+    loop = Loop()
+    opt.sgd(None, np.zeros(1), [_RowIndex(N)], batch_size=M, maxiter=steps, random_state=np.random.RandomState(8),
+            prefetch=[lambda bt: list(bt), lambda bt: list(bt)], device_loop=loop)
+    assert len(loop.seen) == steps and all(np.array_equal(u, v) for u, v in zip(loop.seen, want))
 
 
 def test_schedule_model_of_the_pipelined_diagonal_block_cholesky():
