@@ -295,7 +295,9 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
     device r % visible GPUs, 8-way file rendezvous, one RCCL all-reduce per step) -- with fewer rows than BASELINE's: after the
     headline the ranks time BASELINE config 3 (RandomMatern52 + LinearBasis, F_tot = 8257, the 273 MB exchange) and the
     RandomRBF F = 4096 `_elbo`, rows sharded (slm.py:142-199 over all shards), every stage on the ranks' clocks."""
-    r = _bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", "800000", "--dist-rows", "48000"])
+    # (world 4: half the rows -- the suite's budget; the 8-way run keeps the larger shapes)
+    rows, drows = (800000, 48000) if world == 8 else (400000, 24000)
+    r = _bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--rows", str(rows), "--dist-rows", str(drows)])
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -305,7 +307,7 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
     assert out["n_gpus"] == world == out["exchange"]["ranks_rccl_reports"]
     assert out["config"]["trace_rel_err"] < 1e-6
     assert out["exchange"]["message_bytes"] == 8 * (F * (F + 1) // 2 + F + 2)
-    assert out["config"]["rows_per_gpu"] == 800000 // world and out["scaling"] == "strong" and out["value"] > 0
+    assert out["config"]["rows_per_gpu"] == rows // world and out["scaling"] == "strong" and out["value"] > 0
     pr = out["per_rank"]
     kmax, kmin = pr["kernel_ms_per_step_max_min_over_ranks"]
     assert kmax >= kmin > 0 and pr["kernel_ms_per_step_sum_over_ranks"] >= kmax
@@ -317,12 +319,12 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
     for name, Ft in (("C3_matern52_linear_dist", 8257), ("elbo_rbf_f4096_dist", 4096)):
         c = out["configs"][name]
         assert "error" not in c, c
-        assert c["rows"] == 48000 and c["rows_per_gpu"] == 48000 // world and c["F"] == Ft
+        assert c["rows"] == drows and c["rows_per_gpu"] == drows // world and c["F"] == Ft
         assert c["exchange_bytes"] == 8 * (Ft * (Ft + 1) // 2 + Ft + 2)
         st = c["stage_ms"]
         assert all(st[k] > 0 for k in ("statistics", "exchange", "posterior", "second_pass")) and c["ms"] > 0
         par = c["parity"]
-        assert par["N_total"] == 48000 and par["G_symmetric"] and par["ranks_identical"]
+        assert par["N_total"] == drows and par["G_symmetric"] and par["ranks_identical"]
         assert par["trace_fourier_block"] < 1e-5 and par["neg_elbo_256_rows"] < 1e-5 and par["gradient_256_rows"] < 1e-3
         assert 0 < c["roofline"]["frac"] < 1 and c["speedup_model"]["speedup"] > 0
     # the preflight: where every rank's GPU sits, config 3's message through the communicator before anything is timed
