@@ -341,35 +341,50 @@ int rr_featmat_glm_edphi(rr_featmat *fm, int64_t col0, int64_t ncols, double *E)
 int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
 
 /* ---- the SVI loop of GeneralizedLinearModel.fit with its parameters resident (round 5) ----------------------------
- * Replaces, for a model whose basis is ONE random Fourier basis (Xdim <= 128) and whose minibatches are gathered on the
- * device, the host loop  sgd (optimize/sgd.py:337-425)  o  logtrick_sgd (optimize/decorators.py:329-408)  o
- * structured_sgd (:133-252)  around  GeneralizedLinearModel._elbo (glm.py:205-294):  the flat parameter vector
- *     z = [ m (F, K) | C (F, K) | regulariser | likelihood parameter (n_lik = 1: the Gaussian variance) | length scales ]
- * (row-major blocks in the order of glm.py:170-176; coordinates with is_log != 0 are log(x), the log trick's Positive
- * coordinates), the updater's state, the gradient and every intermediate stay in HBM.  One rr_glm_sgd_step call queues a
- * whole step -- x = from_log(z), the basis rescaled by the length scales in x, Phi of the minibatch rows dX, the step of
- * rr_featmat_glm_step_draws_dev / _sampled with (m, C) read from x, the length-scale contraction, the mixture terms
- * (glm.py:238-262), the gradient (:255-283), the chain rule of the log trick, bound truncation + updater + clip
- * (sgd.py:404-420), the step's -ELBO (glm.py:285-292) and gradient norm -- and returns without waiting for it; at most two
- * steps are in flight (the call waits for step t - 2), so a caller cycling through >= 3 minibatch buffers may refill the
- * oldest.  Float64 arithmetic of the NumPy expressions, the feature / GEMM kernels in float32 as in rr_featmat_glm_step. */
+ * Replaces, for a model whose basis is a random Fourier basis, a linear basis or a concatenation of such children (Xdim <= 128
+ * each) and whose minibatches are gathered on the device, the host loop  sgd (optimize/sgd.py:337-425)  o  logtrick_sgd
+ * (optimize/decorators.py:329-408)  o  structured_sgd (:133-252)  around  GeneralizedLinearModel._elbo (glm.py:205-294):  the flat
+ * parameter vector
+ *     z = [ m (F, K) | C (F, K) | regularisers (one per child) | likelihood parameter (n_lik = 1: the Gaussian variance) |
+ *           length scales, child by child ]
+ * (row-major blocks in the order of glm.py:170-176 / BasisCat's parameter lists, basis_functions.py:1750-1763; coordinates with
+ * is_log != 0 are log(x), the log trick's Positive coordinates), the updater's state, the gradient and every intermediate stay
+ * in HBM.  One rr_glm_sgd_step call queues a whole step -- x = from_log(z), the bases rescaled by the length scales in x, Phi of
+ * the minibatch rows, the step of rr_featmat_glm_step_draws_dev / _sampled with (m, C) read from x, the length-scale
+ * contractions, the mixture terms (glm.py:238-262), the gradient (:255-283) with every child's own regulariser over its column
+ * slice (basis_functions.py:1712-1748), the chain rule of the log trick, bound truncation + updater + clip (sgd.py:404-420), the
+ * step's -ELBO (glm.py:285-292) and gradient norm -- and returns without waiting for it; at most two steps are in flight (the
+ * call waits for step t - 2), so a caller cycling through >= 3 minibatch buffers may refill the oldest.  Float64 arithmetic of
+ * the NumPy expressions, the feature / GEMM kernels in float32 as in rr_featmat_glm_step. */
 typedef struct rr_glm_sgd rr_glm_sgd;
 #define RR_UPD_SGD 0      /* upd_par = (eta)                          sgd.py:14-68   */
 #define RR_UPD_ADADELTA 1 /* (rho, epsilon)                                  :71-133  */
 #define RR_UPD_ADAGRAD 2  /* (eta, epsilon)                                  :136-196 */
 #define RR_UPD_MOMENTUM 3 /* (rho, eta)                                      :199-256 */
 #define RR_UPD_ADAM 4     /* (alpha, beta1, beta2, epsilon)                  :259-330 */
-/* fm: an (empty) feature matrix of F = 2 n columns on the basis' context; z0, lower, upper (float64) and is_log (bytes):
- * host vectors of 2 F K + 1 + n_lik + n_ls entries; upd_par: 4 doubles (unused ones ignored); maxiter: steps at most. */
-int rr_glm_sgd_create(rr_featmat *fm, rr_basis *basis, int K, int n_lik, int n_ls, const double *z0, const double *lower,
-                      const double *upper, const unsigned char *is_log, int updater, const double *upd_par, int64_t maxiter,
-                      rr_glm_sgd **out);
-/* One step on the minibatch rows dX (device, rr_rff_padded layout, ldx) with targets dy / per-row argument drowarg (device,
- * dtype).  llconst: the f-independent constant of sum(loglike) per latent sample (ignored for the Gaussian, whose constant
- * follows the variance in z); bmag = N / minibatch size (glm.py:158).  dE: the caller's standard normals (device float32
- * (K L, F), the reference's stream) or NULL: counter-based device draws keyed by (seed, key). */
-int rr_glm_sgd_step(rr_glm_sgd *s, const void *dX, int x_dtype, int64_t ldx, int64_t rows, const void *dy, const void *drowarg,
-                    int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed, uint64_t key);
+#define RR_SGD_CHILD_RFF 0    /* [cos | sin] of a random Fourier basis: 2 n columns, n_ls = 1 (isotropic) or Xdim length scales */
+#define RR_SGD_CHILD_LINEAR 1 /* LinearBasis (basis_functions.py:468-485): d columns of X (+ a leading column of ones)           */
+typedef struct rr_glm_sgd_child {
+    int kind;        /* RR_SGD_CHILD_* */
+    rr_basis *basis; /* RFF: the basis (same context as the feature matrix); else NULL */
+    int d;           /* LINEAR: columns of X */
+    int onescol;     /* LINEAR: 1 = a column of ones first */
+    int n_ls;        /* RFF: 1 or Xdim; LINEAR: 0 */
+} rr_glm_sgd_child;
+/* fm: an (empty) feature matrix whose F columns the children fill in order; z0, lower, upper (float64) and is_log (bytes):
+ * host vectors of 2 F K + n_children + n_lik + (all length scales) entries; upd_par: 4 doubles (unused ones ignored);
+ * maxiter: steps at most. */
+int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *children, int K, int n_lik, const double *z0,
+                      const double *lower, const double *upper, const unsigned char *is_log, int updater, const double *upd_par,
+                      int64_t maxiter, rr_glm_sgd **out);
+/* One step on the minibatch: dX[c], x_dtype[c], ldx[c] -- every child's rows of ITS columns of X (device; random Fourier: the
+ * rr_rff_padded layout), targets dy / per-row argument drowarg (device, dtype).  llconst: the f-independent constant of
+ * sum(loglike) per latent sample (ignored for the Gaussian, whose constant follows the variance in z); bmag = N / minibatch
+ * size (glm.py:158).  dE: the caller's standard normals (device float32 (K L, F), the reference's stream) or NULL:
+ * counter-based device draws keyed by (seed, key). */
+int rr_glm_sgd_step(rr_glm_sgd *s, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows, const void *dy,
+                    const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed,
+                    uint64_t key);
 /* Waits for the queued steps; z (all coordinates, log space where is_log), objs / norms: -ELBO and |gradient| of every
  * step done so far (*steps of them); any pointer may be NULL. */
 int rr_glm_sgd_read(rr_glm_sgd *s, double *z, double *objs, double *norms, int64_t *steps);

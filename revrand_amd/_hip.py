@@ -146,10 +146,10 @@ SIGNATURES = {
                                                ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_glm_edphi": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),
     "rr_featmat_project": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
-    "rr_glm_sgd_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+    "rr_glm_sgd_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p)]),
-    "rr_glm_sgd_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+    "rr_glm_sgd_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
     "rr_glm_sgd_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -1034,30 +1034,54 @@ class FeatureMatrix(object):
 UPDATER_IDS = {"SGDUpdater": 0, "AdaDelta": 1, "AdaGrad": 2, "Momentum": 3, "Adam": 4}   # RR_UPD_*
 
 
-class ResidentSgd(object):
-    """The SVI loop with its parameters in HBM (rr_glm_sgd): `step` queues one whole SGD step and returns at once."""
+class SgdChild(ctypes.Structure):
+    """rr_glm_sgd_child (include/revrand_hip.h)"""
+    _fields_ = [("kind", ctypes.c_int), ("basis", ctypes.c_void_p), ("d", ctypes.c_int), ("onescol", ctypes.c_int),
+                ("n_ls", ctypes.c_int)]
 
-    def __init__(self, fm, handle, K, n_lik, n_ls, z0, lower, upper, is_log, updater_id, updater_par, maxiter):
-        self.fm, self.handle, self.lib = fm, handle, fm.lib      # (both kept alive for as long as the loop)
+
+class ResidentSgd(object):
+    """The SVI loop with its parameters in HBM (rr_glm_sgd): `step` queues one whole SGD step and returns at once.
+    children: ("rff", RffHandle, n_ls) | ("linear", d, onescol) in concatenation order."""
+
+    def __init__(self, fm, children, K, n_lik, z0, lower, upper, is_log, updater_id, updater_par, maxiter):
+        self.fm, self.children, self.lib = fm, list(children), fm.lib      # (all kept alive for as long as the loop)
         z0 = np.ascontiguousarray(z0, dtype=np.float64)
         lower = np.ascontiguousarray(lower, dtype=np.float64)
         upper = np.ascontiguousarray(upper, dtype=np.float64)
         is_log = np.ascontiguousarray(is_log, dtype=np.uint8)
-        self.np_ = 2 * fm.F * K + 1 + n_lik + n_ls
+        kids = (SgdChild * len(self.children))()
+        n_ls = 0
+        for k, ch in zip(kids, self.children):
+            if ch[0] == "rff":
+                k.kind, k.basis, k.d, k.onescol, k.n_ls = 0, ch[1].h, 0, 0, int(ch[2])
+                n_ls += int(ch[2])
+            else:
+                k.kind, k.basis, k.d, k.onescol, k.n_ls = 1, None, int(ch[1]), 1 if ch[2] else 0, 0
+        self.nk = len(self.children)
+        self.np_ = 2 * fm.F * K + self.nk + n_lik + n_ls
         if not (z0.shape == lower.shape == upper.shape == is_log.shape == (self.np_,)):
-            raise ValueError("z0, lower, upper, is_log must have 2 F K + 1 + n_lik + n_ls = %d entries" % self.np_)
+            raise ValueError("z0, lower, upper, is_log must have 2 F K + children + n_lik + length scales = %d entries" % self.np_)
         par = np.zeros(4)
         par[:len(updater_par)] = updater_par
         self.maxiter = int(maxiter)
+        self._ptrs, self._dts, self._lds = (ctypes.c_void_p * self.nk)(), (ctypes.c_int * self.nk)(), (ctypes.c_int64 * self.nk)()
         h = ctypes.c_void_p()
-        _check(self.lib, self.lib.rr_glm_sgd_create(fm.h, handle.h, K, n_lik, n_ls, z0.ctypes.data_as(ctypes.c_void_p),
-                                                    lower.ctypes.data_as(ctypes.c_void_p), upper.ctypes.data_as(ctypes.c_void_p),
-                                                    is_log.ctypes.data_as(ctypes.c_void_p), int(updater_id),
-                                                    par.ctypes.data_as(ctypes.c_void_p), self.maxiter, ctypes.byref(h)))
+        _check(self.lib, self.lib.rr_glm_sgd_create(fm.h, self.nk, ctypes.cast(kids, ctypes.c_void_p), K, n_lik,
+                                                    z0.ctypes.data_as(ctypes.c_void_p), lower.ctypes.data_as(ctypes.c_void_p),
+                                                    upper.ctypes.data_as(ctypes.c_void_p), is_log.ctypes.data_as(ctypes.c_void_p),
+                                                    int(updater_id), par.ctypes.data_as(ctypes.c_void_p), self.maxiter,
+                                                    ctypes.byref(h)))
         self.h = h
 
-    def step(self, dX, rows, dy, drowarg, lik, llconst, bmag, L, dE=None, seed=0, key=0):
-        _check(self.lib, self.lib.rr_glm_sgd_step(self.h, dX.ptr, rr_dtype(dX.dtype), dX.ld, int(rows), _ptr(dy), _ptr(drowarg),
+    def step(self, dXs, rows, dy, drowarg, lik, llconst, bmag, L, dE=None, seed=0, key=0):
+        """dXs: every child's minibatch rows (DeviceView), in concatenation order."""
+        for i, dX in enumerate(dXs):
+            p = dX.ptr
+            self._ptrs[i] = p if isinstance(p, int) else p.value
+            self._dts[i], self._lds[i] = rr_dtype(dX.dtype), dX.ld
+        _check(self.lib, self.lib.rr_glm_sgd_step(self.h, ctypes.cast(self._ptrs, ctypes.c_void_p), ctypes.cast(self._dts, ctypes.c_void_p),
+                                                  ctypes.cast(self._lds, ctypes.c_void_p), int(rows), _ptr(dy), _ptr(drowarg),
                                                   rr_dtype(dy.dtype), int(lik), float(llconst), float(bmag), int(L),
                                                   None if dE is None else dE.ptr, int(seed), int(key)))
 

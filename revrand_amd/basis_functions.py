@@ -710,12 +710,14 @@ class MinibatchFeatures(object):
         self.M = M  # (no synchronisation: the gathers and feature kernels run while the host prepares the step)
 
     def batch_rows(self, idx, gathered=None):
-        """The rows `idx` of the lone resident child's data on the device (the resident SVI loop, glm._ResidentLoop):
-        gathered ahead by `prefetch_batch` (its slot) or now."""
-        child, M = self._kids[0], len(idx)
+        """Every resident child's rows `idx` of its data on the device, in concatenation order (the resident SVI loop,
+        glm._ResidentLoop): gathered ahead by `prefetch_batch` (its slot) or now."""
+        M = len(idx)
         if gathered is None:
-            child.gather(self._stage("idx", idx, np.int32), M)
-        return _hip.DeviceView(_batch_buffer(child, None if gathered is None else gathered.slot), 0, M)
+            didx = self._stage("idx", idx, np.int32)
+            for child in self._kids:
+                child.gather(didx, M)
+        return [_hip.DeviceView(_batch_buffer(child, None if gathered is None else gathered.slot), 0, M) for child in self._kids]
 
     PREFETCH_SLOTS = 3  # the worker runs up to two steps ahead of the step on the device (6 under the resident loop, whose
     #                     host queues steps up to two ahead of the device on top of that)

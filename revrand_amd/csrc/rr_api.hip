@@ -530,6 +530,12 @@ static int basis_raw_w(rr_basis *b) {  // first use: W up once, pad rows / colum
     return RR_OK;
 }
 
+int rr_basis_raw_w(rr_basis *b) {  // (rr_elbo.hip: the resident SVI loop contracts T with W as given)
+    RR_REQUIRE(b != nullptr && !b->large && b->d <= 128, "resident W needs Xdim <= 128");
+    RR_CHECK_HIP(hipSetDevice(b->ctx->device));
+    return basis_raw_w(b);
+}
+
 int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls) {
     RR_REQUIRE(b != nullptr && dls != nullptr, "lenscale: null argument");
     RR_REQUIRE(n_ls == 1 || n_ls == b->d, "Dimension of input parameter is inconsistent! (n_ls=%d, d=%d)", n_ls, b->d);

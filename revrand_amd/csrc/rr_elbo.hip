@@ -2910,11 +2910,14 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
 // optimize/sgd.py:337-425, optimize/decorators.py:329-408).  The step above returns (Edm, EdC, sums, dT) to the host, which
 // forms the mixture-entropy terms, assembles the gradient, applies the log trick, the bounds and the updater, and sends the new
 // (m, C, length scales) back: ~1.2 ms of serial host work and two synchronisations around 3.6 ms of kernels at config 5.
-// Here the optimiser's vector z = [m (F, K) | C (F, K) | reg | likelihood parameter (Gaussian: variance) | length scales]
-// (the flat vector of structured_sgd, Positive coordinates in log space) lives in HBM together with the updater's state:
+// Here the optimiser's vector
+//     z = [m (F, K) | C (F, K) | regularisers (one per child) | likelihood parameter (Gaussian: variance) | length scales, child by child]
+// (the flat vector of structured_sgd over a basis or a concatenation of random Fourier and linear children, Positive coordinates
+// in log space) lives in HBM together with the updater's state:
 //   rr_glm_sgd_from_log_kernel   x = from_log(z)                                           decorators.py:377-381
-//   rr_scale_w_dev_kernel, feature kernel, the step's kernels (glm_pipeline) with m, C, lengths read from x
-//   rr_glm_sgd_sums_kernel       the K(K+1)/2 mixture cross terms of _qmatrix, sum(m^2 + C), W[i,:].T[i,:]   glm.py:697-712,265
+//   rr_scale_w_dev_kernel, feature kernels, the step's kernels (glm_pipeline) with m, C, lengths read from x
+//   rr_glm_sgd_sums_kernel       the K(K+1)/2 mixture cross terms of _qmatrix, sum(m^2 + C) per regulariser slice, W[i,:].T[i,:]
+//                                per length scale                                                  glm.py:697-712,265,274-275
 //   rr_glm_sgd_update_kernel     log N_kl, log z_k, alpha; dm, dC, dreg, dlik, dl (glm.py:238-283); the chain rule of the log
 //                                trick; |grad|^2 partials; bound truncation, updater, clip (sgd.py:404-420)
 //   rr_glm_sgd_finish_kernel     the gradient norm and -ELBO of the step (glm.py:285-292) into per-step arrays
@@ -2922,29 +2925,39 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
 // caller's minibatch buffers are reused in turn).  Float64 throughout, multiply-add contraction off: the arithmetic of the
 // NumPy expressions it stands for, reduction order aside.
 // Order within a step, and the second stream: the length scales' gradient comes from the EdPhi product alone, (m, C)'s from
-// Ed = dfs Phi.  So the step runs fs -> EdPhi (contracted) -> the LENGTH SCALES' update -> Ed -> the rest of the update, and as
-// soon as the length scales of step t + 1 exist its features (an HBM-write-bound 0.2 ms at config 5) are made on a second
-// stream into the OTHER of two feature matrices while the matrix cores form step t's Ed.
+// Ed = dfs Phi.  So the step runs fs -> EdPhi (contracted, or stored and contracted per child) -> the LENGTH SCALES' update -> Ed
+// -> the rest of the update, and as soon as the length scales of step t + 1 exist its features (an HBM-write-bound 0.2 ms at
+// config 5) are made on a second stream into the OTHER of two feature matrices while the matrix cores form step t's Ed.
 // =============================================================================================
 #define RR_SGD_MAXK 32
+#define RR_SGD_MAXCHILD 16
+
+struct SgdHRow {  // one length-scale gradient: W[i, :] . T[i, :] of a random Fourier child
+    const double *T, *W;
+    int n;
+};
 
 struct rr_glm_sgd {
     rr_featmat *fm = nullptr;
-    rr_basis *b = nullptr;
-    int K = 0, F = 0, n_ls = 0, n_lik = 0, updater = 0;
-    int64_t fk = 0, np = 0, maxiter = 0, t = 0;
+    std::vector<rr_glm_sgd_child> kids;
+    std::vector<int> col0, width, ls0;  // per child: first column, columns, first length-scale coordinate (relative to the ls block)
+    std::vector<double *> dTk;          // per child (random Fourier): its (d, n) contraction inside dT
+    int nkids = 0, K = 0, F = 0, n_ls = 0, n_lik = 0, updater = 0, n_h = 0;
+    int64_t fk = 0, np = 0, maxiter = 0, t = 0, dT_count = 0;
     double up[4] = {0, 0, 0, 0};
     double *z = nullptr, *x = nullptr, *s1 = nullptr, *s2 = nullptr, *lower = nullptr, *upper = nullptr;
     unsigned char *islog = nullptr;
-    double *red = nullptr;    // [Q (K, K) | R | H (d)]
+    double *red = nullptr;    // [Q (K, K) | R (children) | H (length-scale gradients)]
     double *npart = nullptr;  // |grad|^2 per block of the update kernel: [main blocks | length-scale blocks]
     double *objs = nullptr, *norms = nullptr;
-    double *dT = nullptr;     // (d, n): X^T (E_s o P_c - E_c o P_s) of the step
+    double *dT = nullptr;     // the children's (d, n) blocks X^T (E_s o P_c - E_c o P_s) of the step
+    int *slice_of_f = nullptr, *slice_lo = nullptr, *slice_hi = nullptr, *h_of_ls = nullptr;  // device tables
+    SgdHRow *hrows = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     rr_featmat *fm2 = nullptr;                  // steps alternate between fm and fm2 (owned)
     hipStream_t sfeat = nullptr;                // features of the next step
     hipEvent_t e_ls[2] = {nullptr, nullptr};    // step t's length scales are updated (recorded on the context's stream)
-    hipEvent_t e_feat[2] = {nullptr, nullptr};  // step t's features are in its matrix (recorded on s1)
+    hipEvent_t e_feat[2] = {nullptr, nullptr};  // step t's features are in its matrix (recorded on sfeat)
     bool overlap = true;                        // RR_GLM_SGD_OVERLAP=0: one stream, one matrix (A/B runs)
 };
 
@@ -2967,14 +2980,17 @@ __device__ __forceinline__ double rr_block_sum256(double v, double *sh) {  // fi
     return r;
 }
 
+// blocks [0, npairs): the mixture's cross terms; [npairs, npairs + nkids): sum (m^2 + C) over a child's rows of (m, C);
+// then one block per length-scale gradient
 __global__ void __launch_bounds__(256)
-rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, const double *__restrict__ T, const double *__restrict__ W,
-                       int n, int nh, double *__restrict__ red, int first_block) {
+rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, int nkids, const int *__restrict__ slice_lo,
+                       const int *__restrict__ slice_hi, const SgdHRow *__restrict__ hrows, int n_h, double *__restrict__ red,
+                       int first_block) {
 #pragma clang fp contract(off)
     __shared__ double sh[256];
     const int npairs = K * (K + 1) / 2, tid = threadIdx.x;
     const int64_t fk = (int64_t)F * K;
-    int bid = blockIdx.x + first_block;  // blocks [0, npairs]: the mixture's sums; (npairs, npairs + nh]: the length scales'
+    int bid = blockIdx.x + first_block;
     double acc = 0.0;
     if (bid < npairs) {  // sum_f log(C_fk + C_fl) + (m_fk - m_fl)^2 / (C_fk + C_fl)
         int k = 0;
@@ -2990,16 +3006,18 @@ rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, const double 
         }
         const double q = rr_block_sum256(acc, sh);
         if (tid == 0) red[k * K + l] = red[l * K + k] = q;
-    } else if (bid == npairs) {  // sum (m^2 + C)
-        for (int64_t p = tid; p < fk; p += 256) acc += x[p] * x[p] + x[fk + p];
+    } else if (bid < npairs + nkids) {  // sum (m^2 + C) over the child's slice
+        const int s = bid - npairs;
+        for (int64_t p = (int64_t)slice_lo[s] * K + tid; p < (int64_t)slice_hi[s] * K; p += 256) acc += x[p] * x[p] + x[fk + p];
         const double r = rr_block_sum256(acc, sh);
-        if (tid == 0) red[K * K] = r;
+        if (tid == 0) red[K * K + s] = r;
     } else {  // W[i, :] . T[i, :]
-        const int i = bid - npairs - 1;
-        if (i < nh) {
-            for (int f = tid; f < n; f += 256) acc += T[(int64_t)i * n + f] * W[(int64_t)i * n + f];
-            const double h = rr_block_sum256(acc, sh);
-            if (tid == 0) red[K * K + 1 + i] = h;
+        const int i = bid - npairs - nkids;
+        if (i < n_h) {
+            const SgdHRow h = hrows[i];
+            for (int f = tid; f < h.n; f += 256) acc += h.T[f] * h.W[f];
+            const double v = rr_block_sum256(acc, sh);
+            if (tid == 0) red[K * K + nkids + i] = v;
         }
     }
 }
@@ -3007,8 +3025,9 @@ rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, const double 
 struct SgdUpdArgs {
     const double *x, *red, *Edm, *EdC, *aux, *lower, *upper;
     const unsigned char *islog;
+    const int *slice_of_f, *slice_lo, *slice_hi, *h_of_ls;
     double *z, *s1, *s2, *npart;
-    int F, K, n_lik, n_ls, updater, L;
+    int F, K, nkids, n_lik, n_ls, updater, L;
     int64_t np, p0, p1;  // all coordinates; this launch's are [p0, p1)
     double bmag, nrows, up[4], b1t, b2t;
 };
@@ -3039,11 +3058,11 @@ __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs
     double g = 0.0;
     const bool live = p < a.p1;
     if (live) {
-        const double reg = a.x[2 * fk], iL = 1.0 / reg;
         if (p < 2 * fk) {
             const bool cov = p >= fk;
             const int64_t q = cov ? p - fk : p;
             const int f = (int)(q / K), k = (int)(q % K);
+            const double reg = a.x[2 * fk + a.slice_of_f[f]];  // the regulariser of this feature's child (glm.py:218-219)
             const double mk = a.x[q], Ck = a.x[fk + q];
             double mix = 0.0;
             for (int l = 0; l < K; ++l) {
@@ -3054,17 +3073,19 @@ __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs
             }
             if (!cov) g = -((a.bmag * a.Edm[(int64_t)k * F + f] - mk / reg + mix) / K);
             else g = -((a.bmag * a.EdC[(int64_t)k * F + f] - 1.0 / reg + mix) / (2 * K));
-        } else if (p == 2 * fk) {
-            g = -(0.5 * (a.red[K * K] * (iL * iL) / K - (double)F * iL));
-        } else if (p < 2 * fk + 1 + a.n_lik) {  // Gaussian variance: dp = ((y - f)^2 / var^2 - 1 / var) / 2  (likelihoods.py:360-381)
+        } else if (p < 2 * fk + a.nkids) {  // dreg of the child's slice (glm.py:265-268)
+            const int s = (int)(p - 2 * fk);
+            const double iL = 1.0 / a.x[p];
+            g = -(0.5 * (a.red[K * K + s] * (iL * iL) / K - (double)(a.slice_hi[s] - a.slice_lo[s]) * iL));
+        } else if (p < 2 * fk + a.nkids + a.n_lik) {  // Gaussian variance: dp = ((y - f)^2 / var^2 - 1 / var) / 2  (likelihoods.py:360-381)
             const double ivar = 1.0 / a.x[p];
             double sm = 0.0;
             for (int k = 0; k < K; ++k) sm += 0.5 * (a.aux[k] * ivar * ivar - ivar * a.nrows * a.L) / a.L;
             g = 0.0 - sm / K;
         } else {  // -(EdPhi o dPhi_i).sum() = W[i,:].T[i,:] / l_i^2; isotropic: input dimension 0 only, as the reference
-            const int i = (int)(p - (2 * fk + 1 + a.n_lik));
+            const int j = (int)(p - (2 * fk + a.nkids + a.n_lik));
             const double l = a.x[p];
-            g = a.red[K * K + 1 + i] / (1.0 * (l * l));
+            g = a.red[K * K + a.nkids + a.h_of_ls[j]] / (1.0 * (l * l));
         }
         if (a.islog[p]) g *= a.x[p];  // d/dz through x = exp(z)
     }
@@ -3107,8 +3128,9 @@ __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs
 
 __global__ void __launch_bounds__(256)
 rr_glm_sgd_finish_kernel(const double *__restrict__ x, const double *__restrict__ red, const double *__restrict__ llsum,
-                         const double *__restrict__ npart, int nblocks, int F, int K, int L, int n_lik, double llconst, double nrows,
-                         double bmag, double *__restrict__ obj, double *__restrict__ norm) {
+                         const double *__restrict__ npart, int nblocks, int F, int K, int L, int nkids, const int *__restrict__ slice_lo,
+                         const int *__restrict__ slice_hi, int n_lik, double llconst, double nrows, double bmag,
+                         double *__restrict__ obj, double *__restrict__ norm) {
 #pragma clang fp contract(off)
     __shared__ double sh[256];
     const int tid = threadIdx.x;
@@ -3126,19 +3148,24 @@ rr_glm_sgd_finish_kernel(const double *__restrict__ x, const double *__restrict_
     const double logzsum = rr_block_sum256(lz, sh);
     if (tid == 0) {
         const int64_t fk = (int64_t)F * K;
-        const double reg = x[2 * fk];
-        if (n_lik) llconst = -0.5 * log(2.0 * 3.141592653589793 * x[2 * fk + 1]) * nrows;  // Gaussian (likelihoods.py:295-317)
+        if (n_lik) llconst = -0.5 * log(2.0 * 3.141592653589793 * x[2 * fk + nkids]) * nrows;  // Gaussian (likelihoods.py:295-317)
         double ell = 0.0;
         for (int k = 0; k < K; ++k) ell += llsum[k] / L + llconst;
-        const double elbo = (ell * bmag - 0.5 * F * K * 1.8378770664093453 - 0.5 * K * ((double)F * log(reg)) - 0.5 * (red[K * K] / reg) -
-                             logzsum + log((double)K)) / K;
+        double logL = 0.0, quad = 0.0;  // log(L).sum() and ((m^2 + C) iL).sum(), child by child (glm.py:288-289)
+        for (int s = 0; s < nkids; ++s) {
+            const double reg = x[2 * fk + s];
+            logL += (double)(slice_hi[s] - slice_lo[s]) * log(reg);
+            quad += red[K * K + s] / reg;
+        }
+        const double elbo = (ell * bmag - 0.5 * F * K * 1.8378770664093453 - 0.5 * K * logL - 0.5 * quad - logzsum + log((double)K)) / K;
         *obj = -elbo;
         *norm = sqrt(n2);
     }
 }
 
 static void sgd_free(rr_glm_sgd *o) {
-    void *q[] = {o->z, o->x, o->s1, o->s2, o->lower, o->upper, o->islog, o->red, o->npart, o->objs, o->norms, o->dT};
+    void *q[] = {o->z, o->x, o->s1, o->s2, o->lower, o->upper, o->islog, o->red, o->npart, o->objs, o->norms, o->dT,
+                 o->slice_of_f, o->slice_lo, o->slice_hi, o->h_of_ls, o->hrows};
     for (void *v : q)
         if (v) (void)hipFree(v);
     for (hipEvent_t e : {o->ev[0], o->ev[1], o->e_ls[0], o->e_ls[1], o->e_feat[0], o->e_feat[1]})
@@ -3148,28 +3175,80 @@ static void sgd_free(rr_glm_sgd *o) {
     delete o;
 }
 
+int rr_basis_raw_w(rr_basis *b);  // rr_api.hip: W as given, resident (dWraw)
+
 extern "C" {
 
-int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, const double *z0, const double *lower,
-                      const double *upper, const unsigned char *is_log, int updater, const double *upd_par, int64_t maxiter,
-                      rr_glm_sgd **out) {
-    RR_REQUIRE(fm != nullptr && b != nullptr && out != nullptr && z0 != nullptr && lower != nullptr && upper != nullptr &&
+int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *children, int K, int n_lik, const double *z0,
+                      const double *lower, const double *upper, const unsigned char *is_log, int updater, const double *upd_par,
+                      int64_t maxiter, rr_glm_sgd **out) {
+    RR_REQUIRE(fm != nullptr && children != nullptr && out != nullptr && z0 != nullptr && lower != nullptr && upper != nullptr &&
                is_log != nullptr && upd_par != nullptr, "rr_glm_sgd_create: null argument");
     *out = nullptr;
-    RR_REQUIRE(b->kind == RR_KIND_RFF && !b->large && b->d <= 128 && 2 * (int64_t)b->n == fm->F && b->ctx == fm->ctx,
-               "rr_glm_sgd_create: the feature matrix must be one random Fourier basis of Xdim <= 128 on the same context");
+    RR_REQUIRE(n_children >= 1 && n_children <= RR_SGD_MAXCHILD, "rr_glm_sgd_create: 1 <= children <= %d", RR_SGD_MAXCHILD);
     RR_REQUIRE(K >= 1 && K <= RR_SGD_MAXK, "rr_glm_sgd_create: 1 <= K <= %d", RR_SGD_MAXK);
     RR_REQUIRE(n_lik == 0 || n_lik == 1, "rr_glm_sgd_create: at most one likelihood parameter");
-    RR_REQUIRE(n_ls == 1 || n_ls == b->d, "rr_glm_sgd_create: %d length scales for Xdim = %d", n_ls, b->d);
     RR_REQUIRE(updater >= RR_UPD_SGD && updater <= RR_UPD_ADAM, "rr_glm_sgd_create: unknown updater %d", updater);
     RR_REQUIRE(maxiter >= 1 && maxiter < ((int64_t)1 << 31), "rr_glm_sgd_create: bad maxiter");
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
     rr_glm_sgd *o = new rr_glm_sgd();
-    o->fm = fm; o->b = b; o->K = K; o->F = fm->F; o->n_ls = n_ls; o->n_lik = n_lik; o->updater = updater;
+    o->fm = fm; o->K = K; o->F = fm->F; o->n_lik = n_lik; o->updater = updater; o->nkids = n_children;
+    std::vector<int> h_slice(fm->F, 0), h_lo, h_hi, h_of_ls;
+    std::vector<SgdHRow> hrows;
+    int col = 0, nls = 0;
+    int64_t dT_count = 0;
+    for (int s = 0; s < n_children; ++s) {
+        const rr_glm_sgd_child &k = children[s];
+        int w = 0;
+        if (k.kind == RR_SGD_CHILD_RFF) {
+            rr_basis *b = k.basis;
+            if (!(b != nullptr && b->kind == RR_KIND_RFF && !b->large && b->d <= 128 && b->ctx == fm->ctx &&
+                  (k.n_ls == 1 || k.n_ls == b->d))) {
+                delete o;
+                rr_set_error("rr_glm_sgd_create: child %d must be a random Fourier basis of Xdim <= 128 on the matrix' context with 1 or "
+                             "Xdim length scales", s);
+                return RR_ERR_INVALID;
+            }
+            w = 2 * b->n;
+            dT_count += (int64_t)b->d * b->n;
+        } else if (k.kind == RR_SGD_CHILD_LINEAR) {
+            if (!(k.d >= 1 && k.n_ls == 0)) {
+                delete o;
+                rr_set_error("rr_glm_sgd_create: child %d: a linear child has d >= 1 columns and no length scale", s);
+                return RR_ERR_INVALID;
+            }
+            w = k.d + (k.onescol ? 1 : 0);
+        } else {
+            delete o;
+            rr_set_error("rr_glm_sgd_create: child %d: unknown kind %d", s, k.kind);
+            return RR_ERR_INVALID;
+        }
+        if (col + w > fm->F) {
+            delete o;
+            rr_set_error("rr_glm_sgd_create: the children are wider than the feature matrix (%d columns)", fm->F);
+            return RR_ERR_INVALID;
+        }
+        o->kids.push_back(k);
+        o->col0.push_back(col);
+        o->width.push_back(w);
+        o->ls0.push_back(nls);
+        h_lo.push_back(col);
+        h_hi.push_back(col + w);
+        for (int f = col; f < col + w; ++f) h_slice[f] = s;
+        col += w;
+        nls += k.n_ls;
+    }
+    if (col != fm->F) {
+        delete o;
+        rr_set_error("rr_glm_sgd_create: the children cover %d of the feature matrix' %d columns", col, fm->F);
+        return RR_ERR_INVALID;
+    }
+    o->n_ls = nls;
     o->fk = (int64_t)fm->F * K;
-    o->np = 2 * o->fk + 1 + n_lik + n_ls;
+    o->np = 2 * o->fk + n_children + n_lik + nls;
     o->maxiter = maxiter;
+    o->dT_count = dT_count > 0 ? dT_count : 1;
     for (int i = 0; i < 4; ++i) o->up[i] = upd_par[i];
     const size_t nb = (size_t)o->np * 8, nblocks = (size_t)((o->np + 255) / 256) + 1;  // (main and length-scale launches)
     const char *ov = getenv("RR_GLM_SGD_OVERLAP");
@@ -3181,11 +3260,16 @@ int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, c
     if (e == hipSuccess) e = hipMalloc((void **)&o->lower, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->upper, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->islog, (size_t)o->np);
-    if (e == hipSuccess) e = hipMalloc((void **)&o->red, (size_t)(K * K + 1 + b->d) * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->red, (size_t)(K * K + n_children + (nls > 0 ? nls : 1)) * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&o->npart, nblocks * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&o->objs, (size_t)maxiter * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&o->norms, (size_t)maxiter * 8);
-    if (e == hipSuccess) e = hipMalloc((void **)&o->dT, (size_t)b->d * b->n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->dT, (size_t)o->dT_count * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->slice_of_f, (size_t)fm->F * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&o->slice_lo, (size_t)n_children * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&o->slice_hi, (size_t)n_children * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&o->h_of_ls, (size_t)(nls > 0 ? nls : 1) * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&o->hrows, (size_t)(nls > 0 ? nls : 1) * sizeof(SgdHRow));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[1], hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -3206,11 +3290,36 @@ int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, c
             return rc2;
         }
     }
+    // the length-scale gradients: one W[i, :] . T[i, :] per ARD coordinate, dimension 0 alone for an isotropic child (the
+    // reference's quirk, basis_functions.py:866-901)
+    double *dTp = o->dT;
+    for (int s = 0; s < n_children; ++s) {
+        const rr_glm_sgd_child &k = o->kids[(size_t)s];
+        o->dTk.push_back(nullptr);
+        if (k.kind != RR_SGD_CHILD_RFF) continue;
+        const int rcw = rr_basis_raw_w(k.basis);
+        if (rcw != RR_OK) {
+            sgd_free(o);
+            return rcw;
+        }
+        o->dTk.back() = dTp;
+        for (int i = 0; i < k.n_ls; ++i) {
+            h_of_ls.push_back((int)hrows.size());
+            hrows.push_back({dTp + (int64_t)i * k.basis->n, k.basis->dWraw + (int64_t)i * k.basis->n, k.basis->n});
+        }
+        dTp += (int64_t)k.basis->d * k.basis->n;
+    }
+    o->n_h = (int)hrows.size();
     hipError_t h = hipStreamSynchronize(c->stream);
     if (h == hipSuccess) h = hipMemcpy(o->z, z0, nb, hipMemcpyHostToDevice);
     if (h == hipSuccess) h = hipMemcpy(o->lower, lower, nb, hipMemcpyHostToDevice);
     if (h == hipSuccess) h = hipMemcpy(o->upper, upper, nb, hipMemcpyHostToDevice);
     if (h == hipSuccess) h = hipMemcpy(o->islog, is_log, (size_t)o->np, hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemcpy(o->slice_of_f, h_slice.data(), (size_t)fm->F * sizeof(int), hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemcpy(o->slice_lo, h_lo.data(), (size_t)n_children * sizeof(int), hipMemcpyHostToDevice);
+    if (h == hipSuccess) h = hipMemcpy(o->slice_hi, h_hi.data(), (size_t)n_children * sizeof(int), hipMemcpyHostToDevice);
+    if (h == hipSuccess && nls > 0) h = hipMemcpy(o->h_of_ls, h_of_ls.data(), (size_t)nls * sizeof(int), hipMemcpyHostToDevice);
+    if (h == hipSuccess && nls > 0) h = hipMemcpy(o->hrows, hrows.data(), hrows.size() * sizeof(SgdHRow), hipMemcpyHostToDevice);
     if (h == hipSuccess) h = hipMemset(o->s1, 0, nb);
     if (h == hipSuccess) h = hipMemset(o->s2, 0, nb);
     if (h == hipSuccess) h = hipMemset(o->objs, 0, (size_t)maxiter * 8);
@@ -3226,34 +3335,42 @@ int rr_glm_sgd_create(rr_featmat *fm, rr_basis *b, int K, int n_lik, int n_ls, c
     return RR_OK;
 }
 
-int rr_glm_sgd_step(rr_glm_sgd *o, const void *dX, int x_dtype, int64_t ldx, int64_t rows, const void *dy, const void *drowarg,
-                    int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed, uint64_t key) {
-    RR_REQUIRE(o != nullptr && dX != nullptr && dy != nullptr, "rr_glm_sgd_step: null argument");
+int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows, const void *dy,
+                    const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed,
+                    uint64_t key) {
+    RR_REQUIRE(o != nullptr && dX != nullptr && x_dtype != nullptr && ldx != nullptr && dy != nullptr, "rr_glm_sgd_step: null argument");
     RR_REQUIRE(o->t < o->maxiter, "rr_glm_sgd_step: all %lld steps of this loop are done", (long long)o->maxiter);
     RR_REQUIRE((lik == RR_LIK_GAUSSIAN) == (o->n_lik == 1), "rr_glm_sgd_step: likelihood %d with %d likelihood parameter(s)", lik, o->n_lik);
     RR_REQUIRE(rows >= 1 && rows <= o->fm->max_rows, "rr_glm_sgd_step: rows out of range");
+    for (int s = 0; s < o->nkids; ++s)
+        RR_REQUIRE(dX[s] != nullptr && (x_dtype[s] == RR_F32 || x_dtype[s] == RR_F64), "rr_glm_sgd_step: child %d: bad rows", s);
     rr_featmat *fm = o->fm;
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
-    const int K = o->K, F = o->F;
+    const int K = o->K, F = o->F, nk = o->nkids;
     const int64_t fk = o->fk;
     // at most two steps in flight: the event of step t - 2 (which also was the last user of this step's feature matrix)
     if (o->t >= 2) RR_CHECK_HIP(hipEventSynchronize(o->ev[o->t & 1]));
     const int par = (int)(o->t & 1);
     if (o->overlap && par) fm = o->fm2;
-    const int64_t n_main = 2 * fk + 1 + o->n_lik;
+    const int64_t n_main = 2 * fk + nk + o->n_lik;
     const unsigned nb_main = (unsigned)((n_main + 255) / 256), nb_ls = (unsigned)((o->n_ls + 255) / 256);
-    const double *xls = o->x + n_main, *xpar = o->n_lik ? o->x + 2 * fk + 1 : nullptr;
+    const double *xls = o->x + n_main, *xpar = o->n_lik ? o->x + 2 * fk + nk : nullptr;
     int rc = RR_OK;
     // ---- this step's features: after the previous step's length-scale update, on the second stream, into this step's
     //      matrix -- while the previous step's Ed product runs on the first
     hipStream_t s0 = c->stream, sf = o->overlap ? o->sfeat : s0;
     if (o->overlap && o->t >= 1) RR_CHECK_HIP(hipStreamWaitEvent(sf, o->e_ls[1 - par], 0));
     c->stream = sf;  // (every launch helper below reads the context's stream when it is called)
-    hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, sf, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
-                       o->x + n_main);
+    if (nb_ls)
+        hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, sf, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
+                           o->x + n_main);
     rc = rr_featmat_begin(fm, rows);
-    if (rc == RR_OK) rc = rr_fm_put_rff_dev(fm, o->b, dX, x_dtype, ldx, xls, o->n_ls, 0);
+    for (int s = 0; s < nk && rc == RR_OK; ++s) {
+        const rr_glm_sgd_child &k = o->kids[(size_t)s];
+        if (k.kind == RR_SGD_CHILD_RFF) rc = rr_fm_put_rff_dev(fm, k.basis, dX[s], x_dtype[s], ldx[s], xls + o->ls0[(size_t)s], k.n_ls, o->col0[(size_t)s]);
+        else rc = rr_featmat_put_linear(fm, dX[s], x_dtype[s], ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
+    }
     c->stream = s0;
     if (rc != RR_OK) return rc;
     RR_CHECK_HIP(hipGetLastError());
@@ -3272,47 +3389,54 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *dX, int x_dtype, int64_t ldx, int
     if (rc != RR_OK) return rc;
     FmPass2 &s = *(FmPass2 *)fm->pass2;
     const int64_t kl_ld = s.klp;
-    RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->b->d * o->b->n * 8, s0));
-    rc = rr_featmat_glm_plan_rff(fm, o->b, dX, x_dtype, ldx, 0, o->dT);
-    if (rc != RR_OK) return rc;
+    RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->dT_count * 8, s0));
+    const bool lone_rff = nk == 1 && o->kids[0].kind == RR_SGD_CHILD_RFF;
+    if (lone_rff) {  // the EdPhi product may contract itself with the one child (rr_gemm_gradt_f32_kernel)
+        rc = rr_featmat_glm_plan_rff(fm, o->kids[0].basis, dX[0], x_dtype[0], ldx[0], 0, o->dTk[0]);
+        if (rc != RR_OK) return rc;
+    }
     hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, s0, o->x, o->x + fk, F, K,
                        L, Fp, kl_ld, seed, key, dE, s.Ee, s.WSs);
     RR_CHECK_HIP(hipGetLastError());
     rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 1);      // fs, likelihood terms
-    if (rc == RR_OK) rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 4);  // EdPhi, contracted or stored
-    if (rc != RR_OK) return rc;
-    rc = rr_featmat_glm_rff(fm, o->b, dX, x_dtype, ldx, 0, o->dT);  // (returns at once when the step contracted EdPhi itself)
+    if (rc == RR_OK && o->n_h) rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 4);  // EdPhi, contracted or stored
+    for (int ch = 0; ch < nk && rc == RR_OK; ++ch)  // (returns at once when the step contracted EdPhi itself)
+        if (o->kids[(size_t)ch].kind == RR_SGD_CHILD_RFF)
+            rc = rr_featmat_glm_rff(fm, o->kids[(size_t)ch].basis, dX[ch], x_dtype[ch], ldx[ch], o->col0[(size_t)ch], o->dTk[(size_t)ch]);
     if (rc != RR_OK) return rc;
     SgdUpdArgs a;
     double *Edm = s.mc + 2 * fk, *EdC = s.mc + 3 * fk;
     a.x = o->x; a.red = o->red; a.Edm = Edm; a.EdC = EdC; a.aux = s.kacc + s.kcap; a.lower = o->lower; a.upper = o->upper;
     a.islog = o->islog; a.z = o->z; a.s1 = o->s1; a.s2 = o->s2;
-    a.F = F; a.K = K; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = L; a.np = o->np;
+    a.slice_of_f = o->slice_of_f; a.slice_lo = o->slice_lo; a.slice_hi = o->slice_hi; a.h_of_ls = o->h_of_ls;
+    a.F = F; a.K = K; a.nkids = nk; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = L; a.np = o->np;
     a.bmag = bmag; a.nrows = (double)rows;
     for (int i = 0; i < 4; ++i) a.up[i] = o->up[i];
     const double tt = (double)(o->t + 1);
     a.b1t = 1.0 - pow(o->up[1], tt);
     a.b2t = 1.0 - pow(o->up[2], tt);
     // the length scales: W[i,:].T[i,:], their gradient, their update -- and the next step's features may start
-    const int nh = o->n_ls == 1 ? 1 : o->b->d, npairs = K * (K + 1) / 2;
-    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)nh), dim3(256), 0, s0, o->x, F, K, o->dT, o->b->dWraw, o->b->n, nh,
-                       o->red, npairs + 1);
-    a.p0 = n_main; a.p1 = o->np; a.npart = o->npart + nb_main;
-    hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_ls), dim3(256), 0, s0, a);
-    RR_CHECK_HIP(hipGetLastError());
+    const int npairs = K * (K + 1) / 2;
+    if (o->n_ls) {
+        hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)o->n_h), dim3(256), 0, s0, o->x, F, K, nk, o->slice_lo, o->slice_hi,
+                           o->hrows, o->n_h, o->red, npairs + nk);
+        a.p0 = n_main; a.p1 = o->np; a.npart = o->npart + nb_main;
+        hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_ls), dim3(256), 0, s0, a);
+        RR_CHECK_HIP(hipGetLastError());
+    }
     RR_CHECK_HIP(hipEventRecord(o->e_ls[par], s0));
-    // Ed = dfs Phi, its reductions over the samples, the mixture's sums, the update of (m, C, reg, variance)
+    // Ed = dfs Phi, its reductions over the samples, the mixture's sums, the update of (m, C, regularisers, variance)
     rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 2);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, s0, s.Ed, s.Ee, o->x + fk, F, K,
                        L, Fp, Edm, EdC);
-    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)(npairs + 1)), dim3(256), 0, s0, o->x, F, K, o->dT, o->b->dWraw, o->b->n,
-                       nh, o->red, 0);
+    hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)(npairs + nk)), dim3(256), 0, s0, o->x, F, K, nk, o->slice_lo, o->slice_hi,
+                       o->hrows, o->n_h, o->red, 0);
     a.p0 = 0; a.p1 = n_main; a.npart = o->npart;
     hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_main), dim3(256), 0, s0, a);
     RR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(rr_glm_sgd_finish_kernel, dim3(1), dim3(256), 0, s0, o->x, o->red, s.kacc, o->npart, (int)(nb_main + nb_ls), F, K, L,
-                       o->n_lik, llconst, (double)rows, bmag, o->objs + o->t, o->norms + o->t);
+                       nk, o->slice_lo, o->slice_hi, o->n_lik, llconst, (double)rows, bmag, o->objs + o->t, o->norms + o->t);
     RR_CHECK_HIP(hipGetLastError());
     RR_CHECK_HIP(hipEventRecord(o->ev[o->t & 1], c->stream));
     o->t += 1;
@@ -3344,6 +3468,7 @@ void rr_glm_sgd_destroy(rr_glm_sgd *o) {
     if (!o) return;
     (void)hipSetDevice(o->fm->ctx->device);
     (void)hipStreamSynchronize(o->fm->ctx->stream);
+    if (o->sfeat) (void)hipStreamSynchronize(o->sfeat);
     sgd_free(o);
 }
 

@@ -259,11 +259,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
     def _resident_loop(self, params):
         """The SGD loop with parameters, updater state and gradient in device memory (`_ResidentLoop`, rr_glm_sgd) when this
-        fit is one it covers: minibatches gathered on the device, ONE random Fourier basis (Xdim <= 128) with a scalar
-        regulariser, one of the reference's likelihoods and updaters, K <= 32, one process and one GPU.  None otherwise --
-        the host loop around `_elbo` then runs, with the same results."""
+        fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a LinearBasis or a
+        concatenation of such children (Xdim <= 128, a scalar regulariser each); one of the reference's likelihoods and updaters;
+        K <= 32; one process and one GPU.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
         from . import optimize as opt
-        from .basis_functions import _ResidentRFF
+        from .basis_functions import _ResidentLinear, _ResidentRFF
         if not self._resident_sgd or os.environ.get("RR_GLM_RESIDENT_SGD", "1") == "0":
             return None
         feats = self._features()
@@ -271,16 +271,32 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 or type(feats) is not MinibatchFeatures or self.sampler not in ("host", "device"):
             return None
         kids = getattr(feats, "_kids", [])
-        if len(kids) != 1 or type(kids[0]) is not _ResidentRFF or self.basis.d > 128 or not 1 <= self.K <= 32:
+        if not 1 <= len(kids) <= 16 or not 1 <= self.K <= 32:
             return None
         if self.updater is not None and type(self.updater) not in (opt.SGDUpdater, opt.AdaDelta, opt.AdaGrad, opt.Momentum, opt.Adam):
             return None
         if type(self.likelihood) not in (Bernoulli, Binomial, Gaussian, Poisson):
             return None
-        n_reg, n_lik, n_ls = (int(np.prod(p.shape, dtype=int)) if not isinstance(p, list) else -1 for p in params[2:5])
-        if n_reg != 1 or n_lik != (1 if type(self.likelihood) is Gaussian else 0) or n_ls not in (1, self.basis.d):
+        regs, lpar = atleast_list(params[2]), atleast_list(params[3])
+        if len(regs) != len(kids) or any(getattr(p, "shape", None) != () for p in regs):  # one scalar regulariser per child
             return None
-        return _ResidentLoop(self, feats, n_lik, n_ls)
+        n_lik = sum(int(np.prod(p.shape, dtype=int)) for p in lpar)
+        if n_lik != (1 if type(self.likelihood) is Gaussian else 0):
+            return None
+        children = []
+        for kid, b in zip(kids, feats.bases):
+            if type(kid) is _ResidentRFF and b.d <= 128 and kid.W.shape[0] == b.d:
+                n_ls = int(np.prod(b.params.shape, dtype=int))
+                if n_ls not in (1, b.d):
+                    return None
+                children.append(("rff", kid.h, n_ls))
+            elif type(kid) is _ResidentLinear and int(np.prod(b.params.shape, dtype=int)) == 0:
+                children.append(("linear", int(kid.dX.shape[1]), bool(kid.onescol)))
+            else:
+                return None
+        if sum(c[2] for c in children if c[0] == "rff") != sum(int(np.prod(p.shape, dtype=int)) for p in atleast_list(params[4])):
+            return None
+        return _ResidentLoop(self, feats, n_lik, children)
 
     def _reference_draws(self, out=None):
         """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component.
@@ -651,8 +667,8 @@ class _ResidentLoop(object):
 
     log_coordinates = None
 
-    def __init__(self, glm, feats, n_lik, n_ls):
-        self.glm, self.feats, self.n_lik, self.n_ls = glm, feats, n_lik, n_ls
+    def __init__(self, glm, feats, n_lik, children):
+        self.glm, self.feats, self.n_lik, self.children = glm, feats, n_lik, children
         self.sgd = None
 
     def begin(self, z0, lower, upper, updater, maxiter):
@@ -668,7 +684,7 @@ class _ResidentLoop(object):
         self.pos = np.asarray(pos, dtype=bool)
         self.t = 0
         self.clock = []   # host time at which each step was queued (the queue is two deep: it follows the device's pace)
-        self._make = lambda M: _hip.ResidentSgd(feats.fm, feats._kids[0].h, g.K, self.n_lik, self.n_ls, z0, lower, upper, self.pos,
+        self._make = lambda M: _hip.ResidentSgd(feats.fm, self.children, g.K, self.n_lik, z0, lower, upper, self.pos,
                                                 _hip.UPDATER_IDS[kind], par, max(1, int(maxiter)))
         self._z0 = np.array(z0, dtype=float)
 
@@ -681,9 +697,14 @@ class _ResidentLoop(object):
         """(reg, likelihood parameters, basis parameters) as the host loop's log line prints them"""
         z = self.sgd.read()[0]
         x = np.where(self.pos, np.exp(np.where(self.pos, z, 0.0)), z)
-        o = 2 * self.glm.D_ * self.glm.K
-        ls = x[o + 1 + self.n_lik:]
-        return x[o], ([x[o + 1]] if self.n_lik else []), (ls[0] if self.n_ls == 1 else ls)
+        o, nk = 2 * self.glm.D_ * self.glm.K, len(self.children)
+        regs = list(x[o:o + nk])
+        ls, q = [], o + nk + self.n_lik
+        for c in self.children:
+            n = c[2] if c[0] == "rff" else 0
+            ls.append(x[q] if n == 1 else x[q:q + n])
+            q += n
+        return (regs[0] if nk == 1 else regs), ([x[o + nk]] if self.n_lik else []), (ls[0] if nk == 1 else ls)
 
     def step(self, batch):
         g, feats = self.glm, self.feats

@@ -137,8 +137,62 @@ def test_device_sampler_and_the_log_lines(caplog):
         assert abs(elbo(u) - elbo(v)) < 1e-5 * abs(elbo(v))
 
 
+@pytest.mark.parametrize("lik", ["poisson", "gaussian", "binomial"])
+def test_concatenation_of_fourier_and_linear_children(lik, monkeypatch):
+    """The reference's own model tests fit concatenations (tests/test_models.py:83-147: LinearBasis + RandomRBF + RandomMatern52):
+    every child with its own regulariser over its column slice (basis_functions.py:1712-1748), its own length scales (ARD and
+    isotropic here), its own columns of X (apply_ind); the EdPhi product is stored and contracted child by child."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    from revrand_amd import _hip
+    X, y, largs = _data(lik)
+    d = X.shape[1]
+    steps = [0]
+    real = _hip.ResidentSgd.step
+
+    def spy(self, *a, **k):
+        steps[0] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(_hip.ResidentSgd, "step", spy)
+    like = {"poisson": lk.Poisson, "gaussian": lk.Gaussian, "binomial": lk.Binomial}[lik]
+    out = []
+    for resident in (True, False):
+        basis = bs.RandomRBF(nbases=48, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()),
+                             regularizer=Parameter(1.5, Positive())) \
+            + bs.LinearBasis(onescol=True, regularizer=Parameter(0.7, Positive())) \
+            + bs.RandomMatern52(nbases=24, Xdim=2, random_state=2, apply_ind=[0, 2], lenscale=Parameter(0.8, Positive()))
+        glm = GLM(like(), basis, K=3, nsamples=8, batch_size=1500, maxiter=20, nstarts=2, random_state=11)
+        glm._resident_sgd = resident
+        np.random.seed(3)
+        steps[0] = 0
+        glm.fit(X, y, likelihood_args=largs)
+        assert steps[0] == (20 if resident else 0)
+
+        def flat(v):
+            v = v if isinstance(v, (list, tuple)) else [v]
+            return np.concatenate([np.atleast_1d(np.asarray(u, dtype=float)).ravel() for u in v] + [np.empty(0)])
+        out.append((glm.weights_.copy(), glm.covariance_.copy(), flat(glm.regularizer_), flat(glm.like_hypers_),
+                    flat([h for h in glm.basis_hypers_ if np.size(h)]), glm.random_.randn()))
+        assert out[-1][2].shape == (3,) and out[-1][4].shape == (d + 1,)
+    _same(out[0], out[1], 2e-5)
+
+
+def test_linear_basis_alone():
+    """No length scale at all: the loop runs without the length-scale half of its update."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    X, y, _ = _data("gaussian")
+    out = []
+    for resident in (True, False):
+        glm = GLM(lk.Gaussian(), bs.LinearBasis(onescol=True), K=2, nsamples=6, batch_size=800, maxiter=15, nstarts=0, random_state=4)
+        glm._resident_sgd = resident
+        np.random.seed(2)
+        glm.fit(X, y)
+        out.append((glm.weights_.copy(), glm.covariance_.copy(), np.atleast_1d(float(glm.regularizer_)),
+                    np.atleast_1d(np.asarray(glm.like_hypers_, dtype=float)), np.empty(0), glm.random_.randn()))
+    _same(out[0], out[1], 2e-5)
+
+
 def test_fits_the_loop_does_not_cover_take_the_host_loop(monkeypatch):
-    """A concatenation, a custom updater, K > 32: `_resident_loop` declines and `fit` is what it was."""
+    """A FastFood child, a custom updater, K > 32: `_resident_loop` declines and `fit` is what it was."""
     bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
     from revrand_amd import _hip
     monkeypatch.setattr(_hip.ResidentSgd, "step", lambda *a, **k: (_ for _ in ()).throw(AssertionError("resident loop used")))
@@ -147,7 +201,7 @@ def test_fits_the_loop_does_not_cover_take_the_host_loop(monkeypatch):
 
     class MyAdam(opt.Adam):
         pass
-    for basis, kw in ((bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {}),
+    for basis, kw in ((bs.LinearBasis(onescol=True) + bs.FastFoodRBF(nbases=16, Xdim=d, random_state=1), {}),
                       (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"updater": MyAdam()}),
                       (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"K": 33})):
         glm = GLM(lk.Poisson(), basis, nsamples=4, batch_size=300, maxiter=3, nstarts=0, random_state=1, **{"K": 2, **kw})
