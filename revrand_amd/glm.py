@@ -351,7 +351,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             if ring[0] and ring[0][0].shape != shape:
                 ring[0].clear()
             ring[0].append(np.empty(shape, dtype=np.float32))
-            out = ring[0][-1]
+            out = ring[0][-1]   # (every entry is written in full by the draw that follows: touched at once)
         else:
             out = ring[0][ring[1] % 16]
         ring[1] += 1

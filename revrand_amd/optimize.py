@@ -289,6 +289,8 @@ def gen_batch(data, batch_size, maxiter=np.inf, random_state=None, _reuse=False)
     # shootdowns of that stalled every thread of config 5's fit for 15-30 ms at each epoch boundary.
     # (`_reuse`: only for a consumer that holds fewer than 16 batches at a time -- `sgd`; anybody else may keep every batch)
     ring = [np.empty(N, dtype=np.int64) for _ in range(3)] if (_reuse and N >= 4096 and N >= 16 * batch_size) else None
+    for r in ring or ():
+        r.fill(0)  # (touched now: the first use of an untouched 16 MB array is 4096 page faults in the middle of the loop)
     turn = 0
     while it < maxiter:
         it += 1
