@@ -30,7 +30,10 @@ RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "test
           "tests/test_gpu_posterior.py::test_not_positive_definite_in_a_late_panel_is_reported_and_leaves_nothing_in_flight[8257-8256-default]",
           # round 4: `predict` from the feature kernel alone (no feature-major output), ragged row counts; the paired
           # triangular product with the diagonal blocks' zero quarters skipped runs under the two predict tests above
-          "tests/test_gpu_slm.py::test_predict_of_a_random_kernel_basis_comes_from_the_feature_kernel_alone"]
+          "tests/test_gpu_slm.py::test_predict_of_a_random_kernel_basis_comes_from_the_feature_kernel_alone",
+          # round 5: the resident SVI loop (per-child tables, two feature matrices, the second stream), ragged minibatches
+          "tests/test_gpu_resident_sgd.py::test_concatenation_of_fourier_and_linear_children[gaussian]",
+          "tests/test_gpu_resident_sgd.py::test_resident_loop_equals_host_loop[poisson]"]
 
 
 def _asan_runtime():
@@ -65,6 +68,7 @@ def test_asan_build_passes_the_abi_checks():
         pytest.skip("make -C revrand_amd/csrc asan has not been run")
     # the ABI checks, and the one host-only entry point with real work in it (rr_legacy_randn: worker threads, scratch)
     r = _pytest_with(ASAN_LIB, ["tests/test_abi.py", "tests/test_host_logic.py::test_library_generator_reproduces_numpy_legacy_randn",
+                                "tests/test_host_logic.py::test_library_generator_reproduces_numpy_legacy_permutation",
                                 "-m", "not gpu"], preload=rt, timeout=900)
     assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, (r.stdout[-1500:], r.stderr[-3000:])
 

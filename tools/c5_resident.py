@@ -25,7 +25,8 @@ for rep in range(int(os.environ.get("REPS", "2"))):
         sampler = ("host", "device")[rep % 2]
     for iters in (short, long_):
         g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
-                                   K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler)
+                                   K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler,
+                                   gram_engine=os.environ.get("ENGINE") or None)
         g._resident_sgd = resident
         marks = {"A": [], "B": []}
         if os.environ.get("STAGES"):   # when did each pipeline stage finish each batch?
