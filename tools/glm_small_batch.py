@@ -19,6 +19,12 @@ for resident in (True, False, True, False):
     basis = bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=20, Xdim=2) + bs.RandomMatern52(nbases=20, Xdim=2)
     glm = GeneralizedLinearModel(lk.Gaussian(), basis, random_state=1)
     glm._resident_sgd = resident
+    marks = []
+    ah = glm._ahead
+
+    def ahead(batch, draws=True, ah=ah):
+        t0 = time.perf_counter(); r = ah(batch, draws); marks.append(time.perf_counter() - t0); return r
+    glm._ahead = ahead
     np.random.seed(0)
     t0 = time.perf_counter()
     glm.fit(X, y)
@@ -27,3 +33,9 @@ for resident in (True, False, True, False):
     print("%s: fit %.2f s (%d random starts + %d steps: %.0f us per step), smse %.2e"
           % ("resident loop" if resident else "host loop    ", t, glm.nstarts, glm.maxiter, 1e6 * t / (glm.maxiter + glm.nstarts),
              ((Ey - y[:50]) ** 2).mean() / y.var()))
+    if marks:
+        print("   upload stage per batch: median %.0f us" % (1e6 * np.median(marks)))
+    ck = glm.__dict__.get("_resident_clock")
+    if ck is not None:
+        dt = 1e6 * np.diff(ck[20:-2])
+        print("   step intervals: mean %.0f us, median %.0f us, p90 %.0f us" % (dt.mean(), np.median(dt), np.percentile(dt, 90)))
