@@ -3252,7 +3252,10 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
     for (int i = 0; i < 4; ++i) o->up[i] = upd_par[i];
     const size_t nb = (size_t)o->np * 8, nblocks = (size_t)((o->np + 255) / 256) + 1;  // (main and length-scale launches)
     const char *ov = getenv("RR_GLM_SGD_OVERLAP");
-    o->overlap = !(ov && atoi(ov) == 0);
+    // (the second stream and matrix pay when a step's features are worth hiding: not for the reference's default batch of 10
+    // rows, where a step is ~35 launches of a few microseconds and two more events only add to the host's part.
+    // RR_GLM_SGD_OVERLAP=1 forces it, for tests)
+    o->overlap = ov ? atoi(ov) != 0 : fm->max_rows * (int64_t)fm->F >= ((int64_t)1 << 22);
     hipError_t e = hipMalloc((void **)&o->z, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->x, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->s1, nb);

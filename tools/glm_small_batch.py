@@ -25,6 +25,14 @@ for resident in (True, False, True, False):
     def ahead(batch, draws=True, ah=ah):
         t0 = time.perf_counter(); r = ah(batch, draws); marks.append(time.perf_counter() - t0); return r
     glm._ahead = ahead
+    from revrand_amd import _hip
+    calls = []
+    if not hasattr(_hip.ResidentSgd, "_real_step"):
+        _hip.ResidentSgd._real_step = _hip.ResidentSgd.step
+
+    def timed(self, *a, calls=calls, **k):
+        t0 = time.perf_counter(); r = _hip.ResidentSgd._real_step(self, *a, **k); calls.append(time.perf_counter() - t0); return r
+    _hip.ResidentSgd.step = timed
     np.random.seed(0)
     t0 = time.perf_counter()
     glm.fit(X, y)
@@ -33,6 +41,8 @@ for resident in (True, False, True, False):
     print("%s: fit %.2f s (%d random starts + %d steps: %.0f us per step), smse %.2e"
           % ("resident loop" if resident else "host loop    ", t, glm.nstarts, glm.maxiter, 1e6 * t / (glm.maxiter + glm.nstarts),
              ((Ey - y[:50]) ** 2).mean() / y.var()))
+    if calls:
+        print("   rr_glm_sgd_step on the host: median %.0f us" % (1e6 * np.median(calls)))
     if marks:
         print("   upload stage per batch: median %.0f us" % (1e6 * np.median(marks)))
     ck = glm.__dict__.get("_resident_clock")
