@@ -238,3 +238,37 @@ def test_config5_shape_runs_the_fused_contraction_and_improves_the_objective(mon
         out.append((glm.weights_.copy(), glm.covariance_.copy(), np.array(glm.basis_hypers_), float(glm.regularizer_)))
     (wa, ca, ha, ra), (wb, cb, hb, rb) = out
     assert normwise(wa, wb) < 1e-4 and normwise(ca, cb) < 1e-4 and normwise(ha, hb) < 1e-4 and abs(ra - rb) < 1e-4 * rb
+
+
+def test_edge_shapes_refits_clone_and_pickle():
+    """The loop at the edges: one mixture component, one step, a batch larger than the data (batch = N), an estimator fitted
+    twice, cloned and pickled afterwards, then serving -- each against the host loop."""
+    import pickle
+    from sklearn.base import clone
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    X, y, _ = _data("poisson", N=700)
+    d = X.shape[1]
+
+    def make(resident, **kw):
+        basis = bs.RandomRBF(nbases=24, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        g = GLM(lk.Poisson(), basis, nsamples=5, random_state=7, nstarts=0, **kw)
+        g._resident_sgd = resident
+        return g
+
+    def fitted(g):
+        np.random.seed(4)
+        g.fit(X, y)
+        return np.concatenate((g.weights_.ravel(), g.covariance_.ravel(), np.atleast_1d(g.basis_hypers_), [float(g.regularizer_)]))
+    for kw in ({"K": 1, "batch_size": 64, "maxiter": 9}, {"K": 2, "batch_size": 64, "maxiter": 1},
+               {"K": 2, "batch_size": 5000, "maxiter": 6}, {"K": 3, "batch_size": 10, "maxiter": 40}):
+        a, b = fitted(make(True, **kw)), fitted(make(False, **kw))
+        assert normwise(a, b) < 2e-5, (kw, normwise(a, b))
+    g = make(True, K=2, batch_size=100, maxiter=8)
+    first = fitted(g)
+    g.random_ = np.random.RandomState(7)
+    assert normwise(fitted(g), first) < 2e-5          # a second fit of the same estimator starts from scratch
+    assert np.all(np.isfinite(g.predict(X[:50])))      # serving after a resident fit
+    g2 = pickle.loads(pickle.dumps(g))
+    assert np.array_equal(g2.weights_, g.weights_) and "_resident_clock" not in g2.__dict__
+    c = clone(g)
+    assert c.get_params()["K"] == 2 and not hasattr(c, "weights_")
