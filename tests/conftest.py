@@ -14,7 +14,6 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "one_stream: test_gpu_resident_sgd.py -- the resident loop without its second stream")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -12,12 +12,12 @@ from conftest import normwise
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _second_stream(monkeypatch, request):
-    """The loop takes its second stream and feature matrix (next step's features under this step's Ed product) by default only
-    when a step is large (rows x F >= 2^22: config 5's shape below); these small fits force it, so that both orders of
-    work are held to the host loop -- except the tests marked `one_stream`."""
-    monkeypatch.setenv("RR_GLM_SGD_OVERLAP", "0" if request.node.get_closest_marker("one_stream") else "1")
+@pytest.fixture(autouse=True, params=["two streams", "one stream"])
+def _order_of_work(monkeypatch, request):
+    """Both forms of the loop are held to the host loop by every test here: with the second stream and feature matrix (next
+    step's features under this step's Ed product -- the library's choice when a step is large, rows x F >= 2^22: config 5's
+    shape below) and without (small steps)."""
+    monkeypatch.setenv("RR_GLM_SGD_OVERLAP", "1" if request.param == "two streams" else "0")
 
 
 def _imports():
@@ -95,7 +95,6 @@ def test_resident_loop_equals_host_loop(lik, monkeypatch):
     _same(dev, host, 2e-5)
 
 
-@pytest.mark.one_stream
 def test_isotropic_length_scale_takes_dimension_zero_only_like_the_reference():
     _same(_fit(True, iso=True), _fit(False, iso=True), 2e-5)
 
@@ -185,7 +184,6 @@ def test_concatenation_of_fourier_and_linear_children(lik, monkeypatch):
     _same(out[0], out[1], 2e-5)
 
 
-@pytest.mark.one_stream
 def test_linear_basis_alone():
     """No length scale at all: the loop runs without the length-scale half of its update."""
     bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
