@@ -1571,9 +1571,56 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
     return RR_OK;
 }
 
+// Small products (the reference's default minibatch of 10 rows: 256 x 1024 x 256 once padded).  A 256 x 256 tile of the kernel
+// above is one workgroup walking its k-blocks at the rate of ONE CU -- 7 us per 32-row k-block, 60-70 us for K = 256, most of it
+// spent on padding -- and the GLM step has three such products on its dependent chain (200 of its 340 us).  Here a workgroup
+// owns a 32 x 32 block of D (2 x 2 per thread, k in steps of 32 through LDS, plain FMAs): hundreds of workgroups instead of a
+// handful, a few microseconds.  Same operands, zero padding included; summation order differs from the tile kernel's.
+__global__ void __launch_bounds__(256)
+rr_gemm_tn_small_f32_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb, float *__restrict__ D,
+                            int64_t ldd, int K) {
+    __shared__ float As[32][33], Bs[32][33];
+    const int ti = blockIdx.y * 32, tj = blockIdx.x * 32;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    for (int k0 = 0; k0 < K; k0 += 32) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = q * 256 + threadIdx.x, kk = e >> 5, cc = e & 31;
+            As[kk][cc] = A[(int64_t)(k0 + kk) * lda + ti + cc];
+            Bs[kk][cc] = B[(int64_t)(k0 + kk) * ldb + tj + cc];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 32; ++kk) {
+            const float a0 = As[kk][2 * ty], a1 = As[kk][2 * ty + 1], b0 = Bs[kk][2 * tx], b1 = Bs[kk][2 * tx + 1];
+            acc[0][0] = fmaf(a0, b0, acc[0][0]);
+            acc[0][1] = fmaf(a0, b1, acc[0][1]);
+            acc[1][0] = fmaf(a1, b0, acc[1][0]);
+            acc[1][1] = fmaf(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) D[(int64_t)(ti + 2 * ty + i) * ldd + tj + 2 * tx + j] = acc[i][j];
+}
+
+static inline bool fm_gemm_is_small(int64_t Kd, int64_t Md, int64_t Nd) {
+    static const bool off = getenv("RR_GEMM_SMALL") != nullptr && atoi(getenv("RR_GEMM_SMALL")) == 0;  // (A/B runs)
+    return !off && Kd * Md * Nd <= ((int64_t)1 << 27) && Md / 32 < 65536;
+}
+
 static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd, int64_t Kd,
                    int64_t Md, int64_t Nd) {
     RR_REQUIRE(lda < (1 << 25) && ldb < (1 << 25), "GEMM: leading dimensions up to 2^25 floats (rr_dma_kblock's 32-bit row offsets)");
+    if (fm_gemm_is_small(Kd, Md, Nd)) {
+        hipLaunchKernelGGL(rr_gemm_tn_small_f32_kernel, dim3((unsigned)(Nd / 32), (unsigned)(Md / 32)), dim3(256), 0, c->stream, A, lda, B,
+                           ldb, D, ldd, (int)Kd);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
     GemmArgs g;
     g.A = A; g.B = B; g.D = D; g.lda = lda; g.ldb = ldb; g.ldd = ldd; g.K = (int)Kd; g.ntb = (int)(Nd / 256);
     const int64_t tiles = (Md / 256) * g.ntb, nkb = Kd / GR_KB;
@@ -2592,7 +2639,9 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         const int64_t tiles1 = (rows256 / 256) * (kl_ld / 256);
         const bool lik_force = fl && !strcmp(fl, "force"), lik_off = fl && !strcmp(fl, "0");
         const bool lik_auto = tiles1 >= 2 * (int64_t)c->num_cu || Fp / GR_KB < 16;  // (fm_gemm would not split K)
-        s.fuse.take_lik = !no_fuse && c->gram_engine == 0 && !c->deterministic && !lik_off && (lik_force || lik_auto) &&
+        // (a small product goes to the small kernel and the likelihood kernel behind it: one tile's k-loop would take longer)
+        const bool small = !lik_force && fm_gemm_is_small(Fp, rows256, kl_ld);
+        s.fuse.take_lik = !no_fuse && c->gram_engine == 0 && !c->deterministic && !lik_off && (lik_force || lik_auto) && !small &&
                           fm->max_rows < (1 << 20) && kl_ld < (1 << 20);
         if (s.fuse.take_lik) {
             GemmLikArgs g;
