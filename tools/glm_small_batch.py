@@ -17,7 +17,7 @@ y = 3 + 2 * x + rs.randn(600) * 1e-4
 X = np.column_stack((np.ones(600), x))
 for resident in (True, False, True, False):
     basis = bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=20, Xdim=2) + bs.RandomMatern52(nbases=20, Xdim=2)
-    glm = GeneralizedLinearModel(lk.Gaussian(), basis, random_state=1)
+    glm = GeneralizedLinearModel(lk.Gaussian(), basis, random_state=1, sampler=os.environ.get("SAMPLER", "host"))
     glm._resident_sgd = resident
     marks = []
     ah = glm._ahead
