@@ -253,6 +253,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                  .format(self.regularizer_, self.like_hypers_, self.basis_hypers_, res.message))
         return self
 
+    def _iteration(self, advance=0):
+        """The SGD iteration counter `_elbo` logs by (glm.py:233-236), for the resident loop that runs instead of `_elbo`."""
+        it = self.__it
+        self.__it = it + advance
+        return it
+
     _prefetch_draws = True  # False: `_elbo` draws for itself, strictly sequentially (what the tests compare against)
     _draw_buffers = 3
     _resident_sgd = True    # False (or RR_GLM_RESIDENT_SGD=0): always the host loop around `_elbo` (tests, A/B runs)
@@ -725,7 +731,7 @@ class _ResidentLoop(object):
             lid, rowarg, llconst = RR_LIK_GAUSSIAN, None, 0.0
         else:
             lid, _, rowarg, llconst = spec if spec is not None else g.likelihood.device_spec(y, [], largs)
-        it = g._GeneralizedLinearModel__it
+        it = g._iteration(advance=1)
         dolog = (it % LOGITER == 0) or (it == g.maxiter - 1)
         if self.sgd is None:
             self._start(len(idx))
@@ -749,7 +755,6 @@ class _ResidentLoop(object):
             log.info("Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
                      .format(it, -self.sgd.objective(self.t), shown[0], shown[1], shown[2]))
         self.t += 1
-        g._GeneralizedLinearModel__it = it + 1
 
     def end(self):
         if self.sgd is None:   # no step was taken (maxiter = 0)
