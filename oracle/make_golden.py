@@ -503,6 +503,128 @@ def gen_glm():
     save("glm", **out)
 
 
+def gen_glm_fit():
+    """End-to-end `GeneralizedLinearModel.fit` of the reference (glm.py:141-203): random starts (decorators.py:541-583),
+    structured_sgd / logtrick_sgd (decorators.py:133-252, 329-408), sgd with bounds (optimize/sgd.py:337-425) and the
+    interleaving of `gen_batch` permutations with `_reparam_k` draws on ONE RandomState -- 20 Adam steps on small data,
+    seeds fixed (the estimator's `random_state` and NumPy's global stream, from which the reference draws the start
+    point).  Stored per case: data, W of every Fourier child, the five fitted blocks, the optimiser's objective / norm
+    records and `random_.randn()` after the fit (the stream's end state).
+
+    `bs64f` cases: the reference's structured_sgd does not forward `batch_size` to sgd (decorators.py:244-246), so its
+    main loop always runs sgd's default of 10 rows while B_ = N / batch_size.  The implementation here forwards it.  For
+    those cases the REFERENCE'S OWN code is run with sgd's default batch size set to the estimator's (`functools.partial`
+    on the name `revrand.glm` imported, process-local); `bs64` (no `f`) is the unmodified reference at batch_size=64."""
+    import functools
+    from scipy.stats import gamma
+    import revrand.glm as rglm
+    import revrand.likelihoods as rl
+    from revrand.btypes import Bound
+    real_sgd = rglm.sgd
+    out = {}
+    rs = np.random.RandomState(21)
+    N, d, n = 300, 3, 8
+    X = rs.randn(N, d)
+    f = 0.6 * np.sin(X[:, 0]) + 0.3 * X[:, 1]
+    nbin = rs.randint(4, 12, size=N).astype(float)
+    ys = {"poisson_exp": rs.poisson(np.exp(f)).astype(float), "gaussian": f + 0.1 * rs.randn(N),
+          "binomial": rs.binomial(nbin.astype(int), 1 / (1 + np.exp(-2 * f))).astype(float)}
+    out.update(X=X, nbin=nbin, **{"y_" + k: v for k, v in ys.items()})
+    K, L, maxiter, seed, gseed = 3, 6, 20, 17, 5
+    out.update(K=K, L=L, maxiter=maxiter, seed=seed, global_seed=gseed, nbases=n)
+
+    def ard_rbf():
+        return rb.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(gamma(4., scale=0.25), Positive(), shape=(d,)))
+
+    def concat():  # tests/test_models.py:97-99
+        return rb.LinearBasis(onescol=True) + rb.RandomRBF(nbases=n, Xdim=d, random_state=3) \
+            + rb.RandomMatern52(nbases=n, Xdim=d, random_state=4)
+
+    def bounded():  # a plain Bound (no log trick) that 20 Adam steps of 0.01 run into
+        return rb.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(1.0, Bound(0.996, 1.001)))
+
+    def posupper():  # Positive with an upper limit: the log trick's upper bound log(upper)
+        return rb.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(1.0, Positive(1.03)))
+
+    def child_specs(basis):
+        kids = basis.bases if hasattr(basis, "bases") else [basis]
+        ch, regs, lss = [], [], []
+        for b in kids:
+            r = b.regularizer
+            regs.append(orc.ParamSpec(dist=r.dist, value=None if r.dist is not None else r.value, positive=True, shape=r.shape))
+            if isinstance(b, rb.LinearBasis):
+                ch.append(("linear", b.onescol))
+                lss.append(orc.ParamSpec(value=[]))
+            else:
+                p = b.params
+                ch.append(("rff", b.W, int(np.prod(p.shape, dtype=int))))
+                lss.append(orc.ParamSpec(dist=p.dist, value=None if p.dist is not None else p.value,
+                                         positive=isinstance(p.bounds, Positive), lower=None if isinstance(p.bounds, Positive) else p.bounds.lower,
+                                         upper=p.bounds.upper, shape=p.shape))
+        return ch, regs, lss
+
+    cases = [  # tag, likelihood, basis, batch_size, nstarts, forward batch size to sgd
+        ("poisson_ard_bs10_ns0", "poisson_exp", ard_rbf, 10, 0, False),
+        ("poisson_ard_bs10_ns5", "poisson_exp", ard_rbf, 10, 5, False),
+        ("gaussian_cat_bs10_ns5", "gaussian", concat, 10, 5, False),
+        ("gaussian_cat_bs10_ns0", "gaussian", concat, 10, 0, False),
+        ("binomial_cat_bs10_ns3", "binomial", concat, 10, 3, False),
+        ("poisson_ard_bs64f_ns5", "poisson_exp", ard_rbf, 64, 5, True),
+        ("gaussian_cat_bs64f_ns0", "gaussian", concat, 64, 0, True),
+        ("poisson_ard_bs64_ns5", "poisson_exp", ard_rbf, 64, 5, False),
+        ("poisson_bound_bs10_ns0", "poisson_exp", bounded, 10, 0, False),
+        ("gaussian_posupper_bs64f_ns4", "gaussian", posupper, 64, 4, True),
+    ]
+    mk = {"poisson_exp": lambda: rl.Poisson("exp"), "gaussian": rl.Gaussian, "binomial": rl.Binomial}
+    for tag, lik, mkbasis, bs, ns, fwd in cases:
+        basis = mkbasis()
+        like = mk[lik]()
+        largs = (nbin,) if lik == "binomial" else ()
+        cap = []
+
+        def spy(*a, **k):
+            if fwd:
+                k.setdefault("batch_size", bs)
+            res = real_sgd(*a, **k)
+            cap.append(res)
+            return res
+        rglm.sgd = spy
+        try:
+            glm = rglm.GeneralizedLinearModel(like, basis, K=K, nsamples=L, batch_size=bs, maxiter=maxiter, nstarts=ns,
+                                              random_state=seed)
+            np.random.seed(gseed)
+            glm.fit(X, ys[lik], likelihood_args=largs)
+        finally:
+            rglm.sgd = real_sgd
+        end = glm.random_.randn()
+        res = cap[0]
+        ch, regs, lss = child_specs(basis)
+        lp = like.params
+        likpar = [orc.ParamSpec(dist=lp.dist, positive=True, shape=lp.shape)] if lik == "gaussian" else []
+        o = orc.glm_fit(X, ys[lik], lik, list(largs), ch, regs, likpar, lss, K, L, bs, maxiter, ns, seed, gseed,
+                        sgd_batch_size=bs if fwd else 10)
+        flat = lambda v: np.concatenate([np.ravel(np.asarray(u, float)) for u in (v if isinstance(v, (list, tuple)) else [v])] + [np.empty(0)])
+        close(o[0], glm.weights_, 1e-9)
+        close(o[1], glm.covariance_, 1e-9)
+        close(flat(o[2]), flat(glm.regularizer_), 1e-9)
+        close(flat(o[3]), flat(glm.like_hypers_), 1e-9)
+        close(flat(o[4]), flat(glm.basis_hypers_), 1e-9)
+        close(o[6], np.array(res.norms), 1e-9)
+        fin = np.isfinite(np.array(res.objs, float))
+        assert np.array_equal(fin, np.isfinite(o[5])) and fin.any()
+        close(o[5][fin], np.array(res.objs, float)[fin], 1e-9)
+        assert o[7] == end, (o[7], end)
+        out.update({tag + "_m": glm.weights_, tag + "_C": glm.covariance_, tag + "_reg": flat(glm.regularizer_),
+                    tag + "_lik": flat(glm.like_hypers_), tag + "_ls": flat(glm.basis_hypers_),
+                    tag + "_norms": np.array(res.norms), tag + "_objs": np.array(res.objs, float), tag + "_end": np.array(end)})
+        for i, c in enumerate(ch):
+            if c[0] == "rff":
+                out["%s_W%d" % (tag, i)] = c[1]
+        print("   ", tag, "||g|| first/last %.4g %.4g" % (res.norms[0], res.norms[-1]),
+              "ls", np.round(flat(glm.basis_hypers_), 4))
+    save("glm_fit", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `make_golden.py fit_c1`
         for name in sys.argv[1:]:
@@ -520,4 +642,5 @@ if __name__ == "__main__":
     gen_fit_c1()
     gen_fit_converged()
     gen_glm()
+    gen_glm_fit()
     print("oracle agrees with the reference on every fixture")

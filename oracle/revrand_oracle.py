@@ -559,3 +559,162 @@ def sgd_update(name, state, x, grad, **hp):
         vbar = state["v"] / (1 - b2 ** state["t"])
         return x - a * mbar / (np.sqrt(vbar) + eps)
     raise ValueError(name)
+
+
+# --------------------------------------------------------------------------
+# a-15 / f-3  GeneralizedLinearModel.fit: the optimiser stack around `_elbo`
+# --------------------------------------------------------------------------
+
+class ParamSpec(object):
+    """What the optimiser stack needs of a btypes.Parameter (btypes.py:193-349): a value OR a scipy.stats frozen
+    distribution, whether its bound is Positive (log trick) and the bound's limits."""
+
+    def __init__(self, value=None, dist=None, positive=False, lower=None, upper=None, shape=()):
+        self.value, self.dist, self.positive = value, dist, positive
+        self.lower = 1e-14 if (positive and lower is None) else lower      # btypes.py:176 (Positive's lower)
+        self.upper = upper
+        self.shape = tuple(shape) if dist is not None else np.shape(value if value is not None else [])
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=int))
+
+    def rvs(self, rs):
+        """btypes.py:290-324: a clipped draw, or the value."""
+        if self.dist is None:
+            return self.value
+        s = self.dist.rvs(size=self.shape, random_state=rs)
+        if not self.lower and not self.upper:                               # btypes.py:61-79 (clip)
+            return s
+        return np.clip(s, self.lower, self.upper)
+
+
+def glm_features(children):
+    """The concatenated feature map of a GLM fit as a closure ``(X, [basis parameters]) -> (Phi, [dPhi slab per flat
+    length-scale coordinate], [column slice per child])``.  children: ("linear", onescol) | ("rff", W, n_ls) with
+    n_ls = 1 (isotropic: the dimension-0 slab only, basis_functions.py:896) or d (ARD).  Gradient slabs are zero-padded
+    to the concatenation's width (basis_functions.py:1629-1677)."""
+    def build(X, bpars):
+        cols, slabs, o = [], [], 0
+        for c, p in zip(children, bpars):
+            cols.append(linear_transform(X, c[1]) if c[0] == "linear" else rff_transform(X, c[1], p))
+        Phi = np.hstack(cols)
+        slices = []
+        for c, p, blk in zip(children, bpars, cols):
+            w = blk.shape[1]
+            slices.append(slice(o, o + w))
+            if c[0] == "rff":
+                g = rff_grad(X, c[1], p)
+                for s in ([g] if g.ndim == 2 else [g[:, :, i] for i in range(g.shape[2])]):
+                    full = np.zeros_like(Phi)
+                    full[:, o:o + w] = s
+                    slabs.append(full)
+            o += w
+        return Phi, slabs, slices
+    return build
+
+
+def glm_fit(X, y, lik, largs, children, regs, likpar, lss, K, L, batch_size, maxiter, nstarts, seed, global_seed,
+            sgd_batch_size=10, adam=(0.01, 0.9, 0.99, 1e-8)):
+    """GeneralizedLinearModel.fit (glm.py:141-203) with the optimiser it builds, ``structured_sgd(logtrick_sgd(sgd))``
+    (glm.py:176), restated as one loop:
+
+    * structured_sgd (optimize/decorators.py:133-252): the start point is a draw of every random Parameter from NumPy's
+      GLOBAL stream (``flatten(..., ravel=bt.ravel)`` -> ``rvs(random_state=None)``, btypes.py:351-371); with nstarts > 0
+      the best of nstarts candidates replaces it -- per candidate: a minibatch of ``batch_size`` rows off
+      ``gen_batch`` (one RandomState: the estimator's ``random_``), then a draw of every Parameter from that same
+      RandomState, then ``_elbo`` (which draws K x randn(L, D) from it) -- first minimum wins (decorators.py:541-583);
+    * the main loop's batch size is ``sgd``'s own default of 10: structured_sgd does NOT forward batch_size
+      (decorators.py:244-246) -- `sgd_batch_size` (pass batch_size for an implementation that forwards it);
+    * logtrick_sgd (decorators.py:329-408, 586-616): z = log x on Positive coordinates, gradient times exp(z), bounds
+      (log 1e-100, log upper | log sqrt(max float));
+    * sgd (optimize/sgd.py:337-425): fresh ``endless_permutations`` (utils/rand.py:7-31), per step a batch, ``fun``,
+      ||grad||, outward gradients truncated on coordinates AT a bound, Adam (sgd.py:259-330), clip;
+    * `_elbo`'s iteration counter starts at -nstarts; the objective is only evaluated while it is negative, every 500th
+      iteration and at maxiter - 1 (glm.py:232-236), inf otherwise.
+
+    regs / lss: one ParamSpec per child (shape (0,) for a child without length scale); likpar: [] or [ParamSpec].
+    Returns (m, C, regs, likpars, lss, objs, norms, next randn of the estimator's RandomState)."""
+    from scipy.stats import gamma as _gamma, norm as _norm
+    rs = np.random.RandomState(seed)
+    grs = np.random.RandomState(global_seed)
+    X, y = np.asarray(X, float), np.asarray(y, float)
+    N = len(X)
+    B = N / batch_size
+    feats = glm_features(children)
+    D = feats(X[:1], [np.ones(p.shape) if p.size else [] for p in lss])[0].shape[1]
+    specs = [ParamSpec(dist=_norm(), shape=(D, K)), ParamSpec(dist=_gamma(a=2, scale=0.5), positive=True, shape=(D, K))] \
+        + list(regs) + list(likpar) + list(lss)
+    nreg, nlik = len(regs), len(likpar)
+
+    def flat(vals):
+        return np.concatenate([np.ravel(np.asarray(v, float)) for v in vals]) if vals else np.empty(0)
+
+    def unflat(x):
+        out, o = [], 0
+        for p in specs:
+            v = x[o:o + p.size]
+            out.append(float(v[0]) if p.shape == () else v.reshape(p.shape))
+            o += p.size
+        return out
+
+    it = [-nstarts]
+
+    def elbo(vals, idx):
+        m, C = vals[0], vals[1]
+        rg, lp, bp = vals[2:2 + nreg], vals[2 + nreg:2 + nreg + nlik], vals[2 + nreg + nlik:]
+        Phi, slabs, slices = feats(X[idx], bp)
+        diag = np.concatenate([np.full(s.stop - s.start, r) for s, r in zip(slices, rg)])
+        e = np.stack([rs.randn(L, D) for _ in range(K)])
+        dolog = (it[0] % 500 == 0) or (it[0] == maxiter - 1)
+        calc = dolog or it[0] < 0
+        it[0] += 1
+        o, (ndm, ndC, dL, dlp, dbp) = glm_elbo(m, C, diag, slices, lik, list(lp), [a[idx] for a in largs], Phi, slabs,
+                                                y[idx], e, B, calc_ll=calc)
+        return o, flat([ndm, ndC] + list(dL) + list(dlp) + list(dbp))
+
+    def batches(bs):
+        perm, pos = np.empty(0, dtype=int), 0
+        while True:
+            ind = []
+            for _ in range(min(bs, N)):
+                if pos == len(perm):
+                    perm, pos = rs.permutation(N), 0
+                ind.append(perm[pos])
+                pos += 1
+            yield np.array(ind)
+
+    x0 = flat([p.rvs(grs) for p in specs])
+    if nstarts > 0:
+        gen, best = batches(batch_size), None
+        for _ in range(nstarts):
+            idx = next(gen)
+            cand = [p.rvs(rs) for p in specs]
+            obj = elbo(cand, idx)[0]
+            if best is None or obj < best[0]:
+                best = (obj, cand)
+        x0 = flat(best[1])
+
+    pos = np.concatenate([np.full(p.size, p.positive) for p in specs])
+    lo = np.concatenate([np.full(p.size, np.log(1e-100) if p.positive else (-np.inf if p.lower is None else p.lower))
+                         for p in specs])
+    hi = np.concatenate([np.full(p.size, (np.log(np.sqrt(np.finfo(float).max)) if p.upper is None else np.log(p.upper))
+                                 if p.positive else (np.inf if p.upper is None else p.upper)) for p in specs])
+    z = np.array(x0, dtype=float)
+    z[pos] = np.log(z[pos])
+    state, objs, norms = {}, [], []
+    gen = batches(sgd_batch_size)
+    hp = dict(zip(("alpha", "beta1", "beta2", "epsilon"), adam))
+    for _ in range(maxiter):
+        idx = next(gen)
+        x = np.where(pos, np.exp(np.where(pos, z, 0.)), z)
+        obj, g = elbo(unflat(x), idx)
+        g = np.where(pos, g * np.exp(np.where(pos, z, 0.)), g)
+        objs.append(obj)
+        norms.append(np.linalg.norm(g))
+        g[z <= lo] = np.minimum(g[z <= lo], 0)
+        g[z >= hi] = np.maximum(g[z >= hi], 0)
+        z = np.clip(sgd_update("adam", state, z, g, **hp), lo, hi)
+    vals = unflat(np.where(pos, np.exp(np.where(pos, z, 0.)), z))
+    return (vals[0], vals[1], vals[2:2 + nreg], vals[2 + nreg:2 + nreg + nlik], vals[2 + nreg + nlik:],
+            np.array(objs), np.array(norms), rs.randn())

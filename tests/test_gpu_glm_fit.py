@@ -1,0 +1,84 @@
+"""`GeneralizedLinearModel.fit` against fits THE REFERENCE computed (tests/golden/glm_fit.npz, oracle/make_golden.py:
+gen_glm_fit; cases in tests/glm_fit_cases.py) -- both SVI loops: the host loop (optimize.sgd o logtrick_sgd o structured_sgd
+around `_elbo`) and the resident loop (rr_glm_sgd_*, glm._ResidentLoop).  What the piecewise fixtures (one `_elbo`, five
+updater steps: test_gpu_glm.py) leave open is pinned here: random starts (decorators.py:541-583), the start point drawn from
+NumPy's global stream (btypes.py:351-371), the log trick and its bounds (decorators.py:329-408, 586-616), truncation and
+clipping at bounds (optimize/sgd.py:404-420), and the interleaving of `gen_batch`'s permutations with `_reparam_k`'s draws on
+one RandomState (glm.py:300, utils/rand.py:7-31) -- the stream must END in the reference's state.
+
+Tolerance: 1e-4 normwise per fitted block after 20 Adam steps (the step's products are float32 on the device, the
+reference's float64; Adam's normalised step passes a gradient's relative error on to the parameters)."""
+import numpy as np
+import pytest
+
+from conftest import normwise
+from glm_fit_cases import IMPLEMENTED
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def _model(g, case):
+    from scipy.stats import gamma
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd.btypes import Bound, Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    tag, lik, kind, batch, nstarts, _ = case
+    d, n = g["X"].shape[1], int(g["nbases"])
+    if kind == "cat":   # the reference's model-test basis (tests/test_models.py:97-99)
+        basis = bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=n, Xdim=d, random_state=3) \
+            + bs.RandomMatern52(nbases=n, Xdim=d, random_state=4)
+        for i, b in enumerate(basis.bases[1:], 1):
+            assert np.array_equal(b.W, g["%s_W%d" % (tag, i)])   # the reference's frequencies, bit for bit
+    else:
+        ls = {"ard": lambda: Parameter(gamma(4., scale=0.25), Positive(), shape=(d,)),
+              "bound": lambda: Parameter(1.0, Bound(0.996, 1.001)),
+              "posupper": lambda: Parameter(1.0, Positive(1.03))}[kind]()
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=ls)
+        assert np.array_equal(basis.W, g[tag + "_W0"])
+    like = {"poisson_exp": lambda: lk.Poisson("exp"), "gaussian": lk.Gaussian, "binomial": lk.Binomial}[lik]()
+    glm = GeneralizedLinearModel(like, basis, K=int(g["K"]), nsamples=int(g["L"]), batch_size=batch, maxiter=int(g["maxiter"]),
+                                 nstarts=nstarts, random_state=int(g["seed"]))
+    return glm, ((g["nbin"],) if lik == "binomial" else ())
+
+
+def _flat(v):
+    v = v if isinstance(v, (list, tuple)) else [v]
+    return np.concatenate([np.ravel(np.asarray(u, dtype=float)) for u in v] + [np.empty(0)])
+
+
+@pytest.mark.parametrize("resident", [True, False], ids=["resident loop", "host loop"])
+@pytest.mark.parametrize("case", IMPLEMENTED, ids=[c[0] for c in IMPLEMENTED])
+def test_fit_equals_the_references_fit(golden, case, resident, monkeypatch):
+    from revrand_amd import _hip
+    g = golden("glm_fit")
+    tag, lik = case[0], case[1]
+    glm, largs = _model(g, case)
+    glm._resident_sgd = resident
+    steps = [0]
+    real = _hip.ResidentSgd.step
+
+    def spy(self, *a, **k):
+        steps[0] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(_hip.ResidentSgd, "step", spy)
+    np.random.seed(int(g["global_seed"]))
+    glm.fit(g["X"], g["y_" + lik], likelihood_args=largs)
+    assert steps[0] == (int(g["maxiter"]) if resident else 0)   # the loop under test is the one that ran
+    errs = {"m": normwise(glm.weights_, g[tag + "_m"]), "C": normwise(glm.covariance_, g[tag + "_C"]),
+            "reg": normwise(_flat(glm.regularizer_), g[tag + "_reg"]), "ls": normwise(_flat(glm.basis_hypers_), g[tag + "_ls"])}
+    if lik == "gaussian":
+        errs["lik"] = normwise(_flat(glm.like_hypers_), g[tag + "_lik"])
+    else:
+        assert _flat(glm.like_hypers_).size == 0
+    assert max(errs.values()) < TOL, errs
+    # same minibatches, same candidates, same draws consumed: the stream ends where the reference's does
+    assert glm.random_.randn() == float(g[tag + "_end"])
+    # the structure `fit` hands back is the reference's: scalars for scalar Parameters, lists per child of a concatenation
+    if case[2] == "cat":
+        assert isinstance(glm.regularizer_, list) and len(glm.regularizer_) == 3
+        assert isinstance(glm.basis_hypers_, list) and len(glm.basis_hypers_) == 2   # (children WITH parameters: basis_functions.py:1757)
+    if case[2] == "posupper":
+        assert float(glm.basis_hypers_) == pytest.approx(1.03, rel=1e-6)

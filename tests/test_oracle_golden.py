@@ -275,3 +275,43 @@ def test_oracle_gradient_trace_identity_above_its_size_switch():
     err = y - Phi @ o["m"]
     want = [(o["m"] @ (err @ dP) - ((dP.T @ Phi) * o["C"]).sum()) / 0.4 for dP in dPs]
     assert np.allclose(o["dhyp"], want, rtol=1e-11, atol=1e-12)
+
+
+from glm_fit_cases import CASES as GLM_FIT_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("case", GLM_FIT_CASES, ids=[c[0] for c in GLM_FIT_CASES])
+def test_glm_fit_optimiser_stack(golden, case):
+    """`orc.glm_fit` -- random starts, structured_sgd / logtrick_sgd, sgd with bounds, one RandomState shared by the
+    permutations and the reparameterisation draws -- against `GeneralizedLinearModel.fit` of the reference: fitted blocks,
+    the optimiser's gradient norms and objectives, and the stream's end state."""
+    from scipy.stats import gamma
+    g = golden("glm_fit")
+    tag, lik, kind, bs, ns, fwd = case
+    d, n = g["X"].shape[1], int(g["nbases"])
+    P = orc.ParamSpec
+    reg = lambda: P(dist=gamma(1.), positive=True)  # noqa: E731  (basis_functions.py:210: the default regulariser)
+    if kind == "cat":
+        ch = [("linear", True), ("rff", g[tag + "_W1"], 1), ("rff", g[tag + "_W2"], 1)]
+        regs, lss = [reg(), reg(), reg()], [P(value=[]), P(dist=gamma(1.), positive=True), P(dist=gamma(1.), positive=True)]
+    else:
+        ls = {"ard": P(dist=gamma(4., scale=0.25), positive=True, shape=(d,)), "bound": P(value=1.0, lower=0.996, upper=1.001),
+              "posupper": P(value=1.0, positive=True, upper=1.03)}[kind]
+        ch, regs, lss = [("rff", g[tag + "_W0"], d if kind == "ard" else 1)], [reg()], [ls]
+    likpar = [P(dist=gamma(1.), positive=True)] if lik == "gaussian" else []
+    largs = [g["nbin"]] if lik == "binomial" else []
+    o = orc.glm_fit(g["X"], g["y_" + lik], lik, largs, ch, regs, likpar, lss, int(g["K"]), int(g["L"]), bs, int(g["maxiter"]),
+                    ns, int(g["seed"]), int(g["global_seed"]), sgd_batch_size=bs if fwd else 10)
+    flat = lambda v: np.concatenate([np.ravel(np.asarray(u, float)) for u in v] + [np.empty(0)])  # noqa: E731
+    assert normwise(o[0], g[tag + "_m"]) < 1e-9 and normwise(o[1], g[tag + "_C"]) < 1e-9
+    assert normwise(flat(o[2]), g[tag + "_reg"]) < 1e-9
+    assert normwise(flat(o[3]), g[tag + "_lik"]) < 1e-9
+    assert normwise(flat(o[4]), g[tag + "_ls"]) < 1e-9
+    assert normwise(o[6], g[tag + "_norms"]) < 1e-9
+    fin = np.isfinite(g[tag + "_objs"])
+    assert np.array_equal(fin, np.isfinite(o[5])) and normwise(o[5][fin], g[tag + "_objs"][fin]) < 1e-9
+    assert o[7] == float(g[tag + "_end"])
+    if kind == "bound":   # the case is there for the bounds: a step of Adam's 0.01 from 1.0 leaves [0.996, 1.001] at once
+        assert 0.996 <= float(o[4][0]) <= 1.001
+    if kind == "posupper":
+        assert float(o[4][0]) == pytest.approx(1.03, abs=1e-12)
