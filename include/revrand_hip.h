@@ -69,6 +69,10 @@ int rr_abi_version(void);
  * allocation, verified at rr_ctx_sync / rr_free, and index assertions inside the kernels). */
 #define RR_BUILD_BOUNDS 1
 int rr_build_flags(void);
+/* RR_BUILD_BOUNDS builds: the number of kernel launches checked so far for "the calling thread's current device is the
+ * device of the stream launched on" (the invariant of the in-process device group; a violation fails the next rr_ctx_sync
+ * with the launch site named).  0 in a release build, which makes no such check. */
+int64_t rr_debug_launch_checks(void);
 const char *rr_last_error(void);
 int rr_device_count(int *count);
 
@@ -381,7 +385,12 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
  * rr_rff_padded layout), targets dy / per-row argument drowarg (device, dtype).  llconst: the f-independent constant of
  * sum(loglike) per latent sample (ignored for the Gaussian, whose constant follows the variance in z); bmag = N / minibatch
  * size (glm.py:158).  dE: the caller's standard normals (device float32 (K L, F), the reference's stream) or NULL:
- * counter-based device draws keyed by (seed, key). */
+ * counter-based device draws keyed by (seed, key).
+ * Stream order: dX, dy, drowarg and dE are read by kernels on the context's stream AND (large steps) on a second stream of the
+ * loop's own; the call orders both behind everything queued on the context's stream before it, so a caller that fills these
+ * buffers with asynchronous work on that stream (row gathers, rr_memcpy_h2d) need not synchronise.  Work on OTHER streams
+ * (an upload context's) must be complete -- or waited for on the context's stream -- before the call.  The context serves this
+ * call's thread alone while it runs. */
 int rr_glm_sgd_step(rr_glm_sgd *s, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows, const void *dy,
                     const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed,
                     uint64_t key);

@@ -29,6 +29,7 @@ _c_double_p = ctypes.POINTER(ctypes.c_double)
 SIGNATURES = {
     "rr_abi_version": (ctypes.c_int, []),
     "rr_build_flags": (ctypes.c_int, []),
+    "rr_debug_launch_checks": (ctypes.c_int64, []),
     "rr_legacy_permutation": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
     "rr_legacy_randn": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_int, ctypes.c_int64, ctypes.c_int]),

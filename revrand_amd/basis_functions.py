@@ -25,6 +25,8 @@ import inspect
 from functools import reduce, wraps
 from itertools import repeat
 
+import threading
+
 import numpy as np
 from scipy.linalg import qr
 from scipy.stats import gamma, norm as norm_dist
@@ -263,14 +265,18 @@ def _sharded_gram(basis, X, y, params, devices):
     return res
 
 
+_HANDLE_CACHE_LOCK = threading.Lock()
+
+
 def _handle_cache(basis, name="_hip_handle"):
     """(cache, key) of a basis' device handles: one per process AND per device context (`_hip.device_key`) -- a basis
     whose rows are sharded over the members of a device group (multigpu.ShardedFitState) holds W once on every member.
     Entries of another process (a fork) are dropped; the cache is never pickled."""
-    cache = basis.__dict__.get(name)
     key = _hip.device_key()
-    if not isinstance(cache, dict) or any(k[0] != key[0] for k in cache):
-        cache = basis.__dict__[name] = {}
+    with _HANDLE_CACHE_LOCK:  # (the member threads of a device group build their fit states on the same basis side by side)
+        cache = basis.__dict__.get(name)
+        if not isinstance(cache, dict) or any(k[0] != key[0] for k in list(cache)):
+            cache = basis.__dict__[name] = {}
     return cache, key
 
 

@@ -59,8 +59,37 @@ static int guard_check_one(void *user, const GuardRec &r, const char *where) {
     return RR_OK;
 }
 
+static std::string g_launch_violation;  // first launch made with another device current than its stream's (under g_guard_mu)
+static long g_launch_checks = 0;
+
+void rr_launch_device_check(hipStream_t s, const char *file, int line) {
+    int cur = -1;
+    hipDevice_t sd = -1;
+    if (hipGetDevice(&cur) != hipSuccess || hipStreamGetDevice(s, &sd) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    ++g_launch_checks;
+    if (cur != (int)sd && g_launch_violation.empty()) {
+        char buf[256];
+        snprintf(buf, sizeof buf, "RR_BOUNDS: kernel launched at %s:%d with device %d current on a stream of device %d", file, line, cur, (int)sd);
+        g_launch_violation = buf;
+        fprintf(stderr, "%s\n", buf);
+    }
+}
+
+long rr_launch_checks_done(void) {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    return g_launch_checks;
+}
+
 int rr_guard_check(const char *where) {
     std::lock_guard<std::mutex> lk(g_guard_mu);
+    if (!g_launch_violation.empty()) {
+        rr_set_error("%s (reported by %s)", g_launch_violation.c_str(), where);
+        return RR_ERR_HIP;
+    }
     int dev = 0;
     (void)hipGetDevice(&dev);
     for (auto &kv : g_guarded)
@@ -94,6 +123,14 @@ hipError_t rr_guard_free(void *p) {
 extern "C" {
 
 int rr_abi_version(void) { return RR_ABI_VERSION; }
+
+int64_t rr_debug_launch_checks(void) {
+#ifdef RR_BOUNDS
+    return (int64_t)rr_launch_checks_done();
+#else
+    return 0;
+#endif
+}
 
 int rr_build_flags(void) {
 #ifdef RR_BOUNDS

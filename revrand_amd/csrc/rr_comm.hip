@@ -459,6 +459,78 @@ static int peer_enable(int n, rr_ctx *const *ctxs) {
     return RR_OK;
 }
 
+// ncclGroupStart -> every member's ncclAllReduce on its own stream -> ncclGroupEnd (one thread drives all members)
+static int group_rccl_allreduce(rr_group *g, double *const *dbufs, int64_t count, ncclRedOp_t rop, const char *who) {
+    RR_CHECK_NCCL(g_rccl.GroupStart());
+    for (int i = 0; i < g->n; ++i) {
+        rr_comm *m = g->members[(size_t)i];
+        rr_ctx *c = m->ctx;
+        hipError_t e = hipSetDevice(c->device);
+        ncclResult_t r = e == hipSuccess ? g_rccl.AllReduce(dbufs[i], dbufs[i], (size_t)count, ncclDouble, rop, m->comm, c->stream)
+                                         : ncclUnhandledCudaError;
+        if (r != ncclSuccess) {
+            (void)g_rccl.GroupEnd();
+            rr_set_error("%s: member %d: %s", who, i, e != hipSuccess ? hipGetErrorString(e) : g_rccl.GetErrorString(r));
+            return RR_ERR_HIP;
+        }
+    }
+    RR_CHECK_NCCL(g_rccl.GroupEnd());
+    return RR_OK;
+}
+
+// One 64-number all-reduce over the group's RCCL communicators, checked on every member: member i contributes i + 1 + j / 64.
+static int group_rccl_probe(rr_group *g) {
+    const int n = g->n, cnt = 64;
+    std::vector<double *> bufs((size_t)n, nullptr);
+    std::vector<double> h((size_t)cnt);
+    int rc = RR_OK;
+    for (int i = 0; i < n && rc == RR_OK; ++i) {
+        rr_ctx *c = g->members[(size_t)i]->ctx;
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipMalloc((void **)&bufs[(size_t)i], cnt * sizeof(double));
+        for (int j = 0; j < cnt; ++j) h[(size_t)j] = (double)(i + 1) + j / 64.0;
+        if (e == hipSuccess) e = hipMemcpy(bufs[(size_t)i], h.data(), cnt * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            rr_set_error("probe: member %d: %s", i, hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+        }
+    }
+    if (rc == RR_OK) rc = group_rccl_allreduce(g, bufs.data(), cnt, ncclSum, "probe");
+    if (rc == RR_OK && getenv("RR_COMM_PROBE_FAIL")) {  // test switch: take the fallback as if the collective had failed
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(g->members[(size_t)i]->ctx->device);
+            (void)hipStreamSynchronize(g->members[(size_t)i]->ctx->stream);
+        }
+        rr_set_error("probe: failure forced by RR_COMM_PROBE_FAIL");
+        rc = RR_ERR_HIP;
+    }
+    for (int i = 0; i < n && rc == RR_OK; ++i) {
+        rr_ctx *c = g->members[(size_t)i]->ctx;
+        hipError_t e = hipSetDevice(c->device);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipMemcpy(h.data(), bufs[(size_t)i], cnt * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            rr_set_error("probe: member %d: %s", i, hipGetErrorString(e));
+            rc = RR_ERR_HIP;
+            break;
+        }
+        for (int j = 0; j < cnt; ++j) {
+            const double want = n * (n + 1) / 2.0 + n * (j / 64.0);
+            if (h[(size_t)j] != want) {
+                rr_set_error("probe: member %d holds %.17g where the sum is %.17g", i, h[(size_t)j], want);
+                rc = RR_ERR_HIP;
+                break;
+            }
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (bufs[(size_t)i]) {
+            (void)hipSetDevice(g->members[(size_t)i]->ctx->device);
+            (void)hipFree(bufs[(size_t)i]);
+        }
+    return rc;
+}
+
 int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
     RR_REQUIRE(ctxs != nullptr && out != nullptr, "rr_comm_init_all: null argument");
     RR_REQUIRE(n >= 1 && n <= RR_GROUP_MAX, "rr_comm_init_all: %d members (1..%d supported)", n, RR_GROUP_MAX);
@@ -473,6 +545,7 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
             if (ctxs[j]->device == ctxs[i]->device) distinct = false;
         }
     }
+    const bool was_auto = transport == RR_TRANSPORT_AUTO;  // (a preference from the environment keeps AUTO's fallback to peer)
     if (const char *e = getenv("RR_COMM_TRANSPORT")) {  // measurement / fallback switch for RR_TRANSPORT_AUTO
         if (transport == RR_TRANSPORT_AUTO && !strcmp(e, "peer")) transport = RR_TRANSPORT_PEER;
         if (transport == RR_TRANSPORT_AUTO && !strcmp(e, "rccl")) transport = RR_TRANSPORT_RCCL;
@@ -481,7 +554,6 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
     // device -- or a box without a loadable librccl -- take the in-process peer transport
     if (transport == RR_TRANSPORT_RCCL)
         RR_REQUIRE(distinct || n == 1, "rr_comm_init_all: RCCL needs one member per device; members share a device -- use RR_TRANSPORT_PEER");
-    const bool was_auto = transport == RR_TRANSPORT_AUTO;
     if (transport == RR_TRANSPORT_AUTO) transport = (distinct && n > 1 && rccl_load(nullptr) == RR_OK) ? RR_TRANSPORT_RCCL : RR_TRANSPORT_PEER;
     std::vector<ncclComm_t> nc((size_t)n, nullptr);
     if (transport == RR_TRANSPORT_RCCL) {
@@ -520,6 +592,31 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
         c->world = n;
         g->members[(size_t)i] = c;
         out[i] = c;
+    }
+    if (transport == RR_TRANSPORT_RCCL && was_auto) {
+        // RR_TRANSPORT_AUTO: the communicator exists, but whether a grouped collective WORKS on this node is only known once
+        // one has run (no collective of this library had crossed two physical GPUs when this was written).  One tiny
+        // all-reduce through exactly the path the statistics take; if it errors or sums wrong, the group takes the peer
+        // transport instead and says so.
+        const int prc = group_rccl_probe(g);
+        if (prc != RR_OK) {
+            fprintf(stderr, "librevrand_hip: the first grouped RCCL all-reduce over %d devices failed (%s): the device group uses the "
+                            "peer transport\n", n, rr_last_error());
+            (void)hipGetLastError();
+            for (int i = 0; i < n; ++i) {
+                if (out[i]->comm) (void)g_rccl.CommAbort(out[i]->comm);
+                out[i]->comm = nullptr;
+            }
+            int rc = peer_enable(n, ctxs);
+            if (rc != RR_OK) {
+                for (int k = 0; k < n; ++k) {
+                    rr_comm_destroy(out[k]);
+                    out[k] = nullptr;
+                }
+                return rc;
+            }
+            transport = g->transport = RR_TRANSPORT_PEER;
+        }
     }
     if (transport == RR_TRANSPORT_PEER) {
         g->ready.resize((size_t)n, nullptr);
@@ -608,27 +705,16 @@ int rr_comm_group_allreduce_dev(rr_comm *const *comms, int n, double *const *dbu
     RR_REQUIRE(dbufs != nullptr && count >= 0, "rr_comm_group_allreduce_dev: bad argument");
     ncclRedOp_t rop;
     rc = comm_op(op, &rop);
-    if (rc != RR_OK || count == 0 || n == 1) return rc;
+    rr_group *g = comms[0]->group;
+    // (a one-member group has nothing to exchange -- except under RR_TRANSPORT_RCCL, where the one member still goes through
+    // ncclGroupStart / ncclAllReduce / ncclGroupEnd: the symbols and the call order of the N-member case, on any box)
+    if (rc != RR_OK || count == 0 || (n == 1 && g->transport != RR_TRANSPORT_RCCL)) return rc;
     for (int i = 0; i < n; ++i) {
         RR_REQUIRE(dbufs[i] != nullptr, "rr_comm_group_allreduce_dev: member %d has no buffer", i);
         for (int j = 0; j < i; ++j) RR_REQUIRE(dbufs[j] != dbufs[i], "rr_comm_group_allreduce_dev: members %d and %d share a buffer", j, i);
     }
-    rr_group *g = comms[0]->group;
     if (g->transport == RR_TRANSPORT_PEER) return peer_allreduce(g, dbufs, count, op);
-    RR_CHECK_NCCL(g_rccl.GroupStart());
-    for (int i = 0; i < n; ++i) {
-        rr_ctx *c = comms[i]->ctx;
-        hipError_t e = hipSetDevice(c->device);
-        ncclResult_t r = e == hipSuccess ? g_rccl.AllReduce(dbufs[i], dbufs[i], (size_t)count, ncclDouble, rop, comms[i]->comm, c->stream)
-                                         : ncclUnhandledCudaError;
-        if (r != ncclSuccess) {
-            (void)g_rccl.GroupEnd();
-            rr_set_error("rr_comm_group_allreduce_dev: member %d: %s", i, e != hipSuccess ? hipGetErrorString(e) : g_rccl.GetErrorString(r));
-            return RR_ERR_HIP;
-        }
-    }
-    RR_CHECK_NCCL(g_rccl.GroupEnd());
-    return RR_OK;
+    return group_rccl_allreduce(g, dbufs, count, rop, "rr_comm_group_allreduce_dev");
 }
 
 int rr_comm_group_broadcast_dev(rr_comm *const *comms, int n, void *const *dbufs, int64_t bytes, int root) {
@@ -636,9 +722,9 @@ int rr_comm_group_broadcast_dev(rr_comm *const *comms, int n, void *const *dbufs
     if (rc != RR_OK) return rc;
     RR_REQUIRE(dbufs != nullptr && bytes >= 0 && bytes % 8 == 0 && root >= 0 && root < n,
                "rr_comm_group_broadcast_dev: bad argument (bytes must be a multiple of 8)");
-    if (bytes == 0 || n == 1) return RR_OK;
-    for (int i = 0; i < n; ++i) RR_REQUIRE(dbufs[i] != nullptr, "rr_comm_group_broadcast_dev: member %d has no buffer", i);
     rr_group *g = comms[0]->group;
+    if (bytes == 0 || (n == 1 && g->transport != RR_TRANSPORT_RCCL)) return RR_OK;
+    for (int i = 0; i < n; ++i) RR_REQUIRE(dbufs[i] != nullptr, "rr_comm_group_broadcast_dev: member %d has no buffer", i);
     if (g->transport == RR_TRANSPORT_RCCL) {
         RR_CHECK_NCCL(g_rccl.GroupStart());
         for (int i = 0; i < n; ++i) {

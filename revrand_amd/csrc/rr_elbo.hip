@@ -3007,6 +3007,7 @@ struct rr_glm_sgd {
     hipStream_t sfeat = nullptr;                // features of the next step
     hipEvent_t e_ls[2] = {nullptr, nullptr};    // step t's length scales are updated (recorded on the context's stream)
     hipEvent_t e_feat[2] = {nullptr, nullptr};  // step t's features are in its matrix (recorded on sfeat)
+    hipEvent_t e_in = nullptr;                  // what the caller queued on the context's stream before this step (its row gathers)
     bool overlap = true;                        // RR_GLM_SGD_OVERLAP=0: one stream, one matrix (A/B runs)
 };
 
@@ -3217,7 +3218,7 @@ static void sgd_free(rr_glm_sgd *o) {
                  o->slice_of_f, o->slice_lo, o->slice_hi, o->h_of_ls, o->hrows};
     for (void *v : q)
         if (v) (void)hipFree(v);
-    for (hipEvent_t e : {o->ev[0], o->ev[1], o->e_ls[0], o->e_ls[1], o->e_feat[0], o->e_feat[1]})
+    for (hipEvent_t e : {o->ev[0], o->ev[1], o->e_ls[0], o->e_ls[1], o->e_feat[0], o->e_feat[1], o->e_in})
         if (e) (void)hipEventDestroy(e);
     if (o->sfeat) (void)hipStreamDestroy(o->sfeat);
     if (o->fm2) rr_featmat_destroy(o->fm2);
@@ -3329,6 +3330,7 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
         if (e == hipSuccess) e = hipEventCreateWithFlags(&o->e_feat[i], hipEventDisableTiming);
     }
     if (e == hipSuccess && o->overlap) e = hipStreamCreateWithFlags(&o->sfeat, hipStreamNonBlocking);
+    if (e == hipSuccess && o->overlap) e = hipEventCreateWithFlags(&o->e_in, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipGetLastError();
         sgd_free(o);
@@ -3412,18 +3414,32 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, co
     // ---- this step's features: after the previous step's length-scale update, on the second stream, into this step's
     //      matrix -- while the previous step's Ed product runs on the first
     hipStream_t s0 = c->stream, sf = o->overlap ? o->sfeat : s0;
-    if (o->overlap && o->t >= 1) RR_CHECK_HIP(hipStreamWaitEvent(sf, o->e_ls[1 - par], 0));
-    c->stream = sf;  // (every launch helper below reads the context's stream when it is called)
-    if (nb_ls)
-        hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, sf, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
-                           o->x + n_main);
-    rc = rr_featmat_begin(fm, rows);
-    for (int s = 0; s < nk && rc == RR_OK; ++s) {
-        const rr_glm_sgd_child &k = o->kids[(size_t)s];
-        if (k.kind == RR_SGD_CHILD_RFF) rc = rr_fm_put_rff_dev(fm, k.basis, dX[s], x_dtype[s], ldx[s], xls + o->ls0[(size_t)s], k.n_ls, o->col0[(size_t)s]);
-        else rc = rr_featmat_put_linear(fm, dX[s], x_dtype[s], ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
+    if (o->overlap) {
+        // stream order of dX / dy / drowarg / dE: whatever the caller queued on the context's stream before this call (row
+        // gathers of a minibatch that was not prefetched, uploads) is ordered BEFORE the feature kernels on the second stream
+        RR_CHECK_HIP(hipEventRecord(o->e_in, s0));
+        RR_CHECK_HIP(hipStreamWaitEvent(sf, o->e_in, 0));
+        if (o->t >= 1) RR_CHECK_HIP(hipStreamWaitEvent(sf, o->e_ls[1 - par], 0));
     }
-    c->stream = s0;
+    {
+        // every launch helper below reads the context's stream when it is called; restored on every way out of this block.
+        // (A context serves ONE host thread at a time -- include/revrand_hip.h -- so nobody else reads the field meanwhile.)
+        struct StreamScope {
+            rr_ctx *c;
+            hipStream_t prev;
+            StreamScope(rr_ctx *c_, hipStream_t s_) : c(c_), prev(c_->stream) { c->stream = s_; }
+            ~StreamScope() { c->stream = prev; }
+        } scope(c, sf);
+        if (nb_ls)
+            hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, sf, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
+                               o->x + n_main);
+        rc = rr_featmat_begin(fm, rows);
+        for (int s = 0; s < nk && rc == RR_OK; ++s) {
+            const rr_glm_sgd_child &k = o->kids[(size_t)s];
+            if (k.kind == RR_SGD_CHILD_RFF) rc = rr_fm_put_rff_dev(fm, k.basis, dX[s], x_dtype[s], ldx[s], xls + o->ls0[(size_t)s], k.n_ls, o->col0[(size_t)s]);
+            else rc = rr_featmat_put_linear(fm, dX[s], x_dtype[s], ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
+        }
+    }
     if (rc != RR_OK) return rc;
     RR_CHECK_HIP(hipGetLastError());
     if (o->overlap) {

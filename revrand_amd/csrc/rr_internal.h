@@ -154,6 +154,17 @@ hipError_t rr_guard_free(void *p);
 int rr_guard_check(const char *where);  // RR_OK, or RR_ERR_HIP with the message set
 #define hipMalloc(p, n) rr_guard_malloc((void **)(p), (n))
 #define hipFree(p) rr_guard_free((void *)(p))
+// (3) every kernel launch checks that the calling thread's current device IS the device of the stream it launches on -- the
+//     invariant of the in-process device group (one context per member, hipSetDevice at the top of every entry point) that a
+//     one-GPU box cannot show broken.  A violation is remembered and fails the next rr_guard_check (rr_ctx_sync) with the
+//     launch site named.
+void rr_launch_device_check(hipStream_t s, const char *file, int line);
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, numBlocks, numThreads, memPerBlock, streamId, ...)                              \
+    do {                                                                                                               \
+        rr_launch_device_check((streamId), __FILE__, __LINE__);                                                        \
+        hipLaunchKernelGGLInternal((kernelName), (numBlocks), (numThreads), (memPerBlock), (streamId), __VA_ARGS__);   \
+    } while (0)
 #define RR_DEV_ASSERT(cond)                                                                         \
     do {                                                                                            \
         if (!(cond)) {                                                                              \

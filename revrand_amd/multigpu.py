@@ -83,7 +83,8 @@ class DeviceGroup(object):
         # contexts of their OWN (never the process-wide default context of a GPU: two members may share a GPU, and a member's
         # stream must not be the one an unrelated estimator of this process queues work on)
         self.members = [_hip.Device(d) for d in self.devices]
-        if transport != "peer" and len(set(self.devices)) == self.n and self.n > 1:
+        wants_rccl = transport == "rccl" or os.environ.get("RR_COMM_TRANSPORT") == "rccl"   # (also a one-member group then)
+        if transport != "peer" and len(set(self.devices)) == self.n and (self.n > 1 or wants_rccl):
             try:
                 from .parallel import RcclComm
                 RcclComm.load()  # the librccl paired with this process's HIP runtime, before ncclCommInitAll binds one

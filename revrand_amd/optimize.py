@@ -267,8 +267,15 @@ def _len_data(data):
 def _legacy_permutation(generator, N, out=None):
     if N < 4096 or not isinstance(generator, np.random.RandomState):
         return generator.permutation(N)
-    from . import _hip
-    return _hip.legacy_permutation(generator, N, out=out)
+    try:  # (the generic host optimisers must keep working where the native library is not built or loadable)
+        from . import _hip
+        return _hip.legacy_permutation(generator, N, out=out)
+    except (ImportError, OSError, AttributeError):
+        perm = generator.permutation(N)
+        if out is not None:
+            out[:] = perm
+            return out
+        return perm
 
 
 def gen_batch(data, batch_size, maxiter=np.inf, random_state=None, _reuse=False):

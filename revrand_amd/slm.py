@@ -426,6 +426,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         if group is None or X.shape[0] < 2 * group.n:
             return serve(X)
         from . import multigpu
+        if with_cov:
+            self._serving()   # (created on THIS thread: the members' threads then only add their own entry to it)
         return multigpu.map_rows(group, X.shape[0], lambda i, s, e: serve(X[s:e]))
 
     def _predict_moments(self, X):

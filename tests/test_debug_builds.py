@@ -33,7 +33,11 @@ RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "test
           "tests/test_gpu_slm.py::test_predict_of_a_random_kernel_basis_comes_from_the_feature_kernel_alone",
           # round 5: the resident SVI loop (per-child tables, two feature matrices, the second stream), ragged minibatches
           "tests/test_gpu_resident_sgd.py::test_concatenation_of_fourier_and_linear_children",
-          "tests/test_gpu_resident_sgd.py::test_resident_loop_equals_host_loop"]
+          "tests/test_gpu_resident_sgd.py::test_resident_loop_equals_host_loop",
+          # round 6: the in-process device group (every launch checked for "current device == the stream's device"), on
+          # distinct GPUs where the box has them; the reference-pinned GLM fits through both loops
+          "tests/test_gpu_multigpu.py::test_sharded_elbo_equals_the_one_context_elbo",
+          "tests/test_gpu_multigpu_devices.py", "tests/test_gpu_glm_fit.py"]
 
 
 def _asan_runtime():
@@ -118,3 +122,35 @@ def test_bounds_build_catches_an_overrun():
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVRAND_HIP_LIB=DEBUG_LIB), capture_output=True,
                        text=True, timeout=600)
     assert "caught" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.gpu
+def test_bounds_build_checks_the_device_of_every_launch():
+    """-DRR_BOUNDS wraps every kernel launch of the library in a check that the calling thread's current HIP device is the
+    device of the stream launched on (rr_internal.h) -- what the in-process device group relies on and a one-GPU box cannot
+    show broken.  A sharded `_elbo` (members on distinct GPUs when the box has two) makes thousands of such launches from
+    several host threads: all checked, none in violation (a violation fails the next synchronisation)."""
+    if not os.path.exists(DEBUG_LIB):
+        pytest.skip("make -C revrand_amd/csrc debug has not been run")
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from revrand_amd import _hip, multigpu\n"
+        "import revrand_amd.basis_functions as bs\n"
+        "from revrand_amd.slm import StandardLinearModel\n"
+        "lib = _hip.load_library()\n"
+        "assert lib.rr_build_flags() & 1 and lib.rr_debug_launch_checks() == 0\n"
+        "v = multigpu.visible_devices()\n"
+        "devices = list(range(min(v, 4))) if v >= 2 else [0, 0, 0]\n"
+        "rs = np.random.RandomState(0)\n"
+        "X = rs.randn(20000, 5).astype(np.float32); y = np.sin(X[:, 0]).astype(np.float32)\n"
+        "slm = StandardLinearModel(bs.RandomRBF(nbases=64, Xdim=5, random_state=1) + bs.LinearBasis(), nstarts=0, maxiter=3,\n"
+        "                          devices=devices).fit(X, y)\n"
+        "slm.predict_moments(X[:3000])\n"
+        "multigpu.get_group(devices).sync()\n"
+        "n = lib.rr_debug_launch_checks()\n"
+        "assert n > 100, n\n"
+        "print('checked', n, 'launches on', devices)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, REVRAND_HIP_LIB=DEBUG_LIB), capture_output=True,
+                       text=True, timeout=900)
+    assert "checked" in r.stdout and "RR_BOUNDS" not in (r.stdout + r.stderr), (r.stdout[-1500:], r.stderr[-3000:])
