@@ -275,3 +275,55 @@ def test_fit_predict_and_glm_between_gpus(devices, transport, monkeypatch):
     a, b = glm(None), glm(devices)
     assert normwise(b.weights_, a.weights_) < 1e-4 and normwise(b.covariance_, a.covariance_) < 1e-4
     assert a.random_.randn() == b.random_.randn()
+
+
+# ---- every kind of resident fit state behind devices= (distinct GPUs when the box has two, else two members on one) -------
+
+DEV2 = [0, 1] if VISIBLE >= 2 else [0, 0]
+
+
+@pytest.mark.parametrize("kind", ["fastfood", "fastfood_gm", "rbf_f64", "cat_f64", "config4_width"])
+def test_elbo_with_devices_for_every_fit_state(kind, monkeypatch):
+    """`_elbo` (objective, all gradients, weights) with the rows on two members against one context for the fit states the
+    round-5 tests did not cover: FastFoodRBF and FastFoodGM (the chain kernels writing into each member's feature matrix),
+    dtype="f64" (the float64 pipeline end to end: 1e-9) alone and in a concatenation, and config 4's `_elbo` width
+    (FastFoodRBF F = 16384, D = 128: SURVEY 8e lists C4 as row-sharded too)."""
+    bs, _hip, multigpu, Parameter, Positive, SLM = _setup()
+    from revrand_amd.btypes import Bound
+    from revrand_amd.utils import flatten_values
+    monkeypatch.setenv("RR_POSDEF", "device")
+    d = 128 if kind == "config4_width" else (16 if kind.startswith("fastfood") else 6)   # (the GM chain wants d2 >= 16)
+    N = 6000 if kind == "config4_width" else 30001
+    X, y = _data(N, d, seed=9)
+    ard = lambda: Parameter(np.ones(d), Positive())  # noqa: E731
+    ls = np.linspace(0.8, 1.3, d)
+    if kind == "fastfood":
+        basis, reg, hyp, tol = bs.FastFoodRBF(nbases=96, Xdim=d, random_state=2, lenscale=ard()), 1.2, ls, 2e-4
+    elif kind == "config4_width":
+        basis, reg, hyp, tol = bs.FastFoodRBF(nbases=8192, Xdim=d, random_state=2, lenscale=ard()), 1.2, ls * 6.0, 2e-4
+    elif kind == "fastfood_gm":
+        basis = bs.FastFoodGM(nbases=96, Xdim=d, random_state=2, mean=Parameter(np.zeros(d), Bound()), lenscale=ard())
+        reg, hyp, tol = 1.2, [0.1 * np.sin(np.arange(d)), ls], 2e-4
+    elif kind == "rbf_f64":
+        basis, reg, hyp, tol = bs.RandomRBF(nbases=80, Xdim=d, random_state=2, lenscale=ard(), dtype="f64"), 1.2, ls, 1e-9
+    else:
+        basis = bs.RandomRBF(nbases=80, Xdim=d, random_state=2, lenscale=ard(), dtype="f64") + bs.LinearBasis(onescol=True)
+        reg, hyp, tol = [1.2, 0.7], ls, 1e-9
+    Xf = X.astype(np.float64) if "f64" in kind else X
+
+    def once(devices):
+        slm = SLM(basis, devices=devices)
+        slm.obj_ = -np.inf
+        slm._state = slm._make_state(Xf, y.astype(Xf.dtype))
+        assert slm._state is not None          # resident: the statistics never leave HBM
+        try:
+            f, g = slm._elbo(Xf, y, 0.3, reg, hyp)
+        finally:
+            slm._state.release()
+            slm._state = None
+        return np.asarray(flatten_values([f] + list(g)), dtype=float), np.array(slm.weights_)
+    v1, w1 = once(None)
+    v2, w2 = once(DEV2)
+    assert v1.shape == v2.shape and np.all(np.isfinite(v2))
+    assert abs(v2[0] - v1[0]) < max(tol * 1e-2, 1e-12) * abs(v1[0]), (v2[0], v1[0])
+    assert normwise(v2[1:], v1[1:]) < tol and normwise(w2, w1) < 2 * tol

@@ -14,17 +14,21 @@ from conftest import normwise
 
 pytestmark = pytest.mark.gpu
 
-# The largest size: 96 panels (F = 12288) by default -- the paired-panel schedule of round 5 (trailing matrix >= 4096 columns)
-# over most of its panels, the oracle's inverse in ~10 s -- and config 4's full width F = 16384 (128 panels, ~half a minute of
-# host LAPACK per case) with RR_TEST_FULL=1; bench.py's `posterior_F16384` line checks iC C = I at that width in every run.
-F_LARGE = 16384 if os.environ.get("RR_TEST_FULL") == "1" else 12288
+# The largest size is config 4's full width, F = 16384 (128 panels: the paired-panel schedule over most of them).  Up to
+# F_FULL_INVERSE the oracle forms the whole inverse; above it -- where the host's inverse alone takes the better part of a
+# minute -- the oracle's solve_posdef is asked for 128 random COLUMNS of the inverse and for the mean (one Cholesky and 129
+# right-hand sides: still the oracle, still every panel of the device's factor and substitution behind each column), plus
+# log|iC|; sum(G o C) is then held to the host sum over the device's own C.  RR_TEST_FULL=1: the whole inverse at every size.
+F_LARGE = 16384
+F_FULL_INVERSE = 1 << 30 if os.environ.get("RR_TEST_FULL") == "1" else 12288
+NCOLS = 128
 
 _CASES = {}
 
 
 def _case(F):
     """(G, b, iL, var) with G the Gram of F / 8 random rows (as a fit with fewer rows than features has it), and the oracle's
-    posterior of it -- made once per size (the host Cholesky + inverse at F = 16384 takes the better part of a minute)."""
+    posterior of it (`cols` None: the whole inverse; else those columns of it and the mean) -- made once per size."""
     if F not in _CASES:
         _CASES.clear()  # one size at a time in memory: 2 GiB per matrix at F = 16384
         rs = np.random.RandomState(F)
@@ -33,8 +37,20 @@ def _case(F):
         b = B.T @ rs.standard_normal(B.shape[0])
         iL = 1.0 / rs.gamma(2.0, 1.0, F)
         var = 0.37
-        Ch, ld_iC = orc.solve_posdef(np.diag(iL) + G / var, np.eye(F))
-        _CASES[F] = (G, b, iL, var, Ch, ld_iC)
+        iC = np.diag(iL) + G / var
+        if F <= F_FULL_INVERSE:
+            cols = None
+            Ch, ld_iC = orc.solve_posdef(iC, np.eye(F))
+            mh = Ch @ b / var
+        else:
+            cols = np.sort(rs.choice(F, NCOLS, replace=False))
+            rhs = np.zeros((F, NCOLS + 1))
+            rhs[cols, np.arange(NCOLS)] = 1.0
+            rhs[:, NCOLS] = b / var
+            sol, ld_iC = orc.solve_posdef(iC, rhs)
+            Ch, mh = sol[:, :NCOLS], sol[:, NCOLS]
+        del iC
+        _CASES[F] = (G, b, iL, var, Ch, mh, ld_iC, cols)
     return _CASES[F]
 
 
@@ -57,7 +73,7 @@ def _posterior(dev, _hip, F, G, b, iL, var):
 def test_posterior_vs_oracle_solve_posdef(F, mode):
     from revrand_amd import _hip
     dev = _hip.get_device()
-    G, b, iL, var, Ch, ld_iC = _case(F)
+    G, b, iL, var, Ch, mh, ld_iC, cols = _case(F)
     was = dev.deterministic
     dev.set_deterministic(mode == "deterministic")
     try:
@@ -69,10 +85,15 @@ def test_posterior_vs_oracle_solve_posdef(F, mode):
     finally:
         dev.set_deterministic(was)
     assert np.array_equal(C, C.T)
-    assert normwise(C, Ch) < 1e-9
-    assert normwise(m, Ch @ b / var) < 1e-9 and normwise(dg, Ch.diagonal()) < 1e-9
+    if cols is None:
+        assert normwise(C, Ch) < 1e-9 and normwise(dg, Ch.diagonal()) < 1e-9
+        trh = float((G * Ch).sum())
+    else:   # the oracle's columns of the inverse (C is symmetric: rows too), the diagonal where they cross it
+        assert normwise(C[:, cols], Ch) < 1e-9 and normwise(dg[cols], Ch[cols, np.arange(len(cols))]) < 1e-9
+        assert np.array_equal(dg, C.diagonal())
+        trh = float(np.einsum("ij,ij->", G, C))
+    assert normwise(m, mh) < 1e-9
     assert abs(logdet - ld_iC) < 1e-9 * abs(ld_iC)
-    trh = float((G * Ch).sum())
     assert abs(tr - trh) < 1e-9 * abs(trh)
 
 
@@ -114,9 +135,9 @@ def test_not_positive_definite_in_a_late_panel_is_reported_and_leaves_nothing_in
         assert post is None
         assert b"not safely positive definite" in dev.lib.rr_last_error()
         # the good matrix of the same size right behind it
-        Gg, bg, iLg, varg, Ch, ld_iC = _case(F)
+        Gg, bg, iLg, varg, Ch, mh, ld_iC, cols = _case(F)
         (m, dg, logdet, tr), C = _posterior(dev, _hip, F, Gg, bg, iLg, varg)
         dev.sync()
     finally:
         dev.set_deterministic(was)
-    assert normwise(C, Ch) < 1e-9 and normwise(m, Ch @ bg / varg) < 1e-9 and abs(logdet - ld_iC) < 1e-9 * abs(ld_iC)
+    assert normwise(C if cols is None else C[:, cols], Ch) < 1e-9 and normwise(m, mh) < 1e-9 and abs(logdet - ld_iC) < 1e-9 * abs(ld_iC)
