@@ -619,6 +619,31 @@ def config_c4gm(dev, _hip, args, N_elbo=131_072):
                          "bytes_per_row": bytes_row, "avg_launch_ms": kms / NCH, "_rows_per_launch": CH}}
 
 
+def _ff_elbo_parity(make_basis, X, y, var, reg, ls, rows=64, nh=8):
+    """One `_elbo` of the product on a FastFoodRBF basis (resident route, chain kernel, ONE process) on the first `rows` rows
+    against the oracle's FWHT chain in float64: -ELBO, dvar, dreg and the first `nh` of the length-scale gradients (each is an
+    F x rows x F product on the host).  (rel. error of -ELBO, normwise error of the gradient)."""
+    from revrand_amd.slm import StandardLinearModel
+    orc = _oracle()
+    Xs, ys = np.ascontiguousarray(X[:rows]), np.ascontiguousarray(y[:rows])
+    fb = make_basis()
+    F = 2 * fb.n
+    s2 = StandardLinearModel(fb)
+    s2.obj_ = -np.inf
+    s2._state = fb.device_fit_state(Xs, ys)
+    nel, (gv, gr, gh) = s2._elbo(Xs, ys, var, reg, ls)
+    s2._state.release()
+    s2._state = None
+    X64 = Xs.astype(np.float64)
+    Phi = orc.fastfood_transform(X64, fb.B, fb.G, fb.PI, fb.S, ls)
+    dP = orc.fastfood_grad(X64, fb.B, fb.G, fb.PI, fb.S, ls)
+    ref = orc.slm_elbo(Phi, ys.astype(np.float64), var, np.full(F, reg), slice(None), [dP[:, :, i] for i in range(nh)])
+    del dP
+    got = np.concatenate(([gv], np.atleast_1d(gr), np.atleast_1d(gh)[:nh]))
+    want = np.concatenate(([-ref["dvar"]], [-g for g in ref["dreg"]], [-g for g in ref["dhyp"]]))
+    return abs(nel + ref["elbo"]) / abs(ref["elbo"]), float(np.linalg.norm(got - want) / np.linalg.norm(want))
+
+
 def config_ff_elbo(dev, _hip, args, N=524_288):
     """configs[3] WITH the Gram (SURVEY 8 a-11 "C4-with-Gram", f-4's width): one `_elbo` of StandardLinearModel on FastFoodRBF
     nbases=8192, D=128 ARD (F = 16384) over one GPU's share of N = 4M rows (4 194 304 / 8), resident: the statistics pass
@@ -658,27 +683,9 @@ def config_ff_elbo(dev, _hip, args, N=524_288):
     slm._state = None
     perr = (None, None)
     if not args.no_parity_check:
-        # the same evaluation on 64 rows against the oracle's FWHT chain in float64: -ELBO, dvar, dreg and the first 8 of
-        # the 128 length-scale gradients (each is an F x N x F product on the host)
-        orc = _oracle()
-        ns, nh = 64, 8
-        Xs, ys = np.ascontiguousarray(X[:ns]), np.ascontiguousarray(y[:ns])
-        fb = make_basis()
-        s2 = StandardLinearModel(fb)
-        s2.obj_ = -np.inf
-        s2._state = fb.device_fit_state(Xs, ys)
-        nel, (gv, gr, gh) = s2._elbo(Xs, ys, var, reg, ls)
-        s2._state.release()
-        s2._state = None
-        X64 = Xs.astype(np.float64)
-        Phi = orc.fastfood_transform(X64, fb.B, fb.G, fb.PI, fb.S, ls)
-        dP = orc.fastfood_grad(X64, fb.B, fb.G, fb.PI, fb.S, ls)
-        ref = orc.slm_elbo(Phi, ys.astype(np.float64), var, np.full(F, reg), slice(None), [dP[:, :, i] for i in range(nh)])
-        del dP
-        got = np.concatenate(([gv], np.atleast_1d(gr), np.atleast_1d(gh)[:nh]))
-        want = np.concatenate(([-ref["dvar"]], [-g for g in ref["dreg"]], [-g for g in ref["dhyp"]]))
-        perr = (parity("-ELBO of 64 rows vs the oracle's chain", abs(nel + ref["elbo"]) / abs(ref["elbo"]), 1e-5),
-                parity("gradient of 64 rows vs the oracle's chain (normwise)", float(np.linalg.norm(got - want) / np.linalg.norm(want)), 1e-3))
+        e0, e1 = _ff_elbo_parity(make_basis, X, y, var, reg, ls)
+        perr = (parity("-ELBO of 64 rows vs the oracle's chain", e0, 1e-5),
+                parity("gradient of 64 rows vs the oracle's chain (normwise)", e1, 1e-3))
     fl_stats = F * (F + 1.0) + 2.0 * F + f.k * (2.0 * f.d2 * np.log2(f.d2) + 3.0 * f.d2)
     fl_pass2 = 2.0 * F * F + 2.0 * d * F
     fl_post = posterior_flops(F)
@@ -1160,7 +1167,7 @@ def config_predict_c3(dev, _hip, args, N=300_000):
 # N > 1: BASELINE config 3 and the C2-shape `_elbo` with the rows sharded over the ranks (slm.py:142-199 over all shards)
 # ----------------------------------------------------------------------------------------------------
 
-def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var=0.5, reps=2):
+def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var=0.5, reps=2, parity_fn=None, flops=None):
     """One distributed `_elbo` evaluation, every stage on the ranks' clocks (barrier before, MAX over ranks after):
       statistics   this rank's features + Gram kernels (no exchange)
       exchange     pack the upper triangle, ONE ncclAllReduce of [tri G | b | y^T y | N], unpack + mirror  (HIP events)
@@ -1263,13 +1270,15 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
         prev = parallel.get_comm()
         parallel.set_comm(parallel.SingleComm())
         try:
-            perr = _elbo_parity(make_basis, X, y, var, reg, hyp)
+            perr = (parity_fn or _elbo_parity)(make_basis, X, y, var, reg, hyp)
         finally:
             parallel.set_comm(prev)
     tick("oracle parity")
     d_ = d
     fl_stats = 2.0 * d_ * n_rff + F * (F + 1.0) + 2.0 * F
     fl_p2 = 2.0 * F * F + 4.0 * d_ * n_rff
+    if flops is not None:   # (a basis whose features are not a d x n product: FastFood's chain)
+        fl_stats, fl_p2 = flops(F)
     peak = world * PEAK_F32_MFMA_TFLOPS
     out = {"rows": N, "rows_per_gpu": rows, "F": F, "dtype": "f32", "ms": t_eval, "value": N / (t_eval * 1e-3),
            "unit": "rows/s per _elbo",
@@ -1296,6 +1305,15 @@ def dist_elbo(dev, _hip, comm, args, make_basis, gen, N, d, n_rff, hyp, reg, var
     return out
 
 
+def _c4_data(rows, c):
+    """Chunk c of config 4's synthetic data set (D = 128), the same on every world size."""
+    rng = np.random.default_rng([20260928, 44, c])
+    X = rng.standard_normal((rows, 128), dtype=np.float32)
+    w = np.random.default_rng([20260928, 45]).standard_normal(128, dtype=np.float32)
+    y = (np.sin(X @ w / np.sqrt(128.0)) + 0.1 * rng.standard_normal(rows, dtype=np.float32)).astype(np.float32)
+    return X, y
+
+
 def dist_configs(dev, _hip, comm, args, emit=None):
     """BASELINE config 3 (RandomMatern52 + LinearBasis, F_tot = 8257, D = 64, N = 10M, "8 GPUs N-sharded with RCCL Gram
     all-reduce") and the headline shape's `_elbo` (RandomRBF F = 4096, D = 32, N = 10M), rows sharded over the ranks."""
@@ -1313,7 +1331,14 @@ def dist_configs(dev, _hip, comm, args, emit=None):
             ("elbo_rbf_f4096_dist", lambda: dist_elbo(
                 dev, _hip, comm, args, lambda: bs.RandomRBF(nbases=2048, Xdim=32, random_state=42,
                                                             lenscale=Parameter(np.ones(32), Positive())),
-                rbf_gen, args.dist_rows, 32, 2048, np.linspace(0.8, 1.3, 32), 1.0)))
+                rbf_gen, args.dist_rows, 32, 2048, np.linspace(0.8, 1.3, 32), 1.0)),
+            # BASELINE config 4 with the Gram (C4 is row-sharded too): FastFoodRBF F = 16384, D = 128, the chain
+            # kernel into every rank's feature matrix, the 2 GiB-per-rank statistics summed as ONE 1.07 GB message
+            ("C4elbo_fastfood_f16384_dist", lambda: dist_elbo(
+                dev, _hip, comm, args, lambda: bs.FastFoodRBF(nbases=8192, Xdim=128, random_state=1,
+                                                              lenscale=Parameter(np.ones(128), Positive())),
+                _c4_data, args.dist_rows_c4, 128, 8192, np.linspace(0.8, 1.3, 128), 1.0, parity_fn=_ff_elbo_parity,
+                flops=lambda F: (F * (F + 1.0) + 2.0 * F + 64 * (2.0 * 128 * 7 + 3.0 * 128), 2.0 * F * F + 2.0 * 128 * F))))
     for name, fn in jobs:
         if args.configs != "all" and name.split("_")[0].lower() not in want and name.lower() not in want:
             continue
@@ -1815,6 +1840,9 @@ def main():
                          "c3,elbo (N>1: the row-sharded _elbo evaluations)")
     ap.add_argument("--dist-rows", type=int, default=10_000_000,
                     help="global N of the N>1 configurations (BASELINE config 3: 10M; rehearsals on one GPU pass fewer)")
+    ap.add_argument("--dist-rows-c4", type=int, default=None,
+                    help="global N of the row-sharded config 4 `_elbo` (FastFoodRBF F = 16384; BASELINE: 4 194 304; default: that, "
+                         "scaled down with --dist-rows)")
     ap.add_argument("--full-json", default=os.environ.get("RR_BENCH_FULL_JSON"),
                     help="where rank 0 writes the unabridged record (default: gpurun_out/bench_full_n<N>.json when that "
                          "directory exists)")
@@ -1822,6 +1850,8 @@ def main():
                     help="N GPUs behind ONE process: the in-process device group of StandardLinearModel(devices=N) "
                          "(revrand_amd/multigpu.py) instead of one rank per GPU; same line shape")
     args = ap.parse_args()
+    if args.dist_rows_c4 is None:
+        args.dist_rows_c4 = 4_194_304 if args.dist_rows >= 10_000_000 else max(4096, int(args.dist_rows * 0.4194304))
     faulthandler.enable()  # a crash inside a library call leaves the Python stack on stderr
 
     if args.single_process:
