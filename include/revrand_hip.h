@@ -401,6 +401,41 @@ int rr_glm_sgd_read(rr_glm_sgd *s, double *z, double *objs, double *norms, int64
 int rr_glm_sgd_objective(rr_glm_sgd *s, int64_t step, double *obj);
 void rr_glm_sgd_destroy(rr_glm_sgd *s);
 
+/* ---- the SAME loop for small minibatches: many SGD steps per launch (rr_svi.hip) ----------------------------------------
+ * The reference's own defaults -- GeneralizedLinearModel(K=10, maxiter=3000, batch_size=10, nsamples=50, nstarts=500),
+ * glm.py:120-124 -- make a step ~1 MFLOP: rr_glm_sgd_step's ~30 dependent launches are then all of its time.  rr_glm_svi
+ * keeps X, y, the per-row argument, the flat vector z of rr_glm_sgd and the updater's state in HBM and runs `steps` steps of
+ *     sgd (optimize/sgd.py:337-425)  o  logtrick_sgd (decorators.py:329-408)  o  structured_sgd (:133-252)  around  _elbo (glm.py:205-294)
+ * inside ONE kernel launch: K cooperating workgroups (workgroup k owns mixture component k), the minibatch rows gathered by
+ * index, Phi, the three products, the likelihood terms, the mixture terms, the gradient, the log trick's chain rule, bounds,
+ * updater, -ELBO and |gradient| per step -- float64 throughout (draws are float32 values).  Same children, z layout, updaters
+ * and likelihoods as rr_glm_sgd; rr_glm_svi_supported says whether a shape is in range (F K and minibatch x F small enough for
+ * one CU's LDS).
+ * dX[c], x_dtype[c], ldx[c]: child c's RESIDENT rows of its columns of X (all N rows, device); dy / drowarg: targets and the
+ * binomial's n for all N rows (device, dtype); M: minibatch rows; bmag = N / M (glm.py:158). */
+typedef struct rr_glm_svi rr_glm_svi;
+int rr_glm_svi_supported(int F, int K, int L, int M, int n_children, int dsum, int n_ls);
+int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *children, const void *const *dX, const int *x_dtype,
+                      const int64_t *ldx, int64_t N, const void *dy, const void *drowarg, int dtype, int K, int L, int M, int lik,
+                      int n_lik, const double *z0, const double *lower, const double *upper, const unsigned char *is_log,
+                      int updater, const double *upd_par, int64_t maxiter, double bmag, rr_glm_svi **out);
+/* The start point (structured_sgd picks it after the random starts, decorators.py:223-234), the bounds and the log-space
+ * flags as logtrick_sgd leaves them (decorators.py:586-616), before the first step; NULL: unchanged. */
+int rr_glm_svi_set_start(rr_glm_svi *s, const double *z0, const double *lower, const double *upper, const unsigned char *is_log);
+/* `steps` SGD steps in one launch, asynchronous on the context's stream.  d_idx: device int32 (steps, M), the minibatches' row
+ * indices in gen_batch's order (sgd.py:428-470); dE: device float32 (steps, K L, F), the caller's standard normals in the
+ * reference's order (glm.py:300: randn(L, D) per component, component by component), or NULL: the counter-based device
+ * generator of rr_featmat_glm_step_sampled keyed by (seed, key0 + step). */
+int rr_glm_svi_run(rr_glm_svi *s, int64_t steps, const int *d_idx, const float *dE, uint64_t seed, uint64_t key0);
+/* The random starts of structured_sgd (decorators.py:541-583) as ONE launch: candidate c (cand_host: (ncand, np) float64 in x
+ * space, i.e. the Parameters' draws themselves) is scored on minibatch d_idx[c] (device int32 (ncand, M)) with draws dE[c]
+ * (device float32 (ncand, K L, F)) or the device generator keyed by (seed, key0 + c); objs_host[c] = -ELBO.  Synchronous. */
+int rr_glm_svi_starts(rr_glm_svi *s, int ncand, const int *d_idx, const double *cand_host, const float *dE, uint64_t seed,
+                      uint64_t key0, double *objs_host);
+/* As rr_glm_sgd_read. */
+int rr_glm_svi_read(rr_glm_svi *s, double *z, double *objs, double *norms, int64_t *steps);
+void rr_glm_svi_destroy(rr_glm_svi *s);
+
 /* ---- arithmetic of the f32 Gram (Phi^T Phi of slm.py:145-150 for "f32" bases) -------------------
  * RR_GRAM_F32 (default): f32 features, v_mfma_f32_32x32x2_f32, f32 accumulation per K-split -- bitwise an fmaf chain.
  * RR_GRAM_BF16X3 / RR_GRAM_BF16X4: each f32 feature value is split into bf16 hi + lo and the Gram accumulates

@@ -157,6 +157,20 @@ SIGNATURES = {
                                        ctypes.POINTER(ctypes.c_int64)]),
     "rr_glm_sgd_objective": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]),
     "rr_glm_sgd_destroy": (None, [ctypes.c_void_p]),
+    "rr_glm_svi_supported": (ctypes.c_int, [ctypes.c_int] * 7),
+    "rr_glm_svi_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
+                                         ctypes.c_int64, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]),
+    "rr_glm_svi_set_start": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "rr_glm_svi_run": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64,
+                                      ctypes.c_uint64]),
+    "rr_glm_svi_starts": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_uint64, ctypes.c_uint64, ctypes.c_void_p]),
+    "rr_glm_svi_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.POINTER(ctypes.c_int64)]),
+    "rr_glm_svi_destroy": (None, [ctypes.c_void_p]),
     "rr_posterior_available": (ctypes.c_int, []),
     "rr_set_gram_engine": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int]),
     "rr_get_gram_engine": (ctypes.c_int, [ctypes.c_void_p]),
@@ -1109,6 +1123,94 @@ class ResidentSgd(object):
             self.close()
         except Exception:
             pass
+
+
+class FusedSvi(object):
+    """The SVI loop for small minibatches, many steps per launch (rr_glm_svi, rr_svi.hip).
+    children: ("rff", RffHandle, n_ls, dX) | ("linear", d, onescol, dX) in concatenation order, dX the child's RESIDENT
+    rows (DeviceMatrix, all N rows); dy / drowarg: DeviceBuffers of all N targets / per-row arguments."""
+
+    def __init__(self, dev, children, N, dy, drowarg, K, L, M, lik, n_lik, z0, lower, upper, is_log, updater_id, updater_par,
+                 maxiter, bmag):
+        self.dev, self.lib, self.children = dev, dev.lib, list(children)
+        self._keep = (dy, drowarg)
+        z0 = np.ascontiguousarray(z0, dtype=np.float64)
+        lower = np.ascontiguousarray(lower, dtype=np.float64)
+        upper = np.ascontiguousarray(upper, dtype=np.float64)
+        is_log = np.ascontiguousarray(is_log, dtype=np.uint8)
+        nk = len(self.children)
+        kids = (SgdChild * nk)()
+        ptrs, dts, lds = (ctypes.c_void_p * nk)(), (ctypes.c_int * nk)(), (ctypes.c_int64 * nk)()
+        F = n_ls = 0
+        for i, (k, ch) in enumerate(zip(kids, self.children)):
+            dX = ch[3]
+            if ch[0] == "rff":
+                k.kind, k.basis, k.d, k.onescol, k.n_ls = 0, ch[1].h, 0, 0, int(ch[2])
+                n_ls += int(ch[2])
+                F += 2 * ch[1].n
+            else:
+                k.kind, k.basis, k.d, k.onescol, k.n_ls = 1, None, int(ch[1]), 1 if ch[2] else 0, 0
+                F += int(ch[1]) + (1 if ch[2] else 0)
+            p = dX.ptr
+            ptrs[i] = p if isinstance(p, int) else p.value
+            dts[i], lds[i] = rr_dtype(dX.dtype), dX.ld
+        self.F, self.K, self.L, self.M = F, int(K), int(L), int(M)
+        self.np_ = 2 * F * self.K + nk + n_lik + n_ls
+        if not (z0.shape == lower.shape == upper.shape == is_log.shape == (self.np_,)):
+            raise ValueError("z0, lower, upper, is_log must have 2 F K + children + n_lik + length scales = %d entries" % self.np_)
+        par = np.zeros(4)
+        par[:len(updater_par)] = updater_par
+        self.maxiter = int(maxiter)
+        h = ctypes.c_void_p()
+        _check(self.lib, self.lib.rr_glm_svi_create(
+            dev.ctx, nk, ctypes.cast(kids, ctypes.c_void_p), ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dts, ctypes.c_void_p),
+            ctypes.cast(lds, ctypes.c_void_p), int(N), _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), self.K, self.L, self.M,
+            int(lik), int(n_lik), z0.ctypes.data_as(ctypes.c_void_p), lower.ctypes.data_as(ctypes.c_void_p),
+            upper.ctypes.data_as(ctypes.c_void_p), is_log.ctypes.data_as(ctypes.c_void_p), int(updater_id),
+            par.ctypes.data_as(ctypes.c_void_p), self.maxiter, float(bmag), ctypes.byref(h)))
+        self.h = h
+
+    def set_start(self, z0, lower, upper, is_log):
+        arrs = [np.ascontiguousarray(z0, dtype=np.float64), np.ascontiguousarray(lower, dtype=np.float64),
+                np.ascontiguousarray(upper, dtype=np.float64), np.ascontiguousarray(is_log, dtype=np.uint8)]
+        if any(a.shape != (self.np_,) for a in arrs):
+            raise ValueError("set_start: %d coordinates expected" % self.np_)
+        _check(self.lib, self.lib.rr_glm_svi_set_start(self.h, *[a.ctypes.data_as(ctypes.c_void_p) for a in arrs]))
+
+    def run(self, steps, didx, dE=None, seed=0, key0=0):
+        """`steps` SGD steps in one launch (asynchronous): didx a device int32 (steps, M) buffer, dE device float32 draws or None."""
+        _check(self.lib, self.lib.rr_glm_svi_run(self.h, int(steps), _ptr(didx), None if dE is None else _ptr(dE), int(seed), int(key0)))
+
+    def starts(self, didx, cand, dE=None, seed=0, key0=0):
+        """-ELBO of every candidate row of `cand` (ncand, np; x space) on its own minibatch / draws: one launch."""
+        cand = np.ascontiguousarray(cand, dtype=np.float64)
+        out = np.empty(cand.shape[0])
+        _check(self.lib, self.lib.rr_glm_svi_starts(self.h, cand.shape[0], _ptr(didx), cand.ctypes.data_as(ctypes.c_void_p),
+                                                    None if dE is None else _ptr(dE), int(seed), int(key0),
+                                                    out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def read(self):
+        z, objs, norms = np.empty(self.np_), np.empty(self.maxiter), np.empty(self.maxiter)
+        n = ctypes.c_int64()
+        _check(self.lib, self.lib.rr_glm_svi_read(self.h, z.ctypes.data_as(ctypes.c_void_p), objs.ctypes.data_as(ctypes.c_void_p),
+                                                  norms.ctypes.data_as(ctypes.c_void_p), ctypes.byref(n)))
+        return z, objs[:n.value], norms[:n.value]
+
+    def close(self):
+        h, self.h = getattr(self, "h", None), None
+        if h:
+            self.lib.rr_glm_svi_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def svi_supported(F, K, L, M, n_children, dsum, n_ls):
+    return bool(load_library().rr_glm_svi_supported(int(F), int(K), int(L), int(M), int(n_children), int(dsum), int(n_ls)))
 
 
 class FeatureMatrix64(object):

@@ -1,0 +1,873 @@
+// The small-minibatch regime of GeneralizedLinearModel.fit -- the reference's own defaults are batch_size = 10, K = 10,
+// nsamples = 50, maxiter = 3000, nstarts = 500 (glm.py:120-124; "1 million iterations ... batch size of 10", docs/report) --
+// as ONE persistent kernel that runs MANY SGD steps per launch.
+//
+// One step of sgd (optimize/sgd.py:337-425) o logtrick_sgd (decorators.py:329-408) o structured_sgd (:133-252) around `_elbo`
+// (glm.py:205-294) at that size is ~1.3 MFLOP: through the general route (rr_glm_sgd_step: ~31 dependent launches of the
+// tile kernels) it is dispatch-bound at 140-160 us however little arithmetic the kernels hold.  Here a CLUSTER of K
+// workgroups -- workgroup k owns mixture component k: column k of (m, C), its L weight samples, its share of every sum --
+// walks through the steps inside the kernel:
+//
+//   a  x = from_log(z) of ALL coordinates into LDS (every workgroup; the other columns come from what their owners published)
+//   b  row k of the mixture's cross terms  q[k][l] = sum_f log(C_fk + C_fl) + (m_fk - m_fl)^2 / (C_fk + C_fl)   glm.py:697-712
+//      -> published, barrier B1 ARRIVE (nobody waits yet)
+//   c  the minibatch: rows gathered by index from the resident X, Phi (M, F) in float64 (every workgroup, redundantly:
+//      M F sincos)                                                                             basis_functions.py:838-864
+//   d  e (L, F): the caller's draws (the reference's stream, uploaded for the whole block of steps) or the counter-based
+//      device generator of rr_glm_draw_kernel -- same function of (seed, step, sample, feature)
+//   e  fs = ws Phi^T for the L samples of component k, ws = m_k + sqrt(C_k) e; df, loglike            glm.py:300-305,321
+//   f  Edws = dfs Phi -> Edm, EdC (complete: they are sums over component k's samples only); the component's share of
+//      EdPhi = dfs^T ws and of -(EdPhi o dPhi_i).sum() per length scale                            glm.py:308-311,274-275
+//   g  barrier B1 WAIT; log N_kl, log z, alpha                                                      glm.py:221-222,244-246
+//   h  gradient of column k, chain rule of the log trick, |g|^2, bound truncation, updater, clip   glm.py:252-256, sgd.py:404-420
+//      -> new column + the component's scalars published, barrier B2
+//   i  the few shared coordinates (regularisers, Gaussian variance, length scales): their gradients are sums over the
+//      components' published scalars, formed and applied by EVERY workgroup identically (fixed order) -- no further
+//      exchange; workgroup 0 records the step's -ELBO and |g|                                       glm.py:265-292
+//
+// so a step costs two device-scope barriers (one of them split-phase) instead of thirty launches.  Everything is float64
+// (the draws are float32 values, as everywhere on this path).  The K workgroups must be co-resident (K <= 32 of 256 CUs).
+//
+// rr_glm_svi_starts evaluates the random starts of structured_sgd (decorators.py:541-583) -- nstarts candidates, each on its
+// own minibatch with its own draws -- as ONE launch, one workgroup per candidate (objective only).
+#include "rr_internal.h"
+
+#include <algorithm>
+
+#define SVI_MAXCHILD 16
+#define SVI_MAXK 32
+#define SVI_THREADS 512
+#define SVI_WAVES (SVI_THREADS / 64)
+
+namespace {
+
+struct SviChild {
+    int kind, col0, width, d, n, n_ls, ls0, onescol, x_f64, xoff;  // xoff: first entry of this child's columns in a gathered row
+    const void *X;
+    int64_t ldx;
+    const double *W;  // RFF: raw (d, n) row-major on the device
+};
+
+struct SviArgs {
+    SviChild kid[SVI_MAXCHILD];
+    int nkids, F, Fp, K, L, M, lik, n_lik, n_ls, ns, updater, y_f64, dsum;
+    int64_t np, N;
+    const void *y, *rowarg;
+    double *z, *s1, *s2;
+    const double *lower, *upper;
+    const unsigned char *islog;
+    double *pubcol, *pubrow, *pubsc;
+    unsigned int *bar;
+    float *Ebuf;
+    const float *E;
+    const int *idx;
+    double *objs, *norms;
+    int64_t t0;
+    int steps;
+    double up[4], bmag;
+    uint64_t seed, key0;
+    // rr_glm_svi_starts
+    const double *cand;
+    double *out;
+};
+
+__device__ __forceinline__ uint64_t svi_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// the draw of rr_glm_draw_kernel (rr_elbo.hip) for (seed, step, counter)
+__device__ __forceinline__ float svi_draw(uint64_t stepkey, uint64_t ctr) {
+    const uint64_t h = svi_splitmix64(stepkey ^ ctr);
+    const float u1 = ((float)(uint32_t)(h >> 40) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(uint32_t)((h >> 8) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+    return sqrtf(-2.0f * __logf(u1)) * __builtin_amdgcn_cosf(u2);
+}
+
+__device__ __forceinline__ double svi_softplus(double f) { return fmax(f, 0.0) + log1p(exp(-fabs(f))); }
+__device__ __forceinline__ double svi_expit(double f) {
+    const double e = exp(-fabs(f));
+    return f >= 0.0 ? 1.0 / (1.0 + e) : e / (1.0 + e);
+}
+
+// d loglike / d f and the f-dependent part of loglike (Gaussian: the squared error)   likelihoods.py:46-104,171-233,298-368,456-521
+__device__ __forceinline__ void svi_lik(int lik, double f, double y, double n, double ivar, double &df, double &ll) {
+    if (lik == RR_LIK_BERNOULLI) {
+        df = y - svi_expit(f);
+        ll = y * f - svi_softplus(f);
+    } else if (lik == RR_LIK_BINOMIAL) {
+        df = y - n * svi_expit(f);
+        ll = y * f - n * svi_softplus(f);
+    } else if (lik == RR_LIK_GAUSSIAN) {
+        const double er = y - f;
+        df = er * ivar;
+        ll = er * er;
+    } else if (lik == RR_LIK_POISSON_EXP) {
+        const double g = exp(f);
+        df = y - g;
+        ll = y * f - g;
+    } else {
+        const double g = fmax(svi_softplus(f), 1e-100);
+        df = svi_expit(f) * (y / g - 1.0);
+        ll = y * log(g) - g;
+    }
+}
+
+__device__ __forceinline__ double svi_wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// sum over the block, fixed order (the same bits in every workgroup that sums the same values); all threads get it
+__device__ __forceinline__ double svi_block_sum(double v, double *red) {
+    const int tid = threadIdx.x;
+    v = svi_wave_sum(v);
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < SVI_WAVES; ++w) r += red[w];
+    return r;
+}
+
+__device__ __forceinline__ void svi_arrive(unsigned int *ctr) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void svi_wait(unsigned int *ctr, unsigned int target) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+__device__ __forceinline__ double svi_xval(const SviChild &c, int64_t row, int i) {
+    return c.x_f64 ? ((const double *)c.X)[row * c.ldx + i] : (double)((const float *)c.X)[row * c.ldx + i];
+}
+
+struct SviLds {
+    double *xm, *xC, *xs;           // x of all coordinates: (F, K) means, (F, K) covariances, the ns shared coordinates
+    double *zc, *s1c, *s2c;         // this workgroup's column (2 F: means then covariances), z space + updater state
+    double *zs, *s1s, *s2s;         // the shared coordinates' z and updater state (replicated in every workgroup)
+    double *Phi, *dfs, *EP, *Xb, *yb, *nb, *mk, *sk, *edm, *edc, *q, *logz, *alpha, *gls, *red, *misc;
+};
+
+__device__ __forceinline__ SviLds svi_carve(double *sm, const SviArgs &a) {
+    SviLds s;
+    const int FK = a.F * a.K;
+    double *p = sm;
+    s.xm = p; p += FK;
+    s.xC = p; p += FK;
+    s.xs = p; p += a.ns;
+    s.zc = p; p += 2 * a.F;
+    s.s1c = p; p += 2 * a.F;
+    s.s2c = p; p += 2 * a.F;
+    s.zs = p; p += a.ns;
+    s.s1s = p; p += a.ns;
+    s.s2s = p; p += a.ns;
+    s.Phi = p; p += a.M * a.Fp;
+    s.dfs = p; p += a.L * a.M;
+    s.EP = p; p += a.M * a.F;
+    s.Xb = p; p += a.M * a.dsum;
+    s.yb = p; p += a.M;
+    s.nb = p; p += a.M;
+    s.mk = p; p += a.F;
+    s.sk = p; p += a.F;
+    s.edm = p; p += a.F;
+    s.edc = p; p += a.F;
+    s.q = p; p += a.K * a.K;
+    s.logz = p; p += a.K;
+    s.alpha = p; p += a.K;
+    s.gls = p; p += (a.n_ls > 0 ? a.n_ls : 1);
+    s.red = p; p += SVI_WAVES;
+    s.misc = p; p += 8;
+    return s;
+}
+
+static size_t svi_lds_doubles(const SviArgs &a) {
+    const size_t FK = (size_t)a.F * a.K;
+    return 2 * FK + 4 * (size_t)a.ns + 6 * (size_t)a.F + (size_t)a.M * a.Fp + (size_t)a.L * a.M + (size_t)a.M * a.F +
+           (size_t)a.M * a.dsum + 2 * (size_t)a.M + 4 * (size_t)a.F + (size_t)a.K * a.K + 2 * (size_t)a.K +
+           (size_t)(a.n_ls > 0 ? a.n_ls : 1) + SVI_WAVES + 8;
+}
+
+// c: rows of the minibatch by index, targets, Phi (M, F) in float64, the batch's loglike constant -> misc[0]
+__device__ void svi_features(const SviArgs &a, const SviLds &s, const int *idx) {
+    const int tid = threadIdx.x, M = a.M;
+    for (int e = tid; e < M * a.dsum; e += SVI_THREADS) {
+        const int r = e / a.dsum, o = e % a.dsum;
+        int c = 0;
+        while (c + 1 < a.nkids && o >= a.kid[c + 1].xoff) ++c;
+        s.Xb[e] = svi_xval(a.kid[c], (int64_t)idx[r], o - a.kid[c].xoff);
+    }
+    if (tid < M) {
+        const int64_t row = idx[tid];
+        const double yv = a.y_f64 ? ((const double *)a.y)[row] : (double)((const float *)a.y)[row];
+        const double nv = a.rowarg ? (a.y_f64 ? ((const double *)a.rowarg)[row] : (double)((const float *)a.rowarg)[row]) : 0.0;
+        s.yb[tid] = yv;
+        s.nb[tid] = nv;
+    }
+    __syncthreads();
+    for (int c = 0; c < a.nkids; ++c) {
+        const SviChild &k = a.kid[c];
+        if (k.kind == RR_SGD_CHILD_LINEAR) {
+            for (int e = tid; e < M * k.width; e += SVI_THREADS) {
+                const int r = e / k.width, j = e % k.width;
+                s.Phi[r * a.Fp + k.col0 + j] = (k.onescol && j == 0) ? 1.0 : s.Xb[r * a.dsum + k.xoff + j - k.onescol];
+            }
+        } else {
+            const double scale = 1.0 / sqrt((double)k.n), inv2pi = 0.15915494309189533576888;
+            const double *ls = s.xs + (a.ns - a.n_ls) + k.ls0;
+            for (int e = tid; e < M * k.n; e += SVI_THREADS) {
+                const int r = e / k.n, j = e % k.n;
+                double t = 0.0;
+                for (int i = 0; i < k.d; ++i) t = fma(s.Xb[r * a.dsum + k.xoff + i], k.W[(size_t)i * k.n + j] * (inv2pi / ls[k.n_ls == 1 ? 0 : i]), t);
+                double sn, cs;
+                rr_sincos_rev_f64(t, sn, cs);
+                s.Phi[r * a.Fp + k.col0 + j] = cs * scale;
+                s.Phi[r * a.Fp + k.col0 + k.n + j] = sn * scale;
+            }
+        }
+    }
+    // the f-independent part of sum_r loglike per latent sample (likelihoods.py: the log-factorial terms; the Gaussian's
+    // follows the variance)
+    double lc = 0.0;
+    if (tid < M) {
+        const double yv = s.yb[tid], nv = s.nb[tid];
+        if (a.lik == RR_LIK_POISSON_EXP || a.lik == RR_LIK_POISSON_SOFTPLUS) lc = -lgamma(yv + 1.0);
+        else if (a.lik == RR_LIK_BINOMIAL) lc = lgamma(nv + 1.0) - lgamma(yv + 1.0) - lgamma(nv - yv + 1.0);
+    }
+    lc = svi_block_sum(lc, s.red);
+    if (tid == 0) s.misc[0] = lc;
+    __syncthreads();
+}
+
+// e: fs of component k's L samples against the minibatch, df into dfs (L, M); returns (sum loglike terms, sum squared errors)
+__device__ void svi_pass1(const SviArgs &a, const SviLds &s, const float *E, double ivar, double &llsum, double &aux) {
+    const int tid = threadIdx.x, M = a.M, F = a.F;
+    double ll_acc = 0.0;
+    for (int o = tid; o < a.L * M; o += SVI_THREADS) {
+        const int l = o / M, r = o % M;
+        const float *er = E + (size_t)l * F;
+        const double *ph = s.Phi + r * a.Fp;
+        double f = 0.0;
+        for (int j = 0; j < F; ++j) f = fma(fma(s.sk[j], (double)er[j], s.mk[j]), ph[j], f);
+        double df, ll;
+        svi_lik(a.lik, f, s.yb[r], s.nb[r], ivar, df, ll);
+        s.dfs[o] = df;
+        ll_acc += ll;
+    }
+    const double tot = svi_block_sum(ll_acc, s.red);
+    if (a.lik == RR_LIK_GAUSSIAN) {
+        aux = tot;
+        llsum = -0.5 * tot * ivar;
+    } else {
+        aux = 0.0;
+        llsum = tot;
+    }
+}
+
+// log N_jl = -(F log 2 pi + q_jl) / 2 and log z_l = logsumexp_j log N_jl from the full q (K, K) in s.q      glm.py:221-222
+__device__ __forceinline__ void svi_logz(const SviArgs &a, const SviLds &s) {
+    const int tid = threadIdx.x, K = a.K;
+    if (tid < K) {
+        double mx = -INFINITY;
+        for (int j = 0; j < K; ++j) mx = fmax(mx, -0.5 * ((double)a.F * 1.8378770664093453 + s.q[j * K + tid]));
+        double sm = 0.0;
+        for (int j = 0; j < K; ++j) sm += exp(-0.5 * ((double)a.F * 1.8378770664093453 + s.q[j * K + tid]) - mx);
+        s.logz[tid] = log(sm) + mx;
+    }
+    __syncthreads();
+}
+
+// q[k][l] for l = l0, l0 + step, ...: one wave per l
+__device__ __forceinline__ void svi_qrow(const SviArgs &a, const SviLds &s, int k, double *out) {
+    const int tid = threadIdx.x, K = a.K, F = a.F, wave = tid >> 6, lane = tid & 63;
+    for (int l = wave; l < K; l += SVI_WAVES) {
+        double acc = 0.0;
+        for (int f = lane; f < F; f += 64) {
+            const double dc = s.xC[f * K + k] + s.xC[f * K + l];
+            const double dm = s.xm[f * K + k] - s.xm[f * K + l];
+            acc += log(dc) + dm * dm / dc;
+        }
+        acc = svi_wave_sum(acc);
+        if (lane == 0) out[l] = acc;
+    }
+}
+
+// -ELBO from the sums (glm.py:285-292); called by one thread
+__device__ __forceinline__ double svi_neg_elbo(const SviArgs &a, const SviLds &s, double ell_total, const double *Rs) {
+    const int K = a.K, F = a.F;
+    double logL = 0.0, quad = 0.0, lz = 0.0;
+    for (int c = 0; c < a.nkids; ++c) {
+        const double reg = s.xs[c];
+        logL += (double)a.kid[c].width * log(reg);
+        quad += Rs[c] / reg;
+    }
+    for (int k = 0; k < K; ++k) lz += s.logz[k];
+    const double elbo = (ell_total * a.bmag - 0.5 * F * K * 1.8378770664093453 - 0.5 * K * logL - 0.5 * quad - lz + log((double)K)) / K;
+    return -elbo;
+}
+
+// one coordinate's truncation + updater + clip (sgd.py:404-420, :14-330); g is the gradient in z space
+__device__ __forceinline__ double svi_update(const SviArgs &a, double zz, double g, double lo, double hi, double &s1, double &s2,
+                                             double b1t, double b2t) {
+#pragma clang fp contract(off)
+    if (zz <= lo) g = (g <= 0.0 || g != g) ? g : 0.0;
+    if (zz >= hi) g = (g >= 0.0 || g != g) ? g : 0.0;
+    double zn;
+    switch (a.updater) {
+        case RR_UPD_SGD: zn = zz - a.up[0] * g; break;
+        case RR_UPD_ADADELTA: {
+            const double eg2 = a.up[0] * s1 + (1 - a.up[0]) * (g * g);
+            const double dx = -g * sqrt(s2 + a.up[1]) / sqrt(eg2 + a.up[1]);
+            s1 = eg2;
+            s2 = a.up[0] * s2 + (1 - a.up[0]) * (dx * dx);
+            zn = zz + dx;
+        } break;
+        case RR_UPD_ADAGRAD: {
+            const double h = s1 + g * g;
+            s1 = h;
+            zn = zz - a.up[0] * g / (a.up[1] + sqrt(h));
+        } break;
+        case RR_UPD_MOMENTUM: {
+            const double dx = a.up[0] * s1 - a.up[1] * g;
+            s1 = dx;
+            zn = zz + dx;
+        } break;
+        default: {
+            const double m = a.up[1] * s1 + (1 - a.up[1]) * g;
+            const double v = a.up[2] * s2 + (1 - a.up[2]) * (g * g);
+            s1 = m;
+            s2 = v;
+            zn = zz - a.up[0] * (m / b1t) / (sqrt(v / b2t) + a.up[3]);
+        }
+    }
+    return zn < lo ? lo : (zn > hi ? hi : zn);
+}
+
+__global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const SviArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ double sm[];
+    const SviLds s = svi_carve(sm, a);
+    const int tid = threadIdx.x, k = blockIdx.x, K = a.K, F = a.F, M = a.M, L = a.L, ns = a.ns, nk = a.nkids;
+    const int64_t fk = (int64_t)F * K;
+    const int npub = a.n_ls + 4;
+    // ---- launch start: this workgroup's column and the shared coordinates, with their updater state
+    for (int p = tid; p < 2 * F; p += SVI_THREADS) {
+        const int64_t g = (p < F ? 0 : fk) + (int64_t)(p < F ? p : p - F) * K + k;
+        s.zc[p] = a.z[g];
+        s.s1c[p] = a.s1[g];
+        s.s2c[p] = a.s2[g];
+    }
+    for (int p = tid; p < ns; p += SVI_THREADS) {
+        s.zs[p] = a.z[2 * fk + p];
+        s.s1s[p] = a.s1[2 * fk + p];
+        s.s2s[p] = a.s2[2 * fk + p];
+    }
+    __syncthreads();
+    for (int t = 0; t < a.steps; ++t) {
+        const int par = t & 1;
+        const int64_t gt = a.t0 + t;
+        // ---- a: x = from_log(z) of everything
+        for (int p = tid; p < 2 * (int)fk; p += SVI_THREADS) {
+            const int cov = p >= fk, q = cov ? p - (int)fk : p, f = q / K, j = q % K;
+            double zv;
+            if (j == k) zv = s.zc[cov * F + f];
+            else zv = t == 0 ? a.z[p] : a.pubcol[((size_t)(1 - par) * K + j) * 2 * F + cov * F + f];
+            (cov ? s.xC : s.xm)[q] = a.islog[p] ? exp(zv) : zv;
+        }
+        for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = a.islog[2 * fk + p] ? exp(s.zs[p]) : s.zs[p];
+        __syncthreads();
+        for (int f = tid; f < F; f += SVI_THREADS) {
+            s.mk[f] = s.xm[f * K + k];
+            s.sk[f] = sqrt(s.xC[f * K + k]);
+        }
+        // ---- b: row k of the mixture's cross terms, published
+        svi_qrow(a, s, k, a.pubrow + ((size_t)par * K + k) * K);
+        svi_arrive(a.bar + 0);
+        // ---- c: the minibatch
+        svi_features(a, s, a.idx + (size_t)t * M);
+        // ---- d: the draws of component k's samples
+        const float *E;
+        if (a.E) {
+            E = a.E + ((size_t)t * K * L + (size_t)k * L) * F;
+        } else {
+            float *Eb = a.Ebuf + (size_t)k * L * F;
+            const uint64_t stepkey = svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)t) * 0xD1B54A32D192ED03ull));
+            for (int o = tid; o < L * F; o += SVI_THREADS) Eb[o] = svi_draw(stepkey, (uint64_t)(k * L) * (uint64_t)F + (uint64_t)o);
+            __syncthreads();
+            E = Eb;
+        }
+        // ---- e: fs, df, loglike
+        const double ivar = a.n_lik ? 1.0 / s.xs[nk] : 0.0;
+        double llsum, aux;
+        svi_pass1(a, s, E, ivar, llsum, aux);
+        __syncthreads();
+        // ---- f: Edws = dfs Phi summed over the samples -> Edm, EdC; this component's share of EdPhi
+        {
+            const int LG = 8;
+            for (int o0 = 0; o0 < F * LG; o0 += SVI_THREADS) {
+                const int o = o0 + tid, f = o / LG, lg = o % LG;
+                double am = 0.0, ac = 0.0;
+                if (f < F) {
+                    for (int l = lg; l < L; l += LG) {
+                        const double *d = s.dfs + l * M;
+                        double ed = 0.0;
+                        for (int r = 0; r < M; ++r) ed = fma(d[r], s.Phi[r * a.Fp + f], ed);
+                        am += ed;
+                        ac = fma(ed, (double)E[(size_t)l * F + f], ac);
+                    }
+                }
+                am += __shfl_xor(am, 1, 64); ac += __shfl_xor(ac, 1, 64);
+                am += __shfl_xor(am, 2, 64); ac += __shfl_xor(ac, 2, 64);
+                am += __shfl_xor(am, 4, 64); ac += __shfl_xor(ac, 4, 64);
+                if (f < F && lg == 0) {
+                    s.edm[f] = am / L;
+                    s.edc[f] = ac / (L * s.sk[f]);
+                }
+            }
+            for (int o = tid; o < M * F; o += SVI_THREADS) {
+                const int r = o / F, f = o % F;
+                double acc = 0.0;
+                for (int l = 0; l < L; ++l) acc = fma(s.dfs[l * M + r], fma(s.sk[f], (double)E[(size_t)l * F + f], s.mk[f]), acc);
+                s.EP[o] = acc / ((double)L * K);
+            }
+            __syncthreads();
+            // -(EdPhi o dPhi_i).sum() of this component: W[i, :] . T[i, :] / l_i^2 with T = X^T (E_s o P_c - E_c o P_s); the
+            // isotropic parameter takes input dimension 0 only, as the reference does (basis_functions.py:896)
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int h = wave; h < a.n_ls; h += SVI_WAVES) {
+                int c = 0;
+                while (!(a.kid[c].kind == RR_SGD_CHILD_RFF && h >= a.kid[c].ls0 && h < a.kid[c].ls0 + a.kid[c].n_ls)) ++c;
+                const SviChild &kd = a.kid[c];
+                const int i = h - kd.ls0;
+                double acc = 0.0;
+                for (int o = lane; o < M * kd.n; o += 64) {
+                    const int r = o / kd.n, j = o % kd.n;
+                    const double *ph = s.Phi + r * a.Fp + kd.col0, *ep = s.EP + r * F + kd.col0;
+                    acc = fma(kd.W[(size_t)i * kd.n + j] * s.Xb[r * a.dsum + kd.xoff + i], ep[kd.n + j] * ph[j] - ep[j] * ph[kd.n + j], acc);
+                }
+                acc = svi_wave_sum(acc);
+                if (lane == 0) s.gls[h] = acc;
+            }
+        }
+        // ---- g: the other components' rows of q
+        svi_wait(a.bar + 0, (unsigned)(t + 1) * (unsigned)K);
+        for (int o = tid; o < K * K; o += SVI_THREADS) s.q[o] = a.pubrow[(size_t)par * K * K + o];
+        __syncthreads();
+        svi_logz(a, s);
+        if (tid < K) {
+            const double lN = -0.5 * ((double)F * 1.8378770664093453 + s.q[tid * K + k]);
+            s.alpha[tid] = exp(lN - s.logz[k]) + exp(lN - s.logz[tid]);
+        }
+        __syncthreads();
+        // ---- h: column k's gradient and update
+        const double tt = (double)(gt + 1);
+        const double b1t = 1.0 - pow(a.up[1], tt), b2t = 1.0 - pow(a.up[2], tt);
+        double n2 = 0.0;
+        for (int p = tid; p < 2 * F; p += SVI_THREADS) {
+            const int cov = p >= F, f = cov ? p - F : p;
+            int c = 0;
+            while (c + 1 < nk && f >= a.kid[c + 1].col0) ++c;
+            const double reg = s.xs[c];
+            const double mkv = s.xm[f * K + k], Ck = s.xC[f * K + k];
+            double mix = 0.0;
+            for (int l = 0; l < K; ++l) {
+                const double ic = 1.0 / (Ck + s.xC[f * K + l]);
+                const double dm = mkv - s.xm[f * K + l];
+                const double e = dm * ic;
+                mix += (cov ? ic - e * e : ic * dm) * s.alpha[l];
+            }
+            double g;
+            if (!cov) g = -((a.bmag * s.edm[f] - mkv / reg + mix) / K);
+            else g = -((a.bmag * s.edc[f] - 1.0 / reg + mix) / (2 * K));
+            const int64_t gp = (cov ? fk : 0) + (int64_t)f * K + k;
+            if (a.islog[gp]) g *= cov ? Ck : mkv;
+            n2 += g * g;
+            const double zn = svi_update(a, s.zc[p], g, a.lower[gp], a.upper[gp], s.s1c[p], s.s2c[p], b1t, b2t);
+            s.zc[p] = zn;
+            a.pubcol[((size_t)par * K + k) * 2 * F + p] = zn;
+        }
+        n2 = svi_block_sum(n2, s.red);
+        {
+            double *pb = a.pubsc + ((size_t)par * K + k) * npub;
+            for (int h = tid; h < a.n_ls; h += SVI_THREADS) pb[h] = s.gls[h];
+            if (tid == 0) {
+                pb[a.n_ls] = aux;
+                pb[a.n_ls + 1] = llsum;
+                pb[a.n_ls + 2] = n2;
+                pb[a.n_ls + 3] = 0.0;
+            }
+        }
+        svi_arrive(a.bar + 1);
+        svi_wait(a.bar + 1, (unsigned)(t + 1) * (unsigned)K);
+        // ---- i: the shared coordinates (every workgroup, identically) and the step's record
+        {
+            const double *pb = a.pubsc + (size_t)par * K * npub;
+            double g = 0.0;
+            // R_c = sum (m^2 + C) over child c's rows of (m, C): one wave per child (s.edm is free again; F >= children)
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int c = wave; c < nk; c += SVI_WAVES) {
+                double acc = 0.0;
+                const int lo = a.kid[c].col0 * K, hi = (a.kid[c].col0 + a.kid[c].width) * K;
+                for (int o = lo + lane; o < hi; o += 64) acc += s.xm[o] * s.xm[o] + s.xC[o];
+                acc = svi_wave_sum(acc);
+                if (lane == 0) s.edm[c] = acc;
+            }
+            __syncthreads();
+            double n2s = 0.0;
+            if (tid < ns) {
+                const int p = tid;
+                if (p < nk) {  // dreg of the child's slice (glm.py:265-268)
+                    const double iL = 1.0 / s.xs[p];
+                    g = -(0.5 * (s.edm[p] * (iL * iL) / K - (double)a.kid[p].width * iL));
+                } else if (p < nk + a.n_lik) {  // Gaussian variance (likelihoods.py:370-396)
+                    const double iv = 1.0 / s.xs[p];
+                    double sm2 = 0.0;
+                    for (int j = 0; j < K; ++j) sm2 += 0.5 * (pb[j * npub + a.n_ls] * iv * iv - iv * (double)M * L) / L;
+                    g = 0.0 - sm2 / K;
+                } else {
+                    const int h = p - nk - a.n_lik;
+                    double sm2 = 0.0;
+                    for (int j = 0; j < K; ++j) sm2 += pb[j * npub + h];
+                    const double l = s.xs[p];
+                    g = sm2 / (1.0 * (l * l));
+                }
+                if (a.islog[2 * fk + p]) g *= s.xs[p];
+                n2s = g * g;
+                s.zs[p] = svi_update(a, s.zs[p], g, a.lower[2 * fk + p], a.upper[2 * fk + p], s.s1s[p], s.s2s[p], b1t, b2t);
+            }
+            n2s = svi_block_sum(n2s, s.red);
+            if (k == 0 && tid == 0) {
+                double tot = n2s, ell = 0.0;
+                for (int j = 0; j < K; ++j) tot += pb[j * npub + a.n_ls + 2];
+                double llc = s.misc[0];
+                if (a.n_lik) llc = -0.5 * log(2.0 * 3.141592653589793 * s.xs[nk]) * (double)M;
+                for (int j = 0; j < K; ++j) ell += pb[j * npub + a.n_ls + 1] / L + llc;
+                a.norms[gt] = sqrt(tot);
+                a.objs[gt] = svi_neg_elbo(a, s, ell, s.edm);
+            }
+            __syncthreads();
+        }
+    }
+    // ---- launch end: state back to HBM
+    for (int p = tid; p < 2 * F; p += SVI_THREADS) {
+        const int64_t g = (p < F ? 0 : fk) + (int64_t)(p < F ? p : p - F) * K + k;
+        a.z[g] = s.zc[p];
+        a.s1[g] = s.s1c[p];
+        a.s2[g] = s.s2c[p];
+    }
+    if (k == 0) {
+        for (int p = tid; p < ns; p += SVI_THREADS) {
+            a.z[2 * fk + p] = s.zs[p];
+            a.s1[2 * fk + p] = s.s1s[p];
+            a.s2[2 * fk + p] = s.s2s[p];
+        }
+    }
+}
+
+// One workgroup per candidate: -ELBO of candidate c (x space, np coordinates) on its own minibatch with its own draws.
+__global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_starts_kernel(const SviArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ double sm[];
+    const SviLds s = svi_carve(sm, a);
+    const int tid = threadIdx.x, c = blockIdx.x, K = a.K, F = a.F, M = a.M, L = a.L, ns = a.ns, nk = a.nkids;
+    const int64_t fk = (int64_t)F * K;
+    const double *x = a.cand + (size_t)c * a.np;
+    for (int p = tid; p < (int)fk; p += SVI_THREADS) {
+        s.xm[p] = x[p];
+        s.xC[p] = x[fk + p];
+    }
+    for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = x[2 * fk + p];
+    __syncthreads();
+    svi_features(a, s, a.idx + (size_t)c * M);
+    const double ivar = a.n_lik ? 1.0 / s.xs[nk] : 0.0;
+    double ell = 0.0;
+    const uint64_t stepkey = svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)c) * 0xD1B54A32D192ED03ull));
+    for (int k = 0; k < K; ++k) {
+        __syncthreads();
+        for (int f = tid; f < F; f += SVI_THREADS) {
+            s.mk[f] = s.xm[f * K + k];
+            s.sk[f] = sqrt(s.xC[f * K + k]);
+        }
+        const float *E;
+        if (a.E) {
+            E = a.E + ((size_t)c * K * L + (size_t)k * L) * F;
+        } else {
+            float *Eb = a.Ebuf + (size_t)c * L * F;
+            for (int o = tid; o < L * F; o += SVI_THREADS) Eb[o] = svi_draw(stepkey, (uint64_t)(k * L) * (uint64_t)F + (uint64_t)o);
+            E = Eb;
+        }
+        __syncthreads();
+        double llsum, aux;
+        svi_pass1(a, s, E, ivar, llsum, aux);
+        ell += llsum / L;
+    }
+    for (int k = 0; k < K; ++k) svi_qrow(a, s, k, s.q + k * K);
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int ch = wave; ch < nk; ch += SVI_WAVES) {
+        double acc = 0.0;
+        const int lo = a.kid[ch].col0 * K, hi = (a.kid[ch].col0 + a.kid[ch].width) * K;
+        for (int o = lo + lane; o < hi; o += 64) acc += s.xm[o] * s.xm[o] + s.xC[o];
+        acc = svi_wave_sum(acc);
+        if (lane == 0) s.edm[ch] = acc;
+    }
+    __syncthreads();
+    svi_logz(a, s);
+    if (tid == 0) {
+        double llc = s.misc[0];
+        if (a.n_lik) llc = -0.5 * log(2.0 * 3.141592653589793 * s.xs[nk]) * (double)M;
+        a.out[c] = svi_neg_elbo(a, s, ell + llc * K, s.edm);
+    }
+}
+
+}  // namespace
+
+struct rr_glm_svi {
+    rr_ctx *ctx = nullptr;
+    SviArgs a;
+    std::vector<double *> dW;
+    unsigned char *islog = nullptr;
+    double *lower = nullptr, *upper = nullptr;
+    int64_t maxiter = 0, t = 0;
+    size_t lds_bytes = 0;
+    float *Ebuf_starts = nullptr;
+    size_t Ebuf_starts_count = 0;
+    double *cand = nullptr, *out = nullptr;
+    size_t cand_cap = 0;
+};
+
+static void svi_free(rr_glm_svi *o) {
+    void *q[] = {o->a.z, o->a.s1, o->a.s2, o->lower, o->upper, o->islog, o->a.pubcol, o->a.pubrow, o->a.pubsc, o->a.bar, o->a.Ebuf,
+                 o->a.objs, o->a.norms, o->Ebuf_starts, o->cand, o->out};
+    for (void *v : q)
+        if (v) (void)hipFree(v);
+    for (double *w : o->dW)
+        if (w) (void)hipFree(w);
+    delete o;
+}
+
+extern "C" {
+
+int rr_glm_svi_supported(int F, int K, int L, int M, int n_children, int dsum, int n_ls) {
+    if (F < 1 || K < 1 || K > SVI_MAXK || L < 1 || M < 1 || n_children < 1 || n_children > SVI_MAXCHILD) return 0;
+    if (F < n_children || M > SVI_THREADS || n_children + 1 + n_ls > SVI_THREADS) return 0;
+    SviArgs a;
+    a.F = F; a.Fp = F | 1; a.K = K; a.L = L; a.M = M; a.nkids = n_children; a.dsum = dsum; a.n_ls = n_ls;
+    a.ns = n_children + 1 + n_ls;
+    // the work one workgroup does per step stays small (this is the dispatch-bound regime, not a GEMM engine), and its
+    // state fits the CU's LDS
+    if ((int64_t)L * M * F > (int64_t)1 << 20 || (int64_t)M * F > 8192) return 0;
+    return svi_lds_doubles(a) * 8 <= 150 * 1024 ? 1 : 0;
+}
+
+int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *children, const void *const *dX, const int *x_dtype,
+                      const int64_t *ldx, int64_t N, const void *dy, const void *drowarg, int dtype, int K, int L, int M, int lik,
+                      int n_lik, const double *z0, const double *lower, const double *upper, const unsigned char *is_log,
+                      int updater, const double *upd_par, int64_t maxiter, double bmag, rr_glm_svi **out) {
+    RR_REQUIRE(ctx != nullptr && children != nullptr && dX != nullptr && x_dtype != nullptr && ldx != nullptr && dy != nullptr &&
+               z0 != nullptr && lower != nullptr && upper != nullptr && is_log != nullptr && upd_par != nullptr && out != nullptr,
+               "rr_glm_svi_create: null argument");
+    *out = nullptr;
+    RR_REQUIRE(n_children >= 1 && n_children <= SVI_MAXCHILD, "rr_glm_svi_create: 1 <= children <= %d", SVI_MAXCHILD);
+    RR_REQUIRE(K >= 1 && K <= SVI_MAXK && L >= 1 && M >= 1 && N >= 1, "rr_glm_svi_create: bad K, L, minibatch or N");
+    RR_REQUIRE(lik >= RR_LIK_BERNOULLI && lik <= RR_LIK_POISSON_SOFTPLUS && (lik == RR_LIK_GAUSSIAN) == (n_lik == 1),
+               "rr_glm_svi_create: likelihood %d with %d likelihood parameter(s)", lik, n_lik);
+    RR_REQUIRE((lik == RR_LIK_BINOMIAL) == (drowarg != nullptr), "rr_glm_svi_create: the per-row argument goes with the binomial likelihood");
+    RR_REQUIRE(updater >= RR_UPD_SGD && updater <= RR_UPD_ADAM, "rr_glm_svi_create: unknown updater %d", updater);
+    RR_REQUIRE(maxiter >= 1 && maxiter < ((int64_t)1 << 31) && N < ((int64_t)1 << 31), "rr_glm_svi_create: bad maxiter / N");
+    RR_REQUIRE(dtype == RR_F32 || dtype == RR_F64, "rr_glm_svi_create: bad dtype");
+    RR_CHECK_HIP(hipSetDevice(ctx->device));
+    rr_glm_svi *o = new rr_glm_svi();
+    o->ctx = ctx;
+    SviArgs &a = o->a;
+    memset(&a, 0, sizeof a);
+    int col = 0, nls = 0, xoff = 0;
+    for (int s = 0; s < n_children; ++s) {
+        const rr_glm_sgd_child &k = children[s];
+        SviChild &c = a.kid[s];
+        c.kind = k.kind;
+        c.col0 = col;
+        c.ls0 = nls;
+        c.xoff = xoff;
+        c.X = dX[s];
+        c.ldx = ldx[s];
+        c.x_f64 = x_dtype[s] == RR_F64;
+        bool ok = dX[s] != nullptr && (x_dtype[s] == RR_F32 || x_dtype[s] == RR_F64);
+        if (ok && k.kind == RR_SGD_CHILD_RFF) {
+            rr_basis *b = k.basis;
+            ok = b != nullptr && b->kind == RR_KIND_RFF && b->ctx == ctx && (k.n_ls == 1 || k.n_ls == b->d) && (int)b->W.size() == b->d * b->n;
+            if (ok) {
+                c.d = b->d; c.n = b->n; c.n_ls = k.n_ls; c.width = 2 * b->n; c.onescol = 0;
+                double *w = nullptr;
+                if (hipMalloc((void **)&w, b->W.size() * 8) != hipSuccess ||
+                    hipMemcpy(w, b->W.data(), b->W.size() * 8, hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipGetLastError();
+                    if (w) (void)hipFree(w);
+                    svi_free(o);
+                    rr_set_error("rr_glm_svi_create: device allocation failed");
+                    return RR_ERR_OOM;
+                }
+                o->dW.push_back(w);
+                c.W = w;
+            }
+        } else if (ok && k.kind == RR_SGD_CHILD_LINEAR) {
+            ok = k.d >= 1 && k.n_ls == 0;
+            c.d = k.d; c.n = 0; c.n_ls = 0; c.onescol = k.onescol ? 1 : 0; c.width = k.d + c.onescol;
+        } else {
+            ok = false;
+        }
+        if (!ok) {
+            svi_free(o);
+            rr_set_error("rr_glm_svi_create: child %d: a random Fourier basis of this context with 1 or Xdim length scales, or a "
+                         "linear child with d >= 1 columns, and its resident rows", s);
+            return RR_ERR_INVALID;
+        }
+        col += c.width;
+        nls += c.n_ls;
+        xoff += c.d;
+    }
+    a.nkids = n_children; a.F = col; a.Fp = col | 1; a.K = K; a.L = L; a.M = M; a.lik = lik; a.n_lik = n_lik; a.n_ls = nls;
+    a.ns = n_children + n_lik + nls; a.updater = updater; a.y_f64 = dtype == RR_F64; a.dsum = xoff; a.N = N;
+    a.np = 2 * (int64_t)col * K + a.ns;
+    a.y = dy; a.rowarg = drowarg; a.bmag = bmag;
+    for (int i = 0; i < 4; ++i) a.up[i] = upd_par[i];
+    if (!rr_glm_svi_supported(a.F, K, L, M, n_children, a.dsum, nls)) {
+        svi_free(o);
+        rr_set_error("rr_glm_svi_create: F = %d, K = %d, nsamples = %d, minibatch = %d is outside the fused small-batch loop's range "
+                     "(rr_glm_svi_supported)", a.F, K, L, M);
+        return RR_ERR_UNSUPPORTED;
+    }
+    o->lds_bytes = svi_lds_doubles(a) * 8;
+    o->maxiter = maxiter;
+    const size_t nb = (size_t)a.np * 8;
+    const int npub = nls + 4;
+    hipError_t e = hipMalloc((void **)&a.z, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.s1, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.s2, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->lower, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->upper, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->islog, (size_t)a.np);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.pubcol, (size_t)2 * K * 2 * a.F * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.pubrow, (size_t)2 * K * K * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.pubsc, (size_t)2 * K * npub * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.bar, 64);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.Ebuf, (size_t)K * L * a.F * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.objs, (size_t)maxiter * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&a.norms, (size_t)maxiter * 8);
+    if (e == hipSuccess) e = hipMemcpy(a.z, z0, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(o->lower, lower, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(o->upper, upper, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(o->islog, is_log, (size_t)a.np, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(a.s1, 0, nb);
+    if (e == hipSuccess) e = hipMemset(a.s2, 0, nb);
+    if (e == hipSuccess) e = hipMemset(a.objs, 0, (size_t)maxiter * 8);
+    if (e == hipSuccess) e = hipMemset(a.norms, 0, (size_t)maxiter * 8);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)rr_glm_svi_steps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void *)rr_glm_svi_starts_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        svi_free(o);
+        rr_set_error("rr_glm_svi_create: %s", hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? RR_ERR_OOM : RR_ERR_HIP;
+    }
+    a.lower = o->lower; a.upper = o->upper; a.islog = o->islog;
+    *out = o;
+    return RR_OK;
+}
+
+int rr_glm_svi_set_start(rr_glm_svi *o, const double *z0, const double *lower, const double *upper, const unsigned char *is_log) {
+    RR_REQUIRE(o != nullptr && o->t == 0, "rr_glm_svi_set_start: before the first step only");
+    RR_CHECK_HIP(hipSetDevice(o->ctx->device));
+    RR_CHECK_HIP(hipStreamSynchronize(o->ctx->stream));
+    const size_t nb = (size_t)o->a.np * 8;
+    if (z0) RR_CHECK_HIP(hipMemcpy(o->a.z, z0, nb, hipMemcpyHostToDevice));
+    if (lower) RR_CHECK_HIP(hipMemcpy(o->lower, lower, nb, hipMemcpyHostToDevice));
+    if (upper) RR_CHECK_HIP(hipMemcpy(o->upper, upper, nb, hipMemcpyHostToDevice));
+    if (is_log) RR_CHECK_HIP(hipMemcpy(o->islog, is_log, (size_t)o->a.np, hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+int rr_glm_svi_run(rr_glm_svi *o, int64_t steps, const int *d_idx, const float *dE, uint64_t seed, uint64_t key0) {
+    RR_REQUIRE(o != nullptr && d_idx != nullptr && steps >= 1 && steps <= (1 << 20), "rr_glm_svi_run: 1 <= steps <= 2^20 per launch");
+    RR_REQUIRE(o->t + steps <= o->maxiter, "rr_glm_svi_run: %lld steps done, %lld more asked, %lld at most", (long long)o->t,
+               (long long)steps, (long long)o->maxiter);
+    rr_ctx *c = o->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    SviArgs a = o->a;
+    a.idx = d_idx; a.E = dE; a.seed = seed; a.key0 = key0; a.t0 = o->t; a.steps = (int)steps;
+    RR_CHECK_HIP(hipMemsetAsync(a.bar, 0, 64, c->stream));
+    hipLaunchKernelGGL(rr_glm_svi_steps_kernel, dim3((unsigned)a.K), dim3(SVI_THREADS), o->lds_bytes, c->stream, a);
+    RR_CHECK_HIP(hipGetLastError());
+    o->t += steps;
+    return RR_OK;
+}
+
+int rr_glm_svi_starts(rr_glm_svi *o, int ncand, const int *d_idx, const double *cand_host, const float *dE, uint64_t seed, uint64_t key0,
+                      double *objs_host) {
+    RR_REQUIRE(o != nullptr && d_idx != nullptr && cand_host != nullptr && objs_host != nullptr && ncand >= 1 && ncand < (1 << 20),
+               "rr_glm_svi_starts: bad argument");
+    rr_ctx *c = o->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    SviArgs a = o->a;
+    const size_t want = (size_t)ncand * a.np;
+    if (o->cand_cap < want) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (o->cand) (void)hipFree(o->cand);
+        if (o->out) (void)hipFree(o->out);
+        o->cand = o->out = nullptr;
+        o->cand_cap = 0;
+        RR_CHECK_HIP(hipMalloc((void **)&o->cand, want * 8));
+        RR_CHECK_HIP(hipMalloc((void **)&o->out, (size_t)ncand * 8));
+        o->cand_cap = want;
+    }
+    if (!dE) {
+        const size_t ec = (size_t)ncand * a.L * a.F;
+        if (o->Ebuf_starts_count < ec) {
+            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+            if (o->Ebuf_starts) (void)hipFree(o->Ebuf_starts);
+            o->Ebuf_starts = nullptr;
+            o->Ebuf_starts_count = 0;
+            RR_CHECK_HIP(hipMalloc((void **)&o->Ebuf_starts, ec * 4));
+            o->Ebuf_starts_count = ec;
+        }
+        a.Ebuf = o->Ebuf_starts;
+    }
+    RR_CHECK_HIP(hipMemcpyAsync(o->cand, cand_host, want * 8, hipMemcpyHostToDevice, c->stream));
+    a.idx = d_idx; a.E = dE; a.seed = seed; a.key0 = key0; a.cand = o->cand; a.out = o->out;
+    hipLaunchKernelGGL(rr_glm_svi_starts_kernel, dim3((unsigned)ncand), dim3(SVI_THREADS), o->lds_bytes, c->stream, a);
+    RR_CHECK_HIP(hipGetLastError());
+    RR_CHECK_HIP(hipMemcpyAsync(objs_host, o->out, (size_t)ncand * 8, hipMemcpyDeviceToHost, c->stream));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    return RR_OK;
+}
+
+int rr_glm_svi_read(rr_glm_svi *o, double *z, double *objs, double *norms, int64_t *steps) {
+    RR_REQUIRE(o != nullptr, "rr_glm_svi_read: null argument");
+    rr_ctx *c = o->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (z) RR_CHECK_HIP(hipMemcpy(z, o->a.z, (size_t)o->a.np * 8, hipMemcpyDeviceToHost));
+    if (objs && o->t) RR_CHECK_HIP(hipMemcpy(objs, o->a.objs, (size_t)o->t * 8, hipMemcpyDeviceToHost));
+    if (norms && o->t) RR_CHECK_HIP(hipMemcpy(norms, o->a.norms, (size_t)o->t * 8, hipMemcpyDeviceToHost));
+    if (steps) *steps = o->t;
+    return RR_OK;
+}
+
+void rr_glm_svi_destroy(rr_glm_svi *o) {
+    if (!o) return;
+    (void)hipSetDevice(o->ctx->device);
+    (void)hipStreamSynchronize(o->ctx->stream);
+    svi_free(o);
+}
+
+}  // extern "C"

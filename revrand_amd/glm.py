@@ -184,8 +184,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                   self.basis.regularizer,
                   self.likelihood.params,
                   self.basis.params]
-        loop = self._resident_loop(params)
-        if loop is not None:  # (decided before the upload contexts' buffer rings are sized)
+        loop = self._resident_loop(params, y, likelihood_args)
+        fused = isinstance(loop, _FusedLoop)   # small minibatches: many steps per launch, nothing per batch on the device
+        if loop is not None and not fused:  # (decided before the upload contexts' buffer rings are sized)
             self.__dict__["_draw_buffers"] = 6
             self._features().PREFETCH_SLOTS = 6
         log.info("Optimising parameters...")
@@ -207,18 +208,20 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # batch -- the order in which a sequential run consumes the stream -- and hands them over with the batch, so
         # the ~12 ms of randn per config-5 step overlap the kernels instead of preceding them.
         prefetch = self._ahead if (self.sampler == "device" or self._prefetch_draws) else False
+        if fused:   # the worker thread cuts the batches and (reference's stream) makes the draws; the loop uploads them in blocks
+            prefetch = [self._draw_ahead] if (self.sampler != "device" and self._prefetch_draws) else False
         # (RR_GLM_DRAW_UPLOAD=0: measurement switch, the step uploads its draws itself)
-        if callable(prefetch) and self.sampler != "device" and self._prefetch_draws and self._native_draws \
+        if callable(prefetch) and not fused and self.sampler != "device" and self._prefetch_draws and self._native_draws \
                 and getattr(self._features(), "accepts_device_draws", False) \
                 and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":  # the worker uploads its draws too: own context, three buffers in turn
             # (one upload context per process and device, shared by every fit: a context is a stream and two events, and a
             # cross-validation loop must not accumulate them)
             self.__dict__["_draw_upload"] = (_hip.get_upload_device(_hip.get_device().index), [None] * self._draw_buffers, [0])
         # (RR_GLM_BATCH_PREFETCH=0: measurement switch, the step uploads its indices / targets and gathers its rows itself)
-        if callable(prefetch) and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
+        if callable(prefetch) and not fused and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
                 and self._group() is None:  # (a device group's members gather for themselves, on their own threads)
             self.__dict__["_batch_upload"] = _hip.get_upload_device(_hip.get_device().index)
-        if callable(prefetch) and os.environ.get("RR_GLM_PREFETCH_STAGES", "2") != "1":
+        if callable(prefetch) and not fused and os.environ.get("RR_GLM_PREFETCH_STAGES", "2") != "1":
             # two workers in a row: the draws (2.5 ms of MT19937 + polar method per config-5 step, on the thread that cuts the
             # batches -- one RandomState, the reference's order -- next to its 0.4 ms of y[idx] and, once per epoch, 18 ms of
             # permutation(N)), then the uploads and gathers (1.1 ms): one worker doing both needed 4 ms per step, more than the
@@ -263,7 +266,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
     _draw_buffers = 3
     _resident_sgd = True    # False (or RR_GLM_RESIDENT_SGD=0): always the host loop around `_elbo` (tests, A/B runs)
 
-    def _resident_loop(self, params):
+    _fused_sgd = True       # False (or RR_GLM_FUSED=0): never the many-steps-per-launch loop of small minibatches
+
+    def _resident_loop(self, params, y=None, likelihood_args=()):
         """The SGD loop with parameters, updater state and gradient in device memory (`_ResidentLoop`, rr_glm_sgd) when this
         fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a LinearBasis or a
         concatenation of such children (Xdim <= 128, a scalar regulariser each); one of the reference's likelihoods and updaters;
@@ -302,6 +307,16 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 return None
         if sum(c[2] for c in children if c[0] == "rff") != sum(int(np.prod(p.shape, dtype=int)) for p in atleast_list(params[4])):
             return None
+        # small minibatches (the reference's default is 10 rows): the whole loop inside one kernel, many steps per launch
+        if self._fused_sgd and os.environ.get("RR_GLM_FUSED", "1") != "0" and y is not None and len(likelihood_args) <= 1 \
+                and np.isfinite(self.maxiter):
+            N = len(y)
+            M = int(min(self.batch_size, N))
+            F = int(self.D_)
+            dsum = sum((kid.W.shape[0] if c[0] == "rff" else c[1]) for kid, c in zip(kids, children))
+            n_ls = sum(c[2] for c in children if c[0] == "rff")
+            if _hip.svi_supported(F, self.K, self.nsamples, M, len(children), dsum, n_ls):
+                return _FusedLoop(self, feats, n_lik, children, y, likelihood_args)
         return _ResidentLoop(self, feats, n_lik, children)
 
     def _reference_draws(self, out=None):
@@ -770,6 +785,203 @@ class _ResidentLoop(object):
         if sgd is not None:
             sgd.close()
         self.feats.__dict__.pop("PREFETCH_SLOTS", None)
+
+
+class _FusedLoop(object):
+    """`optimize.sgd`'s loop AND structured_sgd's random starts for SMALL minibatches (the reference's defaults: 10 rows, K = 10,
+    50 samples, 3000 steps, 500 starts -- glm.py:120-124): rr_glm_svi runs many SGD steps inside ONE kernel launch (K
+    cooperating workgroups; rr_svi.hip) and scores all candidates of the random starts in one more.  The host's part of a
+    step is what must stay in the reference's order on ONE RandomState -- cutting the minibatch (the permutation stream) and,
+    with sampler="host", drawing the step's normals -- both on the prefetch worker; row indices and draws go up in blocks of
+    steps.  X, y, the per-row likelihood argument, z, the updater's state: resident.  `_elbo` is never called."""
+
+    log_coordinates = None
+    BLOCK_BYTES = 48 << 20    # draws uploaded per launch at most (two device buffers of this size in turn)
+    BLOCK_STEPS = 256
+
+    def __init__(self, glm, feats, n_lik, children, y, likelihood_args):
+        from . import optimize as opt
+        self.glm, self.feats, self.n_lik, self.children = glm, feats, n_lik, children
+        self.y, self.largs = np.asarray(y, dtype=float), tuple(likelihood_args)
+        self.svi = None
+        self.updater = opt.Adam() if glm.updater is None else glm.updater
+        self.M = int(min(glm.batch_size, len(self.y)))
+        self._cands, self._start_idx, self._start_draws = [], [], []
+        self._bufs = {}
+
+    # -- the device object ---------------------------------------------------------------------------------------------------
+    def _ensure(self):
+        if self.svi is not None:
+            return self.svi
+        g, feats = self.glm, self.feats
+        dev = _hip.get_device()
+        self.dev = dev
+        kind = type(self.updater).__name__
+        u = self.updater
+        par = {"SGDUpdater": lambda: [u.eta], "AdaDelta": lambda: [u.rho, u.epsilon], "AdaGrad": lambda: [u.eta, u.epsilon],
+               "Momentum": lambda: [u.rho, u.eta], "Adam": lambda: [u.alpha, u.beta1, u.beta2, u.epsilon]}[kind]()
+        self.dy = dev.upload_vector(self.y, np.float64)
+        self.dn = dev.upload_vector(np.asarray(self.largs[0], dtype=float), np.float64) if self.largs and len(self.largs[0]) else None
+        from .likelihoods import RR_LIK_GAUSSIAN
+        if self.n_lik:
+            lik = RR_LIK_GAUSSIAN
+        else:
+            lik = g.likelihood.device_spec(self.y[:1], [], [a[:1] for a in self.largs if len(a)])[0]
+        kids = [c + (kid.dX,) for c, kid in zip(self.children, feats._kids)]
+        F = int(g.D_)
+        self.np_ = 2 * F * g.K + len(kids) + self.n_lik + sum(c[2] for c in self.children if c[0] == "rff")
+        hold = np.zeros(self.np_)
+        self.svi = _hip.FusedSvi(dev, kids, len(self.y), self.dy, self.dn, g.K, g.nsamples, self.M, lik, self.n_lik, hold,
+                                 np.full(self.np_, -np.inf), np.full(self.np_, np.inf), np.zeros(self.np_, dtype=np.uint8),
+                                 _hip.UPDATER_IDS[kind], par, max(1, int(g.maxiter)), g.B_)
+        self.F = F
+        return self.svi
+
+    def _device(self, name, nbytes):
+        buf = self._bufs.get(name)
+        if buf is None or buf.nbytes < nbytes:
+            if buf is not None:
+                self.dev.sync()
+                buf.free()
+            buf = self._bufs[name] = self.dev.malloc(max(int(nbytes), 4))
+        return buf
+
+    def _up(self, name, arr):
+        arr = np.ascontiguousarray(arr)
+        buf = self._device(name, arr.nbytes)
+        if arr.nbytes:
+            _hip._check(self.dev.lib, self.dev.lib.rr_memcpy_h2d(self.dev.ctx, buf.ptr, arr.ctypes.data_as(_hip.ctypes.c_void_p), arr.nbytes))
+        return buf
+
+    @staticmethod
+    def _split(batch):
+        """(row indices, draws or None) of a batch as the generator / the prefetch worker hands it over"""
+        items = list(batch)
+        draws = None
+        while items and isinstance(items[-1], (_Draws, _Spec, _Batch)):
+            last = items.pop()
+            if isinstance(last, _Draws):
+                draws = last.e
+        return np.asarray(items[-1]), draws
+
+    # -- the random starts (structured_sgd: decorators.py:541-583) -------------------------------------------------------------
+    def note_start(self, batch, cand_flat):
+        """One candidate: its minibatch (already cut), its parameter draw (already made); with the reference's stream its
+        `_elbo`'s normals are drawn from `random_` NOW -- the order of a sequential run (batch, candidate, draws)."""
+        g = self.glm
+        idx, _ = self._split(batch)
+        self._start_idx.append(np.asarray(idx, dtype=np.int32))
+        self._cands.append(np.asarray(cand_flat, dtype=float))
+        if g.sampler != "device":
+            self._start_draws.append(g._reference_draws())
+
+    def score_starts(self):
+        """-ELBO of every noted candidate, in order: one launch."""
+        g = self.glm
+        svi = self._ensure()
+        ns = len(self._cands)
+        didx = self._up("sidx", np.stack(self._start_idx))
+        if g.sampler == "device":
+            objs = svi.starts(didx, np.stack(self._cands), None, g._dev_seed, g._dev_step)
+            g._dev_step += ns
+        else:
+            objs = svi.starts(didx, np.stack(self._cands), self._up("sE", np.stack(self._start_draws)))
+        g._iteration(advance=ns)
+        self._cands, self._start_idx, self._start_draws = [], [], []
+        self._bufs.pop("sE").free() if "sE" in self._bufs else None
+        return objs
+
+    # -- the loop (optimize.sgd: device_loop protocol) -----------------------------------------------------------------------
+    def begin(self, z0, lower, upper, updater, maxiter):
+        if not np.isfinite(maxiter):
+            raise ValueError("the fused loop needs a finite maxiter")
+        if updater is not None and (type(updater) is not type(self.updater) or vars(updater) != vars(self.updater)):
+            raise ValueError("the fused loop was built for another updater")
+        svi = self._ensure()
+        pos = self.log_coordinates if self.log_coordinates is not None else np.zeros(len(z0), dtype=bool)
+        self.pos = np.asarray(pos, dtype=bool)
+        svi.set_start(z0, lower, upper, self.pos)
+        g = self.glm
+        per_step = g.K * g.nsamples * self.F * 4 if g.sampler != "device" else 0
+        self.T = int(max(1, min(self.BLOCK_STEPS, self.BLOCK_BYTES // max(per_step, 1), max(1, int(maxiter)))))
+        self._idx = np.empty((self.T, self.M), dtype=np.int32)
+        self._E = [np.empty((self.T, g.K * g.nsamples, self.F), dtype=np.float32) for _ in range(2)] if per_step else None
+        self._fill, self._turn, self.t = 0, 0, 0
+        self._z0 = np.array(z0, dtype=float)
+        self.clock = []
+
+    def _values(self, z):
+        x = np.where(self.pos, np.exp(np.where(self.pos, z, 0.0)), z)
+        o, nk = 2 * self.glm.D_ * self.glm.K, len(self.children)
+        regs = list(x[o:o + nk])
+        ls, q = [], o + nk + self.n_lik
+        for c in self.children:
+            n = c[2] if c[0] == "rff" else 0
+            if n:
+                ls.append(x[q] if n == 1 else x[q:q + n])
+            q += n
+        return (regs[0] if nk == 1 else regs), ([x[o + nk]] if self.n_lik else []), (ls[0] if len(ls) == 1 else ls)
+
+    def _flush(self):
+        n = self._fill
+        if n == 0:
+            return
+        g, svi = self.glm, self.svi
+        # (two device buffers in turn: the launch that read buffer `turn` two flushes ago is over once the copy into it may
+        # start -- rr_memcpy_h2d is ordered on the stream the launches run on)
+        didx = self._up("idx%d" % self._turn, self._idx[:n])
+        if g.sampler == "device":
+            svi.run(n, didx, None, g._dev_seed, g._dev_step)
+            g._dev_step += n
+        else:
+            svi.run(n, didx, self._up("E%d" % self._turn, self._E[self._turn][:n]))
+        self._turn ^= 1
+        self._fill = 0
+        self.clock.append((time.perf_counter(), n))
+
+    def step(self, batch):
+        g = self.glm
+        idx, draws = self._split(batch)
+        it = g._iteration(advance=1)
+        dolog = ((it % LOGITER == 0) or (it == g.maxiter - 1)) and log.isEnabledFor(logging.INFO)
+        shown = None
+        if dolog:   # the log line shows the parameters this step STARTS from: everything before it runs first
+            self._flush()
+            shown = self._values(self.svi.read()[0])
+        self._idx[self._fill] = idx
+        if g.sampler != "device":
+            self._E[self._turn][self._fill] = draws if draws is not None else g._reference_draws()
+        self._fill += 1
+        self.t += 1
+        if self._fill == self.T or dolog:
+            self._flush()
+        if dolog:
+            log.info("Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
+                     .format(it, -self.svi.read()[1][self.t - 1], shown[0], shown[1], shown[2]))
+
+    def end(self):
+        if self.svi is None or self.t == 0:
+            z0 = getattr(self, "_z0", None)
+            self.abort()
+            return z0, np.empty(0), np.empty(0)
+        self._flush()
+        z, objs, norms = self.svi.read()
+        self.clock.append((time.perf_counter(), 0))
+        self.glm.__dict__["_resident_clock"] = np.array([c[0] for c in self.clock])
+        self.abort()
+        return z, objs, norms
+
+    def abort(self):
+        svi, self.svi = self.svi, None
+        if svi is not None:
+            svi.close()
+        for b in self._bufs.values():
+            b.free()
+        self._bufs = {}
+        for name in ("dy", "dn"):
+            b = self.__dict__.pop(name, None)
+            if b is not None:
+                b.free()
 
 
 class _Batch(object):

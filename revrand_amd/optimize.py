@@ -492,6 +492,21 @@ def structured_sgd(sgd):
                 log.info("Evaluating random starts...")
                 best_obj, best = np.inf, None
                 objective_only = getattr(fun, "objective_only", None)
+                # a device loop may score ALL candidates in one launch (glm._FusedLoop): the candidates, their minibatches
+                # and -- with the reference's random stream -- their draws are made here in the reference's order
+                # (batch, candidate, the evaluation's draws: decorators.py:560-566), the evaluations happen afterwards
+                batched = sgd_kwargs.get("device_loop") if sync is None else None
+                if batched is not None and getattr(batched, "note_start", None) is not None:
+                    cands = []
+                    for _ in range(nstarts):
+                        batch = next(data_gen)
+                        cand = _map(lambda p: p.rvs(random_state), parameters)
+                        batched.note_start(list(batch) + list(args), flatten_values(cand))
+                        cands.append(cand)
+                    for cand, obj in zip(cands, batched.score_starts()):
+                        if best is None or obj < best_obj:
+                            best_obj, best = obj, cand
+                    nstarts = 0
                 for _ in range(nstarts):
                     batch = next(data_gen)
                     cand = _map(lambda p: p.rvs(random_state), parameters)

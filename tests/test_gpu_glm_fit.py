@@ -49,24 +49,42 @@ def _flat(v):
     return np.concatenate([np.ravel(np.asarray(u, dtype=float)) for u in v] + [np.empty(0)])
 
 
-@pytest.mark.parametrize("resident", [True, False], ids=["resident loop", "host loop"])
+@pytest.mark.parametrize("loop", ["fused loop", "resident loop", "host loop"])
 @pytest.mark.parametrize("case", IMPLEMENTED, ids=[c[0] for c in IMPLEMENTED])
-def test_fit_equals_the_references_fit(golden, case, resident, monkeypatch):
+def test_fit_equals_the_references_fit(golden, case, loop, monkeypatch):
+    """fused: rr_glm_svi, many steps per launch and the random starts as one launch (what these small shapes take by
+    default); resident: rr_glm_sgd_step, one library call per step; host: optimize.sgd around `_elbo`."""
     from revrand_amd import _hip
     g = golden("glm_fit")
     tag, lik = case[0], case[1]
     glm, largs = _model(g, case)
-    glm._resident_sgd = resident
-    steps = [0]
-    real = _hip.ResidentSgd.step
+    glm._resident_sgd = loop != "host loop"
+    glm._fused_sgd = loop == "fused loop"
+    steps = {"resident loop": 0, "fused loop": 0, "starts": 0}
+    real, real_run, real_starts = _hip.ResidentSgd.step, _hip.FusedSvi.run, _hip.FusedSvi.starts
 
     def spy(self, *a, **k):
-        steps[0] += 1
+        steps["resident loop"] += 1
         return real(self, *a, **k)
+
+    def spy_run(self, n, *a, **k):
+        steps["fused loop"] += n
+        return real_run(self, n, *a, **k)
+
+    def spy_starts(self, didx, cand, *a, **k):
+        steps["starts"] += len(cand)
+        return real_starts(self, didx, cand, *a, **k)
     monkeypatch.setattr(_hip.ResidentSgd, "step", spy)
+    monkeypatch.setattr(_hip.FusedSvi, "run", spy_run)
+    monkeypatch.setattr(_hip.FusedSvi, "starts", spy_starts)
     np.random.seed(int(g["global_seed"]))
     glm.fit(g["X"], g["y_" + lik], likelihood_args=largs)
-    assert steps[0] == (int(g["maxiter"]) if resident else 0)   # the loop under test is the one that ran
+    want = {"resident loop": 0, "fused loop": 0, "starts": 0}     # the loop under test is the one that ran
+    if loop != "host loop":
+        want[loop] = int(g["maxiter"])
+    if loop == "fused loop":
+        want["starts"] = case[4]
+    assert steps == want
     errs = {"m": normwise(glm.weights_, g[tag + "_m"]), "C": normwise(glm.covariance_, g[tag + "_C"]),
             "reg": normwise(_flat(glm.regularizer_), g[tag + "_reg"]), "ls": normwise(_flat(glm.basis_hypers_), g[tag + "_ls"])}
     if lik == "gaussian":
