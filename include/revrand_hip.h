@@ -412,13 +412,16 @@ void rr_glm_sgd_destroy(rr_glm_sgd *s);
  * and likelihoods as rr_glm_sgd; rr_glm_svi_supported says whether a shape is in range (F K and minibatch x F small enough for
  * one CU's LDS).
  * dX[c], x_dtype[c], ldx[c]: child c's RESIDENT rows of its columns of X (all N rows, device); dy / drowarg: targets and the
- * binomial's n for all N rows (device, dtype); M: minibatch rows; bmag = N / M (glm.py:158). */
+ * binomial's n for all N rows (device, dtype); dlconst: per row, the part of loglike that does not depend on f (device float64:
+ * Poisson -lgamma(y + 1), binomial lgamma(n + 1) - lgamma(y + 1) - lgamma(n - y + 1); NULL: zero -- Bernoulli, Gaussian);
+ * M: minibatch rows; bmag = N / M (glm.py:158). */
 typedef struct rr_glm_svi rr_glm_svi;
 int rr_glm_svi_supported(int F, int K, int L, int M, int n_children, int dsum, int n_ls);
 int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *children, const void *const *dX, const int *x_dtype,
-                      const int64_t *ldx, int64_t N, const void *dy, const void *drowarg, int dtype, int K, int L, int M, int lik,
-                      int n_lik, const double *z0, const double *lower, const double *upper, const unsigned char *is_log,
-                      int updater, const double *upd_par, int64_t maxiter, double bmag, rr_glm_svi **out);
+                      const int64_t *ldx, int64_t N, const void *dy, const void *drowarg, const double *dlconst, int dtype, int K,
+                      int L, int M, int lik, int n_lik, const double *z0, const double *lower, const double *upper,
+                      const unsigned char *is_log, int updater, const double *upd_par, int64_t maxiter, double bmag,
+                      rr_glm_svi **out);
 /* The start point (structured_sgd picks it after the random starts, decorators.py:223-234), the bounds and the log-space
  * flags as logtrick_sgd leaves them (decorators.py:586-616), before the first step; NULL: unchanged. */
 int rr_glm_svi_set_start(rr_glm_svi *s, const double *z0, const double *lower, const double *upper, const unsigned char *is_log);

@@ -159,7 +159,7 @@ SIGNATURES = {
     "rr_glm_sgd_destroy": (None, [ctypes.c_void_p]),
     "rr_glm_svi_supported": (ctypes.c_int, [ctypes.c_int] * 7),
     "rr_glm_svi_create": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p,
                                          ctypes.c_int64, ctypes.c_double, ctypes.POINTER(ctypes.c_void_p)]),
@@ -1130,10 +1130,10 @@ class FusedSvi(object):
     children: ("rff", RffHandle, n_ls, dX) | ("linear", d, onescol, dX) in concatenation order, dX the child's RESIDENT
     rows (DeviceMatrix, all N rows); dy / drowarg: DeviceBuffers of all N targets / per-row arguments."""
 
-    def __init__(self, dev, children, N, dy, drowarg, K, L, M, lik, n_lik, z0, lower, upper, is_log, updater_id, updater_par,
+    def __init__(self, dev, children, N, dy, drowarg, dlconst, K, L, M, lik, n_lik, z0, lower, upper, is_log, updater_id, updater_par,
                  maxiter, bmag):
         self.dev, self.lib, self.children = dev, dev.lib, list(children)
-        self._keep = (dy, drowarg)
+        self._keep = (dy, drowarg, dlconst)
         z0 = np.ascontiguousarray(z0, dtype=np.float64)
         lower = np.ascontiguousarray(lower, dtype=np.float64)
         upper = np.ascontiguousarray(upper, dtype=np.float64)
@@ -1164,7 +1164,7 @@ class FusedSvi(object):
         h = ctypes.c_void_p()
         _check(self.lib, self.lib.rr_glm_svi_create(
             dev.ctx, nk, ctypes.cast(kids, ctypes.c_void_p), ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(dts, ctypes.c_void_p),
-            ctypes.cast(lds, ctypes.c_void_p), int(N), _ptr(dy), _ptr(drowarg), rr_dtype(dy.dtype), self.K, self.L, self.M,
+            ctypes.cast(lds, ctypes.c_void_p), int(N), _ptr(dy), _ptr(drowarg), _ptr(dlconst), rr_dtype(dy.dtype), self.K, self.L, self.M,
             int(lik), int(n_lik), z0.ctypes.data_as(ctypes.c_void_p), lower.ctypes.data_as(ctypes.c_void_p),
             upper.ctypes.data_as(ctypes.c_void_p), is_log.ctypes.data_as(ctypes.c_void_p), int(updater_id),
             par.ctypes.data_as(ctypes.c_void_p), self.maxiter, float(bmag), ctypes.byref(h)))

@@ -15,7 +15,12 @@
 // restatement serves every NumPy the reference runs on; tests/test_host_logic.py compares against the installed one
 // (values, cached-value parity, interleaving with other draws, final state).
 #include <atomic>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <unistd.h>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -140,6 +145,89 @@ struct Batch {
     int64_t cand0, c, pair0;  // its candidates [cand0, cand0 + c), the number of its first accepted pair
 };
 
+// Worker threads that outlive a call.  An SVI fit at the reference's default sizes asks for 41 500 normals per step,
+// thousands of times: std::thread per call costs more than the work it takes over (and round 5 therefore ran such calls on
+// the calling thread alone: 235 us each on the GPU box's host, 170 of them the logarithms and square roots).  The workers
+// spin for a moment after a job -- the next call is ~100 us away in that loop -- and sleep on a condition variable otherwise.
+// One job at a time (a mutex around start .. wait); a forked child starts its own pool (threads do not survive a fork).
+class WorkerPool {
+  public:
+    static WorkerPool &get() {
+        static WorkerPool *pool = nullptr;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pool || pool->pid_ != getpid()) pool = new WorkerPool();  // (a fork's inheritance is abandoned, not joined)
+        return *pool;
+    }
+    // fn runs on `n` workers; returns at once.  wait() blocks until all of them are done.
+    void start(int n, std::function<void()> fn) {
+        call_.lock();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while ((int)th_.size() < n) {
+                const int id = (int)th_.size();
+                th_.emplace_back([this, id] { loop(id); });
+                th_.back().detach();
+            }
+            job_ = std::move(fn);
+            want_ = n;
+            remaining_.store(n, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+    }
+    void wait() {
+        for (int spin = 0; remaining_.load(std::memory_order_acquire) > 0; ++spin) {
+            if (spin < 4096) std::this_thread::yield();
+            else {
+                std::unique_lock<std::mutex> lk(mu_);
+                done_.wait_for(lk, std::chrono::microseconds(200), [this] { return remaining_.load(std::memory_order_acquire) == 0; });
+            }
+        }
+        call_.unlock();
+    }
+
+  private:
+    WorkerPool() : pid_(getpid()) {}
+    void loop(int id) {
+        int64_t seen = 0;
+        for (;;) {
+            // a job for this worker? spin first (the caller comes back every ~100 us inside a fit), then sleep
+            int64_t g = gen_.load(std::memory_order_acquire);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (g == seen) {
+                std::this_thread::yield();
+                g = gen_.load(std::memory_order_acquire);
+                if (g == seen && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                    g = gen_.load(std::memory_order_acquire);
+                }
+            }
+            seen = g;
+            std::function<void()> fn;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (id >= want_) continue;
+                fn = job_;
+            }
+            fn();
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(mu_);
+                done_.notify_all();
+            }
+        }
+    }
+    pid_t pid_;
+    std::mutex mu_, call_;
+    std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;
+    std::function<void()> job_;
+    int want_ = 0;
+    std::atomic<int> remaining_{0};
+    std::atomic<int64_t> gen_{0};
+};
+
 // The stream is consumed candidate by candidate (four words each) until `npairs` are accepted -- not one word more, or the
 // generator's state would differ from NumPy's afterwards.  A batch of c candidates yields at most c pairs, so batches of
 // min(pairs still missing, BATCH) candidates can never overshoot; the last < 64 pairs go one by one.  The calling thread
@@ -191,9 +279,11 @@ int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, i
             }
         };
         if (threads < 1) threads = 1;
-        std::vector<std::thread> pool;
-        if (npairs >= 16 * BATCH)
-            for (int t = 0; t < threads; ++t) pool.emplace_back(worker);
+        if (threads > 16) threads = 16;
+        // (from 2 batches on the pick runs on the pool: at 41 500 values -- an SVI step of the reference's default sizes --
+        // the logarithms and square roots are 170 of the call's 235 us on one thread)
+        const bool pooled = npairs >= 2 * BATCH;
+        if (pooled) WorkerPool::get().start(threads, worker);
         uint32_t w[4 * BATCH];
         int64_t cand = 0;
         while (npairs - cnt >= 64 && (size_t)(cand + BATCH) <= cap && batches.size() < batches.capacity()) {
@@ -206,8 +296,8 @@ int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, i
             cnt += acc;
         }
         closed.store(true, std::memory_order_release);
-        if (pool.empty()) worker();
-        for (auto &t : pool) t.join();
+        if (pooled) WorkerPool::get().wait();
+        else worker();
     }
     // the last pairs (fewer than 64, or all of a short request) one by one, as legacy_gauss does
     while (cnt < npairs) {

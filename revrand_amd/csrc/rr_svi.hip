@@ -49,16 +49,18 @@ struct SviChild {
 };
 
 struct SviArgs {
-    SviChild kid[SVI_MAXCHILD];
+    const SviChild *kid;  // the children's table in device memory (uniform loads; not in the kernel arguments, which would
+                          // be copied to registers for the dynamic index)
     int nkids, F, Fp, K, L, M, lik, n_lik, n_ls, ns, updater, y_f64, dsum;
     int64_t np, N;
     const void *y, *rowarg;
+    const double *lconst;  // per row: the f-independent part of loglike (log-factorial terms), or null
+    const double *bias;    // per step of this launch: Adam's 1 - beta1^t, 1 - beta2^t (sgd.py:322-323)
     double *z, *s1, *s2;
     const double *lower, *upper;
     const unsigned char *islog;
     double *pubcol, *pubrow, *pubsc;
     unsigned int *bar;
-    float *Ebuf;
     const float *E;
     const int *idx;
     double *objs, *norms;
@@ -69,6 +71,7 @@ struct SviArgs {
     // rr_glm_svi_starts
     const double *cand;
     double *out;
+    long long *prof;  // RR_SVI_PROF=1: workgroup 0's time per phase (100 MHz ticks), summed over the steps
 };
 
 __device__ __forceinline__ uint64_t svi_splitmix64(uint64_t x) {
@@ -115,6 +118,10 @@ __device__ __forceinline__ void svi_lik(int lik, double f, double y, double n, d
     }
 }
 
+typedef __attribute__((address_space(3))) double ldsd;   // LDS pointers keep their address space: ds_read / ds_write, never flat
+typedef __attribute__((address_space(3))) float ldsf;
+typedef __attribute__((address_space(3))) unsigned char ldsb;
+
 __device__ __forceinline__ double svi_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -122,7 +129,7 @@ __device__ __forceinline__ double svi_wave_sum(double v) {
 }
 
 // sum over the block, fixed order (the same bits in every workgroup that sums the same values); all threads get it
-__device__ __forceinline__ double svi_block_sum(double v, double *red) {
+__device__ __forceinline__ double svi_block_sum(double v, ldsd *red) {
     const int tid = threadIdx.x;
     v = svi_wave_sum(v);
     __syncthreads();
@@ -152,67 +159,91 @@ __device__ __forceinline__ double svi_xval(const SviChild &c, int64_t row, int i
     return c.x_f64 ? ((const double *)c.X)[row * c.ldx + i] : (double)((const float *)c.X)[row * c.ldx + i];
 }
 
+#define SVI_GREG 2  // gathered X entries a thread holds in registers between the loads and their use (M dsum <= 2 x 512)
+
 struct SviLds {
-    double *xm, *xC, *xs;           // x of all coordinates: (F, K) means, (F, K) covariances, the ns shared coordinates
-    double *zc, *s1c, *s2c;         // this workgroup's column (2 F: means then covariances), z space + updater state
-    double *zs, *s1s, *s2s;         // the shared coordinates' z and updater state (replicated in every workgroup)
-    double *Phi, *dfs, *EP, *Xb, *yb, *nb, *mk, *sk, *edm, *edc, *q, *logz, *alpha, *gls, *red, *misc;
+    ldsd *xm, *xC, *xs;             // x of all coordinates: (F, K) means, (F, K) covariances, the ns shared coordinates
+    ldsd *zc, *s1c, *s2c, *loc, *hic;  // this workgroup's column (2 F: means then covariances): z, updater state, bounds
+    ldsd *zs, *s1s, *s2s, *los, *his;  // the shared coordinates (replicated in every workgroup)
+    ldsd *Phi, *dfs, *Q, *Xb, *yb, *nb, *Dr, *mk, *sk, *edm, *edc, *q, *logz, *alpha, *gls, *psc, *red, *misc;
+    ldsf *Ef;                       // the draws of this component's samples (L, F)
+    ldsb *lg;                       // is_log of all np coordinates
 };
 
+static __host__ __device__ size_t svi_lds_layout(const SviArgs &a, size_t *off) {
+    // offsets in doubles; returns the total (the float / byte arrays are placed behind, rounded to doubles)
+    const size_t FK = (size_t)a.F * a.K, F = (size_t)a.F, ns = (size_t)a.ns, M = (size_t)a.M;
+    const size_t cnt[] = {FK, FK, ns, 2 * F, 2 * F, 2 * F, 2 * F, 2 * F, ns, ns, ns, ns, ns, M * (size_t)a.Fp, (size_t)a.L * M, M * F,
+                          M * (size_t)a.dsum, M, M, M, F, F, F, F, (size_t)a.K * a.K, (size_t)a.K, (size_t)a.K,
+                          (size_t)(a.n_ls > 0 ? a.n_ls : 1), (size_t)a.K * (a.n_ls + 4), (size_t)SVI_WAVES, 8,
+                          ((size_t)a.L * F * 4 + 7) / 8, ((size_t)a.np + 7) / 8};
+    size_t o = 0;
+    for (size_t i = 0; i < sizeof(cnt) / sizeof(cnt[0]); ++i) {
+        if (off) off[i] = o;
+        o += cnt[i];
+    }
+    return o;
+}
+
 __device__ __forceinline__ SviLds svi_carve(double *sm, const SviArgs &a) {
+    size_t off[40];
+    svi_lds_layout(a, off);
+    ldsd *b = (ldsd *)sm;
     SviLds s;
-    const int FK = a.F * a.K;
-    double *p = sm;
-    s.xm = p; p += FK;
-    s.xC = p; p += FK;
-    s.xs = p; p += a.ns;
-    s.zc = p; p += 2 * a.F;
-    s.s1c = p; p += 2 * a.F;
-    s.s2c = p; p += 2 * a.F;
-    s.zs = p; p += a.ns;
-    s.s1s = p; p += a.ns;
-    s.s2s = p; p += a.ns;
-    s.Phi = p; p += a.M * a.Fp;
-    s.dfs = p; p += a.L * a.M;
-    s.EP = p; p += a.M * a.F;
-    s.Xb = p; p += a.M * a.dsum;
-    s.yb = p; p += a.M;
-    s.nb = p; p += a.M;
-    s.mk = p; p += a.F;
-    s.sk = p; p += a.F;
-    s.edm = p; p += a.F;
-    s.edc = p; p += a.F;
-    s.q = p; p += a.K * a.K;
-    s.logz = p; p += a.K;
-    s.alpha = p; p += a.K;
-    s.gls = p; p += (a.n_ls > 0 ? a.n_ls : 1);
-    s.red = p; p += SVI_WAVES;
-    s.misc = p; p += 8;
+    int i = 0;
+    s.xm = b + off[i++]; s.xC = b + off[i++]; s.xs = b + off[i++];
+    s.zc = b + off[i++]; s.s1c = b + off[i++]; s.s2c = b + off[i++]; s.loc = b + off[i++]; s.hic = b + off[i++];
+    s.zs = b + off[i++]; s.s1s = b + off[i++]; s.s2s = b + off[i++]; s.los = b + off[i++]; s.his = b + off[i++];
+    s.Phi = b + off[i++]; s.dfs = b + off[i++]; s.Q = b + off[i++]; s.Xb = b + off[i++]; s.yb = b + off[i++]; s.nb = b + off[i++];
+    s.Dr = b + off[i++]; s.mk = b + off[i++]; s.sk = b + off[i++]; s.edm = b + off[i++]; s.edc = b + off[i++];
+    s.q = b + off[i++]; s.logz = b + off[i++]; s.alpha = b + off[i++]; s.gls = b + off[i++]; s.psc = b + off[i++];
+    s.red = b + off[i++]; s.misc = b + off[i++];
+    s.Ef = (ldsf *)(b + off[i++]);
+    s.lg = (ldsb *)(b + off[i++]);
     return s;
 }
 
-static size_t svi_lds_doubles(const SviArgs &a) {
-    const size_t FK = (size_t)a.F * a.K;
-    return 2 * FK + 4 * (size_t)a.ns + 6 * (size_t)a.F + (size_t)a.M * a.Fp + (size_t)a.L * a.M + (size_t)a.M * a.F +
-           (size_t)a.M * a.dsum + 2 * (size_t)a.M + 4 * (size_t)a.F + (size_t)a.K * a.K + 2 * (size_t)a.K +
-           (size_t)(a.n_ls > 0 ? a.n_ls : 1) + SVI_WAVES + 8;
-}
+static size_t svi_lds_doubles(const SviArgs &a) { return svi_lds_layout(a, nullptr); }
 
-// c: rows of the minibatch by index, targets, Phi (M, F) in float64, the batch's loglike constant -> misc[0]
-__device__ void svi_features(const SviArgs &a, const SviLds &s, const int *idx) {
-    const int tid = threadIdx.x, M = a.M;
-    for (int e = tid; e < M * a.dsum; e += SVI_THREADS) {
-        const int r = e / a.dsum, o = e % a.dsum;
-        int c = 0;
-        while (c + 1 < a.nkids && o >= a.kid[c + 1].xoff) ++c;
-        s.Xb[e] = svi_xval(a.kid[c], (int64_t)idx[r], o - a.kid[c].xoff);
+// the minibatch's rows of X (and targets) by index: loads issued now, values parked in registers until svi_features
+struct SviGather {
+    double x[SVI_GREG];
+    double y, n, lc;
+};
+
+__device__ __forceinline__ void svi_gather_issue(const SviArgs &a, const int *idx, SviGather &g) {
+    const int tid = threadIdx.x, M = a.M, tot = M * a.dsum;
+#pragma unroll
+    for (int u = 0; u < SVI_GREG; ++u) {
+        const int e = tid + u * SVI_THREADS;
+        g.x[u] = 0.0;
+        if (e < tot) {
+            const int r = e / a.dsum, o = e % a.dsum;
+            int c = 0;
+            while (c + 1 < a.nkids && o >= a.kid[c + 1].xoff) ++c;
+            g.x[u] = svi_xval(a.kid[c], (int64_t)idx[r], o - a.kid[c].xoff);
+        }
     }
+    g.y = g.n = g.lc = 0.0;
     if (tid < M) {
         const int64_t row = idx[tid];
-        const double yv = a.y_f64 ? ((const double *)a.y)[row] : (double)((const float *)a.y)[row];
-        const double nv = a.rowarg ? (a.y_f64 ? ((const double *)a.rowarg)[row] : (double)((const float *)a.rowarg)[row]) : 0.0;
-        s.yb[tid] = yv;
-        s.nb[tid] = nv;
+        if (a.lconst) g.lc = a.lconst[row];
+        g.y = a.y_f64 ? ((const double *)a.y)[row] : (double)((const float *)a.y)[row];
+        if (a.rowarg) g.n = a.y_f64 ? ((const double *)a.rowarg)[row] : (double)((const float *)a.rowarg)[row];
+    }
+}
+
+// c: Phi (M, F) in float64 from the gathered rows, the batch's loglike constant -> misc[0]
+__device__ __forceinline__ void svi_features(const SviArgs &a, const SviLds &s, const SviGather &g) {
+    const int tid = threadIdx.x, M = a.M, tot = M * a.dsum;
+#pragma unroll
+    for (int u = 0; u < SVI_GREG; ++u) {
+        const int e = tid + u * SVI_THREADS;
+        if (e < tot) s.Xb[e] = g.x[u];
+    }
+    if (tid < M) {
+        s.yb[tid] = g.y;
+        s.nb[tid] = g.n;
     }
     __syncthreads();
     for (int c = 0; c < a.nkids; ++c) {
@@ -224,7 +255,7 @@ __device__ void svi_features(const SviArgs &a, const SviLds &s, const int *idx) 
             }
         } else {
             const double scale = 1.0 / sqrt((double)k.n), inv2pi = 0.15915494309189533576888;
-            const double *ls = s.xs + (a.ns - a.n_ls) + k.ls0;
+            const ldsd *ls = s.xs + (a.ns - a.n_ls) + k.ls0;
             for (int e = tid; e < M * k.n; e += SVI_THREADS) {
                 const int r = e / k.n, j = e % k.n;
                 double t = 0.0;
@@ -238,31 +269,58 @@ __device__ void svi_features(const SviArgs &a, const SviLds &s, const int *idx) 
     }
     // the f-independent part of sum_r loglike per latent sample (likelihoods.py: the log-factorial terms; the Gaussian's
     // follows the variance)
-    double lc = 0.0;
-    if (tid < M) {
-        const double yv = s.yb[tid], nv = s.nb[tid];
-        if (a.lik == RR_LIK_POISSON_EXP || a.lik == RR_LIK_POISSON_SOFTPLUS) lc = -lgamma(yv + 1.0);
-        else if (a.lik == RR_LIK_BINOMIAL) lc = lgamma(nv + 1.0) - lgamma(yv + 1.0) - lgamma(nv - yv + 1.0);
-    }
+    double lc = tid < M ? g.lc : 0.0;
     lc = svi_block_sum(lc, s.red);
     if (tid == 0) s.misc[0] = lc;
     __syncthreads();
 }
 
-// e: fs of component k's L samples against the minibatch, df into dfs (L, M); returns (sum loglike terms, sum squared errors)
-__device__ void svi_pass1(const SviArgs &a, const SviLds &s, const float *E, double ivar, double &llsum, double &aux) {
-    const int tid = threadIdx.x, M = a.M, F = a.F;
+// d: the draws of samples [kl0, kl0 + L) into LDS: the caller's (E: (L, F) float32 in HBM) or the device generator's
+__device__ __forceinline__ void svi_draws(const SviArgs &a, const SviLds &s, const float *E, uint64_t stepkey, int kl0) {
+    const int tid = threadIdx.x, tot = a.L * a.F;
+    if (E) {
+        for (int o = tid; o < tot; o += SVI_THREADS) s.Ef[o] = E[o];
+    } else {
+        for (int o = tid; o < tot; o += SVI_THREADS) s.Ef[o] = svi_draw(stepkey, (uint64_t)kl0 * (uint64_t)a.F + (uint64_t)o);
+    }
+}
+
+typedef double svi_d4 __attribute__((ext_vector_type(4)));
+
+// e: fs = ws Phi^T of the L samples in s.Ef against the minibatch (ws = mk + sk e) on the f64 matrix cores -- one
+// v_mfma_f64_16x16x4 tile (16 samples x 16 rows) per wave and turn, A[i][k] = ws[l0 + i][j0 + k], B[k][c] = Phi[r0 + c][j0 + k]
+// (lane = i + 16 k for A, c + 16 k for B; D[row = k + 4 v][col = c], v < 4) -- then df into dfs (L, M) from the accumulators;
+// (sum loglike terms, sum squared errors).  (As scalar dot products out of LDS this pass is bound by LDS reads: 6 us of a step.)
+__device__ __forceinline__ void svi_pass1(const SviArgs &a, const SviLds &s, double ivar, double &llsum, double &aux) {
+    const int tid = threadIdx.x, M = a.M, F = a.F, L = a.L, wave = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int nrb = (L + 15) / 16, ncb = (M + 15) / 16;
     double ll_acc = 0.0;
-    for (int o = tid; o < a.L * M; o += SVI_THREADS) {
-        const int l = o / M, r = o % M;
-        const float *er = E + (size_t)l * F;
-        const double *ph = s.Phi + r * a.Fp;
-        double f = 0.0;
-        for (int j = 0; j < F; ++j) f = fma(fma(s.sk[j], (double)er[j], s.mk[j]), ph[j], f);
-        double df, ll;
-        svi_lik(a.lik, f, s.yb[r], s.nb[r], ivar, df, ll);
-        s.dfs[o] = df;
-        ll_acc += ll;
+    for (int tile = wave; tile < nrb * ncb; tile += SVI_WAVES) {
+        const int rb = tile / ncb, cb = tile % ncb;
+        const int l = rb * 16 + i, r = cb * 16 + i;
+        const bool lv = l < L, rv = r < M;
+        const ldsf *er = s.Ef + (lv ? l : 0) * F;
+        const ldsd *ph = s.Phi + (rv ? r : 0) * a.Fp;
+        svi_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int j0 = 0; j0 < F; j0 += 4) {
+            const int j = j0 + kk;
+            const bool jv = j < F;
+            const int jc = jv ? j : 0;
+            const double av = (lv && jv) ? fma(s.sk[jc], (double)er[jc], s.mk[jc]) : 0.0;
+            const double bv = (rv && jv) ? ph[jc] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int lo = rb * 16 + kk + 4 * v, ro = cb * 16 + i;
+            if (lo < L && ro < M) {
+                double df, ll;
+                svi_lik(a.lik, acc[v], s.yb[ro], s.nb[ro], ivar, df, ll);
+                s.dfs[lo * M + ro] = df;
+                ll_acc += ll;
+            }
+        }
     }
     const double tot = svi_block_sum(ll_acc, s.red);
     if (a.lik == RR_LIK_GAUSSIAN) {
@@ -271,6 +329,36 @@ __device__ void svi_pass1(const SviArgs &a, const SviLds &s, const float *E, dou
     } else {
         aux = 0.0;
         llsum = tot;
+    }
+}
+
+// f (first half): Q[r][j] = sum_l dfs[l][r] e[l][j] and D_r = sum_l dfs[l][r] (the column j = F of the same product, e = 1)
+// on the f64 matrix cores: A[i][k] = dfs[l0 + k][r0 + i], B[k][c] = e[l0 + k][j0 + c]
+__device__ __forceinline__ void svi_pass2(const SviArgs &a, const SviLds &s) {
+    const int tid = threadIdx.x, M = a.M, F = a.F, L = a.L, wave = tid >> 6, lane = tid & 63, i = lane & 15, kk = lane >> 4;
+    const int nrb = (M + 15) / 16, ncb = (F + 1 + 15) / 16;
+    for (int tile = wave; tile < nrb * ncb; tile += SVI_WAVES) {
+        const int rb = tile / ncb, cb = tile % ncb;
+        const int r = rb * 16 + i, j = cb * 16 + i;
+        const bool rv = r < M, jv = j < F;
+        svi_d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+        for (int l0 = 0; l0 < L; l0 += 4) {
+            const int l = l0 + kk;
+            const bool lv = l < L;
+            const int lc = lv ? l : 0;
+            const double av = (rv && lv) ? s.dfs[lc * M + r] : 0.0;
+            const double bv = lv ? (jv ? (double)s.Ef[lc * F + j] : (j == F ? 1.0 : 0.0)) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int ro = rb * 16 + kk + 4 * v, jo = cb * 16 + i;
+            if (ro < M) {
+                if (jo < F) s.Q[ro * F + jo] = acc[v];
+                else if (jo == F) s.Dr[ro] = acc[v];
+            }
+        }
     }
 }
 
@@ -287,8 +375,9 @@ __device__ __forceinline__ void svi_logz(const SviArgs &a, const SviLds &s) {
     __syncthreads();
 }
 
-// q[k][l] for l = l0, l0 + step, ...: one wave per l
-__device__ __forceinline__ void svi_qrow(const SviArgs &a, const SviLds &s, int k, double *out) {
+// q[k][l] for every l: one wave per l (out: LDS or HBM)
+template <typename P>
+__device__ __forceinline__ void svi_qrow(const SviArgs &a, const SviLds &s, int k, P out) {
     const int tid = threadIdx.x, K = a.K, F = a.F, wave = tid >> 6, lane = tid & 63;
     for (int l = wave; l < K; l += SVI_WAVES) {
         double acc = 0.0;
@@ -302,17 +391,29 @@ __device__ __forceinline__ void svi_qrow(const SviArgs &a, const SviLds &s, int 
     }
 }
 
-// -ELBO from the sums (glm.py:285-292); called by one thread
-__device__ __forceinline__ double svi_neg_elbo(const SviArgs &a, const SviLds &s, double ell_total, const double *Rs) {
-    const int K = a.K, F = a.F;
-    double logL = 0.0, quad = 0.0, lz = 0.0;
-    for (int c = 0; c < a.nkids; ++c) {
-        const double reg = s.xs[c];
-        logL += (double)a.kid[c].width * log(reg);
-        quad += Rs[c] / reg;
+// R_c = sum (m^2 + C) over child c's rows of (m, C) into s.edm[c]: one wave per child
+__device__ __forceinline__ void svi_child_sums(const SviArgs &a, const SviLds &s) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, K = a.K;
+    for (int c = wave; c < a.nkids; c += SVI_WAVES) {
+        double acc = 0.0;
+        const int lo = a.kid[c].col0 * K, hi = (a.kid[c].col0 + a.kid[c].width) * K;
+        for (int o = lo + lane; o < hi; o += 64) acc += s.xm[o] * s.xm[o] + s.xC[o];
+        acc = svi_wave_sum(acc);
+        if (lane == 0) s.edm[c] = acc;
     }
-    for (int k = 0; k < K; ++k) lz += s.logz[k];
-    const double elbo = (ell_total * a.bmag - 0.5 * F * K * 1.8378770664093453 - 0.5 * K * logL - 0.5 * quad - lz + log((double)K)) / K;
+}
+
+// -ELBO from the sums (glm.py:285-292) by the lanes of ONE wave (R_c in s.edm, log z in s.logz); every lane gets it
+__device__ __forceinline__ double svi_neg_elbo(const SviArgs &a, const SviLds &s, double ell_total, int lane) {
+    const int K = a.K, F = a.F;
+    double part = 0.0;
+    for (int c = lane; c < a.nkids; c += 64) {
+        const double reg = s.xs[c];
+        part += -0.5 * K * ((double)a.kid[c].width * log(reg)) - 0.5 * (s.edm[c] / reg);
+    }
+    for (int k = lane; k < K; k += 64) part -= s.logz[k];
+    part = svi_wave_sum(part);
+    const double elbo = (ell_total * a.bmag - 0.5 * F * K * 1.8378770664093453 + part + log((double)K)) / K;
     return -elbo;
 }
 
@@ -353,125 +454,132 @@ __device__ __forceinline__ double svi_update(const SviArgs &a, double zz, double
     return zn < lo ? lo : (zn > hi ? hi : zn);
 }
 
+#define SVI_MARK(i)                                                   \
+    do {                                                              \
+        if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {          \
+            const long long now_ = wall_clock64();                    \
+            a.prof[i] += now_ - tprev;                                \
+            tprev = now_;                                             \
+        }                                                             \
+    } while (0)
+
 __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const SviArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ double sm[];
+    long long tprev = a.prof ? wall_clock64() : 0;
     const SviLds s = svi_carve(sm, a);
     const int tid = threadIdx.x, k = blockIdx.x, K = a.K, F = a.F, M = a.M, L = a.L, ns = a.ns, nk = a.nkids;
+    const int wave = tid >> 6, lane = tid & 63;
     const int64_t fk = (int64_t)F * K;
     const int npub = a.n_ls + 4;
-    // ---- launch start: this workgroup's column and the shared coordinates, with their updater state
+    // ---- launch start: this workgroup's column and the shared coordinates, with their updater state and bounds
     for (int p = tid; p < 2 * F; p += SVI_THREADS) {
         const int64_t g = (p < F ? 0 : fk) + (int64_t)(p < F ? p : p - F) * K + k;
         s.zc[p] = a.z[g];
         s.s1c[p] = a.s1[g];
         s.s2c[p] = a.s2[g];
+        s.loc[p] = a.lower[g];
+        s.hic[p] = a.upper[g];
     }
     for (int p = tid; p < ns; p += SVI_THREADS) {
         s.zs[p] = a.z[2 * fk + p];
         s.s1s[p] = a.s1[2 * fk + p];
         s.s2s[p] = a.s2[2 * fk + p];
+        s.los[p] = a.lower[2 * fk + p];
+        s.his[p] = a.upper[2 * fk + p];
     }
+    for (int p = tid; p < (int)a.np; p += SVI_THREADS) s.lg[p] = a.islog[p];
+    SviGather gth;
+    svi_gather_issue(a, a.idx, gth);
     __syncthreads();
     for (int t = 0; t < a.steps; ++t) {
         const int par = t & 1;
         const int64_t gt = a.t0 + t;
+        SVI_MARK(0);
         // ---- a: x = from_log(z) of everything
         for (int p = tid; p < 2 * (int)fk; p += SVI_THREADS) {
             const int cov = p >= fk, q = cov ? p - (int)fk : p, f = q / K, j = q % K;
             double zv;
             if (j == k) zv = s.zc[cov * F + f];
             else zv = t == 0 ? a.z[p] : a.pubcol[((size_t)(1 - par) * K + j) * 2 * F + cov * F + f];
-            (cov ? s.xC : s.xm)[q] = a.islog[p] ? exp(zv) : zv;
+            (cov ? s.xC : s.xm)[q] = s.lg[p] ? exp(zv) : zv;
         }
-        for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = a.islog[2 * fk + p] ? exp(s.zs[p]) : s.zs[p];
+        for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = s.lg[2 * fk + p] ? exp(s.zs[p]) : s.zs[p];
         __syncthreads();
         for (int f = tid; f < F; f += SVI_THREADS) {
             s.mk[f] = s.xm[f * K + k];
             s.sk[f] = sqrt(s.xC[f * K + k]);
         }
+        SVI_MARK(1);
         // ---- b: row k of the mixture's cross terms, published
         svi_qrow(a, s, k, a.pubrow + ((size_t)par * K + k) * K);
         svi_arrive(a.bar + 0);
+        SVI_MARK(2);
         // ---- c: the minibatch
-        svi_features(a, s, a.idx + (size_t)t * M);
+        svi_features(a, s, gth);
+        if (t + 1 < a.steps) svi_gather_issue(a, a.idx + (size_t)(t + 1) * M, gth);  // the next step's rows: in flight from here
+        SVI_MARK(3);
         // ---- d: the draws of component k's samples
-        const float *E;
-        if (a.E) {
-            E = a.E + ((size_t)t * K * L + (size_t)k * L) * F;
-        } else {
-            float *Eb = a.Ebuf + (size_t)k * L * F;
-            const uint64_t stepkey = svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)t) * 0xD1B54A32D192ED03ull));
-            for (int o = tid; o < L * F; o += SVI_THREADS) Eb[o] = svi_draw(stepkey, (uint64_t)(k * L) * (uint64_t)F + (uint64_t)o);
-            __syncthreads();
-            E = Eb;
-        }
+        svi_draws(a, s, a.E ? a.E + ((size_t)t * K * L + (size_t)k * L) * F : nullptr,
+                  svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)t) * 0xD1B54A32D192ED03ull)), k * L);
+        __syncthreads();
+        SVI_MARK(4);
         // ---- e: fs, df, loglike
         const double ivar = a.n_lik ? 1.0 / s.xs[nk] : 0.0;
         double llsum, aux;
-        svi_pass1(a, s, E, ivar, llsum, aux);
+        svi_pass1(a, s, ivar, llsum, aux);
         __syncthreads();
-        // ---- f: Edws = dfs Phi summed over the samples -> Edm, EdC; this component's share of EdPhi
-        {
-            const int LG = 8;
-            for (int o0 = 0; o0 < F * LG; o0 += SVI_THREADS) {
-                const int o = o0 + tid, f = o / LG, lg = o % LG;
-                double am = 0.0, ac = 0.0;
-                if (f < F) {
-                    for (int l = lg; l < L; l += LG) {
-                        const double *d = s.dfs + l * M;
-                        double ed = 0.0;
-                        for (int r = 0; r < M; ++r) ed = fma(d[r], s.Phi[r * a.Fp + f], ed);
-                        am += ed;
-                        ac = fma(ed, (double)E[(size_t)l * F + f], ac);
-                    }
-                }
-                am += __shfl_xor(am, 1, 64); ac += __shfl_xor(ac, 1, 64);
-                am += __shfl_xor(am, 2, 64); ac += __shfl_xor(ac, 2, 64);
-                am += __shfl_xor(am, 4, 64); ac += __shfl_xor(ac, 4, 64);
-                if (f < F && lg == 0) {
-                    s.edm[f] = am / L;
-                    s.edc[f] = ac / (L * s.sk[f]);
-                }
+        SVI_MARK(5);
+        // ---- f: with D_r = sum_l dfs[l][r] and Q[r][j] = sum_l dfs[l][r] e[l][j] (the only sums over the samples needed):
+        //   Edm[j] = sum_r D_r Phi[r][j] / L                  (Edws = dfs Phi summed over l, glm.py:308-309)
+        //   EdC[j] = sum_r Q[r][j] Phi[r][j] / (L sk[j])      (sum_l Edws e / sqrt(C), glm.py:310)
+        //   EdPhi[r][j] = (mk[j] D_r + sk[j] Q[r][j]) / (L K) (this component's share of dfs^T ws / L / K, glm.py:311,237)
+        svi_pass2(a, s);
+        __syncthreads();
+        for (int j = tid; j < F; j += SVI_THREADS) {
+            double am = 0.0, ac = 0.0;
+            for (int r = 0; r < M; ++r) {
+                const double ph = s.Phi[r * a.Fp + j];
+                am = fma(s.Dr[r], ph, am);
+                ac = fma(s.Q[r * F + j], ph, ac);
             }
-            for (int o = tid; o < M * F; o += SVI_THREADS) {
-                const int r = o / F, f = o % F;
-                double acc = 0.0;
-                for (int l = 0; l < L; ++l) acc = fma(s.dfs[l * M + r], fma(s.sk[f], (double)E[(size_t)l * F + f], s.mk[f]), acc);
-                s.EP[o] = acc / ((double)L * K);
-            }
-            __syncthreads();
-            // -(EdPhi o dPhi_i).sum() of this component: W[i, :] . T[i, :] / l_i^2 with T = X^T (E_s o P_c - E_c o P_s); the
-            // isotropic parameter takes input dimension 0 only, as the reference does (basis_functions.py:896)
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int h = wave; h < a.n_ls; h += SVI_WAVES) {
-                int c = 0;
-                while (!(a.kid[c].kind == RR_SGD_CHILD_RFF && h >= a.kid[c].ls0 && h < a.kid[c].ls0 + a.kid[c].n_ls)) ++c;
-                const SviChild &kd = a.kid[c];
-                const int i = h - kd.ls0;
-                double acc = 0.0;
-                for (int o = lane; o < M * kd.n; o += 64) {
-                    const int r = o / kd.n, j = o % kd.n;
-                    const double *ph = s.Phi + r * a.Fp + kd.col0, *ep = s.EP + r * F + kd.col0;
-                    acc = fma(kd.W[(size_t)i * kd.n + j] * s.Xb[r * a.dsum + kd.xoff + i], ep[kd.n + j] * ph[j] - ep[j] * ph[kd.n + j], acc);
-                }
-                acc = svi_wave_sum(acc);
-                if (lane == 0) s.gls[h] = acc;
-            }
+            s.edm[j] = am / L;
+            s.edc[j] = ac / (L * s.sk[j]);
         }
+        // -(EdPhi o dPhi_i).sum() of this component: W[i, :] . T[i, :] / l_i^2 with T = X^T (E_s o P_c - E_c o P_s); the
+        // isotropic parameter takes input dimension 0 only, as the reference does (basis_functions.py:896)
+        for (int h = wave; h < a.n_ls; h += SVI_WAVES) {
+            int c = 0;
+            while (!(a.kid[c].kind == RR_SGD_CHILD_RFF && h >= a.kid[c].ls0 && h < a.kid[c].ls0 + a.kid[c].n_ls)) ++c;
+            const SviChild &kd = a.kid[c];
+            const int i = h - kd.ls0;
+            const double sc = 1.0 / ((double)L * K);
+            double acc = 0.0;
+            for (int o = lane; o < M * kd.n; o += 64) {
+                const int r = o / kd.n, j = o % kd.n, jc = kd.col0 + j, js = jc + kd.n;
+                const double epc = (s.mk[jc] * s.Dr[r] + s.sk[jc] * s.Q[r * F + jc]) * sc;
+                const double eps = (s.mk[js] * s.Dr[r] + s.sk[js] * s.Q[r * F + js]) * sc;
+                acc = fma(kd.W[(size_t)i * kd.n + j] * s.Xb[r * a.dsum + kd.xoff + i],
+                          eps * s.Phi[r * a.Fp + jc] - epc * s.Phi[r * a.Fp + js], acc);
+            }
+            acc = svi_wave_sum(acc);
+            if (lane == 0) s.gls[h] = acc;
+        }
+        SVI_MARK(6);
         // ---- g: the other components' rows of q
         svi_wait(a.bar + 0, (unsigned)(t + 1) * (unsigned)K);
         for (int o = tid; o < K * K; o += SVI_THREADS) s.q[o] = a.pubrow[(size_t)par * K * K + o];
         __syncthreads();
+        SVI_MARK(7);
         svi_logz(a, s);
         if (tid < K) {
             const double lN = -0.5 * ((double)F * 1.8378770664093453 + s.q[tid * K + k]);
             s.alpha[tid] = exp(lN - s.logz[k]) + exp(lN - s.logz[tid]);
         }
         __syncthreads();
+        SVI_MARK(8);
         // ---- h: column k's gradient and update
-        const double tt = (double)(gt + 1);
-        const double b1t = 1.0 - pow(a.up[1], tt), b2t = 1.0 - pow(a.up[2], tt);
+        const double b1t = a.bias[2 * t], b2t = a.bias[2 * t + 1];
         double n2 = 0.0;
         for (int p = tid; p < 2 * F; p += SVI_THREADS) {
             const int cov = p >= F, f = cov ? p - F : p;
@@ -489,10 +597,12 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
             double g;
             if (!cov) g = -((a.bmag * s.edm[f] - mkv / reg + mix) / K);
             else g = -((a.bmag * s.edc[f] - 1.0 / reg + mix) / (2 * K));
-            const int64_t gp = (cov ? fk : 0) + (int64_t)f * K + k;
-            if (a.islog[gp]) g *= cov ? Ck : mkv;
+            if (s.lg[(cov ? fk : 0) + (int64_t)f * K + k]) g *= cov ? Ck : mkv;
             n2 += g * g;
-            const double zn = svi_update(a, s.zc[p], g, a.lower[gp], a.upper[gp], s.s1c[p], s.s2c[p], b1t, b2t);
+            double s1 = s.s1c[p], s2 = s.s2c[p];
+            const double zn = svi_update(a, s.zc[p], g, s.loc[p], s.hic[p], s1, s2, b1t, b2t);
+            s.s1c[p] = s1;
+            s.s2c[p] = s2;
             s.zc[p] = zn;
             a.pubcol[((size_t)par * K + k) * 2 * F + p] = zn;
         }
@@ -507,56 +617,58 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
                 pb[a.n_ls + 3] = 0.0;
             }
         }
+        SVI_MARK(9);
         svi_arrive(a.bar + 1);
         svi_wait(a.bar + 1, (unsigned)(t + 1) * (unsigned)K);
+        SVI_MARK(10);
         // ---- i: the shared coordinates (every workgroup, identically) and the step's record
-        {
-            const double *pb = a.pubsc + (size_t)par * K * npub;
-            double g = 0.0;
-            // R_c = sum (m^2 + C) over child c's rows of (m, C): one wave per child (s.edm is free again; F >= children)
-            const int wave = tid >> 6, lane = tid & 63;
-            for (int c = wave; c < nk; c += SVI_WAVES) {
-                double acc = 0.0;
-                const int lo = a.kid[c].col0 * K, hi = (a.kid[c].col0 + a.kid[c].width) * K;
-                for (int o = lo + lane; o < hi; o += 64) acc += s.xm[o] * s.xm[o] + s.xC[o];
-                acc = svi_wave_sum(acc);
-                if (lane == 0) s.edm[c] = acc;
+        for (int o = tid; o < K * npub; o += SVI_THREADS) s.psc[o] = a.pubsc[(size_t)par * K * npub + o];
+        svi_child_sums(a, s);
+        __syncthreads();
+        double n2s = 0.0;
+        if (tid < ns) {
+            const int p = tid;
+            double g;
+            if (p < nk) {  // dreg of the child's slice (glm.py:265-268)
+                const double iL = 1.0 / s.xs[p];
+                g = -(0.5 * (s.edm[p] * (iL * iL) / K - (double)a.kid[p].width * iL));
+            } else if (p < nk + a.n_lik) {  // Gaussian variance (likelihoods.py:370-396)
+                const double iv = 1.0 / s.xs[p];
+                double sm2 = 0.0;
+                for (int j = 0; j < K; ++j) sm2 += 0.5 * (s.psc[j * npub + a.n_ls] * iv * iv - iv * (double)M * L) / L;
+                g = 0.0 - sm2 / K;
+            } else {
+                const int h = p - nk - a.n_lik;
+                double sm2 = 0.0;
+                for (int j = 0; j < K; ++j) sm2 += s.psc[j * npub + h];
+                const double l = s.xs[p];
+                g = sm2 / (1.0 * (l * l));
             }
-            __syncthreads();
-            double n2s = 0.0;
-            if (tid < ns) {
-                const int p = tid;
-                if (p < nk) {  // dreg of the child's slice (glm.py:265-268)
-                    const double iL = 1.0 / s.xs[p];
-                    g = -(0.5 * (s.edm[p] * (iL * iL) / K - (double)a.kid[p].width * iL));
-                } else if (p < nk + a.n_lik) {  // Gaussian variance (likelihoods.py:370-396)
-                    const double iv = 1.0 / s.xs[p];
-                    double sm2 = 0.0;
-                    for (int j = 0; j < K; ++j) sm2 += 0.5 * (pb[j * npub + a.n_ls] * iv * iv - iv * (double)M * L) / L;
-                    g = 0.0 - sm2 / K;
-                } else {
-                    const int h = p - nk - a.n_lik;
-                    double sm2 = 0.0;
-                    for (int j = 0; j < K; ++j) sm2 += pb[j * npub + h];
-                    const double l = s.xs[p];
-                    g = sm2 / (1.0 * (l * l));
-                }
-                if (a.islog[2 * fk + p]) g *= s.xs[p];
-                n2s = g * g;
-                s.zs[p] = svi_update(a, s.zs[p], g, a.lower[2 * fk + p], a.upper[2 * fk + p], s.s1s[p], s.s2s[p], b1t, b2t);
-            }
-            n2s = svi_block_sum(n2s, s.red);
-            if (k == 0 && tid == 0) {
-                double tot = n2s, ell = 0.0;
-                for (int j = 0; j < K; ++j) tot += pb[j * npub + a.n_ls + 2];
-                double llc = s.misc[0];
-                if (a.n_lik) llc = -0.5 * log(2.0 * 3.141592653589793 * s.xs[nk]) * (double)M;
-                for (int j = 0; j < K; ++j) ell += pb[j * npub + a.n_ls + 1] / L + llc;
-                a.norms[gt] = sqrt(tot);
-                a.objs[gt] = svi_neg_elbo(a, s, ell, s.edm);
-            }
-            __syncthreads();
+            if (s.lg[2 * fk + p]) g *= s.xs[p];
+            n2s = g * g;
+            double s1 = s.s1s[p], s2 = s.s2s[p];
+            s.zs[p] = svi_update(a, s.zs[p], g, s.los[p], s.his[p], s1, s2, b1t, b2t);
+            s.s1s[p] = s1;
+            s.s2s[p] = s2;
         }
+        n2s = svi_block_sum(n2s, s.red);
+        if (k == 0 && wave == 0) {  // the step's record: |g| (sgd.py:399) and -ELBO (glm.py:285-292), by one wave
+            double tot = 0.0, ell = 0.0;
+            for (int j = lane; j < K; j += 64) {
+                tot += s.psc[j * npub + a.n_ls + 2];
+                ell += s.psc[j * npub + a.n_ls + 1] / L;
+            }
+            tot = svi_wave_sum(tot) + n2s;
+            double llc = s.misc[0];
+            if (a.n_lik) llc = -0.5 * log(2.0 * 3.141592653589793 * s.xs[nk]) * (double)M;
+            ell = svi_wave_sum(ell) + llc * K;
+            const double obj = svi_neg_elbo(a, s, ell, lane);
+            if (lane == 0) {
+                a.norms[gt] = sqrt(tot);
+                a.objs[gt] = obj;
+            }
+        }
+        __syncthreads();
     }
     // ---- launch end: state back to HBM
     for (int p = tid; p < 2 * F; p += SVI_THREADS) {
@@ -580,15 +692,18 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_starts_kernel(const Sv
     extern __shared__ double sm[];
     const SviLds s = svi_carve(sm, a);
     const int tid = threadIdx.x, c = blockIdx.x, K = a.K, F = a.F, M = a.M, L = a.L, ns = a.ns, nk = a.nkids;
+    const int lane = tid & 63;
     const int64_t fk = (int64_t)F * K;
     const double *x = a.cand + (size_t)c * a.np;
+    SviGather gth;
+    svi_gather_issue(a, a.idx + (size_t)c * M, gth);
     for (int p = tid; p < (int)fk; p += SVI_THREADS) {
         s.xm[p] = x[p];
         s.xC[p] = x[fk + p];
     }
     for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = x[2 * fk + p];
     __syncthreads();
-    svi_features(a, s, a.idx + (size_t)c * M);
+    svi_features(a, s, gth);
     const double ivar = a.n_lik ? 1.0 / s.xs[nk] : 0.0;
     double ell = 0.0;
     const uint64_t stepkey = svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)c) * 0xD1B54A32D192ED03ull));
@@ -598,34 +713,21 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_starts_kernel(const Sv
             s.mk[f] = s.xm[f * K + k];
             s.sk[f] = sqrt(s.xC[f * K + k]);
         }
-        const float *E;
-        if (a.E) {
-            E = a.E + ((size_t)c * K * L + (size_t)k * L) * F;
-        } else {
-            float *Eb = a.Ebuf + (size_t)c * L * F;
-            for (int o = tid; o < L * F; o += SVI_THREADS) Eb[o] = svi_draw(stepkey, (uint64_t)(k * L) * (uint64_t)F + (uint64_t)o);
-            E = Eb;
-        }
+        svi_draws(a, s, a.E ? a.E + ((size_t)c * K * L + (size_t)k * L) * F : nullptr, stepkey, k * L);
         __syncthreads();
         double llsum, aux;
-        svi_pass1(a, s, E, ivar, llsum, aux);
+        svi_pass1(a, s, ivar, llsum, aux);
         ell += llsum / L;
     }
     for (int k = 0; k < K; ++k) svi_qrow(a, s, k, s.q + k * K);
-    const int wave = tid >> 6, lane = tid & 63;
-    for (int ch = wave; ch < nk; ch += SVI_WAVES) {
-        double acc = 0.0;
-        const int lo = a.kid[ch].col0 * K, hi = (a.kid[ch].col0 + a.kid[ch].width) * K;
-        for (int o = lo + lane; o < hi; o += 64) acc += s.xm[o] * s.xm[o] + s.xC[o];
-        acc = svi_wave_sum(acc);
-        if (lane == 0) s.edm[ch] = acc;
-    }
+    svi_child_sums(a, s);
     __syncthreads();
     svi_logz(a, s);
-    if (tid == 0) {
+    if (tid < 64) {
         double llc = s.misc[0];
         if (a.n_lik) llc = -0.5 * log(2.0 * 3.141592653589793 * s.xs[nk]) * (double)M;
-        a.out[c] = svi_neg_elbo(a, s, ell + llc * K, s.edm);
+        const double obj = svi_neg_elbo(a, s, ell + llc * K, lane);
+        if (lane == 0) a.out[c] = obj;
     }
 }
 
@@ -634,20 +736,27 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_starts_kernel(const Sv
 struct rr_glm_svi {
     rr_ctx *ctx = nullptr;
     SviArgs a;
+    SviChild hkid[SVI_MAXCHILD];
+    SviChild *dkid = nullptr;
+    double *dbias = nullptr;
+    size_t bias_cap = 0;
+    std::vector<double> hbias;
     std::vector<double *> dW;
     unsigned char *islog = nullptr;
     double *lower = nullptr, *upper = nullptr;
     int64_t maxiter = 0, t = 0;
     size_t lds_bytes = 0;
-    float *Ebuf_starts = nullptr;
-    size_t Ebuf_starts_count = 0;
     double *cand = nullptr, *out = nullptr;
     size_t cand_cap = 0;
+    long long *prof = nullptr;
 };
 
 static void svi_free(rr_glm_svi *o) {
-    void *q[] = {o->a.z, o->a.s1, o->a.s2, o->lower, o->upper, o->islog, o->a.pubcol, o->a.pubrow, o->a.pubsc, o->a.bar, o->a.Ebuf,
-                 o->a.objs, o->a.norms, o->Ebuf_starts, o->cand, o->out};
+    if (o->prof) (void)hipFree(o->prof);
+    if (o->dkid) (void)hipFree(o->dkid);
+    if (o->dbias) (void)hipFree(o->dbias);
+    void *q[] = {o->a.z, o->a.s1, o->a.s2, o->lower, o->upper, o->islog, o->a.pubcol, o->a.pubrow, o->a.pubsc, o->a.bar,
+                 o->a.objs, o->a.norms, o->cand, o->out};
     for (void *v : q)
         if (v) (void)hipFree(v);
     for (double *w : o->dW)
@@ -665,13 +774,14 @@ int rr_glm_svi_supported(int F, int K, int L, int M, int n_children, int dsum, i
     a.ns = n_children + 1 + n_ls;
     // the work one workgroup does per step stays small (this is the dispatch-bound regime, not a GEMM engine), and its
     // state fits the CU's LDS
-    if ((int64_t)L * M * F > (int64_t)1 << 20 || (int64_t)M * F > 8192) return 0;
+    if ((int64_t)L * M * F > (int64_t)1 << 20 || (int64_t)M * F > 8192 || (int64_t)M * dsum > SVI_GREG * SVI_THREADS) return 0;
+    a.np = 2 * (int64_t)F * K + a.ns;
     return svi_lds_doubles(a) * 8 <= 150 * 1024 ? 1 : 0;
 }
 
 int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *children, const void *const *dX, const int *x_dtype,
-                      const int64_t *ldx, int64_t N, const void *dy, const void *drowarg, int dtype, int K, int L, int M, int lik,
-                      int n_lik, const double *z0, const double *lower, const double *upper, const unsigned char *is_log,
+                      const int64_t *ldx, int64_t N, const void *dy, const void *drowarg, const double *dlconst, int dtype, int K, int L,
+                      int M, int lik, int n_lik, const double *z0, const double *lower, const double *upper, const unsigned char *is_log,
                       int updater, const double *upd_par, int64_t maxiter, double bmag, rr_glm_svi **out) {
     RR_REQUIRE(ctx != nullptr && children != nullptr && dX != nullptr && x_dtype != nullptr && ldx != nullptr && dy != nullptr &&
                z0 != nullptr && lower != nullptr && upper != nullptr && is_log != nullptr && upd_par != nullptr && out != nullptr,
@@ -693,7 +803,7 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
     int col = 0, nls = 0, xoff = 0;
     for (int s = 0; s < n_children; ++s) {
         const rr_glm_sgd_child &k = children[s];
-        SviChild &c = a.kid[s];
+        SviChild &c = o->hkid[s];
         c.kind = k.kind;
         c.col0 = col;
         c.ls0 = nls;
@@ -738,7 +848,7 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
     a.nkids = n_children; a.F = col; a.Fp = col | 1; a.K = K; a.L = L; a.M = M; a.lik = lik; a.n_lik = n_lik; a.n_ls = nls;
     a.ns = n_children + n_lik + nls; a.updater = updater; a.y_f64 = dtype == RR_F64; a.dsum = xoff; a.N = N;
     a.np = 2 * (int64_t)col * K + a.ns;
-    a.y = dy; a.rowarg = drowarg; a.bmag = bmag;
+    a.y = dy; a.rowarg = drowarg; a.lconst = dlconst; a.bmag = bmag;
     for (int i = 0; i < 4; ++i) a.up[i] = upd_par[i];
     if (!rr_glm_svi_supported(a.F, K, L, M, n_children, a.dsum, nls)) {
         svi_free(o);
@@ -751,6 +861,8 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
     const size_t nb = (size_t)a.np * 8;
     const int npub = nls + 4;
     hipError_t e = hipMalloc((void **)&a.z, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&o->dkid, sizeof(o->hkid));
+    if (e == hipSuccess) e = hipMemcpy(o->dkid, o->hkid, sizeof(o->hkid), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&a.s1, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&a.s2, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&o->lower, nb);
@@ -760,7 +872,6 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
     if (e == hipSuccess) e = hipMalloc((void **)&a.pubrow, (size_t)2 * K * K * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&a.pubsc, (size_t)2 * K * npub * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&a.bar, 64);
-    if (e == hipSuccess) e = hipMalloc((void **)&a.Ebuf, (size_t)K * L * a.F * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&a.objs, (size_t)maxiter * 8);
     if (e == hipSuccess) e = hipMalloc((void **)&a.norms, (size_t)maxiter * 8);
     if (e == hipSuccess) e = hipMemcpy(a.z, z0, nb, hipMemcpyHostToDevice);
@@ -780,7 +891,11 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
         rr_set_error("rr_glm_svi_create: %s", hipGetErrorString(e));
         return e == hipErrorOutOfMemory ? RR_ERR_OOM : RR_ERR_HIP;
     }
-    a.lower = o->lower; a.upper = o->upper; a.islog = o->islog;
+    a.lower = o->lower; a.upper = o->upper; a.islog = o->islog; a.kid = o->dkid;
+    if (getenv("RR_SVI_PROF")) {
+        if (hipMalloc((void **)&o->prof, 16 * sizeof(long long)) == hipSuccess) (void)hipMemset(o->prof, 0, 16 * sizeof(long long));
+        a.prof = o->prof;
+    }
     *out = o;
     return RR_OK;
 }
@@ -805,6 +920,23 @@ int rr_glm_svi_run(rr_glm_svi *o, int64_t steps, const int *d_idx, const float *
     RR_CHECK_HIP(hipSetDevice(c->device));
     SviArgs a = o->a;
     a.idx = d_idx; a.E = dE; a.seed = seed; a.key0 = key0; a.t0 = o->t; a.steps = (int)steps;
+    if (o->bias_cap < (size_t)steps) {
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        if (o->dbias) (void)hipFree(o->dbias);
+        o->dbias = nullptr;
+        o->bias_cap = 0;
+        RR_CHECK_HIP(hipMalloc((void **)&o->dbias, (size_t)steps * 16));
+        o->bias_cap = (size_t)steps;
+    }
+    RR_CHECK_HIP(hipStreamSynchronize(c->stream));  // (the previous launch reads dbias; hbias is reused)
+    o->hbias.resize((size_t)steps * 2);
+    for (int64_t t = 0; t < steps; ++t) {
+        const double tt = (double)(o->t + t + 1);
+        o->hbias[(size_t)2 * t] = 1.0 - pow(a.up[1], tt);
+        o->hbias[(size_t)2 * t + 1] = 1.0 - pow(a.up[2], tt);
+    }
+    RR_CHECK_HIP(hipMemcpyAsync(o->dbias, o->hbias.data(), (size_t)steps * 16, hipMemcpyHostToDevice, c->stream));
+    a.bias = o->dbias;
     RR_CHECK_HIP(hipMemsetAsync(a.bar, 0, 64, c->stream));
     hipLaunchKernelGGL(rr_glm_svi_steps_kernel, dim3((unsigned)a.K), dim3(SVI_THREADS), o->lds_bytes, c->stream, a);
     RR_CHECK_HIP(hipGetLastError());
@@ -830,18 +962,6 @@ int rr_glm_svi_starts(rr_glm_svi *o, int ncand, const int *d_idx, const double *
         RR_CHECK_HIP(hipMalloc((void **)&o->out, (size_t)ncand * 8));
         o->cand_cap = want;
     }
-    if (!dE) {
-        const size_t ec = (size_t)ncand * a.L * a.F;
-        if (o->Ebuf_starts_count < ec) {
-            RR_CHECK_HIP(hipStreamSynchronize(c->stream));
-            if (o->Ebuf_starts) (void)hipFree(o->Ebuf_starts);
-            o->Ebuf_starts = nullptr;
-            o->Ebuf_starts_count = 0;
-            RR_CHECK_HIP(hipMalloc((void **)&o->Ebuf_starts, ec * 4));
-            o->Ebuf_starts_count = ec;
-        }
-        a.Ebuf = o->Ebuf_starts;
-    }
     RR_CHECK_HIP(hipMemcpyAsync(o->cand, cand_host, want * 8, hipMemcpyHostToDevice, c->stream));
     a.idx = d_idx; a.E = dE; a.seed = seed; a.key0 = key0; a.cand = o->cand; a.out = o->out;
     hipLaunchKernelGGL(rr_glm_svi_starts_kernel, dim3((unsigned)ncand), dim3(SVI_THREADS), o->lds_bytes, c->stream, a);
@@ -860,6 +980,16 @@ int rr_glm_svi_read(rr_glm_svi *o, double *z, double *objs, double *norms, int64
     if (objs && o->t) RR_CHECK_HIP(hipMemcpy(objs, o->a.objs, (size_t)o->t * 8, hipMemcpyDeviceToHost));
     if (norms && o->t) RR_CHECK_HIP(hipMemcpy(norms, o->a.norms, (size_t)o->t * 8, hipMemcpyDeviceToHost));
     if (steps) *steps = o->t;
+    if (o->prof && o->t) {
+        long long h[16];
+        RR_CHECK_HIP(hipMemcpy(h, o->prof, sizeof h, hipMemcpyDeviceToHost));
+        static const char *nm[] = {"i(prev)+loop", "a x=from_log", "b qrow+arrive", "c features", "d draws", "e pass1", "f pass2", "g wait B1", "g read q", "g logz/alpha", "h update", "B2"};
+        fprintf(stderr, "rr_glm_svi phases (workgroup 0, us per step over %lld steps):", (long long)o->t);
+        const char *names[] = {"loop/i", "a", "b", "c", "d", "e", "f", "g-wait", "g-logz", "h", "B2"};
+        (void)nm;
+        for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.2f", names[i], 0.01 * (double)h[i] / (double)o->t);
+        fprintf(stderr, "\n");
+    }
     return RR_OK;
 }
 

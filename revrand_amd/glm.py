@@ -827,11 +827,21 @@ class _FusedLoop(object):
             lik = RR_LIK_GAUSSIAN
         else:
             lik = g.likelihood.device_spec(self.y[:1], [], [a[:1] for a in self.largs if len(a)])[0]
+        # per row, the part of loglike that does not depend on f (likelihoods.py:171-192, 456-481: the log-factorials)
+        from scipy.special import gammaln
+        from .likelihoods import RR_LIK_BINOMIAL, RR_LIK_POISSON_EXP, RR_LIK_POISSON_SOFTPLUS
+        lc = None
+        if lik in (RR_LIK_POISSON_EXP, RR_LIK_POISSON_SOFTPLUS):
+            lc = -gammaln(self.y + 1.0)
+        elif lik == RR_LIK_BINOMIAL:
+            n = np.asarray(self.largs[0], dtype=float)
+            lc = gammaln(n + 1.0) - gammaln(self.y + 1.0) - gammaln(n - self.y + 1.0)
+        self.dlc = dev.upload_vector(lc, np.float64) if lc is not None else None
         kids = [c + (kid.dX,) for c, kid in zip(self.children, feats._kids)]
         F = int(g.D_)
         self.np_ = 2 * F * g.K + len(kids) + self.n_lik + sum(c[2] for c in self.children if c[0] == "rff")
         hold = np.zeros(self.np_)
-        self.svi = _hip.FusedSvi(dev, kids, len(self.y), self.dy, self.dn, g.K, g.nsamples, self.M, lik, self.n_lik, hold,
+        self.svi = _hip.FusedSvi(dev, kids, len(self.y), self.dy, self.dn, self.dlc, g.K, g.nsamples, self.M, lik, self.n_lik, hold,
                                  np.full(self.np_, -np.inf), np.full(self.np_, np.inf), np.zeros(self.np_, dtype=np.uint8),
                                  _hip.UPDATER_IDS[kind], par, max(1, int(g.maxiter)), g.B_)
         self.F = F
@@ -978,7 +988,7 @@ class _FusedLoop(object):
         for b in self._bufs.values():
             b.free()
         self._bufs = {}
-        for name in ("dy", "dn"):
+        for name in ("dy", "dn", "dlc"):
             b = self.__dict__.pop(name, None)
             if b is not None:
                 b.free()
