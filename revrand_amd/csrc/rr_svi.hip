@@ -42,7 +42,7 @@
 namespace {
 
 struct SviChild {
-    int kind, col0, width, d, n, n_ls, ls0, onescol, x_f64, xoff;  // xoff: first entry of this child's columns in a gathered row
+    int kind, col0, width, d, n, n_ls, ls0, onescol, x_f64, xoff, woff;  // xoff: first entry of this child's columns in a gathered row; woff: of its W in the LDS copy
     const void *X;
     int64_t ldx;
     const double *W;  // RFF: raw (d, n) row-major on the device
@@ -51,7 +51,7 @@ struct SviChild {
 struct SviArgs {
     const SviChild *kid;  // the children's table in device memory (uniform loads; not in the kernel arguments, which would
                           // be copied to registers for the dynamic index)
-    int nkids, F, Fp, K, L, M, lik, n_lik, n_ls, ns, updater, y_f64, dsum;
+    int nkids, F, Fp, K, L, M, lik, n_lik, n_ls, ns, updater, y_f64, dsum, wtot;  // wtot: entries of all children's W
     int64_t np, N;
     const void *y, *rowarg;
     const double *lconst;  // per row: the f-independent part of loglike (log-factorial terms), or null
@@ -122,6 +122,16 @@ typedef __attribute__((address_space(3))) double ldsd;   // LDS pointers keep th
 typedef __attribute__((address_space(3))) float ldsf;
 typedef __attribute__((address_space(3))) unsigned char ldsb;
 
+// The workgroup barrier for data exchanged through LDS: orders LDS accesses only (s_waitcnt lgkmcnt(0) + s_barrier), so
+// global loads in flight -- the next step's minibatch rows, prefetched a step ahead -- are not waited for at every barrier
+// (__syncthreads() waits for vmcnt(0) as well: the prefetch's HBM latency then lands on whatever barrier comes next).
+// Nothing one wave of a workgroup writes to HBM is read back by another wave of the same workgroup.
+__device__ __forceinline__ void svi_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ double svi_wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -132,27 +142,31 @@ __device__ __forceinline__ double svi_wave_sum(double v) {
 __device__ __forceinline__ double svi_block_sum(double v, ldsd *red) {
     const int tid = threadIdx.x;
     v = svi_wave_sum(v);
-    __syncthreads();
+    svi_sync();
     if ((tid & 63) == 0) red[tid >> 6] = v;
-    __syncthreads();
+    svi_sync();
     double r = 0.0;
 #pragma unroll
     for (int w = 0; w < SVI_WAVES; ++w) r += red[w];
     return r;
 }
 
-__device__ __forceinline__ void svi_arrive(unsigned int *ctr) {
+// Device-scope barrier of the K workgroups, split in two.  ARRIVE: what this workgroup publishes is stored to HBM by the
+// lanes of wave 0 alone (the callers copy it out of LDS there), so wave 0's release fence -- L2 write-back, the expensive
+// part -- covers it; the other waves only reach the workgroup barrier in front.  WAIT: thread 0 spins on the counter with
+// acquire loads (the L1 / L2 invalidate that makes the peers' stores visible to this CU is a property of the CU, not of
+// the wave that issued it; no wave has loads of published data in flight across the workgroup barrier behind it).
+__device__ __forceinline__ void svi_arrive_wave0(unsigned int *ctr) {   // call from wave 0 only, after ITS stores
     __threadfence();
-    __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ void svi_wait(unsigned int *ctr, unsigned int target) {
     if (threadIdx.x == 0) {
         while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
     }
-    __syncthreads();
-    __threadfence();
+    svi_sync();
 }
 
 __device__ __forceinline__ double svi_xval(const SviChild &c, int64_t row, int i) {
@@ -165,7 +179,7 @@ struct SviLds {
     ldsd *xm, *xC, *xs;             // x of all coordinates: (F, K) means, (F, K) covariances, the ns shared coordinates
     ldsd *zc, *s1c, *s2c, *loc, *hic;  // this workgroup's column (2 F: means then covariances): z, updater state, bounds
     ldsd *zs, *s1s, *s2s, *los, *his;  // the shared coordinates (replicated in every workgroup)
-    ldsd *Phi, *dfs, *Q, *Xb, *yb, *nb, *Dr, *mk, *sk, *edm, *edc, *q, *logz, *alpha, *gls, *psc, *red, *misc;
+    ldsd *Phi, *dfs, *Q, *Xb, *yb, *nb, *Dr, *mk, *sk, *edm, *edc, *q, *logz, *alpha, *gls, *psc, *red, *misc, *Wl, *ils, *Rc, *stage;
     ldsf *Ef;                       // the draws of this component's samples (L, F)
     ldsb *lg;                       // is_log of all np coordinates
 };
@@ -176,6 +190,7 @@ static __host__ __device__ size_t svi_lds_layout(const SviArgs &a, size_t *off) 
     const size_t cnt[] = {FK, FK, ns, 2 * F, 2 * F, 2 * F, 2 * F, 2 * F, ns, ns, ns, ns, ns, M * (size_t)a.Fp, (size_t)a.L * M, M * F,
                           M * (size_t)a.dsum, M, M, M, F, F, F, F, (size_t)a.K * a.K, (size_t)a.K, (size_t)a.K,
                           (size_t)(a.n_ls > 0 ? a.n_ls : 1), (size_t)a.K * (a.n_ls + 4), (size_t)SVI_WAVES, 8,
+                          (size_t)a.wtot, (size_t)(a.n_ls > 0 ? a.n_ls : 1), (size_t)a.nkids, (size_t)(a.K + a.n_ls + 4),
                           ((size_t)a.L * F * 4 + 7) / 8, ((size_t)a.np + 7) / 8};
     size_t o = 0;
     for (size_t i = 0; i < sizeof(cnt) / sizeof(cnt[0]); ++i) {
@@ -198,6 +213,7 @@ __device__ __forceinline__ SviLds svi_carve(double *sm, const SviArgs &a) {
     s.Dr = b + off[i++]; s.mk = b + off[i++]; s.sk = b + off[i++]; s.edm = b + off[i++]; s.edc = b + off[i++];
     s.q = b + off[i++]; s.logz = b + off[i++]; s.alpha = b + off[i++]; s.gls = b + off[i++]; s.psc = b + off[i++];
     s.red = b + off[i++]; s.misc = b + off[i++];
+    s.Wl = b + off[i++]; s.ils = b + off[i++]; s.Rc = b + off[i++]; s.stage = b + off[i++];
     s.Ef = (ldsf *)(b + off[i++]);
     s.lg = (ldsb *)(b + off[i++]);
     return s;
@@ -245,7 +261,7 @@ __device__ __forceinline__ void svi_features(const SviArgs &a, const SviLds &s, 
         s.yb[tid] = g.y;
         s.nb[tid] = g.n;
     }
-    __syncthreads();
+    svi_sync();
     for (int c = 0; c < a.nkids; ++c) {
         const SviChild &k = a.kid[c];
         if (k.kind == RR_SGD_CHILD_LINEAR) {
@@ -254,12 +270,12 @@ __device__ __forceinline__ void svi_features(const SviArgs &a, const SviLds &s, 
                 s.Phi[r * a.Fp + k.col0 + j] = (k.onescol && j == 0) ? 1.0 : s.Xb[r * a.dsum + k.xoff + j - k.onescol];
             }
         } else {
-            const double scale = 1.0 / sqrt((double)k.n), inv2pi = 0.15915494309189533576888;
-            const ldsd *ls = s.xs + (a.ns - a.n_ls) + k.ls0;
+            const double scale = 1.0 / sqrt((double)k.n);
+            const ldsd *il = s.ils + k.ls0, *W = s.Wl + k.woff;
             for (int e = tid; e < M * k.n; e += SVI_THREADS) {
                 const int r = e / k.n, j = e % k.n;
                 double t = 0.0;
-                for (int i = 0; i < k.d; ++i) t = fma(s.Xb[r * a.dsum + k.xoff + i], k.W[(size_t)i * k.n + j] * (inv2pi / ls[k.n_ls == 1 ? 0 : i]), t);
+                for (int i = 0; i < k.d; ++i) t = fma(s.Xb[r * a.dsum + k.xoff + i], W[i * k.n + j] * il[k.n_ls == 1 ? 0 : i], t);
                 double sn, cs;
                 rr_sincos_rev_f64(t, sn, cs);
                 s.Phi[r * a.Fp + k.col0 + j] = cs * scale;
@@ -272,7 +288,7 @@ __device__ __forceinline__ void svi_features(const SviArgs &a, const SviLds &s, 
     double lc = tid < M ? g.lc : 0.0;
     lc = svi_block_sum(lc, s.red);
     if (tid == 0) s.misc[0] = lc;
-    __syncthreads();
+    svi_sync();
 }
 
 // d: the draws of samples [kl0, kl0 + L) into LDS: the caller's (E: (L, F) float32 in HBM) or the device generator's
@@ -302,14 +318,25 @@ __device__ __forceinline__ void svi_pass1(const SviArgs &a, const SviLds &s, dou
         const ldsf *er = s.Ef + (lv ? l : 0) * F;
         const ldsd *ph = s.Phi + (rv ? r : 0) * a.Fp;
         svi_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int j0 = 0; j0 < F; j0 += 4) {
-            const int j = j0 + kk;
-            const bool jv = j < F;
-            const int jc = jv ? j : 0;
-            const double av = (lv && jv) ? fma(s.sk[jc], (double)er[jc], s.mk[jc]) : 0.0;
-            const double bv = (rv && jv) ? ph[jc] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        for (int j0 = 0; j0 < F; j0 += 32) {   // eight k-steps per turn: ALL their LDS reads are issued before the first product
+            double sk8[8], mk8[8], ph8[8];
+            float e8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + 4 * u + kk, jc = j < F ? j : 0;
+                sk8[u] = s.sk[jc];
+                mk8[u] = s.mk[jc];
+                e8[u] = er[jc];
+                ph8[u] = ph[jc];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool jv = j0 + 4 * u + kk < F;
+                const double av = (lv && jv) ? fma(sk8[u], (double)e8[u], mk8[u]) : 0.0;
+                const double bv = (rv && jv) ? ph8[u] : 0.0;
+                if (j0 + 4 * u < F) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -342,14 +369,24 @@ __device__ __forceinline__ void svi_pass2(const SviArgs &a, const SviLds &s) {
         const int r = rb * 16 + i, j = cb * 16 + i;
         const bool rv = r < M, jv = j < F;
         svi_d4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-        for (int l0 = 0; l0 < L; l0 += 4) {
-            const int l = l0 + kk;
-            const bool lv = l < L;
-            const int lc = lv ? l : 0;
-            const double av = (rv && lv) ? s.dfs[lc * M + r] : 0.0;
-            const double bv = lv ? (jv ? (double)s.Ef[lc * F + j] : (j == F ? 1.0 : 0.0)) : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        const int rc = rv ? r : 0, jcl = jv ? j : 0;
+        for (int l0 = 0; l0 < L; l0 += 32) {
+            double d8[8];
+            float e8[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int l = l0 + 4 * u + kk, lc = l < L ? l : 0;
+                d8[u] = s.dfs[lc * M + rc];
+                e8[u] = s.Ef[lc * F + jcl];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool lv = l0 + 4 * u + kk < L;
+                const double av = (rv && lv) ? d8[u] : 0.0;
+                const double bv = lv ? (jv ? (double)e8[u] : (j == F ? 1.0 : 0.0)) : 0.0;
+                if (l0 + 4 * u < L) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -372,7 +409,7 @@ __device__ __forceinline__ void svi_logz(const SviArgs &a, const SviLds &s) {
         for (int j = 0; j < K; ++j) sm += exp(-0.5 * ((double)a.F * 1.8378770664093453 + s.q[j * K + tid]) - mx);
         s.logz[tid] = log(sm) + mx;
     }
-    __syncthreads();
+    svi_sync();
 }
 
 // q[k][l] for every l: one wave per l (out: LDS or HBM)
@@ -391,7 +428,7 @@ __device__ __forceinline__ void svi_qrow(const SviArgs &a, const SviLds &s, int 
     }
 }
 
-// R_c = sum (m^2 + C) over child c's rows of (m, C) into s.edm[c]: one wave per child
+// R_c = sum (m^2 + C) over child c's rows of (m, C) into s.Rc[c]: one wave per child
 __device__ __forceinline__ void svi_child_sums(const SviArgs &a, const SviLds &s) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, K = a.K;
     for (int c = wave; c < a.nkids; c += SVI_WAVES) {
@@ -399,17 +436,17 @@ __device__ __forceinline__ void svi_child_sums(const SviArgs &a, const SviLds &s
         const int lo = a.kid[c].col0 * K, hi = (a.kid[c].col0 + a.kid[c].width) * K;
         for (int o = lo + lane; o < hi; o += 64) acc += s.xm[o] * s.xm[o] + s.xC[o];
         acc = svi_wave_sum(acc);
-        if (lane == 0) s.edm[c] = acc;
+        if (lane == 0) s.Rc[c] = acc;
     }
 }
 
-// -ELBO from the sums (glm.py:285-292) by the lanes of ONE wave (R_c in s.edm, log z in s.logz); every lane gets it
+// -ELBO from the sums (glm.py:285-292) by the lanes of ONE wave (R_c in s.Rc, log z in s.logz); every lane gets it
 __device__ __forceinline__ double svi_neg_elbo(const SviArgs &a, const SviLds &s, double ell_total, int lane) {
     const int K = a.K, F = a.F;
     double part = 0.0;
     for (int c = lane; c < a.nkids; c += 64) {
         const double reg = s.xs[c];
-        part += -0.5 * K * ((double)a.kid[c].width * log(reg)) - 0.5 * (s.edm[c] / reg);
+        part += -0.5 * K * ((double)a.kid[c].width * log(reg)) - 0.5 * (s.Rc[c] / reg);
     }
     for (int k = lane; k < K; k += 64) part -= s.logz[k];
     part = svi_wave_sum(part);
@@ -454,19 +491,47 @@ __device__ __forceinline__ double svi_update(const SviArgs &a, double zz, double
     return zn < lo ? lo : (zn > hi ? hi : zn);
 }
 
+// RR_SVI_PROF=1: workgroup 0's thread 0 accumulates the 100 MHz clock per phase in REGISTERS (a read-modify-write of HBM per
+// mark would cost more than the phases it times, and its wait would cover the prefetched loads) and adds them to a.prof at
+// the end of the launch
 #define SVI_MARK(i)                                                   \
     do {                                                              \
         if (a.prof && blockIdx.x == 0 && threadIdx.x == 0) {          \
             const long long now_ = wall_clock64();                    \
-            a.prof[i] += now_ - tprev;                                \
+            pacc[i] += now_ - tprev;                                  \
             tprev = now_;                                             \
         }                                                             \
     } while (0)
+
+// a: x = from_log(z) of every coordinate into LDS -- this workgroup's column from its own z (LDS), the others' from `src`
+// (their owners' columns: (K, 2 F) as published, or the flat vector z of the launch's start) -- then what depends on x
+// alone: component k's means and standard deviations, 1 / (2 pi l) per length scale, R_c = sum (m^2 + C) per child.
+__device__ __forceinline__ void svi_form_x(const SviArgs &a, const SviLds &s, int k, const double *src, bool src_is_z) {
+    const int tid = threadIdx.x, K = a.K, F = a.F, ns = a.ns;
+    const int fk = F * K;
+    for (int p = tid; p < 2 * fk; p += SVI_THREADS) {
+        const int cov = p >= fk, q = cov ? p - fk : p, f = q / K, j = q % K;
+        double zv;
+        if (j == k) zv = s.zc[cov * F + f];
+        else zv = src_is_z ? src[p] : src[(size_t)j * 2 * F + cov * F + f];
+        (cov ? s.xC : s.xm)[q] = s.lg[p] ? exp(zv) : zv;
+    }
+    for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = s.lg[2 * fk + p] ? exp(s.zs[p]) : s.zs[p];
+    svi_sync();
+    for (int f = tid; f < F; f += SVI_THREADS) {
+        s.mk[f] = s.xm[f * K + k];
+        s.sk[f] = sqrt(s.xC[f * K + k]);
+    }
+    for (int h = tid; h < a.n_ls; h += SVI_THREADS) s.ils[h] = 0.15915494309189533576888 / s.xs[ns - a.n_ls + h];
+    svi_child_sums(a, s);   // -> s.Rc
+    svi_sync();
+}
 
 __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const SviArgs a) {
 #pragma clang fp contract(off)
     extern __shared__ double sm[];
     long long tprev = a.prof ? wall_clock64() : 0;
+    long long pacc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     const SviLds s = svi_carve(sm, a);
     const int tid = threadIdx.x, k = blockIdx.x, K = a.K, F = a.F, M = a.M, L = a.L, ns = a.ns, nk = a.nkids;
     const int wave = tid >> 6, lane = tid & 63;
@@ -489,53 +554,43 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
         s.his[p] = a.upper[2 * fk + p];
     }
     for (int p = tid; p < (int)a.np; p += SVI_THREADS) s.lg[p] = a.islog[p];
+    for (int c = 0; c < nk; ++c)
+        if (a.kid[c].kind == RR_SGD_CHILD_RFF)
+            for (int o = tid; o < a.kid[c].d * a.kid[c].n; o += SVI_THREADS) s.Wl[a.kid[c].woff + o] = a.kid[c].W[o];
     SviGather gth;
     svi_gather_issue(a, a.idx, gth);
-    __syncthreads();
+    svi_sync();
+    svi_form_x(a, s, k, a.z, true);
+    svi_draws(a, s, a.E ? a.E + (size_t)k * L * F : nullptr, svi_splitmix64(a.seed ^ (a.key0 * 0xD1B54A32D192ED03ull)), k * L);
+    svi_sync();
     for (int t = 0; t < a.steps; ++t) {
         const int par = t & 1;
         const int64_t gt = a.t0 + t;
         SVI_MARK(0);
-        // ---- a: x = from_log(z) of everything
-        for (int p = tid; p < 2 * (int)fk; p += SVI_THREADS) {
-            const int cov = p >= fk, q = cov ? p - (int)fk : p, f = q / K, j = q % K;
-            double zv;
-            if (j == k) zv = s.zc[cov * F + f];
-            else zv = t == 0 ? a.z[p] : a.pubcol[((size_t)(1 - par) * K + j) * 2 * F + cov * F + f];
-            (cov ? s.xC : s.xm)[q] = s.lg[p] ? exp(zv) : zv;
-        }
-        for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = s.lg[2 * fk + p] ? exp(s.zs[p]) : s.zs[p];
-        __syncthreads();
-        for (int f = tid; f < F; f += SVI_THREADS) {
-            s.mk[f] = s.xm[f * K + k];
-            s.sk[f] = sqrt(s.xC[f * K + k]);
+        // ---- b: row k of the mixture's cross terms, published
+        svi_qrow(a, s, k, s.stage);
+        svi_sync();
+        if (wave == 0) {
+            for (int l = lane; l < K; l += 64) a.pubrow[((size_t)par * K + k) * K + l] = s.stage[l];
+            svi_arrive_wave0(a.bar + 0);
         }
         SVI_MARK(1);
-        // ---- b: row k of the mixture's cross terms, published
-        svi_qrow(a, s, k, a.pubrow + ((size_t)par * K + k) * K);
-        svi_arrive(a.bar + 0);
-        SVI_MARK(2);
         // ---- c: the minibatch
         svi_features(a, s, gth);
         if (t + 1 < a.steps) svi_gather_issue(a, a.idx + (size_t)(t + 1) * M, gth);  // the next step's rows: in flight from here
-        SVI_MARK(3);
-        // ---- d: the draws of component k's samples
-        svi_draws(a, s, a.E ? a.E + ((size_t)t * K * L + (size_t)k * L) * F : nullptr,
-                  svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)t) * 0xD1B54A32D192ED03ull)), k * L);
-        __syncthreads();
-        SVI_MARK(4);
-        // ---- e: fs, df, loglike
+        SVI_MARK(2);
+        // ---- e: fs, df, loglike (the draws are in LDS since the previous step's barrier)
         const double ivar = a.n_lik ? 1.0 / s.xs[nk] : 0.0;
         double llsum, aux;
         svi_pass1(a, s, ivar, llsum, aux);
-        __syncthreads();
-        SVI_MARK(5);
+        svi_sync();
+        SVI_MARK(3);
         // ---- f: with D_r = sum_l dfs[l][r] and Q[r][j] = sum_l dfs[l][r] e[l][j] (the only sums over the samples needed):
         //   Edm[j] = sum_r D_r Phi[r][j] / L                  (Edws = dfs Phi summed over l, glm.py:308-309)
         //   EdC[j] = sum_r Q[r][j] Phi[r][j] / (L sk[j])      (sum_l Edws e / sqrt(C), glm.py:310)
         //   EdPhi[r][j] = (mk[j] D_r + sk[j] Q[r][j]) / (L K) (this component's share of dfs^T ws / L / K, glm.py:311,237)
         svi_pass2(a, s);
-        __syncthreads();
+        svi_sync();
         for (int j = tid; j < F; j += SVI_THREADS) {
             double am = 0.0, ac = 0.0;
             for (int r = 0; r < M; ++r) {
@@ -554,30 +609,30 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
             const SviChild &kd = a.kid[c];
             const int i = h - kd.ls0;
             const double sc = 1.0 / ((double)L * K);
+            const ldsd *W = s.Wl + kd.woff + i * kd.n;
             double acc = 0.0;
             for (int o = lane; o < M * kd.n; o += 64) {
                 const int r = o / kd.n, j = o % kd.n, jc = kd.col0 + j, js = jc + kd.n;
                 const double epc = (s.mk[jc] * s.Dr[r] + s.sk[jc] * s.Q[r * F + jc]) * sc;
                 const double eps = (s.mk[js] * s.Dr[r] + s.sk[js] * s.Q[r * F + js]) * sc;
-                acc = fma(kd.W[(size_t)i * kd.n + j] * s.Xb[r * a.dsum + kd.xoff + i],
-                          eps * s.Phi[r * a.Fp + jc] - epc * s.Phi[r * a.Fp + js], acc);
+                acc = fma(W[j] * s.Xb[r * a.dsum + kd.xoff + i], eps * s.Phi[r * a.Fp + jc] - epc * s.Phi[r * a.Fp + js], acc);
             }
             acc = svi_wave_sum(acc);
             if (lane == 0) s.gls[h] = acc;
         }
-        SVI_MARK(6);
+        SVI_MARK(4);
         // ---- g: the other components' rows of q
         svi_wait(a.bar + 0, (unsigned)(t + 1) * (unsigned)K);
         for (int o = tid; o < K * K; o += SVI_THREADS) s.q[o] = a.pubrow[(size_t)par * K * K + o];
-        __syncthreads();
-        SVI_MARK(7);
+        svi_sync();
+        SVI_MARK(5);
         svi_logz(a, s);
         if (tid < K) {
             const double lN = -0.5 * ((double)F * 1.8378770664093453 + s.q[tid * K + k]);
             s.alpha[tid] = exp(lN - s.logz[k]) + exp(lN - s.logz[tid]);
         }
-        __syncthreads();
-        SVI_MARK(8);
+        svi_sync();
+        SVI_MARK(6);
         // ---- h: column k's gradient and update
         const double b1t = a.bias[2 * t], b2t = a.bias[2 * t + 1];
         double n2 = 0.0;
@@ -604,34 +659,38 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
             s.s1c[p] = s1;
             s.s2c[p] = s2;
             s.zc[p] = zn;
-            a.pubcol[((size_t)par * K + k) * 2 * F + p] = zn;
         }
         n2 = svi_block_sum(n2, s.red);
-        {
-            double *pb = a.pubsc + ((size_t)par * K + k) * npub;
-            for (int h = tid; h < a.n_ls; h += SVI_THREADS) pb[h] = s.gls[h];
-            if (tid == 0) {
+        SVI_MARK(7);
+        if (wave == 0) {   // publish: the new column, this component's scalars
+            double *pc = a.pubcol + ((size_t)par * K + k) * 2 * F, *pb = a.pubsc + ((size_t)par * K + k) * npub;
+            for (int p = lane; p < 2 * F; p += 64) pc[p] = s.zc[p];
+            for (int h = lane; h < a.n_ls; h += 64) pb[h] = s.gls[h];
+            if (lane == 0) {
                 pb[a.n_ls] = aux;
                 pb[a.n_ls + 1] = llsum;
                 pb[a.n_ls + 2] = n2;
                 pb[a.n_ls + 3] = 0.0;
             }
+            svi_arrive_wave0(a.bar + 1);
         }
-        SVI_MARK(9);
-        svi_arrive(a.bar + 1);
+        // ---- d (of the NEXT step, while the slowest component gets to the barrier): its draws into LDS
+        if (t + 1 < a.steps)
+            svi_draws(a, s, a.E ? a.E + ((size_t)(t + 1) * K * L + (size_t)k * L) * F : nullptr,
+                      svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)(t + 1)) * 0xD1B54A32D192ED03ull)), k * L);
+        SVI_MARK(8);
         svi_wait(a.bar + 1, (unsigned)(t + 1) * (unsigned)K);
-        SVI_MARK(10);
+        SVI_MARK(9);
         // ---- i: the shared coordinates (every workgroup, identically) and the step's record
         for (int o = tid; o < K * npub; o += SVI_THREADS) s.psc[o] = a.pubsc[(size_t)par * K * npub + o];
-        svi_child_sums(a, s);
-        __syncthreads();
+        svi_sync();
         double n2s = 0.0;
         if (tid < ns) {
             const int p = tid;
             double g;
             if (p < nk) {  // dreg of the child's slice (glm.py:265-268)
                 const double iL = 1.0 / s.xs[p];
-                g = -(0.5 * (s.edm[p] * (iL * iL) / K - (double)a.kid[p].width * iL));
+                g = -(0.5 * (s.Rc[p] * (iL * iL) / K - (double)a.kid[p].width * iL));
             } else if (p < nk + a.n_lik) {  // Gaussian variance (likelihoods.py:370-396)
                 const double iv = 1.0 / s.xs[p];
                 double sm2 = 0.0;
@@ -668,8 +727,13 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
                 a.objs[gt] = obj;
             }
         }
-        __syncthreads();
+        svi_sync();
+        SVI_MARK(10);
+        // ---- a (of the next step): x = from_log(z) of everything
+        if (t + 1 < a.steps) svi_form_x(a, s, k, a.pubcol + (size_t)par * K * 2 * F, false);
     }
+    if (a.prof && k == 0 && tid == 0)
+        for (int i = 0; i < 11; ++i) a.prof[i] += pacc[i];
     // ---- launch end: state back to HBM
     for (int p = tid; p < 2 * F; p += SVI_THREADS) {
         const int64_t g = (p < F ? 0 : fk) + (int64_t)(p < F ? p : p - F) * K + k;
@@ -702,26 +766,30 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_starts_kernel(const Sv
         s.xC[p] = x[fk + p];
     }
     for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = x[2 * fk + p];
-    __syncthreads();
+    for (int ch = 0; ch < nk; ++ch)
+        if (a.kid[ch].kind == RR_SGD_CHILD_RFF)
+            for (int o = tid; o < a.kid[ch].d * a.kid[ch].n; o += SVI_THREADS) s.Wl[a.kid[ch].woff + o] = a.kid[ch].W[o];
+    for (int h = tid; h < a.n_ls; h += SVI_THREADS) s.ils[h] = 0.15915494309189533576888 / x[2 * fk + ns - a.n_ls + h];
+    svi_sync();
     svi_features(a, s, gth);
     const double ivar = a.n_lik ? 1.0 / s.xs[nk] : 0.0;
     double ell = 0.0;
     const uint64_t stepkey = svi_splitmix64(a.seed ^ ((a.key0 + (uint64_t)c) * 0xD1B54A32D192ED03ull));
     for (int k = 0; k < K; ++k) {
-        __syncthreads();
+        svi_sync();
         for (int f = tid; f < F; f += SVI_THREADS) {
             s.mk[f] = s.xm[f * K + k];
             s.sk[f] = sqrt(s.xC[f * K + k]);
         }
         svi_draws(a, s, a.E ? a.E + ((size_t)c * K * L + (size_t)k * L) * F : nullptr, stepkey, k * L);
-        __syncthreads();
+        svi_sync();
         double llsum, aux;
         svi_pass1(a, s, ivar, llsum, aux);
         ell += llsum / L;
     }
     for (int k = 0; k < K; ++k) svi_qrow(a, s, k, s.q + k * K);
     svi_child_sums(a, s);
-    __syncthreads();
+    svi_sync();
     svi_logz(a, s);
     if (tid < 64) {
         double llc = s.misc[0];
@@ -776,6 +844,7 @@ int rr_glm_svi_supported(int F, int K, int L, int M, int n_children, int dsum, i
     // state fits the CU's LDS
     if ((int64_t)L * M * F > (int64_t)1 << 20 || (int64_t)M * F > 8192 || (int64_t)M * dsum > SVI_GREG * SVI_THREADS) return 0;
     a.np = 2 * (int64_t)F * K + a.ns;
+    a.wtot = dsum * (F / 2 + 1);  // (an upper bound of sum d_c n_c: the children's frequency matrices, kept in LDS)
     return svi_lds_doubles(a) * 8 <= 150 * 1024 ? 1 : 0;
 }
 
@@ -800,7 +869,7 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
     o->ctx = ctx;
     SviArgs &a = o->a;
     memset(&a, 0, sizeof a);
-    int col = 0, nls = 0, xoff = 0;
+    int col = 0, nls = 0, xoff = 0, woff = 0;
     for (int s = 0; s < n_children; ++s) {
         const rr_glm_sgd_child &k = children[s];
         SviChild &c = o->hkid[s];
@@ -808,6 +877,7 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
         c.col0 = col;
         c.ls0 = nls;
         c.xoff = xoff;
+        c.woff = woff;
         c.X = dX[s];
         c.ldx = ldx[s];
         c.x_f64 = x_dtype[s] == RR_F64;
@@ -844,9 +914,10 @@ int rr_glm_svi_create(rr_ctx *ctx, int n_children, const rr_glm_sgd_child *child
         col += c.width;
         nls += c.n_ls;
         xoff += c.d;
+        if (c.kind == RR_SGD_CHILD_RFF) woff += c.d * c.n;
     }
     a.nkids = n_children; a.F = col; a.Fp = col | 1; a.K = K; a.L = L; a.M = M; a.lik = lik; a.n_lik = n_lik; a.n_ls = nls;
-    a.ns = n_children + n_lik + nls; a.updater = updater; a.y_f64 = dtype == RR_F64; a.dsum = xoff; a.N = N;
+    a.ns = n_children + n_lik + nls; a.updater = updater; a.y_f64 = dtype == RR_F64; a.dsum = xoff; a.N = N; a.wtot = woff;
     a.np = 2 * (int64_t)col * K + a.ns;
     a.y = dy; a.rowarg = drowarg; a.lconst = dlconst; a.bmag = bmag;
     for (int i = 0; i < 4; ++i) a.up[i] = upd_par[i];
@@ -985,7 +1056,7 @@ int rr_glm_svi_read(rr_glm_svi *o, double *z, double *objs, double *norms, int64
         RR_CHECK_HIP(hipMemcpy(h, o->prof, sizeof h, hipMemcpyDeviceToHost));
         static const char *nm[] = {"i(prev)+loop", "a x=from_log", "b qrow+arrive", "c features", "d draws", "e pass1", "f pass2", "g wait B1", "g read q", "g logz/alpha", "h update", "B2"};
         fprintf(stderr, "rr_glm_svi phases (workgroup 0, us per step over %lld steps):", (long long)o->t);
-        const char *names[] = {"loop/i", "a", "b", "c", "d", "e", "f", "g-wait", "g-logz", "h", "B2"};
+        const char *names[] = {"a(form x)", "b(q row)", "c(features)", "e(pass1)", "f(pass2)", "g(wait B1)", "g(logz)", "h(update)", "publish+draws", "wait B2", "i(shared)"};
         (void)nm;
         for (int i = 0; i < 11; ++i) fprintf(stderr, " %s=%.2f", names[i], 0.01 * (double)h[i] / (double)o->t);
         fprintf(stderr, "\n");
