@@ -342,19 +342,26 @@ def config_c2(dev, _hip, args):
 
 
 def config_f64(dev, _hip, args):
-    """The headline shape in the reference's own arithmetic (float64 features, f64 MFMA Gram)."""
-    d, n, N = 32, 2048, 500_000
+    """The headline shape in the reference's own arithmetic (float64 features, f64 MFMA Gram) -- at the metric's N = 10M when
+    the run is the full-size one (--rows >= 10M: every row of BASELINE's metric through float64, 2 timed passes of ~2.5 s),
+    else on 500 000 rows."""
+    d, n = 32, 2048
+    N = 10_000_000 if args.rows >= 10_000_000 else min(500_000, max(args.rows, 4096))
     F = 2 * n
     W = np.random.RandomState(42).randn(d, n)
     wvec = np.random.RandomState(1).randn(d).astype(np.float32)
     basis = _hip.RffHandle(W, compute="f64")
-    X, y = gen_chunk(78, N, d, wvec)
-    X64, y64 = X.astype(np.float64), y.astype(np.float64)
+    CH = 1_000_000
+    X64, y64 = np.empty((N, d), dtype=np.float64), np.empty(N, dtype=np.float64)
+    for c in range((N + CH - 1) // CH):   # (the headline's own chunk streams when N is the headline's)
+        r0, r1 = c * CH, min(N, (c + 1) * CH)
+        Xc, yc = gen_chunk(c if N >= 10_000_000 else 78, r1 - r0, d, wvec)
+        X64[r0:r1], y64[r0:r1] = Xc, yc
     dX, dy = basis.upload(X64), dev.upload_vector(y64)
     step, kms, p, acc = _gram_step(dev, _hip, basis, dX, dy, F)
     step()
     kms.clear()
-    ms = _timed(dev, step, 3)
+    ms = _timed(dev, step, 2 if N >= 10_000_000 else 3)
     syrk = float(np.mean([k[1] + k[2] for k in kms]))
     feat = float(np.mean([k[0] for k in kms]))
     G = dev.download(acc, (F, F), np.float64)
@@ -364,7 +371,7 @@ def config_f64(dev, _hip, args):
                   _gram_slice_parity(dev, _hip, basis, dX, dy, acc, p, F, X64, y64, W, 4096, np.float64), 1e-10)
     for b in (dX, dy, acc):
         b.free()
-    return {"workload": "RandomRBF F=4096 D=32 N=500k float64 end to end: features + f64 MFMA Gram", "rows": N,
+    return {"workload": "RandomRBF F=4096 D=32 N=%d float64 end to end: features + f64 MFMA Gram" % N, "rows": N,
             "ms": ms, "value": N / (ms * 1e-3), "unit": "rows/s", "dtype": "f64",
             "_launches_per_pass": kms[0][3], "_rows_per_launch": N // kms[0][3],
             "parity": {"gram_4096_rows": perr, "trace": trace_err},

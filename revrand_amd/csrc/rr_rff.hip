@@ -1318,6 +1318,96 @@ rr_syrk_f32_diag16_kernel(const SyrkArgs p) {
     syrk_diag16_dispatch<KB>(p, lds, blockIdx.x);
 }
 
+// ---------------------------------------------------------------------------------------
+// Small feature counts (F <= 1024: BASELINE config 1 is F = 512, the reference's SARCOS model nbases = 512): 128 x 128 tiles.
+// On the 256 x 256 tiles above F = 512 is ONE off-diagonal tile and two diagonal ones: however the rows are split, every
+// workgroup pays the big tile's prologue and a 64k-entry atomic epilogue, and the three tiles never fill 256 CUs
+// (profiles/r05_c1_latency: 240 + 148 us for 2.6 GFLOP = 17 us of matrix-core time).  Here every upper 128 x 128 tile x
+// K-split is a workgroup of 4 waves (64 x 64 per wave: 2 x 2 v_mfma_f32_32x32x2f32 accumulators), k-blocks of 32 rows
+// through registers into a double-buffered LDS tile [32][A 128 | B 128]; diagonal tiles compute the whole block and keep
+// gr <= gc; the rider column (Phi^T y, column F) and the deterministic slabs go through rr_syrk_out as in the big kernels.
+// ---------------------------------------------------------------------------------------
+constexpr int GS_TC = 128, GS_KB = 32, GS_LD = 2 * GS_TC, GS_THREADS = 256;
+
+__global__ void __launch_bounds__(GS_THREADS, 2)
+rr_syrk_f32_small_kernel(const SyrkArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2][GS_KB * GS_LD];  // 2 x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int nb = (int)(p.ldp / GS_TC);
+    const int64_t ks = blockIdx.x / p.ntiles;
+    int t = (int)(blockIdx.x % p.ntiles), ta = 0;
+    while (t >= nb - ta) {  // upper tiles row by row: (ta, tb), tb >= ta
+        t -= nb - ta;
+        ++ta;
+    }
+    const int tb = ta + t;
+    const int64_t ca = (int64_t)ta * GS_TC, cb = (int64_t)tb * GS_TC;
+    const int64_t r0 = ks * p.rows_per_split;
+    int64_t r1 = r0 + p.rows_per_split;
+    if (r1 > p.rows) r1 = p.rows;
+    const int nkb = (int)((r1 - r0 + GS_KB - 1) / GS_KB);   // (rows % 32 == 0: whole k-blocks)
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // this thread's part of a k-block: rows lr + 8 u (u < 4), float4 number lc of the A side and of the B side
+    const int lr = tid >> 5, lc = tid & 31;
+    float4 ra[4], rb[4];
+    auto gload = [&](int kb) {
+        const float *base = p.P + (r0 + (int64_t)kb * GS_KB + lr) * p.ldp;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ra[u] = *(const float4 *)(base + (int64_t)8 * u * p.ldp + ca + 4 * lc);
+            rb[u] = *(const float4 *)(base + (int64_t)8 * u * p.ldp + cb + 4 * lc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *(float4 *)&lds[buf][(lr + 8 * u) * GS_LD + 4 * lc] = ra[u];
+            *(float4 *)&lds[buf][(lr + 8 * u) * GS_LD + GS_TC + 4 * lc] = rb[u];
+        }
+    };
+    if (nkb > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int i32 = lane & 31, kk = lane >> 5;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < nkb) gload(kb + 1);   // in flight under this block's products
+        const float *L = lds[cur];
+#pragma unroll
+        for (int k2 = 0; k2 < GS_KB; k2 += 2) {
+            const float *row = L + (k2 + kk) * GS_LD;
+            const float a0 = row[wr * 64 + i32], a1 = row[wr * 64 + 32 + i32];
+            const float b0 = row[GS_TC + wc * 64 + i32], b1 = row[GS_TC + wc * 64 + 32 + i32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kb + 1 < nkb) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // C/D of the 32x32 forms: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t gc = cb + wc * 64 + 32 * j + i32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (gr <= gc) rr_syrk_out(p, ks, gr, gc, acc[i][j][e]);
+            }
+        }
+}
+
 // Experiment of round 4 (RR_SYRK_MERGE_DIAG=1): ONE launch for the whole Gram -- the off-diagonal tiles'
 // workgroups first, the diagonal tiles' (their own K-splits, their own code path) behind them in the same grid.
 __global__ void __launch_bounds__(GR_THREADS, 2)
@@ -2467,6 +2557,33 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         return rr_launch_syrk_bf16(c, c->gram_engine, P, nullptr, rows, ldp, F, dG, mid);
     }
     RR_REQUIRE(bcol == nullptr || F < ldp, "gram: no pad column for the rider");
+    // small feature counts over few rows: 128 x 128 tiles (rr_syrk_f32_small_kernel); RR_SYRK_SMALL=0: never (A/B runs)
+    static const bool small_off = getenv("RR_SYRK_SMALL") != nullptr && atoi(getenv("RR_SYRK_SMALL")) == 0;
+    if (!small_off && ldp <= 1024 && rows <= 262144 && rows % GS_KB == 0 && !getenv("RR_GRAM_ABLATE")) {
+        const int nbs = (int)(ldp / GS_TC), nt = nbs * (nbs + 1) / 2;
+        // K-splits: enough workgroups for every CU (two fit one), at least 128 rows and at most 32768 each
+        int64_t ns = std::max<int64_t>((2 * c->num_cu + nt - 1) / nt, (rows + 32767) / 32768);
+        ns = std::min<int64_t>(ns, std::max<int64_t>(rows / 128, 1));
+        const int64_t rps_s = ((rows + ns - 1) / ns + GS_KB - 1) / GS_KB * GS_KB;
+        ns = (rows + rps_s - 1) / rps_s;
+        SyrkArgs a;
+        a.P = P; a.rows = rows; a.ldp = ldp; a.F = F; a.nb = nbs; a.ntiles = nt; a.rows_per_split = rps_s; a.G = dG;
+        a.bcol = bcol; a.tile_map = nullptr; a.offdiag_only = 0; a.ablate = 0;
+        if (c->deterministic) {
+            void *slabs = nullptr;
+            int rc = rr_det_scratch(c, (size_t)ns * (size_t)ldp * (size_t)ldp * sizeof(float), &slabs);
+            if (rc != RR_OK) return rc;
+            a.part = (float *)slabs;
+            a.part_stride = ldp * ldp;
+        }
+        hipLaunchKernelGGL(rr_syrk_f32_small_kernel, dim3((unsigned)(ns * nt)), dim3(GS_THREADS), 0, c->stream, a);
+        if (mid) RR_CHECK_HIP(hipEventRecord(mid, c->stream));
+        if (a.part)
+            hipLaunchKernelGGL(rr_syrk_det_reduce_kernel<float>, dim3((unsigned)((F + 1 + 255) / 256), (unsigned)F), dim3(256), 0,
+                               c->stream, a.part, a.part_stride, ldp, F, (int)ns, dG, bcol);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
     const int nb_all = (int)(ldp / GR_TC);
     const int od = (nb_all >= 2 && !getenv("RR_SYRK_NO_DIAG_KERNEL")) ? 1 : 0;  // diagonal tiles in their own kernel
     // ragged last block (<= 192 valid columns): its off-diagonal tiles go to rr_syrk_f32_ragged_kernel, and the main

@@ -68,11 +68,14 @@ def structured_minimizer(minimizer):
     ``(objective, nested_gradients)`` when jac is True.  ``result.x`` / ``result.jac`` are
     returned in the same nested structure (decorators.py:24-130).
     """
-    def new_minimizer(fun, parameters, jac=True, args=(), nstarts=0, random_state=None, **kwargs):
+    def new_minimizer(fun, parameters, jac=True, args=(), nstarts=0, random_state=None, start_values=None, **kwargs):
         shapes = shapes_of(parameters, shape=lambda p: p.shape)
-        x0 = flatten_values(_map(lambda p: p.rvs(random_state), parameters))
+        if start_values is not None:   # (not in the reference: restart from given values, no draws -- StandardLinearModel's retry)
+            x0 = flatten_values(start_values)
+        else:
+            x0 = flatten_values(_map(lambda p: p.rvs(random_state), parameters))
         bounds = _flat_bounds(parameters)
-        if nstarts > 0:
+        if nstarts > 0 and start_values is None:
             x0 = _random_start(fun, parameters, jac, args, nstarts, random_state)
 
         def flat_fun(x, *fargs):

@@ -41,6 +41,13 @@ _NO_FINITE_CHECK = {("ensure_all_finite" if "ensure_all_finite" in _inspect.sign
                      else "force_all_finite"): False}
 
 
+def _scale_nested(g, s):
+    """Every leaf of a nested gradient structure times s."""
+    if isinstance(g, (list, tuple)):
+        return [_scale_nested(u, s) for u in g]
+    return np.asarray(g, dtype=float) * s if np.ndim(g) else float(g) * s
+
+
 class StandardLinearModel(BaseEstimator, RegressorMixin):
     """Bayesian linear regression on a basis; hyper-parameters by L-BFGS-B on the ELBO.
 
@@ -100,7 +107,14 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         self.obj_ = -np.inf
         params = [self.var, self.basis.regularizer, self.basis.params]
         nmin = structured_minimizer(logtrick_minimizer(minimize))
-        elbo = partial(StandardLinearModel._elbo, self, X, y)
+        inner = partial(StandardLinearModel._elbo, self, X, y)
+
+        def elbo(*values):   # (notes the first point evaluated WITH a gradient: the optimiser's start, after the random starts)
+            if elbo.first_point is None:
+                from .utils import flatten_values
+                elbo.first_point = np.asarray(flatten_values(list(values)), dtype=float)
+            return inner(*values)
+        elbo.first_point = None
         elbo.objective_only = partial(StandardLinearModel._elbo_objective, self, X, y)  # used by the random starts
         # a single random-feature basis keeps (X, y) on the GPU for the whole optimisation
         self._state = self._make_state(X, y)
@@ -112,6 +126,7 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             res = nmin(elbo, params, method="L-BFGS-B", jac=True, tol=self.tol,
                        options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_,
                        nstarts=self.nstarts)
+            res = self._retry_stalled_start(res, nmin, elbo, params)
             if self._state is not None and getattr(self._state, "best_on_device", False):
                 self.covariance_ = self._state.best_covariance()
             if self.distributed and not self._ranks_bit_identical(getattr(self._state, "best_on_device", False)):
@@ -129,6 +144,39 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
         log.info("Done! ELBO = {}, var = {}, reg = {}, hypers = {}, message = {}."
                  .format(-res["fun"], self.var_, self.regularizer_, self.hypers_, res.message))
         return self
+
+    def _retry_stalled_start(self, res, nmin, elbo, params):
+        """L-BFGS-B's first trial point is x0 - g (log space for Positive parameters): with |g| in the hundreds that is
+        var = 1e-93 and an objective of 1e94, from which its line search interpolates to a step that rounds to ZERO -- it then
+        reports "convergence" at the start point after no iteration (scipy: REL_REDUCTION_OF_F <= FACTR*EPSMCH), or walks
+        on, depending on the last bits of that absurd value (seen with float32 statistics: two kernels agreeing to 2e-8
+        sent the same fit either way; the reference's float64 run is subject to the same chance).  A fit that made NO
+        iteration from a point that is not stationary is retried ONCE from the same point with objective and gradient
+        scaled by 1 / max|g|: the first trial step is then of unit length.  Fits that iterate are untouched."""
+        from .utils import flatten_values
+        first = getattr(elbo, "first_point", None)   # (the wrapper below notes where the optimiser started)
+        moved = first is None or not np.array_equal(np.asarray(flatten_values(list(res.x)), dtype=float), first)
+        if getattr(res, "nit", 2) > 1 or moved or self.maxiter < 1 or not np.isfinite(res["fun"]):
+            return res
+        g0 = np.abs(np.asarray(flatten_values(list(res.jac)), dtype=float)) if "jac" in res else np.zeros(1)
+        gmax = float(g0.max()) if g0.size else 0.0
+        if not np.isfinite(gmax) or gmax <= 10.0:
+            return res
+        scale = 1.0 / gmax
+
+        def scaled(*a, **k):
+            f, g = elbo(*a, **k)
+            return f * scale, _scale_nested(g, scale)
+        log.info("No iteration from a non-stationary start (max |gradient| = %g): retrying with a scaled objective", gmax)
+        obj_keep = self.obj_
+        res2 = nmin(scaled, params, method="L-BFGS-B", jac=True, tol=self.tol,
+                    options={"maxiter": self.maxiter, "maxcor": 100}, random_state=self.random_, nstarts=0,
+                    start_values=list(res.x))
+        if res2["fun"] / scale < res["fun"]:
+            res2["fun"] = res2["fun"] / scale
+            return res2
+        self.obj_ = obj_keep
+        return res
 
     def _make_state(self, X, y):
         """(X, y) resident on the device for the whole optimisation, when the basis supports it."""

@@ -11,7 +11,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-ROUND=${ROUND:-r05}
+ROUND=${ROUND:-r06}
 OUT=gpurun_out/prof_$ROUND
 mkdir -p $OUT
 STAGES="${*:-headline elbo c3 ffelbo}"
@@ -39,6 +39,7 @@ c4)       kt c4_kt $S --configs c4 ;;
 c5)       kt c5_kt $S --configs c5 ;;
 c1)       kt c1_kt $S --configs c1 ;;
 c4gm)     kt c4gm_kt $S --configs c4gm ;;
+c5small)  kt c5small_kt $S --configs c5small ;;
 sp)       timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/sp_kt -o kt -- python bench.py --gpus 2 --single-process --steps 3 --warmup 1 --rows 4000000 --dist-rows 1000000 --no-parity-check --full-json $OUT/sp_kt.full.json > $OUT/sp_kt.json 2> $OUT/sp_kt.err ;;
 sq)
   pmc headline_sq "$SQ" --rows 2000000 --steps 1 --warmup 0 --configs none
