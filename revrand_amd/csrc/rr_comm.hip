@@ -260,6 +260,7 @@ int rr_comm_init_rank(rr_ctx *ctx, int rank, int world, const void *id, rr_comm 
     ncclUniqueId u;
     memcpy(&u, id, sizeof(u));
     ncclComm_t comm = nullptr;
+    (void)hipGetLastError();  // (see rr_comm_init_all)
     RR_CHECK_NCCL(g_rccl.CommInitRank(&comm, world, u, rank));
     rr_comm *c = new rr_comm();
     c->ctx = ctx;
@@ -561,6 +562,8 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
         if (rc != RR_OK) return rc;
         std::vector<int> devs((size_t)n);
         for (int i = 0; i < n; ++i) devs[(size_t)i] = ctxs[i]->device;
+        (void)hipGetLastError();  // (RCCL reads the runtime's last-error record: one left by an earlier, handled failure of
+                                  // this process -- a refused allocation, a peer link already enabled -- is not its business)
         const ncclResult_t r = g_rccl.CommInitAll(nc.data(), n, devs.data());
         if (r != ncclSuccess) {
             if (!was_auto) {

@@ -14,6 +14,7 @@
 // rounds twice as it does there.  RandomState's stream is frozen by NumPy's compatibility policy (NEP 19), so one
 // restatement serves every NumPy the reference runs on; tests/test_host_logic.py compares against the installed one
 // (values, cached-value parity, interleaving with other draws, final state).
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -51,6 +52,12 @@ struct Mt {
         }
     }
     __attribute__((always_inline)) void gen() {  // (inlined into mt_fill's clones: the AVX2 build of the refill)
+        twist();
+        pos = 0;
+        temper_from(0);
+    }
+    // the refill alone: key <- the next 624 state words (tempering is the consumer's: mt_fill writes it straight to its output)
+    __attribute__((always_inline)) void twist() {
         uint32_t y;
         int i;
         for (i = 0; i < MT_N - MT_M; i++) {
@@ -63,8 +70,6 @@ struct Mt {
         }
         y = (key[MT_N - 1] & 0x80000000u) | (key[0] & 0x7fffffffu);
         key[MT_N - 1] = key[MT_M - 1] ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908b0dfu);
-        pos = 0;
-        temper_from(0);
     }
     inline uint32_t next() {
         if (__builtin_expect(pos == MT_N, 0)) gen();
@@ -88,7 +93,24 @@ constexpr int64_t BATCH = 2048;  // candidates per hand-over
 // n tempered words of the stream into w
 RR_HOST_CLONES void mt_fill(Mt &mt, uint32_t *w, int64_t n) {
     while (n > 0) {
-        if (mt.pos == MT_N) mt.gen();
+        if (mt.pos == MT_N) {
+            if (n >= MT_N) {  // a whole refill goes out: tempered from the state straight into w (buf is not touched -- nor
+                              // read before the next gen(): pos stays at MT_N)
+                mt.twist();
+                for (int i = 0; i < MT_N; ++i) {
+                    uint32_t y = mt.key[i];
+                    y ^= (y >> 11);
+                    y ^= (y << 7) & 0x9d2c5680u;
+                    y ^= (y << 15) & 0xefc60000u;
+                    y ^= (y >> 18);
+                    w[i] = y;
+                }
+                w += MT_N;
+                n -= MT_N;
+                continue;
+            }
+            mt.gen();
+        }
         int64_t c = MT_N - mt.pos;
         if (c > n) c = n;
         for (int64_t i = 0; i < c; ++i) w[i] = mt.buf[mt.pos + i];
@@ -228,6 +250,119 @@ class WorkerPool {
     std::atomic<int64_t> gen_{0};
 };
 
+// Large requests, pipelined (round 6).  Until round 5 the calling thread drew the words AND formed the candidates AND counted
+// the accepted ones (1.5-2 ns per word plus 4 ns per candidate: 160 of the 235 us of a 41 500-value call on the GPU box's
+// host); only the logarithms ran elsewhere.  Now the calling thread does nothing but run the generator: it fills batch j's
+// 8192 words (a snapshot of the generator's state in front of every batch) and moves on; a worker takes batch j through
+//   1. candidates + accept flags + the count a_j of accepted pairs          (needs the words only)
+//   2. pair0[j + 1] = pair0[j] + a_j, as soon as pair0[j] is known          (a chain of additions across the workers)
+//   3. sqrt(-2 log(r2) / r2) (x2, x1) of its accepted pairs into out[2 (pair0[j] + i)]
+// The stream must be consumed up to EXACTLY the candidate that yields pair number npairs - 1: the worker that finds it says
+// which batch and which candidate; the calling thread -- which by then has run a few batches ahead -- goes back to that
+// batch's snapshot and advances the generator by the words the batch really used.  Values, order and final state are
+// those of the one-by-one loop (tests/test_host_logic.py against the installed NumPy).
+struct MtSnap {
+    uint32_t key[MT_N];
+    int pos;
+};
+
+template <typename T>
+int legacy_randn_pipelined(Mt &mt, T *o, int64_t nout, int64_t npairs, int threads, double *gauss_last) {
+    const int64_t expect = (int64_t)((double)npairs / 0.78) + 4 * BATCH;          // candidates, with room
+    const int64_t maxb = std::max<int64_t>((2 * npairs + BATCH) / BATCH + 2, expect / BATCH + 2);
+    struct Scratch {
+        std::vector<uint32_t> W;
+        std::vector<MtSnap> snaps;
+        std::vector<double> x1, x2;
+        std::vector<unsigned char> ok;
+    };
+    static thread_local Scratch sc;
+    try {
+        if ((int64_t)sc.snaps.size() < maxb) {
+            sc.W.resize((size_t)maxb * 4 * BATCH);
+            sc.snaps.resize((size_t)maxb);
+            sc.x1.resize((size_t)maxb * BATCH);
+            sc.x2.resize((size_t)maxb * BATCH);
+            sc.ok.resize((size_t)maxb * BATCH);
+        }
+    } catch (const std::bad_alloc &) {
+        rr_set_error("rr_legacy_randn: out of host memory");
+        return RR_ERR_OOM;
+    }
+    uint32_t *const W = sc.W.data();
+    double *const X1 = sc.x1.data(), *const X2 = sc.x2.data();
+    unsigned char *const OK = sc.ok.data();
+    std::vector<std::atomic<int64_t>> pair0((size_t)maxb + 1);
+    for (auto &v : pair0) v.store(-1, std::memory_order_relaxed);
+    pair0[0].store(0, std::memory_order_relaxed);
+    std::atomic<int64_t> ready(0), claim(0), phase1(0);
+    std::atomic<bool> closed(false), done(false);
+    int64_t final_batch = -1, final_cand = -1;
+    auto worker = [&]() {
+        for (;;) {
+            const int64_t j = claim.fetch_add(1);
+            while (ready.load(std::memory_order_acquire) <= j) {
+                if (done.load(std::memory_order_acquire) || closed.load(std::memory_order_acquire)) {
+                    if (ready.load(std::memory_order_acquire) <= j) return;
+                }
+                std::this_thread::yield();
+            }
+            double *x1 = X1 + j * BATCH, *x2 = X2 + j * BATCH;
+            unsigned char *ok = OK + j * BATCH;
+            const int64_t a = candidates(W + j * 4 * BATCH, BATCH, x1, x2, ok);
+            phase1.fetch_add(1, std::memory_order_release);
+            int64_t p0;
+            while ((p0 = pair0[(size_t)j].load(std::memory_order_acquire)) < 0) {
+                if (done.load(std::memory_order_acquire)) return;   // (a batch behind the last one needed)
+                std::this_thread::yield();
+            }
+            pair0[(size_t)j + 1].store(p0 + a, std::memory_order_release);
+            if (p0 >= npairs) {
+                done.store(true, std::memory_order_release);
+                return;
+            }
+            const int64_t need = npairs - p0;
+            int64_t i = 0;
+            for (int64_t q = 0; q < BATCH; ++q) {
+                if (!ok[q]) continue;
+                emit_pair<T>(x1[q], x2[q], p0 + i, o, nout, gauss_last);
+                if (++i == need) {   // the last pair of the request: the stream ends behind this candidate
+                    final_batch = j;
+                    final_cand = q;
+                    done.store(true, std::memory_order_release);
+                    return;
+                }
+            }
+        }
+    };
+    if (threads < 1) threads = 1;
+    if (threads > 16) threads = 16;
+    WorkerPool &pool = WorkerPool::get();
+    pool.start(threads, worker);
+    int64_t j = 0;
+    while (!done.load(std::memory_order_acquire) && j < maxb) {
+        // (not more than a few dozen batches ahead of the candidates: what is drawn beyond the end is drawn for nothing)
+        while (j - phase1.load(std::memory_order_acquire) > 8 * threads + 8 && !done.load(std::memory_order_acquire)) std::this_thread::yield();
+        memcpy(sc.snaps[(size_t)j].key, mt.key, sizeof(mt.key));
+        sc.snaps[(size_t)j].pos = mt.pos;
+        mt_fill(mt, W + j * 4 * BATCH, 4 * BATCH);
+        ++j;
+        ready.store(j, std::memory_order_release);
+    }
+    closed.store(true, std::memory_order_release);
+    pool.wait();
+    if (final_batch < 0) {
+        rr_set_error("rr_legacy_randn: the candidate buffer ran out (%lld batches for %lld pairs)", (long long)maxb, (long long)npairs);
+        return RR_ERR_INVALID;
+    }
+    // back to the state in front of the last batch needed, then the words it really used
+    memcpy(mt.key, sc.snaps[(size_t)final_batch].key, sizeof(mt.key));
+    mt.pos = sc.snaps[(size_t)final_batch].pos;
+    mt.temper_from(mt.pos);
+    mt_fill(mt, W, 4 * (final_cand + 1));
+    return RR_OK;
+}
+
 // The stream is consumed candidate by candidate (four words each) until `npairs` are accepted -- not one word more, or the
 // generator's state would differ from NumPy's afterwards.  A batch of c candidates yields at most c pairs, so batches of
 // min(pairs still missing, BATCH) candidates can never overshoot; the last < 64 pairs go one by one.  The calling thread
@@ -248,7 +383,12 @@ int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, i
     T *o = out + done;
     double gauss_last = 0.0;
     int64_t cnt = 0;  // accepted pairs so far
-    if (npairs >= 64) {
+    static const bool no_pipe = getenv("RR_RANDN_PIPELINE") != nullptr && atoi(getenv("RR_RANDN_PIPELINE")) == 0;  // A/B runs
+    if (npairs >= 4 * BATCH && !no_pipe) {
+        const int rc = legacy_randn_pipelined<T>(mt, o, nout, npairs, threads, &gauss_last);
+        if (rc != RR_OK) return rc;
+        cnt = npairs;
+    } else if (npairs >= 64) {
         // room for twice the pairs in candidates (78.5 % are accepted); should a stream ever need more, the rest goes one by one
         const size_t cap = (size_t)(2 * npairs + BATCH);
         static thread_local CandBuf scratch;
