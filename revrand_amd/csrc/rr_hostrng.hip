@@ -250,7 +250,7 @@ class WorkerPool {
     std::atomic<int64_t> gen_{0};
 };
 
-// Large requests, pipelined (round 6).  Until round 5 the calling thread drew the words AND formed the candidates AND counted
+// Large requests, pipelined (round 6; opt-in, see legacy_randn).  Until round 5 the calling thread drew the words AND formed the candidates AND counted
 // the accepted ones (1.5-2 ns per word plus 4 ns per candidate: 160 of the 235 us of a 41 500-value call on the GPU box's
 // host); only the logarithms ran elsewhere.  Now the calling thread does nothing but run the generator: it fills batch j's
 // 8192 words (a snapshot of the generator's state in front of every batch) and moves on; a worker takes batch j through
@@ -383,8 +383,11 @@ int legacy_randn(Mt &mt, int32_t *has_gauss, double *gauss, T *out, int64_t n, i
     T *o = out + done;
     double gauss_last = 0.0;
     int64_t cnt = 0;  // accepted pairs so far
-    static const bool no_pipe = getenv("RR_RANDN_PIPELINE") != nullptr && atoi(getenv("RR_RANDN_PIPELINE")) == 0;  // A/B runs
-    if (npairs >= 4 * BATCH && !no_pipe) {
+    // RR_RANDN_PIPELINE=1 (A/B runs): the pipelined form above.  Measured on the GPU box's host at 41 500 values and not
+    // adopted: 146 us against 125 us for the batches below on the pool (the generator itself, ~1.2 ns per word on that
+    // host, is the bound either way, and the pipeline's extra hand-overs cost more than the candidate loop it moves away)
+    static const bool pipe = getenv("RR_RANDN_PIPELINE") != nullptr && atoi(getenv("RR_RANDN_PIPELINE")) != 0;
+    if (npairs >= 4 * BATCH && pipe) {
         const int rc = legacy_randn_pipelined<T>(mt, o, nout, npairs, threads, &gauss_last);
         if (rc != RR_OK) return rc;
         cnt = npairs;

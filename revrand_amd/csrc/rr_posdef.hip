@@ -528,17 +528,325 @@ rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict_
     }
 }
 
+// =============================================================================================
+// The posterior at SMALL feature counts (F <= 1024; round 6) as ONE cooperative kernel -- opt-in, see rr_posterior_dev.
+// BASELINE config 1 (F = 512), the reference's SARCOS model (nbases = 512) and everything below sit where the panel
+// pipeline above is nothing but dependent launches: 8 diagonal-block kernels + ~35 one-tile f64 products + their gaps
+// = 1.2 ms of kernel time for 0.13 GFLOP (profiles/r06_c1_latency) -- `_elbo`'s critical path at config 1.  Here 32
+// workgroups walk through the same algebra inside one launch, separated by device-scope barriers (as rr_svi.hip):
+//   assemble  A = G / var + diag(iL) (lower triangle, identity on the padding)
+//   per 64-column panel p:  S1 workgroup 0 factors the diagonal block in LDS (A_pp = L_pp L_pp^T, unblocked)
+//                           S2 block rows below: A_ip <- A_ip L_pp^-T (forward substitution, a thread per row)
+//                           S3 trailing tiles:   A_ik -= A_ip A_kp^T
+//   T_i = L_ii^-1 (workgroup i, a thread per column); M = L^-1 block column slabs (64 x 16, no barrier inside:
+//   M_ip = -T_i sum_{k=p}^{i-1} L_ik M_kp);  C = M^T M tile by tile, written to both triangles.
+// 3 P + 4 barriers for P = F / 64 panels; the flops (F^3) are nothing -- plain float64 FMAs out of LDS.
+// m, diag C, sum(G o C) follow in rr_posterior_rows_kernel as before; a pivot that is not positive leaves a
+// negative entry in the factor's diagonal and the host reports RR_ERR_NOT_POSDEF exactly as the pipeline does.
+// =============================================================================================
+constexpr int PS_NB = 64, PS_WG = 32, PS_T = 256, PS_LD = PS_NB + 1;
+
+struct PsArgs {
+    const double *G, *iL;
+    double ivar;
+    int F, Fp, P;
+    double *A, *M, *C, *dvec;
+    unsigned int *bar;
+    long long *prof;  // RR_PS_PROF=1: workgroup 0's 100 MHz ticks per phase
+};
+
+__device__ __forceinline__ void ps_barrier(unsigned int *ctr, unsigned int target) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+// LDS block loads of a 64 x 64 block of a row-major matrix: dst[r][c] = src[r][c] or dst[c][r] = src[r][c]
+__device__ __forceinline__ void ps_load(double (*dst)[PS_LD], const double *src, int64_t ld, bool transpose) {
+    for (int e = threadIdx.x; e < PS_NB * PS_NB; e += PS_T) {
+        const int r = e >> 6, c = e & 63;
+        const double v = src[(int64_t)r * ld + c];
+        if (transpose) dst[c][r] = v;
+        else dst[r][c] = v;
+    }
+}
+
+// acc[4][4] += sum_t As[t][4 tm + a] Bs[t][4 tn + b]  (thread (tm, tn) of a 16 x 16 grid: a 64 x 64 x 64 product per workgroup)
+__device__ __forceinline__ void ps_mma(const double (*As)[PS_LD], const double (*Bs)[PS_LD], double (&acc)[4][4]) {
+    const int tm = threadIdx.x >> 4, tn = threadIdx.x & 15;
+#pragma unroll 4
+    for (int t = 0; t < PS_NB; ++t) {
+        double a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] = As[t][4 * tm + u];
+            b[u] = Bs[t][4 * tn + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = fma(a[u], b[v], acc[u][v]);
+    }
+}
+
+__global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p) {
+    __shared__ double L0[PS_NB][PS_LD], L1[PS_NB][PS_LD], Pp[4][PS_NB];
+    const int tid = threadIdx.x, wg = blockIdx.x, F = p.F, P = p.P;
+    long long tprev = p.prof ? wall_clock64() : 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PS_MARK(i)                                                  \
+    do {                                                            \
+        if (p.prof && wg == 0 && tid == 0) {                        \
+            const long long now_ = wall_clock64();                  \
+            pacc[i] += now_ - tprev;                                \
+            tprev = now_;                                           \
+        }                                                           \
+    } while (0)
+    const int64_t ld = p.Fp;
+    unsigned int nbar = 0;
+    // ---- assemble (lower triangle and diagonal; identity on the padding)
+    for (int64_t e = (int64_t)wg * PS_T + tid; e < ld * ld; e += (int64_t)PS_WG * PS_T) {
+        const int64_t r = e / ld, c = e % ld;
+        double v = 0.0;
+        if (r < F && c < F) v = p.G[r * F + c] * p.ivar + (r == c ? p.iL[r] : 0.0);
+        else if (r == c) v = 1.0;
+        p.A[e] = v;
+        p.M[e] = 0.0;
+    }
+    ps_barrier(p.bar, ++nbar * PS_WG);
+    PS_MARK(0);
+    for (int pp = 0; pp < P; ++pp) {
+        double *App = p.A + (int64_t)pp * PS_NB * (ld + 1);
+        // ---- S1: the diagonal block, by workgroup 0
+        if (wg == 0) {
+            ps_load(L0, App, ld, false);
+            __syncthreads();
+            for (int k = 0; k < PS_NB; ++k) {
+                if (tid == 0) {
+                    const double d = L0[k][k];
+                    L0[k][k] = d > 0.0 ? sqrt(d) : -1.0;   // (a non-positive pivot: reported through the diagonal)
+                }
+                __syncthreads();
+                const double piv = L0[k][k];
+                if (tid > k && tid < PS_NB) L0[tid][k] /= piv;
+                __syncthreads();
+                {   // trailing block: row r = tid / 4, its columns k < c <= r dealt to the row's four threads
+                    const int r = tid >> 2;
+                    if (r > k) {
+                        const double lrk = L0[r][k];
+                        for (int c = k + 1 + (tid & 3); c <= r; c += 4) L0[r][c] = fma(-lrk, L0[c][k], L0[r][c]);
+                    }
+                }
+                __syncthreads();
+            }
+            for (int e = tid; e < PS_NB * PS_NB; e += PS_T) {
+                const int r = e >> 6, c = e & 63;
+                App[(int64_t)r * ld + c] = c <= r ? L0[r][c] : 0.0;
+            }
+            if (tid < PS_NB) p.dvec[pp * PS_NB + tid] = L0[tid][tid];
+        }
+        PS_MARK(1);
+        ps_barrier(p.bar, ++nbar * PS_WG);
+        PS_MARK(2);
+        // ---- S2: A_ip <- A_ip L_pp^-T for the block rows below (x L^T = a, row by row: a thread per row)
+        if (pp + 1 < P) {
+            bool loaded = false;
+            for (int i = pp + 1 + wg; i < P; i += PS_WG) {
+                if (!loaded) {
+                    ps_load(L0, App, ld, false);
+                    loaded = true;
+                }
+                double *Aip = p.A + ((int64_t)i * PS_NB) * ld + (int64_t)pp * PS_NB;
+                ps_load(L1, Aip, ld, false);
+                __syncthreads();
+                {   // x L_pp^T = a for the block's 64 rows at once: column k needs columns t < k of every row -- lane = row,
+                    // the sum over t dealt to the four waves, partial sums through LDS (two barriers per column)
+                    const int r = tid & 63, g = tid >> 6;
+                    for (int k = 0; k < PS_NB; ++k) {
+                        double part = 0.0;
+                        for (int t = g; t < k; t += 4) part = fma(L1[r][t], L0[k][t], part);
+                        Pp[g][r] = part;
+                        __syncthreads();
+                        if (g == 0) L1[r][k] = (L1[r][k] - (Pp[0][r] + Pp[1][r] + Pp[2][r] + Pp[3][r])) / L0[k][k];
+                        __syncthreads();
+                    }
+                }
+                for (int e = tid; e < PS_NB * PS_NB; e += PS_T) Aip[(int64_t)(e >> 6) * ld + (e & 63)] = L1[e >> 6][e & 63];
+                __syncthreads();
+            }
+        }
+        PS_MARK(3);
+        ps_barrier(p.bar, ++nbar * PS_WG);
+        PS_MARK(4);
+        // ---- S3: trailing tiles (i, k), pp < k <= i: A_ik -= A_ip A_kp^T
+        {
+            const int n = P - pp - 1, ntile = n * (n + 1) / 2;
+            for (int t = wg; t < ntile; t += PS_WG) {
+                int i = 0, rem = t;
+                while (rem > i) {  // row i of the triangle holds i + 1 tiles
+                    rem -= i + 1;
+                    ++i;
+                }
+                const int bi = pp + 1 + i, bk = pp + 1 + rem;
+                ps_load(L0, p.A + ((int64_t)bi * PS_NB) * ld + (int64_t)pp * PS_NB, ld, true);   // As[t][m] = A_ip[m][t]
+                ps_load(L1, p.A + ((int64_t)bk * PS_NB) * ld + (int64_t)pp * PS_NB, ld, true);   // Bs[t][n] = A_kp[n][t]
+                __syncthreads();
+                double acc[4][4] = {};
+                ps_mma(L0, L1, acc);
+                double *Aik = p.A + ((int64_t)bi * PS_NB) * ld + (int64_t)bk * PS_NB;
+                const int tm = tid >> 4, tn = tid & 15;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) Aik[(int64_t)(4 * tm + u) * ld + 4 * tn + v] -= acc[u][v];
+                __syncthreads();
+            }
+        }
+        PS_MARK(5);
+        ps_barrier(p.bar, ++nbar * PS_WG);
+        PS_MARK(6);
+    }
+    // ---- not safely positive definite? (every workgroup reads the same diagonal: the same decision everywhere)
+    {
+        double mn = INFINITY;
+        for (int i = tid; i < F; i += PS_T) {
+            const double d = p.dvec[i];
+            mn = fmin(mn, (d > 0.0 && d == d) ? d : -1.0);
+        }
+        L0[0][tid & 63] = INFINITY;
+        __syncthreads();
+        for (int w = 0; w < 4; ++w) {   // (four waves, one after the other: a min over 256 values without atomics)
+            if ((tid >> 6) == w) L0[0][tid & 63] = fmin(L0[0][tid & 63], mn);
+            __syncthreads();
+        }
+        if (tid == 0) {
+            double m2 = INFINITY;
+            for (int i = 0; i < 64; ++i) m2 = fmin(m2, L0[0][i]);
+            L0[1][0] = m2;
+        }
+        __syncthreads();
+        if (L0[1][0] < 1e-5) return;   // CHOLTHRESH, mathfun/linalg.py:31 (no barrier follows for anybody)
+        __syncthreads();
+    }
+    // ---- T_i = L_ii^-1 into M's diagonal blocks (a thread per column)
+    for (int i = wg; i < P; i += PS_WG) {
+        ps_load(L0, p.A + (int64_t)i * PS_NB * (ld + 1), ld, false);
+        __syncthreads();
+        {   // L_ii X = I row by row: row r needs rows t < r of every column -- lane = column, the sum over t dealt to the waves
+            const int c = tid & 63, g = tid >> 6;
+            for (int r = 0; r < PS_NB; ++r) {
+                double part = 0.0;
+                for (int t = g; t < r; t += 4) part = fma(L0[r][t], L1[t][c], part);
+                Pp[g][c] = part;
+                __syncthreads();
+                if (g == 0) L1[r][c] = ((r == c ? 1.0 : 0.0) - (Pp[0][c] + Pp[1][c] + Pp[2][c] + Pp[3][c])) / L0[r][r];
+                __syncthreads();
+            }
+        }
+        double *Mii = p.M + (int64_t)i * PS_NB * (ld + 1);
+        for (int e = tid; e < PS_NB * PS_NB; e += PS_T) Mii[(int64_t)(e >> 6) * ld + (e & 63)] = L1[e >> 6][e & 63];
+        __syncthreads();
+    }
+    ps_barrier(p.bar, ++nbar * PS_WG);
+    PS_MARK(7);
+    // ---- M = L^-1 below the diagonal: slab (block column pb, 16 columns q) walks down its block rows
+    {
+        // LDS: L0 = the 64 x 64 left operand (L_ik, then T_i); L1 columns [0, 16) = the slab rows of M_k, columns [32, 48) = R
+        for (int item = wg; item < P * 4; item += PS_WG) {
+            const int pb = item >> 2, q = item & 3;
+            const int tm = tid >> 2, tn = tid & 3;   // output (row tm, columns 4 tn .. 4 tn + 3) of a 64 x 16 slab
+            for (int i = pb + 1; i < P; ++i) {
+                double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int k = pb; k < i; ++k) {
+                    __syncthreads();
+                    ps_load(L0, p.A + ((int64_t)i * PS_NB) * ld + (int64_t)k * PS_NB, ld, false);   // L_ik[m][t]
+                    {
+                        const double *Mk = p.M + ((int64_t)k * PS_NB) * ld + (int64_t)pb * PS_NB + 16 * q;   // M_k,slab[t][c]
+                        for (int e = tid; e < PS_NB * 16; e += PS_T) L1[e >> 4][e & 15] = Mk[(int64_t)(e >> 4) * ld + (e & 15)];
+                    }
+                    __syncthreads();
+#pragma unroll 8
+                    for (int t = 0; t < PS_NB; ++t) {
+                        const double a = L0[tm][t];
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) acc[v] = fma(a, L1[t][4 * tn + v], acc[v]);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int v = 0; v < 4; ++v) L1[tm][32 + 4 * tn + v] = acc[v];
+                ps_load(L0, p.M + (int64_t)i * PS_NB * (ld + 1), ld, false);   // T_i
+                __syncthreads();
+                double o[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int t = 0; t <= tm; ++t) {   // (T_i is lower triangular)
+                    const double a = L0[tm][t];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) o[v] = fma(a, L1[t][32 + 4 * tn + v], o[v]);
+                }
+                double *Mi = p.M + ((int64_t)i * PS_NB) * ld + (int64_t)pb * PS_NB + 16 * q;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) Mi[(int64_t)tm * ld + 4 * tn + v] = -o[v];
+                __threadfence_block();   // (this workgroup reads the slab back in the next block row's sums)
+            }
+        }
+    }
+    ps_barrier(p.bar, ++nbar * PS_WG);
+    PS_MARK(8);
+    // ---- C = M^T M: tile (i, k), k <= i: sum over block rows r >= i of M_ri^T M_rk; both triangles of the (F, F) output
+    {
+        const int ntile = P * (P + 1) / 2;
+        for (int t = wg; t < ntile; t += PS_WG) {
+            // heavy tiles first: enumerate i ascending (tile (i, k) sums P - i products)
+            int i = 0, rem = t;
+            while (rem > i) {
+                rem -= i + 1;
+                ++i;
+            }
+            const int k = rem;
+            double acc[4][4] = {};
+            for (int r = i; r < P; ++r) {
+                __syncthreads();
+                ps_load(L0, p.M + ((int64_t)r * PS_NB) * ld + (int64_t)i * PS_NB, ld, false);   // As[t][m] = M_ri[t][m]
+                ps_load(L1, p.M + ((int64_t)r * PS_NB) * ld + (int64_t)k * PS_NB, ld, false);   // Bs[t][n] = M_rk[t][n]
+                __syncthreads();
+                ps_mma(L0, L1, acc);
+            }
+            const int tm = tid >> 4, tn = tid & 15;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int64_t gr = (int64_t)i * PS_NB + 4 * tm + u, gc = (int64_t)k * PS_NB + 4 * tn + v;
+                    if (gr < F && gc < F) {
+                        p.C[gr * F + gc] = acc[u][v];
+                        p.C[gc * F + gr] = acc[u][v];
+                    }
+                }
+        }
+    }
+    PS_MARK(9);
+    if (p.prof && wg == 0 && tid == 0)
+        for (int i = 0; i < 10; ++i) p.prof[i] += pacc[i];
+#undef PS_MARK
+}
+
 struct PosdefScratch {
     double *W = nullptr, *Y = nullptr, *Cp = nullptr;  // (Fp, Fp) each
     double *diL = nullptr, *dvec = nullptr;            // dvec: [chol diag (Fp) | m (F) | diagC (F) | tr (1)]
     double *Uinv = nullptr;                            // (Fp / 128) blocks of 128 x 128: U_jj^-1
+    unsigned int *bar = nullptr;                       // barrier counter of rr_posterior_small_kernel
     int64_t Fp = 0;
     std::vector<hipEvent_t> ev;                        // "block row j of the factor is final" (+ one for the join), grow-only
     void release() {
-        void *q[] = {W, Y, Cp, diL, dvec, Uinv};
+        void *q[] = {W, Y, Cp, diL, dvec, Uinv, bar};
         for (void *x : q)
             if (x) (void)hipFree(x);
         W = Y = Cp = diL = dvec = Uinv = nullptr;
+        bar = nullptr;
         Fp = 0;
     }
 };
@@ -563,6 +871,7 @@ static int posdef_scratch(rr_ctx *c, int64_t Fp, int64_t F, const char *who) {
         if (ea == hipSuccess) ea = hipMalloc((void **)&s.diL, (size_t)Fp * 8);
         if (ea == hipSuccess) ea = hipMalloc((void **)&s.dvec, (size_t)(3 * Fp + 1) * 8);
         if (ea == hipSuccess) ea = hipMalloc((void **)&s.Uinv, (size_t)Fp * PB * 8);
+        if (ea == hipSuccess) ea = hipMalloc((void **)&s.bar, 64);
         if (ea != hipSuccess) {
             (void)hipGetLastError();
             s.release();
@@ -655,6 +964,72 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     const int64_t ld = Fp;
     const double ivar = 1.0 / var;
     RR_CHECK_HIP(hipMemcpyAsync(s.diL, iL, (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
+    // small feature counts: the whole factorisation, inverse and C in ONE cooperative launch -- OPT-IN (RR_POSDEF_SMALL=1).
+    // Measured at config 1 (F = 512) and not adopted: 1.35 ms per call (S1 410 us: 0.8 us per pivot of the unblocked
+    // diagonal-block factorisation out of LDS; S2 307; M 222; C 112; 27 barriers 136) against ~0.75 ms for the panel
+    // pipeline's share of `_elbo` -- its diagonal blocks run at 0.3 us per pivot on the matrix cores
+    // (rr_chol_diag_mfma_kernel).  One launch is not the point; the pivot chain is.  Kept for the next attempt and held to
+    // the oracle by tests/test_gpu_posterior.py.
+    const char *small_env = getenv("RR_POSDEF_SMALL");
+    if (F <= 1024 && small_env != nullptr && atoi(small_env) != 0 && c->num_cu >= PS_WG) {
+        PsArgs a;
+        a.G = dG; a.iL = s.diL; a.ivar = ivar; a.F = (int)F; a.Fp = (int)Fp; a.P = (int)(Fp / PS_NB);
+        a.A = s.W; a.M = s.Y; a.C = dC; a.dvec = s.dvec; a.bar = s.bar;
+        static long long *dprof = nullptr;
+        static int prof_calls = 0;
+        if (getenv("RR_PS_PROF") && !dprof && hipMalloc((void **)&dprof, 80) == hipSuccess) (void)hipMemset(dprof, 0, 80);
+        a.prof = dprof;
+        if (dprof && ++prof_calls % 50 == 0) {
+            long long h[10];
+            (void)hipMemcpy(h, dprof, 80, hipMemcpyDeviceToHost);
+            static const char *nm[] = {"assemble", "S1", "bar1", "S2", "bar2", "S3", "bar3", "T+bar", "M+bar", "C"};
+            fprintf(stderr, "rr_posterior_small (us per call over %d calls):", prof_calls - 1);
+            for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f", nm[i], 0.01 * (double)h[i] / (prof_calls - 1));
+            fprintf(stderr, "\n");
+        }
+        RR_CHECK_HIP(hipMemsetAsync(s.bar, 0, 64, c->stream));
+        hipLaunchKernelGGL(rr_posterior_small_kernel, dim3(PS_WG), dim3(PS_T), 0, c->stream, a);
+        RR_CHECK_HIP(hipGetLastError());
+        double *dm = s.dvec + Fp, *ddg = s.dvec + 2 * Fp, *dtr = s.dvec + 3 * Fp;
+        RR_CHECK_HIP(hipMemsetAsync(dtr, 0, 8, c->stream));
+        int rc = RR_OK;
+        if (c->deterministic) {
+            void *part = nullptr;
+            rc = rr_det_scratch(c, (size_t)F * 8, &part);
+            if (rc != RR_OK) return rc;
+            hipLaunchKernelGGL(rr_posterior_rows_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream, dC, dG, db, ivar, F,
+                               dm, ddg, (double *)part, (int64_t)1);
+            rc = rr_det_reduce(c, (const double *)part, F, 1, 1, dtr);
+            if (rc != RR_OK) return rc;
+        } else {
+            hipLaunchKernelGGL(rr_posterior_rows_kernel, dim3((unsigned)((F + 3) / 4)), dim3(256), 0, c->stream, dC, dG, db, ivar, F,
+                               dm, ddg, dtr);
+        }
+        RR_CHECK_HIP(hipGetLastError());
+        std::vector<double> h((size_t)3 * Fp + 1);
+        RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)(3 * Fp + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        double logdet = 0.0, mind = INFINITY;
+        for (int64_t i = 0; i < F; ++i) {
+            const double dval = h[(size_t)i];
+            if (!(dval > 0.0) || !std::isfinite(dval)) {
+                mind = -1.0;
+                break;
+            }
+            logdet += 2.0 * std::log(dval);
+            if (dval < mind) mind = dval;
+        }
+        scal[0] = logdet;
+        scal[2] = mind;
+        if (mind < 1e-5) {  // CHOLTHRESH, mathfun/linalg.py:31 (the kernel stopped behind the factorisation: C, m are not formed)
+            rr_set_error("rr_posterior_dev: matrix is not safely positive definite (min diag of the factor %g)", mind);
+            return RR_ERR_NOT_POSDEF;
+        }
+        memcpy(m, h.data() + Fp, (size_t)F * 8);
+        memcpy(diagC, h.data() + 2 * Fp, (size_t)F * 8);
+        scal[1] = h[(size_t)3 * Fp];
+        return RR_OK;
+    }
     const unsigned eb = (unsigned)((Fp * Fp + 255) / 256);
     hipLaunchKernelGGL(rr_assemble_ic_kernel, dim3(eb), dim3(256), 0, c->stream, dG, s.diL, ivar, F, Fp, s.W);
     hipLaunchKernelGGL(rr_set_identity_kernel, dim3(eb), dim3(256), 0, c->stream, s.Y, Fp);

@@ -141,3 +141,58 @@ def test_not_positive_definite_in_a_late_panel_is_reported_and_leaves_nothing_in
     finally:
         dev.set_deterministic(was)
     assert normwise(C if cols is None else C[:, cols], Ch) < 1e-9 and normwise(m, mh) < 1e-9 and abs(logdet - ld_iC) < 1e-9 * abs(ld_iC)
+
+
+@pytest.mark.parametrize("mode", ["default", "deterministic"])
+@pytest.mark.parametrize("F", [1, 5, 64, 100, 256, 300, 512, 1000, 1024])
+def test_small_posterior_in_one_launch_vs_oracle(F, mode, monkeypatch):
+    """(opt-in route, RR_POSDEF_SMALL=1: measured slower than the panel pipeline at F = 512 and kept for its next attempt.)
+    F <= 1024 (BASELINE config 1 is F = 512): rr_posterior_small_kernel -- factor, inverse and C in ONE cooperative launch
+    (32 workgroups, device-scope barriers) -- against the oracle's solve_posdef (mathfun/linalg.py:84-125): C, m, diag C,
+    log|iC|, sum(G o C); ragged F (padding to 64-column panels), F below one panel."""
+    from revrand_amd import _hip
+    monkeypatch.setenv("RR_POSDEF_SMALL", "1")
+    dev = _hip.get_device()
+    rs = np.random.RandomState(F)
+    B = rs.standard_normal((max(F // 2, 3), F))
+    G = B.T @ B
+    b = B.T @ rs.standard_normal(B.shape[0])
+    iL = 1.0 / rs.gamma(2.0, 1.0, F)
+    var = 0.37
+    Ch, ld_iC = orc.solve_posdef(np.diag(iL) + G / var, np.eye(F))
+    was = dev.deterministic
+    dev.set_deterministic(mode == "deterministic")
+    try:
+        (m, dg, logdet, tr), C = _posterior(dev, _hip, F, G, b, iL, var)
+        (m2, dg2, logdet2, tr2), C2 = _posterior(dev, _hip, F, G, b, iL, var)
+    finally:
+        dev.set_deterministic(was)
+    assert np.array_equal(C, C2) and np.array_equal(m, m2) and logdet == logdet2   # fixed-order sums: the same bits
+    assert np.array_equal(C, C.T)
+    assert normwise(C, Ch) < 1e-10 and normwise(m, Ch @ b / var) < 1e-10 and normwise(dg, Ch.diagonal()) < 1e-10
+    assert abs(logdet - ld_iC) < 1e-10 * max(abs(ld_iC), 1.0)
+    trh = float((G * Ch).sum())
+    assert abs(tr - trh) < 1e-9 * abs(trh)
+
+
+@pytest.mark.parametrize("F,k", [(512, 500), (300, 10), (1024, 700)])
+def test_small_posterior_reports_a_matrix_that_is_not_positive_definite(F, k, monkeypatch):
+    """A pivot below CHOLTHRESH (or negative) in a late panel: RR_ERR_NOT_POSDEF (`None`), nothing left in flight, and the
+    next call on a good matrix is right (the cooperative kernel's workgroups all leave behind the factorisation)."""
+    from revrand_amd import _hip
+    monkeypatch.setenv("RR_POSDEF_SMALL", "1")
+    dev = _hip.get_device()
+    iC = _breaks_in_panel(F, k, F + k)
+    iL, var = np.full(F, 0.5), 1.0
+    post, _ = _posterior(dev, _hip, F, iC - np.diag(iL), np.ones(F), iL, var)
+    assert post is None and b"not safely positive definite" in dev.lib.rr_last_error()
+    iCn = iC.copy()
+    iCn[k, k] = -1.0 + iC[k, k]     # an indefinite matrix: a negative pivot
+    post, _ = _posterior(dev, _hip, F, iCn - np.diag(iL), np.ones(F), iL, var)
+    assert post is None
+    rs = np.random.RandomState(1)
+    B = rs.standard_normal((F // 2, F))
+    G = B.T @ B
+    (m, dg, logdet, tr), C = _posterior(dev, _hip, F, G, np.ones(F), iL, var)
+    Ch, ld = orc.solve_posdef(np.diag(iL) + G / var, np.eye(F))
+    assert normwise(C, Ch) < 1e-10 and abs(logdet - ld) < 1e-10 * abs(ld)
