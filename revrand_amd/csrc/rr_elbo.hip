@@ -2978,7 +2978,7 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
 // -> the rest of the update, and as soon as the length scales of step t + 1 exist its features (an HBM-write-bound 0.2 ms at
 // config 5) are made on a second stream into the OTHER of two feature matrices while the matrix cores form step t's Ed.
 // =============================================================================================
-#define RR_SGD_MAXK 32
+#define RR_SGD_MAXK 64
 #define RR_SGD_MAXCHILD 16
 
 struct SgdHRow {  // one length-scale gradient: W[i, :] . T[i, :] of a random Fourier child

@@ -270,11 +270,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
     def _resident_loop(self, params, y=None, likelihood_args=()):
         """The SGD loop with parameters, updater state and gradient in device memory (`_ResidentLoop`, rr_glm_sgd) when this
-        fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a LinearBasis or a
-        concatenation of such children (Xdim <= 128, a scalar regulariser each); one of the reference's likelihoods and updaters;
-        K <= 32; one process and one GPU.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
+        fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a FastFoodRBF (through its
+        dense equivalent), a LinearBasis or a concatenation of such children (Xdim <= 128, a scalar regulariser each); one of
+        the reference's likelihoods and updaters; K <= 64 (the fused small-batch loop: K <= 32); one process and one GPU.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
         from . import optimize as opt
-        from .basis_functions import _ResidentLinear, _ResidentRFF
+        from .basis_functions import _ResidentFastFood, _ResidentLinear, _ResidentRFF
         if not self._resident_sgd or os.environ.get("RR_GLM_RESIDENT_SGD", "1") == "0":
             return None
         feats = self._features()
@@ -282,7 +282,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 or type(feats) is not MinibatchFeatures or self.sampler not in ("host", "device"):
             return None
         kids = getattr(feats, "_kids", [])
-        if not 1 <= len(kids) <= 16 or not 1 <= self.K <= 32:
+        if not 1 <= len(kids) <= 16 or not 1 <= self.K <= 64:
             return None
         if self.updater is not None and type(self.updater) not in (opt.SGDUpdater, opt.AdaDelta, opt.AdaGrad, opt.Momentum, opt.Adam):
             return None
@@ -296,7 +296,10 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             return None
         children = []
         for kid, b in zip(kids, feats.bases):
-            if type(kid) is _ResidentRFF and b.d <= 128 and kid.W.shape[0] == b.d:
+            # (a FastFoodRBF child: through its dense equivalent W = _makeVX(I_d) -- the chain is linear in x, so
+            # [cos | sin](x (W / l)) / sqrt(n) IS basis_functions.py:1263-1289 -- on the random Fourier kernels: its handle is
+            # that basis; the chain kernel stays the host loop's and the SLM's route)
+            if type(kid) in (_ResidentRFF, _ResidentFastFood) and b.d <= 128 and kid.W.shape[0] == b.d:
                 n_ls = int(np.prod(b.params.shape, dtype=int))
                 if n_ls not in (1, b.d):
                     return None

@@ -200,21 +200,69 @@ def test_linear_basis_alone():
 
 
 def test_fits_the_loop_does_not_cover_take_the_host_loop(monkeypatch):
-    """A FastFood child, a custom updater, K > 32: `_resident_loop` declines and `fit` is what it was."""
+    """A custom updater, K > 64, a FastFoodGM child (two parameters per child): `_resident_loop` declines and `fit` is what it
+    was."""
     bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
     from revrand_amd import _hip
     monkeypatch.setattr(_hip.ResidentSgd, "step", lambda *a, **k: (_ for _ in ()).throw(AssertionError("resident loop used")))
+    monkeypatch.setattr(_hip.FusedSvi, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused loop used")))
     X, y, _ = _data("poisson", N=1200)
     d = X.shape[1]
 
     class MyAdam(opt.Adam):
         pass
-    for basis, kw in ((bs.LinearBasis(onescol=True) + bs.FastFoodRBF(nbases=16, Xdim=d, random_state=1), {}),
-                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"updater": MyAdam()}),
-                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"K": 33})):
+    for basis, kw in ((bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"updater": MyAdam()}),
+                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"K": 65}),
+                      (bs.FastFoodGM(nbases=16, Xdim=d, random_state=1), {})):
         glm = GLM(lk.Poisson(), basis, nsamples=4, batch_size=300, maxiter=3, nstarts=0, random_state=1, **{"K": 2, **kw})
         glm.fit(X, y)
         assert np.all(np.isfinite(glm.weights_))
+
+
+@pytest.mark.parametrize("batch", [1500, 12])
+def test_fastfood_children_and_many_components_run_resident(batch, monkeypatch):
+    """Round 6: a FastFoodRBF child takes the resident loops through its dense equivalent W = _makeVX(I_d) (the chain is linear in
+    x: basis_functions.py:1263-1289, 1356-1371) -- alone (ARD) and in a concatenation -- and K up to 64 components
+    (rr_glm_sgd) / 32 (the fused small-batch loop): the host loop's fit, which runs the CHAIN kernel, from the same seeds."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    from revrand_amd import _hip
+    X, y, _ = _data("poisson", N=3000)
+    d = X.shape[1]
+    steps = {"resident": 0, "fused": 0}
+    real, real_run = _hip.ResidentSgd.step, _hip.FusedSvi.run
+
+    def spy(self, *a, **k):
+        steps["resident"] += 1
+        return real(self, *a, **k)
+
+    def spy_run(self, n, *a, **k):
+        steps["fused"] += n
+        return real_run(self, n, *a, **k)
+    monkeypatch.setattr(_hip.ResidentSgd, "step", spy)
+    monkeypatch.setattr(_hip.FusedSvi, "run", spy_run)
+
+    def bases():
+        return [bs.FastFoodRBF(nbases=24, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
+                bs.LinearBasis(onescol=True) + bs.FastFoodRBF(nbases=16, Xdim=d, random_state=2)
+                + bs.RandomRBF(nbases=8, Xdim=d, random_state=3)]
+    for which in (0, 1):
+        for K in ((3, 40) if batch > 100 else (3, 20)):
+            out = []
+            for resident in (True, False):
+                glm = GLM(lk.Poisson(), bases()[which], K=K, nsamples=6, batch_size=batch, maxiter=12, nstarts=2, random_state=5)
+                glm._resident_sgd = resident
+                np.random.seed(3)
+                steps["resident"] = steps["fused"] = 0
+                glm.fit(X, y)
+                if resident:
+                    assert steps["resident" if batch > 100 else "fused"] == 12, (steps, which, K)
+                else:
+                    assert steps == {"resident": 0, "fused": 0}
+                out.append((glm.weights_.copy(), glm.covariance_.copy(), np.atleast_1d(np.array(glm.regularizer_, dtype=float)),
+                            np.zeros(0), np.concatenate([np.ravel(np.asarray(h, dtype=float)) for h in
+                                                         (glm.basis_hypers_ if isinstance(glm.basis_hypers_, list) else [glm.basis_hypers_])]),
+                            glm.random_.randn()))
+            _same(out[0], out[1], 5e-5)
 
 
 def test_config5_shape_runs_the_fused_contraction_and_improves_the_objective(monkeypatch):
