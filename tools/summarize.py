@@ -12,7 +12,7 @@ duration (round 3's summary priced a 475 712-row remainder launch as a 524 288-r
 0.949).  Where a configuration's kernel also serves another stage (the f64 GEMM: second pass and posterior), launches are
 selected by GRID SIZE from the kernel trace, and the selection is written into the summary.
 
-    python tools/summarize.py [round]          (default r05)
+    python tools/summarize.py [round]          (default r06)
 """
 import csv
 import json
@@ -21,7 +21,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + ROUND)
 PEAK = {"f32": 157.3e12, "f64": 78.6e12, "hbm": 8.0e12}
 MAX_CLOCK_FRAC = 1.0  # a fraction above clock / 2.40 GHz cannot be right: checked below against 1.0
@@ -207,6 +207,7 @@ for tag, name, keys in (("posdef_kt", "posdef", ("posterior_F4096", "posterior_F
                         ("predict_kt", "predict", ("predict_moments_n300k",)), ("laplace_kt", "laplace", ("C2laplace_f64phase_n1m",)),
                         ("c4_kt", "c4_fastfood", ("C4_fastfood_f16384",)), ("c5_kt", "c5_glm", ("C5_glm_poisson_svi_step",)),
                         ("c1_kt", "c1_latency", ("C1_elbo_latency",)), ("c4gm_kt", "c4gm", ("C4gm_fastfoodgm_f16384",)),
+                        ("c5small_kt", "glm_small_batch", ("C5small_glm_default_fit",)),
                         ("sp_kt", "single_process", ())):
     b = bench_record(tag)
     if not b:
