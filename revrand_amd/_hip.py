@@ -303,12 +303,21 @@ def hip_runtime_path():
     return paths[0] if len(paths) == 1 else (paths or None)
 
 
+_bound_runtime = None   # libamdhip64 path(s) mapped at the moment librevrand_hip.so was loaded
+
+
 def _runtime_is_torchs():
+    """Does librevrand_hip.so run on the torch wheel's HIP runtime?  Decided by what was mapped when the library was LOADED:
+    a process that loads it first (on /opt/rocm's runtime) and imports torch afterwards has both copies mapped, and RCCL
+    must still be the one paired with OURS -- the wheel's librccl on /opt/rocm's runtime sees no device
+    (ncclCommInitAll: 'no ROCm-capable device is detected'; found by the full GPU suite, where a torch-launcher test ran
+    before the in-process RCCL group's)."""
     cand = _torch_lib("libamdhip64.so")
     if cand is None:
         return False
     tdir = os.path.realpath(os.path.dirname(cand))
-    return any(os.path.realpath(os.path.dirname(p)) == tdir for p in _mapped("libamdhip64"))
+    paths = _bound_runtime if _bound_runtime else _mapped("libamdhip64")
+    return any(os.path.realpath(os.path.dirname(p)) == tdir for p in paths)
 
 
 def rccl_library_path():
@@ -319,6 +328,12 @@ def rccl_library_path():
         return os.environ["RR_RCCL_LIB"]
     if _runtime_is_torchs():
         return _torch_lib("librccl.so")
+    # the copy next to OUR runtime, by path: a bare dlopen("librccl.so.1") hands back whichever copy is already in the
+    # process -- the torch wheel's, once anybody imported torch
+    for rt in (_bound_runtime or _mapped("libamdhip64")):
+        cand = os.path.join(os.path.dirname(os.path.realpath(rt)), "librccl.so.1")
+        if os.path.exists(cand):
+            return cand
     return None
 
 
@@ -364,6 +379,9 @@ def load_library(path=None):
                 "librevrand_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'` or `make -C revrand_amd/csrc`; there is no CPU fallback for this path" % p)
         lib = ctypes.CDLL(p)
+        global _bound_runtime
+        if _bound_runtime is None:   # the HIP runtime OUR library is bound to: what is mapped now (a torch imported later
+            _bound_runtime = _mapped("libamdhip64")   # maps its own copy next to it, which is not ours)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is missing
             fn.restype = res

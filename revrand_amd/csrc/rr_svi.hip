@@ -506,15 +506,30 @@ __device__ __forceinline__ double svi_update(const SviArgs &a, double zz, double
 // a: x = from_log(z) of every coordinate into LDS -- this workgroup's column from its own z (LDS), the others' from `src`
 // (their owners' columns: (K, 2 F) as published, or the flat vector z of the launch's start) -- then what depends on x
 // alone: component k's means and standard deviations, 1 / (2 pi l) per length scale, R_c = sum (m^2 + C) per child.
-__device__ __forceinline__ void svi_form_x(const SviArgs &a, const SviLds &s, int k, const double *src, bool src_is_z) {
-    const int tid = threadIdx.x, K = a.K, F = a.F, ns = a.ns;
+// (first half) the raw z of every coordinate into the LDS arrays of x: this workgroup's column from its own z (LDS), the
+// others' from `src` (their owners' columns (K, 2 F) as published, or the flat vector z of the launch's start)
+__device__ __forceinline__ void svi_load_z(const SviArgs &a, const SviLds &s, int k, const double *src, bool src_is_z) {
+    const int tid = threadIdx.x, K = a.K, F = a.F;
     const int fk = F * K;
     for (int p = tid; p < 2 * fk; p += SVI_THREADS) {
         const int cov = p >= fk, q = cov ? p - fk : p, f = q / K, j = q % K;
         double zv;
         if (j == k) zv = s.zc[cov * F + f];
         else zv = src_is_z ? src[p] : src[(size_t)j * 2 * F + cov * F + f];
-        (cov ? s.xC : s.xm)[q] = s.lg[p] ? exp(zv) : zv;
+        (cov ? s.xC : s.xm)[q] = zv;
+    }
+}
+
+// (second half) x = from_log(z) in place, then what depends on x alone: component k's means and standard deviations,
+// 1 / (2 pi l) per length scale, R_c = sum (m^2 + C) per child
+__device__ __forceinline__ void svi_form_x(const SviArgs &a, const SviLds &s, int k) {
+    const int tid = threadIdx.x, K = a.K, F = a.F, ns = a.ns;
+    const int fk = F * K;
+    for (int p = tid; p < 2 * fk; p += SVI_THREADS) {
+        if (s.lg[p]) {
+            ldsd *x = p >= fk ? s.xC + (p - fk) : s.xm + p;
+            *x = exp(*x);
+        }
     }
     for (int p = tid; p < ns; p += SVI_THREADS) s.xs[p] = s.lg[2 * fk + p] ? exp(s.zs[p]) : s.zs[p];
     svi_sync();
@@ -560,7 +575,9 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
     SviGather gth;
     svi_gather_issue(a, a.idx, gth);
     svi_sync();
-    svi_form_x(a, s, k, a.z, true);
+    svi_load_z(a, s, k, a.z, true);
+    svi_sync();
+    svi_form_x(a, s, k);
     svi_draws(a, s, a.E ? a.E + (size_t)k * L * F : nullptr, svi_splitmix64(a.seed ^ (a.key0 * 0xD1B54A32D192ED03ull)), k * L);
     svi_sync();
     for (int t = 0; t < a.steps; ++t) {
@@ -681,8 +698,11 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
         SVI_MARK(8);
         svi_wait(a.bar + 1, (unsigned)(t + 1) * (unsigned)K);
         SVI_MARK(9);
-        // ---- i: the shared coordinates (every workgroup, identically) and the step's record
+        // ---- i: the shared coordinates (every workgroup, identically) and the step's record -- behind ONE round of HBM
+        // reads: the components' scalars AND the other components' new columns (raw z into the arrays of x: what follows
+        // reads the shared coordinates' x, R_c and log z of THIS step, none of which live there)
         for (int o = tid; o < K * npub; o += SVI_THREADS) s.psc[o] = a.pubsc[(size_t)par * K * npub + o];
+        if (t + 1 < a.steps) svi_load_z(a, s, k, a.pubcol + (size_t)par * K * 2 * F, false);
         svi_sync();
         double n2s = 0.0;
         if (tid < ns) {
@@ -730,7 +750,7 @@ __global__ void __launch_bounds__(SVI_THREADS) rr_glm_svi_steps_kernel(const Svi
         svi_sync();
         SVI_MARK(10);
         // ---- a (of the next step): x = from_log(z) of everything
-        if (t + 1 < a.steps) svi_form_x(a, s, k, a.pubcol + (size_t)par * K * 2 * F, false);
+        if (t + 1 < a.steps) svi_form_x(a, s, k);
     }
     if (a.prof && k == 0 && tid == 0)
         for (int i = 0; i < 11; ++i) a.prof[i] += pacc[i];
