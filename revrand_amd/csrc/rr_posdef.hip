@@ -398,11 +398,11 @@ __device__ __forceinline__ void chol16_trow(double *S, const double *Rv, double 
     for (int e = 0; e < 4; ++e) S[(kb * CB + g + 4 * e) * SLD + jb * CB + c] = -acc2[e];
 }
 
-__global__ void __launch_bounds__(256) rr_chol_diag_mfma_kernel(double *__restrict__ A, int64_t ld, double *__restrict__ Uinv) {
-    __shared__ double S[PB * SLD];          // 133 120 B
-    __shared__ double Rv[8 * CB * RLD];     //  18 432 B: T_kb = R_kb^-T, row-major 16 x 16 each
-    __shared__ double Tw[4 * CB * RLD];     //   9 216 B: one scratch block per wave
-    __shared__ int flag;
+// the kernel's body on LDS the caller provides (S: PB * SLD doubles, Rv: 8 * CB * RLD, Tw: 4 * CB * RLD, flag): a workgroup of
+// 256 threads; also workgroup 0's part of a panel step inside rr_posterior_coop_kernel
+__device__ __forceinline__ void chol_diag_mfma_body(double *__restrict__ A, int64_t ld, double *__restrict__ Uinv, double *S, double *Rv,
+                                                    double *Tw, int *flagp) {
+    int &flag = *flagp;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
@@ -471,6 +471,14 @@ __global__ void __launch_bounds__(256) rr_chol_diag_mfma_kernel(double *__restri
     }
 }
 
+__global__ void __launch_bounds__(256) rr_chol_diag_mfma_kernel(double *__restrict__ A, int64_t ld, double *__restrict__ Uinv) {
+    __shared__ double S[PB * SLD];          // 133 120 B
+    __shared__ double Rv[8 * CB * RLD];     //  18 432 B: T_kb = R_kb^-T, row-major 16 x 16 each
+    __shared__ double Tw[4 * CB * RLD];     //   9 216 B: one scratch block per wave
+    __shared__ int flag;
+    chol_diag_mfma_body(A, ld, Uinv, S, Rv, Tw, &flag);
+}
+
 // RR_CHOL_DIAG=0: the unpipelined kernel, =1: the pipelined one (A/B runs); default: the sub-panel / MFMA kernel
 static void launch_chol_diag(hipStream_t stream, double *Ujj, int64_t ld, double *Uij) {
     static const int which = getenv("RR_CHOL_DIAG") != nullptr ? atoi(getenv("RR_CHOL_DIAG")) : 2;
@@ -533,24 +541,27 @@ rr_posterior_rows_kernel(const double *__restrict__ C, const double *__restrict_
 // BASELINE config 1 (F = 512), the reference's SARCOS model (nbases = 512) and everything below sit where the panel
 // pipeline above is nothing but dependent launches: 8 diagonal-block kernels + ~35 one-tile f64 products + their gaps
 // = 1.2 ms of kernel time for 0.13 GFLOP (profiles/r06_c1_latency) -- `_elbo`'s critical path at config 1.  Here 32
-// workgroups walk through the same algebra inside one launch, separated by device-scope barriers (as rr_svi.hip):
-//   assemble  A = G / var + diag(iL) (lower triangle, identity on the padding)
-//   per 64-column panel p:  S1 workgroup 0 factors the diagonal block in LDS (A_pp = L_pp L_pp^T, unblocked)
-//                           S2 block rows below: A_ip <- A_ip L_pp^-T (forward substitution, a thread per row)
-//                           S3 trailing tiles:   A_ik -= A_ip A_kp^T
-//   T_i = L_ii^-1 (workgroup i, a thread per column); M = L^-1 block column slabs (64 x 16, no barrier inside:
-//   M_ip = -T_i sum_{k=p}^{i-1} L_ik M_kp);  C = M^T M tile by tile, written to both triangles.
-// 3 P + 4 barriers for P = F / 64 panels; the flops (F^3) are nothing -- plain float64 FMAs out of LDS.
-// m, diag C, sum(G o C) follow in rr_posterior_rows_kernel as before; a pivot that is not positive leaves a
-// negative entry in the factor's diagonal and the host reports RR_ERR_NOT_POSDEF exactly as the pipeline does.
+// workgroups walk through the same algebra (W = U^T U, upper; 128-column panels) inside one launch, separated by
+// device-scope barriers (as rr_svi.hip):
+//   assemble  W = G / var + diag(iL) (identity on the padding)
+//   per panel p:  S1 workgroup 0: the diagonal block on the matrix cores -- chol_diag_mfma_body, the SAME code as the
+//                    pipeline's diagonal-block kernel (0.3 us per pivot) -> U_pp and U_pp^-1
+//                 S2 block row p right of it: U_pj = U_pp^-T W_pj, a 64-column strip per workgroup
+//                 S3 trailing 64 x 64 tiles: W_ij -= U_pi^T U_pj
+//   Y = U^-T in 16-column slabs (no barrier inside: Y_ip = -U_ii^-T sum_{k=p}^{i-1} U_ki^T Y_kp), C = Y^T Y tile by tile,
+//   written to both triangles.  3 P + 3 barriers for P = F / 128 panels; the products are plain float64 FMAs out of LDS
+//   (64 x 64 x 64 per workgroup and turn) -- the flops (F^3) are nothing here.
+// m, diag C, sum(G o C) follow in rr_posterior_rows_kernel as before; a pivot that is not positive leaves -1 in the
+// factor's diagonal and the host reports RR_ERR_NOT_POSDEF exactly as the pipeline does.
+// (First version, 64-column panels factored by an unblocked loop out of LDS: 0.8 us per pivot, 1.35 ms at F = 512.)
 // =============================================================================================
 constexpr int PS_NB = 64, PS_WG = 32, PS_T = 256, PS_LD = PS_NB + 1;
 
 struct PsArgs {
     const double *G, *iL;
     double ivar;
-    int F, Fp, P;
-    double *A, *M, *C, *dvec;
+    int F, Fp, P;      // P panels of PB = 128 columns
+    double *A, *M, *C, *dvec, *Uinv;
     unsigned int *bar;
     long long *prof;  // RR_PS_PROF=1: workgroup 0's 100 MHz ticks per phase
 };
@@ -566,8 +577,10 @@ __device__ __forceinline__ void ps_barrier(unsigned int *ctr, unsigned int targe
     __threadfence();
 }
 
+typedef double (*ps_tile)[PS_LD];
+
 // LDS block loads of a 64 x 64 block of a row-major matrix: dst[r][c] = src[r][c] or dst[c][r] = src[r][c]
-__device__ __forceinline__ void ps_load(double (*dst)[PS_LD], const double *src, int64_t ld, bool transpose) {
+__device__ __forceinline__ void ps_load(ps_tile dst, const double *src, int64_t ld, bool transpose) {
     for (int e = threadIdx.x; e < PS_NB * PS_NB; e += PS_T) {
         const int r = e >> 6, c = e & 63;
         const double v = src[(int64_t)r * ld + c];
@@ -594,9 +607,25 @@ __device__ __forceinline__ void ps_mma(const double (*As)[PS_LD], const double (
     }
 }
 
-__global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p) {
-    __shared__ double L0[PS_NB][PS_LD], L1[PS_NB][PS_LD], Pp[4][PS_NB];
+// out (row tm, columns 4 tn .. 4 tn + 3 of a 64 x 16 slab) += sum_t As[t][tm] Bs[t][4 tn + v]   (thread = (tm = tid / 4, tn = tid % 4))
+__device__ __forceinline__ void ps_mma16(const double (*As)[PS_LD], const double (*Bs)[PS_LD], int bcol0, double (&acc)[4]) {
+    const int tm = threadIdx.x >> 2, tn = threadIdx.x & 3;
+#pragma unroll 8
+    for (int t = 0; t < PS_NB; ++t) {
+        const double a = As[t][tm];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] = fma(a, Bs[t][bcol0 + 4 * tn + v], acc[v]);
+    }
+}
+
+__global__ void __launch_bounds__(PS_T) rr_posterior_coop_kernel(const PsArgs p) {
+    // one LDS block: the diagonal-block body's (S | Rv | Tw | flag) or four 64 x 65 tiles of the products
+    __shared__ __attribute__((aligned(16))) double lds[PB * SLD + 8 * CB * RLD + 4 * CB * RLD + 2];
+    ps_tile L0 = (ps_tile)lds, L1 = (ps_tile)(lds + PS_NB * PS_LD), L2 = (ps_tile)(lds + 2 * PS_NB * PS_LD),
+            L3 = (ps_tile)(lds + 3 * PS_NB * PS_LD);
     const int tid = threadIdx.x, wg = blockIdx.x, F = p.F, P = p.P;
+    const int64_t ld = p.Fp;
+    const int n64 = p.Fp / PS_NB;   // 64-column tiles per row
     long long tprev = p.prof ? wall_clock64() : 0, pacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define PS_MARK(i)                                                  \
     do {                                                            \
@@ -606,9 +635,8 @@ __global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p
             tprev = now_;                                           \
         }                                                           \
     } while (0)
-    const int64_t ld = p.Fp;
     unsigned int nbar = 0;
-    // ---- assemble (lower triangle and diagonal; identity on the padding)
+    // ---- assemble (identity on the padding); Y = 0
     for (int64_t e = (int64_t)wg * PS_T + tid; e < ld * ld; e += (int64_t)PS_WG * PS_T) {
         const int64_t r = e / ld, c = e % ld;
         double v = 0.0;
@@ -620,90 +648,73 @@ __global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p
     ps_barrier(p.bar, ++nbar * PS_WG);
     PS_MARK(0);
     for (int pp = 0; pp < P; ++pp) {
-        double *App = p.A + (int64_t)pp * PS_NB * (ld + 1);
-        // ---- S1: the diagonal block, by workgroup 0
+        double *App = p.A + (int64_t)pp * PB * (ld + 1);
+        double *Ui = p.Uinv + (int64_t)pp * PB * PB;
+        // ---- S1: the diagonal block, by workgroup 0, on the matrix cores
         if (wg == 0) {
-            ps_load(L0, App, ld, false);
+            chol_diag_mfma_body(App, ld, Ui, lds, lds + PB * SLD, lds + PB * SLD + 8 * CB * RLD, (int *)(lds + PB * SLD + 12 * CB * RLD));
+            __threadfence_block();
             __syncthreads();
-            for (int k = 0; k < PS_NB; ++k) {
-                if (tid == 0) {
-                    const double d = L0[k][k];
-                    L0[k][k] = d > 0.0 ? sqrt(d) : -1.0;   // (a non-positive pivot: reported through the diagonal)
-                }
-                __syncthreads();
-                const double piv = L0[k][k];
-                if (tid > k && tid < PS_NB) L0[tid][k] /= piv;
-                __syncthreads();
-                {   // trailing block: row r = tid / 4, its columns k < c <= r dealt to the row's four threads
-                    const int r = tid >> 2;
-                    if (r > k) {
-                        const double lrk = L0[r][k];
-                        for (int c = k + 1 + (tid & 3); c <= r; c += 4) L0[r][c] = fma(-lrk, L0[c][k], L0[r][c]);
-                    }
-                }
-                __syncthreads();
-            }
-            for (int e = tid; e < PS_NB * PS_NB; e += PS_T) {
-                const int r = e >> 6, c = e & 63;
-                App[(int64_t)r * ld + c] = c <= r ? L0[r][c] : 0.0;
-            }
-            if (tid < PS_NB) p.dvec[pp * PS_NB + tid] = L0[tid][tid];
+            if (tid < PB) p.dvec[pp * PB + tid] = App[(int64_t)tid * (ld + 1)];
         }
         PS_MARK(1);
         ps_barrier(p.bar, ++nbar * PS_WG);
         PS_MARK(2);
-        // ---- S2: A_ip <- A_ip L_pp^-T for the block rows below (x L^T = a, row by row: a thread per row)
-        if (pp + 1 < P) {
-            bool loaded = false;
-            for (int i = pp + 1 + wg; i < P; i += PS_WG) {
-                if (!loaded) {
-                    ps_load(L0, App, ld, false);
-                    loaded = true;
+        // ---- S2: U_p,strip = U_pp^-T W_p,strip for the 64-column strips right of the diagonal block: rows 0..63 need the
+        // top-left quarter of U_pp^-1 only (it is upper triangular), rows 64..127 the two right quarters
+        for (int ct = (pp + 1) * 2 + wg; ct < n64; ct += PS_WG) {
+            double *strip = p.A + (int64_t)pp * PB * ld + (int64_t)ct * PS_NB;
+            __syncthreads();
+            ps_load(L0, strip, ld, false);                          // W rows 0..63   [t][n]
+            ps_load(L1, strip + (int64_t)PS_NB * ld, ld, false);    // W rows 64..127 [t][n]
+            ps_load(L2, Ui, PB, false);                             // Uinv[0:64][0:64]    [t][m]
+            __syncthreads();
+            double top[4][4] = {}, bot[4][4] = {};
+            ps_mma(L2, L0, top);
+            __syncthreads();
+            ps_load(L2, Ui + PS_NB, PB, false);                     // Uinv[0:64][64:128]  [t][m]
+            ps_load(L3, Ui + (int64_t)PS_NB * PB + PS_NB, PB, false);   // Uinv[64:128][64:128]
+            __syncthreads();
+            ps_mma(L2, L0, bot);
+            ps_mma(L3, L1, bot);
+            const int tm = tid >> 4, tn = tid & 15;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    strip[(int64_t)(4 * tm + u) * ld + 4 * tn + v] = top[u][v];
+                    strip[(int64_t)(PS_NB + 4 * tm + u) * ld + 4 * tn + v] = bot[u][v];
                 }
-                double *Aip = p.A + ((int64_t)i * PS_NB) * ld + (int64_t)pp * PS_NB;
-                ps_load(L1, Aip, ld, false);
-                __syncthreads();
-                {   // x L_pp^T = a for the block's 64 rows at once: column k needs columns t < k of every row -- lane = row,
-                    // the sum over t dealt to the four waves, partial sums through LDS (two barriers per column)
-                    const int r = tid & 63, g = tid >> 6;
-                    for (int k = 0; k < PS_NB; ++k) {
-                        double part = 0.0;
-                        for (int t = g; t < k; t += 4) part = fma(L1[r][t], L0[k][t], part);
-                        Pp[g][r] = part;
-                        __syncthreads();
-                        if (g == 0) L1[r][k] = (L1[r][k] - (Pp[0][r] + Pp[1][r] + Pp[2][r] + Pp[3][r])) / L0[k][k];
-                        __syncthreads();
-                    }
-                }
-                for (int e = tid; e < PS_NB * PS_NB; e += PS_T) Aip[(int64_t)(e >> 6) * ld + (e & 63)] = L1[e >> 6][e & 63];
-                __syncthreads();
-            }
         }
         PS_MARK(3);
         ps_barrier(p.bar, ++nbar * PS_WG);
         PS_MARK(4);
-        // ---- S3: trailing tiles (i, k), pp < k <= i: A_ik -= A_ip A_kp^T
+        // ---- S3: trailing 64 x 64 tiles (i, j), (pp + 1) 2 <= i <= j: W_ij -= U_p,i^T U_p,j (128 rows of block row pp)
         {
-            const int n = P - pp - 1, ntile = n * (n + 1) / 2;
+            const int i0 = (pp + 1) * 2, n = n64 - i0, ntile = n * (n + 1) / 2;
             for (int t = wg; t < ntile; t += PS_WG) {
-                int i = 0, rem = t;
-                while (rem > i) {  // row i of the triangle holds i + 1 tiles
-                    rem -= i + 1;
-                    ++i;
+                int jr = 0, rem = t;
+                while (rem > jr) {  // column jr of the triangle holds jr + 1 tiles (i <= j)
+                    rem -= jr + 1;
+                    ++jr;
                 }
-                const int bi = pp + 1 + i, bk = pp + 1 + rem;
-                ps_load(L0, p.A + ((int64_t)bi * PS_NB) * ld + (int64_t)pp * PS_NB, ld, true);   // As[t][m] = A_ip[m][t]
-                ps_load(L1, p.A + ((int64_t)bk * PS_NB) * ld + (int64_t)pp * PS_NB, ld, true);   // Bs[t][n] = A_kp[n][t]
+                const int bi = i0 + rem, bj = i0 + jr;
+                const double *Ui_ = p.A + (int64_t)pp * PB * ld + (int64_t)bi * PS_NB, *Uj_ = p.A + (int64_t)pp * PB * ld + (int64_t)bj * PS_NB;
+                __syncthreads();
+                ps_load(L0, Ui_, ld, false);                          // [t][m], rows 0..63
+                ps_load(L1, Uj_, ld, false);                          // [t][n]
+                ps_load(L2, Ui_ + (int64_t)PS_NB * ld, ld, false);    // rows 64..127
+                ps_load(L3, Uj_ + (int64_t)PS_NB * ld, ld, false);
                 __syncthreads();
                 double acc[4][4] = {};
                 ps_mma(L0, L1, acc);
-                double *Aik = p.A + ((int64_t)bi * PS_NB) * ld + (int64_t)bk * PS_NB;
+                ps_mma(L2, L3, acc);
+                double *Wij = p.A + (int64_t)bi * PS_NB * ld + (int64_t)bj * PS_NB;
                 const int tm = tid >> 4, tn = tid & 15;
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) Aik[(int64_t)(4 * tm + u) * ld + 4 * tn + v] -= acc[u][v];
-                __syncthreads();
+                    for (int v = 0; v < 4; ++v) Wij[(int64_t)(4 * tm + u) * ld + 4 * tn + v] -= acc[u][v];
             }
         }
         PS_MARK(5);
@@ -717,6 +728,7 @@ __global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p
             const double d = p.dvec[i];
             mn = fmin(mn, (d > 0.0 && d == d) ? d : -1.0);
         }
+        __syncthreads();
         L0[0][tid & 63] = INFINITY;
         __syncthreads();
         for (int w = 0; w < 4; ++w) {   // (four waves, one after the other: a min over 256 values without atomics)
@@ -732,86 +744,78 @@ __global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p
         if (L0[1][0] < 1e-5) return;   // CHOLTHRESH, mathfun/linalg.py:31 (no barrier follows for anybody)
         __syncthreads();
     }
-    // ---- T_i = L_ii^-1 into M's diagonal blocks (a thread per column)
-    for (int i = wg; i < P; i += PS_WG) {
-        ps_load(L0, p.A + (int64_t)i * PS_NB * (ld + 1), ld, false);
-        __syncthreads();
-        {   // L_ii X = I row by row: row r needs rows t < r of every column -- lane = column, the sum over t dealt to the waves
-            const int c = tid & 63, g = tid >> 6;
-            for (int r = 0; r < PS_NB; ++r) {
-                double part = 0.0;
-                for (int t = g; t < r; t += 4) part = fma(L0[r][t], L1[t][c], part);
-                Pp[g][c] = part;
-                __syncthreads();
-                if (g == 0) L1[r][c] = ((r == c ? 1.0 : 0.0) - (Pp[0][c] + Pp[1][c] + Pp[2][c] + Pp[3][c])) / L0[r][r];
-                __syncthreads();
-            }
-        }
-        double *Mii = p.M + (int64_t)i * PS_NB * (ld + 1);
-        for (int e = tid; e < PS_NB * PS_NB; e += PS_T) Mii[(int64_t)(e >> 6) * ld + (e & 63)] = L1[e >> 6][e & 63];
-        __syncthreads();
-    }
-    ps_barrier(p.bar, ++nbar * PS_WG);
-    PS_MARK(7);
-    // ---- M = L^-1 below the diagonal: slab (block column pb, 16 columns q) walks down its block rows
+    // ---- Y = U^-T (lower): 16-column slabs of block column pb walk down the 64-row blocks below; Y_pp = (U_pp^-1)^T
     {
-        // LDS: L0 = the 64 x 64 left operand (L_ik, then T_i); L1 columns [0, 16) = the slab rows of M_k, columns [32, 48) = R
-        for (int item = wg; item < P * 4; item += PS_WG) {
-            const int pb = item >> 2, q = item & 3;
-            const int tm = tid >> 2, tn = tid & 3;   // output (row tm, columns 4 tn .. 4 tn + 3) of a 64 x 16 slab
-            for (int i = pb + 1; i < P; ++i) {
-                double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int k = pb; k < i; ++k) {
+        const int tm = tid >> 2, tn = tid & 3;
+        for (int item = wg; item < P * 8; item += PS_WG) {
+            const int pb = item >> 3, q = item & 7, c0 = pb * PB + 16 * q;   // global columns c0 .. c0 + 15
+            // rows of block pb: Y[pb PB + r][c0 + c] = Uinv_pb[16 q + c][r]  (transposed read; zero above the diagonal by itself)
+            {
+                const double *Up = p.Uinv + (int64_t)pb * PB * PB;
+                for (int e = tid; e < PB * 16; e += PS_T) {
+                    const int r = e >> 4, c = e & 15;
+                    p.M[((int64_t)pb * PB + r) * ld + c0 + c] = Up[(int64_t)(16 * q + c) * PB + r];
+                }
+                __threadfence_block();
+            }
+            for (int i = pb + 1; i < P; ++i) {        // 128-row block i of the slab
+                double acc0[4] = {0.0, 0.0, 0.0, 0.0}, acc1[4] = {0.0, 0.0, 0.0, 0.0};   // rows 0..63 / 64..127 of R = sum_k U_ki^T Y_k
+                for (int kh = pb * 2; kh < i * 2; ++kh) {   // 64-row blocks kh of U's block column i and of the slab
                     __syncthreads();
-                    ps_load(L0, p.A + ((int64_t)i * PS_NB) * ld + (int64_t)k * PS_NB, ld, false);   // L_ik[m][t]
-                    {
-                        const double *Mk = p.M + ((int64_t)k * PS_NB) * ld + (int64_t)pb * PS_NB + 16 * q;   // M_k,slab[t][c]
-                        for (int e = tid; e < PS_NB * 16; e += PS_T) L1[e >> 4][e & 15] = Mk[(int64_t)(e >> 4) * ld + (e & 15)];
-                    }
+                    ps_load(L0, p.A + (int64_t)kh * PS_NB * ld + (int64_t)i * PB, ld, false);            // U[kh][i, left half]  [t][m]
+                    ps_load(L1, p.A + (int64_t)kh * PS_NB * ld + (int64_t)i * PB + PS_NB, ld, false);    // right half
+                    for (int e = tid; e < PS_NB * 16; e += PS_T)
+                        L2[e >> 4][e & 15] = p.M[((int64_t)kh * PS_NB + (e >> 4)) * ld + c0 + (e & 15)];  // Y rows of block kh  [t][c]
                     __syncthreads();
-#pragma unroll 8
-                    for (int t = 0; t < PS_NB; ++t) {
-                        const double a = L0[tm][t];
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) acc[v] = fma(a, L1[t][4 * tn + v], acc[v]);
-                    }
+                    ps_mma16(L0, L2, 0, acc0);
+                    ps_mma16(L1, L2, 0, acc1);
                 }
                 __syncthreads();
 #pragma unroll
-                for (int v = 0; v < 4; ++v) L1[tm][32 + 4 * tn + v] = acc[v];
-                ps_load(L0, p.M + (int64_t)i * PS_NB * (ld + 1), ld, false);   // T_i
-                __syncthreads();
-                double o[4] = {0.0, 0.0, 0.0, 0.0};
-                for (int t = 0; t <= tm; ++t) {   // (T_i is lower triangular)
-                    const double a = L0[tm][t];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) o[v] = fma(a, L1[t][32 + 4 * tn + v], o[v]);
+                for (int v = 0; v < 4; ++v) {
+                    L2[tm][32 + 4 * tn + v] = acc0[v];          // R rows 0..63   in columns [32, 48)
+                    L3[tm][32 + 4 * tn + v] = acc1[v];          // R rows 64..127
                 }
-                double *Mi = p.M + ((int64_t)i * PS_NB) * ld + (int64_t)pb * PS_NB + 16 * q;
+                // Y_i = -U_ii^-T R = -Uinv_i^T R:  out[m][c] = -sum_t Uinv_i[t][m] R[t][c], t <= m (upper triangular)
+                const double *Uii = p.Uinv + (int64_t)i * PB * PB;
+                ps_load(L0, Uii, PB, false);                         // Uinv[0:64][0:64]
+                ps_load(L1, Uii + PS_NB, PB, false);                 // Uinv[0:64][64:128]
+                __syncthreads();
+                double o0[4] = {0.0, 0.0, 0.0, 0.0}, o1[4] = {0.0, 0.0, 0.0, 0.0};
+                ps_mma16(L0, L2, 32, o0);                            // rows 0..63:   t in [0, 64)
+                ps_mma16(L1, L2, 32, o1);                            // rows 64..127: t in [0, 64) ...
+                __syncthreads();
+                ps_load(L0, Uii + (int64_t)PS_NB * PB + PS_NB, PB, false);   // Uinv[64:128][64:128]
+                __syncthreads();
+                ps_mma16(L0, L3, 32, o1);                            // ... and t in [64, 128)
+                double *Yi = p.M + ((int64_t)i * PB) * ld + c0;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) Mi[(int64_t)tm * ld + 4 * tn + v] = -o[v];
-                __threadfence_block();   // (this workgroup reads the slab back in the next block row's sums)
+                for (int v = 0; v < 4; ++v) {
+                    Yi[(int64_t)tm * ld + 4 * tn + v] = -o0[v];
+                    Yi[(int64_t)(PS_NB + tm) * ld + 4 * tn + v] = -o1[v];
+                }
+                __threadfence_block();   // (this workgroup reads the slab back in the next block's sums)
             }
         }
     }
+    PS_MARK(7);
     ps_barrier(p.bar, ++nbar * PS_WG);
     PS_MARK(8);
-    // ---- C = M^T M: tile (i, k), k <= i: sum over block rows r >= i of M_ri^T M_rk; both triangles of the (F, F) output
+    // ---- C = Y^T Y: 64 x 64 tile (a, b), b <= a: sum over 64-row blocks r >= a of Y_r,a^T Y_r,b; both triangles of the output
     {
-        const int ntile = P * (P + 1) / 2;
+        const int ntile = n64 * (n64 + 1) / 2;
         for (int t = wg; t < ntile; t += PS_WG) {
-            // heavy tiles first: enumerate i ascending (tile (i, k) sums P - i products)
-            int i = 0, rem = t;
-            while (rem > i) {
-                rem -= i + 1;
-                ++i;
+            int a = 0, rem = t;   // a ascending: the tiles with the longest sums first
+            while (rem > a) {
+                rem -= a + 1;
+                ++a;
             }
-            const int k = rem;
+            const int b = rem;
             double acc[4][4] = {};
-            for (int r = i; r < P; ++r) {
+            for (int r = a; r < n64; ++r) {
                 __syncthreads();
-                ps_load(L0, p.M + ((int64_t)r * PS_NB) * ld + (int64_t)i * PS_NB, ld, false);   // As[t][m] = M_ri[t][m]
-                ps_load(L1, p.M + ((int64_t)r * PS_NB) * ld + (int64_t)k * PS_NB, ld, false);   // Bs[t][n] = M_rk[t][n]
+                ps_load(L0, p.M + (int64_t)r * PS_NB * ld + (int64_t)a * PS_NB, ld, false);   // [t][m]
+                ps_load(L1, p.M + (int64_t)r * PS_NB * ld + (int64_t)b * PS_NB, ld, false);   // [t][n]
                 __syncthreads();
                 ps_mma(L0, L1, acc);
             }
@@ -820,7 +824,7 @@ __global__ void __launch_bounds__(PS_T) rr_posterior_small_kernel(const PsArgs p
             for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
-                    const int64_t gr = (int64_t)i * PS_NB + 4 * tm + u, gc = (int64_t)k * PS_NB + 4 * tn + v;
+                    const int64_t gr = (int64_t)a * PS_NB + 4 * tm + u, gc = (int64_t)b * PS_NB + 4 * tn + v;
                     if (gr < F && gc < F) {
                         p.C[gr * F + gc] = acc[u][v];
                         p.C[gc * F + gr] = acc[u][v];
@@ -965,16 +969,14 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
     const double ivar = 1.0 / var;
     RR_CHECK_HIP(hipMemcpyAsync(s.diL, iL, (size_t)F * 8, hipMemcpyHostToDevice, c->stream));
     // small feature counts: the whole factorisation, inverse and C in ONE cooperative launch -- OPT-IN (RR_POSDEF_SMALL=1).
-    // Measured at config 1 (F = 512) and not adopted: 1.35 ms per call (S1 410 us: 0.8 us per pivot of the unblocked
-    // diagonal-block factorisation out of LDS; S2 307; M 222; C 112; 27 barriers 136) against ~0.75 ms for the panel
-    // pipeline's share of `_elbo` -- its diagonal blocks run at 0.3 us per pivot on the matrix cores
-    // (rr_chol_diag_mfma_kernel).  One launch is not the point; the pivot chain is.  Kept for the next attempt and held to
-    // the oracle by tests/test_gpu_posterior.py.
+    // Measured at config 1 (F = 512) and not adopted: 0.82 ms per call (S1 174 us, S2 138, S3 83, Y 192, C 117, barriers
+    // 100) against ~0.46 ms for the panel pipeline's share of `_elbo`: the pipeline's three streams overlap what this kernel
+    // runs in sequence.  Kept for the next attempt and held to the oracle by tests/test_gpu_posterior.py.
     const char *small_env = getenv("RR_POSDEF_SMALL");
     if (F <= 1024 && small_env != nullptr && atoi(small_env) != 0 && c->num_cu >= PS_WG) {
         PsArgs a;
-        a.G = dG; a.iL = s.diL; a.ivar = ivar; a.F = (int)F; a.Fp = (int)Fp; a.P = (int)(Fp / PS_NB);
-        a.A = s.W; a.M = s.Y; a.C = dC; a.dvec = s.dvec; a.bar = s.bar;
+        a.G = dG; a.iL = s.diL; a.ivar = ivar; a.F = (int)F; a.Fp = (int)Fp; a.P = (int)(Fp / PB);
+        a.A = s.W; a.M = s.Y; a.C = dC; a.dvec = s.dvec; a.bar = s.bar; a.Uinv = s.Uinv;
         static long long *dprof = nullptr;
         static int prof_calls = 0;
         if (getenv("RR_PS_PROF") && !dprof && hipMalloc((void **)&dprof, 80) == hipSuccess) (void)hipMemset(dprof, 0, 80);
@@ -982,13 +984,13 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         if (dprof && ++prof_calls % 50 == 0) {
             long long h[10];
             (void)hipMemcpy(h, dprof, 80, hipMemcpyDeviceToHost);
-            static const char *nm[] = {"assemble", "S1", "bar1", "S2", "bar2", "S3", "bar3", "T+bar", "M+bar", "C"};
-            fprintf(stderr, "rr_posterior_small (us per call over %d calls):", prof_calls - 1);
+            static const char *nm[] = {"assemble", "S1", "bar1", "S2", "bar2", "S3", "bar3", "Y", "bar", "C"};
+            fprintf(stderr, "rr_posterior_coop (us per call over %d calls):", prof_calls - 1);
             for (int i = 0; i < 10; ++i) fprintf(stderr, " %s=%.1f", nm[i], 0.01 * (double)h[i] / (prof_calls - 1));
             fprintf(stderr, "\n");
         }
         RR_CHECK_HIP(hipMemsetAsync(s.bar, 0, 64, c->stream));
-        hipLaunchKernelGGL(rr_posterior_small_kernel, dim3(PS_WG), dim3(PS_T), 0, c->stream, a);
+        hipLaunchKernelGGL(rr_posterior_coop_kernel, dim3(PS_WG), dim3(PS_T), 0, c->stream, a);
         RR_CHECK_HIP(hipGetLastError());
         double *dm = s.dvec + Fp, *ddg = s.dvec + 2 * Fp, *dtr = s.dvec + 3 * Fp;
         RR_CHECK_HIP(hipMemsetAsync(dtr, 0, 8, c->stream));

@@ -147,7 +147,7 @@ def test_not_positive_definite_in_a_late_panel_is_reported_and_leaves_nothing_in
 @pytest.mark.parametrize("F", [1, 5, 64, 100, 256, 300, 512, 1000, 1024])
 def test_small_posterior_in_one_launch_vs_oracle(F, mode, monkeypatch):
     """(opt-in route, RR_POSDEF_SMALL=1: measured slower than the panel pipeline at F = 512 and kept for its next attempt.)
-    F <= 1024 (BASELINE config 1 is F = 512): rr_posterior_small_kernel -- factor, inverse and C in ONE cooperative launch
+    F <= 1024 (BASELINE config 1 is F = 512): rr_posterior_coop_kernel -- factor, inverse and C in ONE cooperative launch
     (32 workgroups, device-scope barriers) -- against the oracle's solve_posdef (mathfun/linalg.py:84-125): C, m, diag C,
     log|iC|, sum(G o C); ragged F (padding to 64-column panels), F below one panel."""
     from revrand_amd import _hip
