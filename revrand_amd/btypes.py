@@ -9,6 +9,33 @@ import numpy as np
 from sklearn.utils import check_random_state
 
 
+def _frozen_rvs(dist, shape, rs):
+    """`dist.rvs(size=shape, random_state=rs)` for the two frozen scipy.stats distributions the estimators' Parameters use --
+    `norm` (glm.py:40, the mixture means) and `gamma` (glm.py:41, basis_functions.py:210: covariances, regularisers, length
+    scales, the Gaussian's variance) -- by the calls scipy itself ends in (`random_state.standard_normal(size)`,
+    `random_state.standard_gamma(a, size)`, then `* scale + loc`): the same values from the same stream, without the ~25 us
+    of argument checking per call that made up half of a default-shaped GLM fit's random starts (4000 calls).  None: not one
+    of these (scipy's own `rvs` then)."""
+    gen = getattr(dist, "dist", None)
+    name = getattr(gen, "name", None)
+    if name not in ("norm", "gamma") or type(rs) is not np.random.RandomState:
+        return None
+    try:
+        args, loc, scale = gen._parse_args(*dist.args, **dist.kwds)
+    except Exception:
+        return None
+    if not (np.ndim(loc) == 0 and np.ndim(scale) == 0 and all(np.ndim(a) == 0 for a in args)) or not scale > 0:
+        return None
+    if name == "norm":
+        vals = rs.standard_normal(shape)
+    else:
+        if len(args) != 1 or not args[0] > 0:
+            return None
+        vals = rs.standard_gamma(args[0], shape)
+    vals = vals * scale + loc
+    return vals[()] if shape == () else vals
+
+
 class _BoundChecks(object):
     """check()/clip() shared by Bound and Positive (btypes.py:12-79)."""
 
@@ -84,7 +111,8 @@ class Parameter(object):
         if self.dist is None:
             return self.value
         rs = check_random_state(random_state)
-        return self.bounds.clip(self.dist.rvs(size=self.shape, random_state=rs))
+        fast = _frozen_rvs(self.dist, self.shape, rs)
+        return self.bounds.clip(fast if fast is not None else self.dist.rvs(size=self.shape, random_state=rs))
 
     @property
     def has_value(self):

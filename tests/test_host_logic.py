@@ -785,3 +785,26 @@ def test_multigpu_host_logic_shards_sums_and_routes():
         s, e = smf.bounds[i]
         assert np.all((idx[pos] >= s) & (idx[pos] < e)) and np.array_equal(local, idx[pos] - s)
     assert [p[0] for p in smf._split_rows(5000)] == [0, 1] and [p[0] for p in smf._split_rows(100)] == [0]
+
+
+def test_parameter_draws_equal_scipys_without_its_overhead():
+    """btypes.Parameter.rvs (btypes.py:290-324) for the frozen `norm` / `gamma` distributions the estimators use goes straight
+    to RandomState.standard_normal / standard_gamma -- the calls scipy's rvs ends in: same values, same type, same stream
+    afterwards; anything else is scipy's own rvs."""
+    from scipy.stats import gamma, norm, uniform
+    from revrand_amd.btypes import Bound, Parameter, Positive, _frozen_rvs
+    for dist in (norm(), norm(1.5, 0.3), norm(loc=-2, scale=4), gamma(1.), gamma(a=2, scale=0.5), gamma(4., scale=0.25),
+                 gamma(3., loc=1.0, scale=2.0)):
+        for shape in ((), (3,), (7, 4), (83, 10)):
+            r1, r2 = np.random.RandomState(5), np.random.RandomState(5)
+            a, b = _frozen_rvs(dist, shape, r1), dist.rvs(size=shape, random_state=r2)
+            assert a is not None and type(a) is type(b) and np.array_equal(np.asarray(a), np.asarray(b))
+            assert r1.randn() == r2.randn()
+            for bounds in (Positive(), Bound(0.2, 1.1)):
+                p = Parameter(dist, bounds, shape=shape)
+                r1, r2 = np.random.RandomState(9), np.random.RandomState(9)
+                assert np.array_equal(np.asarray(p.rvs(r1)), np.asarray(bounds.clip(dist.rvs(size=shape, random_state=r2))))
+    assert _frozen_rvs(uniform(), (2,), np.random.RandomState(0)) is None          # not one of the two: scipy's rvs
+    assert _frozen_rvs(norm(), (2,), np.random.default_rng(0)) is None             # not a legacy RandomState
+    p = Parameter(uniform(0.5, 1.0), Positive(), shape=(3,))
+    assert np.array_equal(p.rvs(np.random.RandomState(3)), uniform(0.5, 1.0).rvs(size=(3,), random_state=np.random.RandomState(3)))
