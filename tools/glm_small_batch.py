@@ -46,6 +46,6 @@ for resident in (True, False, True, False):
     if marks:
         print("   upload stage per batch: median %.0f us" % (1e6 * np.median(marks)))
     ck = glm.__dict__.get("_resident_clock")
-    if ck is not None:
+    if ck is not None and len(ck) > 24:   # (the step-per-call loop's per-step clock; the fused loop records one time per launch)
         dt = 1e6 * np.diff(ck[20:-2])
         print("   step intervals: mean %.0f us, median %.0f us, p90 %.0f us" % (dt.mean(), np.median(dt), np.percentile(dt, 90)))
