@@ -217,3 +217,41 @@ def test_shapes_outside_the_fused_range_take_the_step_per_call_loop():
     assert not _hip.svi_supported(83, 64, 50, 10, 3, 6, 2)         # K > 32
     fit, calls = _fit("fused", "poisson", batch=400, maxiter=4)    # 400 rows x 24 features > 8192
     assert calls["steps"] == 0 and calls["resident"] == 4
+
+
+@pytest.mark.parametrize("shape", [dict(nbases=64, d=8, K=8, L=20, batch=16), dict(nbases=20, d=3, K=1, L=5, batch=7),
+                                   dict(nbases=10, d=2, K=32, L=3, batch=1), dict(nbases=33, d=5, K=5, L=1, batch=64),
+                                   dict(nbases=24, d=16, K=6, L=17, batch=33)])
+def test_shapes_across_the_tiles_of_the_matrix_core_products(shape):
+    """The fused loop's two sample products are 16 x 16 x 4 MFMA tiles (samples x rows, rows x features + 1): shapes with
+    several tiles per side, ragged last tiles, one sample / one row / one component, K = 32 workgroups, ARD over 16 inputs --
+    against the host loop (and rr_glm_svi_supported must accept them)."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    from revrand_amd import _hip
+    d, n = shape["d"], shape["nbases"]
+    assert _hip.svi_supported(2 * n, shape["K"], shape["L"], shape["batch"], 1, d, d)
+    rs = np.random.RandomState(9)
+    X = rs.randn(700, d)
+    y = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]) + 0.1 * X[:, -1])).astype(float)
+    out = []
+    for loop in ("fused", "host"):
+        basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
+        glm = GLM(lk.Poisson(), basis, K=shape["K"], nsamples=shape["L"], batch_size=shape["batch"], maxiter=15, nstarts=2,
+                  random_state=4)
+        glm._resident_sgd = loop != "host"
+        steps = [0]
+        real = _hip.FusedSvi.run
+
+        def run(self, nn, *a, **k):
+            steps[0] += nn
+            return real(self, nn, *a, **k)
+        _hip.FusedSvi.run = run
+        try:
+            np.random.seed(2)
+            glm.fit(X, y)
+        finally:
+            _hip.FusedSvi.run = real
+        assert steps[0] == (15 if loop == "fused" else 0)
+        out.append((glm.weights_.copy(), glm.covariance_.copy(), np.atleast_1d(np.asarray(glm.regularizer_, dtype=float)), np.zeros(0),
+                    np.ravel(np.asarray(glm.basis_hypers_, dtype=float)), glm.random_.randn()))
+    _same(out[0], out[1], 5e-5)
