@@ -243,6 +243,11 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                     ctx.sync()
                 except Exception:  # the original exception, if any, is the one to report
                     log.exception("synchronising the upload context failed")
+            if loop is not None:   # (idempotent: whatever the loop still holds on the device -- also when the random starts raised)
+                try:
+                    loop.abort()
+                except Exception:
+                    log.exception("releasing the device loop failed")
             self._resident_fit = False
             self.__dict__.pop("_draw_buffers", None)
             self.__dict__.pop("_draw_ring", None)
