@@ -625,6 +625,57 @@ def gen_glm_fit():
     save("glm_fit", **out)
 
 
+def gen_glm_predict():
+    """The prediction surface of the reference's GeneralizedLinearModel on a model whose fitted attributes are SET (no fit):
+    `_sample_func` (glm.py:572-620: k ~ randint(K), w = m_k + randn sqrt(C_k), f = Phi w), `predict_moments` (:351-393),
+    `predict_logpdf` (:395-444), `predict_cdf` (:446-495) and `predict_interval` (:497-570, brentq per row) for a Gaussian, a
+    Poisson and a binomial likelihood, `random_` re-seeded before every call."""
+    import revrand.glm as rglm
+    import revrand.likelihoods as rl
+    out = {}
+    rs = np.random.RandomState(31)
+    N, d, n, K, S = 40, 3, 6, 3, 50
+    X = rs.randn(N, d)
+    nbin = rs.randint(5, 15, size=N).astype(float)
+    basis = rb.LinearBasis(onescol=True) + rb.RandomRBF(nbases=n, Xdim=d, random_state=8)
+    D = d + 1 + 2 * n
+    m = 0.4 * rs.randn(D, K)
+    C = rs.gamma(2., 0.05, size=(D, K))
+    ls = 1.3
+    yq = {"gaussian": rs.randn(N), "poisson_exp": rs.poisson(2.0, N).astype(float), "binomial": rs.binomial(nbin.astype(int), 0.4).astype(float)}
+    out.update(X=X, nbin=nbin, m=m, C=C, ls=ls, K=K, S=S, W=basis.bases[1].W, **{"yq_" + k: v for k, v in yq.items()})
+    mk = {"gaussian": (rl.Gaussian, [0.3]), "poisson_exp": (lambda: rl.Poisson("exp"), []), "binomial": (rl.Binomial, [])}
+    for lik, (ctor, lhyp) in mk.items():
+        glm = rglm.GeneralizedLinearModel(ctor(), basis, K=K, random_state=0)
+        glm.weights_, glm.covariance_, glm.regularizer_ = m, C, [1.0, 1.0]
+        glm.like_hypers_ = lhyp[0] if lhyp else []
+        glm.basis_hypers_ = ls
+        largs = (nbin,) if lik == "binomial" else ()
+
+        def seeded(fn, *a, **k):
+            glm.random_ = np.random.RandomState(77)
+            return fn(*a, **k)
+        fs = np.array(list(seeded(glm._sample_func, X, S)))                       # (S, N)
+        Ey, Vy = seeded(glm.predict_moments, X, S, likelihood_args=largs)
+        lp = seeded(glm.predict_logpdf, X, yq[lik], S, likelihood_args=largs)
+        q = 2.5 if lik != "gaussian" else 0.2
+        cdf = seeded(glm.predict_cdf, X, q, S, likelihood_args=largs)
+        ql, qu = seeded(glm.predict_interval, X[:12], 0.9, S, likelihood_args=tuple(a[:12] for a in largs), multiproc=False)
+        # the oracle's restatement on the same draws
+        o = orc.glm_predictions(X, m, C, [("linear", True), ("rff", basis.bases[1].W, 1)], [[], ls], lik, lhyp, list(largs), S, 77,
+                                yq[lik], q)
+        close(o["fs"], fs, 1e-12)
+        close(o["Ey"], Ey, 1e-12); close(o["Vy"], Vy, 1e-12)
+        for a, b in zip(o["logpdf"], lp):
+            close(a, b, 1e-12)
+        for a, b in zip(o["cdf"], cdf):
+            close(a, b, 1e-12)
+        out.update({lik + "_fs": fs, lik + "_Ey": Ey, lik + "_Vy": Vy, lik + "_logpdf": np.array(lp), lik + "_cdf": np.array(cdf),
+                    lik + "_q": q, lik + "_ql": ql, lik + "_qu": qu})
+        print("   ", lik, "Ey[:3]", np.round(Ey[:3], 4), "interval[0]", ql[0], qu[0])
+    save("glm_predict", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `make_golden.py fit_c1`
         for name in sys.argv[1:]:
@@ -643,4 +694,5 @@ if __name__ == "__main__":
     gen_fit_converged()
     gen_glm()
     gen_glm_fit()
+    gen_glm_predict()
     print("oracle agrees with the reference on every fixture")

@@ -718,3 +718,56 @@ def glm_fit(X, y, lik, largs, children, regs, likpar, lss, K, L, batch_size, max
     vals = unflat(np.where(pos, np.exp(np.where(pos, z, 0.)), z))
     return (vals[0], vals[1], vals[2:2 + nreg], vals[2 + nreg:2 + nreg + nlik], vals[2 + nreg + nlik:],
             np.array(objs), np.array(norms), rs.randn())
+
+
+def lik_Ey(name, f, *args):
+    """Expected target given the latent function: likelihoods.py Bernoulli :69-84, Binomial :194-211, Gaussian :325-344,
+    Poisson :483-498."""
+    f = np.asarray(f, float)
+    if name == "bernoulli":
+        return _expit(f)
+    if name == "binomial":
+        return _expit(f) * np.asarray(args[0], float)
+    if name == "gaussian":
+        return f
+    if name == "poisson_exp":
+        return np.exp(f)
+    if name == "poisson_softplus":
+        return softplus(f)
+    raise ValueError(name)
+
+
+def lik_cdf(name, y, f, *args):
+    """Cumulative distribution of the target: likelihoods.py :133-150, :241-258, :398-423, :523-545 (scipy.stats' cdfs)."""
+    from scipy.stats import bernoulli, binom, norm, poisson
+    if name == "bernoulli":
+        return bernoulli.cdf(y, _expit(f))
+    if name == "binomial":
+        return binom.cdf(y, n=args[0], p=_expit(f))
+    if name == "gaussian":
+        return norm.cdf(y, loc=f, scale=np.sqrt(args[0]))
+    if name == "poisson_exp":
+        return poisson.cdf(y, mu=np.exp(f))
+    if name == "poisson_softplus":
+        return poisson.cdf(y, mu=softplus(f))
+    raise ValueError(name)
+
+
+def glm_predictions(X, m, C, children, bpars, lik, lpars, largs, nsamples, seed, yq, q):
+    """GeneralizedLinearModel's Monte-Carlo predictions (glm.py:351-495, 572-620), every call on a RandomState freshly
+    seeded with `seed`: the draws are `randint(0, K, nsamples)` then `randn(D, nsamples)`; latent samples f_s = Phi w_s;
+    moments of E[y | f_s], mean / min / max over the samples of the log-density of yq and of the CDF at q."""
+    D, K = m.shape
+    rs = np.random.RandomState(seed)
+    k = rs.randint(0, K, size=(nsamples,))
+    w = m[:, k] + rs.randn(D, nsamples) * np.sqrt(C[:, k])
+    Phi = glm_features(children)(np.asarray(X, float), bpars)[0]
+    fs = (Phi @ w).T                                                                      # (S, N)
+    pars = list(lpars) + list(largs)
+    ys = np.stack([lik_Ey(lik, f, *pars) for f in fs], axis=1)                            # (N, S)
+    Ey = ys.mean(axis=1)
+    Vy = ((ys - Ey[:, None]) ** 2).mean(axis=1)
+    lp = np.stack([lik_loglike(lik, yq, f, *pars) for f in fs], axis=1)
+    cd = np.stack([lik_cdf(lik, q, f, *pars) for f in fs], axis=1)
+    return {"fs": fs, "Ey": Ey, "Vy": Vy, "logpdf": (lp.mean(axis=1), lp.min(axis=1), lp.max(axis=1)),
+            "cdf": (cd.mean(axis=1), cd.min(axis=1), cd.max(axis=1))}

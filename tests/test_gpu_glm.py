@@ -625,3 +625,46 @@ def test_objective_only_step_equals_full_objective(sampler):
               nstarts=6, maxiter=20, batch_size=500)
     glm.fit(X, y)
     assert np.isfinite(glm.predict(X[:20])).all()
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "poisson_exp", "binomial"])
+def test_prediction_surface_vs_reference(golden, lik):
+    """`_sample_func`, `predict_moments`, `predict_logpdf`, `predict_cdf`, `predict_interval` of a model whose fitted attributes
+    are set, `random_` seeded as the reference's was (tests/golden/glm_predict.npz, oracle/make_golden.py: gen_glm_predict):
+    the reference's draws (randint then randn, glm.py:606-610), the latent samples f = Phi w from the device
+    (rr_featmat_project), the likelihoods' Ey / loglike / cdf, and the intervals -- the reference root-finds per row with
+    brentq (glm.py:659-690), here every row is bisected at once: the same quantiles (for the count likelihoods the sampled CDF
+    is a step function and both land on the step)."""
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd.glm import GeneralizedLinearModel
+    g = golden("glm_predict")
+    X, K, S = g["X"], int(g["K"]), int(g["S"])
+    d = X.shape[1]
+    basis = bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=g["W"].shape[1], Xdim=d, random_state=8)
+    assert np.array_equal(basis.bases[1].W, g["W"])
+    like = {"gaussian": lk.Gaussian, "poisson_exp": lambda: lk.Poisson("exp"), "binomial": lk.Binomial}[lik]()
+    glm = GeneralizedLinearModel(like, basis, K=K, random_state=0)
+    glm.weights_, glm.covariance_, glm.regularizer_ = g["m"], g["C"], [1.0, 1.0]
+    glm.like_hypers_ = 0.3 if lik == "gaussian" else []
+    glm.basis_hypers_ = float(g["ls"])
+    largs = (g["nbin"],) if lik == "binomial" else ()
+
+    def seeded(fn, *a, **k):
+        glm.random_ = np.random.RandomState(77)
+        return fn(*a, **k)
+    fs = np.array(list(seeded(glm._sample_func, X, S)))
+    assert normwise(fs, g[lik + "_fs"]) < 1e-5          # (float32 features on the device)
+    rows = np.array(list(seeded(glm._sample_func, X, S, genaxis=0)))
+    assert normwise(rows, g[lik + "_fs"].T) < 1e-5
+    Ey, Vy = seeded(glm.predict_moments, X, S, likelihood_args=largs)
+    assert normwise(Ey, g[lik + "_Ey"]) < 1e-5 and normwise(Vy, g[lik + "_Vy"]) < 1e-4
+    assert normwise(seeded(glm.predict, X, S, likelihood_args=largs), g[lik + "_Ey"]) < 1e-5
+    lp = seeded(glm.predict_logpdf, X, g["yq_" + lik], S, likelihood_args=largs)
+    assert normwise(np.array(lp), g[lik + "_logpdf"]) < 1e-5
+    cdf = seeded(glm.predict_cdf, X, float(g[lik + "_q"]), S, likelihood_args=largs)
+    assert normwise(np.array(cdf), g[lik + "_cdf"]) < 1e-5
+    ql, qu = seeded(glm.predict_interval, X[:12], 0.9, S, likelihood_args=tuple(a[:12] for a in largs))
+    tol = 1e-4 if lik == "gaussian" else 1e-6
+    assert np.all(np.abs(ql - g[lik + "_ql"]) < tol * np.maximum(1.0, np.abs(g[lik + "_ql"])))
+    assert np.all(np.abs(qu - g[lik + "_qu"]) < tol * np.maximum(1.0, np.abs(g[lik + "_qu"])))

@@ -315,3 +315,17 @@ def test_glm_fit_optimiser_stack(golden, case):
         assert 0.996 <= float(o[4][0]) <= 1.001
     if kind == "posupper":
         assert float(o[4][0]) == pytest.approx(1.03, abs=1e-12)
+
+
+@pytest.mark.parametrize("lik", ["gaussian", "poisson_exp", "binomial"])
+def test_glm_predictions(golden, lik):
+    """`orc.glm_predictions` against the reference's `_sample_func` / `predict_moments` / `predict_logpdf` / `predict_cdf`
+    (glm.py:351-495, 572-620) on the reference's own draws."""
+    g = golden("glm_predict")
+    largs = [g["nbin"]] if lik == "binomial" else []
+    lhyp = [0.3] if lik == "gaussian" else []
+    o = orc.glm_predictions(g["X"], g["m"], g["C"], [("linear", True), ("rff", g["W"], 1)], [[], float(g["ls"])], lik, lhyp, largs,
+                            int(g["S"]), 77, g["yq_" + lik], float(g[lik + "_q"]))
+    assert normwise(o["fs"], g[lik + "_fs"]) < 1e-12
+    assert normwise(o["Ey"], g[lik + "_Ey"]) < 1e-12 and normwise(o["Vy"], g[lik + "_Vy"]) < 1e-12
+    assert normwise(np.array(o["logpdf"]), g[lik + "_logpdf"]) < 1e-12 and normwise(np.array(o["cdf"]), g[lik + "_cdf"]) < 1e-12
