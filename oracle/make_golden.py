@@ -676,6 +676,41 @@ def gen_glm_predict():
     save("glm_predict", **out)
 
 
+def gen_slm_starts():
+    """The random starts of `StandardLinearModel.fit` (slm.py:74-140 -> structured_minimizer, decorators.py:24-130, 541-583): with
+    distributions as initial values the reference first draws a start from `random_` (the flatten of :79-84), then `nstarts`
+    candidates, each scored by `_elbo`, and hands the best to L-BFGS-B.  maxiter = 0 makes `fit` return that start: stored
+    with every candidate's objective (spy on `_elbo`) and `random_.randn()` afterwards."""
+    from scipy.stats import gamma
+    out = {}
+    rs = np.random.RandomState(41)
+    N, d, n = 300, 3, 10
+    X = rs.randn(N, d)
+    y = np.sin(X @ np.array([1.0, -0.5, 0.3])) + 0.1 * rs.randn(N)
+    out.update(X=X, y=y)
+    for tag, ns in (("ns6", 6), ("ns1", 1)):
+        basis = rb.RandomRBF(nbases=n, Xdim=d, random_state=9, lenscale=Parameter(gamma(2., scale=0.5), Positive(), shape=(d,)),
+                             regularizer=Parameter(gamma(1.), Positive()))
+        slm = StandardLinearModel(basis, var=Parameter(gamma(1.), Positive()), nstarts=ns, maxiter=0, random_state=13)
+        objs = []
+        real = StandardLinearModel._elbo
+
+        def spy(self, *a, **k):
+            r = real(self, *a, **k)
+            objs.append(r[0])
+            return r
+        StandardLinearModel._elbo = spy
+        try:
+            slm.fit(X, y)
+        finally:
+            StandardLinearModel._elbo = real
+        assert len(objs) >= ns + 1
+        out.update({tag + "_var": slm.var_, tag + "_reg": slm.regularizer_, tag + "_hyp": np.asarray(slm.hypers_),
+                    tag + "_cand_objs": np.array(objs[:ns]), tag + "_end": slm.random_.randn(), "W": basis.W})
+        print("   ", tag, "start var %.4f reg %.4f hyp %s; best of" % (slm.var_, slm.regularizer_, np.round(slm.hypers_, 3)), np.round(objs[:ns], 2))
+    save("slm_starts", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate selected fixtures only, e.g. `make_golden.py fit_c1`
         for name in sys.argv[1:]:
@@ -695,4 +730,5 @@ if __name__ == "__main__":
     gen_glm()
     gen_glm_fit()
     gen_glm_predict()
+    gen_slm_starts()
     print("oracle agrees with the reference on every fixture")

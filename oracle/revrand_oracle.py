@@ -771,3 +771,24 @@ def glm_predictions(X, m, C, children, bpars, lik, lpars, largs, nsamples, seed,
     cd = np.stack([lik_cdf(lik, q, f, *pars) for f in fs], axis=1)
     return {"fs": fs, "Ey": Ey, "Vy": Vy, "logpdf": (lp.mean(axis=1), lp.min(axis=1), lp.max(axis=1)),
             "cdf": (cd.mean(axis=1), cd.min(axis=1), cd.max(axis=1))}
+
+
+def slm_random_starts(X, y, W, var_spec, reg_spec, ls_spec, nstarts, seed):
+    """The start point of StandardLinearModel.fit (slm.py:112-125) as structured_minimizer picks it (decorators.py:79-97,
+    541-583): one draw of (var, regulariser, length scales) from the estimator's RandomState (the flatten's `rvs`), then
+    `nstarts` candidates, each scored by `_elbo` (-ELBO); the first minimum wins.  Returns (best candidate, objectives,
+    the RandomState's next randn)."""
+    rs = np.random.RandomState(seed)
+    specs = (var_spec, reg_spec, ls_spec)
+    [p.rvs(rs) for p in specs]                       # the start the candidates then replace
+    best, objs = None, []
+    for _ in range(nstarts):
+        var, reg, ls = [p.rvs(rs) for p in specs]
+        Phi = rff_transform(X, W, ls)
+        g = rff_grad(X, W, ls)
+        slabs = [g] if g.ndim == 2 else [g[:, :, i] for i in range(g.shape[2])]
+        obj = -slm_elbo(Phi, y, var, np.full(Phi.shape[1], reg), slice(None), slabs)["elbo"]
+        objs.append(obj)
+        if best is None or obj < best[0]:
+            best = (obj, (var, reg, ls))
+    return best[1], np.array(objs), rs.randn()

@@ -934,3 +934,41 @@ def test_predict_moments_validates_a_large_query_while_the_gpu_works_on_it(monke
             slm.predict_moments(Xb[bad_row - 5 if bad_row > 5 else 0:][:64])   # a small query: validated up front
     Ey2, _ = slm.predict_moments(X)               # nothing is left behind by the failed calls
     assert np.array_equal(Ey2, Ey)
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+@pytest.mark.parametrize("tag,ns", [("ns6", 6), ("ns1", 1)])
+def test_fit_random_starts_vs_reference(golden, tag, ns, dtype):
+    """`StandardLinearModel.fit` with distributions as initial values (slm.py:112-125; structured_minimizer's random starts,
+    decorators.py:79-97, 541-583): the draw order on `random_` (one start, then nstarts candidates of (var, regulariser,
+    length scales)), every candidate's -ELBO, the candidate handed to L-BFGS-B (maxiter = 0 returns it) and the stream's end
+    state -- against what the reference's own `fit` did (tests/golden/slm_starts.npz)."""
+    from scipy.stats import gamma
+    import revrand_amd.basis_functions as bs
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.slm import StandardLinearModel
+    g = golden("slm_starts")
+    X, y = g["X"], g["y"]
+    d = X.shape[1]
+    basis = bs.RandomRBF(nbases=g["W"].shape[1], Xdim=d, random_state=9, lenscale=Parameter(gamma(2., scale=0.5), Positive(), shape=(d,)),
+                         regularizer=Parameter(gamma(1.), Positive()), dtype=dtype)
+    assert np.array_equal(basis.W, g["W"])
+    slm = StandardLinearModel(basis, var=Parameter(gamma(1.), Positive()), nstarts=ns, maxiter=0, random_state=13)
+    objs = []
+    real = StandardLinearModel._elbo_objective
+
+    def spy(self, *a, **k):
+        v = real(self, *a, **k)
+        objs.append(v)
+        return v
+    StandardLinearModel._elbo_objective = spy
+    try:
+        slm.fit(X, y)
+    finally:
+        StandardLinearModel._elbo_objective = real
+    tol = 1e-5 if dtype == "f32" else 1e-10
+    assert len(objs) == ns and normwise(np.array(objs), g[tag + "_cand_objs"]) < tol
+    assert abs(slm.var_ - float(g[tag + "_var"])) < 1e-12 * float(g[tag + "_var"])
+    assert abs(slm.regularizer_ - float(g[tag + "_reg"])) < 1e-12 * float(g[tag + "_reg"])
+    assert normwise(np.asarray(slm.hypers_), g[tag + "_hyp"]) < 1e-12
+    assert slm.random_.randn() == float(g[tag + "_end"])

@@ -329,3 +329,18 @@ def test_glm_predictions(golden, lik):
     assert normwise(o["fs"], g[lik + "_fs"]) < 1e-12
     assert normwise(o["Ey"], g[lik + "_Ey"]) < 1e-12 and normwise(o["Vy"], g[lik + "_Vy"]) < 1e-12
     assert normwise(np.array(o["logpdf"]), g[lik + "_logpdf"]) < 1e-12 and normwise(np.array(o["cdf"]), g[lik + "_cdf"]) < 1e-12
+
+
+@pytest.mark.parametrize("tag,ns", [("ns6", 6), ("ns1", 1)])
+def test_slm_random_starts(golden, tag, ns):
+    """`orc.slm_random_starts` against the start the reference's `fit` hands to L-BFGS-B (maxiter = 0 returns it), every
+    candidate's objective and the stream's end state."""
+    from scipy.stats import gamma
+    g = golden("slm_starts")
+    P = orc.ParamSpec
+    d = g["X"].shape[1]
+    (var, reg, ls), objs, end = orc.slm_random_starts(g["X"], g["y"], g["W"], P(dist=gamma(1.), positive=True), P(dist=gamma(1.), positive=True),
+                                                      P(dist=gamma(2., scale=0.5), positive=True, shape=(d,)), ns, 13)
+    assert normwise(objs, g[tag + "_cand_objs"]) < 1e-10 and end == float(g[tag + "_end"])
+    assert abs(var - float(g[tag + "_var"])) < 1e-12 and abs(reg - float(g[tag + "_reg"])) < 1e-12
+    assert normwise(ls, g[tag + "_hyp"]) < 1e-12
