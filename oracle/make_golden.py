@@ -529,7 +529,9 @@ def gen_glm_fit():
     nbin = rs.randint(4, 12, size=N).astype(float)
     ys = {"poisson_exp": rs.poisson(np.exp(f)).astype(float), "gaussian": f + 0.1 * rs.randn(N),
           "binomial": rs.binomial(nbin.astype(int), 1 / (1 + np.exp(-2 * f))).astype(float)}
-    out.update(X=X, nbin=nbin, **{"y_" + k: v for k, v in ys.items()})
+    ys["bernoulli"] = (np.random.RandomState(22).rand(N) < 1 / (1 + np.exp(-3 * f))).astype(float)   # (own stream: the others' data stay as they were)
+    ys["poisson_softplus"] = ys["poisson_exp"]
+    out.update(X=X, nbin=nbin, **{"y_" + k: v for k, v in ys.items() if k != "poisson_softplus"})
     K, L, maxiter, seed, gseed = 3, 6, 20, 17, 5
     out.update(K=K, L=L, maxiter=maxiter, seed=seed, global_seed=gseed, nbases=n)
 
@@ -563,19 +565,14 @@ def gen_glm_fit():
                                          upper=p.bounds.upper, shape=p.shape))
         return ch, regs, lss
 
-    cases = [  # tag, likelihood, basis, batch_size, nstarts, forward batch size to sgd
-        ("poisson_ard_bs10_ns0", "poisson_exp", ard_rbf, 10, 0, False),
-        ("poisson_ard_bs10_ns5", "poisson_exp", ard_rbf, 10, 5, False),
-        ("gaussian_cat_bs10_ns5", "gaussian", concat, 10, 5, False),
-        ("gaussian_cat_bs10_ns0", "gaussian", concat, 10, 0, False),
-        ("binomial_cat_bs10_ns3", "binomial", concat, 10, 3, False),
-        ("poisson_ard_bs64f_ns5", "poisson_exp", ard_rbf, 64, 5, True),
-        ("gaussian_cat_bs64f_ns0", "gaussian", concat, 64, 0, True),
-        ("poisson_ard_bs64_ns5", "poisson_exp", ard_rbf, 64, 5, False),
-        ("poisson_bound_bs10_ns0", "poisson_exp", bounded, 10, 0, False),
-        ("gaussian_posupper_bs64f_ns4", "gaussian", posupper, 64, 4, True),
-    ]
-    mk = {"poisson_exp": lambda: rl.Poisson("exp"), "gaussian": rl.Gaussian, "binomial": rl.Binomial}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from glm_fit_cases import CASES as cases, updater_of
+    import importlib
+    rsgd = importlib.import_module("revrand.optimize.sgd")
+    bas = {"ard": ard_rbf, "cat": concat, "bound": bounded, "posupper": posupper}
+    cases = [(t, l, bas[b], bs_, ns_, f) for t, l, b, bs_, ns_, f in cases]
+    mk = {"poisson_exp": lambda: rl.Poisson("exp"), "gaussian": rl.Gaussian, "binomial": rl.Binomial, "bernoulli": rl.Bernoulli,
+          "poisson_softplus": lambda: rl.Poisson("softplus")}
     for tag, lik, mkbasis, bs, ns, fwd in cases:
         basis = mkbasis()
         like = mk[lik]()
@@ -590,8 +587,9 @@ def gen_glm_fit():
             return res
         rglm.sgd = spy
         try:
+            upd = updater_of(tag)
             glm = rglm.GeneralizedLinearModel(like, basis, K=K, nsamples=L, batch_size=bs, maxiter=maxiter, nstarts=ns,
-                                              random_state=seed)
+                                              random_state=seed, updater=None if upd is None else getattr(rsgd, upd[0])(**upd[1]))
             np.random.seed(gseed)
             glm.fit(X, ys[lik], likelihood_args=largs)
         finally:
@@ -602,7 +600,7 @@ def gen_glm_fit():
         lp = like.params
         likpar = [orc.ParamSpec(dist=lp.dist, positive=True, shape=lp.shape)] if lik == "gaussian" else []
         o = orc.glm_fit(X, ys[lik], lik, list(largs), ch, regs, likpar, lss, K, L, bs, maxiter, ns, seed, gseed,
-                        sgd_batch_size=bs if fwd else 10)
+                        sgd_batch_size=bs if fwd else 10, **({} if upd is None else {"updater": upd[2], "updater_hp": upd[1]}))
         flat = lambda v: np.concatenate([np.ravel(np.asarray(u, float)) for u in (v if isinstance(v, (list, tuple)) else [v])] + [np.empty(0)])
         close(o[0], glm.weights_, 1e-9)
         close(o[1], glm.covariance_, 1e-9)

@@ -615,7 +615,7 @@ def glm_features(children):
 
 
 def glm_fit(X, y, lik, largs, children, regs, likpar, lss, K, L, batch_size, maxiter, nstarts, seed, global_seed,
-            sgd_batch_size=10, adam=(0.01, 0.9, 0.99, 1e-8)):
+            sgd_batch_size=10, updater="adam", updater_hp=None):
     """GeneralizedLinearModel.fit (glm.py:141-203) with the optimiser it builds, ``structured_sgd(logtrick_sgd(sgd))``
     (glm.py:176), restated as one loop:
 
@@ -629,7 +629,7 @@ def glm_fit(X, y, lik, largs, children, regs, likpar, lss, K, L, batch_size, max
     * logtrick_sgd (decorators.py:329-408, 586-616): z = log x on Positive coordinates, gradient times exp(z), bounds
       (log 1e-100, log upper | log sqrt(max float));
     * sgd (optimize/sgd.py:337-425): fresh ``endless_permutations`` (utils/rand.py:7-31), per step a batch, ``fun``,
-      ||grad||, outward gradients truncated on coordinates AT a bound, Adam (sgd.py:259-330), clip;
+      ||grad||, outward gradients truncated on coordinates AT a bound, the updater (Adam by default, sgd.py:14-330), clip;
     * `_elbo`'s iteration counter starts at -nstarts; the objective is only evaluated while it is negative, every 500th
       iteration and at maxiter - 1 (glm.py:232-236), inf otherwise.
 
@@ -704,7 +704,7 @@ def glm_fit(X, y, lik, largs, children, regs, likpar, lss, K, L, batch_size, max
     z[pos] = np.log(z[pos])
     state, objs, norms = {}, [], []
     gen = batches(sgd_batch_size)
-    hp = dict(zip(("alpha", "beta1", "beta2", "epsilon"), adam))
+    hp = dict(updater_hp or {})
     for _ in range(maxiter):
         idx = next(gen)
         x = np.where(pos, np.exp(np.where(pos, z, 0.)), z)
@@ -714,7 +714,7 @@ def glm_fit(X, y, lik, largs, children, regs, likpar, lss, K, L, batch_size, max
         norms.append(np.linalg.norm(g))
         g[z <= lo] = np.minimum(g[z <= lo], 0)
         g[z >= hi] = np.maximum(g[z >= hi], 0)
-        z = np.clip(sgd_update("adam", state, z, g, **hp), lo, hi)
+        z = np.clip(sgd_update(updater, state, z, g, **hp), lo, hi)
     vals = unflat(np.where(pos, np.exp(np.where(pos, z, 0.)), z))
     return (vals[0], vals[1], vals[2:2 + nreg], vals[2 + nreg:2 + nreg + nlik], vals[2 + nreg + nlik:],
             np.array(objs), np.array(norms), rs.randn())

@@ -11,7 +11,13 @@ rows); this implementation forwards it.  True = the reference's own code with sg
 estimator's; False with batch 64 = the reference unmodified (main loop at 10 rows, B_ = N / 64), which this implementation
 does not reproduce by design (only the oracle is held to it)."""
 
-CASES = [  # tag, likelihood, basis, batch_size, nstarts, forward
+UPDATERS = {  # tag suffix -> (class name in optimize / revrand.optimize.sgd, constructor arguments, oracle name)
+    "adadelta": ("AdaDelta", {}, "adadelta"),
+    "adagrad": ("AdaGrad", {"eta": 0.05}, "adagrad"),
+    "momentum": ("Momentum", {"rho": 0.5, "eta": 1e-4}, "momentum"),
+}
+
+CASES = [  # tag, likelihood, basis, batch_size, nstarts, forward   (a tag ending in _<updater>: that updater instead of Adam)
     ("poisson_ard_bs10_ns0", "poisson_exp", "ard", 10, 0, False),
     ("poisson_ard_bs10_ns5", "poisson_exp", "ard", 10, 5, False),
     ("gaussian_cat_bs10_ns5", "gaussian", "cat", 10, 5, False),
@@ -22,7 +28,17 @@ CASES = [  # tag, likelihood, basis, batch_size, nstarts, forward
     ("poisson_ard_bs64_ns5", "poisson_exp", "ard", 64, 5, False),
     ("poisson_bound_bs10_ns0", "poisson_exp", "bound", 10, 0, False),
     ("gaussian_posupper_bs64f_ns4", "gaussian", "posupper", 64, 4, True),
+    ("bernoulli_cat_bs10_ns2", "bernoulli", "cat", 10, 2, False),
+    ("poisson_softplus_ard_bs10_ns0", "poisson_softplus", "ard", 10, 0, False),
+    ("poisson_ard_bs10_ns0_adadelta", "poisson_exp", "ard", 10, 0, False),
+    ("gaussian_cat_bs10_ns3_adagrad", "gaussian", "cat", 10, 3, False),
+    ("binomial_cat_bs64f_ns0_momentum", "binomial", "cat", 64, 0, True),
 ]
+
+
+def updater_of(tag):
+    """(class name, kwargs, oracle name) of a case's updater, or None for the default Adam."""
+    return UPDATERS.get(tag.rsplit("_", 1)[-1])
 
 # the cases an implementation that forwards batch_size reproduces (at the reference's default 10 the two agree)
 IMPLEMENTED = [c for c in CASES if c[3] == 10 or c[5]]

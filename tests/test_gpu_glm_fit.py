@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import normwise
-from glm_fit_cases import IMPLEMENTED
+from glm_fit_cases import IMPLEMENTED, updater_of
 
 pytestmark = pytest.mark.gpu
 
@@ -38,9 +38,13 @@ def _model(g, case):
               "posupper": lambda: Parameter(1.0, Positive(1.03))}[kind]()
         basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=ls)
         assert np.array_equal(basis.W, g[tag + "_W0"])
-    like = {"poisson_exp": lambda: lk.Poisson("exp"), "gaussian": lk.Gaussian, "binomial": lk.Binomial}[lik]()
+    like = {"poisson_exp": lambda: lk.Poisson("exp"), "gaussian": lk.Gaussian, "binomial": lk.Binomial, "bernoulli": lk.Bernoulli,
+            "poisson_softplus": lambda: lk.Poisson("softplus")}[lik]()
+    from revrand_amd import optimize as opt
+    upd = updater_of(tag)
     glm = GeneralizedLinearModel(like, basis, K=int(g["K"]), nsamples=int(g["L"]), batch_size=batch, maxiter=int(g["maxiter"]),
-                                 nstarts=nstarts, random_state=int(g["seed"]))
+                                 nstarts=nstarts, random_state=int(g["seed"]),
+                                 updater=None if upd is None else getattr(opt, upd[0])(**upd[1]))
     return glm, ((g["nbin"],) if lik == "binomial" else ())
 
 
@@ -78,7 +82,7 @@ def test_fit_equals_the_references_fit(golden, case, loop, monkeypatch):
     monkeypatch.setattr(_hip.FusedSvi, "run", spy_run)
     monkeypatch.setattr(_hip.FusedSvi, "starts", spy_starts)
     np.random.seed(int(g["global_seed"]))
-    glm.fit(g["X"], g["y_" + lik], likelihood_args=largs)
+    glm.fit(g["X"], g["y_" + ("poisson_exp" if lik == "poisson_softplus" else lik)], likelihood_args=largs)
     want = {"resident loop": 0, "fused loop": 0, "starts": 0}     # the loop under test is the one that ran
     if loop != "host loop":
         want[loop] = int(g["maxiter"])

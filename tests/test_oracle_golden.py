@@ -277,7 +277,7 @@ def test_oracle_gradient_trace_identity_above_its_size_switch():
     assert np.allclose(o["dhyp"], want, rtol=1e-11, atol=1e-12)
 
 
-from glm_fit_cases import CASES as GLM_FIT_CASES  # noqa: E402
+from glm_fit_cases import CASES as GLM_FIT_CASES, updater_of  # noqa: E402
 
 
 @pytest.mark.parametrize("case", GLM_FIT_CASES, ids=[c[0] for c in GLM_FIT_CASES])
@@ -300,8 +300,9 @@ def test_glm_fit_optimiser_stack(golden, case):
         ch, regs, lss = [("rff", g[tag + "_W0"], d if kind == "ard" else 1)], [reg()], [ls]
     likpar = [P(dist=gamma(1.), positive=True)] if lik == "gaussian" else []
     largs = [g["nbin"]] if lik == "binomial" else []
-    o = orc.glm_fit(g["X"], g["y_" + lik], lik, largs, ch, regs, likpar, lss, int(g["K"]), int(g["L"]), bs, int(g["maxiter"]),
-                    ns, int(g["seed"]), int(g["global_seed"]), sgd_batch_size=bs if fwd else 10)
+    o = orc.glm_fit(g["X"], g["y_" + ("poisson_exp" if lik == "poisson_softplus" else lik)], lik, largs, ch, regs, likpar, lss, int(g["K"]), int(g["L"]), bs, int(g["maxiter"]),
+                    ns, int(g["seed"]), int(g["global_seed"]), sgd_batch_size=bs if fwd else 10,
+                    **({} if updater_of(tag) is None else {"updater": updater_of(tag)[2], "updater_hp": updater_of(tag)[1]}))
     flat = lambda v: np.concatenate([np.ravel(np.asarray(u, float)) for u in v] + [np.empty(0)])  # noqa: E731
     assert normwise(o[0], g[tag + "_m"]) < 1e-9 and normwise(o[1], g[tag + "_C"]) < 1e-9
     assert normwise(flat(o[2]), g[tag + "_reg"]) < 1e-9
