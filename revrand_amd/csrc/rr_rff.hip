@@ -1319,7 +1319,7 @@ rr_syrk_f32_diag16_kernel(const SyrkArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// Small feature counts (F <= 1024: BASELINE config 1 is F = 512, the reference's SARCOS model nbases = 512): 128 x 128 tiles.
+// Small feature counts over FEW rows (F <= 1024: BASELINE config 1 is F = 512, N = 10 000): 128 x 128 tiles.
 // On the 256 x 256 tiles above F = 512 is ONE off-diagonal tile and two diagonal ones: however the rows are split, every
 // workgroup pays the big tile's prologue and a 64k-entry atomic epilogue, and the three tiles never fill 256 CUs
 // (profiles/r05_c1_latency: 240 + 148 us for 2.6 GFLOP = 17 us of matrix-core time).  Here every upper 128 x 128 tile x
@@ -2559,7 +2559,11 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
     RR_REQUIRE(bcol == nullptr || F < ldp, "gram: no pad column for the rider");
     // small feature counts over few rows: 128 x 128 tiles (rr_syrk_f32_small_kernel); RR_SYRK_SMALL=0: never (A/B runs)
     static const bool small_off = getenv("RR_SYRK_SMALL") != nullptr && atoi(getenv("RR_SYRK_SMALL")) == 0;
-    if (!small_off && ldp <= 1024 && rows <= 262144 && rows % GS_KB == 0 && !getenv("RR_GRAM_ABLATE")) {
+    // (where it wins, tools/small_gram_bench.py: while the 256 x 256 tiles x 1024-row splits cannot give every CU a workgroup --
+    // F = 512: up to ~85 000 rows (10 000 rows: 0.148 against 0.200 ms per pass), F = 1024: up to ~26 000; above that the big
+    // tiles' LDS-DMA pipeline is 2-3x faster per flop than this kernel's register-staged loads)
+    const int64_t big_tiles = (ldp / GR_TC) * (ldp / GR_TC + 1) / 2;
+    if (!small_off && ldp <= 1024 && big_tiles * ((rows + 1023) / 1024) < c->num_cu && rows % GS_KB == 0 && !getenv("RR_GRAM_ABLATE")) {
         const int nbs = (int)(ldp / GS_TC), nt = nbs * (nbs + 1) / 2;
         // K-splits: enough workgroups for every CU (two fit one), at least 128 rows and at most 32768 each
         int64_t ns = std::max<int64_t>((2 * c->num_cu + nt - 1) / nt, (rows + 32767) / 32768);
