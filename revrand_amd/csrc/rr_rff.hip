@@ -2630,7 +2630,28 @@ int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int
         const int64_t want = (c->num_cu + tiles_per_split - 1) / std::max<int64_t>(tiles_per_split, 1);
         return std::min((rows + fr - 1) / fr, std::max((rows + 1023) / 1024, want));
     };
-    if (rows / nsplit < 1024) nsplit = small_split(std::max(ntiles, 1));
+    if (rows / nsplit < 1024) {
+        nsplit = small_split(std::max(ntiles, 1));
+        // (round 6) ... and among the split counts around it, the one whose workgroups finish soonest: time ~ rounds x (rows per
+        // split + a workgroup's prologue and 64k-entry atomic epilogue, ~96 rows' worth).  F = 1024, N = 44 484 (the reference's
+        // SARCOS shape): 44 splits x 6 tiles = 264 workgroups were TWO rounds on 256 CUs, the second with 8 workgroups.
+        static const bool no_search = getenv("RR_SYRK_SPLIT_SEARCH") != nullptr && atoi(getenv("RR_SYRK_SPLIT_SEARCH")) == 0;
+        if (ntiles > 0 && !no_search) {
+            double best_cost = 1e300;
+            int64_t best_ns = nsplit;
+            const int64_t ns_hi = std::max<int64_t>(rows / 256, 1), ns_lo = std::max<int64_t>(rows / 32768, 1);
+            for (int64_t ns = ns_lo; ns <= ns_hi && ns <= ns_lo + 4096; ++ns) {
+                const int64_t rp = rows_per(ns), n2 = (rows + rp - 1) / rp;
+                const int64_t rounds = ((int64_t)ntiles * n2 + c->num_cu - 1) / c->num_cu;
+                const double cost = (double)rounds * ((double)rp + 96.0);
+                if (cost < best_cost - 1e-9) {
+                    best_cost = cost;
+                    best_ns = n2;
+                }
+            }
+            nsplit = best_ns;
+        }
+    }
     if (nsplit < 1) nsplit = 1;
     int64_t rps = rows_per(nsplit);
     int64_t nsplit_d = nsplit, rps_d = rps;
