@@ -678,6 +678,26 @@ int rr_comm_group_broadcast_dev(rr_comm *const *comms, int n, void *const *dbufs
 int rr_comm_group_reduce_stats_dev(rr_comm *const *comms, int n, int64_t F, double *const *dG, double *const *db,
                                    double *const *dyty, const double *nrows, double *const *dmsg, double *total_rows);
 
+/* The same step with the minibatch's rows spread over the n members of an in-process device group (rr_comm_init_all; the
+ * reference has no counterpart: GeneralizedLinearModel(devices=[...]).fit, the estimator's one call over several GPUs).
+ * loops[i]: member i's loop, created on the context comms[i] is bound to from the SAME z0 / bounds / updater; batches[i]: ITS
+ * rows of the minibatch (rows == 0 allowed: a member none of the minibatch's indices fell to), draws dE on ITS device (the
+ * same values for every member) or NULL with the shared (seed, key).  llconst and bmag are the whole minibatch's.  Member i
+ * forms the products on its rows; what a step sums over rows -- the length-scale contractions, [Edm | EdC], the likelihood
+ * sums -- is added over the members in HBM (three stream-ordered all-reduces: 8 (dT + 2 F K + 2 K) bytes), and every member
+ * makes the same update of its copy of z: the copies stay bit-identical, rr_glm_sgd_read of any member returns the fit.
+ * Queued from ONE host thread; returns without waiting, like rr_glm_sgd_step. */
+typedef struct rr_glm_sgd_batch {
+    const void *const *dX; /* [children] */
+    const int *x_dtype;
+    const int64_t *ldx;
+    int64_t rows;
+    const void *dy, *drowarg;
+    const float *dE;
+} rr_glm_sgd_batch;
+int rr_glm_sgd_group_step(int n, rr_glm_sgd *const *loops, rr_comm *const *comms, const rr_glm_sgd_batch *batches, int dtype,
+                          int lik, double llconst, double bmag, int L, uint64_t seed, uint64_t key);
+
 /* ---- host-side random stream of the GLM step ------------------------------ */
 
 /* Advance a NumPy legacy RandomState (MT19937 + polar Box-Muller with one cached value) by n standard normals and write

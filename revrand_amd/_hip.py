@@ -153,6 +153,8 @@ SIGNATURES = {
     "rr_glm_sgd_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
+    "rr_glm_sgd_group_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                             ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]),
     "rr_glm_sgd_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.POINTER(ctypes.c_int64)]),
     "rr_glm_sgd_objective": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_double)]),
@@ -1141,6 +1143,51 @@ class ResidentSgd(object):
             self.close()
         except Exception:
             pass
+
+
+class SgdBatch(ctypes.Structure):
+    """rr_glm_sgd_batch (include/revrand_hip.h)"""
+    _fields_ = [("dX", ctypes.c_void_p), ("x_dtype", ctypes.c_void_p), ("ldx", ctypes.c_void_p), ("rows", ctypes.c_int64),
+                ("dy", ctypes.c_void_p), ("drowarg", ctypes.c_void_p), ("dE", ctypes.c_void_p)]
+
+
+class ResidentSgdGroup(object):
+    """One ResidentSgd per member of a device group, stepped together (rr_glm_sgd_group_step): every member works on ITS rows of
+    the minibatch, the row sums are all-reduced in HBM, the members' copies of the parameters stay bit-identical."""
+
+    def __init__(self, comms, sgds):
+        self.comms, self.sgds, self.n, self.lib = comms, list(sgds), len(sgds), sgds[0].lib
+        self._loops = (ctypes.c_void_p * self.n)(*[s.h for s in self.sgds])
+        self._batches = (SgdBatch * self.n)()
+
+    def step(self, parts, lik, llconst, bmag, L, seed=0, key=0):
+        """parts[i] = (dXs, rows, dy, drowarg, dE) of member i (rows == 0: the rest may be None)."""
+        dtype = None
+        for b, sgd, (dXs, rows, dy, drowarg, dE) in zip(self._batches, self.sgds, parts):
+            b.rows = int(rows)
+            if not rows:
+                b.dX = b.x_dtype = b.ldx = b.dy = b.drowarg = b.dE = None
+                continue
+            for i, dX in enumerate(dXs):
+                p = dX.ptr
+                sgd._ptrs[i] = p if isinstance(p, int) else p.value
+                sgd._dts[i], sgd._lds[i] = rr_dtype(dX.dtype), dX.ld
+            b.dX, b.x_dtype, b.ldx = (ctypes.cast(a, ctypes.c_void_p) for a in (sgd._ptrs, sgd._dts, sgd._lds))
+            b.dy, b.drowarg, b.dE = _ptr(dy), _ptr(drowarg), None if dE is None else dE.ptr
+            dtype = rr_dtype(dy.dtype)
+        _check(self.lib, self.lib.rr_glm_sgd_group_step(self.n, ctypes.cast(self._loops, ctypes.c_void_p), self.comms,
+                                                        ctypes.cast(self._batches, ctypes.c_void_p), dtype, int(lik), float(llconst),
+                                                        float(bmag), int(L), int(seed), int(key)))
+
+    def objective(self, step):
+        return self.sgds[0].objective(step)
+
+    def read(self, member=0):
+        return self.sgds[member].read()
+
+    def close(self):
+        for s in self.sgds:
+            s.close()
 
 
 class FusedSvi(object):

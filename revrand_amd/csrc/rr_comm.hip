@@ -227,6 +227,8 @@ struct rr_comm {
     size_t scratch_count = 0;
 };
 
+rr_ctx *rr_comm_ctx(rr_comm *comm) { return comm ? comm->ctx : nullptr; }
+
 extern "C" {
 
 int rr_comm_load(const char *path) { return rccl_load(path); }

@@ -3389,31 +3389,72 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
     return RR_OK;
 }
 
-int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows, const void *dy,
-                    const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed,
-                    uint64_t key) {
-    RR_REQUIRE(o != nullptr && dX != nullptr && x_dtype != nullptr && ldx != nullptr && dy != nullptr, "rr_glm_sgd_step: null argument");
-    RR_REQUIRE(o->t < o->maxiter, "rr_glm_sgd_step: all %lld steps of this loop are done", (long long)o->maxiter);
-    RR_REQUIRE((lik == RR_LIK_GAUSSIAN) == (o->n_lik == 1), "rr_glm_sgd_step: likelihood %d with %d likelihood parameter(s)", lik, o->n_lik);
-    RR_REQUIRE(rows >= 1 && rows <= o->fm->max_rows, "rr_glm_sgd_step: rows out of range");
-    for (int s = 0; s < o->nkids; ++s)
-        RR_REQUIRE(dX[s] != nullptr && (x_dtype[s] == RR_F32 || x_dtype[s] == RR_F64), "rr_glm_sgd_step: child %d: bad rows", s);
+// One step in three parts, so that the members of a device group (rr_glm_sgd_group_step) can put their all-reduces between
+// them; rr_glm_sgd_step runs the three back to back.  Everything a step sums over ROWS ends up in three buffers: dT (the
+// length-scale contractions), [Edm | EdC] and [llsum | aux]; everything else is a function of z and of those.
+struct SgdStepIn {
+    const void *const *dX;
+    const int *x_dtype;
+    const int64_t *ldx;
+    int64_t rows;        // of THIS loop's share of the minibatch (a group member's may be 0)
+    int64_t rows_total;  // of the whole minibatch
+    const void *dy, *drowarg;
+    int dtype, lik;
+    double llconst, bmag;
+    int L;
+    const float *dE;
+    uint64_t seed, key;
+};
+
+static rr_featmat *sgd_step_fm(rr_glm_sgd *o) { return (o->overlap && (o->t & 1)) ? o->fm2 : o->fm; }
+
+static int sgd_step_check(rr_glm_sgd *o, const SgdStepIn &in, int64_t min_rows, const char *who) {
+    RR_REQUIRE(o->t < o->maxiter, "%s: all %lld steps of this loop are done", who, (long long)o->maxiter);
+    RR_REQUIRE((in.lik == RR_LIK_GAUSSIAN) == (o->n_lik == 1), "%s: likelihood %d with %d likelihood parameter(s)", who, in.lik, o->n_lik);
+    RR_REQUIRE(in.rows >= min_rows && in.rows <= o->fm->max_rows, "%s: rows out of range", who);
+    if (in.rows > 0) {
+        RR_REQUIRE(in.dX != nullptr && in.x_dtype != nullptr && in.ldx != nullptr && in.dy != nullptr, "%s: null argument", who);
+        for (int s = 0; s < o->nkids; ++s)
+            RR_REQUIRE(in.dX[s] != nullptr && (in.x_dtype[s] == RR_F32 || in.x_dtype[s] == RR_F64), "%s: child %d: bad rows", who, s);
+    }
+    return RR_OK;
+}
+
+// features, draws, fs and the likelihood terms, EdPhi and its contraction with every child: dT is complete
+static int sgd_step_front(rr_glm_sgd *o, const SgdStepIn &in) {
     rr_featmat *fm = o->fm;
     rr_ctx *c = fm->ctx;
     RR_CHECK_HIP(hipSetDevice(c->device));
-    const int K = o->K, F = o->F, nk = o->nkids;
+    const int K = o->K, F = o->F, nk = o->nkids, L = in.L;
     const int64_t fk = o->fk;
     // at most two steps in flight: the event of step t - 2 (which also was the last user of this step's feature matrix)
     if (o->t >= 2) RR_CHECK_HIP(hipEventSynchronize(o->ev[o->t & 1]));
     const int par = (int)(o->t & 1);
-    if (o->overlap && par) fm = o->fm2;
+    fm = sgd_step_fm(o);
     const int64_t n_main = 2 * fk + nk + o->n_lik;
     const unsigned nb_main = (unsigned)((n_main + 255) / 256), nb_ls = (unsigned)((o->n_ls + 255) / 256);
     const double *xls = o->x + n_main, *xpar = o->n_lik ? o->x + 2 * fk + nk : nullptr;
     int rc = RR_OK;
+    hipStream_t s0 = c->stream;
+    const int KL = K * L;
+    const int64_t klp = ((int64_t)KL + 255) / 256 * 256, Fp = fm->ld;
+    if (in.rows == 0) {  // (a group member without rows of this minibatch: its sums are zero, its parameters follow the others')
+        if (nb_ls)
+            hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, s0, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
+                               o->x + n_main);
+        hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_main), dim3(256), 0, s0, o->z, o->islog, n_main, o->x);
+        RR_CHECK_HIP(hipGetLastError());
+        rc = fm_glm_scratch(fm, klp, K);
+        if (rc != RR_OK) return rc;
+        FmPass2 &s = *(FmPass2 *)fm->pass2;
+        RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->dT_count * 8, s0));
+        RR_CHECK_HIP(hipMemsetAsync(s.mc + 2 * fk, 0, (size_t)(2 * fk) * 8, s0));
+        RR_CHECK_HIP(hipMemsetAsync(s.kacc, 0, (size_t)2 * s.kcap * 8, s0));
+        return RR_OK;
+    }
     // ---- this step's features: after the previous step's length-scale update, on the second stream, into this step's
     //      matrix -- while the previous step's Ed product runs on the first
-    hipStream_t s0 = c->stream, sf = o->overlap ? o->sfeat : s0;
+    hipStream_t sf = o->overlap ? o->sfeat : s0;
     if (o->overlap) {
         // stream order of dX / dy / drowarg / dE: whatever the caller queued on the context's stream before this call (row
         // gathers of a minibatch that was not prefetched, uploads) is ordered BEFORE the feature kernels on the second stream
@@ -3433,11 +3474,11 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, co
         if (nb_ls)
             hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_ls), dim3(256), 0, sf, o->z + n_main, o->islog + n_main, (int64_t)o->n_ls,
                                o->x + n_main);
-        rc = rr_featmat_begin(fm, rows);
+        rc = rr_featmat_begin(fm, in.rows);
         for (int s = 0; s < nk && rc == RR_OK; ++s) {
             const rr_glm_sgd_child &k = o->kids[(size_t)s];
-            if (k.kind == RR_SGD_CHILD_RFF) rc = rr_fm_put_rff_dev(fm, k.basis, dX[s], x_dtype[s], ldx[s], xls + o->ls0[(size_t)s], k.n_ls, o->col0[(size_t)s]);
-            else rc = rr_featmat_put_linear(fm, dX[s], x_dtype[s], ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
+            if (k.kind == RR_SGD_CHILD_RFF) rc = rr_fm_put_rff_dev(fm, k.basis, in.dX[s], in.x_dtype[s], in.ldx[s], xls + o->ls0[(size_t)s], k.n_ls, o->col0[(size_t)s]);
+            else rc = rr_featmat_put_linear(fm, in.dX[s], in.x_dtype[s], in.ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
         }
     }
     if (rc != RR_OK) return rc;
@@ -3449,10 +3490,8 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, co
     // ---- the step proper
     hipLaunchKernelGGL(rr_glm_sgd_from_log_kernel, dim3(nb_main), dim3(256), 0, s0, o->z, o->islog, n_main, o->x);
     RR_CHECK_HIP(hipGetLastError());
-    rc = glm_step_checks(fm, dy, drowarg, dtype, lik, 1.0, K, L, "rr_glm_sgd_step");
+    rc = glm_step_checks(fm, in.dy, in.drowarg, in.dtype, in.lik, 1.0, K, L, "rr_glm_sgd_step");
     if (rc != RR_OK) return rc;
-    const int KL = K * L;
-    const int64_t klp = ((int64_t)KL + 255) / 256 * 256, Fp = fm->ld;
     rc = fm_glm_scratch(fm, klp, K);
     if (rc != RR_OK) return rc;
     FmPass2 &s = *(FmPass2 *)fm->pass2;
@@ -3460,30 +3499,47 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, co
     RR_CHECK_HIP(hipMemsetAsync(o->dT, 0, (size_t)o->dT_count * 8, s0));
     const bool lone_rff = nk == 1 && o->kids[0].kind == RR_SGD_CHILD_RFF;
     if (lone_rff) {  // the EdPhi product may contract itself with the one child (rr_gemm_gradt_f32_kernel)
-        rc = rr_featmat_glm_plan_rff(fm, o->kids[0].basis, dX[0], x_dtype[0], ldx[0], 0, o->dTk[0]);
+        rc = rr_featmat_glm_plan_rff(fm, o->kids[0].basis, in.dX[0], in.x_dtype[0], in.ldx[0], 0, o->dTk[0]);
         if (rc != RR_OK) return rc;
     }
     hipLaunchKernelGGL(rr_glm_draw_kernel, dim3((unsigned)((kl_ld * Fp + 255) / 256)), dim3(256), 0, s0, o->x, o->x + fk, F, K,
-                       L, Fp, kl_ld, seed, key, dE, s.Ee, s.WSs);
+                       L, Fp, kl_ld, in.seed, in.key, in.dE, s.Ee, s.WSs);
     RR_CHECK_HIP(hipGetLastError());
-    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 1);      // fs, likelihood terms
-    if (rc == RR_OK && o->n_h) rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 4);  // EdPhi, contracted or stored
+    rc = glm_pipeline(fm, s, in.dy, in.drowarg, in.dtype, in.lik, 1.0, K, L, false, xpar, 1);      // fs, likelihood terms
+    if (rc == RR_OK && o->n_h) rc = glm_pipeline(fm, s, in.dy, in.drowarg, in.dtype, in.lik, 1.0, K, L, false, xpar, 4);  // EdPhi, contracted or stored
     for (int ch = 0; ch < nk && rc == RR_OK; ++ch)  // (returns at once when the step contracted EdPhi itself)
         if (o->kids[(size_t)ch].kind == RR_SGD_CHILD_RFF)
-            rc = rr_featmat_glm_rff(fm, o->kids[(size_t)ch].basis, dX[ch], x_dtype[ch], ldx[ch], o->col0[(size_t)ch], o->dTk[(size_t)ch]);
-    if (rc != RR_OK) return rc;
-    SgdUpdArgs a;
-    double *Edm = s.mc + 2 * fk, *EdC = s.mc + 3 * fk;
-    a.x = o->x; a.red = o->red; a.Edm = Edm; a.EdC = EdC; a.aux = s.kacc + s.kcap; a.lower = o->lower; a.upper = o->upper;
+            rc = rr_featmat_glm_rff(fm, o->kids[(size_t)ch].basis, in.dX[ch], in.x_dtype[ch], in.ldx[ch], o->col0[(size_t)ch], o->dTk[(size_t)ch]);
+    return rc;
+}
+
+static void sgd_update_args(rr_glm_sgd *o, const SgdStepIn &in, FmPass2 &s, SgdUpdArgs &a) {
+    const int64_t fk = o->fk;
+    a.x = o->x; a.red = o->red; a.Edm = s.mc + 2 * fk; a.EdC = s.mc + 3 * fk; a.aux = s.kacc + s.kcap; a.lower = o->lower; a.upper = o->upper;
     a.islog = o->islog; a.z = o->z; a.s1 = o->s1; a.s2 = o->s2;
     a.slice_of_f = o->slice_of_f; a.slice_lo = o->slice_lo; a.slice_hi = o->slice_hi; a.h_of_ls = o->h_of_ls;
-    a.F = F; a.K = K; a.nkids = nk; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = L; a.np = o->np;
-    a.bmag = bmag; a.nrows = (double)rows;
+    a.F = o->F; a.K = o->K; a.nkids = o->nkids; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = in.L; a.np = o->np;
+    a.bmag = in.bmag; a.nrows = (double)in.rows_total;
     for (int i = 0; i < 4; ++i) a.up[i] = o->up[i];
     const double tt = (double)(o->t + 1);
     a.b1t = 1.0 - pow(o->up[1], tt);
     a.b2t = 1.0 - pow(o->up[2], tt);
-    // the length scales: W[i,:].T[i,:], their gradient, their update -- and the next step's features may start
+}
+
+// (dT summed over all rows:) the length scales' gradient and update -- the next step's features may start --, then
+// Ed = dfs Phi and its reductions over the samples: [Edm | EdC] and [llsum | aux] of this loop's rows are complete
+static int sgd_step_middle(rr_glm_sgd *o, const SgdStepIn &in) {
+    rr_featmat *fm = sgd_step_fm(o);
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int K = o->K, F = o->F, nk = o->nkids, L = in.L, par = (int)(o->t & 1);
+    const int64_t fk = o->fk, n_main = 2 * fk + nk + o->n_lik;
+    const unsigned nb_main = (unsigned)((n_main + 255) / 256), nb_ls = (unsigned)((o->n_ls + 255) / 256);
+    const double *xpar = o->n_lik ? o->x + 2 * fk + nk : nullptr;
+    hipStream_t s0 = c->stream;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    SgdUpdArgs a;
+    sgd_update_args(o, in, s, a);
     const int npairs = K * (K + 1) / 2;
     if (o->n_ls) {
         hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)o->n_h), dim3(256), 0, s0, o->x, F, K, nk, o->slice_lo, o->slice_hi,
@@ -3493,22 +3549,103 @@ int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, co
         RR_CHECK_HIP(hipGetLastError());
     }
     RR_CHECK_HIP(hipEventRecord(o->e_ls[par], s0));
-    // Ed = dfs Phi, its reductions over the samples, the mixture's sums, the update of (m, C, regularisers, variance)
-    rc = glm_pipeline(fm, s, dy, drowarg, dtype, lik, 1.0, K, L, false, xpar, 2);
+    if (in.rows == 0) return RR_OK;  // (zeroed by the front part)
+    int rc = glm_pipeline(fm, s, in.dy, in.drowarg, in.dtype, in.lik, 1.0, K, L, false, xpar, 2);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(rr_glm_reduce_kernel, dim3((unsigned)((fk + 255) / 256)), dim3(256), 0, s0, s.Ed, s.Ee, o->x + fk, F, K,
-                       L, Fp, Edm, EdC);
+                       L, fm->ld, s.mc + 2 * fk, s.mc + 3 * fk);
+    RR_CHECK_HIP(hipGetLastError());
+    return RR_OK;
+}
+
+// ([Edm | EdC], [llsum | aux] summed over all rows:) the mixture's sums, the update of (m, C, regularisers, variance), the
+// step's record
+static int sgd_step_back(rr_glm_sgd *o, const SgdStepIn &in) {
+    rr_featmat *fm = sgd_step_fm(o);
+    rr_ctx *c = fm->ctx;
+    RR_CHECK_HIP(hipSetDevice(c->device));
+    const int K = o->K, F = o->F, nk = o->nkids, L = in.L;
+    const int64_t fk = o->fk, n_main = 2 * fk + nk + o->n_lik;
+    const unsigned nb_main = (unsigned)((n_main + 255) / 256), nb_ls = (unsigned)((o->n_ls + 255) / 256);
+    hipStream_t s0 = c->stream;
+    FmPass2 &s = *(FmPass2 *)fm->pass2;
+    SgdUpdArgs a;
+    sgd_update_args(o, in, s, a);
+    const int npairs = K * (K + 1) / 2;
     hipLaunchKernelGGL(rr_glm_sgd_sums_kernel, dim3((unsigned)(npairs + nk)), dim3(256), 0, s0, o->x, F, K, nk, o->slice_lo, o->slice_hi,
                        o->hrows, o->n_h, o->red, 0);
     a.p0 = 0; a.p1 = n_main; a.npart = o->npart;
     hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_main), dim3(256), 0, s0, a);
     RR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(rr_glm_sgd_finish_kernel, dim3(1), dim3(256), 0, s0, o->x, o->red, s.kacc, o->npart, (int)(nb_main + nb_ls), F, K, L,
-                       nk, o->slice_lo, o->slice_hi, o->n_lik, llconst, (double)rows, bmag, o->objs + o->t, o->norms + o->t);
+                       nk, o->slice_lo, o->slice_hi, o->n_lik, in.llconst, (double)in.rows_total, in.bmag, o->objs + o->t, o->norms + o->t);
     RR_CHECK_HIP(hipGetLastError());
     RR_CHECK_HIP(hipEventRecord(o->ev[o->t & 1], c->stream));
     o->t += 1;
     return RR_OK;
+}
+
+int rr_glm_sgd_step(rr_glm_sgd *o, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows, const void *dy,
+                    const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE, uint64_t seed,
+                    uint64_t key) {
+    RR_REQUIRE(o != nullptr && dX != nullptr && x_dtype != nullptr && ldx != nullptr && dy != nullptr, "rr_glm_sgd_step: null argument");
+    const SgdStepIn in = {dX, x_dtype, ldx, rows, rows, dy, drowarg, dtype, lik, llconst, bmag, L, dE, seed, key};
+    int rc = sgd_step_check(o, in, 1, "rr_glm_sgd_step");
+    if (rc == RR_OK) rc = sgd_step_front(o, in);
+    if (rc == RR_OK) rc = sgd_step_middle(o, in);
+    if (rc == RR_OK) rc = sgd_step_back(o, in);
+    return rc;
+}
+
+// The same step with the minibatch's rows spread over the n members of a device group (rr_comm_init_all): member i runs the
+// products on ITS rows, the three row sums are added over the members in HBM (dT before the length scales' update, [Edm | EdC]
+// and [llsum | aux] before the main update), and every member then makes the SAME update of its own copy of z -- the copies
+// stay bit-identical (the all-reduce leaves the same bits with every member).  One host thread queues everything.
+int rr_glm_sgd_group_step(int n, rr_glm_sgd *const *loops, rr_comm *const *comms, const rr_glm_sgd_batch *batches, int dtype, int lik,
+                          double llconst, double bmag, int L, uint64_t seed, uint64_t key) {
+    RR_REQUIRE(n >= 1 && loops != nullptr && comms != nullptr && batches != nullptr, "rr_glm_sgd_group_step: null argument");
+    std::vector<SgdStepIn> in((size_t)n);
+    int64_t total = 0;
+    for (int i = 0; i < n; ++i) {
+        RR_REQUIRE(loops[i] != nullptr && comms[i] != nullptr, "rr_glm_sgd_group_step: member %d: null loop or communicator", i);
+        RR_REQUIRE(batches[i].rows >= 0, "rr_glm_sgd_group_step: member %d: rows out of range", i);
+        total += batches[i].rows;
+    }
+    RR_REQUIRE(total >= 1, "rr_glm_sgd_group_step: a minibatch without rows");
+    rr_glm_sgd *o0 = loops[0];
+    for (int i = 0; i < n; ++i) {
+        rr_glm_sgd *o = loops[i];
+        RR_REQUIRE(o->np == o0->np && o->t == o0->t && o->K == o0->K && o->F == o0->F && o->dT_count == o0->dT_count,
+                   "rr_glm_sgd_group_step: member %d's loop is not a copy of member 0's (shape or step count)", i);
+        RR_REQUIRE(rr_comm_ctx(comms[i]) == o->fm->ctx, "rr_glm_sgd_group_step: member %d: loop and communicator live on different contexts", i);
+        const rr_glm_sgd_batch &b = batches[i];
+        in[(size_t)i] = SgdStepIn{b.dX, b.x_dtype, b.ldx, b.rows, total, b.dy, b.drowarg, dtype, lik, llconst, bmag, L, b.dE, seed, key};
+        const int rc = sgd_step_check(o, in[(size_t)i], 0, "rr_glm_sgd_group_step");
+        if (rc != RR_OK) return rc;
+    }
+    std::vector<double *> bufs((size_t)n);
+    int rc = RR_OK;
+    for (int i = 0; i < n && rc == RR_OK; ++i) rc = sgd_step_front(loops[i], in[(size_t)i]);
+    if (rc != RR_OK) return rc;
+    if (o0->n_ls) {
+        for (int i = 0; i < n; ++i) bufs[(size_t)i] = loops[i]->dT;
+        rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), o0->dT_count, RR_COMM_SUM);
+        if (rc != RR_OK) return rc;
+    }
+    for (int i = 0; i < n && rc == RR_OK; ++i) rc = sgd_step_middle(loops[i], in[(size_t)i]);
+    if (rc != RR_OK) return rc;
+    for (int i = 0; i < n; ++i) bufs[(size_t)i] = ((FmPass2 *)sgd_step_fm(loops[i])->pass2)->mc + 2 * o0->fk;
+    rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), 2 * o0->fk, RR_COMM_SUM);
+    if (rc != RR_OK) return rc;
+    const int kcap = ((FmPass2 *)sgd_step_fm(o0)->pass2)->kcap;
+    for (int i = 0; i < n; ++i) {
+        FmPass2 *s = (FmPass2 *)sgd_step_fm(loops[i])->pass2;
+        RR_REQUIRE(s->kcap == kcap, "rr_glm_sgd_group_step: member %d's scratch differs", i);
+        bufs[(size_t)i] = s->kacc;
+    }
+    rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), 2 * (int64_t)kcap, RR_COMM_SUM);
+    for (int i = 0; i < n && rc == RR_OK; ++i) rc = sgd_step_back(loops[i], in[(size_t)i]);
+    return rc;
 }
 
 int rr_glm_sgd_read(rr_glm_sgd *o, double *z, double *objs, double *norms, int64_t *steps) {

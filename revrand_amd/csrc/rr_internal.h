@@ -225,6 +225,7 @@ int rr_fm_put_rff_dev(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, 
                       int64_t col0);
 void rr_fm_pass2_free(void *p);
 float *rr_fm_pass2_pt(void *p);  // FmPass2::Pt or null
+rr_ctx *rr_comm_ctx(rr_comm *comm);  // the context a communicator was bound to (rr_comm.hip)
 // Consumers of the feature matrix call this first: every column of [0, F) must have been put since rr_featmat_begin.
 #define RR_FM_REQUIRE_FILLED(fm, who)                                                                              \
     RR_REQUIRE((fm)->rows == 0 || (fm)->covered == (fm)->F,                                                        \

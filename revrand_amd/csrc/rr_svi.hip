@@ -166,7 +166,7 @@ __device__ __forceinline__ void svi_wait(unsigned int *ctr, unsigned int target)
         while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
         __threadfence();
     }
-    svi_sync();
+    __syncthreads();   // the full barrier (global memory too): what thread 0 acquired is ordered before every wave's reads
 }
 
 __device__ __forceinline__ double svi_xval(const SviChild &c, int64_t row, int i) {

@@ -185,10 +185,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                   self.likelihood.params,
                   self.basis.params]
         loop = self._resident_loop(params, y, likelihood_args)
-        fused = isinstance(loop, _FusedLoop)   # small minibatches: many steps per launch, nothing per batch on the device
+        fused = isinstance(getattr(loop, "_loop", loop), _FusedLoop)   # small minibatches: many steps per launch, nothing per batch on the device
+        grouped = isinstance(loop, _GroupResidentLoop)   # the minibatch's rows spread over the members of a device group
         if loop is not None and not fused:  # (decided before the upload contexts' buffer rings are sized)
             self.__dict__["_draw_buffers"] = 6
-            self._features().PREFETCH_SLOTS = 6
+            for f in (self._features().feats if grouped else [self._features()]):
+                f.PREFETCH_SLOTS = 6
         log.info("Optimising parameters...")
         self.__it = -self.nstarts
         nsgd = structured_sgd(logtrick_sgd(sgd))
@@ -221,6 +223,12 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if callable(prefetch) and not fused and self._resident_fit and os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0" \
                 and self._group() is None:  # (a device group's members gather for themselves, on their own threads)
             self.__dict__["_batch_upload"] = _hip.get_upload_device(_hip.get_device().index)
+        if callable(prefetch) and grouped:   # the same two hand-overs per MEMBER: an upload context on each member's GPU
+            ups = [_hip.get_upload_device(d) for d in loop.group.devices]
+            if os.environ.get("RR_GLM_BATCH_PREFETCH", "1") != "0":
+                self.__dict__["_batch_upload"] = ups
+            if self.sampler != "device" and self._prefetch_draws and self._native_draws and os.environ.get("RR_GLM_DRAW_UPLOAD", "1") != "0":
+                self.__dict__["_draw_upload"] = [(u, [None] * self._draw_buffers, [0]) for u in ups]
         if callable(prefetch) and not fused and os.environ.get("RR_GLM_PREFETCH_STAGES", "2") != "1":
             # two workers in a row: the draws (2.5 ms of MT19937 + polar method per config-5 step, on the thread that cuts the
             # batches -- one RandomState, the reference's order -- next to its 0.4 ms of y[idx] and, once per epoch, 18 ms of
@@ -238,7 +246,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             # upload context's stream must have landed before the buffers it wrote to are freed)
             upb = self.__dict__.pop("_batch_upload", None)
             up = self.__dict__.pop("_draw_upload", None)
-            for ctx in {id(c): c for c in (upb, up[0] if up is not None else None) if c is not None}.values():
+            ups = [] if up is None else (up if isinstance(up, list) else [up])   # (a device group: one per member)
+            upbs = [] if upb is None else (upb if isinstance(upb, list) else [upb])
+            for ctx in {id(c): c for c in upbs + [u[0] for u in ups]}.values():
                 try:
                     ctx.sync()
                 except Exception:  # the original exception, if any, is the one to report
@@ -252,8 +262,8 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             self.__dict__.pop("_draw_buffers", None)
             self.__dict__.pop("_draw_ring", None)
             self._release_features()
-            if up is not None:
-                for buf in up[1]:
+            for u in ups:
+                for buf in u[1]:
                     if buf is not None:
                         buf.free()
         (self.weights_, self.covariance_, self.regularizer_, self.like_hypers_, self.basis_hypers_) = res.x
@@ -279,25 +289,53 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         dense equivalent), a LinearBasis or a concatenation of such children (Xdim <= 128, a scalar regulariser each); one of
         the reference's likelihoods and updaters; K <= 64 (the fused small-batch loop: K <= 32); one process and one GPU.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
         from . import optimize as opt
-        from .basis_functions import _ResidentFastFood, _ResidentLinear, _ResidentRFF
         if not self._resident_sgd or os.environ.get("RR_GLM_RESIDENT_SGD", "1") == "0":
             return None
         feats = self._features()
-        if not getattr(self, "_resident_fit", False) or self.distributed or self._group() is not None \
-                or type(feats) is not MinibatchFeatures or self.sampler not in ("host", "device"):
+        if not getattr(self, "_resident_fit", False) or self.distributed or self.sampler not in ("host", "device"):
             return None
-        kids = getattr(feats, "_kids", [])
-        if not 1 <= len(kids) <= 16 or not 1 <= self.K <= 64:
+        group = self._group()
+        if group is not None:
+            # a device group: the minibatch's rows spread over ALL members (`_GroupResidentLoop`: per-member products, the row
+            # sums all-reduced in HBM, the update replicated), or -- minibatches too small to split (multigpu.
+            # ShardedMinibatchFeatures.n_use == 1: the reference's default of 10 rows) -- the one-device loops on member 0
+            from .multigpu import ShardedMinibatchFeatures
+            if type(feats) is not ShardedMinibatchFeatures or not feats.resident or feats.n_use not in (1, group.n):
+                return None
+            if feats.n_use == 1:
+                with _hip.device_scope(group.members[0]):
+                    inner = self._one_device_loop(feats.feats[0], params, y, likelihood_args)
+                return None if inner is None else _ScopedLoop(inner, group.members[0])
+            kids = [self._loop_children(f, params) for f in feats.feats]
+            if any(k is None for k in kids) or not self._loop_covers(params):
+                return None
+            return _GroupResidentLoop(self, feats, self._n_lik(params), kids)
+        if type(feats) is not MinibatchFeatures:
             return None
+        return self._one_device_loop(feats, params, y, likelihood_args)
+
+    def _n_lik(self, params):
+        return sum(int(np.prod(p.shape, dtype=int)) for p in atleast_list(params[3]))
+
+    def _loop_covers(self, params):
+        """updater, likelihood, mixture size and likelihood parameters are ones the device loops implement"""
+        from . import optimize as opt
+        if not 1 <= self.K <= 64:
+            return False
         if self.updater is not None and type(self.updater) not in (opt.SGDUpdater, opt.AdaDelta, opt.AdaGrad, opt.Momentum, opt.Adam):
-            return None
+            return False
         if type(self.likelihood) not in (Bernoulli, Binomial, Gaussian, Poisson):
+            return False
+        return self._n_lik(params) == (1 if type(self.likelihood) is Gaussian else 0)
+
+    def _loop_children(self, feats, params):
+        """The children of one device's MinibatchFeatures as rr_glm_sgd takes them, or None when one is not covered."""
+        from .basis_functions import _ResidentFastFood, _ResidentLinear, _ResidentRFF
+        kids = getattr(feats, "_kids", [])
+        if not 1 <= len(kids) <= 16:
             return None
-        regs, lpar = atleast_list(params[2]), atleast_list(params[3])
+        regs = atleast_list(params[2])
         if len(regs) != len(kids) or any(getattr(p, "shape", None) != () for p in regs):  # one scalar regulariser per child
-            return None
-        n_lik = sum(int(np.prod(p.shape, dtype=int)) for p in lpar)
-        if n_lik != (1 if type(self.likelihood) is Gaussian else 0):
             return None
         children = []
         for kid, b in zip(kids, feats.bases):
@@ -315,6 +353,15 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 return None
         if sum(c[2] for c in children if c[0] == "rff") != sum(int(np.prod(p.shape, dtype=int)) for p in atleast_list(params[4])):
             return None
+        return children
+
+    def _one_device_loop(self, feats, params, y, likelihood_args):
+        if not self._loop_covers(params):
+            return None
+        children = self._loop_children(feats, params)
+        if children is None:
+            return None
+        kids, n_lik = feats._kids, self._n_lik(params)
         # small minibatches (the reference's default is 10 rows): the whole loop inside one kernel, many steps per launch
         if self._fused_sgd and os.environ.get("RR_GLM_FUSED", "1") != "0" and y is not None and len(likelihood_args) <= 1 \
                 and np.isfinite(self.maxiter):
@@ -397,16 +444,20 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if up is None:
             return d
         e = d.e
-        dev, bufs, turn = up
-        buf = bufs[turn[0] % len(bufs)]
-        if buf is None or buf.nbytes < e.nbytes:
-            if buf is not None:
-                buf.free()
-            buf = bufs[turn[0] % len(bufs)] = dev.malloc(e.nbytes)
-        _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, buf.ptr, e.ctypes.data_as(_hip.ctypes.c_void_p), e.nbytes))
-        buf.shape, buf.dtype = e.shape, e.dtype
-        turn[0] += 1
-        return _Draws(buf)
+
+        def upload(dev, bufs, turn):
+            buf = bufs[turn[0] % len(bufs)]
+            if buf is None or buf.nbytes < e.nbytes:
+                if buf is not None:
+                    buf.free()
+                buf = bufs[turn[0] % len(bufs)] = dev.malloc(e.nbytes)
+            _hip._check(dev.lib, dev.lib.rr_memcpy_h2d(dev.ctx, buf.ptr, e.ctypes.data_as(_hip.ctypes.c_void_p), e.nbytes))
+            buf.shape, buf.dtype = e.shape, e.dtype
+            turn[0] += 1
+            return buf
+        if isinstance(up, list):   # a device group: the same draws into every member's HBM
+            return _Draws(tuple(upload(*u) for u in up))
+        return _Draws(upload(*up))
 
     # -- device features of one minibatch ------------------------------------------------------
     def _features(self):
@@ -713,8 +764,9 @@ class _ResidentLoop(object):
         self.pos = np.asarray(pos, dtype=bool)
         self.t = 0
         self.clock = []   # host time at which each step was queued (the queue is two deep: it follows the device's pace)
-        self._make = lambda M: _hip.ResidentSgd(feats.fm, self.children, g.K, self.n_lik, z0, lower, upper, self.pos,
-                                                _hip.UPDATER_IDS[kind], par, max(1, int(maxiter)))
+        self._make = lambda M, fm=None, children=None: _hip.ResidentSgd(
+            feats.fm if fm is None else fm, self.children if children is None else children, g.K, self.n_lik, z0, lower, upper,
+            self.pos, _hip.UPDATER_IDS[kind], par, max(1, int(maxiter)))
         self._z0 = np.array(z0, dtype=float)
 
     def _start(self, M):
@@ -793,6 +845,127 @@ class _ResidentLoop(object):
         if sgd is not None:
             sgd.close()
         self.feats.__dict__.pop("PREFETCH_SLOTS", None)
+
+
+class _ScopedLoop(object):
+    """A one-device loop (`_ResidentLoop`, `_FusedLoop`) on ONE member of a device group -- `GeneralizedLinearModel(devices=...)`
+    with minibatches too small to split: every call runs with the member's context as the calling thread's default device
+    (`_hip.device_scope`), everything else is the inner loop's."""
+
+    def __init__(self, loop, dev):
+        object.__setattr__(self, "_loop", loop)
+        object.__setattr__(self, "_dev", dev)
+
+    def __getattr__(self, name):
+        v = getattr(self._loop, name)
+        if not callable(v):
+            return v
+
+        def scoped(*args, **kwargs):
+            with _hip.device_scope(self._dev):
+                return v(*args, **kwargs)
+        return scoped
+
+    def __setattr__(self, name, value):
+        setattr(self._loop, name, value)
+
+
+class _GroupResidentLoop(_ResidentLoop):
+    """`_ResidentLoop` over the members of a device group (`GeneralizedLinearModel(devices=[...])`, multigpu.DeviceGroup): X's
+    rows are sharded over the members (multigpu.ShardedMinibatchFeatures), a minibatch -- the optimiser's own index stream --
+    is split by owner, every member gathers ITS rows and runs the step's products on them, the three row sums (the
+    length-scale contractions, [Edm | EdC], the likelihood sums) are all-reduced in HBM and every member makes the same update
+    of its own copy of the flat vector (rr_glm_sgd_group_step: the copies stay bit-identical).  One host thread queues a
+    step for all members without waiting; the minibatch worker uploads and gathers every member's share ahead
+    (`ShardedMinibatchFeatures.prefetch_batch`) through an upload context per member."""
+
+    def __init__(self, glm, feats, n_lik, children_by_member):
+        _ResidentLoop.__init__(self, glm, feats, n_lik, children_by_member[0])
+        self.group, self.kids = feats.group, children_by_member
+
+    def begin(self, z0, lower, upper, updater, maxiter):
+        _ResidentLoop.begin(self, z0, lower, upper, updater, maxiter)
+        one = self._make   # (for the feature matrix `fm` of a member, made by `_start`)
+
+        def make(M):
+            sgds = []
+            for i, f in enumerate(self.feats.feats):
+                with _hip.device_scope(self.group.members[i]):
+                    f._ensure(M, int(self.glm.D_))
+                    sgds.append(one(M, fm=f.fm, children=self.kids[i]))
+            return _hip.ResidentSgdGroup(self.group._comms, sgds)
+        self._make_group = make
+
+    def _start(self, M):
+        # (every member's feature matrix holds a whole minibatch: which share of it falls to a member varies by step)
+        self.sgd = self._make_group(M)
+
+    def step(self, batch):
+        g, feats = self.glm, self.feats
+        batch = _gathered(batch)
+        y, largs = batch[1], list(batch[2:])
+        draws = spec = gathered = None
+        while largs and isinstance(largs[-1], (_Draws, _Spec, _Batch)):      # made ahead on the worker (`_ahead`)
+            last = largs.pop()
+            if isinstance(last, _Draws):
+                draws = last.e
+            elif isinstance(last, _Batch):
+                gathered = last.token
+            else:
+                spec = last.spec
+        idx = largs.pop()
+        if self.n_lik:
+            from .likelihoods import RR_LIK_GAUSSIAN
+            lid, rowarg, llconst = RR_LIK_GAUSSIAN, None, 0.0
+        else:
+            lid, _, rowarg, llconst = spec if spec is not None else g.likelihood.device_spec(y, [], largs)
+        it = g._iteration(advance=1)
+        dolog = (it % LOGITER == 0) or (it == g.maxiter - 1)
+        if self.sgd is None:
+            self._start(len(idx))
+        shown = self._values() if dolog else None
+        if gathered is not None and gathered.key != (id(y), len(y), rowarg is None):
+            gathered = None
+        parts = gathered.parts if gathered is not None else feats._split_idx(idx)
+        mine = {i: (pos, local) for i, pos, local in parts}
+        seed = key = 0
+        if g.sampler == "device":
+            seed, key = g._dev_seed, g._dev_step
+            g._dev_step += 1
+        elif draws is None:
+            draws = g._reference_draws()
+        step = []
+        for i, f in enumerate(feats.feats):
+            if i not in mine:
+                step.append((None, 0, None, None, None))
+                continue
+            pos, local = mine[i]
+            with _hip.device_scope(self.group.members[i]):
+                got = gathered.got[i] if gathered is not None else None
+                if got is not None:
+                    dy, dn = got.dy, got.dn
+                else:
+                    dy = f._stage("y", np.asarray(y)[pos], np.float32)
+                    dn = None if rowarg is None else f._stage("rowarg", np.asarray(rowarg)[pos], np.float32)
+                dX = f.batch_rows(local, got)
+                dE = None
+                if g.sampler != "device":
+                    dE = draws[i] if isinstance(draws, tuple) else f._stage("E", draws, np.float32)
+            step.append((dX, len(local), dy, dn, dE))
+        self.sgd.step(step, lid, llconst, g.B_, g.nsamples, seed, key)
+        self.clock.append(time.perf_counter())
+        if dolog:
+            log.info("Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"
+                     .format(it, -self.sgd.objective(self.t), shown[0], shown[1], shown[2]))
+        self.t += 1
+
+    def abort(self):
+        sgd, self.sgd = self.sgd, None
+        if sgd is not None:
+            self.group.sync()   # (a member's step may still read what another member's loop owns: all idle before any goes)
+            sgd.close()
+        for f in self.feats.feats:
+            f.__dict__.pop("PREFETCH_SLOTS", None)
 
 
 class _FusedLoop(object):

@@ -361,6 +361,13 @@ def map_rows(group, N, fn, n=None):
     return tuple(None if parts[0][k] is None else np.concatenate([p[k] for p in parts]) for k in range(len(parts[0])))
 
 
+class _GroupGathered(object):
+    """A minibatch made ready on the members' devices ahead of its step (ShardedMinibatchFeatures.prefetch_batch)."""
+
+    def __init__(self, parts, got, key):
+        self.parts, self.got, self.key = parts, got, key
+
+
 class ShardedMinibatchFeatures(object):
     """``basis_functions.MinibatchFeatures`` -- what ``GeneralizedLinearModel._elbo`` programs against -- with the resident
     rows of X sharded over the members of a device group (``GeneralizedLinearModel(devices=[...])``).
@@ -425,6 +432,17 @@ class ShardedMinibatchFeatures(object):
 
     def take_prefetched_targets(self, gathered, y, rowarg):
         return False
+
+    def prefetch_batch(self, ups, idx, y, rowarg):
+        """`MinibatchFeatures.prefetch_batch` per member, for a FUTURE step of the group's resident loop (glm.
+        _GroupResidentLoop), on the minibatch worker thread: member i's share of the indices, its rows gathered, its targets --
+        through ups[i], an upload context on member i's GPU."""
+        parts = self._split_idx(idx)
+        got = [None] * self.n_use
+        for i, pos, local in parts:
+            with _hip.device_scope(self.group.members[i]):
+                got[i] = self.feats[i].prefetch_batch(ups[i], local, self._take(y, pos), self._take(rowarg, pos))
+        return _GroupGathered(parts, got, (id(y), len(y), rowarg is None))
 
     def assemble_idx(self, idx, hypers, gathered=None):
         self._parts = self._split_idx(idx)
