@@ -684,7 +684,7 @@ int rr_comm_group_reduce_stats_dev(rr_comm *const *comms, int n, int64_t F, doub
  * rows of the minibatch (rows == 0 allowed: a member none of the minibatch's indices fell to), draws dE on ITS device (the
  * same values for every member) or NULL with the shared (seed, key).  llconst and bmag are the whole minibatch's.  Member i
  * forms the products on its rows; what a step sums over rows -- the length-scale contractions, [Edm | EdC], the likelihood
- * sums -- is added over the members in HBM (three stream-ordered all-reduces: 8 (dT + 2 F K + 2 K) bytes), and every member
+ * sums -- is added over the members in HBM (two stream-ordered all-reduces: 8 dT and 8 (2 F K + 2 K) bytes), and every member
  * makes the same update of its copy of z: the copies stay bit-identical, rr_glm_sgd_read of any member returns the fit.
  * Queued from ONE host thread; returns without waiting, like rr_glm_sgd_step. */
 typedef struct rr_glm_sgd_batch {

@@ -215,6 +215,7 @@ struct rr_group {
     std::vector<rr_comm *> members;
     // peer transport: per member, "my input is complete", "my slice is reduced", "my copies are done"
     std::vector<hipEvent_t> ready, reduced, gathered;
+    hipEvent_t hub[3] = {nullptr, nullptr, nullptr};  // on member 0's device: "all are ready / reduced / done" (peer_wait_all)
     int alive = 0;  // members not yet destroyed
 };
 
@@ -291,6 +292,8 @@ void rr_comm_destroy(rr_comm *comm) {
             for (auto *evs : {&g->ready, &g->reduced, &g->gathered})
                 for (hipEvent_t e : *evs)
                     if (e) (void)hipEventDestroy(e);
+            for (hipEvent_t e : g->hub)
+                if (e) (void)hipEventDestroy(e);
             delete g;
         }
     }
@@ -631,6 +634,7 @@ int rr_comm_init_all(int n, rr_ctx *const *ctxs, int transport, rr_comm **out) {
             hipError_t e = hipSetDevice(ctxs[i]->device);
             for (auto *evs : {&g->ready, &g->reduced, &g->gathered})
                 if (e == hipSuccess) e = hipEventCreateWithFlags(&(*evs)[(size_t)i], hipEventDisableTiming);
+            for (int k = 0; k < 3 && i == 0 && e == hipSuccess; ++k) e = hipEventCreateWithFlags(&g->hub[k], hipEventDisableTiming);
             if (e != hipSuccess) {
                 rr_set_error("rr_comm_init_all: event creation failed: %s", hipGetErrorString(e));
                 for (int k = 0; k < n; ++k) {
@@ -649,11 +653,25 @@ int rr_comm_transport(rr_comm *comm) {
     return comm->group ? comm->group->transport : RR_TRANSPORT_RCCL;
 }
 
-// every member's stream waits for the events `evs` of all members (recorded by the caller just before)
-static int peer_wait_all(rr_group *g, const std::vector<hipEvent_t> &evs, int i) {
-    rr_ctx *c = g->members[(size_t)i]->ctx;
-    for (int j = 0; j < g->n; ++j)
-        if (j != i) RR_CHECK_HIP(hipStreamWaitEvent(c->stream, evs[(size_t)j], 0));
+// Every member's stream waits for the events `evs` of ALL members (recorded by the caller just before).  Pairwise that is
+// n (n - 1) hipStreamWaitEvent calls -- three times per all-reduce: 168 of its ~210 runtime calls at n = 8, ~0.3 ms of host
+// time, which a caller with small messages (the GLM step's two all-reduces of a few hundred KB: rr_glm_sgd_group_step) pays
+// per step.  From three members on the waits go THROUGH member 0: its stream waits for the other n - 1 events and records
+// `hub`, the other streams wait for `hub` -- 2 (n - 1) calls, one more hop of event latency.
+static int peer_wait_all(rr_group *g, const std::vector<hipEvent_t> &evs, hipEvent_t hub) {
+    const int n = g->n;
+    static const bool pairwise = getenv("RR_COMM_PAIRWISE_WAITS") != nullptr;  // (A/B runs)
+    if (n <= 2 || pairwise) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+                if (j != i) RR_CHECK_HIP(hipStreamWaitEvent(g->members[(size_t)i]->ctx->stream, evs[(size_t)j], 0));
+        return RR_OK;
+    }
+    rr_ctx *c0 = g->members[0]->ctx;
+    RR_CHECK_HIP(hipSetDevice(c0->device));
+    for (int j = 1; j < n; ++j) RR_CHECK_HIP(hipStreamWaitEvent(c0->stream, evs[(size_t)j], 0));
+    RR_CHECK_HIP(hipEventRecord(hub, c0->stream));  // (behind evs[0], recorded on this stream before)
+    for (int i = 1; i < n; ++i) RR_CHECK_HIP(hipStreamWaitEvent(g->members[(size_t)i]->ctx->stream, hub, 0));
     return RR_OK;
 }
 
@@ -669,11 +687,11 @@ static int peer_allreduce(rr_group *g, double *const *dbufs, int64_t count, int 
         RR_CHECK_HIP(hipSetDevice(c->device));
         RR_CHECK_HIP(hipEventRecord(g->ready[(size_t)i], c->stream));
     }
+    int rc = peer_wait_all(g, g->ready, g->hub[0]);
+    if (rc != RR_OK) return rc;
     for (int i = 0; i < n; ++i) {
         rr_ctx *c = g->members[(size_t)i]->ctx;
         RR_CHECK_HIP(hipSetDevice(c->device));
-        int rc = peer_wait_all(g, g->ready, i);
-        if (rc != RR_OK) return rc;
         const int64_t off = (int64_t)i * slice;
         const int64_t len = off >= count ? 0 : (count - off < slice ? count - off : slice);
         if (len > 0) {
@@ -684,11 +702,11 @@ static int peer_allreduce(rr_group *g, double *const *dbufs, int64_t count, int 
         }
         RR_CHECK_HIP(hipEventRecord(g->reduced[(size_t)i], c->stream));
     }
+    rc = peer_wait_all(g, g->reduced, g->hub[1]);
+    if (rc != RR_OK) return rc;
     for (int i = 0; i < n; ++i) {
         rr_ctx *c = g->members[(size_t)i]->ctx;
         RR_CHECK_HIP(hipSetDevice(c->device));
-        int rc = peer_wait_all(g, g->reduced, i);
-        if (rc != RR_OK) return rc;
         const int64_t want = (slice + 4 * 256 - 1) / (4 * 256);
         const unsigned blocks = (unsigned)(want < 1 ? 1 : want > 512 ? 512 : want);
         hipLaunchKernelGGL(rr_peer_gather_kernel, dim3(blocks, (unsigned)n), dim3(256), 0, c->stream, pb, i, slice, count);
@@ -697,11 +715,7 @@ static int peer_allreduce(rr_group *g, double *const *dbufs, int64_t count, int 
     }
     // a member's buffer is read by its peers until THEIR copies are done: what the caller queues next on any member's
     // stream (a memset of the accumulators, the next pack) must come after all of them
-    for (int i = 0; i < n; ++i) {
-        int rc = peer_wait_all(g, g->gathered, i);
-        if (rc != RR_OK) return rc;
-    }
-    return RR_OK;
+    return peer_wait_all(g, g->gathered, g->hub[2]);
 }
 
 int rr_comm_group_allreduce_dev(rr_comm *const *comms, int n, double *const *dbufs, int64_t count, int op) {

@@ -12,6 +12,13 @@
 // SYRK kernel's LDS-DMA / MFMA structure, plain f32 stores), rr_rowdot_kernel, rr_grad_t_kernel.
 #include "rr_internal.h"
 #include "rr_mfma_tile.h"
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
 
 // ---------------------------------------------------------------------------------------------
 // Feature-major features:  Pt[f][r] = cos/sqrt(n), Pt[n+f][r] = sin/sqrt(n)  (GEMM operand, K-major),
@@ -1463,7 +1470,7 @@ float *rr_fm_pass2_pt(void *p) { return p ? ((FmPass2 *)p)->Pt : nullptr; }
 void rr_fm_pass2_free(void *p) {
     if (!p) return;
     FmPass2 *s = (FmPass2 *)p;
-    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->kacc, s->Ee, s->mc,
+    void *q[] = {s->Pt, s->U, s->C32, s->m32, s->dot, s->err, s->sq, s->vf, s->FSt, s->DFS, s->WSt, s->WSs, s->Ed, s->Ee, s->mc,
                  s->Ab, s->Cb};
     for (void *x : q)
         if (x) (void)hipFree(x);
@@ -1545,7 +1552,7 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
     RR_CHECK_HIP(hipStreamSynchronize(fm->ctx->stream));
     if (klp < s.klp) klp = s.klp;  // grow-only in both dimensions
     if (K < s.kcap) K = s.kcap;
-    void *q[] = {s.FSt, s.DFS, s.WSt, s.WSs, s.Ed, s.kacc, s.Ee, s.mc};
+    void *q[] = {s.FSt, s.DFS, s.WSt, s.WSs, s.Ed, s.Ee, s.mc};  // (kacc lives behind mc)
     for (void *x : q)
         if (x) (void)hipFree(x);
     s.FSt = s.DFS = s.WSt = s.WSs = s.Ed = s.Ee = nullptr;
@@ -1559,8 +1566,11 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.WSs, (size_t)klp * fm->ld * 4);
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.Ed, (size_t)klp * fm->ld * 4);
     if (ea == hipSuccess) ea = hipMalloc((void **)&s.Ee, (size_t)klp * fm->ld * 4);
-    if (ea == hipSuccess) ea = hipMalloc((void **)&s.mc, (size_t)4 * (K > 1 ? K : 1) * fm->F * 8);
-    if (ea == hipSuccess) ea = hipMalloc((void **)&s.kacc, (size_t)2 * (K > 1 ? K : 1) * 8);
+    // [m | C | Edm | EdC] and, right behind them, [llsum | aux]: with K == kcap (one K per fit) everything a step sums over rows
+    // besides dT is ONE contiguous run -- one all-reduce per step of a device group (rr_glm_sgd_group_step)
+    const size_t kc = (size_t)(K > 1 ? K : 1);
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.mc, (4 * kc * (size_t)fm->F + 2 * kc) * 8);
+    if (ea == hipSuccess) s.kacc = s.mc + 4 * kc * (size_t)fm->F;
     if (ea != hipSuccess) {
         (void)hipGetLastError();
         rr_set_error("featmat GLM step: device allocation failed");
@@ -3009,6 +3019,114 @@ struct rr_glm_sgd {
     hipEvent_t e_feat[2] = {nullptr, nullptr};  // step t's features are in its matrix (recorded on sfeat)
     hipEvent_t e_in = nullptr;                  // what the caller queued on the context's stream before this step (its row gathers)
     bool overlap = true;                        // RR_GLM_SGD_OVERLAP=0: one stream, one matrix (A/B runs)
+    // RR_GLM_GROUP_TIMING=1 (measurement): host time inside rr_glm_sgd_group_step, and of it the wait for step t - 2
+    int64_t call_ns = 0, wait_ns = 0, group_steps = 0;
+};
+
+static inline int64_t sgd_now_ns() {
+    return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// The members of a device group are queued CONCURRENTLY: member 0 on the calling thread, member i > 0 on worker i of this
+// pool -- a part of a step is ~10-15 launches per member (~150 us of host time per step and member), which one thread
+// queueing 8 members in turn would stretch to more than the members' kernels take.  A context is still served by one thread at
+// a time (the caller waits for all workers before it goes on); a worker's error text is handed back to the caller's thread.
+// Workers spin for a millisecond after a job (the next part of the step is tens of microseconds away), then sleep.
+class SgdGroupWorkers {
+  public:
+    static SgdGroupWorkers &get() {
+        static SgdGroupWorkers *pool = nullptr;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!pool || pool->pid_ != getpid()) pool = new SgdGroupWorkers();  // (a fork's inheritance is abandoned, not joined)
+        return *pool;
+    }
+    // fn(i) for i in [0, n); the first failure's status (its message restored on this thread)
+    int run(int n, const std::function<int(int)> &fn) {
+        static const bool serial = [] { const char *e = getenv("RR_GLM_GROUP_THREADS"); return e && atoi(e) == 0; }();
+        if (n <= 1 || serial) {
+            for (int i = 0; i < n; ++i) {
+                const int rc = fn(i);
+                if (rc != RR_OK) return rc;
+            }
+            return RR_OK;
+        }
+        std::lock_guard<std::mutex> one(call_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            while ((int)slots_.size() < n - 1) {
+                slots_.emplace_back(new Slot());
+                const int id = (int)slots_.size() - 1;
+                std::thread([this, id] { loop(id); }).detach();
+            }
+            job_ = &fn;
+            want_ = n - 1;
+            remaining_.store(n - 1, std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
+        cv_.notify_all();
+        int rc = fn(0);
+        for (int spin = 0; remaining_.load(std::memory_order_acquire) > 0; ++spin) {
+            if (spin < 1 << 16) std::this_thread::yield();
+            else {
+                std::unique_lock<std::mutex> lk(mu_);
+                done_.wait_for(lk, std::chrono::microseconds(200), [this] { return remaining_.load(std::memory_order_acquire) == 0; });
+            }
+        }
+        if (rc != RR_OK) return rc;
+        for (int i = 0; i < n - 1; ++i)
+            if (slots_[(size_t)i]->rc != RR_OK) {
+                rr_set_error("%s", slots_[(size_t)i]->err.c_str());
+                return slots_[(size_t)i]->rc;
+            }
+        return RR_OK;
+    }
+
+  private:
+    struct Slot {
+        int rc = RR_OK;
+        std::string err;
+    };
+    SgdGroupWorkers() : pid_(getpid()) {}
+    void loop(int id) {
+        int64_t seen = 0;
+        for (;;) {
+            int64_t g = gen_.load(std::memory_order_acquire);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (g == seen) {
+                std::this_thread::yield();
+                g = gen_.load(std::memory_order_acquire);
+                if (g == seen && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(1000)) {
+                    std::unique_lock<std::mutex> lk(mu_);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
+                    g = gen_.load(std::memory_order_acquire);
+                }
+            }
+            seen = g;
+            const std::function<int(int)> *fn;
+            Slot *slot;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (id >= want_) continue;
+                fn = job_;
+                slot = slots_[(size_t)id].get();
+            }
+            slot->rc = (*fn)(id + 1);
+            if (slot->rc != RR_OK) slot->err = rr_last_error();
+            if (remaining_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+                std::lock_guard<std::mutex> lk(mu_);
+                done_.notify_all();
+            }
+        }
+    }
+    pid_t pid_;
+    std::mutex mu_, call_;
+    std::condition_variable cv_, done_;
+    std::vector<std::unique_ptr<Slot>> slots_;
+    const std::function<int(int)> *job_ = nullptr;
+    int want_ = 0;
+    std::atomic<int> remaining_{0};
+    std::atomic<int64_t> gen_{0};
 };
 
 __global__ void __launch_bounds__(256)
@@ -3428,7 +3546,11 @@ static int sgd_step_front(rr_glm_sgd *o, const SgdStepIn &in) {
     const int K = o->K, F = o->F, nk = o->nkids, L = in.L;
     const int64_t fk = o->fk;
     // at most two steps in flight: the event of step t - 2 (which also was the last user of this step's feature matrix)
-    if (o->t >= 2) RR_CHECK_HIP(hipEventSynchronize(o->ev[o->t & 1]));
+    if (o->t >= 2) {
+        const int64_t t0 = sgd_now_ns();
+        RR_CHECK_HIP(hipEventSynchronize(o->ev[o->t & 1]));
+        o->wait_ns += sgd_now_ns() - t0;
+    }
     const int par = (int)(o->t & 1);
     fm = sgd_step_fm(o);
     const int64_t n_main = 2 * fk + nk + o->n_lik;
@@ -3624,27 +3746,38 @@ int rr_glm_sgd_group_step(int n, rr_glm_sgd *const *loops, rr_comm *const *comms
         if (rc != RR_OK) return rc;
     }
     std::vector<double *> bufs((size_t)n);
-    int rc = RR_OK;
-    for (int i = 0; i < n && rc == RR_OK; ++i) rc = sgd_step_front(loops[i], in[(size_t)i]);
+    static const bool timing = getenv("RR_GLM_GROUP_TIMING") != nullptr;
+    const int64_t t_call = timing ? sgd_now_ns() : 0;
+    SgdGroupWorkers &pool = SgdGroupWorkers::get();
+    int rc = pool.run(n, [&](int i) { return sgd_step_front(loops[i], in[(size_t)i]); });
     if (rc != RR_OK) return rc;
     if (o0->n_ls) {
         for (int i = 0; i < n; ++i) bufs[(size_t)i] = loops[i]->dT;
         rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), o0->dT_count, RR_COMM_SUM);
         if (rc != RR_OK) return rc;
     }
-    for (int i = 0; i < n && rc == RR_OK; ++i) rc = sgd_step_middle(loops[i], in[(size_t)i]);
+    rc = pool.run(n, [&](int i) { return sgd_step_middle(loops[i], in[(size_t)i]); });
     if (rc != RR_OK) return rc;
-    for (int i = 0; i < n; ++i) bufs[(size_t)i] = ((FmPass2 *)sgd_step_fm(loops[i])->pass2)->mc + 2 * o0->fk;
-    rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), 2 * o0->fk, RR_COMM_SUM);
-    if (rc != RR_OK) return rc;
+    // [Edm | EdC] and [llsum | aux]: one run of 2 F K + 2 K doubles when the scratch was made for this K (fm_glm_scratch), else two
     const int kcap = ((FmPass2 *)sgd_step_fm(o0)->pass2)->kcap;
+    bool one_run = true;
     for (int i = 0; i < n; ++i) {
         FmPass2 *s = (FmPass2 *)sgd_step_fm(loops[i])->pass2;
         RR_REQUIRE(s->kcap == kcap, "rr_glm_sgd_group_step: member %d's scratch differs", i);
-        bufs[(size_t)i] = s->kacc;
+        bufs[(size_t)i] = s->mc + 2 * o0->fk;
+        one_run = one_run && s->kacc == s->mc + 4 * o0->fk;
     }
-    rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), 2 * (int64_t)kcap, RR_COMM_SUM);
-    for (int i = 0; i < n && rc == RR_OK; ++i) rc = sgd_step_back(loops[i], in[(size_t)i]);
+    rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), 2 * o0->fk + (one_run ? 2 * (int64_t)kcap : 0), RR_COMM_SUM);
+    if (rc != RR_OK) return rc;
+    if (!one_run) {
+        for (int i = 0; i < n; ++i) bufs[(size_t)i] = ((FmPass2 *)sgd_step_fm(loops[i])->pass2)->kacc;
+        rc = rr_comm_group_allreduce_dev(comms, n, bufs.data(), 2 * (int64_t)kcap, RR_COMM_SUM);
+    }
+    if (rc == RR_OK) rc = pool.run(n, [&](int i) { return sgd_step_back(loops[i], in[(size_t)i]); });
+    if (timing) {
+        o0->call_ns += sgd_now_ns() - t_call;
+        o0->group_steps += 1;
+    }
     return rc;
 }
 
@@ -3674,6 +3807,9 @@ void rr_glm_sgd_destroy(rr_glm_sgd *o) {
     (void)hipSetDevice(o->fm->ctx->device);
     (void)hipStreamSynchronize(o->fm->ctx->stream);
     if (o->sfeat) (void)hipStreamSynchronize(o->sfeat);
+    if (o->group_steps > 0)
+        fprintf(stderr, "rr_glm_sgd_group_step: %lld steps, %.1f us of host time per step, %.1f us of it waiting for step t - 2 (member 0)\n",
+                (long long)o->group_steps, 1e-3 * (double)o->call_ns / (double)o->group_steps, 1e-3 * (double)o->wait_ns / (double)o->group_steps);
     sgd_free(o);
 }
 

@@ -287,7 +287,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         """The SGD loop with parameters, updater state and gradient in device memory (`_ResidentLoop`, rr_glm_sgd) when this
         fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a FastFoodRBF (through its
         dense equivalent), a LinearBasis or a concatenation of such children (Xdim <= 128, a scalar regulariser each); one of
-        the reference's likelihoods and updaters; K <= 64 (the fused small-batch loop: K <= 32); one process and one GPU.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
+        the reference's likelihoods and updaters; K <= 64 (the fused small-batch loop: K <= 32); one process; one GPU, or --
+        `devices=` -- every member of the device group (`_GroupResidentLoop`), or member 0 alone when the minibatches are too small
+        to split.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
         from . import optimize as opt
         if not self._resident_sgd or os.environ.get("RR_GLM_RESIDENT_SGD", "1") == "0":
             return None

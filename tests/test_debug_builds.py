@@ -42,7 +42,9 @@ RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "test
           "tests/test_gpu_glm_fit.py::test_fit_equals_the_references_fit[gaussian_cat_bs10_ns5-fused loop]",
           "tests/test_gpu_glm_fit.py::test_fit_equals_the_references_fit[binomial_cat_bs10_ns3-fused loop]",
           "tests/test_gpu_glm_fit.py::test_fit_equals_the_references_fit[poisson_ard_bs64f_ns5-resident loop]",
-          "tests/test_gpu_fused_svi.py::test_shapes_across_the_tiles_of_the_matrix_core_products"]
+          "tests/test_gpu_fused_svi.py::test_shapes_across_the_tiles_of_the_matrix_core_products",
+          "tests/test_gpu_resident_group.py::test_a_member_without_rows_of_a_minibatch_follows_the_others",
+          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit"]
 
 
 def _asan_runtime():

@@ -267,14 +267,30 @@ def test_fit_predict_and_glm_between_gpus(devices, transport, monkeypatch):
     rs = np.random.RandomState(5)
     yp = rs.poisson(np.exp(0.4 * np.sin(X[:, 0]))).astype(float)
 
-    def glm(dv):
+    # the GLM: the resident loop over the group (rr_glm_sgd_group_step: every member's share of a minibatch on its own GPU, the
+    # row sums all-reduced across them, the update replicated) and the host loop around the sharded `_elbo`
+    from revrand_amd import _hip as hip_
+    steps = [0]
+    real = hip_.ResidentSgdGroup.step
+
+    def spy(self, *a, **k):
+        steps[0] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(hip_.ResidentSgdGroup, "step", spy)
+
+    def glm(dv, resident=True):
         basis = bs.RandomRBF(nbases=64, Xdim=5, random_state=3, lenscale=Parameter(np.ones(5), Positive()))
         np.random.seed(4)
-        return GeneralizedLinearModel(lk.Poisson(), basis, K=3, nsamples=8, batch_size=8192, maxiter=6, nstarts=2,
-                                      random_state=2, devices=dv).fit(X, yp)
-    a, b = glm(None), glm(devices)
-    assert normwise(b.weights_, a.weights_) < 1e-4 and normwise(b.covariance_, a.covariance_) < 1e-4
-    assert a.random_.randn() == b.random_.randn()
+        g = GeneralizedLinearModel(lk.Poisson(), basis, K=3, nsamples=8, batch_size=2048 * len(devices), maxiter=6, nstarts=2,
+                                   random_state=2, devices=dv)
+        g._resident_sgd = resident
+        return g.fit(X, yp)
+    a, b, c = glm(None), glm(devices), glm(devices, resident=False)
+    assert steps[0] == 6
+    for m in (b, c):
+        assert normwise(m.weights_, a.weights_) < 1e-4 and normwise(m.covariance_, a.covariance_) < 1e-4
+        assert normwise(m.basis_hypers_, a.basis_hypers_) < 1e-4
+    assert a.random_.randn() == b.random_.randn() == c.random_.randn()
 
 
 # ---- every kind of resident fit state behind devices= (distinct GPUs when the box has two, else two members on one) -------

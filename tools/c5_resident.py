@@ -1,5 +1,6 @@
 """Config 5's `fit` through the resident SVI loop (rr_glm_sgd), for rocprofv3: two fits of different length, the per-step
-wall-clock from their difference.  `python tools/c5_resident.py [host|device] [resident|hostloop] [short long]`."""
+wall-clock from their difference.  `python tools/c5_resident.py [host|device] [resident|hostloop] [short long]`.
+DEVICES=0,0 (or 0,1,...): the same fit with devices=[...] -- the loop over a device group (rr_glm_sgd_group_step)."""
 import os
 import sys
 import time
@@ -26,7 +27,8 @@ for rep in range(int(os.environ.get("REPS", "2"))):
     for iters in (short, long_):
         g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
                                    K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler=sampler,
-                                   gram_engine=os.environ.get("ENGINE") or None)
+                                   gram_engine=os.environ.get("ENGINE") or None,
+                                   devices=[int(v) for v in os.environ["DEVICES"].split(",")] if os.environ.get("DEVICES") else None)
         g._resident_sgd = resident
         marks = {"A": [], "B": []}
         if os.environ.get("STAGES"):   # when did each pipeline stage finish each batch?
