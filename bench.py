@@ -1811,6 +1811,12 @@ def single_process(args, json_out):
         except Exception as e:  # noqa: BLE001 -- the line still goes out, with the failure named
             configs["elbo_rbf_f4096_single_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
         dog.cancel()
+        dog = _watchdog(args, "C5_glm_svi_step_single_process", configs, emit)
+        try:
+            configs["C5_glm_svi_step_single_process"] = single_process_glm(args, devices, group)
+        except Exception as e:  # noqa: BLE001
+            configs["C5_glm_svi_step_single_process"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        dog.cancel()
     emit(configs or None)
     assert ok, (trace_err, members_identical)
     if peer_hung:
@@ -1876,6 +1882,49 @@ def single_process_elbo(args, devices, group):
                          "frac": (fl_stats + fl_pass2) * N / (t_eval * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
 
 
+def single_process_glm(args, devices, group):
+    """Config 5's SVI step with the loop resident on EVERY member of the device group (`GeneralizedLinearModel(devices=...)`:
+    rr_glm_sgd_group_step -- each member steps its share of the 65 536-row minibatch, two all-reduces per step in HBM,
+    parameters replicated), next to the same fit on ONE context of this process: the interval between the moments the loop
+    queues its steps (the queue is two deep: it follows the devices) over steps 8.. of a 56-step fit, device sampler (no
+    host generator in the way); parity: the two fits' parameters after 8 steps."""
+    import logging
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    logging.getLogger("revrand_amd").setLevel(logging.ERROR)
+    N, d, n, K, L, M = 2_000_000, 32, 1024, 10, 50, 65536
+    rng = np.random.default_rng([20260928, 5])
+    X = rng.standard_normal((N, d), dtype=np.float32)
+    y = rng.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(np.float64)
+
+    def fit(iters, dv):
+        g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
+                                   K=K, nsamples=L, batch_size=M, maxiter=iters, nstarts=0, random_state=2, sampler="device", devices=dv)
+        np.random.seed(20260930)
+        g.fit(X, y)
+        ck = g.__dict__.get("_resident_clock")
+        flat = np.concatenate((g.weights_.ravel(), g.covariance_.ravel(), np.atleast_1d(g.basis_hypers_)))
+        return flat, (1e3 * np.diff(ck[8:-1]) if ck is not None and len(ck) > 12 else None)
+    out = {}
+    p1, _ = fit(8, None)
+    pg, _ = fit(8, devices)
+    err = float(np.linalg.norm(pg - p1) / np.linalg.norm(p1))
+    _, dt1 = fit(56, None)
+    _, dtg = fit(56, devices)
+    parity("C5 group loop: parameters after 8 steps vs one context (normwise)", err, 1e-4)
+    gemm_flops = 3 * 2.0 * K * L * M * 2 * n
+    world = len(devices)
+    ms1, msg = float(np.median(dt1)), float(np.median(dtg))
+    out = {"workload": "GLM Poisson, RandomRBF F=2048 D=32 ARD, N=2M, K=10 L=50, minibatch 65536: SVI step of fit(devices=%d), device sampler" % world,
+           "ms": msg, "one_context_ms": ms1, "speedup_vs_one_context": ms1 / msg, "value": M / (msg * 1e-3), "unit": "minibatch-rows/s",
+           "dtype": "f32", "transport": group.transport, "parity": {"params_after_8_steps_vs_one_context": err},
+           "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS * world,
+                        "frac": gemm_flops / (msg * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
+    return out
+
+
 def single_process_under_ranks(args, comm, rank, world):
     """Inside the one-process-per-GPU run: once the ranks are done, rank 0 starts `bench.py --gpus N --single-process` as a
     CHILD (the same N GPUs behind one process: the in-process device group of StandardLinearModel(devices=N)) and reports
@@ -1910,6 +1959,7 @@ def single_process_under_ranks(args, comm, rank, world):
             else:
                 d = json.loads(lines[-1])
                 ex, el = d.get("exchange", {}), (d.get("configs") or {}).get("elbo_rbf_f4096_single_process", {})
+                gl = (d.get("configs") or {}).get("C5_glm_svi_step_single_process", {})
                 res = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
                        "n_gpus": d["n_gpus"], "frac": d["roofline"].get("whole_path_frac"),
                        "exchange": {k: ex.get(k) for k in ("transport", "ms_per_step_pack_allreduce_unpack", "busbw_GBps",
@@ -1919,7 +1969,8 @@ def single_process_under_ranks(args, comm, rank, world):
                                                     if k in (ex.get("preflight_peer_transport") or {})} or None,
                        "speedup_model": (d.get("per_rank") or {}).get("expected_speedup_model", {}).get("speedup_vs_one_gpu"),
                        "members_bit_identical": d["config"].get("members_bit_identical"),
-                       "elbo": {k: el.get(k) for k in ("ms", "stage_ms", "parity", "error") if k in el}}
+                       "elbo": {k: el.get(k) for k in ("ms", "stage_ms", "parity", "error") if k in el},
+                       "glm_c5": {k: gl.get(k) for k in ("ms", "one_context_ms", "speedup_vs_one_context", "parity", "error") if k in gl}}
         except subprocess.TimeoutExpired:
             res = {"error": "child still running after %.0f s" % child_limit}
         except Exception as e:  # noqa: BLE001

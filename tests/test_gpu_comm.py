@@ -351,6 +351,7 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
     assert sp["exchange"]["transport"] == "peer" and sp["exchange"]["oversubscribed"]
     assert sp["elbo"]["parity"]["neg_elbo_256_rows"] < 1e-5 and sp["elbo"]["parity"]["gradient_256_rows"] < 1e-3
     assert sp["elbo"]["parity"]["members_bit_identical"]
+    assert "error" not in sp["glm_c5"] and sp["glm_c5"]["parity"]["params_after_8_steps_vs_one_context"] < 1e-4, sp["glm_c5"]
 
 
 def test_bench_launcher_timeout_ends_all_ranks_and_says_which():

@@ -287,6 +287,10 @@ def test_bench_single_process_line():
     c = out["configs"]["elbo_rbf_f4096_single_process"]
     assert "error" not in c, c
     assert c["parity"]["members_bit_identical"] and c["parity"]["neg_elbo_256_rows"] < 1e-5 and c["parity"]["gradient_256_rows"] < 1e-3
+    # config 5's SVI step with the loop resident on both members (rr_glm_sgd_group_step) next to the one-context fit
+    g = out["configs"]["C5_glm_svi_step_single_process"]
+    assert "error" not in g, g
+    assert g["parity"]["params_after_8_steps_vs_one_context"] < 1e-4 and g["ms"] > 0 and g["one_context_ms"] > 0
 
 
 def test_glm_with_devices_matches_the_one_context_run():
