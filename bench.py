@@ -1460,7 +1460,8 @@ def dist_configs(dev, _hip, comm, args, emit=None):
                 dev, _hip, comm, args, lambda: bs.FastFoodRBF(nbases=8192, Xdim=128, random_state=1,
                                                               lenscale=Parameter(np.ones(128), Positive())),
                 _c4_data, args.dist_rows_c4, 128, 8192, np.linspace(0.8, 1.3, 128), 1.0, parity_fn=_ff_elbo_parity,
-                flops=lambda F: (F * (F + 1.0) + 2.0 * F + 64 * (2.0 * 128 * 7 + 3.0 * 128), 2.0 * F * F + 2.0 * 128 * F))))
+                flops=lambda F: (F * (F + 1.0) + 2.0 * F + 64 * (2.0 * 128 * 7 + 3.0 * 128), 2.0 * F * F + 2.0 * 128 * F))),
+            ("C5_glm_svi_step_dist", lambda: dist_glm(dev, _hip, comm, args)))
     for name, fn in jobs:
         if args.configs != "all" and name.split("_")[0].lower() not in want and name.lower() not in want:
             continue
@@ -1488,6 +1489,54 @@ def dist_configs(dev, _hip, comm, args, emit=None):
         if fatal:
             break
     return res
+
+
+def dist_glm(dev, _hip, comm, args):
+    """Config 5's SVI step with one process per GPU (`GeneralizedLinearModel(distributed=True)`): the 2 M rows sharded over the
+    ranks, every rank cuts 65 536 / world rows of ITS shard per step (the job's minibatch stays 65 536 rows), the loop resident
+    on every rank (rr_glm_sgd_dist_step: dT and [Edm | EdC | sums | llconst | rows] all-reduced over the ranks in HBM, the
+    update replicated).  The interval between the moments rank 0 queues its steps over steps 8.. of a 56-step fit, device
+    sampler; the ranks' parameters after the fit must be the same bits."""
+    import logging
+    import revrand_amd.basis_functions as bs
+    from revrand_amd import likelihoods as lk
+    from revrand_amd import parallel
+    from revrand_amd.btypes import Parameter, Positive
+    from revrand_amd.glm import GeneralizedLinearModel
+    logging.getLogger("revrand_amd").setLevel(logging.ERROR)
+    N, d, n, K, L, M = 2_000_000, 32, 1024, 10, 50, 65536
+    world, rank = comm.world, comm.rank
+    a, b = parallel.shard_bounds(N, rank, world)
+    rng = np.random.default_rng([20260928, 5, rank])
+    X = rng.standard_normal((b - a, d), dtype=np.float32)
+    y = rng.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(np.float64)
+
+    def fit(iters):
+        g = GeneralizedLinearModel(lk.Poisson(), bs.RandomRBF(nbases=n, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive())),
+                                   K=K, nsamples=L, batch_size=M // world, maxiter=iters, nstarts=0, random_state=2, sampler="device",
+                                   distributed=True)
+        np.random.seed(20260930)
+        g.fit(X, y)
+        flat = np.concatenate((g.weights_.ravel(), g.covariance_.ravel(), np.atleast_1d(g.basis_hypers_)))
+        return flat, g.__dict__.get("_resident_clock")
+    fit(8)
+    flat, ck = fit(56)
+    resident = ck is not None and len(ck) > 12
+    ms = float(np.median(1e3 * np.diff(ck[8:-1]))) if resident else float("nan")
+    ms = float(comm.allreduce_host(np.array([ms]), op="max")[0])
+    # every rank holds the same parameters: max and min over the ranks of a few checksums coincide
+    chk = np.array([flat.sum(), np.abs(flat).sum(), float(flat[:: max(1, flat.size // 997)] @ np.arange(len(flat[:: max(1, flat.size // 997)])))])
+    hi, lo = comm.allreduce_host(chk, op="max"), comm.allreduce_host(chk, op="min")
+    same = bool(np.array_equal(hi, lo)) and bool(np.all(np.isfinite(flat)))
+    gemm_flops = 3 * 2.0 * K * L * M * 2 * n
+    out = {"workload": "config 5's SVI step, fit(distributed=True): N=2M over %d ranks, job minibatch 65536, device sampler" % world,
+           "ms": ms, "value": M / (ms * 1e-3), "unit": "minibatch-rows/s", "dtype": "f32", "resident_loop": bool(resident),
+           "parity": {"ranks_identical": same},
+           "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS * world,
+                        "frac": gemm_flops / (ms * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
+    if not same:
+        raise ParityError("C5 distributed fit: the ranks' parameters differ")
+    return out
 
 
 def _watchdog(args, name, res, emit):

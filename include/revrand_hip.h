@@ -698,6 +698,15 @@ typedef struct rr_glm_sgd_batch {
 int rr_glm_sgd_group_step(int n, rr_glm_sgd *const *loops, rr_comm *const *comms, const rr_glm_sgd_batch *batches, int dtype,
                           int lik, double llconst, double bmag, int L, uint64_t seed, uint64_t key);
 
+/* The same step on ONE rank of a one-process-per-GPU job (comm from rr_comm_init_rank, bound to the loop's context):
+ * GeneralizedLinearModel(distributed=True).fit -- every rank calls it with a minibatch of ITS rows (rows == 0 allowed), its
+ * llconst and the whole job's bmag; dT and [Edm | EdC | llsum | aux | llconst | rows] are all-reduced over the ranks in HBM
+ * (ncclAllReduce on the context's stream) and every rank makes the same update of its copy of z.  Collective: all ranks, the
+ * same number of times.  Returns without waiting, like rr_glm_sgd_step. */
+int rr_glm_sgd_dist_step(rr_glm_sgd *s, rr_comm *comm, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows,
+                         const void *dy, const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE,
+                         uint64_t seed, uint64_t key);
+
 /* ---- host-side random stream of the GLM step ------------------------------ */
 
 /* Advance a NumPy legacy RandomState (MT19937 + polar Box-Muller with one cached value) by n standard normals and write

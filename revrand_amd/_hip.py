@@ -153,6 +153,9 @@ SIGNATURES = {
     "rr_glm_sgd_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
+    "rr_glm_sgd_dist_step": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_double,
+                                            ctypes.c_double, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]),
     "rr_glm_sgd_group_step": (ctypes.c_int, [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                              ctypes.c_double, ctypes.c_double, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint64]),
     "rr_glm_sgd_read": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -1109,16 +1112,21 @@ class ResidentSgd(object):
                                                     ctypes.byref(h)))
         self.h = h
 
-    def step(self, dXs, rows, dy, drowarg, lik, llconst, bmag, L, dE=None, seed=0, key=0):
-        """dXs: every child's minibatch rows (DeviceView), in concatenation order."""
+    def step(self, dXs, rows, dy, drowarg, lik, llconst, bmag, L, dE=None, seed=0, key=0, comm=None):
+        """dXs: every child's minibatch rows (DeviceView), in concatenation order.  comm (an rr_comm handle of this rank, one
+        process per GPU): rr_glm_sgd_dist_step -- the step's row sums all-reduced over the ranks in HBM."""
         for i, dX in enumerate(dXs):
             p = dX.ptr
             self._ptrs[i] = p if isinstance(p, int) else p.value
             self._dts[i], self._lds[i] = rr_dtype(dX.dtype), dX.ld
-        _check(self.lib, self.lib.rr_glm_sgd_step(self.h, ctypes.cast(self._ptrs, ctypes.c_void_p), ctypes.cast(self._dts, ctypes.c_void_p),
-                                                  ctypes.cast(self._lds, ctypes.c_void_p), int(rows), _ptr(dy), _ptr(drowarg),
-                                                  rr_dtype(dy.dtype), int(lik), float(llconst), float(bmag), int(L),
-                                                  None if dE is None else dE.ptr, int(seed), int(key)))
+        args = (ctypes.cast(self._ptrs, ctypes.c_void_p), ctypes.cast(self._dts, ctypes.c_void_p),
+                ctypes.cast(self._lds, ctypes.c_void_p), int(rows), _ptr(dy), _ptr(drowarg),
+                rr_dtype(dy.dtype), int(lik), float(llconst), float(bmag), int(L),
+                None if dE is None else dE.ptr, int(seed), int(key))
+        if comm is None:
+            _check(self.lib, self.lib.rr_glm_sgd_step(self.h, *args))
+        else:
+            _check(self.lib, self.lib.rr_glm_sgd_dist_step(self.h, comm, *args))
 
     def objective(self, step):
         v = ctypes.c_double()

@@ -1569,7 +1569,8 @@ static int fm_glm_scratch(rr_featmat *fm, int64_t klp, int K) {
     // [m | C | Edm | EdC] and, right behind them, [llsum | aux]: with K == kcap (one K per fit) everything a step sums over rows
     // besides dT is ONE contiguous run -- one all-reduce per step of a device group (rr_glm_sgd_group_step)
     const size_t kc = (size_t)(K > 1 ? K : 1);
-    if (ea == hipSuccess) ea = hipMalloc((void **)&s.mc, (4 * kc * (size_t)fm->F + 2 * kc) * 8);
+    // (+ 2: [llconst | rows] of the minibatch when they are sums over RANKS -- rr_glm_sgd_dist_step)
+    if (ea == hipSuccess) ea = hipMalloc((void **)&s.mc, (4 * kc * (size_t)fm->F + 2 * kc + 2) * 8);
     if (ea == hipSuccess) s.kacc = s.mc + 4 * kc * (size_t)fm->F;
     if (ea != hipSuccess) {
         (void)hipGetLastError();
@@ -3198,6 +3199,7 @@ struct SgdUpdArgs {
     int F, K, nkids, n_lik, n_ls, updater, L;
     int64_t np, p0, p1;  // all coordinates; this launch's are [p0, p1)
     double bmag, nrows, up[4], b1t, b2t;
+    const double *tot = nullptr;  // device [llconst | rows] summed over ranks (rr_glm_sgd_dist_step); null: nrows above
 };
 
 __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs a) {
@@ -3248,7 +3250,8 @@ __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs
         } else if (p < 2 * fk + a.nkids + a.n_lik) {  // Gaussian variance: dp = ((y - f)^2 / var^2 - 1 / var) / 2  (likelihoods.py:360-381)
             const double ivar = 1.0 / a.x[p];
             double sm = 0.0;
-            for (int k = 0; k < K; ++k) sm += 0.5 * (a.aux[k] * ivar * ivar - ivar * a.nrows * a.L) / a.L;
+            const double nrows = a.tot ? a.tot[1] : a.nrows;
+            for (int k = 0; k < K; ++k) sm += 0.5 * (a.aux[k] * ivar * ivar - ivar * nrows * a.L) / a.L;
             g = 0.0 - sm / K;
         } else {  // -(EdPhi o dPhi_i).sum() = W[i,:].T[i,:] / l_i^2; isotropic: input dimension 0 only, as the reference
             const int j = (int)(p - (2 * fk + a.nkids + a.n_lik));
@@ -3298,7 +3301,7 @@ __global__ void __launch_bounds__(256)
 rr_glm_sgd_finish_kernel(const double *__restrict__ x, const double *__restrict__ red, const double *__restrict__ llsum,
                          const double *__restrict__ npart, int nblocks, int F, int K, int L, int nkids, const int *__restrict__ slice_lo,
                          const int *__restrict__ slice_hi, int n_lik, double llconst, double nrows, double bmag,
-                         double *__restrict__ obj, double *__restrict__ norm) {
+                         double *__restrict__ obj, double *__restrict__ norm, const double *__restrict__ tot) {
 #pragma clang fp contract(off)
     __shared__ double sh[256];
     const int tid = threadIdx.x;
@@ -3316,6 +3319,10 @@ rr_glm_sgd_finish_kernel(const double *__restrict__ x, const double *__restrict_
     const double logzsum = rr_block_sum256(lz, sh);
     if (tid == 0) {
         const int64_t fk = (int64_t)F * K;
+        if (tot) {  // the whole job's minibatch: sums over the ranks
+            llconst = tot[0];
+            nrows = tot[1];
+        }
         if (n_lik) llconst = -0.5 * log(2.0 * 3.141592653589793 * x[2 * fk + nkids]) * nrows;  // Gaussian (likelihoods.py:295-317)
         double ell = 0.0;
         for (int k = 0; k < K; ++k) ell += llsum[k] / L + llconst;
@@ -3522,7 +3529,13 @@ struct SgdStepIn {
     int L;
     const float *dE;
     uint64_t seed, key;
+    bool totals_on_device = false;  // rr_glm_sgd_dist_step: llconst and the row count are summed over the ranks in HBM
 };
+
+__global__ void rr_glm_sgd_set_totals_kernel(double *tot, double llconst, double rows) {
+    tot[0] = llconst;
+    tot[1] = rows;
+}
 
 static rr_featmat *sgd_step_fm(rr_glm_sgd *o) { return (o->overlap && (o->t & 1)) ? o->fm2 : o->fm; }
 
@@ -3642,6 +3655,7 @@ static void sgd_update_args(rr_glm_sgd *o, const SgdStepIn &in, FmPass2 &s, SgdU
     a.slice_of_f = o->slice_of_f; a.slice_lo = o->slice_lo; a.slice_hi = o->slice_hi; a.h_of_ls = o->h_of_ls;
     a.F = o->F; a.K = o->K; a.nkids = o->nkids; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = in.L; a.np = o->np;
     a.bmag = in.bmag; a.nrows = (double)in.rows_total;
+    a.tot = in.totals_on_device ? s.kacc + 2 * s.kcap : nullptr;
     for (int i = 0; i < 4; ++i) a.up[i] = o->up[i];
     const double tt = (double)(o->t + 1);
     a.b1t = 1.0 - pow(o->up[1], tt);
@@ -3700,7 +3714,8 @@ static int sgd_step_back(rr_glm_sgd *o, const SgdStepIn &in) {
     hipLaunchKernelGGL(rr_glm_sgd_update_kernel, dim3(nb_main), dim3(256), 0, s0, a);
     RR_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(rr_glm_sgd_finish_kernel, dim3(1), dim3(256), 0, s0, o->x, o->red, s.kacc, o->npart, (int)(nb_main + nb_ls), F, K, L,
-                       nk, o->slice_lo, o->slice_hi, o->n_lik, in.llconst, (double)in.rows_total, in.bmag, o->objs + o->t, o->norms + o->t);
+                       nk, o->slice_lo, o->slice_hi, o->n_lik, in.llconst, (double)in.rows_total, in.bmag, o->objs + o->t, o->norms + o->t,
+                       a.tot);
     RR_CHECK_HIP(hipGetLastError());
     RR_CHECK_HIP(hipEventRecord(o->ev[o->t & 1], c->stream));
     o->t += 1;
@@ -3778,6 +3793,42 @@ int rr_glm_sgd_group_step(int n, rr_glm_sgd *const *loops, rr_comm *const *comms
         o0->call_ns += sgd_now_ns() - t_call;
         o0->group_steps += 1;
     }
+    return rc;
+}
+
+// The same step on ONE rank of a one-process-per-GPU job (rr_comm_init_rank): this rank's minibatch -- rows of ITS shard of the
+// data, cut by its own generator -- and two all-reduces over the ranks, as between the members of a group: dT, then
+// [Edm | EdC | llsum | aux | llconst | rows] (the f-independent constant and the row count are sums over ranks too: they
+// travel in the same message and the Gaussian's terms / the step's record read them from HBM).  Every rank makes the same
+// update of its copy of z.  Asynchronous like rr_glm_sgd_step: nothing is waited for but step t - 2's event.
+int rr_glm_sgd_dist_step(rr_glm_sgd *o, rr_comm *comm, const void *const *dX, const int *x_dtype, const int64_t *ldx, int64_t rows,
+                         const void *dy, const void *drowarg, int dtype, int lik, double llconst, double bmag, int L, const float *dE,
+                         uint64_t seed, uint64_t key) {
+    RR_REQUIRE(o != nullptr && comm != nullptr, "rr_glm_sgd_dist_step: null argument");
+    RR_REQUIRE(rr_comm_ctx(comm) == o->fm->ctx, "rr_glm_sgd_dist_step: loop and communicator live on different contexts");
+    SgdStepIn in = {dX, x_dtype, ldx, rows, rows, dy, drowarg, dtype, lik, llconst, bmag, L, dE, seed, key};
+    in.totals_on_device = true;
+    int rc = sgd_step_check(o, in, 0, "rr_glm_sgd_dist_step");
+    if (rc == RR_OK) rc = sgd_step_front(o, in);
+    if (rc != RR_OK) return rc;
+    if (o->n_ls) {
+        rc = rr_comm_allreduce_dev(comm, o->dT, o->dT_count, RR_COMM_SUM);
+        if (rc != RR_OK) return rc;
+    }
+    rc = sgd_step_middle(o, in);
+    if (rc != RR_OK) return rc;
+    rr_ctx *c = o->fm->ctx;
+    FmPass2 *s = (FmPass2 *)sgd_step_fm(o)->pass2;
+    double *tot = s->kacc + 2 * s->kcap;
+    hipLaunchKernelGGL(rr_glm_sgd_set_totals_kernel, dim3(1), dim3(1), 0, c->stream, tot, llconst, (double)rows);
+    RR_CHECK_HIP(hipGetLastError());
+    if (s->kacc == s->mc + 4 * o->fk) {  // one run (the scratch was made for this K)
+        rc = rr_comm_allreduce_dev(comm, s->mc + 2 * o->fk, 2 * o->fk + 2 * (int64_t)s->kcap + 2, RR_COMM_SUM);
+    } else {
+        rc = rr_comm_allreduce_dev(comm, s->mc + 2 * o->fk, 2 * o->fk, RR_COMM_SUM);
+        if (rc == RR_OK) rc = rr_comm_allreduce_dev(comm, s->kacc, 2 * (int64_t)s->kcap + 2, RR_COMM_SUM);
+    }
+    if (rc == RR_OK) rc = sgd_step_back(o, in);
     return rc;
 }
 

@@ -118,12 +118,14 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         Row-sharded SVI, one process per GPU under ``torch.distributed``: every rank calls ``fit`` with ITS rows and
         the same integer ``random_state``; per step each rank takes a minibatch of its shard, the Monte-Carlo sums
         ``[Edm | EdC | sum loglike | likelihood sums | basis gradient | batch rows]`` are all-reduced (one message,
-        2 D K + O(d) numbers) and every rank applies the same update.
+        2 D K + O(d) numbers) and every rank applies the same update.  Over an RCCL communicator the optimiser's loop is
+        resident on every rank and the sums are all-reduced in HBM (rr_glm_sgd_dist_step).
     devices : None | sequence of GPU indices | int | "all"
         Several GPUs behind THIS call, in this process (``revrand_amd.multigpu``): the rows of X stay resident sharded over
         the listed GPUs, every member serves the rows of a minibatch that fall into its shard, and the step's Monte-Carlo
-        sums are added over the members on the host.  The minibatch stream, the draws and the optimiser are the single-GPU
-        run's; minibatches of fewer than 2048 rows per member are not split."""
+        sums are added over the members -- in HBM, with the optimiser's loop resident on every member (rr_glm_sgd_group_step),
+        or on the host when the fit is one the device loops do not cover.  The minibatch stream, the draws and the optimiser
+        are the single-GPU run's; minibatches of fewer than 2048 rows per member are not split."""
 
     def __init__(self, likelihood=Gaussian(), basis=LinearBasis(), K=10, maxiter=3000, batch_size=10, updater=None,
                  nsamples=50, nstarts=500, random_state=None, sampler="host", distributed=False, gram_engine=None,
@@ -294,8 +296,21 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         if not self._resident_sgd or os.environ.get("RR_GLM_RESIDENT_SGD", "1") == "0":
             return None
         feats = self._features()
-        if not getattr(self, "_resident_fit", False) or self.distributed or self.sampler not in ("host", "device"):
+        if not getattr(self, "_resident_fit", False) or self.sampler not in ("host", "device"):
             return None
+        if self.distributed:
+            # one process per GPU: the step-per-call loop with its two all-reduces over the ranks in HBM (rr_glm_sgd_dist_step)
+            # when the job's communicator is RCCL on this rank's context; a gloo group (the CPU test transport) keeps the
+            # host loop, whose one all-reduce per step goes through the host
+            from . import parallel
+            comm = parallel.get_comm()
+            if type(feats) is not MinibatchFeatures:
+                return None
+            if getattr(comm, "world", 1) == 1:
+                return self._one_device_loop(feats, params, y, likelihood_args)
+            if getattr(comm, "kind", None) != "rccl" or comm.dev.ctx.value != _hip.get_device().ctx.value:
+                return None
+            return self._one_device_loop(feats, params, y, likelihood_args, comm=comm.h)
         group = self._group()
         if group is not None:
             # a device group: the minibatch's rows spread over ALL members (`_GroupResidentLoop`: per-member products, the row
@@ -357,7 +372,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             return None
         return children
 
-    def _one_device_loop(self, feats, params, y, likelihood_args):
+    def _one_device_loop(self, feats, params, y, likelihood_args, comm=None):
         if not self._loop_covers(params):
             return None
         children = self._loop_children(feats, params)
@@ -365,8 +380,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             return None
         kids, n_lik = feats._kids, self._n_lik(params)
         # small minibatches (the reference's default is 10 rows): the whole loop inside one kernel, many steps per launch
+        # (not between ranks: that kernel has no exchange step)
         if self._fused_sgd and os.environ.get("RR_GLM_FUSED", "1") != "0" and y is not None and len(likelihood_args) <= 1 \
-                and np.isfinite(self.maxiter):
+                and np.isfinite(self.maxiter) and comm is None:
             N = len(y)
             M = int(min(self.batch_size, N))
             F = int(self.D_)
@@ -374,7 +390,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
             n_ls = sum(c[2] for c in children if c[0] == "rff")
             if _hip.svi_supported(F, self.K, self.nsamples, M, len(children), dsum, n_ls):
                 return _FusedLoop(self, feats, n_lik, children, y, likelihood_args)
-        return _ResidentLoop(self, feats, n_lik, children)
+        return _ResidentLoop(self, feats, n_lik, children, comm=comm)
 
     def _reference_draws(self, out=None):
         """The step's standard normals from `random_` in the reference's order (glm.py:300): randn(L, D) per component.
@@ -748,10 +764,12 @@ class _ResidentLoop(object):
     what it would have logged every LOGITER iterations is logged from the device's objective."""
 
     log_coordinates = None
+    comm = None   # distributed=True over RCCL: this rank's rr_comm -- the step's row sums are all-reduced over the ranks in HBM
 
-    def __init__(self, glm, feats, n_lik, children):
+    def __init__(self, glm, feats, n_lik, children, comm=None):
         self.glm, self.feats, self.n_lik, self.children = glm, feats, n_lik, children
         self.sgd = None
+        self.comm = comm
 
     def begin(self, z0, lower, upper, updater, maxiter):
         from . import optimize as opt
@@ -826,7 +844,7 @@ class _ResidentLoop(object):
             if draws is None:
                 draws = g._reference_draws()
             dE = draws if isinstance(draws, _hip.DeviceBuffer) else feats._stage("E", draws, np.float32)
-        self.sgd.step(dX, len(idx), dy, dn, lid, llconst, g.B_, g.nsamples, dE, seed, key)
+        self.sgd.step(dX, len(idx), dy, dn, lid, llconst, g.B_, g.nsamples, dE, seed, key, comm=self.comm)
         self.clock.append(time.perf_counter())
         if dolog:
             log.info("Iter {}: ELBO = {}, reg = {}, like_hypers = {}, basis_hypers = {}"

@@ -193,12 +193,26 @@ if rank == 0:
     parallel.set_comm(comm)
 # the GLM's SVI over the same communicator: unequal shards (2501 / 2500 rows), random starts -> identical parameters
 from revrand_amd.glm import GeneralizedLinearModel
-from revrand_amd.likelihoods import Poisson
+from revrand_amd.likelihoods import Gaussian, Poisson
 yp = np.random.RandomState(5).poisson(np.exp(0.3 * np.sin(X[:, 0].astype(float)))).astype(float)
-glm = GeneralizedLinearModel(Poisson(), bs.RandomRBF(nbases=24, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())),
-                             K=2, nsamples=6, batch_size=300, maxiter=6, nstarts=3, random_state=4, distributed=True)
-glm.fit(X[a:b].astype(float), yp[a:b])
-out["glm"] = glm.weights_.ravel().tolist() + np.asarray(glm.basis_hypers_).tolist() + [float(glm.regularizer_)]
+# -- with the loop resident on every rank (rr_glm_sgd_dist_step: dT and [Edm | EdC | sums | llconst | rows] all-reduced over the ranks
+# in HBM, the update replicated) and, from the same seeds, with the host loop around `_elbo` (one host all-reduce per step)
+dist_steps = [0]
+real_step = _hip.ResidentSgd.step
+def spy(self, *a, **k):
+    dist_steps[0] += k.get("comm") is not None
+    return real_step(self, *a, **k)
+_hip.ResidentSgd.step = spy
+for tag, resident, lik, yy in (("glm", True, Poisson(), yp), ("glm_host", False, Poisson(), yp),
+                               ("glm_gauss", True, Gaussian(), y.astype(float)), ("glm_gauss_host", False, Gaussian(), y.astype(float))):
+    glm = GeneralizedLinearModel(lik, bs.RandomRBF(nbases=24, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive())),
+                                 K=2, nsamples=6, batch_size=300, maxiter=6, nstarts=3, random_state=4, distributed=True)
+    glm._resident_sgd = resident
+    np.random.seed(7)
+    glm.fit(X[a:b].astype(float), yy[a:b])
+    out[tag] = glm.weights_.ravel().tolist() + glm.covariance_.ravel().tolist() + np.asarray(glm.basis_hypers_).tolist() \
+        + [float(glm.regularizer_)] + np.atleast_1d(np.asarray(glm.like_hypers_, dtype=float)).tolist()
+out["glm_dist_steps"] = dist_steps[0]
 assert "torch" not in sys.modules
 comm.barrier()
 comm.close()
@@ -220,6 +234,11 @@ def test_two_rccl_ranks_sum_shard_statistics_and_fit_identically(tmp_path):
     assert res[0]["cat_elbo"] == res[1]["cat_elbo"]                                      # concatenation (config 3's form)
     assert normwise(np.array(res[0]["cat_elbo"]), np.array(res[0]["cat_elbo_single"])) < 5e-4
     assert res[0]["glm"] == res[1]["glm"] and len(set(np.round(res[0]["glm"], 10))) > 4  # SVI: ranks bit-identical
+    # ... through the resident loop (6 steps of rr_glm_sgd_dist_step per fit) as through the host loop, and the two agree
+    assert res[0]["glm_dist_steps"] == res[1]["glm_dist_steps"] == 12
+    for tag in ("glm", "glm_gauss"):
+        assert res[0][tag] == res[1][tag] and res[0][tag + "_host"] == res[1][tag + "_host"]
+        assert normwise(np.array(res[0][tag]), np.array(res[0][tag + "_host"])) < 1e-4, tag
 
 
 def test_bench_two_ranks_as_the_driver_calls_it():
@@ -345,6 +364,9 @@ def test_bench_rehearsal_of_the_drivers_multi_gpu_call(world):
     # ranks are done: here the members share the one GPU and take the peer transport
     if world != 8:
         return
+    # config 5's SVI step between the ranks: the loop resident on every rank (rr_glm_sgd_dist_step), same bits everywhere
+    g5 = out["configs"]["C5_glm_svi_step_dist"]
+    assert "error" not in g5 and g5["resident_loop"] and g5["parity"]["ranks_identical"] and g5["ms"] > 0, g5
     sp = out["configs"]["single_process"]
     assert "error" not in sp, sp
     assert sp["n_gpus"] == world and sp["value"] > 0 and sp["members_bit_identical"]
