@@ -1504,7 +1504,7 @@ def dist_glm(dev, _hip, comm, args):
     from revrand_amd.btypes import Parameter, Positive
     from revrand_amd.glm import GeneralizedLinearModel
     logging.getLogger("revrand_amd").setLevel(logging.ERROR)
-    N, d, n, K, L, M = 2_000_000, 32, 1024, 10, 50, 65536
+    N, d, n, K, L, M = _glm_rows(args), 32, 1024, 10, 50, 65536
     world, rank = comm.world, comm.rank
     a, b = parallel.shard_bounds(N, rank, world)
     rng = np.random.default_rng([20260928, 5, rank])
@@ -1529,7 +1529,7 @@ def dist_glm(dev, _hip, comm, args):
     hi, lo = comm.allreduce_host(chk, op="max"), comm.allreduce_host(chk, op="min")
     same = bool(np.array_equal(hi, lo)) and bool(np.all(np.isfinite(flat)))
     gemm_flops = 3 * 2.0 * K * L * M * 2 * n
-    out = {"workload": "config 5's SVI step, fit(distributed=True): N=2M over %d ranks, job minibatch 65536, device sampler" % world,
+    out = {"workload": "config 5's SVI step, fit(distributed=True): N=%d over %d ranks, job minibatch 65536, device sampler" % (N, world),
            "ms": ms, "value": M / (ms * 1e-3), "unit": "minibatch-rows/s", "dtype": "f32", "resident_loop": bool(resident),
            "parity": {"ranks_identical": same},
            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS * world,
@@ -1931,6 +1931,11 @@ def single_process_elbo(args, devices, group):
                          "frac": (fl_stats + fl_pass2) * N / (t_eval * 1e-3) / 1e12 / (PEAK_F32_MFMA_TFLOPS * world)}}
 
 
+def _glm_rows(args):
+    """Rows of config 5's data in the N > 1 configurations: BASELINE's 2 M, fewer when --dist-rows asks for a rehearsal."""
+    return 2_000_000 if args.dist_rows >= 1_000_000 else max(300_000, 4 * int(args.dist_rows))
+
+
 def single_process_glm(args, devices, group):
     """Config 5's SVI step with the loop resident on EVERY member of the device group (`GeneralizedLinearModel(devices=...)`:
     rr_glm_sgd_group_step -- each member steps its share of the 65 536-row minibatch, two all-reduces per step in HBM,
@@ -1943,7 +1948,7 @@ def single_process_glm(args, devices, group):
     from revrand_amd.btypes import Parameter, Positive
     from revrand_amd.glm import GeneralizedLinearModel
     logging.getLogger("revrand_amd").setLevel(logging.ERROR)
-    N, d, n, K, L, M = 2_000_000, 32, 1024, 10, 50, 65536
+    N, d, n, K, L, M = _glm_rows(args), 32, 1024, 10, 50, 65536
     rng = np.random.default_rng([20260928, 5])
     X = rng.standard_normal((N, d), dtype=np.float32)
     y = rng.poisson(np.exp(0.3 * X[:, 0].astype(np.float64))).astype(np.float64)
@@ -1966,7 +1971,7 @@ def single_process_glm(args, devices, group):
     gemm_flops = 3 * 2.0 * K * L * M * 2 * n
     world = len(devices)
     ms1, msg = float(np.median(dt1)), float(np.median(dtg))
-    out = {"workload": "GLM Poisson, RandomRBF F=2048 D=32 ARD, N=2M, K=10 L=50, minibatch 65536: SVI step of fit(devices=%d), device sampler" % world,
+    out = {"workload": "GLM Poisson, RandomRBF F=2048 D=32 ARD, N=%d, K=10 L=50, minibatch 65536: SVI step of fit(devices=%d), device sampler" % (N, world),
            "ms": msg, "one_context_ms": ms1, "speedup_vs_one_context": ms1 / msg, "value": M / (msg * 1e-3), "unit": "minibatch-rows/s",
            "dtype": "f32", "transport": group.transport, "parity": {"params_after_8_steps_vs_one_context": err},
            "roofline": {"bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS * world,

@@ -43,8 +43,9 @@ RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "test
           "tests/test_gpu_glm_fit.py::test_fit_equals_the_references_fit[binomial_cat_bs10_ns3-fused loop]",
           "tests/test_gpu_glm_fit.py::test_fit_equals_the_references_fit[poisson_ard_bs64f_ns5-resident loop]",
           "tests/test_gpu_fused_svi.py::test_shapes_across_the_tiles_of_the_matrix_core_products",
-          "tests/test_gpu_resident_group.py::test_a_member_without_rows_of_a_minibatch_follows_the_others",
-          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit"]
+          "tests/test_gpu_resident_group.py::test_a_member_without_rows_of_a_minibatch_follows_the_others[two streams]",
+          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit[two streams-gaussian-cat-devices2-host]",
+          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit[one stream-binomial-iso-devices1-device]"]
 
 
 def _asan_runtime():
