@@ -368,6 +368,10 @@ typedef struct rr_glm_sgd rr_glm_sgd;
 #define RR_UPD_ADAM 4     /* (alpha, beta1, beta2, epsilon)                  :259-330 */
 #define RR_SGD_CHILD_RFF 0    /* [cos | sin] of a random Fourier basis: 2 n columns, n_ls = 1 (isotropic) or Xdim length scales */
 #define RR_SGD_CHILD_LINEAR 1 /* LinearBasis (basis_functions.py:468-485): d columns of X (+ a leading column of ones)           */
+#define RR_SGD_CHILD_GM 2     /* FastFoodGM (basis_functions.py:1386-1562), one spectral-mixture component through the dense equivalent \
+                                 of its chain: basis = that random Fourier basis (n frequencies), 4 n columns                        \
+                                 [cos | sin](VX + mX) | [cos | sin](VX - mX) (the reference's column order is cos+, sin+, cos-, sin-:  \
+                                 the same blocks), n_ls = 2 Xdim coordinates [mean | length scales]                                   */
 typedef struct rr_glm_sgd_child {
     int kind;        /* RR_SGD_CHILD_* */
     rr_basis *basis; /* RFF: the basis (same context as the feature matrix); else NULL */

@@ -1080,7 +1080,8 @@ class SgdChild(ctypes.Structure):
 
 class ResidentSgd(object):
     """The SVI loop with its parameters in HBM (rr_glm_sgd): `step` queues one whole SGD step and returns at once.
-    children: ("rff", RffHandle, n_ls) | ("linear", d, onescol) in concatenation order."""
+    children: ("rff", RffHandle, n_ls) | ("gm", RffHandle of the chain's dense equivalent, 2 Xdim) | ("linear", d, onescol) in
+    concatenation order."""
 
     def __init__(self, fm, children, K, n_lik, z0, lower, upper, is_log, updater_id, updater_par, maxiter):
         self.fm, self.children, self.lib = fm, list(children), fm.lib      # (all kept alive for as long as the loop)
@@ -1091,8 +1092,8 @@ class ResidentSgd(object):
         kids = (SgdChild * len(self.children))()
         n_ls = 0
         for k, ch in zip(kids, self.children):
-            if ch[0] == "rff":
-                k.kind, k.basis, k.d, k.onescol, k.n_ls = 0, ch[1].h, 0, 0, int(ch[2])
+            if ch[0] in ("rff", "gm"):   # gm: a spectral-mixture component on its dense handle, [mean | length scales]
+                k.kind, k.basis, k.d, k.onescol, k.n_ls = (0 if ch[0] == "rff" else 2), ch[1].h, 0, 0, int(ch[2])
                 n_ls += int(ch[2])
             else:
                 k.kind, k.basis, k.d, k.onescol, k.n_ls = 1, None, int(ch[1]), 1 if ch[2] else 0, 0

@@ -833,8 +833,8 @@ class MinibatchFeatures(object):
             else:
                 g = []
             grads.extend(g)
-        if not self.is_cat:
-            return grads[0] if grads else []
+        if not self.is_cat:   # (a lone spectral-mixture component has TWO gradients: [dmean, dlenscale])
+            return (grads[0] if len(grads) == 1 else grads) if grads else []
         return grads if len(grads) != 1 else grads[0]
 
     def project(self, X, hypers, W):

@@ -529,16 +529,18 @@ rr_scale_w_kernel(const double *__restrict__ W, const LsArgs a, int d, int n, in
 
 // The same rescaling with the length scales in DEVICE memory (the resident SVI loop: they are the optimiser's own
 // coordinates and never visit the host between steps).
+// `shift` (a spectral-mixture component, basis_functions.py:1443-1475: phases VX +- X . mean): every frequency of input dimension
+// i is moved by sgn * shift[i] -- x . (W[:, f] / l + sgn mean) = (VX + sgn mX)[f].
 __global__ void __launch_bounds__(256)
 rr_scale_w_dev_kernel(const double *__restrict__ W, const double *__restrict__ ls, int n_ls, int d, int n, int npad, int dpad,
                       float *__restrict__ w32, double *__restrict__ w64, float *__restrict__ wt32, float *__restrict__ g32,
-                      double *__restrict__ g64) {
+                      double *__restrict__ g64, const double *__restrict__ shift = nullptr, double sgn = 0.0) {
     const double inv2pi = 0.15915494309189533576888, twopi = 6.283185307179586476925, wmax = 4611686018427387904.0;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= (int64_t)d * n) return;
     const int i = (int)(t / n), f = (int)(t % n);
     const double l = ls[n_ls == 1 ? 0 : i];
-    const double v = W[t] * (inv2pi / l);
+    const double v = shift ? (W[t] / l + sgn * shift[i]) * inv2pi : W[t] * (inv2pi / l);
     const float vf = (float)(v > wmax ? wmax : (v < -wmax ? -wmax : v));
     w64[(size_t)i * npad + f] = v;
     w32[(size_t)i * npad + f] = vf;
@@ -573,7 +575,7 @@ int rr_basis_raw_w(rr_basis *b) {  // (rr_elbo.hip: the resident SVI loop contra
     return basis_raw_w(b);
 }
 
-int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls) {
+int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls, const double *dshift, double sgn) {
     RR_REQUIRE(b != nullptr && dls != nullptr, "lenscale: null argument");
     RR_REQUIRE(n_ls == 1 || n_ls == b->d, "Dimension of input parameter is inconsistent! (n_ls=%d, d=%d)", n_ls, b->d);
     RR_REQUIRE(!b->large && b->d <= 128, "device-resident length scales need Xdim <= 128");
@@ -582,7 +584,7 @@ int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls) {
     int rc = basis_raw_w(b);
     if (rc != RR_OK) return rc;
     hipLaunchKernelGGL(rr_scale_w_dev_kernel, dim3((unsigned)(((int64_t)b->d * b->n + 255) / 256)), dim3(256), 0, c->stream,
-                       b->dWraw, dls, n_ls, b->d, b->n, b->npad, b->dpad, b->dWs32, b->dWs64, b->dWt32, b->dgfac32, b->dgfac64);
+                       b->dWraw, dls, n_ls, b->d, b->n, b->npad, b->dpad, b->dWs32, b->dWs64, b->dWt32, b->dgfac32, b->dgfac64, dshift, sgn);
     RR_CHECK_HIP(hipGetLastError());
     b->ls_cache.clear();  // the host does not know these values: the next rr_basis_prepare rescales
     return RR_OK;

@@ -741,7 +741,7 @@ void rr_pass2_scratch_free(void *p) {
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              float *P, int64_t ldp, bool zero_pad_cols, float *Pt = nullptr, int64_t ldt = 0,
-                             bool *pt_written = nullptr);  // rr_rff.hip
+                             bool *pt_written = nullptr, double scale_mult = 1.0);  // rr_rff.hip
 int rr_launch_gemm_tn_bf16(rr_ctx *c, int nprod, const float *A, int64_t lda, const float *B, int64_t ldb, float *D,
                            int64_t ldd, int64_t K, int64_t M, int64_t N, void *sa, void *sb, bool sb_ready,
                            bool upper_b = false);  // rr_syrk16.hip
@@ -2992,9 +2992,11 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out) {
 #define RR_SGD_MAXK 64
 #define RR_SGD_MAXCHILD 16
 
-struct SgdHRow {  // one length-scale gradient: W[i, :] . T[i, :] of a random Fourier child
-    const double *T, *W;
-    int n;
+struct SgdHRow {  // one basis-parameter gradient: W[i, :] . T[i, :] of a random Fourier child; a spectral-mixture component has
+    const double *T, *W;  // two contractions (T+, T-: phases VX +- mX) and two parameters per input dimension --
+    int n;                //   dmean_i = -sum_f (T+ - T-)[i, f]           (W == null: the constants c1, c2 as weights)
+    const double *T2 = nullptr, *W2 = nullptr;  //   dl_i = sum_f W[i, f] (T+ + T-)[i, f] / l_i^2
+    double c1 = 0.0, c2 = 0.0;
 };
 
 struct rr_glm_sgd {
@@ -3012,6 +3014,7 @@ struct rr_glm_sgd {
     double *objs = nullptr, *norms = nullptr;
     double *dT = nullptr;     // the children's (d, n) blocks X^T (E_s o P_c - E_c o P_s) of the step
     int *slice_of_f = nullptr, *slice_lo = nullptr, *slice_hi = nullptr, *h_of_ls = nullptr;  // device tables
+    unsigned char *ls_plain = nullptr;                                                         // (SgdUpdArgs::ls_plain)
     SgdHRow *hrows = nullptr;
     hipEvent_t ev[2] = {nullptr, nullptr};
     rr_featmat *fm2 = nullptr;                  // steps alternate between fm and fm2 (owned)
@@ -3184,7 +3187,10 @@ rr_glm_sgd_sums_kernel(const double *__restrict__ x, int F, int K, int nkids, co
         const int i = bid - npairs - nkids;
         if (i < n_h) {
             const SgdHRow h = hrows[i];
-            for (int f = tid; f < h.n; f += 256) acc += h.T[f] * h.W[f];
+            for (int f = tid; f < h.n; f += 256) {
+                acc += h.T[f] * (h.W ? h.W[f] : h.c1);
+                if (h.T2) acc += h.T2[f] * (h.W2 ? h.W2[f] : h.c2);
+            }
             const double v = rr_block_sum256(acc, sh);
             if (tid == 0) red[K * K + nkids + i] = v;
         }
@@ -3195,6 +3201,7 @@ struct SgdUpdArgs {
     const double *x, *red, *Edm, *EdC, *aux, *lower, *upper;
     const unsigned char *islog;
     const int *slice_of_f, *slice_lo, *slice_hi, *h_of_ls;
+    const unsigned char *ls_plain = nullptr;  // per basis parameter: 1 = its gradient is the sum itself (a mixture's mean), 0 = / l^2
     double *z, *s1, *s2, *npart;
     int F, K, nkids, n_lik, n_ls, updater, L;
     int64_t np, p0, p1;  // all coordinates; this launch's are [p0, p1)
@@ -3256,7 +3263,8 @@ __global__ void __launch_bounds__(256) rr_glm_sgd_update_kernel(const SgdUpdArgs
         } else {  // -(EdPhi o dPhi_i).sum() = W[i,:].T[i,:] / l_i^2; isotropic: input dimension 0 only, as the reference
             const int j = (int)(p - (2 * fk + a.nkids + a.n_lik));
             const double l = a.x[p];
-            g = a.red[K * K + a.nkids + a.h_of_ls[j]] / (1.0 * (l * l));
+            g = a.red[K * K + a.nkids + a.h_of_ls[j]];
+            if (!(a.ls_plain && a.ls_plain[j])) g = g / (1.0 * (l * l));
         }
         if (a.islog[p]) g *= a.x[p];  // d/dz through x = exp(z)
     }
@@ -3340,7 +3348,7 @@ rr_glm_sgd_finish_kernel(const double *__restrict__ x, const double *__restrict_
 
 static void sgd_free(rr_glm_sgd *o) {
     void *q[] = {o->z, o->x, o->s1, o->s2, o->lower, o->upper, o->islog, o->red, o->npart, o->objs, o->norms, o->dT,
-                 o->slice_of_f, o->slice_lo, o->slice_hi, o->h_of_ls, o->hrows};
+                 o->slice_of_f, o->slice_lo, o->slice_hi, o->h_of_ls, o->hrows, o->ls_plain};
     for (void *v : q)
         if (v) (void)hipFree(v);
     for (hipEvent_t e : {o->ev[0], o->ev[1], o->e_ls[0], o->e_ls[1], o->e_feat[0], o->e_feat[1], o->e_in})
@@ -3370,6 +3378,7 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
     rr_glm_sgd *o = new rr_glm_sgd();
     o->fm = fm; o->K = K; o->F = fm->F; o->n_lik = n_lik; o->updater = updater; o->nkids = n_children;
     std::vector<int> h_slice(fm->F, 0), h_lo, h_hi, h_of_ls;
+    std::vector<unsigned char> h_plain;
     std::vector<SgdHRow> hrows;
     int col = 0, nls = 0;
     int64_t dT_count = 0;
@@ -3387,6 +3396,16 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
             }
             w = 2 * b->n;
             dT_count += (int64_t)b->d * b->n;
+        } else if (k.kind == RR_SGD_CHILD_GM) {
+            rr_basis *b = k.basis;
+            if (!(b != nullptr && b->kind == RR_KIND_RFF && !b->large && b->d <= 128 && b->ctx == fm->ctx && k.n_ls == 2 * b->d)) {
+                delete o;
+                rr_set_error("rr_glm_sgd_create: child %d must be the dense equivalent of a spectral-mixture component of Xdim <= 128 on "
+                             "the matrix' context with 2 Xdim parameters (mean, length scales)", s);
+                return RR_ERR_INVALID;
+            }
+            w = 4 * b->n;
+            dT_count += 2 * (int64_t)b->d * b->n;
         } else if (k.kind == RR_SGD_CHILD_LINEAR) {
             if (!(k.d >= 1 && k.n_ls == 0)) {
                 delete o;
@@ -3448,6 +3467,7 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
     if (e == hipSuccess) e = hipMalloc((void **)&o->slice_hi, (size_t)n_children * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&o->h_of_ls, (size_t)(nls > 0 ? nls : 1) * sizeof(int));
     if (e == hipSuccess) e = hipMalloc((void **)&o->hrows, (size_t)(nls > 0 ? nls : 1) * sizeof(SgdHRow));
+    if (e == hipSuccess) e = hipMalloc((void **)&o->ls_plain, (size_t)(nls > 0 ? nls : 1));
     if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[0], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&o->ev[1], hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -3475,18 +3495,38 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
     for (int s = 0; s < n_children; ++s) {
         const rr_glm_sgd_child &k = o->kids[(size_t)s];
         o->dTk.push_back(nullptr);
-        if (k.kind != RR_SGD_CHILD_RFF) continue;
+        if (k.kind != RR_SGD_CHILD_RFF && k.kind != RR_SGD_CHILD_GM) continue;
         const int rcw = rr_basis_raw_w(k.basis);
         if (rcw != RR_OK) {
             sgd_free(o);
             return rcw;
         }
         o->dTk.back() = dTp;
+        const int64_t n = k.basis->n, dn = (int64_t)k.basis->d * n;
+        if (k.kind == RR_SGD_CHILD_GM) {  // [mean (d) | length scales (d)]: T+ at dTp, T- behind it
+            for (int i = 0; i < k.basis->d; ++i) {
+                h_of_ls.push_back((int)hrows.size());
+                h_plain.push_back(1);
+                SgdHRow r{dTp + i * n, nullptr, (int)n};
+                r.T2 = dTp + dn + i * n; r.c1 = -1.0; r.c2 = 1.0;
+                hrows.push_back(r);
+            }
+            for (int i = 0; i < k.basis->d; ++i) {
+                h_of_ls.push_back((int)hrows.size());
+                h_plain.push_back(0);
+                SgdHRow r{dTp + i * n, k.basis->dWraw + i * n, (int)n};
+                r.T2 = dTp + dn + i * n; r.W2 = r.W;
+                hrows.push_back(r);
+            }
+            dTp += 2 * dn;
+            continue;
+        }
         for (int i = 0; i < k.n_ls; ++i) {
             h_of_ls.push_back((int)hrows.size());
-            hrows.push_back({dTp + (int64_t)i * k.basis->n, k.basis->dWraw + (int64_t)i * k.basis->n, k.basis->n});
+            h_plain.push_back(0);
+            hrows.push_back(SgdHRow{dTp + (int64_t)i * n, k.basis->dWraw + (int64_t)i * n, (int)n});
         }
-        dTp += (int64_t)k.basis->d * k.basis->n;
+        dTp += dn;
     }
     o->n_h = (int)hrows.size();
     hipError_t h = hipStreamSynchronize(c->stream);
@@ -3499,6 +3539,7 @@ int rr_glm_sgd_create(rr_featmat *fm, int n_children, const rr_glm_sgd_child *ch
     if (h == hipSuccess) h = hipMemcpy(o->slice_hi, h_hi.data(), (size_t)n_children * sizeof(int), hipMemcpyHostToDevice);
     if (h == hipSuccess && nls > 0) h = hipMemcpy(o->h_of_ls, h_of_ls.data(), (size_t)nls * sizeof(int), hipMemcpyHostToDevice);
     if (h == hipSuccess && nls > 0) h = hipMemcpy(o->hrows, hrows.data(), hrows.size() * sizeof(SgdHRow), hipMemcpyHostToDevice);
+    if (h == hipSuccess && nls > 0) h = hipMemcpy(o->ls_plain, h_plain.data(), h_plain.size(), hipMemcpyHostToDevice);
     if (h == hipSuccess) h = hipMemset(o->s1, 0, nb);
     if (h == hipSuccess) h = hipMemset(o->s2, 0, nb);
     if (h == hipSuccess) h = hipMemset(o->objs, 0, (size_t)maxiter * 8);
@@ -3613,7 +3654,14 @@ static int sgd_step_front(rr_glm_sgd *o, const SgdStepIn &in) {
         for (int s = 0; s < nk && rc == RR_OK; ++s) {
             const rr_glm_sgd_child &k = o->kids[(size_t)s];
             if (k.kind == RR_SGD_CHILD_RFF) rc = rr_fm_put_rff_dev(fm, k.basis, in.dX[s], in.x_dtype[s], in.ldx[s], xls + o->ls0[(size_t)s], k.n_ls, o->col0[(size_t)s]);
-            else rc = rr_featmat_put_linear(fm, in.dX[s], in.x_dtype[s], in.ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
+            else if (k.kind == RR_SGD_CHILD_GM) {
+                // [cos | sin](VX + mX) at col0, [cos | sin](VX - mX) at col0 + 2n: the random Fourier kernels with every frequency
+                // moved by +- mean (stream order: the second rescaling of W follows the first block's feature kernel)
+                const double *mean = xls + o->ls0[(size_t)s], *ls = mean + k.basis->d;
+                rc = rr_fm_put_rff_dev(fm, k.basis, in.dX[s], in.x_dtype[s], in.ldx[s], ls, k.basis->d, o->col0[(size_t)s], mean, 1.0);
+                if (rc == RR_OK)
+                    rc = rr_fm_put_rff_dev(fm, k.basis, in.dX[s], in.x_dtype[s], in.ldx[s], ls, k.basis->d, o->col0[(size_t)s] + 2 * k.basis->n, mean, -1.0);
+            } else rc = rr_featmat_put_linear(fm, in.dX[s], in.x_dtype[s], in.ldx[s], k.d, k.onescol, o->col0[(size_t)s]);
         }
     }
     if (rc != RR_OK) return rc;
@@ -3645,6 +3693,13 @@ static int sgd_step_front(rr_glm_sgd *o, const SgdStepIn &in) {
     for (int ch = 0; ch < nk && rc == RR_OK; ++ch)  // (returns at once when the step contracted EdPhi itself)
         if (o->kids[(size_t)ch].kind == RR_SGD_CHILD_RFF)
             rc = rr_featmat_glm_rff(fm, o->kids[(size_t)ch].basis, in.dX[ch], in.x_dtype[ch], in.ldx[ch], o->col0[(size_t)ch], o->dTk[(size_t)ch]);
+        else if (o->kids[(size_t)ch].kind == RR_SGD_CHILD_GM) {  // T+ and T-: the two blocks' contractions
+            rr_basis *b = o->kids[(size_t)ch].basis;
+            rc = rr_featmat_glm_rff(fm, b, in.dX[ch], in.x_dtype[ch], in.ldx[ch], o->col0[(size_t)ch], o->dTk[(size_t)ch]);
+            if (rc == RR_OK)
+                rc = rr_featmat_glm_rff(fm, b, in.dX[ch], in.x_dtype[ch], in.ldx[ch], o->col0[(size_t)ch] + 2 * b->n,
+                                        o->dTk[(size_t)ch] + (int64_t)b->d * b->n);
+        }
     return rc;
 }
 
@@ -3652,7 +3707,7 @@ static void sgd_update_args(rr_glm_sgd *o, const SgdStepIn &in, FmPass2 &s, SgdU
     const int64_t fk = o->fk;
     a.x = o->x; a.red = o->red; a.Edm = s.mc + 2 * fk; a.EdC = s.mc + 3 * fk; a.aux = s.kacc + s.kcap; a.lower = o->lower; a.upper = o->upper;
     a.islog = o->islog; a.z = o->z; a.s1 = o->s1; a.s2 = o->s2;
-    a.slice_of_f = o->slice_of_f; a.slice_lo = o->slice_lo; a.slice_hi = o->slice_hi; a.h_of_ls = o->h_of_ls;
+    a.slice_of_f = o->slice_of_f; a.slice_lo = o->slice_lo; a.slice_hi = o->slice_hi; a.h_of_ls = o->h_of_ls; a.ls_plain = o->ls_plain;
     a.F = o->F; a.K = o->K; a.nkids = o->nkids; a.n_lik = o->n_lik; a.n_ls = o->n_ls; a.updater = o->updater; a.L = in.L; a.np = o->np;
     a.bmag = in.bmag; a.nrows = (double)in.rows_total;
     a.tot = in.totals_on_device ? s.kacc + 2 * s.kcap : nullptr;

@@ -6,7 +6,7 @@
 
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
                              float *P, int64_t ldp, bool zero_pad_cols, float *Pt = nullptr, int64_t ldt = 0,
-                             bool *pt_written = nullptr);
+                             bool *pt_written = nullptr, double scale_mult = 1.0);
 int rr_launch_syrk_f32(rr_ctx *c, const float *P, int64_t rows, int64_t ldp, int F, double *dG, hipEvent_t mid,
                        double *bcol = nullptr);
 
@@ -205,12 +205,12 @@ int rr_fm_claim(rr_featmat *fm, int64_t col0, int64_t width, const char *who) {
 
 // lenscale: host values, or (ls_on_device) the same in device memory -- rr_basis_prepare_dev, the resident SVI loop
 static int fm_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *lenscale, int n_ls,
-                      int64_t col0, bool ls_on_device) {
+                      int64_t col0, bool ls_on_device, const double *dshift = nullptr, double sgn = 0.0) {
     RR_REQUIRE(fm != nullptr && b != nullptr && b->kind == RR_KIND_RFF, "rr_featmat_put_rff: bad argument");
     RR_REQUIRE(x_dtype == RR_F32 || x_dtype == RR_F64, "rr_featmat_put_rff: bad dtype");
     RR_REQUIRE(col0 >= 0 && col0 + 2 * (int64_t)b->n <= fm->F, "rr_featmat_put_rff: columns out of range");
     RR_REQUIRE(ldx >= b->dpad, "rr_featmat_put_rff: device X needs ldx >= rr_rff_padded_dim() = %d", b->dpad);
-    int rc = ls_on_device ? rr_basis_prepare_dev(b, lenscale, n_ls) : rr_basis_prepare(b, lenscale, n_ls);
+    int rc = ls_on_device ? rr_basis_prepare_dev(b, lenscale, n_ls, dshift, sgn) : rr_basis_prepare(b, lenscale, n_ls);
     if (rc != RR_OK || fm->rows == 0) return rc;
     RR_REQUIRE(dX != nullptr, "rr_featmat_put_rff: null X");
     RR_CHECK_HIP(hipSetDevice(fm->ctx->device));
@@ -222,14 +222,14 @@ static int fm_put_rff(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, 
     float *Pt = (fm->pt_rows == fm->rows && !no_pt) ? rr_fm_pass2_pt(fm->pass2) : nullptr;
     bool wrote = false;
     rc = rr_features_rowmajor_f32(b, dX, x_dtype, fm->rows, fm->rows, ldx, fm->P + col0, fm->ld, false,
-                                  Pt ? Pt + col0 * fm->max_rows : nullptr, fm->max_rows, &wrote);
+                                  Pt ? Pt + col0 * fm->max_rows : nullptr, fm->max_rows, &wrote, dshift ? 0.70710678118654752440 : 1.0);
     if (wrote) fm->pt_covered += 2 * (int64_t)b->n;
     return rc;
 }
 
 int rr_fm_put_rff_dev(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *dls, int n_ls,
-                      int64_t col0) {
-    return fm_put_rff(fm, b, dX, x_dtype, ldx, dls, n_ls, col0, true);
+                      int64_t col0, const double *dshift, double sgn) {
+    return fm_put_rff(fm, b, dX, x_dtype, ldx, dls, n_ls, col0, true, dshift, sgn);
 }
 
 extern "C" {

@@ -197,7 +197,9 @@ void rr_launch_device_check(hipStream_t s, const char *file, int line);
 
 // Upload W scaled by the given lenscale (cached); implemented in rr_api.hip.
 int rr_basis_prepare(rr_basis *b, const double *lenscale, int n_ls);
-int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls);  // length scales in device memory (d <= 128)
+// length scales in device memory (d <= 128); dshift (d, device) with sgn: the frequencies moved by sgn * shift (a spectral-mixture
+// component's phases VX +- X . mean on the random Fourier kernels)
+int rr_basis_prepare_dev(rr_basis *b, const double *dls, int n_ls, const double *dshift = nullptr, double sgn = 0.0);
 int rr_pick_dmax(int d);
 void rr_pass2_scratch_free(void *p);
 void rr_pass2d_scratch_free(void *p);
@@ -222,7 +224,7 @@ struct rr_featmat {
 int rr_fm_claim(rr_featmat *fm, int64_t col0, int64_t width, const char *who);  // rr_featmat.hip
 // rr_featmat_put_rff with the length scales in device memory (rr_featmat.hip; the resident SVI loop of rr_elbo.hip)
 int rr_fm_put_rff_dev(rr_featmat *fm, rr_basis *b, const void *dX, int x_dtype, int64_t ldx, const double *dls, int n_ls,
-                      int64_t col0);
+                      int64_t col0, const double *dshift = nullptr, double sgn = 0.0);
 void rr_fm_pass2_free(void *p);
 float *rr_fm_pass2_pt(void *p);  // FmPass2::Pt or null
 rr_ctx *rr_comm_ctx(rr_comm *comm);  // the context a communicator was bound to (rr_comm.hip)

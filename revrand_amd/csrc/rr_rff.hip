@@ -3021,18 +3021,19 @@ static int launch_gram(rr_basis *b, const void *dX, const void *dy, int64_t N, i
 
 // Row-major f32 features of a row block into a caller-provided scratch (used by the second _elbo pass).
 int rr_features_rowmajor_f32(rr_basis *b, const void *dX, int x_dtype, int64_t m, int64_t mpad, int64_t ldx,
-                             float *P, int64_t ldp, bool zero_pad_cols, float *Pt, int64_t ldt, bool *pt_written) {
+                             float *P, int64_t ldp, bool zero_pad_cols, float *Pt, int64_t ldt, bool *pt_written, double scale_mult) {
+    // scale_mult: 1, or sqrt(1/2) for one of the two blocks of a spectral-mixture component (1 / sqrt(2 n) over its 4 n columns)
     if (pt_written) *pt_written = false;
     rr_ctx *c = b->ctx;
     const int F = 2 * b->n;
-    const float scale = (float)(1.0 / sqrt((double)b->n));
+    const float scale = (float)(scale_mult / sqrt((double)b->n));
     if (zero_pad_cols && ldp > F) {
         const int64_t cnt = mpad * (ldp - F);
         hipLaunchKernelGGL(rr_zero_padcols_kernel<float>, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c->stream, P,
                            mpad, ldp, F);
     }
     if (b->phase64) {  // RR_F32P64: phases on the f64 matrix cores, float32 features out; no direct P^T (consumers transpose)
-        const double sc = 1.0 / sqrt((double)b->n);
+        const double sc = scale_mult / sqrt((double)b->n);
         const bool done = x_dtype == RR_F32
                               ? rr_features_mfma64_launch<float, float>(b, (const float *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, sc)
                               : rr_features_mfma64_launch<double, float>(b, (const double *)dX, nullptr, m, mpad, ldx, P, ldp, nullptr, sc);

@@ -347,7 +347,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
     def _loop_children(self, feats, params):
         """The children of one device's MinibatchFeatures as rr_glm_sgd takes them, or None when one is not covered."""
-        from .basis_functions import _ResidentFastFood, _ResidentLinear, _ResidentRFF
+        from .basis_functions import _ResidentFastFood, _ResidentFastFoodGM, _ResidentLinear, _ResidentRFF
         kids = getattr(feats, "_kids", [])
         if not 1 <= len(kids) <= 16:
             return None
@@ -364,11 +364,18 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
                 if n_ls not in (1, b.d):
                     return None
                 children.append(("rff", kid.h, n_ls))
+            elif type(kid) is _ResidentFastFoodGM and b.d <= 128 and kid.W.shape[0] == b.d \
+                    and [getattr(p, "shape", None) for p in atleast_list(b.params)] == [(b.d,), (b.d,)]:
+                # (a spectral-mixture component: [cos | sin](VX + mX) | [cos | sin](VX - mX) are two random Fourier blocks of
+                # the chain's dense equivalent with every frequency moved by +- mean -- basis_functions.py:1443-1475 -- and its
+                # two gradients two sums over their contractions: _ResidentFastFoodGM.dhyp)
+                children.append(("gm", kid.h, 2 * b.d))
             elif type(kid) is _ResidentLinear and int(np.prod(b.params.shape, dtype=int)) == 0:
                 children.append(("linear", int(kid.dX.shape[1]), bool(kid.onescol)))
             else:
                 return None
-        if sum(c[2] for c in children if c[0] == "rff") != sum(int(np.prod(p.shape, dtype=int)) for p in atleast_list(params[4])):
+        n_par = sum(int(np.prod(getattr(p, "shape", ()), dtype=int)) for p in _flat_params(params[4]))
+        if sum(c[2] for c in children if c[0] in ("rff", "gm")) != n_par:
             return None
         return children
 
@@ -382,7 +389,7 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
         # small minibatches (the reference's default is 10 rows): the whole loop inside one kernel, many steps per launch
         # (not between ranks: that kernel has no exchange step)
         if self._fused_sgd and os.environ.get("RR_GLM_FUSED", "1") != "0" and y is not None and len(likelihood_args) <= 1 \
-                and np.isfinite(self.maxiter) and comm is None:
+                and np.isfinite(self.maxiter) and comm is None and all(c[0] != "gm" for c in children):
             N = len(y)
             M = int(min(self.batch_size, N))
             F = int(self.D_)
@@ -802,8 +809,8 @@ class _ResidentLoop(object):
         regs = list(x[o:o + nk])
         ls, q = [], o + nk + self.n_lik
         for c in self.children:
-            n = c[2] if c[0] == "rff" else 0
-            ls.append(x[q] if n == 1 else x[q:q + n])
+            n = c[2] if c[0] in ("rff", "gm") else 0
+            ls.append(x[q] if n == 1 else ([x[q:q + n // 2], x[q + n // 2:q + n]] if c[0] == "gm" else x[q:q + n]))
             q += n
         return (regs[0] if nk == 1 else regs), ([x[o + nk]] if self.n_lik else []), (ls[0] if nk == 1 else ls)
 
@@ -1214,6 +1221,13 @@ class _Draws(object):
 
     def __init__(self, e):
         self.e = e
+
+
+def _flat_params(p):
+    """the Parameter objects of a (nested) parameter list, in order"""
+    if isinstance(p, (list, tuple)) and not isinstance(p, Parameter):
+        return [q for item in p for q in _flat_params(item)]
+    return [p]
 
 
 def _like_structure(template, flat):

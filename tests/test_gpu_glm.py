@@ -101,6 +101,47 @@ def test_minibatch_elbo_concat_and_generic_children_vs_oracle():
     assert normwise(flat, np.array(want[1][4])) < 2e-3
 
 
+@pytest.mark.parametrize("alone", [True, False])
+def test_minibatch_elbo_of_a_spectral_mixture_component_on_the_chain_kernel_vs_oracle(alone):
+    """FastFoodGM with Xdim > 8 (the chain kernel's mixture mode writes its four blocks, both gradients come from the two
+    contractions T+ / T-: basis_functions.py:1443-1537) as the GLM's basis -- ALONE (its gradient is the pair [dmean, dlenscale],
+    not one array) and between two other children: -ELBO and every gradient block against the oracle's glm_elbo on this
+    basis' own transform / grad, which tests/test_gpu_fastfood.py holds to the reference's."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(4)
+    M, d, K, L = 257, 12, 3, 5
+    X = rs.randn(M, d)
+    y = rs.poisson(np.exp(0.5 * np.sin(X[:, 0]))).astype(float)
+    gm = bs.FastFoodGM(nbases=24, Xdim=d, random_state=2)
+    mu, lsg = 0.3 * rs.randn(d), 0.8 + 0.5 * rs.rand(d)
+    if alone:
+        basis, hyp, regs = gm, [mu, lsg], 1.3
+    else:
+        basis = bs.LinearBasis(onescol=True) + gm + bs.RandomRBF(nbases=20, Xdim=d, random_state=4)
+        hyp, regs = [mu, lsg, 0.9], [0.8, 1.3, 0.6]
+    Phi = basis.transform(X, *hyp)
+    dPs = []
+    for gfull in (basis.grad(X, *hyp) if not alone else list(basis.grad(X, *hyp))):
+        dPs.extend([gfull[:, :, i] for i in range(gfull.shape[2])] if gfull.ndim == 3 else [gfull])
+    D = Phi.shape[1]
+    m = 0.2 * rs.randn(D, K)
+    C = rs.gamma(2., 0.5, size=(D, K))
+    Ld, slices = basis.regularizer_diagonal(X, *(regs if isinstance(regs, list) else [regs]))
+    e = np.stack([np.random.RandomState(9).randn(K * L, D)[k * L:(k + 1) * L] for k in range(K)])
+    want = orc.glm_elbo(m, C, Ld, slices, "poisson_exp", [], (), Phi, dPs, y, e, 4.0)
+    glm = GLM(likelihood=lk.Poisson(), basis=basis, K=K, nsamples=L, random_state=9)
+    glm.B_, glm.D_ = 4.0, D
+    glm._GeneralizedLinearModel__it = -1
+    nobj, (ndm, ndC, dL, dlp, dbp) = glm._elbo(m.copy(), C.copy(), regs, [], hyp if not alone else hyp, X, y)
+    glm._release_features()
+    assert abs(nobj - want[0]) < 2e-4 * abs(want[0])
+    assert normwise(ndm, want[1][0]) < 1e-3 and normwise(ndC, want[1][1]) < 1e-3
+    assert normwise(np.atleast_1d(np.array(dL)), np.atleast_1d(np.array(want[1][2]))) < 1e-6
+    assert isinstance(dbp, list) and [np.shape(v) for v in dbp] == ([(d,), (d,)] if alone else [(d,), (d,), ()])
+    flat = np.concatenate([np.atleast_1d(v) for v in dbp])
+    assert normwise(flat, np.array(want[1][4])) < 2e-3
+
+
 def test_project_and_sample_func():
     bs, lk, Parameter, Positive, GLM = _imports()
     from revrand_amd.basis_functions import MinibatchFeatures

@@ -46,13 +46,15 @@ def _basis(kind, d):
         return bs.RandomRBF(nbases=48, Xdim=d, random_state=1, lenscale=Parameter(np.ones(d), Positive()))
     if kind == "iso":
         return bs.RandomMatern32(nbases=48, Xdim=d, random_state=1)
+    if kind == "gm":   # a spectral-mixture component (two parameters per input dimension) next to a linear child
+        return bs.LinearBasis(onescol=True) + bs.FastFoodGM(nbases=16, Xdim=d, random_state=2)
     return bs.LinearBasis(onescol=True) + bs.RandomRBF(nbases=24, Xdim=d, random_state=2) \
         + bs.FastFoodRBF(nbases=16, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
 
 
 def _fit(devices, lik="poisson", basis="ard", sampler="host", batch=1500, maxiter=12, nstarts=2, N=6000, fused=True, K=3):
     bs, lk, Parameter, Positive, GLM = _imports()
-    X, y, largs = _data(lik, N=N)
+    X, y, largs = _data(lik, N=N, d=12 if basis == "gm" else 5)
     like = {"poisson": lk.Poisson, "bernoulli": lk.Bernoulli, "binomial": lk.Binomial, "gaussian": lk.Gaussian}[lik]()
     glm = GLM(like, _basis(basis, X.shape[1]), K=K, nsamples=8, batch_size=batch, maxiter=maxiter, nstarts=nstarts, random_state=11,
               sampler=sampler, devices=devices)
@@ -112,7 +114,7 @@ def spies(monkeypatch):
 
 @pytest.mark.parametrize("sampler", ["host", "device"])
 @pytest.mark.parametrize("lik,basis,devices", [("poisson", "ard", [0, 0]), ("binomial", "iso", [0, 0, 0]), ("gaussian", "cat", [0, 0]),
-                                               ("bernoulli", "cat", [0, 0, 0, 0])])
+                                               ("bernoulli", "cat", [0, 0, 0, 0]), ("poisson", "gm", [0, 0])])
 def test_group_resident_fit_equals_the_one_context_fit(lik, basis, devices, sampler, spies):
     one = _fit(None, lik, basis, sampler)
     assert spies["one"] == 12 and spies["group"] == 0

@@ -200,8 +200,7 @@ def test_linear_basis_alone():
 
 
 def test_fits_the_loop_does_not_cover_take_the_host_loop(monkeypatch):
-    """A custom updater, K > 64, a FastFoodGM child (two parameters per child): `_resident_loop` declines and `fit` is what it
-    was."""
+    """A custom updater, K > 64: `_resident_loop` declines and `fit` is what it was."""
     bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
     from revrand_amd import _hip
     monkeypatch.setattr(_hip.ResidentSgd, "step", lambda *a, **k: (_ for _ in ()).throw(AssertionError("resident loop used")))
@@ -212,8 +211,7 @@ def test_fits_the_loop_does_not_cover_take_the_host_loop(monkeypatch):
     class MyAdam(opt.Adam):
         pass
     for basis, kw in ((bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"updater": MyAdam()}),
-                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"K": 65}),
-                      (bs.FastFoodGM(nbases=16, Xdim=d, random_state=1), {})):
+                      (bs.RandomRBF(nbases=16, Xdim=d, random_state=1), {"K": 65})):
         glm = GLM(lk.Poisson(), basis, nsamples=4, batch_size=300, maxiter=3, nstarts=0, random_state=1, **{"K": 2, **kw})
         glm.fit(X, y)
         assert np.all(np.isfinite(glm.weights_))
@@ -263,6 +261,54 @@ def test_fastfood_children_and_many_components_run_resident(batch, monkeypatch):
                                                          (glm.basis_hypers_ if isinstance(glm.basis_hypers_, list) else [glm.basis_hypers_])]),
                             glm.random_.randn()))
             _same(out[0], out[1], 5e-5)
+
+
+def _flat(v):
+    if isinstance(v, (list, tuple)):
+        return np.concatenate([_flat(u) for u in v]) if len(v) else np.zeros(0)
+    return np.atleast_1d(np.asarray(v, dtype=float)).ravel()
+
+
+@pytest.mark.parametrize("lik", ["poisson", "gaussian"])
+@pytest.mark.parametrize("batch", [1500, 12])
+def test_spectral_mixture_children_run_resident(lik, batch, monkeypatch):
+    """A FastFoodGM child (basis_functions.py:1386-1562: [cos | sin](VX + mX) | [cos | sin](VX - mX), parameters mean AND length
+    scales) -- alone and in `Linear + FastFoodGM + RandomRBF` -- on the step-per-call loop: its two blocks are random Fourier
+    blocks of the chain's dense equivalent with every frequency moved by +- mean (RR_SGD_CHILD_GM), its two gradients sums over
+    their contractions.  Against the host loop, whose features come from the CHAIN kernel's mixture mode; small minibatches too
+    (the fused many-steps-per-launch kernel does not take this child: the step-per-call loop does)."""
+    bs, lk, opt, Bound, Parameter, Positive, GLM = _imports()
+    from revrand_amd import _hip
+    X, y, _ = _data(lik, N=3000, d=12)
+    d = X.shape[1]
+    steps = [0]
+    real = _hip.ResidentSgd.step
+
+    def spy(self, *a, **k):
+        steps[0] += 1
+        return real(self, *a, **k)
+    monkeypatch.setattr(_hip.ResidentSgd, "step", spy)
+    monkeypatch.setattr(_hip.FusedSvi, "run", lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused loop used")))
+    like = {"poisson": lk.Poisson, "gaussian": lk.Gaussian}[lik]
+
+    def bases():
+        return [bs.FastFoodGM(nbases=24, Xdim=d, random_state=1),
+                bs.LinearBasis(onescol=True) + bs.FastFoodGM(nbases=16, Xdim=d, random_state=2, mean=Parameter(0.3 * np.ones(d), Bound()),
+                                                              lenscale=Parameter(1.2 * np.ones(d), Positive()))
+                + bs.RandomRBF(nbases=8, Xdim=d, random_state=3)]
+    for which in (0, 1):
+        out = []
+        for resident in (True, False):
+            glm = GLM(like(), bases()[which], K=3, nsamples=6, batch_size=batch, maxiter=12, nstarts=2, random_state=5)
+            glm._resident_sgd = resident
+            np.random.seed(3)
+            steps[0] = 0
+            glm.fit(X, y)
+            assert steps[0] == (12 if resident else 0), (steps, which)
+            out.append((glm.weights_.copy(), glm.covariance_.copy(), _flat(glm.regularizer_), _flat(glm.like_hypers_),
+                        _flat(glm.basis_hypers_), glm.random_.randn()))
+        assert out[0][4].size == (2 * d if which == 0 else 2 * d + 1)
+        _same(out[0], out[1], 1e-4)
 
 
 def test_config5_shape_runs_the_fused_contraction_and_improves_the_objective(monkeypatch):
