@@ -287,8 +287,9 @@ class GeneralizedLinearModel(BaseEstimator, RegressorMixin):
 
     def _resident_loop(self, params, y=None, likelihood_args=()):
         """The SGD loop with parameters, updater state and gradient in device memory (`_ResidentLoop`, rr_glm_sgd) when this
-        fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a FastFoodRBF (through its
-        dense equivalent), a LinearBasis or a concatenation of such children (Xdim <= 128, a scalar regulariser each); one of
+        fit is one it covers: minibatches gathered on the device; the basis a random Fourier basis, a FastFoodRBF or FastFoodGM
+        (through the dense equivalent of its chain), a LinearBasis or a concatenation of such children (Xdim <= 128, a scalar
+        regulariser each); one of
         the reference's likelihoods and updaters; K <= 64 (the fused small-batch loop: K <= 32); one process; one GPU, or --
         `devices=` -- every member of the device group (`_GroupResidentLoop`), or member 0 alone when the minibatches are too small
         to split.  None otherwise -- the host loop around `_elbo` then runs, with the same results."""
