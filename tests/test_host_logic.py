@@ -787,6 +787,40 @@ def test_multigpu_host_logic_shards_sums_and_routes():
     assert [p[0] for p in smf._split_rows(5000)] == [0, 1] and [p[0] for p in smf._split_rows(100)] == [0]
 
 
+def test_device_loops_of_a_group_host_logic():
+    """glm._ScopedLoop (a one-device loop on one member of a device group: `devices=` with minibatches too small to split): every
+    call runs with the member's context as the thread's default device, attribute reads and writes reach the inner loop -- what
+    optimize.sgd / logtrick_sgd / structured_sgd do with a device loop (`log_coordinates = ...`, `getattr(loop, "note_start")`);
+    glm._flat_params (a nested parameter list, FastFoodGM's [mean, lenscale] inside a concatenation's)."""
+    from revrand_amd import _hip
+    from revrand_amd import glm as G
+
+    class Inner(object):
+        log_coordinates = None
+
+        def __init__(self):
+            self.seen = []
+
+        def begin(self, *a):
+            self.seen.append(("begin", getattr(_hip._tls, "dev", None), a))
+            return "began"
+
+        def step(self, batch):
+            self.seen.append(("step", getattr(_hip._tls, "dev", None), batch))
+    inner, member = Inner(), object()
+    before = getattr(_hip._tls, "dev", None)
+    loop = G._ScopedLoop(inner, member)
+    loop.log_coordinates = [True, False]
+    assert inner.log_coordinates == [True, False] and loop.log_coordinates == [True, False]
+    assert loop.begin(1, 2) == "began" and loop.step([3]) is None
+    assert [(n, d is member) for n, d, _ in inner.seen] == [("begin", True), ("step", True)]
+    assert getattr(_hip._tls, "dev", None) is before                       # restored after every call
+    assert getattr(loop, "note_start", None) is None                        # absent on the inner loop: absent here
+    assert isinstance(getattr(loop, "_loop"), Inner)                        # (how `fit` tells a fused loop from a step-per-call one)
+    a, b, c = Parameter(1.0, Positive()), Parameter(np.ones(3), Bound()), Parameter(np.ones(3), Positive())
+    assert G._flat_params([a, [b, c], []]) == [a, b, c] and G._flat_params(a) == [a]
+
+
 def test_parameter_draws_equal_scipys_without_its_overhead():
     """btypes.Parameter.rvs (btypes.py:290-324) for the frozen `norm` / `gamma` distributions the estimators use goes straight
     to RandomState.standard_normal / standard_gamma -- the calls scipy's rvs ends in: same values, same type, same stream
