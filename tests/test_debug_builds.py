@@ -45,7 +45,9 @@ RAGGED = ["tests/test_gpu_rff.py::test_tiny_and_ragged_shapes_end_to_end", "test
           "tests/test_gpu_fused_svi.py::test_shapes_across_the_tiles_of_the_matrix_core_products",
           "tests/test_gpu_resident_group.py::test_a_member_without_rows_of_a_minibatch_follows_the_others[two streams]",
           "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit[two streams-gaussian-cat-devices2-host]",
-          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit[one stream-binomial-iso-devices1-device]"]
+          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit[one stream-binomial-iso-devices1-device]",
+          "tests/test_gpu_resident_group.py::test_group_resident_fit_equals_the_one_context_fit[two streams-poisson-gm-devices4-host]",
+          "tests/test_gpu_resident_sgd.py::test_spectral_mixture_children_run_resident[two streams-12-gaussian]"]
 
 
 def _asan_runtime():
