@@ -350,7 +350,7 @@ int rr_featmat_project(rr_featmat *fm, const double *W, int S, double *out);
  * (optimize/decorators.py:329-408)  o  structured_sgd (:133-252)  around  GeneralizedLinearModel._elbo (glm.py:205-294):  the flat
  * parameter vector
  *     z = [ m (F, K) | C (F, K) | regularisers (one per child) | likelihood parameter (n_lik = 1: the Gaussian variance) |
- *           length scales, child by child ]
+ *           basis parameters, child by child: length scales (a spectral-mixture component: its means, then its length scales) ]
  * (row-major blocks in the order of glm.py:170-176 / BasisCat's parameter lists, basis_functions.py:1750-1763; coordinates with
  * is_log != 0 are log(x), the log trick's Positive coordinates), the updater's state, the gradient and every intermediate stay
  * in HBM.  One rr_glm_sgd_step call queues a whole step -- x = from_log(z), the bases rescaled by the length scales in x, Phi of
@@ -374,10 +374,10 @@ typedef struct rr_glm_sgd rr_glm_sgd;
                                  the same blocks), n_ls = 2 Xdim coordinates [mean | length scales]                                   */
 typedef struct rr_glm_sgd_child {
     int kind;        /* RR_SGD_CHILD_* */
-    rr_basis *basis; /* RFF: the basis (same context as the feature matrix); else NULL */
+    rr_basis *basis; /* RFF, GM: the basis (same context as the feature matrix); else NULL */
     int d;           /* LINEAR: columns of X */
     int onescol;     /* LINEAR: 1 = a column of ones first */
-    int n_ls;        /* RFF: 1 or Xdim; LINEAR: 0 */
+    int n_ls;        /* RFF: 1 or Xdim; LINEAR: 0; GM: 2 Xdim ([mean | length scales]) */
 } rr_glm_sgd_child;
 /* fm: an (empty) feature matrix whose F columns the children fill in order; z0, lower, upper (float64) and is_log (bytes):
  * host vectors of 2 F K + n_children + n_lik + (all length scales) entries; upd_par: 4 doubles (unused ones ignored);
