@@ -294,7 +294,9 @@ class _DevicePosterior(object):
         base, F = self.acc.ptr.value, self.F
         return tuple(_hip.ctypes.c_void_p(base + o * 8) for o in (0, F * F, F * F + F))
 
-    def _finish_stats(self, reduce=None, nrows=0):
+    lazy_yty = True   # gram_device(..., want_yty=False): y^T y stays in HBM (a full `_elbo` never reads it: one host round trip less)
+
+    def _finish_stats(self, reduce=None, nrows=0, want_yty=True):
         pG, pb, pt = self._stat_ptrs()
         if reduce is not None:
             # row-sharded fit: pack the upper triangle, ONE ncclAllReduce of [tri G | b | yty | N], unpack into the full
@@ -302,6 +304,8 @@ class _DevicePosterior(object):
             self.N_total = reduce(self.F, pG, pb, pt, nrows)
         else:
             _hip._check(self.dev.lib, self.dev.lib.rr_symmetrize_dev(self.dev.ctx, pG, self.F))
+        if not want_yty:
+            return None
         return float(self.dev.download(self.acc, (1,), np.float64, offset_bytes=(self.F * self.F + self.F) * 8)[0])
 
     def stats_host(self):
@@ -356,11 +360,11 @@ class DeviceFitState(_DevicePosterior):
     def gram(self, lenscale):
         return self.handle.gram_host(self.dX, self.dy, lenscale)
 
-    def gram_device(self, lenscale, reduce=None):
+    def gram_device(self, lenscale, reduce=None, want_yty=True):
         """Statistics of this length scale into the resident buffer (summed over ranks by `reduce`); returns
-        y^T y."""
+        y^T y (want_yty=False: None, and nothing is waited for)."""
         self.gram_launch(lenscale)
-        return self._finish_stats(reduce, self.dX.shape[0])
+        return self._finish_stats(reduce, self.dX.shape[0], want_yty)
 
     def gram_launch(self, lenscale):
         """The asynchronous part of ``gram_device``: this state's rows into its (zeroed) accumulators, nothing waited for --
@@ -912,11 +916,11 @@ class CatFitState(_DevicePosterior):
         for r0 in range(0, self.N, self.chunk):
             yield r0, min(self.chunk, self.N - r0)
 
-    def gram_device(self, hypers, reduce=None):
+    def gram_device(self, hypers, reduce=None, want_yty=True):
         """Statistics of these hyper-parameters into the resident buffer (summed over ranks by `reduce`);
-        returns y^T y."""
+        returns y^T y (want_yty=False: None, and nothing is waited for)."""
         self.gram_launch(hypers)
-        return self._finish_stats(reduce, self.N)
+        return self._finish_stats(reduce, self.N, want_yty)
 
     def gram_launch(self, hypers):
         """The part of ``gram_device`` before the statistics are summed / mirrored (see DeviceFitState.gram_launch)."""

@@ -232,7 +232,10 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             on_dev = on_dev and comm.device_reduce
         if on_dev:
             # distributed: the one exchange -- [tri G | b | y^T y | N] of all row shards summed in HBM over RCCL / xGMI
-            yty = st.gram_device(hypers, comm.reduce_stats_device if self.distributed else None)
+            # (y^T y is read by the objective-only evaluation alone: a full `_elbo` takes sqErr from its second pass and leaves
+            # it in HBM -- one host round trip less per evaluation; the host SVD route fetches all statistics anyway)
+            lazy = not objective_only and not self.distributed and getattr(st, "lazy_yty", False)
+            yty = st.gram_device(hypers, comm.reduce_stats_device if self.distributed else None, **({"want_yty": False} if lazy else {}))
             if self.distributed:
                 N = st.N_total
             D = st.F
