@@ -1192,25 +1192,38 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
         if (rc != RR_OK) return rc;
     }
     RR_CHECK_HIP(hipGetLastError());
-    // the diagonal decides before the rest is worth computing
+    // The diagonal decides whether the rest is worth computing.  Up to Fp = 4096 the rest is cheaper than finding out: C = Y^T Y
+    // is a few hundred microseconds there and the question a host round trip of ~35 us in the middle of a chain of dependent
+    // launches (4 % of an evaluation at BASELINE config 1) -- so it is queued regardless, the pivots come back with the results,
+    // and a matrix that is not safely positive definite costs the (rare) caller the wasted product before its SVD route.
+    // (RR_POSDEF_EARLY_CHECK=1: always ask first.)
+    static const bool early_env = getenv("RR_POSDEF_EARLY_CHECK") != nullptr;
+    const bool ask_first = early_env || Fp > 4096;
     std::vector<double> h((size_t)3 * Fp + 1);
-    RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)Fp * 8, hipMemcpyDeviceToHost, c->stream));
-    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
-    double logdet = 0.0, mind = INFINITY;
-    for (int64_t i = 0; i < F; ++i) {
-        const double dval = h[i];
-        if (!(dval > 0.0) || !std::isfinite(dval)) {
-            mind = -1.0;
-            break;
+    auto pivots = [&]() -> int {  // h[0, F): the factor's diagonal
+        double logdet = 0.0, mind = INFINITY;
+        for (int64_t i = 0; i < F; ++i) {
+            const double dval = h[i];
+            if (!(dval > 0.0) || !std::isfinite(dval)) {
+                mind = -1.0;
+                break;
+            }
+            logdet += 2.0 * std::log(dval);
+            if (dval < mind) mind = dval;
         }
-        logdet += 2.0 * std::log(dval);
-        if (dval < mind) mind = dval;
-    }
-    scal[0] = logdet;
-    scal[2] = mind;
-    if (mind < 1e-5) {  // CHOLTHRESH, mathfun/linalg.py:31
-        rr_set_error("rr_posterior_dev: matrix is not safely positive definite (min diag of the factor %g)", mind);
-        return RR_ERR_NOT_POSDEF;
+        scal[0] = logdet;
+        scal[2] = mind;
+        if (mind < 1e-5) {  // CHOLTHRESH, mathfun/linalg.py:31
+            rr_set_error("rr_posterior_dev: matrix is not safely positive definite (min diag of the factor %g)", mind);
+            return RR_ERR_NOT_POSDEF;
+        }
+        return RR_OK;
+    };
+    if (ask_first) {
+        RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)Fp * 8, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        rc = pivots();
+        if (rc != RR_OK) return rc;
     }
     // ---- C = Y^T Y ----
     RR_CHECK_HIP(hipMemsetAsync(s.Cp, 0, (size_t)Fp * Fp * 8, c->stream));
@@ -1234,8 +1247,15 @@ int rr_posterior_dev(rr_ctx *c, int64_t F, const double *dG, const double *db, c
                            dm, ddg, dtr);
     }
     RR_CHECK_HIP(hipGetLastError());
-    RR_CHECK_HIP(hipMemcpyAsync(h.data() + Fp, dm, (size_t)(2 * Fp + 1) * 8, hipMemcpyDeviceToHost, c->stream));
-    RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    if (ask_first) {
+        RR_CHECK_HIP(hipMemcpyAsync(h.data() + Fp, dm, (size_t)(2 * Fp + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+    } else {  // [diagonal of the factor | m | diag C | sum(G o C)] in one copy
+        RR_CHECK_HIP(hipMemcpyAsync(h.data(), s.dvec, (size_t)(3 * Fp + 1) * 8, hipMemcpyDeviceToHost, c->stream));
+        RR_CHECK_HIP(hipStreamSynchronize(c->stream));
+        rc = pivots();
+        if (rc != RR_OK) return rc;
+    }
     memcpy(m, h.data() + Fp, (size_t)F * 8);
     memcpy(diagC, h.data() + 2 * Fp, (size_t)F * 8);
     scal[1] = h[(size_t)3 * Fp];
