@@ -301,7 +301,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
                 st.keep_best()  # stays in HBM; fetched once at the end of fit
                 if not getattr(self, "_defer_cov", False):
                     self.covariance_ = st.best_covariance()
-        log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
+        if log.isEnabledFor(logging.INFO):   # (the reference's line, slm.py:179-180; formatted only when somebody listens)
+            log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
         return -ELBO, [-dvar, dL, dhypers]
 
     def _ranks_bit_identical(self, posterior_on_device):
@@ -374,7 +375,8 @@ class StandardLinearModel(BaseEstimator, RegressorMixin):
             self.covariance_ = C
             self.obj_ = ELBO
 
-        log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
+        if log.isEnabledFor(logging.INFO):   # (the reference's line, slm.py:179-180; formatted only when somebody listens)
+            log.info("ELBO = {}, var = {}, reg = {}, hypers = {}.".format(ELBO, var, reg, hypers))
 
         dvar = 0.5 * (-N + (sqErr + TrPhiPhiC) / var) / var
 
