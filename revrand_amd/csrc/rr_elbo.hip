@@ -54,6 +54,43 @@ rr_rff_features_t_kernel(const TX *__restrict__ X, int64_t N, int64_t Npad, int6
     if (dot && valid) dot[r] = acc;
 }
 
+// The same for FEW rows (fewer than two of the blocks above per CU: BASELINE config 1's 10 000 rows are 40 of them, each
+// looping over all n frequencies on one CU -- 75 us of a 0.9 ms evaluation): 64 rows per workgroup, wave q takes the q-th
+// quarter of the frequencies for all of them (stores still 64 consecutive rows per wave), the four partial dot products meet
+// in LDS and are added in wave order.
+template <int DMAX, typename TX>
+__global__ void __launch_bounds__(256)
+rr_rff_features_t4_kernel(const TX *__restrict__ X, int64_t N, int64_t Npad, int64_t ldx,
+                          const float *__restrict__ Wt, const float *__restrict__ mvec, int n,
+                          float *__restrict__ Pt, int64_t ldt, float *__restrict__ dot, float scale) {
+    __shared__ float part[4][64];
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), rl = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 64 + rl;
+    const bool valid = r < N;
+    float x[DMAX];
+#pragma unroll
+    for (int i = 0; i < DMAX; ++i) x[i] = valid ? (float)X[r * ldx + i] : 0.f;
+    const int chunk = (n + 3) / 4, f0 = q * chunk, f1 = f0 + chunk < n ? f0 + chunk : n;
+    float acc = 0.f;
+    for (int f = f0; f < f1; ++f) {
+        const float *w = Wt + (size_t)f * DMAX;  // wave-uniform
+        float z = 0.f;
+#pragma unroll
+        for (int i = 0; i < DMAX; ++i) z = fmaf(x[i], w[i], z);
+        const float fr = z - __builtin_rintf(z);
+        const float c = valid ? __builtin_amdgcn_cosf(fr) * scale : 0.f;
+        const float s = valid ? __builtin_amdgcn_sinf(fr) * scale : 0.f;
+        if (Pt && r < Npad) {
+            Pt[(size_t)f * ldt + r] = c;
+            Pt[(size_t)(n + f) * ldt + r] = s;
+        }
+        if (mvec) acc = fmaf(c, mvec[f], fmaf(s, mvec[n + f], acc));
+    }
+    part[q][rl] = acc;
+    __syncthreads();
+    if (q == 0 && dot && valid) dot[r] = ((part[0][rl] + part[1][rl]) + part[2][rl]) + part[3][rl];
+}
+
 // zero rows [F, Fp) of the feature-major matrix (pad features)
 __global__ void __launch_bounds__(256) rr_zero_rows_kernel(float *P, int64_t row0, int64_t row1, int64_t ld) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -756,9 +793,16 @@ static int launch_features_t(rr_basis *b, const TX *X, int64_t N, int64_t Npad, 
         rr_set_error("pass2: internal: feature-major kernel called for Xdim > 128");
         return RR_ERR_INVALID;
     }
+    static const bool no_t4 = getenv("RR_FEATURES_T_NO_SPLIT") != nullptr;  // (A/B runs)
+    const bool few = !no_t4 && Npad / 256 < 2 * (int64_t)c->num_cu && b->n >= 16;
+    const dim3 grid4((unsigned)(Npad / 64));
 #define RR_FT(DM)                                                                                                  \
-    hipLaunchKernelGGL((rr_rff_features_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, X, N, Npad, ldx, b->dWt32, \
-                       m32, b->n, Pt, ldt, dot, scale)
+    if (few)                                                                                                       \
+        hipLaunchKernelGGL((rr_rff_features_t4_kernel<DM, TX>), grid4, dim3(256), 0, c->stream, X, N, Npad, ldx, b->dWt32, \
+                           m32, b->n, Pt, ldt, dot, scale);                                                        \
+    else                                                                                                           \
+        hipLaunchKernelGGL((rr_rff_features_t_kernel<DM, TX>), grid, dim3(256), 0, c->stream, X, N, Npad, ldx, b->dWt32, \
+                           m32, b->n, Pt, ldt, dot, scale)
     switch (b->dpad) {
         case 8: RR_FT(8); break;
         case 16: RR_FT(16); break;
