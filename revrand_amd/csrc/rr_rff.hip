@@ -2773,9 +2773,14 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
     int64_t g = slots, t = ntiles;
     while (t) { const int64_t u = g % t; g = t; t = u; }
     const int64_t unit = slots / g;
+    // (the posterior's C = Y^T Y at small F -- a square, triangular operand of <= 2048 rows: a few tiles whose k-loops are the
+    // whole launch -- splits down to 128 rows: at F = 1024 two splits of 512 rows left 56 workgroups walking up to 32
+    // k-blocks each, 69 + 40 us for a third of a GFLOP)
+    static const bool no_fine = getenv("RR_SYRK64_FINE_SPLIT") != nullptr && atoi(getenv("RR_SYRK64_FINE_SPLIT")) == 0;  // A/B runs
+    const int64_t min_rows = (lower_tri && rows == ldp && rows <= 2048 && !no_fine) ? 128 : 512;
     int64_t nsplit = unit;
     if (rows / nsplit < 2048) nsplit = (slots * 4 + ntiles - 1) / ntiles;
-    if (rows / nsplit < 512) nsplit = (rows + 511) / 512;
+    if (rows / nsplit < min_rows) nsplit = (rows + min_rows - 1) / min_rows;
     if (nsplit < 1) nsplit = 1;
     const int64_t rps = ((rows + nsplit - 1) / nsplit + G64_KB - 1) / G64_KB * G64_KB;
     nsplit = (rows + rps - 1) / rps;
@@ -2801,7 +2806,7 @@ int rr_launch_syrk_f64(rr_ctx *c, const double *P, int64_t rows, int64_t ldp, in
         int64_t best_ns = 1;
         double best = -1.0;
         for (int64_t ns = 1; ns <= 4 * dslots / nb + 1; ++ns) {
-            if (rows / ns < 512 && ns > 1) break;
+            if (rows / ns < min_rows && ns > 1) break;
             const int64_t wg = ns * nb, rounds = (wg + dslots - 1) / dslots;
             const double eff = (double)wg / (double)(rounds * dslots);
             if (eff > best + 1e-9) {
