@@ -532,7 +532,12 @@ static bool rr_features_mfma_launch(rr_basis *b, const TX *X, const TX *y, int64
     do {                                                                                                            \
         const int cgroups = (b->n + 32 * CBK - 1) / (32 * CBK);                                                     \
         int64_t tpb = 64;                                                                                           \
-        while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < 4 * (int64_t)c->num_cu) tpb >>= 1;                 \
+        /* a wave loads its CB x KS weight operands once and then walks its tiles: down to 16 tiles per workgroup (4 per */ \
+        /* wave) for four workgroups per CU, below that only to give every CU one -- at 4 (one tile per wave) the operand */ \
+        /* loads cost 10 % of a statistics pass of 44 484 or 200 000 rows at F = 1024 (RR_FEAT_TPB: A/B runs)            */ \
+        while (tpb > 16 && cgroups * ((ntiles + tpb - 1) / tpb) < 4 * (int64_t)c->num_cu) tpb >>= 1;                \
+        while (tpb > 4 && cgroups * ((ntiles + tpb - 1) / tpb) < (int64_t)c->num_cu) tpb >>= 1;                     \
+        if (getenv("RR_FEAT_TPB")) tpb = atoi(getenv("RR_FEAT_TPB"));                                               \
         if ((ntiles + tpb - 1) / tpb > 65535) tpb = (ntiles + 65534) / 65535;                                       \
         const dim3 grid(cgroups, (unsigned)((ntiles + tpb - 1) / tpb));                                             \
         if (y && c->deterministic) {                                                                                \
