@@ -1662,17 +1662,131 @@ rr_gemm_tn_small_f32_kernel(const float *__restrict__ A, int64_t lda, const floa
         for (int j = 0; j < 2; ++j) D[(int64_t)(ti + 2 * ty + i) * ldd + tj + 2 * tx + j] = acc[i][j];
 }
 
+// Products BETWEEN the two (late round 6): a GLM step on a minibatch of a few thousand rows -- D = 4096 x 512, K = 512 -- is 32
+// tiles of 256 x 256: an eighth of the CUs walk 8-16 k-blocks each (73 us per product, 126 us for the EdPhi product with its
+// contraction, for 2 GFLOP = 14 us of the matrix cores), and there is too much of it for the FMA kernel above.  Here a workgroup
+// of four waves owns a 128 x 128 block (64 x 64 per wave: 2 x 2 v_mfma_f32_32x32x2f32 accumulators), k-blocks of 32 rows
+// through registers into a double-buffered LDS tile [32][A 128 | B 128] -- rr_syrk_f32_small_kernel's loop with two operands
+// -- two workgroups per CU (64 KiB of LDS each), K split over blockIdx.y into a zeroed D (f32 atomics) when the tiles alone do
+// not fill the chip.  M, N % 128 == 0, K % 32 == 0, 16-byte aligned rows.
+struct GemmMidArgs {
+    const float *A, *B;
+    float *D;
+    int64_t lda, ldb, ldd;
+    int K, ntb;          // ntb = N / 128 column tiles (fastest-varying in blockIdx.x)
+    int kb_per_split;    // > 0: blockIdx.y owns that many k-blocks and ADDS
+};
+
+__global__ void __launch_bounds__(256, 2) rr_gemm_tn_mid_f32_kernel(const GemmMidArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2][32 * 256];  // 2 x 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int64_t ca = (int64_t)(blockIdx.x / p.ntb) * 128, cb = (int64_t)(blockIdx.x % p.ntb) * 128;
+    int kb0 = 0, nkb = p.K / 32;
+    if (p.kb_per_split > 0) {
+        kb0 = blockIdx.y * p.kb_per_split;
+        nkb = nkb - kb0 < p.kb_per_split ? nkb - kb0 : p.kb_per_split;
+    }
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // this thread's part of a k-block: rows lr + 8 u (u < 4), float4 number lc of the A side and of the B side
+    const int lr = tid >> 5, lc = tid & 31;
+    float4 ra[4], rb[4];
+    auto gload = [&](int kb) {
+        const int64_t r = (int64_t)(kb0 + kb) * 32 + lr;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ra[u] = *(const float4 *)(p.A + (r + 8 * u) * p.lda + ca + 4 * lc);
+            rb[u] = *(const float4 *)(p.B + (r + 8 * u) * p.ldb + cb + 4 * lc);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *(float4 *)&lds[buf][(lr + 8 * u) * 256 + 4 * lc] = ra[u];
+            *(float4 *)&lds[buf][(lr + 8 * u) * 256 + 128 + 4 * lc] = rb[u];
+        }
+    };
+    if (nkb > 0) {
+        gload(0);
+        lstore(0);
+    }
+    __syncthreads();
+    const int i32 = lane & 31, kk = lane >> 5;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int cur = kb & 1;
+        if (kb + 1 < nkb) gload(kb + 1);   // in flight under this block's products
+        const float *L = lds[cur];
+#pragma unroll
+        for (int k2 = 0; k2 < 32; k2 += 2) {
+            const float *row = L + (k2 + kk) * 256;
+            const float a0 = row[wr * 64 + i32], a1 = row[wr * 64 + 32 + i32];
+            const float b0 = row[128 + wc * 64 + i32], b1 = row[128 + wc * 64 + 32 + i32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kb + 1 < nkb) lstore(cur ^ 1);
+        __syncthreads();
+    }
+    // C/D of the 32x32 forms: column = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    const bool atomic = p.kb_per_split > 0;  // (uniform)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int64_t gc = cb + wc * 64 + 32 * j + i32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int64_t gr = ca + wr * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * kk;
+                if (atomic) unsafeAtomicAdd(&p.D[gr * p.ldd + gc], acc[i][j][e]);
+                else p.D[gr * p.ldd + gc] = acc[i][j][e];
+            }
+        }
+}
+
+// (tiles of 256 x 256 would leave three quarters of the CUs without one, and K is short enough that splitting it cannot make up
+// for that: with K = 16 384 the tile kernel's 16-32 K-splits of 32 k-blocks fill the chip at its better rate per flop -- a GLM
+// step of 16 384 x 2048 measured 6 % slower with this kernel on its Ed product.  RR_GEMM_MID=0: the tile kernel -- A/B runs)
+static inline bool fm_gemm_is_mid(rr_ctx *c, int64_t Kd, int64_t Md, int64_t Nd) {
+    static const bool off = getenv("RR_GEMM_MID") != nullptr && atoi(getenv("RR_GEMM_MID")) == 0;
+    return !off && (Md / 256) * (Nd / 256) * 4 <= (int64_t)c->num_cu && Kd <= 4096 && Kd % 32 == 0 && Md % 128 == 0 && Nd % 128 == 0;
+}
+
 static inline bool fm_gemm_is_small(int64_t Kd, int64_t Md, int64_t Nd) {
     static const bool off = getenv("RR_GEMM_SMALL") != nullptr && atoi(getenv("RR_GEMM_SMALL")) == 0;  // (A/B runs)
     return !off && Kd * Md * Nd <= ((int64_t)1 << 27) && Md / 32 < 65536;
 }
 
 static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd, int64_t Kd,
-                   int64_t Md, int64_t Nd) {
+                   int64_t Md, int64_t Nd, bool allow_mid = true) {
     RR_REQUIRE(lda < (1 << 25) && ldb < (1 << 25), "GEMM: leading dimensions up to 2^25 floats (rr_dma_kblock's 32-bit row offsets)");
     if (fm_gemm_is_small(Kd, Md, Nd)) {
         hipLaunchKernelGGL(rr_gemm_tn_small_f32_kernel, dim3((unsigned)(Nd / 32), (unsigned)(Md / 32)), dim3(256), 0, c->stream, A, lda, B,
                            ldb, D, ldd, (int)Kd);
+        RR_CHECK_HIP(hipGetLastError());
+        return RR_OK;
+    }
+    if (allow_mid && fm_gemm_is_mid(c, Kd, Md, Nd)) {
+        GemmMidArgs m;
+        m.A = A; m.B = B; m.D = D; m.lda = lda; m.ldb = ldb; m.ldd = ldd; m.K = (int)Kd; m.ntb = (int)(Nd / 128); m.kb_per_split = 0;
+        const int64_t tiles = (Md / 128) * m.ntb, nkb = Kd / 32;
+        // K-splits for RR_GEMM_MID_ROUNDS (default 2: two workgroups fit a CU) workgroups per CU, at least 4 k-blocks each
+        static const int rounds = getenv("RR_GEMM_MID_ROUNDS") ? atoi(getenv("RR_GEMM_MID_ROUNDS")) : 2;
+        int64_t want = (rounds * (int64_t)c->num_cu + tiles - 1) / tiles;
+        if (want > nkb / 4) want = nkb / 4;
+        unsigned splits = 1;
+        if (want > 1) {
+            m.kb_per_split = (int)((nkb + want - 1) / want);
+            splits = (unsigned)((nkb + m.kb_per_split - 1) / m.kb_per_split);
+            RR_CHECK_HIP(hipMemsetAsync(D, 0, (size_t)Md * ldd * sizeof(float), c->stream));
+        }
+        hipLaunchKernelGGL(rr_gemm_tn_mid_f32_kernel, dim3((unsigned)tiles, splits), dim3(256), 0, c->stream, m);
         RR_CHECK_HIP(hipGetLastError());
         return RR_OK;
     }
@@ -1698,7 +1812,10 @@ static int fm_gemm(rr_ctx *c, const float *A, int64_t lda, const float *B, int64
 
 int rr_launch_gemm_tn_f32(rr_ctx *c, const float *A, int64_t lda, const float *B, int64_t ldb, float *D, int64_t ldd,
                           int64_t K, int64_t M, int64_t N) {  // D (M, N) = A^T B, A (K, M), B (K, N); M, N % 256 == 0, K % 32 == 0
-    return fm_gemm(c, A, lda, B, ldb, D, ldd, K, M, N);
+    // (the phase matrix of a basis with Xdim > 128, in row sub-chunks: a row's phases must not depend on how many rows came
+    // with it -- tests/test_gpu_large_xdim.py holds a sub-chunked transform to the one-pass one BIT FOR BIT -- and the 128 x 128
+    // kernel rounds differently from the other two (3.7e-7), so it stays out of this product)
+    return fm_gemm(c, A, lda, B, ldb, D, ldd, K, M, N, false);
 }
 
 // The same product with the random Fourier feature epilogue (GemmArgs: TRIG): P (nout rows, ldp) <- cos / sin of the
@@ -2673,7 +2790,10 @@ static int glm_pipeline(rr_featmat *fm, FmPass2 &s, const void *dy, const void *
         // (RR_GLM_NO_FUSE=1: never -- the EdPhi GEMM and rr_glm_grad_t_kernel as separate passes, for A/B runs)
         const char *nf = getenv("RR_GLM_NO_FUSE");
         const bool no_fuse = nf && atoi(nf) != 0;
+        // (not where 256 x 256 tiles leave most CUs idle: the EdPhi product then goes through fm_gemm's 128 x 128 kernel and
+        // rr_glm_grad_t_kernel contracts it)
         s.fuse.take = s.fuse.armed && !objective_only && !no_fuse && c->gram_engine == 0 && !c->deterministic &&
+                      !fm_gemm_is_mid(c, kl_ld, rows256, Fp) &&
                       s.fuse.col0 == 0 && 2 * (int64_t)s.fuse.b->n == fm->F && fm->F == Fp && s.fuse.b->n % 256 == 0 &&
                       s.fuse.b->d <= 128 && Fp < (1 << 21) && s.fuse.ldx < (1 << 21);
         s.fuse.armed = false;

@@ -142,6 +142,39 @@ def test_minibatch_elbo_of_a_spectral_mixture_component_on_the_chain_kernel_vs_o
     assert normwise(flat, np.array(want[1][4])) < 2e-3
 
 
+def test_minibatch_elbo_on_the_128_tile_products_vs_oracle(monkeypatch):
+    """A minibatch of 1280 rows, F = 512, K L = 192: every product of the step (fs = Phi ws, Ed = dfs Phi, EdPhi) is one that
+    256 x 256 tiles cannot spread over the CUs and that is too large for the FMA kernel -- rr_gemm_tn_mid_f32_kernel's (128 x 128
+    tiles, K-split); the EdPhi product is stored and contracted by rr_glm_grad_t_kernel.  -ELBO and all gradient blocks against
+    the oracle's glm_elbo (glm.py:205-294), and against the same evaluation on the tile kernel (RR_GEMM_MID=0 is read once
+    per process: the oracle is the reference here, the A/B lives in tools/glm_mid_batch.py)."""
+    bs, lk, Parameter, Positive, GLM = _imports()
+    rs = np.random.RandomState(5)
+    M, d, n, K, L = 1280, 6, 256, 6, 32
+    X = rs.randn(M, d)
+    y = rs.poisson(np.exp(0.5 * np.sin(X[:, 0]))).astype(float)
+    basis = bs.RandomRBF(nbases=n, Xdim=d, random_state=3, lenscale=Parameter(np.ones(d), Positive()))
+    ls = np.linspace(0.8, 1.4, d)
+    Phi = basis.transform(X, ls)
+    G = basis.grad(X, ls)
+    dPs = [G[:, :, i] for i in range(d)]
+    D = 2 * n
+    m = 0.2 * rs.randn(D, K)
+    C = rs.gamma(2., 0.5, size=(D, K))
+    Ld, slices = basis.regularizer_diagonal(X, 1.3)
+    e = np.stack([np.random.RandomState(9).randn(K * L, D)[k * L:(k + 1) * L] for k in range(K)])
+    want = orc.glm_elbo(m, C, Ld, slices, "poisson_exp", [], (), Phi, dPs, y, e, 3.0)
+    glm = GLM(likelihood=lk.Poisson(), basis=basis, K=K, nsamples=L, random_state=9)
+    glm.B_, glm.D_ = 3.0, D
+    glm._GeneralizedLinearModel__it = -1
+    nobj, (ndm, ndC, dL, dlp, dbp) = glm._elbo(m.copy(), C.copy(), 1.3, [], ls, X, y)
+    glm._release_features()
+    assert abs(nobj - want[0]) < 2e-4 * abs(want[0])
+    assert normwise(ndm, want[1][0]) < 1e-3 and normwise(ndC, want[1][1]) < 1e-3
+    assert normwise(np.atleast_1d(np.array(dL)), np.atleast_1d(np.array(want[1][2]))) < 1e-6
+    assert np.shape(dbp) == (d,) and normwise(np.asarray(dbp), np.concatenate([np.atleast_1d(v) for v in want[1][4]])) < 2e-3
+
+
 def test_project_and_sample_func():
     bs, lk, Parameter, Positive, GLM = _imports()
     from revrand_amd.basis_functions import MinibatchFeatures
