@@ -1755,7 +1755,9 @@ __global__ void __launch_bounds__(256, 2) rr_gemm_tn_mid_f32_kernel(const GemmMi
 // step of 16 384 x 2048 measured 6 % slower with this kernel on its Ed product.  RR_GEMM_MID=0: the tile kernel -- A/B runs)
 static inline bool fm_gemm_is_mid(rr_ctx *c, int64_t Kd, int64_t Md, int64_t Nd) {
     static const bool off = getenv("RR_GEMM_MID") != nullptr && atoi(getenv("RR_GEMM_MID")) == 0;
-    return !off && (Md / 256) * (Nd / 256) * 4 <= (int64_t)c->num_cu && Kd <= 4096 && Kd % 32 == 0 && Md % 128 == 0 && Nd % 128 == 0;
+    // (not in deterministic mode: its K-split adds float32 atomics where the tile kernel had none)
+    return !off && !c->deterministic && (Md / 256) * (Nd / 256) * 4 <= (int64_t)c->num_cu && Kd <= 4096 && Kd % 32 == 0 &&
+           Md % 128 == 0 && Nd % 128 == 0;
 }
 
 static inline bool fm_gemm_is_small(int64_t Kd, int64_t Md, int64_t Nd) {
